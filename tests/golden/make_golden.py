@@ -1,0 +1,225 @@
+#!/usr/bin/env python3
+"""Golden-vector generator: runs the REFERENCE's own code and records its outputs.
+
+Runs only in the build container (it reads /root/reference); the GPU box never executes it.
+Nothing from the reference is copied: its modules are imported in place, driven, and only
+input/output DATA is saved to tests/golden/*.npz.
+
+Recipe:
+  1. stub the seven absent third-party packages in sys.modules; the arithmetic ones
+     (torchgeometry, smplx model, VPoser, chamferDist) are backed by oracle/ restatements;
+  2. shim torch.Tensor.cuda -> identity (no GPU here);
+  3. import /root/reference/global_optimization.py unmodified;
+  4. supply the method the reference calls but never defines
+     (HumanCVAE.body_params_encapsulate_batch, global_optimization.py:268);
+  5. build FittingOP without __init__ (which needs the licensed model files) and set the
+     attributes __init__ would have set (:142-188);
+  6. call the reference's FittingOP.fitting(body, 'global') and its helper functions.
+
+Usage:  python tests/golden/make_golden.py            (writes tests/golden/*.npz)
+"""
+import contextlib
+import hashlib
+import io
+import json
+import os
+import re
+import sys
+import tempfile
+import types
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, ROOT)
+
+import fdcap_amd  # noqa: E402
+from fdcap_amd import synth  # noqa: E402
+from oracle import tgm as o_tgm  # noqa: E402
+from oracle.chamfer import chamferDist as OracleChamfer  # noqa: E402
+from oracle.smplx import SMPLXOracle  # noqa: E402
+from oracle.vposer import VPoserDecoder  # noqa: E402
+
+REF = "/root/reference"
+
+
+def install_stubs():
+    def mod(name, **attrs):
+        m = types.ModuleType(name)
+        for k, v in attrs.items():
+            setattr(m, k, v)
+        sys.modules[name] = m
+        return m
+
+    mod("open3d")
+    mod("torchvision")
+    mod("smplx", create=lambda *a, **k: None)
+    hbp = mod("human_body_prior")
+    tools = mod("human_body_prior.tools")
+    ml = mod("human_body_prior.tools.model_loader", load_vposer=lambda *a, **k: (None, None))
+    hbp.tools = tools
+    tools.model_loader = ml
+    cdp = mod("ChamferDistancePytorch")
+    dc = mod("ChamferDistancePytorch.dist_chamfer",
+             chamferDist=lambda: OracleChamfer(one_direction=False))
+    cdp.dist_chamfer = dc
+    mod("MotionGeneration", LocalHumanDynamicsGRUNoise=object)
+    mod("torchgeometry",
+        angle_axis_to_rotation_matrix=o_tgm.angle_axis_to_rotation_matrix,
+        rotation_matrix_to_angle_axis=o_tgm.rotation_matrix_to_angle_axis)
+    torch.Tensor.cuda = lambda self, *a, **k: self
+
+
+def import_reference():
+    install_stubs()
+    sys.path.insert(0, REF)
+    cwd = os.getcwd()
+    os.chdir(REF)
+    try:
+        import global_optimization as g
+    finally:
+        os.chdir(cwd)
+
+    def encapsulate_batch(body_rec):  # A6: slicing per cvae.py:196-201, tensors kept live
+        return {"transl": body_rec[:, 0:3], "global_orient": body_rec[:, 3:6],
+                "betas": body_rec[:, 6:16], "body_pose_vp": body_rec[:, 16:48],
+                "left_hand_pose": body_rec[:, 48:60], "right_hand_pose": body_rec[:, 60:72]}
+
+    g.HumanCVAE.body_params_encapsulate_batch = staticmethod(encapsulate_batch)
+    return g
+
+
+def sha(a):
+    return hashlib.sha256(np.ascontiguousarray(a).tobytes()).hexdigest()[:16]
+
+
+LOG_RE = re.compile(r"iter=(\d+), l_rec=([-\d.e]+), l_vposer=([-\d.e]+), loss_smoothing=([-\d.e]+), "
+                    r"loss_contact=([-\d.e]+)(?:, loss_world_smoothing=([-\d.e]+))?, total_loss=([-\d.e]+)")
+
+
+def run_global(g, num_iter, num_verts, ns, model_seed, vposer_seed, clip_seed, scene_seed,
+               contact_seed, per_part, tmp):
+    n = 300  # the reference hard-codes 300 (:465, :472, :41-42)
+    bm = synth.make_body_model(num_verts, seed=model_seed)
+    vp = synth.make_vposer(seed=vposer_seed)
+    clip = synth.make_clip(n, seed=clip_seed, num_outliers=3)
+    scene = synth.make_scene(ns, seed=scene_seed)
+    left, right = synth.make_contact_ids(bm.v_template, per_part=per_part, seed=contact_seed)
+
+    seg = os.path.join(tmp, "body_segments")
+    os.makedirs(seg, exist_ok=True)
+    for name, ids in (("L_Leg", left), ("R_Leg", right)):
+        with open(os.path.join(seg, name + ".json"), "w") as f:
+            json.dump({"verts_ind": [int(i) for i in ids], "faces_ind": [0]}, f)
+    cam_path = os.path.join(tmp, "camerapose.txt")
+    with open(cam_path, "w") as f:
+        f.write("\n".join(clip.camerapose_lines) + "\n")
+
+    torch.manual_seed(0)
+    f = object.__new__(g.FittingOP)
+    f.batch_size = f.num_body = n
+    f.device = torch.device("cpu")
+    f.vposer = VPoserDecoder.from_data(vp)
+    f.body_mesh_model = SMPLXOracle(bm)
+    f.contact_id_folder = seg
+    f.contact_part = ["L_Leg", "R_Leg"]
+    f.camera_path = cam_path
+    f.weight_loss_rec = 1
+    f.weight_loss_vposer = 0.001
+    f.weight_contact = 0.1
+    f.weight_collision = 0.5
+    f.init_lr_h = 0.005
+    f.num_iter = num_iter
+    f.verbose = False
+    f.s_verts_batch = torch.tensor(scene, dtype=torch.float32).unsqueeze(0).repeat(n, 1, 1)
+    f.scale = torch.tensor(1.8, requires_grad=True)
+    f.body_rotation_rec = torch.randn(n, 75).requires_grad_(True)
+    f.camera_ext = torch.randn(n, 4, 4).requires_grad_(True)
+    f.dct_mtx = torch.tensor(synth.dct_basis(60, 5), dtype=torch.float32)
+    f.c_dct = torch.randn(5, 23, 3, 5).requires_grad_(True)
+    f.optimizer = torch.optim.Adam([f.body_rotation_rec, f.scale, f.camera_ext, f.c_dct],
+                                   lr=f.init_lr_h)
+
+    vid_ref, _ = g.get_contact_id(seg, ["L_Leg", "R_Leg"])
+    body = torch.tensor(clip.body_params, dtype=torch.float32)
+    buf = io.StringIO()
+    with contextlib.redirect_stdout(buf):
+        body_rec, scale, camera_ext = f.fitting(body, "global")
+    text = buf.getvalue()
+    log = []
+    for m in LOG_RE.finditer(text):
+        it, rec, vpz, sm, con, ws, tot = m.groups()
+        log.append([float(it), float(rec), float(vpz), float(sm), float(con),
+                    float(ws) if ws is not None else float("nan"), float(tot)])
+    log = np.array(log, dtype=np.float64)
+    assert log.shape[0] == num_iter, (log.shape, num_iter)
+    idx_line = text.splitlines()[0]
+    idx1 = np.array([int(t) for t in re.findall(r"\d+", idx_line)], dtype=np.int64)
+    return dict(
+        num_iter=num_iter, num_verts=num_verts, ns=ns, model_seed=model_seed,
+        vposer_seed=vposer_seed, clip_seed=clip_seed, scene_seed=scene_seed,
+        contact_seed=contact_seed, per_part=per_part,
+        body_in=clip.body_params, camerapose=np.array(clip.camerapose_lines),
+        planted_outliers=clip.outlier_frames, scene=scene, vid=np.asarray(vid_ref, dtype=np.int64),
+        idx1=idx1, body_rec=body_rec.detach().numpy(), scale=np.float32(scale),
+        camera_ext=camera_ext.detach().numpy(), log=log,
+        sha_posedirs=sha(bm.posedirs), sha_vtemplate=sha(bm.v_template), sha_fc2=sha(vp.fc2_w))
+
+
+def run_units(g):
+    rng = np.random.Generator(np.random.PCG64(11))
+    out = {}
+    q = rng.standard_normal((6, 4))
+    q /= np.linalg.norm(q, axis=1, keepdims=True)
+    q[0] = (0.5, 0.5, 0.5, 0.5)
+    out["qvec"] = q
+    out["qvec_R"] = np.stack([g.qvec2rotmat(x) for x in q])
+    x75 = torch.tensor(rng.standard_normal((16, 75)), dtype=torch.float32)
+    x78 = g.convert_to_6D_rot(x75)
+    out["x75"] = x75.numpy()
+    out["x78"] = x78.numpy()
+    out["x75_back"] = g.convert_to_3D_rot(x78).numpy()
+    six = torch.tensor(rng.standard_normal((10, 6)), dtype=torch.float32)
+    out["six"] = six.numpy()
+    out["six_R"] = g.ContinousRotReprDecoder.decode(six).numpy()
+    v = torch.tensor(rng.standard_normal((3, 7, 3)), dtype=torch.float32)
+    M = torch.tensor(rng.standard_normal((3, 4, 4)), dtype=torch.float32)
+    out["vt_v"] = v.numpy()
+    out["vt_M"] = M.numpy()
+    out["vt_out"] = g.verts_transform(v, M).numpy()
+    d = {"transl": rng.standard_normal((1, 3)), "global_orient": rng.standard_normal((1, 3)),
+         "betas": rng.standard_normal((1, 10)), "body_pose": rng.standard_normal((1, 32)),
+         "left_hand_pose": rng.standard_normal((1, 12)),
+         "right_hand_pose": rng.standard_normal((1, 12)),
+         "camera_translation": rng.standard_normal((1, 3)),
+         "camera_rotation": rng.standard_normal((1, 3, 3))}
+    for k, val in d.items():
+        out["parse_" + k] = val
+    out["parse_out"] = g.body_params_parse(d)
+    return out
+
+
+def main():
+    g = import_reference()
+    with tempfile.TemporaryDirectory() as tmp:
+        units = run_units(g)
+        np.savez_compressed(os.path.join(HERE, "ref_units.npz"), **units)
+        print("wrote ref_units.npz")
+        for name, kw in (
+            ("ref_global_20it", dict(num_iter=20, num_verts=640, ns=3000, model_seed=0,
+                                     vposer_seed=1, clip_seed=3, scene_seed=2, contact_seed=4,
+                                     per_part=24)),
+            ("ref_global_5it", dict(num_iter=5, num_verts=320, ns=1500, model_seed=5,
+                                    vposer_seed=6, clip_seed=7, scene_seed=8, contact_seed=9,
+                                    per_part=12)),
+        ):
+            res = run_global(g, tmp=tmp, **kw)
+            np.savez_compressed(os.path.join(HERE, name + ".npz"), **res)
+            print("wrote", name, "idx1", res["idx1"], "scale", res["scale"],
+                  "final loss", res["log"][-1])
+
+
+if __name__ == "__main__":
+    main()
