@@ -1,0 +1,289 @@
+// Per-frame body-model math: joint rotations, kinematic chain, world transform -- forward and
+// hand-derived backward -- written as block-cooperative code.  A "team" of `nthr` threads runs
+// one frame; `sync()` separates data-parallel phases.  On the GPU the team is one 64-thread
+// workgroup (one wavefront) and the scratch arrays live in LDS; the test-only host harness runs
+// the same source with nthr = 1 and a no-op sync.
+//
+// Restates (forward): smplx.SMPLX.forward + lbs.batch_rigid_transform as configured at
+// /root/reference/global_optimization.py:154-168 and called at :280-283, the
+// VPoser 6D->rotation tail (A.2), body2world (:191-206) and verts_transform on joints (:298-299).
+// The R -> angle-axis -> Rodrigues round trip the reference makes for global_orient and the 21
+// VPoser joints is the identity on SO(3), including its gradient after composition with
+// Gram-Schmidt, so rotation matrices feed the chain directly.
+#pragma once
+#include "fdc_math.h"
+
+namespace fdc {
+
+constexpr int NJ = 55;          // SMPL-X joints
+constexpr int NJW = 23;         // world joints the reference reads (joints[:, 0:23], :298)
+constexpr int NBETA = 10;
+constexpr int NPF = (NJ - 1) * 9;   // 486 pose-feature columns
+constexpr int XDIM = 78;        // optimised parameter row
+constexpr int X_TRANSL = 0, X_SIXD = 3, X_BETAS = 9, X_LATENT = 19, X_LH = 51, X_RH = 63, X_CAMT = 75;
+constexpr int ODIM = 126;       // VPoser decoder output (21 joints x 6D)
+constexpr int MAX_LEVELS = 16;
+
+struct PoseModel {
+    const float* Jt;          // [55,3]   J_regressor @ v_template
+    const float* Jd;          // [55,3,10] J_regressor @ shapedirs[:, :, :10]
+    const int* parents;       // [55], root -1
+    const int* order;         // [55] joints sorted by depth
+    const int* level_start;   // [nlevels+1] ranges into order
+    const int* child_start;   // [56] CSR of children
+    const int* child_list;    // [54]
+    const float* hand_comp;   // [2,12,45]
+    const float* hand_mean;   // [2,45]
+    int nlevels;
+};
+
+// scratch a team needs (LDS on device)
+struct PoseScratch {
+    float R[NJ][9];
+    float J[NJ][3];
+    float G[NJ][12];      // [R | t] row-major 3x4
+    float dG[NJ][12];
+    float dR[NJ][9];
+    float drel[NJ][3];
+    float dJ[NJ][3];
+    float dMj[NJW][12];
+    float dTj[NJW][3];
+    float daa[2][45];
+};
+
+FDC_HD M3 load_m3(const float* p) { M3 r; for (int i = 0; i < 9; ++i) r.m[i] = p[i]; return r; }
+FDC_HD void store_m3(float* p, const M3& a) { for (int i = 0; i < 9; ++i) p[i] = a.m[i]; }
+FDC_HD M3 g_rot(const float* g) { M3 r; for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) r.m[3 * i + j] = g[4 * i + j]; return r; }
+FDC_HD V3 g_trn(const float* g) { return v3(g[3], g[7], g[11]); }
+FDC_HD void g_store(float* g, const M3& R, V3 t) {
+    for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) g[4 * i + j] = R.m[3 * i + j];
+    g[3] = t.x; g[7] = t.y; g[11] = t.z;
+}
+
+FDC_HD V3 hand_aa(const PoseModel& pm, const float* x, int j) {
+    int h = (j - 25) / 15, f = (j - 25) % 15;
+    const float* pca = x + (h == 0 ? X_LH : X_RH);
+    const float* comp = pm.hand_comp + h * 12 * 45;
+    float a[3];
+    for (int c = 0; c < 3; ++c) {
+        float acc = 0.f;
+        for (int i = 0; i < 12; ++i) acc += pca[i] * comp[i * 45 + 3 * f + c];
+        a[c] = acc + pm.hand_mean[h * 45 + 3 * f + c];
+    }
+    return v3(a[0], a[1], a[2]);
+}
+
+// body2world (:191-206): M = cam_ext[:3,:] @ [[I, cam_t*s],[0,1]]
+FDC_HD void world_matrix(const float* cam_ext, const float* x, float scale, M3* MR, V3* Mt) {
+    M3 E; for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) E.m[3 * i + j] = cam_ext[4 * i + j];
+    V3 Et = v3(cam_ext[3], cam_ext[7], cam_ext[11]);
+    V3 ct = v3(x[X_CAMT] * scale, x[X_CAMT + 1] * scale, x[X_CAMT + 2] * scale);
+    *MR = E;
+    *Mt = m3_vec(E, ct) + Et;
+}
+
+// Forward for one frame.  Global outputs (any may be null):
+//   Rm[55*9], PF[486], Jrest[55*3], G[55*12], A[55*12], M[12], Jw[23*3]
+template <class Sync>
+FDC_HD void pose_forward(const PoseModel& pm, const float* x, const float* o, const float* cam_ext,
+                         float scale, PoseScratch& sc, float* Rm, float* PF, float* Jrest, float* G,
+                         float* A, float* M, float* Jw, int tid, int nthr, Sync sync,
+                         const float* aa22 = nullptr) {
+    for (int j = tid; j < NJ; j += nthr) {
+        M3 R;
+        // aa22 (operator-level API only): global_orient + 21 body joints given as axis-angle
+        if (aa22 && j <= 21) R = rodrigues_forward(v3(aa22[3 * j], aa22[3 * j + 1], aa22[3 * j + 2]));
+        else if (j == 0) R = gs_forward(x + X_SIXD, 1, nullptr);
+        else if (j <= 21) R = gs_forward(o + 6 * (j - 1), 1, nullptr);
+        else if (j < 25) R = m3_identity();          // jaw / eyes: zero Parameters, never optimised
+        else R = rodrigues_forward(hand_aa(pm, x, j));
+        store_m3(sc.R[j], R);
+        for (int c = 0; c < 3; ++c) {
+            float acc = pm.Jt[3 * j + c];
+            for (int l = 0; l < NBETA; ++l) acc += pm.Jd[(3 * j + c) * NBETA + l] * x[X_BETAS + l];
+            sc.J[j][c] = acc;
+        }
+    }
+    sync();
+    for (int L = 0; L < pm.nlevels; ++L) {
+        for (int k = pm.level_start[L] + tid; k < pm.level_start[L + 1]; k += nthr) {
+            int j = pm.order[k];
+            int p = pm.parents[j];
+            M3 R = load_m3(sc.R[j]);
+            V3 Jj = v3(sc.J[j][0], sc.J[j][1], sc.J[j][2]);
+            if (p < 0) {
+                g_store(sc.G[j], R, Jj);
+            } else {
+                M3 Rp = g_rot(sc.G[p]);
+                V3 rel = Jj - v3(sc.J[p][0], sc.J[p][1], sc.J[p][2]);
+                g_store(sc.G[j], m3_mul(Rp, R), m3_vec(Rp, rel) + g_trn(sc.G[p]));
+            }
+        }
+        sync();
+    }
+    M3 MR; V3 Mt;
+    world_matrix(cam_ext, x, scale, &MR, &Mt);
+    V3 transl = v3(x[X_TRANSL], x[X_TRANSL + 1], x[X_TRANSL + 2]);
+    for (int j = tid; j < NJ; j += nthr) {
+        M3 GR = g_rot(sc.G[j]);
+        V3 Gt = g_trn(sc.G[j]);
+        V3 Jj = v3(sc.J[j][0], sc.J[j][1], sc.J[j][2]);
+        if (A) g_store(A + 12 * j, GR, Gt - m3_vec(GR, Jj));
+        if (G) for (int e = 0; e < 12; ++e) G[12 * j + e] = sc.G[j][e];
+        if (Rm) for (int e = 0; e < 9; ++e) Rm[9 * j + e] = sc.R[j][e];
+        if (Jrest) for (int c = 0; c < 3; ++c) Jrest[3 * j + c] = sc.J[j][c];
+        if (PF && j >= 1)
+            for (int e = 0; e < 9; ++e) PF[9 * (j - 1) + e] = sc.R[j][e] - ((e == 0 || e == 4 || e == 8) ? 1.f : 0.f);
+        if (Jw && j < NJW) {
+            V3 w = m3_vec(MR, Gt + transl) + Mt;        // joints are NOT multiplied by scale (:298-299)
+            Jw[3 * j] = w.x; Jw[3 * j + 1] = w.y; Jw[3 * j + 2] = w.z;
+        }
+    }
+    if (M && tid == 0) g_store(M, MR, Mt);
+}
+
+// Backward for one frame.
+// In : x, o, cam_ext, scale; stored Rm / Jrest / G from the forward;
+//      dA[55*12] (d loss / d skinning transforms, may be null), dPF[486] (may be null),
+//      dJw[23*3] (may be null), dMv[12], dsv, dbeta_v[10], dtransl_v[3]: vertex-side sums (null -> 0)
+// Out: dx[78] += (transl, 6D, betas, hands, cam_t),  dO[126] =,  dcam_ext[16] =,  *dscale =
+template <class Sync>
+FDC_HD void pose_backward(const PoseModel& pm, const float* x, const float* o, const float* cam_ext,
+                          float scale, const float* Rm, const float* Jrest, const float* G,
+                          const float* dA, const float* dPF, const float* dJw, const float* dMv,
+                          const float* dsv, const float* dbeta_v, const float* dtransl_v,
+                          PoseScratch& sc, float* dx, float* dO, float* dcam_ext, float* dscale,
+                          int tid, int nthr, Sync sync) {
+    M3 MR; V3 Mt;
+    world_matrix(cam_ext, x, scale, &MR, &Mt);
+    V3 transl = v3(x[X_TRANSL], x[X_TRANSL + 1], x[X_TRANSL + 2]);
+    for (int j = tid; j < NJ; j += nthr) {
+        for (int e = 0; e < 9; ++e) sc.R[j][e] = Rm[9 * j + e];
+        for (int e = 0; e < 12; ++e) sc.G[j][e] = G[12 * j + e];
+        for (int c = 0; c < 3; ++c) sc.J[j][c] = Jrest[3 * j + c];
+        M3 GR = g_rot(sc.G[j]);
+        V3 Jj = v3(sc.J[j][0], sc.J[j][1], sc.J[j][2]);
+        M3 dGR = m3_zero();
+        V3 dGt = v3(0, 0, 0), dJ = v3(0, 0, 0);
+        if (dA) {
+            dGR = g_rot(dA + 12 * j);
+            V3 dAt = g_trn(dA + 12 * j);
+            m3_add_outer(dGR, -1.f * dAt, Jj);          // A.t = G.t - G.R J
+            dGt = dAt;
+            dJ = -1.f * m3t_vec(GR, dAt);
+        }
+        if (j < NJW) {
+            M3 dMR = m3_zero();
+            V3 q = v3(0, 0, 0), g = v3(0, 0, 0);
+            if (dJw) {
+                g = v3(dJw[3 * j], dJw[3 * j + 1], dJw[3 * j + 2]);
+                m3_add_outer(dMR, g, g_trn(sc.G[j]) + transl);
+                q = m3t_vec(MR, g);
+                dGt = dGt + q;
+            }
+            g_store(sc.dMj[j], dMR, g);
+            sc.dTj[j][0] = q.x; sc.dTj[j][1] = q.y; sc.dTj[j][2] = q.z;
+        }
+        g_store(sc.dG[j], dGR, dGt);
+        sc.dJ[j][0] = dJ.x; sc.dJ[j][1] = dJ.y; sc.dJ[j][2] = dJ.z;
+    }
+    sync();
+    // reverse chain: children (level L) hand their gradient to parents (level L-1)
+    for (int L = pm.nlevels - 1; L >= 1; --L) {
+        for (int k = pm.level_start[L] + tid; k < pm.level_start[L + 1]; k += nthr) {
+            int c = pm.order[k];
+            int p = pm.parents[c];
+            M3 Rp = g_rot(sc.G[p]);
+            store_m3(sc.dR[c], m3_mul_at(Rp, g_rot(sc.dG[c])));
+            V3 dr = m3t_vec(Rp, g_trn(sc.dG[c]));
+            sc.drel[c][0] = dr.x; sc.drel[c][1] = dr.y; sc.drel[c][2] = dr.z;
+        }
+        for (int k = pm.level_start[L - 1] + tid; k < pm.level_start[L]; k += nthr) {
+            int p = pm.order[k];
+            M3 acc = g_rot(sc.dG[p]);
+            V3 acct = g_trn(sc.dG[p]);
+            V3 Jp = v3(sc.J[p][0], sc.J[p][1], sc.J[p][2]);
+            for (int ci = pm.child_start[p]; ci < pm.child_start[p + 1]; ++ci) {
+                int c = pm.child_list[ci];
+                M3 dGc = g_rot(sc.dG[c]);
+                V3 dGct = g_trn(sc.dG[c]);
+                m3_add(acc, m3_mul_bt(dGc, load_m3(sc.R[c])));
+                m3_add_outer(acc, dGct, v3(sc.J[c][0], sc.J[c][1], sc.J[c][2]) - Jp);
+                acct = acct + dGct;
+            }
+            g_store(sc.dG[p], acc, acct);
+        }
+        sync();
+    }
+    if (tid == 0) {
+        int r = pm.order[0];
+        store_m3(sc.dR[r], g_rot(sc.dG[r]));
+        V3 t = g_trn(sc.dG[r]);
+        sc.drel[r][0] = t.x; sc.drel[r][1] = t.y; sc.drel[r][2] = t.z;
+    }
+    for (int i = tid; i < 90; i += nthr) (&sc.daa[0][0])[i] = 0.f;
+    sync();
+    for (int j = tid; j < NJ; j += nthr) {
+        // rel_j = J_j - J_parent
+        V3 dJ = v3(sc.dJ[j][0] + sc.drel[j][0], sc.dJ[j][1] + sc.drel[j][1], sc.dJ[j][2] + sc.drel[j][2]);
+        for (int ci = pm.child_start[j]; ci < pm.child_start[j + 1]; ++ci) {
+            int c = pm.child_list[ci];
+            dJ = dJ - v3(sc.drel[c][0], sc.drel[c][1], sc.drel[c][2]);
+        }
+        sc.dJ[j][0] = dJ.x; sc.dJ[j][1] = dJ.y; sc.dJ[j][2] = dJ.z;
+        M3 dR = load_m3(sc.dR[j]);
+        if (dPF && j >= 1) for (int e = 0; e < 9; ++e) dR.m[e] += dPF[9 * (j - 1) + e];
+        if (j == 0) {
+            GsCache c; gs_forward(x + X_SIXD, 1, &c);
+            float d6[6]; gs_backward(c, dR, d6, 1);
+            for (int e = 0; e < 6; ++e) dx[X_SIXD + e] += d6[e];
+        } else if (j <= 21) {
+            GsCache c; gs_forward(o + 6 * (j - 1), 1, &c);
+            gs_backward(c, dR, dO + 6 * (j - 1), 1);
+        } else if (j >= 25) {
+            V3 d = rodrigues_backward(hand_aa(pm, x, j), dR);
+            int h = (j - 25) / 15, f = (j - 25) % 15;
+            sc.daa[h][3 * f] = d.x; sc.daa[h][3 * f + 1] = d.y; sc.daa[h][3 * f + 2] = d.z;
+        }
+    }
+    sync();
+    // small per-frame reductions, one output element per thread, fixed summation order
+    for (int t = tid; t < 64; t += nthr) {
+        if (t < NBETA) {
+            float acc = dbeta_v ? dbeta_v[t] : 0.f;
+            for (int j = 0; j < NJ; ++j)
+                for (int c = 0; c < 3; ++c) acc += pm.Jd[(3 * j + c) * NBETA + t] * sc.dJ[j][c];
+            dx[X_BETAS + t] += acc;
+        } else if (t < NBETA + 24) {
+            int i = t - NBETA, h = i / 12, ii = i % 12;
+            const float* comp = pm.hand_comp + (h * 12 + ii) * 45;
+            float acc = 0.f;
+            for (int k = 0; k < 45; ++k) acc += comp[k] * sc.daa[h][k];
+            dx[(h == 0 ? X_LH : X_RH) + ii] += acc;
+        } else if (t < NBETA + 24 + 3) {
+            int c = t - NBETA - 24;
+            float acc = dtransl_v ? dtransl_v[c] : 0.f;
+            for (int j = 0; j < NJW; ++j) acc += sc.dTj[j][c];
+            dx[X_TRANSL + c] += acc;
+        } else if (t == NBETA + 24 + 3) {
+            float dM[12];
+            for (int e = 0; e < 12; ++e) {
+                float acc = dMv ? dMv[e] : 0.f;
+                for (int j = 0; j < NJW; ++j) acc += sc.dMj[j][e];
+                dM[e] = acc;
+            }
+            M3 dMR = g_rot(dM);
+            V3 dMt = g_trn(dM);
+            V3 ct = v3(x[X_CAMT], x[X_CAMT + 1], x[X_CAMT + 2]);
+            M3 dER = dMR;
+            m3_add_outer(dER, dMt, scale * ct);           // M.t = E.R (s ct) + E.t
+            V3 q = m3t_vec(MR, dMt);
+            dx[X_CAMT] += scale * q.x; dx[X_CAMT + 1] += scale * q.y; dx[X_CAMT + 2] += scale * q.z;
+            *dscale = (dsv ? *dsv : 0.f) + dot(q, ct);
+            g_store(dcam_ext, dER, dMt);
+            dcam_ext[12] = dcam_ext[13] = dcam_ext[14] = dcam_ext[15] = 0.f;   // bottom row never used
+        }
+    }
+}
+
+}  // namespace fdc

@@ -1,0 +1,132 @@
+// fp32 GEMM on the gfx950 matrix cores (v_mfma_f32_32x32x2_f32: exact fp32, bitwise an fmaf
+// chain) used for every dense contraction of the hot path:
+//   VPoser decoder layers forward / data-gradient (K3),
+//   pose blendshapes  v_off[F,3V'] = pose_feature[F,486] x posedirs[486,3V']  (K8) and its
+//   data-gradient     dPF[F,486]   = dv_off[F,3V'] x posedirs^T.
+// C[M,N] = epi(A[M,K] x B), A row-major with leading dimension lda (the latent is read in place
+// from the 78-wide parameter rows), B either [K,N] ("NN") or [N,K] ("NT").
+// 64-wide wavefronts: a workgroup is 4 waves in a 2x2 arrangement, each wave owns TM x TN
+// 32x32 accumulator tiles; operands are staged through LDS with a +1 padded K stride so both
+// fragment reads (lanes walk rows, fixed k) are bank-conflict free.
+#pragma once
+#include <hip/hip_runtime.h>
+
+namespace fdc {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+enum GemmEpi {
+    EPI_STORE = 0,        // C = acc
+    EPI_BIAS = 1,         // C = acc + bias[n]
+    EPI_BIAS_LRELU = 2,   // C = leaky_relu(acc + bias[n], 0.2)
+    EPI_MASK_LRELU = 3,   // C = acc * (aux[m,n] > 0 ? 1 : 0.2)   (aux = forward activation)
+    EPI_ACCUM = 4         // C += acc
+};
+
+template <bool B_IS_NK, int EPI, int TM, int TN>
+__global__ __launch_bounds__(256) void gemm_f32_mfma_kernel(
+    const float* __restrict__ A, int lda, const float* __restrict__ B, int ldb, float* __restrict__ C,
+    int ldc, int M, int N, int K, const float* __restrict__ aux, int ldaux) {
+    constexpr int BM = 64 * TM, BN = 64 * TN, BK = 32, LD = BK + 1;
+    __shared__ float As[BM * LD];
+    __shared__ float Bs[BN * LD];
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    for (int k0 = 0; k0 < K; k0 += BK) {
+#pragma unroll
+        for (int i = 0; i < (BM * BK) / 256; ++i) {
+            int e = tid + i * 256, r = e >> 5, c = e & 31;
+            int gm = m0 + r, gk = k0 + c;
+            As[r * LD + c] = (gm < M && gk < K) ? A[(size_t)gm * lda + gk] : 0.f;
+        }
+        if (B_IS_NK) {
+#pragma unroll
+            for (int i = 0; i < (BN * BK) / 256; ++i) {
+                int e = tid + i * 256, r = e >> 5, c = e & 31;
+                int gn = n0 + r, gk = k0 + c;
+                Bs[r * LD + c] = (gn < N && gk < K) ? B[(size_t)gn * ldb + gk] : 0.f;
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < (BN * BK) / 256; ++i) {
+                int e = tid + i * 256, kk = e / BN, nn = e % BN;
+                int gn = n0 + nn, gk = k0 + kk;
+                Bs[nn * LD + kk] = (gn < N && gk < K) ? B[(size_t)gk * ldb + gn] : 0.f;
+            }
+        }
+        __syncthreads();
+#pragma unroll 4
+        for (int kk = 0; kk < BK; kk += 2) {
+            float a[TM], b[TN];
+#pragma unroll
+            for (int i = 0; i < TM; ++i) a[i] = As[((wm * TM + i) * 32 + (lane & 31)) * LD + kk + (lane >> 5)];
+#pragma unroll
+            for (int j = 0; j < TN; ++j) b[j] = Bs[((wn * TN + j) * 32 + (lane & 31)) * LD + kk + (lane >> 5)];
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[j], acc[i][j], 0, 0, 0);
+        }
+        __syncthreads();
+    }
+    // C/D layout of the 32x32 tile: col = lane & 31, row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5)
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                int m = m0 + (wm * TM + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                int n = n0 + (wn * TN + j) * 32 + (lane & 31);
+                if (m < M && n < N) {
+                    float v = acc[i][j][r];
+                    if (EPI == EPI_BIAS || EPI == EPI_BIAS_LRELU) v += aux[n];
+                    if (EPI == EPI_BIAS_LRELU) v = v > 0.f ? v : 0.2f * v;
+                    if (EPI == EPI_MASK_LRELU) v *= (aux[(size_t)m * ldaux + n] > 0.f) ? 1.f : 0.2f;
+                    float* dst = C + (size_t)m * ldc + n;
+                    if (EPI == EPI_ACCUM) v += *dst;
+                    *dst = v;
+                }
+            }
+}
+
+template <bool NK, int EPI>
+static inline hipError_t gemm_dispatch_tile(const float* A, int lda, const float* B, int ldb, float* C, int ldc,
+                                            int M, int N, int K, const float* aux, int ldaux, hipStream_t st) {
+    if (M <= 0 || N <= 0) return hipSuccess;
+    // large outputs: 128x128 workgroup tiles (4 accumulators per wave); small ones: 64x64
+    if ((long long)M * N >= 128LL * 128 * 512) {
+        dim3 grid((N + 127) / 128, (M + 127) / 128);
+        hipLaunchKernelGGL((gemm_f32_mfma_kernel<NK, EPI, 2, 2>), grid, dim3(256), 0, st, A, lda, B, ldb, C, ldc,
+                           M, N, K, aux, ldaux);
+    } else {
+        dim3 grid((N + 63) / 64, (M + 63) / 64);
+        hipLaunchKernelGGL((gemm_f32_mfma_kernel<NK, EPI, 1, 1>), grid, dim3(256), 0, st, A, lda, B, ldb, C, ldc,
+                           M, N, K, aux, ldaux);
+    }
+    return hipGetLastError();
+}
+
+// b_is_nk: B stored [N,K] (C = A B^T) else [K,N]
+static inline hipError_t gemm_f32(bool b_is_nk, int epi, const float* A, int lda, const float* B, int ldb, float* C,
+                                  int ldc, int M, int N, int K, const float* aux, int ldaux, hipStream_t st) {
+#define FDC_GEMM_CASE(NK, E) \
+    if (b_is_nk == NK && epi == E) return gemm_dispatch_tile<NK, E>(A, lda, B, ldb, C, ldc, M, N, K, aux, ldaux, st);
+    FDC_GEMM_CASE(true, EPI_STORE) FDC_GEMM_CASE(true, EPI_BIAS) FDC_GEMM_CASE(true, EPI_BIAS_LRELU)
+    FDC_GEMM_CASE(true, EPI_ACCUM)
+    FDC_GEMM_CASE(false, EPI_STORE) FDC_GEMM_CASE(false, EPI_MASK_LRELU) FDC_GEMM_CASE(false, EPI_ACCUM)
+#undef FDC_GEMM_CASE
+    return hipErrorInvalidValue;
+}
+
+}  // namespace fdc

@@ -1,0 +1,69 @@
+// Data / temporal losses on the raw 78-d rows and on world joints, with their gradients, and
+// the Adam update.  Restates /root/reference/global_optimization.py:255-259 (loss_rec),
+// :266-267 (loss_smoothing), :304 (loss_world_smoothing), :262-263 (loss_vposer, logged only)
+// and torch.optim.Adam's single-tensor update (:188, :592).
+#pragma once
+#include "fdc_math.h"
+
+namespace fdc {
+
+FDC_HD float sgn(float v) { return (v > 0.f) ? 1.f : ((v < 0.f) ? -1.f : 0.f); }
+
+// second difference exactly as the reference groups it: (x_i - x_{i+1}) - (x_{i+1} - x_{i+2})
+FDC_HD float second_diff(float a, float b, float c) { return (a - b) - (b - c); }
+
+// One element of one frame.  xm2..xp2 are x[g-2..g+2][e] (values outside the clip are ignored
+// through the range tests on g).  Returns d loss / d x[g][e] for
+//   w_rec * mean(|x0-x|*mask) + w_sm * mean(|second diff|)
+// and accumulates this row's share of the two un-weighted sums.
+FDC_HD float param_loss_grad(int g, int n_total, float xm2, float xm1, float x0c, float xp1, float xp2,
+                             float xdata, float mask, float w_rec_over_cnt, float w_sm_over_cnt,
+                             float* rec_abs, float* sm_abs) {
+    float diff = xdata - x0c;
+    *rec_abs = fabsf(diff) * mask;
+    float grad = -sgn(diff) * mask * w_rec_over_cnt;
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f;
+    *sm_abs = 0.f;
+    if (g <= n_total - 3) { float e = second_diff(x0c, xp1, xp2); s0 = sgn(e); *sm_abs = fabsf(e); }
+    if (g >= 1 && g <= n_total - 2) s1 = sgn(second_diff(xm1, x0c, xp1));
+    if (g >= 2) s2 = sgn(second_diff(xm2, xm1, x0c));
+    grad += (s0 - 2.f * s1 + s2) * w_sm_over_cnt;
+    return grad;
+}
+
+// world-joint first difference (:304): d/dJw[g] of w * mean(|Jw_i - Jw_{i+1}|)
+FDC_HD float world_smooth_grad(int g, int n_total, float jm1, float j0, float jp1, float w_over_cnt,
+                               float* abs_term) {
+    float grad = 0.f;
+    *abs_term = 0.f;
+    if (g <= n_total - 2) { float d = j0 - jp1; grad += sgn(d); *abs_term = fabsf(d); }
+    if (g >= 1) grad -= sgn(jm1 - j0);
+    return grad * w_over_cnt;
+}
+
+struct AdamScalars { float one_minus_b1, b2, one_minus_b2, step_size, bc2_sqrt, eps; };
+
+// torch.optim.Adam defaults: betas (0.9, 0.999), eps 1e-8; the bias corrections are evaluated
+// in double exactly like torch's python scalars and then applied in fp32.
+FDC_HD AdamScalars adam_scalars(double lr, int step) {
+    AdamScalars a;
+    double b1 = 0.9, b2 = 0.999;
+    double bc1 = 1.0 - pow(b1, (double)step);
+    double bc2 = 1.0 - pow(b2, (double)step);
+    a.one_minus_b1 = (float)(1.0 - b1);
+    a.b2 = (float)b2;
+    a.one_minus_b2 = (float)(1.0 - b2);
+    a.step_size = (float)(lr / bc1);
+    a.bc2_sqrt = (float)sqrt(bc2);
+    a.eps = 1e-8f;
+    return a;
+}
+
+FDC_HD void adam_update(float& p, float& m, float& v, float g, const AdamScalars& a) {
+    m = m + (g - m) * a.one_minus_b1;                 // exp_avg.lerp_(grad, 1-beta1)
+    v = v * a.b2 + a.one_minus_b2 * g * g;            // exp_avg_sq.mul_(beta2).addcmul_(g, g, 1-beta2)
+    float denom = sqrtf(v) / a.bc2_sqrt + a.eps;      // sqrt(v)/sqrt(bc2) + eps
+    p = p - a.step_size * (m / denom);                // addcdiv_(m, denom, -step_size)
+}
+
+}  // namespace fdc

@@ -1,0 +1,88 @@
+// Per-vertex shape blend + linear-blend skinning + world transform, forward and backward.
+// Restates smplx.lbs.lbs steps v_shaped / v_posed / T = W·A / verts, `+transl`,
+// `*scale` (/root/reference/global_optimization.py:284) and verts_transform (:119-127, :285).
+// The per-vertex 4x4 transform T[B,V,4,4] the library materialises (670 KB/frame) only ever
+// exists in registers here.
+#pragma once
+#include "fdc_math.h"
+
+namespace fdc {
+
+struct SkinModel {
+    const float* vt;      // [V,3]  v_template (+ constant expression offset folded in)
+    const float* S;       // [V,3,10] shapedirs (betas part)
+    const int* wj;        // [V,K] joint ids of the non-zero skinning weights (padded with 0)
+    const float* ww;      // [V,K] weights (padded with 0.0)
+    int K;
+};
+
+struct SkinFwd { V3 vp, vb, vw; float T[12]; };
+
+// v: vertex id in the full mesh; voff: this vertex's 3 pose-blend offsets (PF @ posedirs)
+FDC_HD SkinFwd skin_forward_vertex(const SkinModel& sm, int v, const float* beta, const float* voff,
+                                   const float* A, V3 transl, const float* M, float scale) {
+    SkinFwd r;
+    float p[3];
+    for (int c = 0; c < 3; ++c) {
+        float acc = sm.vt[3 * v + c];
+        const float* s = sm.S + (3 * v + c) * 10;
+        for (int l = 0; l < 10; ++l) acc += s[l] * beta[l];
+        p[c] = acc + voff[c];
+    }
+    r.vp = v3(p[0], p[1], p[2]);
+    for (int e = 0; e < 12; ++e) r.T[e] = 0.f;
+    for (int k = 0; k < sm.K; ++k) {
+        float w = sm.ww[v * sm.K + k];
+        const float* a = A + 12 * sm.wj[v * sm.K + k];
+        for (int e = 0; e < 12; ++e) r.T[e] += w * a[e];
+    }
+    V3 vl = v3(r.T[0] * p[0] + r.T[1] * p[1] + r.T[2] * p[2] + r.T[3],
+               r.T[4] * p[0] + r.T[5] * p[1] + r.T[6] * p[2] + r.T[7],
+               r.T[8] * p[0] + r.T[9] * p[1] + r.T[10] * p[2] + r.T[11]);
+    r.vb = vl + transl;
+    V3 sv = scale * r.vb;
+    r.vw = v3(M[0] * sv.x + M[1] * sv.y + M[2] * sv.z + M[3],
+              M[4] * sv.x + M[5] * sv.y + M[6] * sv.z + M[7],
+              M[8] * sv.x + M[9] * sv.y + M[10] * sv.z + M[11]);
+    return r;
+}
+
+// Gradient of one vertex.  g = d loss / d vw.  Emits
+//   dT[12]  : d loss / d T_v  (caller scatters w_vj * dT into dA_j)
+//   dvp     : d loss / d v_posed  (= d voff; caller contracts with shapedirs for d beta)
+//   gv      : d loss / d (v + transl)  (= d transl contribution)
+//   dM[12]  : contribution to d loss / d M
+//   ds      : contribution to d loss / d scale
+struct SkinBwd { float dT[12]; V3 dvp, gv; float dM[12]; float ds; };
+
+FDC_HD SkinBwd skin_backward_vertex(const SkinFwd& f, const float* M, float scale, V3 g) {
+    SkinBwd b;
+    V3 sv = scale * f.vb;
+    // vw = M.R (s vb) + M.t
+    b.dM[0] = g.x * sv.x; b.dM[1] = g.x * sv.y; b.dM[2] = g.x * sv.z;  b.dM[3] = g.x;
+    b.dM[4] = g.y * sv.x; b.dM[5] = g.y * sv.y; b.dM[6] = g.y * sv.z;  b.dM[7] = g.y;
+    b.dM[8] = g.z * sv.x; b.dM[9] = g.z * sv.y; b.dM[10] = g.z * sv.z; b.dM[11] = g.z;
+    V3 gs = v3(M[0] * g.x + M[4] * g.y + M[8] * g.z,
+               M[1] * g.x + M[5] * g.y + M[9] * g.z,
+               M[2] * g.x + M[6] * g.y + M[10] * g.z);       // d loss / d (s vb)
+    b.ds = dot(gs, f.vb);
+    b.gv = scale * gs;
+    // vl = T.R vp + T.t
+    b.dT[0] = b.gv.x * f.vp.x; b.dT[1] = b.gv.x * f.vp.y; b.dT[2] = b.gv.x * f.vp.z;  b.dT[3] = b.gv.x;
+    b.dT[4] = b.gv.y * f.vp.x; b.dT[5] = b.gv.y * f.vp.y; b.dT[6] = b.gv.y * f.vp.z;  b.dT[7] = b.gv.y;
+    b.dT[8] = b.gv.z * f.vp.x; b.dT[9] = b.gv.z * f.vp.y; b.dT[10] = b.gv.z * f.vp.z; b.dT[11] = b.gv.z;
+    b.dvp = v3(f.T[0] * b.gv.x + f.T[4] * b.gv.y + f.T[8] * b.gv.z,
+               f.T[1] * b.gv.x + f.T[5] * b.gv.y + f.T[9] * b.gv.z,
+               f.T[2] * b.gv.x + f.T[6] * b.gv.y + f.T[10] * b.gv.z);
+    return b;
+}
+
+// contact robustifier (:295): per-query value and d value / d dist, before the mean and weights
+FDC_HD float contact_term(float d, float* dterm_dd) {
+    float r = sqrtf(d + 1e-4f);
+    float q = 1.f / (r + 1.f);
+    *dterm_dd = q * q * (0.5f / r);
+    return r * q;
+}
+
+}  // namespace fdc

@@ -1,0 +1,882 @@
+// libfdcap_hip.so -- kernels + C-ABI (include/fdcap.h) of the MI355X global-optimisation path.
+// gfx950 only.  See DESIGN.md for the data layout and the per-kernel rooflines.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string.h>
+
+#include <algorithm>
+#include <vector>
+
+#include "../../include/fdcap.h"
+#include "fdc_chamfer.h"
+#include "fdc_frame.h"
+#include "fdc_gemm.h"
+#include "fdc_host_setup.h"
+#include "fdc_loss.h"
+#include "fdc_math.h"
+#include "fdc_skin.h"
+
+using namespace fdc;
+
+#define HIP_TRY(expr)                              \
+    do {                                           \
+        hipError_t _e = (expr);                    \
+        if (_e != hipSuccess) return (int)_e;      \
+    } while (0)
+
+namespace {
+
+struct SyncBlock {
+    __device__ void operator()() const { __syncthreads(); }
+};
+
+// ------------------------------------------------------------------------------------------
+// kernels
+// ------------------------------------------------------------------------------------------
+
+// one 64-thread workgroup (one wavefront) per frame
+__global__ __launch_bounds__(64) void pose_fwd_kernel(PoseModel pm, const float* __restrict__ X, const float* __restrict__ O,
+                                                      const float* __restrict__ CAM, const float* __restrict__ scale,
+                                                      int row0, float* Rm, float* PF, float* Jrest, float* G, float* A,
+                                                      float* M, float* Jw, const float* AA) {
+    __shared__ PoseScratch sc;
+    int r = row0 + blockIdx.x;
+    pose_forward(pm, X + (size_t)r * XDIM, O ? O + (size_t)r * ODIM : nullptr, CAM + (size_t)r * 16, *scale, sc,
+                 Rm ? Rm + (size_t)r * NJ * 9 : nullptr, PF ? PF + (size_t)r * NPF : nullptr,
+                 Jrest ? Jrest + (size_t)r * NJ * 3 : nullptr, G ? G + (size_t)r * NJ * 12 : nullptr,
+                 A ? A + (size_t)r * NJ * 12 : nullptr, M ? M + (size_t)r * 12 : nullptr,
+                 Jw ? Jw + (size_t)r * NJW * 3 : nullptr, threadIdx.x, 64, SyncBlock(),
+                 AA ? AA + (size_t)r * 66 : nullptr);
+}
+
+__global__ __launch_bounds__(64) void pose_bwd_kernel(PoseModel pm, const float* __restrict__ X, const float* __restrict__ O,
+                                                      const float* __restrict__ CAM, const float* __restrict__ scale,
+                                                      int row0, const float* Rm, const float* Jrest, const float* G,
+                                                      const float* dA, const float* dPF, const float* dJw,
+                                                      const float* dMv, const float* dsv, const float* dbeta_v,
+                                                      const float* dtransl_v, float* dX, float* dO, float* dCAM,
+                                                      float* dscale_row) {
+    __shared__ PoseScratch sc;
+    int r = row0 + blockIdx.x;
+    pose_backward(pm, X + (size_t)r * XDIM, O + (size_t)r * ODIM, CAM + (size_t)r * 16, *scale,
+                  Rm + (size_t)r * NJ * 9, Jrest + (size_t)r * NJ * 3, G + (size_t)r * NJ * 12,
+                  dA ? dA + (size_t)r * NJ * 12 : nullptr, dPF ? dPF + (size_t)r * NPF : nullptr,
+                  dJw ? dJw + (size_t)r * NJW * 3 : nullptr, dMv ? dMv + (size_t)r * 12 : nullptr,
+                  dsv ? dsv + r : nullptr, dbeta_v ? dbeta_v + (size_t)r * NBETA : nullptr,
+                  dtransl_v ? dtransl_v + (size_t)r * 3 : nullptr, sc, dX + (size_t)r * XDIM,
+                  dO + (size_t)r * ODIM, dCAM + (size_t)r * 16, dscale_row + r, threadIdx.x, 64, SyncBlock());
+}
+
+// thread per (frame, vertex).  Vout layout [rows, nv, 3].  world = 0: body frame (+transl only)
+__global__ void skin_fwd_kernel(SkinModel sm, int nv, const float* __restrict__ X, int ldx, int beta_off, int transl_off,
+                                const float* __restrict__ Voff, const float* __restrict__ A,
+                                const float* __restrict__ M, const float* __restrict__ scale, int row0, int world,
+                                float* __restrict__ Vout) {
+    int c = blockIdx.x * blockDim.x + threadIdx.x;
+    int r = row0 + blockIdx.y;
+    if (c >= nv) return;
+    const float* x = X + (size_t)r * ldx;
+    V3 transl = v3(x[transl_off], x[transl_off + 1], x[transl_off + 2]);
+    const float ident[12] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0};
+    SkinFwd f = skin_forward_vertex(sm, c, x + beta_off, Voff + ((size_t)r * nv + c) * 3, A + (size_t)r * NJ * 12,
+                                    transl, world ? M + (size_t)r * 12 : ident, world ? *scale : 1.f);
+    float* o = Vout + ((size_t)r * nv + c) * 3;
+    o[0] = f.vw.x; o[1] = f.vw.y; o[2] = f.vw.z;
+}
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+    return v;
+}
+
+// workgroup per frame: contact-term gradient -> skinning backward, reduced over the frame's
+// contact vertices.  dist/idx/Vw/dVoff are [rows, nc(,3)].
+constexpr int SKB_NACC = NBETA + 3 + 12 + 1 + 1;   // dbeta, dtransl, dM, ds, contact-term sum
+__global__ __launch_bounds__(256) void skin_bwd_kernel(SkinModel sm, int nc, const float* __restrict__ X,
+                                                       const float* __restrict__ Voff, const float* __restrict__ A,
+                                                       const float* __restrict__ M, const float* __restrict__ scale,
+                                                       int row0, const float* __restrict__ Vw,
+                                                       const float* __restrict__ dist, const int* __restrict__ idx,
+                                                       const float4* __restrict__ scene, float coef,
+                                                       float* __restrict__ dVoff, float* __restrict__ dA,
+                                                       float* __restrict__ dbeta_v, float* __restrict__ dtransl_v,
+                                                       float* __restrict__ dMv, float* __restrict__ dsv,
+                                                       double* __restrict__ loss_contact_sum) {
+    __shared__ float sdA[NJ * 12];
+    __shared__ float sred[4][SKB_NACC];
+    const int tid = threadIdx.x;
+    const int r = row0 + blockIdx.x;
+    for (int i = tid; i < NJ * 12; i += 256) sdA[i] = 0.f;
+    __syncthreads();
+    const float* x = X + (size_t)r * XDIM;
+    const float s = *scale;
+    V3 transl = v3(x[X_TRANSL], x[X_TRANSL + 1], x[X_TRANSL + 2]);
+    float acc[SKB_NACC];
+#pragma unroll
+    for (int i = 0; i < SKB_NACC; ++i) acc[i] = 0.f;
+    for (int c = tid; c < nc; c += 256) {
+        size_t qi = (size_t)r * nc + c;
+        float dterm;
+        float term = contact_term(dist[qi], &dterm);
+        int j = idx[qi];
+        float4 p = scene[j];
+        float gg = 2.f * coef * dterm;
+        V3 g = v3(gg * (Vw[3 * qi] - p.x), gg * (Vw[3 * qi + 1] - p.y), gg * (Vw[3 * qi + 2] - p.z));
+        SkinFwd f = skin_forward_vertex(sm, c, x + X_BETAS, Voff + 3 * qi, A + (size_t)r * NJ * 12, transl,
+                                        M + (size_t)r * 12, s);
+        SkinBwd b = skin_backward_vertex(f, M + (size_t)r * 12, s, g);
+        dVoff[3 * qi] = b.dvp.x; dVoff[3 * qi + 1] = b.dvp.y; dVoff[3 * qi + 2] = b.dvp.z;
+        for (int l = 0; l < NBETA; ++l)
+            acc[l] += sm.S[(3 * c) * 10 + l] * b.dvp.x + sm.S[(3 * c + 1) * 10 + l] * b.dvp.y +
+                      sm.S[(3 * c + 2) * 10 + l] * b.dvp.z;
+        acc[NBETA] += b.gv.x; acc[NBETA + 1] += b.gv.y; acc[NBETA + 2] += b.gv.z;
+#pragma unroll
+        for (int e = 0; e < 12; ++e) acc[NBETA + 3 + e] += b.dM[e];
+        acc[NBETA + 15] += b.ds;
+        acc[NBETA + 16] += term;
+        for (int k = 0; k < sm.K; ++k) {
+            float w = sm.ww[c * sm.K + k];
+            if (w != 0.f) {
+                int jj = sm.wj[c * sm.K + k];
+#pragma unroll
+                for (int e = 0; e < 12; ++e) atomicAdd(&sdA[jj * 12 + e], w * b.dT[e]);
+            }
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < SKB_NACC; ++i) {
+        float v = wave_sum(acc[i]);
+        if ((tid & 63) == 0) sred[tid >> 6][i] = v;
+    }
+    __syncthreads();
+    for (int i = tid; i < NJ * 12; i += 256) dA[(size_t)r * NJ * 12 + i] = sdA[i];
+    if (tid < SKB_NACC) {
+        float v = sred[0][tid] + sred[1][tid] + sred[2][tid] + sred[3][tid];
+        if (tid < NBETA) dbeta_v[(size_t)r * NBETA + tid] = v;
+        else if (tid < NBETA + 3) dtransl_v[(size_t)r * 3 + tid - NBETA] = v;
+        else if (tid < NBETA + 15) dMv[(size_t)r * 12 + tid - NBETA - 3] = v;
+        else if (tid == NBETA + 15) dsv[r] = v;
+        else atomicAdd(loss_contact_sum, (double)v);
+    }
+}
+
+// sum of the contact robustifier only (phase-2 logging)
+__global__ void contact_loss_kernel(const float* __restrict__ dist, size_t n, double* __restrict__ out) {
+    __shared__ float sred[4];
+    size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    float v = 0.f;
+    for (; i < n; i += (size_t)gridDim.x * 256) { float d; v += contact_term(dist[i], &d); }
+    v = wave_sum(v);
+    if ((threadIdx.x & 63) == 0) sred[threadIdx.x >> 6] = v;
+    __syncthreads();
+    if (threadIdx.x == 0) atomicAdd(out, (double)(sred[0] + sred[1] + sred[2] + sred[3]));
+}
+
+// block (128 threads) per owned frame: data + temporal terms on the raw rows, optional world
+// smoothing on joints.  Initialises dX (=) and dJw (=).
+__global__ __launch_bounds__(128) void param_loss_kernel(const float* __restrict__ X, const float* __restrict__ X0,
+                                                         const float* __restrict__ mask, const float* __restrict__ Jw,
+                                                         int row0, int frame0, int n_total, float w_rec_over_cnt,
+                                                         float w_sm_over_cnt, float w_ws_over_cnt, int world_grad,
+                                                         float* __restrict__ dX, float* __restrict__ dJw,
+                                                         double* __restrict__ losses) {
+    __shared__ float sred[2][4];
+    const int tid = threadIdx.x;
+    const int r = row0 + blockIdx.x;
+    const int g = frame0 + blockIdx.x;
+    float rec = 0.f, sm = 0.f, ws = 0.f, vp = 0.f;
+    if (tid < XDIM) {
+        const float* x = X + (size_t)r * XDIM + tid;
+        float xm2 = (g >= 2) ? x[-2 * XDIM] : 0.f;
+        float xm1 = (g >= 1) ? x[-XDIM] : 0.f;
+        float xp1 = (g + 1 < n_total) ? x[XDIM] : 0.f;
+        float xp2 = (g + 2 < n_total) ? x[2 * XDIM] : 0.f;
+        dX[(size_t)r * XDIM + tid] = param_loss_grad(g, n_total, xm2, xm1, x[0], xp1, xp2, X0[(size_t)r * XDIM + tid],
+                                                     mask[r], w_rec_over_cnt, w_sm_over_cnt, &rec, &sm);
+        if (tid >= X_LATENT && tid < X_LATENT + 32) vp = x[0] * x[0];
+    }
+    if (tid < NJW * 3) {
+        const float* j = Jw + (size_t)r * NJW * 3 + tid;
+        float jm1 = (g >= 1) ? j[-NJW * 3] : 0.f;
+        float jp1 = (g + 1 < n_total) ? j[NJW * 3] : 0.f;
+        float gr = world_smooth_grad(g, n_total, jm1, j[0], jp1, w_ws_over_cnt, &ws);
+        if (world_grad) dJw[(size_t)r * NJW * 3 + tid] = gr;
+    }
+    float vals[4] = {rec, vp, sm, ws};
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        float v = wave_sum(vals[i]);
+        if ((tid & 63) == 0) sred[tid >> 6][i] = v;
+    }
+    __syncthreads();
+    if (tid < 4) {
+        const int slot[4] = {0, 1, 2, 4};
+        atomicAdd(&losses[slot[tid]], (double)(sred[0][tid] + sred[1][tid]));
+    }
+}
+
+__global__ void reduce_rows_kernel(const float* __restrict__ v, int row0, int n, float* __restrict__ out) {
+    // fixed-order tree: thread t sums elements t, t+256, ... then a butterfly; deterministic
+    __shared__ float sred[4];
+    float a = 0.f;
+    for (int i = threadIdx.x; i < n; i += 256) a += v[row0 + i];
+    a = wave_sum(a);
+    if ((threadIdx.x & 63) == 0) sred[threadIdx.x >> 6] = a;
+    __syncthreads();
+    if (threadIdx.x == 0) *out = (sred[0] + sred[1]) + (sred[2] + sred[3]);
+}
+
+__global__ void adam_kernel(float* __restrict__ p, float* __restrict__ m, float* __restrict__ v,
+                            const float* __restrict__ g, size_t n, AdamScalars a, int zero_grad) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    float pp = p[i], mm = m[i], vv = v[i];
+    adam_update(pp, mm, vv, zero_grad ? 0.f : g[i], a);
+    p[i] = pp; m[i] = mm; v[i] = vv;
+}
+
+__global__ void p75_to_78_kernel(const float* __restrict__ in, int B, float* __restrict__ out) {
+    int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= B) return;
+    const float* p = in + (size_t)b * 75;
+    float* x = out + (size_t)b * XDIM;
+    for (int i = 0; i < 3; ++i) x[i] = p[i];
+    M3 R = tgm_aa_to_rotmat(v3(p[3], p[4], p[5]));
+    // first two COLUMNS, flattened row-major (global_optimization.py:101-102)
+    x[3] = R.m[0]; x[4] = R.m[1]; x[5] = R.m[3]; x[6] = R.m[4]; x[7] = R.m[6]; x[8] = R.m[7];
+    for (int i = 6; i < 75; ++i) x[i + 3] = p[i];
+}
+
+__global__ void p78_to_75_kernel(const float* __restrict__ in, int B, float* __restrict__ out) {
+    int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= B) return;
+    const float* x = in + (size_t)b * XDIM;
+    float* p = out + (size_t)b * 75;
+    for (int i = 0; i < 3; ++i) p[i] = x[i];
+    V3 aa = tgm_rotmat_to_aa(gs_forward(x + X_SIXD, 1, nullptr));
+    p[3] = aa.x; p[4] = aa.y; p[5] = aa.z;
+    for (int i = 9; i < XDIM; ++i) p[i - 3] = x[i];
+}
+
+// O[B,126] -> rot[B,21,9] (+ optional aa[B,63])
+__global__ void sixd_to_rot_kernel(const float* __restrict__ O, int n, float* __restrict__ rot, float* __restrict__ aa) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    M3 R = gs_forward(O + (size_t)i * 6, 1, nullptr);
+    if (rot) for (int e = 0; e < 9; ++e) rot[(size_t)i * 9 + e] = R.m[e];
+    if (aa) { V3 a = tgm_rotmat_to_aa(R); aa[(size_t)i * 3] = a.x; aa[(size_t)i * 3 + 1] = a.y; aa[(size_t)i * 3 + 2] = a.z; }
+}
+
+__global__ void joints_out_kernel(const float* __restrict__ G, const float* __restrict__ X, int ldx, int B, float* __restrict__ J) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= B * NJ) return;
+    int b = i / NJ;
+    const float* g = G + (size_t)i * 12;
+    const float* x = X + (size_t)b * ldx;
+    J[(size_t)i * 3] = g[3] + x[0]; J[(size_t)i * 3 + 1] = g[7] + x[1]; J[(size_t)i * 3 + 2] = g[11] + x[2];
+}
+
+// operator-level inputs -> a 78-wide row (6D / latent slots unused) + the 22 axis-angle joints
+__global__ void assemble_rows_kernel(const float* __restrict__ go, const float* __restrict__ bp, const float* __restrict__ betas,
+                                     const float* __restrict__ lh, const float* __restrict__ rh, const float* __restrict__ transl,
+                                     int B, float* __restrict__ X, float* __restrict__ AA) {
+    int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= B) return;
+    float* x = X + (size_t)b * XDIM;
+    for (int i = 0; i < XDIM; ++i) x[i] = 0.f;
+    for (int i = 0; i < 3; ++i) x[X_TRANSL + i] = transl[3 * b + i];
+    for (int i = 0; i < NBETA; ++i) x[X_BETAS + i] = betas[NBETA * b + i];
+    for (int i = 0; i < 12; ++i) { x[X_LH + i] = lh[12 * b + i]; x[X_RH + i] = rh[12 * b + i]; }
+    float* a = AA + (size_t)b * 66;
+    for (int i = 0; i < 3; ++i) a[i] = go[3 * b + i];
+    for (int i = 0; i < 63; ++i) a[3 + i] = bp[63 * b + i];
+}
+
+__global__ void copy_rows_kernel(const float* __restrict__ src, int lds, float* __restrict__ dst, int ldd, int rows, int cols) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (size_t)rows * cols) return;
+    int r = i / cols, c = i % cols;
+    dst[(size_t)r * ldd + c] = src[(size_t)r * lds + c];
+}
+
+// ------------------------------------------------------------------------------------------
+// host side
+// ------------------------------------------------------------------------------------------
+template <class T>
+struct DevBuf {
+    T* p = nullptr;
+    size_t n = 0;
+    hipError_t ensure(size_t count) {
+        if (count <= n) return hipSuccess;
+        if (p) (void)hipFree(p);
+        p = nullptr; n = 0;
+        hipError_t e = hipMalloc((void**)&p, std::max<size_t>(count, 1) * sizeof(T));
+        if (e == hipSuccess) n = count;
+        return e;
+    }
+    hipError_t upload(const T* h, size_t count) {
+        hipError_t e = ensure(count);
+        if (e != hipSuccess) return e;
+        return count ? hipMemcpy(p, h, count * sizeof(T), hipMemcpyHostToDevice) : hipSuccess;
+    }
+    void release() { if (p) (void)hipFree(p); p = nullptr; n = 0; }
+};
+
+struct SkinSet {          // skinning constants for a vertex set (all V, or the contact subset)
+    int nv = 0, K = 0;
+    DevBuf<float> vt, S, ww, posedirs;   // posedirs [486, 3*nv]
+    DevBuf<int> wj;
+    SkinModel model() const { SkinModel m; m.vt = vt.p; m.S = S.p; m.wj = wj.p; m.ww = ww.p; m.K = K; return m; }
+    void release() { vt.release(); S.release(); ww.release(); posedirs.release(); wj.release(); }
+};
+
+struct OptState {
+    fdcap_opt_config cfg;
+    int R = 0;            // rows = n_local + 4
+    bool contact_on = false;
+    int nsplit = 8;
+    struct Ext { float* p = nullptr; } X, CAM, scale, dscale;   // caller-owned, registered
+    struct ExtD { double* p = nullptr; } losses;
+    DevBuf<float> X0, mask, mX, vX, mCAM, vCAM, mS, vS;
+    DevBuf<float> H1, H2, O, dO, dH2, dH1;
+    DevBuf<float> Rm, PF, Jrest, G, A, M, Jw;
+    DevBuf<float> Voff, Vw, dist, pd, dVoff;
+    DevBuf<int> idx, pi;
+    DevBuf<float> dA, dbeta_v, dtransl_v, dMv, dsv, dPF, dJw, dX, dCAM, dscale_row;
+    int cam_steps = 0;
+};
+
+}  // namespace
+
+struct fdcap_ctx {
+    int V = 0;
+    // host copies needed to build vertex subsets
+    std::vector<float> h_vt, h_S10, h_posedirs, h_lbs;
+    // device constants
+    DevBuf<float> Jt, Jd, hand_comp, hand_mean;
+    DevBuf<int> parents, order, level_start, child_start, child_list;
+    int nlevels = 0;
+    DevBuf<float> W1, b1, W2, b2, W3, b3;
+    SkinSet full, contact;
+    bool full_ready = false;
+    DevBuf<float4> scene;
+    int64_t ns = 0;
+    int nc = 0;
+    // growable workspaces for the stand-alone operators
+    DevBuf<float> ws_f[12];
+    DevBuf<int> ws_i[2];
+    DevBuf<float4> ws_p;
+    OptState* opt = nullptr;
+
+    PoseModel pose_model() const {
+        PoseModel pm;
+        pm.Jt = Jt.p; pm.Jd = Jd.p; pm.parents = parents.p; pm.order = order.p; pm.level_start = level_start.p;
+        pm.child_start = child_start.p; pm.child_list = child_list.p; pm.hand_comp = hand_comp.p;
+        pm.hand_mean = hand_mean.p; pm.nlevels = nlevels;
+        return pm;
+    }
+};
+
+namespace {
+
+int build_skin_set(fdcap_ctx* c, const std::vector<int64_t>& ids, SkinSet* out) {
+    const int V = c->V;
+    const int nv = (int)ids.size();
+    int K = 1;
+    for (int v : ids) {
+        int k = 0;
+        for (int j = 0; j < NJ; ++j) k += c->h_lbs[(size_t)v * NJ + j] != 0.f;
+        K = std::max(K, k);
+    }
+    std::vector<float> vt((size_t)nv * 3), S((size_t)nv * 30), ww((size_t)nv * K, 0.f), pd((size_t)NPF * 3 * nv);
+    std::vector<int> wj((size_t)nv * K, 0);
+    for (int i = 0; i < nv; ++i) {
+        int64_t v = ids[i];
+        for (int k = 0; k < 3; ++k) vt[3 * i + k] = c->h_vt[3 * v + k];
+        for (int k = 0; k < 30; ++k) S[(size_t)30 * i + k] = c->h_S10[(size_t)30 * v + k];
+        int k = 0;
+        for (int j = 0; j < NJ; ++j) {
+            float w = c->h_lbs[(size_t)v * NJ + j];
+            if (w != 0.f) { wj[(size_t)i * K + k] = j; ww[(size_t)i * K + k] = w; ++k; }
+        }
+    }
+    for (int r = 0; r < NPF; ++r)
+        for (int i = 0; i < nv; ++i)
+            for (int k = 0; k < 3; ++k)
+                pd[(size_t)r * 3 * nv + 3 * i + k] = c->h_posedirs[(size_t)r * 3 * V + 3 * ids[i] + k];
+    out->nv = nv; out->K = K;
+    HIP_TRY(out->vt.upload(vt.data(), vt.size()));
+    HIP_TRY(out->S.upload(S.data(), S.size()));
+    HIP_TRY(out->ww.upload(ww.data(), ww.size()));
+    HIP_TRY(out->wj.upload(wj.data(), wj.size()));
+    HIP_TRY(out->posedirs.upload(pd.data(), pd.size()));
+    return 0;
+}
+
+// VPoser decoder forward for `rows` rows of X (latent read in place): H1, H2, O
+int vposer_forward(fdcap_ctx* c, const float* X, int ldx, int latent_off, int rows, float* H1, float* H2, float* O,
+                   hipStream_t st) {
+    HIP_TRY(gemm_f32(true, EPI_BIAS_LRELU, X + latent_off, ldx, c->W1.p, 32, H1, 512, rows, 512, 32, c->b1.p, 0, st));
+    HIP_TRY(gemm_f32(true, EPI_BIAS_LRELU, H1, 512, c->W2.p, 512, H2, 512, rows, 512, 512, c->b2.p, 0, st));
+    HIP_TRY(gemm_f32(true, EPI_BIAS, H2, 512, c->W3.p, 512, O, ODIM, rows, ODIM, 512, c->b3.p, 0, st));
+    return 0;
+}
+
+}  // namespace
+
+// ------------------------------------------------------------------------------------------
+// C-ABI
+// ------------------------------------------------------------------------------------------
+extern "C" {
+
+const char* fdcap_version(void) { return "fdcap-hip 0.1 (gfx950)"; }
+
+int fdcap_ctx_create(const fdcap_model_desc* md, fdcap_ctx** out) {
+    if (!md || !out || md->num_verts <= 0 || md->num_shape < NBETA) return FDCAP_E_ARG;
+    if (!md->v_template || !md->shapedirs || !md->posedirs || !md->J_regressor || !md->parents ||
+        !md->lbs_weights || !md->hands_componentsl || !md->hands_componentsr || !md->hands_meanl ||
+        !md->hands_meanr || !md->vp_fc1_w || !md->vp_fc1_b || !md->vp_fc2_w || !md->vp_fc2_b || !md->vp_out_w ||
+        !md->vp_out_b)
+        return FDCAP_E_ARG;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) return FDCAP_E_NODEVICE;
+    fdcap_ctx* c = new fdcap_ctx();
+    const int V = c->V = md->num_verts;
+    c->h_vt.assign(md->v_template, md->v_template + (size_t)V * 3);
+    c->h_S10.resize((size_t)V * 30);
+    for (size_t i = 0; i < (size_t)V * 3; ++i)
+        for (int l = 0; l < NBETA; ++l) c->h_S10[i * NBETA + l] = md->shapedirs[i * md->num_shape + l];
+    c->h_posedirs.assign(md->posedirs, md->posedirs + (size_t)NPF * 3 * V);
+    c->h_lbs.assign(md->lbs_weights, md->lbs_weights + (size_t)V * NJ);
+    HostPoseSetup hs;
+    if (!host_pose_setup(V, c->h_vt.data(), c->h_S10.data(), md->J_regressor, md->parents, &hs)) { delete c; return FDCAP_E_ARG; }
+    std::vector<float>&Jt = hs.Jt, &Jd = hs.Jd;
+    std::vector<int>&parents = hs.parents, &order = hs.order, &level_start = hs.level_start,
+                    &child_start = hs.child_start, &child_list = hs.child_list;
+    c->nlevels = hs.nlevels;
+    std::vector<float> hc(2 * 12 * 45), hm(90);
+    memcpy(hc.data(), md->hands_componentsl, 12 * 45 * sizeof(float));
+    memcpy(hc.data() + 12 * 45, md->hands_componentsr, 12 * 45 * sizeof(float));
+    memcpy(hm.data(), md->hands_meanl, 45 * sizeof(float));
+    memcpy(hm.data() + 45, md->hands_meanr, 45 * sizeof(float));
+    int err = 0;
+#define UP(buf, ptr, cnt) if (!err) { hipError_t e_ = (buf).upload(ptr, cnt); if (e_ != hipSuccess) err = (int)e_; }
+    UP(c->Jt, Jt.data(), Jt.size()) UP(c->Jd, Jd.data(), Jd.size())
+    UP(c->parents, parents.data(), parents.size()) UP(c->order, order.data(), order.size())
+    UP(c->level_start, level_start.data(), level_start.size())
+    UP(c->child_start, child_start.data(), child_start.size()) UP(c->child_list, child_list.data(), child_list.size())
+    UP(c->hand_comp, hc.data(), hc.size()) UP(c->hand_mean, hm.data(), hm.size())
+    UP(c->W1, md->vp_fc1_w, 512 * 32) UP(c->b1, md->vp_fc1_b, 512)
+    UP(c->W2, md->vp_fc2_w, 512 * 512) UP(c->b2, md->vp_fc2_b, 512)
+    UP(c->W3, md->vp_out_w, ODIM * 512) UP(c->b3, md->vp_out_b, ODIM)
+#undef UP
+    if (err) { fdcap_ctx_destroy(c); return err; }
+    *out = c;
+    return FDCAP_OK;
+}
+
+void fdcap_ctx_destroy(fdcap_ctx* c) {
+    if (!c) return;
+    fdcap_opt_destroy(c);
+    c->Jt.release(); c->Jd.release(); c->hand_comp.release(); c->hand_mean.release();
+    c->parents.release(); c->order.release(); c->level_start.release(); c->child_start.release(); c->child_list.release();
+    c->W1.release(); c->b1.release(); c->W2.release(); c->b2.release(); c->W3.release(); c->b3.release();
+    c->full.release(); c->contact.release(); c->scene.release();
+    for (auto& b : c->ws_f) b.release();
+    for (auto& b : c->ws_i) b.release();
+    c->ws_p.release();
+    delete c;
+}
+
+int fdcap_set_scene(fdcap_ctx* c, const float* xyz, int64_t ns) {
+    if (!c || ns < 0 || (ns > 0 && !xyz) || ns > 0x7fffffff) return FDCAP_E_ARG;
+    std::vector<float4> packed((size_t)ns);
+    for (int64_t i = 0; i < ns; ++i) {
+        float x = xyz[3 * i], y = xyz[3 * i + 1], z = xyz[3 * i + 2];
+        packed[i] = make_float4(x, y, z, x * x + y * y + z * z);
+    }
+    HIP_TRY(c->scene.upload(packed.data(), packed.size()));
+    c->ns = ns;
+    return FDCAP_OK;
+}
+
+int fdcap_set_contact_ids(fdcap_ctx* c, const int64_t* vid, int32_t nc) {
+    if (!c || nc < 0 || (nc > 0 && !vid)) return FDCAP_E_ARG;
+    std::vector<int64_t> ids(vid, vid + nc);
+    for (int64_t v : ids) if (v < 0 || v >= c->V) return FDCAP_E_ARG;
+    int e = build_skin_set(c, ids, &c->contact);
+    if (e) return e;
+    c->nc = nc;
+    return FDCAP_OK;
+}
+
+// ---- Op 1 ----------------------------------------------------------------------------------
+int fdcap_chamfer_fwd(fdcap_ctx* c, const float* xyz1, const float* xyz2, int32_t B, int32_t n, int32_t m,
+                      int64_t stride2, float* dist1, int32_t* idx1, float* dist2, int32_t* idx2, void* stream) {
+    if (!c || !xyz1 || !xyz2 || !dist1 || !idx1 || B <= 0 || n <= 0 || m <= 0) return FDCAP_E_ARG;
+    if (dist2 && !idx2) return FDCAP_E_ARG;
+    hipStream_t st = (hipStream_t)stream;
+    const bool shared = (stride2 == 0);
+    size_t big = (size_t)std::max(n, m);
+    HIP_TRY(c->ws_p.ensure(shared ? (size_t)m + (dist2 ? big : 0) : big));
+    if (shared) {
+        hipLaunchKernelGGL(pack_points_kernel, dim3((m + 255) / 256), dim3(256), 0, st, xyz2, m, c->ws_p.p);
+        int nq = B * n;
+        int nsplit = nn_pick_nsplit(nq, m);
+        HIP_TRY(c->ws_f[0].ensure((size_t)nsplit * nq));
+        HIP_TRY(c->ws_i[0].ensure((size_t)nsplit * nq));
+        HIP_TRY(nn_search(xyz1, nq, c->ws_p.p, m, dist1, idx1, c->ws_f[0].p, c->ws_i[0].p, nsplit, st));
+    }
+    for (int b = 0; b < B && (!shared || dist2); ++b) {
+        const float* x1 = xyz1 + (size_t)b * n * 3;
+        const float* x2 = xyz2 + (size_t)b * stride2;
+        float4* pk = c->ws_p.p + (shared ? m : 0);
+        if (!shared) {
+            hipLaunchKernelGGL(pack_points_kernel, dim3((m + 255) / 256), dim3(256), 0, st, x2, m, pk);
+            int nsplit = nn_pick_nsplit(n, m);
+            HIP_TRY(c->ws_f[0].ensure((size_t)nsplit * n));
+            HIP_TRY(c->ws_i[0].ensure((size_t)nsplit * n));
+            HIP_TRY(nn_search(x1, n, pk, m, dist1 + (size_t)b * n, idx1 + (size_t)b * n, c->ws_f[0].p, c->ws_i[0].p, nsplit, st));
+        }
+        if (dist2) {
+            hipLaunchKernelGGL(pack_points_kernel, dim3((n + 255) / 256), dim3(256), 0, st, x1, n, pk);
+            int nsplit = nn_pick_nsplit(m, n);
+            HIP_TRY(c->ws_f[1].ensure((size_t)nsplit * m));
+            HIP_TRY(c->ws_i[1].ensure((size_t)nsplit * m));
+            HIP_TRY(nn_search(x2, m, pk, n, dist2 + (size_t)b * m, idx2 + (size_t)b * m, c->ws_f[1].p, c->ws_i[1].p, nsplit, st));
+        }
+    }
+    return (int)hipGetLastError();
+}
+
+int fdcap_chamfer_bwd(fdcap_ctx* c, const float* xyz1, const float* xyz2, int32_t B, int32_t n, int32_t m,
+                      int64_t stride2, const float* gdist1, const int32_t* idx1, float* gxyz1, void* stream) {
+    if (!c || !xyz1 || !xyz2 || !gdist1 || !idx1 || !gxyz1 || B <= 0 || n <= 0 || m <= 0) return FDCAP_E_ARG;
+    hipStream_t st = (hipStream_t)stream;
+    HIP_TRY(c->ws_p.ensure(m));
+    if (stride2 == 0) {
+        hipLaunchKernelGGL(pack_points_kernel, dim3((m + 255) / 256), dim3(256), 0, st, xyz2, m, c->ws_p.p);
+        int nq = B * n;
+        hipLaunchKernelGGL(nn_grad_kernel, dim3((nq + 255) / 256), dim3(256), 0, st, xyz1, c->ws_p.p, gdist1, idx1, nq, gxyz1);
+    } else {
+        for (int b = 0; b < B; ++b) {
+            hipLaunchKernelGGL(pack_points_kernel, dim3((m + 255) / 256), dim3(256), 0, st, xyz2 + (size_t)b * stride2, m, c->ws_p.p);
+            hipLaunchKernelGGL(nn_grad_kernel, dim3((n + 255) / 256), dim3(256), 0, st, xyz1 + (size_t)b * n * 3, c->ws_p.p,
+                               gdist1 + (size_t)b * n, idx1 + (size_t)b * n, n, gxyz1 + (size_t)b * n * 3);
+        }
+    }
+    return (int)hipGetLastError();
+}
+
+// ---- Op 3 ----------------------------------------------------------------------------------
+int fdcap_vposer_decode(fdcap_ctx* c, const float* z, int32_t ldz, int32_t B, float* rot, float* aa, void* stream) {
+    if (!c || !z || B <= 0 || ldz < 32 || (!rot && !aa)) return FDCAP_E_ARG;
+    hipStream_t st = (hipStream_t)stream;
+    HIP_TRY(c->ws_f[2].ensure((size_t)B * 512));
+    HIP_TRY(c->ws_f[3].ensure((size_t)B * 512));
+    HIP_TRY(c->ws_f[4].ensure((size_t)B * ODIM));
+    int e = vposer_forward(c, z, ldz, 0, B, c->ws_f[2].p, c->ws_f[3].p, c->ws_f[4].p, st);
+    if (e) return e;
+    int n = B * 21;
+    hipLaunchKernelGGL(sixd_to_rot_kernel, dim3((n + 255) / 256), dim3(256), 0, st, c->ws_f[4].p, n, rot, aa);
+    return (int)hipGetLastError();
+}
+
+// ---- parameter conversions -------------------------------------------------------------------
+int fdcap_params_75_to_78(const float* p75, int32_t B, float* x78, void* stream) {
+    if (!p75 || !x78 || B <= 0) return FDCAP_E_ARG;
+    hipLaunchKernelGGL(p75_to_78_kernel, dim3((B + 127) / 128), dim3(128), 0, (hipStream_t)stream, p75, B, x78);
+    return (int)hipGetLastError();
+}
+int fdcap_params_78_to_75(const float* x78, int32_t B, float* p75, void* stream) {
+    if (!p75 || !x78 || B <= 0) return FDCAP_E_ARG;
+    hipLaunchKernelGGL(p78_to_75_kernel, dim3((B + 127) / 128), dim3(128), 0, (hipStream_t)stream, x78, B, p75);
+    return (int)hipGetLastError();
+}
+
+// ---- Op 2 ----------------------------------------------------------------------------------
+int fdcap_body_forward(fdcap_ctx* c, const float* params, int32_t B, float* vertices, float* joints, void* stream) {
+    if (!c || !params || B <= 0 || (!vertices && !joints)) return FDCAP_E_ARG;
+    hipStream_t st = (hipStream_t)stream;
+    if (vertices && !c->full_ready) {
+        std::vector<int64_t> all(c->V);
+        for (int i = 0; i < c->V; ++i) all[i] = i;
+        int e = build_skin_set(c, all, &c->full);
+        if (e) return e;
+        c->full_ready = true;
+    }
+    const int V = c->V;
+    DevBuf<float>* w = c->ws_f;
+    HIP_TRY(w[2].ensure((size_t)B * 512)); HIP_TRY(w[3].ensure((size_t)B * 512)); HIP_TRY(w[4].ensure((size_t)B * ODIM));
+    HIP_TRY(w[5].ensure((size_t)B * XDIM)); HIP_TRY(w[6].ensure((size_t)B * NPF)); HIP_TRY(w[7].ensure((size_t)B * NJ * 12));
+    HIP_TRY(w[8].ensure((size_t)B * NJ * 12)); HIP_TRY(w[9].ensure((size_t)B * 16)); HIP_TRY(w[10].ensure(1));
+    float* X = w[5].p;
+    hipLaunchKernelGGL(p75_to_78_kernel, dim3((B + 127) / 128), dim3(128), 0, st, params, B, X);
+    int e = vposer_forward(c, X, XDIM, X_LATENT, B, w[2].p, w[3].p, w[4].p, st);
+    if (e) return e;
+    HIP_TRY(hipMemsetAsync(w[9].p, 0, (size_t)B * 16 * sizeof(float), st));
+    HIP_TRY(hipMemsetAsync(w[10].p, 0, sizeof(float), st));
+    hipLaunchKernelGGL(pose_fwd_kernel, dim3(B), dim3(64), 0, st, c->pose_model(), X, w[4].p, w[9].p, w[10].p, 0,
+                       (float*)nullptr, w[6].p, (float*)nullptr, w[7].p, w[8].p, (float*)nullptr, (float*)nullptr, (const float*)nullptr);
+    if (joints) hipLaunchKernelGGL(joints_out_kernel, dim3((B * NJ + 255) / 256), dim3(256), 0, st, w[7].p, X, XDIM, B, joints);
+    if (vertices) {
+        HIP_TRY(w[11].ensure((size_t)B * 3 * V));
+        HIP_TRY(gemm_f32(false, EPI_STORE, w[6].p, NPF, c->full.posedirs.p, 3 * V, w[11].p, 3 * V, B, 3 * V, NPF, nullptr, 0, st));
+        hipLaunchKernelGGL(skin_fwd_kernel, dim3((V + 255) / 256, B), dim3(256), 0, st, c->full.model(), V, X, XDIM, X_BETAS,
+                           X_TRANSL, w[11].p, w[8].p, (const float*)nullptr, (const float*)nullptr, 0, 0, vertices);
+    }
+    return (int)hipGetLastError();
+}
+
+int fdcap_smplx_forward(fdcap_ctx* c, const float* go, const float* bp, const float* betas, const float* lh, const float* rh,
+                        const float* transl, int32_t B, float* vertices, float* joints, void* stream) {
+    if (!c || !go || !bp || !betas || !lh || !rh || !transl || B <= 0 || (!vertices && !joints)) return FDCAP_E_ARG;
+    hipStream_t st = (hipStream_t)stream;
+    if (vertices && !c->full_ready) {
+        std::vector<int64_t> all(c->V);
+        for (int i = 0; i < c->V; ++i) all[i] = i;
+        int e = build_skin_set(c, all, &c->full);
+        if (e) return e;
+        c->full_ready = true;
+    }
+    const int V = c->V;
+    DevBuf<float>* w = c->ws_f;
+    HIP_TRY(w[4].ensure((size_t)B * 66));
+    HIP_TRY(w[5].ensure((size_t)B * XDIM)); HIP_TRY(w[6].ensure((size_t)B * NPF)); HIP_TRY(w[7].ensure((size_t)B * NJ * 12));
+    HIP_TRY(w[8].ensure((size_t)B * NJ * 12)); HIP_TRY(w[9].ensure((size_t)B * 16)); HIP_TRY(w[10].ensure(1));
+    float* X = w[5].p;
+    hipLaunchKernelGGL(assemble_rows_kernel, dim3((B + 127) / 128), dim3(128), 0, st, go, bp, betas, lh, rh, transl, B, X, w[4].p);
+    HIP_TRY(hipMemsetAsync(w[9].p, 0, (size_t)B * 16 * sizeof(float), st));
+    HIP_TRY(hipMemsetAsync(w[10].p, 0, sizeof(float), st));
+    hipLaunchKernelGGL(pose_fwd_kernel, dim3(B), dim3(64), 0, st, c->pose_model(), X, (const float*)nullptr, w[9].p, w[10].p, 0,
+                       (float*)nullptr, w[6].p, (float*)nullptr, w[7].p, w[8].p, (float*)nullptr, (float*)nullptr, w[4].p);
+    if (joints) hipLaunchKernelGGL(joints_out_kernel, dim3((B * NJ + 255) / 256), dim3(256), 0, st, w[7].p, X, XDIM, B, joints);
+    if (vertices) {
+        HIP_TRY(w[11].ensure((size_t)B * 3 * V));
+        HIP_TRY(gemm_f32(false, EPI_STORE, w[6].p, NPF, c->full.posedirs.p, 3 * V, w[11].p, 3 * V, B, 3 * V, NPF, nullptr, 0, st));
+        hipLaunchKernelGGL(skin_fwd_kernel, dim3((V + 255) / 256, B), dim3(256), 0, st, c->full.model(), V, X, XDIM, X_BETAS,
+                           X_TRANSL, w[11].p, w[8].p, (const float*)nullptr, (const float*)nullptr, 0, 0, vertices);
+    }
+    return (int)hipGetLastError();
+}
+
+// ---- optimiser -------------------------------------------------------------------------------
+void fdcap_opt_destroy(fdcap_ctx* c) {
+    if (!c || !c->opt) return;
+    OptState* o = c->opt;
+    DevBuf<float>* fb[] = {&o->X0, &o->mask, &o->mX, &o->vX, &o->mCAM, &o->vCAM, &o->mS, &o->vS,
+                           &o->H1, &o->H2, &o->O, &o->dO, &o->dH2, &o->dH1, &o->Rm, &o->PF, &o->Jrest, &o->G, &o->A, &o->M,
+                           &o->Jw, &o->Voff, &o->Vw, &o->dist, &o->pd, &o->dVoff, &o->dA, &o->dbeta_v, &o->dtransl_v, &o->dMv,
+                           &o->dsv, &o->dPF, &o->dJw, &o->dX, &o->dCAM, &o->dscale_row};
+    for (auto* b : fb) b->release();
+    o->idx.release(); o->pi.release();
+    delete o;
+    c->opt = nullptr;
+}
+
+int fdcap_opt_create(fdcap_ctx* c, const fdcap_opt_config* cfg, float* rows_x, float* rows_cam, float* scale_d,
+                     float* dscale_d, double* losses_d) {
+    if (!c || !cfg || !rows_x || !rows_cam || !scale_d || !dscale_d || !losses_d || cfg->n_local <= 0 || cfg->n_total < cfg->n_local || cfg->frame0 < 0 ||
+        cfg->frame0 + cfg->n_local > cfg->n_total)
+        return FDCAP_E_ARG;
+    fdcap_opt_destroy(c);
+    OptState* o = new OptState();
+    c->opt = o;
+    o->cfg = *cfg;
+    const int R = o->R = cfg->n_local + 4;
+    o->contact_on = c->ns > 0 && c->nc > 0 && cfg->weight_contact != 0.f;
+    const size_t nq = (size_t)R * std::max(c->nc, 1);
+    o->nsplit = o->contact_on ? nn_pick_nsplit((int)((size_t)cfg->n_local * c->nc), (int)c->ns) : 1;
+    int err = 0;
+#define AL(buf, cnt) if (!err) { hipError_t e_ = (buf).ensure(cnt); if (e_ != hipSuccess) err = (int)e_; else e_ = hipMemset((buf).p, 0, (size_t)(cnt) * sizeof(*(buf).p)); }
+    o->X.p = rows_x; o->CAM.p = rows_cam; o->scale.p = scale_d; o->dscale.p = dscale_d; o->losses.p = losses_d;
+    AL(o->X0, (size_t)R * XDIM) AL(o->mask, R)
+    AL(o->mX, (size_t)R * XDIM) AL(o->vX, (size_t)R * XDIM) AL(o->mCAM, (size_t)R * 16) AL(o->vCAM, (size_t)R * 16)
+    AL(o->mS, 1) AL(o->vS, 1)
+    AL(o->H1, (size_t)R * 512) AL(o->H2, (size_t)R * 512) AL(o->O, (size_t)R * ODIM) AL(o->dO, (size_t)R * ODIM)
+    AL(o->dH2, (size_t)R * 512) AL(o->dH1, (size_t)R * 512)
+    AL(o->Rm, (size_t)R * NJ * 9) AL(o->PF, (size_t)R * NPF) AL(o->Jrest, (size_t)R * NJ * 3) AL(o->G, (size_t)R * NJ * 12)
+    AL(o->A, (size_t)R * NJ * 12) AL(o->M, (size_t)R * 12) AL(o->Jw, (size_t)R * NJW * 3)
+    AL(o->dA, (size_t)R * NJ * 12) AL(o->dbeta_v, (size_t)R * NBETA) AL(o->dtransl_v, (size_t)R * 3) AL(o->dMv, (size_t)R * 12)
+    AL(o->dsv, R) AL(o->dPF, (size_t)R * NPF) AL(o->dJw, (size_t)R * NJW * 3) AL(o->dX, (size_t)R * XDIM)
+    AL(o->dCAM, (size_t)R * 16) AL(o->dscale_row, R)
+    if (o->contact_on) {
+        AL(o->Voff, nq * 3) AL(o->Vw, nq * 3) AL(o->dist, nq) AL(o->idx, nq) AL(o->dVoff, nq * 3)
+        AL(o->pd, (size_t)o->nsplit * nq) AL(o->pi, (size_t)o->nsplit * nq)
+    }
+#undef AL
+    if (!err) {
+        float s = cfg->scale_init;
+        hipError_t e_ = hipMemcpy(o->scale.p, &s, sizeof(float), hipMemcpyHostToDevice);
+        if (e_ != hipSuccess) err = (int)e_;
+    }
+    if (err) { fdcap_opt_destroy(c); return err; }
+    return FDCAP_OK;
+}
+
+int fdcap_opt_set_inputs(fdcap_ctx* c, const float* data78, const float* init78, const float* mask, const float* cam,
+                         void* stream) {
+    if (!c || !c->opt || !data78 || !init78 || !mask || !cam) return FDCAP_E_ARG;
+    OptState* o = c->opt;
+    hipStream_t st = (hipStream_t)stream;
+    const size_t n = o->cfg.n_local;
+    HIP_TRY(hipMemcpyAsync(o->X0.p + 2 * XDIM, data78, n * XDIM * sizeof(float), hipMemcpyDeviceToDevice, st));
+    HIP_TRY(hipMemcpyAsync(o->X.p + 2 * XDIM, init78, n * XDIM * sizeof(float), hipMemcpyDeviceToDevice, st));
+    HIP_TRY(hipMemcpyAsync(o->mask.p + 2, mask, n * sizeof(float), hipMemcpyDeviceToDevice, st));
+    HIP_TRY(hipMemcpyAsync(o->CAM.p + 2 * 16, cam, n * 16 * sizeof(float), hipMemcpyDeviceToDevice, st));
+    return FDCAP_OK;
+}
+
+static int opt_contact_forward(fdcap_ctx* c, hipStream_t st) {
+    OptState* o = c->opt;
+    const int nl = o->cfg.n_local, nc = c->nc;
+    const size_t off = (size_t)2 * nc * 3;
+    HIP_TRY(gemm_f32(false, EPI_STORE, o->PF.p + 2 * NPF, NPF, c->contact.posedirs.p, 3 * nc, o->Voff.p + off, 3 * nc, nl,
+                     3 * nc, NPF, nullptr, 0, st));
+    hipLaunchKernelGGL(skin_fwd_kernel, dim3((nc + 255) / 256, nl), dim3(256), 0, st, c->contact.model(), nc, o->X.p, XDIM,
+                       X_BETAS, X_TRANSL, o->Voff.p, o->A.p, o->M.p, o->scale.p, 2, 1, o->Vw.p);
+    const int nq = nl * nc;
+    HIP_TRY(nn_search(o->Vw.p + off, nq, c->scene.p, (int)c->ns, o->dist.p + 2 * nc, o->idx.p + 2 * nc, o->pd.p, o->pi.p,
+                      o->nsplit, st));
+    return 0;
+}
+
+int fdcap_opt_backward(fdcap_ctx* c, int32_t ii, int32_t P, int32_t log_terms, void* stream) {
+    if (!c || !c->opt) return FDCAP_E_STATE;
+    OptState* o = c->opt;
+    hipStream_t st = (hipStream_t)stream;
+    const fdcap_opt_config& cf = o->cfg;
+    const int R = o->R, nl = cf.n_local, nc = c->nc, N = cf.n_total;
+    const bool phase2 = ii >= P;
+    PoseModel pm = c->pose_model();
+    HIP_TRY(hipMemsetAsync(o->losses.p, 0, FDCAP_NUM_LOSSES * sizeof(double), st));
+    int e = vposer_forward(c, o->X.p, XDIM, X_LATENT, R, o->H1.p, o->H2.p, o->O.p, st);
+    if (e) return e;
+    hipLaunchKernelGGL(pose_fwd_kernel, dim3(R), dim3(64), 0, st, pm, o->X.p, o->O.p, o->CAM.p, o->scale.p, 0, o->Rm.p,
+                       o->PF.p, o->Jrest.p, o->G.p, o->A.p, o->M.p, o->Jw.p, (const float*)nullptr);
+    const bool contact_grad = o->contact_on && !phase2;
+    const bool contact_fwd = o->contact_on && (!phase2 || log_terms);
+    if (contact_fwd) { e = opt_contact_forward(c, st); if (e) return e; }
+    const float w_rec = cf.weight_loss_rec / ((float)N * XDIM);
+    const float w_sm = (N >= 3) ? (phase2 ? cf.phase2_smooth : cf.phase1_smooth) / ((float)(N - 2) * XDIM) : 0.f;
+    const float w_ws = (phase2 && N >= 2) ? cf.phase2_world / ((float)(N - 1) * NJW * 3) : 0.f;
+    hipLaunchKernelGGL(param_loss_kernel, dim3(nl), dim3(128), 0, st, o->X.p, o->X0.p, o->mask.p, o->Jw.p, 2, cf.frame0, N,
+                       w_rec, w_sm, w_ws, phase2 ? 1 : 0, o->dX.p, o->dJw.p, o->losses.p);
+    if (contact_grad) {
+        const float coef = cf.phase1_contact * cf.weight_contact / ((float)N * nc);
+        hipLaunchKernelGGL(skin_bwd_kernel, dim3(nl), dim3(256), 0, st, c->contact.model(), nc, o->X.p, o->Voff.p, o->A.p,
+                           o->M.p, o->scale.p, 2, o->Vw.p, o->dist.p, o->idx.p, c->scene.p, coef, o->dVoff.p, o->dA.p,
+                           o->dbeta_v.p, o->dtransl_v.p, o->dMv.p, o->dsv.p, o->losses.p + 3);
+        HIP_TRY(gemm_f32(true, EPI_STORE, o->dVoff.p + (size_t)2 * nc * 3, 3 * nc, c->contact.posedirs.p, 3 * nc,
+                         o->dPF.p + 2 * NPF, NPF, nl, NPF, 3 * nc, nullptr, 0, st));
+    } else if (contact_fwd) {
+        hipLaunchKernelGGL(contact_loss_kernel, dim3(256), dim3(256), 0, st, o->dist.p + 2 * nc, (size_t)nl * nc,
+                           o->losses.p + 3);
+    }
+    hipLaunchKernelGGL(pose_bwd_kernel, dim3(nl), dim3(64), 0, st, pm, o->X.p, o->O.p, o->CAM.p, o->scale.p, 2, o->Rm.p,
+                       o->Jrest.p, o->G.p, contact_grad ? o->dA.p : nullptr, contact_grad ? o->dPF.p : nullptr,
+                       phase2 ? o->dJw.p : nullptr, contact_grad ? o->dMv.p : nullptr, contact_grad ? o->dsv.p : nullptr,
+                       contact_grad ? o->dbeta_v.p : nullptr, contact_grad ? o->dtransl_v.p : nullptr, o->dX.p, o->dO.p,
+                       o->dCAM.p, o->dscale_row.p);
+    // VPoser data-gradient: dO -> dH2 -> dH1 -> d latent (accumulated into dX[:, 19:51])
+    HIP_TRY(gemm_f32(false, EPI_MASK_LRELU, o->dO.p + 2 * ODIM, ODIM, c->W3.p, 512, o->dH2.p + 2 * 512, 512, nl, 512, ODIM,
+                     o->H2.p + 2 * 512, 512, st));
+    HIP_TRY(gemm_f32(false, EPI_MASK_LRELU, o->dH2.p + 2 * 512, 512, c->W2.p, 512, o->dH1.p + 2 * 512, 512, nl, 512, 512,
+                     o->H1.p + 2 * 512, 512, st));
+    HIP_TRY(gemm_f32(false, EPI_ACCUM, o->dH1.p + 2 * 512, 512, c->W1.p, 32, o->dX.p + 2 * XDIM + X_LATENT, XDIM, nl, 32, 512,
+                     nullptr, 0, st));
+    hipLaunchKernelGGL(reduce_rows_kernel, dim3(1), dim3(256), 0, st, o->dscale_row.p, 2, nl, o->dscale.p);
+    return (int)hipGetLastError();
+}
+
+int fdcap_opt_step(fdcap_ctx* c, int32_t ii, int32_t P, void* stream) {
+    if (!c || !c->opt) return FDCAP_E_STATE;
+    OptState* o = c->opt;
+    hipStream_t st = (hipStream_t)stream;
+    const fdcap_opt_config& cf = o->cfg;
+    const int nl = cf.n_local;
+    const size_t nx = (size_t)nl * XDIM, ncam = (size_t)nl * 16;
+    // body_rotation_rec: every iteration, its own step counter = ii + 1
+    hipLaunchKernelGGL(adam_kernel, dim3((nx + 255) / 256), dim3(256), 0, st, o->X.p + 2 * XDIM, o->mX.p + 2 * XDIM,
+                       o->vX.p + 2 * XDIM, o->dX.p + 2 * XDIM, nx, adam_scalars(cf.lr, ii + 1), 0);
+    // scale: receives a gradient while ii < P (and only if the contact term exists)
+    if (o->contact_on && (ii < P || cf.legacy_zero_grad))
+        hipLaunchKernelGGL(adam_kernel, dim3(1), dim3(64), 0, st, o->scale.p, o->mS.p, o->vS.p, o->dscale.p, (size_t)1,
+                           adam_scalars(cf.lr, ii + 1), ii < P ? 0 : 1);
+    // camera_ext: first gradient at ii = P + 1 (flag flips after the forward of ii = P)
+    if (ii >= P + 1)
+        hipLaunchKernelGGL(adam_kernel, dim3((ncam + 255) / 256), dim3(256), 0, st, o->CAM.p + 2 * 16, o->mCAM.p + 2 * 16,
+                           o->vCAM.p + 2 * 16, o->dCAM.p + 2 * 16, ncam, adam_scalars(cf.lr, ii - P), 0);
+    return (int)hipGetLastError();
+}
+
+int fdcap_opt_get_results(fdcap_ctx* c, float* body75, float* scale, float* cam, void* stream) {
+    if (!c || !c->opt) return FDCAP_E_STATE;
+    OptState* o = c->opt;
+    hipStream_t st = (hipStream_t)stream;
+    const int nl = o->cfg.n_local;
+    if (body75) hipLaunchKernelGGL(p78_to_75_kernel, dim3((nl + 127) / 128), dim3(128), 0, st, o->X.p + 2 * XDIM, nl, body75);
+    if (scale) HIP_TRY(hipMemcpyAsync(scale, o->scale.p, sizeof(float), hipMemcpyDeviceToDevice, st));
+    if (cam) HIP_TRY(hipMemcpyAsync(cam, o->CAM.p + 2 * 16, (size_t)nl * 16 * sizeof(float), hipMemcpyDeviceToDevice, st));
+    return (int)hipGetLastError();
+}
+
+int fdcap_opt_forward_world(fdcap_ctx* c, float* verts, float* joints, void* stream) {
+    if (!c || !c->opt) return FDCAP_E_STATE;
+    OptState* o = c->opt;
+    hipStream_t st = (hipStream_t)stream;
+    const int R = o->R, nl = o->cfg.n_local, nc = c->nc;
+    int e = vposer_forward(c, o->X.p, XDIM, X_LATENT, R, o->H1.p, o->H2.p, o->O.p, st);
+    if (e) return e;
+    hipLaunchKernelGGL(pose_fwd_kernel, dim3(R), dim3(64), 0, st, c->pose_model(), o->X.p, o->O.p, o->CAM.p, o->scale.p, 0,
+                       o->Rm.p, o->PF.p, o->Jrest.p, o->G.p, o->A.p, o->M.p, o->Jw.p, (const float*)nullptr);
+    if (verts) {
+        if (!o->contact_on) return FDCAP_E_STATE;
+        e = opt_contact_forward(c, st);
+        if (e) return e;
+        HIP_TRY(hipMemcpyAsync(verts, o->Vw.p + (size_t)2 * nc * 3, (size_t)nl * nc * 3 * sizeof(float), hipMemcpyDeviceToDevice, st));
+    }
+    if (joints)
+        HIP_TRY(hipMemcpyAsync(joints, o->Jw.p + 2 * NJW * 3, (size_t)nl * NJW * 3 * sizeof(float), hipMemcpyDeviceToDevice, st));
+    return (int)hipGetLastError();
+}
+
+int fdcap_opt_get_grads(fdcap_ctx* c, float* dx, float* dcam, void* stream) {
+    if (!c || !c->opt) return FDCAP_E_STATE;
+    OptState* o = c->opt;
+    hipStream_t st = (hipStream_t)stream;
+    const int nl = o->cfg.n_local;
+    if (dx) HIP_TRY(hipMemcpyAsync(dx, o->dX.p + 2 * XDIM, (size_t)nl * XDIM * sizeof(float), hipMemcpyDeviceToDevice, st));
+    if (dcam) HIP_TRY(hipMemcpyAsync(dcam, o->dCAM.p + 2 * 16, (size_t)nl * 16 * sizeof(float), hipMemcpyDeviceToDevice, st));
+    return FDCAP_OK;
+}
+
+int fdcap_opt_time_chamfer(fdcap_ctx* c, int32_t iters, float* ms, void* stream) {
+    if (!c || !c->opt || !ms || iters <= 0) return FDCAP_E_ARG;
+    OptState* o = c->opt;
+    if (!o->contact_on) return FDCAP_E_STATE;
+    hipStream_t st = (hipStream_t)stream;
+    const int nl = o->cfg.n_local, nc = c->nc;
+    const size_t off = (size_t)2 * nc * 3;
+    hipEvent_t e0, e1;
+    HIP_TRY(hipEventCreate(&e0));
+    HIP_TRY(hipEventCreate(&e1));
+    HIP_TRY(nn_search(o->Vw.p + off, nl * nc, c->scene.p, (int)c->ns, o->dist.p + 2 * nc, o->idx.p + 2 * nc, o->pd.p, o->pi.p,
+                      o->nsplit, st));
+    HIP_TRY(hipEventRecord(e0, st));
+    for (int i = 0; i < iters; ++i)
+        HIP_TRY(nn_search(o->Vw.p + off, nl * nc, c->scene.p, (int)c->ns, o->dist.p + 2 * nc, o->idx.p + 2 * nc, o->pd.p,
+                          o->pi.p, o->nsplit, st));
+    HIP_TRY(hipEventRecord(e1, st));
+    HIP_TRY(hipEventSynchronize(e1));
+    float t = 0.f;
+    HIP_TRY(hipEventElapsedTime(&t, e0, e1));
+    *ms = t / iters;
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+    return FDCAP_OK;
+}
+
+}  // extern "C"

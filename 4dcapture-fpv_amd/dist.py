@@ -1,0 +1,82 @@
+"""Frame sharding across the GPUs of one node and the per-iteration exchange step.
+
+The reference has no distributed code; this is the MI355X design of §8e: rank r
+owns a contiguous block of frames, every per-frame kernel is independent, and the only
+cross-frame coupling is the 3-frame stencil of loss_smoothing (global_optimization.py:266-267)
+and the 2-frame stencil of loss_world_smoothing (:304).  So per iteration each rank needs
+  * its neighbours' 2 boundary rows of body_rotation_rec [78] and camera_ext [16]  (halo), and
+  * the global sum of d loss / d scale (one float; scale is a shared parameter, :179).
+Both are latency-bound (752 B per neighbour), sent with torch.distributed point-to-point ops --
+backend "nccl" is RCCL over xGMI on ROCm; the CPU tests use "gloo".  No reverse exchange is
+needed: every rank evaluates all loss terms that touch its own frames.
+"""
+from __future__ import annotations
+
+HALO = 2
+
+
+class FrameShard:
+    """Contiguous block partition of `n_total` frames over the ranks of `group`."""
+
+    def __init__(self, n_total: int, group=None, rank: int | None = None, world: int | None = None):
+        self.n_total = int(n_total)
+        self.group = group
+        if rank is None or world is None:
+            if group is None:
+                rank, world = 0, 1
+            else:
+                import torch.distributed as dist
+                rank, world = dist.get_rank(group), dist.get_world_size(group)
+        self.rank, self.world = int(rank), int(world)
+        base, rem = divmod(self.n_total, self.world)
+        if base < HALO and self.world > 1:
+            raise ValueError(f"{n_total} frames over {world} ranks leaves fewer than {HALO} frames per rank")
+        self.n_local = base + (1 if self.rank < rem else 0)
+        self.frame0 = self.rank * base + min(self.rank, rem)
+
+    def bounds(self, rank: int):
+        base, rem = divmod(self.n_total, self.world)
+        lo = rank * base + min(rank, rem)
+        return lo, lo + base + (1 if rank < rem else 0)
+
+    def global_rank(self, r: int) -> int:
+        if self.group is None:
+            return r
+        import torch.distributed as dist
+        return dist.get_global_rank(self.group, r)
+
+
+def exchange_halos(shard: FrameShard, rows_x, rows_cam) -> None:
+    """Fill the 2 halo rows each side of `rows_x` [n_local+4,78] / `rows_cam` [n_local+4,16]
+    from the neighbouring ranks' boundary rows (chain topology; clip ends keep zeros)."""
+    if shard.world == 1:
+        return
+    import torch.distributed as dist
+    n = shard.n_local
+    ops = []
+    keep = []
+    for t in (rows_x, rows_cam):
+        if shard.rank > 0:
+            left = shard.global_rank(shard.rank - 1)
+            send = t[HALO:2 * HALO].contiguous()            # my first two owned rows
+            keep.append(send)
+            ops.append(dist.P2POp(dist.isend, send, left, group=shard.group))
+            ops.append(dist.P2POp(dist.irecv, t[0:HALO], left, group=shard.group))
+        if shard.rank < shard.world - 1:
+            right = shard.global_rank(shard.rank + 1)
+            send = t[n:n + HALO].contiguous()               # my last two owned rows
+            keep.append(send)
+            ops.append(dist.P2POp(dist.isend, send, right, group=shard.group))
+            ops.append(dist.P2POp(dist.irecv, t[n + HALO:n + 2 * HALO], right, group=shard.group))
+    for req in dist.batch_isend_irecv(ops):
+        req.wait()
+
+
+def allreduce_scalars(shard: FrameShard, dscale, losses=None) -> None:
+    """Sum the per-rank d loss / d scale (and, when logging, the loss partial sums)."""
+    if shard.world == 1:
+        return
+    import torch.distributed as dist
+    dist.all_reduce(dscale, op=dist.ReduceOp.SUM, group=shard.group)
+    if losses is not None:
+        dist.all_reduce(losses, op=dist.ReduceOp.SUM, group=shard.group)

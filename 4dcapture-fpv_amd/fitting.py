@@ -1,0 +1,244 @@
+"""FittingOP mirror: the reference's optimiser driver (global_optimization.py:141-188, :450-489,
+:491-635, :637-653) over the fused HIP iteration (include/fdcap.h fdcap_opt_*).
+
+Same constructor dictionaries, same `fitting(body_gpu, mode) -> (body_rec, scale, camera_ext)`
+and `save_result(...)`.  Differences that are documented deviations, not behaviour changes:
+clip length is free (the reference hard-codes 300), an empty outlier set is legal, the scene is
+stored once, and log-only terms are evaluated only when logging is requested."""
+from __future__ import annotations
+
+import math
+from dataclasses import dataclass
+
+import numpy as np
+
+from . import capi, io
+from .dist import FrameShard, exchange_halos, allreduce_scalars
+
+# loss-total constants buried in fitting() (global_optimization.py:564, :570, :582)
+PHASE_SPLIT = 0.8
+PHASE1_CONTACT = 0.1
+PHASE1_SMOOTH = 1.0
+PHASE2_WORLD = 1.0
+PHASE2_SMOOTH = 0.5
+SCALE_INIT = 1.8
+OUTLIER_FACTOR = 1.8
+
+DEFAULT_FITTINGCONFIG = {
+    "scene_verts_path": None, "camera_path": None, "human_model_path": "./models",
+    "vposer_ckpt_path": "./vposer/", "init_lr_h": 0.005, "num_iter": 500, "batch_size": 1,
+    "device": "cuda", "contact_id_folder": "./body_segments", "contact_part": ["L_Leg", "R_Leg"],
+    "verbose": False,
+}
+DEFAULT_LOSSCONFIG = {"weight_loss_rec": 1, "weight_loss_vposer": 0.001, "weight_contact": 0.1,
+                      "weight_collision": 0.5}
+
+
+def first_phase2_iter(num_iter: int) -> int:
+    """Smallest ii with not (ii < num_iter*0.8) (:564)."""
+    return int(math.ceil(num_iter * PHASE_SPLIT - 1e-12))
+
+
+def find_outliers(x78: np.ndarray):
+    """init() :459-487.  x78 [N,78] fp32 (6D form).  Returns (idx1 outlier rows, pos nearest
+    inlier for each, ties -> lower index).  Generalised from the hard-coded 300 to N."""
+    x78 = np.asarray(x78, dtype=np.float32)
+    n = x78.shape[0]
+    z = x78[:, 19:51]
+    stats = np.sum(z * z, axis=1, dtype=np.float32)
+    avg = np.float32(np.sum(stats, dtype=np.float32) / np.float32(n))
+    idx1 = np.where(stats > avg * np.float32(OUTLIER_FACTOR))[0]
+    temp = np.ones(n)
+    temp[idx1] = 0.0
+    index_one = np.where(temp == 1)[0]
+    index_zero = np.where(temp == 0)[0]
+    if index_zero.size == 0 or index_one.size == 0:
+        return idx1, np.zeros(0, dtype=np.int64)
+    diff = np.abs(index_zero[:, None] - index_one[None, :])
+    pos = index_one[np.argmin(diff, axis=1)]
+    return idx1, pos
+
+
+@dataclass
+class FitLog:
+    """Per-logged-iteration losses in the reference's print order (:573-575, :587-589)."""
+    iters: list
+    l_rec: list
+    l_vposer: list
+    loss_smoothing: list
+    loss_contact: list
+    loss_world_smoothing: list
+    total: list
+
+
+class FittingOP:
+    def __init__(self, fittingconfig, lossconfig, num_body, body_model=None, vposer=None, scene_verts=None,
+                 contact_ids=None, camera_ext=None, group=None, legacy_zero_grad=False):
+        """`body_model` / `vposer`: objects with the SMPL-X npz / VPoser state-dict arrays
+        (synth.BodyModelData / synth.VPoserData or assets.load_*).  `scene_verts`, `contact_ids`,
+        `camera_ext` override the paths in `fittingconfig` when given (synthetic runs).
+        `group`: torch.distributed process group for frame sharding (None = single GPU);
+        `num_body` is the clip length N (the reference's batch_size = num_body, :152)."""
+        import torch
+        cfg = dict(DEFAULT_FITTINGCONFIG)
+        cfg.update(fittingconfig or {})
+        lcfg = dict(DEFAULT_LOSSCONFIG)
+        lcfg.update(lossconfig or {})
+        for k, v in cfg.items():
+            setattr(self, k, v)
+        for k, v in lcfg.items():
+            setattr(self, k, v)
+        self.batch_size = self.num_body = int(num_body)
+        self.legacy_zero_grad = bool(legacy_zero_grad)
+        if not torch.cuda.is_available():
+            raise capi.FdcapError("no HIP device: the fdcap_amd optimiser only runs on the GPU")
+        self.device = torch.device("cuda", torch.cuda.current_device())
+        if body_model is None or vposer is None:
+            from . import assets
+            body_model = body_model or assets.load_smplx_npz(self.human_model_path)
+            vposer = vposer or assets.load_vposer_snapshot(self.vposer_ckpt_path)
+        self.ctx = capi.Context(body_model, vposer)
+        if scene_verts is None and self.scene_verts_path:
+            scene_verts = io.read_scene_points(self.scene_verts_path)
+        if scene_verts is None:
+            scene_verts = np.zeros((0, 3), np.float32)
+        self.ctx.set_scene(scene_verts)
+        if contact_ids is None:
+            contact_ids = io.read_contact_ids(self.contact_id_folder, self.contact_part)
+        self.vid = np.asarray(contact_ids, dtype=np.int64)
+        self.ctx.set_contact_ids(self.vid)
+        if camera_ext is None and self.camera_path:
+            camera_ext = io.read_camerapose(self.camera_path)
+        self._camera_ext_init = None if camera_ext is None else np.asarray(camera_ext, np.float32).reshape(-1, 4, 4)
+        self.shard = FrameShard(self.num_body, group)
+        self.group = group
+        self.scale = None
+        self.camera_ext = None
+        self.body_rotation_rec = None
+        self.log = None
+        self.idx1 = None
+
+    # ---- :450-489 -------------------------------------------------------------------------
+    def init(self, body_data_rotation):
+        """body_data_rotation: [N,78] device tensor (whole clip).  Host-side index logic on a
+        copy; returns idx1 like the reference and stages the optimiser's inputs."""
+        import torch
+        x78 = body_data_rotation.detach().cpu().numpy()
+        idx1, pos = find_outliers(x78)
+        init78 = x78.copy()
+        if idx1.size and pos.size:
+            init78[idx1, :] = x78[pos, :]
+        mask = np.ones(self.num_body, np.float32)
+        mask[idx1] = 0.0
+        if self._camera_ext_init is None or self._camera_ext_init.shape[0] != self.num_body:
+            raise capi.FdcapError("camera_ext / camerapose.txt must have one pose per frame (:455)")
+        sh = self.shard
+        lo, hi = sh.frame0, sh.frame0 + sh.n_local
+        oc = capi.OptConfig(self.num_body, sh.n_local, sh.frame0, float(self.init_lr_h), float(self.weight_loss_rec),
+                            float(self.weight_loss_vposer), float(self.weight_contact), PHASE1_CONTACT, PHASE1_SMOOTH,
+                            PHASE2_WORLD, PHASE2_SMOOTH, SCALE_INIT, int(self.legacy_zero_grad))
+        lib = self.ctx.lib
+        import ctypes
+        dev = self.device
+        R = sh.n_local + 4
+        # optimiser state is owned here (torch tensors) and registered with the library, so the
+        # same storage is what RCCL exchanges / reduces
+        self._rows_x = torch.zeros(R, capi.XDIM, device=dev)
+        self._rows_cam = torch.zeros(R, 16, device=dev)
+        self._scale = torch.zeros(1, device=dev)
+        self._dscale = torch.zeros(1, device=dev)
+        self._losses = torch.zeros(capi.NUM_LOSSES, device=dev, dtype=torch.float64)
+        torch.cuda.current_stream().synchronize()
+        capi.check(lib.fdcap_opt_create(self.ctx.handle, ctypes.byref(oc), capi.dptr(self._rows_x),
+                                        capi.dptr(self._rows_cam), capi.dptr(self._scale), capi.dptr(self._dscale),
+                                        capi.dptr(self._losses)), "fdcap_opt_create")
+        t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+        d_data, d_init = body_data_rotation[lo:hi].contiguous(), t(init78[lo:hi])
+        d_mask, d_cam = t(mask[lo:hi]), t(self._camera_ext_init[lo:hi].reshape(-1, 16))
+        st = capi.current_stream()
+        capi.check(lib.fdcap_opt_set_inputs(self.ctx.handle, capi.dptr(d_data), capi.dptr(d_init), capi.dptr(d_mask),
+                                            capi.dptr(d_cam), st), "fdcap_opt_set_inputs")
+        torch.cuda.current_stream().synchronize()
+        exchange_halos(self.shard, self._rows_x, self._rows_cam)
+        self.idx1 = idx1
+        return idx1
+
+    # ---- :491-635 -------------------------------------------------------------------------
+    def fitting(self, body_data, mode="global", log_every=0):
+        """body_data: [N,75] (device tensor or numpy), SMPLify-X layout (:64-76).
+        Returns (body_rec [N_local,75] device tensor, scale numpy scalar, camera_ext [N_local,4,4])
+        -- the whole clip when not sharded, exactly the reference's triple (:635)."""
+        import torch
+        if mode != "global":
+            raise NotImplementedError("only mode='global' is on the accelerated path (SURVEY.md §8f lists "
+                                      "'local' and 'dct' as next rows)")
+        lib, h = self.ctx.lib, self.ctx.handle
+        dev = self.device
+        if not torch.is_tensor(body_data):
+            body_data = torch.from_numpy(np.ascontiguousarray(body_data, dtype=np.float32))
+        body_data = body_data.to(dev, torch.float32).contiguous()
+        n = body_data.shape[0]
+        if n != self.num_body:
+            raise capi.FdcapError(f"body_data has {n} frames, FittingOP was built for {self.num_body}")
+        st = capi.current_stream()
+        x78 = torch.empty(n, capi.XDIM, device=dev)
+        capi.check(lib.fdcap_params_75_to_78(capi.dptr(body_data), n, capi.dptr(x78), st), "fdcap_params_75_to_78")
+        self.init(x78)                                                                      # :495
+        P = first_phase2_iter(self.num_iter)
+        log = FitLog([], [], [], [], [], [], [])
+        multi = self.shard.world > 1
+        for ii in range(self.num_iter):                                                     # :560
+            do_log = bool(log_every) and (ii % log_every == 0 or ii == self.num_iter - 1)
+            st = capi.current_stream()
+            capi.check(lib.fdcap_opt_backward(h, ii, P, 1 if do_log else 0, st), "fdcap_opt_backward")
+            if multi:
+                allreduce_scalars(self.shard, self._dscale, self._losses if do_log else None)
+            if do_log:
+                self._append_log(log, ii, ii >= P)
+            capi.check(lib.fdcap_opt_step(h, ii, P, st), "fdcap_opt_step")
+            if multi:
+                exchange_halos(self.shard, self._rows_x, self._rows_cam)
+        nl = self.shard.n_local
+        body_rec = torch.empty(nl, capi.PDIM, device=dev)
+        scale = torch.empty(1, device=dev)
+        cam = torch.empty(nl, 16, device=dev)
+        capi.check(lib.fdcap_opt_get_results(h, capi.dptr(body_rec), capi.dptr(scale), capi.dptr(cam),
+                                             capi.current_stream()), "fdcap_opt_get_results")
+        self.scale = scale
+        self.camera_ext = cam.view(nl, 4, 4)
+        self.body_rotation_rec = self._rows_x[2:2 + nl]
+        self.log = log
+        return body_rec, scale.detach().cpu().numpy().squeeze(), self.camera_ext
+
+    def _append_log(self, log, ii, phase2):
+        s = self._losses.cpu().numpy()
+        N, nc = self.num_body, max(self.ctx.num_contact, 1)
+        l_rec = self.weight_loss_rec * s[0] / (N * capi.XDIM)
+        l_vp = self.weight_loss_vposer * s[1] / (N * 32)
+        l_sm = s[2] / ((N - 2) * capi.XDIM) if N >= 3 else float("nan")
+        l_con = self.weight_contact * s[3] / (N * nc)
+        l_ws = s[4] / ((N - 1) * 69) if N >= 2 else float("nan")
+        total = (l_rec + PHASE2_WORLD * l_ws + PHASE2_SMOOTH * l_sm) if phase2 else \
+            (PHASE1_CONTACT * l_con + PHASE1_SMOOTH * l_sm + l_rec)
+        log.iters.append(ii); log.l_rec.append(l_rec); log.l_vposer.append(l_vp)
+        log.loss_smoothing.append(l_sm); log.loss_contact.append(l_con)
+        log.loss_world_smoothing.append(l_ws); log.total.append(total)
+        if self.verbose and self.shard.rank == 0:
+            if phase2:
+                print('[INFO][fitting] iter={:d}, l_rec={:f}, l_vposer={:f}, loss_smoothing={:f}, loss_contact={:f}, '
+                      'loss_world_smoothing={:f}, total_loss={:f}'.format(ii, l_rec, l_vp, l_sm, l_con, l_ws, total))
+            else:
+                print('[INFO][fitting] iter={:d}, l_rec={:f}, l_vposer={:f}, loss_smoothing={:f}, loss_contact={:f}, '
+                      'total_loss={:f}'.format(ii, l_rec, l_vp, l_sm, l_con, total))
+
+    # ---- :637-653 -------------------------------------------------------------------------
+    def save_result(self, body_rec, scale, camera_ext, fit_path):
+        import torch
+        br = body_rec.detach().cpu().numpy() if torch.is_tensor(body_rec) else np.asarray(body_rec)
+        ce = camera_ext.detach().cpu().numpy() if torch.is_tensor(camera_ext) else np.asarray(camera_ext)
+        return io.save_result(br, scale, ce, fit_path)
+
+    def close(self):
+        if getattr(self, "ctx", None) is not None:
+            self.ctx.close()
+            self.ctx = None

@@ -1,0 +1,178 @@
+/* fdcap.h -- C-ABI of libfdcap_hip.so: the MI355X (gfx950) hot path of
+ * aptx4869lm/4DCapture-FPV `global_optimization.py` FittingOP.fitting(mode='global').
+ *
+ * The reference has no FFI layer; its boundary is three third-party Python operators plus the
+ * optimiser loop around them.  Each entry point below names the reference
+ * call site (file:line in /root/reference) it replaces.  Binding stub: INTEGRATION.md.
+ *
+ * Conventions
+ *   - plain C, no torch types; every `*_d` / "device" pointer is a caller-owned HIP device
+ *     pointer (a torch tensor's storage), never freed or retained beyond the call unless the
+ *     function says "registered";
+ *   - `stream` is a hipStream_t passed as void* (torch.cuda.current_stream().cuda_stream);
+ *     all work is enqueued on it, nothing synchronises unless stated;
+ *   - return value: 0 ok, negative FDCAP_E_* bad argument / state, positive = hipError_t;
+ *   - one context per device per clip; calls on one context are serialised by the caller
+ *     (the reference is single-threaded, single-stream);
+ *   - fp32 everywhere (reference dtype: global_optimization.py:175,:185,:224,:707), int32 /
+ *     int64 only for indices.
+ */
+#ifndef FDCAP_H
+#define FDCAP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define FDCAP_OK 0
+#define FDCAP_E_ARG (-1)      /* null pointer / bad size */
+#define FDCAP_E_STATE (-2)    /* call order (e.g. no scene registered) */
+#define FDCAP_E_NODEVICE (-3) /* no HIP device visible */
+
+#define FDCAP_NUM_JOINTS 55
+#define FDCAP_XDIM 78         /* optimised row: transl3 6D6 betas10 latent32 lh12 rh12 camt3 */
+#define FDCAP_PDIM 75         /* file row:      transl3 aa3 betas10 latent32 lh12 rh12 camt3 */
+#define FDCAP_NUM_LOSSES 8    /* rec, vposer, smoothing, contact, world_smoothing, total, 2 spare */
+
+typedef struct fdcap_ctx fdcap_ctx;
+
+/* Host arrays (copied to the device by fdcap_ctx_create).  Names follow the SMPL-X npz keys
+ * read by smplx.create (global_optimization.py:154-168) and the VPoser v1 state-dict keys read
+ * by load_vposer (:153). */
+typedef struct fdcap_model_desc {
+    int32_t num_verts;            /* V (10475 for SMPL-X) */
+    const float* v_template;      /* [V,3] */
+    const float* shapedirs;       /* [V,3,num_shape] first 10 = betas (num_betas=10, :156-159) */
+    int32_t num_shape;            /* >= 10; columns >= 10 are expression (zero in the reference) */
+    const float* posedirs;        /* [486, V*3] (library layout) */
+    const float* J_regressor;     /* [55,V] */
+    const int32_t* parents;       /* [55], root -1 */
+    const float* lbs_weights;     /* [V,55] */
+    const float* hands_componentsl; /* [12,45] first num_pca_comps=12 rows */
+    const float* hands_componentsr; /* [12,45] */
+    const float* hands_meanl;     /* [45] (flat_hand_mean=False) */
+    const float* hands_meanr;     /* [45] */
+    const float* vp_fc1_w;        /* bodyprior_dec_fc1.weight [512,32] */
+    const float* vp_fc1_b;        /* [512] */
+    const float* vp_fc2_w;        /* bodyprior_dec_fc2.weight [512,512] */
+    const float* vp_fc2_b;        /* [512] */
+    const float* vp_out_w;        /* bodyprior_dec_out.weight [126,512] */
+    const float* vp_out_b;        /* [126] */
+} fdcap_model_desc;
+
+/* Optimiser configuration = fittingconfig / lossconfig (global_optimization.py:663-686) plus
+ * the constants buried in fitting() (:564, :570, :582). */
+typedef struct fdcap_opt_config {
+    int32_t n_total;        /* frames in the whole clip (mean denominators) */
+    int32_t n_local;        /* frames owned by this rank */
+    int32_t frame0;         /* global index of the first owned frame */
+    float lr;               /* init_lr_h = 0.005 (:671) */
+    float weight_loss_rec;  /* 1 (:682) */
+    float weight_loss_vposer; /* 0.001 (:683), logged only */
+    float weight_contact;   /* 0.1 (:684) */
+    float phase1_contact;   /* 0.1  (:570) */
+    float phase1_smooth;    /* 1.0  (:570) */
+    float phase2_world;     /* 1.0  (:582) */
+    float phase2_smooth;    /* 0.5  (:582) */
+    float scale_init;       /* 1.8  (:179) */
+    int32_t legacy_zero_grad; /* 0: torch>=2 zero_grad(set_to_none=True) semantics */
+} fdcap_opt_config;
+
+/* ---- context ------------------------------------------------------------------------------ */
+/* Replaces FittingOP.__init__'s model construction (global_optimization.py:153-171). */
+int fdcap_ctx_create(const fdcap_model_desc* model, fdcap_ctx** out);
+void fdcap_ctx_destroy(fdcap_ctx* ctx);
+const char* fdcap_version(void);
+
+/* Scene vertices, stored ONCE (the reference repeats them per frame, :175-176).  `scene_xyz`
+ * is a HOST pointer [ns,3]; registered (copied + packed for the NN kernel). */
+int fdcap_set_scene(fdcap_ctx* ctx, const float* scene_xyz, int64_t ns);
+/* Contact vertex ids = get_contact_id(...) (global_optimization.py:79-94, :288); HOST pointer. */
+int fdcap_set_contact_ids(fdcap_ctx* ctx, const int64_t* vid, int32_t nc);
+
+/* ---- Op 1: Chamfer (ext.chamferDist()(xyz1, xyz2), global_optimization.py:292-294) -------- */
+/* xyz1_d [B,n,3] queries, xyz2_d [B,m,3] targets with batch stride `stride2` elements
+ * (0 = one scene shared by all batches).  Writes dist1_d [B,n] (squared L2 to the nearest
+ * target, direct-difference form) and idx1_d [B,n] (lowest index among ties).  If dist2_d is
+ * non-null also the reverse direction dist2_d [B,m], idx2_d [B,m] (the reference discards it). */
+int fdcap_chamfer_fwd(fdcap_ctx* ctx, const float* xyz1_d, const float* xyz2_d, int32_t B,
+                      int32_t n, int32_t m, int64_t stride2, float* dist1_d, int32_t* idx1_d,
+                      float* dist2_d, int32_t* idx2_d, void* stream);
+/* grad wrt the queries only (the scene needs none): gxyz1_d[b,i] = 2 g1[b,i] (x1[b,i]-x2[b,idx]) */
+int fdcap_chamfer_bwd(fdcap_ctx* ctx, const float* xyz1_d, const float* xyz2_d, int32_t B,
+                      int32_t n, int32_t m, int64_t stride2, const float* gdist1_d,
+                      const int32_t* idx1_d, float* gxyz1_d, void* stream);
+
+/* ---- Op 3: VPoser decode (self.vposer.decode(z,'aa'), global_optimization.py:270-271) ----- */
+/* z_d [B,32] with row stride ldz -> rot_d [B,21,9] rotation matrices; aa_d (optional) [B,63]. */
+int fdcap_vposer_decode(fdcap_ctx* ctx, const float* z_d, int32_t ldz, int32_t B, float* rot_d,
+                        float* aa_d, void* stream);
+
+/* ---- Op 2: body model (self.body_mesh_model(...), global_optimization.py:280-283) ---------- */
+/* params_d [B,75] file layout rows (transl, global_orient aa, betas, latent, lh, rh, cam_t);
+ * runs VPoser + SMPL-X and writes vertices_d [B,V,3] and joints_d [B,55,3] (either optional),
+ * body frame, `+transl` applied, no scale / world transform. */
+int fdcap_body_forward(fdcap_ctx* ctx, const float* params_d, int32_t B, float* vertices_d,
+                       float* joints_d, void* stream);
+/* The same with the operator's own argument list (:280-283): global_orient_d [B,3] and
+ * body_pose_d [B,63] axis-angle (Rodrigues as smplx.lbs.batch_rodrigues), betas_d [B,10],
+ * left/right_hand_pose_d [B,12] PCA coefficients, transl_d [B,3]. */
+int fdcap_smplx_forward(fdcap_ctx* ctx, const float* global_orient_d, const float* body_pose_d,
+                        const float* betas_d, const float* left_hand_pose_d,
+                        const float* right_hand_pose_d, const float* transl_d, int32_t B,
+                        float* vertices_d, float* joints_d, void* stream);
+
+/* ---- parameter-vector conversions (global_optimization.py:96-115, cvae.py:62-93) ----------- */
+int fdcap_params_75_to_78(const float* p75_d, int32_t B, float* x78_d, void* stream);
+int fdcap_params_78_to_75(const float* x78_d, int32_t B, float* p75_d, void* stream);
+
+/* ---- the optimiser loop (FittingOP.init + fitting('global'), :450-489, :558-593) ----------- */
+/* Allocates scratch for n_local (+2 halo rows each side) frames and REGISTERS the caller-owned
+ * optimiser state (kept alive by the caller until fdcap_opt_destroy; a multi-GPU caller hands the
+ * same tensors to RCCL):
+ *   rows_x_d   [n_local+4,78] body_rotation_rec (:180) with 2 halo rows each side; owned rows start at 2
+ *   rows_cam_d [n_local+4,16] camera_ext (:182), same row layout
+ *   scale_d    [1]  scale (:179); set to cfg->scale_init here
+ *   dscale_d   [1]  this rank's d loss / d scale (sum over owned frames) -- all-reduce(sum) it
+ *   losses_d   [FDCAP_NUM_LOSSES] double: this rank's un-normalised partial sums of the last
+ *              backward: [0] sum|x0-x|*mask  [1] sum z^2  [2] sum|2nd diff|  [3] sum r/(r+1)
+ *              [4] sum|Jw_i-Jw_{i+1}| */
+int fdcap_opt_create(fdcap_ctx* ctx, const fdcap_opt_config* cfg, float* rows_x_d, float* rows_cam_d,
+                     float* scale_d, float* dscale_d, double* losses_d);
+/* data78_d [n_local,78]: the 6D-converted SMPLify-X rows (loss_rec target);
+ * init78_d [n_local,78]: initial value of body_rotation_rec (= data with outlier rows replaced, :487);
+ * mask_d   [n_local]   : 0 for outlier rows (idx1), 1 otherwise (:255-257);
+ * cam_ext_d[n_local,16]: extract_ext() (:455).  All copied. */
+int fdcap_opt_set_inputs(fdcap_ctx* ctx, const float* data78_d, const float* init78_d,
+                         const float* mask_d, const float* cam_ext_d, void* stream);
+/* One pass of the loop body :562-592 for iteration `ii` of `num_iter`, split in two so a
+ * multi-GPU caller can all-reduce the scalar `scale` gradient in between:
+ *   backward: zero_grad + cal_loss + loss.backward()  -> gradients + loss partial sums
+ *   step    : optimizer.step() (fused Adam over body_rotation_rec, scale, camera_ext)
+ * `phase2` = (ii >= 0.8*num_iter) decides the loss total; the requires_grad toggling of
+ * :564-568/:577-580 (effective one forward late) is reproduced from ii and first_phase2_iter. */
+int fdcap_opt_backward(fdcap_ctx* ctx, int32_t ii, int32_t first_phase2_iter, int32_t log_terms,
+                       void* stream);
+int fdcap_opt_step(fdcap_ctx* ctx, int32_t ii, int32_t first_phase2_iter, void* stream);
+/* Results: body_rec75_d [n_local,75] (= convert_to_3D_rot, :633), scale_d [1], cam_ext_d [n_local,16]. */
+int fdcap_opt_get_results(fdcap_ctx* ctx, float* body_rec75_d, float* scale_d, float* cam_ext_d,
+                          void* stream);
+void fdcap_opt_destroy(fdcap_ctx* ctx);
+
+/* World-space contact vertices / joints of the current state (testing + viewers):
+ * verts_d [n_local,nc,3] (optional), joints_d [n_local,23,3] (optional). */
+int fdcap_opt_forward_world(fdcap_ctx* ctx, float* verts_d, float* joints_d, void* stream);
+/* Gradients of the last fdcap_opt_backward (testing): dx_d [n_local,78], dcam_d [n_local,16]. */
+int fdcap_opt_get_grads(fdcap_ctx* ctx, float* dx_d, float* dcam_d, void* stream);
+
+/* Kernel-level timing of the Chamfer NN launch for the roofline line: runs `iters` launches of
+ * the optimiser's Chamfer forward on `stream` between two HIP events and returns the mean
+ * milliseconds per launch in *ms. */
+int fdcap_opt_time_chamfer(fdcap_ctx* ctx, int32_t iters, float* ms, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* FDCAP_H */
