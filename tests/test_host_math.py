@@ -200,7 +200,7 @@ def test_host_trajectory_matches_reference_golden(golden_dir, name):
     assert err.max() <= 2 * 0.005 * num_iter
     assert q50 < 1e-6 and q90 < 1e-4 and q99 < 3e-3, (q50, q90, q99)
     hands = err[:, 48:72]                      # no kink-free path couples the hands to anything
-    assert hands.max() <= 2e-7                 # -> rec/smoothing/Adam arithmetic agrees to 1 ulp
+    assert hands.max() <= 2e-6                 # -> rec/smoothing/Adam arithmetic agrees to a few ulp
     np.testing.assert_allclose(scale, float(g["scale"]), rtol=0, atol=1e-4)
     P_ = first_phase2_iter(num_iter)
     np.testing.assert_allclose(cam, g["camera_ext"], rtol=0, atol=2 * 0.005 * max(num_iter - P_ - 1, 0) + 1e-6)
