@@ -1,0 +1,292 @@
+"""GPU parity tests: every call goes through the C-ABI (libfdcap_hip.so) on a real MI355X and is
+compared with the oracle on the same seeded inputs, with the committed reference-generated
+goldens, and -- at BASELINE sizes -- through size-independent properties."""
+import ctypes
+import os
+
+import numpy as np
+import pytest
+import torch
+
+import fdcap_amd  # noqa: F401
+from fdcap_amd import capi, ops, synth
+from fdcap_amd.fitting import FittingOP, find_outliers, first_phase2_iter
+from fdcap_amd.io import read_camerapose
+from oracle import rotrepr
+from oracle.chamfer import nn_direct, pairwise_dist
+from oracle.fitting import FittingOracle
+from oracle.smplx import SMPLXOracle
+from oracle.vposer import VPoserDecoder
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def small():
+    bm = synth.make_body_model(300, seed=0)
+    vp = synth.make_vposer(seed=1)
+    ctx = capi.Context(bm, vp)
+    yield bm, vp, ctx
+    ctx.close()
+
+
+def _nn_check(q, t, dist, idx):
+    """dist/idx from the HIP path vs the oracle's direct-difference scan.  Distances must agree
+    to fp32 rounding (the kernel contracts to FMA, torch-CPU does not); an index may differ only
+    between candidates whose oracle distances are equal to that rounding."""
+    od, oi = nn_direct(torch.from_numpy(q), torch.from_numpy(t))
+    od, oi = od.numpy(), oi.numpy()
+    np.testing.assert_allclose(dist, od, rtol=2e-6, atol=1e-12)
+    diff = idx != oi
+    if diff.any():
+        d_at = ((q[diff] - t[idx[diff]]) ** 2).sum(1)
+        np.testing.assert_allclose(d_at, od[diff], rtol=4e-6, atol=1e-12)
+    assert diff.mean() < 1e-3
+
+
+@pytest.mark.parametrize("B,n,m", [(1, 1, 1), (2, 37, 5), (3, 64, 1024), (2, 300, 1500), (1, 513, 9000), (4, 100, 33000)])
+def test_chamfer_shared_scene_matches_oracle(small, B, n, m):
+    _, _, ctx = small
+    rng = np.random.default_rng(B * 1000 + n + m)
+    q = rng.uniform(-3, 3, (B, n, 3)).astype(np.float32)
+    t = rng.uniform(-3, 3, (m, 3)).astype(np.float32)
+    cd = ops.chamferDist(ctx, both=False)
+    d1, _ = cd(torch.tensor(q).cuda(), torch.tensor(t).cuda().unsqueeze(0).expand(B, -1, -1))
+    _nn_check(q.reshape(-1, 3), t, d1.cpu().numpy().reshape(-1), cd.last_idx1.cpu().numpy().reshape(-1).astype(np.int64))
+
+
+def test_chamfer_both_directions_and_backward(small):
+    """The reference's own call shape: per-batch scene copies, both directions (:292-294)."""
+    _, _, ctx = small
+    from oracle.chamfer import chamferDist as OracleChamfer
+    rng = np.random.default_rng(7)
+    a = rng.uniform(-1, 1, (3, 50, 3)).astype(np.float32)
+    b = rng.uniform(-1, 1, (3, 700, 3)).astype(np.float32)
+    ta, tb = torch.tensor(a, requires_grad=True), torch.tensor(b, requires_grad=True)
+    o1, o2 = OracleChamfer(False)(ta, tb)
+    w1 = torch.tensor(rng.standard_normal((3, 50)).astype(np.float32))
+    w2 = torch.tensor(rng.standard_normal((3, 700)).astype(np.float32))
+    ((o1 * w1).sum() + (o2 * w2).sum()).backward()
+    ga, gb = torch.tensor(a).cuda().requires_grad_(True), torch.tensor(b).cuda().requires_grad_(True)
+    d1, d2 = ops.chamferDist(ctx, both=True)(ga, gb)
+    ((d1 * w1.cuda()).sum() + (d2 * w2.cuda()).sum()).backward()
+    np.testing.assert_allclose(d1.detach().cpu().numpy(), o1.detach().numpy(), rtol=2e-6)
+    np.testing.assert_allclose(d2.detach().cpu().numpy(), o2.detach().numpy(), rtol=2e-6)
+    np.testing.assert_allclose(ga.grad.cpu().numpy(), ta.grad.numpy(), rtol=1e-5, atol=1e-6)
+    np.testing.assert_allclose(gb.grad.cpu().numpy(), tb.grad.numpy(), rtol=1e-5, atol=1e-6)
+
+
+def test_chamfer_equal_sizes_vs_reference_chamfer_python(small):
+    """chamfer_python.pairwise_dist (expansion form, equal sizes only, chamfer_python.py:4-9)."""
+    _, _, ctx = small
+    rng = np.random.default_rng(3)
+    x = rng.uniform(-8, 8, (256, 3)).astype(np.float32)
+    y = rng.uniform(-8, 8, (256, 3)).astype(np.float32)
+    P = pairwise_dist(torch.tensor(x), torch.tensor(y))
+    d1, _ = ops.chamferDist(ctx, both=False)(torch.tensor(x).cuda()[None], torch.tensor(y).cuda()[None])
+    # the expansion form loses ~1e-4 absolute at this coordinate scale
+    np.testing.assert_allclose(d1.cpu().numpy()[0], P.min(dim=1)[0].numpy(), atol=2e-4)
+
+
+def test_chamfer_full_size_properties(small):
+    """BASELINE config 2 size (256 frames x 500 contact verts vs a 100k scene): properties."""
+    _, _, ctx = small
+    rng = np.random.default_rng(11)
+    scene = synth.make_scene(100_000, seed=2)
+    q = (rng.uniform(-2, 2, (256, 500, 3)) * [1, 1, 0.3]).astype(np.float32)
+    tq, ts = torch.tensor(q).cuda(), torch.tensor(scene).cuda()
+    cd = ops.chamferDist(ctx, both=False)
+    d, _ = cd(tq, ts.unsqueeze(0).expand(256, -1, -1))
+    idx = cd.last_idx1.long()
+    assert int(idx.min()) >= 0 and int(idx.max()) < scene.shape[0]
+    # (1) the reported distance is the distance to the reported neighbour
+    nb = ts[idx.reshape(-1)].reshape(256, 500, 3)
+    rec = ((tq - nb) ** 2).sum(-1)
+    torch.testing.assert_close(d, rec, rtol=2e-6, atol=1e-12)
+    # (2) no sampled scene point is closer
+    samp = ts[torch.randint(0, scene.shape[0], (4096,), device="cuda")]
+    dmin = torch.cdist(tq.reshape(-1, 3)[:4096], samp).min(dim=1)[0] ** 2
+    assert bool((d.reshape(-1)[:4096] <= dmin * (1 + 1e-5) + 1e-9).all())
+    # (3) shuffling the scene leaves every distance unchanged
+    perm = torch.randperm(scene.shape[0], device="cuda")
+    d2, _ = cd(tq, ts[perm].unsqueeze(0).expand(256, -1, -1))
+    assert torch.equal(d, d2)
+    # (4) exact agreement with the oracle on a slice the CPU finishes in seconds
+    od, oi = nn_direct(torch.tensor(q[0]), torch.tensor(scene))
+    np.testing.assert_allclose(d[0].cpu().numpy(), od.numpy(), rtol=2e-6)
+
+
+def test_vposer_decode_matches_oracle(small):
+    bm, vp, ctx = small
+    rng = np.random.default_rng(5)
+    for B in (1, 7, 130):
+        z = rng.standard_normal((B, 32)).astype(np.float32)
+        orc = VPoserDecoder.from_data(vp)
+        want_rot = orc.decode(torch.tensor(z), output_type="matrot").numpy()
+        want_aa = orc.decode(torch.tensor(z), output_type="aa").numpy()
+        v = ops.VPoser(ctx)
+        np.testing.assert_allclose(v.decode(torch.tensor(z).cuda(), "matrot").cpu().numpy(), want_rot, atol=3e-6)
+        np.testing.assert_allclose(v.decode(torch.tensor(z).cuda(), "aa").cpu().numpy(), want_aa, atol=1e-5)
+
+
+def test_body_model_operator_matches_oracle(small):
+    bm, vp, ctx = small
+    rng = np.random.default_rng(9)
+    B = 5
+    kw = dict(body_pose=rng.standard_normal((B, 63)) * 0.3, transl=rng.standard_normal((B, 3)),
+              global_orient=rng.standard_normal((B, 3)), betas=rng.standard_normal((B, 10)),
+              left_hand_pose=rng.standard_normal((B, 12)), right_hand_pose=rng.standard_normal((B, 12)))
+    kw = {k: torch.tensor(v, dtype=torch.float32) for k, v in kw.items()}
+    want = SMPLXOracle(bm)(return_verts=True, **kw)
+    got = ops.BodyModel(ctx)(return_verts=True, **{k: v.cuda() for k, v in kw.items()})
+    np.testing.assert_allclose(got.vertices.cpu().numpy(), want.vertices.numpy(), atol=2e-5)
+    np.testing.assert_allclose(got.joints.cpu().numpy(), want.joints.numpy(), atol=2e-5)
+
+
+def test_body_forward_from_file_rows(small):
+    """[N,75] rows -> vertices: VPoser decode + SMPL-X as global_vis.py:131-146 chains them."""
+    bm, vp, ctx = small
+    clip = synth.make_clip(9, seed=4)
+    p = torch.tensor(clip.body_params)
+    aa = VPoserDecoder.from_data(vp).decode(p[:, 16:48], output_type="aa").view(9, -1)
+    want = SMPLXOracle(bm)(return_verts=True, body_pose=aa, transl=p[:, 0:3], global_orient=p[:, 3:6], betas=p[:, 6:16],
+                           left_hand_pose=p[:, 48:60], right_hand_pose=p[:, 60:72])
+    verts, joints = ops.body_forward_from_params(ctx, p.cuda())
+    np.testing.assert_allclose(verts.cpu().numpy(), want.vertices.numpy(), atol=3e-5)
+    np.testing.assert_allclose(joints.cpu().numpy(), want.joints.numpy(), atol=3e-5)
+
+
+def test_param_conversions_vs_reference_golden(small, golden_dir):
+    _, _, ctx = small
+    u = np.load(os.path.join(golden_dir, "ref_units.npz"))
+    x75 = torch.tensor(u["x75"]).cuda()
+    x78 = torch.empty(16, 78, device="cuda")
+    capi.check(ctx.lib.fdcap_params_75_to_78(capi.dptr(x75), 16, capi.dptr(x78), capi.current_stream()), "75->78")
+    np.testing.assert_allclose(x78.cpu().numpy(), u["x78"], atol=3e-7)
+    back = torch.empty(16, 75, device="cuda")
+    capi.check(ctx.lib.fdcap_params_78_to_75(capi.dptr(torch.tensor(u["x78"]).cuda()), 16, capi.dptr(back),
+                                             capi.current_stream()), "78->75")
+    np.testing.assert_allclose(back.cpu().numpy(), u["x75_back"], atol=3e-6)
+
+
+def _make_fop(n, V, ns, per_part, num_iter, seed=0, weight_contact=0.1):
+    bm = synth.make_body_model(V, seed=seed)
+    vp = synth.make_vposer(seed=seed + 1)
+    clip = synth.make_clip(n, seed=seed + 2)
+    scene = synth.make_scene(ns, seed=seed + 3)
+    left, right = synth.make_contact_ids(bm.v_template, per_part=per_part, seed=seed + 4)
+    vid = np.concatenate([left, right])
+    fop = FittingOP({"num_iter": num_iter}, {"weight_contact": weight_contact}, n, body_model=bm, vposer=vp,
+                    scene_verts=scene, contact_ids=vid, camera_ext=read_camerapose(clip.camerapose_lines))
+    return fop, bm, vp, clip, scene, vid
+
+
+@pytest.mark.parametrize("phase2", [False, True])
+def test_optimiser_gradients_match_autograd(phase2):
+    n = 12
+    fop, bm, vp, clip, scene, vid = _make_fop(n, 300, 800, 20, 500)
+    dt = torch.float64
+    f = FittingOracle(SMPLXOracle(bm, dt), VPoserDecoder.from_data(vp, dt), scene, vid, clip.camerapose_lines, n, dtype=dt)
+    x78 = rotrepr.convert_to_6D_rot(torch.tensor(clip.body_params, dtype=dt)).detach()
+    f.init(x78)
+    g = torch.Generator().manual_seed(5)
+    pert = 0.01 * torch.randn(f.body_rotation_rec.shape, generator=g, dtype=dt)
+    f.body_rotation_rec.data += pert
+    idx1, _ = find_outliers(x78.numpy().astype(np.float32))
+    l_rec, l_vp, l_con, l_sm, l_ws = f.cal_loss(x78, idx1)
+    ((l_rec + l_ws + 0.5 * l_sm) if phase2 else (0.1 * l_con + l_sm + l_rec)).backward()
+    # same state on the GPU
+    x78g = torch.tensor(x78.numpy(), dtype=torch.float32).cuda()
+    fop.init(x78g)
+    fop._rows_x[2:2 + n] += pert.float().cuda()
+    lib, h = fop.ctx.lib, fop.ctx.handle
+    P = 0 if phase2 else 10 ** 6
+    capi.check(lib.fdcap_opt_backward(h, 5, P, 1, capi.current_stream()), "backward")
+    dx = torch.empty(n, 78, device="cuda")
+    dcam = torch.empty(n, 16, device="cuda")
+    capi.check(lib.fdcap_opt_get_grads(h, capi.dptr(dx), capi.dptr(dcam), capi.current_stream()), "grads")
+    torch.cuda.synchronize()
+    gx = f.body_rotation_rec.grad.numpy()
+    np.testing.assert_allclose(dx.cpu().numpy(), gx, rtol=2e-3, atol=2e-4 * np.abs(gx).max())
+    s = fop._losses.cpu().numpy()
+    np.testing.assert_allclose(s[0] / (n * 78), float(l_rec.detach()), rtol=1e-5)
+    np.testing.assert_allclose(0.001 * s[1] / (n * 32), float(l_vp.detach()), rtol=1e-5)
+    np.testing.assert_allclose(s[2] / ((n - 2) * 78), float(l_sm.detach()), rtol=1e-5)
+    np.testing.assert_allclose(s[4] / ((n - 1) * 69), float(l_ws.detach()), rtol=1e-4)
+    np.testing.assert_allclose(0.1 * s[3] / (n * len(vid)), float(l_con.detach()), rtol=1e-5)
+    if phase2:
+        gc = f.camera_ext.grad.numpy().reshape(n, 16)
+        np.testing.assert_allclose(dcam.cpu().numpy(), gc, rtol=2e-3, atol=2e-4 * np.abs(gc).max())
+    else:
+        np.testing.assert_allclose(float(fop._dscale.cpu()), float(f.scale.grad), rtol=2e-3)
+    fop.close()
+
+
+def test_forward_world_matches_oracle():
+    n = 10
+    fop, bm, vp, clip, scene, vid = _make_fop(n, 300, 800, 20, 500)
+    f = FittingOracle(SMPLXOracle(bm), VPoserDecoder.from_data(vp), scene, vid, clip.camerapose_lines, n)
+    x78 = rotrepr.convert_to_6D_rot(torch.tensor(clip.body_params)).detach()
+    f.init(x78)
+    with torch.no_grad():
+        _, verts, joints = f.forward_world()
+    fop.init(x78.cuda())
+    v = torch.empty(n, len(vid), 3, device="cuda")
+    j = torch.empty(n, 23, 3, device="cuda")
+    capi.check(fop.ctx.lib.fdcap_opt_forward_world(fop.ctx.handle, capi.dptr(v), capi.dptr(j), capi.current_stream()), "fw")
+    np.testing.assert_allclose(v.cpu().numpy(), verts[:, vid].numpy(), atol=3e-5)
+    np.testing.assert_allclose(j.cpu().numpy(), joints.numpy(), atol=3e-5)
+    fop.close()
+
+
+@pytest.mark.parametrize("name", ["ref_global_5it.npz", "ref_global_20it.npz"])
+def test_trajectory_matches_reference_golden(golden_dir, name):
+    """FittingOP.fitting on the GPU vs what the REFERENCE'S OWN loop produced on the same inputs.
+    Tolerances: see tests/test_host_math.py (Adam + L1 kinks; yardstick = fp64 oracle vs the fp32
+    reference run: q50 2e-8, q90 2e-7, q99 4e-4, max 1.1e-2)."""
+    g = np.load(os.path.join(golden_dir, name))
+    bm = synth.make_body_model(int(g["num_verts"]), seed=int(g["model_seed"]))
+    vp = synth.make_vposer(seed=int(g["vposer_seed"]))
+    num_iter = int(g["num_iter"])
+    fop = FittingOP({"num_iter": num_iter}, {}, 300, body_model=bm, vposer=vp, scene_verts=g["scene"],
+                    contact_ids=g["vid"], camera_ext=read_camerapose(list(g["camerapose"])))
+    body, scale, cam = fop.fitting(torch.tensor(g["body_in"]).cuda(), "global", log_every=1)
+    np.testing.assert_array_equal(fop.idx1, g["idx1"])
+    err = np.abs(body.cpu().numpy() - g["body_rec"])
+    q50, q90, q99 = np.quantile(err, [0.5, 0.9, 0.99])
+    assert err.max() <= 2 * 0.005 * num_iter
+    assert q50 < 1e-6 and q90 < 1e-4 and q99 < 3e-3, (q50, q90, q99)
+    assert err[:, 48:72].max() <= 2e-6
+    np.testing.assert_allclose(float(scale), float(g["scale"]), atol=1e-4)
+    P = first_phase2_iter(num_iter)
+    np.testing.assert_allclose(cam.cpu().numpy(), g["camera_ext"], atol=2 * 0.005 * max(num_iter - P - 1, 0) + 1e-6)
+    tol = 3e-6 + 2e-6 * np.arange(num_iter)
+    log = fop.log
+    assert np.all(np.abs(np.array(log.l_rec) - g["log"][:, 1]) <= tol)
+    assert np.all(np.abs(np.array(log.l_vposer) - g["log"][:, 2]) <= tol)
+    assert np.all(np.abs(np.array(log.loss_smoothing) - g["log"][:, 3]) <= tol)
+    assert np.all(np.abs(np.array(log.loss_contact) - g["log"][:, 4]) <= tol)
+    assert np.all(np.abs(np.array(log.total) - g["log"][:, 6]) <= 2 * tol)
+    assert np.all(np.abs(np.array(log.loss_world_smoothing)[P:] - g["log"][P:, 5]) <= tol[P:])
+    fop.close()
+
+
+def test_no_contact_config_and_ragged_sizes():
+    """BASELINE config 1 (8 frames, no scene: rec + temporal only) and awkward sizes."""
+    for n, ns in ((8, 0), (3, 0), (17, 1100)):
+        fop, bm, vp, clip, scene, vid = _make_fop(n, 200, ns, 7, 10, seed=20 + n)
+        body, scale, cam = fop.fitting(torch.tensor(clip.body_params).cuda(), "global", log_every=1)
+        orc = FittingOracle(SMPLXOracle(bm), VPoserDecoder.from_data(vp), scene, vid, clip.camerapose_lines, n, num_iter=10)
+        ob, osc, ocam = orc.fitting(torch.tensor(clip.body_params))
+        err = np.abs(body.cpu().numpy() - ob.numpy())
+        assert np.quantile(err, 0.9) < 1e-4 and err.max() <= 0.1, (n, ns, err.max())
+        assert abs(float(scale) - float(osc)) < 1e-3
+        if ns == 0:
+            assert float(scale) == pytest.approx(1.8)       # no gradient path -> never stepped
+        fop.close()
+
+
+def test_library_fails_loudly_without_gpu_fallback(small):
+    _, _, ctx = small
+    with pytest.raises(capi.FdcapError):
+        ops.chamferDist(ctx)(torch.zeros(1, 4, 3), torch.zeros(1, 4, 3))    # host tensors are refused
