@@ -51,6 +51,7 @@ SYMBOLS = {
                                      c_void_p, c_void_p, c_void_p, c_void_p]),
     "fdcap_chamfer_bwd": (c_int32, [c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_int32, c_int64, c_void_p,
                                      c_void_p, c_void_p, c_void_p]),
+    "fdcap_set_nn_kernel": (c_int32, [c_int32]),
     "fdcap_vposer_decode": (c_int32, [c_void_p, c_void_p, c_int32, c_int32, c_void_p, c_void_p, c_void_p]),
     "fdcap_body_forward": (c_int32, [c_void_p, c_void_p, c_int32, c_void_p, c_void_p, c_void_p]),
     "fdcap_params_75_to_78": (c_int32, [c_void_p, c_int32, c_void_p, c_void_p]),

@@ -14,10 +14,18 @@
 //     reference kernel gives.
 #pragma once
 #include <hip/hip_runtime.h>
+#include <stdlib.h>
 
 namespace fdc {
 
 constexpr int NN_TILE = 1024;
+
+// The one definition of the squared distance every kernel reports (direct-difference form as
+// the reference CUDA kernel computes it; fixed operation order so all kernels agree bitwise).
+__device__ __forceinline__ float nn_exact_d2(float qx, float qy, float qz, float px, float py, float pz) {
+    float dx = qx - px, dy = qy - py, dz = qz - pz;
+    return __fmaf_rn(dz, dz, __fmaf_rn(dy, dy, __fmul_rn(dx, dx)));
+}
 
 template <int QPT>
 __global__ __launch_bounds__(256) void nn_direct_kernel(const float* __restrict__ q, int nq,
@@ -51,8 +59,7 @@ __global__ __launch_bounds__(256) void nn_direct_kernel(const float* __restrict_
             const float4 p = tile[j];
 #pragma unroll
             for (int u = 0; u < QPT; ++u) {
-                float dx = qx[u] - p.x, dy = qy[u] - p.y, dz = qz[u] - p.z;
-                float d = dx * dx + dy * dy + dz * dz;
+                float d = nn_exact_d2(qx[u], qy[u], qz[u], p.x, p.y, p.z);
                 if (d < best[u]) { best[u] = d; bi[u] = base + j; }
             }
         }
@@ -64,6 +71,185 @@ __global__ __launch_bounds__(256) void nn_direct_kernel(const float* __restrict_
         if (qi < nq) {
             pd[(size_t)split * nq + qi] = best[u];
             pi[(size_t)split * nq + qi] = bi[u];
+        }
+    }
+}
+
+
+// ---------------------------------------------------------------------------------------------
+// MFMA-filtered exact nearest neighbour.
+//
+// Brute force still visits every (query, scene point) pair, but the per-pair work moves to the
+// matrix cores: one v_mfma_f32_32x32x16_bf16 evaluates 32 scene points x 32 queries of
+//     s_ij = |y'_j|^2 - 2 x'_i . y'_j        (x' = x - c, y' = y - c, c = workgroup's query centroid)
+// with both coordinate vectors split into bf16 hi+lo parts (16 significant bits each) and
+// |y'|^2 into three parts, laid out along K = 16:
+//     A (scene) : [yh_x yh_x yl_x yl_x | yh_y yh_y yl_y yl_y | yh_z yh_z yl_z yl_z | nh nm nl 0]
+//     B (query) : [-2xh_x -2xl_x -2xh_x -2xl_x | ... y ... | ... z ... | 1 1 1 0]
+// The score only FILTERS: |s_ij + |x'_i|^2 - d_ij| <= eps_i (bound below), so a pair is skipped
+// only when s_ij > thr_i = best_i - |x'_i|^2 + eps_i proves d_ij > best_i.  Every surviving pair
+// is re-evaluated with nn_exact_d2 in fp32 and compared (d, index) lexicographically, so the
+// result is bit-identical to nn_direct_kernel (checked on the GPU in tests/test_gpu_parity.py).
+// The VALU's share per MFMA is a 16-way v_min3 tree and one compare.
+//
+// eps_i = K1 * X * Y + K2 * (X^2 + Y^2),  X = |x'_i|,  Y = X + sqrt(best_i) >= |y'_j| for any j
+// that could beat best_i.  Dominant term: each coordinate keeps 16 bits, so the cross term errs
+// by <= 4 * 2^-16 * X * Y = 6.1e-5 X Y; fp32 accumulation, the 3-part norm and the fp32
+// centring add < 2e-6 (X Y + Y^2).  K1 = 1e-4, K2 = 8e-6 leave >= 50 % margin.
+constexpr int MF_CH = 512;             // scene points staged per LDS buffer
+constexpr float MF_K1 = 1e-4f, MF_K2 = 8e-6f;
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef float f32x16_t __attribute__((ext_vector_type(16)));
+
+__device__ __forceinline__ unsigned f2bf(float f) {
+    __bf16 h = (__bf16)f;                                  // v_cvt_pk_bf16_f32, round-to-nearest-even
+    return (unsigned)__builtin_bit_cast(unsigned short, h);
+}
+__device__ __forceinline__ float bf2f(unsigned h) { return __uint_as_float(h << 16); }
+// hi/lo bf16 split of v; returns (hi | hi<<16) in .x and (lo | lo<<16) in .y
+__device__ __forceinline__ uint2 bf_split_dup(float v) {
+    unsigned h = f2bf(v);
+    unsigned l = f2bf(v - bf2f(h));
+    return make_uint2(h | (h << 16), l | (l << 16));
+}
+__device__ __forceinline__ float mf_thr(float best, float X, float X2) {
+    float Y = X + sqrtf(best);
+    return best - X2 + (MF_K1 * X * Y + MF_K2 * (X2 + Y * Y));
+}
+
+template <int NQ>
+__global__ __launch_bounds__(256) void nn_mfma_kernel(const float* __restrict__ q, int nq,
+                                                      const float4* __restrict__ tgt, int nt, int nsplit,
+                                                      float* __restrict__ pd, int* __restrict__ pi) {
+    __shared__ uint4 sA[2][MF_CH / 32][2][32];     // [buffer][tile][k-half][point] bf16 x 8
+    __shared__ float4 sP[2][MF_CH];                // fp32 coordinates for the exact re-evaluation
+    __shared__ float sred[4][4];
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, half = lane >> 5, col = lane & 31;
+    const int split = blockIdx.x % nsplit;
+    const int qb = blockIdx.x / nsplit;
+    const int per = (nt + nsplit - 1) / nsplit;
+    const int t_begin = split * per;
+    const int t_end = min(nt, t_begin + per);
+
+    float qx[NQ], qy[NQ], qz[NQ], own_d[NQ], thr[NQ], X[NQ], X2[NQ];
+    int own_i[NQ], qidx[NQ];
+    float sx = 0.f, sy = 0.f, sz = 0.f, sc = 0.f;
+#pragma unroll
+    for (int n = 0; n < NQ; ++n) {
+        qidx[n] = qb * (128 * NQ) + (wave * NQ + n) * 32 + col;
+        bool ok = qidx[n] < nq;
+        qx[n] = ok ? q[3 * (size_t)qidx[n]] : 0.f;
+        qy[n] = ok ? q[3 * (size_t)qidx[n] + 1] : 0.f;
+        qz[n] = ok ? q[3 * (size_t)qidx[n] + 2] : 0.f;
+        if (ok && half == 0) { sx += qx[n]; sy += qy[n]; sz += qz[n]; sc += 1.f; }
+    }
+    // workgroup centroid of the queries
+    {
+        float v[4] = {sx, sy, sz, sc};
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1) v[i] += __shfl_xor(v[i], off, 64);
+            if (lane == 0) sred[wave][i] = v[i];
+        }
+    }
+    __syncthreads();
+    const float cnt = fmaxf(sred[0][3] + sred[1][3] + sred[2][3] + sred[3][3], 1.f);
+    const float cx = (sred[0][0] + sred[1][0] + sred[2][0] + sred[3][0]) / cnt;
+    const float cy = (sred[0][1] + sred[1][1] + sred[2][1] + sred[3][1]) / cnt;
+    const float cz = (sred[0][2] + sred[1][2] + sred[2][2] + sred[3][2]) / cnt;
+
+    bf16x8 bfrag[NQ];
+#pragma unroll
+    for (int n = 0; n < NQ; ++n) {
+        float xx = qx[n] - cx, xy = qy[n] - cy, xz = qz[n] - cz;
+        X2[n] = __fmaf_rn(xz, xz, __fmaf_rn(xy, xy, xx * xx));
+        X[n] = sqrtf(X2[n]);
+        // -2 * (bf16 value) is exact in bf16; pairs are (hi, lo)
+        unsigned hx = f2bf(xx), hy = f2bf(xy), hz = f2bf(xz);
+        unsigned lx = f2bf(xx - bf2f(hx)), ly = f2bf(xy - bf2f(hy)), lz = f2bf(xz - bf2f(hz));
+        unsigned px = f2bf(-2.f * bf2f(hx)) | (f2bf(-2.f * bf2f(lx)) << 16);
+        unsigned py = f2bf(-2.f * bf2f(hy)) | (f2bf(-2.f * bf2f(ly)) << 16);
+        unsigned pz = f2bf(-2.f * bf2f(hz)) | (f2bf(-2.f * bf2f(lz)) << 16);
+        const unsigned one = 0x3F80u;                       // bf16 1.0
+        uint4 u = half == 0 ? make_uint4(px, px, py, py) : make_uint4(pz, pz, one | (one << 16), one);
+        bfrag[n] = __builtin_bit_cast(bf16x8, u);
+        own_d[n] = INFINITY;
+        own_i[n] = -1;
+        thr[n] = (qidx[n] < nq) ? INFINITY : -INFINITY;     // padding queries are never flagged
+    }
+    const f32x16_t zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+
+    // stage one chunk of the scene: centre, split to bf16, store MFMA A fragments + fp32 copy
+    auto stage = [&](int buf, int base) {
+#pragma unroll
+        for (int it = 0; it < MF_CH / 256; ++it) {
+            int j = tid + it * 256;
+            int g = base + j;
+            float4 p = (g < t_end) ? tgt[g] : make_float4(0.f, 0.f, 0.f, 0.f);
+            float yx = p.x - cx, yy = p.y - cy, yz = p.z - cz;
+            float n2 = __fmaf_rn(yz, yz, __fmaf_rn(yy, yy, yx * yx));
+            if (g >= t_end) { yx = yy = yz = 0.f; n2 = 1e30f; }   // padding rows: score 1e30, never below a finite thr
+            uint2 sxp = bf_split_dup(yx), syp = bf_split_dup(yy), szp = bf_split_dup(yz);
+            unsigned nh = f2bf(n2);
+            float r1 = n2 - bf2f(nh);
+            unsigned nm = f2bf(r1);
+            unsigned nl = f2bf(r1 - bf2f(nm));
+            int tile = j >> 5, pt = j & 31;
+            sA[buf][tile][0][pt] = make_uint4(sxp.x, sxp.y, syp.x, syp.y);
+            sA[buf][tile][1][pt] = make_uint4(szp.x, szp.y, nh | (nm << 16), nl);
+            sP[buf][j] = p;
+        }
+    };
+
+    int buf = 0;
+    if (t_begin < t_end) stage(0, t_begin);
+    __syncthreads();
+    for (int base = t_begin; base < t_end; base += MF_CH) {
+        if (base + MF_CH < t_end) stage(buf ^ 1, base + MF_CH);
+        const int ntile = (min(MF_CH, t_end - base) + 31) >> 5;
+        for (int tile = 0; tile < ntile; ++tile) {
+            const bf16x8 afrag = __builtin_bit_cast(bf16x8, sA[buf][tile][half][col]);
+#pragma unroll
+            for (int n = 0; n < NQ; ++n) {
+                f32x16_t acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afrag, bfrag[n], zero, 0, 0, 0);
+                float m = fminf(acc[0], acc[1]);
+#pragma unroll
+                for (int r = 2; r < 16; ++r) m = fminf(m, acc[r]);
+                if (__any(m < thr[n])) {
+                    // rare path: exact fp32 re-evaluation of the surviving rows, ascending index
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        if (acc[r] < thr[n]) {
+                            const int row = (r & 3) + 8 * (r >> 2) + 4 * half;
+                            const int g = base + tile * 32 + row;
+                            const float4 p = sP[buf][tile * 32 + row];
+                            const float d = nn_exact_d2(qx[n], qy[n], qz[n], p.x, p.y, p.z);
+                            if (g < t_end && (d < own_d[n] || (d == own_d[n] && g < own_i[n]))) {
+                                own_d[n] = d;
+                                own_i[n] = g;
+                                thr[n] = mf_thr(d, X[n], X2[n]);
+                            }
+                        }
+                    }
+                    // both half-waves hold the same 32 queries: share the tighter bound
+                    const float sb = fminf(own_d[n], __shfl_xor(own_d[n], 32, 64));
+                    if (qidx[n] < nq) thr[n] = mf_thr(sb, X[n], X2[n]);
+                }
+            }
+        }
+        __syncthreads();
+        buf ^= 1;
+    }
+#pragma unroll
+    for (int n = 0; n < NQ; ++n) {
+        float od = __shfl_xor(own_d[n], 32, 64);
+        int oi = __shfl_xor(own_i[n], 32, 64);
+        if (oi >= 0 && (od < own_d[n] || (od == own_d[n] && (own_i[n] < 0 || oi < own_i[n])))) { own_d[n] = od; own_i[n] = oi; }
+        if (half == 0 && qidx[n] < nq) {
+            pd[(size_t)split * nq + qidx[n]] = own_d[n];
+            pi[(size_t)split * nq + qidx[n]] = own_i[n];
         }
     }
 }
@@ -102,6 +288,23 @@ __global__ void nn_grad_kernel(const float* __restrict__ q, const float4* __rest
     gq[3 * (size_t)qi + 2] = j >= 0 ? gg * (q[3 * (size_t)qi + 2] - p.z) : 0.f;
 }
 
+// kernel choice: 0 = by size (MFMA-filtered for non-trivial sizes), 1 = plain VALU scan,
+// 2 = MFMA-filtered.  Env FDCAP_NN_KERNEL=direct|mfma or fdcap_set_nn_kernel() override (A/B).
+inline int& nn_mode_ref() {
+    static int mode = -1;
+    if (mode < 0) {
+        const char* e = getenv("FDCAP_NN_KERNEL");
+        mode = (e && e[0] == 'd') ? 1 : (e && e[0] == 'm') ? 2 : 0;
+    }
+    return mode;
+}
+static inline bool nn_use_mfma(int nq, int nt) {
+    int mode = nn_mode_ref();
+    if (mode == 1) return false;
+    if (mode == 2) return true;
+    return (long long)nq * nt >= (1LL << 22);
+}
+
 static inline int nn_pick_nsplit(int nq, int nt) {
     // enough workgroups to fill 256 CUs several times over; 8 = one split per XCD
     int qblocks = (nq + 511) / 512;
@@ -116,7 +319,10 @@ static inline hipError_t nn_search(const float* q, int nq, const float4* tgt, in
                                    float* pd, int* pi, int nsplit, hipStream_t st) {
     if (nq <= 0) return hipSuccess;
     int qblocks = (nq + 511) / 512;
-    hipLaunchKernelGGL((nn_direct_kernel<2>), dim3(qblocks * nsplit), dim3(256), 0, st, q, nq, tgt, nt, nsplit, pd, pi);
+    if (nn_use_mfma(nq, nt))
+        hipLaunchKernelGGL((nn_mfma_kernel<4>), dim3(qblocks * nsplit), dim3(256), 0, st, q, nq, tgt, nt, nsplit, pd, pi);
+    else
+        hipLaunchKernelGGL((nn_direct_kernel<2>), dim3(qblocks * nsplit), dim3(256), 0, st, q, nq, tgt, nt, nsplit, pd, pi);
     hipLaunchKernelGGL(nn_combine_kernel, dim3((nq + 255) / 256), dim3(256), 0, st, pd, pi, nsplit, nq, dist, idx);
     return hipGetLastError();
 }

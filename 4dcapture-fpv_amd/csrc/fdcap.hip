@@ -431,7 +431,13 @@ int vposer_forward(fdcap_ctx* c, const float* X, int ldx, int latent_off, int ro
 // ------------------------------------------------------------------------------------------
 extern "C" {
 
-const char* fdcap_version(void) { return "fdcap-hip 0.1 (gfx950)"; }
+const char* fdcap_version(void) { return "fdcap-hip 0.2 (gfx950)"; }
+
+int fdcap_set_nn_kernel(int32_t mode) {
+    if (mode < 0 || mode > 2) return FDCAP_E_ARG;
+    nn_mode_ref() = mode;
+    return FDCAP_OK;
+}
 
 int fdcap_ctx_create(const fdcap_model_desc* md, fdcap_ctx** out) {
     if (!md || !out || md->num_verts <= 0 || md->num_shape < NBETA) return FDCAP_E_ARG;

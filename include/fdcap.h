@@ -105,6 +105,11 @@ int fdcap_chamfer_bwd(fdcap_ctx* ctx, const float* xyz1_d, const float* xyz2_d, 
                       int32_t n, int32_t m, int64_t stride2, const float* gdist1_d,
                       const int32_t* idx1_d, float* gxyz1_d, void* stream);
 
+/* Nearest-neighbour kernel selection for A/B measurement: 0 = by size (default), 1 = plain VALU
+ * scan (nn_direct_kernel), 2 = MFMA-filtered exact scan (nn_mfma_kernel).  Both give bit-identical
+ * results.  Process-wide. */
+int fdcap_set_nn_kernel(int32_t mode);
+
 /* ---- Op 3: VPoser decode (self.vposer.decode(z,'aa'), global_optimization.py:270-271) ----- */
 /* z_d [B,32] with row stride ldz -> rot_d [B,21,9] rotation matrices; aa_d (optional) [B,63]. */
 int fdcap_vposer_decode(fdcap_ctx* ctx, const float* z_d, int32_t ldz, int32_t B, float* rot_d,
