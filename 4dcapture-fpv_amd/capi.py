@@ -12,7 +12,7 @@ from ctypes import POINTER, c_char_p, c_double, c_float, c_int32, c_int64, c_voi
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libfdcap_hip.so")
+LIB_PATH = os.environ.get("FDCAP_LIB") or os.path.join(_HERE, "libfdcap_hip.so")
 
 NUM_LOSSES = 8
 XDIM = 78

@@ -99,6 +99,15 @@ __global__ __launch_bounds__(256) void nn_direct_kernel(const float* __restrict_
 constexpr int MF_CH = 512;             // scene points staged per LDS buffer
 constexpr float MF_K1 = 1e-4f, MF_K2 = 8e-6f;
 
+#ifdef FDC_NN_STATS
+// instrumentation build only (never shipped): [0] MFMA results reduced, [1] results that entered
+// the exact path (wave level), [2] rows re-evaluated exactly (lane level)
+__device__ unsigned long long g_nn_stats[4];
+#define FDC_STAT(i, v) st_cnt[i] += (v)
+#else
+#define FDC_STAT(i, v)
+#endif
+
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef float f32x16_t __attribute__((ext_vector_type(16)));
 
@@ -179,6 +188,9 @@ __global__ __launch_bounds__(256) void nn_mfma_kernel(const float* __restrict__ 
         own_i[n] = -1;
         thr[n] = (qidx[n] < nq) ? INFINITY : -INFINITY;     // padding queries are never flagged
     }
+#ifdef FDC_NN_STATS
+    unsigned st_cnt[3] = {0, 0, 0};
+#endif
     const f32x16_t zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
 
     // stage one chunk of the scene: centre, split to bf16, store MFMA A fragments + fp32 copy
@@ -207,21 +219,49 @@ __global__ __launch_bounds__(256) void nn_mfma_kernel(const float* __restrict__ 
     if (t_begin < t_end) stage(0, t_begin);
     __syncthreads();
     for (int base = t_begin; base < t_end; base += MF_CH) {
+#if defined(FDC_NN_EXP) && FDC_NN_EXP >= 3
+        if (base == t_begin) stage(buf ^ 1, base);   // experiment: no per-chunk staging
+#else
         if (base + MF_CH < t_end) stage(buf ^ 1, base + MF_CH);
+#endif
         const int ntile = (min(MF_CH, t_end - base) + 31) >> 5;
+        // software pipeline: the next tile's A fragment is fetched from LDS and the next MFMA is
+        // issued before the current result is reduced, so the matrix pipe, the LDS read and the
+        // v_min3 tree of one wave overlap
+        bf16x8 afrag_next = __builtin_bit_cast(bf16x8, sA[buf][0][half][col]);
         for (int tile = 0; tile < ntile; ++tile) {
-            const bf16x8 afrag = __builtin_bit_cast(bf16x8, sA[buf][tile][half][col]);
+            const bf16x8 afrag = afrag_next;
+            if (tile + 1 < ntile) afrag_next = __builtin_bit_cast(bf16x8, sA[buf][tile + 1][half][col]);
+            f32x16_t acc_q[NQ];
+            acc_q[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afrag, bfrag[0], zero, 0, 0, 0);
+            if (NQ > 1) acc_q[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afrag, bfrag[1], zero, 0, 0, 0);
 #pragma unroll
             for (int n = 0; n < NQ; ++n) {
-                f32x16_t acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afrag, bfrag[n], zero, 0, 0, 0);
-                float m = fminf(acc[0], acc[1]);
-#pragma unroll
-                for (int r = 2; r < 16; ++r) m = fminf(m, acc[r]);
+                const f32x16_t acc = acc_q[n];
+                if (n + 2 < NQ) acc_q[n + 2] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afrag, bfrag[n + 2], zero, 0, 0, 0);
+                // 16-way minimum as a depth-3 tree of v_min3 (a serial chain would put 8 dependent
+                // VALU latencies on the wave's critical path)
+                const float t0 = fminf(fminf(acc[0], acc[1]), acc[2]), t1 = fminf(fminf(acc[3], acc[4]), acc[5]);
+                const float t2 = fminf(fminf(acc[6], acc[7]), acc[8]), t3 = fminf(fminf(acc[9], acc[10]), acc[11]);
+                const float t4 = fminf(fminf(acc[12], acc[13]), acc[14]);
+                const float m = fminf(fminf(fminf(t0, t1), t2), fminf(fminf(t3, t4), acc[15]));
+                FDC_STAT(0, lane == 0);
+#if defined(FDC_NN_EXP) && FDC_NN_EXP >= 1
+#if FDC_NN_EXP == 2 || FDC_NN_EXP == 4
+                own_d[n] = fminf(own_d[n], m);         // experiment: no branch at all
+#else
+                if (m < -1e30f) own_d[n] = m;          // experiment: fast path only (results wrong)
+#endif
+                if (false) {
+#else
                 if (__any(m < thr[n])) {
+#endif
+                    FDC_STAT(1, lane == 0);
                     // rare path: exact fp32 re-evaluation of the surviving rows, ascending index
 #pragma unroll
                     for (int r = 0; r < 16; ++r) {
                         if (acc[r] < thr[n]) {
+                            FDC_STAT(2, 1);
                             const int row = (r & 3) + 8 * (r >> 2) + 4 * half;
                             const int g = base + tile * 32 + row;
                             const float4 p = sP[buf][tile * 32 + row];
@@ -242,6 +282,9 @@ __global__ __launch_bounds__(256) void nn_mfma_kernel(const float* __restrict__ 
         __syncthreads();
         buf ^= 1;
     }
+#ifdef FDC_NN_STATS
+    for (int i = 0; i < 3; ++i) atomicAdd(&g_nn_stats[i], (unsigned long long)st_cnt[i]);
+#endif
 #pragma unroll
     for (int n = 0; n < NQ; ++n) {
         float od = __shfl_xor(own_d[n], 32, 64);

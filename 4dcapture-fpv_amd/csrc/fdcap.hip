@@ -121,7 +121,7 @@ __global__ __launch_bounds__(256) void skin_bwd_kernel(SkinModel sm, int nc, con
         float dterm;
         float term = contact_term(dist[qi], &dterm);
         int j = idx[qi];
-        float4 p = scene[j];
+        float4 p = j >= 0 ? scene[j] : make_float4(Vw[3 * qi], Vw[3 * qi + 1], Vw[3 * qi + 2], 0.f);   // no neighbour (NaN query): zero gradient
         float gg = 2.f * coef * dterm;
         V3 g = v3(gg * (Vw[3 * qi] - p.x), gg * (Vw[3 * qi + 1] - p.y), gg * (Vw[3 * qi + 2] - p.z));
         SkinFwd f = skin_forward_vertex(sm, c, x + X_BETAS, Voff + 3 * qi, A + (size_t)r * NJ * 12, transl,
@@ -432,6 +432,16 @@ int vposer_forward(fdcap_ctx* c, const float* X, int ldx, int latent_off, int ro
 extern "C" {
 
 const char* fdcap_version(void) { return "fdcap-hip 0.2 (gfx950)"; }
+
+#ifdef FDC_NN_STATS
+int fdcap_debug_nn_stats(unsigned long long* out) {
+    HIP_TRY(hipDeviceSynchronize());
+    HIP_TRY(hipMemcpyFromSymbol(out, HIP_SYMBOL(g_nn_stats), 4 * sizeof(unsigned long long)));
+    unsigned long long z[4] = {0, 0, 0, 0};
+    HIP_TRY(hipMemcpyToSymbol(HIP_SYMBOL(g_nn_stats), z, sizeof(z)));
+    return 0;
+}
+#endif
 
 int fdcap_set_nn_kernel(int32_t mode) {
     if (mode < 0 || mode > 2) return FDCAP_E_ARG;

@@ -89,8 +89,8 @@ def cpu_baseline(bm, vp, clip, scene, vid, args):
 
     F = args.cpu_sample_frames
     if F <= 0:
-        t_probe = best_t * (len(scene) / 65536.0) * 1.3      # seconds per frame-iteration, estimated
-        F = int(max(2, min(args.frames, 12.0 / (3 * max(t_probe, 1e-6)))))
+        t_probe = run(2, 2)[1] / 2.0                         # measured seconds per frame-iteration
+        F = int(max(2, min(args.frames, 10.0 / (3 * max(t_probe, 1e-6)))))
     ts = run(F, 3)
     t_iter = float(np.mean(ts[1:]))
     fps = F / (t_iter * args.iters)
@@ -167,7 +167,7 @@ def main():
     pairs = float(nl) * nc * ns
     sec = ms.value * 1e-3
     ach = alg_bytes / sec / 1e9
-    roofline = {"bound": "hbm", "kernel": "nn_direct_kernel (Chamfer body->scene NN, fwd)", "achieved": ach,
+    roofline = {"bound": "hbm", "kernel": "fdc::nn_mfma_kernel<4> (Chamfer body->scene NN forward: bf16-split MFMA filter + exact fp32 re-evaluation)", "achieved": ach,
                 "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "traffic": None,
                 "ms_per_launch": ms.value, "algorithmic_bytes_per_launch": alg_bytes,
                 "compute_side": {"pairs_per_s": pairs / sec, "flop_per_pair": NN_FLOP_PER_PAIR,
