@@ -132,9 +132,13 @@ class HostPipeline:
         self.lib.h_param_loss(P(X), P(X0), P(mask), P(fw["Jw"]), row0, n_own, frame0, N, ctypes.c_float(w_rec),
                               ctypes.c_float(w_sm), ctypes.c_float(w_ws), 1 if phase2 else 0, P(dX), P(dJw),
                               P(losses, dp))
+        # everything below touches owned rows only (halo rows exist for the temporal stencils)
+        o = slice(row0, row0 + n_own)
+        Xo, CAMo = f32(X[o]), f32(CAM[o])
+        fwo = {k: f32(v[o]) for k, v in fw.items()}
         dA = dPF = dMv = dsv = dbeta_v = dtransl_v = None
         if contact_on:
-            Voff, Vw = self.contact_forward(X, fw, scale)
+            Voff, Vw = self.contact_forward(Xo, fwo, scale)
             q = torch.from_numpy(Vw.reshape(-1, 3))
             d, idx = nn_direct(q, torch.from_numpy(self.scene))
             dist = f32(d.numpy())
@@ -142,28 +146,29 @@ class HostPipeline:
             fw["Vw"], fw["dist"], fw["idx"] = Vw, dist, idx
         if contact_grad:
             coef = np.float32(cfg["phase1_contact"] * cfg["weight_contact"] / (np.float32(N) * self.nc))
-            dVoff = np.zeros((n, 3 * self.nc), np.float32)
-            dA = np.zeros((n, NJ * 12), np.float32)
-            dbeta_v = np.zeros((n, 10), np.float32)
-            dtransl_v = np.zeros((n, 3), np.float32)
-            dMv = np.zeros((n, 12), np.float32)
-            dsv = np.zeros(n, np.float32)
+            dVoff = np.zeros((n_own, 3 * self.nc), np.float32)
+            dA = np.zeros((n_own, NJ * 12), np.float32)
+            dbeta_v = np.zeros((n_own, 10), np.float32)
+            dtransl_v = np.zeros((n_own, 3), np.float32)
+            dMv = np.zeros((n_own, 12), np.float32)
+            dsv = np.zeros(n_own, np.float32)
             lc = np.zeros(1, np.float64)
-            self.lib.h_skin_backward(self.nc, self.K, P(self.vt), P(self.S), P(self.wj, ip), P(self.ww), n, P(X),
-                                     P(Voff), P(fw["A"]), P(fw["M"]), ctypes.c_float(scale), P(Vw), P(dist),
+            self.lib.h_skin_backward(self.nc, self.K, P(self.vt), P(self.S), P(self.wj, ip), P(self.ww), n_own, P(Xo),
+                                     P(Voff), P(fwo["A"]), P(fwo["M"]), ctypes.c_float(scale), P(Vw), P(dist),
                                      P(idx, ip), P(self.scene4), ctypes.c_float(coef), P(dVoff), P(dA), P(dbeta_v),
                                      P(dtransl_v), P(dMv), P(dsv), P(lc, dp))
             losses[3] = lc[0]
             dPF = f32(dVoff @ self.Pc.T)
-        dO = np.zeros((n, ODIM), np.float32)
-        dCAM = np.zeros((n, 16), np.float32)
-        dscale_row = np.zeros(n, np.float32)
-        self.lib.h_pose_backward(self.h, n, P(X), P(fw["O"]), P(CAM), ctypes.c_float(scale), P(fw["Rm"]),
-                                 P(fw["Jrest"]), P(fw["G"]), P(dA), P(dPF), P(dJw) if phase2 else None, P(dMv),
-                                 P(dsv), P(dbeta_v), P(dtransl_v), P(dX), P(dO), P(dCAM), P(dscale_row))
-        dX[:, 19:51] += self.mlp_backward(dO, fw["h1"], fw["h2"])
-        return dict(dX=dX, dCAM=dCAM.reshape(n, 4, 4), dscale=float(dscale_row[row0:row0 + n_own].sum()),
-                    losses=losses, fw=fw)
+        dXo = f32(dX[o])
+        dJwo = f32(dJw[o])
+        dO = np.zeros((n_own, ODIM), np.float32)
+        dCAM = np.zeros((n_own, 16), np.float32)
+        dscale_row = np.zeros(n_own, np.float32)
+        self.lib.h_pose_backward(self.h, n_own, P(Xo), P(fwo["O"]), P(CAMo), ctypes.c_float(scale), P(fwo["Rm"]),
+                                 P(fwo["Jrest"]), P(fwo["G"]), P(dA), P(dPF), P(dJwo) if phase2 else None, P(dMv),
+                                 P(dsv), P(dbeta_v), P(dtransl_v), P(dXo), P(dO), P(dCAM), P(dscale_row))
+        dXo[:, 19:51] += self.mlp_backward(dO, fwo["h1"], fwo["h2"])
+        return dict(dX=dXo, dCAM=dCAM.reshape(n_own, 4, 4), dscale=float(dscale_row.sum()), losses=losses, fw=fw)
 
     def adam(self, p, m, v, g, lr, step, zero_grad=False):
         self.lib.h_adam(P(p), P(m), P(v), P(g), ctypes.c_int64(p.size), ctypes.c_double(lr), step,
