@@ -130,7 +130,8 @@ __device__ __forceinline__ float mf_thr(float best, float X, float X2) {
 template <int NQ>
 __global__ __launch_bounds__(256) void nn_mfma_kernel(const float* __restrict__ q, int nq,
                                                       const float4* __restrict__ tgt, int nt, int nsplit,
-                                                      float* __restrict__ pd, int* __restrict__ pi) {
+                                                      const int* __restrict__ seed, float* __restrict__ pd,
+                                                      int* __restrict__ pi) {
     __shared__ uint4 sA[2][MF_CH / 32][2][32];     // [buffer][tile][k-half][point] bf16 x 8
     __shared__ float4 sP[2][MF_CH];                // fp32 coordinates for the exact re-evaluation
     __shared__ float sred[4][4];
@@ -187,19 +188,40 @@ __global__ __launch_bounds__(256) void nn_mfma_kernel(const float* __restrict__ 
         own_d[n] = INFINITY;
         own_i[n] = -1;
         thr[n] = (qidx[n] < nq) ? INFINITY : -INFINITY;     // padding queries are never flagged
+        // Optional seed (the optimiser passes last iteration's neighbour): an exact upper bound
+        // from the first tile on.  It only prunes -- ties and anything closer still reach the exact
+        // path and win by the (d, index) order -- so the result does not depend on it.
+        if (seed != nullptr && qidx[n] < nq) {
+            const int sj = seed[qidx[n]];
+            if (sj >= 0 && sj < nt) {
+                const float4 p = tgt[sj];
+                own_d[n] = nn_exact_d2(qx[n], qy[n], qz[n], p.x, p.y, p.z);
+                own_i[n] = sj;
+                thr[n] = mf_thr(own_d[n], X[n], X2[n]);
+            }
+        }
     }
 #ifdef FDC_NN_STATS
     unsigned st_cnt[3] = {0, 0, 0};
 #endif
     const f32x16_t zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
 
-    // stage one chunk of the scene: centre, split to bf16, store MFMA A fragments + fp32 copy
-    auto stage = [&](int buf, int base) {
+    // stage one chunk of the scene (issue-early / write-late): the global loads of chunk c+1 are
+    // issued before chunk c's MFMA loop, the centre/split/LDS-write happens after it
+    float4 pre[MF_CH / 256];
+    auto stage_load = [&](int base) {
+#pragma unroll
+        for (int it = 0; it < MF_CH / 256; ++it) {
+            int g = base + tid + it * 256;
+            pre[it] = (g < t_end) ? tgt[g] : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+    };
+    auto stage_write = [&](int buf, int base) {
 #pragma unroll
         for (int it = 0; it < MF_CH / 256; ++it) {
             int j = tid + it * 256;
             int g = base + j;
-            float4 p = (g < t_end) ? tgt[g] : make_float4(0.f, 0.f, 0.f, 0.f);
+            float4 p = pre[it];
             float yx = p.x - cx, yy = p.y - cy, yz = p.z - cz;
             float n2 = __fmaf_rn(yz, yz, __fmaf_rn(yy, yy, yx * yx));
             if (g >= t_end) { yx = yy = yz = 0.f; n2 = 1e30f; }   // padding rows: score 1e30, never below a finite thr
@@ -216,14 +238,11 @@ __global__ __launch_bounds__(256) void nn_mfma_kernel(const float* __restrict__ 
     };
 
     int buf = 0;
-    if (t_begin < t_end) stage(0, t_begin);
+    if (t_begin < t_end) { stage_load(t_begin); stage_write(0, t_begin); }
     __syncthreads();
     for (int base = t_begin; base < t_end; base += MF_CH) {
-#if defined(FDC_NN_EXP) && FDC_NN_EXP >= 3
-        if (base == t_begin) stage(buf ^ 1, base);   // experiment: no per-chunk staging
-#else
-        if (base + MF_CH < t_end) stage(buf ^ 1, base + MF_CH);
-#endif
+        const bool more = base + MF_CH < t_end;
+        if (more) stage_load(base + MF_CH);
         const int ntile = (min(MF_CH, t_end - base) + 31) >> 5;
         // software pipeline: the next tile's A fragment is fetched from LDS and the next MFMA is
         // issued before the current result is reduced, so the matrix pipe, the LDS read and the
@@ -279,6 +298,7 @@ __global__ __launch_bounds__(256) void nn_mfma_kernel(const float* __restrict__ 
                 }
             }
         }
+        if (more) stage_write(buf ^ 1, base + MF_CH);
         __syncthreads();
         buf ^= 1;
     }
@@ -305,7 +325,8 @@ __global__ void nn_combine_kernel(const float* __restrict__ pd, const int* __res
     int bi = -1;
     for (int s = 0; s < nsplit; ++s) {
         float d = pd[(size_t)s * nq + qi];
-        if (d < best) { best = d; bi = pi[(size_t)s * nq + qi]; }
+        int j = pi[(size_t)s * nq + qi];
+        if (j >= 0 && (d < best || (d == best && j < bi))) { best = d; bi = j; }
     }
     dist[qi] = best;
     idx[qi] = bi;
@@ -358,12 +379,13 @@ static inline int nn_pick_nsplit(int nq, int nt) {
 }
 
 // workspace: pd/pi [nsplit*nq]
+// seed: optional [nq] previous neighbour indices (may alias idx; read before idx is rewritten)
 static inline hipError_t nn_search(const float* q, int nq, const float4* tgt, int nt, float* dist, int* idx,
-                                   float* pd, int* pi, int nsplit, hipStream_t st) {
+                                   float* pd, int* pi, int nsplit, hipStream_t st, const int* seed = nullptr) {
     if (nq <= 0) return hipSuccess;
     int qblocks = (nq + 511) / 512;
     if (nn_use_mfma(nq, nt))
-        hipLaunchKernelGGL((nn_mfma_kernel<4>), dim3(qblocks * nsplit), dim3(256), 0, st, q, nq, tgt, nt, nsplit, pd, pi);
+        hipLaunchKernelGGL((nn_mfma_kernel<4>), dim3(qblocks * nsplit), dim3(256), 0, st, q, nq, tgt, nt, nsplit, seed, pd, pi);
     else
         hipLaunchKernelGGL((nn_direct_kernel<2>), dim3(qblocks * nsplit), dim3(256), 0, st, q, nq, tgt, nt, nsplit, pd, pi);
     hipLaunchKernelGGL(nn_combine_kernel, dim3((nq + 255) / 256), dim3(256), 0, st, pd, pi, nsplit, nq, dist, idx);

@@ -14,6 +14,11 @@ struct SkinModel {
     const int* wj;        // [V,K] joint ids of the non-zero skinning weights (padded with 0)
     const float* ww;      // [V,K] weights (padded with 0.0)
     int K;
+    // transpose of the sparse weights (per joint: vertices ascending) for the ordered, atomic-free
+    // reduction of d loss / d A_j in the backward
+    const int* csc_start; // [56]
+    const int* csc_v;     // [nnz]
+    const float* csc_w;   // [nnz]
 };
 
 struct SkinFwd { V3 vp, vb, vw; float T[12]; };

@@ -104,46 +104,64 @@ __global__ __launch_bounds__(256) void skin_bwd_kernel(SkinModel sm, int nc, con
                                                        float* __restrict__ dbeta_v, float* __restrict__ dtransl_v,
                                                        float* __restrict__ dMv, float* __restrict__ dsv,
                                                        double* __restrict__ loss_contact_sum) {
-    __shared__ float sdA[NJ * 12];
+    constexpr int VCH = 1024;                      // vertices per LDS chunk
+    constexpr int NOUT = (NJ * 12 + 255) / 256;    // d loss / d A elements per thread
+    __shared__ float sdT[VCH * 12];
     __shared__ float sred[4][SKB_NACC];
     const int tid = threadIdx.x;
     const int r = row0 + blockIdx.x;
-    for (int i = tid; i < NJ * 12; i += 256) sdA[i] = 0.f;
-    __syncthreads();
     const float* x = X + (size_t)r * XDIM;
     const float s = *scale;
     V3 transl = v3(x[X_TRANSL], x[X_TRANSL + 1], x[X_TRANSL + 2]);
     float acc[SKB_NACC];
 #pragma unroll
     for (int i = 0; i < SKB_NACC; ++i) acc[i] = 0.f;
-    for (int c = tid; c < nc; c += 256) {
-        size_t qi = (size_t)r * nc + c;
-        float dterm;
-        float term = contact_term(dist[qi], &dterm);
-        int j = idx[qi];
-        float4 p = j >= 0 ? scene[j] : make_float4(Vw[3 * qi], Vw[3 * qi + 1], Vw[3 * qi + 2], 0.f);   // no neighbour (NaN query): zero gradient
-        float gg = 2.f * coef * dterm;
-        V3 g = v3(gg * (Vw[3 * qi] - p.x), gg * (Vw[3 * qi + 1] - p.y), gg * (Vw[3 * qi + 2] - p.z));
-        SkinFwd f = skin_forward_vertex(sm, c, x + X_BETAS, Voff + 3 * qi, A + (size_t)r * NJ * 12, transl,
-                                        M + (size_t)r * 12, s);
-        SkinBwd b = skin_backward_vertex(f, M + (size_t)r * 12, s, g);
-        dVoff[3 * qi] = b.dvp.x; dVoff[3 * qi + 1] = b.dvp.y; dVoff[3 * qi + 2] = b.dvp.z;
-        for (int l = 0; l < NBETA; ++l)
-            acc[l] += sm.S[(3 * c) * 10 + l] * b.dvp.x + sm.S[(3 * c + 1) * 10 + l] * b.dvp.y +
-                      sm.S[(3 * c + 2) * 10 + l] * b.dvp.z;
-        acc[NBETA] += b.gv.x; acc[NBETA + 1] += b.gv.y; acc[NBETA + 2] += b.gv.z;
+    // ordered (atomic-free, run-to-run reproducible) reduction of dA_j = sum_v w_vj dT_v: each thread owns
+    // up to NOUT elements (j, e) and walks joint j's vertex list (ascending) chunk by chunk
+    float accA[NOUT];
+    int ptr[NOUT], pend[NOUT];
 #pragma unroll
-        for (int e = 0; e < 12; ++e) acc[NBETA + 3 + e] += b.dM[e];
-        acc[NBETA + 15] += b.ds;
-        acc[NBETA + 16] += term;
-        for (int k = 0; k < sm.K; ++k) {
-            float w = sm.ww[c * sm.K + k];
-            if (w != 0.f) {
-                int jj = sm.wj[c * sm.K + k];
+    for (int k = 0; k < NOUT; ++k) {
+        int o = tid + k * 256;
+        accA[k] = 0.f;
+        ptr[k] = o < NJ * 12 ? sm.csc_start[o / 12] : 0;
+        pend[k] = o < NJ * 12 ? sm.csc_start[o / 12 + 1] : 0;
+    }
+    for (int c0 = 0; c0 < nc; c0 += VCH) {
+        const int c1 = min(nc, c0 + VCH);
+        for (int c = c0 + tid; c < c1; c += 256) {
+            size_t qi = (size_t)r * nc + c;
+            float dterm;
+            float term = contact_term(dist[qi], &dterm);
+            int j = idx[qi];
+            float4 p = j >= 0 ? scene[j] : make_float4(Vw[3 * qi], Vw[3 * qi + 1], Vw[3 * qi + 2], 0.f);   // no neighbour (NaN query): zero gradient
+            float gg = 2.f * coef * dterm;
+            V3 g = v3(gg * (Vw[3 * qi] - p.x), gg * (Vw[3 * qi + 1] - p.y), gg * (Vw[3 * qi + 2] - p.z));
+            SkinFwd f = skin_forward_vertex(sm, c, x + X_BETAS, Voff + 3 * qi, A + (size_t)r * NJ * 12, transl,
+                                            M + (size_t)r * 12, s);
+            SkinBwd b = skin_backward_vertex(f, M + (size_t)r * 12, s, g);
+            dVoff[3 * qi] = b.dvp.x; dVoff[3 * qi + 1] = b.dvp.y; dVoff[3 * qi + 2] = b.dvp.z;
+            for (int l = 0; l < NBETA; ++l)
+                acc[l] += sm.S[(3 * c) * 10 + l] * b.dvp.x + sm.S[(3 * c + 1) * 10 + l] * b.dvp.y +
+                          sm.S[(3 * c + 2) * 10 + l] * b.dvp.z;
+            acc[NBETA] += b.gv.x; acc[NBETA + 1] += b.gv.y; acc[NBETA + 2] += b.gv.z;
 #pragma unroll
-                for (int e = 0; e < 12; ++e) atomicAdd(&sdA[jj * 12 + e], w * b.dT[e]);
+            for (int e = 0; e < 12; ++e) acc[NBETA + 3 + e] += b.dM[e];
+            acc[NBETA + 15] += b.ds;
+            acc[NBETA + 16] += term;
+#pragma unroll
+            for (int e = 0; e < 12; ++e) sdT[(c - c0) * 12 + e] = b.dT[e];
+        }
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < NOUT; ++k) {
+            const int e = (tid + k * 256) % 12;
+            while (ptr[k] < pend[k] && sm.csc_v[ptr[k]] < c1) {
+                accA[k] += sm.csc_w[ptr[k]] * sdT[(sm.csc_v[ptr[k]] - c0) * 12 + e];
+                ++ptr[k];
             }
         }
+        __syncthreads();
     }
 #pragma unroll
     for (int i = 0; i < SKB_NACC; ++i) {
@@ -151,7 +169,9 @@ __global__ __launch_bounds__(256) void skin_bwd_kernel(SkinModel sm, int nc, con
         if ((tid & 63) == 0) sred[tid >> 6][i] = v;
     }
     __syncthreads();
-    for (int i = tid; i < NJ * 12; i += 256) dA[(size_t)r * NJ * 12 + i] = sdA[i];
+#pragma unroll
+    for (int k = 0; k < NOUT; ++k)
+        if (tid + k * 256 < NJ * 12) dA[(size_t)r * NJ * 12 + tid + k * 256] = accA[k];
     if (tid < SKB_NACC) {
         float v = sred[0][tid] + sred[1][tid] + sred[2][tid] + sred[3][tid];
         if (tid < NBETA) dbeta_v[(size_t)r * NBETA + tid] = v;
@@ -326,10 +346,14 @@ struct DevBuf {
 
 struct SkinSet {          // skinning constants for a vertex set (all V, or the contact subset)
     int nv = 0, K = 0;
-    DevBuf<float> vt, S, ww, posedirs;   // posedirs [486, 3*nv]
-    DevBuf<int> wj;
-    SkinModel model() const { SkinModel m; m.vt = vt.p; m.S = S.p; m.wj = wj.p; m.ww = ww.p; m.K = K; return m; }
-    void release() { vt.release(); S.release(); ww.release(); posedirs.release(); wj.release(); }
+    DevBuf<float> vt, S, ww, posedirs, csc_w;   // posedirs [486, 3*nv]
+    DevBuf<int> wj, csc_start, csc_v;
+    SkinModel model() const {
+        SkinModel m; m.vt = vt.p; m.S = S.p; m.wj = wj.p; m.ww = ww.p; m.K = K;
+        m.csc_start = csc_start.p; m.csc_v = csc_v.p; m.csc_w = csc_w.p;
+        return m;
+    }
+    void release() { vt.release(); S.release(); ww.release(); posedirs.release(); wj.release(); csc_w.release(); csc_start.release(); csc_v.release(); }
 };
 
 struct OptState {
@@ -346,6 +370,7 @@ struct OptState {
     DevBuf<int> idx, pi;
     DevBuf<float> dA, dbeta_v, dtransl_v, dMv, dsv, dPF, dJw, dX, dCAM, dscale_row;
     int cam_steps = 0;
+    bool use_seed = true;     // last iteration's neighbours seed the NN bound (pruning only)
 };
 
 }  // namespace
@@ -406,7 +431,21 @@ int build_skin_set(fdcap_ctx* c, const std::vector<int64_t>& ids, SkinSet* out) 
         for (int i = 0; i < nv; ++i)
             for (int k = 0; k < 3; ++k)
                 pd[(size_t)r * 3 * nv + 3 * i + k] = c->h_posedirs[(size_t)r * 3 * V + 3 * ids[i] + k];
+    std::vector<int> csc_start(NJ + 1, 0), csc_v;
+    std::vector<float> csc_w;
+    for (int j = 0; j < NJ; ++j) {
+        csc_start[j] = (int)csc_v.size();
+        for (int i = 0; i < nv; ++i) {
+            float w = c->h_lbs[(size_t)ids[i] * NJ + j];
+            if (w != 0.f) { csc_v.push_back(i); csc_w.push_back(w); }
+        }
+    }
+    csc_start[NJ] = (int)csc_v.size();
+    if (csc_v.empty()) { csc_v.push_back(0); csc_w.push_back(0.f); }
     out->nv = nv; out->K = K;
+    HIP_TRY(out->csc_start.upload(csc_start.data(), csc_start.size()));
+    HIP_TRY(out->csc_v.upload(csc_v.data(), csc_v.size()));
+    HIP_TRY(out->csc_w.upload(csc_w.data(), csc_w.size()));
     HIP_TRY(out->vt.upload(vt.data(), vt.size()));
     HIP_TRY(out->S.upload(S.data(), S.size()));
     HIP_TRY(out->ww.upload(ww.data(), ww.size()));
@@ -723,7 +762,13 @@ int fdcap_opt_create(fdcap_ctx* c, const fdcap_opt_config* cfg, float* rows_x, f
         AL(o->pd, (size_t)o->nsplit * nq) AL(o->pi, (size_t)o->nsplit * nq)
     }
 #undef AL
+    if (!err && o->contact_on) {
+        hipError_t e_ = hipMemset(o->idx.p, 0xFF, nq * sizeof(int));      // -1: no seed yet
+        if (e_ != hipSuccess) err = (int)e_;
+    }
     if (!err) {
+        const char* e = getenv("FDCAP_NN_SEED");
+        o->use_seed = !(e && e[0] == '0');
         float s = cfg->scale_init;
         hipError_t e_ = hipMemcpy(o->scale.p, &s, sizeof(float), hipMemcpyHostToDevice);
         if (e_ != hipSuccess) err = (int)e_;
@@ -755,7 +800,7 @@ static int opt_contact_forward(fdcap_ctx* c, hipStream_t st) {
                        X_BETAS, X_TRANSL, o->Voff.p, o->A.p, o->M.p, o->scale.p, 2, 1, o->Vw.p);
     const int nq = nl * nc;
     HIP_TRY(nn_search(o->Vw.p + off, nq, c->scene.p, (int)c->ns, o->dist.p + 2 * nc, o->idx.p + 2 * nc, o->pd.p, o->pi.p,
-                      o->nsplit, st));
+                      o->nsplit, st, o->use_seed ? o->idx.p + 2 * nc : nullptr));
     return 0;
 }
 
@@ -859,6 +904,17 @@ int fdcap_opt_forward_world(fdcap_ctx* c, float* verts, float* joints, void* str
     return (int)hipGetLastError();
 }
 
+int fdcap_opt_get_contact(fdcap_ctx* c, float* dist, int32_t* idx, void* stream) {
+    if (!c || !c->opt) return FDCAP_E_STATE;
+    OptState* o = c->opt;
+    if (!o->contact_on) return FDCAP_E_STATE;
+    hipStream_t st = (hipStream_t)stream;
+    const size_t n = (size_t)o->cfg.n_local * c->nc;
+    if (dist) HIP_TRY(hipMemcpyAsync(dist, o->dist.p + 2 * c->nc, n * sizeof(float), hipMemcpyDeviceToDevice, st));
+    if (idx) HIP_TRY(hipMemcpyAsync(idx, o->idx.p + 2 * c->nc, n * sizeof(int), hipMemcpyDeviceToDevice, st));
+    return FDCAP_OK;
+}
+
 int fdcap_opt_get_grads(fdcap_ctx* c, float* dx, float* dcam, void* stream) {
     if (!c || !c->opt) return FDCAP_E_STATE;
     OptState* o = c->opt;
@@ -879,12 +935,13 @@ int fdcap_opt_time_chamfer(fdcap_ctx* c, int32_t iters, float* ms, void* stream)
     hipEvent_t e0, e1;
     HIP_TRY(hipEventCreate(&e0));
     HIP_TRY(hipEventCreate(&e1));
+    const int* seed = o->use_seed ? o->idx.p + 2 * nc : nullptr;   // steady state of the loop: seeded by the previous result
     HIP_TRY(nn_search(o->Vw.p + off, nl * nc, c->scene.p, (int)c->ns, o->dist.p + 2 * nc, o->idx.p + 2 * nc, o->pd.p, o->pi.p,
-                      o->nsplit, st));
+                      o->nsplit, st, seed));
     HIP_TRY(hipEventRecord(e0, st));
     for (int i = 0; i < iters; ++i)
         HIP_TRY(nn_search(o->Vw.p + off, nl * nc, c->scene.p, (int)c->ns, o->dist.p + 2 * nc, o->idx.p + 2 * nc, o->pd.p,
-                          o->pi.p, o->nsplit, st));
+                          o->pi.p, o->nsplit, st, seed));
     HIP_TRY(hipEventRecord(e1, st));
     HIP_TRY(hipEventSynchronize(e1));
     float t = 0.f;

@@ -169,6 +169,10 @@ void fdcap_opt_destroy(fdcap_ctx* ctx);
 /* World-space contact vertices / joints of the current state (testing + viewers):
  * verts_d [n_local,nc,3] (optional), joints_d [n_local,23,3] (optional). */
 int fdcap_opt_forward_world(fdcap_ctx* ctx, float* verts_d, float* joints_d, void* stream);
+/* Nearest-neighbour result of the last contact forward (testing): dist_d [n_local,nc] squared
+ * distances, idx_d [n_local,nc] scene indices.  The optimiser seeds each search with the previous
+ * call's idx (an exact upper bound that only prunes; FDCAP_NN_SEED=0 disables). */
+int fdcap_opt_get_contact(fdcap_ctx* ctx, float* dist_d, int32_t* idx_d, void* stream);
 /* Gradients of the last fdcap_opt_backward (testing): dx_d [n_local,78], dcam_d [n_local,16]. */
 int fdcap_opt_get_grads(fdcap_ctx* ctx, float* dx_d, float* dcam_d, void* stream);
 

@@ -313,6 +313,55 @@ def test_trajectory_matches_reference_golden(golden_dir, name):
     fop.close()
 
 
+def test_seeding_the_nn_bound_does_not_change_results():
+    """The optimiser seeds each NN search with the previous call's neighbour (an exact upper bound
+    that only prunes): cold search, search seeded by its own result, and search seeded by a STALE
+    result (state moved in between) must all equal the unseeded answer bit for bit."""
+    n = 64
+    clip_x = None
+
+    def contact(fop):
+        d = torch.empty(n, len(fop.vid), device="cuda")
+        i = torch.empty(n, len(fop.vid), device="cuda", dtype=torch.int32)
+        capi.check(fop.ctx.lib.fdcap_opt_forward_world(fop.ctx.handle, capi.dptr(torch.empty(n, len(fop.vid), 3, device="cuda")),
+                                                       None, capi.current_stream()), "fw")
+        capi.check(fop.ctx.lib.fdcap_opt_get_contact(fop.ctx.handle, capi.dptr(d), capi.dptr(i), capi.current_stream()), "gc")
+        torch.cuda.synchronize()
+        return d.clone(), i.clone()
+
+    res = {}
+    for flag in ("0", "1"):
+        os.environ["FDCAP_NN_SEED"] = flag
+        fop, bm, vp, clip, scene, vid = _make_fop(n, 300, 70_000, 40, 8, seed=60)
+        x78 = torch.empty(n, 78, device="cuda")
+        capi.check(fop.ctx.lib.fdcap_params_75_to_78(capi.dptr(torch.tensor(clip.body_params).cuda()), n, capi.dptr(x78),
+                                                     capi.current_stream()), "75->78")
+        fop.init(x78)
+        a = contact(fop)                 # cold
+        b = contact(fop)                 # seeded by its own result (flag 1)
+        g = torch.Generator(device="cuda").manual_seed(3)
+        fop._rows_x[2:2 + n, 0:3] += 0.03 * torch.randn(n, 3, device="cuda", generator=g)     # move the bodies
+        fop._rows_x[2:2 + n, 19:51] += 0.05 * torch.randn(n, 32, device="cuda", generator=g)
+        c = contact(fop)                 # seeded by a stale result (flag 1)
+        res[flag] = (a, b, c)
+        fop.close()
+    os.environ.pop("FDCAP_NN_SEED")
+    for k in range(3):
+        assert torch.equal(res["0"][k][0], res["1"][k][0]) and torch.equal(res["0"][k][1], res["1"][k][1]), k
+    assert not torch.equal(res["1"][1][1], res["1"][2][1])       # the stale seeds really were stale
+
+
+def test_runs_are_bit_reproducible():
+    """No float atomics on the gradient path: two runs of the same clip give identical bits."""
+    outs = []
+    for _ in range(2):
+        fop, bm, vp, clip, scene, vid = _make_fop(48, 300, 20_000, 40, 12, seed=70)
+        body, scale, cam = fop.fitting(torch.tensor(clip.body_params).cuda(), "global")
+        outs.append((body.clone(), float(scale), cam.clone()))
+        fop.close()
+    assert torch.equal(outs[0][0], outs[1][0]) and outs[0][1] == outs[1][1] and torch.equal(outs[0][2], outs[1][2])
+
+
 def test_no_contact_config_and_ragged_sizes():
     """BASELINE config 1 (8 frames, no scene: rec + temporal only) and awkward sizes."""
     for n, ns in ((8, 0), (3, 0), (17, 1100)):
@@ -332,3 +381,39 @@ def test_library_fails_loudly_without_gpu_fallback(small):
     _, _, ctx = small
     with pytest.raises(capi.FdcapError):
         ops.chamferDist(ctx)(torch.zeros(1, 4, 3), torch.zeros(1, 4, 3))    # host tensors are refused
+
+
+def test_cli_file_interface_end_to_end(tmp_path):
+    """body_gen/results/*/*.pkl + camerapose.txt + scene .ply + body_segments/*.json in,
+    smoothed_body/body_gen_%06d.pkl out (global_optimization.py:658-714), synthetic assets injected."""
+    import json
+    import pickle
+    from fdcap_amd import io
+    n = 10
+    fop, bm, vp, clip, scene, vid = _make_fop(n, 220, 900, 8, 6, seed=40)
+    fop.close()
+    root = tmp_path / "data"
+    body_path = root / "sampleA" / "body_gen"
+    io.write_body_gen(clip.body_params, str(body_path))
+    (root / "sampleA" / "camerapose.txt").write_text("\n".join(clip.camerapose_lines) + "\n")
+    io.write_ply_points(str(root / "sampleA" / "meshed-poisson.ply"), scene)
+    seg = tmp_path / "body_segments"
+    seg.mkdir()
+    half = len(vid) // 2
+    (seg / "L_Leg.json").write_text(json.dumps({"verts_ind": [int(v) for v in vid[:half]], "faces_ind": [0]}))
+    (seg / "R_Leg.json").write_text(json.dumps({"verts_ind": [int(v) for v in vid[half:]], "faces_ind": [0]}))
+    cfg = {"scene_verts_path": str(root / "sampleA" / "meshed-poisson.ply"),
+           "camera_path": str(root / "sampleA" / "camerapose.txt"), "contact_id_folder": str(seg), "num_iter": 6}
+    data = io.load_body_gen(str(body_path))
+    f2 = FittingOP(cfg, {}, n, body_model=bm, vposer=vp)
+    body, scale, cam = f2.fitting(torch.tensor(data).cuda(), "global")
+    files = f2.save_result(body, scale, cam, str(tmp_path / "smoothed_body"))
+    assert len(files) == n
+    d = pickle.load(open(files[-1], "rb"))
+    np.testing.assert_allclose(d["transl"], body[-1:, 0:3].cpu().numpy())
+    np.testing.assert_allclose(d["camera_ext"], cam[-1].cpu().numpy())
+    # same numbers as the array-injected path up to set() ordering of the contact ids (sum order)
+    orc = FittingOracle(SMPLXOracle(bm), VPoserDecoder.from_data(vp), scene, f2.vid, clip.camerapose_lines, n, num_iter=6)
+    ob, osc, _ = orc.fitting(torch.tensor(clip.body_params))
+    assert np.quantile(np.abs(body.cpu().numpy() - ob.numpy()), 0.9) < 1e-4
+    f2.close()

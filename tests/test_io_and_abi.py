@@ -1,0 +1,88 @@
+"""Host-side file boundary (body_gen -> smoothed_body pickles, camerapose.txt, scene readers) and
+the C-ABI surface: the library loads and exports every symbol include/fdcap.h declares (no compute
+calls -- this file runs without a GPU)."""
+import ctypes
+import os
+import pickle
+import re
+
+import numpy as np
+import torch
+
+import fdcap_amd  # noqa: F401
+from fdcap_amd import capi, io, synth
+from oracle.fitting import extract_ext
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_header_symbols_are_exported_and_bound():
+    hdr = open(os.path.join(ROOT, "include", "fdcap.h")).read()
+    declared = set(re.findall(r"^\s*(?:int|void|const char\*)\s+(fdcap_\w+)\s*\(", hdr, flags=re.M))
+    assert len(declared) >= 20
+    lib = capi.load_library()
+    for name in declared:
+        assert hasattr(lib, name), f"{name} declared in include/fdcap.h but not exported"
+    assert declared == set(capi.SYMBOLS), declared ^ set(capi.SYMBOLS)
+    assert lib.fdcap_version().startswith(b"fdcap-hip")
+
+
+def test_struct_layouts_match_header():
+    # 18 pointers/ints of fdcap_model_desc and 13 fields of fdcap_opt_config, natural alignment
+    assert ctypes.sizeof(capi.OptConfig) == 13 * 4
+    assert ctypes.sizeof(capi.ModelDesc) == 8 + 2 * 8 + 8 + 14 * 8   # int32+pad, 2 ptr, int32+pad, 14 ptr
+
+
+def test_body_gen_roundtrip_and_output_schema(tmp_path):
+    clip = synth.make_clip(6, seed=1)
+    io.write_body_gen(clip.body_params, str(tmp_path / "sample" / "body_gen"))
+    got = io.load_body_gen(str(tmp_path / "sample" / "body_gen"))
+    np.testing.assert_array_equal(got, clip.body_params)
+    cam = np.tile(np.eye(4, dtype=np.float32), (6, 1, 1))
+    files = io.save_result(clip.body_params, np.float32(1.7), cam, str(tmp_path / "smoothed_body"))
+    assert [os.path.basename(f) for f in files][:2] == ["body_gen_000000.pkl", "body_gen_000001.pkl"]
+    d = pickle.load(open(files[3], "rb"))
+    # what global_vis.py:116-129 / local_vis.py:309-313 read
+    assert set(d) == {"transl", "global_orient", "betas", "body_pose", "left_hand_pose", "right_hand_pose",
+                      "camera_translation", "scale", "camera_ext"}
+    assert d["body_pose"].shape == (1, 32) and d["betas"].shape == (1, 10) and d["camera_ext"].shape == (4, 4)
+    np.testing.assert_array_equal(d["camera_translation"], clip.body_params[3:4, 72:75])
+    assert float(d["scale"]) == np.float32(1.7)
+
+
+def test_camerapose_parsing_matches_reference_restatement(tmp_path):
+    clip = synth.make_clip(9, seed=2)
+    p = tmp_path / "camerapose.txt"
+    p.write_text("\n".join(clip.camerapose_lines) + "\n")
+    got = io.read_camerapose(str(p))
+    want = extract_ext(clip.camerapose_lines).numpy()
+    np.testing.assert_array_equal(got, want)
+    np.testing.assert_allclose(got, clip.cam_ext, atol=1e-5)       # the lines invert to the generator's poses
+    assert clip.camerapose_lines[0].startswith(" ")                # utils/camerapose_helper.py:27 format
+
+
+def test_scene_readers(tmp_path):
+    pts = synth.make_scene(1234, seed=5)
+    for binary in (True, False):
+        f = str(tmp_path / f"s{int(binary)}.ply")
+        io.write_ply_points(f, pts, binary=binary)
+        np.testing.assert_allclose(io.read_scene_points(f), pts, rtol=0, atol=0 if binary else 1e-7)
+    np.savetxt(tmp_path / "s.xyz", pts)
+    np.testing.assert_allclose(io.read_scene_points(str(tmp_path / "s.xyz")), pts, atol=1e-6)
+
+
+def test_contact_ids_follow_reference_set_semantics(tmp_path):
+    import json
+    (tmp_path / "L_Leg.json").write_text(json.dumps({"verts_ind": [5, 3, 3, 9], "faces_ind": [1]}))
+    (tmp_path / "R_Leg.json").write_text(json.dumps({"verts_ind": [7, 7, 2], "faces_ind": [1]}))
+    vid = io.read_contact_ids(str(tmp_path))
+    assert sorted(vid[:3].tolist()) == [3, 5, 9] and sorted(vid[3:].tolist()) == [2, 7]   # :87 list(set(...)), :90 concat
+
+
+def test_product_package_never_imports_the_oracle():
+    pkg = os.path.join(ROOT, "4dcapture-fpv_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for fn in files:
+            if fn.endswith((".py", ".h", ".hip")):
+                text = open(os.path.join(dirpath, fn)).read()
+                assert "import oracle" not in text and "from oracle" not in text, fn
