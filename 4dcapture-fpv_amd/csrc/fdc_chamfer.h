@@ -1,24 +1,34 @@
-// Body -> scene nearest neighbour (squared L2), brute force over the whole scene.
+// Body -> scene nearest neighbour (squared L2) over the whole scene.
 // Replaces ChamferDistancePytorch's NmDistanceKernel as called at
 // /root/reference/global_optimization.py:292-294 (only dist1 = query -> scene is consumed).
 //
-// Layout decisions (DESIGN.md §4):
-//   * the scene is stored ONCE as float4 {x,y,z,|p|^2} and shared by every frame; all
+// Layout decisions (DESIGN.md §5):
+//   * the scene is stored ONCE as float4 {x, y, z, bits(index)} and shared by every frame; all
 //     frames' contact vertices form one flat query array, so a scene tile staged in LDS is
-//     reused by 256*QPT queries of any frame (the reference re-reads a per-frame scene copy);
+//     reused by every query of a workgroup, whatever frame it belongs to (the reference re-reads a
+//     per-frame copy of the scene);
 //   * the scene is cut into `nsplit` contiguous ranges and workgroup b handles range b % nsplit:
-//     with nsplit = 8 and the observed block -> XCD round-robin each XCD's L2 only ever sees its
-//     own eighth of the scene (speed only; any placement is correct);
-//   * per-split minima are merged by nn_combine_kernel in ascending split order with a strict
-//     `<`, so the result is the lowest index among exact ties, as the ascending scan of the
-//     reference kernel gives.
+//     with the observed block -> XCD round-robin each XCD's L2 only ever sees its own eighth of
+//     the scene (speed only; any placement is correct);
+//   * every kernel reports (d, index) with d from nn_exact_d2 and the LOWEST index among exact
+//     ties -- what the ascending strict-`<` scan of the reference kernel gives -- independent of the
+//     order in which points are visited; per-split minima are merged by the same (d, index) order.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdlib.h>
 
 namespace fdc {
 
-constexpr int NN_TILE = 1024;
+constexpr int NN_TILE = 1024;          // scene points per LDS tile of the plain scan
+constexpr int MF_CH = 512;             // scene points per LDS chunk of the MFMA scan (= bound granularity)
+
+// scene as the NN kernels see it
+struct NNTarget {
+    const float4* pts;        // [n] {x, y, z, bits(original index)}
+    int n;
+    const float4* bounds;     // optional [ceil(n / MF_CH)] {centre xyz, radius} of each chunk (pts spatially sorted)
+    const int* inv_perm;      // optional [n] original index -> position in pts (null: identity)
+};
 
 // The one definition of the squared distance every kernel reports (direct-difference form as
 // the reference CUDA kernel computes it; fixed operation order so all kernels agree bitwise).
@@ -26,18 +36,24 @@ __device__ __forceinline__ float nn_exact_d2(float qx, float qy, float qz, float
     float dx = qx - px, dy = qy - py, dz = qz - pz;
     return __fmaf_rn(dz, dz, __fmaf_rn(dy, dy, __fmul_rn(dx, dx)));
 }
+__device__ __forceinline__ bool nn_better(float d, int i, float bd, int bi) {
+    return d < bd || (d == bd && i < bi);
+}
+__host__ __device__ __forceinline__ int nn_split_len(int nt, int nsplit) {
+    int per = (nt + nsplit - 1) / nsplit;
+    return (per + MF_CH - 1) / MF_CH * MF_CH;             // chunk-aligned so bounds[] indexes uniformly
+}
 
 template <int QPT>
-__global__ __launch_bounds__(256) void nn_direct_kernel(const float* __restrict__ q, int nq,
-                                                        const float4* __restrict__ tgt, int nt, int nsplit,
+__global__ __launch_bounds__(256) void nn_direct_kernel(const float* __restrict__ q, int nq, NNTarget T, int nsplit,
                                                         float* __restrict__ pd, int* __restrict__ pi) {
     __shared__ float4 tile[NN_TILE];
     const int tid = threadIdx.x;
     const int split = blockIdx.x % nsplit;
     const int qb = blockIdx.x / nsplit;
-    const int per = (nt + nsplit - 1) / nsplit;
-    const int t_begin = split * per;
-    const int t_end = min(nt, t_begin + per);
+    const int per = nn_split_len(T.n, nsplit);
+    const int t_begin = min(T.n, split * per);
+    const int t_end = min(T.n, t_begin + per);
     float qx[QPT], qy[QPT], qz[QPT], best[QPT];
     int bi[QPT];
 #pragma unroll
@@ -52,15 +68,16 @@ __global__ __launch_bounds__(256) void nn_direct_kernel(const float* __restrict_
     }
     for (int base = t_begin; base < t_end; base += NN_TILE) {
         const int cnt = min(NN_TILE, t_end - base);
-        for (int j = tid; j < cnt; j += 256) tile[j] = tgt[base + j];
+        for (int j = tid; j < cnt; j += 256) tile[j] = T.pts[base + j];
         __syncthreads();
 #pragma unroll 4
         for (int j = 0; j < cnt; ++j) {
             const float4 p = tile[j];
+            const int gi = __float_as_int(p.w);
 #pragma unroll
             for (int u = 0; u < QPT; ++u) {
                 float d = nn_exact_d2(qx[u], qy[u], qz[u], p.x, p.y, p.z);
-                if (d < best[u]) { best[u] = d; bi[u] = base + j; }
+                if (nn_better(d, gi, best[u], bi[u])) { best[u] = d; bi[u] = gi; }
             }
         }
         __syncthreads();
@@ -75,33 +92,39 @@ __global__ __launch_bounds__(256) void nn_direct_kernel(const float* __restrict_
     }
 }
 
-
 // ---------------------------------------------------------------------------------------------
 // MFMA-filtered exact nearest neighbour.
 //
-// Brute force still visits every (query, scene point) pair, but the per-pair work moves to the
-// matrix cores: one v_mfma_f32_32x32x16_bf16 evaluates 32 scene points x 32 queries of
+// Every (query, scene point) pair that is visited is scored on the matrix cores: one
+// v_mfma_f32_32x32x16_bf16 evaluates 32 scene points x 32 queries of
 //     s_ij = |y'_j|^2 - 2 x'_i . y'_j        (x' = x - c, y' = y - c, c = workgroup's query centroid)
 // with both coordinate vectors split into bf16 hi+lo parts (16 significant bits each) and
 // |y'|^2 into three parts, laid out along K = 16:
 //     A (scene) : [yh_x yh_x yl_x yl_x | yh_y yh_y yl_y yl_y | yh_z yh_z yl_z yl_z | nh nm nl 0]
 //     B (query) : [-2xh_x -2xl_x -2xh_x -2xl_x | ... y ... | ... z ... | 1 1 1 0]
 // The score only FILTERS: |s_ij + |x'_i|^2 - d_ij| <= eps_i (bound below), so a pair is skipped
-// only when s_ij > thr_i = best_i - |x'_i|^2 + eps_i proves d_ij > best_i.  Every surviving pair
-// is re-evaluated with nn_exact_d2 in fp32 and compared (d, index) lexicographically, so the
-// result is bit-identical to nn_direct_kernel (checked on the GPU in tests/test_gpu_parity.py).
+// only when s_ij >= thr_i = best_i - |x'_i|^2 + eps_i proves d_ij > best_i.  Every surviving pair
+// is re-evaluated with nn_exact_d2 in fp32 and compared by (d, index), so the result is
+// bit-identical to nn_direct_kernel (checked on the GPU in tests/test_gpu_parity.py).
 // The VALU's share per MFMA is a 16-way v_min3 tree and one compare.
 //
 // eps_i = K1 * X * Y + K2 * (X^2 + Y^2),  X = |x'_i|,  Y = X + sqrt(best_i) >= |y'_j| for any j
 // that could beat best_i.  Dominant term: each coordinate keeps 16 bits, so the cross term errs
 // by <= 4 * 2^-16 * X * Y = 6.1e-5 X Y; fp32 accumulation, the 3-part norm and the fp32
 // centring add < 2e-6 (X Y + Y^2).  K1 = 1e-4, K2 = 8e-6 leave >= 50 % margin.
-constexpr int MF_CH = 512;             // scene points staged per LDS buffer
+//
+// Two exact accelerators sit on top (both only prune; results do not depend on them):
+//   seed   : an initial neighbour per query (the optimiser passes last iteration's result) gives a
+//            tight bound from the first tile on;
+//   bounds : if the scene is spatially sorted and comes with a bounding sphere per MF_CH-point
+//            chunk, a chunk is skipped when it lies farther from the workgroup's centroid than
+//            Rw = max_i (X_i + sqrt(best_i)) -- no point of it can beat or tie any query's bound.
+//            Without seeds Rw is infinite and the scan is plain brute force.
 constexpr float MF_K1 = 1e-4f, MF_K2 = 8e-6f;
 
 #ifdef FDC_NN_STATS
 // instrumentation build only (never shipped): [0] MFMA results reduced, [1] results that entered
-// the exact path (wave level), [2] rows re-evaluated exactly (lane level)
+// the exact path (wave level), [2] rows re-evaluated exactly (lane level), [3] chunks staged
 __device__ unsigned long long g_nn_stats[4];
 #define FDC_STAT(i, v) st_cnt[i] += (v)
 #else
@@ -128,19 +151,18 @@ __device__ __forceinline__ float mf_thr(float best, float X, float X2) {
 }
 
 template <int NQ>
-__global__ __launch_bounds__(256) void nn_mfma_kernel(const float* __restrict__ q, int nq,
-                                                      const float4* __restrict__ tgt, int nt, int nsplit,
+__global__ __launch_bounds__(256) void nn_mfma_kernel(const float* __restrict__ q, int nq, NNTarget T, int nsplit,
                                                       const int* __restrict__ seed, float* __restrict__ pd,
                                                       int* __restrict__ pi) {
     __shared__ uint4 sA[2][MF_CH / 32][2][32];     // [buffer][tile][k-half][point] bf16 x 8
-    __shared__ float4 sP[2][MF_CH];                // fp32 coordinates for the exact re-evaluation
+    __shared__ float4 sP[2][MF_CH];                // fp32 coordinates (+ index) for the exact re-evaluation
     __shared__ float sred[4][4];
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, half = lane >> 5, col = lane & 31;
     const int split = blockIdx.x % nsplit;
     const int qb = blockIdx.x / nsplit;
-    const int per = (nt + nsplit - 1) / nsplit;
-    const int t_begin = split * per;
-    const int t_end = min(nt, t_begin + per);
+    const int per = nn_split_len(T.n, nsplit);
+    const int t_begin = min(T.n, split * per);
+    const int t_end = min(T.n, t_begin + per);
 
     float qx[NQ], qy[NQ], qz[NQ], own_d[NQ], thr[NQ], X[NQ], X2[NQ];
     int own_i[NQ], qidx[NQ];
@@ -169,8 +191,10 @@ __global__ __launch_bounds__(256) void nn_mfma_kernel(const float* __restrict__ 
     const float cx = (sred[0][0] + sred[1][0] + sred[2][0] + sred[3][0]) / cnt;
     const float cy = (sred[0][1] + sred[1][1] + sred[2][1] + sred[3][1]) / cnt;
     const float cz = (sred[0][2] + sred[1][2] + sred[2][2] + sred[3][2]) / cnt;
+    __syncthreads();                                       // sred is reused below
 
     bf16x8 bfrag[NQ];
+    float reach = 0.f;                                     // max_i (X_i + sqrt(best_i)) over this lane's queries
 #pragma unroll
     for (int n = 0; n < NQ; ++n) {
         float xx = qx[n] - cx, xy = qy[n] - cy, xz = qz[n] - cz;
@@ -188,32 +212,52 @@ __global__ __launch_bounds__(256) void nn_mfma_kernel(const float* __restrict__ 
         own_d[n] = INFINITY;
         own_i[n] = -1;
         thr[n] = (qidx[n] < nq) ? INFINITY : -INFINITY;     // padding queries are never flagged
-        // Optional seed (the optimiser passes last iteration's neighbour): an exact upper bound
-        // from the first tile on.  It only prunes -- ties and anything closer still reach the exact
-        // path and win by the (d, index) order -- so the result does not depend on it.
         if (seed != nullptr && qidx[n] < nq) {
             const int sj = seed[qidx[n]];
-            if (sj >= 0 && sj < nt) {
-                const float4 p = tgt[sj];
+            if (sj >= 0 && sj < T.n) {
+                const float4 p = T.pts[T.inv_perm ? T.inv_perm[sj] : sj];
                 own_d[n] = nn_exact_d2(qx[n], qy[n], qz[n], p.x, p.y, p.z);
                 own_i[n] = sj;
                 thr[n] = mf_thr(own_d[n], X[n], X2[n]);
             }
         }
+        if (qidx[n] < nq) reach = fmaxf(reach, X[n] + sqrtf(own_d[n]));
     }
-#ifdef FDC_NN_STATS
-    unsigned st_cnt[3] = {0, 0, 0};
-#endif
+    // workgroup reach for chunk culling (infinite unless every query is seeded)
+    float Rw = INFINITY;
+    if (T.bounds != nullptr) {
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) reach = fmaxf(reach, __shfl_xor(reach, off, 64));
+        if (lane == 0) sred[wave][0] = reach;
+        __syncthreads();
+        Rw = fmaxf(fmaxf(sred[0][0], sred[1][0]), fmaxf(sred[2][0], sred[3][0]));
+        Rw = Rw * 1.00001f + 1e-6f;                        // rounding of the bound test itself
+    }
     const f32x16_t zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+#ifdef FDC_NN_STATS
+    unsigned st_cnt[4] = {0, 0, 0, 0};
+#endif
 
-    // stage one chunk of the scene (issue-early / write-late): the global loads of chunk c+1 are
-    // issued before chunk c's MFMA loop, the centre/split/LDS-write happens after it
+    // first chunk at or after `base` that may hold a relevant point (workgroup-uniform)
+    auto next_chunk = [&](int base) -> int {
+        if (T.bounds == nullptr || !(Rw < INFINITY)) return base;
+        for (; base < t_end; base += MF_CH) {
+            const float4 b = T.bounds[base / MF_CH];
+            const float dx = b.x - cx, dy = b.y - cy, dz = b.z - cz;
+            const float gap = sqrtf(dx * dx + dy * dy + dz * dz) - b.w;
+            if (!(gap > Rw)) break;
+        }
+        return base;
+    };
+
+    // staging (issue-early / write-late): the global loads of the next chunk are issued before the
+    // current chunk's MFMA loop, the centre / bf16 split / LDS write happens after it
     float4 pre[MF_CH / 256];
     auto stage_load = [&](int base) {
 #pragma unroll
         for (int it = 0; it < MF_CH / 256; ++it) {
             int g = base + tid + it * 256;
-            pre[it] = (g < t_end) ? tgt[g] : make_float4(0.f, 0.f, 0.f, 0.f);
+            pre[it] = (g < t_end) ? T.pts[g] : make_float4(0.f, 0.f, 0.f, __int_as_float(0x7fffffff));
         }
     };
     auto stage_write = [&](int buf, int base) {
@@ -238,15 +282,17 @@ __global__ __launch_bounds__(256) void nn_mfma_kernel(const float* __restrict__ 
     };
 
     int buf = 0;
-    if (t_begin < t_end) { stage_load(t_begin); stage_write(0, t_begin); }
+    int base = next_chunk(t_begin);
+    if (base < t_end) { stage_load(base); stage_write(0, base); }
     __syncthreads();
-    for (int base = t_begin; base < t_end; base += MF_CH) {
-        const bool more = base + MF_CH < t_end;
-        if (more) stage_load(base + MF_CH);
+    while (base < t_end) {
+        const int nxt = next_chunk(base + MF_CH);
+        const bool more = nxt < t_end;
+        if (more) stage_load(nxt);
+        FDC_STAT(3, tid == 0);
         const int ntile = (min(MF_CH, t_end - base) + 31) >> 5;
-        // software pipeline: the next tile's A fragment is fetched from LDS and the next MFMA is
-        // issued before the current result is reduced, so the matrix pipe, the LDS read and the
-        // v_min3 tree of one wave overlap
+        // software pipeline: the next tile's A fragment is fetched from LDS and two MFMAs are in
+        // flight before a result is reduced, so matrix pipe, LDS read and v_min3 tree overlap
         bf16x8 afrag_next = __builtin_bit_cast(bf16x8, sA[buf][0][half][col]);
         for (int tile = 0; tile < ntile; ++tile) {
             const bf16x8 afrag = afrag_next;
@@ -258,8 +304,7 @@ __global__ __launch_bounds__(256) void nn_mfma_kernel(const float* __restrict__ 
             for (int n = 0; n < NQ; ++n) {
                 const f32x16_t acc = acc_q[n];
                 if (n + 2 < NQ) acc_q[n + 2] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afrag, bfrag[n + 2], zero, 0, 0, 0);
-                // 16-way minimum as a depth-3 tree of v_min3 (a serial chain would put 8 dependent
-                // VALU latencies on the wave's critical path)
+                // 16-way minimum as a depth-3 tree of v_min3
                 const float t0 = fminf(fminf(acc[0], acc[1]), acc[2]), t1 = fminf(fminf(acc[3], acc[4]), acc[5]);
                 const float t2 = fminf(fminf(acc[6], acc[7]), acc[8]), t3 = fminf(fminf(acc[9], acc[10]), acc[11]);
                 const float t4 = fminf(fminf(acc[12], acc[13]), acc[14]);
@@ -276,18 +321,18 @@ __global__ __launch_bounds__(256) void nn_mfma_kernel(const float* __restrict__ 
                 if (__any(m < thr[n])) {
 #endif
                     FDC_STAT(1, lane == 0);
-                    // rare path: exact fp32 re-evaluation of the surviving rows, ascending index
+                    // rare path: exact fp32 re-evaluation of the surviving rows
 #pragma unroll
                     for (int r = 0; r < 16; ++r) {
                         if (acc[r] < thr[n]) {
                             FDC_STAT(2, 1);
                             const int row = (r & 3) + 8 * (r >> 2) + 4 * half;
-                            const int g = base + tile * 32 + row;
                             const float4 p = sP[buf][tile * 32 + row];
+                            const int gi = __float_as_int(p.w);
                             const float d = nn_exact_d2(qx[n], qy[n], qz[n], p.x, p.y, p.z);
-                            if (g < t_end && (d < own_d[n] || (d == own_d[n] && g < own_i[n]))) {
+                            if (base + tile * 32 + row < t_end && nn_better(d, gi, own_d[n], own_i[n])) {
                                 own_d[n] = d;
-                                own_i[n] = g;
+                                own_i[n] = gi;
                                 thr[n] = mf_thr(d, X[n], X2[n]);
                             }
                         }
@@ -298,18 +343,19 @@ __global__ __launch_bounds__(256) void nn_mfma_kernel(const float* __restrict__ 
                 }
             }
         }
-        if (more) stage_write(buf ^ 1, base + MF_CH);
+        if (more) stage_write(buf ^ 1, nxt);
         __syncthreads();
         buf ^= 1;
+        base = nxt;
     }
 #ifdef FDC_NN_STATS
-    for (int i = 0; i < 3; ++i) atomicAdd(&g_nn_stats[i], (unsigned long long)st_cnt[i]);
+    for (int i = 0; i < 4; ++i) atomicAdd(&g_nn_stats[i], (unsigned long long)st_cnt[i]);
 #endif
 #pragma unroll
     for (int n = 0; n < NQ; ++n) {
         float od = __shfl_xor(own_d[n], 32, 64);
         int oi = __shfl_xor(own_i[n], 32, 64);
-        if (oi >= 0 && (od < own_d[n] || (od == own_d[n] && (own_i[n] < 0 || oi < own_i[n])))) { own_d[n] = od; own_i[n] = oi; }
+        if (oi >= 0 && (own_i[n] < 0 || nn_better(od, oi, own_d[n], own_i[n]))) { own_d[n] = od; own_i[n] = oi; }
         if (half == 0 && qidx[n] < nq) {
             pd[(size_t)split * nq + qidx[n]] = own_d[n];
             pi[(size_t)split * nq + qidx[n]] = own_i[n];
@@ -326,20 +372,21 @@ __global__ void nn_combine_kernel(const float* __restrict__ pd, const int* __res
     for (int s = 0; s < nsplit; ++s) {
         float d = pd[(size_t)s * nq + qi];
         int j = pi[(size_t)s * nq + qi];
-        if (j >= 0 && (d < best || (d == best && j < bi))) { best = d; bi = j; }
+        if (j >= 0 && (bi < 0 || nn_better(d, j, best, bi))) { best = d; bi = j; }
     }
     dist[qi] = best;
     idx[qi] = bi;
 }
 
+// xyz [n,3] -> float4 {x, y, z, bits(i)}
 __global__ void pack_points_kernel(const float* __restrict__ xyz, int n, float4* __restrict__ out) {
     int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
-    float x = xyz[3 * (size_t)i], y = xyz[3 * (size_t)i + 1], z = xyz[3 * (size_t)i + 2];
-    out[i] = make_float4(x, y, z, x * x + y * y + z * z);
+    out[i] = make_float4(xyz[3 * (size_t)i], xyz[3 * (size_t)i + 1], xyz[3 * (size_t)i + 2], __int_as_float(i));
 }
 
-// d dist / d query: NmDistanceGradKernel restricted to the query side (the scene has no grad)
+// d dist / d query: NmDistanceGradKernel restricted to the query side (the scene has no grad);
+// tgt is indexed by original index
 __global__ void nn_grad_kernel(const float* __restrict__ q, const float4* __restrict__ tgt, const float* __restrict__ g,
                                const int* __restrict__ idx, int nq, float* __restrict__ gq) {
     int qi = blockIdx.x * blockDim.x + threadIdx.x;
@@ -370,24 +417,25 @@ static inline bool nn_use_mfma(int nq, int nt) {
 }
 
 static inline int nn_pick_nsplit(int nq, int nt) {
-    // enough workgroups to fill 256 CUs several times over; 8 = one split per XCD
+    // ~1000-2000 workgroups (256 CUs x 3 resident); each split re-reads the queries / seeds and
+    // writes its own partial minima, so fewer, longer splits win once there are enough query blocks
+    // (measured on 1024 frames x 500 contacts vs 500k points: nsplit 2 beats 1, 4 and 8)
     int qblocks = (nq + 511) / 512;
-    int ns = 8;
-    while (qblocks * ns < 2048 && ns < 64 && nt / (ns * 2) >= NN_TILE) ns *= 2;
-    if (nt < NN_TILE * 8) ns = max(1, nt / NN_TILE);
-    return max(1, ns);
+    int ns = 1;
+    while (qblocks * ns < 1024 && ns < 64 && nt / (ns * 2) >= 4 * MF_CH) ns *= 2;
+    if (qblocks >= 512 && nt >= 8 * MF_CH) ns = max(ns, 2);
+    return ns;
 }
 
-// workspace: pd/pi [nsplit*nq]
-// seed: optional [nq] previous neighbour indices (may alias idx; read before idx is rewritten)
-static inline hipError_t nn_search(const float* q, int nq, const float4* tgt, int nt, float* dist, int* idx,
-                                   float* pd, int* pi, int nsplit, hipStream_t st, const int* seed = nullptr) {
+// workspace: pd/pi [nsplit*nq]; seed: optional [nq] original indices (may alias idx: read before idx is rewritten)
+static inline hipError_t nn_search(const float* q, int nq, const NNTarget& T, float* dist, int* idx, float* pd, int* pi,
+                                   int nsplit, hipStream_t st, const int* seed = nullptr) {
     if (nq <= 0) return hipSuccess;
     int qblocks = (nq + 511) / 512;
-    if (nn_use_mfma(nq, nt))
-        hipLaunchKernelGGL((nn_mfma_kernel<4>), dim3(qblocks * nsplit), dim3(256), 0, st, q, nq, tgt, nt, nsplit, seed, pd, pi);
+    if (nn_use_mfma(nq, T.n))
+        hipLaunchKernelGGL((nn_mfma_kernel<4>), dim3(qblocks * nsplit), dim3(256), 0, st, q, nq, T, nsplit, seed, pd, pi);
     else
-        hipLaunchKernelGGL((nn_direct_kernel<2>), dim3(qblocks * nsplit), dim3(256), 0, st, q, nq, tgt, nt, nsplit, pd, pi);
+        hipLaunchKernelGGL((nn_direct_kernel<2>), dim3(qblocks * nsplit), dim3(256), 0, st, q, nq, T, nsplit, pd, pi);
     hipLaunchKernelGGL(nn_combine_kernel, dim3((nq + 255) / 256), dim3(256), 0, st, pd, pi, nsplit, nq, dist, idx);
     return hipGetLastError();
 }

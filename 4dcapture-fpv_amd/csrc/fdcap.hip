@@ -371,6 +371,7 @@ struct OptState {
     DevBuf<float> dA, dbeta_v, dtransl_v, dMv, dsv, dPF, dJw, dX, dCAM, dscale_row;
     int cam_steps = 0;
     bool use_seed = true;     // last iteration's neighbours seed the NN bound (pruning only)
+    bool use_cull = true;     // skip scene chunks whose bounding sphere is out of every query's reach
 };
 
 }  // namespace
@@ -386,8 +387,15 @@ struct fdcap_ctx {
     DevBuf<float> W1, b1, W2, b2, W3, b3;
     SkinSet full, contact;
     bool full_ready = false;
-    DevBuf<float4> scene;
+    DevBuf<float4> scene;          // original order {x,y,z,bits(i)}: gradient gather by index
+    DevBuf<float4> scene_sorted;   // Morton order {x,y,z,bits(original index)}: what the NN scan streams
+    DevBuf<float4> scene_bounds;   // bounding sphere of each MF_CH-point chunk of scene_sorted
+    DevBuf<int> scene_inv;         // original index -> position in scene_sorted
     int64_t ns = 0;
+    NNTarget nn_target(bool cull) const {
+        NNTarget t; t.pts = scene_sorted.p; t.n = (int)ns; t.bounds = cull ? scene_bounds.p : nullptr; t.inv_perm = scene_inv.p;
+        return t;
+    }
     int nc = 0;
     // growable workspaces for the stand-alone operators
     DevBuf<float> ws_f[12];
@@ -538,7 +546,7 @@ void fdcap_ctx_destroy(fdcap_ctx* c) {
     c->Jt.release(); c->Jd.release(); c->hand_comp.release(); c->hand_mean.release();
     c->parents.release(); c->order.release(); c->level_start.release(); c->child_start.release(); c->child_list.release();
     c->W1.release(); c->b1.release(); c->W2.release(); c->b2.release(); c->W3.release(); c->b3.release();
-    c->full.release(); c->contact.release(); c->scene.release();
+    c->full.release(); c->contact.release(); c->scene.release(); c->scene_sorted.release(); c->scene_bounds.release(); c->scene_inv.release();
     for (auto& b : c->ws_f) b.release();
     for (auto& b : c->ws_i) b.release();
     c->ws_p.release();
@@ -547,12 +555,52 @@ void fdcap_ctx_destroy(fdcap_ctx* c) {
 
 int fdcap_set_scene(fdcap_ctx* c, const float* xyz, int64_t ns) {
     if (!c || ns < 0 || (ns > 0 && !xyz) || ns > 0x7fffffff) return FDCAP_E_ARG;
-    std::vector<float4> packed((size_t)ns);
+    std::vector<float4> orig((size_t)ns), sorted((size_t)ns);
+    float lo[3] = {1e30f, 1e30f, 1e30f}, hi[3] = {-1e30f, -1e30f, -1e30f};
     for (int64_t i = 0; i < ns; ++i) {
-        float x = xyz[3 * i], y = xyz[3 * i + 1], z = xyz[3 * i + 2];
-        packed[i] = make_float4(x, y, z, x * x + y * y + z * z);
+        orig[i] = make_float4(xyz[3 * i], xyz[3 * i + 1], xyz[3 * i + 2], 0.f);
+        int ii = (int)i;
+        memcpy(&orig[i].w, &ii, 4);
+        for (int k = 0; k < 3; ++k) { lo[k] = std::min(lo[k], xyz[3 * i + k]); hi[k] = std::max(hi[k], xyz[3 * i + k]); }
     }
-    HIP_TRY(c->scene.upload(packed.data(), packed.size()));
+    // spatial (Morton, 3 x 10 bit) order: consecutive MF_CH-point chunks become compact, so their
+    // bounding spheres let the NN scan skip chunks that cannot matter.  Ties keep index order.
+    auto spread = [](uint32_t v) { v &= 1023; v = (v | (v << 16)) & 0x030000FF; v = (v | (v << 8)) & 0x0300F00F;
+                                   v = (v | (v << 4)) & 0x030C30C3; v = (v | (v << 2)) & 0x09249249; return v; };
+    std::vector<std::pair<uint32_t, int>> key((size_t)ns);
+    for (int64_t i = 0; i < ns; ++i) {
+        uint32_t code = 0;
+        for (int k = 0; k < 3; ++k) {
+            float ext = hi[k] - lo[k];
+            float u = ext > 0.f ? (xyz[3 * i + k] - lo[k]) / ext : 0.f;
+            code |= spread((uint32_t)std::min(1023.f, std::max(0.f, u * 1023.f))) << k;
+        }
+        key[i] = {code, (int)i};
+    }
+    std::sort(key.begin(), key.end());
+    std::vector<int> inv((size_t)ns);
+    for (int64_t p = 0; p < ns; ++p) { sorted[p] = orig[key[p].second]; inv[key[p].second] = (int)p; }
+    const int64_t nchunk = (ns + MF_CH - 1) / MF_CH;
+    std::vector<float4> bounds((size_t)nchunk);
+    for (int64_t ch = 0; ch < nchunk; ++ch) {
+        int64_t a = ch * MF_CH, b = std::min<int64_t>(ns, a + MF_CH);
+        float blo[3] = {1e30f, 1e30f, 1e30f}, bhi[3] = {-1e30f, -1e30f, -1e30f};
+        for (int64_t p = a; p < b; ++p) {
+            const float v[3] = {sorted[p].x, sorted[p].y, sorted[p].z};
+            for (int k = 0; k < 3; ++k) { blo[k] = std::min(blo[k], v[k]); bhi[k] = std::max(bhi[k], v[k]); }
+        }
+        double cc[3] = {0.5 * ((double)blo[0] + bhi[0]), 0.5 * ((double)blo[1] + bhi[1]), 0.5 * ((double)blo[2] + bhi[2])};
+        double r2 = 0.0;
+        for (int64_t p = a; p < b; ++p) {
+            double dx = sorted[p].x - cc[0], dy = sorted[p].y - cc[1], dz = sorted[p].z - cc[2];
+            r2 = std::max(r2, dx * dx + dy * dy + dz * dz);
+        }
+        bounds[ch] = make_float4((float)cc[0], (float)cc[1], (float)cc[2], (float)(sqrt(r2) * 1.00001 + 1e-6));
+    }
+    HIP_TRY(c->scene.upload(orig.data(), orig.size()));
+    HIP_TRY(c->scene_sorted.upload(sorted.data(), sorted.size()));
+    HIP_TRY(c->scene_bounds.upload(bounds.data(), bounds.size()));
+    HIP_TRY(c->scene_inv.upload(inv.data(), inv.size()));
     c->ns = ns;
     return FDCAP_OK;
 }
@@ -582,7 +630,7 @@ int fdcap_chamfer_fwd(fdcap_ctx* c, const float* xyz1, const float* xyz2, int32_
         int nsplit = nn_pick_nsplit(nq, m);
         HIP_TRY(c->ws_f[0].ensure((size_t)nsplit * nq));
         HIP_TRY(c->ws_i[0].ensure((size_t)nsplit * nq));
-        HIP_TRY(nn_search(xyz1, nq, c->ws_p.p, m, dist1, idx1, c->ws_f[0].p, c->ws_i[0].p, nsplit, st));
+        { NNTarget T{c->ws_p.p, m, nullptr, nullptr}; HIP_TRY(nn_search(xyz1, nq, T, dist1, idx1, c->ws_f[0].p, c->ws_i[0].p, nsplit, st)); }
     }
     for (int b = 0; b < B && (!shared || dist2); ++b) {
         const float* x1 = xyz1 + (size_t)b * n * 3;
@@ -593,14 +641,14 @@ int fdcap_chamfer_fwd(fdcap_ctx* c, const float* xyz1, const float* xyz2, int32_
             int nsplit = nn_pick_nsplit(n, m);
             HIP_TRY(c->ws_f[0].ensure((size_t)nsplit * n));
             HIP_TRY(c->ws_i[0].ensure((size_t)nsplit * n));
-            HIP_TRY(nn_search(x1, n, pk, m, dist1 + (size_t)b * n, idx1 + (size_t)b * n, c->ws_f[0].p, c->ws_i[0].p, nsplit, st));
+            { NNTarget T{pk, m, nullptr, nullptr}; HIP_TRY(nn_search(x1, n, T, dist1 + (size_t)b * n, idx1 + (size_t)b * n, c->ws_f[0].p, c->ws_i[0].p, nsplit, st)); }
         }
         if (dist2) {
             hipLaunchKernelGGL(pack_points_kernel, dim3((n + 255) / 256), dim3(256), 0, st, x1, n, pk);
             int nsplit = nn_pick_nsplit(m, n);
             HIP_TRY(c->ws_f[1].ensure((size_t)nsplit * m));
             HIP_TRY(c->ws_i[1].ensure((size_t)nsplit * m));
-            HIP_TRY(nn_search(x2, m, pk, n, dist2 + (size_t)b * m, idx2 + (size_t)b * m, c->ws_f[1].p, c->ws_i[1].p, nsplit, st));
+            { NNTarget T{pk, n, nullptr, nullptr}; HIP_TRY(nn_search(x2, m, T, dist2 + (size_t)b * m, idx2 + (size_t)b * m, c->ws_f[1].p, c->ws_i[1].p, nsplit, st)); }
         }
     }
     return (int)hipGetLastError();
@@ -744,6 +792,7 @@ int fdcap_opt_create(fdcap_ctx* c, const fdcap_opt_config* cfg, float* rows_x, f
     o->contact_on = c->ns > 0 && c->nc > 0 && cfg->weight_contact != 0.f;
     const size_t nq = (size_t)R * std::max(c->nc, 1);
     o->nsplit = o->contact_on ? nn_pick_nsplit((int)((size_t)cfg->n_local * c->nc), (int)c->ns) : 1;
+    if (const char* e = getenv("FDCAP_NN_NSPLIT")) o->nsplit = std::max(1, atoi(e));      // tuning knob
     int err = 0;
 #define AL(buf, cnt) if (!err) { hipError_t e_ = (buf).ensure(cnt); if (e_ != hipSuccess) err = (int)e_; else e_ = hipMemset((buf).p, 0, (size_t)(cnt) * sizeof(*(buf).p)); }
     o->X.p = rows_x; o->CAM.p = rows_cam; o->scale.p = scale_d; o->dscale.p = dscale_d; o->losses.p = losses_d;
@@ -769,6 +818,8 @@ int fdcap_opt_create(fdcap_ctx* c, const fdcap_opt_config* cfg, float* rows_x, f
     if (!err) {
         const char* e = getenv("FDCAP_NN_SEED");
         o->use_seed = !(e && e[0] == '0');
+        const char* e2 = getenv("FDCAP_NN_CULL");
+        o->use_cull = !(e2 && e2[0] == '0');
         float s = cfg->scale_init;
         hipError_t e_ = hipMemcpy(o->scale.p, &s, sizeof(float), hipMemcpyHostToDevice);
         if (e_ != hipSuccess) err = (int)e_;
@@ -799,7 +850,7 @@ static int opt_contact_forward(fdcap_ctx* c, hipStream_t st) {
     hipLaunchKernelGGL(skin_fwd_kernel, dim3((nc + 255) / 256, nl), dim3(256), 0, st, c->contact.model(), nc, o->X.p, XDIM,
                        X_BETAS, X_TRANSL, o->Voff.p, o->A.p, o->M.p, o->scale.p, 2, 1, o->Vw.p);
     const int nq = nl * nc;
-    HIP_TRY(nn_search(o->Vw.p + off, nq, c->scene.p, (int)c->ns, o->dist.p + 2 * nc, o->idx.p + 2 * nc, o->pd.p, o->pi.p,
+    HIP_TRY(nn_search(o->Vw.p + off, nq, c->nn_target(o->use_cull), o->dist.p + 2 * nc, o->idx.p + 2 * nc, o->pd.p, o->pi.p,
                       o->nsplit, st, o->use_seed ? o->idx.p + 2 * nc : nullptr));
     return 0;
 }
@@ -925,23 +976,25 @@ int fdcap_opt_get_grads(fdcap_ctx* c, float* dx, float* dcam, void* stream) {
     return FDCAP_OK;
 }
 
-int fdcap_opt_time_chamfer(fdcap_ctx* c, int32_t iters, float* ms, void* stream) {
+int fdcap_opt_time_chamfer(fdcap_ctx* c, int32_t iters, int32_t brute_force, float* ms, void* stream) {
     if (!c || !c->opt || !ms || iters <= 0) return FDCAP_E_ARG;
     OptState* o = c->opt;
     if (!o->contact_on) return FDCAP_E_STATE;
     hipStream_t st = (hipStream_t)stream;
     const int nl = o->cfg.n_local, nc = c->nc;
     const size_t off = (size_t)2 * nc * 3;
+    // brute_force: every (query, scene point) pair is visited (no seed, no chunk bounds);
+    // otherwise the launch is exactly what the loop issues in steady state
+    const int* seed = (!brute_force && o->use_seed) ? o->idx.p + 2 * nc : nullptr;
+    NNTarget T = c->nn_target(!brute_force && o->use_cull);
+    if (brute_force) { T.pts = c->scene.p; T.inv_perm = nullptr; }   // input order (a spatial sort is adversarial for an unseeded running minimum)
     hipEvent_t e0, e1;
     HIP_TRY(hipEventCreate(&e0));
     HIP_TRY(hipEventCreate(&e1));
-    const int* seed = o->use_seed ? o->idx.p + 2 * nc : nullptr;   // steady state of the loop: seeded by the previous result
-    HIP_TRY(nn_search(o->Vw.p + off, nl * nc, c->scene.p, (int)c->ns, o->dist.p + 2 * nc, o->idx.p + 2 * nc, o->pd.p, o->pi.p,
-                      o->nsplit, st, seed));
+    HIP_TRY(nn_search(o->Vw.p + off, nl * nc, T, o->dist.p + 2 * nc, o->idx.p + 2 * nc, o->pd.p, o->pi.p, o->nsplit, st, seed));
     HIP_TRY(hipEventRecord(e0, st));
     for (int i = 0; i < iters; ++i)
-        HIP_TRY(nn_search(o->Vw.p + off, nl * nc, c->scene.p, (int)c->ns, o->dist.p + 2 * nc, o->idx.p + 2 * nc, o->pd.p,
-                          o->pi.p, o->nsplit, st, seed));
+        HIP_TRY(nn_search(o->Vw.p + off, nl * nc, T, o->dist.p + 2 * nc, o->idx.p + 2 * nc, o->pd.p, o->pi.p, o->nsplit, st, seed));
     HIP_TRY(hipEventRecord(e1, st));
     HIP_TRY(hipEventSynchronize(e1));
     float t = 0.f;

@@ -178,8 +178,10 @@ int fdcap_opt_get_grads(fdcap_ctx* ctx, float* dx_d, float* dcam_d, void* stream
 
 /* Kernel-level timing of the Chamfer NN launch for the roofline line: runs `iters` launches of
  * the optimiser's Chamfer forward on `stream` between two HIP events and returns the mean
- * milliseconds per launch in *ms. */
-int fdcap_opt_time_chamfer(fdcap_ctx* ctx, int32_t iters, float* ms, void* stream);
+ * milliseconds per launch in *ms.  brute_force = 1: every (query, scene point) pair is visited
+ * (no seed, no chunk bounds) -- the launch the algorithmic byte count describes; 0: the launch
+ * exactly as the loop issues it in steady state (seeded, chunk-culled). */
+int fdcap_opt_time_chamfer(fdcap_ctx* ctx, int32_t iters, int32_t brute_force, float* ms, void* stream);
 
 #ifdef __cplusplus
 }

@@ -315,8 +315,9 @@ def test_trajectory_matches_reference_golden(golden_dir, name):
 
 def test_seeding_the_nn_bound_does_not_change_results():
     """The optimiser seeds each NN search with the previous call's neighbour (an exact upper bound
-    that only prunes): cold search, search seeded by its own result, and search seeded by a STALE
-    result (state moved in between) must all equal the unseeded answer bit for bit."""
+    that only prunes) and skips scene chunks whose bounding sphere is out of every query's reach:
+    cold search, search seeded by its own result, and search seeded by a STALE result (state moved
+    in between), with and without chunk culling, must all equal the plain answer bit for bit."""
     n = 64
     clip_x = None
 
@@ -330,8 +331,9 @@ def test_seeding_the_nn_bound_does_not_change_results():
         return d.clone(), i.clone()
 
     res = {}
-    for flag in ("0", "1"):
+    for flag, cull in (("0", "0"), ("1", "0"), ("1", "1")):
         os.environ["FDCAP_NN_SEED"] = flag
+        os.environ["FDCAP_NN_CULL"] = cull
         fop, bm, vp, clip, scene, vid = _make_fop(n, 300, 70_000, 40, 8, seed=60)
         x78 = torch.empty(n, 78, device="cuda")
         capi.check(fop.ctx.lib.fdcap_params_75_to_78(capi.dptr(torch.tensor(clip.body_params).cuda()), n, capi.dptr(x78),
@@ -343,12 +345,14 @@ def test_seeding_the_nn_bound_does_not_change_results():
         fop._rows_x[2:2 + n, 0:3] += 0.03 * torch.randn(n, 3, device="cuda", generator=g)     # move the bodies
         fop._rows_x[2:2 + n, 19:51] += 0.05 * torch.randn(n, 32, device="cuda", generator=g)
         c = contact(fop)                 # seeded by a stale result (flag 1)
-        res[flag] = (a, b, c)
+        res[flag + cull] = (a, b, c)
         fop.close()
     os.environ.pop("FDCAP_NN_SEED")
-    for k in range(3):
-        assert torch.equal(res["0"][k][0], res["1"][k][0]) and torch.equal(res["0"][k][1], res["1"][k][1]), k
-    assert not torch.equal(res["1"][1][1], res["1"][2][1])       # the stale seeds really were stale
+    os.environ.pop("FDCAP_NN_CULL")
+    for cfg in ("10", "11"):          # seeded; seeded + chunk-culled (Morton-sorted scene, bounding spheres)
+        for k in range(3):
+            assert torch.equal(res["00"][k][0], res[cfg][k][0]) and torch.equal(res["00"][k][1], res[cfg][k][1]), (cfg, k)
+    assert not torch.equal(res["11"][1][1], res["11"][2][1])     # the stale seeds really were stale
 
 
 def test_runs_are_bit_reproducible():

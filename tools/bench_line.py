@@ -1,0 +1,9 @@
+#!/usr/bin/env python3
+"""Print the interesting numbers of a bench.py JSON line read from stdin."""
+import json, sys
+tag = sys.argv[1] if len(sys.argv) > 1 else ""
+d = json.loads(sys.stdin.read().strip().splitlines()[-1])
+r = d["roofline"]
+print(tag, "frames/s %.1f  ms/step %.1f  NN brute %.2f ms (%.1f%% HBM-alg, %.2e pairs/s)  in-loop %.2f ms" % (
+    d["value"], d["ms_per_step"], r["ms_per_launch"], 100 * r["frac"], r["compute_side"]["pairs_per_s"],
+    r["in_loop"]["ms_per_launch"]))

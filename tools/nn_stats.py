@@ -34,8 +34,9 @@ out = (ctypes.c_ulonglong * 4)()
 L.fdcap_debug_nn_stats.argtypes = [ctypes.POINTER(ctypes.c_ulonglong)]
 L.fdcap_debug_nn_stats(out)
 ms = ctypes.c_float()
-capi.check(L.fdcap_opt_time_chamfer(fop.ctx.handle, 1, ctypes.byref(ms), capi.current_stream()), "time")
+capi.check(L.fdcap_opt_time_chamfer(fop.ctx.handle, 1, int(os.environ.get("NN_BRUTE", "0")), ctypes.byref(ms), capi.current_stream()), "time")
 L.fdcap_debug_nn_stats(out)   # one warm-up + one timed launch
-tot, slow, rows = out[0], out[1], out[2]
+tot, slow, rows = max(out[0], 1), out[1], out[2]
+print('chunks staged', out[3], 'of', 2 * ((N * 500 + 511) // 512) * ((ns + 511) // 512))
 print(f"ms/launch {ms.value:.3f}  MFMA results {tot}  exact-path entries {slow} ({100.0*slow/tot:.2f} %)  rows re-evaluated {rows} "
       f"({rows/max(slow,1):.2f} per entry, {rows/(2*N*500):.1f} per query-launch)  [2 launches]")

@@ -11,12 +11,13 @@ def main(db, out=None):
     lines.append("## kernel-trace --stats (durations in microseconds)")
     lines.append(f"{'calls':>7} {'total_us':>14} {'avg_us':>12} {'%':>7}  kernel")
     for name, calls, tot, avg, pct in cur:
-        short = name.split("(")[0].replace("(anonymous namespace)::", "").replace("void ", "")
+        short = name.replace("(anonymous namespace)::", "").replace("void ", "").split("(")[0]
         lines.append(f"{calls:7d} {tot:14.1f} {avg:12.2f} {pct:7.2f}  {short}")
     try:
         rows = list(c.execute(
-            "select k.name, p.counter_name, count(*), avg(p.value), sum(p.value) from pmc_events p "
-            "join kernels k on k.dispatch_id = p.dispatch_id group by k.name, p.counter_name"))
+            "select k.name, p.counter_name, count(*), avg(p.counter_value), sum(p.counter_value) from pmc_events p "
+            "join kernels k on k.dispatch_id = p.dispatch_id group by k.name, p.counter_name "
+            "order by avg(p.counter_value) desc"))
     except Exception as e:  # schema differs between rocprofv3 builds
         rows = []
         try:
@@ -27,7 +28,7 @@ def main(db, out=None):
     if rows:
         lines += ["", "## PMC counters (per-dispatch average, sum)"]
         for name, ctr, n, avg, tot in rows:
-            short = name.split("(")[0].replace("(anonymous namespace)::", "").replace("void ", "")
+            short = name.replace("(anonymous namespace)::", "").replace("void ", "").split("(")[0]
             lines.append(f"{ctr:>14} n={n:<6d} avg={avg:16.1f} sum={tot:18.1f}  {short}")
     text = "\n".join(lines) + "\n"
     if out:
