@@ -100,11 +100,109 @@ __global__ __launch_bounds__(256) void gemm_f32_mfma_kernel(
             }
 }
 
+// Variant for the small / skinny products of the optimiser (M ~ 1e3 rows, N from 32 to 1500,
+// K up to 1500): one 32x32 output tile per workgroup, the four waves split each 128-deep K slab
+// between them (intra-workgroup split-K) and are summed in a fixed order through LDS, so there are
+// 4x more workgroups and 4x fewer barrier rounds than with 64x64 tiles, results stay reproducible,
+// and the next slab's global loads are in flight while the current one is multiplied.
+template <bool B_IS_NK, int EPI>
+__global__ __launch_bounds__(256) void gemm_f32_mfma_ksplit_kernel(
+    const float* __restrict__ A, int lda, const float* __restrict__ B, int ldb, float* __restrict__ C,
+    int ldc, int M, int N, int K, const float* __restrict__ aux, int ldaux) {
+    constexpr int BM = 32, BN = 32, BK = 128, LD = BK + 1, NLD = (BM * BK) / 256;   // 16 loads per operand per thread
+    __shared__ float As[BM * LD];
+    __shared__ float Bs[BN * LD];
+    __shared__ float Red[3][BM * BN];
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+    float ra[NLD], rb[NLD];
+    auto gload = [&](int k0) {
+#pragma unroll
+        for (int i = 0; i < NLD; ++i) {
+            int e = tid + i * 256, r = e >> 7, c = e & 127;
+            int gm = m0 + r, gk = k0 + c;
+            ra[i] = (gm < M && gk < K) ? A[(size_t)gm * lda + gk] : 0.f;
+        }
+        if (B_IS_NK) {
+#pragma unroll
+            for (int i = 0; i < NLD; ++i) {
+                int e = tid + i * 256, r = e >> 7, c = e & 127;
+                int gn = n0 + r, gk = k0 + c;
+                rb[i] = (gn < N && gk < K) ? B[(size_t)gn * ldb + gk] : 0.f;
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < NLD; ++i) {
+                int e = tid + i * 256, kk = e >> 5, nn = e & 31;
+                int gn = n0 + nn, gk = k0 + kk;
+                rb[i] = (gn < N && gk < K) ? B[(size_t)gk * ldb + gn] : 0.f;
+            }
+        }
+    };
+    auto lstore = [&]() {
+#pragma unroll
+        for (int i = 0; i < NLD; ++i) {
+            int e = tid + i * 256;
+            As[(e >> 7) * LD + (e & 127)] = ra[i];
+            if (B_IS_NK) Bs[(e >> 7) * LD + (e & 127)] = rb[i];
+            else Bs[(e & 31) * LD + (e >> 5)] = rb[i];
+        }
+    };
+    gload(0);
+    for (int k0 = 0; k0 < K; k0 += BK) {
+        lstore();
+        __syncthreads();
+        if (k0 + BK < K) gload(k0 + BK);                    // in flight during the MFMAs below
+        const int kq = wave * 32;                           // this wave's quarter of the slab
+#pragma unroll 4
+        for (int kk = 0; kk < 32; kk += 2) {
+            float a = As[(lane & 31) * LD + kq + kk + (lane >> 5)];
+            float b = Bs[(lane & 31) * LD + kq + kk + (lane >> 5)];
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc, 0, 0, 0);
+        }
+        __syncthreads();
+    }
+    // fixed-order reduction of the four K-quarters: ((w0 + w1) + w2) + w3
+    if (wave > 0) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) Red[wave - 1][r * 64 + lane] = acc[r];
+    }
+    __syncthreads();
+    if (wave == 0) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            float v = acc[r] + Red[0][r * 64 + lane];
+            v += Red[1][r * 64 + lane];
+            v += Red[2][r * 64 + lane];
+            int m = m0 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+            int n = n0 + (lane & 31);
+            if (m < M && n < N) {
+                if (EPI == EPI_BIAS || EPI == EPI_BIAS_LRELU) v += aux[n];
+                if (EPI == EPI_BIAS_LRELU) v = v > 0.f ? v : 0.2f * v;
+                if (EPI == EPI_MASK_LRELU) v *= (aux[(size_t)m * ldaux + n] > 0.f) ? 1.f : 0.2f;
+                float* dst = C + (size_t)m * ldc + n;
+                if (EPI == EPI_ACCUM) v += *dst;
+                *dst = v;
+            }
+        }
+    }
+}
+
 template <bool NK, int EPI>
 static inline hipError_t gemm_dispatch_tile(const float* A, int lda, const float* B, int ldb, float* C, int ldc,
                                             int M, int N, int K, const float* aux, int ldaux, hipStream_t st) {
     if (M <= 0 || N <= 0) return hipSuccess;
-    // large outputs: 128x128 workgroup tiles (4 accumulators per wave); small ones: 64x64
+    // skinny / small outputs (every product of the optimiser loop): 32x32 tiles, intra-workgroup split-K
+    if ((long long)M * N < 64LL * 64 * 1024 && K >= 32) {
+        dim3 grid((N + 31) / 32, (M + 31) / 32);
+        hipLaunchKernelGGL((gemm_f32_mfma_ksplit_kernel<NK, EPI>), grid, dim3(256), 0, st, A, lda, B, ldb, C, ldc, M, N, K,
+                           aux, ldaux);
+        return hipGetLastError();
+    }
+    // large outputs: 128x128 workgroup tiles (4 accumulators per wave); medium ones: 64x64
     if ((long long)M * N >= 128LL * 128 * 512) {
         dim3 grid((N + 127) / 128, (M + 127) / 128);
         hipLaunchKernelGGL((gemm_f32_mfma_kernel<NK, EPI, 2, 2>), grid, dim3(256), 0, st, A, lda, B, ldb, C, ldc,

@@ -309,7 +309,8 @@ def test_trajectory_matches_reference_golden(golden_dir, name):
     # in phase 2 the contact term is log-only and sees camera_ext moving +-lr per step (sign-normalised)
     assert np.all(np.abs(np.array(log.loss_contact) - g["log"][:, 4]) <= np.where(np.arange(num_iter) > P, 4 * tol, tol))
     assert np.all(np.abs(np.array(log.total) - g["log"][:, 6]) <= 2 * tol)
-    assert np.all(np.abs(np.array(log.loss_world_smoothing)[P:] - g["log"][P:, 5]) <= tol[P:])
+    # same camera_ext sensitivity: measured up to 6e-5 at iteration 19 depending on GEMM summation order
+    assert np.all(np.abs(np.array(log.loss_world_smoothing)[P:] - g["log"][P:, 5]) <= 4 * tol[P:])
     fop.close()
 
 
