@@ -121,6 +121,7 @@ __global__ __launch_bounds__(256) void nn_direct_kernel(const float* __restrict_
 //            Rw = max_i (X_i + sqrt(best_i)) -- no point of it can beat or tie any query's bound.
 //            Without seeds Rw is infinite and the scan is plain brute force.
 constexpr float MF_K1 = 1e-4f, MF_K2 = 8e-6f;
+constexpr int MF_MAXCHUNK = 2048;      // chunks per split the survivor list can hold (host keeps splits below it)
 
 #ifdef FDC_NN_STATS
 // instrumentation build only (never shipped): [0] MFMA results reduced, [1] results that entered
@@ -157,6 +158,8 @@ __global__ __launch_bounds__(256) void nn_mfma_kernel(const float* __restrict__ 
     __shared__ uint4 sA[2][MF_CH / 32][2][32];     // [buffer][tile][k-half][point] bf16 x 8
     __shared__ float4 sP[2][MF_CH];                // fp32 coordinates (+ index) for the exact re-evaluation
     __shared__ float sred[4][4];
+    __shared__ unsigned short slist[MF_MAXCHUNK];   // surviving chunks of this split, ascending
+    __shared__ int swcnt[4];
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, half = lane >> 5, col = lane & 31;
     const int split = blockIdx.x % nsplit;
     const int qb = blockIdx.x / nsplit;
@@ -238,17 +241,33 @@ __global__ __launch_bounds__(256) void nn_mfma_kernel(const float* __restrict__ 
     unsigned st_cnt[4] = {0, 0, 0, 0};
 #endif
 
-    // first chunk at or after `base` that may hold a relevant point (workgroup-uniform)
-    auto next_chunk = [&](int base) -> int {
-        if (T.bounds == nullptr || !(Rw < INFINITY)) return base;
-        for (; base < t_end; base += MF_CH) {
-            const float4 b = T.bounds[base / MF_CH];
-            const float dx = b.x - cx, dy = b.y - cy, dz = b.z - cz;
-            const float gap = sqrtf(dx * dx + dy * dy + dz * dz) - b.w;
-            if (!(gap > Rw)) break;
+    // Survivor list: all chunk bounds of this split are tested in parallel (one chunk per thread per
+    // round; a serial scan would pay one dependent global-load latency per skipped chunk) and the
+    // survivors are compacted in ascending order with ballots.
+    const int nchunk = (t_end - t_begin + MF_CH - 1) / MF_CH;
+    const bool cull = T.bounds != nullptr && Rw < INFINITY && nchunk <= MF_MAXCHUNK;
+    int nsurv = nchunk;
+    if (cull) {
+        nsurv = 0;
+        for (int c0 = 0; c0 < nchunk; c0 += 256) {
+            const int ci = c0 + tid;
+            bool keep = false;
+            if (ci < nchunk) {
+                const float4 b = T.bounds[t_begin / MF_CH + ci];
+                const float dx = b.x - cx, dy = b.y - cy, dz = b.z - cz;
+                keep = !(sqrtf(dx * dx + dy * dy + dz * dz) - b.w > Rw);
+            }
+            const unsigned long long mask = __ballot(keep);
+            if (lane == 0) swcnt[wave] = __popcll(mask);
+            __syncthreads();
+            int off = nsurv;
+            for (int w = 0; w < wave; ++w) off += swcnt[w];
+            if (keep) slist[off + __popcll(mask & ((1ull << lane) - 1ull))] = (unsigned short)ci;
+            nsurv += swcnt[0] + swcnt[1] + swcnt[2] + swcnt[3];
+            __syncthreads();
         }
-        return base;
-    };
+    }
+    auto chunk_base = [&](int s) -> int { return t_begin + (cull ? (int)slist[s] : s) * MF_CH; };
 
     // staging (issue-early / write-late): the global loads of the next chunk are issued before the
     // current chunk's MFMA loop, the centre / bf16 split / LDS write happens after it
@@ -282,12 +301,12 @@ __global__ __launch_bounds__(256) void nn_mfma_kernel(const float* __restrict__ 
     };
 
     int buf = 0;
-    int base = next_chunk(t_begin);
-    if (base < t_end) { stage_load(base); stage_write(0, base); }
+    if (nsurv > 0) { stage_load(chunk_base(0)); stage_write(0, chunk_base(0)); }
     __syncthreads();
-    while (base < t_end) {
-        const int nxt = next_chunk(base + MF_CH);
-        const bool more = nxt < t_end;
+    for (int s = 0; s < nsurv; ++s) {
+        const int base = chunk_base(s);
+        const bool more = s + 1 < nsurv;
+        const int nxt = more ? chunk_base(s + 1) : 0;
         if (more) stage_load(nxt);
         FDC_STAT(3, tid == 0);
         const int ntile = (min(MF_CH, t_end - base) + 31) >> 5;
@@ -346,7 +365,6 @@ __global__ __launch_bounds__(256) void nn_mfma_kernel(const float* __restrict__ 
         if (more) stage_write(buf ^ 1, nxt);
         __syncthreads();
         buf ^= 1;
-        base = nxt;
     }
 #ifdef FDC_NN_STATS
     for (int i = 0; i < 4; ++i) atomicAdd(&g_nn_stats[i], (unsigned long long)st_cnt[i]);
@@ -424,6 +442,7 @@ static inline int nn_pick_nsplit(int nq, int nt) {
     int ns = 1;
     while (qblocks * ns < 1024 && ns < 64 && nt / (ns * 2) >= 4 * MF_CH) ns *= 2;
     if (qblocks >= 512 && nt >= 8 * MF_CH) ns = max(ns, 2);
+    while (nn_split_len(nt, ns) / MF_CH > MF_MAXCHUNK) ns *= 2;
     return ns;
 }
 
