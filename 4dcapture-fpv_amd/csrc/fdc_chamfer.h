@@ -241,22 +241,44 @@ __global__ __launch_bounds__(256) void nn_mfma_kernel(const float* __restrict__ 
     unsigned st_cnt[4] = {0, 0, 0, 0};
 #endif
 
-    // Survivor list: all chunk bounds of this split are tested in parallel (one chunk per thread per
-    // round; a serial scan would pay one dependent global-load latency per skipped chunk) and the
-    // survivors are compacted in ascending order with ballots.
+    // Survivor list.  A chunk (bounding sphere centre cc, radius rc) matters to query i only if
+    // |x_i - cc| - rc <= sqrt(best_i).  Pass 1 (one chunk per thread, parallel loads -- a serial scan
+    // would pay a dependent global-load latency per chunk) keeps the chunks within the workgroup's
+    // reach Rw of the centroid; pass 2 tests those against every query individually (much tighter for
+    // queries far from the centroid or with a distant neighbour); survivors are compacted in ascending
+    // order with ballots.
     const int nchunk = (t_end - t_begin + MF_CH - 1) / MF_CH;
     const bool cull = T.bounds != nullptr && Rw < INFINITY && nchunk <= MF_MAXCHUNK;
     int nsurv = nchunk;
     if (cull) {
-        nsurv = 0;
-        for (int c0 = 0; c0 < nchunk; c0 += 256) {
+        float sb[NQ];
+#pragma unroll
+        for (int n = 0; n < NQ; ++n) sb[n] = (qidx[n] < nq) ? sqrtf(own_d[n]) * 1.00001f + 1e-6f : -INFINITY;
+        for (int c0 = 0; c0 < nchunk; c0 += 256) {            // pass 1: centroid reach
             const int ci = c0 + tid;
-            bool keep = false;
             if (ci < nchunk) {
                 const float4 b = T.bounds[t_begin / MF_CH + ci];
                 const float dx = b.x - cx, dy = b.y - cy, dz = b.z - cz;
-                keep = !(sqrtf(dx * dx + dy * dy + dz * dz) - b.w > Rw);
+                slist[ci] = (sqrtf(dx * dx + dy * dy + dz * dz) - b.w > Rw) ? 0 : 1;
             }
+        }
+        __syncthreads();
+        for (int ci = half; ci < nchunk; ci += 2) {           // pass 2: per query (each half-wave takes every other chunk)
+            if (slist[ci] == 0) continue;                     // workgroup-uniform
+            const float4 b = T.bounds[t_begin / MF_CH + ci];
+            bool hit = false;
+#pragma unroll
+            for (int n = 0; n < NQ; ++n) {
+                const float dx = b.x - qx[n], dy = b.y - qy[n], dz = b.z - qz[n];
+                hit |= sqrtf(dx * dx + dy * dy + dz * dz) - b.w <= sb[n];
+            }
+            if (hit) slist[ci] = 2;                           // same-value stores from several lanes: benign
+        }
+        __syncthreads();
+        nsurv = 0;
+        for (int c0 = 0; c0 < nchunk; c0 += 256) {            // ordered compaction (in place: writes trail reads)
+            const int ci = c0 + tid;
+            const bool keep = ci < nchunk && slist[ci] == 2;
             const unsigned long long mask = __ballot(keep);
             if (lane == 0) swcnt[wave] = __popcll(mask);
             __syncthreads();
