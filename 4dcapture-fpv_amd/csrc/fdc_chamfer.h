@@ -7,9 +7,9 @@
 //     frames' contact vertices form one flat query array, so a scene tile staged in LDS is
 //     reused by every query of a workgroup, whatever frame it belongs to (the reference re-reads a
 //     per-frame copy of the scene);
-//   * the scene is cut into `nsplit` contiguous ranges and workgroup b handles range b % nsplit:
-//     with the observed block -> XCD round-robin each XCD's L2 only ever sees its own eighth of
-//     the scene (speed only; any placement is correct);
+//   * the scene is cut into `nsplit` contiguous ranges; the blockIdx -> (query block, split) map is
+//     XCD-aware (nn_block_map): every XCD gets an equal share of every split's work (speed only;
+//     any placement is correct);
 //   * every kernel reports (d, index) with d from nn_exact_d2 and the LOWEST index among exact
 //     ties -- what the ascending strict-`<` scan of the reference kernel gives -- independent of the
 //     order in which points are visited; per-split minima are merged by the same (d, index) order.
@@ -44,13 +44,25 @@ __host__ __device__ __forceinline__ int nn_split_len(int nt, int nsplit) {
     return (per + MF_CH - 1) / MF_CH * MF_CH;             // chunk-aligned so bounds[] indexes uniformly
 }
 
+// Workgroup -> (query block, scene split).  Blocks are dealt to the 8 XCDs round-robin (b % 8), and
+// with chunk culling nearly all the work of a query block sits in the one or two splits that hold
+// its neighbourhood, so the split must NOT be a function of b % 8 (half the XCDs would idle --
+// measured 2x).  Within each XCD consecutive slots walk the splits of one query block.
+__device__ __forceinline__ void nn_block_map(int b, int nsplit, int* qb, int* split) {
+    const int xcd = b & 7, slot = b >> 3;
+    *split = slot % nsplit;
+    *qb = (slot / nsplit) * 8 + xcd;
+}
+static inline int nn_grid_blocks(int qblocks, int nsplit) { return (qblocks + 7) / 8 * 8 * nsplit; }
+
 template <int QPT>
 __global__ __launch_bounds__(256) void nn_direct_kernel(const float* __restrict__ q, int nq, NNTarget T, int nsplit,
                                                         float* __restrict__ pd, int* __restrict__ pi) {
     __shared__ float4 tile[NN_TILE];
     const int tid = threadIdx.x;
-    const int split = blockIdx.x % nsplit;
-    const int qb = blockIdx.x / nsplit;
+    int split, qb;
+    nn_block_map(blockIdx.x, nsplit, &qb, &split);
+    if (qb * (256 * QPT) >= nq) return;
     const int per = nn_split_len(T.n, nsplit);
     const int t_begin = min(T.n, split * per);
     const int t_end = min(T.n, t_begin + per);
@@ -161,8 +173,9 @@ __global__ __launch_bounds__(256) void nn_mfma_kernel(const float* __restrict__ 
     __shared__ unsigned short slist[MF_MAXCHUNK];   // surviving chunks of this split, ascending
     __shared__ int swcnt[4];
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, half = lane >> 5, col = lane & 31;
-    const int split = blockIdx.x % nsplit;
-    const int qb = blockIdx.x / nsplit;
+    int split, qb;
+    nn_block_map(blockIdx.x, nsplit, &qb, &split);
+    if (qb * (128 * NQ) >= nq) return;
     const int per = nn_split_len(T.n, nsplit);
     const int t_begin = min(T.n, split * per);
     const int t_end = min(T.n, t_begin + per);
@@ -474,9 +487,9 @@ static inline hipError_t nn_search(const float* q, int nq, const NNTarget& T, fl
     if (nq <= 0) return hipSuccess;
     int qblocks = (nq + 511) / 512;
     if (nn_use_mfma(nq, T.n))
-        hipLaunchKernelGGL((nn_mfma_kernel<4>), dim3(qblocks * nsplit), dim3(256), 0, st, q, nq, T, nsplit, seed, pd, pi);
+        hipLaunchKernelGGL((nn_mfma_kernel<4>), dim3(nn_grid_blocks(qblocks, nsplit)), dim3(256), 0, st, q, nq, T, nsplit, seed, pd, pi);
     else
-        hipLaunchKernelGGL((nn_direct_kernel<2>), dim3(qblocks * nsplit), dim3(256), 0, st, q, nq, T, nsplit, pd, pi);
+        hipLaunchKernelGGL((nn_direct_kernel<2>), dim3(nn_grid_blocks(qblocks, nsplit)), dim3(256), 0, st, q, nq, T, nsplit, pd, pi);
     hipLaunchKernelGGL(nn_combine_kernel, dim3((nq + 255) / 256), dim3(256), 0, st, pd, pi, nsplit, nq, dist, idx);
     return hipGetLastError();
 }
