@@ -302,6 +302,9 @@ __global__ __launch_bounds__(256) void nn_mfma_kernel(const float* __restrict__ 
             __syncthreads();
         }
     }
+#if defined(FDC_NN_EXP) && FDC_NN_EXP == 6
+    nsurv = 0;                                              // experiment: prologue + survivor list only
+#endif
     auto chunk_base = [&](int s) -> int { return t_begin + (cull ? (int)slist[s] : s) * MF_CH; };
 
     // staging (issue-early / write-late): the global loads of the next chunk are issued before the
@@ -469,14 +472,16 @@ static inline bool nn_use_mfma(int nq, int nt) {
     return (long long)nq * nt >= (1LL << 22);
 }
 
-static inline int nn_pick_nsplit(int nq, int nt) {
-    // ~1000-2000 workgroups (256 CUs x 3 resident); each split re-reads the queries / seeds and
-    // writes its own partial minima, so fewer, longer splits win once there are enough query blocks
-    // (measured on 1024 frames x 500 contacts vs 500k points: nsplit 2 beats 1, 4 and 8)
-    int qblocks = (nq + 511) / 512;
+static inline int nn_pick_nsplit(int nq, int nt, bool culled = false) {
+    // Each split re-reads the queries / seeds and writes its own partial minima, so fewer, longer
+    // splits win once there are enough query blocks to occupy 256 CUs x 3 resident workgroups.
+    // Measured on 1024 frames x 500 contacts vs 500k points: brute-force scan nsplit 2 (9.7 ms) beats
+    // 1 (11.1) and 8 (9.9); seeded + chunk-culled scan nsplit 1 (1.09 ms) beats 2 (1.23) and 4 (1.43).
+    int qblocks = culled ? (nq + 255) / 256 : (nq + 511) / 512;
     int ns = 1;
-    while (qblocks * ns < 1024 && ns < 64 && nt / (ns * 2) >= 4 * MF_CH) ns *= 2;
-    if (qblocks >= 512 && nt >= 8 * MF_CH) ns = max(ns, 2);
+    const int target = culled ? 1536 : 1024;
+    while (qblocks * ns < target && ns < 64 && nt / (ns * 2) >= 4 * MF_CH) ns *= 2;
+    if (!culled && qblocks >= 512 && nt >= 8 * MF_CH) ns = max(ns, 2);
     while (nn_split_len(nt, ns) / MF_CH > MF_MAXCHUNK) ns *= 2;
     return ns;
 }
@@ -485,11 +490,22 @@ static inline int nn_pick_nsplit(int nq, int nt) {
 static inline hipError_t nn_search(const float* q, int nq, const NNTarget& T, float* dist, int* idx, float* pd, int* pi,
                                    int nsplit, hipStream_t st, const int* seed = nullptr) {
     if (nq <= 0) return hipSuccess;
-    int qblocks = (nq + 511) / 512;
-    if (nn_use_mfma(nq, T.n))
-        hipLaunchKernelGGL((nn_mfma_kernel<4>), dim3(nn_grid_blocks(qblocks, nsplit)), dim3(256), 0, st, q, nq, T, nsplit, seed, pd, pi);
+    // Query blocks per workgroup: 4 waves x NQ x 32.  A brute-force scan wants NQ = 4 (most MFMAs per
+    // staged chunk: 9.7 ms vs 10.9 at NQ = 2); a seeded + chunk-culled scan wants NQ = 2 (the union of
+    // the chunks 256 queries need is smaller than what 512 need, twice the workgroups: 0.92 ms vs
+    // 1.10 ms at NQ = 4, 1.09 ms at NQ = 1).  FDCAP_NN_NQ overrides.
+    static int forced_nq = -1;
+    if (forced_nq < 0) { const char* e = getenv("FDCAP_NN_NQ"); forced_nq = e ? atoi(e) : 0; }
+    const bool culled = seed != nullptr && T.bounds != nullptr;
+    const int NQsel = forced_nq ? forced_nq : (culled ? 2 : 4);
+    if (nn_use_mfma(nq, T.n) && NQsel == 1)
+        hipLaunchKernelGGL((nn_mfma_kernel<1>), dim3(nn_grid_blocks((nq + 127) / 128, nsplit)), dim3(256), 0, st, q, nq, T, nsplit, seed, pd, pi);
+    else if (nn_use_mfma(nq, T.n) && NQsel == 2)
+        hipLaunchKernelGGL((nn_mfma_kernel<2>), dim3(nn_grid_blocks((nq + 255) / 256, nsplit)), dim3(256), 0, st, q, nq, T, nsplit, seed, pd, pi);
+    else if (nn_use_mfma(nq, T.n))
+        hipLaunchKernelGGL((nn_mfma_kernel<4>), dim3(nn_grid_blocks((nq + 511) / 512, nsplit)), dim3(256), 0, st, q, nq, T, nsplit, seed, pd, pi);
     else
-        hipLaunchKernelGGL((nn_direct_kernel<2>), dim3(nn_grid_blocks(qblocks, nsplit)), dim3(256), 0, st, q, nq, T, nsplit, pd, pi);
+        hipLaunchKernelGGL((nn_direct_kernel<2>), dim3(nn_grid_blocks((nq + 511) / 512, nsplit)), dim3(256), 0, st, q, nq, T, nsplit, pd, pi);
     hipLaunchKernelGGL(nn_combine_kernel, dim3((nq + 255) / 256), dim3(256), 0, st, pd, pi, nsplit, nq, dist, idx);
     return hipGetLastError();
 }

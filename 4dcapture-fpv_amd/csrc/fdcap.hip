@@ -105,10 +105,10 @@ __global__ __launch_bounds__(256) void skin_bwd_kernel(SkinModel sm, int nc, con
                                                        float* __restrict__ dMv, float* __restrict__ dsv,
                                                        double* __restrict__ loss_contact_sum) {
     constexpr int VCH = 1024;                      // vertices per LDS chunk
-    constexpr int NOUT = (NJ * 12 + 255) / 256;    // d loss / d A elements per thread
     __shared__ float sdT[VCH * 12];
+    __shared__ float sdA[NJ * 12];
     __shared__ float sred[4][SKB_NACC];
-    const int tid = threadIdx.x;
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const int r = row0 + blockIdx.x;
     const float* x = X + (size_t)r * XDIM;
     const float s = *scale;
@@ -116,17 +116,7 @@ __global__ __launch_bounds__(256) void skin_bwd_kernel(SkinModel sm, int nc, con
     float acc[SKB_NACC];
 #pragma unroll
     for (int i = 0; i < SKB_NACC; ++i) acc[i] = 0.f;
-    // ordered (atomic-free, run-to-run reproducible) reduction of dA_j = sum_v w_vj dT_v: each thread owns
-    // up to NOUT elements (j, e) and walks joint j's vertex list (ascending) chunk by chunk
-    float accA[NOUT];
-    int ptr[NOUT], pend[NOUT];
-#pragma unroll
-    for (int k = 0; k < NOUT; ++k) {
-        int o = tid + k * 256;
-        accA[k] = 0.f;
-        ptr[k] = o < NJ * 12 ? sm.csc_start[o / 12] : 0;
-        pend[k] = o < NJ * 12 ? sm.csc_start[o / 12 + 1] : 0;
-    }
+    for (int i = tid; i < NJ * 12; i += 256) sdA[i] = 0.f;
     for (int c0 = 0; c0 < nc; c0 += VCH) {
         const int c1 = min(nc, c0 + VCH);
         for (int c = c0 + tid; c < c1; c += 256) {
@@ -153,12 +143,32 @@ __global__ __launch_bounds__(256) void skin_bwd_kernel(SkinModel sm, int nc, con
             for (int e = 0; e < 12; ++e) sdT[(c - c0) * 12 + e] = b.dT[e];
         }
         __syncthreads();
+        // dA_j += sum_v w_vj dT_v, ordered and atomic-free (run-to-run reproducible): the joints are dealt
+        // to the 4 waves; a wave's lanes stride over joint j's vertex list (ascending, restricted to this
+        // chunk by two binary searches) and are combined by a butterfly
+        for (int j = wave; j < NJ; j += 4) {
+            int lo = sm.csc_start[j], hi = sm.csc_start[j + 1];
+            if (lo == hi) continue;                         // wave-uniform
+            if (nc > VCH) {
+                int a = lo, bnd = hi;
+                while (a < bnd) { int m = (a + bnd) >> 1; if (sm.csc_v[m] < c0) a = m + 1; else bnd = m; }
+                lo = a; bnd = hi;
+                while (a < bnd) { int m = (a + bnd) >> 1; if (sm.csc_v[m] < c1) a = m + 1; else bnd = m; }
+                hi = a;
+            }
+            float pa[12];
 #pragma unroll
-        for (int k = 0; k < NOUT; ++k) {
-            const int e = (tid + k * 256) % 12;
-            while (ptr[k] < pend[k] && sm.csc_v[ptr[k]] < c1) {
-                accA[k] += sm.csc_w[ptr[k]] * sdT[(sm.csc_v[ptr[k]] - c0) * 12 + e];
-                ++ptr[k];
+            for (int e = 0; e < 12; ++e) pa[e] = 0.f;
+            for (int i = lo + lane; i < hi; i += 64) {
+                const float w = sm.csc_w[i];
+                const float* t = sdT + (sm.csc_v[i] - c0) * 12;
+#pragma unroll
+                for (int e = 0; e < 12; ++e) pa[e] += w * t[e];
+            }
+#pragma unroll
+            for (int e = 0; e < 12; ++e) {
+                float v = wave_sum(pa[e]);
+                if (lane == 0) sdA[j * 12 + e] += v;
             }
         }
         __syncthreads();
@@ -169,9 +179,7 @@ __global__ __launch_bounds__(256) void skin_bwd_kernel(SkinModel sm, int nc, con
         if ((tid & 63) == 0) sred[tid >> 6][i] = v;
     }
     __syncthreads();
-#pragma unroll
-    for (int k = 0; k < NOUT; ++k)
-        if (tid + k * 256 < NJ * 12) dA[(size_t)r * NJ * 12 + tid + k * 256] = accA[k];
+    for (int i = tid; i < NJ * 12; i += 256) dA[(size_t)r * NJ * 12 + i] = sdA[i];
     if (tid < SKB_NACC) {
         float v = sred[0][tid] + sred[1][tid] + sred[2][tid] + sred[3][tid];
         if (tid < NBETA) dbeta_v[(size_t)r * NBETA + tid] = v;
@@ -360,7 +368,8 @@ struct OptState {
     fdcap_opt_config cfg;
     int R = 0;            // rows = n_local + 4
     bool contact_on = false;
-    int nsplit = 8;
+    int nsplit = 8;           // scene splits of the in-loop NN launch
+    int nsplit_bf = 8;        // ... of a brute-force launch (timing API)
     struct Ext { float* p = nullptr; } X, CAM, scale, dscale;   // caller-owned, registered
     struct ExtD { double* p = nullptr; } losses;
     DevBuf<float> X0, mask, mX, vX, mCAM, vCAM, mS, vS;
@@ -791,8 +800,16 @@ int fdcap_opt_create(fdcap_ctx* c, const fdcap_opt_config* cfg, float* rows_x, f
     const int R = o->R = cfg->n_local + 4;
     o->contact_on = c->ns > 0 && c->nc > 0 && cfg->weight_contact != 0.f;
     const size_t nq = (size_t)R * std::max(c->nc, 1);
-    o->nsplit = o->contact_on ? nn_pick_nsplit((int)((size_t)cfg->n_local * c->nc), (int)c->ns) : 1;
-    if (const char* e = getenv("FDCAP_NN_NSPLIT")) o->nsplit = std::max(1, atoi(e));      // tuning knob
+    {
+        const char* e1 = getenv("FDCAP_NN_SEED");
+        const char* e2 = getenv("FDCAP_NN_CULL");
+        o->use_seed = !(e1 && e1[0] == '0');
+        o->use_cull = !(e2 && e2[0] == '0');
+    }
+    const int nq_all = (int)((size_t)cfg->n_local * c->nc);
+    o->nsplit = o->contact_on ? nn_pick_nsplit(nq_all, (int)c->ns, o->use_seed && o->use_cull) : 1;
+    o->nsplit_bf = o->contact_on ? nn_pick_nsplit(nq_all, (int)c->ns, false) : 1;
+    if (const char* e = getenv("FDCAP_NN_NSPLIT")) o->nsplit = o->nsplit_bf = std::max(1, atoi(e));      // tuning knob
     int err = 0;
 #define AL(buf, cnt) if (!err) { hipError_t e_ = (buf).ensure(cnt); if (e_ != hipSuccess) err = (int)e_; else e_ = hipMemset((buf).p, 0, (size_t)(cnt) * sizeof(*(buf).p)); }
     o->X.p = rows_x; o->CAM.p = rows_cam; o->scale.p = scale_d; o->dscale.p = dscale_d; o->losses.p = losses_d;
@@ -808,7 +825,7 @@ int fdcap_opt_create(fdcap_ctx* c, const fdcap_opt_config* cfg, float* rows_x, f
     AL(o->dCAM, (size_t)R * 16) AL(o->dscale_row, R)
     if (o->contact_on) {
         AL(o->Voff, nq * 3) AL(o->Vw, nq * 3) AL(o->dist, nq) AL(o->idx, nq) AL(o->dVoff, nq * 3)
-        AL(o->pd, (size_t)o->nsplit * nq) AL(o->pi, (size_t)o->nsplit * nq)
+        AL(o->pd, (size_t)std::max(o->nsplit, o->nsplit_bf) * nq) AL(o->pi, (size_t)std::max(o->nsplit, o->nsplit_bf) * nq)
     }
 #undef AL
     if (!err && o->contact_on) {
@@ -816,10 +833,6 @@ int fdcap_opt_create(fdcap_ctx* c, const fdcap_opt_config* cfg, float* rows_x, f
         if (e_ != hipSuccess) err = (int)e_;
     }
     if (!err) {
-        const char* e = getenv("FDCAP_NN_SEED");
-        o->use_seed = !(e && e[0] == '0');
-        const char* e2 = getenv("FDCAP_NN_CULL");
-        o->use_cull = !(e2 && e2[0] == '0');
         float s = cfg->scale_init;
         hipError_t e_ = hipMemcpy(o->scale.p, &s, sizeof(float), hipMemcpyHostToDevice);
         if (e_ != hipSuccess) err = (int)e_;
@@ -991,10 +1004,11 @@ int fdcap_opt_time_chamfer(fdcap_ctx* c, int32_t iters, int32_t brute_force, flo
     hipEvent_t e0, e1;
     HIP_TRY(hipEventCreate(&e0));
     HIP_TRY(hipEventCreate(&e1));
-    HIP_TRY(nn_search(o->Vw.p + off, nl * nc, T, o->dist.p + 2 * nc, o->idx.p + 2 * nc, o->pd.p, o->pi.p, o->nsplit, st, seed));
+    const int nsp = brute_force ? o->nsplit_bf : o->nsplit;
+    HIP_TRY(nn_search(o->Vw.p + off, nl * nc, T, o->dist.p + 2 * nc, o->idx.p + 2 * nc, o->pd.p, o->pi.p, nsp, st, seed));
     HIP_TRY(hipEventRecord(e0, st));
     for (int i = 0; i < iters; ++i)
-        HIP_TRY(nn_search(o->Vw.p + off, nl * nc, T, o->dist.p + 2 * nc, o->idx.p + 2 * nc, o->pd.p, o->pi.p, o->nsplit, st, seed));
+        HIP_TRY(nn_search(o->Vw.p + off, nl * nc, T, o->dist.p + 2 * nc, o->idx.p + 2 * nc, o->pd.p, o->pi.p, nsp, st, seed));
     HIP_TRY(hipEventRecord(e1, st));
     HIP_TRY(hipEventSynchronize(e1));
     float t = 0.f;

@@ -19,7 +19,7 @@ bm = synth.make_body_model(10475, seed=0); vp = synth.make_vposer(seed=1); clip 
 scene = synth.make_scene(ns, seed=2); l, r = synth.make_contact_ids(bm.v_template, per_part=250, seed=4)
 fop = FittingOP({"num_iter": 2}, {}, N, body_model=bm, vposer=vp, scene_verts=scene, contact_ids=np.concatenate([l, r]),
                 camera_ext=read_camerapose(clip.camerapose_lines))
-if os.environ.get("FDC_NN_EXP"):
+if os.environ.get("FDC_NN_EXP") and os.environ["FDC_NN_EXP"] != "6":
     import time
     from fdcap_amd import ops
     q = (torch.rand(N, 500, 3, device="cuda") * torch.tensor([2.0, 2.0, 1.5], device="cuda"))
