@@ -26,7 +26,7 @@ constexpr int MF_CH = 512;             // scene points per LDS chunk of the MFMA
 struct NNTarget {
     const float4* pts;        // [n] {x, y, z, bits(original index)}
     int n;
-    const float4* bounds;     // optional [ceil(n / MF_CH)] {centre xyz, radius} of each chunk (pts spatially sorted)
+    const float4* bounds;     // optional [2 * ceil(n / MF_CH)] axis-aligned box {lo xyz, -}, {hi xyz, -} of each chunk (pts spatially sorted)
     const int* inv_perm;      // optional [n] original index -> position in pts (null: identity)
 };
 
@@ -128,10 +128,11 @@ __global__ __launch_bounds__(256) void nn_direct_kernel(const float* __restrict_
 // Two exact accelerators sit on top (both only prune; results do not depend on them):
 //   seed   : an initial neighbour per query (the optimiser passes last iteration's result) gives a
 //            tight bound from the first tile on;
-//   bounds : if the scene is spatially sorted and comes with a bounding sphere per MF_CH-point
-//            chunk, a chunk is skipped when it lies farther from the workgroup's centroid than
-//            Rw = max_i (X_i + sqrt(best_i)) -- no point of it can beat or tie any query's bound.
-//            Without seeds Rw is infinite and the scan is plain brute force.
+//   bounds : if the scene is spatially sorted and comes with an axis-aligned box per MF_CH-point
+//            chunk, a chunk is skipped unless some query i has dist(x_i, box) <= sqrt(best_i) -- no
+//            point of a skipped chunk can beat or tie any query's bound.  (Boxes, not spheres: scanned
+//            surfaces give flat chunks, and a query 1 m above a floor patch must not pull in every
+//            patch within 1 m.)  Without seeds the bound is infinite and the scan is plain brute force.
 constexpr float MF_K1 = 1e-4f, MF_K2 = 8e-6f;
 constexpr int MF_MAXCHUNK = 2048;      // chunks per split the survivor list can hold (host keeps splits below it)
 
@@ -161,6 +162,13 @@ __device__ __forceinline__ uint2 bf_split_dup(float v) {
 __device__ __forceinline__ float mf_thr(float best, float X, float X2) {
     float Y = X + sqrtf(best);
     return best - X2 + (MF_K1 * X * Y + MF_K2 * (X2 + Y * Y));
+}
+
+// squared distance from a point to an axis-aligned box
+__device__ __forceinline__ float box_d2(float4 lo, float4 hi, float x, float y, float z) {
+    float dx = fmaxf(fmaxf(lo.x - x, x - hi.x), 0.f), dy = fmaxf(fmaxf(lo.y - y, y - hi.y), 0.f);
+    float dz = fmaxf(fmaxf(lo.z - z, z - hi.z), 0.f);
+    return dx * dx + dy * dy + dz * dz;
 }
 
 template <int NQ>
@@ -264,27 +272,24 @@ __global__ __launch_bounds__(256) void nn_mfma_kernel(const float* __restrict__ 
     const bool cull = T.bounds != nullptr && Rw < INFINITY && nchunk <= MF_MAXCHUNK;
     int nsurv = nchunk;
     if (cull) {
-        float sb[NQ];
+        float sb[NQ];                                         // best_i with the rounding slack of the box test
 #pragma unroll
-        for (int n = 0; n < NQ; ++n) sb[n] = (qidx[n] < nq) ? sqrtf(own_d[n]) * 1.00001f + 1e-6f : -INFINITY;
+        for (int n = 0; n < NQ; ++n) sb[n] = (qidx[n] < nq) ? own_d[n] * 1.00002f + 1e-9f : -INFINITY;
+        const float Rw2 = Rw * Rw;
         for (int c0 = 0; c0 < nchunk; c0 += 256) {            // pass 1: centroid reach
             const int ci = c0 + tid;
             if (ci < nchunk) {
-                const float4 b = T.bounds[t_begin / MF_CH + ci];
-                const float dx = b.x - cx, dy = b.y - cy, dz = b.z - cz;
-                slist[ci] = (sqrtf(dx * dx + dy * dy + dz * dz) - b.w > Rw) ? 0 : 1;
+                const float4 lo = T.bounds[2 * (t_begin / MF_CH + ci)], hi = T.bounds[2 * (t_begin / MF_CH + ci) + 1];
+                slist[ci] = (box_d2(lo, hi, cx, cy, cz) > Rw2) ? 0 : 1;
             }
         }
         __syncthreads();
         for (int ci = half; ci < nchunk; ci += 2) {           // pass 2: per query (each half-wave takes every other chunk)
             if (slist[ci] == 0) continue;                     // workgroup-uniform
-            const float4 b = T.bounds[t_begin / MF_CH + ci];
+            const float4 lo = T.bounds[2 * (t_begin / MF_CH + ci)], hi = T.bounds[2 * (t_begin / MF_CH + ci) + 1];
             bool hit = false;
 #pragma unroll
-            for (int n = 0; n < NQ; ++n) {
-                const float dx = b.x - qx[n], dy = b.y - qy[n], dz = b.z - qz[n];
-                hit |= sqrtf(dx * dx + dy * dy + dz * dz) - b.w <= sb[n];
-            }
+            for (int n = 0; n < NQ; ++n) hit |= box_d2(lo, hi, qx[n], qy[n], qz[n]) <= sb[n];
             if (hit) slist[ci] = 2;                           // same-value stores from several lanes: benign
         }
         __syncthreads();

@@ -398,7 +398,7 @@ struct fdcap_ctx {
     bool full_ready = false;
     DevBuf<float4> scene;          // original order {x,y,z,bits(i)}: gradient gather by index
     DevBuf<float4> scene_sorted;   // Morton order {x,y,z,bits(original index)}: what the NN scan streams
-    DevBuf<float4> scene_bounds;   // bounding sphere of each MF_CH-point chunk of scene_sorted
+    DevBuf<float4> scene_bounds;   // axis-aligned box {lo},{hi} of each MF_CH-point chunk of scene_sorted
     DevBuf<int> scene_inv;         // original index -> position in scene_sorted
     int64_t ns = 0;
     NNTarget nn_target(bool cull) const {
@@ -590,7 +590,7 @@ int fdcap_set_scene(fdcap_ctx* c, const float* xyz, int64_t ns) {
     std::vector<int> inv((size_t)ns);
     for (int64_t p = 0; p < ns; ++p) { sorted[p] = orig[key[p].second]; inv[key[p].second] = (int)p; }
     const int64_t nchunk = (ns + MF_CH - 1) / MF_CH;
-    std::vector<float4> bounds((size_t)nchunk);
+    std::vector<float4> bounds((size_t)nchunk * 2);           // axis-aligned box per chunk, slightly inflated
     for (int64_t ch = 0; ch < nchunk; ++ch) {
         int64_t a = ch * MF_CH, b = std::min<int64_t>(ns, a + MF_CH);
         float blo[3] = {1e30f, 1e30f, 1e30f}, bhi[3] = {-1e30f, -1e30f, -1e30f};
@@ -598,13 +598,12 @@ int fdcap_set_scene(fdcap_ctx* c, const float* xyz, int64_t ns) {
             const float v[3] = {sorted[p].x, sorted[p].y, sorted[p].z};
             for (int k = 0; k < 3; ++k) { blo[k] = std::min(blo[k], v[k]); bhi[k] = std::max(bhi[k], v[k]); }
         }
-        double cc[3] = {0.5 * ((double)blo[0] + bhi[0]), 0.5 * ((double)blo[1] + bhi[1]), 0.5 * ((double)blo[2] + bhi[2])};
-        double r2 = 0.0;
-        for (int64_t p = a; p < b; ++p) {
-            double dx = sorted[p].x - cc[0], dy = sorted[p].y - cc[1], dz = sorted[p].z - cc[2];
-            r2 = std::max(r2, dx * dx + dy * dy + dz * dz);
+        for (int k = 0; k < 3; ++k) {
+            float pad = 1e-6f + 1e-6f * std::max(fabsf(blo[k]), fabsf(bhi[k]));
+            blo[k] -= pad; bhi[k] += pad;
         }
-        bounds[ch] = make_float4((float)cc[0], (float)cc[1], (float)cc[2], (float)(sqrt(r2) * 1.00001 + 1e-6));
+        bounds[2 * ch] = make_float4(blo[0], blo[1], blo[2], 0.f);
+        bounds[2 * ch + 1] = make_float4(bhi[0], bhi[1], bhi[2], 0.f);
     }
     HIP_TRY(c->scene.upload(orig.data(), orig.size()));
     HIP_TRY(c->scene_sorted.upload(sorted.data(), sorted.size()));
