@@ -191,6 +191,93 @@ __global__ __launch_bounds__(256) void gemm_f32_mfma_ksplit_kernel(
     }
 }
 
+// Wide "NN" product C[M,N] = A[M,K] x B[K,N] with N >> M (the full-mesh pose blendshapes:
+// M = frames ~ 1e3, K = 486, N = 3V = 31 425).  B (61 MB) is the only operand that does not fit in
+// L2, so the blockIdx -> tile map keeps all M-tiles of one 128-column B panel on ONE XCD, back to
+// back (blocks b, b+8, ..., b+8*(MT-1) share n-tile): the panel is fetched from HBM once per XCD L2
+// and reused by the other M-tiles.  128x128 tiles, 2x2 waves x 2x2 MFMA accumulators, next K slab
+// prefetched into registers during the MFMAs, coalesced loads along N for B.
+template <int EPI>
+__global__ __launch_bounds__(256) void gemm_f32_mfma_wide_kernel(
+    const float* __restrict__ A, int lda, const float* __restrict__ B, int ldb, float* __restrict__ C,
+    int ldc, int M, int N, int K, const float* __restrict__ aux, int ldaux) {
+    constexpr int BM = 128, BN = 128, BK = 32, LD = BK + 1, NL = (BM * BK) / 256;   // 16 loads per operand per thread
+    __shared__ float As[BM * LD];
+    __shared__ float Bs[BN * LD];
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int MT = (M + BM - 1) / BM, NT = (N + BN - 1) / BN;
+    // XCD-aware map: xcd = b % 8 owns n-tiles {xcd, xcd + 8, ...}; within an XCD consecutive slots walk M
+    const int b = blockIdx.x, xcd = b & 7, slot = b >> 3;
+    const int nt = (slot / MT) * 8 + xcd, mt = slot % MT;
+    if (nt >= NT) return;
+    const int m0 = mt * BM, n0 = nt * BN;
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    float ra[NL], rb[NL];
+    auto gload = [&](int k0) {
+#pragma unroll
+        for (int i = 0; i < NL; ++i) {
+            int e = tid + i * 256, r = e >> 5, c = e & 31;          // A: 32 consecutive k per row
+            int gm = m0 + r, gk = k0 + c;
+            ra[i] = (gm < M && gk < K) ? A[(size_t)gm * lda + gk] : 0.f;
+        }
+#pragma unroll
+        for (int i = 0; i < NL; ++i) {
+            int e = tid + i * 256, kk = e >> 7, nn = e & 127;       // B: 128 consecutive n per k row
+            int gn = n0 + nn, gk = k0 + kk;
+            rb[i] = (gn < N && gk < K) ? B[(size_t)gk * ldb + gn] : 0.f;
+        }
+    };
+    auto lstore = [&]() {
+#pragma unroll
+        for (int i = 0; i < NL; ++i) {
+            int e = tid + i * 256;
+            As[(e >> 5) * LD + (e & 31)] = ra[i];
+            Bs[(e & 127) * LD + (e >> 7)] = rb[i];
+        }
+    };
+    gload(0);
+    for (int k0 = 0; k0 < K; k0 += BK) {
+        lstore();
+        __syncthreads();
+        if (k0 + BK < K) gload(k0 + BK);
+#pragma unroll 4
+        for (int kk = 0; kk < BK; kk += 2) {
+            float a[2], bb[2];
+#pragma unroll
+            for (int i = 0; i < 2; ++i) a[i] = As[((wm * 2 + i) * 32 + (lane & 31)) * LD + kk + (lane >> 5)];
+#pragma unroll
+            for (int j = 0; j < 2; ++j) bb[j] = Bs[((wn * 2 + j) * 32 + (lane & 31)) * LD + kk + (lane >> 5)];
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], bb[j], acc[i][j], 0, 0, 0);
+        }
+        __syncthreads();
+    }
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                int m = m0 + (wm * 2 + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                int n = n0 + (wn * 2 + j) * 32 + (lane & 31);
+                if (m < M && n < N) {
+                    float v = acc[i][j][r];
+                    if (EPI == EPI_ACCUM) v += C[(size_t)m * ldc + n];
+                    C[(size_t)m * ldc + n] = v;
+                }
+            }
+}
+
 template <bool NK, int EPI>
 static inline hipError_t gemm_dispatch_tile(const float* A, int lda, const float* B, int ldb, float* C, int ldc,
                                             int M, int N, int K, const float* aux, int ldaux, hipStream_t st) {
@@ -199,6 +286,14 @@ static inline hipError_t gemm_dispatch_tile(const float* A, int lda, const float
     if ((long long)M * N < 64LL * 64 * 1024 && K >= 32) {
         dim3 grid((N + 31) / 32, (M + 31) / 32);
         hipLaunchKernelGGL((gemm_f32_mfma_ksplit_kernel<NK, EPI>), grid, dim3(256), 0, st, A, lda, B, ldb, C, ldc, M, N, K,
+                           aux, ldaux);
+        return hipGetLastError();
+    }
+    // wide NN products (full-mesh pose blendshapes): XCD-aware B-panel reuse + register prefetch
+    if (!NK && (EPI == EPI_STORE || EPI == EPI_ACCUM) && (long long)M * N >= 128LL * 128 * 512 && N >= 8 * 128) {
+        const int MT = (M + 127) / 128, NT = (N + 127) / 128;
+        const int blocks = (NT + 7) / 8 * 8 * MT;
+        hipLaunchKernelGGL((gemm_f32_mfma_wide_kernel<EPI>), dim3(blocks), dim3(256), 0, st, A, lda, B, ldb, C, ldc, M, N, K,
                            aux, ldaux);
         return hipGetLastError();
     }

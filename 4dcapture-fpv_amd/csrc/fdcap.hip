@@ -988,6 +988,37 @@ int fdcap_opt_get_grads(fdcap_ctx* c, float* dx, float* dcam, void* stream) {
     return FDCAP_OK;
 }
 
+int fdcap_time_blend_gemm(fdcap_ctx* c, int32_t rows, int32_t iters, float* ms, void* stream) {
+    if (!c || rows <= 0 || iters <= 0 || !ms) return FDCAP_E_ARG;
+    hipStream_t st = (hipStream_t)stream;
+    if (!c->full_ready) {
+        std::vector<int64_t> all(c->V);
+        for (int i = 0; i < c->V; ++i) all[i] = i;
+        int e = build_skin_set(c, all, &c->full);
+        if (e) return e;
+        c->full_ready = true;
+    }
+    const int V = c->V;
+    HIP_TRY(c->ws_f[6].ensure((size_t)rows * NPF));
+    HIP_TRY(c->ws_f[11].ensure((size_t)rows * 3 * V));
+    HIP_TRY(hipMemsetAsync(c->ws_f[6].p, 0x3c, (size_t)rows * NPF * sizeof(float), st));   // arbitrary finite pattern
+    hipEvent_t e0, e1;
+    HIP_TRY(hipEventCreate(&e0));
+    HIP_TRY(hipEventCreate(&e1));
+    HIP_TRY(gemm_f32(false, EPI_STORE, c->ws_f[6].p, NPF, c->full.posedirs.p, 3 * V, c->ws_f[11].p, 3 * V, rows, 3 * V, NPF, nullptr, 0, st));
+    HIP_TRY(hipEventRecord(e0, st));
+    for (int i = 0; i < iters; ++i)
+        HIP_TRY(gemm_f32(false, EPI_STORE, c->ws_f[6].p, NPF, c->full.posedirs.p, 3 * V, c->ws_f[11].p, 3 * V, rows, 3 * V, NPF, nullptr, 0, st));
+    HIP_TRY(hipEventRecord(e1, st));
+    HIP_TRY(hipEventSynchronize(e1));
+    float t = 0.f;
+    HIP_TRY(hipEventElapsedTime(&t, e0, e1));
+    *ms = t / iters;
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+    return FDCAP_OK;
+}
+
 int fdcap_opt_time_chamfer(fdcap_ctx* c, int32_t iters, int32_t brute_force, float* ms, void* stream) {
     if (!c || !c->opt || !ms || iters <= 0) return FDCAP_E_ARG;
     OptState* o = c->opt;

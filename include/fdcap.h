@@ -176,6 +176,10 @@ int fdcap_opt_get_contact(fdcap_ctx* ctx, float* dist_d, int32_t* idx_d, void* s
 /* Gradients of the last fdcap_opt_backward (testing): dx_d [n_local,78], dcam_d [n_local,16]. */
 int fdcap_opt_get_grads(fdcap_ctx* ctx, float* dx_d, float* dcam_d, void* stream);
 
+/* Kernel-level timing of the full-mesh pose-blendshape GEMM ([rows,486] x posedirs
+ * [486, 3V] on the fp32 matrix cores), HIP events on `stream`, mean milliseconds per launch. */
+int fdcap_time_blend_gemm(fdcap_ctx* ctx, int32_t rows, int32_t iters, float* ms, void* stream);
+
 /* Kernel-level timing of the Chamfer NN launch for the roofline line: runs `iters` launches of
  * the optimiser's Chamfer forward on `stream` between two HIP events and returns the mean
  * milliseconds per launch in *ms.  brute_force = 1: every (query, scene point) pair is visited
