@@ -792,10 +792,11 @@ int fdcap_opt_create(fdcap_ctx* c, const fdcap_opt_config* cfg, float* rows_x, f
     if (!c || !cfg || !rows_x || !rows_cam || !scale_d || !dscale_d || !losses_d || cfg->n_local <= 0 || cfg->n_total < cfg->n_local || cfg->frame0 < 0 ||
         cfg->frame0 + cfg->n_local > cfg->n_total)
         return FDCAP_E_ARG;
-    fdcap_opt_destroy(c);
-    OptState* o = new OptState();
+    // a second clip of the same shape reuses the scratch allocations (every buffer is re-zeroed below)
+    OptState* o = c->opt ? c->opt : new OptState();
     c->opt = o;
     o->cfg = *cfg;
+    o->cam_steps = 0;
     const int R = o->R = cfg->n_local + 4;
     o->contact_on = c->ns > 0 && c->nc > 0 && cfg->weight_contact != 0.f;
     const size_t nq = (size_t)R * std::max(c->nc, 1);

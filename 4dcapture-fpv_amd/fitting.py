@@ -191,7 +191,7 @@ class FittingOP:
             do_log = bool(log_every) and (ii % log_every == 0 or ii == self.num_iter - 1)
             st = capi.current_stream()
             capi.check(lib.fdcap_opt_backward(h, ii, P, 1 if do_log else 0, st), "fdcap_opt_backward")
-            if multi:
+            if multi and (ii < P or do_log):          # scale only steps in phase 1 (:566, :578)
                 allreduce_scalars(self.shard, self._dscale, self._losses if do_log else None)
             if do_log:
                 self._append_log(log, ii, ii >= P)
