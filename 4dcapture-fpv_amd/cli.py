@@ -17,7 +17,7 @@ def main(argv=None):
     ap = argparse.ArgumentParser(prog="global_optimization (fdcap_amd / MI355X)")
     ap.add_argument("body_path")
     ap.add_argument("fit_path")
-    ap.add_argument("mode", nargs="?", default="global", choices=["global"])
+    ap.add_argument("mode", nargs="?", default="global", choices=["global", "local"])
     ap.add_argument("--scene-root", default="/home/miao/")
     ap.add_argument("--scene", default=None, help="scene vertices (.ply/.xyz/.npy); default <root>/<sample>/meshed-poisson.ply")
     ap.add_argument("--camera", default=None, help="camerapose.txt; default <root>/<sample>/camerapose.txt")

@@ -93,17 +93,40 @@ __device__ __forceinline__ float wave_sum(float v) {
 
 // workgroup per frame: contact-term gradient -> skinning backward, reduced over the frame's
 // contact vertices.  dist/idx/Vw/dVoff are [rows, nc(,3)].
-constexpr int SKB_NACC = NBETA + 3 + 12 + 1 + 1;   // dbeta, dtransl, dM, ds, contact-term sum
+// contact robustifier (:295) gradient wrt the world-space contact vertices + its un-weighted sum
+__global__ void contact_grad_kernel(const float* __restrict__ Vw, const float* __restrict__ dist,
+                                    const int* __restrict__ idx, const float4* __restrict__ scene, size_t n,
+                                    float coef, float* __restrict__ dVw, double* __restrict__ loss_contact_sum) {
+    __shared__ float sred[4];
+    size_t qi = (size_t)blockIdx.x * 256 + threadIdx.x;
+    float term = 0.f;
+    if (qi < n) {
+        float dterm;
+        term = contact_term(dist[qi], &dterm);
+        int j = idx[qi];
+        float gg = j >= 0 ? 2.f * coef * dterm : 0.f;           // no neighbour (NaN query): zero gradient
+        float4 p = j >= 0 ? scene[j] : make_float4(0.f, 0.f, 0.f, 0.f);
+        dVw[3 * qi] = gg * (Vw[3 * qi] - p.x);
+        dVw[3 * qi + 1] = gg * (Vw[3 * qi + 1] - p.y);
+        dVw[3 * qi + 2] = gg * (Vw[3 * qi + 2] - p.z);
+    }
+    term = wave_sum(term);
+    if ((threadIdx.x & 63) == 0) sred[threadIdx.x >> 6] = term;
+    __syncthreads();
+    if (threadIdx.x == 0) atomicAdd(loss_contact_sum, (double)((sred[0] + sred[1]) + (sred[2] + sred[3])));
+}
+
+// workgroup per frame: skinning + world-transform backward of d loss / d world vertices, reduced over
+// the frame's vertex set.  dVw / dVoff are [rows, nc, 3] and may alias (each thread reads its vertex's
+// gradient before it writes the vertex's pose-blend gradient).
+constexpr int SKB_NACC = NBETA + 3 + 12 + 1;   // dbeta, dtransl, dM, ds
 __global__ __launch_bounds__(256) void skin_bwd_kernel(SkinModel sm, int nc, const float* __restrict__ X,
                                                        const float* __restrict__ Voff, const float* __restrict__ A,
                                                        const float* __restrict__ M, const float* __restrict__ scale,
-                                                       int row0, const float* __restrict__ Vw,
-                                                       const float* __restrict__ dist, const int* __restrict__ idx,
-                                                       const float4* __restrict__ scene, float coef,
-                                                       float* __restrict__ dVoff, float* __restrict__ dA,
-                                                       float* __restrict__ dbeta_v, float* __restrict__ dtransl_v,
-                                                       float* __restrict__ dMv, float* __restrict__ dsv,
-                                                       double* __restrict__ loss_contact_sum) {
+                                                       int row0, const float* dVw, float* dVoff,
+                                                       float* __restrict__ dA, float* __restrict__ dbeta_v,
+                                                       float* __restrict__ dtransl_v, float* __restrict__ dMv,
+                                                       float* __restrict__ dsv) {
     constexpr int VCH = 1024;                      // vertices per LDS chunk
     __shared__ float sdT[VCH * 12];
     __shared__ float sdA[NJ * 12];
@@ -121,12 +144,7 @@ __global__ __launch_bounds__(256) void skin_bwd_kernel(SkinModel sm, int nc, con
         const int c1 = min(nc, c0 + VCH);
         for (int c = c0 + tid; c < c1; c += 256) {
             size_t qi = (size_t)r * nc + c;
-            float dterm;
-            float term = contact_term(dist[qi], &dterm);
-            int j = idx[qi];
-            float4 p = j >= 0 ? scene[j] : make_float4(Vw[3 * qi], Vw[3 * qi + 1], Vw[3 * qi + 2], 0.f);   // no neighbour (NaN query): zero gradient
-            float gg = 2.f * coef * dterm;
-            V3 g = v3(gg * (Vw[3 * qi] - p.x), gg * (Vw[3 * qi + 1] - p.y), gg * (Vw[3 * qi + 2] - p.z));
+            V3 g = v3(dVw[3 * qi], dVw[3 * qi + 1], dVw[3 * qi + 2]);
             SkinFwd f = skin_forward_vertex(sm, c, x + X_BETAS, Voff + 3 * qi, A + (size_t)r * NJ * 12, transl,
                                             M + (size_t)r * 12, s);
             SkinBwd b = skin_backward_vertex(f, M + (size_t)r * 12, s, g);
@@ -138,7 +156,6 @@ __global__ __launch_bounds__(256) void skin_bwd_kernel(SkinModel sm, int nc, con
 #pragma unroll
             for (int e = 0; e < 12; ++e) acc[NBETA + 3 + e] += b.dM[e];
             acc[NBETA + 15] += b.ds;
-            acc[NBETA + 16] += term;
 #pragma unroll
             for (int e = 0; e < 12; ++e) sdT[(c - c0) * 12 + e] = b.dT[e];
         }
@@ -185,8 +202,91 @@ __global__ __launch_bounds__(256) void skin_bwd_kernel(SkinModel sm, int nc, con
         if (tid < NBETA) dbeta_v[(size_t)r * NBETA + tid] = v;
         else if (tid < NBETA + 3) dtransl_v[(size_t)r * 3 + tid - NBETA] = v;
         else if (tid < NBETA + 15) dMv[(size_t)r * 12 + tid - NBETA - 3] = v;
-        else if (tid == NBETA + 15) dsv[r] = v;
-        else atomicAdd(loss_contact_sum, (double)v);
+        else dsv[r] = v;
+    }
+}
+
+// mode 'local', cal_loss2 (:404-405): d/dV of mean |second difference over frames| of ALL world vertices.
+// V is [rows, nv3] (nv3 = 3 * vertices); owned rows start at row0, global frame = frame0 + blockIdx.y.
+__global__ void vert_smooth_kernel(const float* __restrict__ V, size_t nv3, int row0, int frame0, int n_total,
+                                   float w_over_cnt, float* __restrict__ dV, double* __restrict__ loss_sum) {
+    __shared__ float sred[4];
+    const size_t e = (size_t)blockIdx.x * 256 + threadIdx.x;
+    const int r = row0 + blockIdx.y, g = frame0 + blockIdx.y;
+    float ab = 0.f;
+    if (e < nv3) {
+        const float* v = V + (size_t)r * nv3 + e;
+        const float x0 = v[0];
+        const float xm2 = g >= 2 ? v[-2 * (ptrdiff_t)nv3] : 0.f, xm1 = g >= 1 ? v[-(ptrdiff_t)nv3] : 0.f;
+        const float xp1 = g + 1 < n_total ? v[nv3] : 0.f, xp2 = g + 2 < n_total ? v[2 * nv3] : 0.f;
+        float s0 = 0.f, s1 = 0.f, s2 = 0.f;
+        if (g <= n_total - 3) { float d = second_diff(x0, xp1, xp2); s0 = sgn(d); ab = fabsf(d); }
+        if (g >= 1 && g <= n_total - 2) s1 = sgn(second_diff(xm1, x0, xp1));
+        if (g >= 2) s2 = sgn(second_diff(xm2, xm1, x0));
+        dV[(size_t)r * nv3 + e] = (s0 - 2.f * s1 + s2) * w_over_cnt;
+    }
+    ab = wave_sum(ab);
+    if ((threadIdx.x & 63) == 0) sred[threadIdx.x >> 6] = ab;
+    __syncthreads();
+    if (threadIdx.x == 0) atomicAdd(loss_sum, (double)((sred[0] + sred[1]) + (sred[2] + sred[3])));
+}
+
+// mode 'local', cal_loss2 (:415-429): foot-skate term  mean|dL * w_left| + mean|dR * w_right| on the first
+// difference over frames of the left / right contact vertices; adds its gradient into dV (full-mesh layout).
+// vid[c] = mesh vertex of contact slot c in the CALLER's order (first n_left = left part); wgt[N] per frame.
+__global__ void foot_skate_kernel(const float* __restrict__ V, size_t nv3, const int* __restrict__ vid, int nc,
+                                  int n_left, const float* __restrict__ wgt, int row0, int frame0, int n_total,
+                                  float* __restrict__ dV, double* __restrict__ loss_sum) {
+    __shared__ float sred[4];
+    const int t = blockIdx.x * 256 + threadIdx.x;
+    const int r = row0 + blockIdx.y, g = frame0 + blockIdx.y;
+    float ab = 0.f;
+    if (t < nc * 3) {
+        const int c = t / 3, k = t % 3;
+        const bool is_left = c < n_left;
+        const int npart = is_left ? n_left : nc - n_left;
+        const float inv = 1.f / ((float)(n_total - 1) * (float)npart * 3.f);
+        const size_t e = (size_t)vid[c] * 3 + k;
+        const float* v = V + (size_t)r * nv3 + e;
+        float grad = 0.f;
+        // weight_right = w, weight_left = 1 - w, both zeroed below 0.5 (:418-422); pair (i, i+1) uses w[i+1]
+        if (g + 1 < n_total) {
+            float w = wgt[g + 1];
+            w = is_left ? 1.f - w : w;
+            w = w < 0.5f ? 0.f : w;
+            float d = (v[0] - v[nv3]) * w;
+            ab = fabsf(d);
+            grad += sgn(d) * w;
+        }
+        if (g >= 1) {
+            float w = wgt[g];
+            w = is_left ? 1.f - w : w;
+            w = w < 0.5f ? 0.f : w;
+            grad -= sgn((v[-(ptrdiff_t)nv3] - v[0]) * w) * w;
+        }
+        dV[(size_t)r * nv3 + e] += grad * inv;
+        ab *= inv;                                          // the two parts have different denominators
+    }
+    ab = wave_sum(ab);
+    if ((threadIdx.x & 63) == 0) sred[threadIdx.x >> 6] = ab;
+    __syncthreads();
+    if (threadIdx.x == 0) atomicAdd(loss_sum, (double)((sred[0] + sred[1]) + (sred[2] + sred[3])));
+}
+
+// detect_contact (:355-364): per frame, mean squared NN distance of the left part and left / (left + left)
+__global__ void detect_contact_kernel(const float* __restrict__ dist, int nc, int n_left, int row0,
+                                      float* __restrict__ weight_left) {
+    __shared__ float sred[4];
+    const int r = row0 + blockIdx.x;
+    float a = 0.f;
+    for (int c = threadIdx.x; c < nc; c += 256)
+        if (c < n_left) a += dist[(size_t)r * nc + c];
+    a = wave_sum(a);
+    if ((threadIdx.x & 63) == 0) sred[threadIdx.x >> 6] = a;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        float left = ((sred[0] + sred[1]) + (sred[2] + sred[3])) / (float)n_left;
+        weight_left[blockIdx.x] = left / (left + left);
     }
 }
 
@@ -378,6 +478,7 @@ struct OptState {
     DevBuf<float> Voff, Vw, dist, pd, dVoff;
     DevBuf<int> idx, pi;
     DevBuf<float> dA, dbeta_v, dtransl_v, dMv, dsv, dPF, dJw, dX, dCAM, dscale_row;
+    DevBuf<float> VoffF, VwF, dVF;      // mode 'local' second loop: full-mesh pose offsets / world vertices / gradient
     int cam_steps = 0;
     bool use_seed = true;     // last iteration's neighbours seed the NN bound (pruning only)
     bool use_cull = true;     // skip scene chunks whose bounding sphere is out of every query's reach
@@ -406,6 +507,7 @@ struct fdcap_ctx {
         return t;
     }
     int nc = 0;
+    DevBuf<int> contact_vid;       // mesh vertex of each contact slot (caller's order)
     // growable workspaces for the stand-alone operators
     DevBuf<float> ws_f[12];
     DevBuf<int> ws_i[2];
@@ -555,7 +657,7 @@ void fdcap_ctx_destroy(fdcap_ctx* c) {
     c->Jt.release(); c->Jd.release(); c->hand_comp.release(); c->hand_mean.release();
     c->parents.release(); c->order.release(); c->level_start.release(); c->child_start.release(); c->child_list.release();
     c->W1.release(); c->b1.release(); c->W2.release(); c->b2.release(); c->W3.release(); c->b3.release();
-    c->full.release(); c->contact.release(); c->scene.release(); c->scene_sorted.release(); c->scene_bounds.release(); c->scene_inv.release();
+    c->full.release(); c->contact.release(); c->contact_vid.release(); c->scene.release(); c->scene_sorted.release(); c->scene_bounds.release(); c->scene_inv.release();
     for (auto& b : c->ws_f) b.release();
     for (auto& b : c->ws_i) b.release();
     c->ws_p.release();
@@ -619,6 +721,9 @@ int fdcap_set_contact_ids(fdcap_ctx* c, const int64_t* vid, int32_t nc) {
     for (int64_t v : ids) if (v < 0 || v >= c->V) return FDCAP_E_ARG;
     int e = build_skin_set(c, ids, &c->contact);
     if (e) return e;
+    std::vector<int> v32((size_t)std::max(nc, 1), 0);
+    for (int i = 0; i < nc; ++i) v32[i] = (int)vid[i];
+    HIP_TRY(c->contact_vid.upload(v32.data(), v32.size()));
     c->nc = nc;
     return FDCAP_OK;
 }
@@ -780,7 +885,7 @@ void fdcap_opt_destroy(fdcap_ctx* c) {
     DevBuf<float>* fb[] = {&o->X0, &o->mask, &o->mX, &o->vX, &o->mCAM, &o->vCAM, &o->mS, &o->vS,
                            &o->H1, &o->H2, &o->O, &o->dO, &o->dH2, &o->dH1, &o->Rm, &o->PF, &o->Jrest, &o->G, &o->A, &o->M,
                            &o->Jw, &o->Voff, &o->Vw, &o->dist, &o->pd, &o->dVoff, &o->dA, &o->dbeta_v, &o->dtransl_v, &o->dMv,
-                           &o->dsv, &o->dPF, &o->dJw, &o->dX, &o->dCAM, &o->dscale_row};
+                           &o->dsv, &o->dPF, &o->dJw, &o->dX, &o->dCAM, &o->dscale_row, &o->VoffF, &o->VwF, &o->dVF};
     for (auto* b : fb) b->release();
     o->idx.release(); o->pi.release();
     delete o;
@@ -891,9 +996,12 @@ int fdcap_opt_backward(fdcap_ctx* c, int32_t ii, int32_t P, int32_t log_terms, v
                        w_rec, w_sm, w_ws, phase2 ? 1 : 0, o->dX.p, o->dJw.p, o->losses.p);
     if (contact_grad) {
         const float coef = cf.phase1_contact * cf.weight_contact / ((float)N * nc);
+        const size_t nqv = (size_t)nl * nc, offq = (size_t)2 * nc;
+        hipLaunchKernelGGL(contact_grad_kernel, dim3((nqv + 255) / 256), dim3(256), 0, st, o->Vw.p + offq * 3, o->dist.p + offq,
+                           o->idx.p + offq, c->scene.p, nqv, coef, o->dVoff.p + offq * 3, o->losses.p + 3);
         hipLaunchKernelGGL(skin_bwd_kernel, dim3(nl), dim3(256), 0, st, c->contact.model(), nc, o->X.p, o->Voff.p, o->A.p,
-                           o->M.p, o->scale.p, 2, o->Vw.p, o->dist.p, o->idx.p, c->scene.p, coef, o->dVoff.p, o->dA.p,
-                           o->dbeta_v.p, o->dtransl_v.p, o->dMv.p, o->dsv.p, o->losses.p + 3);
+                           o->M.p, o->scale.p, 2, o->dVoff.p, o->dVoff.p, o->dA.p, o->dbeta_v.p, o->dtransl_v.p, o->dMv.p,
+                           o->dsv.p);
         HIP_TRY(gemm_f32(true, EPI_STORE, o->dVoff.p + (size_t)2 * nc * 3, 3 * nc, c->contact.posedirs.p, 3 * nc,
                          o->dPF.p + 2 * NPF, NPF, nl, NPF, 3 * nc, nullptr, 0, st));
     } else if (contact_fwd) {
@@ -931,9 +1039,89 @@ int fdcap_opt_step(fdcap_ctx* c, int32_t ii, int32_t P, void* stream) {
         hipLaunchKernelGGL(adam_kernel, dim3(1), dim3(64), 0, st, o->scale.p, o->mS.p, o->vS.p, o->dscale.p, (size_t)1,
                            adam_scalars(cf.lr, ii + 1), ii < P ? 0 : 1);
     // camera_ext: first gradient at ii = P + 1 (flag flips after the forward of ii = P)
-    if (ii >= P + 1)
+    if (ii >= P + 1 && cf.phase2_world != 0.f)       // mode 'local': the late-phase loss has no camera_ext path -> grad None, never stepped
         hipLaunchKernelGGL(adam_kernel, dim3((ncam + 255) / 256), dim3(256), 0, st, o->CAM.p + 2 * 16, o->mCAM.p + 2 * 16,
                            o->vCAM.p + 2 * 16, o->dCAM.p + 2 * 16, ncam, adam_scalars(cf.lr, ii - P), 0);
+    return (int)hipGetLastError();
+}
+
+// ---- mode 'local' (global_optimization.py:499-556) --------------------------------------------
+int fdcap_opt_detect_contact(fdcap_ctx* c, int32_t n_left, float* weight_left, void* stream) {
+    if (!c || !c->opt || !weight_left || n_left <= 0 || n_left > c->nc) return FDCAP_E_ARG;
+    OptState* o = c->opt;
+    if (!o->contact_on) return FDCAP_E_STATE;
+    hipStream_t st = (hipStream_t)stream;
+    const int R = o->R, nl = o->cfg.n_local, nc = c->nc;
+    int e = vposer_forward(c, o->X.p, XDIM, X_LATENT, R, o->H1.p, o->H2.p, o->O.p, st);
+    if (e) return e;
+    hipLaunchKernelGGL(pose_fwd_kernel, dim3(R), dim3(64), 0, st, c->pose_model(), o->X.p, o->O.p, o->CAM.p, o->scale.p, 0,
+                       o->Rm.p, o->PF.p, o->Jrest.p, o->G.p, o->A.p, o->M.p, o->Jw.p, (const float*)nullptr);
+    e = opt_contact_forward(c, st);
+    if (e) return e;
+    hipLaunchKernelGGL(detect_contact_kernel, dim3(nl), dim3(256), 0, st, o->dist.p, nc, n_left, 2, weight_left);
+    return (int)hipGetLastError();
+}
+
+int fdcap_opt_backward_local2(fdcap_ctx* c, const float* contact_weight, int32_t n_left, void* stream) {
+    if (!c || !c->opt || !contact_weight || n_left <= 0 || n_left >= c->nc) return FDCAP_E_ARG;
+    OptState* o = c->opt;
+    hipStream_t st = (hipStream_t)stream;
+    const fdcap_opt_config& cf = o->cfg;
+    const int R = o->R, nl = cf.n_local, nc = c->nc, N = cf.n_total, V = c->V;
+    if (!c->full_ready) {
+        std::vector<int64_t> all(V);
+        for (int i = 0; i < V; ++i) all[i] = i;
+        int e = build_skin_set(c, all, &c->full);
+        if (e) return e;
+        c->full_ready = true;
+    }
+    const size_t nv3 = (size_t)3 * V;
+    HIP_TRY(o->VoffF.ensure((size_t)R * nv3));
+    HIP_TRY(o->VwF.ensure((size_t)R * nv3));
+    HIP_TRY(o->dVF.ensure((size_t)R * nv3));
+    PoseModel pm = c->pose_model();
+    HIP_TRY(hipMemsetAsync(o->losses.p, 0, FDCAP_NUM_LOSSES * sizeof(double), st));
+    int e = vposer_forward(c, o->X.p, XDIM, X_LATENT, R, o->H1.p, o->H2.p, o->O.p, st);
+    if (e) return e;
+    hipLaunchKernelGGL(pose_fwd_kernel, dim3(R), dim3(64), 0, st, pm, o->X.p, o->O.p, o->CAM.p, o->scale.p, 0, o->Rm.p,
+                       o->PF.p, o->Jrest.p, o->G.p, o->A.p, o->M.p, o->Jw.p, (const float*)nullptr);
+    // full-mesh world vertices of every row (the vertex stencil needs 2 halo frames each side)
+    HIP_TRY(gemm_f32(false, EPI_STORE, o->PF.p, NPF, c->full.posedirs.p, 3 * V, o->VoffF.p, 3 * V, R, 3 * V, NPF, nullptr, 0, st));
+    hipLaunchKernelGGL(skin_fwd_kernel, dim3((V + 255) / 256, R), dim3(256), 0, st, c->full.model(), V, o->X.p, XDIM, X_BETAS,
+                       X_TRANSL, o->VoffF.p, o->A.p, o->M.p, o->scale.p, 0, 1, o->VwF.p);
+    // losses [0] rec, [1] z^2, [2] local (parameter) smoothing, [5] vertex smoothing, [6] foot skate
+    const float w_rec = cf.weight_loss_rec / ((float)N * XDIM);
+    const float w_sm = (N >= 3) ? 1.f / ((float)(N - 2) * XDIM) : 0.f;
+    hipLaunchKernelGGL(param_loss_kernel, dim3(nl), dim3(128), 0, st, o->X.p, o->X0.p, o->mask.p, o->Jw.p, 2, cf.frame0, N,
+                       w_rec, w_sm, 0.f, 0, o->dX.p, o->dJw.p, o->losses.p);
+    const float w_vs = (N >= 3) ? 1.f / ((float)(N - 2) * (float)nv3) : 0.f;
+    hipLaunchKernelGGL(vert_smooth_kernel, dim3((nv3 + 255) / 256, nl), dim3(256), 0, st, o->VwF.p, nv3, 2, cf.frame0, N, w_vs,
+                       o->dVF.p, o->losses.p + 5);
+    if (N >= 2)
+        hipLaunchKernelGGL(foot_skate_kernel, dim3((nc * 3 + 255) / 256, nl), dim3(256), 0, st, o->VwF.p, nv3, c->contact_vid.p,
+                           nc, n_left, contact_weight, 2, cf.frame0, N, o->dVF.p, o->losses.p + 6);
+    hipLaunchKernelGGL(skin_bwd_kernel, dim3(nl), dim3(256), 0, st, c->full.model(), V, o->X.p, o->VoffF.p, o->A.p, o->M.p,
+                       o->scale.p, 2, o->dVF.p, o->dVF.p, o->dA.p, o->dbeta_v.p, o->dtransl_v.p, o->dMv.p, o->dsv.p);
+    HIP_TRY(gemm_f32(true, EPI_STORE, o->dVF.p + 2 * nv3, 3 * V, c->full.posedirs.p, 3 * V, o->dPF.p + 2 * NPF, NPF, nl, NPF,
+                     3 * V, nullptr, 0, st));
+    hipLaunchKernelGGL(pose_bwd_kernel, dim3(nl), dim3(64), 0, st, pm, o->X.p, o->O.p, o->CAM.p, o->scale.p, 2, o->Rm.p,
+                       o->Jrest.p, o->G.p, o->dA.p, o->dPF.p, (const float*)nullptr, o->dMv.p, o->dsv.p, o->dbeta_v.p,
+                       o->dtransl_v.p, o->dX.p, o->dO.p, o->dCAM.p, o->dscale_row.p);
+    HIP_TRY(gemm_f32(false, EPI_MASK_LRELU, o->dO.p + 2 * ODIM, ODIM, c->W3.p, 512, o->dH2.p + 2 * 512, 512, nl, 512, ODIM,
+                     o->H2.p + 2 * 512, 512, st));
+    HIP_TRY(gemm_f32(false, EPI_MASK_LRELU, o->dH2.p + 2 * 512, 512, c->W2.p, 512, o->dH1.p + 2 * 512, 512, nl, 512, 512,
+                     o->H1.p + 2 * 512, 512, st));
+    HIP_TRY(gemm_f32(false, EPI_ACCUM, o->dH1.p + 2 * 512, 512, c->W1.p, 32, o->dX.p + 2 * XDIM + X_LATENT, XDIM, nl, 32, 512,
+                     nullptr, 0, st));
+    return (int)hipGetLastError();
+}
+
+int fdcap_opt_step_x(fdcap_ctx* c, int32_t step, void* stream) {
+    if (!c || !c->opt || step <= 0) return FDCAP_E_ARG;
+    OptState* o = c->opt;
+    const size_t nx = (size_t)o->cfg.n_local * XDIM;
+    hipLaunchKernelGGL(adam_kernel, dim3((nx + 255) / 256), dim3(256), 0, (hipStream_t)stream, o->X.p + 2 * XDIM,
+                       o->mX.p + 2 * XDIM, o->vX.p + 2 * XDIM, o->dX.p + 2 * XDIM, nx, adam_scalars(o->cfg.lr, step), 0);
     return (int)hipGetLastError();
 }
 

@@ -18,6 +18,8 @@ from .dist import FrameShard, exchange_halos, allreduce_scalars
 # loss-total constants buried in fitting() (global_optimization.py:564, :570, :582)
 PHASE_SPLIT = 0.8
 PHASE1_CONTACT = 0.1
+LOCAL_PHASE1_CONTACT = 0.2      # mode 'local' (:511)
+LOCAL_SECOND_LOOP = 0.4         # int(0.4 * num_iter) iterations of cal_loss2 (:536)
 PHASE1_SMOOTH = 1.0
 PHASE2_WORLD = 1.0
 PHASE2_SMOOTH = 0.5
@@ -73,7 +75,7 @@ class FitLog:
 
 class FittingOP:
     def __init__(self, fittingconfig, lossconfig, num_body, body_model=None, vposer=None, scene_verts=None,
-                 contact_ids=None, camera_ext=None, group=None, legacy_zero_grad=False):
+                 contact_ids=None, camera_ext=None, group=None, legacy_zero_grad=False, n_left=None):
         """`body_model` / `vposer`: objects with the SMPL-X npz / VPoser state-dict arrays
         (synth.BodyModelData / synth.VPoserData or assets.load_*).  `scene_verts`, `contact_ids`,
         `camera_ext` override the paths in `fittingconfig` when given (synthetic runs).
@@ -104,8 +106,12 @@ class FittingOP:
             scene_verts = np.zeros((0, 3), np.float32)
         self.ctx.set_scene(scene_verts)
         if contact_ids is None:
-            contact_ids = io.read_contact_ids(self.contact_id_folder, self.contact_part)
+            parts = [io.read_contact_ids(self.contact_id_folder, [p]) for p in self.contact_part]
+            contact_ids = np.concatenate(parts)
+            n_left = len(parts[0])
         self.vid = np.asarray(contact_ids, dtype=np.int64)
+        # mode 'local' treats the two contact parts separately (L_Leg ids first, :341-347)
+        self.n_left = int(n_left) if n_left is not None else len(self.vid) // 2
         self.ctx.set_contact_ids(self.vid)
         if camera_ext is None and self.camera_path:
             camera_ext = io.read_camerapose(self.camera_path)
@@ -134,9 +140,11 @@ class FittingOP:
             raise capi.FdcapError("camera_ext / camerapose.txt must have one pose per frame (:455)")
         sh = self.shard
         lo, hi = sh.frame0, sh.frame0 + sh.n_local
+        local = getattr(self, "_mode", "global") == "local"
         oc = capi.OptConfig(self.num_body, sh.n_local, sh.frame0, float(self.init_lr_h), float(self.weight_loss_rec),
-                            float(self.weight_loss_vposer), float(self.weight_contact), PHASE1_CONTACT, PHASE1_SMOOTH,
-                            PHASE2_WORLD, PHASE2_SMOOTH, SCALE_INIT, int(self.legacy_zero_grad))
+                            float(self.weight_loss_vposer), float(self.weight_contact),
+                            LOCAL_PHASE1_CONTACT if local else PHASE1_CONTACT, PHASE1_SMOOTH,
+                            0.0 if local else PHASE2_WORLD, PHASE2_SMOOTH, SCALE_INIT, int(self.legacy_zero_grad))
         lib = self.ctx.lib
         import ctypes
         dev = self.device
@@ -169,9 +177,9 @@ class FittingOP:
         Returns (body_rec [N_local,75] device tensor, scale numpy scalar, camera_ext [N_local,4,4])
         -- the whole clip when not sharded, exactly the reference's triple (:635)."""
         import torch
-        if mode != "global":
-            raise NotImplementedError("only mode='global' is on the accelerated path (SURVEY.md §8f lists "
-                                      "'local' and 'dct' as next rows)")
+        if mode not in ("global", "local"):
+            raise NotImplementedError("modes 'global' and 'local' are on the accelerated path ('dct' is a SURVEY.md §8f next row)")
+        self._mode = mode
         lib, h = self.ctx.lib, self.ctx.handle
         dev = self.device
         if not torch.is_tensor(body_data):
@@ -198,6 +206,8 @@ class FittingOP:
             capi.check(lib.fdcap_opt_step(h, ii, P, st), "fdcap_opt_step")
             if multi:
                 exchange_halos(self.shard, self._rows_x, self._rows_cam)
+        if mode == "local":
+            self._local_second_loop(lib, h, multi, log_every)
         nl = self.shard.n_local
         body_rec = torch.empty(nl, capi.PDIM, device=dev)
         scale = torch.empty(1, device=dev)
@@ -210,6 +220,49 @@ class FittingOP:
         self.log = log
         return body_rec, scale.detach().cpu().numpy().squeeze(), self.camera_ext
 
+    def _local_second_loop(self, lib, h, multi, log_every):
+        """detect_contact + the cal_loss2 loop of mode 'local' (:534-556)."""
+        import torch
+        nl = self.shard.n_local
+        w_local = torch.empty(nl, device=self.device)
+        capi.check(lib.fdcap_opt_detect_contact(h, self.n_left, capi.dptr(w_local), capi.current_stream()),
+                   "fdcap_opt_detect_contact")
+        if multi:                                            # every rank needs the weight of its right neighbour's first frame
+            import torch.distributed as dist
+            parts = [torch.empty(self.shard.bounds(r)[1] - self.shard.bounds(r)[0], device=self.device)
+                     for r in range(self.shard.world)]
+            if dist.get_backend(self.group) == "gloo":
+                cpu_parts = [p.cpu() for p in parts]
+                dist.all_gather(cpu_parts, w_local.cpu(), group=self.group)
+                parts = [p.to(self.device) for p in cpu_parts]
+            else:
+                dist.all_gather(parts, w_local, group=self.group)
+            weight = torch.cat(parts).contiguous()
+        else:
+            weight = w_local
+        self.contact_weight = weight
+        self.log2 = []
+        for jj in range(int(LOCAL_SECOND_LOOP * self.num_iter)):
+            st = capi.current_stream()
+            capi.check(lib.fdcap_opt_backward_local2(h, capi.dptr(weight), self.n_left, st), "fdcap_opt_backward_local2")
+            if log_every and (jj % log_every == 0):
+                s = self._losses.clone()
+                if multi:
+                    allreduce_scalars(self.shard, torch.zeros(1, device=self.device), s)
+                s = s.cpu().numpy()
+                N = self.num_body
+                l_rec = self.weight_loss_rec * s[0] / (N * capi.XDIM)
+                l_loc = s[2] / ((N - 2) * capi.XDIM)
+                l_sm = s[5] / ((N - 2) * 3 * self.ctx.num_verts)
+                l_cs = s[6]
+                self.log2.append([jj, l_rec, l_loc, l_sm, l_cs, l_sm + l_loc + l_rec + l_cs])
+                if self.verbose and self.shard.rank == 0:
+                    print('[INFO][fitting] iter={:d}, l_rec={:f}, loss_local_smoothing={:f}, loss_smoothing={:f}, '
+                          'loss_contact_smoothing={:f}, total_loss={:f}'.format(*self.log2[-1]))
+            capi.check(lib.fdcap_opt_step_x(h, self.num_iter + jj + 1, st), "fdcap_opt_step_x")
+            if multi:
+                exchange_halos(self.shard, self._rows_x, self._rows_cam)
+
     def _append_log(self, log, ii, phase2):
         s = self._losses.cpu().numpy()
         N, nc = self.num_body, max(self.ctx.num_contact, 1)
@@ -218,8 +271,9 @@ class FittingOP:
         l_sm = s[2] / ((N - 2) * capi.XDIM) if N >= 3 else float("nan")
         l_con = self.weight_contact * s[3] / (N * nc)
         l_ws = s[4] / ((N - 1) * 69) if N >= 2 else float("nan")
-        total = (l_rec + PHASE2_WORLD * l_ws + PHASE2_SMOOTH * l_sm) if phase2 else \
-            (PHASE1_CONTACT * l_con + PHASE1_SMOOTH * l_sm + l_rec)
+        local = getattr(self, "_mode", "global") == "local"
+        total = (l_rec + (0.0 if local else PHASE2_WORLD * l_ws) + PHASE2_SMOOTH * l_sm) if phase2 else \
+            ((LOCAL_PHASE1_CONTACT if local else PHASE1_CONTACT) * l_con + PHASE1_SMOOTH * l_sm + l_rec)
         log.iters.append(ii); log.l_rec.append(l_rec); log.l_vposer.append(l_vp)
         log.loss_smoothing.append(l_sm); log.loss_contact.append(l_con)
         log.loss_world_smoothing.append(l_ws); log.total.append(total)

@@ -161,6 +161,21 @@ int fdcap_opt_set_inputs(fdcap_ctx* ctx, const float* data78_d, const float* ini
 int fdcap_opt_backward(fdcap_ctx* ctx, int32_t ii, int32_t first_phase2_iter, int32_t log_terms,
                        void* stream);
 int fdcap_opt_step(fdcap_ctx* ctx, int32_t ii, int32_t first_phase2_iter, void* stream);
+/* ---- mode 'local' (:499-556).  Its first loop is fdcap_opt_backward / _step with
+ * phase1_contact = 0.2 and phase2_world = 0 in the config (:511, :523); then: */
+/* detect_contact (:315-365): weight_left_d [n_local] = left / (left + left) per frame, `left` = mean
+ * squared NN distance of the first n_left contact ids (the L_Leg part) -- the reference's own formula,
+ * identically 0.5 (NaN where the distance is 0). */
+int fdcap_opt_detect_contact(fdcap_ctx* ctx, int32_t n_left, float* weight_left_d, void* stream);
+/* zero_grad + cal_loss2 + backward (:368-447, :538-554): loss = vertex-space second-difference smoothing
+ * over ALL mesh vertices + parameter smoothing + loss_rec + foot-skate term; only body_rotation_rec gets
+ * a gradient.  contact_weight_d [n_total]: detect_contact's output for the WHOLE clip (all ranks).
+ * losses_d afterwards: [0] rec, [2] parameter smoothing, [5] vertex smoothing, [6] foot-skate (already
+ * normalised per part). */
+int fdcap_opt_backward_local2(fdcap_ctx* ctx, const float* contact_weight_d, int32_t n_left, void* stream);
+/* Adam on body_rotation_rec only, with its running step count `step` (continues after the first loop). */
+int fdcap_opt_step_x(fdcap_ctx* ctx, int32_t step, void* stream);
+
 /* Results: body_rec75_d [n_local,75] (= convert_to_3D_rot, :633), scale_d [1], cam_ext_d [n_local,16]. */
 int fdcap_opt_get_results(fdcap_ctx* ctx, float* body_rec75_d, float* scale_d, float* cam_ext_d,
                           void* stream);

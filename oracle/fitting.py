@@ -177,6 +177,88 @@ class FittingOracle:
         self.optimizer.step()
         return loss
 
+    # ---- 'local' mode: detect_contact :315-365, cal_loss2 :368-447 ----
+    def detect_contact(self, n_left):
+        """Per-frame mean Chamfer distance of the left / right leg sets; the reference then returns
+        left / (left + left) (:364) -- identically 0.5 (NaN where the distance is 0) -- reproduced as is."""
+        with torch.no_grad():
+            _, verts, _ = self.forward_world()
+            left = verts[:, self.vid[:n_left], :].contiguous()
+            right = verts[:, self.vid[n_left:], :].contiguous()
+            dl, _ = chamferDist(self.one_direction_chamfer)(left, self.s_verts_batch)
+            dr, _ = chamferDist(self.one_direction_chamfer)(right, self.s_verts_batch)
+            dl, dr = dl.mean(dim=1), dr.mean(dim=1)
+            self.contact_dist_left, self.contact_dist_right = dl, dr
+            return (dl / (dl + dl)).detach()
+
+    def cal_loss2(self, body_data_rotation, idx1, contact_weight, n_left):
+        weights = torch.ones(body_data_rotation.size(), dtype=self.dtype)
+        weights[idx1, :] = 0.0
+        loss_rec = self.weight_loss_rec * torch.mean(
+            torch.abs(body_data_rotation - self.body_rotation_rec) * weights)             # :376
+        diff_local = self.body_rotation_rec[0:-1, :] - self.body_rotation_rec[1:, :]
+        loss_local_smoothing = torch.mean(torch.abs(diff_local[0:-1, :] - diff_local[1:, :]))   # :382
+        _, verts, _ = self.forward_world()
+        diff = verts[0:-1, :] - verts[1:, :]
+        loss_smoothing = torch.mean(torch.abs(diff[0:-1, :] - diff[1:, :]))                # :404-405
+        cl = verts[:, self.vid[:n_left], :]
+        cr = verts[:, self.vid[n_left:], :]
+        dleft = cl[0:-1] - cl[1:]
+        dright = cr[0:-1] - cr[1:]
+        weight_right = contact_weight.clone()
+        weight_left = 1 - weight_right
+        weight_left[weight_left < 0.5] = 0.0                                                # :421-422
+        weight_right[weight_right < 0.5] = 0.0
+        wr = weight_right[1:].unsqueeze(1).unsqueeze(1)
+        wl = weight_left[1:].unsqueeze(1).unsqueeze(1)
+        loss_contact_smoothing = torch.mean(torch.abs(dleft * wl)) + torch.mean(torch.abs(dright * wr))   # :429
+        return loss_rec, loss_local_smoothing, loss_smoothing, loss_contact_smoothing
+
+    def step_local_a(self, ii, body_data_rotation, idx1):
+        """Phase A of mode 'local' (:501-532): like 'global' but 0.2*contact and no world term."""
+        self.optimizer.zero_grad(set_to_none=not self.legacy_zero_grad)
+        l_rec, l_vp, l_con, l_sm, l_ws = self.cal_loss(body_data_rotation, idx1)
+        if ii < self.num_iter * self.phase_split:
+            self.camera_ext.requires_grad = False
+            self.scale.requires_grad = True
+            self.body_rotation_rec.requires_grad = True
+            loss = l_con * 0.2 + l_sm * 1.0 + l_rec                                        # :511
+        else:
+            self.camera_ext.requires_grad = True
+            self.scale.requires_grad = False
+            self.body_rotation_rec.requires_grad = True
+            loss = l_rec + l_sm * 0.5                                                      # :523
+        self.loss_log.append([float(v.detach()) for v in (l_rec, l_vp, l_sm, l_con, l_ws, loss)])
+        loss.backward()
+        self.optimizer.step()
+
+    def step_local_b(self, body_data_rotation, idx1, contact_weight, n_left):
+        """One pass of the second loop of mode 'local' (:536-556)."""
+        self.optimizer.zero_grad(set_to_none=not self.legacy_zero_grad)
+        l_rec, l_loc, l_sm, l_cs = self.cal_loss2(body_data_rotation, idx1, contact_weight, n_left)
+        self.camera_ext.requires_grad = False
+        self.scale.requires_grad = False
+        self.body_rotation_rec.requires_grad = True
+        loss = l_sm * 1.0 + l_loc + l_rec + l_cs                                           # :547
+        self.loss_log2.append([float(v.detach()) for v in (l_rec, l_loc, l_sm, l_cs, loss)])
+        loss.backward()
+        self.optimizer.step()
+
+    def fitting_local(self, body_data, n_left):
+        """mode='local' (:499-556).  n_left = number of L_Leg entries at the head of the contact ids."""
+        body_data_rotation = rotrepr.convert_to_6D_rot(torch.as_tensor(body_data).to(self.dtype))
+        idx1 = self.init(body_data_rotation)
+        body_data_rotation = body_data_rotation.detach()
+        self.idx1 = idx1
+        self.loss_log2 = []
+        for ii in range(self.num_iter):
+            self.step_local_a(ii, body_data_rotation, idx1)
+        self.contact_weight = self.detect_contact(n_left)                                  # :534
+        for ii in range(int(0.4 * self.num_iter)):
+            self.step_local_b(body_data_rotation, idx1, self.contact_weight, n_left)
+        body_rec = rotrepr.convert_to_3D_rot(self.body_rotation_rec)
+        return body_rec.detach(), self.scale.detach().cpu().numpy().squeeze(), self.camera_ext.detach()
+
     def fitting(self, body_data):
         """[N,75] -> (body_rec [N,75], scale ndarray scalar, camera_ext [N,4,4])."""
         body_data_rotation = rotrepr.convert_to_6D_rot(torch.as_tensor(body_data).to(self.dtype))

@@ -99,8 +99,12 @@ LOG_RE = re.compile(r"iter=(\d+), l_rec=([-\d.e]+), l_vposer=([-\d.e]+), loss_sm
                     r"loss_contact=([-\d.e]+)(?:, loss_world_smoothing=([-\d.e]+))?, total_loss=([-\d.e]+)")
 
 
+LOG2_RE = re.compile(r"iter=(\d+), l_rec=([-\d.e]+), loss_local_smoothing=([-\d.e]+), loss_smoothing=([-\d.e]+), "
+                     r"loss_contact_smoothing=([-\d.e]+), total_loss=([-\d.e]+)")
+
+
 def run_global(g, num_iter, num_verts, ns, model_seed, vposer_seed, clip_seed, scene_seed,
-               contact_seed, per_part, tmp):
+               contact_seed, per_part, tmp, mode="global"):
     n = 300  # the reference hard-codes 300 (:465, :472, :41-42)
     bm = synth.make_body_model(num_verts, seed=model_seed)
     vp = synth.make_vposer(seed=vposer_seed)
@@ -146,7 +150,7 @@ def run_global(g, num_iter, num_verts, ns, model_seed, vposer_seed, clip_seed, s
     body = torch.tensor(clip.body_params, dtype=torch.float32)
     buf = io.StringIO()
     with contextlib.redirect_stdout(buf):
-        body_rec, scale, camera_ext = f.fitting(body, "global")
+        body_rec, scale, camera_ext = f.fitting(body, mode)
     text = buf.getvalue()
     log = []
     for m in LOG_RE.finditer(text):
@@ -155,6 +159,9 @@ def run_global(g, num_iter, num_verts, ns, model_seed, vposer_seed, clip_seed, s
                     float(ws) if ws is not None else float("nan"), float(tot)])
     log = np.array(log, dtype=np.float64)
     assert log.shape[0] == num_iter, (log.shape, num_iter)
+    log2 = np.array([[float(v) for v in m.groups()] for m in LOG2_RE.finditer(text)], dtype=np.float64)
+    if mode == "local":
+        assert log2.shape[0] == int(0.4 * num_iter), log2.shape
     idx_line = text.splitlines()[0]
     idx1 = np.array([int(t) for t in re.findall(r"\d+", idx_line)], dtype=np.int64)
     return dict(
@@ -164,7 +171,7 @@ def run_global(g, num_iter, num_verts, ns, model_seed, vposer_seed, clip_seed, s
         body_in=clip.body_params, camerapose=np.array(clip.camerapose_lines),
         planted_outliers=clip.outlier_frames, scene=scene, vid=np.asarray(vid_ref, dtype=np.int64),
         idx1=idx1, body_rec=body_rec.detach().numpy(), scale=np.float32(scale),
-        camera_ext=camera_ext.detach().numpy(), log=log,
+        camera_ext=camera_ext.detach().numpy(), log=log, log2=log2, n_left=np.int64(len(left)), mode=mode,
         sha_posedirs=sha(bm.posedirs), sha_vtemplate=sha(bm.v_template), sha_fc2=sha(vp.fc2_w))
 
 
@@ -214,6 +221,9 @@ def main():
             ("ref_global_5it", dict(num_iter=5, num_verts=320, ns=1500, model_seed=5,
                                     vposer_seed=6, clip_seed=7, scene_seed=8, contact_seed=9,
                                     per_part=12)),
+            ("ref_local_10it", dict(num_iter=10, num_verts=256, ns=1200, model_seed=15,
+                                    vposer_seed=16, clip_seed=17, scene_seed=18, contact_seed=19,
+                                    per_part=10, mode="local")),
         ):
             res = run_global(g, tmp=tmp, **kw)
             np.savez_compressed(os.path.join(HERE, name + ".npz"), **res)

@@ -482,3 +482,63 @@ def test_full_size_body_model_and_wide_gemm():
     np.testing.assert_allclose(joints[sel].cpu().numpy(), want.joints.numpy(), atol=5e-5)
     assert bool(torch.isfinite(verts).all())
     ctx.close()
+
+
+def test_local_mode_matches_reference_golden(golden_dir):
+    """mode='local' (:499-556) on the GPU vs the reference's own run: first loop (0.2*contact, no world
+    term, camera_ext never stepped), detect_contact (== 0.5), then the cal_loss2 loop with the
+    vertex-space smoothing over ALL mesh vertices (full pose-blend GEMM forward + backward) and the
+    foot-skate term."""
+    g = np.load(os.path.join(golden_dir, "ref_local_10it.npz"))
+    bm = synth.make_body_model(int(g["num_verts"]), seed=int(g["model_seed"]))
+    vp = synth.make_vposer(seed=int(g["vposer_seed"]))
+    num_iter = int(g["num_iter"])
+    cam0 = read_camerapose(list(g["camerapose"]))
+    fop = FittingOP({"num_iter": num_iter}, {}, 300, body_model=bm, vposer=vp, scene_verts=g["scene"], contact_ids=g["vid"],
+                    camera_ext=cam0, n_left=int(g["n_left"]))
+    body, scale, cam = fop.fitting(torch.tensor(g["body_in"]).cuda(), "local", log_every=1)
+    assert bool((fop.contact_weight == 0.5).all())
+    err = np.abs(body.cpu().numpy() - g["body_rec"])
+    q50, q90, q99 = np.quantile(err, [0.5, 0.9, 0.99])
+    assert err.max() <= 2 * 0.005 * 14 and q50 < 1e-6 and q90 < 1e-4 and q99 < 3e-3, (q50, q90, q99, err.max())
+    np.testing.assert_allclose(float(scale), float(g["scale"]), atol=1e-4)
+    np.testing.assert_array_equal(cam.cpu().numpy(), cam0)                 # camera_ext is never stepped in this mode
+    ref2 = g["log2"]
+    log2 = np.array(fop.log2)
+    tol = 3e-6 + 2e-6 * (num_iter + np.arange(len(ref2)))
+    for k in range(1, 6):
+        assert np.all(np.abs(log2[:, k] - ref2[:, k]) <= 2 * tol), (k, np.abs(log2[:, k] - ref2[:, k]).max())
+    fop.close()
+
+
+def test_local_mode_second_loop_gradient_matches_autograd():
+    n = 10
+    fop, bm, vp, clip, scene, vid = _make_fop(n, 260, 700, 12, 500, seed=90)
+    dt = torch.float64
+    f = FittingOracle(SMPLXOracle(bm, dt), VPoserDecoder.from_data(vp, dt), scene, vid, clip.camerapose_lines, n, dtype=dt)
+    x78 = rotrepr.convert_to_6D_rot(torch.tensor(clip.body_params, dtype=dt)).detach()
+    f.init(x78)
+    g = torch.Generator().manual_seed(6)
+    pert = 0.01 * torch.randn(f.body_rotation_rec.shape, generator=g, dtype=dt)
+    f.body_rotation_rec.data += pert
+    idx1, _ = find_outliers(x78.numpy().astype(np.float32))
+    w = torch.full((n,), 0.5, dtype=dt)
+    w[3] = 0.8            # exercise the thresholding of (:421-422): left weight 0.2 -> 0, right 0.8
+    w[6] = 0.3
+    n_left = len(vid) // 2
+    l_rec, l_loc, l_sm, l_cs = f.cal_loss2(x78, idx1, w, n_left)
+    (l_sm + l_loc + l_rec + l_cs).backward()
+    fop._mode = "local"
+    fop.init(torch.tensor(x78.numpy(), dtype=torch.float32).cuda())
+    fop._rows_x[2:2 + n] += pert.float().cuda()
+    lib, h = fop.ctx.lib, fop.ctx.handle
+    capi.check(lib.fdcap_opt_backward_local2(h, capi.dptr(w.float().cuda()), n_left, capi.current_stream()), "local2")
+    dx = torch.empty(n, 78, device="cuda")
+    capi.check(lib.fdcap_opt_get_grads(h, capi.dptr(dx), None, capi.current_stream()), "grads")
+    gx = f.body_rotation_rec.grad.numpy()
+    np.testing.assert_allclose(dx.cpu().numpy(), gx, rtol=3e-3, atol=3e-4 * np.abs(gx).max())
+    s = fop._losses.cpu().numpy()
+    np.testing.assert_allclose(s[5] / ((n - 2) * 3 * 260), float(l_sm.detach()), rtol=1e-5)
+    np.testing.assert_allclose(s[6], float(l_cs.detach()), rtol=1e-5)
+    np.testing.assert_allclose(s[2] / ((n - 2) * 78), float(l_loc.detach()), rtol=1e-5)
+    fop.close()

@@ -28,24 +28,25 @@ def _inputs():
     return bm, vp, clip, scene, np.concatenate([l, r])
 
 
-def _fit(group):
+def _fit(group, mode="global"):
     from fdcap_amd.fitting import FittingOP
     bm, vp, clip, scene, vid = _inputs()
     fop = FittingOP({"num_iter": ITERS}, {}, N, body_model=bm, vposer=vp, scene_verts=scene, contact_ids=vid,
                     camera_ext=read_camerapose(clip.camerapose_lines), group=group)
-    body, scale, cam = fop.fitting(torch.tensor(clip.body_params).cuda(), "global", log_every=1)
-    out = (fop.shard.frame0, body.cpu().numpy(), float(scale), cam.cpu().numpy(), np.array(fop.log.total))
+    body, scale, cam = fop.fitting(torch.tensor(clip.body_params).cuda(), mode, log_every=1)
+    tot = np.array(fop.log.total) if mode == "global" else np.array(fop.log2)[:, 5]
+    out = (fop.shard.frame0, body.cpu().numpy(), float(scale), cam.cpu().numpy(), tot)
     fop.close()
     return out
 
 
-def _worker(rank, world, port, q):
+def _worker(rank, world, port, q, mode="global"):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     torch.cuda.set_device(0)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
-        q.put((rank,) + _fit(dist.group.WORLD))
+        q.put((rank,) + _fit(dist.group.WORLD, mode))
     finally:
         dist.barrier()
         dist.destroy_process_group()
@@ -59,13 +60,13 @@ def _free_port():
     return p
 
 
-@pytest.mark.parametrize("world", [2, 3])
-def test_sharded_gpu_run_matches_single_rank(world):
-    ref = _fit(None)
+@pytest.mark.parametrize("world,mode", [(2, "global"), (3, "global"), (2, "local")])
+def test_sharded_gpu_run_matches_single_rank(world, mode):
+    ref = _fit(None, mode)
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q, mode)) for r in range(world)]
     for p in procs:
         p.start()
     res = sorted(q.get(timeout=600) for _ in range(world))
