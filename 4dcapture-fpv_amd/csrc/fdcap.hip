@@ -365,6 +365,41 @@ __global__ void adam_kernel(float* __restrict__ p, float* __restrict__ m, float*
     p[i] = pp; m[i] = mm; v[i] = vv;
 }
 
+// one message per rank and iteration: [first 2 owned rows | last 2 owned rows] of (x | camera_ext) + d loss / d scale
+constexpr int XCH_ROW = XDIM + 16;                 // 94 floats
+constexpr int XCH_LEN = 4 * XCH_ROW + 8;           // + dscale partial (+ padding to 32 B)
+__global__ void pack_exchange_kernel(const float* __restrict__ X, const float* __restrict__ CAM, const float* __restrict__ dscale,
+                                     int n_local, float* __restrict__ out) {
+    int t = threadIdx.x;
+    if (t < 4 * XCH_ROW) {
+        int k = t / XCH_ROW, e = t % XCH_ROW;
+        int row = (k < 2) ? 2 + k : n_local + k - 2;             // owned rows start at 2: first two, last two
+        out[t] = e < XDIM ? X[(size_t)row * XDIM + e] : CAM[(size_t)row * 16 + e - XDIM];
+    } else if (t < XCH_LEN) {
+        out[t] = (t == 4 * XCH_ROW) ? *dscale : 0.f;
+    }
+}
+// halo rows <- neighbours' boundary rows; scale gradient = sum over ranks in rank order (same bits everywhere)
+__global__ void unpack_exchange_kernel(const float* __restrict__ all, int rank, int world, int n_local, float* __restrict__ X,
+                                       float* __restrict__ CAM, float* __restrict__ dscale) {
+    int t = threadIdx.x;
+    if (t < 4 * XCH_ROW) {
+        int k = t / XCH_ROW, e = t % XCH_ROW;
+        // k = 0,1: left halo rows 0,1 <- last two rows of rank-1 (its slots 2,3); k = 2,3: right halo <- first two of rank+1
+        int src_rank = (k < 2) ? rank - 1 : rank + 1;
+        if (src_rank >= 0 && src_rank < world) {
+            int slot = (k < 2) ? 2 + k : k - 2;
+            float v = all[(size_t)src_rank * XCH_LEN + slot * XCH_ROW + e];
+            int row = (k < 2) ? k : n_local + k;                 // rows 0,1 and n_local+2, n_local+3
+            if (e < XDIM) X[(size_t)row * XDIM + e] = v; else CAM[(size_t)row * 16 + e - XDIM] = v;
+        }
+    } else if (t == 4 * XCH_ROW) {
+        float s = 0.f;
+        for (int r = 0; r < world; ++r) s += all[(size_t)r * XCH_LEN + 4 * XCH_ROW];
+        *dscale = s;
+    }
+}
+
 __global__ void p75_to_78_kernel(const float* __restrict__ in, int B, float* __restrict__ out) {
     int b = blockIdx.x * blockDim.x + threadIdx.x;
     if (b >= B) return;
@@ -1024,7 +1059,7 @@ int fdcap_opt_backward(fdcap_ctx* c, int32_t ii, int32_t P, int32_t log_terms, v
     return (int)hipGetLastError();
 }
 
-int fdcap_opt_step(fdcap_ctx* c, int32_t ii, int32_t P, void* stream) {
+static int opt_step_impl(fdcap_ctx* c, int32_t ii, int32_t P, bool do_rows, bool do_scale, void* stream) {
     if (!c || !c->opt) return FDCAP_E_STATE;
     OptState* o = c->opt;
     hipStream_t st = (hipStream_t)stream;
@@ -1032,14 +1067,15 @@ int fdcap_opt_step(fdcap_ctx* c, int32_t ii, int32_t P, void* stream) {
     const int nl = cf.n_local;
     const size_t nx = (size_t)nl * XDIM, ncam = (size_t)nl * 16;
     // body_rotation_rec: every iteration, its own step counter = ii + 1
-    hipLaunchKernelGGL(adam_kernel, dim3((nx + 255) / 256), dim3(256), 0, st, o->X.p + 2 * XDIM, o->mX.p + 2 * XDIM,
-                       o->vX.p + 2 * XDIM, o->dX.p + 2 * XDIM, nx, adam_scalars(cf.lr, ii + 1), 0);
+    if (do_rows)
+        hipLaunchKernelGGL(adam_kernel, dim3((nx + 255) / 256), dim3(256), 0, st, o->X.p + 2 * XDIM, o->mX.p + 2 * XDIM,
+                           o->vX.p + 2 * XDIM, o->dX.p + 2 * XDIM, nx, adam_scalars(cf.lr, ii + 1), 0);
     // scale: receives a gradient while ii < P (and only if the contact term exists)
-    if (o->contact_on && (ii < P || cf.legacy_zero_grad))
+    if (do_scale && o->contact_on && (ii < P || cf.legacy_zero_grad))
         hipLaunchKernelGGL(adam_kernel, dim3(1), dim3(64), 0, st, o->scale.p, o->mS.p, o->vS.p, o->dscale.p, (size_t)1,
                            adam_scalars(cf.lr, ii + 1), ii < P ? 0 : 1);
     // camera_ext: first gradient at ii = P + 1 (flag flips after the forward of ii = P)
-    if (ii >= P + 1 && cf.phase2_world != 0.f)       // mode 'local': the late-phase loss has no camera_ext path -> grad None, never stepped
+    if (do_rows && ii >= P + 1 && cf.phase2_world != 0.f)       // mode 'local': the late-phase loss has no camera_ext path -> grad None, never stepped
         hipLaunchKernelGGL(adam_kernel, dim3((ncam + 255) / 256), dim3(256), 0, st, o->CAM.p + 2 * 16, o->mCAM.p + 2 * 16,
                            o->vCAM.p + 2 * 16, o->dCAM.p + 2 * 16, ncam, adam_scalars(cf.lr, ii - P), 0);
     return (int)hipGetLastError();
@@ -1155,6 +1191,29 @@ int fdcap_opt_forward_world(fdcap_ctx* c, float* verts, float* joints, void* str
         HIP_TRY(hipMemcpyAsync(joints, o->Jw.p + 2 * NJW * 3, (size_t)nl * NJW * 3 * sizeof(float), hipMemcpyDeviceToDevice, st));
     return (int)hipGetLastError();
 }
+
+int fdcap_opt_step(fdcap_ctx* c, int32_t ii, int32_t P, void* stream) { return opt_step_impl(c, ii, P, true, true, stream); }
+
+// Multi-GPU iteration tail with ONE collective: Adam on this rank's rows, pack [boundary rows | dscale],
+// (caller all-gathers), unpack halos + rank-ordered dscale sum + Adam on scale.
+int fdcap_opt_step_rows_and_pack(fdcap_ctx* c, int32_t ii, int32_t P, float* send, void* stream) {
+    if (!c || !c->opt || !send) return FDCAP_E_ARG;
+    int e = opt_step_impl(c, ii, P, true, false, stream);
+    if (e) return e;
+    OptState* o = c->opt;
+    hipLaunchKernelGGL(pack_exchange_kernel, dim3(1), dim3(384), 0, (hipStream_t)stream, o->X.p, o->CAM.p, o->dscale.p,
+                       o->cfg.n_local, send);
+    return (int)hipGetLastError();
+}
+int fdcap_opt_unpack_and_step_scale(fdcap_ctx* c, int32_t ii, int32_t P, const float* gathered, int32_t rank, int32_t world,
+                                    void* stream) {
+    if (!c || !c->opt || !gathered || world <= 0 || rank < 0 || rank >= world) return FDCAP_E_ARG;
+    OptState* o = c->opt;
+    hipLaunchKernelGGL(unpack_exchange_kernel, dim3(1), dim3(384), 0, (hipStream_t)stream, gathered, rank, world, o->cfg.n_local,
+                       o->X.p, o->CAM.p, o->dscale.p);
+    return opt_step_impl(c, ii, P, false, true, stream);
+}
+int32_t fdcap_exchange_len(void) { return XCH_LEN; }
 
 int fdcap_opt_get_contact(fdcap_ctx* c, float* dist, int32_t* idx, void* stream) {
     if (!c || !c->opt) return FDCAP_E_STATE;

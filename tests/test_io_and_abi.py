@@ -18,7 +18,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 def test_header_symbols_are_exported_and_bound():
     hdr = open(os.path.join(ROOT, "include", "fdcap.h")).read()
-    declared = set(re.findall(r"^\s*(?:int|void|const char\*)\s+(fdcap_\w+)\s*\(", hdr, flags=re.M))
+    declared = set(re.findall(r"^\s*(?:int|int32_t|void|const char\*)\s+(fdcap_\w+)\s*\(", hdr, flags=re.M))
     assert len(declared) >= 20
     lib = capi.load_library()
     for name in declared:
