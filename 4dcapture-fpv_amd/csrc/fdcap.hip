@@ -274,13 +274,13 @@ __global__ void foot_skate_kernel(const float* __restrict__ V, size_t nv3, const
 }
 
 // detect_contact (:355-364): per frame, mean squared NN distance of the left part and left / (left + left)
-__global__ void detect_contact_kernel(const float* __restrict__ dist, int nc, int n_left, int row0,
-                                      float* __restrict__ weight_left) {
+__global__ void detect_contact_kernel(const float* __restrict__ dist, const int* __restrict__ perm, int nc, int n_left,
+                                      int row0, float* __restrict__ weight_left) {
     __shared__ float sred[4];
     const int r = row0 + blockIdx.x;
     float a = 0.f;
     for (int c = threadIdx.x; c < nc; c += 256)
-        if (c < n_left) a += dist[(size_t)r * nc + c];
+        if (perm[c] < n_left) a += dist[(size_t)r * nc + c];
     a = wave_sum(a);
     if ((threadIdx.x & 63) == 0) sred[threadIdx.x >> 6] = a;
     __syncthreads();
@@ -457,6 +457,18 @@ __global__ void assemble_rows_kernel(const float* __restrict__ go, const float* 
     for (int i = 0; i < 63; ++i) a[3 + i] = bp[63 * b + i];
 }
 
+// dst[r, perm[c], :] = src[r, c, :]   (internal contact-slot order -> caller's order)
+template <class T>
+__global__ void unpermute_kernel(const T* __restrict__ src, const int* __restrict__ perm, int rows, int nc, int w,
+                                 T* __restrict__ dst) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (size_t)rows * nc * w) return;
+    int k = i % w;
+    size_t rc = i / w;
+    int c = rc % nc, r = rc / nc;
+    dst[((size_t)r * nc + perm[c]) * w + k] = src[i];
+}
+
 __global__ void copy_rows_kernel(const float* __restrict__ src, int lds, float* __restrict__ dst, int ldd, int rows, int cols) {
     size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= (size_t)rows * cols) return;
@@ -542,7 +554,8 @@ struct fdcap_ctx {
         return t;
     }
     int nc = 0;
-    DevBuf<int> contact_vid;       // mesh vertex of each contact slot (caller's order)
+    DevBuf<int> contact_vid;       // mesh vertex of each contact id (caller's order)
+    DevBuf<int> contact_perm;      // internal contact slot -> position in the caller's id array
     // growable workspaces for the stand-alone operators
     DevBuf<float> ws_f[12];
     DevBuf<int> ws_i[2];
@@ -692,7 +705,7 @@ void fdcap_ctx_destroy(fdcap_ctx* c) {
     c->Jt.release(); c->Jd.release(); c->hand_comp.release(); c->hand_mean.release();
     c->parents.release(); c->order.release(); c->level_start.release(); c->child_start.release(); c->child_list.release();
     c->W1.release(); c->b1.release(); c->W2.release(); c->b2.release(); c->W3.release(); c->b3.release();
-    c->full.release(); c->contact.release(); c->contact_vid.release(); c->scene.release(); c->scene_sorted.release(); c->scene_bounds.release(); c->scene_inv.release();
+    c->full.release(); c->contact.release(); c->contact_vid.release(); c->contact_perm.release(); c->scene.release(); c->scene_sorted.release(); c->scene_bounds.release(); c->scene_inv.release();
     for (auto& b : c->ws_f) b.release();
     for (auto& b : c->ws_i) b.release();
     c->ws_p.release();
@@ -752,13 +765,38 @@ int fdcap_set_scene(fdcap_ctx* c, const float* xyz, int64_t ns) {
 
 int fdcap_set_contact_ids(fdcap_ctx* c, const int64_t* vid, int32_t nc) {
     if (!c || nc < 0 || (nc > 0 && !vid)) return FDCAP_E_ARG;
-    std::vector<int64_t> ids(vid, vid + nc);
-    for (int64_t v : ids) if (v < 0 || v >= c->V) return FDCAP_E_ARG;
+    for (int i = 0; i < nc; ++i) if (vid[i] < 0 || vid[i] >= c->V) return FDCAP_E_ARG;
+    // Internal slot order = Morton order of the template positions: the 256 consecutive queries of an NN
+    // workgroup are then spatially compact, so far fewer scene chunks survive its bound test (with all
+    // 10 475 vertices as contacts a workgroup would otherwise span the whole body).  The loss is a mean
+    // over the contact set, so the order is free; outputs go back in the caller's order via contact_perm.
+    float lo[3] = {1e30f, 1e30f, 1e30f}, hi[3] = {-1e30f, -1e30f, -1e30f};
+    for (int i = 0; i < nc; ++i)
+        for (int k = 0; k < 3; ++k) {
+            float v = c->h_vt[3 * vid[i] + k];
+            lo[k] = std::min(lo[k], v); hi[k] = std::max(hi[k], v);
+        }
+    auto spread = [](uint32_t v) { v &= 1023; v = (v | (v << 16)) & 0x030000FF; v = (v | (v << 8)) & 0x0300F00F;
+                                   v = (v | (v << 4)) & 0x030C30C3; v = (v | (v << 2)) & 0x09249249; return v; };
+    std::vector<std::pair<uint32_t, int>> key((size_t)nc);
+    for (int i = 0; i < nc; ++i) {
+        uint32_t code = 0;
+        for (int k = 0; k < 3; ++k) {
+            float ext = hi[k] - lo[k];
+            float u = ext > 0.f ? (c->h_vt[3 * vid[i] + k] - lo[k]) / ext : 0.f;
+            code |= spread((uint32_t)std::min(1023.f, std::max(0.f, u * 1023.f))) << k;
+        }
+        key[i] = {code, i};
+    }
+    std::sort(key.begin(), key.end());
+    std::vector<int64_t> ids((size_t)nc);
+    std::vector<int> perm((size_t)std::max(nc, 1), 0), v32((size_t)std::max(nc, 1), 0);
+    for (int sl = 0; sl < nc; ++sl) { ids[sl] = vid[key[sl].second]; perm[sl] = key[sl].second; }
+    for (int i = 0; i < nc; ++i) v32[i] = (int)vid[i];
     int e = build_skin_set(c, ids, &c->contact);
     if (e) return e;
-    std::vector<int> v32((size_t)std::max(nc, 1), 0);
-    for (int i = 0; i < nc; ++i) v32[i] = (int)vid[i];
     HIP_TRY(c->contact_vid.upload(v32.data(), v32.size()));
+    HIP_TRY(c->contact_perm.upload(perm.data(), perm.size()));
     c->nc = nc;
     return FDCAP_OK;
 }
@@ -1094,7 +1132,7 @@ int fdcap_opt_detect_contact(fdcap_ctx* c, int32_t n_left, float* weight_left, v
                        o->Rm.p, o->PF.p, o->Jrest.p, o->G.p, o->A.p, o->M.p, o->Jw.p, (const float*)nullptr);
     e = opt_contact_forward(c, st);
     if (e) return e;
-    hipLaunchKernelGGL(detect_contact_kernel, dim3(nl), dim3(256), 0, st, o->dist.p, nc, n_left, 2, weight_left);
+    hipLaunchKernelGGL(detect_contact_kernel, dim3(nl), dim3(256), 0, st, o->dist.p, c->contact_perm.p, nc, n_left, 2, weight_left);
     return (int)hipGetLastError();
 }
 
@@ -1185,7 +1223,8 @@ int fdcap_opt_forward_world(fdcap_ctx* c, float* verts, float* joints, void* str
         if (!o->contact_on) return FDCAP_E_STATE;
         e = opt_contact_forward(c, st);
         if (e) return e;
-        HIP_TRY(hipMemcpyAsync(verts, o->Vw.p + (size_t)2 * nc * 3, (size_t)nl * nc * 3 * sizeof(float), hipMemcpyDeviceToDevice, st));
+        hipLaunchKernelGGL(unpermute_kernel<float>, dim3(((size_t)nl * nc * 3 + 255) / 256), dim3(256), 0, st,
+                           o->Vw.p + (size_t)2 * nc * 3, c->contact_perm.p, nl, nc, 3, verts);
     }
     if (joints)
         HIP_TRY(hipMemcpyAsync(joints, o->Jw.p + 2 * NJW * 3, (size_t)nl * NJW * 3 * sizeof(float), hipMemcpyDeviceToDevice, st));
@@ -1221,9 +1260,12 @@ int fdcap_opt_get_contact(fdcap_ctx* c, float* dist, int32_t* idx, void* stream)
     if (!o->contact_on) return FDCAP_E_STATE;
     hipStream_t st = (hipStream_t)stream;
     const size_t n = (size_t)o->cfg.n_local * c->nc;
-    if (dist) HIP_TRY(hipMemcpyAsync(dist, o->dist.p + 2 * c->nc, n * sizeof(float), hipMemcpyDeviceToDevice, st));
-    if (idx) HIP_TRY(hipMemcpyAsync(idx, o->idx.p + 2 * c->nc, n * sizeof(int), hipMemcpyDeviceToDevice, st));
-    return FDCAP_OK;
+    const int nl = o->cfg.n_local, nc = c->nc;
+    if (dist) hipLaunchKernelGGL(unpermute_kernel<float>, dim3((n + 255) / 256), dim3(256), 0, st, o->dist.p + 2 * nc,
+                                 c->contact_perm.p, nl, nc, 1, dist);
+    if (idx) hipLaunchKernelGGL(unpermute_kernel<int>, dim3((n + 255) / 256), dim3(256), 0, st, o->idx.p + 2 * nc,
+                                c->contact_perm.p, nl, nc, 1, idx);
+    return (int)hipGetLastError();
 }
 
 int fdcap_opt_get_grads(fdcap_ctx* c, float* dx, float* dcam, void* stream) {

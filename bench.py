@@ -167,6 +167,8 @@ def main():
     #                 iteration's neighbours, scene chunks out of reach skipped; bit-identical result)
     import ctypes
     ms_bf, ms_loop = ctypes.c_float(0), ctypes.c_float(0)
+    if len(scene) == 0:
+        raise SystemExit('bench.py needs a scene (the roofline kernel is the Chamfer NN); BASELINE config 1 is a parity-test case')
     capi.check(fop.ctx.lib.fdcap_opt_time_chamfer(fop.ctx.handle, 3, 1, ctypes.byref(ms_bf), capi.current_stream()),
                "fdcap_opt_time_chamfer")
     capi.check(fop.ctx.lib.fdcap_opt_time_chamfer(fop.ctx.handle, 10, 0, ctypes.byref(ms_loop), capi.current_stream()),

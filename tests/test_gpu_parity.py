@@ -308,7 +308,8 @@ def test_trajectory_matches_reference_golden(golden_dir, name):
     assert np.all(np.abs(np.array(log.loss_smoothing) - g["log"][:, 3]) <= tol)
     # in phase 2 the contact term is log-only and sees camera_ext moving +-lr per step (sign-normalised)
     assert np.all(np.abs(np.array(log.loss_contact) - g["log"][:, 4]) <= np.where(np.arange(num_iter) > P, 4 * tol, tol))
-    assert np.all(np.abs(np.array(log.total) - g["log"][:, 6]) <= 2 * tol)
+    # the phase-2 total contains the camera_ext-sensitive world term (see below)
+    assert np.all(np.abs(np.array(log.total) - g["log"][:, 6]) <= np.where(np.arange(num_iter) > P, 5 * tol, 2 * tol))
     # same camera_ext sensitivity: measured up to 6e-5 at iteration 19 depending on GEMM summation order
     assert np.all(np.abs(np.array(log.loss_world_smoothing)[P:] - g["log"][P:, 5]) <= 4 * tol[P:])
     fop.close()
