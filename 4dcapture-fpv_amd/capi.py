@@ -54,6 +54,7 @@ SYMBOLS = {
     "fdcap_set_nn_kernel": (c_int32, [c_int32]),
     "fdcap_vposer_decode": (c_int32, [c_void_p, c_void_p, c_int32, c_int32, c_void_p, c_void_p, c_void_p]),
     "fdcap_body_forward": (c_int32, [c_void_p, c_void_p, c_int32, c_void_p, c_void_p, c_void_p]),
+    "fdcap_world_mesh": (c_int32, [c_void_p, c_void_p, c_int32, c_void_p, c_void_p, c_void_p, c_void_p]),
     "fdcap_params_75_to_78": (c_int32, [c_void_p, c_int32, c_void_p, c_void_p]),
     "fdcap_params_78_to_75": (c_int32, [c_void_p, c_int32, c_void_p, c_void_p]),
     "fdcap_smplx_forward": (c_int32, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int32,

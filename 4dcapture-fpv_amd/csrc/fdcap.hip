@@ -886,9 +886,9 @@ int fdcap_params_78_to_75(const float* x78, int32_t B, float* p75, void* stream)
 }
 
 // ---- Op 2 ----------------------------------------------------------------------------------
-int fdcap_body_forward(fdcap_ctx* c, const float* params, int32_t B, float* vertices, float* joints, void* stream) {
-    if (!c || !params || B <= 0 || (!vertices && !joints)) return FDCAP_E_ARG;
-    hipStream_t st = (hipStream_t)stream;
+// shared by fdcap_body_forward (body frame) and fdcap_world_mesh (scale + camera_ext @ T(cam_t * scale))
+static int body_forward_impl(fdcap_ctx* c, const float* params, int32_t B, const float* cam_ext, const float* scale,
+                             float* vertices, float* joints, hipStream_t st) {
     if (vertices && !c->full_ready) {
         std::vector<int64_t> all(c->V);
         for (int i = 0; i < c->V; ++i) all[i] = i;
@@ -897,26 +897,43 @@ int fdcap_body_forward(fdcap_ctx* c, const float* params, int32_t B, float* vert
         c->full_ready = true;
     }
     const int V = c->V;
+    const bool world = cam_ext != nullptr && scale != nullptr;
     DevBuf<float>* w = c->ws_f;
     HIP_TRY(w[2].ensure((size_t)B * 512)); HIP_TRY(w[3].ensure((size_t)B * 512)); HIP_TRY(w[4].ensure((size_t)B * ODIM));
     HIP_TRY(w[5].ensure((size_t)B * XDIM)); HIP_TRY(w[6].ensure((size_t)B * NPF)); HIP_TRY(w[7].ensure((size_t)B * NJ * 12));
     HIP_TRY(w[8].ensure((size_t)B * NJ * 12)); HIP_TRY(w[9].ensure((size_t)B * 16)); HIP_TRY(w[10].ensure(1));
+    HIP_TRY(w[1].ensure((size_t)B * 12));
     float* X = w[5].p;
     hipLaunchKernelGGL(p75_to_78_kernel, dim3((B + 127) / 128), dim3(128), 0, st, params, B, X);
     int e = vposer_forward(c, X, XDIM, X_LATENT, B, w[2].p, w[3].p, w[4].p, st);
     if (e) return e;
-    HIP_TRY(hipMemsetAsync(w[9].p, 0, (size_t)B * 16 * sizeof(float), st));
-    HIP_TRY(hipMemsetAsync(w[10].p, 0, sizeof(float), st));
-    hipLaunchKernelGGL(pose_fwd_kernel, dim3(B), dim3(64), 0, st, c->pose_model(), X, w[4].p, w[9].p, w[10].p, 0,
-                       (float*)nullptr, w[6].p, (float*)nullptr, w[7].p, w[8].p, (float*)nullptr, (float*)nullptr, (const float*)nullptr);
+    if (!world) {
+        HIP_TRY(hipMemsetAsync(w[9].p, 0, (size_t)B * 16 * sizeof(float), st));
+        HIP_TRY(hipMemsetAsync(w[10].p, 0, sizeof(float), st));
+    }
+    const float* CAM = world ? cam_ext : w[9].p;
+    const float* S = world ? scale : w[10].p;
+    hipLaunchKernelGGL(pose_fwd_kernel, dim3(B), dim3(64), 0, st, c->pose_model(), X, w[4].p, CAM, S, 0,
+                       (float*)nullptr, w[6].p, (float*)nullptr, w[7].p, w[8].p, w[1].p, (float*)nullptr, (const float*)nullptr);
     if (joints) hipLaunchKernelGGL(joints_out_kernel, dim3((B * NJ + 255) / 256), dim3(256), 0, st, w[7].p, X, XDIM, B, joints);
     if (vertices) {
         HIP_TRY(w[11].ensure((size_t)B * 3 * V));
         HIP_TRY(gemm_f32(false, EPI_STORE, w[6].p, NPF, c->full.posedirs.p, 3 * V, w[11].p, 3 * V, B, 3 * V, NPF, nullptr, 0, st));
         hipLaunchKernelGGL(skin_fwd_kernel, dim3((V + 255) / 256, B), dim3(256), 0, st, c->full.model(), V, X, XDIM, X_BETAS,
-                           X_TRANSL, w[11].p, w[8].p, (const float*)nullptr, (const float*)nullptr, 0, 0, vertices);
+                           X_TRANSL, w[11].p, w[8].p, (const float*)w[1].p, S, 0, world ? 1 : 0, vertices);
     }
     return (int)hipGetLastError();
+}
+
+int fdcap_body_forward(fdcap_ctx* c, const float* params, int32_t B, float* vertices, float* joints, void* stream) {
+    if (!c || !params || B <= 0 || (!vertices && !joints)) return FDCAP_E_ARG;
+    return body_forward_impl(c, params, B, nullptr, nullptr, vertices, joints, (hipStream_t)stream);
+}
+
+int fdcap_world_mesh(fdcap_ctx* c, const float* params, int32_t B, const float* cam_ext, const float* scale, float* vertices,
+                     void* stream) {
+    if (!c || !params || B <= 0 || !cam_ext || !scale || !vertices) return FDCAP_E_ARG;
+    return body_forward_impl(c, params, B, cam_ext, scale, vertices, nullptr, (hipStream_t)stream);
 }
 
 int fdcap_smplx_forward(fdcap_ctx* c, const float* go, const float* bp, const float* betas, const float* lh, const float* rh,

@@ -185,3 +185,48 @@ def write_ply_points(path: str, pts: np.ndarray, binary: bool = True) -> None:
         else:
             for p in pts:
                 f.write(("%r %r %r\n" % (float(p[0]), float(p[1]), float(p[2]))).encode())
+
+
+def load_smoothed_body(fit_path: str):
+    """Read <fit_path>/body_gen_%06d.pkl back (what global_vis.py:105-124 iterates over):
+    -> (body_rec [N,75], scale, camera_ext [N,4,4])."""
+    files = sorted(glob.glob(os.path.join(fit_path, "body_gen_*.pkl")))
+    if not files:
+        raise FileNotFoundError(f"no body_gen_*.pkl under {fit_path}")
+    rows, cams, scale = [], [], None
+    for fn in files:
+        with open(fn, "rb") as f:
+            d = pickle.load(f)
+        rows.append(body_params_parse(d))
+        cams.append(np.asarray(d["camera_ext"], dtype=np.float32).reshape(4, 4))
+        scale = np.float32(d["scale"])
+    return np.vstack(rows).astype(np.float32), scale, np.stack(cams)
+
+
+def colmap_images_to_camerapose(images_txt: str, out_path: str | None = None) -> list:
+    """utils/camerapose_helper.py:15-29: COLMAP images.txt -> camerapose.txt lines
+    ' qw qx qy qz tx ty tz' (first 3 header lines skipped as the reference does, only rows whose
+    last field names a jpg)."""
+    with open(images_txt) as f:
+        lines = [ln.rstrip("\n") for ln in f][3:]
+    out = []
+    for line in lines:
+        items = line.split(" ")
+        if "jpg" in items[-1]:
+            out.append(" " + " ".join(items[1:8]))
+    if out_path:
+        with open(out_path, "w") as f:
+            f.write("\n".join(out) + ("\n" if out else ""))
+    return out
+
+
+def colmap_points_to_xyz(points3d_txt: str, out_path: str | None = None) -> np.ndarray:
+    """utils/pointcloud_helper.py:15-27: COLMAP points3D.txt -> ' x y z r g b' rows; returns xyz [n,3]."""
+    with open(points3d_txt) as f:
+        lines = [ln.rstrip("\n") for ln in f][3:]
+    rows = [ln.split(" ") for ln in lines if ln.strip()]
+    if out_path:
+        with open(out_path, "w") as f:
+            for it in rows:
+                f.write(" " + " ".join(it[1:7]) + "\n")
+    return np.array([[float(it[1]), float(it[2]), float(it[3])] for it in rows], dtype=np.float32).reshape(-1, 3)

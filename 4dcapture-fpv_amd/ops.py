@@ -153,3 +153,20 @@ def body_forward_from_params(ctx, params75: torch.Tensor, want_vertices=True):
     capi.check(fctx.lib.fdcap_body_forward(fctx.handle, capi.dptr(p), B, capi.dptr(verts), capi.dptr(joints),
                                            capi.current_stream()), "fdcap_body_forward")
     return verts, joints
+
+
+def world_mesh(ctx, params75: torch.Tensor, scale, camera_ext: torch.Tensor, shape_from_first: bool = False):
+    """World-space vertices [B,V,3] of optimised results: what global_vis.py:116-152 computes frame by
+    frame on the CPU (`verts * scale`, then `camera_ext @ T(camera_translation * scale)`).
+    shape_from_first=True reuses frame 0's betas for every frame like the viewer does (:118-119, :141)."""
+    fctx = _ctx_of(ctx)
+    p = params75.float().contiguous().clone()
+    if shape_from_first:
+        p[:, 6:16] = p[0:1, 6:16]
+    B = p.shape[0]
+    cam = camera_ext.float().reshape(B, 16).contiguous()
+    s = torch.as_tensor(scale, dtype=torch.float32, device=p.device).reshape(1).contiguous()
+    verts = torch.empty(B, fctx.num_verts, 3, device=p.device)
+    capi.check(fctx.lib.fdcap_world_mesh(fctx.handle, capi.dptr(p), B, capi.dptr(cam), capi.dptr(s), capi.dptr(verts),
+                                         capi.current_stream()), "fdcap_world_mesh")
+    return verts

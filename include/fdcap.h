@@ -121,6 +121,11 @@ int fdcap_vposer_decode(fdcap_ctx* ctx, const float* z_d, int32_t ldz, int32_t B
  * body frame, `+transl` applied, no scale / world transform. */
 int fdcap_body_forward(fdcap_ctx* ctx, const float* params_d, int32_t B, float* vertices_d,
                        float* joints_d, void* stream);
+/* World-space mesh of saved results, as global_vis.py:126-152 builds it per frame on the CPU:
+ * vertices_d [B,V,3] = camera_ext_b @ T(cam_t_b * scale) applied to scale * (SMPL-X(VPoser(row_b)) + transl).
+ * params_d [B,75] rows as saved (:633), cam_ext_d [B,16], scale_d [1] device scalar. */
+int fdcap_world_mesh(fdcap_ctx* ctx, const float* params_d, int32_t B, const float* cam_ext_d,
+                     const float* scale_d, float* vertices_d, void* stream);
 /* The same with the operator's own argument list (:280-283): global_orient_d [B,3] and
  * body_pose_d [B,63] axis-angle (Rodrigues as smplx.lbs.batch_rodrigues), betas_d [B,10],
  * left/right_hand_pose_d [B,12] PCA coefficients, transl_d [B,3]. */

@@ -543,3 +543,28 @@ def test_local_mode_second_loop_gradient_matches_autograd():
     np.testing.assert_allclose(s[6], float(l_cs.detach()), rtol=1e-5)
     np.testing.assert_allclose(s[2] / ((n - 2) * 78), float(l_loc.detach()), rtol=1e-5)
     fop.close()
+
+
+def test_world_mesh_export_matches_viewer_math(tmp_path):
+    """smoothed_body pickles -> world-space mesh exactly as global_vis.py:116-152 composes it."""
+    from fdcap_amd import io
+    n = 7
+    fop, bm, vp, clip, scene, vid = _make_fop(n, 240, 600, 8, 4, seed=95)
+    body, scale, cam = fop.fitting(torch.tensor(clip.body_params).cuda(), "global")
+    fop.save_result(body, scale, cam, str(tmp_path / "smoothed_body"))
+    rows, sc, cams = io.load_smoothed_body(str(tmp_path / "smoothed_body"))
+    got = ops.world_mesh(fop.ctx, torch.tensor(rows).cuda(), sc, torch.tensor(cams).cuda(), shape_from_first=True)
+    p = torch.tensor(rows)
+    p[:, 6:16] = p[0:1, 6:16]
+    aa = VPoserDecoder.from_data(vp).decode(p[:, 16:48], output_type="aa").view(n, -1)
+    out = SMPLXOracle(bm)(return_verts=True, body_pose=aa, transl=p[:, 0:3], global_orient=p[:, 3:6], betas=p[:, 6:16],
+                          left_hand_pose=p[:, 48:60], right_hand_pose=p[:, 60:72])
+    want = []
+    for i in range(n):                                   # the viewer's per-frame numpy arithmetic
+        camera_pose = np.eye(4)
+        camera_pose[:3, 3] = rows[i, 72:75] * sc
+        body_trans = cams[i].astype(np.float64) @ camera_pose
+        v = out.vertices[i].numpy().astype(np.float64) * sc
+        want.append((np.c_[v, np.ones(len(v))] @ body_trans.T)[:, :3])
+    np.testing.assert_allclose(got.cpu().numpy(), np.stack(want), atol=5e-5)
+    fop.close()

@@ -86,3 +86,22 @@ def test_product_package_never_imports_the_oracle():
             if fn.endswith((".py", ".h", ".hip")):
                 text = open(os.path.join(dirpath, fn)).read()
                 assert "import oracle" not in text and "from oracle" not in text, fn
+
+
+def test_colmap_helpers_follow_reference_scripts(tmp_path):
+    img = tmp_path / "images.txt"
+    img.write_text("# Image list\n# IMAGE_ID, QW, QX, QY, QZ, TX, TY, TZ, CAMERA_ID, NAME\n# Number of images: 2\n"
+                   "1 0.9 0.1 0.2 0.3 1.0 2.0 3.0 1 frame_000001.jpg\n"
+                   "10.5 20.5 -1 30.5 40.5 -1\n"
+                   "2 0.8 -0.1 0.25 0.35 1.5 2.5 3.5 1 frame_000002.jpg\n"
+                   "11.5 21.5 -1\n")
+    lines = io.colmap_images_to_camerapose(str(img), str(tmp_path / "camerapose.txt"))
+    assert lines == [" 0.9 0.1 0.2 0.3 1.0 2.0 3.0", " 0.8 -0.1 0.25 0.35 1.5 2.5 3.5"]
+    ext = io.read_camerapose(str(tmp_path / "camerapose.txt"))
+    assert ext.shape == (2, 4, 4)
+    pts = tmp_path / "points3D.txt"
+    pts.write_text("# 3D point list\n# POINT3D_ID, X, Y, Z, R, G, B, ERROR, TRACK[]\n# Number of points: 2\n"
+                   "1 0.5 1.5 2.5 255 0 0 0.1 1 2\n2 -0.5 -1.5 -2.5 0 255 0 0.2 2 3\n")
+    xyz = io.colmap_points_to_xyz(str(pts), str(tmp_path / "xyz.xyz"))
+    np.testing.assert_allclose(xyz, [[0.5, 1.5, 2.5], [-0.5, -1.5, -2.5]])
+    np.testing.assert_allclose(io.read_scene_points(str(tmp_path / "xyz.xyz")), xyz)
