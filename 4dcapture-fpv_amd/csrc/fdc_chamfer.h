@@ -28,6 +28,11 @@ struct NNTarget {
     int n;
     const float4* bounds;     // optional [2 * ceil(n / MF_CH)] axis-aligned box {lo xyz, -}, {hi xyz, -} of each chunk (pts spatially sorted)
     const int* inv_perm;      // optional [n] original index -> position in pts (null: identity)
+    // optional, static per scene: MFMA A fragments precomputed per chunk RELATIVE TO THE CHUNK'S OWN CENTRE
+    // ([chunk][tile 0..15][k-half][point 0..31] uint4) + the centres {cx, cy, cz, radius}: lets a wave
+    // stream a chunk straight from global memory into registers (no LDS staging, no workgroup barrier)
+    const uint4* frags;
+    const float4* centers;
 };
 
 // The one definition of the squared distance every kernel reports (direct-difference form as
@@ -424,6 +429,180 @@ __global__ __launch_bounds__(256) void nn_mfma_kernel(const float* __restrict__ 
     }
 }
 
+
+// ---------------------------------------------------------------------------------------------
+// Streaming variant for seeded + culled launches (the optimiser's steady state).
+// With 2-3 % of the chunks surviving, the staged kernel above is bound by the per-chunk
+// global-load -> convert -> LDS -> barrier latency, not by the matrix pipe.  Here every WAVE is
+// independent: it builds its own survivor list (its 32*NQ queries are spatially compact because the
+// contact slots are Morton-ordered), re-centres its queries on each surviving chunk's centre and
+// streams that chunk's PRECOMPUTED A fragments (NNTarget::frags, static per scene) from global
+// memory straight into registers, software-pipelined two tiles ahead.  No LDS staging, no
+// __syncthreads in the main loop, no partial minima / combine pass (one scan per query).
+// Same filter, same exact re-evaluation, same (d, index) order => bit-identical results.
+// eps per chunk: |y'| <= chunk radius rc, so eps = K1 * X * rc + K2 * (X^2 + rc^2), X = |x - centre|.
+constexpr int ST_MAXLIST = 1024;       // survivors a wave can list (more -> it falls back to scanning every chunk)
+
+template <int NQ>
+__global__ __launch_bounds__(256) void nn_stream_kernel(const float* __restrict__ q, int nq, NNTarget T,
+                                                        const int* __restrict__ seed, float* __restrict__ dist,
+                                                        int* __restrict__ idx) {
+    __shared__ unsigned short slist[4][ST_MAXLIST];
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, half = lane >> 5, col = lane & 31;
+    const int wq0 = (blockIdx.x * 4 + wave) * (32 * NQ);       // first query of this wave
+    if (wq0 >= nq) return;                                      // whole wave idle (no barriers below)
+    const int nchunk = (T.n + MF_CH - 1) / MF_CH;
+
+    float qx[NQ], qy[NQ], qz[NQ], own_d[NQ], sb[NQ];
+    int own_i[NQ], qidx[NQ];
+    float sx = 0.f, sy = 0.f, sz = 0.f, sc = 0.f;
+    bool all_seeded = true;
+#pragma unroll
+    for (int n = 0; n < NQ; ++n) {
+        qidx[n] = wq0 + n * 32 + col;
+        const bool ok = qidx[n] < nq;
+        qx[n] = ok ? q[3 * (size_t)qidx[n]] : 0.f;
+        qy[n] = ok ? q[3 * (size_t)qidx[n] + 1] : 0.f;
+        qz[n] = ok ? q[3 * (size_t)qidx[n] + 2] : 0.f;
+        own_d[n] = INFINITY;
+        own_i[n] = -1;
+        if (ok) {
+            sx += qx[n]; sy += qy[n]; sz += qz[n]; sc += 1.f;
+            const int sj = seed[qidx[n]];
+            if (sj >= 0 && sj < T.n) {
+                const float4 p = T.pts[T.inv_perm ? T.inv_perm[sj] : sj];
+                own_d[n] = nn_exact_d2(qx[n], qy[n], qz[n], p.x, p.y, p.z);
+                own_i[n] = sj;
+            } else {
+                all_seeded = false;
+            }
+        }
+        sb[n] = ok ? own_d[n] * 1.00002f + 1e-9f : -INFINITY;   // bound with the rounding slack of the box test
+    }
+    // wave centroid + reach
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        sx += __shfl_xor(sx, off, 64); sy += __shfl_xor(sy, off, 64); sz += __shfl_xor(sz, off, 64); sc += __shfl_xor(sc, off, 64);
+    }
+    const float inv = 1.f / fmaxf(sc, 1.f);
+    const float wx = sx * inv, wy = sy * inv, wz = sz * inv;
+    float reach = 0.f;
+#pragma unroll
+    for (int n = 0; n < NQ; ++n)
+        if (qidx[n] < nq) {
+            const float dx = qx[n] - wx, dy = qy[n] - wy, dz = qz[n] - wz;
+            reach = fmaxf(reach, sqrtf(dx * dx + dy * dy + dz * dz) + sqrtf(own_d[n]));
+        }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) reach = fmaxf(reach, __shfl_xor(reach, off, 64));
+    reach = reach * 1.00001f + 1e-6f;
+    const bool cull = __all(all_seeded) && reach < INFINITY;
+
+    // survivor list of this wave: pass 1 (64 chunks per round against the wave's reach), pass 2 per query
+    int nsurv = nchunk;
+    bool listed = false;
+    if (cull) {
+        nsurv = 0;
+        listed = true;
+        const float r2 = reach * reach;
+        for (int c0 = 0; c0 < nchunk && listed; c0 += 64) {
+            const int ci = c0 + lane;
+            bool near = false;
+            if (ci < nchunk) near = !(box_d2(T.bounds[2 * ci], T.bounds[2 * ci + 1], wx, wy, wz) > r2);
+            unsigned long long m = __ballot(near);
+            while (m) {                                          // wave-uniform loop over the near chunks of this round
+                const int b = __ffsll((long long)m) - 1;
+                m &= m - 1;
+                const float4 lo = T.bounds[2 * (c0 + b)], hi = T.bounds[2 * (c0 + b) + 1];
+                bool hit = false;
+#pragma unroll
+                for (int n = 0; n < NQ; ++n) hit |= box_d2(lo, hi, qx[n], qy[n], qz[n]) <= sb[n];
+                if (__any(hit)) {
+                    if (nsurv >= ST_MAXLIST) { listed = false; break; }
+                    if (lane == 0) slist[wave][nsurv] = (unsigned short)(c0 + b);
+                    ++nsurv;
+                }
+            }
+        }
+        if (!listed) nsurv = nchunk;                            // list overflow: scan everything (still exact)
+    }
+    const f32x16_t zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+
+    for (int s = 0; s < nsurv; ++s) {
+        const int ch = listed ? (int)slist[wave][s] : s;
+        const float4 cc = T.centers[ch];
+        const uint4* fr = T.frags + (size_t)ch * (MF_CH / 32) * 64 + lane;     // [tile][half][col] == [tile][lane]
+        uint4 f0 = fr[0], f1 = fr[64];                          // two tiles in flight
+        // re-centre this wave's queries on the chunk centre
+        bf16x8 bfrag[NQ];
+        float thr[NQ], X[NQ], X2[NQ];
+        const float rc = cc.w;
+#pragma unroll
+        for (int n = 0; n < NQ; ++n) {
+            const float xx = qx[n] - cc.x, xy = qy[n] - cc.y, xz = qz[n] - cc.z;
+            X2[n] = __fmaf_rn(xz, xz, __fmaf_rn(xy, xy, xx * xx));
+            X[n] = sqrtf(X2[n]);
+            const unsigned hx = f2bf(xx), hy = f2bf(xy), hz = f2bf(xz);
+            const unsigned lx = f2bf(xx - bf2f(hx)), ly = f2bf(xy - bf2f(hy)), lz = f2bf(xz - bf2f(hz));
+            const unsigned px = f2bf(-2.f * bf2f(hx)) | (f2bf(-2.f * bf2f(lx)) << 16);
+            const unsigned py = f2bf(-2.f * bf2f(hy)) | (f2bf(-2.f * bf2f(ly)) << 16);
+            const unsigned pz = f2bf(-2.f * bf2f(hz)) | (f2bf(-2.f * bf2f(lz)) << 16);
+            const unsigned one = 0x3F80u;
+            const uint4 u = half == 0 ? make_uint4(px, px, py, py) : make_uint4(pz, pz, one | (one << 16), one);
+            bfrag[n] = __builtin_bit_cast(bf16x8, u);
+            const float sbest = fminf(own_d[n], __shfl_xor(own_d[n], 32, 64));
+            thr[n] = (qidx[n] < nq) ? sbest - X2[n] + (MF_K1 * X[n] * rc + MF_K2 * (X2[n] + rc * rc)) : -INFINITY;
+        }
+        const int base = ch * MF_CH;
+        const int ntile = (min(MF_CH, T.n - base) + 31) >> 5;
+        for (int tile = 0; tile < ntile; ++tile) {
+            const bf16x8 afrag = __builtin_bit_cast(bf16x8, f0);
+            f0 = f1;
+            if (tile + 2 < ntile) f1 = fr[(tile + 2) * 64];
+            f32x16_t acc_q[NQ];
+            acc_q[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afrag, bfrag[0], zero, 0, 0, 0);
+            if (NQ > 1) acc_q[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afrag, bfrag[1], zero, 0, 0, 0);
+#pragma unroll
+            for (int n = 0; n < NQ; ++n) {
+                const f32x16_t acc = acc_q[n];
+                if (n + 2 < NQ) acc_q[n + 2] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afrag, bfrag[n + 2], zero, 0, 0, 0);
+                const float t0 = fminf(fminf(acc[0], acc[1]), acc[2]), t1 = fminf(fminf(acc[3], acc[4]), acc[5]);
+                const float t2 = fminf(fminf(acc[6], acc[7]), acc[8]), t3 = fminf(fminf(acc[9], acc[10]), acc[11]);
+                const float t4 = fminf(fminf(acc[12], acc[13]), acc[14]);
+                const float m = fminf(fminf(fminf(t0, t1), t2), fminf(fminf(t3, t4), acc[15]));
+                if (__any(m < thr[n])) {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        if (acc[r] < thr[n]) {
+                            const int row = (r & 3) + 8 * (r >> 2) + 4 * half;
+                            const int pos = base + tile * 32 + row;
+                            if (pos < T.n) {
+                                const float4 p = T.pts[pos];
+                                const int gi = __float_as_int(p.w);
+                                const float d = nn_exact_d2(qx[n], qy[n], qz[n], p.x, p.y, p.z);
+                                if (nn_better(d, gi, own_d[n], own_i[n])) {
+                                    own_d[n] = d;
+                                    own_i[n] = gi;
+                                    thr[n] = d - X2[n] + (MF_K1 * X[n] * rc + MF_K2 * (X2[n] + rc * rc));
+                                }
+                            }
+                        }
+                    }
+                    const float sbest = fminf(own_d[n], __shfl_xor(own_d[n], 32, 64));
+                    if (qidx[n] < nq) thr[n] = sbest - X2[n] + (MF_K1 * X[n] * rc + MF_K2 * (X2[n] + rc * rc));
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int n = 0; n < NQ; ++n) {
+        const float od = __shfl_xor(own_d[n], 32, 64);
+        const int oi = __shfl_xor(own_i[n], 32, 64);
+        if (oi >= 0 && (own_i[n] < 0 || nn_better(od, oi, own_d[n], own_i[n]))) { own_d[n] = od; own_i[n] = oi; }
+        if (half == 0 && qidx[n] < nq) { dist[qidx[n]] = own_d[n]; idx[qidx[n]] = own_i[n]; }
+    }
+}
+
 __global__ void nn_combine_kernel(const float* __restrict__ pd, const int* __restrict__ pi, int nsplit, int nq,
                                   float* __restrict__ dist, int* __restrict__ idx) {
     int qi = blockIdx.x * blockDim.x + threadIdx.x;
@@ -502,6 +681,13 @@ static inline hipError_t nn_search(const float* q, int nq, const NNTarget& T, fl
     static int forced_nq = -1;
     if (forced_nq < 0) { const char* e = getenv("FDCAP_NN_NQ"); forced_nq = e ? atoi(e) : 0; }
     const bool culled = seed != nullptr && T.bounds != nullptr;
+    static int use_stream = -1;                              // FDCAP_NN_STREAM=0 keeps the staged kernel for culled launches (A/B)
+    if (use_stream < 0) { const char* e = getenv("FDCAP_NN_STREAM"); use_stream = (e && e[0] == '0') ? 0 : 1; }
+    if (culled && T.frags != nullptr && use_stream && nn_use_mfma(nq, T.n)) {
+        // seed may alias idx: every wave reads its seeds before it writes its own results, and no other wave touches them
+        hipLaunchKernelGGL((nn_stream_kernel<2>), dim3((nq + 255) / 256), dim3(256), 0, st, q, nq, T, seed, dist, idx);
+        return hipGetLastError();
+    }
     const int NQsel = forced_nq ? forced_nq : (culled ? 2 : 4);
     if (nn_use_mfma(nq, T.n) && NQsel == 1)
         hipLaunchKernelGGL((nn_mfma_kernel<1>), dim3(nn_grid_blocks((nq + 127) / 128, nsplit)), dim3(256), 0, st, q, nq, T, nsplit, seed, pd, pi);

@@ -548,9 +548,12 @@ struct fdcap_ctx {
     DevBuf<float4> scene_sorted;   // Morton order {x,y,z,bits(original index)}: what the NN scan streams
     DevBuf<float4> scene_bounds;   // axis-aligned box {lo},{hi} of each MF_CH-point chunk of scene_sorted
     DevBuf<int> scene_inv;         // original index -> position in scene_sorted
+    DevBuf<uint4> scene_frags;     // precomputed chunk-centred bf16 MFMA A fragments of scene_sorted
+    DevBuf<float4> scene_centers;  // chunk centres {x,y,z,radius}
     int64_t ns = 0;
     NNTarget nn_target(bool cull) const {
         NNTarget t; t.pts = scene_sorted.p; t.n = (int)ns; t.bounds = cull ? scene_bounds.p : nullptr; t.inv_perm = scene_inv.p;
+        t.frags = cull ? scene_frags.p : nullptr; t.centers = scene_centers.p;
         return t;
     }
     int nc = 0;
@@ -705,7 +708,7 @@ void fdcap_ctx_destroy(fdcap_ctx* c) {
     c->Jt.release(); c->Jd.release(); c->hand_comp.release(); c->hand_mean.release();
     c->parents.release(); c->order.release(); c->level_start.release(); c->child_start.release(); c->child_list.release();
     c->W1.release(); c->b1.release(); c->W2.release(); c->b2.release(); c->W3.release(); c->b3.release();
-    c->full.release(); c->contact.release(); c->contact_vid.release(); c->contact_perm.release(); c->scene.release(); c->scene_sorted.release(); c->scene_bounds.release(); c->scene_inv.release();
+    c->full.release(); c->contact.release(); c->contact_vid.release(); c->contact_perm.release(); c->scene.release(); c->scene_sorted.release(); c->scene_bounds.release(); c->scene_inv.release(); c->scene_frags.release(); c->scene_centers.release();
     for (auto& b : c->ws_f) b.release();
     for (auto& b : c->ws_i) b.release();
     c->ws_p.release();
@@ -755,6 +758,37 @@ int fdcap_set_scene(fdcap_ctx* c, const float* xyz, int64_t ns) {
         bounds[2 * ch] = make_float4(blo[0], blo[1], blo[2], 0.f);
         bounds[2 * ch + 1] = make_float4(bhi[0], bhi[1], bhi[2], 0.f);
     }
+    // chunk-centred bf16 hi/lo fragments in MFMA A layout (see nn_stream_kernel)
+    auto bf = [](float f) -> uint32_t { uint32_t u; memcpy(&u, &f, 4); u += 0x7FFFu + ((u >> 16) & 1u); return u >> 16; };   // RNE
+    auto bff = [](uint32_t h) -> float { uint32_t u = h << 16; float f; memcpy(&f, &u, 4); return f; };
+    std::vector<uint4> frags((size_t)nchunk * (MF_CH / 32) * 64);
+    std::vector<float4> centers((size_t)nchunk);
+    for (int64_t ch = 0; ch < nchunk; ++ch) {
+        const float4 lo = bounds[2 * ch], hi = bounds[2 * ch + 1];
+        const float cx = 0.5f * (lo.x + hi.x), cy = 0.5f * (lo.y + hi.y), cz = 0.5f * (lo.z + hi.z);
+        float r2 = 0.f;
+        for (int j = 0; j < MF_CH; ++j) {
+            const int64_t p = ch * MF_CH + j;
+            float yx = 0.f, yy = 0.f, yz = 0.f, n2 = 1e30f;      // padding rows: score 1e30
+            if (p < ns) {
+                yx = sorted[p].x - cx; yy = sorted[p].y - cy; yz = sorted[p].z - cz;
+                n2 = yz * yz + (yy * yy + yx * yx);
+                r2 = std::max(r2, n2);
+            }
+            const uint32_t hx = bf(yx), hy = bf(yy), hz = bf(yz);
+            const uint32_t lx = bf(yx - bff(hx)), ly = bf(yy - bff(hy)), lz = bf(yz - bff(hz));
+            const uint32_t nh = bf(n2);
+            const float r1 = n2 - bff(nh);
+            const uint32_t nm = bf(r1), nl = bf(r1 - bff(nm));
+            const int tile = j >> 5, pt = j & 31;
+            uint4* t = frags.data() + ((size_t)ch * (MF_CH / 32) + tile) * 64;
+            t[pt] = make_uint4(hx | (hx << 16), lx | (lx << 16), hy | (hy << 16), ly | (ly << 16));
+            t[32 + pt] = make_uint4(hz | (hz << 16), lz | (lz << 16), nh | (nm << 16), nl);
+        }
+        centers[ch] = make_float4(cx, cy, cz, sqrtf(r2) * 1.00001f + 1e-6f);
+    }
+    HIP_TRY(c->scene_frags.upload(frags.data(), frags.size()));
+    HIP_TRY(c->scene_centers.upload(centers.data(), centers.size()));
     HIP_TRY(c->scene.upload(orig.data(), orig.size()));
     HIP_TRY(c->scene_sorted.upload(sorted.data(), sorted.size()));
     HIP_TRY(c->scene_bounds.upload(bounds.data(), bounds.size()));
@@ -816,7 +850,7 @@ int fdcap_chamfer_fwd(fdcap_ctx* c, const float* xyz1, const float* xyz2, int32_
         int nsplit = nn_pick_nsplit(nq, m);
         HIP_TRY(c->ws_f[0].ensure((size_t)nsplit * nq));
         HIP_TRY(c->ws_i[0].ensure((size_t)nsplit * nq));
-        { NNTarget T{c->ws_p.p, m, nullptr, nullptr}; HIP_TRY(nn_search(xyz1, nq, T, dist1, idx1, c->ws_f[0].p, c->ws_i[0].p, nsplit, st)); }
+        { NNTarget T{c->ws_p.p, m, nullptr, nullptr, nullptr, nullptr}; HIP_TRY(nn_search(xyz1, nq, T, dist1, idx1, c->ws_f[0].p, c->ws_i[0].p, nsplit, st)); }
     }
     for (int b = 0; b < B && (!shared || dist2); ++b) {
         const float* x1 = xyz1 + (size_t)b * n * 3;
@@ -827,14 +861,14 @@ int fdcap_chamfer_fwd(fdcap_ctx* c, const float* xyz1, const float* xyz2, int32_
             int nsplit = nn_pick_nsplit(n, m);
             HIP_TRY(c->ws_f[0].ensure((size_t)nsplit * n));
             HIP_TRY(c->ws_i[0].ensure((size_t)nsplit * n));
-            { NNTarget T{pk, m, nullptr, nullptr}; HIP_TRY(nn_search(x1, n, T, dist1 + (size_t)b * n, idx1 + (size_t)b * n, c->ws_f[0].p, c->ws_i[0].p, nsplit, st)); }
+            { NNTarget T{pk, m, nullptr, nullptr, nullptr, nullptr}; HIP_TRY(nn_search(x1, n, T, dist1 + (size_t)b * n, idx1 + (size_t)b * n, c->ws_f[0].p, c->ws_i[0].p, nsplit, st)); }
         }
         if (dist2) {
             hipLaunchKernelGGL(pack_points_kernel, dim3((n + 255) / 256), dim3(256), 0, st, x1, n, pk);
             int nsplit = nn_pick_nsplit(m, n);
             HIP_TRY(c->ws_f[1].ensure((size_t)nsplit * m));
             HIP_TRY(c->ws_i[1].ensure((size_t)nsplit * m));
-            { NNTarget T{pk, n, nullptr, nullptr}; HIP_TRY(nn_search(x2, m, T, dist2 + (size_t)b * m, idx2 + (size_t)b * m, c->ws_f[1].p, c->ws_i[1].p, nsplit, st)); }
+            { NNTarget T{pk, n, nullptr, nullptr, nullptr, nullptr}; HIP_TRY(nn_search(x2, m, T, dist2 + (size_t)b * m, idx2 + (size_t)b * m, c->ws_f[1].p, c->ws_i[1].p, nsplit, st)); }
         }
     }
     return (int)hipGetLastError();
@@ -1337,7 +1371,7 @@ int fdcap_opt_time_chamfer(fdcap_ctx* c, int32_t iters, int32_t brute_force, flo
     // otherwise the launch is exactly what the loop issues in steady state
     const int* seed = (!brute_force && o->use_seed) ? o->idx.p + 2 * nc : nullptr;
     NNTarget T = c->nn_target(!brute_force && o->use_cull);
-    if (brute_force) { T.pts = c->scene.p; T.inv_perm = nullptr; }   // input order (a spatial sort is adversarial for an unseeded running minimum)
+    if (brute_force) { T.pts = c->scene.p; T.inv_perm = nullptr; T.frags = nullptr; }   // input order (a spatial sort is adversarial for an unseeded running minimum)
     hipEvent_t e0, e1;
     HIP_TRY(hipEventCreate(&e0));
     HIP_TRY(hipEventCreate(&e1));
