@@ -7,6 +7,8 @@ Layout:
   ops.py       drop-in operators with the third-party call signatures the reference uses
                (chamferDist, body model, VPoser decode)
   fitting.py   FittingOP mirror (init / fitting / save_result) driving the fused HIP iteration
+               (modes 'global', 'local', 'dct')
+  smoother.py  optimization.py's per-frame smoother (FittingOP.fitting / fitting_smoothing) in one launch
   io.py        body_gen -> smoothed_body pickle interface, camerapose.txt, scene readers
   synth.py     seeded synthetic stand-ins for the licensed assets
   dist.py      frame sharding + halo exchange over torch.distributed (RCCL on ROCm)

@@ -17,7 +17,7 @@ def main(argv=None):
     ap = argparse.ArgumentParser(prog="global_optimization (fdcap_amd / MI355X)")
     ap.add_argument("body_path")
     ap.add_argument("fit_path")
-    ap.add_argument("mode", nargs="?", default="global", choices=["global", "local"])
+    ap.add_argument("mode", nargs="?", default="global", choices=["global", "local", "dct"])
     ap.add_argument("--scene-root", default="/home/miao/")
     ap.add_argument("--scene", default=None, help="scene vertices (.ply/.xyz/.npy); default <root>/<sample>/meshed-poisson.ply")
     ap.add_argument("--camera", default=None, help="camerapose.txt; default <root>/<sample>/camerapose.txt")
@@ -27,6 +27,8 @@ def main(argv=None):
     ap.add_argument("--num-iter", type=int, default=500)
     ap.add_argument("--lr", type=float, default=0.005)
     ap.add_argument("--log-every", type=int, default=0)
+    ap.add_argument("--dct-mat", default="../Data/DCT_Basis/60.mat", help="DCT basis .mat (:45); generated if absent")
+    ap.add_argument("--dct-num-iter", type=int, default=10000, help="iterations of mode 'dct' (:596)")
     a = ap.parse_args(argv)
 
     import torch
@@ -39,10 +41,10 @@ def main(argv=None):
     fittingconfig = {"scene_verts_path": scene, "camera_path": camera, "human_model_path": a.models,
                      "vposer_ckpt_path": a.vposer, "init_lr_h": a.lr, "num_iter": a.num_iter,
                      "contact_id_folder": a.body_segments, "contact_part": ["L_Leg", "R_Leg"],
-                     "verbose": bool(a.log_every)}
+                     "verbose": bool(a.log_every), "dct_mat_path": a.dct_mat}
     lossconfig = {"weight_loss_rec": 1, "weight_loss_vposer": 0.001, "weight_contact": 0.1, "weight_collision": 0.5}
     data = io.load_body_gen(a.body_path)                                         # :688-707
-    fop = FittingOP(fittingconfig, lossconfig, data.shape[0])
+    fop = FittingOP(fittingconfig, lossconfig, data.shape[0], dct_num_iter=a.dct_num_iter)
     body_rec, scale, camera_ext = fop.fitting(torch.tensor(data).cuda(), a.mode, log_every=a.log_every)
     fop.save_result(body_rec, scale, camera_ext, a.fit_path)                     # :714
     print("[INFO][fitting] fitting finish, returning optimal value")

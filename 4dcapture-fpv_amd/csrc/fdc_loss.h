@@ -59,7 +59,12 @@ FDC_HD AdamScalars adam_scalars(double lr, int step) {
     return a;
 }
 
+// No FMA contraction: torch-CPU's lerp_ / mul_ / addcmul_ / addcdiv_ round every product and sum
+// separately, and next to an L1 kink one ulp decides the sign of the next gradient.
 FDC_HD void adam_update(float& p, float& m, float& v, float g, const AdamScalars& a) {
+#if defined(__clang__)
+#pragma clang fp contract(off)
+#endif
     m = m + (g - m) * a.one_minus_b1;                 // exp_avg.lerp_(grad, 1-beta1)
     v = v * a.b2 + a.one_minus_b2 * g * g;            // exp_avg_sq.mul_(beta2).addcmul_(g, g, 1-beta2)
     float denom = sqrtf(v) / a.bc2_sqrt + a.eps;      // sqrt(v)/sqrt(bc2) + eps

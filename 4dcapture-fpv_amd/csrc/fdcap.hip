@@ -10,6 +10,7 @@
 
 #include "../../include/fdcap.h"
 #include "fdc_chamfer.h"
+#include "fdc_dct.h"
 #include "fdc_frame.h"
 #include "fdc_gemm.h"
 #include "fdc_host_setup.h"
@@ -527,6 +528,12 @@ struct OptState {
     DevBuf<float> dA, dbeta_v, dtransl_v, dMv, dsv, dPF, dJw, dX, dCAM, dscale_row;
     DevBuf<float> VoffF, VwF, dVF;      // mode 'local' second loop: full-mesh pose offsets / world vertices / gradient
     int cam_steps = 0;
+    // mode 'dct': basis [T,C], coefficients + Adam moments [W,69,C] (W = n_total / T windows of the whole clip)
+    DevBuf<float> dctD, dctCoef, dctM, dctV;
+    DevBuf<AdamScalars> adam_tab;
+    std::vector<AdamScalars> adam_tab_h;
+    int dctT = 0, dctC = 0, dctW = 0;
+    bool dct_grad = false;    // the last backward gave `scale` a gradient through the DCT term
     bool use_seed = true;     // last iteration's neighbours seed the NN bound (pruning only)
     bool use_cull = true;     // skip scene chunks whose bounding sphere is out of every query's reach
 };
@@ -560,6 +567,8 @@ struct fdcap_ctx {
     DevBuf<int> contact_vid;       // mesh vertex of each contact id (caller's order)
     DevBuf<int> contact_perm;      // internal contact slot -> position in the caller's id array
     // growable workspaces for the stand-alone operators
+    DevBuf<AdamScalars> ws_adam;
+    std::vector<AdamScalars> ws_adam_h;
     DevBuf<float> ws_f[12];
     DevBuf<int> ws_i[2];
     DevBuf<float4> ws_p;
@@ -705,6 +714,7 @@ int fdcap_ctx_create(const fdcap_model_desc* md, fdcap_ctx** out) {
 void fdcap_ctx_destroy(fdcap_ctx* c) {
     if (!c) return;
     fdcap_opt_destroy(c);
+    c->ws_adam.release();
     c->Jt.release(); c->Jd.release(); c->hand_comp.release(); c->hand_mean.release();
     c->parents.release(); c->order.release(); c->level_start.release(); c->child_start.release(); c->child_list.release();
     c->W1.release(); c->b1.release(); c->W2.release(); c->b2.release(); c->W3.release(); c->b3.release();
@@ -1011,6 +1021,7 @@ void fdcap_opt_destroy(fdcap_ctx* c) {
                            &o->Jw, &o->Voff, &o->Vw, &o->dist, &o->pd, &o->dVoff, &o->dA, &o->dbeta_v, &o->dtransl_v, &o->dMv,
                            &o->dsv, &o->dPF, &o->dJw, &o->dX, &o->dCAM, &o->dscale_row, &o->VoffF, &o->VwF, &o->dVF};
     for (auto* b : fb) b->release();
+    o->dctD.release(); o->dctCoef.release(); o->dctM.release(); o->dctV.release(); o->adam_tab.release();
     o->idx.release(); o->pi.release();
     delete o;
     c->opt = nullptr;
@@ -1026,6 +1037,8 @@ int fdcap_opt_create(fdcap_ctx* c, const fdcap_opt_config* cfg, float* rows_x, f
     c->opt = o;
     o->cfg = *cfg;
     o->cam_steps = 0;
+    o->dctT = o->dctC = o->dctW = 0;
+    o->dct_grad = false;
     const int R = o->R = cfg->n_local + 4;
     o->contact_on = c->ns > 0 && c->nc > 0 && cfg->weight_contact != 0.f;
     const size_t nq = (size_t)R * std::max(c->nc, 1);
@@ -1097,29 +1110,37 @@ static int opt_contact_forward(fdcap_ctx* c, hipStream_t st) {
     return 0;
 }
 
-int fdcap_opt_backward(fdcap_ctx* c, int32_t ii, int32_t P, int32_t log_terms, void* stream) {
-    if (!c || !c->opt) return FDCAP_E_STATE;
+namespace {
+// weights of the loss total of one iteration (multipliers of the lossconfig weights, :570 / :582 / :620)
+struct LossWeights { float rec, smooth, contact, world, dct; bool world_on; };
+}
+
+static int opt_backward_impl(fdcap_ctx* c, const LossWeights& lw, int32_t log_terms, hipStream_t st) {
     OptState* o = c->opt;
-    hipStream_t st = (hipStream_t)stream;
     const fdcap_opt_config& cf = o->cfg;
     const int R = o->R, nl = cf.n_local, nc = c->nc, N = cf.n_total;
-    const bool phase2 = ii >= P;
+    const bool dct_on = lw.dct != 0.f && o->dctW > 0;
     PoseModel pm = c->pose_model();
     HIP_TRY(hipMemsetAsync(o->losses.p, 0, FDCAP_NUM_LOSSES * sizeof(double), st));
     int e = vposer_forward(c, o->X.p, XDIM, X_LATENT, R, o->H1.p, o->H2.p, o->O.p, st);
     if (e) return e;
     hipLaunchKernelGGL(pose_fwd_kernel, dim3(R), dim3(64), 0, st, pm, o->X.p, o->O.p, o->CAM.p, o->scale.p, 0, o->Rm.p,
                        o->PF.p, o->Jrest.p, o->G.p, o->A.p, o->M.p, o->Jw.p, (const float*)nullptr);
-    const bool contact_grad = o->contact_on && !phase2;
-    const bool contact_fwd = o->contact_on && (!phase2 || log_terms);
+    const bool contact_grad = o->contact_on && lw.contact != 0.f;
+    const bool contact_fwd = o->contact_on && (contact_grad || log_terms);
     if (contact_fwd) { e = opt_contact_forward(c, st); if (e) return e; }
-    const float w_rec = cf.weight_loss_rec / ((float)N * XDIM);
-    const float w_sm = (N >= 3) ? (phase2 ? cf.phase2_smooth : cf.phase1_smooth) / ((float)(N - 2) * XDIM) : 0.f;
-    const float w_ws = (phase2 && N >= 2) ? cf.phase2_world / ((float)(N - 1) * NJW * 3) : 0.f;
+    const float w_rec = lw.rec * cf.weight_loss_rec / ((float)N * XDIM);
+    const float w_sm = (N >= 3) ? lw.smooth / ((float)(N - 2) * XDIM) : 0.f;
+    const float w_ws = (lw.world_on && N >= 2) ? lw.world / ((float)(N - 1) * NJW * 3) : 0.f;
     hipLaunchKernelGGL(param_loss_kernel, dim3(nl), dim3(128), 0, st, o->X.p, o->X0.p, o->mask.p, o->Jw.p, 2, cf.frame0, N,
-                       w_rec, w_sm, w_ws, phase2 ? 1 : 0, o->dX.p, o->dJw.p, o->losses.p);
+                       w_rec, w_sm, w_ws, lw.world_on ? 1 : 0, o->dX.p, o->dJw.p, o->losses.p);
+    if (o->dctW > 0 && (dct_on || log_terms))
+        hipLaunchKernelGGL(dct_joint_grad_kernel, dim3((nl * 69 + 255) / 256), dim3(256), 0, st, o->Jw.p, 2, cf.frame0, nl, o->dctT,
+                           o->dctC, o->dctW, o->dctD.p, o->dctCoef.p, dct_on ? lw.dct / (69.f * (float)o->dctW) : 0.f,
+                           lw.world_on ? 1 : 0, o->dJw.p, o->losses.p + 7);
+    o->dct_grad = dct_on;
     if (contact_grad) {
-        const float coef = cf.phase1_contact * cf.weight_contact / ((float)N * nc);
+        const float coef = lw.contact * cf.weight_contact / ((float)N * nc);
         const size_t nqv = (size_t)nl * nc, offq = (size_t)2 * nc;
         hipLaunchKernelGGL(contact_grad_kernel, dim3((nqv + 255) / 256), dim3(256), 0, st, o->Vw.p + offq * 3, o->dist.p + offq,
                            o->idx.p + offq, c->scene.p, nqv, coef, o->dVoff.p + offq * 3, o->losses.p + 3);
@@ -1132,9 +1153,10 @@ int fdcap_opt_backward(fdcap_ctx* c, int32_t ii, int32_t P, int32_t log_terms, v
         hipLaunchKernelGGL(contact_loss_kernel, dim3(256), dim3(256), 0, st, o->dist.p + 2 * nc, (size_t)nl * nc,
                            o->losses.p + 3);
     }
+    const bool joint_grad = lw.world_on || dct_on;
     hipLaunchKernelGGL(pose_bwd_kernel, dim3(nl), dim3(64), 0, st, pm, o->X.p, o->O.p, o->CAM.p, o->scale.p, 2, o->Rm.p,
                        o->Jrest.p, o->G.p, contact_grad ? o->dA.p : nullptr, contact_grad ? o->dPF.p : nullptr,
-                       phase2 ? o->dJw.p : nullptr, contact_grad ? o->dMv.p : nullptr, contact_grad ? o->dsv.p : nullptr,
+                       joint_grad ? o->dJw.p : nullptr, contact_grad ? o->dMv.p : nullptr, contact_grad ? o->dsv.p : nullptr,
                        contact_grad ? o->dbeta_v.p : nullptr, contact_grad ? o->dtransl_v.p : nullptr, o->dX.p, o->dO.p,
                        o->dCAM.p, o->dscale_row.p);
     // VPoser data-gradient: dO -> dH2 -> dH1 -> d latent (accumulated into dX[:, 19:51])
@@ -1145,6 +1167,115 @@ int fdcap_opt_backward(fdcap_ctx* c, int32_t ii, int32_t P, int32_t log_terms, v
     HIP_TRY(gemm_f32(false, EPI_ACCUM, o->dH1.p + 2 * 512, 512, c->W1.p, 32, o->dX.p + 2 * XDIM + X_LATENT, XDIM, nl, 32, 512,
                      nullptr, 0, st));
     hipLaunchKernelGGL(reduce_rows_kernel, dim3(1), dim3(256), 0, st, o->dscale_row.p, 2, nl, o->dscale.p);
+    return (int)hipGetLastError();
+}
+
+int fdcap_opt_backward(fdcap_ctx* c, int32_t ii, int32_t P, int32_t log_terms, void* stream) {
+    if (!c || !c->opt) return FDCAP_E_STATE;
+    const fdcap_opt_config& cf = c->opt->cfg;
+    const bool phase2 = ii >= P;
+    LossWeights lw;
+    lw.rec = 1.f;
+    lw.smooth = phase2 ? cf.phase2_smooth : cf.phase1_smooth;
+    lw.contact = phase2 ? 0.f : cf.phase1_contact;
+    lw.world = phase2 ? cf.phase2_world : 0.f;
+    lw.dct = 0.f;
+    lw.world_on = phase2;
+    return opt_backward_impl(c, lw, log_terms, (hipStream_t)stream);
+}
+
+// ---- mode 'dct' (global_optimization.py:595-630) -----------------------------------------------
+int fdcap_opt_set_dct(fdcap_ctx* c, const float* dct_mtx, int32_t T, int32_t C, const float* c_dct_d, void* stream) {
+    if (!c || !c->opt || !dct_mtx || !c_dct_d || T <= 0 || T > DCT_MAXT || C <= 0 || C > DCT_MAXC) return FDCAP_E_ARG;
+    OptState* o = c->opt;
+    const int W = o->cfg.n_total / T;
+    if (W <= 0) return FDCAP_E_ARG;
+    hipStream_t st = (hipStream_t)stream;
+    const size_t n = (size_t)W * 69 * C;
+    HIP_TRY(o->dctD.upload(dct_mtx, (size_t)T * C));
+    HIP_TRY(o->dctCoef.ensure(n));
+    HIP_TRY(o->dctM.ensure(n));
+    HIP_TRY(o->dctV.ensure(n));
+    HIP_TRY(hipMemcpyAsync(o->dctCoef.p, c_dct_d, n * sizeof(float), hipMemcpyDeviceToDevice, st));
+    HIP_TRY(hipMemsetAsync(o->dctM.p, 0, n * sizeof(float), st));
+    HIP_TRY(hipMemsetAsync(o->dctV.p, 0, n * sizeof(float), st));
+    o->dctT = T; o->dctC = C; o->dctW = W;
+    return FDCAP_OK;
+}
+
+int fdcap_opt_dct_fit(fdcap_ctx* c, int32_t iters, int32_t step0, float weight, float* obj_hist, int32_t log_stride,
+                      void* stream) {
+    if (!c || !c->opt || iters < 0 || step0 < 0 || (obj_hist && log_stride <= 0)) return FDCAP_E_ARG;
+    OptState* o = c->opt;
+    if (o->dctW <= 0) return FDCAP_E_STATE;
+    hipStream_t st = (hipStream_t)stream;
+    const fdcap_opt_config& cf = o->cfg;
+    const int T = o->dctT, R = o->R;
+    // windows that lie completely inside this rank's frames (the caller shards on window boundaries)
+    const int w0 = (cf.frame0 + T - 1) / T;
+    const int w1 = std::min((cf.frame0 + cf.n_local) / T, o->dctW);
+    if (iters == 0 || w1 <= w0) return FDCAP_OK;
+    int e = vposer_forward(c, o->X.p, XDIM, X_LATENT, R, o->H1.p, o->H2.p, o->O.p, st);
+    if (e) return e;
+    hipLaunchKernelGGL(pose_fwd_kernel, dim3(R), dim3(64), 0, st, c->pose_model(), o->X.p, o->O.p, o->CAM.p, o->scale.p, 0,
+                       o->Rm.p, o->PF.p, o->Jrest.p, o->G.p, o->A.p, o->M.p, o->Jw.p, (const float*)nullptr);
+    o->adam_tab_h.resize(iters);
+    for (int i = 0; i < iters; ++i) o->adam_tab_h[i] = adam_scalars(cf.lr, step0 + i + 1);
+    HIP_TRY(o->adam_tab.ensure(iters));
+    HIP_TRY(hipMemcpyAsync(o->adam_tab.p, o->adam_tab_h.data(), (size_t)iters * sizeof(AdamScalars), hipMemcpyHostToDevice, st));
+    hipLaunchKernelGGL(dct_fit_kernel, dim3((w1 - w0) * 69), dim3(64), 0, st, o->Jw.p, 2 + (w0 * T - cf.frame0), T, o->dctC,
+                       o->dctD.p, o->dctCoef.p, o->dctM.p, o->dctV.p, w0, o->adam_tab.p, iters,
+                       weight / (69.f * (float)o->dctW), obj_hist, log_stride > 0 ? log_stride : 1);
+    return (int)hipGetLastError();
+}
+
+int fdcap_opt_backward_dct(fdcap_ctx* c, float w_dct, float w_rec, float w_contact, int32_t log_terms, void* stream) {
+    if (!c || !c->opt) return FDCAP_E_STATE;
+    if (c->opt->dctW <= 0) return FDCAP_E_STATE;
+    LossWeights lw;
+    lw.rec = w_rec; lw.smooth = 0.f; lw.contact = w_contact; lw.world = 0.f; lw.dct = w_dct; lw.world_on = false;
+    return opt_backward_impl(c, lw, log_terms, (hipStream_t)stream);
+}
+
+int fdcap_opt_get_dct(fdcap_ctx* c, float* c_dct_d, void* stream) {
+    if (!c || !c->opt || !c_dct_d) return FDCAP_E_ARG;
+    OptState* o = c->opt;
+    if (o->dctW <= 0) return FDCAP_E_STATE;
+    HIP_TRY(hipMemcpyAsync(c_dct_d, o->dctCoef.p, (size_t)o->dctW * 69 * o->dctC * sizeof(float), hipMemcpyDeviceToDevice,
+                           (hipStream_t)stream));
+    return FDCAP_OK;
+}
+int32_t fdcap_opt_dct_windows(fdcap_ctx* c, int32_t* w0, int32_t* w1) {
+    if (!c || !c->opt || c->opt->dctW <= 0) return 0;
+    const fdcap_opt_config& cf = c->opt->cfg;
+    const int T = c->opt->dctT;
+    int a = (cf.frame0 + T - 1) / T, b = std::min((cf.frame0 + cf.n_local) / T, c->opt->dctW);
+    if (w0) *w0 = a;
+    if (w1) *w1 = std::max(a, b);
+    return c->opt->dctW;
+}
+
+// ---- optimization.py: the per-frame smoother (:185-238, :334-348) ------------------------------
+int fdcap_frame_smoother(fdcap_ctx* c, const float* data78, int32_t N, int32_t iters, float lr, float w_rec, float w_vposer,
+                         float w_prev, float* state, int32_t step0, int32_t has_prev, float* out78, void* stream) {
+    if (!data78 || !out78 || N <= 0 || iters <= 0 || step0 < 0 || ((step0 > 0 || has_prev) && !state)) return FDCAP_E_ARG;
+    hipStream_t st = (hipStream_t)stream;
+    const size_t n = (size_t)N * iters;
+    std::vector<AdamScalars> local_h;
+    std::vector<AdamScalars>& tab_h = c ? c->ws_adam_h : local_h;
+    tab_h.resize(n);
+    for (size_t i = 0; i < n; ++i) tab_h[i] = adam_scalars(lr, step0 + (int)(i + 1));
+    DevBuf<AdamScalars> local_d;
+    DevBuf<AdamScalars>& tab_d = c ? c->ws_adam : local_d;      // ctx == NULL: a temporary, released after a stream sync
+    HIP_TRY(tab_d.ensure(n));
+    HIP_TRY(hipMemcpyAsync(tab_d.p, tab_h.data(), n * sizeof(AdamScalars), hipMemcpyHostToDevice, st));
+    hipLaunchKernelGGL(frame_smoother_kernel, dim3(1), dim3(128), 0, st, data78, N, iters, tab_d.p,
+                       smoother_weights(w_rec, w_vposer, w_prev), state, (step0 > 0 || has_prev) ? 1 : 0, has_prev ? 1 : 0, out78);
+    if (!c) {
+        hipError_t e_ = hipStreamSynchronize(st);
+        local_d.release();
+        if (e_ != hipSuccess) return (int)e_;
+    }
     return (int)hipGetLastError();
 }
 
@@ -1160,7 +1291,7 @@ static int opt_step_impl(fdcap_ctx* c, int32_t ii, int32_t P, bool do_rows, bool
         hipLaunchKernelGGL(adam_kernel, dim3((nx + 255) / 256), dim3(256), 0, st, o->X.p + 2 * XDIM, o->mX.p + 2 * XDIM,
                            o->vX.p + 2 * XDIM, o->dX.p + 2 * XDIM, nx, adam_scalars(cf.lr, ii + 1), 0);
     // scale: receives a gradient while ii < P (and only if the contact term exists)
-    if (do_scale && o->contact_on && (ii < P || cf.legacy_zero_grad))
+    if (do_scale && (o->contact_on || o->dct_grad) && (ii < P || cf.legacy_zero_grad))
         hipLaunchKernelGGL(adam_kernel, dim3(1), dim3(64), 0, st, o->scale.p, o->mS.p, o->vS.p, o->dscale.p, (size_t)1,
                            adam_scalars(cf.lr, ii + 1), ii < P ? 0 : 1);
     // camera_ext: first gradient at ii = P + 1 (flag flips after the forward of ii = P)

@@ -25,6 +25,13 @@ PHASE2_WORLD = 1.0
 PHASE2_SMOOTH = 0.5
 SCALE_INIT = 1.8
 OUTLIER_FACTOR = 1.8
+# mode 'dct' (:41-45, :595-630)
+BATCH_FRAME_NUM = 60            # frames per DCT window (:41)
+DCT_NUM = 5                     # coefficients per trajectory (:43)
+DCT_NUM_ITER = 10000            # forced inside fitting() (:596)
+DCT_PHASE_SPLIT = 0.95          # (:601)
+DCT_PHASE1_WEIGHT = 10.0        # loss = loss_dct*10 (:607)
+DCT_PHASE2 = (0.0001, 0.5, 0.1)  # loss_dct, loss_rec, loss_contact (:620)
 
 DEFAULT_FITTINGCONFIG = {
     "scene_verts_path": None, "camera_path": None, "human_model_path": "./models",
@@ -75,10 +82,14 @@ class FitLog:
 
 class FittingOP:
     def __init__(self, fittingconfig, lossconfig, num_body, body_model=None, vposer=None, scene_verts=None,
-                 contact_ids=None, camera_ext=None, group=None, legacy_zero_grad=False, n_left=None):
+                 contact_ids=None, camera_ext=None, group=None, legacy_zero_grad=False, n_left=None,
+                 dct_mtx=None, c_dct_init=None, dct_num_iter=DCT_NUM_ITER):
         """`body_model` / `vposer`: objects with the SMPL-X npz / VPoser state-dict arrays
         (synth.BodyModelData / synth.VPoserData or assets.load_*).  `scene_verts`, `contact_ids`,
         `camera_ext` override the paths in `fittingconfig` when given (synthetic runs).
+        `dct_mtx` [60,5]: load_dct_base() (:131-136; default: `fittingconfig['dct_mat_path']` if that .mat
+        exists, else the orthonormal DCT-II basis); `c_dct_init` [N//60,23,3,5]: start of c_dct (the
+        reference draws torch.randn, :186 -- so does the default); `dct_num_iter`: the 10000 of :596.
         `group`: torch.distributed process group for frame sharding (None = single GPU);
         `num_body` is the clip length N (the reference's batch_size = num_body, :152)."""
         import torch
@@ -118,6 +129,10 @@ class FittingOP:
         self._camera_ext_init = None if camera_ext is None else np.asarray(camera_ext, np.float32).reshape(-1, 4, 4)
         self.shard = FrameShard(self.num_body, group)
         self.group = group
+        self.dct_mtx = None if dct_mtx is None else np.ascontiguousarray(dct_mtx, dtype=np.float32)
+        self._c_dct_init = c_dct_init
+        self.dct_num_iter = int(dct_num_iter)
+        self.c_dct = None
         self.scale = None
         self.camera_ext = None
         self.body_rotation_rec = None
@@ -180,8 +195,8 @@ class FittingOP:
         Returns (body_rec [N_local,75] device tensor, scale numpy scalar, camera_ext [N_local,4,4])
         -- the whole clip when not sharded, exactly the reference's triple (:635)."""
         import torch
-        if mode not in ("global", "local"):
-            raise NotImplementedError("modes 'global' and 'local' are on the accelerated path ('dct' is a SURVEY.md §8f next row)")
+        if mode not in ("global", "local", "dct"):
+            raise ValueError("mode must be 'local', 'global' or 'dct' (global_optimization.py:660)")
         self._mode = mode
         lib, h = self.ctx.lib, self.ctx.handle
         dev = self.device
@@ -198,7 +213,9 @@ class FittingOP:
         P = first_phase2_iter(self.num_iter)
         log = FitLog([], [], [], [], [], [], [])
         multi = self.shard.world > 1
-        for ii in range(self.num_iter):                                                     # :560
+        if mode == "dct":
+            self._dct_loops(lib, h, multi, log_every)
+        for ii in range(self.num_iter if mode != "dct" else 0):                             # :560
             do_log = bool(log_every) and (ii % log_every == 0 or ii == self.num_iter - 1)
             st = capi.current_stream()
             capi.check(lib.fdcap_opt_backward(h, ii, P, 1 if do_log else 0, st), "fdcap_opt_backward")
@@ -228,6 +245,98 @@ class FittingOP:
         self.body_rotation_rec = self._rows_x[2:2 + nl]
         self.log = log
         return body_rec, scale.detach().cpu().numpy().squeeze(), self.camera_ext
+
+    # ---- :595-630 -------------------------------------------------------------------------
+    def _dct_loops(self, lib, h, multi, log_every):
+        """mode 'dct'.  First 95 % of the iterations: only c_dct moves (loss_dct*10, :601-607) against frozen
+        joint trajectories -- ONE launch; iteration ceil(0.95*num_iter) is a no-op (every leaf's flag was
+        flipped after its forward, :615-618, so nothing receives a gradient); the rest optimise
+        body_rotation_rec + scale with loss_dct*1e-4 + loss_rec*0.5 + loss_contact*0.1 (:620)."""
+        import torch
+        if self.legacy_zero_grad:
+            raise NotImplementedError("mode 'dct' reproduces torch >= 2 zero_grad semantics only")
+        N, T, dev = self.num_body, BATCH_FRAME_NUM, self.device
+        W = N // T
+        if W < 1:
+            raise capi.FdcapError(f"mode 'dct' needs at least one {T}-frame window (:41-42); clip has {N} frames")
+        sh = self.shard
+        if multi and any(sh.bounds(r)[0] % T for r in range(sh.world)):
+            raise capi.FdcapError(f"mode 'dct': frame shards must start on {T}-frame window boundaries "
+                                  f"(N={N}, world={sh.world})")
+        if self.dct_mtx is None:
+            self.dct_mtx = io.load_dct_base(getattr(self, "dct_mat_path", None), T, DCT_NUM)
+        D = np.ascontiguousarray(self.dct_mtx, np.float32)
+        C = D.shape[1]
+        c0 = self._c_dct_init
+        c0 = torch.randn(W, 23, 3, C) if c0 is None else torch.as_tensor(np.asarray(c0, dtype=np.float32))
+        if tuple(c0.shape) != (W, 23, 3, C):
+            raise capi.FdcapError(f"c_dct_init must be [{W},23,3,{C}], got {tuple(c0.shape)}")
+        c0 = c0.to(dev, torch.float32).contiguous()
+        st = capi.current_stream()
+        import ctypes
+        capi.check(lib.fdcap_opt_set_dct(h, D.ctypes.data_as(ctypes.c_void_p), D.shape[0], C, capi.dptr(c0), st),
+                   "fdcap_opt_set_dct")
+        num_iter = self.dct_num_iter
+        P = int(math.ceil(num_iter * DCT_PHASE_SPLIT - 1e-9))           # first ii with not (ii < num_iter*0.95)
+        w0, w1 = ctypes.c_int32(), ctypes.c_int32()
+        lib.fdcap_opt_dct_windows(h, ctypes.byref(w0), ctypes.byref(w1))
+        ntraj = 69 * (w1.value - w0.value)
+        hist = None
+        if log_every and ntraj and P:
+            hist = torch.zeros((P + log_every - 1) // log_every, ntraj, device=dev)
+        capi.check(lib.fdcap_opt_dct_fit(h, P, 0, DCT_PHASE1_WEIGHT, capi.dptr(hist), max(int(log_every), 1), st),
+                   "fdcap_opt_dct_fit")
+        self.log_dct = []
+        if hist is not None:
+            part = hist.sum(dim=1, dtype=torch.float64)
+            if multi:
+                allreduce_scalars(sh, torch.zeros(1, device=dev), part)
+            self.log_dct = [[k * log_every, float(v) / (69 * W)] for k, v in enumerate(part.cpu().numpy())]
+        if multi:                                              # every rank ends up with all windows' coefficients
+            import torch.distributed as dist
+            full = torch.zeros(W, 69 * C, device=dev)
+            capi.check(lib.fdcap_opt_get_dct(h, capi.dptr(full), st), "fdcap_opt_get_dct")
+            own = torch.zeros_like(full)
+            own[w0.value:w1.value] = full[w0.value:w1.value]
+            if dist.get_backend(self.group) == "gloo":
+                t = own.cpu(); dist.all_reduce(t, group=self.group); own = t.to(dev)
+            else:
+                dist.all_reduce(own, group=self.group)
+            capi.check(lib.fdcap_opt_set_dct(h, D.ctypes.data_as(ctypes.c_void_p), D.shape[0], C, capi.dptr(own.contiguous()), st),
+                       "fdcap_opt_set_dct")
+        BIG = 2 ** 30
+        wd, wr, wc = DCT_PHASE2
+        self.log2 = []
+        for k in range(max(num_iter - P - 1, 0)):              # ii = P + 1 + k; Adam step counters k + 1
+            ii = P + 1 + k
+            do_log = bool(log_every) and (ii % log_every == 0 or ii == num_iter - 1)
+            st = capi.current_stream()
+            capi.check(lib.fdcap_opt_backward_dct(h, wd, wr, wc, 1 if do_log else 0, st), "fdcap_opt_backward_dct")
+            if do_log:
+                s = self._losses.clone()
+                if multi:
+                    allreduce_scalars(sh, torch.zeros(1, device=dev), s)
+                s = s.cpu().numpy()
+                nc = max(self.ctx.num_contact, 1)
+                l_rec = self.weight_loss_rec * s[0] / (N * capi.XDIM)
+                l_vp = self.weight_loss_vposer * s[1] / (N * 32)
+                l_sm = s[2] / ((N - 2) * capi.XDIM) if N >= 3 else float("nan")
+                l_con = self.weight_contact * s[3] / (N * nc)
+                l_dct = s[7] / (69 * W)
+                self.log2.append([ii, l_rec, l_vp, l_sm, l_con, l_dct, wd * l_dct + wr * l_rec + wc * l_con])
+                if self.verbose and sh.rank == 0:
+                    print('[INFO][fitting] iter={:d}, l_rec={:f}, l_vposer={:f}, loss_smoothing={:f}, loss_contact={:f}, '
+                          'loss_dct={:f}, total_loss={:f}'.format(*self.log2[-1]))
+            if multi:
+                capi.check(lib.fdcap_opt_step_rows_and_pack(h, k, BIG, capi.dptr(self._xch_send), st), "step_rows_and_pack")
+                allgather_packed(sh, self._xch_send, self._xch_all)
+                capi.check(lib.fdcap_opt_unpack_and_step_scale(h, k, BIG, capi.dptr(self._xch_all), sh.rank, sh.world, st),
+                           "unpack_and_step_scale")
+            else:
+                capi.check(lib.fdcap_opt_step(h, k, BIG, st), "fdcap_opt_step")
+        cd = torch.empty(W, 23, 3, C, device=dev)
+        capi.check(lib.fdcap_opt_get_dct(h, capi.dptr(cd), capi.current_stream()), "fdcap_opt_get_dct")
+        self.c_dct = cd
 
     def _local_second_loop(self, lib, h, multi, log_every):
         """detect_contact + the cal_loss2 loop of mode 'local' (:534-556)."""

@@ -44,6 +44,22 @@ def load_body_gen(body_path: str) -> np.ndarray:
     return np.vstack(rows).astype(np.float32)
 
 
+def load_dct_base(mat_path=None, num_frames: int = 60, num_coef: int = 5) -> np.ndarray:
+    """global_optimization.py:131-136: `loadmat(DCT_MAT_PATH)['D'][:DCT_NUM].T` -> [60,5].  The .mat
+    (../Data/DCT_Basis/60.mat, :45) is not part of the repository; without it the orthonormal DCT-II
+    basis of the same shape is generated (row k = sqrt((1 or 2)/T) cos(pi (n + 1/2) k / T))."""
+    if mat_path and os.path.exists(mat_path):
+        import scipy.io as sio
+        mtx = sio.loadmat(mat_path, squeeze_me=True, struct_as_record=False)["D"]
+        return np.ascontiguousarray(np.array(mtx[:num_coef]).T, dtype=np.float32)
+    n = np.arange(num_frames)
+    D = np.zeros((num_coef, num_frames))
+    for k in range(num_coef):
+        a = np.sqrt(1.0 / num_frames) if k == 0 else np.sqrt(2.0 / num_frames)
+        D[k] = a * np.cos(np.pi * (n + 0.5) * k / num_frames)
+    return np.ascontiguousarray(D.T, dtype=np.float32)
+
+
 def body_params_encapsulate(body_rec: np.ndarray, scale, camera_ext: np.ndarray) -> list:
     """The 3-argument form save_result calls (:644) but cvae.py never defines; the 1-argument
     version (cvae.py:189-208) gives the slicing, the consumers give the two extra keys."""

@@ -181,6 +181,48 @@ int fdcap_opt_backward_local2(fdcap_ctx* ctx, const float* contact_weight_d, int
 /* Adam on body_rotation_rec only, with its running step count `step` (continues after the first loop). */
 int fdcap_opt_step_x(fdcap_ctx* ctx, int32_t step, void* stream);
 
+/* ---- mode 'dct' (global_optimization.py:595-630) ---------------------------------
+ * cal_dctloss (:232-246) over W = n_total / T windows of T frames (reference: 5 x 60, :41-42) and the 23
+ * world joints x 3 axes; c_dct [W,23,3,C] and its Adam moments are library-owned.
+ * fdcap_opt_set_dct: dct_mtx HOST [T,C] (= load_dct_base(), :131-136; T <= 64, C <= 8), c_dct_d DEVICE
+ * [W,23,3,C] initial coefficients (the reference draws them with torch.randn, :186).  After fdcap_opt_create. */
+int fdcap_opt_set_dct(fdcap_ctx* ctx, const float* dct_mtx, int32_t T, int32_t C, const float* c_dct_d, void* stream);
+/* The first phase of the loop (:601-613): body_rotation_rec / scale / camera_ext are frozen, loss =
+ * weight * loss_dct (weight = 10, :607), so `iters` Adam iterations on c_dct (step counters step0+1 ...)
+ * run in one launch against the fixed world-joint trajectories of the current state.  Only windows that
+ * lie inside this rank's frames are fitted.  obj_hist_d (optional) [ceil(iters/log_stride), 69*(w1-w0)]:
+ * each fitted trajectory's objective (sum over the window of e/(e+1)) before the update of iterations
+ * 0, log_stride, 2*log_stride ... */
+int fdcap_opt_dct_fit(fdcap_ctx* ctx, int32_t iters, int32_t step0, float weight, float* obj_hist_d,
+                      int32_t log_stride, void* stream);
+/* The second phase (:614-626): zero_grad + cal_loss + backward of
+ *   loss = w_dct * loss_dct + w_rec * loss_rec + w_contact * loss_contact   (1e-4, 0.5, 0.1 at :620);
+ * body_rotation_rec and scale get gradients, c_dct / camera_ext do not.  Step with fdcap_opt_step(ctx, k,
+ * INT32_MAX, ...) (k = 0, 1, ...: both Adam step counters start at 1 here) or the multi-GPU pair below.
+ * losses_d afterwards: [0] [1] [3] as fdcap_opt_backward, [7] = un-normalised sum of e/(e+1) over this
+ * rank's frames (loss_dct = sum / (69 W)). */
+int fdcap_opt_backward_dct(fdcap_ctx* ctx, float w_dct, float w_rec, float w_contact, int32_t log_terms, void* stream);
+/* c_dct_d [W,23,3,C] <- current coefficients (a sharded caller merges the windows each rank fitted). */
+int fdcap_opt_get_dct(fdcap_ctx* ctx, float* c_dct_d, void* stream);
+/* Returns W; *w0 / *w1 = first / one-past-last window this rank fits (0 when fdcap_opt_set_dct has not run). */
+int32_t fdcap_opt_dct_windows(fdcap_ctx* ctx, int32_t* w0, int32_t* w1);
+
+/* ---- optimization.py: the per-frame smoother (:185-238, driver loop :334-348) -------
+ * data78_d [N,78] = convert_to_6D_rot of the SMPLify-X rows in file order; for every frame `iters` (50, :313)
+ * Adam iterations (lr 0.1, :312) on one 78-d row started at the data row, with
+ *   loss = w_rec * L1(data, x) + w_vposer * mean(x[19:51]^2) [+ w_prev * L1(previous result[9:51], x[9:51])]
+ * (1, 0.001, 5: :197, :227, :323-324); frame 0 has no previous-frame term (:185-208).  torch's optimiser
+ * object is created once (:126), so Adam's moments and step counter carry over from frame to frame -- kept.
+ * out78_d [N,78]: the optimised rows (fdcap_params_78_to_75 gives the saved layout, :206, :236).
+ * state_d (optional) DEVICE [3,78] = Adam m | v | previous frame's result: read when step0 > 0 or has_prev,
+ * always written, so a caller can go file by file like the reference's driver; step0 = Adam steps taken so
+ * far (frames done x iters), has_prev = the first row of this call has a predecessor.  `ctx` only lends a
+ * workspace and may be NULL (the body model plays no part, although the reference loads it, :106-123); the
+ * call then synchronises `stream` before it returns. */
+int fdcap_frame_smoother(fdcap_ctx* ctx, const float* data78_d, int32_t N, int32_t iters, float lr, float w_rec,
+                         float w_vposer, float w_prev, float* state_d, int32_t step0, int32_t has_prev,
+                         float* out78_d, void* stream);
+
 /* Multi-GPU iteration tail with ONE collective per iteration (instead of an all-reduce before the
  * step and point-to-point halo messages after it):
  *   fdcap_opt_step_rows_and_pack : Adam on body_rotation_rec / camera_ext of the owned rows, then writes

@@ -2,13 +2,15 @@
 
 TEST INFRASTRUCTURE (see oracle/__init__.py).  Follows /root/reference/global_optimization.py:
   qvec2rotmat :51-61 · extract_ext :208-230 · body2world :191-206 · verts_transform :119-127 ·
-  cal_loss :249-312 · init :450-489 · fitting('global') :558-593 · return :632-635.
+  cal_loss :249-312 · init :450-489 · fitting('global') :558-593 · return :632-635 ·
+  cal_dctloss :232-246 · fitting('dct') :595-630.
 Pinned by tests/golden/*.npz, which the reference's own code produced (tests/golden/make_golden.py).
 
 Deliberate deviations (all no-ops at the reference's N=300):
   * clip length N is free: `avg = sum/300.0` (:465) -> `sum/N`, `np.ones(300)` (:472) -> N;
   * an empty outlier set is allowed (the reference raises IndexError, SURVEY.md fact 7);
-  * `cal_dctloss` (:232-246, :310) is not evaluated: its value never enters a 'global' total;
+  * `cal_dctloss` (:232-246, :310) is evaluated only in mode 'dct': its value never enters a 'global' or
+    'local' total; its windows generalise from 5 x 60 frames (:41-42) to N // 60 windows of 60 frames;
   * Ns == 0 / weight_contact == 0 skips the Chamfer term (BASELINE config 1).
 """
 import numpy as np
@@ -83,7 +85,7 @@ class FittingOracle:
     def __init__(self, body_model, vposer, scene_verts, contact_vid, camerapose_lines, num_body,
                  init_lr_h=0.005, num_iter=500, weight_loss_rec=1.0, weight_loss_vposer=0.001,
                  weight_contact=0.1, dtype=torch.float32, legacy_zero_grad=False,
-                 one_direction_chamfer=True, phase_split=0.8):
+                 one_direction_chamfer=True, phase_split=0.8, dct_mtx=None, c_dct_init=None):
         self.dtype = dtype
         self.body_mesh_model = body_model
         self.vposer = vposer
@@ -104,8 +106,13 @@ class FittingOracle:
         self.scale = torch.tensor(1.8, dtype=dtype, requires_grad=True)                 # :179
         self.body_rotation_rec = torch.zeros(num_body, 78, dtype=dtype, requires_grad=True)
         self.camera_ext = torch.zeros(num_body, 4, 4, dtype=dtype, requires_grad=True)  # :182
-        self.optimizer = torch.optim.Adam([self.body_rotation_rec, self.scale, self.camera_ext],
-                                          lr=init_lr_h)                                 # :188
+        params = [self.body_rotation_rec, self.scale, self.camera_ext]
+        self.dct_mtx = self.c_dct = None
+        if dct_mtx is not None:                                                         # :184-186
+            self.dct_mtx = torch.as_tensor(dct_mtx).to(dtype)                           # [60, 5]
+            self.c_dct = torch.as_tensor(c_dct_init).to(dtype).clone().requires_grad_(True)   # [W, 23, 3, 5]
+            params.append(self.c_dct)
+        self.optimizer = torch.optim.Adam(params, lr=init_lr_h)                         # :188
         self.loss_log = []
 
     # :191-206 (the per-frame Python loop builds exactly this matrix)
@@ -149,6 +156,69 @@ class FittingOracle:
             loss_contact = torch.zeros((), dtype=self.dtype)
         loss_world_smoothing = torch.mean(torch.abs(joints[0:-1] - joints[1:]))            # :304
         return loss_rec, loss_vposer, loss_contact, loss_smoothing, loss_world_smoothing
+
+    def cal_dctloss(self, joints):
+        """:232-246.  One objective per (joint i, axis j, window k): sum over the window's frames of the
+        Geman-McClure residual e/(e+1), e = (trajectory - dct_mtx @ c_dct[k,i,j])^2; mean over objectives."""
+        T = self.dct_mtx.shape[0]
+        W = self.c_dct.shape[0]
+        traj = joints[:T * W].reshape(W, T, 23, 3)
+        pred = torch.einsum("tc,kijc->ktij", self.dct_mtx, self.c_dct)
+        err = (traj - pred) ** 2
+        return torch.mean(torch.sum(err / (err + 1.0), dim=1))
+
+    def step_dct(self, ii, body_data_rotation, idx1):
+        """One pass of the :597-630 loop body (torch >= 2 zero_grad semantics)."""
+        self.optimizer.zero_grad(set_to_none=True)
+        frozen = not (self.body_rotation_rec.requires_grad or self.scale.requires_grad or self.camera_ext.requires_grad)
+        if frozen and getattr(self, "_dct_cache", None) is not None:
+            # the body / scale / camera leaves are frozen (flags of the previous iteration), so this forward
+            # repeats the previous one value for value: reuse it (test-speed only, no arithmetic change)
+            l_rec, l_vp, l_sm, l_con, joints = self._dct_cache
+        else:
+            weights = torch.ones(body_data_rotation.size(), dtype=self.dtype)
+            weights[idx1, :] = 0.0
+            l_rec = self.weight_loss_rec * torch.mean(torch.abs(body_data_rotation - self.body_rotation_rec) * weights)
+            body_rec, verts, joints = self.forward_world()
+            l_vp = self.weight_loss_vposer * torch.mean(body_rec[:, 16:48] ** 2)
+            diff = self.body_rotation_rec[0:-1, :] - self.body_rotation_rec[1:, :]
+            l_sm = torch.mean(torch.abs(diff[0:-1, :] - diff[1:, :]))
+            if self.s_verts_batch is not None and self.weight_contact != 0.0:
+                d, _ = chamferDist(self.one_direction_chamfer)(verts[:, self.vid, :].contiguous(), self.s_verts_batch)
+                r = torch.sqrt(d + 1e-4)
+                l_con = self.weight_contact * torch.mean(r / (r + 1.0))
+            else:
+                l_con = torch.zeros((), dtype=self.dtype)
+            self._dct_cache = tuple(v.detach() for v in (l_rec, l_vp, l_sm, l_con, joints)) if frozen else None
+        l_dct = self.cal_dctloss(joints)                                                   # :310
+        if ii < self.num_iter * 0.95:                                                      # :601
+            self.camera_ext.requires_grad = False
+            self.scale.requires_grad = False
+            self.body_rotation_rec.requires_grad = False
+            self.c_dct.requires_grad = True
+            loss = l_dct * 10                                                              # :607
+        else:
+            self.camera_ext.requires_grad = False
+            self.scale.requires_grad = True
+            self.body_rotation_rec.requires_grad = True
+            self.c_dct.requires_grad = False
+            loss = l_dct * 0.0001 + l_rec * 0.5 + l_con * 0.1                              # :620
+        self.loss_log.append([float(v.detach()) for v in (l_rec, l_vp, l_sm, l_con, l_dct, loss)])
+        if loss.requires_grad:
+            loss.backward()
+        self.optimizer.step()
+
+    def fitting_dct(self, body_data, num_iter=10000):
+        """mode='dct' (:595-630): the reference forces num_iter = 10000 (:596)."""
+        self.num_iter = num_iter
+        body_data_rotation = rotrepr.convert_to_6D_rot(torch.as_tensor(body_data).to(self.dtype))
+        idx1 = self.init(body_data_rotation)
+        body_data_rotation = body_data_rotation.detach()
+        self.idx1 = idx1
+        for ii in range(self.num_iter):
+            self.step_dct(ii, body_data_rotation, idx1)
+        body_rec = rotrepr.convert_to_3D_rot(self.body_rotation_rec)
+        return body_rec.detach(), self.scale.detach().cpu().numpy().squeeze(), self.camera_ext.detach()
 
     def init(self, body_data_rotation):
         self.body_rotation_rec.data = body_data_rotation.clone()                           # :454

@@ -8,6 +8,7 @@
 
 #include <vector>
 
+#include "../../4dcapture-fpv_amd/csrc/fdc_dct.h"
 #include "../../4dcapture-fpv_amd/csrc/fdc_frame.h"
 #include "../../4dcapture-fpv_amd/csrc/fdc_host_setup.h"
 #include "../../4dcapture-fpv_amd/csrc/fdc_loss.h"
@@ -191,6 +192,61 @@ void h_78_to_75(const float* in, int B, float* out) {
         p[3] = aa.x; p[4] = aa.y; p[5] = aa.z;
         for (int i = 9; i < XDIM; ++i) p[i - 3] = x[i];
     }
+}
+
+// frame_smoother_kernel with the element threads run serially
+void h_frame_smoother(const float* data78, int N, int iters, double lr, float w_rec, float w_vposer, float w_prev,
+                      float* out78) {
+    SmootherWeights w = smoother_weights(w_rec, w_vposer, w_prev);
+    for (int e = 0; e < 78; ++e) {
+        float m = 0.f, v = 0.f, prev = 0.f;
+        for (int f = 0; f < N; ++f) {
+            const float xd = data78[(size_t)f * 78 + e];
+            float x = xd;
+            for (int it = 0; it < iters; ++it)
+                adam_update(x, m, v, smoother_grad(e, x, xd, prev, f > 0, w), adam_scalars(lr, f * iters + it + 1));
+            out78[(size_t)f * 78 + e] = x;
+            prev = x;
+        }
+    }
+}
+
+// dct_fit_kernel for one trajectory with the lane sums run serially (frame-ascending)
+void h_dct_fit(const float* traj, int T, int C, const float* D, float* coef, float* m, float* v, int iters, int step0,
+               double lr, float w_over_cnt, float* obj_hist) {
+    for (int it = 0; it < iters; ++it) {
+        float g[DCT_MAXC] = {0}, osum = 0.f;
+        for (int f = 0; f < T; ++f) {
+            float p = 0.f;
+            for (int c = 0; c < C; ++c) p += D[f * C + c] * coef[c];
+            float obj;
+            float gp = dct_residual(traj[f], p, &obj) * w_over_cnt;
+            osum += obj;
+            for (int c = 0; c < C; ++c) g[c] += D[f * C + c] * gp;
+        }
+        if (obj_hist) obj_hist[it] = osum;
+        AdamScalars a = adam_scalars(lr, step0 + it + 1);
+        for (int c = 0; c < C; ++c) adam_update(coef[c], m[c], v[c], g[c], a);
+    }
+}
+
+// dct_joint_grad_kernel: dJw [n,69] and the un-normalised objective sum
+double h_dct_joint_grad(const float* Jw, int n, int T, int C, int W, const float* D, const float* coef, float w_over_cnt,
+                        float* dJw) {
+    double sum = 0.0;
+    for (int i = 0; i < n * 69; ++i) {
+        int g = i / 69, ij = i % 69, k = g / T, f = g % T;
+        float grad = 0.f, obj = 0.f;
+        if (k < W) {
+            const float* c = coef + ((size_t)k * 69 + ij) * C;
+            float p = 0.f;
+            for (int q = 0; q < C; ++q) p += D[f * C + q] * c[q];
+            grad = -dct_residual(Jw[i], p, &obj) * w_over_cnt;
+        }
+        dJw[i] = grad;
+        sum += obj;
+    }
+    return sum;
 }
 
 void h_rotmat_to_aa(const float* R, int n, float* aa) {

@@ -99,6 +99,10 @@ LOG_RE = re.compile(r"iter=(\d+), l_rec=([-\d.e]+), l_vposer=([-\d.e]+), loss_sm
                     r"loss_contact=([-\d.e]+)(?:, loss_world_smoothing=([-\d.e]+))?, total_loss=([-\d.e]+)")
 
 
+LOGD_RE = re.compile(r"iter=(\d+), l_rec=([-\d.e]+), l_vposer=([-\d.e]+), loss_smoothing=([-\d.e]+), "
+                     r"loss_contact=([-\d.e]+), loss_dct=([-\d.e]+), total_loss=([-\d.e]+)")
+
+
 LOG2_RE = re.compile(r"iter=(\d+), l_rec=([-\d.e]+), loss_local_smoothing=([-\d.e]+), loss_smoothing=([-\d.e]+), "
                      r"loss_contact_smoothing=([-\d.e]+), total_loss=([-\d.e]+)")
 
@@ -148,10 +152,28 @@ def run_global(g, num_iter, num_verts, ns, model_seed, vposer_seed, clip_seed, s
 
     vid_ref, _ = g.get_contact_id(seg, ["L_Leg", "R_Leg"])
     body = torch.tensor(clip.body_params, dtype=torch.float32)
+    c_dct0 = f.c_dct.detach().clone().numpy()
     buf = io.StringIO()
+    if mode == "dct":
+        # 10000 iterations (:596): anomaly detection only traces NaNs (no arithmetic effect) and costs 4x
+        torch.autograd.set_detect_anomaly = lambda *a, **k: contextlib.nullcontext()
     with contextlib.redirect_stdout(buf):
         body_rec, scale, camera_ext = f.fitting(body, mode)
     text = buf.getvalue()
+    if mode == "dct":
+        logd = np.array([[float(v) for v in m.groups()] for m in LOGD_RE.finditer(text)], dtype=np.float64)
+        assert logd.shape[0] == 10000, logd.shape
+        keep = np.unique(np.concatenate([np.arange(0, 9400, 50), np.arange(9400, 10000)]))
+        idx_line = text.splitlines()[0]
+        idx1 = np.array([int(t) for t in re.findall(r"\d+", idx_line)], dtype=np.int64)
+        return dict(
+            num_iter=10000, num_verts=num_verts, ns=ns, model_seed=model_seed, vposer_seed=vposer_seed,
+            clip_seed=clip_seed, scene_seed=scene_seed, contact_seed=contact_seed, per_part=per_part,
+            body_in=clip.body_params, camerapose=np.array(clip.camerapose_lines), scene=scene,
+            vid=np.asarray(vid_ref, dtype=np.int64), idx1=idx1, body_rec=body_rec.detach().numpy(),
+            scale=np.float32(scale), camera_ext=camera_ext.detach().numpy(), logd=logd[keep], n_left=np.int64(len(left)),
+            mode=mode, dct_mtx=f.dct_mtx.numpy(), c_dct0=c_dct0, c_dct=f.c_dct.detach().numpy(),
+            sha_posedirs=sha(bm.posedirs), sha_vtemplate=sha(bm.v_template), sha_fc2=sha(vp.fc2_w))
     log = []
     for m in LOG_RE.finditer(text):
         it, rec, vpz, sm, con, ws, tot = m.groups()
@@ -208,8 +230,62 @@ def run_units(g):
     return out
 
 
+def run_smoother(n=12, seed=31):
+    """The reference's optimization.py driver loop (:334-348) on n synthetic SMPLify-X files."""
+    import pickle
+    install_stubs()
+    sys.path.insert(0, REF)
+    cwd = os.getcwd()
+    os.chdir(REF)
+    try:
+        import optimization as opt
+    finally:
+        os.chdir(cwd)
+    clip = synth.make_clip(n, seed=seed, num_outliers=1)
+    keys = ("transl", "global_orient", "betas", "body_pose", "left_hand_pose", "right_hand_pose", "camera_translation")
+    dims = (3, 3, 10, 32, 12, 12, 3)
+    torch.manual_seed(0)
+    f = object.__new__(opt.FittingOP)
+    f.weight_loss_rec, f.weight_loss_vposer, f.num_iter, f.verbose, f.batch_size = 1, 0.001, 50, False, 1
+    f.device = torch.device("cpu")
+    f.xhr_rec = torch.randn(1, 75).requires_grad_(True)                    # :125
+    f.optimizer = torch.optim.Adam([f.xhr_rec], lr=0.1)                    # :126, lr :312
+    outs = []
+    with tempfile.TemporaryDirectory() as tmp, contextlib.redirect_stdout(io.StringIO()):
+        files = []
+        for i in range(n):
+            d, o = {}, 0
+            for k, w in zip(keys, dims):
+                d[k] = clip.body_params[i:i + 1, o:o + w].astype(np.float32)
+                o += w
+            fn = os.path.join(tmp, "%06d.pkl" % i)
+            with open(fn, "wb") as fh:
+                pickle.dump(d, fh)
+            files.append(fn)
+        xh_prev = None
+        for ii, fn in enumerate(files):                                    # :334-348
+            xh_rec = f.fitting(fn) if ii == 0 else f.fitting_smoothing(fn, xh_prev)
+            xh_prev = xh_rec.detach()
+            outs.append(xh_prev.numpy().copy())
+    return dict(body_in=clip.body_params.astype(np.float32), body_out=np.concatenate(outs, 0), num_iter=50, lr=0.1,
+                clip_seed=seed)
+
+
 def main():
+    if "--smoother" in sys.argv:
+        res = run_smoother()
+        np.savez_compressed(os.path.join(HERE, "ref_smoother.npz"), **res)
+        print("wrote ref_smoother", res["body_out"].shape, float(np.abs(res["body_out"] - res["body_in"]).max()))
+        return
     g = import_reference()
+    if "--dct" in sys.argv:            # ~20 min of CPU: the reference's own 10000-iteration 'dct' run
+        torch.set_num_threads(2)
+        with tempfile.TemporaryDirectory() as tmp:
+            res = run_global(g, tmp=tmp, num_iter=10000, num_verts=96, ns=400, model_seed=25, vposer_seed=26,
+                             clip_seed=27, scene_seed=28, contact_seed=29, per_part=6, mode="dct")
+            np.savez_compressed(os.path.join(HERE, "ref_dct_10000it.npz"), **res)
+            print("wrote ref_dct_10000it", "scale", res["scale"], "last log", res["logd"][-1])
+        return
     with tempfile.TemporaryDirectory() as tmp:
         units = run_units(g)
         np.savez_compressed(os.path.join(HERE, "ref_units.npz"), **units)
