@@ -603,6 +603,259 @@ __global__ __launch_bounds__(256) void nn_stream_kernel(const float* __restrict_
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// Streaming variant, four waves per query group (the optimiser's steady-state launch).
+// nn_stream_kernel gives every wave its own 32*NQ queries and the whole survivor list: at shard sizes
+// (64k queries = 1000 waves on 1024 SIMDs) one wave per SIMD walks a serial chain of
+// list-building -> ~10 chunks x 16 dependent global loads with nothing to overlap them.  Here the FOUR
+// waves of a workgroup share one query group and deal the Morton-ordered chunks round-robin (chunk c
+// belongs to wave c & 3): four times the waves, a quarter of the serial chain each, and neighbouring
+// chunks -- which tend to survive together -- spread evenly.  Each wave keeps ST4_PF A fragments in
+// flight (ring of registers, prefetch runs across chunk boundaries), the exact path is a compact
+// bit-mask loop so the 16-tile body unrolls, and the four partial results meet in LDS once at the end,
+// merged by the same (d, index) order => bit-identical results to every other kernel here.
+// blockIdx -> query group is XCD-aware: each XCD serves a contiguous range of groups (frames that follow
+// each other touch the same scene chunks, so an XCD's L2 holds 1/8 of the clip's neighbourhoods).
+constexpr int ST4_MAXLIST = 512;       // survivors one wave can list out of its quarter of the chunks
+constexpr int ST4_PF = 8;              // A fragments in flight per wave
+
+template <int NQ>
+__global__ __launch_bounds__(256) void nn_stream4_kernel(const float* __restrict__ q, int nq, NNTarget T,
+                                                         const int* __restrict__ seed, float* __restrict__ dist,
+                                                         int* __restrict__ idx) {
+    __shared__ unsigned short slist[4][ST4_MAXLIST];
+    __shared__ float s_d[4][32 * NQ];
+    __shared__ int s_i[4][32 * NQ];
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, half = lane >> 5, col = lane & 31;
+    const int ngroups = (nq + 32 * NQ - 1) / (32 * NQ);
+    const int per_xcd = (ngroups + 7) >> 3;
+    const int group = (blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);
+    if (group >= ngroups) return;                               // whole workgroup idle
+    const int wq0 = group * (32 * NQ);
+    const int nchunk = (T.n + MF_CH - 1) / MF_CH;
+    const int myn = (nchunk - wave + 3) >> 2;                   // this wave's chunks: 4 k + wave, k < myn
+#ifdef FDC_NN_STATS
+    unsigned st_cnt[4] = {0, 0, 0, 0};
+#endif
+
+    float qx[NQ], qy[NQ], qz[NQ], own_d[NQ], sb[NQ];
+    int own_i[NQ], own_pos[NQ], qidx[NQ];        // own_pos: position of the current best in T.pts (it passes the filter
+                                                 // by construction and must not cost a global load every time it is met)
+    float sx = 0.f, sy = 0.f, sz = 0.f, sc = 0.f;
+    bool all_seeded = true;
+#pragma unroll
+    for (int n = 0; n < NQ; ++n) {
+        qidx[n] = wq0 + n * 32 + col;
+        const bool ok = qidx[n] < nq;
+        qx[n] = ok ? q[3 * (size_t)qidx[n]] : 0.f;
+        qy[n] = ok ? q[3 * (size_t)qidx[n] + 1] : 0.f;
+        qz[n] = ok ? q[3 * (size_t)qidx[n] + 2] : 0.f;
+        own_d[n] = INFINITY;
+        own_i[n] = -1;
+        own_pos[n] = -1;
+        if (ok) {
+            sx += qx[n]; sy += qy[n]; sz += qz[n]; sc += 1.f;
+            const int sj = seed[qidx[n]];
+            if (sj >= 0 && sj < T.n) {
+                own_pos[n] = T.inv_perm ? T.inv_perm[sj] : sj;
+                const float4 p = T.pts[own_pos[n]];
+                own_d[n] = nn_exact_d2(qx[n], qy[n], qz[n], p.x, p.y, p.z);
+                own_i[n] = sj;
+            } else {
+                all_seeded = false;
+            }
+        }
+        sb[n] = ok ? own_d[n] * 1.00002f + 1e-9f : -INFINITY;   // bound with the rounding slack of the box test
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        sx += __shfl_xor(sx, off, 64); sy += __shfl_xor(sy, off, 64); sz += __shfl_xor(sz, off, 64); sc += __shfl_xor(sc, off, 64);
+    }
+    const float inv = 1.f / fmaxf(sc, 1.f);
+    const float wx = sx * inv, wy = sy * inv, wz = sz * inv;
+    float reach = 0.f;
+#pragma unroll
+    for (int n = 0; n < NQ; ++n)
+        if (qidx[n] < nq) {
+            const float dx = qx[n] - wx, dy = qy[n] - wy, dz = qz[n] - wz;
+            reach = fmaxf(reach, sqrtf(dx * dx + dy * dy + dz * dz) + sqrtf(own_d[n]));
+        }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) reach = fmaxf(reach, __shfl_xor(reach, off, 64));
+    reach = reach * 1.00001f + 1e-6f;
+    const bool cull = __all(all_seeded) && reach < INFINITY;
+
+    // survivor list over this wave's chunks: 64 boxes per round against the group's reach, then per query
+    int nsurv = myn;
+    bool listed = false;
+    if (cull) {
+        nsurv = 0;
+        listed = true;
+        const float r2 = reach * reach;
+        for (int k0 = 0; k0 < myn && listed; k0 += 64) {
+            const int k = k0 + lane;
+            float4 lo = make_float4(0.f, 0.f, 0.f, 0.f), hi = lo;
+            bool near = false;
+            if (k < myn) {
+                lo = T.bounds[2 * (4 * k + wave)];
+                hi = T.bounds[2 * (4 * k + wave) + 1];
+                near = !(box_d2(lo, hi, wx, wy, wz) > r2);
+            }
+            unsigned long long m = __ballot(near);
+            while (m) {                                          // wave-uniform loop over the near chunks of this round
+                const int b = __ffsll((long long)m) - 1;
+                m &= m - 1;
+                float4 blo, bhi;                                 // lane b's box, broadcast
+                blo.x = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(lo.x), b));
+                blo.y = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(lo.y), b));
+                blo.z = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(lo.z), b));
+                bhi.x = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(hi.x), b));
+                bhi.y = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(hi.y), b));
+                bhi.z = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(hi.z), b));
+                bool hit = false;
+#pragma unroll
+                for (int n = 0; n < NQ; ++n) hit |= box_d2(blo, bhi, qx[n], qy[n], qz[n]) <= sb[n];
+                if (__any(hit)) {
+                    if (nsurv >= ST4_MAXLIST) { listed = false; break; }
+                    if (lane == 0) slist[wave][nsurv] = (unsigned short)(k0 + b);
+                    ++nsurv;
+                }
+            }
+        }
+        if (!listed) nsurv = myn;                               // list overflow: scan the whole quarter (still exact)
+    }
+    const f32x16_t zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    constexpr int NT = MF_CH / 32;                               // 16 tiles per chunk (padding rows score 1e30)
+    static_assert(NT == 2 * ST4_PF, "the prefetch ring assumes two ring turns per chunk");
+
+    if (nsurv > 0) {
+        int ch = 4 * (listed ? (int)slist[wave][0] : 0) + wave;
+        const uint4* fr = T.frags + (size_t)ch * NT * 64 + lane;          // [tile][half][col] == [tile][lane]
+        uint4 f[ST4_PF];
+#pragma unroll
+        for (int j = 0; j < ST4_PF; ++j) f[j] = fr[j * 64];
+        for (int s = 0; s < nsurv; ++s) {
+            const int s1 = min(s + 1, nsurv - 1);                          // last survivor: harmless re-fetch of itself
+            const int ch_next = 4 * (listed ? (int)slist[wave][s1] : s1) + wave;
+            const uint4* fr_next = T.frags + (size_t)ch_next * NT * 64 + lane;
+            const float4 cc = T.centers[ch];
+            FDC_STAT(3, lane == 0);
+            // re-centre the queries on the chunk centre
+            bf16x8 bfrag[NQ];
+            float thr[NQ], X[NQ], X2[NQ];
+            const float rc = cc.w;
+#pragma unroll
+            for (int n = 0; n < NQ; ++n) {
+                const float xx = qx[n] - cc.x, xy = qy[n] - cc.y, xz = qz[n] - cc.z;
+                X2[n] = __fmaf_rn(xz, xz, __fmaf_rn(xy, xy, xx * xx));
+                X[n] = sqrtf(X2[n]);
+                const unsigned hx = f2bf(xx), hy = f2bf(xy), hz = f2bf(xz);
+                const unsigned lx = f2bf(xx - bf2f(hx)), ly = f2bf(xy - bf2f(hy)), lz = f2bf(xz - bf2f(hz));
+                const unsigned px = f2bf(-2.f * bf2f(hx)) | (f2bf(-2.f * bf2f(lx)) << 16);
+                const unsigned py = f2bf(-2.f * bf2f(hy)) | (f2bf(-2.f * bf2f(ly)) << 16);
+                const unsigned pz = f2bf(-2.f * bf2f(hz)) | (f2bf(-2.f * bf2f(lz)) << 16);
+                const unsigned one = 0x3F80u;
+                const uint4 u = half == 0 ? make_uint4(px, px, py, py) : make_uint4(pz, pz, one | (one << 16), one);
+                bfrag[n] = __builtin_bit_cast(bf16x8, u);
+                const float sbest = fminf(own_d[n], __shfl_xor(own_d[n], 32, 64));
+                thr[n] = (qidx[n] < nq) ? sbest - X2[n] + (MF_K1 * X[n] * rc + MF_K2 * (X2[n] + rc * rc)) : -INFINITY;
+            }
+            const int base = ch * MF_CH;
+#pragma unroll
+            for (int tile = 0; tile < NT; ++tile) {
+                const bf16x8 afrag = __builtin_bit_cast(bf16x8, f[tile % ST4_PF]);
+                f[tile % ST4_PF] = tile < ST4_PF ? fr[(tile + ST4_PF) * 64] : fr_next[(tile - ST4_PF) * 64];
+                f32x16_t acc_q[NQ];
+#pragma unroll
+                for (int n = 0; n < NQ; ++n) acc_q[n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afrag, bfrag[n], zero, 0, 0, 0);
+#pragma unroll
+                for (int n = 0; n < NQ; ++n) {
+                    const f32x16_t acc = acc_q[n];
+                    const float t0 = fminf(fminf(acc[0], acc[1]), acc[2]), t1 = fminf(fminf(acc[3], acc[4]), acc[5]);
+                    const float t2 = fminf(fminf(acc[6], acc[7]), acc[8]), t3 = fminf(fminf(acc[9], acc[10]), acc[11]);
+                    const float t4 = fminf(fminf(acc[12], acc[13]), acc[14]);
+                    const float m = fminf(fminf(fminf(t0, t1), t2), fminf(fminf(t3, t4), acc[15]));
+                    FDC_STAT(0, lane == 0);
+                    if (__any(m < thr[n])) {
+                        FDC_STAT(1, lane == 0);
+                        unsigned mask = 0;
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) mask |= (acc[r] < thr[n]) ? (1u << r) : 0u;
+                        while (mask) {                                     // rows of this lane that passed the filter
+                            const int r = __ffs(mask) - 1;
+                            mask &= mask - 1;
+                            const int pos = base + tile * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+                            if (pos < T.n && pos != own_pos[n]) {
+                                FDC_STAT(2, 1);
+                                const float4 p = T.pts[pos];
+                                const int gi = __float_as_int(p.w);
+                                const float d = nn_exact_d2(qx[n], qy[n], qz[n], p.x, p.y, p.z);
+                                if (nn_better(d, gi, own_d[n], own_i[n])) { own_d[n] = d; own_i[n] = gi; own_pos[n] = pos; }
+                            }
+                        }
+                        const float sbest = fminf(own_d[n], __shfl_xor(own_d[n], 32, 64));
+                        if (qidx[n] < nq) thr[n] = sbest - X2[n] + (MF_K1 * X[n] * rc + MF_K2 * (X2[n] + rc * rc));
+                    }
+                }
+            }
+            ch = ch_next;
+            fr = fr_next;
+        }
+    }
+    // the two halves of a wave hold different scene rows of the same queries; then the four waves meet in LDS
+#pragma unroll
+    for (int n = 0; n < NQ; ++n) {
+        const float od = __shfl_xor(own_d[n], 32, 64);
+        const int oi = __shfl_xor(own_i[n], 32, 64);
+        if (oi >= 0 && (own_i[n] < 0 || nn_better(od, oi, own_d[n], own_i[n]))) { own_d[n] = od; own_i[n] = oi; }
+        if (half == 0) { s_d[wave][n * 32 + col] = own_d[n]; s_i[wave][n * 32 + col] = own_i[n]; }
+    }
+    __syncthreads();
+#ifdef FDC_NN_STATS
+    for (int i = 0; i < 4; ++i) atomicAdd(&g_nn_stats[i], (unsigned long long)st_cnt[i]);
+#endif
+    if (tid < 32 * NQ && wq0 + tid < nq) {
+        float bd = s_d[0][tid];
+        int bi = s_i[0][tid];
+#pragma unroll
+        for (int w = 1; w < 4; ++w) {
+            const float d = s_d[w][tid];
+            const int i = s_i[w][tid];
+            if (i >= 0 && (bi < 0 || nn_better(d, i, bd, bi))) { bd = d; bi = i; }
+        }
+        dist[wq0 + tid] = bd;
+        idx[wq0 + tid] = bi;
+    }
+}
+
+// Seeds for queries that have none (the first iteration of a fit): any scene point gives a valid upper
+// bound, a good one makes the culled scan cheap.  Thread per query: nearest chunk box (all boxes, read
+// wave-uniformly), then the nearest point of that one chunk.  Pruning aid only -- results do not depend on it.
+__global__ __launch_bounds__(256) void nn_seed_kernel(const float* __restrict__ q, int nq, NNTarget T, int* __restrict__ seed) {
+    const int qi = blockIdx.x * 256 + threadIdx.x;
+    if (qi >= nq) return;
+    const int old = seed[qi];
+    if (old >= 0 && old < T.n) return;
+    const float x = q[3 * (size_t)qi], y = q[3 * (size_t)qi + 1], z = q[3 * (size_t)qi + 2];
+    const int nchunk = (T.n + MF_CH - 1) / MF_CH;
+    float bb = INFINITY;
+    int bc = -1;
+    for (int c = 0; c < nchunk; ++c) {
+        const float d = box_d2(T.bounds[2 * c], T.bounds[2 * c + 1], x, y, z);
+        if (d < bb) { bb = d; bc = c; }
+    }
+    if (bc < 0) return;                                       // NaN query: stays unseeded (the scan handles it)
+    float bd = INFINITY;
+    int bi = -1;
+    const int p0 = bc * MF_CH, p1 = min(T.n, p0 + MF_CH);
+    for (int p = p0; p < p1; ++p) {
+        const float4 pt = T.pts[p];
+        const float d = nn_exact_d2(x, y, z, pt.x, pt.y, pt.z);
+        if (d < bd) { bd = d; bi = __float_as_int(pt.w); }
+    }
+    seed[qi] = bi;
+}
+
 __global__ void nn_combine_kernel(const float* __restrict__ pd, const int* __restrict__ pi, int nsplit, int nq,
                                   float* __restrict__ dist, int* __restrict__ idx) {
     int qi = blockIdx.x * blockDim.x + threadIdx.x;
@@ -672,7 +925,7 @@ static inline int nn_pick_nsplit(int nq, int nt, bool culled = false) {
 
 // workspace: pd/pi [nsplit*nq]; seed: optional [nq] original indices (may alias idx: read before idx is rewritten)
 static inline hipError_t nn_search(const float* q, int nq, const NNTarget& T, float* dist, int* idx, float* pd, int* pi,
-                                   int nsplit, hipStream_t st, const int* seed = nullptr) {
+                                   int nsplit, hipStream_t st, const int* seed = nullptr, bool seed_missing = false) {
     if (nq <= 0) return hipSuccess;
     // Query blocks per workgroup: 4 waves x NQ x 32.  A brute-force scan wants NQ = 4 (most MFMAs per
     // staged chunk: 9.7 ms vs 10.9 at NQ = 2); a seeded + chunk-culled scan wants NQ = 2 (the union of
@@ -681,11 +934,23 @@ static inline hipError_t nn_search(const float* q, int nq, const NNTarget& T, fl
     static int forced_nq = -1;
     if (forced_nq < 0) { const char* e = getenv("FDCAP_NN_NQ"); forced_nq = e ? atoi(e) : 0; }
     const bool culled = seed != nullptr && T.bounds != nullptr;
-    static int use_stream = -1;                              // FDCAP_NN_STREAM=0 keeps the staged kernel for culled launches (A/B)
-    if (use_stream < 0) { const char* e = getenv("FDCAP_NN_STREAM"); use_stream = (e && e[0] == '0') ? 0 : 1; }
+    // FDCAP_NN_STREAM (A/B): 0 staged kernel, 1 one wave per 64-query group, 42 four waves per 64-query group,
+    // default 41: four waves per 32-query group (0.186 ms vs 0.208 at 512k queries, 0.037 vs 0.049 at 64k)
+    static int use_stream = -1;
+    if (use_stream < 0) { const char* e = getenv("FDCAP_NN_STREAM"); use_stream = e ? atoi(e) : 41; }
     if (culled && T.frags != nullptr && use_stream && nn_use_mfma(nq, T.n)) {
-        // seed may alias idx: every wave reads its seeds before it writes its own results, and no other wave touches them
-        hipLaunchKernelGGL((nn_stream_kernel<2>), dim3((nq + 255) / 256), dim3(256), 0, st, q, nq, T, seed, dist, idx);
+        if (seed == idx && seed_missing)                      // first launch of a fit: cheap seeds instead of a full scan
+            hipLaunchKernelGGL(nn_seed_kernel, dim3((nq + 255) / 256), dim3(256), 0, st, q, nq, T, idx);
+        // seed may alias idx: every workgroup reads its seeds before it writes its own results, and no other workgroup touches them
+        if (use_stream == 1) {
+            hipLaunchKernelGGL((nn_stream_kernel<2>), dim3((nq + 255) / 256), dim3(256), 0, st, q, nq, T, seed, dist, idx);
+        } else if (use_stream == 42) {
+            const int groups = (nq + 63) / 64;
+            hipLaunchKernelGGL((nn_stream4_kernel<2>), dim3((groups + 7) / 8 * 8), dim3(256), 0, st, q, nq, T, seed, dist, idx);
+        } else {
+            const int groups = (nq + 31) / 32;
+            hipLaunchKernelGGL((nn_stream4_kernel<1>), dim3((groups + 7) / 8 * 8), dim3(256), 0, st, q, nq, T, seed, dist, idx);
+        }
         return hipGetLastError();
     }
     const int NQsel = forced_nq ? forced_nq : (culled ? 2 : 4);

@@ -92,42 +92,22 @@ __device__ __forceinline__ float wave_sum(float v) {
     return v;
 }
 
-// workgroup per frame: contact-term gradient -> skinning backward, reduced over the frame's
-// contact vertices.  dist/idx/Vw/dVoff are [rows, nc(,3)].
-// contact robustifier (:295) gradient wrt the world-space contact vertices + its un-weighted sum
-__global__ void contact_grad_kernel(const float* __restrict__ Vw, const float* __restrict__ dist,
-                                    const int* __restrict__ idx, const float4* __restrict__ scene, size_t n,
-                                    float coef, float* __restrict__ dVw, double* __restrict__ loss_contact_sum) {
-    __shared__ float sred[4];
-    size_t qi = (size_t)blockIdx.x * 256 + threadIdx.x;
-    float term = 0.f;
-    if (qi < n) {
-        float dterm;
-        term = contact_term(dist[qi], &dterm);
-        int j = idx[qi];
-        float gg = j >= 0 ? 2.f * coef * dterm : 0.f;           // no neighbour (NaN query): zero gradient
-        float4 p = j >= 0 ? scene[j] : make_float4(0.f, 0.f, 0.f, 0.f);
-        dVw[3 * qi] = gg * (Vw[3 * qi] - p.x);
-        dVw[3 * qi + 1] = gg * (Vw[3 * qi + 1] - p.y);
-        dVw[3 * qi + 2] = gg * (Vw[3 * qi + 2] - p.z);
-    }
-    term = wave_sum(term);
-    if ((threadIdx.x & 63) == 0) sred[threadIdx.x >> 6] = term;
-    __syncthreads();
-    if (threadIdx.x == 0) atomicAdd(loss_contact_sum, (double)((sred[0] + sred[1]) + (sred[2] + sred[3])));
-}
-
 // workgroup per frame: skinning + world-transform backward of d loss / d world vertices, reduced over
 // the frame's vertex set.  dVw / dVoff are [rows, nc, 3] and may alias (each thread reads its vertex's
 // gradient before it writes the vertex's pose-blend gradient).
+// CONTACT: d loss / d world vertex is the contact robustifier's gradient (:295), formed here from the NN
+// result (Vw, dist, idx -> scene point) instead of being read from dVw; its un-weighted sum goes to
+// *contact_sum when that is non-null (logging iterations only: one double atomic per frame).
+struct ContactGradIn { const float* Vw; const float* dist; const int* idx; const float4* scene; float coef; double* contact_sum; };
 constexpr int SKB_NACC = NBETA + 3 + 12 + 1;   // dbeta, dtransl, dM, ds
+template <bool CONTACT>
 __global__ __launch_bounds__(256) void skin_bwd_kernel(SkinModel sm, int nc, const float* __restrict__ X,
                                                        const float* __restrict__ Voff, const float* __restrict__ A,
                                                        const float* __restrict__ M, const float* __restrict__ scale,
                                                        int row0, const float* dVw, float* dVoff,
                                                        float* __restrict__ dA, float* __restrict__ dbeta_v,
                                                        float* __restrict__ dtransl_v, float* __restrict__ dMv,
-                                                       float* __restrict__ dsv) {
+                                                       float* __restrict__ dsv, ContactGradIn cg) {
     constexpr int VCH = 1024;                      // vertices per LDS chunk
     __shared__ float sdT[VCH * 12];
     __shared__ float sdA[NJ * 12];
@@ -138,6 +118,7 @@ __global__ __launch_bounds__(256) void skin_bwd_kernel(SkinModel sm, int nc, con
     const float s = *scale;
     V3 transl = v3(x[X_TRANSL], x[X_TRANSL + 1], x[X_TRANSL + 2]);
     float acc[SKB_NACC];
+    float cterm = 0.f;
 #pragma unroll
     for (int i = 0; i < SKB_NACC; ++i) acc[i] = 0.f;
     for (int i = tid; i < NJ * 12; i += 256) sdA[i] = 0.f;
@@ -145,7 +126,17 @@ __global__ __launch_bounds__(256) void skin_bwd_kernel(SkinModel sm, int nc, con
         const int c1 = min(nc, c0 + VCH);
         for (int c = c0 + tid; c < c1; c += 256) {
             size_t qi = (size_t)r * nc + c;
-            V3 g = v3(dVw[3 * qi], dVw[3 * qi + 1], dVw[3 * qi + 2]);
+            V3 g;
+            if (CONTACT) {
+                float dterm;
+                cterm += contact_term(cg.dist[qi], &dterm);
+                const int j = cg.idx[qi];
+                const float gg = j >= 0 ? 2.f * cg.coef * dterm : 0.f;           // no neighbour (NaN query): zero gradient
+                const float4 p = j >= 0 ? cg.scene[j] : make_float4(0.f, 0.f, 0.f, 0.f);
+                g = v3(gg * (cg.Vw[3 * qi] - p.x), gg * (cg.Vw[3 * qi + 1] - p.y), gg * (cg.Vw[3 * qi + 2] - p.z));
+            } else {
+                g = v3(dVw[3 * qi], dVw[3 * qi + 1], dVw[3 * qi + 2]);
+            }
             SkinFwd f = skin_forward_vertex(sm, c, x + X_BETAS, Voff + 3 * qi, A + (size_t)r * NJ * 12, transl,
                                             M + (size_t)r * 12, s);
             SkinBwd b = skin_backward_vertex(f, M + (size_t)r * 12, s, g);
@@ -197,6 +188,13 @@ __global__ __launch_bounds__(256) void skin_bwd_kernel(SkinModel sm, int nc, con
         if ((tid & 63) == 0) sred[tid >> 6][i] = v;
     }
     __syncthreads();
+    if (CONTACT && cg.contact_sum) {                    // wave-uniform
+        __shared__ float scon[4];
+        const float v = wave_sum(cterm);
+        if ((tid & 63) == 0) scon[tid >> 6] = v;
+        __syncthreads();
+        if (tid == 0) atomicAdd(cg.contact_sum, (double)((scon[0] + scon[1]) + (scon[2] + scon[3])));
+    }
     for (int i = tid; i < NJ * 12; i += 256) dA[(size_t)r * NJ * 12 + i] = sdA[i];
     if (tid < SKB_NACC) {
         float v = sred[0][tid] + sred[1][tid] + sred[2][tid] + sred[3][tid];
@@ -333,6 +331,7 @@ __global__ __launch_bounds__(128) void param_loss_kernel(const float* __restrict
         float gr = world_smooth_grad(g, n_total, jm1, j[0], jp1, w_ws_over_cnt, &ws);
         if (world_grad) dJw[(size_t)r * NJW * 3 + tid] = gr;
     }
+    if (!losses) return;                                   // partial sums only on logging iterations (block-uniform)
     float vals[4] = {rec, vp, sm, ws};
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
@@ -366,18 +365,66 @@ __global__ void adam_kernel(float* __restrict__ p, float* __restrict__ m, float*
     p[i] = pp; m[i] = mm; v[i] = vv;
 }
 
+// One launch for the whole optimizer.step() of an iteration (:592): blocks [0, nb_x) update body_rotation_rec,
+// [nb_x, nb_x + nb_cam) camera_ext, the last block `scale` -- first reducing the per-frame d loss / d scale
+// partials in reduce_rows_kernel's fixed order when `reduce_n` > 0 (single-GPU; a sharded run gets the sum
+// from the exchange instead).
+struct AdamTensor { float* p; float* m; float* v; const float* g; size_t n; AdamScalars a; };
+__global__ __launch_bounds__(256) void adam_step_kernel(AdamTensor x, AdamTensor cam, AdamTensor sc, int nb_x, int nb_cam,
+                                                        const float* __restrict__ dscale_row, int row0, int reduce_n,
+                                                        float* __restrict__ dscale, int scale_zero_grad) {
+    const int b = blockIdx.x;
+    if (b < nb_x + nb_cam) {
+        const AdamTensor& t = b < nb_x ? x : cam;
+        const size_t i = (size_t)(b < nb_x ? b : b - nb_x) * 256 + threadIdx.x;
+        if (i >= t.n) return;
+        float pp = t.p[i], mm = t.m[i], vv = t.v[i];
+        adam_update(pp, mm, vv, t.g[i], t.a);
+        t.p[i] = pp; t.m[i] = mm; t.v[i] = vv;
+        return;
+    }
+    __shared__ float sred[4];
+    float g = 0.f;
+    if (reduce_n > 0) {
+        float a = 0.f;
+        for (int i = threadIdx.x; i < reduce_n; i += 256) a += dscale_row[row0 + i];
+        a = wave_sum(a);
+        if ((threadIdx.x & 63) == 0) sred[threadIdx.x >> 6] = a;
+        __syncthreads();
+        g = (sred[0] + sred[1]) + (sred[2] + sred[3]);
+        if (threadIdx.x == 0) *dscale = g;
+    } else {
+        g = *dscale;
+    }
+    if (threadIdx.x == 0 && sc.p) {
+        float pp = *sc.p, mm = *sc.m, vv = *sc.v;
+        adam_update(pp, mm, vv, scale_zero_grad ? 0.f : g, sc.a);
+        *sc.p = pp; *sc.m = mm; *sc.v = vv;
+    }
+}
+
 // one message per rank and iteration: [first 2 owned rows | last 2 owned rows] of (x | camera_ext) + d loss / d scale
 constexpr int XCH_ROW = XDIM + 16;                 // 94 floats
 constexpr int XCH_LEN = 4 * XCH_ROW + 8;           // + dscale partial (+ padding to 32 B)
-__global__ void pack_exchange_kernel(const float* __restrict__ X, const float* __restrict__ CAM, const float* __restrict__ dscale,
-                                     int n_local, float* __restrict__ out) {
+__global__ __launch_bounds__(384) void pack_exchange_kernel(const float* __restrict__ X, const float* __restrict__ CAM,
+                                                            const float* __restrict__ dscale_row, float* __restrict__ dscale,
+                                                            int n_local, float* __restrict__ out) {
+    __shared__ float sred[4];
     int t = threadIdx.x;
+    if (t < 256) {                                         // this rank's d loss / d scale, reduce_rows_kernel's order
+        float a = 0.f;
+        for (int i = t; i < n_local; i += 256) a += dscale_row[2 + i];
+        a = wave_sum(a);
+        if ((t & 63) == 0) sred[t >> 6] = a;
+    }
+    __syncthreads();
+    if (t == 0) *dscale = (sred[0] + sred[1]) + (sred[2] + sred[3]);
     if (t < 4 * XCH_ROW) {
         int k = t / XCH_ROW, e = t % XCH_ROW;
         int row = (k < 2) ? 2 + k : n_local + k - 2;             // owned rows start at 2: first two, last two
         out[t] = e < XDIM ? X[(size_t)row * XDIM + e] : CAM[(size_t)row * 16 + e - XDIM];
     } else if (t < XCH_LEN) {
-        out[t] = (t == 4 * XCH_ROW) ? *dscale : 0.f;
+        out[t] = (t == 4 * XCH_ROW) ? (sred[0] + sred[1]) + (sred[2] + sred[3]) : 0.f;
     }
 }
 // halo rows <- neighbours' boundary rows; scale gradient = sum over ranks in rank order (same bits everywhere)
@@ -534,6 +581,7 @@ struct OptState {
     std::vector<AdamScalars> adam_tab_h;
     int dctT = 0, dctC = 0, dctW = 0;
     bool dct_grad = false;    // the last backward gave `scale` a gradient through the DCT term
+    bool seeded = false;      // a contact forward has run since fdcap_opt_create (idx holds neighbours)
     bool use_seed = true;     // last iteration's neighbours seed the NN bound (pruning only)
     bool use_cull = true;     // skip scene chunks whose bounding sphere is out of every query's reach
 };
@@ -728,30 +776,44 @@ void fdcap_ctx_destroy(fdcap_ctx* c) {
 int fdcap_set_scene(fdcap_ctx* c, const float* xyz, int64_t ns) {
     if (!c || ns < 0 || (ns > 0 && !xyz) || ns > 0x7fffffff) return FDCAP_E_ARG;
     std::vector<float4> orig((size_t)ns), sorted((size_t)ns);
-    float lo[3] = {1e30f, 1e30f, 1e30f}, hi[3] = {-1e30f, -1e30f, -1e30f};
     for (int64_t i = 0; i < ns; ++i) {
         orig[i] = make_float4(xyz[3 * i], xyz[3 * i + 1], xyz[3 * i + 2], 0.f);
         int ii = (int)i;
         memcpy(&orig[i].w, &ii, 4);
-        for (int k = 0; k < 3; ++k) { lo[k] = std::min(lo[k], xyz[3 * i + k]); hi[k] = std::max(hi[k], xyz[3 * i + k]); }
     }
-    // spatial (Morton, 3 x 10 bit) order: consecutive MF_CH-point chunks become compact, so their
-    // bounding spheres let the NN scan skip chunks that cannot matter.  Ties keep index order.
-    auto spread = [](uint32_t v) { v &= 1023; v = (v | (v << 16)) & 0x030000FF; v = (v | (v << 8)) & 0x0300F00F;
-                                   v = (v | (v << 4)) & 0x030C30C3; v = (v | (v << 2)) & 0x09249249; return v; };
-    std::vector<std::pair<uint32_t, int>> key((size_t)ns);
-    for (int64_t i = 0; i < ns; ++i) {
-        uint32_t code = 0;
-        for (int k = 0; k < 3; ++k) {
-            float ext = hi[k] - lo[k];
-            float u = ext > 0.f ? (xyz[3 * i + k] - lo[k]) / ext : 0.f;
-            code |= spread((uint32_t)std::min(1023.f, std::max(0.f, u * 1023.f))) << k;
+    // Spatial order by recursive median splits (k-d cells): every MF_CH-point chunk is one cell and every
+    // 32-point MFMA tile inside it a sub-cell, so the chunk boxes the NN scan culls with are compact and
+    // disjoint (runs of a Morton curve jump across quadrant borders and give long, overlapping boxes).
+    // A node of n points is cut at a multiple of the unit below it (chunks above MF_CH, tiles below), along
+    // its longest axis; ties by index, so the order is deterministic.  Results never depend on this order.
+    std::vector<int> order((size_t)ns), inv((size_t)ns);
+    for (int64_t i = 0; i < ns; ++i) order[i] = (int)i;
+    {
+        std::vector<std::pair<int64_t, int64_t>> stack;
+        if (ns > 0) stack.push_back({0, ns});
+        while (!stack.empty()) {
+            const int64_t a = stack.back().first, b = stack.back().second;
+            stack.pop_back();
+            const int64_t n = b - a;
+            if (n <= 32) continue;
+            const int64_t unit = n > MF_CH ? MF_CH : 32;
+            const int64_t units = (n + unit - 1) / unit;
+            const int64_t nleft = std::min(n - 1, (units / 2) * unit);
+            if (nleft <= 0) continue;
+            float blo[3] = {1e30f, 1e30f, 1e30f}, bhi[3] = {-1e30f, -1e30f, -1e30f};
+            for (int64_t p = a; p < b; ++p)
+                for (int k = 0; k < 3; ++k) { float v = xyz[3 * (int64_t)order[p] + k]; blo[k] = std::min(blo[k], v); bhi[k] = std::max(bhi[k], v); }
+            int ax = 0;
+            for (int k = 1; k < 3; ++k) if (bhi[k] - blo[k] > bhi[ax] - blo[ax]) ax = k;
+            std::nth_element(order.begin() + a, order.begin() + a + nleft, order.begin() + b, [&](int i, int j) {
+                const float vi = xyz[3 * (int64_t)i + ax], vj = xyz[3 * (int64_t)j + ax];
+                return vi < vj || (vi == vj && i < j);
+            });
+            stack.push_back({a, a + nleft});
+            stack.push_back({a + nleft, b});
         }
-        key[i] = {code, (int)i};
     }
-    std::sort(key.begin(), key.end());
-    std::vector<int> inv((size_t)ns);
-    for (int64_t p = 0; p < ns; ++p) { sorted[p] = orig[key[p].second]; inv[key[p].second] = (int)p; }
+    for (int64_t p = 0; p < ns; ++p) { sorted[p] = orig[order[p]]; inv[order[p]] = (int)p; }
     const int64_t nchunk = (ns + MF_CH - 1) / MF_CH;
     std::vector<float4> bounds((size_t)nchunk * 2);           // axis-aligned box per chunk, slightly inflated
     for (int64_t ch = 0; ch < nchunk; ++ch) {
@@ -1037,6 +1099,7 @@ int fdcap_opt_create(fdcap_ctx* c, const fdcap_opt_config* cfg, float* rows_x, f
     c->opt = o;
     o->cfg = *cfg;
     o->cam_steps = 0;
+    o->seeded = false;
     o->dctT = o->dctC = o->dctW = 0;
     o->dct_grad = false;
     const int R = o->R = cfg->n_local + 4;
@@ -1105,8 +1168,10 @@ static int opt_contact_forward(fdcap_ctx* c, hipStream_t st) {
     hipLaunchKernelGGL(skin_fwd_kernel, dim3((nc + 255) / 256, nl), dim3(256), 0, st, c->contact.model(), nc, o->X.p, XDIM,
                        X_BETAS, X_TRANSL, o->Voff.p, o->A.p, o->M.p, o->scale.p, 2, 1, o->Vw.p);
     const int nq = nl * nc;
+    // the first contact forward of a fit has no neighbours from a previous iteration yet (idx = -1)
     HIP_TRY(nn_search(o->Vw.p + off, nq, c->nn_target(o->use_cull), o->dist.p + 2 * nc, o->idx.p + 2 * nc, o->pd.p, o->pi.p,
-                      o->nsplit, st, o->use_seed ? o->idx.p + 2 * nc : nullptr));
+                      o->nsplit, st, o->use_seed ? o->idx.p + 2 * nc : nullptr, !o->seeded));
+    o->seeded = true;
     return 0;
 }
 
@@ -1121,7 +1186,8 @@ static int opt_backward_impl(fdcap_ctx* c, const LossWeights& lw, int32_t log_te
     const int R = o->R, nl = cf.n_local, nc = c->nc, N = cf.n_total;
     const bool dct_on = lw.dct != 0.f && o->dctW > 0;
     PoseModel pm = c->pose_model();
-    HIP_TRY(hipMemsetAsync(o->losses.p, 0, FDCAP_NUM_LOSSES * sizeof(double), st));
+    double* const losses = log_terms ? o->losses.p : nullptr;       // the partial sums are only formed on logging iterations
+    if (losses) HIP_TRY(hipMemsetAsync(losses, 0, FDCAP_NUM_LOSSES * sizeof(double), st));
     int e = vposer_forward(c, o->X.p, XDIM, X_LATENT, R, o->H1.p, o->H2.p, o->O.p, st);
     if (e) return e;
     hipLaunchKernelGGL(pose_fwd_kernel, dim3(R), dim3(64), 0, st, pm, o->X.p, o->O.p, o->CAM.p, o->scale.p, 0, o->Rm.p,
@@ -1133,25 +1199,24 @@ static int opt_backward_impl(fdcap_ctx* c, const LossWeights& lw, int32_t log_te
     const float w_sm = (N >= 3) ? lw.smooth / ((float)(N - 2) * XDIM) : 0.f;
     const float w_ws = (lw.world_on && N >= 2) ? lw.world / ((float)(N - 1) * NJW * 3) : 0.f;
     hipLaunchKernelGGL(param_loss_kernel, dim3(nl), dim3(128), 0, st, o->X.p, o->X0.p, o->mask.p, o->Jw.p, 2, cf.frame0, N,
-                       w_rec, w_sm, w_ws, lw.world_on ? 1 : 0, o->dX.p, o->dJw.p, o->losses.p);
+                       w_rec, w_sm, w_ws, lw.world_on ? 1 : 0, o->dX.p, o->dJw.p, losses);
     if (o->dctW > 0 && (dct_on || log_terms))
         hipLaunchKernelGGL(dct_joint_grad_kernel, dim3((nl * 69 + 255) / 256), dim3(256), 0, st, o->Jw.p, 2, cf.frame0, nl, o->dctT,
                            o->dctC, o->dctW, o->dctD.p, o->dctCoef.p, dct_on ? lw.dct / (69.f * (float)o->dctW) : 0.f,
-                           lw.world_on ? 1 : 0, o->dJw.p, o->losses.p + 7);
+                           lw.world_on ? 1 : 0, o->dJw.p, losses ? losses + 7 : nullptr);
     o->dct_grad = dct_on;
     if (contact_grad) {
-        const float coef = lw.contact * cf.weight_contact / ((float)N * nc);
-        const size_t nqv = (size_t)nl * nc, offq = (size_t)2 * nc;
-        hipLaunchKernelGGL(contact_grad_kernel, dim3((nqv + 255) / 256), dim3(256), 0, st, o->Vw.p + offq * 3, o->dist.p + offq,
-                           o->idx.p + offq, c->scene.p, nqv, coef, o->dVoff.p + offq * 3, o->losses.p + 3);
-        hipLaunchKernelGGL(skin_bwd_kernel, dim3(nl), dim3(256), 0, st, c->contact.model(), nc, o->X.p, o->Voff.p, o->A.p,
-                           o->M.p, o->scale.p, 2, o->dVoff.p, o->dVoff.p, o->dA.p, o->dbeta_v.p, o->dtransl_v.p, o->dMv.p,
-                           o->dsv.p);
+        ContactGradIn cg;
+        cg.Vw = o->Vw.p; cg.dist = o->dist.p; cg.idx = o->idx.p; cg.scene = c->scene.p;
+        cg.coef = lw.contact * cf.weight_contact / ((float)N * nc);
+        cg.contact_sum = losses ? losses + 3 : nullptr;
+        hipLaunchKernelGGL(skin_bwd_kernel<true>, dim3(nl), dim3(256), 0, st, c->contact.model(), nc, o->X.p, o->Voff.p, o->A.p,
+                           o->M.p, o->scale.p, 2, (const float*)nullptr, o->dVoff.p, o->dA.p, o->dbeta_v.p, o->dtransl_v.p,
+                           o->dMv.p, o->dsv.p, cg);
         HIP_TRY(gemm_f32(true, EPI_STORE, o->dVoff.p + (size_t)2 * nc * 3, 3 * nc, c->contact.posedirs.p, 3 * nc,
                          o->dPF.p + 2 * NPF, NPF, nl, NPF, 3 * nc, nullptr, 0, st));
-    } else if (contact_fwd) {
-        hipLaunchKernelGGL(contact_loss_kernel, dim3(256), dim3(256), 0, st, o->dist.p + 2 * nc, (size_t)nl * nc,
-                           o->losses.p + 3);
+    } else if (contact_fwd && losses) {
+        hipLaunchKernelGGL(contact_loss_kernel, dim3(256), dim3(256), 0, st, o->dist.p + 2 * nc, (size_t)nl * nc, losses + 3);
     }
     const bool joint_grad = lw.world_on || dct_on;
     hipLaunchKernelGGL(pose_bwd_kernel, dim3(nl), dim3(64), 0, st, pm, o->X.p, o->O.p, o->CAM.p, o->scale.p, 2, o->Rm.p,
@@ -1166,7 +1231,9 @@ static int opt_backward_impl(fdcap_ctx* c, const LossWeights& lw, int32_t log_te
                      o->H1.p + 2 * 512, 512, st));
     HIP_TRY(gemm_f32(false, EPI_ACCUM, o->dH1.p + 2 * 512, 512, c->W1.p, 32, o->dX.p + 2 * XDIM + X_LATENT, XDIM, nl, 32, 512,
                      nullptr, 0, st));
-    hipLaunchKernelGGL(reduce_rows_kernel, dim3(1), dim3(256), 0, st, o->dscale_row.p, 2, nl, o->dscale.p);
+    // d loss / d scale of this rank = sum of the per-frame partials: formed by the step kernels (fused with Adam /
+    // the exchange packing); on logging iterations also here, so a caller can read dscale_d right after the backward
+    if (log_terms) hipLaunchKernelGGL(reduce_rows_kernel, dim3(1), dim3(256), 0, st, o->dscale_row.p, 2, nl, o->dscale.p);
     return (int)hipGetLastError();
 }
 
@@ -1279,25 +1346,34 @@ int fdcap_frame_smoother(fdcap_ctx* c, const float* data78, int32_t N, int32_t i
     return (int)hipGetLastError();
 }
 
-static int opt_step_impl(fdcap_ctx* c, int32_t ii, int32_t P, bool do_rows, bool do_scale, void* stream) {
+static int opt_step_impl(fdcap_ctx* c, int32_t ii, int32_t P, bool do_rows, bool do_scale, bool reduce_scale, void* stream) {
     if (!c || !c->opt) return FDCAP_E_STATE;
     OptState* o = c->opt;
     hipStream_t st = (hipStream_t)stream;
     const fdcap_opt_config& cf = o->cfg;
     const int nl = cf.n_local;
-    const size_t nx = (size_t)nl * XDIM, ncam = (size_t)nl * 16;
+    AdamTensor x = {}, cam = {}, sc = {};
+    int nb_x = 0, nb_cam = 0;
     // body_rotation_rec: every iteration, its own step counter = ii + 1
-    if (do_rows)
-        hipLaunchKernelGGL(adam_kernel, dim3((nx + 255) / 256), dim3(256), 0, st, o->X.p + 2 * XDIM, o->mX.p + 2 * XDIM,
-                           o->vX.p + 2 * XDIM, o->dX.p + 2 * XDIM, nx, adam_scalars(cf.lr, ii + 1), 0);
-    // scale: receives a gradient while ii < P (and only if the contact term exists)
-    if (do_scale && (o->contact_on || o->dct_grad) && (ii < P || cf.legacy_zero_grad))
-        hipLaunchKernelGGL(adam_kernel, dim3(1), dim3(64), 0, st, o->scale.p, o->mS.p, o->vS.p, o->dscale.p, (size_t)1,
-                           adam_scalars(cf.lr, ii + 1), ii < P ? 0 : 1);
-    // camera_ext: first gradient at ii = P + 1 (flag flips after the forward of ii = P)
-    if (do_rows && ii >= P + 1 && cf.phase2_world != 0.f)       // mode 'local': the late-phase loss has no camera_ext path -> grad None, never stepped
-        hipLaunchKernelGGL(adam_kernel, dim3((ncam + 255) / 256), dim3(256), 0, st, o->CAM.p + 2 * 16, o->mCAM.p + 2 * 16,
-                           o->vCAM.p + 2 * 16, o->dCAM.p + 2 * 16, ncam, adam_scalars(cf.lr, ii - P), 0);
+    if (do_rows) {
+        x = AdamTensor{o->X.p + 2 * XDIM, o->mX.p + 2 * XDIM, o->vX.p + 2 * XDIM, o->dX.p + 2 * XDIM, (size_t)nl * XDIM,
+                       adam_scalars(cf.lr, ii + 1)};
+        nb_x = (int)((x.n + 255) / 256);
+    }
+    // camera_ext: first gradient at ii = P + 1 (flag flips after the forward of ii = P); mode 'local': the late-phase
+    // loss has no camera_ext path -> grad None, never stepped
+    if (do_rows && ii >= P + 1 && cf.phase2_world != 0.f) {
+        cam = AdamTensor{o->CAM.p + 2 * 16, o->mCAM.p + 2 * 16, o->vCAM.p + 2 * 16, o->dCAM.p + 2 * 16, (size_t)nl * 16,
+                         adam_scalars(cf.lr, ii - P)};
+        nb_cam = (int)((cam.n + 255) / 256);
+    }
+    // scale: receives a gradient while ii < P (and only if a term that reaches it exists)
+    const bool step_scale = do_scale && (o->contact_on || o->dct_grad) && (ii < P || cf.legacy_zero_grad);
+    if (step_scale) sc = AdamTensor{o->scale.p, o->mS.p, o->vS.p, o->dscale.p, 1, adam_scalars(cf.lr, ii + 1)};
+    const bool tail = step_scale || (do_scale && reduce_scale);      // the last block: (reduction +) scale
+    if (nb_x + nb_cam + (tail ? 1 : 0) == 0) return FDCAP_OK;
+    hipLaunchKernelGGL(adam_step_kernel, dim3(nb_x + nb_cam + 1), dim3(256), 0, st, x, cam, sc, nb_x, nb_cam, o->dscale_row.p, 2,
+                       reduce_scale ? nl : 0, o->dscale.p, (step_scale && ii >= P) ? 1 : 0);
     return (int)hipGetLastError();
 }
 
@@ -1356,8 +1432,8 @@ int fdcap_opt_backward_local2(fdcap_ctx* c, const float* contact_weight, int32_t
     if (N >= 2)
         hipLaunchKernelGGL(foot_skate_kernel, dim3((nc * 3 + 255) / 256, nl), dim3(256), 0, st, o->VwF.p, nv3, c->contact_vid.p,
                            nc, n_left, contact_weight, 2, cf.frame0, N, o->dVF.p, o->losses.p + 6);
-    hipLaunchKernelGGL(skin_bwd_kernel, dim3(nl), dim3(256), 0, st, c->full.model(), V, o->X.p, o->VoffF.p, o->A.p, o->M.p,
-                       o->scale.p, 2, o->dVF.p, o->dVF.p, o->dA.p, o->dbeta_v.p, o->dtransl_v.p, o->dMv.p, o->dsv.p);
+    hipLaunchKernelGGL(skin_bwd_kernel<false>, dim3(nl), dim3(256), 0, st, c->full.model(), V, o->X.p, o->VoffF.p, o->A.p, o->M.p,
+                       o->scale.p, 2, o->dVF.p, o->dVF.p, o->dA.p, o->dbeta_v.p, o->dtransl_v.p, o->dMv.p, o->dsv.p, ContactGradIn());
     HIP_TRY(gemm_f32(true, EPI_STORE, o->dVF.p + 2 * nv3, 3 * V, c->full.posedirs.p, 3 * V, o->dPF.p + 2 * NPF, NPF, nl, NPF,
                      3 * V, nullptr, 0, st));
     hipLaunchKernelGGL(pose_bwd_kernel, dim3(nl), dim3(64), 0, st, pm, o->X.p, o->O.p, o->CAM.p, o->scale.p, 2, o->Rm.p,
@@ -1413,17 +1489,17 @@ int fdcap_opt_forward_world(fdcap_ctx* c, float* verts, float* joints, void* str
     return (int)hipGetLastError();
 }
 
-int fdcap_opt_step(fdcap_ctx* c, int32_t ii, int32_t P, void* stream) { return opt_step_impl(c, ii, P, true, true, stream); }
+int fdcap_opt_step(fdcap_ctx* c, int32_t ii, int32_t P, void* stream) { return opt_step_impl(c, ii, P, true, true, true, stream); }
 
 // Multi-GPU iteration tail with ONE collective: Adam on this rank's rows, pack [boundary rows | dscale],
 // (caller all-gathers), unpack halos + rank-ordered dscale sum + Adam on scale.
 int fdcap_opt_step_rows_and_pack(fdcap_ctx* c, int32_t ii, int32_t P, float* send, void* stream) {
     if (!c || !c->opt || !send) return FDCAP_E_ARG;
-    int e = opt_step_impl(c, ii, P, true, false, stream);
+    int e = opt_step_impl(c, ii, P, true, false, false, stream);
     if (e) return e;
     OptState* o = c->opt;
-    hipLaunchKernelGGL(pack_exchange_kernel, dim3(1), dim3(384), 0, (hipStream_t)stream, o->X.p, o->CAM.p, o->dscale.p,
-                       o->cfg.n_local, send);
+    hipLaunchKernelGGL(pack_exchange_kernel, dim3(1), dim3(384), 0, (hipStream_t)stream, o->X.p, o->CAM.p, o->dscale_row.p,
+                       o->dscale.p, o->cfg.n_local, send);
     return (int)hipGetLastError();
 }
 int fdcap_opt_unpack_and_step_scale(fdcap_ctx* c, int32_t ii, int32_t P, const float* gathered, int32_t rank, int32_t world,
@@ -1432,7 +1508,7 @@ int fdcap_opt_unpack_and_step_scale(fdcap_ctx* c, int32_t ii, int32_t P, const f
     OptState* o = c->opt;
     hipLaunchKernelGGL(unpack_exchange_kernel, dim3(1), dim3(384), 0, (hipStream_t)stream, gathered, rank, world, o->cfg.n_local,
                        o->X.p, o->CAM.p, o->dscale.p);
-    return opt_step_impl(c, ii, P, false, true, stream);
+    return opt_step_impl(c, ii, P, false, true, false, stream);
 }
 int32_t fdcap_exchange_len(void) { return XCH_LEN; }
 

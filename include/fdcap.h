@@ -145,9 +145,11 @@ int fdcap_params_78_to_75(const float* x78_d, int32_t B, float* p75_d, void* str
  *   rows_x_d   [n_local+4,78] body_rotation_rec (:180) with 2 halo rows each side; owned rows start at 2
  *   rows_cam_d [n_local+4,16] camera_ext (:182), same row layout
  *   scale_d    [1]  scale (:179); set to cfg->scale_init here
- *   dscale_d   [1]  this rank's d loss / d scale (sum over owned frames) -- all-reduce(sum) it
+ *   dscale_d   [1]  this rank's d loss / d scale (sum over owned frames): written by fdcap_opt_step /
+ *              fdcap_opt_step_rows_and_pack (fused with the update) and, when log_terms != 0, by the backward
  *   losses_d   [FDCAP_NUM_LOSSES] double: this rank's un-normalised partial sums of the last
- *              backward: [0] sum|x0-x|*mask  [1] sum z^2  [2] sum|2nd diff|  [3] sum r/(r+1)
+ *              backward that ran with log_terms != 0 (other iterations do not form them):
+ *              [0] sum|x0-x|*mask  [1] sum z^2  [2] sum|2nd diff|  [3] sum r/(r+1)
  *              [4] sum|Jw_i-Jw_{i+1}| */
 int fdcap_opt_create(fdcap_ctx* ctx, const fdcap_opt_config* cfg, float* rows_x_d, float* rows_cam_d,
                      float* scale_d, float* dscale_d, double* losses_d);
@@ -162,7 +164,9 @@ int fdcap_opt_set_inputs(fdcap_ctx* ctx, const float* data78_d, const float* ini
  *   backward: zero_grad + cal_loss + loss.backward()  -> gradients + loss partial sums
  *   step    : optimizer.step() (fused Adam over body_rotation_rec, scale, camera_ext)
  * `phase2` = (ii >= 0.8*num_iter) decides the loss total; the requires_grad toggling of
- * :564-568/:577-580 (effective one forward late) is reproduced from ii and first_phase2_iter. */
+ * :564-568/:577-580 (effective one forward late) is reproduced from ii and first_phase2_iter.
+ * log_terms != 0: also evaluate what the reference only prints (:573-575, :587-589) -- the loss partial
+ * sums in losses_d, the contact term in phase 2 -- and leave dscale_d valid after the backward. */
 int fdcap_opt_backward(fdcap_ctx* ctx, int32_t ii, int32_t first_phase2_iter, int32_t log_terms,
                        void* stream);
 int fdcap_opt_step(fdcap_ctx* ctx, int32_t ii, int32_t first_phase2_iter, void* stream);
