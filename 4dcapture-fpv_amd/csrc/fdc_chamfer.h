@@ -27,6 +27,7 @@ struct NNTarget {
     const float4* pts;        // [n] {x, y, z, bits(original index)}
     int n;
     const float4* bounds;     // optional [2 * ceil(n / MF_CH)] axis-aligned box {lo xyz, -}, {hi xyz, -} of each chunk (pts spatially sorted)
+    const float4* sbounds;    // with bounds: [2 * ceil(nchunk / 16)] boxes of 16 consecutive chunks (two-level survivor test)
     const int* inv_perm;      // optional [n] original index -> position in pts (null: identity)
     // optional, static per scene: MFMA A fragments precomputed per chunk RELATIVE TO THE CHUNK'S OWN CENTRE
     // ([chunk][tile 0..15][k-half][point 0..31] uint4) + the centres {cx, cy, cz, radius}: lets a wave
@@ -618,29 +619,37 @@ __global__ __launch_bounds__(256) void nn_stream_kernel(const float* __restrict_
 // each other touch the same scene chunks, so an XCD's L2 holds 1/8 of the clip's neighbourhoods).
 constexpr int ST4_MAXLIST = 512;       // survivors one wave can list out of its quarter of the chunks
 constexpr int ST4_PF = 8;              // A fragments in flight per wave
+constexpr int ST4_SUPER = 16;          // chunks per super-cell of the two-level survivor test (consecutive chunks = one k-d subtree)
 
-template <int NQ>
-__global__ __launch_bounds__(256) void nn_stream4_kernel(const float* __restrict__ q, int nq, NNTarget T,
-                                                         const int* __restrict__ seed, float* __restrict__ dist,
-                                                         int* __restrict__ idx) {
+template <int NQ, int WPG>
+__global__ __launch_bounds__(256, NQ == 1 ? 4 : 3) void nn_stream4_kernel(const float* __restrict__ q, int nq, NNTarget T,
+                                                         const int* __restrict__ seed, float4* __restrict__ seedpt,
+                                                         float* __restrict__ dist, int* __restrict__ idx) {
     __shared__ unsigned short slist[4][ST4_MAXLIST];
     __shared__ float s_d[4][32 * NQ];
     __shared__ int s_i[4][32 * NQ];
+    __shared__ float4 s_p[4][32 * NQ];
+    static_assert(WPG == 1 || WPG == 2 || WPG == 4, "waves per query group");
+    constexpr int GPW = 4 / WPG;                                 // query groups per workgroup
+    constexpr int CPS = ST4_SUPER / WPG;                         // chunks of a super-cell that belong to one wave
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, half = lane >> 5, col = lane & 31;
+    const int sub = wave % WPG, gslot = wave / WPG;             // this wave's share of its group's chunks: WPG k + sub
     const int ngroups = (nq + 32 * NQ - 1) / (32 * NQ);
-    const int per_xcd = (ngroups + 7) >> 3;
-    const int group = (blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);
-    if (group >= ngroups) return;                               // whole workgroup idle
-    const int wq0 = group * (32 * NQ);
+    const int nwg = (ngroups + GPW - 1) / GPW;
+    const int per_xcd = (nwg + 7) >> 3;
+    const int wg = (blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);
+    const int group = wg * GPW + gslot;
+    const bool idle = wg >= nwg || group >= ngroups;            // idle waves still meet the barrier below
+    const int wq0 = idle ? nq : group * (32 * NQ);
     const int nchunk = (T.n + MF_CH - 1) / MF_CH;
-    const int myn = (nchunk - wave + 3) >> 2;                   // this wave's chunks: 4 k + wave, k < myn
+    const int myn = idle ? 0 : (nchunk - sub + WPG - 1) / WPG;  // this wave's chunks: WPG k + sub, k < myn
 #ifdef FDC_NN_STATS
     unsigned st_cnt[4] = {0, 0, 0, 0};
 #endif
-
     float qx[NQ], qy[NQ], qz[NQ], own_d[NQ], sb[NQ];
-    int own_i[NQ], own_pos[NQ], qidx[NQ];        // own_pos: position of the current best in T.pts (it passes the filter
-                                                 // by construction and must not cost a global load every time it is met)
+    int own_i[NQ], qidx[NQ];
+    float4 own_p[NQ];          // the current best {x, y, z, bits(position in T.pts)}: it passes the filter by construction and
+                               // must not cost a global load every time it is met; next iteration's seed point
     float sx = 0.f, sy = 0.f, sz = 0.f, sc = 0.f;
     bool all_seeded = true;
 #pragma unroll
@@ -652,13 +661,13 @@ __global__ __launch_bounds__(256) void nn_stream4_kernel(const float* __restrict
         qz[n] = ok ? q[3 * (size_t)qidx[n] + 2] : 0.f;
         own_d[n] = INFINITY;
         own_i[n] = -1;
-        own_pos[n] = -1;
+        own_p[n] = make_float4(0.f, 0.f, 0.f, __int_as_float(-1));
         if (ok) {
             sx += qx[n]; sy += qy[n]; sz += qz[n]; sc += 1.f;
             const int sj = seed[qidx[n]];
+            const float4 p = seedpt[qidx[n]];                  // the seed's coordinates, kept from the launch that found it
             if (sj >= 0 && sj < T.n) {
-                own_pos[n] = T.inv_perm ? T.inv_perm[sj] : sj;
-                const float4 p = T.pts[own_pos[n]];
+                own_p[n] = p;
                 own_d[n] = nn_exact_d2(qx[n], qy[n], qz[n], p.x, p.y, p.z);
                 own_i[n] = sj;
             } else {
@@ -685,40 +694,59 @@ __global__ __launch_bounds__(256) void nn_stream4_kernel(const float* __restrict
     reach = reach * 1.00001f + 1e-6f;
     const bool cull = __all(all_seeded) && reach < INFINITY;
 
-    // survivor list over this wave's chunks: 64 boxes per round against the group's reach, then per query
+    // Survivor list of this wave, two levels: the boxes of 16-chunk super-cells (k-d subtrees) are tested against
+    // the group's reach 64 per round by every wave; inside the near super-cells each wave tests ITS chunks
+    // (4 j + wave, j < 4) -- 16 super-cells x 4 chunks per round of lanes -- against the reach and then per query.
+    // (Testing all chunk boxes directly costs every workgroup the whole box array through L1/L2: 31 KB x 16000
+    // workgroups per launch at 500k points, more than everything else the kernel reads.)
     int nsurv = myn;
     bool listed = false;
     if (cull) {
         nsurv = 0;
         listed = true;
         const float r2 = reach * reach;
-        for (int k0 = 0; k0 < myn && listed; k0 += 64) {
-            const int k = k0 + lane;
-            float4 lo = make_float4(0.f, 0.f, 0.f, 0.f), hi = lo;
-            bool near = false;
-            if (k < myn) {
-                lo = T.bounds[2 * (4 * k + wave)];
-                hi = T.bounds[2 * (4 * k + wave) + 1];
-                near = !(box_d2(lo, hi, wx, wy, wz) > r2);
-            }
-            unsigned long long m = __ballot(near);
-            while (m) {                                          // wave-uniform loop over the near chunks of this round
-                const int b = __ffsll((long long)m) - 1;
-                m &= m - 1;
-                float4 blo, bhi;                                 // lane b's box, broadcast
-                blo.x = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(lo.x), b));
-                blo.y = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(lo.y), b));
-                blo.z = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(lo.z), b));
-                bhi.x = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(hi.x), b));
-                bhi.y = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(hi.y), b));
-                bhi.z = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(hi.z), b));
-                bool hit = false;
+        const int nsuper = (nchunk + ST4_SUPER - 1) / ST4_SUPER;
+        for (int s0 = 0; s0 < nsuper && listed; s0 += 64) {
+            const int si = s0 + lane;
+            bool nearS = false;
+            if (si < nsuper) nearS = !(box_d2(T.sbounds[2 * si], T.sbounds[2 * si + 1], wx, wy, wz) > r2);
+            unsigned long long ms = __ballot(nearS);
+            while (ms && listed) {                               // batches of 64 / CPS near super-cells
+                int mysuper = -1, e = 0;
+                while (ms && e < 64 / CPS) {                     // lane l serves the (l / CPS)-th near super-cell of the batch
+                    const int bsup = __ffsll((long long)ms) - 1;
+                    ms &= ms - 1;
+                    if ((lane / CPS) == e) mysuper = s0 + bsup;
+                    ++e;
+                }
+                const int ci = mysuper * ST4_SUPER + WPG * (lane % CPS) + sub;
+                float4 lo = make_float4(0.f, 0.f, 0.f, 0.f), hi = lo;
+                bool near = false;
+                if (mysuper >= 0 && ci < nchunk) {
+                    lo = T.bounds[2 * ci];
+                    hi = T.bounds[2 * ci + 1];
+                    near = !(box_d2(lo, hi, wx, wy, wz) > r2);
+                }
+                unsigned long long m = __ballot(near);
+                while (m) {                                      // wave-uniform loop over the near chunks of this batch
+                    const int b = __ffsll((long long)m) - 1;
+                    m &= m - 1;
+                    float4 blo, bhi;                             // lane b's box, broadcast
+                    blo.x = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(lo.x), b));
+                    blo.y = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(lo.y), b));
+                    blo.z = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(lo.z), b));
+                    bhi.x = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(hi.x), b));
+                    bhi.y = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(hi.y), b));
+                    bhi.z = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(hi.z), b));
+                    bool hit = false;
 #pragma unroll
-                for (int n = 0; n < NQ; ++n) hit |= box_d2(blo, bhi, qx[n], qy[n], qz[n]) <= sb[n];
-                if (__any(hit)) {
-                    if (nsurv >= ST4_MAXLIST) { listed = false; break; }
-                    if (lane == 0) slist[wave][nsurv] = (unsigned short)(k0 + b);
-                    ++nsurv;
+                    for (int n = 0; n < NQ; ++n) hit |= box_d2(blo, bhi, qx[n], qy[n], qz[n]) <= sb[n];
+                    if (__any(hit)) {
+                        if (nsurv >= ST4_MAXLIST) { listed = false; break; }
+                        const int cb = __builtin_amdgcn_readlane(ci, b);
+                        if (lane == 0) slist[wave][nsurv] = (unsigned short)(cb / WPG);    // k of chunk WPG k + sub
+                        ++nsurv;
+                    }
                 }
             }
         }
@@ -729,14 +757,14 @@ __global__ __launch_bounds__(256) void nn_stream4_kernel(const float* __restrict
     static_assert(NT == 2 * ST4_PF, "the prefetch ring assumes two ring turns per chunk");
 
     if (nsurv > 0) {
-        int ch = 4 * (listed ? (int)slist[wave][0] : 0) + wave;
+        int ch = WPG * (listed ? (int)slist[wave][0] : 0) + sub;
         const uint4* fr = T.frags + (size_t)ch * NT * 64 + lane;          // [tile][half][col] == [tile][lane]
         uint4 f[ST4_PF];
 #pragma unroll
         for (int j = 0; j < ST4_PF; ++j) f[j] = fr[j * 64];
         for (int s = 0; s < nsurv; ++s) {
             const int s1 = min(s + 1, nsurv - 1);                          // last survivor: harmless re-fetch of itself
-            const int ch_next = 4 * (listed ? (int)slist[wave][s1] : s1) + wave;
+            const int ch_next = WPG * (listed ? (int)slist[wave][s1] : s1) + sub;
             const uint4* fr_next = T.frags + (size_t)ch_next * NT * 64 + lane;
             const float4 cc = T.centers[ch];
             FDC_STAT(3, lane == 0);
@@ -785,12 +813,15 @@ __global__ __launch_bounds__(256) void nn_stream4_kernel(const float* __restrict
                             const int r = __ffs(mask) - 1;
                             mask &= mask - 1;
                             const int pos = base + tile * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
-                            if (pos < T.n && pos != own_pos[n]) {
+                            if (pos < T.n && pos != __float_as_int(own_p[n].w)) {
                                 FDC_STAT(2, 1);
                                 const float4 p = T.pts[pos];
                                 const int gi = __float_as_int(p.w);
                                 const float d = nn_exact_d2(qx[n], qy[n], qz[n], p.x, p.y, p.z);
-                                if (nn_better(d, gi, own_d[n], own_i[n])) { own_d[n] = d; own_i[n] = gi; own_pos[n] = pos; }
+                                if (nn_better(d, gi, own_d[n], own_i[n])) {
+                                    own_d[n] = d; own_i[n] = gi;
+                                    own_p[n] = make_float4(p.x, p.y, p.z, __int_as_float(pos));
+                                }
                             }
                         }
                         const float sbest = fminf(own_d[n], __shfl_xor(own_d[n], 32, 64));
@@ -807,35 +838,50 @@ __global__ __launch_bounds__(256) void nn_stream4_kernel(const float* __restrict
     for (int n = 0; n < NQ; ++n) {
         const float od = __shfl_xor(own_d[n], 32, 64);
         const int oi = __shfl_xor(own_i[n], 32, 64);
-        if (oi >= 0 && (own_i[n] < 0 || nn_better(od, oi, own_d[n], own_i[n]))) { own_d[n] = od; own_i[n] = oi; }
-        if (half == 0) { s_d[wave][n * 32 + col] = own_d[n]; s_i[wave][n * 32 + col] = own_i[n]; }
+        float4 op;
+        op.x = __shfl_xor(own_p[n].x, 32, 64); op.y = __shfl_xor(own_p[n].y, 32, 64);
+        op.z = __shfl_xor(own_p[n].z, 32, 64); op.w = __shfl_xor(own_p[n].w, 32, 64);
+        if (oi >= 0 && (own_i[n] < 0 || nn_better(od, oi, own_d[n], own_i[n]))) { own_d[n] = od; own_i[n] = oi; own_p[n] = op; }
+        if (half == 0) { s_d[wave][n * 32 + col] = own_d[n]; s_i[wave][n * 32 + col] = own_i[n]; s_p[wave][n * 32 + col] = own_p[n]; }
     }
     __syncthreads();
 #ifdef FDC_NN_STATS
     for (int i = 0; i < 4; ++i) atomicAdd(&g_nn_stats[i], (unsigned long long)st_cnt[i]);
 #endif
-    if (tid < 32 * NQ && wq0 + tid < nq) {
-        float bd = s_d[0][tid];
-        int bi = s_i[0][tid];
+    if (tid < GPW * 32 * NQ) {
+        const int g = tid / (32 * NQ), e = tid % (32 * NQ);      // group slot of this workgroup, query of the group
+        const int qo = (wg * GPW + g) * (32 * NQ) + e;
+        if (wg < nwg && qo < nq) {
+            int bw = g * WPG;
+            float bd = s_d[bw][e];
+            int bi = s_i[bw][e];
 #pragma unroll
-        for (int w = 1; w < 4; ++w) {
-            const float d = s_d[w][tid];
-            const int i = s_i[w][tid];
-            if (i >= 0 && (bi < 0 || nn_better(d, i, bd, bi))) { bd = d; bi = i; }
+            for (int w = 1; w < WPG; ++w) {
+                const float d = s_d[g * WPG + w][e];
+                const int i = s_i[g * WPG + w][e];
+                if (i >= 0 && (bi < 0 || nn_better(d, i, bd, bi))) { bd = d; bi = i; bw = g * WPG + w; }
+            }
+            dist[qo] = bd;
+            idx[qo] = bi;
+            seedpt[qo] = s_p[bw][e];
         }
-        dist[wq0 + tid] = bd;
-        idx[wq0 + tid] = bi;
     }
 }
 
 // Seeds for queries that have none (the first iteration of a fit): any scene point gives a valid upper
 // bound, a good one makes the culled scan cheap.  Thread per query: nearest chunk box (all boxes, read
 // wave-uniformly), then the nearest point of that one chunk.  Pruning aid only -- results do not depend on it.
-__global__ __launch_bounds__(256) void nn_seed_kernel(const float* __restrict__ q, int nq, NNTarget T, int* __restrict__ seed) {
+__global__ __launch_bounds__(256) void nn_seed_kernel(const float* __restrict__ q, int nq, NNTarget T, int* __restrict__ seed,
+                                                      float4* __restrict__ seedpt) {
     const int qi = blockIdx.x * 256 + threadIdx.x;
     if (qi >= nq) return;
     const int old = seed[qi];
-    if (old >= 0 && old < T.n) return;
+    if (old >= 0 && old < T.n) {                              // a seed without its coordinates (kept from another kernel): fetch them
+        const int pos = T.inv_perm ? T.inv_perm[old] : old;
+        const float4 pt = T.pts[pos];
+        seedpt[qi] = make_float4(pt.x, pt.y, pt.z, __int_as_float(pos));
+        return;
+    }
     const float x = q[3 * (size_t)qi], y = q[3 * (size_t)qi + 1], z = q[3 * (size_t)qi + 2];
     const int nchunk = (T.n + MF_CH - 1) / MF_CH;
     float bb = INFINITY;
@@ -847,13 +893,15 @@ __global__ __launch_bounds__(256) void nn_seed_kernel(const float* __restrict__ 
     if (bc < 0) return;                                       // NaN query: stays unseeded (the scan handles it)
     float bd = INFINITY;
     int bi = -1;
+    float4 bp = make_float4(0.f, 0.f, 0.f, __int_as_float(-1));
     const int p0 = bc * MF_CH, p1 = min(T.n, p0 + MF_CH);
     for (int p = p0; p < p1; ++p) {
         const float4 pt = T.pts[p];
         const float d = nn_exact_d2(x, y, z, pt.x, pt.y, pt.z);
-        if (d < bd) { bd = d; bi = __float_as_int(pt.w); }
+        if (d < bd) { bd = d; bi = __float_as_int(pt.w); bp = make_float4(pt.x, pt.y, pt.z, __int_as_float(p)); }
     }
     seed[qi] = bi;
+    seedpt[qi] = bp;
 }
 
 __global__ void nn_combine_kernel(const float* __restrict__ pd, const int* __restrict__ pi, int nsplit, int nq,
@@ -925,7 +973,8 @@ static inline int nn_pick_nsplit(int nq, int nt, bool culled = false) {
 
 // workspace: pd/pi [nsplit*nq]; seed: optional [nq] original indices (may alias idx: read before idx is rewritten)
 static inline hipError_t nn_search(const float* q, int nq, const NNTarget& T, float* dist, int* idx, float* pd, int* pi,
-                                   int nsplit, hipStream_t st, const int* seed = nullptr, bool seed_missing = false) {
+                                   int nsplit, hipStream_t st, const int* seed = nullptr, bool seed_missing = false,
+                                   float4* seedpt = nullptr) {
     if (nq <= 0) return hipSuccess;
     // Query blocks per workgroup: 4 waves x NQ x 32.  A brute-force scan wants NQ = 4 (most MFMAs per
     // staged chunk: 9.7 ms vs 10.9 at NQ = 2); a seeded + chunk-culled scan wants NQ = 2 (the union of
@@ -934,22 +983,35 @@ static inline hipError_t nn_search(const float* q, int nq, const NNTarget& T, fl
     static int forced_nq = -1;
     if (forced_nq < 0) { const char* e = getenv("FDCAP_NN_NQ"); forced_nq = e ? atoi(e) : 0; }
     const bool culled = seed != nullptr && T.bounds != nullptr;
-    // FDCAP_NN_STREAM (A/B): 0 staged kernel, 1 one wave per 64-query group, 42 four waves per 64-query group,
-    // default 41: four waves per 32-query group (0.186 ms vs 0.208 at 512k queries, 0.037 vs 0.049 at 64k)
+    // FDCAP_NN_STREAM (A/B): 0 staged kernel, 1 the first streaming kernel, WQ = nn_stream4_kernel with W waves per
+    // group of 32 Q queries (41, 42, 21, 22, 11, 12); default: 32-query groups, waves per group by launch size --
+    // measured (1024 x 500 / 128 x 500 queries): 11: 0.146 / 0.071 ms, 21: 0.161 / 0.047, 41: 0.179 / 0.039
     static int use_stream = -1;
-    if (use_stream < 0) { const char* e = getenv("FDCAP_NN_STREAM"); use_stream = e ? atoi(e) : 41; }
+    if (use_stream < 0) { const char* e = getenv("FDCAP_NN_STREAM"); use_stream = e ? atoi(e) : -2; }
     if (culled && T.frags != nullptr && use_stream && nn_use_mfma(nq, T.n)) {
-        if (seed == idx && seed_missing)                      // first launch of a fit: cheap seeds instead of a full scan
-            hipLaunchKernelGGL(nn_seed_kernel, dim3((nq + 255) / 256), dim3(256), 0, st, q, nq, T, idx);
+        const bool four = (use_stream > 1 || use_stream < 0) && seedpt != nullptr && seed == idx;
+        if (four && seed_missing)                             // first launch of a fit: cheap seeds (+ their coordinates) instead of a full scan
+            hipLaunchKernelGGL(nn_seed_kernel, dim3((nq + 255) / 256), dim3(256), 0, st, q, nq, T, idx, seedpt);
         // seed may alias idx: every workgroup reads its seeds before it writes its own results, and no other workgroup touches them
-        if (use_stream == 1) {
+        if (!four) {
             hipLaunchKernelGGL((nn_stream_kernel<2>), dim3((nq + 255) / 256), dim3(256), 0, st, q, nq, T, seed, dist, idx);
-        } else if (use_stream == 42) {
-            const int groups = (nq + 63) / 64;
-            hipLaunchKernelGGL((nn_stream4_kernel<2>), dim3((groups + 7) / 8 * 8), dim3(256), 0, st, q, nq, T, seed, dist, idx);
         } else {
-            const int groups = (nq + 31) / 32;
-            hipLaunchKernelGGL((nn_stream4_kernel<1>), dim3((groups + 7) / 8 * 8), dim3(256), 0, st, q, nq, T, seed, dist, idx);
+            // (queries per group / 32, waves per group): 42 / 41 four waves, 22 / 21 two, 12 / 11 one
+            int nqv = 1, wpg;
+            if (use_stream < 0) {                             // enough waves to fill 1024 SIMDs x 4 twice over, no more (the
+                const int g32 = (nq + 31) / 32;               // per-group setup is repeated by every wave of the group)
+                wpg = g32 >= 6144 ? 1 : g32 >= 3072 ? 2 : 4;
+            } else {
+                nqv = (use_stream % 10 == 2) ? 2 : 1;
+                wpg = (use_stream / 10 == 4) ? 4 : (use_stream / 10 == 2) ? 2 : 1;
+            }
+            const int groups = (nq + 32 * nqv - 1) / (32 * nqv);
+            const int nwg = (groups * wpg + 3) / 4;
+            const dim3 grid((nwg + 7) / 8 * 8);
+#define FDC_ST4(NQV, WPGV) hipLaunchKernelGGL((nn_stream4_kernel<NQV, WPGV>), grid, dim3(256), 0, st, q, nq, T, seed, seedpt, dist, idx)
+            if (nqv == 2 && wpg == 4) FDC_ST4(2, 4); else if (nqv == 2 && wpg == 2) FDC_ST4(2, 2); else if (nqv == 2) FDC_ST4(2, 1);
+            else if (wpg == 4) FDC_ST4(1, 4); else if (wpg == 2) FDC_ST4(1, 2); else FDC_ST4(1, 1);
+#undef FDC_ST4
         }
         return hipGetLastError();
     }

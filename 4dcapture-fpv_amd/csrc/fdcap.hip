@@ -572,6 +572,7 @@ struct OptState {
     DevBuf<float> Rm, PF, Jrest, G, A, M, Jw;
     DevBuf<float> Voff, Vw, dist, pd, dVoff;
     DevBuf<int> idx, pi;
+    DevBuf<float4> seedpt;    // coordinates (+ position in the sorted scene) of each query's current neighbour: next launch's seed
     DevBuf<float> dA, dbeta_v, dtransl_v, dMv, dsv, dPF, dJw, dX, dCAM, dscale_row;
     DevBuf<float> VoffF, VwF, dVF;      // mode 'local' second loop: full-mesh pose offsets / world vertices / gradient
     int cam_steps = 0;
@@ -602,12 +603,14 @@ struct fdcap_ctx {
     DevBuf<float4> scene;          // original order {x,y,z,bits(i)}: gradient gather by index
     DevBuf<float4> scene_sorted;   // Morton order {x,y,z,bits(original index)}: what the NN scan streams
     DevBuf<float4> scene_bounds;   // axis-aligned box {lo},{hi} of each MF_CH-point chunk of scene_sorted
+    DevBuf<float4> scene_sbounds;  // ... of each run of ST4_SUPER chunks
     DevBuf<int> scene_inv;         // original index -> position in scene_sorted
     DevBuf<uint4> scene_frags;     // precomputed chunk-centred bf16 MFMA A fragments of scene_sorted
     DevBuf<float4> scene_centers;  // chunk centres {x,y,z,radius}
     int64_t ns = 0;
     NNTarget nn_target(bool cull) const {
         NNTarget t; t.pts = scene_sorted.p; t.n = (int)ns; t.bounds = cull ? scene_bounds.p : nullptr; t.inv_perm = scene_inv.p;
+        t.sbounds = cull ? scene_sbounds.p : nullptr;
         t.frags = cull ? scene_frags.p : nullptr; t.centers = scene_centers.p;
         return t;
     }
@@ -766,7 +769,7 @@ void fdcap_ctx_destroy(fdcap_ctx* c) {
     c->Jt.release(); c->Jd.release(); c->hand_comp.release(); c->hand_mean.release();
     c->parents.release(); c->order.release(); c->level_start.release(); c->child_start.release(); c->child_list.release();
     c->W1.release(); c->b1.release(); c->W2.release(); c->b2.release(); c->W3.release(); c->b3.release();
-    c->full.release(); c->contact.release(); c->contact_vid.release(); c->contact_perm.release(); c->scene.release(); c->scene_sorted.release(); c->scene_bounds.release(); c->scene_inv.release(); c->scene_frags.release(); c->scene_centers.release();
+    c->full.release(); c->contact.release(); c->contact_vid.release(); c->contact_perm.release(); c->scene.release(); c->scene_sorted.release(); c->scene_bounds.release(); c->scene_sbounds.release(); c->scene_inv.release(); c->scene_frags.release(); c->scene_centers.release();
     for (auto& b : c->ws_f) b.release();
     for (auto& b : c->ws_i) b.release();
     c->ws_p.release();
@@ -864,6 +867,19 @@ int fdcap_set_scene(fdcap_ctx* c, const float* xyz, int64_t ns) {
     HIP_TRY(c->scene.upload(orig.data(), orig.size()));
     HIP_TRY(c->scene_sorted.upload(sorted.data(), sorted.size()));
     HIP_TRY(c->scene_bounds.upload(bounds.data(), bounds.size()));
+    {
+        const int64_t nsuper = (nchunk + ST4_SUPER - 1) / ST4_SUPER;
+        std::vector<float4> sb((size_t)std::max<int64_t>(nsuper, 1) * 2, make_float4(0.f, 0.f, 0.f, 0.f));
+        for (int64_t su = 0; su < nsuper; ++su) {
+            float4 lo = make_float4(1e30f, 1e30f, 1e30f, 0.f), hi = make_float4(-1e30f, -1e30f, -1e30f, 0.f);
+            for (int64_t ch = su * ST4_SUPER; ch < std::min(nchunk, (su + 1) * ST4_SUPER); ++ch) {
+                lo.x = std::min(lo.x, bounds[2 * ch].x); lo.y = std::min(lo.y, bounds[2 * ch].y); lo.z = std::min(lo.z, bounds[2 * ch].z);
+                hi.x = std::max(hi.x, bounds[2 * ch + 1].x); hi.y = std::max(hi.y, bounds[2 * ch + 1].y); hi.z = std::max(hi.z, bounds[2 * ch + 1].z);
+            }
+            sb[2 * su] = lo; sb[2 * su + 1] = hi;
+        }
+        HIP_TRY(c->scene_sbounds.upload(sb.data(), sb.size()));
+    }
     HIP_TRY(c->scene_inv.upload(inv.data(), inv.size()));
     c->ns = ns;
     return FDCAP_OK;
@@ -922,7 +938,7 @@ int fdcap_chamfer_fwd(fdcap_ctx* c, const float* xyz1, const float* xyz2, int32_
         int nsplit = nn_pick_nsplit(nq, m);
         HIP_TRY(c->ws_f[0].ensure((size_t)nsplit * nq));
         HIP_TRY(c->ws_i[0].ensure((size_t)nsplit * nq));
-        { NNTarget T{c->ws_p.p, m, nullptr, nullptr, nullptr, nullptr}; HIP_TRY(nn_search(xyz1, nq, T, dist1, idx1, c->ws_f[0].p, c->ws_i[0].p, nsplit, st)); }
+        { NNTarget T{c->ws_p.p, m, nullptr, nullptr, nullptr, nullptr, nullptr}; HIP_TRY(nn_search(xyz1, nq, T, dist1, idx1, c->ws_f[0].p, c->ws_i[0].p, nsplit, st)); }
     }
     for (int b = 0; b < B && (!shared || dist2); ++b) {
         const float* x1 = xyz1 + (size_t)b * n * 3;
@@ -933,14 +949,14 @@ int fdcap_chamfer_fwd(fdcap_ctx* c, const float* xyz1, const float* xyz2, int32_
             int nsplit = nn_pick_nsplit(n, m);
             HIP_TRY(c->ws_f[0].ensure((size_t)nsplit * n));
             HIP_TRY(c->ws_i[0].ensure((size_t)nsplit * n));
-            { NNTarget T{pk, m, nullptr, nullptr, nullptr, nullptr}; HIP_TRY(nn_search(x1, n, T, dist1 + (size_t)b * n, idx1 + (size_t)b * n, c->ws_f[0].p, c->ws_i[0].p, nsplit, st)); }
+            { NNTarget T{pk, m, nullptr, nullptr, nullptr, nullptr, nullptr}; HIP_TRY(nn_search(x1, n, T, dist1 + (size_t)b * n, idx1 + (size_t)b * n, c->ws_f[0].p, c->ws_i[0].p, nsplit, st)); }
         }
         if (dist2) {
             hipLaunchKernelGGL(pack_points_kernel, dim3((n + 255) / 256), dim3(256), 0, st, x1, n, pk);
             int nsplit = nn_pick_nsplit(m, n);
             HIP_TRY(c->ws_f[1].ensure((size_t)nsplit * m));
             HIP_TRY(c->ws_i[1].ensure((size_t)nsplit * m));
-            { NNTarget T{pk, n, nullptr, nullptr, nullptr, nullptr}; HIP_TRY(nn_search(x2, m, T, dist2 + (size_t)b * m, idx2 + (size_t)b * m, c->ws_f[1].p, c->ws_i[1].p, nsplit, st)); }
+            { NNTarget T{pk, n, nullptr, nullptr, nullptr, nullptr, nullptr}; HIP_TRY(nn_search(x2, m, T, dist2 + (size_t)b * m, idx2 + (size_t)b * m, c->ws_f[1].p, c->ws_i[1].p, nsplit, st)); }
         }
     }
     return (int)hipGetLastError();
@@ -1084,7 +1100,7 @@ void fdcap_opt_destroy(fdcap_ctx* c) {
                            &o->dsv, &o->dPF, &o->dJw, &o->dX, &o->dCAM, &o->dscale_row, &o->VoffF, &o->VwF, &o->dVF};
     for (auto* b : fb) b->release();
     o->dctD.release(); o->dctCoef.release(); o->dctM.release(); o->dctV.release(); o->adam_tab.release();
-    o->idx.release(); o->pi.release();
+    o->idx.release(); o->pi.release(); o->seedpt.release();
     delete o;
     c->opt = nullptr;
 }
@@ -1129,7 +1145,7 @@ int fdcap_opt_create(fdcap_ctx* c, const fdcap_opt_config* cfg, float* rows_x, f
     AL(o->dsv, R) AL(o->dPF, (size_t)R * NPF) AL(o->dJw, (size_t)R * NJW * 3) AL(o->dX, (size_t)R * XDIM)
     AL(o->dCAM, (size_t)R * 16) AL(o->dscale_row, R)
     if (o->contact_on) {
-        AL(o->Voff, nq * 3) AL(o->Vw, nq * 3) AL(o->dist, nq) AL(o->idx, nq) AL(o->dVoff, nq * 3)
+        AL(o->Voff, nq * 3) AL(o->Vw, nq * 3) AL(o->dist, nq) AL(o->idx, nq) AL(o->dVoff, nq * 3) AL(o->seedpt, nq)
         AL(o->pd, (size_t)std::max(o->nsplit, o->nsplit_bf) * nq) AL(o->pi, (size_t)std::max(o->nsplit, o->nsplit_bf) * nq)
     }
 #undef AL
@@ -1170,7 +1186,7 @@ static int opt_contact_forward(fdcap_ctx* c, hipStream_t st) {
     const int nq = nl * nc;
     // the first contact forward of a fit has no neighbours from a previous iteration yet (idx = -1)
     HIP_TRY(nn_search(o->Vw.p + off, nq, c->nn_target(o->use_cull), o->dist.p + 2 * nc, o->idx.p + 2 * nc, o->pd.p, o->pi.p,
-                      o->nsplit, st, o->use_seed ? o->idx.p + 2 * nc : nullptr, !o->seeded));
+                      o->nsplit, st, o->use_seed ? o->idx.p + 2 * nc : nullptr, !o->seeded, o->seedpt.p + 2 * nc));
     o->seeded = true;
     return 0;
 }
@@ -1583,10 +1599,11 @@ int fdcap_opt_time_chamfer(fdcap_ctx* c, int32_t iters, int32_t brute_force, flo
     HIP_TRY(hipEventCreate(&e0));
     HIP_TRY(hipEventCreate(&e1));
     const int nsp = brute_force ? o->nsplit_bf : o->nsplit;
-    HIP_TRY(nn_search(o->Vw.p + off, nl * nc, T, o->dist.p + 2 * nc, o->idx.p + 2 * nc, o->pd.p, o->pi.p, nsp, st, seed));
+    float4* sp = brute_force ? nullptr : o->seedpt.p + 2 * nc;
+    HIP_TRY(nn_search(o->Vw.p + off, nl * nc, T, o->dist.p + 2 * nc, o->idx.p + 2 * nc, o->pd.p, o->pi.p, nsp, st, seed, false, sp));
     HIP_TRY(hipEventRecord(e0, st));
     for (int i = 0; i < iters; ++i)
-        HIP_TRY(nn_search(o->Vw.p + off, nl * nc, T, o->dist.p + 2 * nc, o->idx.p + 2 * nc, o->pd.p, o->pi.p, nsp, st, seed));
+        HIP_TRY(nn_search(o->Vw.p + off, nl * nc, T, o->dist.p + 2 * nc, o->idx.p + 2 * nc, o->pd.p, o->pi.p, nsp, st, seed, false, sp));
     HIP_TRY(hipEventRecord(e1, st));
     HIP_TRY(hipEventSynchronize(e1));
     float t = 0.f;
@@ -1594,6 +1611,7 @@ int fdcap_opt_time_chamfer(fdcap_ctx* c, int32_t iters, int32_t brute_force, flo
     *ms = t / iters;
     (void)hipEventDestroy(e0);
     (void)hipEventDestroy(e1);
+    if (brute_force) o->seeded = false;      // idx was rewritten without the neighbours' coordinates: refresh them before the next seeded launch
     return FDCAP_OK;
 }
 
