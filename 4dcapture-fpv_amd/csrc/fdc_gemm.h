@@ -10,6 +10,7 @@
 // fragment reads (lanes walk rows, fixed k) are bank-conflict free.
 #pragma once
 #include <hip/hip_runtime.h>
+#include <stdlib.h>
 
 namespace fdc {
 
@@ -191,6 +192,94 @@ __global__ __launch_bounds__(256) void gemm_f32_mfma_ksplit_kernel(
     }
 }
 
+// The same scheme on 16x16 output tiles (v_mfma_f32_16x16x4_f32): four times the workgroups and a 19 KB LDS
+// footprint, for products whose 32x32 grid leaves most CUs with one or two workgroups -- there every K slab
+// costs a full, exposed global-load latency (one slab = 2 x TS x 128 floats in flight per workgroup), and only
+// more resident workgroups per CU hide it.  Same fixed-order sum of the four K-quarters.
+typedef float f32x4_t __attribute__((ext_vector_type(4)));
+template <bool B_IS_NK, int EPI>
+__global__ __launch_bounds__(256) void gemm_f32_mfma_ksplit16_kernel(
+    const float* __restrict__ A, int lda, const float* __restrict__ B, int ldb, float* __restrict__ C,
+    int ldc, int M, int N, int K, const float* __restrict__ aux, int ldaux) {
+    constexpr int TS = 16, BK = 128, LD = BK + 1, NLD = (TS * BK) / 256;   // 8 loads per operand per thread
+    __shared__ float As[TS * LD];
+    __shared__ float Bs[TS * LD];
+    __shared__ float Red[3][TS * TS];
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int m0 = blockIdx.y * TS, n0 = blockIdx.x * TS;
+    f32x4_t acc = {0.f, 0.f, 0.f, 0.f};
+    float ra[NLD], rb[NLD];
+    auto gload = [&](int k0) {
+#pragma unroll
+        for (int i = 0; i < NLD; ++i) {
+            int e = tid + i * 256, r = e >> 7, c = e & 127;
+            int gm = m0 + r, gk = k0 + c;
+            ra[i] = (gm < M && gk < K) ? A[(size_t)gm * lda + gk] : 0.f;
+        }
+        if (B_IS_NK) {
+#pragma unroll
+            for (int i = 0; i < NLD; ++i) {
+                int e = tid + i * 256, r = e >> 7, c = e & 127;
+                int gn = n0 + r, gk = k0 + c;
+                rb[i] = (gn < N && gk < K) ? B[(size_t)gn * ldb + gk] : 0.f;
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < NLD; ++i) {
+                int e = tid + i * 256, kk = e >> 4, nn = e & 15;
+                int gn = n0 + nn, gk = k0 + kk;
+                rb[i] = (gn < N && gk < K) ? B[(size_t)gk * ldb + gn] : 0.f;
+            }
+        }
+    };
+    auto lstore = [&]() {
+#pragma unroll
+        for (int i = 0; i < NLD; ++i) {
+            int e = tid + i * 256;
+            As[(e >> 7) * LD + (e & 127)] = ra[i];
+            if (B_IS_NK) Bs[(e >> 7) * LD + (e & 127)] = rb[i];
+            else Bs[(e & 15) * LD + (e >> 4)] = rb[i];
+        }
+    };
+    gload(0);
+    for (int k0 = 0; k0 < K; k0 += BK) {
+        lstore();
+        __syncthreads();
+        if (k0 + BK < K) gload(k0 + BK);                    // in flight during the MFMAs below
+        const int kq = wave * 32;                           // this wave's quarter of the slab
+#pragma unroll
+        for (int kk = 0; kk < 32; kk += 4) {
+            float a = As[(lane & 15) * LD + kq + kk + (lane >> 4)];
+            float b = Bs[(lane & 15) * LD + kq + kk + (lane >> 4)];
+            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, acc, 0, 0, 0);
+        }
+        __syncthreads();
+    }
+    if (wave > 0) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) Red[wave - 1][r * 64 + lane] = acc[r];
+    }
+    __syncthreads();
+    if (wave == 0) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            float v = acc[r] + Red[0][r * 64 + lane];
+            v += Red[1][r * 64 + lane];
+            v += Red[2][r * 64 + lane];
+            int m = m0 + 4 * (lane >> 4) + r;               // C/D layout of the 16x16 tile: col = lane & 15, row = 4 * (lane >> 4) + reg
+            int n = n0 + (lane & 15);
+            if (m < M && n < N) {
+                if (EPI == EPI_BIAS || EPI == EPI_BIAS_LRELU) v += aux[n];
+                if (EPI == EPI_BIAS_LRELU) v = v > 0.f ? v : 0.2f * v;
+                if (EPI == EPI_MASK_LRELU) v *= (aux[(size_t)m * ldaux + n] > 0.f) ? 1.f : 0.2f;
+                float* dst = C + (size_t)m * ldc + n;
+                if (EPI == EPI_ACCUM) v += *dst;
+                *dst = v;
+            }
+        }
+    }
+}
+
 // Wide "NN" product C[M,N] = A[M,K] x B[K,N] with N >> M (the full-mesh pose blendshapes:
 // M = frames ~ 1e3, K = 486, N = 3V = 31 425).  B (61 MB) is the only operand that does not fit in
 // L2, so the blockIdx -> tile map keeps all M-tiles of one 128-column B panel on ONE XCD, back to
@@ -284,6 +373,14 @@ static inline hipError_t gemm_dispatch_tile(const float* A, int lda, const float
     if (M <= 0 || N <= 0) return hipSuccess;
     // skinny / small outputs (every product of the optimiser loop): 32x32 tiles, intra-workgroup split-K
     if ((long long)M * N < 64LL * 64 * 1024 && K >= 32) {
+        static int t16 = -1;                                 // FDCAP_GEMM_T16: 32x32-tile count below which 16x16 tiles are used (A/B)
+        if (t16 < 0) { const char* e = getenv("FDCAP_GEMM_T16"); t16 = e ? atoi(e) : 1024; }
+        if ((long long)((N + 31) / 32) * ((M + 31) / 32) < t16) {
+            dim3 grid((N + 15) / 16, (M + 15) / 16);
+            hipLaunchKernelGGL((gemm_f32_mfma_ksplit16_kernel<NK, EPI>), grid, dim3(256), 0, st, A, lda, B, ldb, C, ldc, M, N, K,
+                               aux, ldaux);
+            return hipGetLastError();
+        }
         dim3 grid((N + 31) / 32, (M + 31) / 32);
         hipLaunchKernelGGL((gemm_f32_mfma_ksplit_kernel<NK, EPI>), grid, dim3(256), 0, st, A, lda, B, ldb, C, ldc, M, N, K,
                            aux, ldaux);
