@@ -19,6 +19,7 @@ constexpr int NJ = 55;          // SMPL-X joints
 constexpr int NJW = 23;         // world joints the reference reads (joints[:, 0:23], :298)
 constexpr int NBETA = 10;
 constexpr int NPF = (NJ - 1) * 9;   // 486 pose-feature columns
+constexpr int NPFX = NPF + NBETA;   // 496: row of the blend GEMMs' operand [pose feature | betas] (shape blend folded in)
 constexpr int XDIM = 78;        // optimised parameter row
 constexpr int X_TRANSL = 0, X_SIXD = 3, X_BETAS = 9, X_LATENT = 19, X_LH = 51, X_RH = 63, X_CAMT = 75;
 constexpr int ODIM = 126;       // VPoser decoder output (21 joints x 6D)

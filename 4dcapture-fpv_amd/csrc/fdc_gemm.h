@@ -373,9 +373,13 @@ static inline hipError_t gemm_dispatch_tile(const float* A, int lda, const float
     if (M <= 0 || N <= 0) return hipSuccess;
     // skinny / small outputs (every product of the optimiser loop): 32x32 tiles, intra-workgroup split-K
     if ((long long)M * N < 64LL * 64 * 1024 && K >= 32) {
-        static int t16 = -1;                                 // FDCAP_GEMM_T16: 32x32-tile count below which 16x16 tiles are used (A/B)
+        // 16x16 tiles read twice the operand bytes per MAC: they pay off while the grid is small (latency-bound) and
+        // K is short; the K = 1500 pose-blend data-gradient at 1024 frames (528 32x32 tiles) is L2-bandwidth-bound
+        // with them (35.9 us vs 31.3).  FDCAP_GEMM_T16 overrides the tile-count threshold (A/B).
+        static int t16 = -1;
         if (t16 < 0) { const char* e = getenv("FDCAP_GEMM_T16"); t16 = e ? atoi(e) : 1024; }
-        if ((long long)((N + 31) / 32) * ((M + 31) / 32) < t16) {
+        const long long tiles32 = (long long)((N + 31) / 32) * ((M + 31) / 32);
+        if (tiles32 < t16 / 4 || (tiles32 < t16 && K <= 768)) {
             dim3 grid((N + 15) / 16, (M + 15) / 16);
             hipLaunchKernelGGL((gemm_f32_mfma_ksplit16_kernel<NK, EPI>), grid, dim3(256), 0, st, A, lda, B, ldb, C, ldc, M, N, K,
                                aux, ldaux);

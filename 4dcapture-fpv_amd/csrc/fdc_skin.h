@@ -10,7 +10,8 @@ namespace fdc {
 
 struct SkinModel {
     const float* vt;      // [V,3]  v_template (+ constant expression offset folded in)
-    const float* S;       // [V,3,10] shapedirs (betas part)
+    const float* S;       // [V,3,10] shapedirs (betas part); null: the shape blend is folded into voff by the blend GEMM
+                          // (its operand rows are [pose feature | betas], its matrix [posedirs ; shapedirs^T])
     const int* wj;        // [V,K] joint ids of the non-zero skinning weights (padded with 0)
     const float* ww;      // [V,K] weights (padded with 0.0)
     int K;
@@ -30,8 +31,10 @@ FDC_HD SkinFwd skin_forward_vertex(const SkinModel& sm, int v, const float* beta
     float p[3];
     for (int c = 0; c < 3; ++c) {
         float acc = sm.vt[3 * v + c];
-        const float* s = sm.S + (3 * v + c) * 10;
-        for (int l = 0; l < 10; ++l) acc += s[l] * beta[l];
+        if (sm.S) {
+            const float* s = sm.S + (3 * v + c) * 10;
+            for (int l = 0; l < 10; ++l) acc += s[l] * beta[l];
+        }
         p[c] = acc + voff[c];
     }
     r.vp = v3(p[0], p[1], p[2]);

@@ -43,8 +43,9 @@ __global__ __launch_bounds__(64) void pose_fwd_kernel(PoseModel pm, const float*
                                                       float* M, float* Jw, const float* AA) {
     __shared__ PoseScratch sc;
     int r = row0 + blockIdx.x;
+    if (PF && threadIdx.x < NBETA) PF[(size_t)r * NPFX + NPF + threadIdx.x] = X[(size_t)r * XDIM + X_BETAS + threadIdx.x];
     pose_forward(pm, X + (size_t)r * XDIM, O ? O + (size_t)r * ODIM : nullptr, CAM + (size_t)r * 16, *scale, sc,
-                 Rm ? Rm + (size_t)r * NJ * 9 : nullptr, PF ? PF + (size_t)r * NPF : nullptr,
+                 Rm ? Rm + (size_t)r * NJ * 9 : nullptr, PF ? PF + (size_t)r * NPFX : nullptr,
                  Jrest ? Jrest + (size_t)r * NJ * 3 : nullptr, G ? G + (size_t)r * NJ * 12 : nullptr,
                  A ? A + (size_t)r * NJ * 12 : nullptr, M ? M + (size_t)r * 12 : nullptr,
                  Jw ? Jw + (size_t)r * NJW * 3 : nullptr, threadIdx.x, 64, SyncBlock(),
@@ -56,15 +57,15 @@ __global__ __launch_bounds__(64) void pose_bwd_kernel(PoseModel pm, const float*
                                                       int row0, const float* Rm, const float* Jrest, const float* G,
                                                       const float* dA, const float* dPF, const float* dJw,
                                                       const float* dMv, const float* dsv, const float* dbeta_v,
-                                                      const float* dtransl_v, float* dX, float* dO, float* dCAM,
-                                                      float* dscale_row) {
+                                                      int dbeta_stride, const float* dtransl_v, float* dX, float* dO,
+                                                      float* dCAM, float* dscale_row) {
     __shared__ PoseScratch sc;
     int r = row0 + blockIdx.x;
     pose_backward(pm, X + (size_t)r * XDIM, O + (size_t)r * ODIM, CAM + (size_t)r * 16, *scale,
                   Rm + (size_t)r * NJ * 9, Jrest + (size_t)r * NJ * 3, G + (size_t)r * NJ * 12,
-                  dA ? dA + (size_t)r * NJ * 12 : nullptr, dPF ? dPF + (size_t)r * NPF : nullptr,
+                  dA ? dA + (size_t)r * NJ * 12 : nullptr, dPF ? dPF + (size_t)r * NPFX : nullptr,
                   dJw ? dJw + (size_t)r * NJW * 3 : nullptr, dMv ? dMv + (size_t)r * 12 : nullptr,
-                  dsv ? dsv + r : nullptr, dbeta_v ? dbeta_v + (size_t)r * NBETA : nullptr,
+                  dsv ? dsv + r : nullptr, dbeta_v ? dbeta_v + (size_t)r * dbeta_stride : nullptr,
                   dtransl_v ? dtransl_v + (size_t)r * 3 : nullptr, sc, dX + (size_t)r * XDIM,
                   dO + (size_t)r * ODIM, dCAM + (size_t)r * 16, dscale_row + r, threadIdx.x, 64, SyncBlock());
 }
@@ -141,9 +142,10 @@ __global__ __launch_bounds__(256) void skin_bwd_kernel(SkinModel sm, int nc, con
                                             M + (size_t)r * 12, s);
             SkinBwd b = skin_backward_vertex(f, M + (size_t)r * 12, s, g);
             dVoff[3 * qi] = b.dvp.x; dVoff[3 * qi + 1] = b.dvp.y; dVoff[3 * qi + 2] = b.dvp.z;
-            for (int l = 0; l < NBETA; ++l)
-                acc[l] += sm.S[(3 * c) * 10 + l] * b.dvp.x + sm.S[(3 * c + 1) * 10 + l] * b.dvp.y +
-                          sm.S[(3 * c + 2) * 10 + l] * b.dvp.z;
+            if (sm.S)                                       // else: d betas = dVoff x shapedirs, columns 486.. of the blend data-gradient GEMM
+                for (int l = 0; l < NBETA; ++l)
+                    acc[l] += sm.S[(3 * c) * 10 + l] * b.dvp.x + sm.S[(3 * c + 1) * 10 + l] * b.dvp.y +
+                              sm.S[(3 * c + 2) * 10 + l] * b.dvp.z;
             acc[NBETA] += b.gv.x; acc[NBETA + 1] += b.gv.y; acc[NBETA + 2] += b.gv.z;
 #pragma unroll
             for (int e = 0; e < 12; ++e) acc[NBETA + 3 + e] += b.dM[e];
@@ -198,7 +200,7 @@ __global__ __launch_bounds__(256) void skin_bwd_kernel(SkinModel sm, int nc, con
     for (int i = tid; i < NJ * 12; i += 256) dA[(size_t)r * NJ * 12 + i] = sdA[i];
     if (tid < SKB_NACC) {
         float v = sred[0][tid] + sred[1][tid] + sred[2][tid] + sred[3][tid];
-        if (tid < NBETA) dbeta_v[(size_t)r * NBETA + tid] = v;
+        if (tid < NBETA) { if (dbeta_v) dbeta_v[(size_t)r * NBETA + tid] = v; }
         else if (tid < NBETA + 3) dtransl_v[(size_t)r * 3 + tid - NBETA] = v;
         else if (tid < NBETA + 15) dMv[(size_t)r * 12 + tid - NBETA - 3] = v;
         else dsv[r] = v;
@@ -549,10 +551,10 @@ struct DevBuf {
 
 struct SkinSet {          // skinning constants for a vertex set (all V, or the contact subset)
     int nv = 0, K = 0;
-    DevBuf<float> vt, S, ww, posedirs, csc_w;   // posedirs [486, 3*nv]
+    DevBuf<float> vt, S, ww, posedirs, csc_w;   // posedirs [496, 3*nv] = [posedirs ; shapedirs^T]
     DevBuf<int> wj, csc_start, csc_v;
     SkinModel model() const {
-        SkinModel m; m.vt = vt.p; m.S = S.p; m.wj = wj.p; m.ww = ww.p; m.K = K;
+        SkinModel m; m.vt = vt.p; m.S = nullptr; m.wj = wj.p; m.ww = ww.p; m.K = K;
         m.csc_start = csc_start.p; m.csc_v = csc_v.p; m.csc_w = csc_w.p;
         return m;
     }
@@ -645,12 +647,11 @@ int build_skin_set(fdcap_ctx* c, const std::vector<int64_t>& ids, SkinSet* out) 
         for (int j = 0; j < NJ; ++j) k += c->h_lbs[(size_t)v * NJ + j] != 0.f;
         K = std::max(K, k);
     }
-    std::vector<float> vt((size_t)nv * 3), S((size_t)nv * 30), ww((size_t)nv * K, 0.f), pd((size_t)NPF * 3 * nv);
+    std::vector<float> vt((size_t)nv * 3), ww((size_t)nv * K, 0.f), pd((size_t)NPFX * 3 * nv);
     std::vector<int> wj((size_t)nv * K, 0);
     for (int i = 0; i < nv; ++i) {
         int64_t v = ids[i];
         for (int k = 0; k < 3; ++k) vt[3 * i + k] = c->h_vt[3 * v + k];
-        for (int k = 0; k < 30; ++k) S[(size_t)30 * i + k] = c->h_S10[(size_t)30 * v + k];
         int k = 0;
         for (int j = 0; j < NJ; ++j) {
             float w = c->h_lbs[(size_t)v * NJ + j];
@@ -661,6 +662,11 @@ int build_skin_set(fdcap_ctx* c, const std::vector<int64_t>& ids, SkinSet* out) 
         for (int i = 0; i < nv; ++i)
             for (int k = 0; k < 3; ++k)
                 pd[(size_t)r * 3 * nv + 3 * i + k] = c->h_posedirs[(size_t)r * 3 * V + 3 * ids[i] + k];
+    // rows 486..495: shapedirs^T (betas part), so [pose feature | betas] x this matrix = pose offsets + shape offsets
+    for (int l = 0; l < NBETA; ++l)
+        for (int i = 0; i < nv; ++i)
+            for (int k = 0; k < 3; ++k)
+                pd[(size_t)(NPF + l) * 3 * nv + 3 * i + k] = c->h_S10[((size_t)3 * ids[i] + k) * 10 + l];
     std::vector<int> csc_start(NJ + 1, 0), csc_v;
     std::vector<float> csc_w;
     for (int j = 0; j < NJ; ++j) {
@@ -677,7 +683,6 @@ int build_skin_set(fdcap_ctx* c, const std::vector<int64_t>& ids, SkinSet* out) 
     HIP_TRY(out->csc_v.upload(csc_v.data(), csc_v.size()));
     HIP_TRY(out->csc_w.upload(csc_w.data(), csc_w.size()));
     HIP_TRY(out->vt.upload(vt.data(), vt.size()));
-    HIP_TRY(out->S.upload(S.data(), S.size()));
     HIP_TRY(out->ww.upload(ww.data(), ww.size()));
     HIP_TRY(out->wj.upload(wj.data(), wj.size()));
     HIP_TRY(out->posedirs.upload(pd.data(), pd.size()));
@@ -1022,7 +1027,7 @@ static int body_forward_impl(fdcap_ctx* c, const float* params, int32_t B, const
     const bool world = cam_ext != nullptr && scale != nullptr;
     DevBuf<float>* w = c->ws_f;
     HIP_TRY(w[2].ensure((size_t)B * 512)); HIP_TRY(w[3].ensure((size_t)B * 512)); HIP_TRY(w[4].ensure((size_t)B * ODIM));
-    HIP_TRY(w[5].ensure((size_t)B * XDIM)); HIP_TRY(w[6].ensure((size_t)B * NPF)); HIP_TRY(w[7].ensure((size_t)B * NJ * 12));
+    HIP_TRY(w[5].ensure((size_t)B * XDIM)); HIP_TRY(w[6].ensure((size_t)B * NPFX)); HIP_TRY(w[7].ensure((size_t)B * NJ * 12));
     HIP_TRY(w[8].ensure((size_t)B * NJ * 12)); HIP_TRY(w[9].ensure((size_t)B * 16)); HIP_TRY(w[10].ensure(1));
     HIP_TRY(w[1].ensure((size_t)B * 12));
     float* X = w[5].p;
@@ -1040,7 +1045,7 @@ static int body_forward_impl(fdcap_ctx* c, const float* params, int32_t B, const
     if (joints) hipLaunchKernelGGL(joints_out_kernel, dim3((B * NJ + 255) / 256), dim3(256), 0, st, w[7].p, X, XDIM, B, joints);
     if (vertices) {
         HIP_TRY(w[11].ensure((size_t)B * 3 * V));
-        HIP_TRY(gemm_f32(false, EPI_STORE, w[6].p, NPF, c->full.posedirs.p, 3 * V, w[11].p, 3 * V, B, 3 * V, NPF, nullptr, 0, st));
+        HIP_TRY(gemm_f32(false, EPI_STORE, w[6].p, NPFX, c->full.posedirs.p, 3 * V, w[11].p, 3 * V, B, 3 * V, NPFX, nullptr, 0, st));
         hipLaunchKernelGGL(skin_fwd_kernel, dim3((V + 255) / 256, B), dim3(256), 0, st, c->full.model(), V, X, XDIM, X_BETAS,
                            X_TRANSL, w[11].p, w[8].p, (const float*)w[1].p, S, 0, world ? 1 : 0, vertices);
     }
@@ -1072,7 +1077,7 @@ int fdcap_smplx_forward(fdcap_ctx* c, const float* go, const float* bp, const fl
     const int V = c->V;
     DevBuf<float>* w = c->ws_f;
     HIP_TRY(w[4].ensure((size_t)B * 66));
-    HIP_TRY(w[5].ensure((size_t)B * XDIM)); HIP_TRY(w[6].ensure((size_t)B * NPF)); HIP_TRY(w[7].ensure((size_t)B * NJ * 12));
+    HIP_TRY(w[5].ensure((size_t)B * XDIM)); HIP_TRY(w[6].ensure((size_t)B * NPFX)); HIP_TRY(w[7].ensure((size_t)B * NJ * 12));
     HIP_TRY(w[8].ensure((size_t)B * NJ * 12)); HIP_TRY(w[9].ensure((size_t)B * 16)); HIP_TRY(w[10].ensure(1));
     float* X = w[5].p;
     hipLaunchKernelGGL(assemble_rows_kernel, dim3((B + 127) / 128), dim3(128), 0, st, go, bp, betas, lh, rh, transl, B, X, w[4].p);
@@ -1083,7 +1088,7 @@ int fdcap_smplx_forward(fdcap_ctx* c, const float* go, const float* bp, const fl
     if (joints) hipLaunchKernelGGL(joints_out_kernel, dim3((B * NJ + 255) / 256), dim3(256), 0, st, w[7].p, X, XDIM, B, joints);
     if (vertices) {
         HIP_TRY(w[11].ensure((size_t)B * 3 * V));
-        HIP_TRY(gemm_f32(false, EPI_STORE, w[6].p, NPF, c->full.posedirs.p, 3 * V, w[11].p, 3 * V, B, 3 * V, NPF, nullptr, 0, st));
+        HIP_TRY(gemm_f32(false, EPI_STORE, w[6].p, NPFX, c->full.posedirs.p, 3 * V, w[11].p, 3 * V, B, 3 * V, NPFX, nullptr, 0, st));
         hipLaunchKernelGGL(skin_fwd_kernel, dim3((V + 255) / 256, B), dim3(256), 0, st, c->full.model(), V, X, XDIM, X_BETAS,
                            X_TRANSL, w[11].p, w[8].p, (const float*)nullptr, (const float*)nullptr, 0, 0, vertices);
     }
@@ -1139,10 +1144,10 @@ int fdcap_opt_create(fdcap_ctx* c, const fdcap_opt_config* cfg, float* rows_x, f
     AL(o->mS, 1) AL(o->vS, 1)
     AL(o->H1, (size_t)R * 512) AL(o->H2, (size_t)R * 512) AL(o->O, (size_t)R * ODIM) AL(o->dO, (size_t)R * ODIM)
     AL(o->dH2, (size_t)R * 512) AL(o->dH1, (size_t)R * 512)
-    AL(o->Rm, (size_t)R * NJ * 9) AL(o->PF, (size_t)R * NPF) AL(o->Jrest, (size_t)R * NJ * 3) AL(o->G, (size_t)R * NJ * 12)
+    AL(o->Rm, (size_t)R * NJ * 9) AL(o->PF, (size_t)R * NPFX) AL(o->Jrest, (size_t)R * NJ * 3) AL(o->G, (size_t)R * NJ * 12)
     AL(o->A, (size_t)R * NJ * 12) AL(o->M, (size_t)R * 12) AL(o->Jw, (size_t)R * NJW * 3)
     AL(o->dA, (size_t)R * NJ * 12) AL(o->dbeta_v, (size_t)R * NBETA) AL(o->dtransl_v, (size_t)R * 3) AL(o->dMv, (size_t)R * 12)
-    AL(o->dsv, R) AL(o->dPF, (size_t)R * NPF) AL(o->dJw, (size_t)R * NJW * 3) AL(o->dX, (size_t)R * XDIM)
+    AL(o->dsv, R) AL(o->dPF, (size_t)R * NPFX) AL(o->dJw, (size_t)R * NJW * 3) AL(o->dX, (size_t)R * XDIM)
     AL(o->dCAM, (size_t)R * 16) AL(o->dscale_row, R)
     if (o->contact_on) {
         AL(o->Voff, nq * 3) AL(o->Vw, nq * 3) AL(o->dist, nq) AL(o->idx, nq) AL(o->dVoff, nq * 3) AL(o->seedpt, nq)
@@ -1179,8 +1184,8 @@ static int opt_contact_forward(fdcap_ctx* c, hipStream_t st) {
     OptState* o = c->opt;
     const int nl = o->cfg.n_local, nc = c->nc;
     const size_t off = (size_t)2 * nc * 3;
-    HIP_TRY(gemm_f32(false, EPI_STORE, o->PF.p + 2 * NPF, NPF, c->contact.posedirs.p, 3 * nc, o->Voff.p + off, 3 * nc, nl,
-                     3 * nc, NPF, nullptr, 0, st));
+    HIP_TRY(gemm_f32(false, EPI_STORE, o->PF.p + 2 * NPFX, NPFX, c->contact.posedirs.p, 3 * nc, o->Voff.p + off, 3 * nc, nl,
+                     3 * nc, NPFX, nullptr, 0, st));
     hipLaunchKernelGGL(skin_fwd_kernel, dim3((nc + 255) / 256, nl), dim3(256), 0, st, c->contact.model(), nc, o->X.p, XDIM,
                        X_BETAS, X_TRANSL, o->Voff.p, o->A.p, o->M.p, o->scale.p, 2, 1, o->Vw.p);
     const int nq = nl * nc;
@@ -1227,10 +1232,10 @@ static int opt_backward_impl(fdcap_ctx* c, const LossWeights& lw, int32_t log_te
         cg.coef = lw.contact * cf.weight_contact / ((float)N * nc);
         cg.contact_sum = losses ? losses + 3 : nullptr;
         hipLaunchKernelGGL(skin_bwd_kernel<true>, dim3(nl), dim3(256), 0, st, c->contact.model(), nc, o->X.p, o->Voff.p, o->A.p,
-                           o->M.p, o->scale.p, 2, (const float*)nullptr, o->dVoff.p, o->dA.p, o->dbeta_v.p, o->dtransl_v.p,
+                           o->M.p, o->scale.p, 2, (const float*)nullptr, o->dVoff.p, o->dA.p, (float*)nullptr, o->dtransl_v.p,
                            o->dMv.p, o->dsv.p, cg);
         HIP_TRY(gemm_f32(true, EPI_STORE, o->dVoff.p + (size_t)2 * nc * 3, 3 * nc, c->contact.posedirs.p, 3 * nc,
-                         o->dPF.p + 2 * NPF, NPF, nl, NPF, 3 * nc, nullptr, 0, st));
+                         o->dPF.p + 2 * NPFX, NPFX, nl, NPFX, 3 * nc, nullptr, 0, st));
     } else if (contact_fwd && losses) {
         hipLaunchKernelGGL(contact_loss_kernel, dim3(256), dim3(256), 0, st, o->dist.p + 2 * nc, (size_t)nl * nc, losses + 3);
     }
@@ -1238,7 +1243,7 @@ static int opt_backward_impl(fdcap_ctx* c, const LossWeights& lw, int32_t log_te
     hipLaunchKernelGGL(pose_bwd_kernel, dim3(nl), dim3(64), 0, st, pm, o->X.p, o->O.p, o->CAM.p, o->scale.p, 2, o->Rm.p,
                        o->Jrest.p, o->G.p, contact_grad ? o->dA.p : nullptr, contact_grad ? o->dPF.p : nullptr,
                        joint_grad ? o->dJw.p : nullptr, contact_grad ? o->dMv.p : nullptr, contact_grad ? o->dsv.p : nullptr,
-                       contact_grad ? o->dbeta_v.p : nullptr, contact_grad ? o->dtransl_v.p : nullptr, o->dX.p, o->dO.p,
+                       contact_grad ? o->dPF.p + NPF : nullptr, NPFX, contact_grad ? o->dtransl_v.p : nullptr, o->dX.p, o->dO.p,
                        o->dCAM.p, o->dscale_row.p);
     // VPoser data-gradient: dO -> dH2 -> dH1 -> d latent (accumulated into dX[:, 19:51])
     HIP_TRY(gemm_f32(false, EPI_MASK_LRELU, o->dO.p + 2 * ODIM, ODIM, c->W3.p, 512, o->dH2.p + 2 * 512, 512, nl, 512, ODIM,
@@ -1434,7 +1439,7 @@ int fdcap_opt_backward_local2(fdcap_ctx* c, const float* contact_weight, int32_t
     hipLaunchKernelGGL(pose_fwd_kernel, dim3(R), dim3(64), 0, st, pm, o->X.p, o->O.p, o->CAM.p, o->scale.p, 0, o->Rm.p,
                        o->PF.p, o->Jrest.p, o->G.p, o->A.p, o->M.p, o->Jw.p, (const float*)nullptr);
     // full-mesh world vertices of every row (the vertex stencil needs 2 halo frames each side)
-    HIP_TRY(gemm_f32(false, EPI_STORE, o->PF.p, NPF, c->full.posedirs.p, 3 * V, o->VoffF.p, 3 * V, R, 3 * V, NPF, nullptr, 0, st));
+    HIP_TRY(gemm_f32(false, EPI_STORE, o->PF.p, NPFX, c->full.posedirs.p, 3 * V, o->VoffF.p, 3 * V, R, 3 * V, NPFX, nullptr, 0, st));
     hipLaunchKernelGGL(skin_fwd_kernel, dim3((V + 255) / 256, R), dim3(256), 0, st, c->full.model(), V, o->X.p, XDIM, X_BETAS,
                        X_TRANSL, o->VoffF.p, o->A.p, o->M.p, o->scale.p, 0, 1, o->VwF.p);
     // losses [0] rec, [1] z^2, [2] local (parameter) smoothing, [5] vertex smoothing, [6] foot skate
@@ -1449,11 +1454,11 @@ int fdcap_opt_backward_local2(fdcap_ctx* c, const float* contact_weight, int32_t
         hipLaunchKernelGGL(foot_skate_kernel, dim3((nc * 3 + 255) / 256, nl), dim3(256), 0, st, o->VwF.p, nv3, c->contact_vid.p,
                            nc, n_left, contact_weight, 2, cf.frame0, N, o->dVF.p, o->losses.p + 6);
     hipLaunchKernelGGL(skin_bwd_kernel<false>, dim3(nl), dim3(256), 0, st, c->full.model(), V, o->X.p, o->VoffF.p, o->A.p, o->M.p,
-                       o->scale.p, 2, o->dVF.p, o->dVF.p, o->dA.p, o->dbeta_v.p, o->dtransl_v.p, o->dMv.p, o->dsv.p, ContactGradIn());
-    HIP_TRY(gemm_f32(true, EPI_STORE, o->dVF.p + 2 * nv3, 3 * V, c->full.posedirs.p, 3 * V, o->dPF.p + 2 * NPF, NPF, nl, NPF,
+                       o->scale.p, 2, o->dVF.p, o->dVF.p, o->dA.p, (float*)nullptr, o->dtransl_v.p, o->dMv.p, o->dsv.p, ContactGradIn());
+    HIP_TRY(gemm_f32(true, EPI_STORE, o->dVF.p + 2 * nv3, 3 * V, c->full.posedirs.p, 3 * V, o->dPF.p + 2 * NPFX, NPFX, nl, NPFX,
                      3 * V, nullptr, 0, st));
     hipLaunchKernelGGL(pose_bwd_kernel, dim3(nl), dim3(64), 0, st, pm, o->X.p, o->O.p, o->CAM.p, o->scale.p, 2, o->Rm.p,
-                       o->Jrest.p, o->G.p, o->dA.p, o->dPF.p, (const float*)nullptr, o->dMv.p, o->dsv.p, o->dbeta_v.p,
+                       o->Jrest.p, o->G.p, o->dA.p, o->dPF.p, (const float*)nullptr, o->dMv.p, o->dsv.p, o->dPF.p + NPF, NPFX,
                        o->dtransl_v.p, o->dX.p, o->dO.p, o->dCAM.p, o->dscale_row.p);
     HIP_TRY(gemm_f32(false, EPI_MASK_LRELU, o->dO.p + 2 * ODIM, ODIM, c->W3.p, 512, o->dH2.p + 2 * 512, 512, nl, 512, ODIM,
                      o->H2.p + 2 * 512, 512, st));
