@@ -974,7 +974,8 @@ static inline int nn_pick_nsplit(int nq, int nt, bool culled = false) {
 // workspace: pd/pi [nsplit*nq]; seed: optional [nq] original indices (may alias idx: read before idx is rewritten)
 static inline hipError_t nn_search(const float* q, int nq, const NNTarget& T, float* dist, int* idx, float* pd, int* pi,
                                    int nsplit, hipStream_t st, const int* seed = nullptr, bool seed_missing = false,
-                                   float4* seedpt = nullptr) {
+                                   float4* seedpt = nullptr, bool* seedpt_written = nullptr) {
+    if (seedpt_written) *seedpt_written = false;             // true: seedpt[q] = coordinates of the neighbour idx[q] after this launch
     if (nq <= 0) return hipSuccess;
     // Query blocks per workgroup: 4 waves x NQ x 32.  A brute-force scan wants NQ = 4 (most MFMAs per
     // staged chunk: 9.7 ms vs 10.9 at NQ = 2); a seeded + chunk-culled scan wants NQ = 2 (the union of
@@ -993,6 +994,7 @@ static inline hipError_t nn_search(const float* q, int nq, const NNTarget& T, fl
         if (four && seed_missing)                             // first launch of a fit: cheap seeds (+ their coordinates) instead of a full scan
             hipLaunchKernelGGL(nn_seed_kernel, dim3((nq + 255) / 256), dim3(256), 0, st, q, nq, T, idx, seedpt);
         // seed may alias idx: every workgroup reads its seeds before it writes its own results, and no other workgroup touches them
+        if (seedpt_written) *seedpt_written = four;
         if (!four) {
             hipLaunchKernelGGL((nn_stream_kernel<2>), dim3((nq + 255) / 256), dim3(256), 0, st, q, nq, T, seed, dist, idx);
         } else {

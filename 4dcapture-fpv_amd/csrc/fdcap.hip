@@ -99,7 +99,9 @@ __device__ __forceinline__ float wave_sum(float v) {
 // CONTACT: d loss / d world vertex is the contact robustifier's gradient (:295), formed here from the NN
 // result (Vw, dist, idx -> scene point) instead of being read from dVw; its un-weighted sum goes to
 // *contact_sum when that is non-null (logging iterations only: one double atomic per frame).
-struct ContactGradIn { const float* Vw; const float* dist; const int* idx; const float4* scene; float coef; double* contact_sum; };
+// nnpt (optional): the neighbours' coordinates as the NN kernel keeps them ([q] {x, y, z, -}, coalesced) instead of the
+// dependent gather scene[idx[q]].
+struct ContactGradIn { const float* Vw; const float* dist; const int* idx; const float4* scene; const float4* nnpt; float coef; double* contact_sum; };
 constexpr int SKB_NACC = NBETA + 3 + 12 + 1;   // dbeta, dtransl, dM, ds
 template <bool CONTACT>
 __global__ __launch_bounds__(256) void skin_bwd_kernel(SkinModel sm, int nc, const float* __restrict__ X,
@@ -110,7 +112,7 @@ __global__ __launch_bounds__(256) void skin_bwd_kernel(SkinModel sm, int nc, con
                                                        float* __restrict__ dtransl_v, float* __restrict__ dMv,
                                                        float* __restrict__ dsv, ContactGradIn cg) {
     constexpr int VCH = 1024;                      // vertices per LDS chunk
-    __shared__ float sdT[VCH * 12];
+    extern __shared__ float sdT[];                 // [min(nc, VCH) * 12] (dynamic: 500 contact vertices leave room for 6 workgroups per CU)
     __shared__ float sdA[NJ * 12];
     __shared__ float sred[4][SKB_NACC];
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
@@ -120,6 +122,8 @@ __global__ __launch_bounds__(256) void skin_bwd_kernel(SkinModel sm, int nc, con
     V3 transl = v3(x[X_TRANSL], x[X_TRANSL + 1], x[X_TRANSL + 2]);
     float acc[SKB_NACC];
     float cterm = 0.f;
+    // lane j of every wave: joint j's range in the transposed weight list (loaded once, while the vertex phase runs)
+    const int jlo = lane < NJ ? sm.csc_start[lane] : 0, jhi = lane < NJ ? sm.csc_start[lane + 1] : 0;
 #pragma unroll
     for (int i = 0; i < SKB_NACC; ++i) acc[i] = 0.f;
     for (int i = tid; i < NJ * 12; i += 256) sdA[i] = 0.f;
@@ -133,7 +137,7 @@ __global__ __launch_bounds__(256) void skin_bwd_kernel(SkinModel sm, int nc, con
                 cterm += contact_term(cg.dist[qi], &dterm);
                 const int j = cg.idx[qi];
                 const float gg = j >= 0 ? 2.f * cg.coef * dterm : 0.f;           // no neighbour (NaN query): zero gradient
-                const float4 p = j >= 0 ? cg.scene[j] : make_float4(0.f, 0.f, 0.f, 0.f);
+                const float4 p = j < 0 ? make_float4(0.f, 0.f, 0.f, 0.f) : (cg.nnpt ? cg.nnpt[qi] : cg.scene[j]);
                 g = v3(gg * (cg.Vw[3 * qi] - p.x), gg * (cg.Vw[3 * qi + 1] - p.y), gg * (cg.Vw[3 * qi + 2] - p.z));
             } else {
                 g = v3(dVw[3 * qi], dVw[3 * qi + 1], dVw[3 * qi + 2]);
@@ -157,15 +161,20 @@ __global__ __launch_bounds__(256) void skin_bwd_kernel(SkinModel sm, int nc, con
         // dA_j += sum_v w_vj dT_v, ordered and atomic-free (run-to-run reproducible): the joints are dealt
         // to the 4 waves; a wave's lanes stride over joint j's vertex list (ascending, restricted to this
         // chunk by two binary searches) and are combined by a butterfly
-        for (int j = wave; j < NJ; j += 4) {
-            int lo = sm.csc_start[j], hi = sm.csc_start[j + 1];
-            if (lo == hi) continue;                         // wave-uniform
+        // the non-empty joints (one ballot over the preloaded list bounds) are dealt to the four waves in turn
+        unsigned long long jact = __ballot(jhi > jlo);
+        for (int kact = 0; jact; ++kact) {
+            const int j = __ffsll((long long)jact) - 1;
+            jact &= jact - 1;
+            if ((kact & 3) != wave) continue;               // wave-uniform
+            int lo = __builtin_amdgcn_readlane(jlo, j), hi = __builtin_amdgcn_readlane(jhi, j);
             if (nc > VCH) {
                 int a = lo, bnd = hi;
                 while (a < bnd) { int m = (a + bnd) >> 1; if (sm.csc_v[m] < c0) a = m + 1; else bnd = m; }
                 lo = a; bnd = hi;
                 while (a < bnd) { int m = (a + bnd) >> 1; if (sm.csc_v[m] < c1) a = m + 1; else bnd = m; }
                 hi = a;
+                if (lo == hi) continue;
             }
             float pa[12];
 #pragma unroll
@@ -585,6 +594,7 @@ struct OptState {
     int dctT = 0, dctC = 0, dctW = 0;
     bool dct_grad = false;    // the last backward gave `scale` a gradient through the DCT term
     bool seeded = false;      // a contact forward has run since fdcap_opt_create (idx holds neighbours)
+    bool nnpt_valid = false;  // the last contact forward left the neighbours' coordinates in seedpt
     bool use_seed = true;     // last iteration's neighbours seed the NN bound (pruning only)
     bool use_cull = true;     // skip scene chunks whose bounding sphere is out of every query's reach
 };
@@ -1191,7 +1201,7 @@ static int opt_contact_forward(fdcap_ctx* c, hipStream_t st) {
     const int nq = nl * nc;
     // the first contact forward of a fit has no neighbours from a previous iteration yet (idx = -1)
     HIP_TRY(nn_search(o->Vw.p + off, nq, c->nn_target(o->use_cull), o->dist.p + 2 * nc, o->idx.p + 2 * nc, o->pd.p, o->pi.p,
-                      o->nsplit, st, o->use_seed ? o->idx.p + 2 * nc : nullptr, !o->seeded, o->seedpt.p + 2 * nc));
+                      o->nsplit, st, o->use_seed ? o->idx.p + 2 * nc : nullptr, !o->seeded, o->seedpt.p + 2 * nc, &o->nnpt_valid));
     o->seeded = true;
     return 0;
 }
@@ -1229,9 +1239,10 @@ static int opt_backward_impl(fdcap_ctx* c, const LossWeights& lw, int32_t log_te
     if (contact_grad) {
         ContactGradIn cg;
         cg.Vw = o->Vw.p; cg.dist = o->dist.p; cg.idx = o->idx.p; cg.scene = c->scene.p;
+        cg.nnpt = o->nnpt_valid ? o->seedpt.p : nullptr;
         cg.coef = lw.contact * cf.weight_contact / ((float)N * nc);
         cg.contact_sum = losses ? losses + 3 : nullptr;
-        hipLaunchKernelGGL(skin_bwd_kernel<true>, dim3(nl), dim3(256), 0, st, c->contact.model(), nc, o->X.p, o->Voff.p, o->A.p,
+        hipLaunchKernelGGL(skin_bwd_kernel<true>, dim3(nl), dim3(256), (size_t)std::min(nc, 1024) * 12 * sizeof(float), st, c->contact.model(), nc, o->X.p, o->Voff.p, o->A.p,
                            o->M.p, o->scale.p, 2, (const float*)nullptr, o->dVoff.p, o->dA.p, (float*)nullptr, o->dtransl_v.p,
                            o->dMv.p, o->dsv.p, cg);
         HIP_TRY(gemm_f32(true, EPI_STORE, o->dVoff.p + (size_t)2 * nc * 3, 3 * nc, c->contact.posedirs.p, 3 * nc,
@@ -1453,7 +1464,7 @@ int fdcap_opt_backward_local2(fdcap_ctx* c, const float* contact_weight, int32_t
     if (N >= 2)
         hipLaunchKernelGGL(foot_skate_kernel, dim3((nc * 3 + 255) / 256, nl), dim3(256), 0, st, o->VwF.p, nv3, c->contact_vid.p,
                            nc, n_left, contact_weight, 2, cf.frame0, N, o->dVF.p, o->losses.p + 6);
-    hipLaunchKernelGGL(skin_bwd_kernel<false>, dim3(nl), dim3(256), 0, st, c->full.model(), V, o->X.p, o->VoffF.p, o->A.p, o->M.p,
+    hipLaunchKernelGGL(skin_bwd_kernel<false>, dim3(nl), dim3(256), (size_t)std::min(V, 1024) * 12 * sizeof(float), st, c->full.model(), V, o->X.p, o->VoffF.p, o->A.p, o->M.p,
                        o->scale.p, 2, o->dVF.p, o->dVF.p, o->dA.p, (float*)nullptr, o->dtransl_v.p, o->dMv.p, o->dsv.p, ContactGradIn());
     HIP_TRY(gemm_f32(true, EPI_STORE, o->dVF.p + 2 * nv3, 3 * V, c->full.posedirs.p, 3 * V, o->dPF.p + 2 * NPFX, NPFX, nl, NPFX,
                      3 * V, nullptr, 0, st));
