@@ -4,9 +4,10 @@ import json, sys
 tag = sys.argv[1] if len(sys.argv) > 1 else ""
 d = json.loads(sys.stdin.read().strip().splitlines()[-1])
 r = d["roofline"]
-print(tag, "frames/s %.1f  ms/step %.1f  NN brute %.2f ms (%.1f%% HBM-alg, %.2e pairs/s)  in-loop %.2f ms" % (
-    d["value"], d["ms_per_step"], r["ms_per_launch"], 100 * r["frac"], r["compute_side"]["pairs_per_s"],
-    r["in_loop"]["ms_per_launch"]))
+b = r["brute_force"]
+print(tag, "frames/s %.1f  ms/step %.1f  in-loop NN %.3f ms (alg %.0f GB/s = %.2f x HBM peak)  brute force %.2f ms (%.1f%% HBM-alg, %.2e pairs/s)" % (
+    d["value"], d["ms_per_step"], r["ms_per_launch"], r["achieved"], r["frac"], b["ms_per_launch"], 100 * b["frac"],
+    b["compute_side"]["pairs_per_s"]))
 if "blendshape_gemm" in d:
     g = d["blendshape_gemm"]
     print("   blend GEMM %.3f ms  %.1f TFLOP/s (%.1f%% of fp32 MFMA peak)" % (g["ms_per_launch"], g["achieved"], 100 * g["frac"]))
