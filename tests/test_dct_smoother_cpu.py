@@ -127,9 +127,9 @@ def test_oracle_dct_mode_reproduces_the_reference_run():
     log, ref = np.array(orc.loss_log), g["logd"]
     it = ref[:, 0].astype(int)
     first = it <= 9501                                     # c_dct phase + the no-op iteration 9500 + the first body step's forward
-    np.testing.assert_allclose(log[it[first]], ref[first, 1:], rtol=0, atol=4e-6)       # measured 3e-6 (6 printed decimals)
+    np.testing.assert_allclose(log[it[first]], ref[first, 1:], rtol=5e-7, atol=4e-6)    # 6 printed decimals + fp32 rounding of values up to 186
     nxt = (it > 9501) & (it < 9506)
-    np.testing.assert_allclose(log[it[nxt]], ref[nxt, 1:], rtol=0, atol=4e-6)
+    np.testing.assert_allclose(log[it[nxt]], ref[nxt, 1:], rtol=5e-7, atol=4e-6)
     dc = np.abs(orc.c_dct.detach().numpy() - g["c_dct"])
     assert np.quantile(dc, 0.9) < 5e-6 and dc.max() < 2e-3, (np.quantile(dc, 0.9), dc.max())   # measured 5e-7 / 7e-4
     err = np.abs(body.numpy() - g["body_rec"])
