@@ -212,7 +212,10 @@ class FittingOP:
         self.init(x78)                                                                      # :495
         P = first_phase2_iter(self.num_iter)
         log = FitLog([], [], [], [], [], [], [])
-        multi = self.shard.world > 1
+        # FDCAP_FORCE_EXCHANGE=1: run the sharded iteration tail (pack -> all-gather -> unpack) even on a one-rank
+        # group -- lets a single-GPU box exercise the RCCL calls of the multi-GPU path
+        import os
+        multi = self.shard.world > 1 or (self.group is not None and os.environ.get("FDCAP_FORCE_EXCHANGE") == "1")
         if mode == "dct":
             self._dct_loops(lib, h, multi, log_every)
         for ii in range(self.num_iter if mode != "dct" else 0):                             # :560

@@ -107,9 +107,10 @@ def main():
         raise SystemExit("bench.py needs a GPU (the HIP path has no CPU fallback)")
     torch.cuda.set_device(local)
     group = None
-    if world > 1:
+    if world > 1 or os.environ.get("FDCAP_FORCE_EXCHANGE") == "1":   # the latter: one-rank RCCL group, measures the exchange path's cost
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
         group = dist.group.WORLD
     import fdcap_amd  # noqa: F401
@@ -127,7 +128,7 @@ def main():
     fop = FittingOP({"num_iter": args.iters}, {}, N, body_model=bm, vposer=vp, scene_verts=scene, contact_ids=vid,
                     camera_ext=read_camerapose(clip.camerapose_lines), group=group)
     body_gpu = torch.tensor(clip.body_params).cuda()
-    if world > 1:                                          # create the RCCL communicator outside the timed region
+    if group is not None:                                  # create the RCCL communicator outside the timed region
         import torch.distributed as dist
         warm = torch.zeros(8, device="cuda")
         allw = torch.zeros(world, 8, device="cuda")
@@ -225,11 +226,18 @@ def main():
                "roofline": roofline, "blendshape_gemm": blend}
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(bm, vp, clip, scene, vid, args)
-        print(json.dumps(out), flush=True)
-    if world > 1:
+    if group is not None:
         import torch.distributed as dist
         dist.barrier()
         dist.destroy_process_group()
+    if rank == 0:
+        # librccl writes its version banner through C stdio (block-buffered when stdout is a pipe): push it out first so
+        # the JSON line is the last thing this process prints
+        try:
+            ctypes.CDLL(None).fflush(None)
+        except OSError:
+            pass
+        print(json.dumps(out), flush=True)
 
 
 if __name__ == "__main__":

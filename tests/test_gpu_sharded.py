@@ -83,3 +83,34 @@ def test_sharded_gpu_run_matches_single_rank(world, mode):
     for r in res:
         assert abs(r[3] - ref[2]) < 2e-6
         np.testing.assert_allclose(r[5], ref[4], rtol=2e-6)      # all-reduced loss totals, every iteration
+
+
+def _rccl_worker(port, q):
+    """One rank, backend nccl (= RCCL): the sharded iteration tail with its real collective on device tensors."""
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    os.environ["FDCAP_FORCE_EXCHANGE"] = "1"
+    torch.cuda.set_device(0)
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    try:
+        q.put(_fit(dist.group.WORLD, "global"))
+    finally:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def test_exchange_path_over_rccl_on_one_rank_equals_the_plain_loop():
+    """The multi-GPU iteration tail (Adam on rows + pack, RCCL all_gather_into_tensor, unpack + Adam on scale, logging
+    all-reduce) on a one-rank RCCL group: same arithmetic as the single-GPU loop, so results must be identical."""
+    ref = _fit(None, "global")
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    p = ctx.Process(target=_rccl_worker, args=(_free_port(), q))
+    p.start()
+    res = q.get(timeout=600)
+    p.join(timeout=120)
+    assert p.exitcode == 0
+    np.testing.assert_array_equal(res[1], ref[1])
+    assert res[2] == ref[2]
+    np.testing.assert_array_equal(res[3], ref[3])
+    np.testing.assert_allclose(res[4], ref[4], rtol=1e-12)
