@@ -40,6 +40,7 @@ def parse():
     ap.add_argument("--frames", type=int, default=1024)
     ap.add_argument("--scene", type=int, default=500_000)
     ap.add_argument("--contacts-per-leg", type=int, default=250)
+    ap.add_argument("--all-contacts", action="store_true", help="every mesh vertex is a contact vertex (BASELINE config 5)")
     ap.add_argument("--iters", type=int, default=500)
     ap.add_argument("--verts", type=int, default=10475)
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -124,7 +125,7 @@ def main():
     clip = synth.make_clip(N, seed=3)
     scene = synth.make_scene(args.scene, seed=2)
     left, right = synth.make_contact_ids(bm.v_template, per_part=args.contacts_per_leg, seed=4)
-    vid = np.concatenate([left, right])
+    vid = np.arange(args.verts) if args.all_contacts else np.concatenate([left, right])
     fop = FittingOP({"num_iter": args.iters}, {}, N, body_model=bm, vposer=vp, scene_verts=scene, contact_ids=vid,
                     camera_ext=read_camerapose(clip.camerapose_lines), group=group)
     body_gpu = torch.tensor(clip.body_params).cuda()

@@ -1,0 +1,42 @@
+#!/usr/bin/env python3
+"""How long the host needs to ISSUE one optimiser iteration (ctypes calls + the torch.distributed collective of the sharded
+tail), against what the GPU needs to run it.  Development tool.  FDCAP_FORCE_EXCHANGE=1 includes the exchange path."""
+import os, sys, time
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import numpy as np, torch
+import fdcap_amd
+from fdcap_amd import capi, synth
+from fdcap_amd.fitting import FittingOP
+from fdcap_amd.io import read_camerapose
+N = int(sys.argv[1]) if len(sys.argv) > 1 else 128
+group = None
+if os.environ.get("FDCAP_FORCE_EXCHANGE") == "1":
+    import torch.distributed as dist
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1"); os.environ.setdefault("MASTER_PORT", "29544")
+    torch.cuda.set_device(0)
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    group = dist.group.WORLD
+bm = synth.make_body_model(10475, seed=0); vp = synth.make_vposer(seed=1); clip = synth.make_clip(N, seed=3)
+scene = synth.make_scene(500000, seed=2); l, r = synth.make_contact_ids(bm.v_template, per_part=250, seed=4)
+fop = FittingOP({"num_iter": 500}, {}, N, body_model=bm, vposer=vp, scene_verts=scene, contact_ids=np.concatenate([l, r]),
+                camera_ext=read_camerapose(clip.camerapose_lines), group=group)
+body = torch.tensor(clip.body_params).cuda()
+fop.fitting(body, "global"); torch.cuda.synchronize()
+from fdcap_amd.dist import allgather_packed
+lib, h = fop.ctx.lib, fop.ctx.handle
+torch.cuda.synchronize()
+t0 = time.perf_counter()
+for ii in range(400):
+    st = capi.current_stream()
+    capi.check(lib.fdcap_opt_backward(h, ii, 10 ** 6, 0, st), "b")
+    if group is not None:
+        capi.check(lib.fdcap_opt_step_rows_and_pack(h, ii, 10 ** 6, capi.dptr(fop._xch_send), st), "p")
+        allgather_packed(fop.shard, fop._xch_send, fop._xch_all)
+        capi.check(lib.fdcap_opt_unpack_and_step_scale(h, ii, 10 ** 6, capi.dptr(fop._xch_all), 0, 1, st), "u")
+    else:
+        capi.check(lib.fdcap_opt_step(h, ii, 10 ** 6, st), "s")
+t1 = time.perf_counter(); torch.cuda.synchronize(); t2 = time.perf_counter()
+print(f"frames {N} exchange {group is not None}: host issued 400 phase-1 iterations in {1e3*(t1-t0):.1f} ms ({(t1-t0)*1e6/400:.1f} us/iter), GPU done after {1e3*(t2-t0):.1f} ms ({(t2-t0)*1e6/400:.1f} us/iter)")
+if group is not None:
+    dist.destroy_process_group()
