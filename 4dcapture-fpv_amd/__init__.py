@@ -9,6 +9,7 @@ Layout:
   fitting.py   FittingOP mirror (init / fitting / save_result) driving the fused HIP iteration
                (modes 'global', 'local', 'dct')
   smoother.py  optimization.py's per-frame smoother (FittingOP.fitting / fitting_smoothing) in one launch
+  innerfit.py  per-frame inner fit with a 2D-keypoint reprojection term (outside the reference)
   io.py        body_gen -> smoothed_body pickle interface, camerapose.txt, scene readers
   synth.py     seeded synthetic stand-ins for the licensed assets
   dist.py      frame sharding + halo exchange over torch.distributed (RCCL on ROCm)

@@ -33,6 +33,11 @@ class ModelDesc(ctypes.Structure):
                 ("vp_fc2_b", POINTER(c_float)), ("vp_out_w", POINTER(c_float)), ("vp_out_b", POINTER(c_float))]
 
 
+class Fit2dStage(ctypes.Structure):
+    _fields_ = [("fx", c_float), ("fy", c_float), ("cx", c_float), ("cy", c_float), ("rho", c_float),
+                ("w_data", c_float), ("w_pose", c_float), ("w_shape", c_float), ("w_hand", c_float)]
+
+
 class OptConfig(ctypes.Structure):
     _fields_ = [("n_total", c_int32), ("n_local", c_int32), ("frame0", c_int32), ("lr", c_float),
                 ("weight_loss_rec", c_float), ("weight_loss_vposer", c_float), ("weight_contact", c_float),
@@ -73,6 +78,9 @@ SYMBOLS = {
     "fdcap_opt_dct_windows": (c_int32, [c_void_p, POINTER(c_int32), POINTER(c_int32)]),
     "fdcap_frame_smoother": (c_int32, [c_void_p, c_void_p, c_int32, c_int32, c_float, c_float, c_float, c_float,
                                         c_void_p, c_int32, c_int32, c_void_p, c_void_p]),
+    "fdcap_opt_set_keypoints": (c_int32, [c_void_p, c_void_p, c_void_p]),
+    "fdcap_opt_backward_fit2d": (c_int32, [c_void_p, POINTER(Fit2dStage), c_int32, c_void_p]),
+    "fdcap_opt_reset_adam": (c_int32, [c_void_p, c_void_p]),
     "fdcap_opt_step_rows_and_pack": (c_int32, [c_void_p, c_int32, c_int32, c_void_p, c_void_p]),
     "fdcap_opt_unpack_and_step_scale": (c_int32, [c_void_p, c_int32, c_int32, c_void_p, c_int32, c_int32, c_void_p]),
     "fdcap_exchange_len": (c_int32, []),

@@ -11,6 +11,7 @@
 #include "../../include/fdcap.h"
 #include "fdc_chamfer.h"
 #include "fdc_dct.h"
+#include "fdc_fit2d.h"
 #include "fdc_frame.h"
 #include "fdc_gemm.h"
 #include "fdc_host_setup.h"
@@ -583,6 +584,7 @@ struct OptState {
     DevBuf<float> Rm, PF, Jrest, G, A, M, Jw;
     DevBuf<float> Voff, Vw, dist, pd, dVoff;
     DevBuf<int> idx, pi;
+    DevBuf<float> kp2d;       // per-frame inner fit: 2D keypoints [n_local,23,3] (u, v, confidence)
     DevBuf<float4> seedpt;    // coordinates (+ position in the sorted scene) of each query's current neighbour: next launch's seed
     DevBuf<float> dA, dbeta_v, dtransl_v, dMv, dsv, dPF, dJw, dX, dCAM, dscale_row;
     DevBuf<float> VoffF, VwF, dVF;      // mode 'local' second loop: full-mesh pose offsets / world vertices / gradient
@@ -1115,7 +1117,7 @@ void fdcap_opt_destroy(fdcap_ctx* c) {
                            &o->dsv, &o->dPF, &o->dJw, &o->dX, &o->dCAM, &o->dscale_row, &o->VoffF, &o->VwF, &o->dVF};
     for (auto* b : fb) b->release();
     o->dctD.release(); o->dctCoef.release(); o->dctM.release(); o->dctV.release(); o->adam_tab.release();
-    o->idx.release(); o->pi.release(); o->seedpt.release();
+    o->idx.release(); o->pi.release(); o->seedpt.release(); o->kp2d.release();
     delete o;
     c->opt = nullptr;
 }
@@ -1352,6 +1354,54 @@ int32_t fdcap_opt_dct_windows(fdcap_ctx* c, int32_t* w0, int32_t* w1) {
     if (w0) *w0 = a;
     if (w1) *w1 = std::max(a, b);
     return c->opt->dctW;
+}
+
+// ---- per-frame inner fit with a 2D reprojection term (outside the reference) ------
+int fdcap_opt_set_keypoints(fdcap_ctx* c, const float* kp_d, void* stream) {
+    if (!c || !c->opt || !kp_d) return FDCAP_E_ARG;
+    OptState* o = c->opt;
+    const size_t n = (size_t)o->cfg.n_local * NJW * 3;
+    HIP_TRY(o->kp2d.ensure(n));
+    HIP_TRY(hipMemcpyAsync(o->kp2d.p, kp_d, n * sizeof(float), hipMemcpyDeviceToDevice, (hipStream_t)stream));
+    return FDCAP_OK;
+}
+
+int fdcap_opt_backward_fit2d(fdcap_ctx* c, const fdcap_fit2d_stage* sg, int32_t log_terms, void* stream) {
+    if (!c || !c->opt || !sg) return FDCAP_E_ARG;
+    OptState* o = c->opt;
+    if (!o->kp2d.p) return FDCAP_E_STATE;
+    hipStream_t st = (hipStream_t)stream;
+    const int R = o->R, nl = o->cfg.n_local;
+    Fit2dStage s = {sg->fx, sg->fy, sg->cx, sg->cy, sg->rho, sg->w_data, sg->w_pose, sg->w_shape, sg->w_hand};
+    PoseModel pm = c->pose_model();
+    double* const losses = log_terms ? o->losses.p : nullptr;
+    if (losses) HIP_TRY(hipMemsetAsync(losses, 0, FDCAP_NUM_LOSSES * sizeof(double), st));
+    int e = vposer_forward(c, o->X.p, XDIM, X_LATENT, R, o->H1.p, o->H2.p, o->O.p, st);
+    if (e) return e;
+    hipLaunchKernelGGL(pose_fwd_kernel, dim3(R), dim3(64), 0, st, pm, o->X.p, o->O.p, o->CAM.p, o->scale.p, 0, o->Rm.p,
+                       o->PF.p, o->Jrest.p, o->G.p, o->A.p, o->M.p, o->Jw.p, (const float*)nullptr);
+    hipLaunchKernelGGL(fit2d_loss_kernel, dim3(nl), dim3(128), 0, st, s, o->X.p, o->Jw.p, o->kp2d.p, 2, o->dX.p, o->dJw.p, losses);
+    hipLaunchKernelGGL(pose_bwd_kernel, dim3(nl), dim3(64), 0, st, pm, o->X.p, o->O.p, o->CAM.p, o->scale.p, 2, o->Rm.p,
+                       o->Jrest.p, o->G.p, (const float*)nullptr, (const float*)nullptr, o->dJw.p, (const float*)nullptr,
+                       (const float*)nullptr, (const float*)nullptr, 0, (const float*)nullptr, o->dX.p, o->dO.p, o->dCAM.p,
+                       o->dscale_row.p);
+    HIP_TRY(gemm_f32(false, EPI_MASK_LRELU, o->dO.p + 2 * ODIM, ODIM, c->W3.p, 512, o->dH2.p + 2 * 512, 512, nl, 512, ODIM,
+                     o->H2.p + 2 * 512, 512, st));
+    HIP_TRY(gemm_f32(false, EPI_MASK_LRELU, o->dH2.p + 2 * 512, 512, c->W2.p, 512, o->dH1.p + 2 * 512, 512, nl, 512, 512,
+                     o->H1.p + 2 * 512, 512, st));
+    HIP_TRY(gemm_f32(false, EPI_ACCUM, o->dH1.p + 2 * 512, 512, c->W1.p, 32, o->dX.p + 2 * XDIM + X_LATENT, XDIM, nl, 32, 512,
+                     nullptr, 0, st));
+    return (int)hipGetLastError();
+}
+
+// zero Adam's moments of body_rotation_rec (SMPLify-X builds a fresh optimiser for every stage of the fit)
+int fdcap_opt_reset_adam(fdcap_ctx* c, void* stream) {
+    if (!c || !c->opt) return FDCAP_E_STATE;
+    OptState* o = c->opt;
+    const size_t n = (size_t)o->R * XDIM * sizeof(float);
+    HIP_TRY(hipMemsetAsync(o->mX.p, 0, n, (hipStream_t)stream));
+    HIP_TRY(hipMemsetAsync(o->vX.p, 0, n, (hipStream_t)stream));
+    return FDCAP_OK;
 }
 
 // ---- optimization.py: the per-frame smoother (:185-238, :334-348) ------------------------------

@@ -227,6 +227,25 @@ int fdcap_frame_smoother(fdcap_ctx* ctx, const float* data78_d, int32_t N, int32
                          float w_vposer, float w_prev, float* state_d, int32_t step0, int32_t has_prev,
                          float* out78_d, void* stream);
 
+/* ---- per-frame inner fit with a true 2D-keypoint reprojection residual (BASELINE config 4) ----
+ * NOT part of the reference repository: there the per-frame fit is the external SMPLify-X step (README.md:14-17) and
+ * the only in-repo projection is a viewer overlay (local_vis.py:368-378; intrinsics fx = fy = 692, cx = 640, cy = 360,
+ * vis.py:358-360).  Objective restated from the published SMPLify-X data term and L2 priors (csrc/fdc_fit2d.h);
+ * frames are independent.  Use: fdcap_opt_create (scale_init = 1), fdcap_opt_set_inputs (camera_ext rows = identity, so
+ * the "world" joints are camera-frame joints + camera_translation), fdcap_opt_set_keypoints, then per iteration
+ * fdcap_opt_backward_fit2d + fdcap_opt_step_x; fdcap_opt_reset_adam between stages; fdcap_opt_get_results. */
+typedef struct fdcap_fit2d_stage {
+    float fx, fy, cx, cy;   /* pinhole intrinsics */
+    float rho;              /* GMoF scale in pixels (SMPLify-X: 100) */
+    float w_data, w_pose, w_shape, w_hand;   /* stage weights (enter squared) */
+} fdcap_fit2d_stage;
+/* kp_d DEVICE [n_local,23,3]: (u, v, confidence) of SMPL-X joints 0..22 (the joints[:, 0:23] the reference reads, :298). */
+int fdcap_opt_set_keypoints(fdcap_ctx* ctx, const float* kp_d, void* stream);
+/* zero_grad + loss + backward; only body_rotation_rec gets a gradient.  log_terms != 0: losses_d [0] = data term,
+ * [1] = priors (both already weighted, summed over this rank's frames). */
+int fdcap_opt_backward_fit2d(fdcap_ctx* ctx, const fdcap_fit2d_stage* stage, int32_t log_terms, void* stream);
+int fdcap_opt_reset_adam(fdcap_ctx* ctx, void* stream);
+
 /* Multi-GPU iteration tail with ONE collective per iteration (instead of an all-reduce before the
  * step and point-to-point halo messages after it):
  *   fdcap_opt_step_rows_and_pack : Adam on body_rotation_rec / camera_ext of the owned rows, then writes

@@ -11,7 +11,11 @@ What it is: a PyTorch-CPU (fp32 / fp64) restatement of
   * smplx SMPLX.forward / lbs                (oracle/smplx.py,   global_optimization.py:280)
   * ChamferDistancePytorch chamferDist       (oracle/chamfer.py, global_optimization.py:292)
   * FittingOP.cal_loss / init / fitting      (oracle/fitting.py, global_optimization.py:191-312,
-                                              :450-489, :558-593, :632-635)
+                                              :450-489, :558-593, :632-635; modes 'local' :315-447, :499-556
+                                              and 'dct' :232-246, :595-630)
+  * optimization.py's per-frame smoother     (oracle/smoother.py, optimization.py:155-238, :334-348)
+  * per-frame inner fit with a 2D reprojection term -- NOT in the reference (external SMPLify-X step): the autograd
+    twin of csrc/fdc_fit2d.h, parity unpinned              (oracle/innerfit.py)
 
 Parity pinning: the reference ships no tests, golden vectors or fixtures, and
 the third-party packages above are absent from /root/reference and from this image, so their

@@ -9,6 +9,7 @@
 #include <vector>
 
 #include "../../4dcapture-fpv_amd/csrc/fdc_dct.h"
+#include "../../4dcapture-fpv_amd/csrc/fdc_fit2d.h"
 #include "../../4dcapture-fpv_amd/csrc/fdc_frame.h"
 #include "../../4dcapture-fpv_amd/csrc/fdc_host_setup.h"
 #include "../../4dcapture-fpv_amd/csrc/fdc_loss.h"
@@ -191,6 +192,28 @@ void h_78_to_75(const float* in, int B, float* out) {
         V3 aa = tgm_rotmat_to_aa(gs_forward(x + X_SIXD, 1, nullptr));
         p[3] = aa.x; p[4] = aa.y; p[5] = aa.z;
         for (int i = 9; i < XDIM; ++i) p[i - 3] = x[i];
+    }
+}
+
+// fit2d_loss_kernel with the threads run serially: X [n,78], Jw [n,23,3], kp [n,23,3] -> dX [n,78], dJw [n,23,3], losses[2]
+void h_fit2d_loss(const float* stage9, const float* X, const float* Jw, const float* kp, int n, float* dX, float* dJw,
+                  double* losses) {
+    Fit2dStage s = {stage9[0], stage9[1], stage9[2], stage9[3], stage9[4], stage9[5], stage9[6], stage9[7], stage9[8]};
+    losses[0] = losses[1] = 0.0;
+    for (int r = 0; r < n; ++r) {
+        for (int e = 0; e < XDIM; ++e) {
+            float val;
+            dX[(size_t)r * XDIM + e] = fit2d_prior_grad(s, e, X[(size_t)r * XDIM + e], &val);
+            losses[1] += val;
+        }
+        for (int j = 0; j < NJW; ++j) {
+            const float* p = Jw + ((size_t)r * NJW + j) * 3;
+            const float* k = kp + ((size_t)r * NJW + j) * 3;
+            V3 dJ;
+            losses[0] += fit2d_joint(s, v3(p[0], p[1], p[2]), k[0], k[1], k[2], &dJ);
+            float* o = dJw + ((size_t)r * NJW + j) * 3;
+            o[0] = dJ.x; o[1] = dJ.y; o[2] = dJ.z;
+        }
     }
 }
 
