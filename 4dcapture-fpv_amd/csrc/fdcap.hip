@@ -37,15 +37,31 @@ struct SyncBlock {
 // kernels
 // ------------------------------------------------------------------------------------------
 
+// The kinematic tree's index arrays, staged in LDS once per workgroup: the level loops of pose_forward / pose_backward
+// chase level_start -> order -> parents -> child lists, and from global memory every hop is a dependent load (~30 per frame).
+struct PoseTopo { int parents[NJ], order[NJ], level_start[MAX_LEVELS + 1], child_start[NJ + 1], child_list[NJ]; };
+__device__ __forceinline__ PoseModel stage_topology(const PoseModel& pm, PoseTopo& t) {
+    const int tid = threadIdx.x;
+    if (tid < NJ) { t.parents[tid] = pm.parents[tid]; t.order[tid] = pm.order[tid]; t.child_list[tid] = tid < NJ - 1 ? pm.child_list[tid] : 0; }
+    if (tid <= NJ) t.child_start[tid] = pm.child_start[tid];
+    if (tid <= pm.nlevels && tid <= MAX_LEVELS) t.level_start[tid] = pm.level_start[tid];
+    __syncthreads();
+    PoseModel l = pm;
+    l.parents = t.parents; l.order = t.order; l.level_start = t.level_start; l.child_start = t.child_start; l.child_list = t.child_list;
+    return l;
+}
+
 // one 64-thread workgroup (one wavefront) per frame
 __global__ __launch_bounds__(64) void pose_fwd_kernel(PoseModel pm, const float* __restrict__ X, const float* __restrict__ O,
                                                       const float* __restrict__ CAM, const float* __restrict__ scale,
                                                       int row0, float* Rm, float* PF, float* Jrest, float* G, float* A,
                                                       float* M, float* Jw, const float* AA) {
     __shared__ PoseScratch sc;
+    __shared__ PoseTopo topo;
+    const PoseModel pml = stage_topology(pm, topo);
     int r = row0 + blockIdx.x;
     if (PF && threadIdx.x < NBETA) PF[(size_t)r * NPFX + NPF + threadIdx.x] = X[(size_t)r * XDIM + X_BETAS + threadIdx.x];
-    pose_forward(pm, X + (size_t)r * XDIM, O ? O + (size_t)r * ODIM : nullptr, CAM + (size_t)r * 16, *scale, sc,
+    pose_forward(pml, X + (size_t)r * XDIM, O ? O + (size_t)r * ODIM : nullptr, CAM + (size_t)r * 16, *scale, sc,
                  Rm ? Rm + (size_t)r * NJ * 9 : nullptr, PF ? PF + (size_t)r * NPFX : nullptr,
                  Jrest ? Jrest + (size_t)r * NJ * 3 : nullptr, G ? G + (size_t)r * NJ * 12 : nullptr,
                  A ? A + (size_t)r * NJ * 12 : nullptr, M ? M + (size_t)r * 12 : nullptr,
@@ -61,8 +77,10 @@ __global__ __launch_bounds__(64) void pose_bwd_kernel(PoseModel pm, const float*
                                                       int dbeta_stride, const float* dtransl_v, float* dX, float* dO,
                                                       float* dCAM, float* dscale_row) {
     __shared__ PoseScratch sc;
+    __shared__ PoseTopo topo;
+    const PoseModel pml = stage_topology(pm, topo);
     int r = row0 + blockIdx.x;
-    pose_backward(pm, X + (size_t)r * XDIM, O + (size_t)r * ODIM, CAM + (size_t)r * 16, *scale,
+    pose_backward(pml, X + (size_t)r * XDIM, O + (size_t)r * ODIM, CAM + (size_t)r * 16, *scale,
                   Rm + (size_t)r * NJ * 9, Jrest + (size_t)r * NJ * 3, G + (size_t)r * NJ * 12,
                   dA ? dA + (size_t)r * NJ * 12 : nullptr, dPF ? dPF + (size_t)r * NPFX : nullptr,
                   dJw ? dJw + (size_t)r * NJW * 3 : nullptr, dMv ? dMv + (size_t)r * 12 : nullptr,
