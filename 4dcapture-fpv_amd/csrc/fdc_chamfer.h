@@ -618,11 +618,20 @@ __global__ __launch_bounds__(256) void nn_stream_kernel(const float* __restrict_
 // blockIdx -> query group is XCD-aware: each XCD serves a contiguous range of groups (frames that follow
 // each other touch the same scene chunks, so an XCD's L2 holds 1/8 of the clip's neighbourhoods).
 constexpr int ST4_MAXLIST = 512;       // survivors one wave can list out of its quarter of the chunks
-constexpr int ST4_PF = 8;              // A fragments in flight per wave
+// Ring depth vs occupancy (measured at 512 k queries, NQ = 1, one wave per group): 8 fragments / 4 waves per SIMD
+// (128 VGPR) 0.148 ms, 4 / 5 (92 VGPR) 0.139, 2 / 6 (80 VGPR) 0.136: the launch is latency-bound on its set-up
+// chain, so resident waves hide more than a deeper ring does.
+#ifndef FDC_ST4_PF
+#define FDC_ST4_PF 2
+#endif
+#ifndef FDC_ST4_OCC
+#define FDC_ST4_OCC 6
+#endif
+constexpr int ST4_PF = FDC_ST4_PF;     // A fragments in flight per wave
 constexpr int ST4_SUPER = 16;          // chunks per super-cell of the two-level survivor test (consecutive chunks = one k-d subtree)
 
 template <int NQ, int WPG>
-__global__ __launch_bounds__(256, NQ == 1 ? 4 : 3) void nn_stream4_kernel(const float* __restrict__ q, int nq, NNTarget T,
+__global__ __launch_bounds__(256, NQ == 1 ? FDC_ST4_OCC : 3) void nn_stream4_kernel(const float* __restrict__ q, int nq, NNTarget T,
                                                          const int* __restrict__ seed, float4* __restrict__ seedpt,
                                                          float* __restrict__ dist, int* __restrict__ idx) {
     __shared__ unsigned short slist[4][ST4_MAXLIST];
@@ -754,7 +763,7 @@ __global__ __launch_bounds__(256, NQ == 1 ? 4 : 3) void nn_stream4_kernel(const 
     }
     const f32x16_t zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     constexpr int NT = MF_CH / 32;                               // 16 tiles per chunk (padding rows score 1e30)
-    static_assert(NT == 2 * ST4_PF, "the prefetch ring assumes two ring turns per chunk");
+    static_assert(NT % ST4_PF == 0, "the prefetch ring turns a whole number of times per chunk");
 
     if (nsurv > 0) {
         int ch = WPG * (listed ? (int)slist[wave][0] : 0) + sub;
@@ -792,7 +801,7 @@ __global__ __launch_bounds__(256, NQ == 1 ? 4 : 3) void nn_stream4_kernel(const 
 #pragma unroll
             for (int tile = 0; tile < NT; ++tile) {
                 const bf16x8 afrag = __builtin_bit_cast(bf16x8, f[tile % ST4_PF]);
-                f[tile % ST4_PF] = tile < ST4_PF ? fr[(tile + ST4_PF) * 64] : fr_next[(tile - ST4_PF) * 64];
+                f[tile % ST4_PF] = tile + ST4_PF < NT ? fr[(tile + ST4_PF) * 64] : fr_next[(tile + ST4_PF - NT) * 64];
                 f32x16_t acc_q[NQ];
 #pragma unroll
                 for (int n = 0; n < NQ; ++n) acc_q[n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afrag, bfrag[n], zero, 0, 0, 0);
