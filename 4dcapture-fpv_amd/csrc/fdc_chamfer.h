@@ -995,7 +995,8 @@ static inline hipError_t nn_search(const float* q, int nq, const NNTarget& T, fl
     const bool culled = seed != nullptr && T.bounds != nullptr;
     // FDCAP_NN_STREAM (A/B): 0 staged kernel, 1 the first streaming kernel, WQ = nn_stream4_kernel with W waves per
     // group of 32 Q queries (41, 42, 21, 22, 11, 12); default: 32-query groups, waves per group by launch size --
-    // measured (1024 x 500 / 128 x 500 queries): 11: 0.146 / 0.071 ms, 21: 0.161 / 0.047, 41: 0.179 / 0.039
+    // measured (1024 / 512 / 256 / 128 frames x 500 queries): 11: 0.139 / 0.095 / 0.054 / 0.072 ms, 21: 0.140 / 0.087 /
+    // 0.049 / 0.047, 41: 0.153 / 0.086 / 0.047 / 0.036
     static int use_stream = -1;
     if (use_stream < 0) { const char* e = getenv("FDCAP_NN_STREAM"); use_stream = e ? atoi(e) : -2; }
     if (culled && T.frags != nullptr && use_stream && nn_use_mfma(nq, T.n)) {
@@ -1011,7 +1012,7 @@ static inline hipError_t nn_search(const float* q, int nq, const NNTarget& T, fl
             int nqv = 1, wpg;
             if (use_stream < 0) {                             // enough waves to fill 1024 SIMDs x 4 twice over, no more (the
                 const int g32 = (nq + 31) / 32;               // per-group setup is repeated by every wave of the group)
-                wpg = g32 >= 6144 ? 1 : g32 >= 3072 ? 2 : 4;
+                wpg = g32 >= 12288 ? 1 : g32 >= 6144 ? 2 : 4;
             } else {
                 nqv = (use_stream % 10 == 2) ? 2 : 1;
                 wpg = (use_stream / 10 == 4) ? 4 : (use_stream / 10 == 2) ? 2 : 1;
