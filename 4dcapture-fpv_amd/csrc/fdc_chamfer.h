@@ -20,7 +20,10 @@
 namespace fdc {
 
 constexpr int NN_TILE = 1024;          // scene points per LDS tile of the plain scan
-constexpr int MF_CH = 512;             // scene points per LDS chunk of the MFMA scan (= bound granularity)
+#ifndef FDC_MF_CH
+#define FDC_MF_CH 512
+#endif
+constexpr int MF_CH = FDC_MF_CH;       // scene points per chunk of the MFMA scans = one k-d cell = culling granularity
 
 // scene as the NN kernels see it
 struct NNTarget {
@@ -627,11 +630,14 @@ constexpr int ST4_MAXLIST = 512;       // survivors one wave can list out of its
 #ifndef FDC_ST4_OCC
 #define FDC_ST4_OCC 6
 #endif
+#ifndef FDC_ST4_OCC2
+#define FDC_ST4_OCC2 3
+#endif
 constexpr int ST4_PF = FDC_ST4_PF;     // A fragments in flight per wave
 constexpr int ST4_SUPER = 16;          // chunks per super-cell of the two-level survivor test (consecutive chunks = one k-d subtree)
 
 template <int NQ, int WPG>
-__global__ __launch_bounds__(256, NQ == 1 ? FDC_ST4_OCC : 3) void nn_stream4_kernel(const float* __restrict__ q, int nq, NNTarget T,
+__global__ __launch_bounds__(256, NQ == 1 ? FDC_ST4_OCC : FDC_ST4_OCC2) void nn_stream4_kernel(const float* __restrict__ q, int nq, NNTarget T,
                                                          const int* __restrict__ seed, float4* __restrict__ seedpt,
                                                          float* __restrict__ dist, int* __restrict__ idx) {
     __shared__ unsigned short slist[4][ST4_MAXLIST];
@@ -710,7 +716,11 @@ __global__ __launch_bounds__(256, NQ == 1 ? FDC_ST4_OCC : 3) void nn_stream4_ker
     // workgroups per launch at 500k points, more than everything else the kernel reads.)
     int nsurv = myn;
     bool listed = false;
+#if defined(FDC_ST4_ABLATE) && FDC_ST4_ABLATE >= 2
+    if (false) {                                                 // timing ablation only: no survivor list either
+#else
     if (cull) {
+#endif
         nsurv = 0;
         listed = true;
         const float r2 = reach * reach;
@@ -765,6 +775,9 @@ __global__ __launch_bounds__(256, NQ == 1 ? FDC_ST4_OCC : 3) void nn_stream4_ker
     constexpr int NT = MF_CH / 32;                               // 16 tiles per chunk (padding rows score 1e30)
     static_assert(NT % ST4_PF == 0, "the prefetch ring turns a whole number of times per chunk");
 
+#if defined(FDC_ST4_ABLATE) && FDC_ST4_ABLATE >= 1
+    nsurv = 0;                                                   // timing ablation only (wrong results): no main loop
+#endif
     if (nsurv > 0) {
         int ch = WPG * (listed ? (int)slist[wave][0] : 0) + sub;
         const uint4* fr = T.frags + (size_t)ch * NT * 64 + lane;          // [tile][half][col] == [tile][lane]
