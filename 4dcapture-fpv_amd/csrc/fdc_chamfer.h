@@ -665,7 +665,6 @@ __global__ __launch_bounds__(256, NQ == 1 ? FDC_ST4_OCC : FDC_ST4_OCC2) void nn_
     int own_i[NQ], qidx[NQ];
     float4 own_p[NQ];          // the current best {x, y, z, bits(position in T.pts)}: it passes the filter by construction and
                                // must not cost a global load every time it is met; next iteration's seed point
-    float sx = 0.f, sy = 0.f, sz = 0.f, sc = 0.f;
     bool all_seeded = true;
 #pragma unroll
     for (int n = 0; n < NQ; ++n) {
@@ -678,7 +677,6 @@ __global__ __launch_bounds__(256, NQ == 1 ? FDC_ST4_OCC : FDC_ST4_OCC2) void nn_
         own_i[n] = -1;
         own_p[n] = make_float4(0.f, 0.f, 0.f, __int_as_float(-1));
         if (ok) {
-            sx += qx[n]; sy += qy[n]; sz += qz[n]; sc += 1.f;
             const int sj = seed[qidx[n]];
             const float4 p = seedpt[qidx[n]];                  // the seed's coordinates, kept from the launch that found it
             if (sj >= 0 && sj < T.n) {
@@ -691,26 +689,32 @@ __global__ __launch_bounds__(256, NQ == 1 ? FDC_ST4_OCC : FDC_ST4_OCC2) void nn_
         }
         sb[n] = ok ? own_d[n] * 1.00002f + 1e-9f : -INFINITY;   // bound with the rounding slack of the box test
     }
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) {
-        sx += __shfl_xor(sx, off, 64); sy += __shfl_xor(sy, off, 64); sz += __shfl_xor(sz, off, 64); sc += __shfl_xor(sc, off, 64);
-    }
-    const float inv = 1.f / fmaxf(sc, 1.f);
-    const float wx = sx * inv, wy = sy * inv, wz = sz * inv;
-    float reach = 0.f;
+    // Group bound for the box tests: the axis-aligned box around the queries' balls (centre x_i, radius sqrt(bound_i)).
+    // A cell some query needs intersects that query's ball, hence this box -- and for elongated groups (a shin above a
+    // floor) the box is far tighter than a sphere around the centroid with the largest reach.
+    float glx = INFINITY, gly = INFINITY, glz = INFINITY, ghx = -INFINITY, ghy = -INFINITY, ghz = -INFINITY;
+    bool finite = true;
 #pragma unroll
     for (int n = 0; n < NQ; ++n)
         if (qidx[n] < nq) {
-            const float dx = qx[n] - wx, dy = qy[n] - wy, dz = qz[n] - wz;
-            reach = fmaxf(reach, sqrtf(dx * dx + dy * dy + dz * dz) + sqrtf(own_d[n]));
+            const float r = sqrtf(sb[n]) * 1.00001f + 1e-6f;
+            finite &= r < INFINITY;
+            glx = fminf(glx, qx[n] - r); gly = fminf(gly, qy[n] - r); glz = fminf(glz, qz[n] - r);
+            ghx = fmaxf(ghx, qx[n] + r); ghy = fmaxf(ghy, qy[n] + r); ghz = fmaxf(ghz, qz[n] + r);
         }
 #pragma unroll
-    for (int off = 32; off > 0; off >>= 1) reach = fmaxf(reach, __shfl_xor(reach, off, 64));
-    reach = reach * 1.00001f + 1e-6f;
-    const bool cull = __all(all_seeded) && reach < INFINITY;
+    for (int off = 32; off > 0; off >>= 1) {
+        glx = fminf(glx, __shfl_xor(glx, off, 64)); gly = fminf(gly, __shfl_xor(gly, off, 64)); glz = fminf(glz, __shfl_xor(glz, off, 64));
+        ghx = fmaxf(ghx, __shfl_xor(ghx, off, 64)); ghy = fmaxf(ghy, __shfl_xor(ghy, off, 64)); ghz = fmaxf(ghz, __shfl_xor(ghz, off, 64));
+    }
+    const bool cull = __all(all_seeded && finite);
+    // box-box overlap (closed): false only if the boxes are strictly apart along some axis
+    auto overlaps = [&](float4 lo, float4 hi) -> bool {
+        return !(lo.x > ghx || hi.x < glx || lo.y > ghy || hi.y < gly || lo.z > ghz || hi.z < glz);
+    };
 
     // Survivor list of this wave, two levels: the boxes of 16-chunk super-cells (k-d subtrees) are tested against
-    // the group's reach 64 per round by every wave; inside the near super-cells each wave tests ITS chunks
+    // the group's box 64 per round by every wave; inside the near super-cells each wave tests ITS chunks
     // (4 j + wave, j < 4) -- 16 super-cells x 4 chunks per round of lanes -- against the reach and then per query.
     // (Testing all chunk boxes directly costs every workgroup the whole box array through L1/L2: 31 KB x 16000
     // workgroups per launch at 500k points, more than everything else the kernel reads.)
@@ -723,12 +727,11 @@ __global__ __launch_bounds__(256, NQ == 1 ? FDC_ST4_OCC : FDC_ST4_OCC2) void nn_
 #endif
         nsurv = 0;
         listed = true;
-        const float r2 = reach * reach;
         const int nsuper = (nchunk + ST4_SUPER - 1) / ST4_SUPER;
         for (int s0 = 0; s0 < nsuper && listed; s0 += 64) {
             const int si = s0 + lane;
             bool nearS = false;
-            if (si < nsuper) nearS = !(box_d2(T.sbounds[2 * si], T.sbounds[2 * si + 1], wx, wy, wz) > r2);
+            if (si < nsuper) nearS = overlaps(T.sbounds[2 * si], T.sbounds[2 * si + 1]);
             unsigned long long ms = __ballot(nearS);
             while (ms && listed) {                               // batches of 64 / CPS near super-cells
                 int mysuper = -1, e = 0;
@@ -744,7 +747,7 @@ __global__ __launch_bounds__(256, NQ == 1 ? FDC_ST4_OCC : FDC_ST4_OCC2) void nn_
                 if (mysuper >= 0 && ci < nchunk) {
                     lo = T.bounds[2 * ci];
                     hi = T.bounds[2 * ci + 1];
-                    near = !(box_d2(lo, hi, wx, wy, wz) > r2);
+                    near = overlaps(lo, hi);
                 }
                 unsigned long long m = __ballot(near);
                 while (m) {                                      // wave-uniform loop over the near chunks of this batch
