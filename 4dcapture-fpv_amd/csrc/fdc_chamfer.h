@@ -436,188 +436,18 @@ __global__ __launch_bounds__(256) void nn_mfma_kernel(const float* __restrict__ 
 
 // ---------------------------------------------------------------------------------------------
 // Streaming variant for seeded + culled launches (the optimiser's steady state).
-// With 2-3 % of the chunks surviving, the staged kernel above is bound by the per-chunk
-// global-load -> convert -> LDS -> barrier latency, not by the matrix pipe.  Here every WAVE is
-// independent: it builds its own survivor list (its 32*NQ queries are spatially compact because the
-// contact slots are Morton-ordered), re-centres its queries on each surviving chunk's centre and
-// streams that chunk's PRECOMPUTED A fragments (NNTarget::frags, static per scene) from global
-// memory straight into registers, software-pipelined two tiles ahead.  No LDS staging, no
-// __syncthreads in the main loop, no partial minima / combine pass (one scan per query).
-// Same filter, same exact re-evaluation, same (d, index) order => bit-identical results.
-// eps per chunk: |y'| <= chunk radius rc, so eps = K1 * X * rc + K2 * (X^2 + rc^2), X = |x - centre|.
-constexpr int ST_MAXLIST = 1024;       // survivors a wave can list (more -> it falls back to scanning every chunk)
-
-template <int NQ>
-__global__ __launch_bounds__(256) void nn_stream_kernel(const float* __restrict__ q, int nq, NNTarget T,
-                                                        const int* __restrict__ seed, float* __restrict__ dist,
-                                                        int* __restrict__ idx) {
-    __shared__ unsigned short slist[4][ST_MAXLIST];
-    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, half = lane >> 5, col = lane & 31;
-    const int wq0 = (blockIdx.x * 4 + wave) * (32 * NQ);       // first query of this wave
-    if (wq0 >= nq) return;                                      // whole wave idle (no barriers below)
-    const int nchunk = (T.n + MF_CH - 1) / MF_CH;
-
-    float qx[NQ], qy[NQ], qz[NQ], own_d[NQ], sb[NQ];
-    int own_i[NQ], qidx[NQ];
-    float sx = 0.f, sy = 0.f, sz = 0.f, sc = 0.f;
-    bool all_seeded = true;
-#pragma unroll
-    for (int n = 0; n < NQ; ++n) {
-        qidx[n] = wq0 + n * 32 + col;
-        const bool ok = qidx[n] < nq;
-        qx[n] = ok ? q[3 * (size_t)qidx[n]] : 0.f;
-        qy[n] = ok ? q[3 * (size_t)qidx[n] + 1] : 0.f;
-        qz[n] = ok ? q[3 * (size_t)qidx[n] + 2] : 0.f;
-        own_d[n] = INFINITY;
-        own_i[n] = -1;
-        if (ok) {
-            sx += qx[n]; sy += qy[n]; sz += qz[n]; sc += 1.f;
-            const int sj = seed[qidx[n]];
-            if (sj >= 0 && sj < T.n) {
-                const float4 p = T.pts[T.inv_perm ? T.inv_perm[sj] : sj];
-                own_d[n] = nn_exact_d2(qx[n], qy[n], qz[n], p.x, p.y, p.z);
-                own_i[n] = sj;
-            } else {
-                all_seeded = false;
-            }
-        }
-        sb[n] = ok ? own_d[n] * 1.00002f + 1e-9f : -INFINITY;   // bound with the rounding slack of the box test
-    }
-    // wave centroid + reach
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) {
-        sx += __shfl_xor(sx, off, 64); sy += __shfl_xor(sy, off, 64); sz += __shfl_xor(sz, off, 64); sc += __shfl_xor(sc, off, 64);
-    }
-    const float inv = 1.f / fmaxf(sc, 1.f);
-    const float wx = sx * inv, wy = sy * inv, wz = sz * inv;
-    float reach = 0.f;
-#pragma unroll
-    for (int n = 0; n < NQ; ++n)
-        if (qidx[n] < nq) {
-            const float dx = qx[n] - wx, dy = qy[n] - wy, dz = qz[n] - wz;
-            reach = fmaxf(reach, sqrtf(dx * dx + dy * dy + dz * dz) + sqrtf(own_d[n]));
-        }
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) reach = fmaxf(reach, __shfl_xor(reach, off, 64));
-    reach = reach * 1.00001f + 1e-6f;
-    const bool cull = __all(all_seeded) && reach < INFINITY;
-
-    // survivor list of this wave: pass 1 (64 chunks per round against the wave's reach), pass 2 per query
-    int nsurv = nchunk;
-    bool listed = false;
-    if (cull) {
-        nsurv = 0;
-        listed = true;
-        const float r2 = reach * reach;
-        for (int c0 = 0; c0 < nchunk && listed; c0 += 64) {
-            const int ci = c0 + lane;
-            bool near = false;
-            if (ci < nchunk) near = !(box_d2(T.bounds[2 * ci], T.bounds[2 * ci + 1], wx, wy, wz) > r2);
-            unsigned long long m = __ballot(near);
-            while (m) {                                          // wave-uniform loop over the near chunks of this round
-                const int b = __ffsll((long long)m) - 1;
-                m &= m - 1;
-                const float4 lo = T.bounds[2 * (c0 + b)], hi = T.bounds[2 * (c0 + b) + 1];
-                bool hit = false;
-#pragma unroll
-                for (int n = 0; n < NQ; ++n) hit |= box_d2(lo, hi, qx[n], qy[n], qz[n]) <= sb[n];
-                if (__any(hit)) {
-                    if (nsurv >= ST_MAXLIST) { listed = false; break; }
-                    if (lane == 0) slist[wave][nsurv] = (unsigned short)(c0 + b);
-                    ++nsurv;
-                }
-            }
-        }
-        if (!listed) nsurv = nchunk;                            // list overflow: scan everything (still exact)
-    }
-    const f32x16_t zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-
-    for (int s = 0; s < nsurv; ++s) {
-        const int ch = listed ? (int)slist[wave][s] : s;
-        const float4 cc = T.centers[ch];
-        const uint4* fr = T.frags + (size_t)ch * (MF_CH / 32) * 64 + lane;     // [tile][half][col] == [tile][lane]
-        uint4 f0 = fr[0], f1 = fr[64];                          // two tiles in flight
-        // re-centre this wave's queries on the chunk centre
-        bf16x8 bfrag[NQ];
-        float thr[NQ], X[NQ], X2[NQ];
-        const float rc = cc.w;
-#pragma unroll
-        for (int n = 0; n < NQ; ++n) {
-            const float xx = qx[n] - cc.x, xy = qy[n] - cc.y, xz = qz[n] - cc.z;
-            X2[n] = __fmaf_rn(xz, xz, __fmaf_rn(xy, xy, xx * xx));
-            X[n] = sqrtf(X2[n]);
-            const unsigned hx = f2bf(xx), hy = f2bf(xy), hz = f2bf(xz);
-            const unsigned lx = f2bf(xx - bf2f(hx)), ly = f2bf(xy - bf2f(hy)), lz = f2bf(xz - bf2f(hz));
-            const unsigned px = f2bf(-2.f * bf2f(hx)) | (f2bf(-2.f * bf2f(lx)) << 16);
-            const unsigned py = f2bf(-2.f * bf2f(hy)) | (f2bf(-2.f * bf2f(ly)) << 16);
-            const unsigned pz = f2bf(-2.f * bf2f(hz)) | (f2bf(-2.f * bf2f(lz)) << 16);
-            const unsigned one = 0x3F80u;
-            const uint4 u = half == 0 ? make_uint4(px, px, py, py) : make_uint4(pz, pz, one | (one << 16), one);
-            bfrag[n] = __builtin_bit_cast(bf16x8, u);
-            const float sbest = fminf(own_d[n], __shfl_xor(own_d[n], 32, 64));
-            thr[n] = (qidx[n] < nq) ? sbest - X2[n] + (MF_K1 * X[n] * rc + MF_K2 * (X2[n] + rc * rc)) : -INFINITY;
-        }
-        const int base = ch * MF_CH;
-        const int ntile = (min(MF_CH, T.n - base) + 31) >> 5;
-        for (int tile = 0; tile < ntile; ++tile) {
-            const bf16x8 afrag = __builtin_bit_cast(bf16x8, f0);
-            f0 = f1;
-            if (tile + 2 < ntile) f1 = fr[(tile + 2) * 64];
-            f32x16_t acc_q[NQ];
-            acc_q[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afrag, bfrag[0], zero, 0, 0, 0);
-            if (NQ > 1) acc_q[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afrag, bfrag[1], zero, 0, 0, 0);
-#pragma unroll
-            for (int n = 0; n < NQ; ++n) {
-                const f32x16_t acc = acc_q[n];
-                if (n + 2 < NQ) acc_q[n + 2] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afrag, bfrag[n + 2], zero, 0, 0, 0);
-                const float t0 = fminf(fminf(acc[0], acc[1]), acc[2]), t1 = fminf(fminf(acc[3], acc[4]), acc[5]);
-                const float t2 = fminf(fminf(acc[6], acc[7]), acc[8]), t3 = fminf(fminf(acc[9], acc[10]), acc[11]);
-                const float t4 = fminf(fminf(acc[12], acc[13]), acc[14]);
-                const float m = fminf(fminf(fminf(t0, t1), t2), fminf(fminf(t3, t4), acc[15]));
-                if (__any(m < thr[n])) {
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) {
-                        if (acc[r] < thr[n]) {
-                            const int row = (r & 3) + 8 * (r >> 2) + 4 * half;
-                            const int pos = base + tile * 32 + row;
-                            if (pos < T.n) {
-                                const float4 p = T.pts[pos];
-                                const int gi = __float_as_int(p.w);
-                                const float d = nn_exact_d2(qx[n], qy[n], qz[n], p.x, p.y, p.z);
-                                if (nn_better(d, gi, own_d[n], own_i[n])) {
-                                    own_d[n] = d;
-                                    own_i[n] = gi;
-                                    thr[n] = d - X2[n] + (MF_K1 * X[n] * rc + MF_K2 * (X2[n] + rc * rc));
-                                }
-                            }
-                        }
-                    }
-                    const float sbest = fminf(own_d[n], __shfl_xor(own_d[n], 32, 64));
-                    if (qidx[n] < nq) thr[n] = sbest - X2[n] + (MF_K1 * X[n] * rc + MF_K2 * (X2[n] + rc * rc));
-                }
-            }
-        }
-    }
-#pragma unroll
-    for (int n = 0; n < NQ; ++n) {
-        const float od = __shfl_xor(own_d[n], 32, 64);
-        const int oi = __shfl_xor(own_i[n], 32, 64);
-        if (oi >= 0 && (own_i[n] < 0 || nn_better(od, oi, own_d[n], own_i[n]))) { own_d[n] = od; own_i[n] = oi; }
-        if (half == 0 && qidx[n] < nq) { dist[qidx[n]] = own_d[n]; idx[qidx[n]] = own_i[n]; }
-    }
-}
-
-// ---------------------------------------------------------------------------------------------
-// Streaming variant, four waves per query group (the optimiser's steady-state launch).
-// nn_stream_kernel gives every wave its own 32*NQ queries and the whole survivor list: at shard sizes
-// (64k queries = 1000 waves on 1024 SIMDs) one wave per SIMD walks a serial chain of
-// list-building -> ~10 chunks x 16 dependent global loads with nothing to overlap them.  Here the FOUR
-// waves of a workgroup share one query group and deal the Morton-ordered chunks round-robin (chunk c
-// belongs to wave c & 3): four times the waves, a quarter of the serial chain each, and neighbouring
-// chunks -- which tend to survive together -- spread evenly.  Each wave keeps ST4_PF A fragments in
-// flight (ring of registers, prefetch runs across chunk boundaries), the exact path is a compact
-// bit-mask loop so the 16-tile body unrolls, and the four partial results meet in LDS once at the end,
-// merged by the same (d, index) order => bit-identical results to every other kernel here.
+// With ~1 % of the cells surviving, the staged kernel above is bound by the per-chunk global-load -> convert ->
+// LDS -> barrier latency, not by the matrix pipe.  Here a group of 32*NQ queries (spatially compact: the contact
+// slots are Morton-ordered) is served by WPG = 1, 2 or 4 waves of a workgroup.  Each wave builds its own survivor
+// list over the cells dealt to it round-robin (cell c belongs to wave c % WPG: neighbouring cells -- which tend to
+// survive together -- spread evenly), re-centres the queries on each surviving cell's centre and streams that cell's
+// PRECOMPUTED A fragments (NNTarget::frags, static per scene) from global memory straight into registers through a
+// short ring (ST4_PF ahead, running across cell boundaries).  No LDS staging, no barrier in the main loop, no partial
+// minima / combine pass; the exact path is a compact bit-mask loop so the 16-tile body unrolls; the waves of a group
+// meet in LDS once at the end, merged by the same (d, index) order => bit-identical results to every other kernel here.
+// eps per cell: |y'| <= cell radius rc, so eps = K1 * X * rc + K2 * (X^2 + rc^2), X = |x - centre|.
+// More waves per group = shorter serial chains and a fuller machine at shard sizes, but the group's set-up is
+// repeated by each of them: the host picks WPG by launch size.
 // blockIdx -> query group is XCD-aware: each XCD serves a contiguous range of groups (frames that follow
 // each other touch the same scene chunks, so an XCD's L2 holds 1/8 of the clip's neighbourhoods).
 constexpr int ST4_MAXLIST = 512;       // survivors one wave can list out of its quarter of the chunks
@@ -1009,21 +839,18 @@ static inline hipError_t nn_search(const float* q, int nq, const NNTarget& T, fl
     static int forced_nq = -1;
     if (forced_nq < 0) { const char* e = getenv("FDCAP_NN_NQ"); forced_nq = e ? atoi(e) : 0; }
     const bool culled = seed != nullptr && T.bounds != nullptr;
-    // FDCAP_NN_STREAM (A/B): 0 staged kernel, 1 the first streaming kernel, WQ = nn_stream4_kernel with W waves per
-    // group of 32 Q queries (41, 42, 21, 22, 11, 12); default: 32-query groups, waves per group by launch size --
+    // FDCAP_NN_STREAM (A/B): 0 staged kernel, WQ = nn_stream4_kernel with W waves per group of 32 Q queries
+    // (41, 42, 21, 22, 11, 12); default: 32-query groups, waves per group by launch size --
     // measured (1024 / 512 / 256 / 128 frames x 500 queries): 11: 0.139 / 0.095 / 0.054 / 0.072 ms, 21: 0.140 / 0.087 /
     // 0.049 / 0.047, 41: 0.153 / 0.086 / 0.047 / 0.036
     static int use_stream = -1;
     if (use_stream < 0) { const char* e = getenv("FDCAP_NN_STREAM"); use_stream = e ? atoi(e) : -2; }
-    if (culled && T.frags != nullptr && use_stream && nn_use_mfma(nq, T.n)) {
-        const bool four = (use_stream > 1 || use_stream < 0) && seedpt != nullptr && seed == idx;
-        if (four && seed_missing)                             // first launch of a fit: cheap seeds (+ their coordinates) instead of a full scan
+    if (culled && T.frags != nullptr && use_stream && nn_use_mfma(nq, T.n) && seedpt != nullptr && seed == idx) {
+        if (seed_missing)                                     // first launch of a fit: cheap seeds (+ their coordinates) instead of a full scan
             hipLaunchKernelGGL(nn_seed_kernel, dim3((nq + 255) / 256), dim3(256), 0, st, q, nq, T, idx, seedpt);
-        // seed may alias idx: every workgroup reads its seeds before it writes its own results, and no other workgroup touches them
-        if (seedpt_written) *seedpt_written = four;
-        if (!four) {
-            hipLaunchKernelGGL((nn_stream_kernel<2>), dim3((nq + 255) / 256), dim3(256), 0, st, q, nq, T, seed, dist, idx);
-        } else {
+        // seed aliases idx: every workgroup reads its seeds before it writes its own results, and no other workgroup touches them
+        if (seedpt_written) *seedpt_written = true;
+        {
             // (queries per group / 32, waves per group): 42 / 41 four waves, 22 / 21 two, 12 / 11 one
             int nqv = 1, wpg;
             if (use_stream < 0) {                             // enough waves to fill 1024 SIMDs x 4 twice over, no more (the

@@ -579,14 +579,14 @@ struct DevBuf {
 
 struct SkinSet {          // skinning constants for a vertex set (all V, or the contact subset)
     int nv = 0, K = 0;
-    DevBuf<float> vt, S, ww, posedirs, csc_w;   // posedirs [496, 3*nv] = [posedirs ; shapedirs^T]
+    DevBuf<float> vt, ww, posedirs, csc_w;      // posedirs [496, 3*nv] = [posedirs ; shapedirs^T]
     DevBuf<int> wj, csc_start, csc_v;
     SkinModel model() const {
         SkinModel m; m.vt = vt.p; m.S = nullptr; m.wj = wj.p; m.ww = ww.p; m.K = K;
         m.csc_start = csc_start.p; m.csc_v = csc_v.p; m.csc_w = csc_w.p;
         return m;
     }
-    void release() { vt.release(); S.release(); ww.release(); posedirs.release(); wj.release(); csc_w.release(); csc_start.release(); csc_v.release(); }
+    void release() { vt.release(); ww.release(); posedirs.release(); wj.release(); csc_w.release(); csc_start.release(); csc_v.release(); }
 };
 
 struct OptState {
@@ -604,7 +604,7 @@ struct OptState {
     DevBuf<int> idx, pi;
     DevBuf<float> kp2d;       // per-frame inner fit: 2D keypoints [n_local,23,3] (u, v, confidence)
     DevBuf<float4> seedpt;    // coordinates (+ position in the sorted scene) of each query's current neighbour: next launch's seed
-    DevBuf<float> dA, dbeta_v, dtransl_v, dMv, dsv, dPF, dJw, dX, dCAM, dscale_row;
+    DevBuf<float> dA, dtransl_v, dMv, dsv, dPF, dJw, dX, dCAM, dscale_row;     // d betas: columns 486.. of dPF
     DevBuf<float> VoffF, VwF, dVF;      // mode 'local' second loop: full-mesh pose offsets / world vertices / gradient
     int cam_steps = 0;
     // mode 'dct': basis [T,C], coefficients + Adam moments [W,69,C] (W = n_total / T windows of the whole clip)
@@ -1131,7 +1131,7 @@ void fdcap_opt_destroy(fdcap_ctx* c) {
     OptState* o = c->opt;
     DevBuf<float>* fb[] = {&o->X0, &o->mask, &o->mX, &o->vX, &o->mCAM, &o->vCAM, &o->mS, &o->vS,
                            &o->H1, &o->H2, &o->O, &o->dO, &o->dH2, &o->dH1, &o->Rm, &o->PF, &o->Jrest, &o->G, &o->A, &o->M,
-                           &o->Jw, &o->Voff, &o->Vw, &o->dist, &o->pd, &o->dVoff, &o->dA, &o->dbeta_v, &o->dtransl_v, &o->dMv,
+                           &o->Jw, &o->Voff, &o->Vw, &o->dist, &o->pd, &o->dVoff, &o->dA, &o->dtransl_v, &o->dMv,
                            &o->dsv, &o->dPF, &o->dJw, &o->dX, &o->dCAM, &o->dscale_row, &o->VoffF, &o->VwF, &o->dVF};
     for (auto* b : fb) b->release();
     o->dctD.release(); o->dctCoef.release(); o->dctM.release(); o->dctV.release(); o->adam_tab.release();
@@ -1176,7 +1176,7 @@ int fdcap_opt_create(fdcap_ctx* c, const fdcap_opt_config* cfg, float* rows_x, f
     AL(o->dH2, (size_t)R * 512) AL(o->dH1, (size_t)R * 512)
     AL(o->Rm, (size_t)R * NJ * 9) AL(o->PF, (size_t)R * NPFX) AL(o->Jrest, (size_t)R * NJ * 3) AL(o->G, (size_t)R * NJ * 12)
     AL(o->A, (size_t)R * NJ * 12) AL(o->M, (size_t)R * 12) AL(o->Jw, (size_t)R * NJW * 3)
-    AL(o->dA, (size_t)R * NJ * 12) AL(o->dbeta_v, (size_t)R * NBETA) AL(o->dtransl_v, (size_t)R * 3) AL(o->dMv, (size_t)R * 12)
+    AL(o->dA, (size_t)R * NJ * 12) AL(o->dtransl_v, (size_t)R * 3) AL(o->dMv, (size_t)R * 12)
     AL(o->dsv, R) AL(o->dPF, (size_t)R * NPFX) AL(o->dJw, (size_t)R * NJW * 3) AL(o->dX, (size_t)R * XDIM)
     AL(o->dCAM, (size_t)R * 16) AL(o->dscale_row, R)
     if (o->contact_on) {

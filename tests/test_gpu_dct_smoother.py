@@ -236,3 +236,16 @@ def test_dct_mode_refuses_shards_off_the_window_grid():
     from fdcap_amd.dist import FrameShard
     sh = FrameShard(150, None, rank=1, world=2)
     assert sh.frame0 % 60 != 0
+
+
+def test_dct_mode_needs_a_full_window_and_smoother_handles_one_frame():
+    bm, vp, clip, scene, vid, _ = _dct_case(60, 120, 500, seed=5)
+    short = synth.make_clip(40, seed=9)
+    fop = FittingOP({}, {}, 40, body_model=bm, vposer=vp, scene_verts=scene, contact_ids=vid,
+                    camera_ext=read_camerapose(short.camerapose_lines), dct_num_iter=20)
+    with pytest.raises(capi.FdcapError):                                  # the reference's windows are 60 frames (:41)
+        fop.fitting(torch.tensor(short.body_params).cuda(), "dct")
+    fop.close()
+    one = SmootherOP().fitting_clip(clip.body_params[:1]).cpu().numpy()
+    ref = SmootherOracle().fitting_clip(clip.body_params[:1]).numpy()
+    assert one.shape == (1, 75) and np.abs(one - ref).max() < 1e-5

@@ -87,3 +87,19 @@ def test_config4_five_stage_fit_matches_oracle_and_reduces_the_reprojection_erro
     print("mean reprojection error (px): start", e0, "end", e1)
     assert e1 < 0.5 * e0
     op.close()
+
+
+def test_undetected_keypoints_leave_only_the_priors():
+    """confidence 0 everywhere: the data term and its gradient vanish, the L2 priors shrink latent / betas / hands and
+    nothing else moves."""
+    n = 8
+    bm, vp, gt, init, kp = _case(n, 33)
+    kp[..., 2] = 0.0
+    op = InnerFitOP(bm, vp, n, iters_per_stage=5)
+    out = op.fitting(init, kp).cpu().numpy()
+    np.testing.assert_allclose(out[:, 0:3], init[:, 0:3], atol=1e-6)          # transl
+    np.testing.assert_allclose(out[:, 72:75], init[:, 72:75], atol=1e-6)      # camera translation
+    np.testing.assert_allclose(out[:, 3:6], init[:, 3:6], atol=2e-5)          # global_orient (6D <-> aa round trip)
+    big = np.abs(init[:, 16:48]) > 0.2
+    assert np.all(np.abs(out[:, 16:48])[big] < np.abs(init[:, 16:48])[big])
+    op.close()
