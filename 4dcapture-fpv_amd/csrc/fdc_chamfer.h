@@ -271,8 +271,7 @@ __global__ __launch_bounds__(256) void nn_mfma_kernel(const float* __restrict__ 
     unsigned st_cnt[4] = {0, 0, 0, 0};
 #endif
 
-    // Survivor list.  A chunk (bounding sphere centre cc, radius rc) matters to query i only if
-    // |x_i - cc| - rc <= sqrt(best_i).  Pass 1 (one chunk per thread, parallel loads -- a serial scan
+    // Survivor list.  A chunk (axis-aligned box) matters to query i only if dist(x_i, box) <= sqrt(best_i).  Pass 1 (one chunk per thread, parallel loads -- a serial scan
     // would pay a dependent global-load latency per chunk) keeps the chunks within the workgroup's
     // reach Rw of the centroid; pass 2 tests those against every query individually (much tighter for
     // queries far from the centroid or with a distant neighbour); survivors are compacted in ascending

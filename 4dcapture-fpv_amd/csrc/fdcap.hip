@@ -616,7 +616,7 @@ struct OptState {
     bool seeded = false;      // a contact forward has run since fdcap_opt_create (idx holds neighbours)
     bool nnpt_valid = false;  // the last contact forward left the neighbours' coordinates in seedpt
     bool use_seed = true;     // last iteration's neighbours seed the NN bound (pruning only)
-    bool use_cull = true;     // skip scene chunks whose bounding sphere is out of every query's reach
+    bool use_cull = true;     // skip k-d cells whose box is out of every query's reach
 };
 
 }  // namespace
@@ -633,7 +633,7 @@ struct fdcap_ctx {
     SkinSet full, contact;
     bool full_ready = false;
     DevBuf<float4> scene;          // original order {x,y,z,bits(i)}: gradient gather by index
-    DevBuf<float4> scene_sorted;   // Morton order {x,y,z,bits(original index)}: what the NN scan streams
+    DevBuf<float4> scene_sorted;   // k-d cell order {x,y,z,bits(original index)}: what the NN scan streams
     DevBuf<float4> scene_bounds;   // axis-aligned box {lo},{hi} of each MF_CH-point chunk of scene_sorted
     DevBuf<float4> scene_sbounds;  // ... of each run of ST4_SUPER chunks
     DevBuf<int> scene_inv;         // original index -> position in scene_sorted
@@ -868,7 +868,7 @@ int fdcap_set_scene(fdcap_ctx* c, const float* xyz, int64_t ns) {
         bounds[2 * ch] = make_float4(blo[0], blo[1], blo[2], 0.f);
         bounds[2 * ch + 1] = make_float4(bhi[0], bhi[1], bhi[2], 0.f);
     }
-    // chunk-centred bf16 hi/lo fragments in MFMA A layout (see nn_stream_kernel)
+    // chunk-centred bf16 hi/lo fragments in MFMA A layout (see nn_stream4_kernel)
     auto bf = [](float f) -> uint32_t { uint32_t u; memcpy(&u, &f, 4); u += 0x7FFFu + ((u >> 16) & 1u); return u >> 16; };   // RNE
     auto bff = [](uint32_t h) -> float { uint32_t u = h << 16; float f; memcpy(&f, &u, 4); return f; };
     std::vector<uint4> frags((size_t)nchunk * (MF_CH / 32) * 64);
