@@ -69,21 +69,46 @@ __global__ __launch_bounds__(64) void pose_fwd_kernel(PoseModel pm, const float*
                  AA ? AA + (size_t)r * 66 : nullptr);
 }
 
+// optional fused prologue of pose_bwd_kernel (X0 == nullptr: off)
+struct ParamLossIn { const float* X0; const float* mask; const float* Jw; int frame0, n_total; float w_rec, w_sm, w_ws; int world_grad; };
+
 __global__ __launch_bounds__(64) void pose_bwd_kernel(PoseModel pm, const float* __restrict__ X, const float* __restrict__ O,
                                                       const float* __restrict__ CAM, const float* __restrict__ scale,
                                                       int row0, const float* Rm, const float* Jrest, const float* G,
                                                       const float* dA, const float* dPF, const float* dJw,
                                                       const float* dMv, const float* dsv, const float* dbeta_v,
                                                       int dbeta_stride, const float* dtransl_v, float* dX, float* dO,
-                                                      float* dCAM, float* dscale_row) {
+                                                      float* dCAM, float* dscale_row, ParamLossIn pl) {
     __shared__ PoseScratch sc;
     __shared__ PoseTopo topo;
+    __shared__ float s_dJw[NJW * 3];
     const PoseModel pml = stage_topology(pm, topo);
     int r = row0 + blockIdx.x;
+    if (pl.X0) {
+        // param_loss_kernel's gradients formed here (non-logging iterations): dX row (=) data + temporal terms on the raw
+        // rows, world-smoothing gradient of this frame's joints into LDS instead of a round trip through dJw
+        const int g = pl.frame0 + blockIdx.x;
+        for (int e = threadIdx.x; e < XDIM; e += 64) {
+            const float* x = X + (size_t)r * XDIM + e;
+            float rec, sm;
+            dX[(size_t)r * XDIM + e] = param_loss_grad(g, pl.n_total, g >= 2 ? x[-2 * XDIM] : 0.f, g >= 1 ? x[-XDIM] : 0.f, x[0],
+                                                       g + 1 < pl.n_total ? x[XDIM] : 0.f, g + 2 < pl.n_total ? x[2 * XDIM] : 0.f,
+                                                       pl.X0[(size_t)r * XDIM + e], pl.mask[r], pl.w_rec, pl.w_sm, &rec, &sm);
+        }
+        if (pl.world_grad)
+            for (int e = threadIdx.x; e < NJW * 3; e += 64) {
+                const float* j = pl.Jw + (size_t)r * NJW * 3 + e;
+                float ws;
+                s_dJw[e] = world_smooth_grad(g, pl.n_total, g >= 1 ? j[-NJW * 3] : 0.f, j[0], g + 1 < pl.n_total ? j[NJW * 3] : 0.f,
+                                             pl.w_ws, &ws);
+            }
+        __syncthreads();
+    }
+    const float* dJw_row = (pl.X0 && pl.world_grad) ? s_dJw : (dJw ? dJw + (size_t)r * NJW * 3 : nullptr);
     pose_backward(pml, X + (size_t)r * XDIM, O + (size_t)r * ODIM, CAM + (size_t)r * 16, *scale,
                   Rm + (size_t)r * NJ * 9, Jrest + (size_t)r * NJ * 3, G + (size_t)r * NJ * 12,
                   dA ? dA + (size_t)r * NJ * 12 : nullptr, dPF ? dPF + (size_t)r * NPFX : nullptr,
-                  dJw ? dJw + (size_t)r * NJW * 3 : nullptr, dMv ? dMv + (size_t)r * 12 : nullptr,
+                  dJw_row, dMv ? dMv + (size_t)r * 12 : nullptr,
                   dsv ? dsv + r : nullptr, dbeta_v ? dbeta_v + (size_t)r * dbeta_stride : nullptr,
                   dtransl_v ? dtransl_v + (size_t)r * 3 : nullptr, sc, dX + (size_t)r * XDIM,
                   dO + (size_t)r * ODIM, dCAM + (size_t)r * 16, dscale_row + r, threadIdx.x, 64, SyncBlock());
@@ -1249,8 +1274,14 @@ static int opt_backward_impl(fdcap_ctx* c, const LossWeights& lw, int32_t log_te
     const float w_rec = lw.rec * cf.weight_loss_rec / ((float)N * XDIM);
     const float w_sm = (N >= 3) ? lw.smooth / ((float)(N - 2) * XDIM) : 0.f;
     const float w_ws = (lw.world_on && N >= 2) ? lw.world / ((float)(N - 1) * NJW * 3) : 0.f;
-    hipLaunchKernelGGL(param_loss_kernel, dim3(nl), dim3(128), 0, st, o->X.p, o->X0.p, o->mask.p, o->Jw.p, 2, cf.frame0, N,
-                       w_rec, w_sm, w_ws, lw.world_on ? 1 : 0, o->dX.p, o->dJw.p, losses);
+    // the parameter-space terms: their own kernel when the loss sums are wanted or the DCT term also writes dJw, else
+    // formed inside pose_bwd_kernel (one launch less per iteration)
+    const bool fuse_pl = !losses && !(o->dctW > 0 && dct_on);
+    ParamLossIn pli = {};
+    if (fuse_pl) pli = ParamLossIn{o->X0.p, o->mask.p, o->Jw.p, cf.frame0, N, w_rec, w_sm, w_ws, lw.world_on ? 1 : 0};
+    else
+        hipLaunchKernelGGL(param_loss_kernel, dim3(nl), dim3(128), 0, st, o->X.p, o->X0.p, o->mask.p, o->Jw.p, 2, cf.frame0, N,
+                           w_rec, w_sm, w_ws, lw.world_on ? 1 : 0, o->dX.p, o->dJw.p, losses);
     if (o->dctW > 0 && (dct_on || log_terms))
         hipLaunchKernelGGL(dct_joint_grad_kernel, dim3((nl * 69 + 255) / 256), dim3(256), 0, st, o->Jw.p, 2, cf.frame0, nl, o->dctT,
                            o->dctC, o->dctW, o->dctD.p, o->dctCoef.p, dct_on ? lw.dct / (69.f * (float)o->dctW) : 0.f,
@@ -1275,7 +1306,7 @@ static int opt_backward_impl(fdcap_ctx* c, const LossWeights& lw, int32_t log_te
                        o->Jrest.p, o->G.p, contact_grad ? o->dA.p : nullptr, contact_grad ? o->dPF.p : nullptr,
                        joint_grad ? o->dJw.p : nullptr, contact_grad ? o->dMv.p : nullptr, contact_grad ? o->dsv.p : nullptr,
                        contact_grad ? o->dPF.p + NPF : nullptr, NPFX, contact_grad ? o->dtransl_v.p : nullptr, o->dX.p, o->dO.p,
-                       o->dCAM.p, o->dscale_row.p);
+                       o->dCAM.p, o->dscale_row.p, pli);
     // VPoser data-gradient: dO -> dH2 -> dH1 -> d latent (accumulated into dX[:, 19:51])
     HIP_TRY(gemm_f32(false, EPI_MASK_LRELU, o->dO.p + 2 * ODIM, ODIM, c->W3.p, 512, o->dH2.p + 2 * 512, 512, nl, 512, ODIM,
                      o->H2.p + 2 * 512, 512, st));
@@ -1402,7 +1433,7 @@ int fdcap_opt_backward_fit2d(fdcap_ctx* c, const fdcap_fit2d_stage* sg, int32_t 
     hipLaunchKernelGGL(pose_bwd_kernel, dim3(nl), dim3(64), 0, st, pm, o->X.p, o->O.p, o->CAM.p, o->scale.p, 2, o->Rm.p,
                        o->Jrest.p, o->G.p, (const float*)nullptr, (const float*)nullptr, o->dJw.p, (const float*)nullptr,
                        (const float*)nullptr, (const float*)nullptr, 0, (const float*)nullptr, o->dX.p, o->dO.p, o->dCAM.p,
-                       o->dscale_row.p);
+                       o->dscale_row.p, ParamLossIn());
     HIP_TRY(gemm_f32(false, EPI_MASK_LRELU, o->dO.p + 2 * ODIM, ODIM, c->W3.p, 512, o->dH2.p + 2 * 512, 512, nl, 512, ODIM,
                      o->H2.p + 2 * 512, 512, st));
     HIP_TRY(gemm_f32(false, EPI_MASK_LRELU, o->dH2.p + 2 * 512, 512, c->W2.p, 512, o->dH1.p + 2 * 512, 512, nl, 512, 512,
@@ -1538,7 +1569,7 @@ int fdcap_opt_backward_local2(fdcap_ctx* c, const float* contact_weight, int32_t
                      3 * V, nullptr, 0, st));
     hipLaunchKernelGGL(pose_bwd_kernel, dim3(nl), dim3(64), 0, st, pm, o->X.p, o->O.p, o->CAM.p, o->scale.p, 2, o->Rm.p,
                        o->Jrest.p, o->G.p, o->dA.p, o->dPF.p, (const float*)nullptr, o->dMv.p, o->dsv.p, o->dPF.p + NPF, NPFX,
-                       o->dtransl_v.p, o->dX.p, o->dO.p, o->dCAM.p, o->dscale_row.p);
+                       o->dtransl_v.p, o->dX.p, o->dO.p, o->dCAM.p, o->dscale_row.p, ParamLossIn());
     HIP_TRY(gemm_f32(false, EPI_MASK_LRELU, o->dO.p + 2 * ODIM, ODIM, c->W3.p, 512, o->dH2.p + 2 * 512, 512, nl, 512, ODIM,
                      o->H2.p + 2 * 512, 512, st));
     HIP_TRY(gemm_f32(false, EPI_MASK_LRELU, o->dH2.p + 2 * 512, 512, c->W2.p, 512, o->dH1.p + 2 * 512, 512, nl, 512, 512,
