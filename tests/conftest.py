@@ -11,6 +11,13 @@ GOLDEN = os.path.join(ROOT, "tests", "golden")
 
 
 def pytest_configure(config):
+    # the oracle runs on torch-CPU: on a 256-thread host torch's intra-op pool is slower than 16 threads for these sizes
+    # (and much slower when the host is shared), so the suite pins a modest pool
+    try:
+        import torch
+        torch.set_num_threads(max(1, min(16, os.cpu_count() or 1)))
+    except Exception:
+        pass
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 
 
