@@ -424,18 +424,31 @@ __global__ void adam_kernel(float* __restrict__ p, float* __restrict__ m, float*
 // [nb_x, nb_x + nb_cam) camera_ext, the last block `scale` -- first reducing the per-frame d loss / d scale
 // partials in reduce_rows_kernel's fixed order when `reduce_n` > 0 (single-GPU; a sharded run gets the sum
 // from the exchange instead).
+// Sharded runs: the message of the iteration's one collective -- [first 2 | last 2 owned rows] of (x | camera_ext) +
+// this rank's d loss / d scale -- is written by the same launch (xch != nullptr): every thread that updates a boundary-row
+// element also stores it into its slot, the last block adds the reduced scale gradient (and the camera_ext rows while
+// camera_ext is not being stepped).
+constexpr int XCH_ROW = XDIM + 16;                 // 94 floats
+constexpr int XCH_LEN = 4 * XCH_ROW + 8;           // + dscale partial (+ padding to 32 B)
 struct AdamTensor { float* p; float* m; float* v; const float* g; size_t n; AdamScalars a; };
 __global__ __launch_bounds__(256) void adam_step_kernel(AdamTensor x, AdamTensor cam, AdamTensor sc, int nb_x, int nb_cam,
                                                         const float* __restrict__ dscale_row, int row0, int reduce_n,
-                                                        float* __restrict__ dscale, int scale_zero_grad) {
+                                                        float* __restrict__ dscale, int scale_zero_grad,
+                                                        float* __restrict__ xch, int n_local, const float* __restrict__ cam_rows) {
     const int b = blockIdx.x;
     if (b < nb_x + nb_cam) {
-        const AdamTensor& t = b < nb_x ? x : cam;
-        const size_t i = (size_t)(b < nb_x ? b : b - nb_x) * 256 + threadIdx.x;
+        const bool is_x = b < nb_x;
+        const AdamTensor& t = is_x ? x : cam;
+        const size_t i = (size_t)(is_x ? b : b - nb_x) * 256 + threadIdx.x;
         if (i >= t.n) return;
         float pp = t.p[i], mm = t.m[i], vv = t.v[i];
         adam_update(pp, mm, vv, t.g[i], t.a);
         t.p[i] = pp; t.m[i] = mm; t.v[i] = vv;
+        if (xch) {
+            const int w = is_x ? XDIM : 16, lr = (int)(i / w), e = (int)(i % w) + (is_x ? 0 : XDIM);
+            if (lr < 2) xch[lr * XCH_ROW + e] = pp;                                    // first two owned rows: slots 0, 1
+            if (lr >= n_local - 2) xch[(2 + lr - (n_local - 2)) * XCH_ROW + e] = pp;  // last two: slots 2, 3
+        }
         return;
     }
     __shared__ float sred[4];
@@ -451,6 +464,14 @@ __global__ __launch_bounds__(256) void adam_step_kernel(AdamTensor x, AdamTensor
     } else {
         g = *dscale;
     }
+    if (xch) {
+        if (threadIdx.x < 8) xch[4 * XCH_ROW + threadIdx.x] = threadIdx.x == 0 ? g : 0.f;
+        if (nb_cam == 0 && threadIdx.x < 64) {                                         // camera_ext unchanged this iteration
+            const int slot = threadIdx.x >> 4, e = threadIdx.x & 15;
+            const int row = slot < 2 ? 2 + slot : n_local + slot - 2;                  // buffer rows (owned rows start at 2)
+            xch[slot * XCH_ROW + XDIM + e] = cam_rows[(size_t)row * 16 + e];
+        }
+    }
     if (threadIdx.x == 0 && sc.p) {
         float pp = *sc.p, mm = *sc.m, vv = *sc.v;
         adam_update(pp, mm, vv, scale_zero_grad ? 0.f : g, sc.a);
@@ -458,33 +479,10 @@ __global__ __launch_bounds__(256) void adam_step_kernel(AdamTensor x, AdamTensor
     }
 }
 
-// one message per rank and iteration: [first 2 owned rows | last 2 owned rows] of (x | camera_ext) + d loss / d scale
-constexpr int XCH_ROW = XDIM + 16;                 // 94 floats
-constexpr int XCH_LEN = 4 * XCH_ROW + 8;           // + dscale partial (+ padding to 32 B)
-__global__ __launch_bounds__(384) void pack_exchange_kernel(const float* __restrict__ X, const float* __restrict__ CAM,
-                                                            const float* __restrict__ dscale_row, float* __restrict__ dscale,
-                                                            int n_local, float* __restrict__ out) {
-    __shared__ float sred[4];
-    int t = threadIdx.x;
-    if (t < 256) {                                         // this rank's d loss / d scale, reduce_rows_kernel's order
-        float a = 0.f;
-        for (int i = t; i < n_local; i += 256) a += dscale_row[2 + i];
-        a = wave_sum(a);
-        if ((t & 63) == 0) sred[t >> 6] = a;
-    }
-    __syncthreads();
-    if (t == 0) *dscale = (sred[0] + sred[1]) + (sred[2] + sred[3]);
-    if (t < 4 * XCH_ROW) {
-        int k = t / XCH_ROW, e = t % XCH_ROW;
-        int row = (k < 2) ? 2 + k : n_local + k - 2;             // owned rows start at 2: first two, last two
-        out[t] = e < XDIM ? X[(size_t)row * XDIM + e] : CAM[(size_t)row * 16 + e - XDIM];
-    } else if (t < XCH_LEN) {
-        out[t] = (t == 4 * XCH_ROW) ? (sred[0] + sred[1]) + (sred[2] + sred[3]) : 0.f;
-    }
-}
-// halo rows <- neighbours' boundary rows; scale gradient = sum over ranks in rank order (same bits everywhere)
+// halo rows <- neighbours' boundary rows; scale gradient = sum over ranks in rank order (same bits everywhere), then
+// Adam on `scale` when sc.p is set (same launch: the sharded iteration tail is latency-bound)
 __global__ void unpack_exchange_kernel(const float* __restrict__ all, int rank, int world, int n_local, float* __restrict__ X,
-                                       float* __restrict__ CAM, float* __restrict__ dscale) {
+                                       float* __restrict__ CAM, float* __restrict__ dscale, AdamTensor sc, int scale_zero_grad) {
     int t = threadIdx.x;
     if (t < 4 * XCH_ROW) {
         int k = t / XCH_ROW, e = t % XCH_ROW;
@@ -500,6 +498,11 @@ __global__ void unpack_exchange_kernel(const float* __restrict__ all, int rank, 
         float s = 0.f;
         for (int r = 0; r < world; ++r) s += all[(size_t)r * XCH_LEN + 4 * XCH_ROW];
         *dscale = s;
+        if (sc.p) {
+            float pp = *sc.p, mm = *sc.m, vv = *sc.v;
+            adam_update(pp, mm, vv, scale_zero_grad ? 0.f : s, sc.a);
+            *sc.p = pp; *sc.m = mm; *sc.v = vv;
+        }
     }
 }
 
@@ -1477,7 +1480,8 @@ int fdcap_frame_smoother(fdcap_ctx* c, const float* data78, int32_t N, int32_t i
     return (int)hipGetLastError();
 }
 
-static int opt_step_impl(fdcap_ctx* c, int32_t ii, int32_t P, bool do_rows, bool do_scale, bool reduce_scale, void* stream) {
+static int opt_step_impl(fdcap_ctx* c, int32_t ii, int32_t P, bool do_rows, bool do_scale, bool reduce_scale, void* stream,
+                         float* xch = nullptr) {
     if (!c || !c->opt) return FDCAP_E_STATE;
     OptState* o = c->opt;
     hipStream_t st = (hipStream_t)stream;
@@ -1501,10 +1505,10 @@ static int opt_step_impl(fdcap_ctx* c, int32_t ii, int32_t P, bool do_rows, bool
     // scale: receives a gradient while ii < P (and only if a term that reaches it exists)
     const bool step_scale = do_scale && (o->contact_on || o->dct_grad) && (ii < P || cf.legacy_zero_grad);
     if (step_scale) sc = AdamTensor{o->scale.p, o->mS.p, o->vS.p, o->dscale.p, 1, adam_scalars(cf.lr, ii + 1)};
-    const bool tail = step_scale || (do_scale && reduce_scale);      // the last block: (reduction +) scale
+    const bool tail = step_scale || reduce_scale;                    // the last block: (reduction +) scale (+ message tail)
     if (nb_x + nb_cam + (tail ? 1 : 0) == 0) return FDCAP_OK;
     hipLaunchKernelGGL(adam_step_kernel, dim3(nb_x + nb_cam + 1), dim3(256), 0, st, x, cam, sc, nb_x, nb_cam, o->dscale_row.p, 2,
-                       reduce_scale ? nl : 0, o->dscale.p, (step_scale && ii >= P) ? 1 : 0);
+                       reduce_scale ? nl : 0, o->dscale.p, (step_scale && ii >= P) ? 1 : 0, xch, nl, o->CAM.p);
     return (int)hipGetLastError();
 }
 
@@ -1626,20 +1630,20 @@ int fdcap_opt_step(fdcap_ctx* c, int32_t ii, int32_t P, void* stream) { return o
 // (caller all-gathers), unpack halos + rank-ordered dscale sum + Adam on scale.
 int fdcap_opt_step_rows_and_pack(fdcap_ctx* c, int32_t ii, int32_t P, float* send, void* stream) {
     if (!c || !c->opt || !send) return FDCAP_E_ARG;
-    int e = opt_step_impl(c, ii, P, true, false, false, stream);
-    if (e) return e;
-    OptState* o = c->opt;
-    hipLaunchKernelGGL(pack_exchange_kernel, dim3(1), dim3(384), 0, (hipStream_t)stream, o->X.p, o->CAM.p, o->dscale_row.p,
-                       o->dscale.p, o->cfg.n_local, send);
-    return (int)hipGetLastError();
+    return opt_step_impl(c, ii, P, true, false, true, stream, send);     // Adam on the rows + the message, one launch
 }
 int fdcap_opt_unpack_and_step_scale(fdcap_ctx* c, int32_t ii, int32_t P, const float* gathered, int32_t rank, int32_t world,
                                     void* stream) {
     if (!c || !c->opt || !gathered || world <= 0 || rank < 0 || rank >= world) return FDCAP_E_ARG;
     OptState* o = c->opt;
-    hipLaunchKernelGGL(unpack_exchange_kernel, dim3(1), dim3(384), 0, (hipStream_t)stream, gathered, rank, world, o->cfg.n_local,
-                       o->X.p, o->CAM.p, o->dscale.p);
-    return opt_step_impl(c, ii, P, false, true, false, stream);
+    const fdcap_opt_config& cf = o->cfg;
+    // scale: same rule as opt_step_impl (receives a gradient while ii < P, if a term that reaches it exists)
+    AdamTensor sc = {};
+    const bool step_scale = (o->contact_on || o->dct_grad) && (ii < P || cf.legacy_zero_grad);
+    if (step_scale) sc = AdamTensor{o->scale.p, o->mS.p, o->vS.p, o->dscale.p, 1, adam_scalars(cf.lr, ii + 1)};
+    hipLaunchKernelGGL(unpack_exchange_kernel, dim3(1), dim3(384), 0, (hipStream_t)stream, gathered, rank, world, cf.n_local,
+                       o->X.p, o->CAM.p, o->dscale.p, sc, (step_scale && ii >= P) ? 1 : 0);
+    return (int)hipGetLastError();
 }
 int32_t fdcap_exchange_len(void) { return XCH_LEN; }
 
