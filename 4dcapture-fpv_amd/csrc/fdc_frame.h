@@ -39,14 +39,14 @@ struct PoseModel {
 };
 
 // scratch a team needs (LDS on device)
-struct PoseScratch {
-    float R[NJ][9];
-    float J[NJ][3];
+struct alignas(16) PoseScratch {   // rows padded to 16 B multiples so a joint's matrix moves as ds_read/write_b128
+    float R[NJ][12];      // 3x3 in the first 9
+    float J[NJ][4];
     float G[NJ][12];      // [R | t] row-major 3x4
     float dG[NJ][12];
-    float dR[NJ][9];
-    float drel[NJ][3];
-    float dJ[NJ][3];
+    float dR[NJ][12];
+    float drel[NJ][4];
+    float dJ[NJ][4];
     float dMj[NJW][12];
     float dTj[NJW][3];
     float daa[2][45];
