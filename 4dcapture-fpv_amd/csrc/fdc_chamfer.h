@@ -17,6 +17,8 @@
 #include <hip/hip_runtime.h>
 #include <stdlib.h>
 
+#include "fdc_math.h"
+
 namespace fdc {
 
 constexpr int NN_TILE = 1024;          // scene points per LDS tile of the plain scan
@@ -531,11 +533,8 @@ __global__ __launch_bounds__(256, NQ == 1 ? FDC_ST4_OCC : FDC_ST4_OCC2) void nn_
             glx = fminf(glx, qx[n] - r); gly = fminf(gly, qy[n] - r); glz = fminf(glz, qz[n] - r);
             ghx = fmaxf(ghx, qx[n] + r); ghy = fmaxf(ghy, qy[n] + r); ghz = fmaxf(ghz, qz[n] + r);
         }
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) {
-        glx = fminf(glx, __shfl_xor(glx, off, 64)); gly = fminf(gly, __shfl_xor(gly, off, 64)); glz = fminf(glz, __shfl_xor(glz, off, 64));
-        ghx = fmaxf(ghx, __shfl_xor(ghx, off, 64)); ghy = fmaxf(ghy, __shfl_xor(ghy, off, 64)); ghz = fmaxf(ghz, __shfl_xor(ghz, off, 64));
-    }
+    glx = wave_min64(glx); gly = wave_min64(gly); glz = wave_min64(glz);       // DPP reductions (fdc_math.h), no LDS traffic
+    ghx = wave_max64(ghx); ghy = wave_max64(ghy); ghz = wave_max64(ghz);
     const bool cull = __all(all_seeded && finite);
     // box-box overlap (closed): false only if the boxes are strictly apart along some axis
     auto overlaps = [&](float4 lo, float4 hi) -> bool {

@@ -52,11 +52,7 @@ FDC_HD float smoother_grad(int e, float x, float xdata, float xprev, bool has_pr
 
 #if defined(__HIPCC__)
 
-__device__ __forceinline__ float dct_wave_sum(float v) {
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
-    return v;
-}
+__device__ __forceinline__ float dct_wave_sum(float v) { return wave_sum64(v); }
 
 // One wavefront per trajectory.  Jw [rows, 69] world joints (row-major joint, axis); trajectory `traj` of
 // local window wl = frames jw_row0 + wl*T .. +T, column ij.  coef/m/v [W_total, 69, C]; this launch covers

@@ -19,6 +19,36 @@
 
 namespace fdc {
 
+#if defined(__HIPCC__)
+// Sum over the 64 lanes of a wavefront, the same bits in every lane, fixed order.  Four DPP steps (quad_perm x2,
+// row_half_mirror, row_mirror: no LDS traffic) leave every 16-lane row with its row sum, then ((r0 + r1) + r2) + r3 via
+// v_readlane.  The obvious __shfl_xor butterfly compiles to six ds_bpermute_b32 (LDS crossbar round trips) per sum.
+template <int CTRL>
+__device__ __forceinline__ float dpp_move(float v) {
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xF, 0xF, false));
+}
+__device__ __forceinline__ float wave_sum64(float v) {
+    v += dpp_move<0xB1>(v);      // quad_perm [1,0,3,2]
+    v += dpp_move<0x4E>(v);      // quad_perm [2,3,0,1]
+    v += dpp_move<0x141>(v);     // row_half_mirror
+    v += dpp_move<0x140>(v);     // row_mirror
+    const float r0 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 0));
+    const float r1 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 16));
+    const float r2 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 32));
+    const float r3 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 48));
+    return ((r0 + r1) + r2) + r3;
+}
+__device__ __forceinline__ float wave_min64(float v) {
+    v = fminf(v, dpp_move<0xB1>(v)); v = fminf(v, dpp_move<0x4E>(v)); v = fminf(v, dpp_move<0x141>(v)); v = fminf(v, dpp_move<0x140>(v));
+    const float r0 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 0));
+    const float r1 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 16));
+    const float r2 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 32));
+    const float r3 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 48));
+    return fminf(fminf(r0, r1), fminf(r2, r3));
+}
+__device__ __forceinline__ float wave_max64(float v) { return -wave_min64(-v); }
+#endif
+
 struct V3 { float x, y, z; };
 struct M3 { float m[9]; };   // row-major m[3*r+c]
 

@@ -131,11 +131,7 @@ __global__ void skin_fwd_kernel(SkinModel sm, int nv, const float* __restrict__ 
     o[0] = f.vw.x; o[1] = f.vw.y; o[2] = f.vw.z;
 }
 
-__device__ __forceinline__ float wave_sum(float v) {
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
-    return v;
-}
+__device__ __forceinline__ float wave_sum(float v) { return wave_sum64(v); }
 
 // workgroup per frame: skinning + world-transform backward of d loss / d world vertices, reduced over
 // the frame's vertex set.  dVw / dVoff are [rows, nc, 3] and may alias (each thread reads its vertex's
