@@ -638,8 +638,9 @@ __global__ __launch_bounds__(256, NQ == 1 ? FDC_ST4_OCC : FDC_ST4_OCC2) void nn_
                 const unsigned one = 0x3F80u;
                 const uint4 u = half == 0 ? make_uint4(px, px, py, py) : make_uint4(pz, pz, one | (one << 16), one);
                 bfrag[n] = __builtin_bit_cast(bf16x8, u);
-                const float sbest = fminf(own_d[n], __shfl_xor(own_d[n], 32, 64));
-                thr[n] = (qidx[n] < nq) ? sbest - X2[n] + (MF_K1 * X[n] * rc + MF_K2 * (X2[n] + rc * rc)) : -INFINITY;
+                // this half's own bound (the other half's may be tighter after an exact hit; it is folded in at the next
+                // hit -- a looser threshold only lets more pairs through, and saves a cross-half exchange per cell)
+                thr[n] = (qidx[n] < nq) ? own_d[n] - X2[n] + (MF_K1 * X[n] * rc + MF_K2 * (X2[n] + rc * rc)) : -INFINITY;
             }
             const int base = ch * MF_CH;
 #pragma unroll
