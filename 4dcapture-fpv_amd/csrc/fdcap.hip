@@ -1715,7 +1715,10 @@ int fdcap_opt_time_chamfer(fdcap_ctx* c, int32_t iters, int32_t brute_force, flo
     HIP_TRY(hipEventCreate(&e1));
     const int nsp = brute_force ? o->nsplit_bf : o->nsplit;
     float4* sp = brute_force ? nullptr : o->seedpt.p + 2 * nc;
-    HIP_TRY(nn_search(o->Vw.p + off, nl * nc, T, o->dist.p + 2 * nc, o->idx.p + 2 * nc, o->pd.p, o->pi.p, nsp, st, seed, false, sp));
+    // (warm-up launch; after a brute-force launch rewrote idx it also refreshes the neighbours' coordinates)
+    HIP_TRY(nn_search(o->Vw.p + off, nl * nc, T, o->dist.p + 2 * nc, o->idx.p + 2 * nc, o->pd.p, o->pi.p, nsp, st, seed,
+                      !brute_force && !o->seeded, sp));
+    if (!brute_force) o->seeded = true;
     HIP_TRY(hipEventRecord(e0, st));
     for (int i = 0; i < iters; ++i)
         HIP_TRY(nn_search(o->Vw.p + off, nl * nc, T, o->dist.p + 2 * nc, o->idx.p + 2 * nc, o->pd.p, o->pi.p, nsp, st, seed, false, sp));

@@ -317,7 +317,7 @@ def test_trajectory_matches_reference_golden(golden_dir, name):
 
 def test_seeding_the_nn_bound_does_not_change_results():
     """The optimiser seeds each NN search with the previous call's neighbour (an exact upper bound
-    that only prunes) and skips scene chunks whose bounding sphere is out of every query's reach:
+    that only prunes) and skips scene cells (k-d boxes) that are out of every query's reach:
     cold search, search seeded by its own result, and search seeded by a STALE result (state moved
     in between), with and without chunk culling, must all equal the plain answer bit for bit."""
     n = 64
@@ -351,10 +351,39 @@ def test_seeding_the_nn_bound_does_not_change_results():
         fop.close()
     os.environ.pop("FDCAP_NN_SEED")
     os.environ.pop("FDCAP_NN_CULL")
-    for cfg in ("10", "11"):          # seeded; seeded + chunk-culled (Morton-sorted scene, bounding spheres)
+    for cfg in ("10", "11"):          # seeded; seeded + culled (k-d-cell-ordered scene, cell boxes)
         for k in range(3):
             assert torch.equal(res["00"][k][0], res[cfg][k][0]) and torch.equal(res["00"][k][1], res[cfg][k][1]), (cfg, k)
     assert not torch.equal(res["11"][1][1], res["11"][2][1])     # the stale seeds really were stale
+
+
+@pytest.mark.parametrize("ns", [40, 600, 5000])
+def test_in_loop_nn_state_survives_the_timing_api_and_small_scenes(ns):
+    """The seeded launch keeps each neighbour's coordinates next to its index; a brute-force timing launch rewrites the
+    indices only.  After fit -> brute-force timing -> in-loop timing the contact result must still be the oracle's NN.
+    Scenes smaller than one k-d cell / one tile go through the same calls."""
+    n = 24
+    fop, bm, vp, clip, scene, vid = _make_fop(n, 300, ns, 40, 6, seed=70 + ns)
+    lib, h = fop.ctx.lib, fop.ctx.handle
+    lib.fdcap_set_nn_kernel(2)                       # the MFMA / streaming kernels whatever the size (default: plain scan below 4 M pairs)
+    try:
+        _in_loop_nn_state_body(fop, clip, scene, vid, n, lib, h)
+    finally:
+        lib.fdcap_set_nn_kernel(0)
+        fop.close()
+
+
+def _in_loop_nn_state_body(fop, clip, scene, vid, n, lib, h):
+    fop.fitting(torch.tensor(clip.body_params).cuda(), "global")
+    ms = ctypes.c_float(0)
+    for brute in (1, 0, 0):
+        capi.check(lib.fdcap_opt_time_chamfer(h, 2, brute, ctypes.byref(ms), capi.current_stream()), "time_chamfer")
+    verts = torch.empty(n, len(vid), 3, device="cuda")
+    capi.check(lib.fdcap_opt_forward_world(h, capi.dptr(verts), None, capi.current_stream()), "fw")
+    d = torch.empty(n, len(vid), device="cuda")
+    i = torch.empty(n, len(vid), device="cuda", dtype=torch.int32)
+    capi.check(lib.fdcap_opt_get_contact(h, capi.dptr(d), capi.dptr(i), capi.current_stream()), "gc")
+    _nn_check(verts.cpu().numpy().reshape(-1, 3), scene, d.cpu().numpy().reshape(-1), i.cpu().numpy().reshape(-1).astype(np.int64))
 
 
 def test_runs_are_bit_reproducible():
