@@ -10,6 +10,7 @@
 // fragment reads (lanes walk rows, fixed k) are bank-conflict free.
 #pragma once
 #include <hip/hip_runtime.h>
+#include <stdint.h>
 #include <stdlib.h>
 
 namespace fdc {
@@ -180,6 +181,109 @@ __global__ __launch_bounds__(256) void gemm_f32_mfma_ksplit_kernel(
             v += Red[2][r * 64 + lane];
             int m = m0 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
             int n = n0 + (lane & 31);
+            if (m < M && n < N) {
+                if (EPI == EPI_BIAS || EPI == EPI_BIAS_LRELU) v += aux[n];
+                if (EPI == EPI_BIAS_LRELU) v = v > 0.f ? v : 0.2f * v;
+                if (EPI == EPI_MASK_LRELU) v *= (aux[(size_t)m * ldaux + n] > 0.f) ? 1.f : 0.2f;
+                float* dst = C + (size_t)m * ldc + n;
+                if (EPI == EPI_ACCUM) v += *dst;
+                *dst = v;
+            }
+        }
+    }
+}
+
+// Vectorised staging for the split-K scheme (32x32 tile): 16-byte global loads and ds_write_b128 / ds_read_b128 instead
+// of one dword per instruction -- a quarter of the vector-memory and LDS instructions per slab (a timing ablation of the
+// scalar kernel put ~1/3 of its time in the load + LDS-store phase, none in the fragment reads).  Needs 16-byte aligned
+// operand rows (lda, ldb multiples of 4, K -- and N for a [K,N] B -- multiples of 4, aligned bases); the dispatcher
+// falls back to the scalar kernel otherwise.  K order inside a wave's 32-deep quarter is permuted so that one float4
+// feeds four MFMAs: MFMA j of group q multiplies k = 8q + j (lanes 0-31) and k = 8q + 4 + j (lanes 32-63) -- any
+// pairing is valid as long as A and B use the same one; the sum over k is the same set of products.
+template <bool B_IS_NK, int EPI>
+__global__ __launch_bounds__(256) void gemm_f32_mfma_ksplit_v4_kernel(
+    const float* __restrict__ A, int lda, const float* __restrict__ B, int ldb, float* __restrict__ C,
+    int ldc, int M, int N, int K, const float* __restrict__ aux, int ldaux) {
+    constexpr int BM = 32, BN = 32, BK = 128, LD = BK + 4, LDB = BN + 4, NV = (BM * BK) / (4 * 256);   // 4 float4 per operand per thread
+    __shared__ __attribute__((aligned(16))) float As[BM * LD];
+    __shared__ __attribute__((aligned(16))) float Bs[B_IS_NK ? BN * LD : BK * LDB];
+    __shared__ float Red[3][BM * BN];
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, half = lane >> 5, col = lane & 31;
+    const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+    const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
+    float4 ra[NV], rb[NV];
+    auto gload = [&](int k0) {
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            const int e = tid + i * 256, r = e >> 5, c4 = e & 31;
+            const int gm = m0 + r, gk = k0 + 4 * c4;
+            ra[i] = z4;
+            if (gm < M && gk < K) ra[i] = *reinterpret_cast<const float4*>(A + (size_t)gm * lda + gk);
+        }
+        if (B_IS_NK) {
+#pragma unroll
+            for (int i = 0; i < NV; ++i) {
+                const int e = tid + i * 256, r = e >> 5, c4 = e & 31;
+                const int gn = n0 + r, gk = k0 + 4 * c4;
+                rb[i] = z4;
+                if (gn < N && gk < K) rb[i] = *reinterpret_cast<const float4*>(B + (size_t)gn * ldb + gk);
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < NV; ++i) {
+                const int e = tid + i * 256, kk = e >> 3, n4 = e & 7;
+                const int gn = n0 + 4 * n4, gk = k0 + kk;
+                rb[i] = z4;
+                if (gn < N && gk < K) rb[i] = *reinterpret_cast<const float4*>(B + (size_t)gk * ldb + gn);
+            }
+        }
+    };
+    auto lstore = [&]() {
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            const int e = tid + i * 256;
+            *reinterpret_cast<float4*>(&As[(e >> 5) * LD + 4 * (e & 31)]) = ra[i];
+            if (B_IS_NK) *reinterpret_cast<float4*>(&Bs[(e >> 5) * LD + 4 * (e & 31)]) = rb[i];
+            else *reinterpret_cast<float4*>(&Bs[(e >> 3) * LDB + 4 * (e & 7)]) = rb[i];
+        }
+    };
+    gload(0);
+    for (int k0 = 0; k0 < K; k0 += BK) {
+        lstore();
+        __syncthreads();
+        if (k0 + BK < K) gload(k0 + BK);                    // in flight during the MFMAs below
+        const int kq = wave * 32;                           // this wave's quarter of the slab
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int kb = kq + 8 * q + 4 * half;
+            const float4 a4 = *reinterpret_cast<const float4*>(&As[col * LD + kb]);
+            float4 b4;
+            if (B_IS_NK) b4 = *reinterpret_cast<const float4*>(&Bs[col * LD + kb]);
+            else b4 = make_float4(Bs[kb * LDB + col], Bs[(kb + 1) * LDB + col], Bs[(kb + 2) * LDB + col], Bs[(kb + 3) * LDB + col]);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.x, b4.x, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.y, b4.y, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.z, b4.z, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.w, b4.w, acc, 0, 0, 0);
+        }
+        __syncthreads();
+    }
+    // fixed-order reduction of the four K-quarters: ((w0 + w1) + w2) + w3
+    if (wave > 0) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) Red[wave - 1][r * 64 + lane] = acc[r];
+    }
+    __syncthreads();
+    if (wave == 0) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            float v = acc[r] + Red[0][r * 64 + lane];
+            v += Red[1][r * 64 + lane];
+            v += Red[2][r * 64 + lane];
+            int m = m0 + (r & 3) + 8 * (r >> 2) + 4 * half;
+            int n = n0 + col;
             if (m < M && n < N) {
                 if (EPI == EPI_BIAS || EPI == EPI_BIAS_LRELU) v += aux[n];
                 if (EPI == EPI_BIAS_LRELU) v = v > 0.f ? v : 0.2f * v;
@@ -386,8 +490,16 @@ static inline hipError_t gemm_dispatch_tile(const float* A, int lda, const float
             return hipGetLastError();
         }
         dim3 grid((N + 31) / 32, (M + 31) / 32);
-        hipLaunchKernelGGL((gemm_f32_mfma_ksplit_kernel<NK, EPI>), grid, dim3(256), 0, st, A, lda, B, ldb, C, ldc, M, N, K,
-                           aux, ldaux);
+        static int v4 = -1;                                  // FDCAP_GEMM_V4=0: scalar staging only (A/B)
+        if (v4 < 0) { const char* e = getenv("FDCAP_GEMM_V4"); v4 = (e && e[0] == '0') ? 0 : 1; }
+        const bool aligned = (lda % 4 == 0) && (ldb % 4 == 0) && (K % 4 == 0) && (NK || N % 4 == 0) &&
+                             ((reinterpret_cast<uintptr_t>(A) | reinterpret_cast<uintptr_t>(B)) & 15) == 0;
+        if (v4 && aligned)
+            hipLaunchKernelGGL((gemm_f32_mfma_ksplit_v4_kernel<NK, EPI>), grid, dim3(256), 0, st, A, lda, B, ldb, C, ldc, M, N, K,
+                               aux, ldaux);
+        else
+            hipLaunchKernelGGL((gemm_f32_mfma_ksplit_kernel<NK, EPI>), grid, dim3(256), 0, st, A, lda, B, ldb, C, ldc, M, N, K,
+                               aux, ldaux);
         return hipGetLastError();
     }
     // wide NN products (full-mesh pose blendshapes): XCD-aware B-panel reuse + register prefetch
