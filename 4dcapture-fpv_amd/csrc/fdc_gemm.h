@@ -384,6 +384,101 @@ __global__ __launch_bounds__(256) void gemm_f32_mfma_ksplit16_kernel(
     }
 }
 
+// 16x16-tile split-K with the vectorised staging of gemm_f32_mfma_ksplit_v4_kernel.  v_mfma_f32_16x16x4_f32: lane group
+// g = lane >> 4 supplies k = 4 s + g of step s; with one float4 per lane, MFMA j of group q multiplies k = 16 q + 4 g + j.
+template <bool B_IS_NK, int EPI>
+__global__ __launch_bounds__(256) void gemm_f32_mfma_ksplit16_v4_kernel(
+    const float* __restrict__ A, int lda, const float* __restrict__ B, int ldb, float* __restrict__ C,
+    int ldc, int M, int N, int K, const float* __restrict__ aux, int ldaux) {
+    constexpr int TS = 16, BK = 128, LD = BK + 4, LDB = TS + 4, NV = (TS * BK) / (4 * 256);   // 2 float4 per operand per thread
+    __shared__ __attribute__((aligned(16))) float As[TS * LD];
+    __shared__ __attribute__((aligned(16))) float Bs[B_IS_NK ? TS * LD : BK * LDB];
+    __shared__ float Red[3][TS * TS];
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, grp = lane >> 4, col = lane & 15;
+    const int m0 = blockIdx.y * TS, n0 = blockIdx.x * TS;
+    f32x4_t acc = {0.f, 0.f, 0.f, 0.f};
+    const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
+    float4 ra[NV], rb[NV];
+    auto gload = [&](int k0) {
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            const int e = tid + i * 256, r = e >> 5, c4 = e & 31;
+            const int gm = m0 + r, gk = k0 + 4 * c4;
+            ra[i] = z4;
+            if (gm < M && gk < K) ra[i] = *reinterpret_cast<const float4*>(A + (size_t)gm * lda + gk);
+        }
+        if (B_IS_NK) {
+#pragma unroll
+            for (int i = 0; i < NV; ++i) {
+                const int e = tid + i * 256, r = e >> 5, c4 = e & 31;
+                const int gn = n0 + r, gk = k0 + 4 * c4;
+                rb[i] = z4;
+                if (gn < N && gk < K) rb[i] = *reinterpret_cast<const float4*>(B + (size_t)gn * ldb + gk);
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < NV; ++i) {
+                const int e = tid + i * 256, kk = e >> 2, n4 = e & 3;
+                const int gn = n0 + 4 * n4, gk = k0 + kk;
+                rb[i] = z4;
+                if (gn < N && gk < K) rb[i] = *reinterpret_cast<const float4*>(B + (size_t)gk * ldb + gn);
+            }
+        }
+    };
+    auto lstore = [&]() {
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            const int e = tid + i * 256;
+            *reinterpret_cast<float4*>(&As[(e >> 5) * LD + 4 * (e & 31)]) = ra[i];
+            if (B_IS_NK) *reinterpret_cast<float4*>(&Bs[(e >> 5) * LD + 4 * (e & 31)]) = rb[i];
+            else *reinterpret_cast<float4*>(&Bs[(e >> 2) * LDB + 4 * (e & 3)]) = rb[i];
+        }
+    };
+    gload(0);
+    for (int k0 = 0; k0 < K; k0 += BK) {
+        lstore();
+        __syncthreads();
+        if (k0 + BK < K) gload(k0 + BK);                    // in flight during the MFMAs below
+        const int kq = wave * 32;                           // this wave's quarter of the slab
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            const int kb = kq + 16 * q + 4 * grp;
+            const float4 a4 = *reinterpret_cast<const float4*>(&As[col * LD + kb]);
+            float4 b4;
+            if (B_IS_NK) b4 = *reinterpret_cast<const float4*>(&Bs[col * LD + kb]);
+            else b4 = make_float4(Bs[kb * LDB + col], Bs[(kb + 1) * LDB + col], Bs[(kb + 2) * LDB + col], Bs[(kb + 3) * LDB + col]);
+            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a4.x, b4.x, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a4.y, b4.y, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a4.z, b4.z, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a4.w, b4.w, acc, 0, 0, 0);
+        }
+        __syncthreads();
+    }
+    if (wave > 0) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) Red[wave - 1][r * 64 + lane] = acc[r];
+    }
+    __syncthreads();
+    if (wave == 0) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            float v = acc[r] + Red[0][r * 64 + lane];
+            v += Red[1][r * 64 + lane];
+            v += Red[2][r * 64 + lane];
+            int m = m0 + 4 * grp + r;
+            int n = n0 + col;
+            if (m < M && n < N) {
+                if (EPI == EPI_BIAS || EPI == EPI_BIAS_LRELU) v += aux[n];
+                if (EPI == EPI_BIAS_LRELU) v = v > 0.f ? v : 0.2f * v;
+                if (EPI == EPI_MASK_LRELU) v *= (aux[(size_t)m * ldaux + n] > 0.f) ? 1.f : 0.2f;
+                float* dst = C + (size_t)m * ldc + n;
+                if (EPI == EPI_ACCUM) v += *dst;
+                *dst = v;
+            }
+        }
+    }
+}
+
 // Wide "NN" product C[M,N] = A[M,K] x B[K,N] with N >> M (the full-mesh pose blendshapes:
 // M = frames ~ 1e3, K = 486, N = 3V = 31 425).  B (61 MB) is the only operand that does not fit in
 // L2, so the blockIdx -> tile map keeps all M-tiles of one 128-column B panel on ONE XCD, back to
@@ -483,17 +578,21 @@ static inline hipError_t gemm_dispatch_tile(const float* A, int lda, const float
         static int t16 = -1;
         if (t16 < 0) { const char* e = getenv("FDCAP_GEMM_T16"); t16 = e ? atoi(e) : 1024; }
         const long long tiles32 = (long long)((N + 31) / 32) * ((M + 31) / 32);
-        if (tiles32 < t16 / 4 || (tiles32 < t16 && K <= 768)) {
-            dim3 grid((N + 15) / 16, (M + 15) / 16);
-            hipLaunchKernelGGL((gemm_f32_mfma_ksplit16_kernel<NK, EPI>), grid, dim3(256), 0, st, A, lda, B, ldb, C, ldc, M, N, K,
-                               aux, ldaux);
-            return hipGetLastError();
-        }
-        dim3 grid((N + 31) / 32, (M + 31) / 32);
         static int v4 = -1;                                  // FDCAP_GEMM_V4=0: scalar staging only (A/B)
         if (v4 < 0) { const char* e = getenv("FDCAP_GEMM_V4"); v4 = (e && e[0] == '0') ? 0 : 1; }
         const bool aligned = (lda % 4 == 0) && (ldb % 4 == 0) && (K % 4 == 0) && (NK || N % 4 == 0) &&
                              ((reinterpret_cast<uintptr_t>(A) | reinterpret_cast<uintptr_t>(B)) & 15) == 0;
+        if (tiles32 < t16 / 4 || (tiles32 < t16 && K <= 768)) {
+            dim3 grid((N + 15) / 16, (M + 15) / 16);
+            if (v4 && aligned)
+                hipLaunchKernelGGL((gemm_f32_mfma_ksplit16_v4_kernel<NK, EPI>), grid, dim3(256), 0, st, A, lda, B, ldb, C, ldc, M, N,
+                                   K, aux, ldaux);
+            else
+                hipLaunchKernelGGL((gemm_f32_mfma_ksplit16_kernel<NK, EPI>), grid, dim3(256), 0, st, A, lda, B, ldb, C, ldc, M, N, K,
+                                   aux, ldaux);
+            return hipGetLastError();
+        }
+        dim3 grid((N + 31) / 32, (M + 31) / 32);
         if (v4 && aligned)
             hipLaunchKernelGGL((gemm_f32_mfma_ksplit_v4_kernel<NK, EPI>), grid, dim3(256), 0, st, A, lda, B, ldb, C, ldc, M, N, K,
                                aux, ldaux);
