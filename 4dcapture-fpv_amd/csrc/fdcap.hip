@@ -119,13 +119,18 @@ __global__ void skin_fwd_kernel(SkinModel sm, int nv, const float* __restrict__ 
                                 const float* __restrict__ Voff, const float* __restrict__ A,
                                 const float* __restrict__ M, const float* __restrict__ scale, int row0, int world,
                                 float* __restrict__ Vout) {
+    // the frame's 55 skinning transforms staged in LDS once per block: per vertex they are reached through its joint
+    // ids (a dependent load chain from global memory otherwise)
+    __shared__ float sA[NJ * 12];
     int c = blockIdx.x * blockDim.x + threadIdx.x;
     int r = row0 + blockIdx.y;
+    for (int i = threadIdx.x; i < NJ * 12; i += blockDim.x) sA[i] = A[(size_t)r * NJ * 12 + i];
+    __syncthreads();
     if (c >= nv) return;
     const float* x = X + (size_t)r * ldx;
     V3 transl = v3(x[transl_off], x[transl_off + 1], x[transl_off + 2]);
     const float ident[12] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0};
-    SkinFwd f = skin_forward_vertex(sm, c, x + beta_off, Voff + ((size_t)r * nv + c) * 3, A + (size_t)r * NJ * 12,
+    SkinFwd f = skin_forward_vertex(sm, c, x + beta_off, Voff + ((size_t)r * nv + c) * 3, sA,
                                     transl, world ? M + (size_t)r * 12 : ident, world ? *scale : 1.f);
     float* o = Vout + ((size_t)r * nv + c) * 3;
     o[0] = f.vw.x; o[1] = f.vw.y; o[2] = f.vw.z;
@@ -164,9 +169,12 @@ __global__ __launch_bounds__(256) void skin_bwd_kernel(SkinModel sm, int nc, con
     float cterm = 0.f;
     // lane j of every wave: joint j's range in the transposed weight list (loaded once, while the vertex phase runs)
     const int jlo = lane < NJ ? sm.csc_start[lane] : 0, jhi = lane < NJ ? sm.csc_start[lane + 1] : 0;
+    __shared__ float sAf[NJ * 12];                  // this frame's skinning transforms (see skin_fwd_kernel)
+    for (int i = tid; i < NJ * 12; i += 256) sAf[i] = A[(size_t)r * NJ * 12 + i];
 #pragma unroll
     for (int i = 0; i < SKB_NACC; ++i) acc[i] = 0.f;
     for (int i = tid; i < NJ * 12; i += 256) sdA[i] = 0.f;
+    __syncthreads();
     for (int c0 = 0; c0 < nc; c0 += VCH) {
         const int c1 = min(nc, c0 + VCH);
         for (int c = c0 + tid; c < c1; c += 256) {
@@ -182,8 +190,7 @@ __global__ __launch_bounds__(256) void skin_bwd_kernel(SkinModel sm, int nc, con
             } else {
                 g = v3(dVw[3 * qi], dVw[3 * qi + 1], dVw[3 * qi + 2]);
             }
-            SkinFwd f = skin_forward_vertex(sm, c, x + X_BETAS, Voff + 3 * qi, A + (size_t)r * NJ * 12, transl,
-                                            M + (size_t)r * 12, s);
+            SkinFwd f = skin_forward_vertex(sm, c, x + X_BETAS, Voff + 3 * qi, sAf, transl, M + (size_t)r * 12, s);
             SkinBwd b = skin_backward_vertex(f, M + (size_t)r * 12, s, g);
             dVoff[3 * qi] = b.dvp.x; dVoff[3 * qi + 1] = b.dvp.y; dVoff[3 * qi + 2] = b.dvp.z;
             if (sm.S)                                       // else: d betas = dVoff x shapedirs, columns 486.. of the blend data-gradient GEMM

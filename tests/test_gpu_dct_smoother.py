@@ -108,7 +108,10 @@ def test_dct_mode_matches_oracle(n, num_iter):
     assert log2.shape[0] == k and int(log2[0, 0]) == P + 1
     tol = 3e-6 + 2e-6 * np.arange(k)
     for col, ocol in ((1, 0), (2, 1), (4, 3), (5, 4), (6, 5)):               # rec, vposer, contact, dct, total
-        assert np.all(np.abs(log2[:, col] - olog[P + 1:, ocol]) <= 2 * tol), (col, np.abs(log2[:, col] - olog[P + 1:, ocol]).max())
+        # loss_dct is O(10) here and moves with every +-lr step of the body (one sign flip at an L1 kink shifts it by
+        # ~1e-5 relative per step): absolute bar for the small terms, relative 5e-5 on top for the large one
+        bar = 2 * tol + 5e-5 * np.abs(olog[P + 1:, ocol])
+        assert np.all(np.abs(log2[:, col] - olog[P + 1:, ocol]) <= bar), (col, np.abs(log2[:, col] - olog[P + 1:, ocol]).max())
     fop.close()
 
 
