@@ -566,6 +566,100 @@ __global__ __launch_bounds__(256) void gemm_f32_mfma_wide_kernel(
             }
 }
 
+// gemm_f32_mfma_wide_kernel with vectorised staging (see gemm_f32_mfma_ksplit_v4_kernel): 16-byte global loads, A
+// fragments as ds_read_b128, B stored transposed ([n][k]) so its fragments are ds_read_b128 too; the K order of a 32-deep
+// slab is permuted as there (MFMA j of group q: k = 8q + j | 8q + 4 + j).  Needs lda, ldb multiples of 4 and 16-byte
+// aligned bases; B rows may be read up to ldb (the caller pads posedirs rows to a multiple of 4 with zeros).
+template <int EPI>
+__global__ __launch_bounds__(256) void gemm_f32_mfma_wide_v4_kernel(
+    const float* __restrict__ A, int lda, const float* __restrict__ B, int ldb, float* __restrict__ C,
+    int ldc, int M, int N, int K, const float* __restrict__ aux, int ldaux) {
+    constexpr int BM = 128, BN = 128, BK = 32, LD = BK + 4, NV = (BM * BK) / (4 * 256);   // 4 float4 per operand per thread
+    __shared__ __attribute__((aligned(16))) float As[BM * LD];
+    __shared__ __attribute__((aligned(16))) float Bs[BN * LD];
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, half = lane >> 5, col = lane & 31;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int MT = (M + BM - 1) / BM, NT = (N + BN - 1) / BN;
+    const int b = blockIdx.x, xcd = b & 7, slot = b >> 3;
+    const int nt = (slot / MT) * 8 + xcd, mt = slot % MT;
+    if (nt >= NT) return;
+    const int m0 = mt * BM, n0 = nt * BN;
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
+    float4 ra[NV], rb[NV];
+    auto gload = [&](int k0) {
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            const int e = tid + i * 256, r = e >> 3, c4 = e & 7;              // A: 8 float4 (32 k) per row
+            const int gm = m0 + r, gk = k0 + 4 * c4;
+            ra[i] = z4;
+            if (gm < M && gk < K) ra[i] = *reinterpret_cast<const float4*>(A + (size_t)gm * lda + gk);
+        }
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            const int e = tid + i * 256, kk = e >> 5, n4 = e & 31;            // B: 32 float4 (128 n) per k row
+            const int gn = n0 + 4 * n4, gk = k0 + kk;
+            rb[i] = z4;
+            if (gn < ldb && gk < K) rb[i] = *reinterpret_cast<const float4*>(B + (size_t)gk * ldb + gn);
+        }
+    };
+    auto lstore = [&]() {
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            const int e = tid + i * 256;
+            *reinterpret_cast<float4*>(&As[(e >> 3) * LD + 4 * (e & 7)]) = ra[i];
+            const int kk = e >> 5, n4 = e & 31;                               // transposed: Bs[n][k]
+            Bs[(4 * n4) * LD + kk] = rb[i].x; Bs[(4 * n4 + 1) * LD + kk] = rb[i].y;
+            Bs[(4 * n4 + 2) * LD + kk] = rb[i].z; Bs[(4 * n4 + 3) * LD + kk] = rb[i].w;
+        }
+    };
+    gload(0);
+    for (int k0 = 0; k0 < K; k0 += BK) {
+        lstore();
+        __syncthreads();
+        if (k0 + BK < K) gload(k0 + BK);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int kb = 8 * q + 4 * half;
+            float4 a4[2], b4[2];
+#pragma unroll
+            for (int i = 0; i < 2; ++i) a4[i] = *reinterpret_cast<const float4*>(&As[((wm * 2 + i) * 32 + col) * LD + kb]);
+#pragma unroll
+            for (int j = 0; j < 2; ++j) b4[j] = *reinterpret_cast<const float4*>(&Bs[((wn * 2 + j) * 32 + col) * LD + kb]);
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[i].x, b4[j].x, acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[i].y, b4[j].y, acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[i].z, b4[j].z, acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[i].w, b4[j].w, acc[i][j], 0, 0, 0);
+                }
+        }
+        __syncthreads();
+    }
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                int m = m0 + (wm * 2 + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+                int n = n0 + (wn * 2 + j) * 32 + col;
+                if (m < M && n < N) {
+                    float v = acc[i][j][r];
+                    if (EPI == EPI_ACCUM) v += C[(size_t)m * ldc + n];
+                    C[(size_t)m * ldc + n] = v;
+                }
+            }
+}
+
 template <bool NK, int EPI>
 static inline hipError_t gemm_dispatch_tile(const float* A, int lda, const float* B, int ldb, float* C, int ldc,
                                             int M, int N, int K, const float* aux, int ldaux, hipStream_t st) {
@@ -605,8 +699,15 @@ static inline hipError_t gemm_dispatch_tile(const float* A, int lda, const float
     if (!NK && (EPI == EPI_STORE || EPI == EPI_ACCUM) && (long long)M * N >= 128LL * 128 * 512 && N >= 8 * 128) {
         const int MT = (M + 127) / 128, NT = (N + 127) / 128;
         const int blocks = (NT + 7) / 8 * 8 * MT;
-        hipLaunchKernelGGL((gemm_f32_mfma_wide_kernel<EPI>), dim3(blocks), dim3(256), 0, st, A, lda, B, ldb, C, ldc, M, N, K,
-                           aux, ldaux);
+        static int wv4 = -1;                                 // FDCAP_GEMM_V4=0: scalar staging only (A/B)
+        if (wv4 < 0) { const char* e = getenv("FDCAP_GEMM_V4"); wv4 = (e && e[0] == '0') ? 0 : 1; }
+        if (wv4 && lda % 4 == 0 && ldb % 4 == 0 && K % 4 == 0 &&
+            ((reinterpret_cast<uintptr_t>(A) | reinterpret_cast<uintptr_t>(B)) & 15) == 0)
+            hipLaunchKernelGGL((gemm_f32_mfma_wide_v4_kernel<EPI>), dim3(blocks), dim3(256), 0, st, A, lda, B, ldb, C, ldc, M, N, K,
+                               aux, ldaux);
+        else
+            hipLaunchKernelGGL((gemm_f32_mfma_wide_kernel<EPI>), dim3(blocks), dim3(256), 0, st, A, lda, B, ldb, C, ldc, M, N, K,
+                               aux, ldaux);
         return hipGetLastError();
     }
     // large outputs: 128x128 workgroup tiles (4 accumulators per wave); medium ones: 64x64

@@ -610,7 +610,8 @@ struct DevBuf {
 
 struct SkinSet {          // skinning constants for a vertex set (all V, or the contact subset)
     int nv = 0, K = 0;
-    DevBuf<float> vt, ww, posedirs, csc_w;      // posedirs [496, 3*nv] = [posedirs ; shapedirs^T]
+    int ldp = 0;                                // row stride of posedirs: 3*nv rounded up to a multiple of 4 (16-byte rows)
+    DevBuf<float> vt, ww, posedirs, csc_w;      // posedirs [496, ldp] = [posedirs ; shapedirs^T], zero padding
     DevBuf<int> wj, csc_start, csc_v;
     SkinModel model() const {
         SkinModel m; m.vt = vt.p; m.S = nullptr; m.wj = wj.p; m.ww = ww.p; m.K = K;
@@ -708,7 +709,8 @@ int build_skin_set(fdcap_ctx* c, const std::vector<int64_t>& ids, SkinSet* out) 
         for (int j = 0; j < NJ; ++j) k += c->h_lbs[(size_t)v * NJ + j] != 0.f;
         K = std::max(K, k);
     }
-    std::vector<float> vt((size_t)nv * 3), ww((size_t)nv * K, 0.f), pd((size_t)NPFX * 3 * nv);
+    const int ldp = (3 * nv + 3) & ~3;
+    std::vector<float> vt((size_t)nv * 3), ww((size_t)nv * K, 0.f), pd((size_t)NPFX * ldp, 0.f);
     std::vector<int> wj((size_t)nv * K, 0);
     for (int i = 0; i < nv; ++i) {
         int64_t v = ids[i];
@@ -722,12 +724,12 @@ int build_skin_set(fdcap_ctx* c, const std::vector<int64_t>& ids, SkinSet* out) 
     for (int r = 0; r < NPF; ++r)
         for (int i = 0; i < nv; ++i)
             for (int k = 0; k < 3; ++k)
-                pd[(size_t)r * 3 * nv + 3 * i + k] = c->h_posedirs[(size_t)r * 3 * V + 3 * ids[i] + k];
+                pd[(size_t)r * ldp + 3 * i + k] = c->h_posedirs[(size_t)r * 3 * V + 3 * ids[i] + k];
     // rows 486..495: shapedirs^T (betas part), so [pose feature | betas] x this matrix = pose offsets + shape offsets
     for (int l = 0; l < NBETA; ++l)
         for (int i = 0; i < nv; ++i)
             for (int k = 0; k < 3; ++k)
-                pd[(size_t)(NPF + l) * 3 * nv + 3 * i + k] = c->h_S10[((size_t)3 * ids[i] + k) * 10 + l];
+                pd[(size_t)(NPF + l) * ldp + 3 * i + k] = c->h_S10[((size_t)3 * ids[i] + k) * 10 + l];
     std::vector<int> csc_start(NJ + 1, 0), csc_v;
     std::vector<float> csc_w;
     for (int j = 0; j < NJ; ++j) {
@@ -739,7 +741,7 @@ int build_skin_set(fdcap_ctx* c, const std::vector<int64_t>& ids, SkinSet* out) 
     }
     csc_start[NJ] = (int)csc_v.size();
     if (csc_v.empty()) { csc_v.push_back(0); csc_w.push_back(0.f); }
-    out->nv = nv; out->K = K;
+    out->nv = nv; out->K = K; out->ldp = ldp;
     HIP_TRY(out->csc_start.upload(csc_start.data(), csc_start.size()));
     HIP_TRY(out->csc_v.upload(csc_v.data(), csc_v.size()));
     HIP_TRY(out->csc_w.upload(csc_w.data(), csc_w.size()));
@@ -1106,7 +1108,7 @@ static int body_forward_impl(fdcap_ctx* c, const float* params, int32_t B, const
     if (joints) hipLaunchKernelGGL(joints_out_kernel, dim3((B * NJ + 255) / 256), dim3(256), 0, st, w[7].p, X, XDIM, B, joints);
     if (vertices) {
         HIP_TRY(w[11].ensure((size_t)B * 3 * V));
-        HIP_TRY(gemm_f32(false, EPI_STORE, w[6].p, NPFX, c->full.posedirs.p, 3 * V, w[11].p, 3 * V, B, 3 * V, NPFX, nullptr, 0, st));
+        HIP_TRY(gemm_f32(false, EPI_STORE, w[6].p, NPFX, c->full.posedirs.p, c->full.ldp, w[11].p, 3 * V, B, 3 * V, NPFX, nullptr, 0, st));
         hipLaunchKernelGGL(skin_fwd_kernel, dim3((V + 255) / 256, B), dim3(256), 0, st, c->full.model(), V, X, XDIM, X_BETAS,
                            X_TRANSL, w[11].p, w[8].p, (const float*)w[1].p, S, 0, world ? 1 : 0, vertices);
     }
@@ -1149,7 +1151,7 @@ int fdcap_smplx_forward(fdcap_ctx* c, const float* go, const float* bp, const fl
     if (joints) hipLaunchKernelGGL(joints_out_kernel, dim3((B * NJ + 255) / 256), dim3(256), 0, st, w[7].p, X, XDIM, B, joints);
     if (vertices) {
         HIP_TRY(w[11].ensure((size_t)B * 3 * V));
-        HIP_TRY(gemm_f32(false, EPI_STORE, w[6].p, NPFX, c->full.posedirs.p, 3 * V, w[11].p, 3 * V, B, 3 * V, NPFX, nullptr, 0, st));
+        HIP_TRY(gemm_f32(false, EPI_STORE, w[6].p, NPFX, c->full.posedirs.p, c->full.ldp, w[11].p, 3 * V, B, 3 * V, NPFX, nullptr, 0, st));
         hipLaunchKernelGGL(skin_fwd_kernel, dim3((V + 255) / 256, B), dim3(256), 0, st, c->full.model(), V, X, XDIM, X_BETAS,
                            X_TRANSL, w[11].p, w[8].p, (const float*)nullptr, (const float*)nullptr, 0, 0, vertices);
     }
@@ -1245,7 +1247,7 @@ static int opt_contact_forward(fdcap_ctx* c, hipStream_t st) {
     OptState* o = c->opt;
     const int nl = o->cfg.n_local, nc = c->nc;
     const size_t off = (size_t)2 * nc * 3;
-    HIP_TRY(gemm_f32(false, EPI_STORE, o->PF.p + 2 * NPFX, NPFX, c->contact.posedirs.p, 3 * nc, o->Voff.p + off, 3 * nc, nl,
+    HIP_TRY(gemm_f32(false, EPI_STORE, o->PF.p + 2 * NPFX, NPFX, c->contact.posedirs.p, c->contact.ldp, o->Voff.p + off, 3 * nc, nl,
                      3 * nc, NPFX, nullptr, 0, st));
     hipLaunchKernelGGL(skin_fwd_kernel, dim3((nc + 255) / 256, nl), dim3(256), 0, st, c->contact.model(), nc, o->X.p, XDIM,
                        X_BETAS, X_TRANSL, o->Voff.p, o->A.p, o->M.p, o->scale.p, 2, 1, o->Vw.p);
@@ -1302,7 +1304,7 @@ static int opt_backward_impl(fdcap_ctx* c, const LossWeights& lw, int32_t log_te
         hipLaunchKernelGGL(skin_bwd_kernel<true>, dim3(nl), dim3(256), (size_t)std::min(nc, 1024) * 12 * sizeof(float), st, c->contact.model(), nc, o->X.p, o->Voff.p, o->A.p,
                            o->M.p, o->scale.p, 2, (const float*)nullptr, o->dVoff.p, o->dA.p, (float*)nullptr, o->dtransl_v.p,
                            o->dMv.p, o->dsv.p, cg);
-        HIP_TRY(gemm_f32(true, EPI_STORE, o->dVoff.p + (size_t)2 * nc * 3, 3 * nc, c->contact.posedirs.p, 3 * nc,
+        HIP_TRY(gemm_f32(true, EPI_STORE, o->dVoff.p + (size_t)2 * nc * 3, 3 * nc, c->contact.posedirs.p, c->contact.ldp,
                          o->dPF.p + 2 * NPFX, NPFX, nl, NPFX, 3 * nc, nullptr, 0, st));
     } else if (contact_fwd && losses) {
         hipLaunchKernelGGL(contact_loss_kernel, dim3(256), dim3(256), 0, st, o->dist.p + 2 * nc, (size_t)nl * nc, losses + 3);
@@ -1556,7 +1558,7 @@ int fdcap_opt_backward_local2(fdcap_ctx* c, const float* contact_weight, int32_t
     hipLaunchKernelGGL(pose_fwd_kernel, dim3(R), dim3(64), 0, st, pm, o->X.p, o->O.p, o->CAM.p, o->scale.p, 0, o->Rm.p,
                        o->PF.p, o->Jrest.p, o->G.p, o->A.p, o->M.p, o->Jw.p, (const float*)nullptr);
     // full-mesh world vertices of every row (the vertex stencil needs 2 halo frames each side)
-    HIP_TRY(gemm_f32(false, EPI_STORE, o->PF.p, NPFX, c->full.posedirs.p, 3 * V, o->VoffF.p, 3 * V, R, 3 * V, NPFX, nullptr, 0, st));
+    HIP_TRY(gemm_f32(false, EPI_STORE, o->PF.p, NPFX, c->full.posedirs.p, c->full.ldp, o->VoffF.p, 3 * V, R, 3 * V, NPFX, nullptr, 0, st));
     hipLaunchKernelGGL(skin_fwd_kernel, dim3((V + 255) / 256, R), dim3(256), 0, st, c->full.model(), V, o->X.p, XDIM, X_BETAS,
                        X_TRANSL, o->VoffF.p, o->A.p, o->M.p, o->scale.p, 0, 1, o->VwF.p);
     // losses [0] rec, [1] z^2, [2] local (parameter) smoothing, [5] vertex smoothing, [6] foot skate
@@ -1572,7 +1574,7 @@ int fdcap_opt_backward_local2(fdcap_ctx* c, const float* contact_weight, int32_t
                            nc, n_left, contact_weight, 2, cf.frame0, N, o->dVF.p, o->losses.p + 6);
     hipLaunchKernelGGL(skin_bwd_kernel<false>, dim3(nl), dim3(256), (size_t)std::min(V, 1024) * 12 * sizeof(float), st, c->full.model(), V, o->X.p, o->VoffF.p, o->A.p, o->M.p,
                        o->scale.p, 2, o->dVF.p, o->dVF.p, o->dA.p, (float*)nullptr, o->dtransl_v.p, o->dMv.p, o->dsv.p, ContactGradIn());
-    HIP_TRY(gemm_f32(true, EPI_STORE, o->dVF.p + 2 * nv3, 3 * V, c->full.posedirs.p, 3 * V, o->dPF.p + 2 * NPFX, NPFX, nl, NPFX,
+    HIP_TRY(gemm_f32(true, EPI_STORE, o->dVF.p + 2 * nv3, 3 * V, c->full.posedirs.p, c->full.ldp, o->dPF.p + 2 * NPFX, NPFX, nl, NPFX,
                      3 * V, nullptr, 0, st));
     hipLaunchKernelGGL(pose_bwd_kernel, dim3(nl), dim3(64), 0, st, pm, o->X.p, o->O.p, o->CAM.p, o->scale.p, 2, o->Rm.p,
                        o->Jrest.p, o->G.p, o->dA.p, o->dPF.p, (const float*)nullptr, o->dMv.p, o->dsv.p, o->dPF.p + NPF, NPFX,
@@ -1685,16 +1687,16 @@ int fdcap_time_blend_gemm(fdcap_ctx* c, int32_t rows, int32_t iters, float* ms, 
         c->full_ready = true;
     }
     const int V = c->V;
-    HIP_TRY(c->ws_f[6].ensure((size_t)rows * NPF));
+    HIP_TRY(c->ws_f[6].ensure((size_t)rows * NPFX));
     HIP_TRY(c->ws_f[11].ensure((size_t)rows * 3 * V));
-    HIP_TRY(hipMemsetAsync(c->ws_f[6].p, 0x3c, (size_t)rows * NPF * sizeof(float), st));   // arbitrary finite pattern
+    HIP_TRY(hipMemsetAsync(c->ws_f[6].p, 0x3c, (size_t)rows * NPFX * sizeof(float), st));   // arbitrary finite pattern
     hipEvent_t e0, e1;
     HIP_TRY(hipEventCreate(&e0));
     HIP_TRY(hipEventCreate(&e1));
-    HIP_TRY(gemm_f32(false, EPI_STORE, c->ws_f[6].p, NPF, c->full.posedirs.p, 3 * V, c->ws_f[11].p, 3 * V, rows, 3 * V, NPF, nullptr, 0, st));
+    HIP_TRY(gemm_f32(false, EPI_STORE, c->ws_f[6].p, NPFX, c->full.posedirs.p, c->full.ldp, c->ws_f[11].p, 3 * V, rows, 3 * V, NPFX, nullptr, 0, st));
     HIP_TRY(hipEventRecord(e0, st));
     for (int i = 0; i < iters; ++i)
-        HIP_TRY(gemm_f32(false, EPI_STORE, c->ws_f[6].p, NPF, c->full.posedirs.p, 3 * V, c->ws_f[11].p, 3 * V, rows, 3 * V, NPF, nullptr, 0, st));
+        HIP_TRY(gemm_f32(false, EPI_STORE, c->ws_f[6].p, NPFX, c->full.posedirs.p, c->full.ldp, c->ws_f[11].p, 3 * V, rows, 3 * V, NPFX, nullptr, 0, st));
     HIP_TRY(hipEventRecord(e1, st));
     HIP_TRY(hipEventSynchronize(e1));
     float t = 0.f;

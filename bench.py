@@ -210,8 +210,8 @@ def main():
     ms_g = ctypes.c_float(0)
     capi.check(fop.ctx.lib.fdcap_time_blend_gemm(fop.ctx.handle, nl, 5, ctypes.byref(ms_g), capi.current_stream()),
                "fdcap_time_blend_gemm")
-    gflop = 2.0 * nl * 486 * 3 * args.verts / 1e9
-    blend = {"kernel": "fdc::gemm_f32_mfma_kernel (pose blendshapes [F,486] x [486,3V], v_mfma_f32_32x32x2_f32)",
+    gflop = 2.0 * nl * 496 * 3 * args.verts / 1e9         # operand rows [pose feature 486 | betas 10]: pose + shape blendshapes in one product
+    blend = {"kernel": "fdc::gemm_f32_mfma_wide_v4_kernel (pose + shape blendshapes [F,496] x [496,3V], v_mfma_f32_32x32x2_f32)",
              "ms_per_launch": ms_g.value, "achieved": gflop / ms_g.value, "peak": 157.3, "unit": "TFLOP/s",
              "frac": gflop / ms_g.value / 157.3, "bound": "mfma"}
     if rank == 0:
