@@ -386,11 +386,11 @@ __global__ __launch_bounds__(256) void gemm_f32_mfma_ksplit16_kernel(
 
 // 16x16-tile split-K with the vectorised staging of gemm_f32_mfma_ksplit_v4_kernel.  v_mfma_f32_16x16x4_f32: lane group
 // g = lane >> 4 supplies k = 4 s + g of step s; with one float4 per lane, MFMA j of group q multiplies k = 16 q + 4 g + j.
-template <bool B_IS_NK, int EPI>
+template <bool B_IS_NK, int EPI, int BK>
 __global__ __launch_bounds__(256) void gemm_f32_mfma_ksplit16_v4_kernel(
     const float* __restrict__ A, int lda, const float* __restrict__ B, int ldb, float* __restrict__ C,
     int ldc, int M, int N, int K, const float* __restrict__ aux, int ldaux) {
-    constexpr int TS = 16, BK = 128, LD = BK + 4, LDB = TS + 4, NV = (TS * BK) / (4 * 256);   // 2 float4 per operand per thread
+    constexpr int TS = 16, LD = BK + 4, LDB = TS + 4, NV = (TS * BK) / (4 * 256), C4 = BK / 4, KW = BK / 4;   // NV float4 per operand per thread; C4 float4 per row; KW k per wave and slab
     __shared__ __attribute__((aligned(16))) float As[TS * LD];
     __shared__ __attribute__((aligned(16))) float Bs[B_IS_NK ? TS * LD : BK * LDB];
     __shared__ float Red[3][TS * TS];
@@ -402,7 +402,7 @@ __global__ __launch_bounds__(256) void gemm_f32_mfma_ksplit16_v4_kernel(
     auto gload = [&](int k0) {
 #pragma unroll
         for (int i = 0; i < NV; ++i) {
-            const int e = tid + i * 256, r = e >> 5, c4 = e & 31;
+            const int e = tid + i * 256, r = e / C4, c4 = e % C4;
             const int gm = m0 + r, gk = k0 + 4 * c4;
             ra[i] = z4;
             if (gm < M && gk < K) ra[i] = *reinterpret_cast<const float4*>(A + (size_t)gm * lda + gk);
@@ -410,7 +410,7 @@ __global__ __launch_bounds__(256) void gemm_f32_mfma_ksplit16_v4_kernel(
         if (B_IS_NK) {
 #pragma unroll
             for (int i = 0; i < NV; ++i) {
-                const int e = tid + i * 256, r = e >> 5, c4 = e & 31;
+                const int e = tid + i * 256, r = e / C4, c4 = e % C4;
                 const int gn = n0 + r, gk = k0 + 4 * c4;
                 rb[i] = z4;
                 if (gn < N && gk < K) rb[i] = *reinterpret_cast<const float4*>(B + (size_t)gn * ldb + gk);
@@ -429,8 +429,8 @@ __global__ __launch_bounds__(256) void gemm_f32_mfma_ksplit16_v4_kernel(
 #pragma unroll
         for (int i = 0; i < NV; ++i) {
             const int e = tid + i * 256;
-            *reinterpret_cast<float4*>(&As[(e >> 5) * LD + 4 * (e & 31)]) = ra[i];
-            if (B_IS_NK) *reinterpret_cast<float4*>(&Bs[(e >> 5) * LD + 4 * (e & 31)]) = rb[i];
+            *reinterpret_cast<float4*>(&As[(e / C4) * LD + 4 * (e % C4)]) = ra[i];
+            if (B_IS_NK) *reinterpret_cast<float4*>(&Bs[(e / C4) * LD + 4 * (e % C4)]) = rb[i];
             else *reinterpret_cast<float4*>(&Bs[(e >> 2) * LDB + 4 * (e & 3)]) = rb[i];
         }
     };
@@ -439,9 +439,9 @@ __global__ __launch_bounds__(256) void gemm_f32_mfma_ksplit16_v4_kernel(
         lstore();
         __syncthreads();
         if (k0 + BK < K) gload(k0 + BK);                    // in flight during the MFMAs below
-        const int kq = wave * 32;                           // this wave's quarter of the slab
+        const int kq = wave * KW;                           // this wave's quarter of the slab
 #pragma unroll
-        for (int q = 0; q < 2; ++q) {
+        for (int q = 0; q < KW / 16; ++q) {
             const int kb = kq + 16 * q + 4 * grp;
             const float4 a4 = *reinterpret_cast<const float4*>(&As[col * LD + kb]);
             float4 b4;
@@ -678,9 +678,16 @@ static inline hipError_t gemm_dispatch_tile(const float* A, int lda, const float
                              ((reinterpret_cast<uintptr_t>(A) | reinterpret_cast<uintptr_t>(B)) & 15) == 0;
         if (tiles32 < t16 / 4 || (tiles32 < t16 && K <= 768)) {
             dim3 grid((N + 15) / 16, (M + 15) / 16);
-            if (v4 && aligned)
-                hipLaunchKernelGGL((gemm_f32_mfma_ksplit16_v4_kernel<NK, EPI>), grid, dim3(256), 0, st, A, lda, B, ldb, C, ldc, M, N,
-                                   K, aux, ldaux);
+            static int bk256 = -1;                           // FDCAP_GEMM_BK256=0: 128-deep slabs only (A/B)
+            if (bk256 < 0) { const char* e = getenv("FDCAP_GEMM_BK256"); bk256 = (e && e[0] == '0') ? 0 : 1; }
+            // deep products on small grids: half the slab rounds (barriers + exposed load latencies); with >= 1024 workgroups
+            // in flight the shorter slabs overlap better (measured: N = 512 layers 14.1 vs 15.0 us, N = 126 / 32 layers 6.8 / 7.1 vs 5.8 / 6.7)
+            if (v4 && aligned && bk256 && K >= 512 && (long long)grid.x * grid.y < 1024)
+                hipLaunchKernelGGL((gemm_f32_mfma_ksplit16_v4_kernel<NK, EPI, 256>), grid, dim3(256), 0, st, A, lda, B, ldb, C, ldc,
+                                   M, N, K, aux, ldaux);
+            else if (v4 && aligned)
+                hipLaunchKernelGGL((gemm_f32_mfma_ksplit16_v4_kernel<NK, EPI, 128>), grid, dim3(256), 0, st, A, lda, B, ldb, C, ldc,
+                                   M, N, K, aux, ldaux);
             else
                 hipLaunchKernelGGL((gemm_f32_mfma_ksplit16_kernel<NK, EPI>), grid, dim3(256), 0, st, A, lda, B, ldb, C, ldc, M, N, K,
                                    aux, ldaux);
