@@ -189,16 +189,10 @@ FDC_HD void pose_backward(const PoseModel& pm, const float* x, const float* o, c
         sc.dJ[j][0] = dJ.x; sc.dJ[j][1] = dJ.y; sc.dJ[j][2] = dJ.z;
     }
     sync();
-    // reverse chain: children (level L) hand their gradient to parents (level L-1)
+    // reverse chain: parents (level L-1) gather the gradient of their children (level L).  Only the accumulation is
+    // level-ordered; what each joint hands to its local rotation / offset (dR, drel) needs its FINAL dG and is formed
+    // for all joints at once afterwards (one LDS round per level instead of two).
     for (int L = pm.nlevels - 1; L >= 1; --L) {
-        for (int k = pm.level_start[L] + tid; k < pm.level_start[L + 1]; k += nthr) {
-            int c = pm.order[k];
-            int p = pm.parents[c];
-            M3 Rp = g_rot(sc.G[p]);
-            store_m3(sc.dR[c], m3_mul_at(Rp, g_rot(sc.dG[c])));
-            V3 dr = m3t_vec(Rp, g_trn(sc.dG[c]));
-            sc.drel[c][0] = dr.x; sc.drel[c][1] = dr.y; sc.drel[c][2] = dr.z;
-        }
         for (int k = pm.level_start[L - 1] + tid; k < pm.level_start[L]; k += nthr) {
             int p = pm.order[k];
             M3 acc = g_rot(sc.dG[p]);
@@ -216,11 +210,18 @@ FDC_HD void pose_backward(const PoseModel& pm, const float* x, const float* o, c
         }
         sync();
     }
-    if (tid == 0) {
-        int r = pm.order[0];
-        store_m3(sc.dR[r], g_rot(sc.dG[r]));
-        V3 t = g_trn(sc.dG[r]);
-        sc.drel[r][0] = t.x; sc.drel[r][1] = t.y; sc.drel[r][2] = t.z;
+    for (int c = tid; c < NJ; c += nthr) {
+        int p = pm.parents[c];
+        if (p >= 0) {
+            M3 Rp = g_rot(sc.G[p]);
+            store_m3(sc.dR[c], m3_mul_at(Rp, g_rot(sc.dG[c])));
+            V3 dr = m3t_vec(Rp, g_trn(sc.dG[c]));
+            sc.drel[c][0] = dr.x; sc.drel[c][1] = dr.y; sc.drel[c][2] = dr.z;
+        } else {
+            store_m3(sc.dR[c], g_rot(sc.dG[c]));
+            V3 t = g_trn(sc.dG[c]);
+            sc.drel[c][0] = t.x; sc.drel[c][1] = t.y; sc.drel[c][2] = t.z;
+        }
     }
     for (int i = tid; i < 90; i += nthr) (&sc.daa[0][0])[i] = 0.f;
     sync();
