@@ -129,9 +129,12 @@ __global__ void skin_fwd_kernel(SkinModel sm, int nv, const float* __restrict__ 
     if (c >= nv) return;
     const float* x = X + (size_t)r * ldx;
     V3 transl = v3(x[transl_off], x[transl_off + 1], x[transl_off + 2]);
-    const float ident[12] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0};
-    SkinFwd f = skin_forward_vertex(sm, c, x + beta_off, Voff + ((size_t)r * nv + c) * 3, sA,
-                                    transl, world ? M + (size_t)r * 12 : ident, world ? *scale : 1.f);
+    float Mr[12] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0};      // registers: a pointer that is either global or a local array turns into flat loads
+    if (world) {
+#pragma unroll
+        for (int e = 0; e < 12; ++e) Mr[e] = M[(size_t)r * 12 + e];
+    }
+    SkinFwd f = skin_forward_vertex(sm, c, x + beta_off, Voff + ((size_t)r * nv + c) * 3, sA, transl, Mr, world ? *scale : 1.f);
     float* o = Vout + ((size_t)r * nv + c) * 3;
     o[0] = f.vw.x; o[1] = f.vw.y; o[2] = f.vw.z;
 }
