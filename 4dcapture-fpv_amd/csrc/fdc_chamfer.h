@@ -507,9 +507,10 @@ __global__ __launch_bounds__(256, NQ == 1 ? FDC_ST4_OCC : FDC_ST4_OCC2) void nn_
         own_d[n] = INFINITY;
         own_i[n] = -1;
         own_p[n] = make_float4(0.f, 0.f, 0.f, __int_as_float(-1));
+        // three independent loads (not a chain seed -> point): a wave's set-up is latency, not bandwidth
+        const int sj = ok ? seed[qidx[n]] : -1;
+        const float4 p = ok ? seedpt[qidx[n]] : make_float4(0.f, 0.f, 0.f, 0.f);   // the seed's coordinates, kept from the launch that found it
         if (ok) {
-            const int sj = seed[qidx[n]];
-            const float4 p = seedpt[qidx[n]];                  // the seed's coordinates, kept from the launch that found it
             if (sj >= 0 && sj < T.n) {
                 own_p[n] = p;
                 own_d[n] = nn_exact_d2(qx[n], qy[n], qz[n], p.x, p.y, p.z);
@@ -610,26 +611,34 @@ __global__ __launch_bounds__(256, NQ == 1 ? FDC_ST4_OCC : FDC_ST4_OCC2) void nn_
     nsurv = 0;                                                   // timing ablation only (wrong results): no main loop
 #endif
     if (nsurv > 0) {
-        int ch = WPG * (listed ? (int)slist[wave][0] : 0) + sub;
-        const uint4* fr = T.frags + (size_t)ch * NT * 64 + lane;          // [tile][half][col] == [tile][lane]
-        uint4 f[ST4_PF];
+        // chunk ids are wave-uniform: kept in SGPRs (readfirstlane), so fragment addresses are scalar base + lane offset +
+        // immediate and the centres come through the scalar cache, one chunk ahead
+        int ch = __builtin_amdgcn_readfirstlane(WPG * (listed ? (int)slist[wave][0] : 0) + sub);
+        const char* fr = (const char*)(T.frags + (size_t)ch * NT * 64);   // [tile][half][col] == [tile][lane]
+        const unsigned lofs = (unsigned)lane * 16u;                        // scalar base + 32-bit lane offset + immediate
+        typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+        u32x4 f[ST4_PF];
 #pragma unroll
-        for (int j = 0; j < ST4_PF; ++j) f[j] = fr[j * 64];
+        for (int j = 0; j < ST4_PF; ++j) f[j] = *(const u32x4*)(fr + j * 1024 + lofs);
+        float4 cc_next = T.centers[ch];
+        nsurv = __builtin_amdgcn_readfirstlane(nsurv);
         for (int s = 0; s < nsurv; ++s) {
             const int s1 = min(s + 1, nsurv - 1);                          // last survivor: harmless re-fetch of itself
-            const int ch_next = WPG * (listed ? (int)slist[wave][s1] : s1) + sub;
-            const uint4* fr_next = T.frags + (size_t)ch_next * NT * 64 + lane;
-            const float4 cc = T.centers[ch];
+            const int ch_next = __builtin_amdgcn_readfirstlane(WPG * (listed ? (int)slist[wave][s1] : s1) + sub);
+            const char* fr_next = (const char*)(T.frags + (size_t)ch_next * NT * 64);
+            const float4 cc = cc_next;
+            cc_next = T.centers[ch_next];
             FDC_STAT(3, lane == 0);
             // re-centre the queries on the chunk centre
             bf16x8 bfrag[NQ];
             float thr[NQ], X[NQ], X2[NQ];
+            bool thr_own[NQ];                                             // thr[n] was formed from this lane's own best (own_p passes it)
             const float rc = cc.w;
 #pragma unroll
             for (int n = 0; n < NQ; ++n) {
                 const float xx = qx[n] - cc.x, xy = qy[n] - cc.y, xz = qz[n] - cc.z;
                 X2[n] = __fmaf_rn(xz, xz, __fmaf_rn(xy, xy, xx * xx));
-                X[n] = sqrtf(X2[n]);
+                X[n] = __builtin_amdgcn_sqrtf(X2[n]) * 1.000001f;           // only feeds eps: 1-ulp v_sqrt_f32, rounded up
                 const unsigned hx = f2bf(xx), hy = f2bf(xy), hz = f2bf(xz);
                 const unsigned lx = f2bf(xx - bf2f(hx)), ly = f2bf(xy - bf2f(hy)), lz = f2bf(xz - bf2f(hz));
                 const unsigned px = f2bf(-2.f * bf2f(hx)) | (f2bf(-2.f * bf2f(lx)) << 16);
@@ -641,12 +650,21 @@ __global__ __launch_bounds__(256, NQ == 1 ? FDC_ST4_OCC : FDC_ST4_OCC2) void nn_
                 // this half's own bound (the other half's may be tighter after an exact hit; it is folded in at the next
                 // hit -- a looser threshold only lets more pairs through, and saves a cross-half exchange per cell)
                 thr[n] = (qidx[n] < nq) ? own_d[n] - X2[n] + (MF_K1 * X[n] * rc + MF_K2 * (X2[n] + rc * rc)) : -INFINITY;
+                thr_own[n] = true;
             }
             const int base = ch * MF_CH;
 #pragma unroll
             for (int tile = 0; tile < NT; ++tile) {
                 const bf16x8 afrag = __builtin_bit_cast(bf16x8, f[tile % ST4_PF]);
-                f[tile % ST4_PF] = tile + ST4_PF < NT ? fr[(tile + ST4_PF) * 64] : fr_next[(tile + ST4_PF - NT) * 64];
+                const int tn = tile + ST4_PF;                               // immediates reach 4 KB: one scalar base per four tiles
+                unsigned long long fb = (unsigned long long)(tn < NT ? fr + (tn / 4) * 4096 : fr_next);
+                unsigned lo = lofs;
+#if defined(__HIP_DEVICE_COMPILE__)
+                asm volatile("" : "+s"(fb), "+v"(lo));   // opaque: base + zext(lane offset) stay in this block, so the load takes
+                                                         // the SGPR base directly (otherwise: three 64-bit VALU adds per tile)
+#endif
+                typedef const __attribute__((address_space(1))) u32x4* gptr_t;
+                f[tile % ST4_PF] = *(gptr_t)(fb + lo + (unsigned long long)((tn < NT ? tn % 4 : tn - NT) * 1024));
                 f32x16_t acc_q[NQ];
 #pragma unroll
                 for (int n = 0; n < NQ; ++n) acc_q[n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afrag, bfrag[n], zero, 0, 0, 0);
@@ -660,9 +678,23 @@ __global__ __launch_bounds__(256, NQ == 1 ? FDC_ST4_OCC : FDC_ST4_OCC2) void nn_
                     FDC_STAT(0, lane == 0);
                     if (__any(m < thr[n])) {
                         FDC_STAT(1, lane == 0);
-                        unsigned mask = 0;
+                        // In the steady state nearly every entry is a query meeting its own seed (it passes the filter by
+                        // construction; 11 of a wave's 80 tiles).  Row masks as wave-wide ballots (SALU): if every lane
+                        // that passed holds its current best in this tile's rows of its half, passed with exactly one row
+                        // and its threshold is its own bound, that row IS the best and there is nothing to re-evaluate.
+                        unsigned long long seen = 0, twice = 0, mrow[16];
 #pragma unroll
-                        for (int r = 0; r < 16; ++r) mask |= (acc[r] < thr[n]) ? (1u << r) : 0u;
+                        for (int r = 0; r < 16; ++r) {
+                            mrow[r] = __ballot(acc[r] < thr[n]);
+                            twice |= seen & mrow[r];
+                            seen |= mrow[r];
+                        }
+                        const int spos = __float_as_int(own_p[n].w);
+                        const bool mine = thr_own[n] && (spos >> 5) == (base >> 5) + tile && ((spos >> 2) & 1) == half;
+                        if (((seen & ~__ballot(mine)) | twice) == 0) continue;
+                        unsigned mask = 0;                                 // rare from here on: this lane's bits of the ballots
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) mask |= (unsigned)((mrow[r] >> lane) & 1ull) << r;
                         while (mask) {                                     // rows of this lane that passed the filter
                             const int r = __ffs(mask) - 1;
                             mask &= mask - 1;
@@ -680,6 +712,7 @@ __global__ __launch_bounds__(256, NQ == 1 ? FDC_ST4_OCC : FDC_ST4_OCC2) void nn_
                         }
                         const float sbest = fminf(own_d[n], __shfl_xor(own_d[n], 32, 64));
                         if (qidx[n] < nq) thr[n] = sbest - X2[n] + (MF_K1 * X[n] * rc + MF_K2 * (X2[n] + rc * rc));
+                        thr_own[n] = sbest == own_d[n];
                     }
                 }
             }
