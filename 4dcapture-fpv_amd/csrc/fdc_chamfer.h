@@ -472,6 +472,7 @@ __global__ __launch_bounds__(256, NQ == 1 ? FDC_ST4_OCC : FDC_ST4_OCC2) void nn_
                                                          const int* __restrict__ seed, float4* __restrict__ seedpt,
                                                          float* __restrict__ dist, int* __restrict__ idx) {
     __shared__ unsigned short slist[4][ST4_MAXLIST];
+    __shared__ float4 sbox[4][64][2];                            // a wave's near chunk boxes of the current batch {lo, bits(chunk)}, {hi, -}
     __shared__ float s_d[4][32 * NQ];
     __shared__ int s_i[4][32 * NQ];
     __shared__ float4 s_p[4][32 * NQ];
@@ -538,8 +539,9 @@ __global__ __launch_bounds__(256, NQ == 1 ? FDC_ST4_OCC : FDC_ST4_OCC2) void nn_
     ghx = wave_max64(ghx); ghy = wave_max64(ghy); ghz = wave_max64(ghz);
     const bool cull = __all(all_seeded && finite);
     // box-box overlap (closed): false only if the boxes are strictly apart along some axis
+    // (bitwise |: with short-circuit || the compiler sinks the component loads into a chain of dependent branches)
     auto overlaps = [&](float4 lo, float4 hi) -> bool {
-        return !(lo.x > ghx || hi.x < glx || lo.y > ghy || hi.y < gly || lo.z > ghz || hi.z < glz);
+        return !((lo.x > ghx) | (hi.x < glx) | (lo.y > ghy) | (hi.y < gly) | (lo.z > ghz) | (hi.z < glz));
     };
 
     // Survivor list of this wave, two levels: the boxes of 16-chunk super-cells (k-d subtrees) are tested against
@@ -578,27 +580,37 @@ __global__ __launch_bounds__(256, NQ == 1 ? FDC_ST4_OCC : FDC_ST4_OCC2) void nn_
                     hi = T.bounds[2 * ci + 1];
                     near = overlaps(lo, hi);
                 }
-                unsigned long long m = __ballot(near);
-                while (m) {                                      // wave-uniform loop over the near chunks of this batch
-                    const int b = __ffsll((long long)m) - 1;
-                    m &= m - 1;
-                    float4 blo, bhi;                             // lane b's box, broadcast
-                    blo.x = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(lo.x), b));
-                    blo.y = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(lo.y), b));
-                    blo.z = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(lo.z), b));
-                    bhi.x = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(hi.x), b));
-                    bhi.y = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(hi.y), b));
-                    bhi.z = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(hi.z), b));
+                // Per-query test of the near chunks (27 per wave at 512 k queries, 5 survive): their boxes are staged in
+                // LDS, compacted in chunk order, and every round tests TWO of them -- the two 32-lane halves of the wave hold
+                // the same queries, so each half takes its own chunk (broadcast reads; the wave's own LDS traffic is in order).
+                const unsigned long long m = __ballot(near);
+                const int nnear = __popcll(m);
+                if (near) {
+                    const int k = __builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0));
+                    sbox[wave][k][0] = make_float4(lo.x, lo.y, lo.z, __int_as_float(ci));
+                    sbox[wave][k][1] = hi;
+                }
+                __builtin_amdgcn_wave_barrier();
+                for (int k0 = 0; k0 < nnear; k0 += 2) {          // wave-uniform
+                    const int k = min(k0 + half, nnear - 1);     // odd count: both halves test the last chunk
+                    const float4 blo = sbox[wave][k][0], bhi = sbox[wave][k][1];
                     bool hit = false;
 #pragma unroll
                     for (int n = 0; n < NQ; ++n) hit |= box_d2(blo, bhi, qx[n], qy[n], qz[n]) <= sb[n];
-                    if (__any(hit)) {
+                    const unsigned long long hm = __ballot(hit);
+                    const int c0 = __builtin_amdgcn_readlane(__float_as_int(blo.w), 0), c1 = __builtin_amdgcn_readlane(__float_as_int(blo.w), 32);
+                    if ((unsigned)hm) {
                         if (nsurv >= ST4_MAXLIST) { listed = false; break; }
-                        const int cb = __builtin_amdgcn_readlane(ci, b);
-                        if (lane == 0) slist[wave][nsurv] = (unsigned short)(cb / WPG);    // k of chunk WPG k + sub
+                        if (lane == 0) slist[wave][nsurv] = (unsigned short)(c0 / WPG);    // k of chunk WPG k + sub
+                        ++nsurv;
+                    }
+                    if (k0 + 1 < nnear && (unsigned)(hm >> 32)) {
+                        if (nsurv >= ST4_MAXLIST) { listed = false; break; }
+                        if (lane == 0) slist[wave][nsurv] = (unsigned short)(c1 / WPG);
                         ++nsurv;
                     }
                 }
+                __builtin_amdgcn_wave_barrier();
             }
         }
         if (!listed) nsurv = myn;                               // list overflow: scan the whole quarter (still exact)
