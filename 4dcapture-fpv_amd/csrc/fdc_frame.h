@@ -189,38 +189,48 @@ FDC_HD void pose_backward(const PoseModel& pm, const float* x, const float* o, c
         sc.dJ[j][0] = dJ.x; sc.dJ[j][1] = dJ.y; sc.dJ[j][2] = dJ.z;
     }
     sync();
-    // reverse chain: parents (level L-1) gather the gradient of their children (level L).  Only the accumulation is
-    // level-ordered; what each joint hands to its local rotation / offset (dR, drel) needs its FINAL dG and is formed
-    // for all joints at once afterwards (one LDS round per level instead of two).
+    // Reverse chain.  With G_c.R = G_p.R R_c and G_c.t = G_p.R (J_c - J_p) + G_p.t, a joint's total gradient is a sum
+    // over its subtree that factors through the WORLD transforms of the forward pass:
+    //     dG_p.t = sum_{d in sub(p)} g_d.t
+    //     dG_p.R = [ sum_{d in sub(p)} (g_d.R G_d.R^T + g_d.t (x) G_d.t)  -  (sum_d g_d.t) (x) G_p.t ] G_p.R
+    // (g = the joints' own gradients formed above; R(p->d)^T = G_d.R^T G_p.R and a (x) (R^T v) = (a (x) v) R).
+    // So the level-ordered part is a plain subtree sum of 12 numbers per joint -- three b128 reads and 12 adds per child
+    // instead of a 3x3 product, an outer product and 24 scalar reads -- and the products run once, for all joints at once.
+    for (int d = tid; d < NJ; d += nthr) {
+        M3 U = m3_mul_bt(g_rot(sc.dG[d]), g_rot(sc.G[d]));
+        V3 gt = g_trn(sc.dG[d]);
+        m3_add_outer(U, gt, g_trn(sc.G[d]));
+        g_store(sc.dG[d], U, gt);
+    }
+    sync();
     for (int L = pm.nlevels - 1; L >= 1; --L) {
         for (int k = pm.level_start[L - 1] + tid; k < pm.level_start[L]; k += nthr) {
             int p = pm.order[k];
-            M3 acc = g_rot(sc.dG[p]);
-            V3 acct = g_trn(sc.dG[p]);
-            V3 Jp = v3(sc.J[p][0], sc.J[p][1], sc.J[p][2]);
+            float acc[12];
+            for (int e = 0; e < 12; ++e) acc[e] = sc.dG[p][e];
             for (int ci = pm.child_start[p]; ci < pm.child_start[p + 1]; ++ci) {
                 int c = pm.child_list[ci];
-                M3 dGc = g_rot(sc.dG[c]);
-                V3 dGct = g_trn(sc.dG[c]);
-                m3_add(acc, m3_mul_bt(dGc, load_m3(sc.R[c])));
-                m3_add_outer(acc, dGct, v3(sc.J[c][0], sc.J[c][1], sc.J[c][2]) - Jp);
-                acct = acct + dGct;
+                for (int e = 0; e < 12; ++e) acc[e] += sc.dG[c][e];
             }
-            g_store(sc.dG[p], acc, acct);
+            for (int e = 0; e < 12; ++e) sc.dG[p][e] = acc[e];
         }
         sync();
     }
+    // subtree sums -> the joint's total gradient -> what it hands to its local rotation and offset (dR, drel)
     for (int c = tid; c < NJ; c += nthr) {
+        M3 SU = g_rot(sc.dG[c]);
+        V3 dGt = g_trn(sc.dG[c]);
+        m3_add_outer(SU, -1.f * dGt, g_trn(sc.G[c]));
+        M3 dGR = m3_mul(SU, g_rot(sc.G[c]));
         int p = pm.parents[c];
         if (p >= 0) {
             M3 Rp = g_rot(sc.G[p]);
-            store_m3(sc.dR[c], m3_mul_at(Rp, g_rot(sc.dG[c])));
-            V3 dr = m3t_vec(Rp, g_trn(sc.dG[c]));
+            store_m3(sc.dR[c], m3_mul_at(Rp, dGR));
+            V3 dr = m3t_vec(Rp, dGt);
             sc.drel[c][0] = dr.x; sc.drel[c][1] = dr.y; sc.drel[c][2] = dr.z;
         } else {
-            store_m3(sc.dR[c], g_rot(sc.dG[c]));
-            V3 t = g_trn(sc.dG[c]);
-            sc.drel[c][0] = t.x; sc.drel[c][1] = t.y; sc.drel[c][2] = t.z;
+            store_m3(sc.dR[c], dGR);
+            sc.drel[c][0] = dGt.x; sc.drel[c][1] = dGt.y; sc.drel[c][2] = dGt.z;
         }
     }
     for (int i = tid; i < 90; i += nthr) (&sc.daa[0][0])[i] = 0.f;
