@@ -653,9 +653,7 @@ __global__ __launch_bounds__(256, NQ == 1 ? FDC_ST4_OCC : FDC_ST4_OCC2) void nn_
                 X[n] = __builtin_amdgcn_sqrtf(X2[n]) * 1.000001f;           // only feeds eps: 1-ulp v_sqrt_f32, rounded up
                 const unsigned hx = f2bf(xx), hy = f2bf(xy), hz = f2bf(xz);
                 const unsigned lx = f2bf(xx - bf2f(hx)), ly = f2bf(xy - bf2f(hy)), lz = f2bf(xz - bf2f(hz));
-                const unsigned px = f2bf(-2.f * bf2f(hx)) | (f2bf(-2.f * bf2f(lx)) << 16);
-                const unsigned py = f2bf(-2.f * bf2f(hy)) | (f2bf(-2.f * bf2f(ly)) << 16);
-                const unsigned pz = f2bf(-2.f * bf2f(hz)) | (f2bf(-2.f * bf2f(lz)) << 16);
+                const unsigned px = hx | (lx << 16), py = hy | (ly << 16), pz = hz | (lz << 16);   // (the factor -2 is in the A fragments)
                 const unsigned one = 0x3F80u;
                 const uint4 u = half == 0 ? make_uint4(px, px, py, py) : make_uint4(pz, pz, one | (one << 16), one);
                 bfrag[n] = __builtin_bit_cast(bf16x8, u);

@@ -921,8 +921,12 @@ int fdcap_set_scene(fdcap_ctx* c, const float* xyz, int64_t ns) {
                 n2 = yz * yz + (yy * yy + yx * yx);
                 r2 = std::max(r2, n2);
             }
-            const uint32_t hx = bf(yx), hy = bf(yy), hz = bf(yz);
-            const uint32_t lx = bf(yx - bff(hx)), ly = bf(yy - bff(hy)), lz = bf(yz - bff(hz));
+            uint32_t hx = bf(yx), hy = bf(yy), hz = bf(yz);
+            uint32_t lx = bf(yx - bff(hx)), ly = bf(yy - bff(hy)), lz = bf(yz - bff(hz));
+            // the score's factor -2 (|y|^2 - 2 x.y) rides on the static side: exact in bf16, and the per-chunk query
+            // fragment is the plain hi | lo split
+            hx = bf(-2.f * bff(hx)); hy = bf(-2.f * bff(hy)); hz = bf(-2.f * bff(hz));
+            lx = bf(-2.f * bff(lx)); ly = bf(-2.f * bff(ly)); lz = bf(-2.f * bff(lz));
             const uint32_t nh = bf(n2);
             const float r1 = n2 - bff(nh);
             const uint32_t nm = bf(r1), nl = bf(r1 - bff(nm));
