@@ -33,6 +33,7 @@ struct NNTarget {
     int n;
     const float4* bounds;     // optional [2 * ceil(n / MF_CH)] axis-aligned box {lo xyz, -}, {hi xyz, -} of each chunk (pts spatially sorted)
     const float4* sbounds;    // with bounds: [2 * ceil(nchunk / 16)] boxes of 16 consecutive chunks (two-level survivor test)
+    const float4* qbounds;    // with frags: [2 * 4 * nchunk] boxes of the quarter chunks (the unit the streaming kernel lists and scans)
     const int* inv_perm;      // optional [n] original index -> position in pts (null: identity)
     // optional, static per scene: MFMA A fragments precomputed per chunk RELATIVE TO THE CHUNK'S OWN CENTRE
     // ([chunk][tile 0..15][k-half][point 0..31] uint4) + the centres {cx, cy, cz, radius}: lets a wave
@@ -451,7 +452,8 @@ __global__ __launch_bounds__(256) void nn_mfma_kernel(const float* __restrict__ 
 // repeated by each of them: the host picks WPG by launch size.
 // blockIdx -> query group is XCD-aware: each XCD serves a contiguous range of groups (frames that follow
 // each other touch the same scene chunks, so an XCD's L2 holds 1/8 of the clip's neighbourhoods).
-constexpr int ST4_MAXLIST = 512;       // survivors one wave can list out of its quarter of the chunks
+constexpr int ST4_MAXLIST = 768;       // quarter chunks one wave can list out of its share of the chunks
+constexpr int ST4_MAXCELL = 256;       // chunks one wave can list before their quarters are tested
 // Ring depth vs occupancy (measured at 512 k queries, NQ = 1, one wave per group): 8 fragments / 4 waves per SIMD
 // (128 VGPR) 0.148 ms, 4 / 5 (92 VGPR) 0.139, 2 / 6 (80 VGPR) 0.136: the launch is latency-bound on its set-up
 // chain, so resident waves hide more than a deeper ring does.
@@ -471,7 +473,8 @@ template <int NQ, int WPG>
 __global__ __launch_bounds__(256, NQ == 1 ? FDC_ST4_OCC : FDC_ST4_OCC2) void nn_stream4_kernel(const float* __restrict__ q, int nq, NNTarget T,
                                                          const int* __restrict__ seed, float4* __restrict__ seedpt,
                                                          float* __restrict__ dist, int* __restrict__ idx) {
-    __shared__ unsigned short slist[4][ST4_MAXLIST];
+    __shared__ unsigned short slist[4][ST4_MAXLIST];             // a wave's work list: quarter chunks 4 k + quarter (chunk WPG k + sub)
+    __shared__ unsigned short clist[4][ST4_MAXCELL];             // ... before that, the chunks that passed the per-query test
     __shared__ float4 sbox[4][64][2];                            // a wave's near chunk boxes of the current batch {lo, bits(chunk)}, {hi, -}
     __shared__ float s_d[4][32 * NQ];
     __shared__ int s_i[4][32 * NQ];
@@ -549,7 +552,7 @@ __global__ __launch_bounds__(256, NQ == 1 ? FDC_ST4_OCC : FDC_ST4_OCC2) void nn_
     // (4 j + wave, j < 4) -- 16 super-cells x 4 chunks per round of lanes -- against the reach and then per query.
     // (Testing all chunk boxes directly costs every workgroup the whole box array through L1/L2: 31 KB x 16000
     // workgroups per launch at 500k points, more than everything else the kernel reads.)
-    int nsurv = myn;
+    int nsurv = 4 * myn;                                         // work items are quarter chunks: 4 k + quarter
     bool listed = false;
 #if defined(FDC_ST4_ABLATE) && FDC_ST4_ABLATE >= 2
     if (false) {                                                 // timing ablation only: no survivor list either
@@ -558,6 +561,7 @@ __global__ __launch_bounds__(256, NQ == 1 ? FDC_ST4_OCC : FDC_ST4_OCC2) void nn_
 #endif
         nsurv = 0;
         listed = true;
+        int ncell = 0;
         const int nsuper = (nchunk + ST4_SUPER - 1) / ST4_SUPER;
         for (int s0 = 0; s0 < nsuper && listed; s0 += 64) {
             const int si = s0 + lane;
@@ -600,33 +604,72 @@ __global__ __launch_bounds__(256, NQ == 1 ? FDC_ST4_OCC : FDC_ST4_OCC2) void nn_
                     const unsigned long long hm = __ballot(hit);
                     const int c0 = __builtin_amdgcn_readlane(__float_as_int(blo.w), 0), c1 = __builtin_amdgcn_readlane(__float_as_int(blo.w), 32);
                     if ((unsigned)hm) {
-                        if (nsurv >= ST4_MAXLIST) { listed = false; break; }
-                        if (lane == 0) slist[wave][nsurv] = (unsigned short)(c0 / WPG);    // k of chunk WPG k + sub
-                        ++nsurv;
+                        if (ncell >= ST4_MAXCELL) { listed = false; break; }
+                        if (lane == 0) clist[wave][ncell] = (unsigned short)(c0 / WPG);    // k of chunk WPG k + sub
+                        ++ncell;
                     }
                     if (k0 + 1 < nnear && (unsigned)(hm >> 32)) {
-                        if (nsurv >= ST4_MAXLIST) { listed = false; break; }
-                        if (lane == 0) slist[wave][nsurv] = (unsigned short)(c1 / WPG);
-                        ++nsurv;
+                        if (ncell >= ST4_MAXCELL) { listed = false; break; }
+                        if (lane == 0) clist[wave][ncell] = (unsigned short)(c1 / WPG);
+                        ++ncell;
                     }
                 }
                 __builtin_amdgcn_wave_barrier();
             }
         }
-        if (!listed) nsurv = myn;                               // list overflow: scan the whole quarter (still exact)
+        // Second stage: the QUARTERS (128 points = four MFMA tiles = one k-d node) of the surviving chunks against every
+        // query.  Only ~11 of the 80 tiles a wave used to scan hold a point within any query's bound; a chunk is a 30 cm
+        // patch, the part of it some query's ball reaches usually one or two of its quarters.  Eight chunks per pass:
+        // lane l fetches box part l & 7 of chunk l >> 3 into LDS (one latency per pass), then two rounds per chunk, each
+        // half-wave on its own quarter.
+        float4* const qbox = &sbox[wave][0][0];
+        for (int cb = 0; cb < ncell && listed; cb += 8) {
+            const int cs_l = cb + (lane >> 3);
+            if (cs_l < ncell) {
+                const int chq = WPG * (int)clist[wave][cs_l] + sub;
+                qbox[lane] = T.qbounds[(size_t)chq * 8 + (lane & 7)];
+            }
+            __builtin_amdgcn_wave_barrier();
+            const int ncs = min(8, ncell - cb);
+            for (int cs = 0; cs < ncs && listed; ++cs) {         // wave-uniform
+                const int k4 = 4 * __builtin_amdgcn_readfirstlane((int)clist[wave][cb + cs]);
+#pragma unroll
+                for (int rnd = 0; rnd < 2; ++rnd) {
+                    const float4 blo = qbox[cs * 8 + 2 * (2 * rnd + half)], bhi = qbox[cs * 8 + 2 * (2 * rnd + half) + 1];
+                    bool hit = false;
+#pragma unroll
+                    for (int n = 0; n < NQ; ++n) hit |= box_d2(blo, bhi, qx[n], qy[n], qz[n]) <= sb[n];
+                    const unsigned long long hm = __ballot(hit);
+                    if ((unsigned)hm) {
+                        if (nsurv >= ST4_MAXLIST) { listed = false; break; }
+                        if (lane == 0) slist[wave][nsurv] = (unsigned short)(k4 + 2 * rnd);
+                        ++nsurv;
+                    }
+                    if ((unsigned)(hm >> 32)) {
+                        if (nsurv >= ST4_MAXLIST) { listed = false; break; }
+                        if (lane == 0) slist[wave][nsurv] = (unsigned short)(k4 + 2 * rnd + 1);
+                        ++nsurv;
+                    }
+                }
+            }
+            __builtin_amdgcn_wave_barrier();
+        }
+        if (!listed) nsurv = 4 * myn;                           // list overflow: scan this wave's whole share (still exact)
     }
     const f32x16_t zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     constexpr int NT = MF_CH / 32;                               // 16 tiles per chunk (padding rows score 1e30)
-    static_assert(NT % ST4_PF == 0, "the prefetch ring turns a whole number of times per chunk");
+    constexpr int QT = NT / 4;                                   // tiles per work item (quarter chunk)
+    static_assert(QT % ST4_PF == 0, "the prefetch ring turns a whole number of times per work item");
 
 #if defined(FDC_ST4_ABLATE) && FDC_ST4_ABLATE >= 1
     nsurv = 0;                                                   // timing ablation only (wrong results): no main loop
 #endif
     if (nsurv > 0) {
-        // chunk ids are wave-uniform: kept in SGPRs (readfirstlane), so fragment addresses are scalar base + lane offset +
-        // immediate and the centres come through the scalar cache, one chunk ahead
-        int ch = __builtin_amdgcn_readfirstlane(WPG * (listed ? (int)slist[wave][0] : 0) + sub);
-        const char* fr = (const char*)(T.frags + (size_t)ch * NT * 64);   // [tile][half][col] == [tile][lane]
+        // work items (quarter chunks) are wave-uniform: ids kept in SGPRs (readfirstlane), so fragment addresses are scalar
+        // base + lane offset + immediate and the centres come through the scalar cache, one item ahead
+        int id = __builtin_amdgcn_readfirstlane(listed ? (int)slist[wave][0] : 0);
+        int ch = __builtin_amdgcn_readfirstlane(WPG * (id >> 2) + sub), qd = id & 3;
+        const char* fr = (const char*)(T.frags + ((size_t)ch * NT + qd * QT) * 64);   // [tile][half][col] == [tile][lane]
         const unsigned lofs = (unsigned)lane * 16u;                        // scalar base + 32-bit lane offset + immediate
         typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
         u32x4 f[ST4_PF];
@@ -634,47 +677,54 @@ __global__ __launch_bounds__(256, NQ == 1 ? FDC_ST4_OCC : FDC_ST4_OCC2) void nn_
         for (int j = 0; j < ST4_PF; ++j) f[j] = *(const u32x4*)(fr + j * 1024 + lofs);
         float4 cc_next = T.centers[ch];
         nsurv = __builtin_amdgcn_readfirstlane(nsurv);
+        int cur = -1;                                                      // chunk the queries are centred on
+        bf16x8 bfrag[NQ];
+        float thr[NQ], X[NQ], X2[NQ], rc = 0.f;
+        bool thr_own[NQ];                                                  // thr[n] was formed from this lane's own best (own_p passes it)
+#pragma unroll
+        for (int n = 0; n < NQ; ++n) { thr[n] = -INFINITY; X[n] = X2[n] = 0.f; thr_own[n] = false; bfrag[n] = __builtin_bit_cast(bf16x8, make_uint4(0u, 0u, 0u, 0u)); }
         for (int s = 0; s < nsurv; ++s) {
-            const int s1 = min(s + 1, nsurv - 1);                          // last survivor: harmless re-fetch of itself
-            const int ch_next = __builtin_amdgcn_readfirstlane(WPG * (listed ? (int)slist[wave][s1] : s1) + sub);
-            const char* fr_next = (const char*)(T.frags + (size_t)ch_next * NT * 64);
+            const int s1 = min(s + 1, nsurv - 1);                          // last item: harmless re-fetch of itself
+            const int id_next = __builtin_amdgcn_readfirstlane(listed ? (int)slist[wave][s1] : s1);
+            const int ch_next = __builtin_amdgcn_readfirstlane(WPG * (id_next >> 2) + sub);
+            const char* fr_next = (const char*)(T.frags + ((size_t)ch_next * NT + (id_next & 3) * QT) * 64);
             const float4 cc = cc_next;
             cc_next = T.centers[ch_next];
             FDC_STAT(3, lane == 0);
-            // re-centre the queries on the chunk centre
-            bf16x8 bfrag[NQ];
-            float thr[NQ], X[NQ], X2[NQ];
-            bool thr_own[NQ];                                             // thr[n] was formed from this lane's own best (own_p passes it)
-            const float rc = cc.w;
+            if (ch != cur) {                                               // wave-uniform: quarters of one chunk follow each other
+                cur = ch;
+                // re-centre the queries on the chunk centre
+                rc = cc.w;
 #pragma unroll
-            for (int n = 0; n < NQ; ++n) {
-                const float xx = qx[n] - cc.x, xy = qy[n] - cc.y, xz = qz[n] - cc.z;
-                X2[n] = __fmaf_rn(xz, xz, __fmaf_rn(xy, xy, xx * xx));
-                X[n] = __builtin_amdgcn_sqrtf(X2[n]) * 1.000001f;           // only feeds eps: 1-ulp v_sqrt_f32, rounded up
-                const unsigned hx = f2bf(xx), hy = f2bf(xy), hz = f2bf(xz);
-                const unsigned lx = f2bf(xx - bf2f(hx)), ly = f2bf(xy - bf2f(hy)), lz = f2bf(xz - bf2f(hz));
-                const unsigned px = hx | (lx << 16), py = hy | (ly << 16), pz = hz | (lz << 16);   // (the factor -2 is in the A fragments)
-                const unsigned one = 0x3F80u;
-                const uint4 u = half == 0 ? make_uint4(px, px, py, py) : make_uint4(pz, pz, one | (one << 16), one);
-                bfrag[n] = __builtin_bit_cast(bf16x8, u);
-                // this half's own bound (the other half's may be tighter after an exact hit; it is folded in at the next
-                // hit -- a looser threshold only lets more pairs through, and saves a cross-half exchange per cell)
-                thr[n] = (qidx[n] < nq) ? own_d[n] - X2[n] + (MF_K1 * X[n] * rc + MF_K2 * (X2[n] + rc * rc)) : -INFINITY;
-                thr_own[n] = true;
+                for (int n = 0; n < NQ; ++n) {
+                    const float xx = qx[n] - cc.x, xy = qy[n] - cc.y, xz = qz[n] - cc.z;
+                    X2[n] = __fmaf_rn(xz, xz, __fmaf_rn(xy, xy, xx * xx));
+                    X[n] = __builtin_amdgcn_sqrtf(X2[n]) * 1.000001f;       // only feeds eps: 1-ulp v_sqrt_f32, rounded up
+                    const unsigned hx = f2bf(xx), hy = f2bf(xy), hz = f2bf(xz);
+                    const unsigned lx = f2bf(xx - bf2f(hx)), ly = f2bf(xy - bf2f(hy)), lz = f2bf(xz - bf2f(hz));
+                    const unsigned px = hx | (lx << 16), py = hy | (ly << 16), pz = hz | (lz << 16);   // (the factor -2 is in the A fragments)
+                    const unsigned one = 0x3F80u;
+                    const uint4 u = half == 0 ? make_uint4(px, px, py, py) : make_uint4(pz, pz, one | (one << 16), one);
+                    bfrag[n] = __builtin_bit_cast(bf16x8, u);
+                    // this half's own bound (the other half's may be tighter after an exact hit; it is folded in at the next
+                    // hit -- a looser threshold only lets more pairs through, and saves a cross-half exchange per cell)
+                    thr[n] = (qidx[n] < nq) ? own_d[n] - X2[n] + (MF_K1 * X[n] * rc + MF_K2 * (X2[n] + rc * rc)) : -INFINITY;
+                    thr_own[n] = true;
+                }
             }
-            const int base = ch * MF_CH;
+            const int base = ch * MF_CH + qd * (QT * 32);
 #pragma unroll
-            for (int tile = 0; tile < NT; ++tile) {
+            for (int tile = 0; tile < QT; ++tile) {
                 const bf16x8 afrag = __builtin_bit_cast(bf16x8, f[tile % ST4_PF]);
-                const int tn = tile + ST4_PF;                               // immediates reach 4 KB: one scalar base per four tiles
-                unsigned long long fb = (unsigned long long)(tn < NT ? fr + (tn / 4) * 4096 : fr_next);
+                const int tn = tile + ST4_PF;                               // a quarter's four tiles are within reach of the immediates
+                unsigned long long fb = (unsigned long long)(tn < QT ? fr : fr_next);
                 unsigned lo = lofs;
 #if defined(__HIP_DEVICE_COMPILE__)
                 asm volatile("" : "+s"(fb), "+v"(lo));   // opaque: base + zext(lane offset) stay in this block, so the load takes
                                                          // the SGPR base directly (otherwise: three 64-bit VALU adds per tile)
 #endif
                 typedef const __attribute__((address_space(1))) u32x4* gptr_t;
-                f[tile % ST4_PF] = *(gptr_t)(fb + lo + (unsigned long long)((tn < NT ? tn % 4 : tn - NT) * 1024));
+                f[tile % ST4_PF] = *(gptr_t)(fb + lo + (unsigned long long)((tn < QT ? tn : tn - QT) * 1024));
                 f32x16_t acc_q[NQ];
 #pragma unroll
                 for (int n = 0; n < NQ; ++n) acc_q[n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afrag, bfrag[n], zero, 0, 0, 0);
@@ -727,6 +777,7 @@ __global__ __launch_bounds__(256, NQ == 1 ? FDC_ST4_OCC : FDC_ST4_OCC2) void nn_
                 }
             }
             ch = ch_next;
+            qd = id_next & 3;
             fr = fr_next;
         }
     }

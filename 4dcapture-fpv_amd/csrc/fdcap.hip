@@ -671,13 +671,14 @@ struct fdcap_ctx {
     DevBuf<float4> scene_sorted;   // k-d cell order {x,y,z,bits(original index)}: what the NN scan streams
     DevBuf<float4> scene_bounds;   // axis-aligned box {lo},{hi} of each MF_CH-point chunk of scene_sorted
     DevBuf<float4> scene_sbounds;  // ... of each run of ST4_SUPER chunks
+    DevBuf<float4> scene_qbounds;  // ... of each quarter chunk (128 points = four MFMA tiles, one k-d node): [chunk][4]{lo},{hi}
     DevBuf<int> scene_inv;         // original index -> position in scene_sorted
     DevBuf<uint4> scene_frags;     // precomputed chunk-centred bf16 MFMA A fragments of scene_sorted
     DevBuf<float4> scene_centers;  // chunk centres {x,y,z,radius}
     int64_t ns = 0;
     NNTarget nn_target(bool cull) const {
         NNTarget t; t.pts = scene_sorted.p; t.n = (int)ns; t.bounds = cull ? scene_bounds.p : nullptr; t.inv_perm = scene_inv.p;
-        t.sbounds = cull ? scene_sbounds.p : nullptr;
+        t.sbounds = cull ? scene_sbounds.p : nullptr; t.qbounds = cull ? scene_qbounds.p : nullptr;
         t.frags = cull ? scene_frags.p : nullptr; t.centers = scene_centers.p;
         return t;
     }
@@ -840,7 +841,7 @@ void fdcap_ctx_destroy(fdcap_ctx* c) {
     c->Jt.release(); c->Jd.release(); c->hand_comp.release(); c->hand_mean.release();
     c->parents.release(); c->order.release(); c->level_start.release(); c->child_start.release(); c->child_list.release();
     c->W1.release(); c->b1.release(); c->W2.release(); c->b2.release(); c->W3.release(); c->b3.release();
-    c->full.release(); c->contact.release(); c->contact_vid.release(); c->contact_perm.release(); c->scene.release(); c->scene_sorted.release(); c->scene_bounds.release(); c->scene_sbounds.release(); c->scene_inv.release(); c->scene_frags.release(); c->scene_centers.release();
+    c->full.release(); c->contact.release(); c->contact_vid.release(); c->contact_perm.release(); c->scene.release(); c->scene_sorted.release(); c->scene_bounds.release(); c->scene_sbounds.release(); c->scene_qbounds.release(); c->scene_inv.release(); c->scene_frags.release(); c->scene_centers.release();
     for (auto& b : c->ws_f) b.release();
     for (auto& b : c->ws_i) b.release();
     c->ws_p.release();
@@ -904,6 +905,24 @@ int fdcap_set_scene(fdcap_ctx* c, const float* xyz, int64_t ns) {
         bounds[2 * ch] = make_float4(blo[0], blo[1], blo[2], 0.f);
         bounds[2 * ch + 1] = make_float4(bhi[0], bhi[1], bhi[2], 0.f);
     }
+    // boxes of the quarter chunks (the k-d recursion goes on below the chunk, so 128 consecutive points are one node);
+    // a quarter past the end of the scene gets the empty box (+inf, -inf): at infinite distance from every query
+    std::vector<float4> qbounds((size_t)nchunk * 8);
+    for (int64_t qc = 0; qc < nchunk * 4; ++qc) {
+        int64_t a = qc * (MF_CH / 4), b = std::min<int64_t>(ns, a + MF_CH / 4);
+        float blo[3] = {INFINITY, INFINITY, INFINITY}, bhi[3] = {-INFINITY, -INFINITY, -INFINITY};
+        for (int64_t p = a; p < b; ++p) {
+            const float v[3] = {sorted[p].x, sorted[p].y, sorted[p].z};
+            for (int k = 0; k < 3; ++k) { blo[k] = std::min(blo[k], v[k]); bhi[k] = std::max(bhi[k], v[k]); }
+        }
+        if (a < b)
+            for (int k = 0; k < 3; ++k) {
+                float pad = 1e-6f + 1e-6f * std::max(fabsf(blo[k]), fabsf(bhi[k]));
+                blo[k] -= pad; bhi[k] += pad;
+            }
+        qbounds[2 * qc] = make_float4(blo[0], blo[1], blo[2], 0.f);
+        qbounds[2 * qc + 1] = make_float4(bhi[0], bhi[1], bhi[2], 0.f);
+    }
     // chunk-centred bf16 hi/lo fragments in MFMA A layout (see nn_stream4_kernel)
     auto bf = [](float f) -> uint32_t { uint32_t u; memcpy(&u, &f, 4); u += 0x7FFFu + ((u >> 16) & 1u); return u >> 16; };   // RNE
     auto bff = [](uint32_t h) -> float { uint32_t u = h << 16; float f; memcpy(&f, &u, 4); return f; };
@@ -954,6 +973,7 @@ int fdcap_set_scene(fdcap_ctx* c, const float* xyz, int64_t ns) {
             sb[2 * su] = lo; sb[2 * su + 1] = hi;
         }
         HIP_TRY(c->scene_sbounds.upload(sb.data(), sb.size()));
+        HIP_TRY(c->scene_qbounds.upload(qbounds.data(), qbounds.size()));
     }
     HIP_TRY(c->scene_inv.upload(inv.data(), inv.size()));
     c->ns = ns;
