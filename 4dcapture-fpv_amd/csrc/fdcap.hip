@@ -182,18 +182,29 @@ __global__ __launch_bounds__(256) void skin_bwd_kernel(SkinModel sm, int nc, con
         const int c1 = min(nc, c0 + VCH);
         for (int c = c0 + tid; c < c1; c += 256) {
             size_t qi = (size_t)r * nc + c;
+            // every global load of this vertex goes out before the first use (the kernel is a chain of latencies: four
+            // workgroups per CU, nothing else to run meanwhile): the NN result first, un-branched, then the skinning inputs
+            float dq = 0.f, vwx = 0.f, vwy = 0.f, vwz = 0.f;
+            int jq = -1;
+            float4 pq = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (CONTACT) {
+                dq = cg.dist[qi];
+                jq = cg.idx[qi];
+                if (cg.nnpt) pq = cg.nnpt[qi];                                   // kernel-uniform
+                vwx = cg.Vw[3 * qi]; vwy = cg.Vw[3 * qi + 1]; vwz = cg.Vw[3 * qi + 2];
+            }
+            SkinFwd f = skin_forward_vertex(sm, c, x + X_BETAS, Voff + 3 * qi, sAf, transl, M + (size_t)r * 12, s);
             V3 g;
             if (CONTACT) {
                 float dterm;
-                cterm += contact_term(cg.dist[qi], &dterm);
-                const int j = cg.idx[qi];
-                const float gg = j >= 0 ? 2.f * cg.coef * dterm : 0.f;           // no neighbour (NaN query): zero gradient
-                const float4 p = j < 0 ? make_float4(0.f, 0.f, 0.f, 0.f) : (cg.nnpt ? cg.nnpt[qi] : cg.scene[j]);
-                g = v3(gg * (cg.Vw[3 * qi] - p.x), gg * (cg.Vw[3 * qi + 1] - p.y), gg * (cg.Vw[3 * qi + 2] - p.z));
+                cterm += contact_term(dq, &dterm);
+                const float gg = jq >= 0 ? 2.f * cg.coef * dterm : 0.f;          // no neighbour (NaN query): zero gradient
+                if (!cg.nnpt && jq >= 0) pq = cg.scene[jq];
+                if (jq < 0) pq = make_float4(0.f, 0.f, 0.f, 0.f);
+                g = v3(gg * (vwx - pq.x), gg * (vwy - pq.y), gg * (vwz - pq.z));
             } else {
                 g = v3(dVw[3 * qi], dVw[3 * qi + 1], dVw[3 * qi + 2]);
             }
-            SkinFwd f = skin_forward_vertex(sm, c, x + X_BETAS, Voff + 3 * qi, sAf, transl, M + (size_t)r * 12, s);
             SkinBwd b = skin_backward_vertex(f, M + (size_t)r * 12, s, g);
             dVoff[3 * qi] = b.dvp.x; dVoff[3 * qi + 1] = b.dvp.y; dVoff[3 * qi + 2] = b.dvp.z;
             if (sm.S)                                       // else: d betas = dVoff x shapedirs, columns 486.. of the blend data-gradient GEMM
