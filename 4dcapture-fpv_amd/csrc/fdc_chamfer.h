@@ -533,13 +533,22 @@ __global__ __launch_bounds__(256, NQ == 1 ? FDC_ST4_OCC : FDC_ST4_OCC2) void nn_
 #pragma unroll
     for (int n = 0; n < NQ; ++n)
         if (qidx[n] < nq) {
-            const float r = sqrtf(sb[n]) * 1.00001f + 1e-6f;
+            const float r = __builtin_amdgcn_sqrtf(sb[n]) * 1.00001f + 1e-6f;   // 1-ulp v_sqrt_f32 inside the 1e-5 slack
             finite &= r < INFINITY;
             glx = fminf(glx, qx[n] - r); gly = fminf(gly, qy[n] - r); glz = fminf(glz, qz[n] - r);
             ghx = fmaxf(ghx, qx[n] + r); ghy = fmaxf(ghy, qy[n] + r); ghz = fmaxf(ghz, qz[n] + r);
         }
-    glx = wave_min64(glx); gly = wave_min64(gly); glz = wave_min64(glz);       // DPP reductions (fdc_math.h), no LDS traffic
-    ghx = wave_max64(ghx); ghy = wave_max64(ghy); ghz = wave_max64(ghz);
+    // DPP reductions (fdc_math.h), no LDS traffic; lanes 32-63 repeat lanes 0-31 here, so two of the four row results suffice
+    auto min_rows01 = [](float v) {
+        v = fminf(v, dpp_move<0xB1>(v)); v = fminf(v, dpp_move<0x4E>(v)); v = fminf(v, dpp_move<0x141>(v)); v = fminf(v, dpp_move<0x140>(v));
+        return fminf(__int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 0)), __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 16)));
+    };
+    auto max_rows01 = [](float v) {
+        v = fmaxf(v, dpp_move<0xB1>(v)); v = fmaxf(v, dpp_move<0x4E>(v)); v = fmaxf(v, dpp_move<0x141>(v)); v = fmaxf(v, dpp_move<0x140>(v));
+        return fmaxf(__int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 0)), __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 16)));
+    };
+    glx = min_rows01(glx); gly = min_rows01(gly); glz = min_rows01(glz);
+    ghx = max_rows01(ghx); ghy = max_rows01(ghy); ghz = max_rows01(ghz);
     const bool cull = __all(all_seeded && finite);
     // box-box overlap (closed): false only if the boxes are strictly apart along some axis
     // (bitwise |: with short-circuit || the compiler sinks the component loads into a chain of dependent branches)
