@@ -452,8 +452,15 @@ __global__ __launch_bounds__(256) void nn_mfma_kernel(const float* __restrict__ 
 // repeated by each of them: the host picks WPG by launch size.
 // blockIdx -> query group is XCD-aware: each XCD serves a contiguous range of groups (frames that follow
 // each other touch the same scene chunks, so an XCD's L2 holds 1/8 of the clip's neighbourhoods).
-constexpr int ST4_MAXLIST = 768;       // quarter chunks one wave can list out of its share of the chunks
-constexpr int ST4_MAXCELL = 256;       // chunks one wave can list before their quarters are tested
+#ifndef FDC_ST4_MAXLIST
+#define FDC_ST4_MAXLIST 768
+#endif
+#ifndef FDC_ST4_MAXCELL
+#define FDC_ST4_MAXCELL 256
+#endif
+constexpr int ST4_MAXLIST = FDC_ST4_MAXLIST;   // quarter chunks one wave can list out of its share of the chunks
+constexpr int ST4_MAXCELL = FDC_ST4_MAXCELL;   // chunks one wave can list before their quarters are tested
+// (tiny values, e.g. -DFDC_ST4_MAXCELL=4 -DFDC_ST4_MAXLIST=8, force the overflow fall-back everywhere: the GPU suite passes with them)
 // Ring depth vs occupancy (measured at 512 k queries, NQ = 1, one wave per group): 8 fragments / 4 waves per SIMD
 // (128 VGPR) 0.148 ms, 4 / 5 (92 VGPR) 0.139, 2 / 6 (80 VGPR) 0.136: the launch is latency-bound on its set-up
 // chain, so resident waves hide more than a deeper ring does.

@@ -357,6 +357,46 @@ def test_seeding_the_nn_bound_does_not_change_results():
     assert not torch.equal(res["11"][1][1], res["11"][2][1])     # the stale seeds really were stale
 
 
+def test_far_stale_seeds_overflow_the_work_list_and_stay_exact():
+    """A seed is only an upper bound: after the bodies jump by metres every query's ball covers most of a 160k-point scene
+    (313 k-d cells), more than a wave can list (ST4_MAXCELL = 256 chunks / ST4_MAXLIST = 768 quarter chunks), and the
+    streaming kernel has to fall back to scanning its whole share -- the result must still be the plain scan's, bit for bit."""
+    n = 48
+    res = {}
+    for flag, cull in (("0", "0"), ("1", "1")):
+        os.environ["FDCAP_NN_SEED"] = flag
+        os.environ["FDCAP_NN_CULL"] = cull
+        try:
+            fop, bm, vp, clip, scene, vid = _make_fop(n, 300, 160_000, 40, 8, seed=90)
+            x78 = torch.empty(n, 78, device="cuda")
+            capi.check(fop.ctx.lib.fdcap_params_75_to_78(capi.dptr(torch.tensor(clip.body_params).cuda()), n, capi.dptr(x78),
+                                                         capi.current_stream()), "75->78")
+            fop.init(x78)
+
+            def contact():
+                d = torch.empty(n, len(fop.vid), device="cuda")
+                i = torch.empty(n, len(fop.vid), device="cuda", dtype=torch.int32)
+                capi.check(fop.ctx.lib.fdcap_opt_forward_world(fop.ctx.handle, capi.dptr(torch.empty(n, len(fop.vid), 3, device="cuda")),
+                                                               None, capi.current_stream()), "fw")
+                capi.check(fop.ctx.lib.fdcap_opt_get_contact(fop.ctx.handle, capi.dptr(d), capi.dptr(i), capi.current_stream()), "gc")
+                torch.cuda.synchronize()
+                return d.clone(), i.clone()
+
+            a = contact()
+            fop._rows_x[2:2 + n, 0:3] += torch.tensor([4.0, -3.0, 2.5], device="cuda")        # metres away from the seeds
+            b = contact()
+            fop._rows_x[2:2 + n, 0:3] -= torch.tensor([4.0, -3.0, 2.5], device="cuda")        # and back: seeds from far away again
+            c = contact()
+            res[flag + cull] = (a, b, c)
+            fop.close()
+        finally:
+            os.environ.pop("FDCAP_NN_SEED")
+            os.environ.pop("FDCAP_NN_CULL")
+    for k in range(3):
+        assert torch.equal(res["00"][k][0], res["11"][k][0]) and torch.equal(res["00"][k][1], res["11"][k][1]), k
+    assert torch.equal(res["11"][0][0], res["11"][2][0])
+
+
 @pytest.mark.parametrize("ns", [40, 600, 5000])
 def test_in_loop_nn_state_survives_the_timing_api_and_small_scenes(ns):
     """The seeded launch keeps each neighbour's coordinates next to its index; a brute-force timing launch rewrites the
