@@ -442,11 +442,16 @@ __global__ __launch_bounds__(256) void nn_mfma_kernel(const float* __restrict__ 
 // LDS -> barrier latency, not by the matrix pipe.  Here a group of 32*NQ queries (spatially compact: the contact
 // slots are Morton-ordered) is served by WPG = 1, 2 or 4 waves of a workgroup.  Each wave builds its own survivor
 // list over the cells dealt to it round-robin (cell c belongs to wave c % WPG: neighbouring cells -- which tend to
-// survive together -- spread evenly), re-centres the queries on each surviving cell's centre and streams that cell's
-// PRECOMPUTED A fragments (NNTarget::frags, static per scene) from global memory straight into registers through a
-// short ring (ST4_PF ahead, running across cell boundaries).  No LDS staging, no barrier in the main loop, no partial
-// minima / combine pass; the exact path is a compact bit-mask loop so the 16-tile body unrolls; the waves of a group
-// meet in LDS once at the end, merged by the same (d, index) order => bit-identical results to every other kernel here.
+// survive together -- spread evenly) in three stages: boxes of 16-cell k-d subtrees and then cell boxes against the box
+// around the queries' balls (lane-parallel), the near cells against every query (two per round, one per half-wave, boxes
+// through LDS), and the QUARTERS of the surviving cells (128 points = four MFMA tiles = one k-d node, NNTarget::qbounds)
+// against every query again.  The work list holds quarter ids; the wave re-centres the queries on a cell's centre when
+// the cell changes and streams each listed quarter's PRECOMPUTED A fragments (NNTarget::frags, static per scene) from
+// global memory straight into registers through a short ring (ST4_PF ahead, running across work items; ids in SGPRs, so
+// the loads take a scalar base).  No LDS staging of points, no barrier in the main loop, no partial minima / combine pass;
+// a filter hit that is only a query meeting its own seed is recognised from wave ballots, the rare real candidates take a
+// compact bit-mask loop; the waves of a group meet in LDS once at the end, merged by the same (d, index) order =>
+// bit-identical results to every other kernel here.
 // eps per cell: |y'| <= cell radius rc, so eps = K1 * X * rc + K2 * (X^2 + rc^2), X = |x - centre|.
 // More waves per group = shorter serial chains and a fuller machine at shard sizes, but the group's set-up is
 // repeated by each of them: the host picks WPG by launch size.
