@@ -562,10 +562,22 @@ __global__ __launch_bounds__(256, NQ == 1 ? FDC_ST4_OCC : FDC_ST4_OCC2) void nn_
     glx = min_rows01(glx); gly = min_rows01(gly); glz = min_rows01(glz);
     ghx = max_rows01(ghx); ghy = max_rows01(ghy); ghz = max_rows01(ghz);
     const bool cull = __all(all_seeded && finite);
+    // ... and the sphere around the box centre that contains every ball (radius max_i |x_i - c| + r_i): for a far group the
+    // ball box's corners reach much further than any ball does, the sphere cuts them off; a cell has to touch both.
+    const float scx = 0.5f * (glx + ghx), scy = 0.5f * (gly + ghy), scz = 0.5f * (glz + ghz);
+    float sR = 0.f;
+#pragma unroll
+    for (int n = 0; n < NQ; ++n)
+        if (qidx[n] < nq) {
+            const float ex = qx[n] - scx, ey = qy[n] - scy, ez = qz[n] - scz;
+            sR = fmaxf(sR, (__builtin_amdgcn_sqrtf(ex * ex + ey * ey + ez * ez) + __builtin_amdgcn_sqrtf(sb[n])) * 1.00001f + 1e-6f);
+        }
+    sR = max_rows01(sR);
+    const float sR2 = sR * sR * 1.00001f;
     // box-box overlap (closed): false only if the boxes are strictly apart along some axis
     // (bitwise |: with short-circuit || the compiler sinks the component loads into a chain of dependent branches)
     auto overlaps = [&](float4 lo, float4 hi) -> bool {
-        return !((lo.x > ghx) | (hi.x < glx) | (lo.y > ghy) | (hi.y < gly) | (lo.z > ghz) | (hi.z < glz));
+        return !((lo.x > ghx) | (hi.x < glx) | (lo.y > ghy) | (hi.y < gly) | (lo.z > ghz) | (hi.z < glz)) & (box_d2(lo, hi, scx, scy, scz) <= sR2);
     };
 
     // Survivor list of this wave, two levels: the boxes of 16-chunk super-cells (k-d subtrees) are tested against
