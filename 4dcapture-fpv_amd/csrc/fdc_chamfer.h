@@ -971,7 +971,9 @@ static inline hipError_t nn_search(const float* q, int nq, const NNTarget& T, fl
     // 0.049 / 0.047, 41: 0.153 / 0.086 / 0.047 / 0.036
     static int use_stream = -1;
     if (use_stream < 0) { const char* e = getenv("FDCAP_NN_STREAM"); use_stream = e ? atoi(e) : -2; }
-    if (culled && T.frags != nullptr && use_stream && nn_use_mfma(nq, T.n) && seedpt != nullptr && seed == idx) {
+    // (the streaming kernel's work list holds 16-bit ids 4 k + quarter: scenes up to 16384 chunks = 8.4 M points; beyond, the staged kernel)
+    if (culled && T.frags != nullptr && use_stream && nn_use_mfma(nq, T.n) && seedpt != nullptr && seed == idx &&
+        (T.n + MF_CH - 1) / MF_CH <= 16384) {
         if (seed_missing)                                     // first launch of a fit: cheap seeds (+ their coordinates) instead of a full scan
             hipLaunchKernelGGL(nn_seed_kernel, dim3((nq + 255) / 256), dim3(256), 0, st, q, nq, T, idx, seedpt);
         // seed aliases idx: every workgroup reads its seeds before it writes its own results, and no other workgroup touches them
