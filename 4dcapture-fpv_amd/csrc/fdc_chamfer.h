@@ -983,7 +983,7 @@ static inline hipError_t nn_search(const float* q, int nq, const NNTarget& T, fl
             int nqv = 1, wpg;
             if (use_stream < 0) {                             // enough waves to fill 1024 SIMDs x 4 twice over, no more (the
                 const int g32 = (nq + 31) / 32;               // per-group setup is repeated by every wave of the group)
-                wpg = g32 >= 12288 ? 1 : g32 >= 6144 ? 2 : 4;
+                wpg = g32 >= 3072 ? 1 : 4;                    // re-measured with quarter work items: 128 / 256 / 512 / 768 frames: 11: 0.036 / 0.033 / 0.057 / 0.068 ms, 21: 0.028 / 0.034 / 0.059 / 0.074, 41: 0.024 / 0.036 / 0.063 / 0.084
             } else {
                 nqv = (use_stream % 10 == 2) ? 2 : 1;
                 wpg = (use_stream / 10 == 4) ? 4 : (use_stream / 10 == 2) ? 2 : 1;
