@@ -89,6 +89,8 @@ SYMBOLS = {
     "fdcap_opt_forward_world": (c_int32, [c_void_p, c_void_p, c_void_p, c_void_p]),
     "fdcap_opt_get_contact": (c_int32, [c_void_p, c_void_p, c_void_p, c_void_p]),
     "fdcap_opt_get_grads": (c_int32, [c_void_p, c_void_p, c_void_p, c_void_p]),
+    "fdcap_panel_gemm": (c_int32, [c_void_p, c_int32, c_int32, c_int32, c_void_p, c_int64, c_int64, c_int32, c_void_p, c_int32,
+                                   c_void_p]),
     "fdcap_time_blend_gemm": (c_int32, [c_void_p, c_int32, c_int32, POINTER(c_float), c_void_p]),
     "fdcap_opt_time_chamfer": (c_int32, [c_void_p, c_int32, c_int32, POINTER(c_float), c_void_p]),
 }

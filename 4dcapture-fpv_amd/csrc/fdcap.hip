@@ -17,6 +17,7 @@
 #include "fdc_host_setup.h"
 #include "fdc_loss.h"
 #include "fdc_math.h"
+#include "fdc_panel.h"
 #include "fdc_skin.h"
 
 using namespace fdc;
@@ -51,22 +52,42 @@ __device__ __forceinline__ PoseModel stage_topology(const PoseModel& pm, PoseTop
     return l;
 }
 
-// one 64-thread workgroup (one wavefront) per frame
-__global__ __launch_bounds__(64) void pose_fwd_kernel(PoseModel pm, const float* __restrict__ X, const float* __restrict__ O,
+// one 64-thread workgroup (one wavefront) per frame.
+// PARTS: the decoder output arrives as the four partial sums of vposer_fwd_fused_kernel (Opart, part_stride apart); they are
+// added here in the fixed order of vp_sum_parts, kept in LDS for this frame and written to O for the backward.
+template <bool PARTS>
+__global__ __launch_bounds__(64) void pose_fwd_kernel(PoseModel pm, const float* __restrict__ X, float* __restrict__ O,
                                                       const float* __restrict__ CAM, const float* __restrict__ scale,
                                                       int row0, float* Rm, float* PF, float* Jrest, float* G, float* A,
-                                                      float* M, float* Jw, const float* AA) {
+                                                      float* M, float* Jw, const float* AA, const float* __restrict__ Opart,
+                                                      size_t part_stride) {
     __shared__ PoseScratch sc;
     __shared__ PoseTopo topo;
-    const PoseModel pml = stage_topology(pm, topo);
+    __shared__ float s_O[ODIM + 2];
     int r = row0 + blockIdx.x;
+    if (PARTS) {
+        for (int e = threadIdx.x; e < ODIM; e += 64) {
+            const float v = vp_sum_parts(Opart, part_stride, (size_t)r * ODIM + e);
+            s_O[e] = v;
+            O[(size_t)r * ODIM + e] = v;
+        }
+    }
+    const PoseModel pml = stage_topology(pm, topo);               // (its barrier also publishes s_O)
     if (PF && threadIdx.x < NBETA) PF[(size_t)r * NPFX + NPF + threadIdx.x] = X[(size_t)r * XDIM + X_BETAS + threadIdx.x];
-    pose_forward(pml, X + (size_t)r * XDIM, O ? O + (size_t)r * ODIM : nullptr, CAM + (size_t)r * 16, *scale, sc,
-                 Rm ? Rm + (size_t)r * NJ * 9 : nullptr, PF ? PF + (size_t)r * NPFX : nullptr,
-                 Jrest ? Jrest + (size_t)r * NJ * 3 : nullptr, G ? G + (size_t)r * NJ * 12 : nullptr,
-                 A ? A + (size_t)r * NJ * 12 : nullptr, M ? M + (size_t)r * 12 : nullptr,
-                 Jw ? Jw + (size_t)r * NJW * 3 : nullptr, threadIdx.x, 64, SyncBlock(),
-                 AA ? AA + (size_t)r * 66 : nullptr);
+    if (PARTS) {
+        pose_forward(pml, X + (size_t)r * XDIM, s_O, CAM + (size_t)r * 16, *scale, sc,
+                     Rm ? Rm + (size_t)r * NJ * 9 : nullptr, PF ? PF + (size_t)r * NPFX : nullptr,
+                     Jrest ? Jrest + (size_t)r * NJ * 3 : nullptr, G ? G + (size_t)r * NJ * 12 : nullptr,
+                     A ? A + (size_t)r * NJ * 12 : nullptr, M ? M + (size_t)r * 12 : nullptr,
+                     Jw ? Jw + (size_t)r * NJW * 3 : nullptr, threadIdx.x, 64, SyncBlock(), nullptr);
+    } else {
+        pose_forward(pml, X + (size_t)r * XDIM, O ? O + (size_t)r * ODIM : nullptr, CAM + (size_t)r * 16, *scale, sc,
+                     Rm ? Rm + (size_t)r * NJ * 9 : nullptr, PF ? PF + (size_t)r * NPFX : nullptr,
+                     Jrest ? Jrest + (size_t)r * NJ * 3 : nullptr, G ? G + (size_t)r * NJ * 12 : nullptr,
+                     A ? A + (size_t)r * NJ * 12 : nullptr, M ? M + (size_t)r * 12 : nullptr,
+                     Jw ? Jw + (size_t)r * NJW * 3 : nullptr, threadIdx.x, 64, SyncBlock(),
+                     AA ? AA + (size_t)r * 66 : nullptr);
+    }
 }
 
 // optional fused prologue of pose_bwd_kernel (X0 == nullptr: off)
@@ -451,7 +472,8 @@ struct AdamTensor { float* p; float* m; float* v; const float* g; size_t n; Adam
 __global__ __launch_bounds__(256) void adam_step_kernel(AdamTensor x, AdamTensor cam, AdamTensor sc, int nb_x, int nb_cam,
                                                         const float* __restrict__ dscale_row, int row0, int reduce_n,
                                                         float* __restrict__ dscale, int scale_zero_grad,
-                                                        float* __restrict__ xch, int n_local, const float* __restrict__ cam_rows) {
+                                                        float* __restrict__ xch, int n_local, const float* __restrict__ cam_rows,
+                                                        const float* __restrict__ dzpart, size_t dz_stride) {
     const int b = blockIdx.x;
     if (b < nb_x + nb_cam) {
         const bool is_x = b < nb_x;
@@ -459,7 +481,12 @@ __global__ __launch_bounds__(256) void adam_step_kernel(AdamTensor x, AdamTensor
         const size_t i = (size_t)(is_x ? b : b - nb_x) * 256 + threadIdx.x;
         if (i >= t.n) return;
         float pp = t.p[i], mm = t.m[i], vv = t.v[i];
-        adam_update(pp, mm, vv, t.g[i], t.a);
+        float gg = t.g[i];
+        if (is_x && dzpart) {                          // latent columns: + the four partials of vposer_bwd_fused_kernel (row0 = first owned row)
+            const int lr = (int)(i / XDIM), col = (int)(i % XDIM) - X_LATENT;
+            if (col >= 0 && col < VP_Z) gg += vp_sum_dz(dzpart, dz_stride, (size_t)(row0 + lr) * VP_Z + col);
+        }
+        adam_update(pp, mm, vv, gg, t.a);
         t.p[i] = pp; t.m[i] = mm; t.v[i] = vv;
         if (xch) {
             const int w = is_x ? XDIM : 16, lr = (int)(i / w), e = (int)(i % w) + (is_x ? 0 : XDIM);
@@ -627,12 +654,17 @@ struct SkinSet {          // skinning constants for a vertex set (all V, or the 
     int ldp = 0;                                // row stride of posedirs: 3*nv rounded up to a multiple of 4 (16-byte rows)
     DevBuf<float> vt, ww, posedirs, csc_w;      // posedirs [496, ldp] = [posedirs ; shapedirs^T], zero padding
     DevBuf<int> wj, csc_start, csc_v;
+    // the blend matrix in MFMA fragment order (fdc_panel.h), built for vertex sets whose K = 3 nv image fits the LDS slabs:
+    // pn_fwd: B(k, n) = posedirs[k, n] (offsets = [pose feature | betas] x B), pn_bwd: B(k, n) = posedirs[n, k] (data gradient)
+    DevBuf<float> pn_fwd_f, pn_bwd_f;
+    PanelB pn_fwd, pn_bwd;
     SkinModel model() const {
         SkinModel m; m.vt = vt.p; m.S = nullptr; m.wj = wj.p; m.ww = ww.p; m.K = K;
         m.csc_start = csc_start.p; m.csc_v = csc_v.p; m.csc_w = csc_w.p;
         return m;
     }
-    void release() { vt.release(); ww.release(); posedirs.release(); wj.release(); csc_w.release(); csc_start.release(); csc_v.release(); }
+    void release() { vt.release(); ww.release(); posedirs.release(); wj.release(); csc_w.release(); csc_start.release(); csc_v.release();
+                     pn_fwd_f.release(); pn_bwd_f.release(); pn_fwd = PanelB(); pn_bwd = PanelB(); }
 };
 
 struct OptState {
@@ -644,7 +676,10 @@ struct OptState {
     struct Ext { float* p = nullptr; } X, CAM, scale, dscale;   // caller-owned, registered
     struct ExtD { double* p = nullptr; } losses;
     DevBuf<float> X0, mask, mX, vX, mCAM, vCAM, mS, vS;
-    DevBuf<float> H1, H2, O, dO, dH2, dH1;
+    DevBuf<float> H1, H2, O, dO;
+    DevBuf<float> Opart, dZpart;       // [4][R*126] partial decoder outputs, [4][R*32] partial latent gradients (fdc_panel.h)
+    bool dz_pending = false;           // the last backward left the latent gradient as partials: the next Adam launch (or
+                                       // fdcap_opt_get_grads) folds them into dX
     DevBuf<float> Rm, PF, Jrest, G, A, M, Jw;
     DevBuf<float> Voff, Vw, dist, pd, dVoff;
     DevBuf<int> idx, pi;
@@ -676,6 +711,8 @@ struct fdcap_ctx {
     DevBuf<int> parents, order, level_start, child_start, child_list;
     int nlevels = 0;
     DevBuf<float> W1, b1, W2, b2, W3, b3;
+    DevBuf<float> vp_pn[6];            // decoder weights in MFMA fragment order: forward w1 w2 w3, backward w3t w2t w1t
+    VPoserPanels vp;
     SkinSet full, contact;
     bool full_ready = false;
     DevBuf<float4> scene;          // original order {x,y,z,bits(i)}: gradient gather by index
@@ -700,6 +737,7 @@ struct fdcap_ctx {
     DevBuf<AdamScalars> ws_adam;
     std::vector<AdamScalars> ws_adam_h;
     DevBuf<float> ws_f[12];
+    DevBuf<float> ws_part;          // partial decoder outputs of the stand-alone operators
     DevBuf<int> ws_i[2];
     DevBuf<float4> ws_p;
     OptState* opt = nullptr;
@@ -714,6 +752,9 @@ struct fdcap_ctx {
 };
 
 namespace {
+
+// largest K = 3 nv for which the blend products run on the fragment-ordered panels (both copies: 2 x 496 x K floats)
+constexpr int PANEL_MAX_K = 6144;
 
 int build_skin_set(fdcap_ctx* c, const std::vector<int64_t>& ids, SkinSet* out) {
     const int V = c->V;
@@ -764,16 +805,69 @@ int build_skin_set(fdcap_ctx* c, const std::vector<int64_t>& ids, SkinSet* out) 
     HIP_TRY(out->ww.upload(ww.data(), ww.size()));
     HIP_TRY(out->wj.upload(wj.data(), wj.size()));
     HIP_TRY(out->posedirs.upload(pd.data(), pd.size()));
+    out->pn_fwd = PanelB(); out->pn_bwd = PanelB();
+    if (nv > 0 && 3 * nv <= PANEL_MAX_K) {
+        std::vector<float> pf;
+        int nt = 0, ns = 0;
+        panel_pack(pd.data(), ldp, 1, NPFX, 3 * nv, pf, &nt, &ns);
+        HIP_TRY(out->pn_fwd_f.upload(pf.data(), pf.size()));
+        out->pn_fwd.f = (const float4*)out->pn_fwd_f.p; out->pn_fwd.ntile = nt; out->pn_fwd.nss = ns;
+        panel_pack(pd.data(), 1, ldp, 3 * nv, NPFX, pf, &nt, &ns);
+        HIP_TRY(out->pn_bwd_f.upload(pf.data(), pf.size()));
+        out->pn_bwd.f = (const float4*)out->pn_bwd_f.p; out->pn_bwd.ntile = nt; out->pn_bwd.nss = ns;
+    }
     return 0;
 }
 
-// VPoser decoder forward for `rows` rows of X (latent read in place): H1, H2, O
-int vposer_forward(fdcap_ctx* c, const float* X, int ldx, int latent_off, int rows, float* H1, float* H2, float* O,
-                   hipStream_t st) {
-    HIP_TRY(gemm_f32(true, EPI_BIAS_LRELU, X + latent_off, ldx, c->W1.p, 32, H1, 512, rows, 512, 32, c->b1.p, 0, st));
-    HIP_TRY(gemm_f32(true, EPI_BIAS_LRELU, H1, 512, c->W2.p, 512, H2, 512, rows, 512, 512, c->b2.p, 0, st));
-    HIP_TRY(gemm_f32(true, EPI_BIAS, H2, 512, c->W3.p, 512, O, ODIM, rows, ODIM, 512, c->b3.p, 0, st));
-    return 0;
+// VPoser decoder forward for rows [row_lo, row_hi) of X (latent read in place at column latent_off): H1, H2 and the four
+// partial outputs Opart (fdc_panel.h); O != nullptr: also the summed output (one more small launch -- the optimiser's
+// pose_fwd_kernel<true> adds the partials itself instead)
+int vposer_forward(fdcap_ctx* c, const float* X, int ldx, int latent_off, int row_lo, int row_hi, float* H1, float* H2,
+                   float* Opart, size_t part_stride, float* O, hipStream_t st) {
+    const int rows = row_hi - row_lo;
+    if (rows <= 0) return 0;
+    hipLaunchKernelGGL(vposer_fwd_fused_kernel, dim3(4 * ((rows + 15) / 16)), dim3(512), 0, st, c->vp, X + latent_off, ldx, row_lo,
+                       row_hi, H1, H2, Opart, part_stride);
+    if (O) {
+        const size_t n = (size_t)rows * ODIM;
+        hipLaunchKernelGGL(vposer_sum_parts_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, Opart, part_stride,
+                           (size_t)row_lo * ODIM, n, O);
+    }
+    return (int)hipGetLastError();
+}
+
+// rows of the optimiser's buffers whose pose is needed: the owned frames plus `halo` frames on each side that has a neighbour
+void opt_row_range(const OptState* o, int halo, int* lo, int* hi) {
+    const fdcap_opt_config& cf = o->cfg;
+    *lo = cf.frame0 > 0 ? 2 - halo : 2;
+    *hi = cf.n_local + 2 + (cf.frame0 + cf.n_local < cf.n_total ? halo : 0);
+}
+
+// decoder + per-frame pose state (Rm, PF, Jrest, G, A, M, Jw) of rows [lo, hi): two launches
+int opt_pose_forward(fdcap_ctx* c, int lo, int hi, hipStream_t st) {
+    OptState* o = c->opt;
+    const size_t ps = (size_t)o->R * ODIM;
+    int e = vposer_forward(c, o->X.p, XDIM, X_LATENT, lo, hi, o->H1.p, o->H2.p, o->Opart.p, ps, nullptr, st);
+    if (e) return e;
+    hipLaunchKernelGGL(pose_fwd_kernel<true>, dim3(hi - lo), dim3(64), 0, st, c->pose_model(), o->X.p, o->O.p, o->CAM.p, o->scale.p, lo,
+                       o->Rm.p, o->PF.p, o->Jrest.p, o->G.p, o->A.p, o->M.p, o->Jw.p, (const float*)nullptr, (const float*)o->Opart.p, ps);
+    return (int)hipGetLastError();
+}
+
+// VPoser data-gradient dO -> d latent of the owned rows, left as four partials in dZpart (fold = true: added into dX here)
+int opt_vposer_backward(fdcap_ctx* c, bool fold, hipStream_t st) {
+    OptState* o = c->opt;
+    const int nl = o->cfg.n_local;
+    const size_t ps = (size_t)o->R * VP_Z;
+    hipLaunchKernelGGL(vposer_bwd_fused_kernel, dim3(4 * ((nl + 15) / 16)), dim3(512), 0, st, c->vp, o->dO.p, 2, 2 + nl, o->H1.p, o->H2.p,
+                       o->dZpart.p, ps);
+    if (fold) {
+        hipLaunchKernelGGL(vposer_fold_dz_kernel, dim3((nl * VP_Z + 255) / 256), dim3(256), 0, st, o->dZpart.p, ps, 2, nl, o->dX.p);
+        o->dz_pending = false;
+    } else {
+        o->dz_pending = true;
+    }
+    return (int)hipGetLastError();
 }
 
 }  // namespace
@@ -840,6 +934,23 @@ int fdcap_ctx_create(const fdcap_model_desc* md, fdcap_ctx** out) {
     UP(c->W2, md->vp_fc2_w, 512 * 512) UP(c->b2, md->vp_fc2_b, 512)
     UP(c->W3, md->vp_out_w, ODIM * 512) UP(c->b3, md->vp_out_b, ODIM)
 #undef UP
+    if (!err) {
+        // decoder weights in MFMA fragment order.  torch Linear weights are [out, in]: forward y = x W^T -> B(k, n) = W[n][k];
+        // data gradient dx = dy W -> B(k, n) = W[k][n]
+        struct { const float* w; long sk, sn; int K, N; PanelB* dst; } pk[6] = {
+            {md->vp_fc1_w, 1, VP_Z, VP_Z, VP_H, &c->vp.w1}, {md->vp_fc2_w, 1, VP_H, VP_H, VP_H, &c->vp.w2},
+            {md->vp_out_w, 1, VP_H, VP_H, ODIM, &c->vp.w3}, {md->vp_out_w, VP_H, 1, ODIM, VP_H, &c->vp.w3t},
+            {md->vp_fc2_w, VP_H, 1, VP_H, VP_H, &c->vp.w2t}, {md->vp_fc1_w, VP_Z, 1, VP_H, VP_Z, &c->vp.w1t}};
+        std::vector<float> pf;
+        for (int i = 0; i < 6 && !err; ++i) {
+            int nt = 0, ns = 0;
+            panel_pack(pk[i].w, pk[i].sk, pk[i].sn, pk[i].K, pk[i].N, pf, &nt, &ns);
+            hipError_t e_ = c->vp_pn[i].upload(pf.data(), pf.size());
+            if (e_ != hipSuccess) err = (int)e_;
+            pk[i].dst->f = (const float4*)c->vp_pn[i].p; pk[i].dst->ntile = nt; pk[i].dst->nss = ns;
+        }
+        c->vp.b1 = c->b1.p; c->vp.b2 = c->b2.p; c->vp.b3 = c->b3.p;
+    }
     if (err) { fdcap_ctx_destroy(c); return err; }
     *out = c;
     return FDCAP_OK;
@@ -852,8 +963,10 @@ void fdcap_ctx_destroy(fdcap_ctx* c) {
     c->Jt.release(); c->Jd.release(); c->hand_comp.release(); c->hand_mean.release();
     c->parents.release(); c->order.release(); c->level_start.release(); c->child_start.release(); c->child_list.release();
     c->W1.release(); c->b1.release(); c->W2.release(); c->b2.release(); c->W3.release(); c->b3.release();
+    for (auto& b : c->vp_pn) b.release();
     c->full.release(); c->contact.release(); c->contact_vid.release(); c->contact_perm.release(); c->scene.release(); c->scene_sorted.release(); c->scene_bounds.release(); c->scene_sbounds.release(); c->scene_qbounds.release(); c->scene_inv.release(); c->scene_frags.release(); c->scene_centers.release();
     for (auto& b : c->ws_f) b.release();
+    c->ws_part.release();
     for (auto& b : c->ws_i) b.release();
     c->ws_p.release();
     delete c;
@@ -1094,7 +1207,8 @@ int fdcap_vposer_decode(fdcap_ctx* c, const float* z, int32_t ldz, int32_t B, fl
     HIP_TRY(c->ws_f[2].ensure((size_t)B * 512));
     HIP_TRY(c->ws_f[3].ensure((size_t)B * 512));
     HIP_TRY(c->ws_f[4].ensure((size_t)B * ODIM));
-    int e = vposer_forward(c, z, ldz, 0, B, c->ws_f[2].p, c->ws_f[3].p, c->ws_f[4].p, st);
+    HIP_TRY(c->ws_part.ensure((size_t)4 * B * ODIM));
+    int e = vposer_forward(c, z, ldz, 0, 0, B, c->ws_f[2].p, c->ws_f[3].p, c->ws_part.p, (size_t)B * ODIM, c->ws_f[4].p, st);
     if (e) return e;
     int n = B * 21;
     hipLaunchKernelGGL(sixd_to_rot_kernel, dim3((n + 255) / 256), dim3(256), 0, st, c->ws_f[4].p, n, rot, aa);
@@ -1133,7 +1247,8 @@ static int body_forward_impl(fdcap_ctx* c, const float* params, int32_t B, const
     HIP_TRY(w[1].ensure((size_t)B * 12));
     float* X = w[5].p;
     hipLaunchKernelGGL(p75_to_78_kernel, dim3((B + 127) / 128), dim3(128), 0, st, params, B, X);
-    int e = vposer_forward(c, X, XDIM, X_LATENT, B, w[2].p, w[3].p, w[4].p, st);
+    HIP_TRY(c->ws_part.ensure((size_t)4 * B * ODIM));
+    int e = vposer_forward(c, X, XDIM, X_LATENT, 0, B, w[2].p, w[3].p, c->ws_part.p, (size_t)B * ODIM, w[4].p, st);
     if (e) return e;
     if (!world) {
         HIP_TRY(hipMemsetAsync(w[9].p, 0, (size_t)B * 16 * sizeof(float), st));
@@ -1141,8 +1256,9 @@ static int body_forward_impl(fdcap_ctx* c, const float* params, int32_t B, const
     }
     const float* CAM = world ? cam_ext : w[9].p;
     const float* S = world ? scale : w[10].p;
-    hipLaunchKernelGGL(pose_fwd_kernel, dim3(B), dim3(64), 0, st, c->pose_model(), X, w[4].p, CAM, S, 0,
-                       (float*)nullptr, w[6].p, (float*)nullptr, w[7].p, w[8].p, w[1].p, (float*)nullptr, (const float*)nullptr);
+    hipLaunchKernelGGL(pose_fwd_kernel<false>, dim3(B), dim3(64), 0, st, c->pose_model(), X, w[4].p, CAM, S, 0,
+                       (float*)nullptr, w[6].p, (float*)nullptr, w[7].p, w[8].p, w[1].p, (float*)nullptr, (const float*)nullptr,
+                       (const float*)nullptr, (size_t)0);
     if (joints) hipLaunchKernelGGL(joints_out_kernel, dim3((B * NJ + 255) / 256), dim3(256), 0, st, w[7].p, X, XDIM, B, joints);
     if (vertices) {
         HIP_TRY(w[11].ensure((size_t)B * 3 * V));
@@ -1184,8 +1300,9 @@ int fdcap_smplx_forward(fdcap_ctx* c, const float* go, const float* bp, const fl
     hipLaunchKernelGGL(assemble_rows_kernel, dim3((B + 127) / 128), dim3(128), 0, st, go, bp, betas, lh, rh, transl, B, X, w[4].p);
     HIP_TRY(hipMemsetAsync(w[9].p, 0, (size_t)B * 16 * sizeof(float), st));
     HIP_TRY(hipMemsetAsync(w[10].p, 0, sizeof(float), st));
-    hipLaunchKernelGGL(pose_fwd_kernel, dim3(B), dim3(64), 0, st, c->pose_model(), X, (const float*)nullptr, w[9].p, w[10].p, 0,
-                       (float*)nullptr, w[6].p, (float*)nullptr, w[7].p, w[8].p, (float*)nullptr, (float*)nullptr, w[4].p);
+    hipLaunchKernelGGL(pose_fwd_kernel<false>, dim3(B), dim3(64), 0, st, c->pose_model(), X, (float*)nullptr, w[9].p, w[10].p, 0,
+                       (float*)nullptr, w[6].p, (float*)nullptr, w[7].p, w[8].p, (float*)nullptr, (float*)nullptr, (const float*)w[4].p,
+                       (const float*)nullptr, (size_t)0);
     if (joints) hipLaunchKernelGGL(joints_out_kernel, dim3((B * NJ + 255) / 256), dim3(256), 0, st, w[7].p, X, XDIM, B, joints);
     if (vertices) {
         HIP_TRY(w[11].ensure((size_t)B * 3 * V));
@@ -1201,7 +1318,7 @@ void fdcap_opt_destroy(fdcap_ctx* c) {
     if (!c || !c->opt) return;
     OptState* o = c->opt;
     DevBuf<float>* fb[] = {&o->X0, &o->mask, &o->mX, &o->vX, &o->mCAM, &o->vCAM, &o->mS, &o->vS,
-                           &o->H1, &o->H2, &o->O, &o->dO, &o->dH2, &o->dH1, &o->Rm, &o->PF, &o->Jrest, &o->G, &o->A, &o->M,
+                           &o->H1, &o->H2, &o->O, &o->dO, &o->Opart, &o->dZpart, &o->Rm, &o->PF, &o->Jrest, &o->G, &o->A, &o->M,
                            &o->Jw, &o->Voff, &o->Vw, &o->dist, &o->pd, &o->dVoff, &o->dA, &o->dtransl_v, &o->dMv,
                            &o->dsv, &o->dPF, &o->dJw, &o->dX, &o->dCAM, &o->dscale_row, &o->VoffF, &o->VwF, &o->dVF};
     for (auto* b : fb) b->release();
@@ -1221,6 +1338,7 @@ int fdcap_opt_create(fdcap_ctx* c, const fdcap_opt_config* cfg, float* rows_x, f
     c->opt = o;
     o->cfg = *cfg;
     o->cam_steps = 0;
+    o->dz_pending = false;
     o->seeded = false;
     o->dctT = o->dctC = o->dctW = 0;
     o->dct_grad = false;
@@ -1244,7 +1362,7 @@ int fdcap_opt_create(fdcap_ctx* c, const fdcap_opt_config* cfg, float* rows_x, f
     AL(o->mX, (size_t)R * XDIM) AL(o->vX, (size_t)R * XDIM) AL(o->mCAM, (size_t)R * 16) AL(o->vCAM, (size_t)R * 16)
     AL(o->mS, 1) AL(o->vS, 1)
     AL(o->H1, (size_t)R * 512) AL(o->H2, (size_t)R * 512) AL(o->O, (size_t)R * ODIM) AL(o->dO, (size_t)R * ODIM)
-    AL(o->dH2, (size_t)R * 512) AL(o->dH1, (size_t)R * 512)
+    AL(o->Opart, (size_t)4 * R * ODIM) AL(o->dZpart, (size_t)4 * R * VP_Z)
     AL(o->Rm, (size_t)R * NJ * 9) AL(o->PF, (size_t)R * NPFX) AL(o->Jrest, (size_t)R * NJ * 3) AL(o->G, (size_t)R * NJ * 12)
     AL(o->A, (size_t)R * NJ * 12) AL(o->M, (size_t)R * 12) AL(o->Jw, (size_t)R * NJW * 3)
     AL(o->dA, (size_t)R * NJ * 12) AL(o->dtransl_v, (size_t)R * 3) AL(o->dMv, (size_t)R * 12)
@@ -1285,8 +1403,11 @@ static int opt_contact_forward(fdcap_ctx* c, hipStream_t st) {
     OptState* o = c->opt;
     const int nl = o->cfg.n_local, nc = c->nc;
     const size_t off = (size_t)2 * nc * 3;
-    HIP_TRY(gemm_f32(false, EPI_STORE, o->PF.p + 2 * NPFX, NPFX, c->contact.posedirs.p, c->contact.ldp, o->Voff.p + off, 3 * nc, nl,
-                     3 * nc, NPFX, nullptr, 0, st));
+    if (c->contact.pn_fwd.f)
+        HIP_TRY(panel_gemm(o->PF.p + 2 * NPFX, NPFX, nl, NPFX, c->contact.pn_fwd, o->Voff.p + off, 3 * nc, 3 * nc, st));
+    else
+        HIP_TRY(gemm_f32(false, EPI_STORE, o->PF.p + 2 * NPFX, NPFX, c->contact.posedirs.p, c->contact.ldp, o->Voff.p + off, 3 * nc, nl,
+                         3 * nc, NPFX, nullptr, 0, st));
     hipLaunchKernelGGL(skin_fwd_kernel, dim3((nc + 255) / 256, nl), dim3(256), 0, st, c->contact.model(), nc, o->X.p, XDIM,
                        X_BETAS, X_TRANSL, o->Voff.p, o->A.p, o->M.p, o->scale.p, 2, 1, o->Vw.p);
     const int nq = nl * nc;
@@ -1310,10 +1431,10 @@ static int opt_backward_impl(fdcap_ctx* c, const LossWeights& lw, int32_t log_te
     PoseModel pm = c->pose_model();
     double* const losses = log_terms ? o->losses.p : nullptr;       // the partial sums are only formed on logging iterations
     if (losses) HIP_TRY(hipMemsetAsync(losses, 0, FDCAP_NUM_LOSSES * sizeof(double), st));
-    int e = vposer_forward(c, o->X.p, XDIM, X_LATENT, R, o->H1.p, o->H2.p, o->O.p, st);
+    int row_lo, row_hi;
+    opt_row_range(o, 1, &row_lo, &row_hi);
+    int e = opt_pose_forward(c, row_lo, row_hi, st);
     if (e) return e;
-    hipLaunchKernelGGL(pose_fwd_kernel, dim3(R), dim3(64), 0, st, pm, o->X.p, o->O.p, o->CAM.p, o->scale.p, 0, o->Rm.p,
-                       o->PF.p, o->Jrest.p, o->G.p, o->A.p, o->M.p, o->Jw.p, (const float*)nullptr);
     const bool contact_grad = o->contact_on && lw.contact != 0.f;
     const bool contact_fwd = o->contact_on && (contact_grad || log_terms);
     if (contact_fwd) { e = opt_contact_forward(c, st); if (e) return e; }
@@ -1342,8 +1463,11 @@ static int opt_backward_impl(fdcap_ctx* c, const LossWeights& lw, int32_t log_te
         hipLaunchKernelGGL(skin_bwd_kernel<true>, dim3(nl), dim3(256), (size_t)std::min(nc, 1024) * 12 * sizeof(float), st, c->contact.model(), nc, o->X.p, o->Voff.p, o->A.p,
                            o->M.p, o->scale.p, 2, (const float*)nullptr, o->dVoff.p, o->dA.p, (float*)nullptr, o->dtransl_v.p,
                            o->dMv.p, o->dsv.p, cg);
-        HIP_TRY(gemm_f32(true, EPI_STORE, o->dVoff.p + (size_t)2 * nc * 3, 3 * nc, c->contact.posedirs.p, c->contact.ldp,
-                         o->dPF.p + 2 * NPFX, NPFX, nl, NPFX, 3 * nc, nullptr, 0, st));
+        if (c->contact.pn_bwd.f)
+            HIP_TRY(panel_gemm(o->dVoff.p + (size_t)2 * nc * 3, 3 * nc, nl, 3 * nc, c->contact.pn_bwd, o->dPF.p + 2 * NPFX, NPFX, NPFX, st));
+        else
+            HIP_TRY(gemm_f32(true, EPI_STORE, o->dVoff.p + (size_t)2 * nc * 3, 3 * nc, c->contact.posedirs.p, c->contact.ldp,
+                             o->dPF.p + 2 * NPFX, NPFX, nl, NPFX, 3 * nc, nullptr, 0, st));
     } else if (contact_fwd && losses) {
         hipLaunchKernelGGL(contact_loss_kernel, dim3(256), dim3(256), 0, st, o->dist.p + 2 * nc, (size_t)nl * nc, losses + 3);
     }
@@ -1353,13 +1477,7 @@ static int opt_backward_impl(fdcap_ctx* c, const LossWeights& lw, int32_t log_te
                        joint_grad ? o->dJw.p : nullptr, contact_grad ? o->dMv.p : nullptr, contact_grad ? o->dsv.p : nullptr,
                        contact_grad ? o->dPF.p + NPF : nullptr, NPFX, contact_grad ? o->dtransl_v.p : nullptr, o->dX.p, o->dO.p,
                        o->dCAM.p, o->dscale_row.p, pli);
-    // VPoser data-gradient: dO -> dH2 -> dH1 -> d latent (accumulated into dX[:, 19:51])
-    HIP_TRY(gemm_f32(false, EPI_MASK_LRELU, o->dO.p + 2 * ODIM, ODIM, c->W3.p, 512, o->dH2.p + 2 * 512, 512, nl, 512, ODIM,
-                     o->H2.p + 2 * 512, 512, st));
-    HIP_TRY(gemm_f32(false, EPI_MASK_LRELU, o->dH2.p + 2 * 512, 512, c->W2.p, 512, o->dH1.p + 2 * 512, 512, nl, 512, 512,
-                     o->H1.p + 2 * 512, 512, st));
-    HIP_TRY(gemm_f32(false, EPI_ACCUM, o->dH1.p + 2 * 512, 512, c->W1.p, 32, o->dX.p + 2 * XDIM + X_LATENT, XDIM, nl, 32, 512,
-                     nullptr, 0, st));
+    { int eb = opt_vposer_backward(c, false, st); if (eb) return eb; }
     // d loss / d scale of this rank = sum of the per-frame partials: formed by the step kernels (fused with Adam /
     // the exchange packing); on logging iterations also here, so a caller can read dscale_d right after the backward
     if (log_terms) hipLaunchKernelGGL(reduce_rows_kernel, dim3(1), dim3(256), 0, st, o->dscale_row.p, 2, nl, o->dscale.p);
@@ -1411,10 +1529,10 @@ int fdcap_opt_dct_fit(fdcap_ctx* c, int32_t iters, int32_t step0, float weight, 
     const int w0 = (cf.frame0 + T - 1) / T;
     const int w1 = std::min((cf.frame0 + cf.n_local) / T, o->dctW);
     if (iters == 0 || w1 <= w0) return FDCAP_OK;
-    int e = vposer_forward(c, o->X.p, XDIM, X_LATENT, R, o->H1.p, o->H2.p, o->O.p, st);
+    int row_lo, row_hi;
+    opt_row_range(o, 1, &row_lo, &row_hi);
+    int e = opt_pose_forward(c, row_lo, row_hi, st);
     if (e) return e;
-    hipLaunchKernelGGL(pose_fwd_kernel, dim3(R), dim3(64), 0, st, c->pose_model(), o->X.p, o->O.p, o->CAM.p, o->scale.p, 0,
-                       o->Rm.p, o->PF.p, o->Jrest.p, o->G.p, o->A.p, o->M.p, o->Jw.p, (const float*)nullptr);
     o->adam_tab_h.resize(iters);
     for (int i = 0; i < iters; ++i) o->adam_tab_h[i] = adam_scalars(cf.lr, step0 + i + 1);
     HIP_TRY(o->adam_tab.ensure(iters));
@@ -1471,21 +1589,16 @@ int fdcap_opt_backward_fit2d(fdcap_ctx* c, const fdcap_fit2d_stage* sg, int32_t 
     PoseModel pm = c->pose_model();
     double* const losses = log_terms ? o->losses.p : nullptr;
     if (losses) HIP_TRY(hipMemsetAsync(losses, 0, FDCAP_NUM_LOSSES * sizeof(double), st));
-    int e = vposer_forward(c, o->X.p, XDIM, X_LATENT, R, o->H1.p, o->H2.p, o->O.p, st);
+    int row_lo, row_hi;
+    opt_row_range(o, 1, &row_lo, &row_hi);
+    int e = opt_pose_forward(c, row_lo, row_hi, st);
     if (e) return e;
-    hipLaunchKernelGGL(pose_fwd_kernel, dim3(R), dim3(64), 0, st, pm, o->X.p, o->O.p, o->CAM.p, o->scale.p, 0, o->Rm.p,
-                       o->PF.p, o->Jrest.p, o->G.p, o->A.p, o->M.p, o->Jw.p, (const float*)nullptr);
     hipLaunchKernelGGL(fit2d_loss_kernel, dim3(nl), dim3(128), 0, st, s, o->X.p, o->Jw.p, o->kp2d.p, 2, o->dX.p, o->dJw.p, losses);
     hipLaunchKernelGGL(pose_bwd_kernel, dim3(nl), dim3(64), 0, st, pm, o->X.p, o->O.p, o->CAM.p, o->scale.p, 2, o->Rm.p,
                        o->Jrest.p, o->G.p, (const float*)nullptr, (const float*)nullptr, o->dJw.p, (const float*)nullptr,
                        (const float*)nullptr, (const float*)nullptr, 0, (const float*)nullptr, o->dX.p, o->dO.p, o->dCAM.p,
                        o->dscale_row.p, ParamLossIn());
-    HIP_TRY(gemm_f32(false, EPI_MASK_LRELU, o->dO.p + 2 * ODIM, ODIM, c->W3.p, 512, o->dH2.p + 2 * 512, 512, nl, 512, ODIM,
-                     o->H2.p + 2 * 512, 512, st));
-    HIP_TRY(gemm_f32(false, EPI_MASK_LRELU, o->dH2.p + 2 * 512, 512, c->W2.p, 512, o->dH1.p + 2 * 512, 512, nl, 512, 512,
-                     o->H1.p + 2 * 512, 512, st));
-    HIP_TRY(gemm_f32(false, EPI_ACCUM, o->dH1.p + 2 * 512, 512, c->W1.p, 32, o->dX.p + 2 * XDIM + X_LATENT, XDIM, nl, 32, 512,
-                     nullptr, 0, st));
+    { int eb = opt_vposer_backward(c, true, st); if (eb) return eb; }
     return (int)hipGetLastError();
 }
 
@@ -1551,7 +1664,9 @@ static int opt_step_impl(fdcap_ctx* c, int32_t ii, int32_t P, bool do_rows, bool
     const bool tail = step_scale || reduce_scale;                    // the last block: (reduction +) scale (+ message tail)
     if (nb_x + nb_cam + (tail ? 1 : 0) == 0) return FDCAP_OK;
     hipLaunchKernelGGL(adam_step_kernel, dim3(nb_x + nb_cam + 1), dim3(256), 0, st, x, cam, sc, nb_x, nb_cam, o->dscale_row.p, 2,
-                       reduce_scale ? nl : 0, o->dscale.p, (step_scale && ii >= P) ? 1 : 0, xch, nl, o->CAM.p);
+                       reduce_scale ? nl : 0, o->dscale.p, (step_scale && ii >= P) ? 1 : 0, xch, nl, o->CAM.p,
+                       (do_rows && o->dz_pending) ? (const float*)o->dZpart.p : (const float*)nullptr, (size_t)o->R * VP_Z);
+    if (do_rows) o->dz_pending = false;
     return (int)hipGetLastError();
 }
 
@@ -1562,10 +1677,10 @@ int fdcap_opt_detect_contact(fdcap_ctx* c, int32_t n_left, float* weight_left, v
     if (!o->contact_on) return FDCAP_E_STATE;
     hipStream_t st = (hipStream_t)stream;
     const int R = o->R, nl = o->cfg.n_local, nc = c->nc;
-    int e = vposer_forward(c, o->X.p, XDIM, X_LATENT, R, o->H1.p, o->H2.p, o->O.p, st);
+    int row_lo, row_hi;
+    opt_row_range(o, 1, &row_lo, &row_hi);
+    int e = opt_pose_forward(c, row_lo, row_hi, st);
     if (e) return e;
-    hipLaunchKernelGGL(pose_fwd_kernel, dim3(R), dim3(64), 0, st, c->pose_model(), o->X.p, o->O.p, o->CAM.p, o->scale.p, 0,
-                       o->Rm.p, o->PF.p, o->Jrest.p, o->G.p, o->A.p, o->M.p, o->Jw.p, (const float*)nullptr);
     e = opt_contact_forward(c, st);
     if (e) return e;
     hipLaunchKernelGGL(detect_contact_kernel, dim3(nl), dim3(256), 0, st, o->dist.p, c->contact_perm.p, nc, n_left, 2, weight_left);
@@ -1591,10 +1706,10 @@ int fdcap_opt_backward_local2(fdcap_ctx* c, const float* contact_weight, int32_t
     HIP_TRY(o->dVF.ensure((size_t)R * nv3));
     PoseModel pm = c->pose_model();
     HIP_TRY(hipMemsetAsync(o->losses.p, 0, FDCAP_NUM_LOSSES * sizeof(double), st));
-    int e = vposer_forward(c, o->X.p, XDIM, X_LATENT, R, o->H1.p, o->H2.p, o->O.p, st);
+    int row_lo, row_hi;
+    opt_row_range(o, 2, &row_lo, &row_hi);
+    int e = opt_pose_forward(c, row_lo, row_hi, st);
     if (e) return e;
-    hipLaunchKernelGGL(pose_fwd_kernel, dim3(R), dim3(64), 0, st, pm, o->X.p, o->O.p, o->CAM.p, o->scale.p, 0, o->Rm.p,
-                       o->PF.p, o->Jrest.p, o->G.p, o->A.p, o->M.p, o->Jw.p, (const float*)nullptr);
     // full-mesh world vertices of every row (the vertex stencil needs 2 halo frames each side)
     HIP_TRY(gemm_f32(false, EPI_STORE, o->PF.p, NPFX, c->full.posedirs.p, c->full.ldp, o->VoffF.p, 3 * V, R, 3 * V, NPFX, nullptr, 0, st));
     hipLaunchKernelGGL(skin_fwd_kernel, dim3((V + 255) / 256, R), dim3(256), 0, st, c->full.model(), V, o->X.p, XDIM, X_BETAS,
@@ -1617,12 +1732,7 @@ int fdcap_opt_backward_local2(fdcap_ctx* c, const float* contact_weight, int32_t
     hipLaunchKernelGGL(pose_bwd_kernel, dim3(nl), dim3(64), 0, st, pm, o->X.p, o->O.p, o->CAM.p, o->scale.p, 2, o->Rm.p,
                        o->Jrest.p, o->G.p, o->dA.p, o->dPF.p, (const float*)nullptr, o->dMv.p, o->dsv.p, o->dPF.p + NPF, NPFX,
                        o->dtransl_v.p, o->dX.p, o->dO.p, o->dCAM.p, o->dscale_row.p, ParamLossIn());
-    HIP_TRY(gemm_f32(false, EPI_MASK_LRELU, o->dO.p + 2 * ODIM, ODIM, c->W3.p, 512, o->dH2.p + 2 * 512, 512, nl, 512, ODIM,
-                     o->H2.p + 2 * 512, 512, st));
-    HIP_TRY(gemm_f32(false, EPI_MASK_LRELU, o->dH2.p + 2 * 512, 512, c->W2.p, 512, o->dH1.p + 2 * 512, 512, nl, 512, 512,
-                     o->H1.p + 2 * 512, 512, st));
-    HIP_TRY(gemm_f32(false, EPI_ACCUM, o->dH1.p + 2 * 512, 512, c->W1.p, 32, o->dX.p + 2 * XDIM + X_LATENT, XDIM, nl, 32, 512,
-                     nullptr, 0, st));
+    { int eb = opt_vposer_backward(c, true, st); if (eb) return eb; }
     return (int)hipGetLastError();
 }
 
@@ -1651,10 +1761,10 @@ int fdcap_opt_forward_world(fdcap_ctx* c, float* verts, float* joints, void* str
     OptState* o = c->opt;
     hipStream_t st = (hipStream_t)stream;
     const int R = o->R, nl = o->cfg.n_local, nc = c->nc;
-    int e = vposer_forward(c, o->X.p, XDIM, X_LATENT, R, o->H1.p, o->H2.p, o->O.p, st);
+    int row_lo, row_hi;
+    opt_row_range(o, 1, &row_lo, &row_hi);
+    int e = opt_pose_forward(c, row_lo, row_hi, st);
     if (e) return e;
-    hipLaunchKernelGGL(pose_fwd_kernel, dim3(R), dim3(64), 0, st, c->pose_model(), o->X.p, o->O.p, o->CAM.p, o->scale.p, 0,
-                       o->Rm.p, o->PF.p, o->Jrest.p, o->G.p, o->A.p, o->M.p, o->Jw.p, (const float*)nullptr);
     if (verts) {
         if (!o->contact_on) return FDCAP_E_STATE;
         e = opt_contact_forward(c, st);
@@ -1709,9 +1819,29 @@ int fdcap_opt_get_grads(fdcap_ctx* c, float* dx, float* dcam, void* stream) {
     OptState* o = c->opt;
     hipStream_t st = (hipStream_t)stream;
     const int nl = o->cfg.n_local;
+    if (o->dz_pending) {                               // the latent gradient still sits in the four partials: fold it into dX once
+        hipLaunchKernelGGL(vposer_fold_dz_kernel, dim3((nl * VP_Z + 255) / 256), dim3(256), 0, st, o->dZpart.p, (size_t)o->R * VP_Z, 2, nl, o->dX.p);
+        o->dz_pending = false;
+    }
     if (dx) HIP_TRY(hipMemcpyAsync(dx, o->dX.p + 2 * XDIM, (size_t)nl * XDIM * sizeof(float), hipMemcpyDeviceToDevice, st));
     if (dcam) HIP_TRY(hipMemcpyAsync(dcam, o->dCAM.p + 2 * 16, (size_t)nl * 16 * sizeof(float), hipMemcpyDeviceToDevice, st));
     return FDCAP_OK;
+}
+
+int fdcap_panel_gemm(const float* A, int32_t lda, int32_t M, int32_t K, const float* B_h, int64_t sk, int64_t sn, int32_t N, float* C,
+                     int32_t ldc, void* stream) {
+    if (!A || !B_h || !C || M <= 0 || K <= 0 || N <= 0 || lda < K || ldc < N) return FDCAP_E_ARG;
+    hipStream_t st = (hipStream_t)stream;
+    std::vector<float> pf;
+    PanelB B;
+    panel_pack(B_h, (long)sk, (long)sn, K, N, pf, &B.ntile, &B.nss);
+    DevBuf<float> d;
+    HIP_TRY(d.upload(pf.data(), pf.size()));
+    B.f = (const float4*)d.p;
+    hipError_t e = panel_gemm(A, lda, M, K, B, C, ldc, N, st);
+    hipError_t e2 = hipStreamSynchronize(st);
+    d.release();
+    return (int)(e != hipSuccess ? e : e2);
 }
 
 int fdcap_time_blend_gemm(fdcap_ctx* c, int32_t rows, int32_t iters, float* ms, void* stream) {

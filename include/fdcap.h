@@ -278,6 +278,13 @@ int fdcap_opt_get_grads(fdcap_ctx* ctx, float* dx_d, float* dcam_d, void* stream
  * [486, 3V] on the fp32 matrix cores), HIP events on `stream`, mean milliseconds per launch. */
 int fdcap_time_blend_gemm(fdcap_ctx* ctx, int32_t rows, int32_t iters, float* ms, void* stream);
 
+/* The loop's dense contraction on its own (testing): C_d[M,N] (row-major, ldc) = A_d[M,K] (row-major, lda) x B,
+ * B a HOST array, element (k, n) at B_h[k * sk + n * sn] -- re-laid out in MFMA fragment order exactly as the
+ * context does for the VPoser weights and the blend directions, then run by the kernel the loop uses
+ * (v_mfma_f32_16x16x4_f32: every output is the k-ordered fp32 fmaf chain).  Synchronises `stream`. */
+int fdcap_panel_gemm(const float* A_d, int32_t lda, int32_t M, int32_t K, const float* B_h, int64_t sk, int64_t sn, int32_t N,
+                     float* C_d, int32_t ldc, void* stream);
+
 /* Kernel-level timing of the Chamfer NN launch for the roofline line: runs `iters` launches of
  * the optimiser's Chamfer forward on `stream` between two HIP events and returns the mean
  * milliseconds per launch in *ms.  brute_force = 1: every (query, scene point) pair is visited

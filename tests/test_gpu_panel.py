@@ -1,0 +1,97 @@
+"""GPU tests of the fragment-ordered ("panel") fp32 MFMA kernels of the loop (csrc/fdc_panel.h): the generic skinny-M product,
+the fused VPoser decoder forward and its fused data-gradient chain -- through the C-ABI, against fp64 numpy / the oracle."""
+import ctypes
+
+import numpy as np
+import pytest
+import torch
+
+import fdcap_amd  # noqa: F401
+from fdcap_amd import capi, ops, synth
+from fdcap_amd.fitting import find_outliers
+from oracle import rotrepr
+from oracle.fitting import FittingOracle
+from oracle.smplx import SMPLXOracle
+from oracle.vposer import VPoserDecoder
+from tests.test_gpu_parity import _make_fop
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("M,K,N,transposed,pad", [
+    (1, 1, 1, False, 0), (5, 3, 7, False, 2), (16, 16, 16, True, 0), (17, 33, 31, True, 3),
+    (33, 496, 1500, False, 0),          # the loop's pose/shape blend product (contact set)
+    (130, 1500, 496, True, 0),          # its data gradient (transposed operand), shard-sized M
+    (70, 2100, 40, False, 5),           # K beyond one LDS slab
+    (1028, 32, 512, True, 0), (257, 126, 512, False, 2),
+])
+def test_panel_gemm_matches_fp64(M, K, N, transposed, pad):
+    lib = capi.load_library()
+    rng = np.random.default_rng(M * 7919 + K * 31 + N)
+    A = rng.standard_normal((M, K + pad)).astype(np.float32)
+    Bm = rng.standard_normal((K, N)).astype(np.float32)                 # the mathematical operand
+    if transposed:
+        store, sk, sn = np.ascontiguousarray(Bm.T), 1, K                # stored [N, K]
+    else:
+        store, sk, sn = Bm, N, 1
+    Ad = torch.tensor(A).cuda()
+    Cd = torch.full((M, N + pad), -7.0, device="cuda")
+    capi.check(lib.fdcap_panel_gemm(capi.dptr(Ad), K + pad, M, K, store.ctypes.data_as(ctypes.c_void_p), sk, sn, N,
+                                    capi.dptr(Cd), N + pad, capi.current_stream()), "fdcap_panel_gemm")
+    C = Cd.cpu().numpy()
+    want = A[:, :K].astype(np.float64) @ Bm.astype(np.float64)
+    # k-ordered fp32 fmaf chain: the error random-walks at ~6e-8 of the partial sums' magnitude; bar = 1e-6 of sum |a||b|
+    tol = 1e-6 * (np.abs(A[:, :K]).astype(np.float64) @ np.abs(Bm).astype(np.float64)) + 1e-6
+    assert (np.abs(C[:, :N] - want) <= tol).all()
+    if pad:
+        assert (C[:, N:] == -7.0).all()                                  # nothing written past the N columns
+
+
+@pytest.mark.parametrize("B", [1, 15, 16, 17, 63, 1028])
+def test_fused_vposer_forward_ragged_rows(B):
+    vp = synth.make_vposer(seed=11)
+    bm = synth.make_body_model(300, seed=0)
+    ctx = capi.Context(bm, vp)
+    rng = np.random.default_rng(B)
+    z = rng.standard_normal((B, 32)).astype(np.float32)
+    want = VPoserDecoder.from_data(vp).decode(torch.tensor(z), output_type="matrot").numpy()
+    got = ops.VPoser(ctx).decode(torch.tensor(z).cuda(), "matrot").cpu().numpy()
+    np.testing.assert_allclose(got, want, atol=4e-5)
+    # rows are independent: the same latent decoded alone gives the same bits as inside a batch
+    if B > 1:
+        one = ops.VPoser(ctx).decode(torch.tensor(z[B // 2:B // 2 + 1]).cuda(), "matrot").cpu().numpy()
+        assert (one == got[B // 2:B // 2 + 1]).all()
+    ctx.close()
+
+
+@pytest.mark.parametrize("n", [37, 70])
+def test_fused_vposer_backward_in_the_optimiser_gradient(n):
+    """Phase-1 gradient of a clip that spans several 16-row blocks (ragged last block): the latent columns come out of
+    vposer_bwd_fused_kernel's four partial sums, folded by fdcap_opt_get_grads; compared with fp64 autograd."""
+    fop, bm, vp, clip, scene, vid = _make_fop(n, 300, 800, 20, 500)
+    dt = torch.float64
+    f = FittingOracle(SMPLXOracle(bm, dt), VPoserDecoder.from_data(vp, dt), scene, vid, clip.camerapose_lines, n, dtype=dt)
+    x78 = rotrepr.convert_to_6D_rot(torch.tensor(clip.body_params, dtype=dt)).detach()
+    f.init(x78)
+    g = torch.Generator().manual_seed(5)
+    pert = 0.01 * torch.randn(f.body_rotation_rec.shape, generator=g, dtype=dt)
+    f.body_rotation_rec.data += pert
+    idx1, _ = find_outliers(x78.numpy().astype(np.float32))
+    l_rec, l_vp, l_con, l_sm, l_ws = f.cal_loss(x78, idx1)
+    (0.1 * l_con + l_sm + l_rec).backward()
+    fop.init(torch.tensor(x78.numpy(), dtype=torch.float32).cuda())
+    fop._rows_x[2:2 + n] += pert.float().cuda()
+    lib, h = fop.ctx.lib, fop.ctx.handle
+    capi.check(lib.fdcap_opt_backward(h, 5, 10 ** 6, 0, capi.current_stream()), "backward")
+    dx = torch.empty(n, 78, device="cuda")
+    dx2 = torch.empty(n, 78, device="cuda")
+    capi.check(lib.fdcap_opt_get_grads(h, capi.dptr(dx), None, capi.current_stream()), "grads")
+    capi.check(lib.fdcap_opt_get_grads(h, capi.dptr(dx2), None, capi.current_stream()), "grads")   # folding happens once
+    torch.cuda.synchronize()
+    gx = f.body_rotation_rec.grad.numpy()
+    np.testing.assert_allclose(dx.cpu().numpy(), gx, rtol=2e-3, atol=2e-4 * np.abs(gx).max())
+    assert torch.equal(dx, dx2)
+    lat = gx[:, 19:51]
+    assert np.abs(lat).max() > 0                                          # the latent block is really exercised
+    np.testing.assert_allclose(dx.cpu().numpy()[:, 19:51], lat, rtol=2e-3, atol=2e-4 * np.abs(lat).max())
+    fop.close()
