@@ -85,83 +85,236 @@ __device__ __forceinline__ void panel_stage(float* __restrict__ sA, const float*
 
 // acc[t] += A[16 x 16 nss] * B_t for T tiles that share the A block.  sA: image at the first super-step; bf[t]: tile t's
 // fragments at the first super-step (without the lane offset).  PF fragments per tile in flight.
+//
+// The fragment ring: loads in the main loop are unconditional and pinned by a scheduling barrier right after their issue.
+// Loads under wave-uniform branches make hipcc wait vmcnt(0) in every super-step; unpinned, its scheduler sinks each load
+// to just before its use -- either way one exposed L2 round trip per 4 MFMAs (the blend product ran 27 us instead of ~12).
+// (Inline-asm loads with hand-counted s_waitcnt were tried and are wrong here: the ring is loop-carried, and the register
+// copies hipcc inserts for it read a destination before the wait.)  -DFDC_PN_PLAIN: no pins (A/B reference; same bits).
+// (-DFDC_PN_ABL=1 / 2 / 3: timing ablations -- no fragment loads / no MFMAs / no LDS reads; results are wrong)
+#ifndef FDC_PN_ABL
+#define FDC_PN_ABL 0
+#endif
+// (addresses are per-lane VGPR pairs: a scalar base would be written by SALU / v_readfirstlane right before the load reads
+// it -- a 5-wait-state hazard hipcc does not pad inside an asm statement; measured: wrong fragments)
+struct PnStream { const char* p; };                                   // this lane's byte address in a tile's fragment stream
+__device__ __forceinline__ PnStream pn_stream(const float4* tile_base, int lane) { return PnStream{(const char*)(tile_base + lane)}; }
+__device__ __forceinline__ f32x4_t pn_load_b(PnStream st, int step) {
+#if FDC_PN_ABL == 1
+    return f32x4_t{(float)step, 1.f, 2.f, (float)(size_t)st.p};
+#else
+    return *(const f32x4_t*)(st.p + (size_t)step * 1024);
+#endif
+}
+// nothing may be scheduled across this point: the fragment load issued before it stays PF super-steps ahead of its use
+__device__ __forceinline__ void pn_pin() {
+#ifndef FDC_PN_PLAIN
+    __builtin_amdgcn_sched_barrier(0);
+#endif
+}
+__device__ __forceinline__ float4 pn_load_a(const float* __restrict__ p) {
+#if FDC_PN_ABL == 3
+    return make_float4(__builtin_amdgcn_readfirstlane((int)(size_t)p) * 1.f, 1.f, 2.f, 3.f);
+#else
+    return *(const float4*)p;
+#endif
+}
+__device__ __forceinline__ f32x4_t pn_mfma(float a, float b, f32x4_t c) {
+#if FDC_PN_ABL == 2
+    c[0] += a * b; return c;
+#else
+    return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
+#endif
+}
+__device__ __forceinline__ f32x4_t pn_step(float4 a, f32x4_t b, f32x4_t acc) {
+    acc = pn_mfma(a.x, b[0], acc);
+    acc = pn_mfma(a.y, b[1], acc);
+    acc = pn_mfma(a.z, b[2], acc);
+    return pn_mfma(a.w, b[3], acc);
+}
+
+// Two register sets, each PF super-steps deep: set A is consumed while set B is being filled and vice versa, so no fragment
+// register is redefined while its previous value is live and the ring needs no copies at the loop's back edge (with one
+// set hipcc rotates the registers there and has to drain the queue once per turn).  The first set is loaded by
+// panel_prefetch -- issued BEFORE the barrier / staging that precedes the product, so the first L2 round trip is hidden.
 template <int T, int PF>
-__device__ __forceinline__ void panel_mma(const float* __restrict__ sA, const float4* const* bf, int nss, f32x4_t* acc, int lane) {
-    float4 b[T][PF];
+struct PnRing { f32x4_t bA[T][PF]; PnStream st[T]; };
+
+template <int T, int PF>
+__device__ __forceinline__ void panel_prefetch(PnRing<T, PF>& rg, const float4* const* bf, int nss, int lane) {
+    const int last = nss - 1;
+#pragma unroll
+    for (int t = 0; t < T; ++t) rg.st[t] = pn_stream(bf[t], lane);
 #pragma unroll
     for (int p = 0; p < PF; ++p)
 #pragma unroll
-        for (int t = 0; t < T; ++t) b[t][p] = (p < nss) ? bf[t][p * 64 + lane] : make_float4(0.f, 0.f, 0.f, 0.f);
-    for (int s0 = 0; s0 < nss; s0 += PF) {
+        for (int t = 0; t < T; ++t) rg.bA[t][p] = pn_load_b(rg.st[t], min(p, last));
+}
+
+template <int T, int PF>
+__device__ __forceinline__ void panel_mma(const float* __restrict__ sA, PnRing<T, PF>& rg, int nss, f32x4_t* acc, int lane) {
+    f32x4_t (&bA)[T][PF] = rg.bA;
+    f32x4_t bB[T][PF];
+    PnStream (&st)[T] = rg.st;
+    const int last = nss - 1;
+    float4 a = pn_load_a(sA + lane * 4);                             // the A fragment runs one super-step ahead of its MFMAs
+    int s = 0;
+    for (; s + 2 * PF <= nss; s += 2 * PF) {
 #pragma unroll
         for (int p = 0; p < PF; ++p) {
-            const int s = s0 + p;
-            if (s < nss) {                                           // wave-uniform
-                const float4 a = *(const float4*)(sA + (size_t)s * 256 + lane * 4);
+            const float4 a_next = pn_load_a(sA + (size_t)(s + p + 1) * 256 + lane * 4);
 #pragma unroll
-                for (int t = 0; t < T; ++t) {
-                    const float4 bb = b[t][p];
-                    if (s + PF < nss) b[t][p] = bf[t][(s + PF) * 64 + lane];
-                    acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.x, bb.x, acc[t], 0, 0, 0);
-                    acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.y, bb.y, acc[t], 0, 0, 0);
-                    acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.z, bb.z, acc[t], 0, 0, 0);
-                    acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.w, bb.w, acc[t], 0, 0, 0);
-                }
+            for (int t = 0; t < T; ++t) {
+                bB[t][p] = pn_load_b(st[t], s + PF + p);
+                pn_pin();
+                acc[t] = pn_step(a, bA[t][p], acc[t]);
             }
+            a = a_next;
+        }
+#pragma unroll
+        for (int p = 0; p < PF; ++p) {
+            const float4 a_next = pn_load_a(sA + (size_t)min(s + PF + p + 1, last) * 256 + lane * 4);
+#pragma unroll
+            for (int t = 0; t < T; ++t) {
+                bA[t][p] = pn_load_b(st[t], min(s + 2 * PF + p, last));
+                pn_pin();
+                acc[t] = pn_step(a, bB[t][p], acc[t]);
+            }
+            a = a_next;
+        }
+    }
+    // tail: fewer than 2 PF super-steps; set A holds the first PF of them
+#pragma unroll
+    for (int p = 0; p < PF; ++p) {
+        if (s + p < nss) {
+            const float4 a_next = pn_load_a(sA + (size_t)min(s + p + 1, last) * 256 + lane * 4);
+#pragma unroll
+            for (int t = 0; t < T; ++t) {
+                bB[t][p] = pn_load_b(st[t], min(s + PF + p, last));
+                acc[t] = pn_step(a, bA[t][p], acc[t]);
+            }
+            a = a_next;
+        }
+    }
+#pragma unroll
+    for (int p = 0; p < PF - 1; ++p) {
+        if (s + PF + p < nss) {
+            const float4 a_next = pn_load_a(sA + (size_t)min(s + PF + p + 1, last) * 256 + lane * 4);
+#pragma unroll
+            for (int t = 0; t < T; ++t) acc[t] = pn_step(a, bB[t][p], acc[t]);
+            a = a_next;
         }
     }
 }
 
 // RB row blocks of 16 share one B fragment stream (wide outputs: B traffic / RB).  sA: RB images, `img` floats apart.
 template <int RB, int PF>
-__device__ __forceinline__ void panel_mma_rows(const float* __restrict__ sA, int img, const float4* __restrict__ bf, int nss,
+__device__ __forceinline__ void panel_mma_rows(const float* __restrict__ sA, int img, PnRing<1, PF>& rg, int nss,
                                                f32x4_t* acc, int lane) {
-    float4 b[PF];
+    f32x4_t (&bA)[PF] = rg.bA[0];
+    f32x4_t bB[PF];
+    const PnStream st = rg.st[0];
+    const int last = nss - 1;
+    float4 a[RB];
 #pragma unroll
-    for (int p = 0; p < PF; ++p) b[p] = (p < nss) ? bf[p * 64 + lane] : make_float4(0.f, 0.f, 0.f, 0.f);
-    for (int s0 = 0; s0 < nss; s0 += PF) {
+    for (int rb = 0; rb < RB; ++rb) a[rb] = pn_load_a(sA + (size_t)rb * img + lane * 4);
+    auto step = [&](int cur, f32x4_t bb) {
+#pragma unroll
+        for (int rb = 0; rb < RB; ++rb) {
+            const float4 a_next = pn_load_a(sA + (size_t)rb * img + (size_t)min(cur + 1, last) * 256 + lane * 4);
+            acc[rb] = pn_step(a[rb], bb, acc[rb]);
+            a[rb] = a_next;
+        }
+    };
+    int s = 0;
+    for (; s + 2 * PF <= nss; s += 2 * PF) {
 #pragma unroll
         for (int p = 0; p < PF; ++p) {
-            const int s = s0 + p;
-            if (s < nss) {
-                const float4 bb = b[p];
-                if (s + PF < nss) b[p] = bf[(s + PF) * 64 + lane];
+            bB[p] = pn_load_b(st, s + PF + p);
+            pn_pin();
+            step(s + p, bA[p]);
+        }
 #pragma unroll
-                for (int rb = 0; rb < RB; ++rb) {
-                    const float4 a = *(const float4*)(sA + (size_t)rb * img + (size_t)s * 256 + lane * 4);
-                    acc[rb] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.x, bb.x, acc[rb], 0, 0, 0);
-                    acc[rb] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.y, bb.y, acc[rb], 0, 0, 0);
-                    acc[rb] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.z, bb.z, acc[rb], 0, 0, 0);
-                    acc[rb] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.w, bb.w, acc[rb], 0, 0, 0);
-                }
-            }
+        for (int p = 0; p < PF; ++p) {
+            bA[p] = pn_load_b(st, min(s + 2 * PF + p, last));
+            pn_pin();
+            step(s + PF + p, bB[p]);
         }
     }
+#pragma unroll
+    for (int p = 0; p < PF; ++p) {
+        if (s + p < nss) {
+            bB[p] = pn_load_b(st, min(s + PF + p, last));
+            step(s + p, bA[p]);
+        }
+    }
+#pragma unroll
+    for (int p = 0; p < PF - 1; ++p)
+        if (s + PF + p < nss) step(s + PF + p, bB[p]);
+}
+
+#ifdef FDC_PN_TIMING
+// instrumentation build only (never shipped): per-workgroup s_memtime stamps [block][8]
+__device__ unsigned long long g_pn_times[8192 * 8];
+#define PN_STAMP(i) do { if (threadIdx.x == 0 && blockIdx.x < 8192) g_pn_times[blockIdx.x * 8 + (i)] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define PN_STAMP(i)
+#endif
+
+// Workgroup -> (row block, column block), XCD-aware.  The dispatcher deals consecutive workgroups to the 8 XCDs round-robin
+// (b % 8), and each XCD has its own 4 MiB L2: with a plain 2-D grid every XCD pulls nearly all of A AND all of B through the
+// fabric in every launch (measured: 5.6 k cycles just to stage a 31 KB A block, fragment loads at Infinity-Cache latency).
+// Here XCD x owns the rectangle (row group x / xc, column group x % xc): its slice of the STATIC operand B stays resident in
+// its L2 from one optimiser iteration to the next, and A crosses the fabric xc times instead of 8.
+struct PnMap { int nrb, ncb, xc, rpg, cpg; };      // row / column blocks; column groups; blocks per group
+static inline PnMap panel_map(int nrb, int ncb, size_t a_bytes, size_t b_bytes) {
+    PnMap best{nrb, ncb, 1, (nrb + 7) / 8, ncb};
+    double best_cost = 1e300;
+    for (int xc = 1; xc <= 8; xc *= 2) {
+        const int xr = 8 / xc;
+        const int rpg = (nrb + xr - 1) / xr, cpg = (ncb + xc - 1) / xc;
+        // fabric bytes per launch: A once per column group; B once per row group unless an XCD's slice is small enough to
+        // stay in its L2 between launches; + a penalty for idle slots of ragged groups
+        double cost = (double)xc * a_bytes + ((b_bytes / xc <= (size_t)(3u << 19)) ? 0.0 : (double)xr * b_bytes);
+        cost *= (double)(8 * rpg * cpg) / (double)(nrb * ncb);
+        if (cost < best_cost) { best_cost = cost; best = PnMap{nrb, ncb, xc, rpg, cpg}; }
+    }
+    return best;
 }
 
 // C[M, N] = A[M, K] x B.  Workgroup = 8 waves = 16 RB rows x 128 columns (a 16-column tile per wave); K in slabs of `kslab`
-// columns (multiple of 16) so any K fits the LDS.  blockIdx.x = column block, blockIdx.y = row block.
+// columns (multiple of 16) so any K fits the LDS.  1-D grid of 8 * rpg * cpg workgroups (PnMap).
 // Dynamic LDS: RB * kslab * 16 floats.
 template <int RB>
 __global__ __launch_bounds__(512) void panel_gemm_kernel(const float* __restrict__ A, int lda, int M, int K, PanelB B, int kslab,
-                                                         float* __restrict__ C, int ldc, int N) {
+                                                         float* __restrict__ C, int ldc, int N, PnMap mp) {
     extern __shared__ __attribute__((aligned(16))) float pn_lds[];
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, j = lane & 15, g = lane >> 4;
-    const int tile = blockIdx.x * 8 + wave;
-    const int m0 = blockIdx.y * (16 * RB);
+    const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+    const int rbk = (xcd / mp.xc) * mp.rpg + slot / mp.cpg, cbk = (xcd % mp.xc) * mp.cpg + slot % mp.cpg;
+    if (slot / mp.cpg >= mp.rpg || rbk >= mp.nrb || cbk >= mp.ncb) return;          // ragged groups (whole workgroup)
+    const int tile = cbk * 8 + wave;
+    const int m0 = rbk * (16 * RB);
     const int img = kslab * 16;
+    PN_STAMP(0);
     f32x4_t acc[RB];
 #pragma unroll
     for (int rb = 0; rb < RB; ++rb) acc[rb] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+    const bool active = tile < B.ntile;
+    const float4* const tf = B.f + (size_t)(active ? tile : 0) * B.nss * 64;
     for (int k0 = 0; k0 < K; k0 += kslab) {
         const int kn = min(kslab, K - k0), kpad = (kn + 15) & ~15;
+        PnRing<1, 4> rg;
+        const float4* bfp = tf + (size_t)(k0 >> 4) * 64;
+        panel_prefetch<1, 4>(rg, &bfp, kpad >> 4, lane);            // in flight while the A block is staged
         if (k0) __syncthreads();
 #pragma unroll
         for (int rb = 0; rb < RB; ++rb) panel_stage<512>(pn_lds + (size_t)rb * img, A, lda, m0 + 16 * rb, M, k0, kn, kpad, tid);
         __syncthreads();
-        if (tile < B.ntile)
-            panel_mma_rows<RB, 4>(pn_lds, img, B.f + ((size_t)tile * B.nss + (k0 >> 4)) * 64, kpad >> 4, acc, lane);
+        PN_STAMP(1);
+        if (active) panel_mma_rows<RB, 4>(pn_lds, img, rg, kpad >> 4, acc, lane);
     }
+    PN_STAMP(2);
     const int n = tile * 16 + j;
     if (tile < B.ntile && n < N) {
 #pragma unroll
@@ -172,21 +325,27 @@ __global__ __launch_bounds__(512) void panel_gemm_kernel(const float* __restrict
                 if (m < M) C[(size_t)m * ldc + n] = acc[rb][r];
             }
     }
+    PN_STAMP(3);
 }
 
 static inline hipError_t panel_gemm(const float* A, int lda, int M, int K, const PanelB& B, float* C, int ldc, int N, hipStream_t st) {
     if (M <= 0 || N <= 0) return hipSuccess;
-    // one row block per workgroup while the operand re-reads stay inside an XCD's L2 (the loop's products: a 3 MB panel);
+    // one row block per workgroup while an XCD's slice of the operand stays inside its L2 (the loop's products: a 3 MB panel);
     // wide outputs (full-mesh blend, N = 31 425) take four row blocks per fragment stream
-    const bool wide = (size_t)B.ntile * B.nss * 1024 > (size_t)(24u << 20) && M >= 64;
+    const size_t b_bytes = (size_t)B.ntile * B.nss * 1024;
+    const bool wide = b_bytes > (size_t)(24u << 20) && M >= 64;
     const int kpad = (K + 15) & ~15;
-    const dim3 grid((B.ntile + 7) / 8, wide ? (M + 63) / 64 : (M + 15) / 16);
+    const int ncb = (B.ntile + 7) / 8;
     if (wide) {
         const int kslab = kpad <= 512 ? kpad : 512;                 // 4 x 32 KiB
-        hipLaunchKernelGGL(panel_gemm_kernel<4>, grid, dim3(512), (size_t)4 * kslab * 16 * sizeof(float), st, A, lda, M, K, B, kslab, C, ldc, N);
+        const PnMap mp = panel_map((M + 63) / 64, ncb, (size_t)M * K * 4, b_bytes);
+        hipLaunchKernelGGL(panel_gemm_kernel<4>, dim3(8 * mp.rpg * mp.cpg), dim3(512), (size_t)4 * kslab * 16 * sizeof(float), st, A, lda, M, K, B,
+                           kslab, C, ldc, N, mp);
     } else {
         const int kslab = kpad <= 1536 ? kpad : 1024;               // <= 96 KiB
-        hipLaunchKernelGGL(panel_gemm_kernel<1>, grid, dim3(512), (size_t)kslab * 16 * sizeof(float), st, A, lda, M, K, B, kslab, C, ldc, N);
+        const PnMap mp = panel_map((M + 15) / 16, ncb, (size_t)M * K * 4, b_bytes);
+        hipLaunchKernelGGL(panel_gemm_kernel<1>, dim3(8 * mp.rpg * mp.cpg), dim3(512), (size_t)kslab * 16 * sizeof(float), st, A, lda, M, K, B,
+                           kslab, C, ldc, N, mp);
     }
     return hipGetLastError();
 }
@@ -215,14 +374,23 @@ __global__ __launch_bounds__(512) void vposer_fwd_fused_kernel(VPoserPanels P, c
     float* const sH2 = sH1 + VP_H * 16;
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, j = lane & 15, g = lane >> 4;
     const int q = blockIdx.x & 3, r0 = row_lo + (int)(blockIdx.x >> 2) * 16;
-    panel_stage<512>(sZ, Z, ldx, r0, row_hi, 0, VP_Z, VP_Z, tid);
-    __syncthreads();
+    PN_STAMP(0);
+    PnRing<1, 4> rg2, rg3;                             // next layer's first fragments are requested before the barrier in front of it
     {   // layer 1, all 512 columns (four tiles per wave)
         f32x4_t acc[4];
         const float4* bf[4];
 #pragma unroll
         for (int t = 0; t < 4; ++t) { acc[t] = f32x4_t{0.f, 0.f, 0.f, 0.f}; bf[t] = P.w1.f + (size_t)(wave * 4 + t) * P.w1.nss * 64; }
-        panel_mma<4, 2>(sZ, bf, VP_Z / 16, acc, lane);
+        PnRing<4, 2> rg1;
+        panel_prefetch<4, 2>(rg1, bf, VP_Z / 16, lane);
+        panel_stage<512>(sZ, Z, ldx, r0, row_hi, 0, VP_Z, VP_Z, tid);
+        __syncthreads();
+        PN_STAMP(1);
+        panel_mma<4, 2>(sZ, rg1, VP_Z / 16, acc, lane);
+        {
+            const float4* bf2 = P.w2.f + (size_t)(q * 8 + wave) * P.w2.nss * 64;
+            panel_prefetch<1, 4>(rg2, &bf2, VP_H / 16, lane);
+        }
 #pragma unroll
         for (int t = 0; t < 4; ++t) {
             const int n = (wave * 4 + t) * 16 + j;
@@ -237,11 +405,15 @@ __global__ __launch_bounds__(512) void vposer_fwd_fused_kernel(VPoserPanels P, c
         }
     }
     __syncthreads();
+    PN_STAMP(2);
     {   // layer 2, this quarter's 128 columns (one tile per wave)
         f32x4_t acc = {0.f, 0.f, 0.f, 0.f};
         const int tile = q * 8 + wave;
-        const float4* bf = P.w2.f + (size_t)tile * P.w2.nss * 64;
-        panel_mma<1, 4>(sH1, &bf, VP_H / 16, &acc, lane);
+        panel_mma<1, 4>(sH1, rg2, VP_H / 16, &acc, lane);
+        {
+            const float4* bf3 = P.w3.f + ((size_t)wave * P.w3.nss + q * (VP_QW / 16)) * 64;
+            panel_prefetch<1, 4>(rg3, &bf3, VP_QW / 16, lane);
+        }
         const int n = tile * 16 + j;
         const float bias = P.b2[n];
 #pragma unroll
@@ -253,10 +425,10 @@ __global__ __launch_bounds__(512) void vposer_fwd_fused_kernel(VPoserPanels P, c
         }
     }
     __syncthreads();
+    PN_STAMP(3);
     {   // output layer: this quarter's K-slice of all 126 (128) columns
         f32x4_t acc = {0.f, 0.f, 0.f, 0.f};
-        const float4* bf = P.w3.f + ((size_t)wave * P.w3.nss + q * (VP_QW / 16)) * 64;
-        panel_mma<1, 4>(sH2, &bf, VP_QW / 16, &acc, lane);
+        panel_mma<1, 4>(sH2, rg3, VP_QW / 16, &acc, lane);
         const int n = wave * 16 + j;
         if (n < ODIM) {
             const float bias = q == 0 ? P.b3[n] : 0.f;
@@ -267,6 +439,7 @@ __global__ __launch_bounds__(512) void vposer_fwd_fused_kernel(VPoserPanels P, c
             }
         }
     }
+    PN_STAMP(4);
 }
 
 // O = ((p0 + p1) + (p2 + p3)) -- the one summation order every consumer of the partial outputs uses
@@ -289,13 +462,23 @@ __global__ __launch_bounds__(512) void vposer_bwd_fused_kernel(VPoserPanels P, c
     float* const sred = sdH1 + VP_H * 16;
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, j = lane & 15, g = lane >> 4;
     const int q = blockIdx.x & 3, r0 = row_lo + (int)(blockIdx.x >> 2) * 16;
-    panel_stage<512>(sdO, dO, ODIM, r0, row_hi, 0, ODIM, 128, tid);
-    __syncthreads();
+    PnRing<4, 4> rgB;
+    PnRing<1, 4> rgC;
     {   // dH2[:, quarter] = (dO x W3[:, quarter]) * mask(H2)
         f32x4_t acc = {0.f, 0.f, 0.f, 0.f};
         const int tile = q * 8 + wave;
         const float4* bf = P.w3t.f + (size_t)tile * P.w3t.nss * 64;
-        panel_mma<1, 4>(sdO, &bf, 8, &acc, lane);
+        PnRing<1, 4> rgA;
+        panel_prefetch<1, 4>(rgA, &bf, 8, lane);
+        panel_stage<512>(sdO, dO, ODIM, r0, row_hi, 0, ODIM, 128, tid);
+        __syncthreads();
+        panel_mma<1, 4>(sdO, rgA, 8, &acc, lane);
+        {
+            const float4* bfb[4];
+#pragma unroll
+            for (int t = 0; t < 4; ++t) bfb[t] = P.w2t.f + ((size_t)(wave + 8 * t) * P.w2t.nss + q * (VP_QW / 16)) * 64;
+            panel_prefetch<4, 4>(rgB, bfb, VP_QW / 16, lane);
+        }
         const int n = tile * 16 + j;
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
@@ -307,13 +490,13 @@ __global__ __launch_bounds__(512) void vposer_bwd_fused_kernel(VPoserPanels P, c
     __syncthreads();
     {   // partial dH1 = (dH2[:, quarter] x W2[quarter rows, :]) * mask(H1): tiles wave, wave + 8, wave + 16, wave + 24
         f32x4_t acc[4];
-        const float4* bf[4];
 #pragma unroll
-        for (int t = 0; t < 4; ++t) {
-            acc[t] = f32x4_t{0.f, 0.f, 0.f, 0.f};
-            bf[t] = P.w2t.f + ((size_t)(wave + 8 * t) * P.w2t.nss + q * (VP_QW / 16)) * 64;
+        for (int t = 0; t < 4; ++t) acc[t] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+        panel_mma<4, 4>(sdH2, rgB, VP_QW / 16, acc, lane);
+        {
+            const float4* bfc = P.w1t.f + ((size_t)(wave & 1) * P.w1t.nss + (wave >> 1) * 8) * 64;
+            panel_prefetch<1, 4>(rgC, &bfc, 8, lane);
         }
-        panel_mma<4, 4>(sdH2, bf, VP_QW / 16, acc, lane);
 #pragma unroll
         for (int t = 0; t < 4; ++t) {
             const int n = (wave + 8 * t) * 16 + j;
@@ -329,8 +512,7 @@ __global__ __launch_bounds__(512) void vposer_bwd_fused_kernel(VPoserPanels P, c
     {   // partial d latent = partial dH1 x W1: 2 column tiles x 4 K-slices over the 8 waves, slices summed in order
         f32x4_t acc = {0.f, 0.f, 0.f, 0.f};
         const int tile = wave & 1, ks = wave >> 1;
-        const float4* bf = P.w1t.f + ((size_t)tile * P.w1t.nss + ks * 8) * 64;
-        panel_mma<1, 4>(sdH1 + (size_t)ks * 8 * 256, &bf, 8, &acc, lane);
+        panel_mma<1, 4>(sdH1 + (size_t)ks * 8 * 256, rgC, 8, &acc, lane);
         *(float4*)(sred + (size_t)(ks * 2 + tile) * 256 + lane * 4) = make_float4(acc[0], acc[1], acc[2], acc[3]);
     }
     __syncthreads();

@@ -889,6 +889,20 @@ int fdcap_debug_nn_stats(unsigned long long* out) {
 }
 #endif
 
+#ifdef FDC_PN_TIMING
+int fdcap_debug_panel_reset(void) {
+    HIP_TRY(hipDeviceSynchronize());
+    static std::vector<unsigned long long> z(8192 * 8, 0ull);
+    HIP_TRY(hipMemcpyToSymbol(HIP_SYMBOL(g_pn_times), z.data(), z.size() * sizeof(unsigned long long)));
+    return 0;
+}
+int fdcap_debug_panel_times(unsigned long long* out, int n) {
+    HIP_TRY(hipDeviceSynchronize());
+    HIP_TRY(hipMemcpyFromSymbol(out, HIP_SYMBOL(g_pn_times), (size_t)n * sizeof(unsigned long long)));
+    return 0;
+}
+#endif
+
 int fdcap_set_nn_kernel(int32_t mode) {
     if (mode < 0 || mode > 2) return FDCAP_E_ARG;
     nn_mode_ref() = mode;

@@ -1,0 +1,7 @@
+#!/bin/bash
+# build an ablation / instrumentation variant of the library next to the product .so:  tools/build_variant.sh <suffix> <extra hipcc flags...>
+set -e
+cd "$(dirname "$0")/.."
+sfx=$1; shift
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -shared -mllvm -amdgpu-mfma-vgpr-form -fno-honor-nans "$@" \
+  -o 4dcapture-fpv_amd/libfdcap_hip_$sfx.so 4dcapture-fpv_amd/csrc/fdcap.hip
