@@ -126,12 +126,18 @@ __device__ __forceinline__ f32x4_t pn_mfma(float a, float b, f32x4_t c) {
     return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
 #endif
 }
+// The static fragment is the MFMA's A operand (its 16 rows = output columns n), the LDS block its B operand (its 16 columns =
+// frame rows), so a lane's four results are FOUR CONSECUTIVE OUTPUT COLUMNS of one frame: lane (j = lane & 15, g = lane >> 4),
+// register r  <->  out[frame j][16 tile + 4 g + r].  Epilogues are one 16-byte store per tile -- to global memory and into
+// the next layer's k-blocked LDS image alike (the other way round each lane holds four frames of one column: four
+// scattered 4-byte LDS writes with an 8-way bank conflict).
 __device__ __forceinline__ f32x4_t pn_step(float4 a, f32x4_t b, f32x4_t acc) {
-    acc = pn_mfma(a.x, b[0], acc);
-    acc = pn_mfma(a.y, b[1], acc);
-    acc = pn_mfma(a.z, b[2], acc);
-    return pn_mfma(a.w, b[3], acc);
+    acc = pn_mfma(b[0], a.x, acc);
+    acc = pn_mfma(b[1], a.y, acc);
+    acc = pn_mfma(b[2], a.z, acc);
+    return pn_mfma(b[3], a.w, acc);
 }
+__device__ __forceinline__ float4 pn_f4(f32x4_t v) { return make_float4(v[0], v[1], v[2], v[3]); }
 
 // Two register sets, each PF super-steps deep: set A is consumed while set B is being filled and vice versa, so no fragment
 // register is redefined while its previous value is live and the ring needs no copies at the loop's back edge (with one
@@ -315,15 +321,21 @@ __global__ __launch_bounds__(512) void panel_gemm_kernel(const float* __restrict
         if (active) panel_mma_rows<RB, 4>(pn_lds, img, rg, kpad >> 4, acc, lane);
     }
     PN_STAMP(2);
-    const int n = tile * 16 + j;
-    if (tile < B.ntile && n < N) {
+    const int n4 = tile * 16 + 4 * g;
+    if (active && n4 < N) {
+        const bool vec = ((ldc & 3) == 0) && ((((size_t)C) & 15) == 0) && n4 + 3 < N;
 #pragma unroll
-        for (int rb = 0; rb < RB; ++rb)
+        for (int rb = 0; rb < RB; ++rb) {
+            const int m = m0 + 16 * rb + j;
+            if (m < M) {
+                float* dst = C + (size_t)m * ldc + n4;
+                if (vec) *(float4*)dst = pn_f4(acc[rb]);
+                else {
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int m = m0 + 16 * rb + 4 * g + r;
-                if (m < M) C[(size_t)m * ldc + n] = acc[rb][r];
+                    for (int r = 0; r < 4; ++r) if (n4 + r < N) dst[r] = acc[rb][r];
+                }
             }
+        }
     }
     PN_STAMP(3);
 }
@@ -393,15 +405,12 @@ __global__ __launch_bounds__(512) void vposer_fwd_fused_kernel(VPoserPanels P, c
         }
 #pragma unroll
         for (int t = 0; t < 4; ++t) {
-            const int n = (wave * 4 + t) * 16 + j;
-            const float bias = P.b1[n];
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int i = 4 * g + r;
-                const float v = vp_lrelu(acc[t][r] + bias);
-                sH1[pn_lds_index(i, n)] = v;
-                if ((n / VP_QW) == q && r0 + i < row_hi) H1[(size_t)(r0 + i) * VP_H + n] = v;
-            }
+            const int n4 = (wave * 4 + t) * 16 + 4 * g;
+            const float4 bias = *(const float4*)(P.b1 + n4);
+            const float4 v = make_float4(vp_lrelu(acc[t][0] + bias.x), vp_lrelu(acc[t][1] + bias.y), vp_lrelu(acc[t][2] + bias.z),
+                                         vp_lrelu(acc[t][3] + bias.w));
+            *(float4*)(sH1 + (size_t)((n4 >> 2) * 16 + j) * 4) = v;
+            if ((n4 / VP_QW) == q && r0 + j < row_hi) *(float4*)(H1 + (size_t)(r0 + j) * VP_H + n4) = v;
         }
     }
     __syncthreads();
@@ -414,28 +423,25 @@ __global__ __launch_bounds__(512) void vposer_fwd_fused_kernel(VPoserPanels P, c
             const float4* bf3 = P.w3.f + ((size_t)wave * P.w3.nss + q * (VP_QW / 16)) * 64;
             panel_prefetch<1, 4>(rg3, &bf3, VP_QW / 16, lane);
         }
-        const int n = tile * 16 + j;
-        const float bias = P.b2[n];
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const int i = 4 * g + r;
-            const float v = vp_lrelu(acc[r] + bias);
-            sH2[pn_lds_index(i, n - q * VP_QW)] = v;
-            if (r0 + i < row_hi) H2[(size_t)(r0 + i) * VP_H + n] = v;
-        }
+        const int n4 = tile * 16 + 4 * g;
+        const float4 bias = *(const float4*)(P.b2 + n4);
+        const float4 v = make_float4(vp_lrelu(acc[0] + bias.x), vp_lrelu(acc[1] + bias.y), vp_lrelu(acc[2] + bias.z), vp_lrelu(acc[3] + bias.w));
+        *(float4*)(sH2 + (size_t)(((n4 - q * VP_QW) >> 2) * 16 + j) * 4) = v;
+        if (r0 + j < row_hi) *(float4*)(H2 + (size_t)(r0 + j) * VP_H + n4) = v;
     }
     __syncthreads();
     PN_STAMP(3);
     {   // output layer: this quarter's K-slice of all 126 (128) columns
         f32x4_t acc = {0.f, 0.f, 0.f, 0.f};
         panel_mma<1, 4>(sH2, rg3, VP_QW / 16, &acc, lane);
-        const int n = wave * 16 + j;
-        if (n < ODIM) {
-            const float bias = q == 0 ? P.b3[n] : 0.f;
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int row = r0 + 4 * g + r;
-                if (row < row_hi) Opart[(size_t)q * part_stride + (size_t)row * ODIM + n] = acc[r] + bias;
+        const int n4 = wave * 16 + 4 * g, row = r0 + j;              // ODIM = 126: rows are 8-byte aligned -> two float2 stores
+        if (row < row_hi) {
+            float* dst = Opart + (size_t)q * part_stride + (size_t)row * ODIM + n4;
+            const float b0 = q == 0 ? P.b3[n4] : 0.f, b1 = q == 0 ? P.b3[n4 + 1] : 0.f;
+            *(float2*)dst = make_float2(acc[0] + b0, acc[1] + b1);
+            if (n4 + 2 < ODIM) {
+                const float b2 = q == 0 ? P.b3[n4 + 2] : 0.f, b3 = q == 0 ? P.b3[n4 + 3] : 0.f;
+                *(float2*)(dst + 2) = make_float2(acc[2] + b2, acc[3] + b3);
             }
         }
     }
@@ -479,13 +485,11 @@ __global__ __launch_bounds__(512) void vposer_bwd_fused_kernel(VPoserPanels P, c
             for (int t = 0; t < 4; ++t) bfb[t] = P.w2t.f + ((size_t)(wave + 8 * t) * P.w2t.nss + q * (VP_QW / 16)) * 64;
             panel_prefetch<4, 4>(rgB, bfb, VP_QW / 16, lane);
         }
-        const int n = tile * 16 + j;
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const int i = 4 * g + r;
-            const float h = (r0 + i < row_hi) ? H2[(size_t)(r0 + i) * VP_H + n] : 0.f;
-            sdH2[pn_lds_index(i, n - q * VP_QW)] = acc[r] * (h > 0.f ? 1.f : 0.2f);
-        }
+        const int n4 = tile * 16 + 4 * g;
+        const float4 h = (r0 + j < row_hi) ? *(const float4*)(H2 + (size_t)(r0 + j) * VP_H + n4) : make_float4(0.f, 0.f, 0.f, 0.f);
+        *(float4*)(sdH2 + (size_t)(((n4 - q * VP_QW) >> 2) * 16 + j) * 4) =
+            make_float4(acc[0] * (h.x > 0.f ? 1.f : 0.2f), acc[1] * (h.y > 0.f ? 1.f : 0.2f), acc[2] * (h.z > 0.f ? 1.f : 0.2f),
+                        acc[3] * (h.w > 0.f ? 1.f : 0.2f));
     }
     __syncthreads();
     {   // partial dH1 = (dH2[:, quarter] x W2[quarter rows, :]) * mask(H1): tiles wave, wave + 8, wave + 16, wave + 24
@@ -499,13 +503,11 @@ __global__ __launch_bounds__(512) void vposer_bwd_fused_kernel(VPoserPanels P, c
         }
 #pragma unroll
         for (int t = 0; t < 4; ++t) {
-            const int n = (wave + 8 * t) * 16 + j;
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int i = 4 * g + r;
-                const float h = (r0 + i < row_hi) ? H1[(size_t)(r0 + i) * VP_H + n] : 0.f;
-                sdH1[pn_lds_index(i, n)] = acc[t][r] * (h > 0.f ? 1.f : 0.2f);
-            }
+            const int n4 = (wave + 8 * t) * 16 + 4 * g;
+            const float4 h = (r0 + j < row_hi) ? *(const float4*)(H1 + (size_t)(r0 + j) * VP_H + n4) : make_float4(0.f, 0.f, 0.f, 0.f);
+            *(float4*)(sdH1 + (size_t)((n4 >> 2) * 16 + j) * 4) =
+                make_float4(acc[t][0] * (h.x > 0.f ? 1.f : 0.2f), acc[t][1] * (h.y > 0.f ? 1.f : 0.2f),
+                            acc[t][2] * (h.z > 0.f ? 1.f : 0.2f), acc[t][3] * (h.w > 0.f ? 1.f : 0.2f));
         }
     }
     __syncthreads();
@@ -519,13 +521,10 @@ __global__ __launch_bounds__(512) void vposer_bwd_fused_kernel(VPoserPanels P, c
     if (wave < 2) {
         const float4 s0 = *(const float4*)(sred + (size_t)(0 + wave) * 256 + lane * 4), s1 = *(const float4*)(sred + (size_t)(2 + wave) * 256 + lane * 4);
         const float4 s2 = *(const float4*)(sred + (size_t)(4 + wave) * 256 + lane * 4), s3 = *(const float4*)(sred + (size_t)(6 + wave) * 256 + lane * 4);
-        const float v[4] = {((s0.x + s1.x) + s2.x) + s3.x, ((s0.y + s1.y) + s2.y) + s3.y, ((s0.z + s1.z) + s2.z) + s3.z, ((s0.w + s1.w) + s2.w) + s3.w};
-        const int n = wave * 16 + j;
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const int row = r0 + 4 * g + r;
-            if (row < row_hi) dZpart[(size_t)q * part_stride + (size_t)row * VP_Z + n] = v[r];
-        }
+        const int n4 = wave * 16 + 4 * g, row = r0 + j;
+        if (row < row_hi)
+            *(float4*)(dZpart + (size_t)q * part_stride + (size_t)row * VP_Z + n4) =
+                make_float4(((s0.x + s1.x) + s2.x) + s3.x, ((s0.y + s1.y) + s2.y) + s3.y, ((s0.z + s1.z) + s2.z) + s3.z, ((s0.w + s1.w) + s2.w) + s3.w);
     }
 }
 
