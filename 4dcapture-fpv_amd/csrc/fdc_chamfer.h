@@ -148,10 +148,14 @@ __global__ __launch_bounds__(256) void nn_direct_kernel(const float* __restrict_
 constexpr float MF_K1 = 1e-4f, MF_K2 = 8e-6f;
 constexpr int MF_MAXCHUNK = 2048;      // chunks per split the survivor list can hold (host keeps splits below it)
 
+#ifdef FDC_NN_TIMELINE
+__device__ unsigned long long g_nn_timeline[8192 * 4];            // instrumentation build only: per workgroup {start, end, xcc}
+#endif
 #ifdef FDC_NN_STATS
 // instrumentation build only (never shipped): [0] MFMA results reduced, [1] results that entered
 // the exact path (wave level), [2] rows re-evaluated exactly (lane level), [3] chunks staged
-__device__ unsigned long long g_nn_stats[4];
+__device__ unsigned long long g_nn_hist[96];    // waves by log2(work items)
+__device__ unsigned long long g_nn_stats[8];   // [4] waves on a kept list, [5] waves that built a list, [6] raw list items, [7] items after the filter
 #define FDC_STAT(i, v) st_cnt[i] += (v)
 #else
 #define FDC_STAT(i, v)
@@ -271,7 +275,7 @@ __global__ __launch_bounds__(256) void nn_mfma_kernel(const float* __restrict__ 
     }
     const f32x16_t zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
 #ifdef FDC_NN_STATS
-    unsigned st_cnt[4] = {0, 0, 0, 0};
+    unsigned st_cnt[8] = {0, 0, 0, 0, 0, 0, 0, 0};
 #endif
 
     // Survivor list.  A chunk (axis-aligned box) matters to query i only if dist(x_i, box) <= sqrt(best_i).  Pass 1 (one chunk per thread, parallel loads -- a serial scan
@@ -421,7 +425,7 @@ __global__ __launch_bounds__(256) void nn_mfma_kernel(const float* __restrict__ 
         buf ^= 1;
     }
 #ifdef FDC_NN_STATS
-    for (int i = 0; i < 4; ++i) atomicAdd(&g_nn_stats[i], (unsigned long long)st_cnt[i]);
+    for (int i = 0; i < 8; ++i) atomicAdd(&g_nn_stats[i], (unsigned long long)st_cnt[i]);
 #endif
 #pragma unroll
     for (int n = 0; n < NQ; ++n) {
@@ -481,10 +485,65 @@ constexpr int ST4_MAXCELL = FDC_ST4_MAXCELL;   // chunks one wave can list befor
 constexpr int ST4_PF = FDC_ST4_PF;     // A fragments in flight per wave
 constexpr int ST4_SUPER = 16;          // chunks per super-cell of the two-level survivor test (consecutive chunks = one k-d subtree)
 
+// Work-list cache of the streaming kernel (optional; pruning only -- results never depend on it).
+// The queries move a few millimetres per optimiser iteration, so the set of quarter chunks a group can possibly need
+// changes slowly.  When a wave has to build its list it builds it with every query's bound radius INFLATED by `slack`
+// and keeps (a) the list and (b) per query the anchor position a_i and the radius R_i the list was built for.  A later
+// launch whose queries satisfy  sqrt(bound_i) + |x_i - a_i| <= R_i  for all i may take the kept list: a quarter that is
+// not on it lies further than R_i from a_i, hence further than R_i - |x_i - a_i| >= sqrt(bound_i) from x_i, for every i --
+// exactly the condition under which the full three-level test would have dropped it.  Either way the (inflated) list is
+// then filtered by the per-query box test with the CURRENT bounds, so the scan visits the same quarters as without a cache.
+// Measured on the bench clip (tools/motion_probe.py): with 4 cm of slack 14 % of the groups rebuild per iteration on
+// average (33 % during the first 100 iterations, 1.4 % during the last 100).
+constexpr int NN_CACHE_CAP = 64;        // quarter ids kept per (group, wave share); longer lists are not cached
+struct NNCache {
+    unsigned short* ids;      // [ngroups * WPG][NN_CACHE_CAP]
+    int* hdr;                 // [ngroups * WPG] list length | launches since the anchors were set << 8; -1: no list (anchors one launch old)
+    float4* anchor;           // [WPG][nq] {a_i, R_i (validity margin already taken off)}
+    float slack;              // metres
+    // Longest-first dispatch (speed only).  A launch is 2.6 "generations" of resident workgroups and ends with a drain in
+    // which a few slow workgroups (specific frames cost 2x the median, every iteration) run alone: measured 48 us of full
+    // machine + 35 us of tail.  Every workgroup leaves its lifetime in wg_cost; every few launches nn_lpt_sort_kernel re-ranks
+    // the workgroups of each XCD's segment by it, and position p of the dispatch order serves workgroup wg_order[p].
+    unsigned* wg_cost;        // [8 * per_xcd] s_memtime ticks of the last launch
+    int* wg_order;            // [8 * per_xcd] permutation inside each XCD segment (null: identity)
+};
+
+// Re-rank the dispatch order of each XCD segment: its K = max(8, n / 16) costliest workgroups go to the front, longest first;
+// all the others keep their natural (frame) order behind them -- neighbouring frames share scene cells, and a fully sorted
+// order lost more to L2 misses early in a fit than it won on the tail.  One 1024-thread block per segment.
+constexpr int NN_LPT_MAXSEG = 8192;
+__global__ __launch_bounds__(1024) void nn_lpt_sort_kernel(const unsigned* __restrict__ cost, int* __restrict__ order, int per_xcd, int nwg) {
+    __shared__ unsigned short s_rank[NN_LPT_MAXSEG];
+    const int base = blockIdx.x * per_xcd;
+    const int n = max(0, min(per_xcd, nwg - base));              // valid workgroups of this segment
+    const int K = min(n, max(8, n / 16));
+    for (int e = threadIdx.x; e < n; e += 1024) {
+        const unsigned c = cost[base + e];
+        int rank = 0;
+        for (int o = 0; o < n; ++o) {
+            const unsigned co = cost[base + o];
+            rank += (co > c) || (co == c && o < e);
+        }
+        s_rank[e] = (unsigned short)rank;
+    }
+    __syncthreads();
+    for (int e = threadIdx.x; e < per_xcd; e += 1024) {
+        if (e >= n) { order[base + e] = base + e; continue; }   // idle slots keep their place at the end
+        const int r = s_rank[e];
+        int pos = r;
+        if (r >= K) {
+            pos = K;
+            for (int o = 0; o < e; ++o) pos += s_rank[o] >= K;
+        }
+        order[base + pos] = base + e;
+    }
+}
+
 template <int NQ, int WPG>
 __global__ __launch_bounds__(256, NQ == 1 ? FDC_ST4_OCC : FDC_ST4_OCC2) void nn_stream4_kernel(const float* __restrict__ q, int nq, NNTarget T,
                                                          const int* __restrict__ seed, float4* __restrict__ seedpt,
-                                                         float* __restrict__ dist, int* __restrict__ idx) {
+                                                         float* __restrict__ dist, int* __restrict__ idx, NNCache cache) {
     __shared__ unsigned short slist[4][ST4_MAXLIST];             // a wave's work list: quarter chunks 4 k + quarter (chunk WPG k + sub)
     __shared__ unsigned short clist[4][ST4_MAXCELL];             // ... before that, the chunks that passed the per-query test
     __shared__ float4 sbox[4][64][2];                            // a wave's near chunk boxes of the current batch {lo, bits(chunk)}, {hi, -}
@@ -499,14 +558,23 @@ __global__ __launch_bounds__(256, NQ == 1 ? FDC_ST4_OCC : FDC_ST4_OCC2) void nn_
     const int ngroups = (nq + 32 * NQ - 1) / (32 * NQ);
     const int nwg = (ngroups + GPW - 1) / GPW;
     const int per_xcd = (nwg + 7) >> 3;
-    const int wg = (blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);
+#ifdef FDC_NN_TIMELINE
+    const unsigned long long tl_t0 = wall_clock64();             // instrumentation build only: 100 MHz device-wide clock
+#endif
+#ifdef FDC_ST4_RR
+    const int wg = blockIdx.x; (void)per_xcd;                    // timing experiment: plain round-robin over the XCDs
+#else
+    const int dpos = (blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);     // position in the dispatch order: XCD-major
+    const int wg = cache.wg_order ? cache.wg_order[dpos] : dpos;
+#endif
+    const unsigned long long lpt_t0 = cache.wg_cost ? __builtin_amdgcn_s_memtime() : 0ull;
     const int group = wg * GPW + gslot;
     const bool idle = wg >= nwg || group >= ngroups;            // idle waves still meet the barrier below
     const int wq0 = idle ? nq : group * (32 * NQ);
     const int nchunk = (T.n + MF_CH - 1) / MF_CH;
     const int myn = idle ? 0 : (nchunk - sub + WPG - 1) / WPG;  // this wave's chunks: WPG k + sub, k < myn
 #ifdef FDC_NN_STATS
-    unsigned st_cnt[4] = {0, 0, 0, 0};
+    unsigned st_cnt[8] = {0, 0, 0, 0, 0, 0, 0, 0};
 #endif
     float qx[NQ], qy[NQ], qz[NQ], own_d[NQ], sb[NQ];
     int own_i[NQ], qidx[NQ];
@@ -537,19 +605,17 @@ __global__ __launch_bounds__(256, NQ == 1 ? FDC_ST4_OCC : FDC_ST4_OCC2) void nn_
         }
         sb[n] = ok ? own_d[n] * 1.00002f + 1e-9f : -INFINITY;   // bound with the rounding slack of the box test
     }
-    // Group bound for the box tests: the axis-aligned box around the queries' balls (centre x_i, radius sqrt(bound_i)).
-    // A cell some query needs intersects that query's ball, hence this box -- and for elongated groups (a shin above a
-    // floor) the box is far tighter than a sphere around the centroid with the largest reach.
-    float glx = INFINITY, gly = INFINITY, glz = INFINITY, ghx = -INFINITY, ghy = -INFINITY, ghz = -INFINITY;
+    float rq[NQ];                                                // radius of each query's bound (rounded up)
     bool finite = true;
 #pragma unroll
-    for (int n = 0; n < NQ; ++n)
+    for (int n = 0; n < NQ; ++n) {
+        rq[n] = 0.f;
         if (qidx[n] < nq) {
-            const float r = __builtin_amdgcn_sqrtf(sb[n]) * 1.00001f + 1e-6f;   // 1-ulp v_sqrt_f32 inside the 1e-5 slack
-            finite &= r < INFINITY;
-            glx = fminf(glx, qx[n] - r); gly = fminf(gly, qy[n] - r); glz = fminf(glz, qz[n] - r);
-            ghx = fmaxf(ghx, qx[n] + r); ghy = fmaxf(ghy, qy[n] + r); ghz = fmaxf(ghz, qz[n] + r);
+            rq[n] = __builtin_amdgcn_sqrtf(sb[n]) * 1.00001f + 1e-6f;   // 1-ulp v_sqrt_f32 inside the 1e-5 slack
+            finite &= rq[n] < INFINITY;
         }
+    }
+    const bool cull = __all(all_seeded && finite);
     // DPP reductions (fdc_math.h), no LDS traffic; lanes 32-63 repeat lanes 0-31 here, so two of the four row results suffice
     auto min_rows01 = [](float v) {
         v = fminf(v, dpp_move<0xB1>(v)); v = fminf(v, dpp_move<0x4E>(v)); v = fminf(v, dpp_move<0x141>(v)); v = fminf(v, dpp_move<0x140>(v));
@@ -559,21 +625,76 @@ __global__ __launch_bounds__(256, NQ == 1 ? FDC_ST4_OCC : FDC_ST4_OCC2) void nn_
         v = fmaxf(v, dpp_move<0xB1>(v)); v = fmaxf(v, dpp_move<0x4E>(v)); v = fmaxf(v, dpp_move<0x141>(v)); v = fmaxf(v, dpp_move<0x140>(v));
         return fmaxf(__int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 0)), __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 16)));
     };
-    glx = min_rows01(glx); gly = min_rows01(gly); glz = min_rows01(glz);
-    ghx = max_rows01(ghx); ghy = max_rows01(ghy); ghz = max_rows01(ghz);
-    const bool cull = __all(all_seeded && finite);
-    // ... and the sphere around the box centre that contains every ball (radius max_i |x_i - c| + r_i): for a far group the
-    // ball box's corners reach much further than any ball does, the sphere cuts them off; a cell has to touch both.
-    const float scx = 0.5f * (glx + ghx), scy = 0.5f * (gly + ghy), scz = 0.5f * (glz + ghz);
-    float sR = 0.f;
+
+    // Work-list cache: may this wave take the list it kept?
+    const bool caching = cache.hdr != nullptr && !idle;            // (idle waves have no group: nothing kept for them)
+    const int cidx = group * WPG + sub;
+    int n_kept = -1;
+    bool inflate = false;                                        // build the list with slack and keep it?
+    if (cull && caching) {
+        const int hv = __builtin_amdgcn_readfirstlane(cache.hdr[cidx]);
+        bool ok = true;
+        float dmax = 0.f;
 #pragma unroll
-    for (int n = 0; n < NQ; ++n)
-        if (qidx[n] < nq) {
-            const float ex = qx[n] - scx, ey = qy[n] - scy, ez = qz[n] - scz;
-            sR = fmaxf(sR, (__builtin_amdgcn_sqrtf(ex * ex + ey * ey + ez * ez) + __builtin_amdgcn_sqrtf(sb[n])) * 1.00001f + 1e-6f);
+        for (int n = 0; n < NQ; ++n)
+            if (qidx[n] < nq) {
+                const float4 a = cache.anchor[(size_t)sub * nq + qidx[n]];
+                const float ex = qx[n] - a.x, ey = qy[n] - a.y, ez = qz[n] - a.z;
+                const float dl = __builtin_amdgcn_sqrtf(ez * ez + (ey * ey + ex * ex)) * 1.00001f + 1e-7f;
+                ok &= rq[n] + dl <= a.w;
+                dmax = fmaxf(dmax, dl);
+            }
+        if (hv >= 0 && __all(ok)) {
+            n_kept = hv & 255;
+            if (lane == 0) cache.hdr[cidx] = hv + 256;            // one launch older
+        } else {
+            // A kept list pays for its slack (a wider build, a longer list to filter) only if it survives a few launches:
+            // the queries' speed since the anchors were set (age launches ago) must leave it about three.
+            dmax = max_rows01(dmax);
+            dmax = fmaxf(dmax, __shfl_xor(dmax, 32, 64));
+            const float age = hv >= 0 ? (float)max(hv >> 8, 1) : 1.f;
+            inflate = dmax * 6.f <= cache.slack * age;
         }
-    sR = max_rows01(sR);
-    const float sR2 = sR * sR * 1.00001f;
+    }
+    // the radii / squared bounds the list is BUILT for: inflated by the slack when the list is going to be kept
+    float sbT[NQ];
+    float glx = INFINITY, gly = INFINITY, glz = INFINITY, ghx = -INFINITY, ghy = -INFINITY, ghz = -INFINITY;
+    float scx = 0.f, scy = 0.f, scz = 0.f, sR2 = 0.f;
+    if (cull && n_kept < 0) {
+        float rT[NQ];
+#pragma unroll
+        for (int n = 0; n < NQ; ++n) {
+            rT[n] = inflate ? rq[n] + cache.slack : rq[n];
+            sbT[n] = (qidx[n] < nq) ? (inflate ? rT[n] * rT[n] * 1.00002f : sb[n]) : -INFINITY;
+        }
+        // Group bound for the box tests: the axis-aligned box around the queries' balls (centre x_i, radius r_i).
+        // A cell some query needs intersects that query's ball, hence this box -- and for elongated groups (a shin above a
+        // floor) the box is far tighter than a sphere around the centroid with the largest reach.
+#pragma unroll
+        for (int n = 0; n < NQ; ++n)
+            if (qidx[n] < nq) {
+                const float r = rT[n];
+                glx = fminf(glx, qx[n] - r); gly = fminf(gly, qy[n] - r); glz = fminf(glz, qz[n] - r);
+                ghx = fmaxf(ghx, qx[n] + r); ghy = fmaxf(ghy, qy[n] + r); ghz = fmaxf(ghz, qz[n] + r);
+            }
+        glx = min_rows01(glx); gly = min_rows01(gly); glz = min_rows01(glz);
+        ghx = max_rows01(ghx); ghy = max_rows01(ghy); ghz = max_rows01(ghz);
+        // ... and the sphere around the box centre that contains every ball (radius max_i |x_i - c| + r_i): for a far group the
+        // ball box's corners reach much further than any ball does, the sphere cuts them off; a cell has to touch both.
+        scx = 0.5f * (glx + ghx); scy = 0.5f * (gly + ghy); scz = 0.5f * (glz + ghz);
+        float sR = 0.f;
+#pragma unroll
+        for (int n = 0; n < NQ; ++n)
+            if (qidx[n] < nq) {
+                const float ex = qx[n] - scx, ey = qy[n] - scy, ez = qz[n] - scz;
+                sR = fmaxf(sR, (__builtin_amdgcn_sqrtf(ex * ex + ey * ey + ez * ez) + rT[n]) * 1.00001f + 1e-6f);
+            }
+        sR = max_rows01(sR);
+        sR2 = sR * sR * 1.00001f;
+    } else {
+#pragma unroll
+        for (int n = 0; n < NQ; ++n) sbT[n] = sb[n];
+    }
     // box-box overlap (closed): false only if the boxes are strictly apart along some axis
     // (bitwise |: with short-circuit || the compiler sinks the component loads into a chain of dependent branches)
     auto overlaps = [&](float4 lo, float4 hi) -> bool {
@@ -590,7 +711,13 @@ __global__ __launch_bounds__(256, NQ == 1 ? FDC_ST4_OCC : FDC_ST4_OCC2) void nn_
 #if defined(FDC_ST4_ABLATE) && FDC_ST4_ABLATE >= 2
     if (false) {                                                 // timing ablation only: no survivor list either
 #else
-    if (cull) {
+    if (cull && n_kept >= 0) {                                    // the kept list is still a superset of what this launch can need
+        nsurv = n_kept;
+        listed = true;
+        FDC_STAT(4, lane == 0);
+        if (lane < n_kept) slist[wave][lane] = cache.ids[(size_t)cidx * NN_CACHE_CAP + lane];
+        __builtin_amdgcn_wave_barrier();
+    } else if (cull) {
 #endif
         nsurv = 0;
         listed = true;
@@ -633,7 +760,7 @@ __global__ __launch_bounds__(256, NQ == 1 ? FDC_ST4_OCC : FDC_ST4_OCC2) void nn_
                     const float4 blo = sbox[wave][k][0], bhi = sbox[wave][k][1];
                     bool hit = false;
 #pragma unroll
-                    for (int n = 0; n < NQ; ++n) hit |= box_d2(blo, bhi, qx[n], qy[n], qz[n]) <= sb[n];
+                    for (int n = 0; n < NQ; ++n) hit |= box_d2(blo, bhi, qx[n], qy[n], qz[n]) <= sbT[n];
                     const unsigned long long hm = __ballot(hit);
                     const int c0 = __builtin_amdgcn_readlane(__float_as_int(blo.w), 0), c1 = __builtin_amdgcn_readlane(__float_as_int(blo.w), 32);
                     if ((unsigned)hm) {
@@ -671,7 +798,7 @@ __global__ __launch_bounds__(256, NQ == 1 ? FDC_ST4_OCC : FDC_ST4_OCC2) void nn_
                     const float4 blo = qbox[cs * 8 + 2 * (2 * rnd + half)], bhi = qbox[cs * 8 + 2 * (2 * rnd + half) + 1];
                     bool hit = false;
 #pragma unroll
-                    for (int n = 0; n < NQ; ++n) hit |= box_d2(blo, bhi, qx[n], qy[n], qz[n]) <= sb[n];
+                    for (int n = 0; n < NQ; ++n) hit |= box_d2(blo, bhi, qx[n], qy[n], qz[n]) <= sbT[n];
                     const unsigned long long hm = __ballot(hit);
                     if ((unsigned)hm) {
                         if (nsurv >= ST4_MAXLIST) { listed = false; break; }
@@ -687,7 +814,55 @@ __global__ __launch_bounds__(256, NQ == 1 ? FDC_ST4_OCC : FDC_ST4_OCC2) void nn_
             }
             __builtin_amdgcn_wave_barrier();
         }
+        FDC_STAT(5, lane == 0 && !idle);
+        if (caching) {                                            // keep the (inflated) list and what it was built for
+            const bool keep = inflate && listed && nsurv <= NN_CACHE_CAP;
+            if (keep && lane < nsurv) cache.ids[(size_t)cidx * NN_CACHE_CAP + lane] = slist[wave][lane];
+            if (lane == 0) cache.hdr[cidx] = keep ? (nsurv | 256) : -1;
+            if (half == 0) {
+#pragma unroll
+                for (int n = 0; n < NQ; ++n)
+                    if (qidx[n] < nq)                              // R_i with the validity test's rounding margin taken off; no list: never valid
+                        cache.anchor[(size_t)sub * nq + qidx[n]] =
+                            make_float4(qx[n], qy[n], qz[n], keep ? (rq[n] + cache.slack) * 0.99998f - 2e-6f : -1.f);
+            }
+        }
         if (!listed) nsurv = 4 * myn;                           // list overflow: scan this wave's whole share (still exact)
+    }
+    // With a cache the list (kept or just built) was made for inflated radii: filter it by the per-query box test with the
+    // CURRENT bounds, in place (32 quarters per pass: lane l fetches box half l & 1 of quarter l >> 1, id in lo.w; writes
+    // trail reads, and a wave's LDS traffic is in order).
+    if (cull && caching && listed && (inflate || n_kept >= 0)) {
+        float4* const qbox = &sbox[wave][0][0];
+        const int n_raw = nsurv;
+        int nout = 0;
+        FDC_STAT(6, lane == 0 ? n_raw : 0);
+        for (int k0 = 0; k0 < n_raw; k0 += 32) {
+            const int kk = k0 + (lane >> 1);
+            if (kk < n_raw) {
+                const int id = slist[wave][kk];
+                const int chq = WPG * (id >> 2) + sub;
+                float4 bx = T.qbounds[((size_t)chq * 4 + (id & 3)) * 2 + (lane & 1)];
+                if (!(lane & 1)) bx.w = __int_as_float(id);
+                qbox[lane] = bx;
+            }
+            __builtin_amdgcn_wave_barrier();
+            const int nb = min(32, n_raw - k0);
+            for (int k = 0; k < nb; k += 2) {                     // wave-uniform; each half-wave on its own quarter
+                const int kq = min(k + half, nb - 1);
+                const float4 blo = qbox[2 * kq], bhi = qbox[2 * kq + 1];
+                bool hit = false;
+#pragma unroll
+                for (int n = 0; n < NQ; ++n) hit |= box_d2(blo, bhi, qx[n], qy[n], qz[n]) <= sb[n];
+                const unsigned long long hm = __ballot(hit);
+                const int i0 = __builtin_amdgcn_readlane(__float_as_int(blo.w), 0), i1 = __builtin_amdgcn_readlane(__float_as_int(blo.w), 32);
+                if ((unsigned)hm) { if (lane == 0) slist[wave][nout] = (unsigned short)i0; ++nout; }
+                if (k + 1 < nb && (unsigned)(hm >> 32)) { if (lane == 0) slist[wave][nout] = (unsigned short)i1; ++nout; }
+            }
+            __builtin_amdgcn_wave_barrier();
+        }
+        nsurv = nout;
+        FDC_STAT(7, lane == 0 ? nout : 0);
     }
     const f32x16_t zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     constexpr int NT = MF_CH / 32;                               // 16 tiles per chunk (padding rows score 1e30)
@@ -696,6 +871,9 @@ __global__ __launch_bounds__(256, NQ == 1 ? FDC_ST4_OCC : FDC_ST4_OCC2) void nn_
 
 #if defined(FDC_ST4_ABLATE) && FDC_ST4_ABLATE >= 1
     nsurv = 0;                                                   // timing ablation only (wrong results): no main loop
+#endif
+#ifdef FDC_NN_STATS
+    if (lane == 0 && !idle) atomicAdd(&g_nn_hist[(listed ? 0 : 16) + (nsurv > 0 ? 32 - __clz(nsurv) : 0)], 1ull);
 #endif
     if (nsurv > 0) {
         // work items (quarter chunks) are wave-uniform: ids kept in SGPRs (readfirstlane), so fragment addresses are scalar
@@ -827,7 +1005,21 @@ __global__ __launch_bounds__(256, NQ == 1 ? FDC_ST4_OCC : FDC_ST4_OCC2) void nn_
     }
     __syncthreads();
 #ifdef FDC_NN_STATS
-    for (int i = 0; i < 4; ++i) atomicAdd(&g_nn_stats[i], (unsigned long long)st_cnt[i]);
+    {   // per wave: slow-path entries (wave-level count sits in lane 0) and the longest per-lane chain of exact re-evaluations
+        unsigned mx = st_cnt[2];
+        for (int off = 32; off > 0; off >>= 1) mx = max(mx, (unsigned)__shfl_xor((int)mx, off, 64));
+        if (lane == 0 && !idle) {
+            atomicAdd(&g_nn_hist[32 + (st_cnt[1] > 0 ? 32 - __clz(st_cnt[1]) : 0)], 1ull);
+            atomicAdd(&g_nn_hist[64 + (mx > 0 ? 32 - __clz(mx) : 0)], 1ull);
+        }
+    }
+    for (int i = 0; i < 8; ++i) atomicAdd(&g_nn_stats[i], (unsigned long long)st_cnt[i]);
+#endif
+#ifdef FDC_NN_TIMELINE
+    if (tid == 0 && blockIdx.x < 8192) {
+        unsigned xcc; asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+        g_nn_timeline[blockIdx.x * 4 + 0] = tl_t0; g_nn_timeline[blockIdx.x * 4 + 1] = wall_clock64(); g_nn_timeline[blockIdx.x * 4 + 2] = xcc & 15;
+    }
 #endif
     if (tid < GPW * 32 * NQ) {
         const int g = tid / (32 * NQ), e = tid % (32 * NQ);      // group slot of this workgroup, query of the group
@@ -847,6 +1039,7 @@ __global__ __launch_bounds__(256, NQ == 1 ? FDC_ST4_OCC : FDC_ST4_OCC2) void nn_
             seedpt[qo] = s_p[bw][e];
         }
     }
+    if (cache.wg_cost && tid == 0 && wg < nwg) cache.wg_cost[wg] = (unsigned)(__builtin_amdgcn_s_memtime() - lpt_t0);
 }
 
 // Seeds for queries that have none (the first iteration of a fit): any scene point gives a valid upper
@@ -955,7 +1148,8 @@ static inline int nn_pick_nsplit(int nq, int nt, bool culled = false) {
 // workspace: pd/pi [nsplit*nq]; seed: optional [nq] original indices (may alias idx: read before idx is rewritten)
 static inline hipError_t nn_search(const float* q, int nq, const NNTarget& T, float* dist, int* idx, float* pd, int* pi,
                                    int nsplit, hipStream_t st, const int* seed = nullptr, bool seed_missing = false,
-                                   float4* seedpt = nullptr, bool* seedpt_written = nullptr) {
+                                   float4* seedpt = nullptr, bool* seedpt_written = nullptr, const NNCache* cache = nullptr,
+                                   bool resort = false) {
     if (seedpt_written) *seedpt_written = false;             // true: seedpt[q] = coordinates of the neighbour idx[q] after this launch
     if (nq <= 0) return hipSuccess;
     // Query blocks per workgroup: 4 waves x NQ x 32.  A brute-force scan wants NQ = 4 (most MFMAs per
@@ -991,10 +1185,16 @@ static inline hipError_t nn_search(const float* q, int nq, const NNTarget& T, fl
             const int groups = (nq + 32 * nqv - 1) / (32 * nqv);
             const int nwg = (groups * wpg + 3) / 4;
             const dim3 grid((nwg + 7) / 8 * 8);
-#define FDC_ST4(NQV, WPGV) hipLaunchKernelGGL((nn_stream4_kernel<NQV, WPGV>), grid, dim3(256), 0, st, q, nq, T, seed, seedpt, dist, idx)
+            NNCache nc = cache ? *cache : NNCache{nullptr, nullptr, nullptr, 0.f, nullptr, nullptr};
+            if (wpg != 1 || nqv != 1) { nc.wg_cost = nullptr; nc.wg_order = nullptr; }     // the schedule arrays are sized for 128-query workgroups
+#define FDC_ST4(NQV, WPGV) hipLaunchKernelGGL((nn_stream4_kernel<NQV, WPGV>), grid, dim3(256), 0, st, q, nq, T, seed, seedpt, dist, idx, nc)
             if (nqv == 2 && wpg == 4) FDC_ST4(2, 4); else if (nqv == 2 && wpg == 2) FDC_ST4(2, 2); else if (nqv == 2) FDC_ST4(2, 1);
             else if (wpg == 4) FDC_ST4(1, 4); else if (wpg == 2) FDC_ST4(1, 2); else FDC_ST4(1, 1);
 #undef FDC_ST4
+            if (nc.wg_order && resort && ((nwg + 7) >> 3) <= NN_LPT_MAXSEG) {
+                const int per_xcd = (nwg + 7) >> 3;
+                hipLaunchKernelGGL(nn_lpt_sort_kernel, dim3(8), dim3(1024), 0, st, nc.wg_cost, nc.wg_order, per_xcd, nwg);
+            }
         }
         return hipGetLastError();
     }

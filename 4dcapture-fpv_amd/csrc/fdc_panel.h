@@ -272,9 +272,9 @@ __device__ unsigned long long g_pn_times[8192 * 8];
 // fabric in every launch (measured: 5.6 k cycles just to stage a 31 KB A block, fragment loads at Infinity-Cache latency).
 // Here XCD x owns the rectangle (row group x / xc, column group x % xc): its slice of the STATIC operand B stays resident in
 // its L2 from one optimiser iteration to the next, and A crosses the fabric xc times instead of 8.
-struct PnMap { int nrb, ncb, xc, rpg, cpg; };      // row / column blocks; column groups; blocks per group
+struct PnMap { int nrb, ncb, xc, rpg, cpg, rfast; };   // row / column blocks; column groups; blocks per group; slot order
 static inline PnMap panel_map(int nrb, int ncb, size_t a_bytes, size_t b_bytes) {
-    PnMap best{nrb, ncb, 1, (nrb + 7) / 8, ncb};
+    PnMap best{nrb, ncb, 1, (nrb + 7) / 8, ncb, 0};
     double best_cost = 1e300;
     for (int xc = 1; xc <= 8; xc *= 2) {
         const int xr = 8 / xc;
@@ -283,8 +283,11 @@ static inline PnMap panel_map(int nrb, int ncb, size_t a_bytes, size_t b_bytes) 
         // stay in its L2 between launches; + a penalty for idle slots of ragged groups
         double cost = (double)xc * a_bytes + ((b_bytes / xc <= (size_t)(3u << 19)) ? 0.0 : (double)xr * b_bytes);
         cost *= (double)(8 * rpg * cpg) / (double)(nrb * ncb);
-        if (cost < best_cost) { best_cost = cost; best = PnMap{nrb, ncb, xc, rpg, cpg}; }
+        if (cost < best_cost) { best_cost = cost; best = PnMap{nrb, ncb, xc, rpg, cpg, 0}; }
     }
+    // an XCD's slice of B does not fit its L2 (wide outputs): walk the row blocks of one column block first, so the
+    // workgroups resident at any time share a few column blocks of B and each slice crosses the fabric once
+    best.rfast = b_bytes / best.xc > (size_t)(3u << 19);
     return best;
 }
 
@@ -297,8 +300,9 @@ __global__ __launch_bounds__(512) void panel_gemm_kernel(const float* __restrict
     extern __shared__ __attribute__((aligned(16))) float pn_lds[];
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, j = lane & 15, g = lane >> 4;
     const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
-    const int rbk = (xcd / mp.xc) * mp.rpg + slot / mp.cpg, cbk = (xcd % mp.xc) * mp.cpg + slot % mp.cpg;
-    if (slot / mp.cpg >= mp.rpg || rbk >= mp.nrb || cbk >= mp.ncb) return;          // ragged groups (whole workgroup)
+    const int r_in = mp.rfast ? slot % mp.rpg : slot / mp.cpg, c_in = mp.rfast ? slot / mp.rpg : slot % mp.cpg;
+    const int rbk = (xcd / mp.xc) * mp.rpg + r_in, cbk = (xcd % mp.xc) * mp.cpg + c_in;
+    if (r_in >= mp.rpg || c_in >= mp.cpg || rbk >= mp.nrb || cbk >= mp.ncb) return;  // ragged groups (whole workgroup)
     const int tile = cbk * 8 + wave;
     const int m0 = rbk * (16 * RB);
     const int img = kslab * 16;
@@ -340,19 +344,75 @@ __global__ __launch_bounds__(512) void panel_gemm_kernel(const float* __restrict
     PN_STAMP(3);
 }
 
+// Wide outputs (the full-mesh blend: N = 3 V = 31 425 columns, B = 62 MB): a workgroup keeps its 16 RB rows of A in LDS and
+// walks ALL the column blocks of its XCD's share of B, so A is staged once per workgroup instead of once per (row, column)
+// block (measured with one column block per workgroup: staging 14.7 k of a 45 k-cycle lifetime, exposed because the 127 KB
+// image leaves room for one workgroup per CU) and the workgroups of an XCD stream the same column blocks at the same
+// time: each slice of B crosses the fabric once.  The next column block's first fragments are requested before the
+// current block's stores.  K must fit one slab.  Grid: 8 * ceil(M / (16 RB)) workgroups, blockIdx & 7 = XCD = column share.
+typedef float f32x4u_t __attribute__((ext_vector_type(4), aligned(4)));      // 16-byte store at 4-byte alignment (3 V is odd)
+template <int RB>
+__global__ __launch_bounds__(512) void panel_gemm_wide_kernel(const float* __restrict__ A, int lda, int M, int K, PanelB B,
+                                                              float* __restrict__ C, int ldc, int N) {
+    extern __shared__ __attribute__((aligned(16))) float pn_lds[];
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, j = lane & 15, g = lane >> 4;
+    const int xcd = blockIdx.x & 7, m0 = (int)(blockIdx.x >> 3) * (16 * RB);
+    const int ncb = (B.ntile + 7) / 8, cpg = (ncb + 7) / 8;
+    const int cb0 = xcd * cpg, cb1 = min(ncb, cb0 + cpg);
+    const int kpad = (K + 15) & ~15, nss = kpad >> 4, img = kpad * 16;
+    if (cb0 >= cb1) return;
+    PN_STAMP(0);
+    PnRing<1, 4> rg;
+    {
+        const int t0 = min(cb0 * 8 + wave, B.ntile - 1);
+        const float4* bfp = B.f + (size_t)t0 * B.nss * 64;
+        panel_prefetch<1, 4>(rg, &bfp, nss, lane);
+    }
+#pragma unroll
+    for (int rb = 0; rb < RB; ++rb) panel_stage<512>(pn_lds + (size_t)rb * img, A, lda, m0 + 16 * rb, M, 0, K, kpad, tid);
+    __syncthreads();
+    PN_STAMP(1);
+    for (int cb = cb0; cb < cb1; ++cb) {
+        if (cb == cb0 + 1) PN_STAMP(2);
+        const int tile = cb * 8 + wave;
+        f32x4_t acc[RB];
+#pragma unroll
+        for (int rb = 0; rb < RB; ++rb) acc[rb] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+        if (tile < B.ntile) panel_mma_rows<RB, 4>(pn_lds, img, rg, nss, acc, lane);
+        if (cb + 1 < cb1) {                                          // next block's first fragments: in flight during the stores
+            const int tn = min((cb + 1) * 8 + wave, B.ntile - 1);
+            const float4* bfp = B.f + (size_t)tn * B.nss * 64;
+            panel_prefetch<1, 4>(rg, &bfp, nss, lane);
+        }
+        const int n4 = tile * 16 + 4 * g;
+        if (tile < B.ntile && n4 < N) {
+#pragma unroll
+            for (int rb = 0; rb < RB; ++rb) {
+                const int m = m0 + 16 * rb + j;
+                if (m < M) {
+                    float* dst = C + (size_t)m * ldc + n4;
+                    if (n4 + 3 < N) *(f32x4u_t*)dst = f32x4u_t{acc[rb][0], acc[rb][1], acc[rb][2], acc[rb][3]};
+                    else {
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) if (n4 + r < N) dst[r] = acc[rb][r];
+                    }
+                }
+            }
+        }
+    }
+    PN_STAMP(3);
+}
+
 static inline hipError_t panel_gemm(const float* A, int lda, int M, int K, const PanelB& B, float* C, int ldc, int N, hipStream_t st) {
     if (M <= 0 || N <= 0) return hipSuccess;
     // one row block per workgroup while an XCD's slice of the operand stays inside its L2 (the loop's products: a 3 MB panel);
-    // wide outputs (full-mesh blend, N = 31 425) take four row blocks per fragment stream
+    // wide outputs (full-mesh blend, N = 31 425) take the column-walking form with two row blocks per fragment stream
     const size_t b_bytes = (size_t)B.ntile * B.nss * 1024;
-    const bool wide = b_bytes > (size_t)(24u << 20) && M >= 64;
     const int kpad = (K + 15) & ~15;
     const int ncb = (B.ntile + 7) / 8;
-    if (wide) {
-        const int kslab = kpad <= 512 ? kpad : 512;                 // 4 x 32 KiB
-        const PnMap mp = panel_map((M + 63) / 64, ncb, (size_t)M * K * 4, b_bytes);
-        hipLaunchKernelGGL(panel_gemm_kernel<4>, dim3(8 * mp.rpg * mp.cpg), dim3(512), (size_t)4 * kslab * 16 * sizeof(float), st, A, lda, M, K, B,
-                           kslab, C, ldc, N, mp);
+    if (b_bytes > (size_t)(24u << 20) && M >= 32 && kpad <= 1024) {
+        hipLaunchKernelGGL(panel_gemm_wide_kernel<2>, dim3(8 * ((M + 31) / 32)), dim3(512), (size_t)2 * kpad * 16 * sizeof(float), st, A, lda, M, K,
+                           B, C, ldc, N);
     } else {
         const int kslab = kpad <= 1536 ? kpad : 1024;               // <= 96 KiB
         const PnMap mp = panel_map((M + 15) / 16, ncb, (size_t)M * K * 4, b_bytes);

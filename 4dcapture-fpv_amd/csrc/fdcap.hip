@@ -685,6 +685,17 @@ struct OptState {
     DevBuf<int> idx, pi;
     DevBuf<float> kp2d;       // per-frame inner fit: 2D keypoints [n_local,23,3] (u, v, confidence)
     DevBuf<float4> seedpt;    // coordinates (+ position in the sorted scene) of each query's current neighbour: next launch's seed
+    // work-list cache of the in-loop NN launch (fdc_chamfer.h NNCache): ids [groups * 4][64], hdr [groups * 4], anchors [4][nq]
+    DevBuf<unsigned short> nnc_ids;
+    DevBuf<int> nnc_hdr;
+    DevBuf<float4> nnc_anchor;
+    float nnc_slack = 0.04f;  // metres; FDCAP_NN_CACHE_SLACK overrides, 0 disables the cache
+    DevBuf<unsigned> nn_wg_cost;   // longest-first dispatch of the in-loop NN launch (NNCache::wg_cost / wg_order)
+    DevBuf<int> nn_wg_order;
+    int nn_launches = 0;
+    bool nn_lpt = true;       // FDCAP_NN_LPT=0 disables
+    NNCache nn_cache(int) { return NNCache{nnc_slack > 0.f ? nnc_ids.p : nullptr, nnc_slack > 0.f ? nnc_hdr.p : nullptr, nnc_anchor.p, nnc_slack,
+                                          nn_lpt ? nn_wg_cost.p : nullptr, nn_lpt ? nn_wg_order.p : nullptr}; }
     DevBuf<float> dA, dtransl_v, dMv, dsv, dPF, dJw, dX, dCAM, dscale_row;     // d betas: columns 486.. of dPF
     DevBuf<float> VoffF, VwF, dVF;      // mode 'local' second loop: full-mesh pose offsets / world vertices / gradient
     int cam_steps = 0;
@@ -806,12 +817,16 @@ int build_skin_set(fdcap_ctx* c, const std::vector<int64_t>& ids, SkinSet* out) 
     HIP_TRY(out->wj.upload(wj.data(), wj.size()));
     HIP_TRY(out->posedirs.upload(pd.data(), pd.size()));
     out->pn_fwd = PanelB(); out->pn_bwd = PanelB();
-    if (nv > 0 && 3 * nv <= PANEL_MAX_K) {
+    if (nv > 0) {                                  // forward panel for every set (the full mesh takes the wide form of the kernel)
         std::vector<float> pf;
         int nt = 0, ns = 0;
         panel_pack(pd.data(), ldp, 1, NPFX, 3 * nv, pf, &nt, &ns);
         HIP_TRY(out->pn_fwd_f.upload(pf.data(), pf.size()));
         out->pn_fwd.f = (const float4*)out->pn_fwd_f.p; out->pn_fwd.ntile = nt; out->pn_fwd.nss = ns;
+    }
+    if (nv > 0 && 3 * nv <= PANEL_MAX_K) {         // data-gradient panel while a 16-row block of K = 3 nv columns fits the LDS slabs
+        std::vector<float> pf;
+        int nt = 0, ns = 0;
         panel_pack(pd.data(), 1, ldp, 3 * nv, NPFX, pf, &nt, &ns);
         HIP_TRY(out->pn_bwd_f.upload(pf.data(), pf.size()));
         out->pn_bwd.f = (const float4*)out->pn_bwd_f.p; out->pn_bwd.ntile = nt; out->pn_bwd.nss = ns;
@@ -880,15 +895,29 @@ extern "C" {
 const char* fdcap_version(void) { return "fdcap-hip 0.2 (gfx950)"; }
 
 #ifdef FDC_NN_STATS
+int fdcap_debug_nn_hist(unsigned long long* out) {
+    HIP_TRY(hipDeviceSynchronize());
+    HIP_TRY(hipMemcpyFromSymbol(out, HIP_SYMBOL(g_nn_hist), 96 * sizeof(unsigned long long)));
+    unsigned long long z[96] = {0};
+    HIP_TRY(hipMemcpyToSymbol(HIP_SYMBOL(g_nn_hist), z, sizeof(z)));
+    return 0;
+}
 int fdcap_debug_nn_stats(unsigned long long* out) {
     HIP_TRY(hipDeviceSynchronize());
-    HIP_TRY(hipMemcpyFromSymbol(out, HIP_SYMBOL(g_nn_stats), 4 * sizeof(unsigned long long)));
-    unsigned long long z[4] = {0, 0, 0, 0};
+    HIP_TRY(hipMemcpyFromSymbol(out, HIP_SYMBOL(g_nn_stats), 8 * sizeof(unsigned long long)));
+    unsigned long long z[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     HIP_TRY(hipMemcpyToSymbol(HIP_SYMBOL(g_nn_stats), z, sizeof(z)));
     return 0;
 }
 #endif
 
+#ifdef FDC_NN_TIMELINE
+int fdcap_debug_nn_timeline(unsigned long long* out, int n) {
+    HIP_TRY(hipDeviceSynchronize());
+    HIP_TRY(hipMemcpyFromSymbol(out, HIP_SYMBOL(g_nn_timeline), (size_t)n * sizeof(unsigned long long)));
+    return 0;
+}
+#endif
 #ifdef FDC_PN_TIMING
 int fdcap_debug_panel_reset(void) {
     HIP_TRY(hipDeviceSynchronize());
@@ -1276,7 +1305,7 @@ static int body_forward_impl(fdcap_ctx* c, const float* params, int32_t B, const
     if (joints) hipLaunchKernelGGL(joints_out_kernel, dim3((B * NJ + 255) / 256), dim3(256), 0, st, w[7].p, X, XDIM, B, joints);
     if (vertices) {
         HIP_TRY(w[11].ensure((size_t)B * 3 * V));
-        HIP_TRY(gemm_f32(false, EPI_STORE, w[6].p, NPFX, c->full.posedirs.p, c->full.ldp, w[11].p, 3 * V, B, 3 * V, NPFX, nullptr, 0, st));
+        HIP_TRY(panel_gemm(w[6].p, NPFX, B, NPFX, c->full.pn_fwd, w[11].p, 3 * V, 3 * V, st));
         hipLaunchKernelGGL(skin_fwd_kernel, dim3((V + 255) / 256, B), dim3(256), 0, st, c->full.model(), V, X, XDIM, X_BETAS,
                            X_TRANSL, w[11].p, w[8].p, (const float*)w[1].p, S, 0, world ? 1 : 0, vertices);
     }
@@ -1320,7 +1349,7 @@ int fdcap_smplx_forward(fdcap_ctx* c, const float* go, const float* bp, const fl
     if (joints) hipLaunchKernelGGL(joints_out_kernel, dim3((B * NJ + 255) / 256), dim3(256), 0, st, w[7].p, X, XDIM, B, joints);
     if (vertices) {
         HIP_TRY(w[11].ensure((size_t)B * 3 * V));
-        HIP_TRY(gemm_f32(false, EPI_STORE, w[6].p, NPFX, c->full.posedirs.p, c->full.ldp, w[11].p, 3 * V, B, 3 * V, NPFX, nullptr, 0, st));
+        HIP_TRY(panel_gemm(w[6].p, NPFX, B, NPFX, c->full.pn_fwd, w[11].p, 3 * V, 3 * V, st));
         hipLaunchKernelGGL(skin_fwd_kernel, dim3((V + 255) / 256, B), dim3(256), 0, st, c->full.model(), V, X, XDIM, X_BETAS,
                            X_TRANSL, w[11].p, w[8].p, (const float*)nullptr, (const float*)nullptr, 0, 0, vertices);
     }
@@ -1338,6 +1367,7 @@ void fdcap_opt_destroy(fdcap_ctx* c) {
     for (auto* b : fb) b->release();
     o->dctD.release(); o->dctCoef.release(); o->dctM.release(); o->dctV.release(); o->adam_tab.release();
     o->idx.release(); o->pi.release(); o->seedpt.release(); o->kp2d.release();
+    o->nnc_ids.release(); o->nnc_hdr.release(); o->nnc_anchor.release(); o->nn_wg_cost.release(); o->nn_wg_order.release();
     delete o;
     c->opt = nullptr;
 }
@@ -1391,6 +1421,32 @@ int fdcap_opt_create(fdcap_ctx* c, const fdcap_opt_config* cfg, float* rows_x, f
         hipError_t e_ = hipMemset(o->idx.p, 0xFF, nq * sizeof(int));      // -1: no seed yet
         if (e_ != hipSuccess) err = (int)e_;
     }
+    if (!err && o->contact_on) {
+        if (const char* e = getenv("FDCAP_NN_LPT")) o->nn_lpt = e[0] != '0';
+        o->nn_launches = 0;
+        const size_t nslot = ((((size_t)nq_all + 127) / 128 + 7) / 8) * 8;      // 128-query workgroups, XCD segments
+        hipError_t e_ = o->nn_wg_cost.ensure(nslot);
+        if (e_ == hipSuccess) e_ = o->nn_wg_order.ensure(nslot);
+        if (e_ == hipSuccess) e_ = hipMemset(o->nn_wg_cost.p, 0, nslot * sizeof(unsigned));
+        if (e_ == hipSuccess) {
+            std::vector<int> ident(nslot);
+            for (size_t i = 0; i < nslot; ++i) ident[i] = (int)i;
+            e_ = hipMemcpy(o->nn_wg_order.p, ident.data(), nslot * sizeof(int), hipMemcpyHostToDevice);
+        }
+        if (e_ != hipSuccess) err = (int)e_;
+    }
+    if (!err && o->contact_on) {
+        if (const char* e = getenv("FDCAP_NN_CACHE_SLACK")) o->nnc_slack = (float)atof(e);
+        if (o->nnc_slack > 0.f) {                                        // groups of 32 queries x up to 4 waves per group
+            const size_t ng4 = ((size_t)nq_all + 31) / 32 * 4;
+            hipError_t e_ = o->nnc_ids.ensure(ng4 * NN_CACHE_CAP);
+            if (e_ == hipSuccess) e_ = o->nnc_hdr.ensure(ng4);
+            if (e_ == hipSuccess) e_ = o->nnc_anchor.ensure((size_t)4 * nq_all);
+            if (e_ == hipSuccess) e_ = hipMemset(o->nnc_hdr.p, 0xFF, ng4 * sizeof(int));                       // -1: nothing kept
+            if (e_ == hipSuccess) e_ = hipMemset(o->nnc_anchor.p, 0, (size_t)4 * nq_all * sizeof(float4));
+            if (e_ != hipSuccess) err = (int)e_;
+        }
+    }
     if (!err) {
         float s = cfg->scale_init;
         hipError_t e_ = hipMemcpy(o->scale.p, &s, sizeof(float), hipMemcpyHostToDevice);
@@ -1426,8 +1482,10 @@ static int opt_contact_forward(fdcap_ctx* c, hipStream_t st) {
                        X_BETAS, X_TRANSL, o->Voff.p, o->A.p, o->M.p, o->scale.p, 2, 1, o->Vw.p);
     const int nq = nl * nc;
     // the first contact forward of a fit has no neighbours from a previous iteration yet (idx = -1)
+    const NNCache cache = o->nn_cache(0);
     HIP_TRY(nn_search(o->Vw.p + off, nq, c->nn_target(o->use_cull), o->dist.p + 2 * nc, o->idx.p + 2 * nc, o->pd.p, o->pi.p,
-                      o->nsplit, st, o->use_seed ? o->idx.p + 2 * nc : nullptr, !o->seeded, o->seedpt.p + 2 * nc, &o->nnpt_valid));
+                      o->nsplit, st, o->use_seed ? o->idx.p + 2 * nc : nullptr, !o->seeded, o->seedpt.p + 2 * nc, &o->nnpt_valid,
+                      &cache, (o->nn_launches++ & 15) == 2));                 // re-rank the dispatch order every 16 launches
     o->seeded = true;
     return 0;
 }
@@ -1725,7 +1783,7 @@ int fdcap_opt_backward_local2(fdcap_ctx* c, const float* contact_weight, int32_t
     int e = opt_pose_forward(c, row_lo, row_hi, st);
     if (e) return e;
     // full-mesh world vertices of every row (the vertex stencil needs 2 halo frames each side)
-    HIP_TRY(gemm_f32(false, EPI_STORE, o->PF.p, NPFX, c->full.posedirs.p, c->full.ldp, o->VoffF.p, 3 * V, R, 3 * V, NPFX, nullptr, 0, st));
+    HIP_TRY(panel_gemm(o->PF.p, NPFX, R, NPFX, c->full.pn_fwd, o->VoffF.p, 3 * V, 3 * V, st));
     hipLaunchKernelGGL(skin_fwd_kernel, dim3((V + 255) / 256, R), dim3(256), 0, st, c->full.model(), V, o->X.p, XDIM, X_BETAS,
                        X_TRANSL, o->VoffF.p, o->A.p, o->M.p, o->scale.p, 0, 1, o->VwF.p);
     // losses [0] rec, [1] z^2, [2] local (parameter) smoothing, [5] vertex smoothing, [6] foot skate
@@ -1875,10 +1933,10 @@ int fdcap_time_blend_gemm(fdcap_ctx* c, int32_t rows, int32_t iters, float* ms, 
     hipEvent_t e0, e1;
     HIP_TRY(hipEventCreate(&e0));
     HIP_TRY(hipEventCreate(&e1));
-    HIP_TRY(gemm_f32(false, EPI_STORE, c->ws_f[6].p, NPFX, c->full.posedirs.p, c->full.ldp, c->ws_f[11].p, 3 * V, rows, 3 * V, NPFX, nullptr, 0, st));
+    HIP_TRY(panel_gemm(c->ws_f[6].p, NPFX, rows, NPFX, c->full.pn_fwd, c->ws_f[11].p, 3 * V, 3 * V, st));
     HIP_TRY(hipEventRecord(e0, st));
     for (int i = 0; i < iters; ++i)
-        HIP_TRY(gemm_f32(false, EPI_STORE, c->ws_f[6].p, NPFX, c->full.posedirs.p, c->full.ldp, c->ws_f[11].p, 3 * V, rows, 3 * V, NPFX, nullptr, 0, st));
+        HIP_TRY(panel_gemm(c->ws_f[6].p, NPFX, rows, NPFX, c->full.pn_fwd, c->ws_f[11].p, 3 * V, 3 * V, st));
     HIP_TRY(hipEventRecord(e1, st));
     HIP_TRY(hipEventSynchronize(e1));
     float t = 0.f;
@@ -1907,12 +1965,14 @@ int fdcap_opt_time_chamfer(fdcap_ctx* c, int32_t iters, int32_t brute_force, flo
     const int nsp = brute_force ? o->nsplit_bf : o->nsplit;
     float4* sp = brute_force ? nullptr : o->seedpt.p + 2 * nc;
     // (warm-up launch; after a brute-force launch rewrote idx it also refreshes the neighbours' coordinates)
+    const NNCache cache = o->nn_cache(0);
+    const NNCache* cp = !brute_force ? &cache : nullptr;
     HIP_TRY(nn_search(o->Vw.p + off, nl * nc, T, o->dist.p + 2 * nc, o->idx.p + 2 * nc, o->pd.p, o->pi.p, nsp, st, seed,
-                      !brute_force && !o->seeded, sp));
+                      !brute_force && !o->seeded, sp, nullptr, cp));
     if (!brute_force) o->seeded = true;
     HIP_TRY(hipEventRecord(e0, st));
     for (int i = 0; i < iters; ++i)
-        HIP_TRY(nn_search(o->Vw.p + off, nl * nc, T, o->dist.p + 2 * nc, o->idx.p + 2 * nc, o->pd.p, o->pi.p, nsp, st, seed, false, sp));
+        HIP_TRY(nn_search(o->Vw.p + off, nl * nc, T, o->dist.p + 2 * nc, o->idx.p + 2 * nc, o->pd.p, o->pi.p, nsp, st, seed, false, sp, nullptr, cp));
     HIP_TRY(hipEventRecord(e1, st));
     HIP_TRY(hipEventSynchronize(e1));
     float t = 0.f;

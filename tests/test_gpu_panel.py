@@ -24,6 +24,7 @@ pytestmark = pytest.mark.gpu
     (130, 1500, 496, True, 0),          # its data gradient (transposed operand), shard-sized M
     (70, 2100, 40, False, 5),           # K beyond one LDS slab
     (1028, 32, 512, True, 0), (257, 126, 512, False, 2),
+    (130, 496, 13001, False, 0),        # wide output: four row blocks per fragment stream, column-block-major workgroup order
 ])
 def test_panel_gemm_matches_fp64(M, K, N, transposed, pad):
     lib = capi.load_library()

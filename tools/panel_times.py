@@ -32,7 +32,7 @@ torch.cuda.synchronize()
 report("vposer_fwd (stage | L1 | L2 | L3)", stamps(256, 5))
 raw.fdcap_debug_panel_reset()
 rng = np.random.default_rng(0)
-for (M, K, N) in ((rows, 496, 1500), (rows, 1500, 496)):
+for (M, K, N) in ((rows, 496, 1500), (rows, 1500, 496), (rows, 496, 31425)):
     A = torch.randn(M, K, device="cuda"); B = rng.standard_normal((K, N)).astype(np.float32); C = torch.empty(M, N, device="cuda")
     for _ in range(3):
         capi.check(lib.fdcap_panel_gemm(capi.dptr(A), K, M, K, B.ctypes.data_as(ctypes.c_void_p), N, 1, N, capi.dptr(C), N, capi.current_stream()), "g")
