@@ -13,6 +13,10 @@
 #pragma once
 #include "fdc_math.h"
 
+#ifndef FDC_FR_STAMP
+#define FDC_FR_STAMP(w, i)      // instrumentation hook (timing builds of the GPU library only)
+#endif
+
 namespace fdc {
 
 constexpr int NJ = 55;          // SMPL-X joints
@@ -50,6 +54,8 @@ struct alignas(16) PoseScratch {   // rows padded to 16 B multiples so a joint's
     float dMj[NJW][12];
     float dTj[NJW][3];
     float daa[2][45];
+    float red[6][NBETA];  // partial d betas (joints j = part, part + 6, ...)
+    float dMs[12];        // d world matrix, summed over the joints
 };
 
 FDC_HD M3 load_m3(const float* p) { M3 r; for (int i = 0; i < 9; ++i) r.m[i] = p[i]; return r; }
@@ -90,6 +96,7 @@ FDC_HD void pose_forward(const PoseModel& pm, const float* x, const float* o, co
                          float scale, PoseScratch& sc, float* Rm, float* PF, float* Jrest, float* G,
                          float* A, float* M, float* Jw, int tid, int nthr, Sync sync,
                          const float* aa22 = nullptr) {
+    FDC_FR_STAMP(0, 1);
     for (int j = tid; j < NJ; j += nthr) {
         M3 R;
         // aa22 (operator-level API only): global_orient + 21 body joints given as axis-angle
@@ -106,6 +113,7 @@ FDC_HD void pose_forward(const PoseModel& pm, const float* x, const float* o, co
         }
     }
     sync();
+    FDC_FR_STAMP(0, 2);
     for (int L = 0; L < pm.nlevels; ++L) {
         for (int k = pm.level_start[L] + tid; k < pm.level_start[L + 1]; k += nthr) {
             int j = pm.order[k];
@@ -122,6 +130,7 @@ FDC_HD void pose_forward(const PoseModel& pm, const float* x, const float* o, co
         }
         sync();
     }
+    FDC_FR_STAMP(0, 3);
     M3 MR; V3 Mt;
     world_matrix(cam_ext, x, scale, &MR, &Mt);
     V3 transl = v3(x[X_TRANSL], x[X_TRANSL + 1], x[X_TRANSL + 2]);
@@ -141,6 +150,7 @@ FDC_HD void pose_forward(const PoseModel& pm, const float* x, const float* o, co
         }
     }
     if (M && tid == 0) g_store(M, MR, Mt);
+    FDC_FR_STAMP(0, 4);
 }
 
 // Backward for one frame.
@@ -155,6 +165,7 @@ FDC_HD void pose_backward(const PoseModel& pm, const float* x, const float* o, c
                           const float* dsv, const float* dbeta_v, const float* dtransl_v,
                           PoseScratch& sc, float* dx, float* dO, float* dcam_ext, float* dscale,
                           int tid, int nthr, Sync sync) {
+    FDC_FR_STAMP(1, 1);
     M3 MR; V3 Mt;
     world_matrix(cam_ext, x, scale, &MR, &Mt);
     V3 transl = v3(x[X_TRANSL], x[X_TRANSL + 1], x[X_TRANSL + 2]);
@@ -189,6 +200,7 @@ FDC_HD void pose_backward(const PoseModel& pm, const float* x, const float* o, c
         sc.dJ[j][0] = dJ.x; sc.dJ[j][1] = dJ.y; sc.dJ[j][2] = dJ.z;
     }
     sync();
+    FDC_FR_STAMP(1, 2);
     // Reverse chain.  With G_c.R = G_p.R R_c and G_c.t = G_p.R (J_c - J_p) + G_p.t, a joint's total gradient is a sum
     // over its subtree that factors through the WORLD transforms of the forward pass:
     //     dG_p.t = sum_{d in sub(p)} g_d.t
@@ -216,6 +228,7 @@ FDC_HD void pose_backward(const PoseModel& pm, const float* x, const float* o, c
         }
         sync();
     }
+    FDC_FR_STAMP(1, 3);
     // subtree sums -> the joint's total gradient -> what it hands to its local rotation and offset (dR, drel)
     for (int c = tid; c < NJ; c += nthr) {
         M3 SU = g_rot(sc.dG[c]);
@@ -235,6 +248,7 @@ FDC_HD void pose_backward(const PoseModel& pm, const float* x, const float* o, c
     }
     for (int i = tid; i < 90; i += nthr) (&sc.daa[0][0])[i] = 0.f;
     sync();
+    FDC_FR_STAMP(1, 4);
     for (int j = tid; j < NJ; j += nthr) {
         // rel_j = J_j - J_parent
         V3 dJ = v3(sc.dJ[j][0] + sc.drel[j][0], sc.dJ[j][1] + sc.drel[j][1], sc.dJ[j][2] + sc.drel[j][2]);
@@ -259,12 +273,28 @@ FDC_HD void pose_backward(const PoseModel& pm, const float* x, const float* o, c
         }
     }
     sync();
-    // small per-frame reductions, one output element per thread, fixed summation order
+    FDC_FR_STAMP(1, 5);
+    // small per-frame reductions with a fixed summation order, in two steps so that no thread walks more than ~30 terms
+    // (one output element per thread made thread t < 10 sum 165 products for d betas and one thread 276 terms for d M)
+    for (int t = tid; t < 6 * NBETA + 12; t += nthr) {
+        if (t < 6 * NBETA) {
+            const int part = t / NBETA, b = t % NBETA;
+            float acc = 0.f;
+            for (int j = part; j < NJ; j += 6)
+                for (int c = 0; c < 3; ++c) acc += pm.Jd[(3 * j + c) * NBETA + b] * sc.dJ[j][c];
+            sc.red[part][b] = acc;
+        } else {
+            const int e = t - 6 * NBETA;
+            float acc = dMv ? dMv[e] : 0.f;
+            for (int j = 0; j < NJW; ++j) acc += sc.dMj[j][e];
+            sc.dMs[e] = acc;
+        }
+    }
+    sync();
     for (int t = tid; t < 64; t += nthr) {
         if (t < NBETA) {
             float acc = dbeta_v ? dbeta_v[t] : 0.f;
-            for (int j = 0; j < NJ; ++j)
-                for (int c = 0; c < 3; ++c) acc += pm.Jd[(3 * j + c) * NBETA + t] * sc.dJ[j][c];
+            for (int part = 0; part < 6; ++part) acc += sc.red[part][t];
             dx[X_BETAS + t] += acc;
         } else if (t < NBETA + 24) {
             int i = t - NBETA, h = i / 12, ii = i % 12;
@@ -278,14 +308,8 @@ FDC_HD void pose_backward(const PoseModel& pm, const float* x, const float* o, c
             for (int j = 0; j < NJW; ++j) acc += sc.dTj[j][c];
             dx[X_TRANSL + c] += acc;
         } else if (t == NBETA + 24 + 3) {
-            float dM[12];
-            for (int e = 0; e < 12; ++e) {
-                float acc = dMv ? dMv[e] : 0.f;
-                for (int j = 0; j < NJW; ++j) acc += sc.dMj[j][e];
-                dM[e] = acc;
-            }
-            M3 dMR = g_rot(dM);
-            V3 dMt = g_trn(dM);
+            M3 dMR = g_rot(sc.dMs);
+            V3 dMt = g_trn(sc.dMs);
             V3 ct = v3(x[X_CAMT], x[X_CAMT + 1], x[X_CAMT + 2]);
             M3 dER = dMR;
             m3_add_outer(dER, dMt, scale * ct);           // M.t = E.R (s ct) + E.t
@@ -296,6 +320,7 @@ FDC_HD void pose_backward(const PoseModel& pm, const float* x, const float* o, c
             dcam_ext[12] = dcam_ext[13] = dcam_ext[14] = dcam_ext[15] = 0.f;   // bottom row never used
         }
     }
+    FDC_FR_STAMP(1, 6);
 }
 
 }  // namespace fdc

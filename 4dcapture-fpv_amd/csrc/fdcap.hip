@@ -8,6 +8,11 @@
 #include <algorithm>
 #include <vector>
 
+#ifdef FDC_PN_TIMING
+// instrumentation build only: per-frame s_memtime stamps of the pose kernels [which][block][8]
+__device__ unsigned long long g_fr_times[2][2048 * 8];
+#define FDC_FR_STAMP(w, i) do { if (threadIdx.x == 0 && blockIdx.x < 2048) g_fr_times[w][blockIdx.x * 8 + (i)] = __builtin_amdgcn_s_memtime(); } while (0)
+#endif
 #include "../../include/fdcap.h"
 #include "fdc_chamfer.h"
 #include "fdc_dct.h"
@@ -38,16 +43,60 @@ struct SyncBlock {
 // kernels
 // ------------------------------------------------------------------------------------------
 
-// The kinematic tree's index arrays, staged in LDS once per workgroup: the level loops of pose_forward / pose_backward
-// chase level_start -> order -> parents -> child lists, and from global memory every hop is a dependent load (~30 per frame).
-struct PoseTopo { int parents[NJ], order[NJ], level_start[MAX_LEVELS + 1], child_start[NJ + 1], child_list[NJ]; };
-__device__ __forceinline__ PoseModel stage_topology(const PoseModel& pm, PoseTopo& t) {
+// Everything a frame's pose kernels read besides their per-joint state, staged in LDS by ONE batch of loads at kernel start:
+// the kinematic tree's index arrays (the level loops chase level_start -> order -> parents -> child lists: ~30 dependent
+// hops per frame from global memory), the collapsed joint regressor Jt / Jd, the hand PCA basis, and this frame's parameter
+// row, camera row and scale.  Measured per frame (s_memtime): the phases that read these tables straight from global memory
+// took 5.5 k (forward: rotations + joints), 6.5 k (backward: rotation gradients) and 14 k cycles (backward: the serial
+// reductions over Jd / the PCA basis) of 25 k / 42 k-cycle kernels.
+struct alignas(16) PoseStage {
+    float Jd[NJ * 3 * NBETA + 2];   // 1650 (+ padding: the arrays below stay 16-byte aligned)
+    float hand_comp[2 * 12 * 45];   // 1080
+    float Jt[NJ * 3 + 3];           // 165
+    float hand_mean[90 + 2];
+    float x[XDIM + 2];
+    float cam[16];
+    int parents[NJ + 1], order[NJ + 1], level_start[MAX_LEVELS + 4], child_start[NJ + 1], child_list[NJ + 1];
+};
+__device__ __forceinline__ PoseModel stage_pose(const PoseModel& pm, PoseStage& t, const float* __restrict__ xrow,
+                                                const float* __restrict__ camrow) {
+    // 64 threads (one wave).  Every load is issued before the first LDS write (two unrolled passes): written as
+    // load-store loops the compiler waits for each trip's load before the next is issued -- 7 serial L2 round trips
+    // (measured 16 k cycles for this prologue instead of ~3 k).  Device allocations are 256-byte aligned: 16-byte loads.
     const int tid = threadIdx.x;
-    if (tid < NJ) { t.parents[tid] = pm.parents[tid]; t.order[tid] = pm.order[tid]; t.child_list[tid] = tid < NJ - 1 ? pm.child_list[tid] : 0; }
-    if (tid <= NJ) t.child_start[tid] = pm.child_start[tid];
-    if (tid <= pm.nlevels && tid <= MAX_LEVELS) t.level_start[tid] = pm.level_start[tid];
+    constexpr int NJD4 = (NJ * 3 * NBETA) / 4, NHC4 = (2 * 12 * 45) / 4;      // 412, 270
+    constexpr int KJD = (NJD4 + 63) / 64, KHC = (NHC4 + 63) / 64;             // 7, 5
+    float4 vj[KJD], vh[KHC];
+    float vt[3], vm[2], vx[2];
+#pragma unroll
+    for (int k = 0; k < KJD; ++k) { const int i = tid + 64 * k; vj[k] = i < NJD4 ? ((const float4*)pm.Jd)[i] : make_float4(0.f, 0.f, 0.f, 0.f); }
+#pragma unroll
+    for (int k = 0; k < KHC; ++k) { const int i = tid + 64 * k; vh[k] = i < NHC4 ? ((const float4*)pm.hand_comp)[i] : make_float4(0.f, 0.f, 0.f, 0.f); }
+#pragma unroll
+    for (int k = 0; k < 3; ++k) { const int i = tid + 64 * k; vt[k] = i < NJ * 3 ? pm.Jt[i] : 0.f; }
+#pragma unroll
+    for (int k = 0; k < 2; ++k) { const int i = tid + 64 * k; vm[k] = i < 90 ? pm.hand_mean[i] : 0.f; vx[k] = i < XDIM ? xrow[i] : 0.f; }
+    const float vjd_tail = tid < (NJ * 3 * NBETA) % 4 ? pm.Jd[NJD4 * 4 + tid] : 0.f;
+    const float vcam = tid < 16 ? camrow[tid] : 0.f;
+    const int ip = tid < NJ ? pm.parents[tid] : 0, io = tid < NJ ? pm.order[tid] : 0, icl = tid < NJ - 1 ? pm.child_list[tid] : 0;
+    const int ics = tid <= NJ ? pm.child_start[tid] : 0;
+    const int ils = (tid <= pm.nlevels && tid <= MAX_LEVELS) ? pm.level_start[tid] : 0;
+#pragma unroll
+    for (int k = 0; k < KJD; ++k) { const int i = tid + 64 * k; if (i < NJD4) ((float4*)t.Jd)[i] = vj[k]; }
+#pragma unroll
+    for (int k = 0; k < KHC; ++k) { const int i = tid + 64 * k; if (i < NHC4) ((float4*)t.hand_comp)[i] = vh[k]; }
+#pragma unroll
+    for (int k = 0; k < 3; ++k) { const int i = tid + 64 * k; if (i < NJ * 3) t.Jt[i] = vt[k]; }
+#pragma unroll
+    for (int k = 0; k < 2; ++k) { const int i = tid + 64 * k; if (i < 90) t.hand_mean[i] = vm[k]; if (i < XDIM) t.x[i] = vx[k]; }
+    if (tid < (NJ * 3 * NBETA) % 4) t.Jd[NJD4 * 4 + tid] = vjd_tail;
+    if (tid < 16) t.cam[tid] = vcam;
+    if (tid < NJ) { t.parents[tid] = ip; t.order[tid] = io; t.child_list[tid] = icl; }
+    if (tid <= NJ) t.child_start[tid] = ics;
+    if (tid <= pm.nlevels && tid <= MAX_LEVELS) t.level_start[tid] = ils;
     __syncthreads();
     PoseModel l = pm;
+    l.Jd = t.Jd; l.Jt = t.Jt; l.hand_comp = t.hand_comp; l.hand_mean = t.hand_mean;
     l.parents = t.parents; l.order = t.order; l.level_start = t.level_start; l.child_start = t.child_start; l.child_list = t.child_list;
     return l;
 }
@@ -62,8 +111,9 @@ __global__ __launch_bounds__(64) void pose_fwd_kernel(PoseModel pm, const float*
                                                       float* M, float* Jw, const float* AA, const float* __restrict__ Opart,
                                                       size_t part_stride) {
     __shared__ PoseScratch sc;
-    __shared__ PoseTopo topo;
+    __shared__ PoseStage stg;
     __shared__ float s_O[ODIM + 2];
+    FDC_FR_STAMP(0, 0);
     int r = row0 + blockIdx.x;
     if (PARTS) {
         for (int e = threadIdx.x; e < ODIM; e += 64) {
@@ -72,16 +122,17 @@ __global__ __launch_bounds__(64) void pose_fwd_kernel(PoseModel pm, const float*
             O[(size_t)r * ODIM + e] = v;
         }
     }
-    const PoseModel pml = stage_topology(pm, topo);               // (its barrier also publishes s_O)
-    if (PF && threadIdx.x < NBETA) PF[(size_t)r * NPFX + NPF + threadIdx.x] = X[(size_t)r * XDIM + X_BETAS + threadIdx.x];
+    const float sc_v = *scale;
+    const PoseModel pml = stage_pose(pm, stg, X + (size_t)r * XDIM, CAM + (size_t)r * 16);   // (its barrier also publishes s_O)
+    if (PF && threadIdx.x < NBETA) PF[(size_t)r * NPFX + NPF + threadIdx.x] = stg.x[X_BETAS + threadIdx.x];
     if (PARTS) {
-        pose_forward(pml, X + (size_t)r * XDIM, s_O, CAM + (size_t)r * 16, *scale, sc,
+        pose_forward(pml, stg.x, s_O, stg.cam, sc_v, sc,
                      Rm ? Rm + (size_t)r * NJ * 9 : nullptr, PF ? PF + (size_t)r * NPFX : nullptr,
                      Jrest ? Jrest + (size_t)r * NJ * 3 : nullptr, G ? G + (size_t)r * NJ * 12 : nullptr,
                      A ? A + (size_t)r * NJ * 12 : nullptr, M ? M + (size_t)r * 12 : nullptr,
                      Jw ? Jw + (size_t)r * NJW * 3 : nullptr, threadIdx.x, 64, SyncBlock(), nullptr);
     } else {
-        pose_forward(pml, X + (size_t)r * XDIM, O ? O + (size_t)r * ODIM : nullptr, CAM + (size_t)r * 16, *scale, sc,
+        pose_forward(pml, stg.x, O ? O + (size_t)r * ODIM : nullptr, stg.cam, sc_v, sc,
                      Rm ? Rm + (size_t)r * NJ * 9 : nullptr, PF ? PF + (size_t)r * NPFX : nullptr,
                      Jrest ? Jrest + (size_t)r * NJ * 3 : nullptr, G ? G + (size_t)r * NJ * 12 : nullptr,
                      A ? A + (size_t)r * NJ * 12 : nullptr, M ? M + (size_t)r * 12 : nullptr,
@@ -101,10 +152,12 @@ __global__ __launch_bounds__(64) void pose_bwd_kernel(PoseModel pm, const float*
                                                       int dbeta_stride, const float* dtransl_v, float* dX, float* dO,
                                                       float* dCAM, float* dscale_row, ParamLossIn pl) {
     __shared__ PoseScratch sc;
-    __shared__ PoseTopo topo;
+    __shared__ PoseStage stg;
     __shared__ float s_dJw[NJW * 3];
-    const PoseModel pml = stage_topology(pm, topo);
+    FDC_FR_STAMP(1, 0);
     int r = row0 + blockIdx.x;
+    const float sc_v = *scale;
+    const PoseModel pml = stage_pose(pm, stg, X + (size_t)r * XDIM, CAM + (size_t)r * 16);
     if (pl.X0) {
         // param_loss_kernel's gradients formed here (non-logging iterations): dX row (=) data + temporal terms on the raw
         // rows, world-smoothing gradient of this frame's joints into LDS instead of a round trip through dJw
@@ -126,7 +179,7 @@ __global__ __launch_bounds__(64) void pose_bwd_kernel(PoseModel pm, const float*
         __syncthreads();
     }
     const float* dJw_row = (pl.X0 && pl.world_grad) ? s_dJw : (dJw ? dJw + (size_t)r * NJW * 3 : nullptr);
-    pose_backward(pml, X + (size_t)r * XDIM, O + (size_t)r * ODIM, CAM + (size_t)r * 16, *scale,
+    pose_backward(pml, stg.x, O + (size_t)r * ODIM, stg.cam, sc_v,
                   Rm + (size_t)r * NJ * 9, Jrest + (size_t)r * NJ * 3, G + (size_t)r * NJ * 12,
                   dA ? dA + (size_t)r * NJ * 12 : nullptr, dPF ? dPF + (size_t)r * NPFX : nullptr,
                   dJw_row, dMv ? dMv + (size_t)r * 12 : nullptr,
@@ -919,6 +972,11 @@ int fdcap_debug_nn_timeline(unsigned long long* out, int n) {
 }
 #endif
 #ifdef FDC_PN_TIMING
+int fdcap_debug_frame_times(unsigned long long* out) {
+    HIP_TRY(hipDeviceSynchronize());
+    HIP_TRY(hipMemcpyFromSymbol(out, HIP_SYMBOL(g_fr_times), sizeof(unsigned long long) * 2 * 2048 * 8));
+    return 0;
+}
 int fdcap_debug_panel_reset(void) {
     HIP_TRY(hipDeviceSynchronize());
     static std::vector<unsigned long long> z(8192 * 8, 0ull);
