@@ -515,28 +515,48 @@ struct NNCache {
 constexpr int NN_LPT_MAXSEG = 8192;
 __global__ __launch_bounds__(1024) void nn_lpt_sort_kernel(const unsigned* __restrict__ cost, int* __restrict__ order, int per_xcd, int nwg) {
     __shared__ unsigned short s_rank[NN_LPT_MAXSEG];
+    __shared__ __attribute__((aligned(16))) unsigned s_cost[NN_LPT_MAXSEG + 4];
+    __shared__ int s_wsum[16];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int base = blockIdx.x * per_xcd;
     const int n = max(0, min(per_xcd, nwg - base));              // valid workgroups of this segment
     const int K = min(n, max(8, n / 16));
-    for (int e = threadIdx.x; e < n; e += 1024) {
-        const unsigned c = cost[base + e];
+    const int n4 = (n + 3) & ~3;
+    for (int e = tid; e < n4; e += 1024) s_cost[e] = e < n ? cost[base + e] : 0u;    // (padding never outranks: cost 0, index >= n)
+    __syncthreads();
+    // rank = number of workgroups that go before e (higher cost; ties: lower id).  16-byte broadcast reads, four compares
+    // per LDS round trip (one 4-byte read per compare made the launch 40 us: every trip waited for its own read)
+    for (int e = tid; e < n; e += 1024) {
+        const unsigned c = s_cost[e];
         int rank = 0;
-        for (int o = 0; o < n; ++o) {
-            const unsigned co = cost[base + o];
-            rank += (co > c) || (co == c && o < e);
+        for (int o = 0; o < n4; o += 4) {
+            const uint4 co = *(const uint4*)(s_cost + o);
+            rank += (co.x > c) || (co.x == c && o < e);
+            rank += (co.y > c) || (co.y == c && o + 1 < e);
+            rank += (co.z > c) || (co.z == c && o + 2 < e);
+            rank += (co.w > c) || (co.w == c && o + 3 < e);
         }
         s_rank[e] = (unsigned short)rank;
     }
     __syncthreads();
-    for (int e = threadIdx.x; e < per_xcd; e += 1024) {
-        if (e >= n) { order[base + e] = base + e; continue; }   // idle slots keep their place at the end
-        const int r = s_rank[e];
-        int pos = r;
-        if (r >= K) {
-            pos = K;
-            for (int o = 0; o < e; ++o) pos += s_rank[o] >= K;
-        }
-        order[base + pos] = base + e;
+    // the K costliest go to position rank; the others follow in natural order: K + (exclusive prefix count of "not in the top K")
+    int running = 0;
+    for (int c0 = 0; c0 < per_xcd; c0 += 1024) {
+        const int e = c0 + tid;
+        const bool valid = e < n;
+        const int r = valid ? (int)s_rank[e] : 0;
+        const bool rest = valid && r >= K;
+        const unsigned long long m = __ballot(rest);
+        if (lane == 0) s_wsum[wave] = __popcll(m);
+        __syncthreads();
+        int before = running;
+        for (int w = 0; w < wave; ++w) before += s_wsum[w];
+        int total = 0;
+        for (int w = 0; w < 16; ++w) total += s_wsum[w];
+        if (valid) order[base + (rest ? K + before + __popcll(m & ((1ull << lane) - 1ull)) : r)] = base + e;
+        else if (e < per_xcd) order[base + e] = base + e;        // idle slots keep their place at the end
+        running += total;
+        __syncthreads();
     }
 }
 

@@ -37,6 +37,7 @@ struct PoseModel {
     const int* level_start;   // [nlevels+1] ranges into order
     const int* child_start;   // [56] CSR of children
     const int* child_list;    // [54]
+    const int* depth = nullptr;   // [55] level of each joint (optional: enables the lane-resident chains of the GPU kernels)
     const float* hand_comp;   // [2,12,45]
     const float* hand_mean;   // [2,45]
     int nlevels;
@@ -114,6 +115,31 @@ FDC_HD void pose_forward(const PoseModel& pm, const float* x, const float* o, co
     }
     sync();
     FDC_FR_STAMP(0, 2);
+#if defined(__HIP_DEVICE_COMPILE__)
+    if (nthr == 64 && pm.depth != nullptr) {
+        // One wave per frame, lane j = joint j: the joint's rotation, rest position, parent and level stay in registers and
+        // a level costs one hand-over through LDS (read the parent's transform, write one's own) -- the generic loop below
+        // re-reads level_start -> order -> parents -> R / J from LDS at every level (measured 970 cycles per level, ten levels).
+        // A wave's LDS operations execute in order, so between levels a compiler-only barrier is enough.
+        const int j = tid;
+        const bool act = j < NJ;
+        const int p = act ? pm.parents[j] : -1, dep = act ? pm.depth[j] : -1;
+        const M3 R = act ? load_m3(sc.R[j]) : m3_identity();
+        const V3 Jj = act ? v3(sc.J[j][0], sc.J[j][1], sc.J[j][2]) : v3(0.f, 0.f, 0.f);
+        const V3 rel = (act && p >= 0) ? Jj - v3(sc.J[p][0], sc.J[p][1], sc.J[p][2]) : Jj;
+        for (int L = 0; L < pm.nlevels; ++L) {
+            if (dep == L) {
+                if (p < 0) g_store(sc.G[j], R, Jj);
+                else {
+                    const M3 Rp = g_rot(sc.G[p]);
+                    g_store(sc.G[j], m3_mul(Rp, R), m3_vec(Rp, rel) + g_trn(sc.G[p]));
+                }
+            }
+            __builtin_amdgcn_wave_barrier();
+        }
+        sync();
+    } else
+#endif
     for (int L = 0; L < pm.nlevels; ++L) {
         for (int k = pm.level_start[L] + tid; k < pm.level_start[L + 1]; k += nthr) {
             int j = pm.order[k];
@@ -215,6 +241,33 @@ FDC_HD void pose_backward(const PoseModel& pm, const float* x, const float* o, c
         g_store(sc.dG[d], U, gt);
     }
     sync();
+#if defined(__HIP_DEVICE_COMPILE__)
+    if (nthr == 64 && pm.depth != nullptr) {
+        // lane p = joint p with its (at most five) children in registers: a level is "add the children's sums to one's own"
+        const int p = tid;
+        const bool act = p < NJ;
+        const int dep = act ? pm.depth[p] : -1;
+        const int c_lo = act ? pm.child_start[p] : 0, nch = act ? pm.child_start[p + 1] - c_lo : 0;
+        const int c0 = nch > 0 ? pm.child_list[c_lo] : 0, c1 = nch > 1 ? pm.child_list[c_lo + 1] : 0, c2 = nch > 2 ? pm.child_list[c_lo + 2] : 0;
+        const int c3 = nch > 3 ? pm.child_list[c_lo + 3] : 0, c4 = nch > 4 ? pm.child_list[c_lo + 4] : 0;
+        for (int L = pm.nlevels - 1; L >= 1; --L) {
+            if (dep == L - 1 && nch > 0) {
+                float acc[12];
+                for (int e = 0; e < 12; ++e) acc[e] = sc.dG[p][e];
+                for (int e = 0; e < 12; ++e) acc[e] += sc.dG[c0][e];
+                if (nch > 1) for (int e = 0; e < 12; ++e) acc[e] += sc.dG[c1][e];
+                if (nch > 2) for (int e = 0; e < 12; ++e) acc[e] += sc.dG[c2][e];
+                if (nch > 3) for (int e = 0; e < 12; ++e) acc[e] += sc.dG[c3][e];
+                if (nch > 4) for (int e = 0; e < 12; ++e) acc[e] += sc.dG[c4][e];
+                for (int ci = c_lo + 5; ci < c_lo + nch; ++ci)            // (no SMPL-X joint has more than five children)
+                    for (int e = 0; e < 12; ++e) acc[e] += sc.dG[pm.child_list[ci]][e];
+                for (int e = 0; e < 12; ++e) sc.dG[p][e] = acc[e];
+            }
+            __builtin_amdgcn_wave_barrier();
+        }
+        sync();
+    } else
+#endif
     for (int L = pm.nlevels - 1; L >= 1; --L) {
         for (int k = pm.level_start[L - 1] + tid; k < pm.level_start[L]; k += nthr) {
             int p = pm.order[k];

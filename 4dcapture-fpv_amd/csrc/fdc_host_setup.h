@@ -10,7 +10,7 @@ namespace fdc {
 
 struct HostPoseSetup {
     std::vector<float> Jt, Jd;                       // [55,3], [55,3,10]
-    std::vector<int> parents, order, level_start, child_start, child_list;
+    std::vector<int> parents, order, level_start, child_start, child_list, depth;
     int nlevels = 0;
 };
 
@@ -40,6 +40,7 @@ inline bool host_pose_setup(int V, const float* v_template, const float* shapedi
         if (d > NJ) return false;                    // cycle
         depth[j] = d;
     }
+    out->depth = depth;
     out->order.resize(NJ);
     for (int j = 0; j < NJ; ++j) out->order[j] = j;
     std::stable_sort(out->order.begin(), out->order.end(), [&](int a, int b) { return depth[a] < depth[b]; });

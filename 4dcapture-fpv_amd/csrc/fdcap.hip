@@ -56,7 +56,7 @@ struct alignas(16) PoseStage {
     float hand_mean[90 + 2];
     float x[XDIM + 2];
     float cam[16];
-    int parents[NJ + 1], order[NJ + 1], level_start[MAX_LEVELS + 4], child_start[NJ + 1], child_list[NJ + 1];
+    int parents[NJ + 1], order[NJ + 1], level_start[MAX_LEVELS + 4], child_start[NJ + 1], child_list[NJ + 1], depth[NJ + 1];
 };
 __device__ __forceinline__ PoseModel stage_pose(const PoseModel& pm, PoseStage& t, const float* __restrict__ xrow,
                                                 const float* __restrict__ camrow) {
@@ -79,6 +79,7 @@ __device__ __forceinline__ PoseModel stage_pose(const PoseModel& pm, PoseStage& 
     const float vjd_tail = tid < (NJ * 3 * NBETA) % 4 ? pm.Jd[NJD4 * 4 + tid] : 0.f;
     const float vcam = tid < 16 ? camrow[tid] : 0.f;
     const int ip = tid < NJ ? pm.parents[tid] : 0, io = tid < NJ ? pm.order[tid] : 0, icl = tid < NJ - 1 ? pm.child_list[tid] : 0;
+    const int idp = tid < NJ ? pm.depth[tid] : 0;
     const int ics = tid <= NJ ? pm.child_start[tid] : 0;
     const int ils = (tid <= pm.nlevels && tid <= MAX_LEVELS) ? pm.level_start[tid] : 0;
 #pragma unroll
@@ -91,13 +92,14 @@ __device__ __forceinline__ PoseModel stage_pose(const PoseModel& pm, PoseStage& 
     for (int k = 0; k < 2; ++k) { const int i = tid + 64 * k; if (i < 90) t.hand_mean[i] = vm[k]; if (i < XDIM) t.x[i] = vx[k]; }
     if (tid < (NJ * 3 * NBETA) % 4) t.Jd[NJD4 * 4 + tid] = vjd_tail;
     if (tid < 16) t.cam[tid] = vcam;
-    if (tid < NJ) { t.parents[tid] = ip; t.order[tid] = io; t.child_list[tid] = icl; }
+    if (tid < NJ) { t.parents[tid] = ip; t.order[tid] = io; t.child_list[tid] = icl; t.depth[tid] = idp; }
     if (tid <= NJ) t.child_start[tid] = ics;
     if (tid <= pm.nlevels && tid <= MAX_LEVELS) t.level_start[tid] = ils;
     __syncthreads();
     PoseModel l = pm;
     l.Jd = t.Jd; l.Jt = t.Jt; l.hand_comp = t.hand_comp; l.hand_mean = t.hand_mean;
     l.parents = t.parents; l.order = t.order; l.level_start = t.level_start; l.child_start = t.child_start; l.child_list = t.child_list;
+    l.depth = t.depth;
     return l;
 }
 
@@ -772,7 +774,7 @@ struct fdcap_ctx {
     std::vector<float> h_vt, h_S10, h_posedirs, h_lbs;
     // device constants
     DevBuf<float> Jt, Jd, hand_comp, hand_mean;
-    DevBuf<int> parents, order, level_start, child_start, child_list;
+    DevBuf<int> parents, order, level_start, child_start, child_list, depth;
     int nlevels = 0;
     DevBuf<float> W1, b1, W2, b2, W3, b3;
     DevBuf<float> vp_pn[6];            // decoder weights in MFMA fragment order: forward w1 w2 w3, backward w3t w2t w1t
@@ -810,7 +812,7 @@ struct fdcap_ctx {
         PoseModel pm;
         pm.Jt = Jt.p; pm.Jd = Jd.p; pm.parents = parents.p; pm.order = order.p; pm.level_start = level_start.p;
         pm.child_start = child_start.p; pm.child_list = child_list.p; pm.hand_comp = hand_comp.p;
-        pm.hand_mean = hand_mean.p; pm.nlevels = nlevels;
+        pm.hand_mean = hand_mean.p; pm.nlevels = nlevels; pm.depth = depth.p;
         return pm;
     }
 };
@@ -1030,6 +1032,7 @@ int fdcap_ctx_create(const fdcap_model_desc* md, fdcap_ctx** out) {
     UP(c->parents, parents.data(), parents.size()) UP(c->order, order.data(), order.size())
     UP(c->level_start, level_start.data(), level_start.size())
     UP(c->child_start, child_start.data(), child_start.size()) UP(c->child_list, child_list.data(), child_list.size())
+    UP(c->depth, hs.depth.data(), hs.depth.size())
     UP(c->hand_comp, hc.data(), hc.size()) UP(c->hand_mean, hm.data(), hm.size())
     UP(c->W1, md->vp_fc1_w, 512 * 32) UP(c->b1, md->vp_fc1_b, 512)
     UP(c->W2, md->vp_fc2_w, 512 * 512) UP(c->b2, md->vp_fc2_b, 512)
@@ -1062,7 +1065,7 @@ void fdcap_ctx_destroy(fdcap_ctx* c) {
     fdcap_opt_destroy(c);
     c->ws_adam.release();
     c->Jt.release(); c->Jd.release(); c->hand_comp.release(); c->hand_mean.release();
-    c->parents.release(); c->order.release(); c->level_start.release(); c->child_start.release(); c->child_list.release();
+    c->parents.release(); c->order.release(); c->level_start.release(); c->child_start.release(); c->child_list.release(); c->depth.release();
     c->W1.release(); c->b1.release(); c->W2.release(); c->b2.release(); c->W3.release(); c->b3.release();
     for (auto& b : c->vp_pn) b.release();
     c->full.release(); c->contact.release(); c->contact_vid.release(); c->contact_perm.release(); c->scene.release(); c->scene_sorted.release(); c->scene_bounds.release(); c->scene_sbounds.release(); c->scene_qbounds.release(); c->scene_inv.release(); c->scene_frags.release(); c->scene_centers.release();
@@ -1543,7 +1546,7 @@ static int opt_contact_forward(fdcap_ctx* c, hipStream_t st) {
     const NNCache cache = o->nn_cache(0);
     HIP_TRY(nn_search(o->Vw.p + off, nq, c->nn_target(o->use_cull), o->dist.p + 2 * nc, o->idx.p + 2 * nc, o->pd.p, o->pi.p,
                       o->nsplit, st, o->use_seed ? o->idx.p + 2 * nc : nullptr, !o->seeded, o->seedpt.p + 2 * nc, &o->nnpt_valid,
-                      &cache, (o->nn_launches++ & 15) == 2));                 // re-rank the dispatch order every 16 launches
+                      &cache, (o->nn_launches++ & 31) == 2));                 // re-rank the dispatch order every 32 launches (16 us each)
     o->seeded = true;
     return 0;
 }

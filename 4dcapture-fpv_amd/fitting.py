@@ -218,14 +218,21 @@ class FittingOP:
         multi = self.shard.world > 1 or (self.group is not None and os.environ.get("FDCAP_FORCE_EXCHANGE") == "1")
         if mode == "dct":
             self._dct_loops(lib, h, multi, log_every)
+        # The reference prints every loss term in every iteration (:573-575, :587-589) with five .item() syncs.  Here the
+        # partial sums of a logging iteration are copied into a device-side history row (no host sync inside the loop) and
+        # read back -- and, when sharded, all-reduced -- once after the last iteration.
+        n_log = 0
+        logged = []
+        if log_every and mode != "dct":
+            n_log = sum(1 for ii in range(self.num_iter) if ii % log_every == 0 or ii == self.num_iter - 1)
+            hist = torch.zeros(max(n_log, 1), capi.NUM_LOSSES, device=dev, dtype=torch.float64)
         for ii in range(self.num_iter if mode != "dct" else 0):                             # :560
             do_log = bool(log_every) and (ii % log_every == 0 or ii == self.num_iter - 1)
             st = capi.current_stream()
             capi.check(lib.fdcap_opt_backward(h, ii, P, 1 if do_log else 0, st), "fdcap_opt_backward")
             if do_log:
-                if multi:
-                    allreduce_scalars(self.shard, torch.zeros(1, device=dev), self._losses)
-                self._append_log(log, ii, ii >= P)
+                hist[len(logged)].copy_(self._losses, non_blocking=True)
+                logged.append(ii)
             if multi:
                 # one collective per iteration: boundary rows (after Adam) + the scale-gradient partial travel
                 # together; every rank then sums the partials in rank order and steps `scale` identically
@@ -235,6 +242,12 @@ class FittingOP:
                                                                self.shard.world, st), "unpack_and_step_scale")
             else:
                 capi.check(lib.fdcap_opt_step(h, ii, P, st), "fdcap_opt_step")
+        if logged:
+            if multi:
+                allreduce_scalars(self.shard, torch.zeros(1, device=dev), hist)
+            rows = hist.cpu().numpy()
+            for k, ii in enumerate(logged):
+                self._append_log(log, ii, ii >= P, rows[k])
         if mode == "local":
             self._local_second_loop(lib, h, multi, log_every)
         nl = self.shard.n_local
@@ -384,8 +397,8 @@ class FittingOP:
             if multi:
                 exchange_halos(self.shard, self._rows_x, self._rows_cam)
 
-    def _append_log(self, log, ii, phase2):
-        s = self._losses.cpu().numpy()
+    def _append_log(self, log, ii, phase2, s=None):
+        s = self._losses.cpu().numpy() if s is None else s
         N, nc = self.num_body, max(self.ctx.num_contact, 1)
         l_rec = self.weight_loss_rec * s[0] / (N * capi.XDIM)
         l_vp = self.weight_loss_vposer * s[1] / (N * 32)

@@ -357,6 +357,47 @@ def test_seeding_the_nn_bound_does_not_change_results():
     assert not torch.equal(res["11"][1][1], res["11"][2][1])     # the stale seeds really were stale
 
 
+@pytest.mark.parametrize("n,per_part", [(64, 40), (256, 200)])       # 5 k queries: four waves per group; 102 k: one (+ dispatch order)
+def test_kept_work_lists_and_dispatch_order_do_not_change_results(n, per_part):
+    """The in-loop NN launch keeps each group's work list (built with slack) while the queries stay inside the region it was
+    built for, and dispatches its costliest workgroups first (re-ranked every 32 launches).  Both only prune / reorder:
+    over a sequence of millimetre moves (lists kept), a 3 cm jump (lists rebuilt) and more small moves, every launch must
+    equal the launch without either, bit for bit."""
+    def run(slack, lpt):
+        os.environ["FDCAP_NN_CACHE_SLACK"] = slack
+        os.environ["FDCAP_NN_LPT"] = lpt
+        try:
+            fop, bm, vp, clip, scene, vid = _make_fop(n, 1000, 70_000, per_part, 8, seed=60)
+            x78 = torch.empty(n, 78, device="cuda")
+            capi.check(fop.ctx.lib.fdcap_params_75_to_78(capi.dptr(torch.tensor(clip.body_params).cuda()), n, capi.dptr(x78),
+                                                         capi.current_stream()), "75->78")
+            fop.init(x78)
+            g = torch.Generator(device="cuda").manual_seed(11)
+            out = []
+            for k in range(45):
+                step = 0.03 if k == 25 else 0.001
+                fop._rows_x[2:2 + n, 0:3] += step * torch.randn(n, 3, device="cuda", generator=g)
+                d = torch.empty(n, len(fop.vid), device="cuda")
+                i = torch.empty(n, len(fop.vid), device="cuda", dtype=torch.int32)
+                capi.check(fop.ctx.lib.fdcap_opt_forward_world(fop.ctx.handle, capi.dptr(torch.empty(n, len(fop.vid), 3, device="cuda")),
+                                                               None, capi.current_stream()), "fw")
+                capi.check(fop.ctx.lib.fdcap_opt_get_contact(fop.ctx.handle, capi.dptr(d), capi.dptr(i), capi.current_stream()), "gc")
+                out.append((d.clone(), i.clone()))
+            torch.cuda.synchronize()
+            fop.close()
+            return out
+        finally:
+            os.environ.pop("FDCAP_NN_CACHE_SLACK")
+            os.environ.pop("FDCAP_NN_LPT")
+
+    base = run("0", "0")
+    for slack, lpt in (("0.04", "1"), ("0.5", "1"), ("0.002", "0")):
+        got = run(slack, lpt)
+        for k, ((d0, i0), (d1, i1)) in enumerate(zip(base, got)):
+            assert torch.equal(d0, d1) and torch.equal(i0, i1), (slack, lpt, k)
+    assert not torch.equal(base[24][1], base[25][1])                 # the jump really changed neighbours
+
+
 def test_far_stale_seeds_overflow_the_work_list_and_stay_exact():
     """A seed is only an upper bound: after the bodies jump by metres every query's ball covers most of a 160k-point scene
     (313 k-d cells), more than a wave can list (ST4_MAXCELL = 256 chunks / ST4_MAXLIST = 768 quarter chunks), and the

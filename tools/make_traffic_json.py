@@ -19,7 +19,7 @@ def per_launch(db, counter, sub, skip):
 def main(fetch_db, write_db, out, skip=30):
     skip = int(skip)
     res = {"source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes, kernel-trace only) of `python3 bench.py --steps 1 "
-                     "--warmup 0 --iters 60 --no-cpu-baseline`; per-dispatch sums over XCDs, mean over the dispatches after the first "
+                     "--warmup 0 [--iters 60 in round 1] --no-cpu-baseline`; per-dispatch sums over XCDs, mean over the dispatches after the first "
                      f"{skip} (steady state) for the in-loop kernel, all dispatches for the brute-force launch",
            "correction": "gfx950: FETCH_SIZE x 1024 x 2 (KB; wide coalesced reads counted at half), WRITE_SIZE x 1024 (KB)"}
     for key, sub, sk in (("nn_in_loop", "nn_stream4", skip), ("nn_bruteforce", "nn_mfma_kernel", 0)):
