@@ -67,6 +67,25 @@ FDC_HD void g_store(float* g, const M3& R, V3 t) {
     for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) g[4 * i + j] = R.m[3 * i + j];
     g[3] = t.x; g[7] = t.y; g[11] = t.z;
 }
+// 12 floats at a 16-byte aligned address (rows of the per-frame [55,12] arrays): three 16-byte accesses on the GPU
+FDC_HD void store12(float* dst, const float* v) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    ((float4*)dst)[0] = make_float4(v[0], v[1], v[2], v[3]);
+    ((float4*)dst)[1] = make_float4(v[4], v[5], v[6], v[7]);
+    ((float4*)dst)[2] = make_float4(v[8], v[9], v[10], v[11]);
+#else
+    for (int e = 0; e < 12; ++e) dst[e] = v[e];
+#endif
+}
+FDC_HD void load12(float* v, const float* src) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    const float4 a = ((const float4*)src)[0], b = ((const float4*)src)[1], c = ((const float4*)src)[2];
+    v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w;
+    v[8] = c.x; v[9] = c.y; v[10] = c.z; v[11] = c.w;
+#else
+    for (int e = 0; e < 12; ++e) v[e] = src[e];
+#endif
+}
 
 FDC_HD V3 hand_aa(const PoseModel& pm, const float* x, int j) {
     int h = (j - 25) / 15, f = (j - 25) % 15;
@@ -164,8 +183,8 @@ FDC_HD void pose_forward(const PoseModel& pm, const float* x, const float* o, co
         M3 GR = g_rot(sc.G[j]);
         V3 Gt = g_trn(sc.G[j]);
         V3 Jj = v3(sc.J[j][0], sc.J[j][1], sc.J[j][2]);
-        if (A) g_store(A + 12 * j, GR, Gt - m3_vec(GR, Jj));
-        if (G) for (int e = 0; e < 12; ++e) G[12 * j + e] = sc.G[j][e];
+        if (A) { float a12[12]; g_store(a12, GR, Gt - m3_vec(GR, Jj)); store12(A + 12 * j, a12); }
+        if (G) store12(G + 12 * j, sc.G[j]);
         if (Rm) for (int e = 0; e < 9; ++e) Rm[9 * j + e] = sc.R[j][e];
         if (Jrest) for (int c = 0; c < 3; ++c) Jrest[3 * j + c] = sc.J[j][c];
         if (PF && j >= 1)
@@ -197,15 +216,17 @@ FDC_HD void pose_backward(const PoseModel& pm, const float* x, const float* o, c
     V3 transl = v3(x[X_TRANSL], x[X_TRANSL + 1], x[X_TRANSL + 2]);
     for (int j = tid; j < NJ; j += nthr) {
         for (int e = 0; e < 9; ++e) sc.R[j][e] = Rm[9 * j + e];
-        for (int e = 0; e < 12; ++e) sc.G[j][e] = G[12 * j + e];
+        { float g12[12]; load12(g12, G + 12 * j); for (int e = 0; e < 12; ++e) sc.G[j][e] = g12[e]; }
         for (int c = 0; c < 3; ++c) sc.J[j][c] = Jrest[3 * j + c];
         M3 GR = g_rot(sc.G[j]);
         V3 Jj = v3(sc.J[j][0], sc.J[j][1], sc.J[j][2]);
         M3 dGR = m3_zero();
         V3 dGt = v3(0, 0, 0), dJ = v3(0, 0, 0);
         if (dA) {
-            dGR = g_rot(dA + 12 * j);
-            V3 dAt = g_trn(dA + 12 * j);
+            float a12[12];
+            load12(a12, dA + 12 * j);
+            dGR = g_rot(a12);
+            V3 dAt = g_trn(a12);
             m3_add_outer(dGR, -1.f * dAt, Jj);          // A.t = G.t - G.R J
             dGt = dAt;
             dJ = -1.f * m3t_vec(GR, dAt);

@@ -10,8 +10,11 @@
 
 #ifdef FDC_PN_TIMING
 // instrumentation build only: per-frame s_memtime stamps of the pose kernels [which][block][8]
-__device__ unsigned long long g_fr_times[2][2048 * 8];
+__device__ unsigned long long g_fr_times[3][2048 * 8];
 #define FDC_FR_STAMP(w, i) do { if (threadIdx.x == 0 && blockIdx.x < 2048) g_fr_times[w][blockIdx.x * 8 + (i)] = __builtin_amdgcn_s_memtime(); } while (0)
+#endif
+#ifndef FDC_FR_STAMP
+#define FDC_FR_STAMP(w, i)
 #endif
 #include "../../include/fdcap.h"
 #include "fdc_chamfer.h"
@@ -241,6 +244,7 @@ __global__ __launch_bounds__(256) void skin_bwd_kernel(SkinModel sm, int nc, con
     __shared__ float sred[4][SKB_NACC];
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const int r = row0 + blockIdx.x;
+    FDC_FR_STAMP(2, 0);
     const float* x = X + (size_t)r * XDIM;
     const float s = *scale;
     V3 transl = v3(x[X_TRANSL], x[X_TRANSL + 1], x[X_TRANSL + 2]);
@@ -254,6 +258,7 @@ __global__ __launch_bounds__(256) void skin_bwd_kernel(SkinModel sm, int nc, con
     for (int i = 0; i < SKB_NACC; ++i) acc[i] = 0.f;
     for (int i = tid; i < NJ * 12; i += 256) sdA[i] = 0.f;
     __syncthreads();
+    FDC_FR_STAMP(2, 1);
     for (int c0 = 0; c0 < nc; c0 += VCH) {
         const int c1 = min(nc, c0 + VCH);
         for (int c = c0 + tid; c < c1; c += 256) {
@@ -295,6 +300,7 @@ __global__ __launch_bounds__(256) void skin_bwd_kernel(SkinModel sm, int nc, con
             for (int e = 0; e < 12; ++e) sdT[(c - c0) * 12 + e] = b.dT[e];
         }
         __syncthreads();
+        FDC_FR_STAMP(2, 2);
         // dA_j += sum_v w_vj dT_v, ordered and atomic-free (run-to-run reproducible): the joints are dealt
         // to the 4 waves; a wave's lanes stride over joint j's vertex list (ascending, restricted to this
         // chunk by two binary searches) and are combined by a butterfly
@@ -330,6 +336,7 @@ __global__ __launch_bounds__(256) void skin_bwd_kernel(SkinModel sm, int nc, con
         }
         __syncthreads();
     }
+    FDC_FR_STAMP(2, 3);
 #pragma unroll
     for (int i = 0; i < SKB_NACC; ++i) {
         float v = wave_sum(acc[i]);
@@ -351,6 +358,169 @@ __global__ __launch_bounds__(256) void skin_bwd_kernel(SkinModel sm, int nc, con
         else if (tid < NBETA + 15) dMv[(size_t)r * 12 + tid - NBETA - 3] = v;
         else dsv[r] = v;
     }
+    FDC_FR_STAMP(2, 4);
+}
+
+// Contact-set form of skin_bwd_kernel<true> (vertex sets of at most SKS_MAXV vertices / SKS_MAXNNZ skinning weights: the
+// optimiser loop's 500 contact vertices).  Same arithmetic per vertex; what differs is where the time went (s_memtime,
+// 41 k cycles per frame: vertex loop 16.5 k, dA reduction 16.2 k):
+//   * the transposed weight lists (static) are staged in LDS at kernel start -- the reduction read them from global memory
+//     joint by joint, a dependent L2 round trip per 64 entries in front of every wave sum;
+//   * dT_v = [gv (x) vp | gv] has rank one: the vertex phase leaves gv and vp (6 floats) in LDS, not the 12 products;
+//   * a thread's vertices (nc / 256 <= 4) are loaded in one batch before the first is processed.
+// The dA sums run joint by joint over ascending vertices with the same wave-sum tree: run-to-run reproducible.
+// (VPT vertices and KC weight-list entries per thread in registers: 130 VGPRs for 4 / 16 cost a wave per SIMD -- the launch
+// then needs a second generation of workgroups; the loop's 500 vertices / 2000 weights take the 2 / 8 instance)
+constexpr int SKS_MAXV = 1024, SKS_MAXNNZ = 4096;
+template <int SKS_VPT, int SKS_KC>
+__global__ __launch_bounds__(256) void skin_bwd_small_kernel(SkinModel sm, int nc, int nnz, const float* __restrict__ X,
+                                                             const float* __restrict__ Voff, const float* __restrict__ A,
+                                                             const float* __restrict__ M, const float* __restrict__ scale,
+                                                             int row0, float* __restrict__ dVoff, float* __restrict__ dA,
+                                                             float* __restrict__ dtransl_v, float* __restrict__ dMv,
+                                                             float* __restrict__ dsv, ContactGradIn cg) {
+    extern __shared__ __attribute__((aligned(16))) float sk_lds[];
+    // dynamic: sGV [nc][3] | sVP [nc][3] | csc_w [nnz] | csc_v [nnz] (ushort)
+    float* const sGV = sk_lds;
+    float* const sVP = sGV + 3 * nc;
+    float* const sCW = sVP + 3 * nc;
+    unsigned short* const sCV = (unsigned short*)(sCW + nnz);
+    __shared__ float sAf[NJ * 12];
+    __shared__ float sdA[NJ * 12];
+    __shared__ float sred[4][SKB_NACC];
+    __shared__ int sCS[NJ + 1];
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int r = row0 + blockIdx.x;
+    FDC_FR_STAMP(2, 0);
+    const float* x = X + (size_t)r * XDIM;
+    const float s = *scale;
+    const V3 transl = v3(x[X_TRANSL], x[X_TRANSL + 1], x[X_TRANSL + 2]);
+    float Mr[12];
+#pragma unroll
+    for (int e = 0; e < 12; ++e) Mr[e] = M[(size_t)r * 12 + e];
+    // batch 1 of loads: this thread's vertices (NN result, world vertex, pose offsets, template, weights)
+    float dq[SKS_VPT], vwx[SKS_VPT], vwy[SKS_VPT], vwz[SKS_VPT], vox[SKS_VPT], voy[SKS_VPT], voz[SKS_VPT], vtx[SKS_VPT], vty[SKS_VPT], vtz[SKS_VPT];
+    int jq[SKS_VPT];
+    float4 pq[SKS_VPT];
+#pragma unroll
+    for (int u = 0; u < SKS_VPT; ++u) {
+        const int c = tid + 256 * u;
+        const bool ok = c < nc;
+        const size_t qi = (size_t)r * nc + (ok ? c : 0);
+        dq[u] = ok ? cg.dist[qi] : 0.f;
+        jq[u] = ok ? cg.idx[qi] : -1;
+        pq[u] = (ok && cg.nnpt) ? cg.nnpt[qi] : make_float4(0.f, 0.f, 0.f, 0.f);
+        vwx[u] = ok ? cg.Vw[3 * qi] : 0.f; vwy[u] = ok ? cg.Vw[3 * qi + 1] : 0.f; vwz[u] = ok ? cg.Vw[3 * qi + 2] : 0.f;
+        vox[u] = ok ? Voff[3 * qi] : 0.f; voy[u] = ok ? Voff[3 * qi + 1] : 0.f; voz[u] = ok ? Voff[3 * qi + 2] : 0.f;
+        vtx[u] = ok ? sm.vt[3 * c] : 0.f; vty[u] = ok ? sm.vt[3 * c + 1] : 0.f; vtz[u] = ok ? sm.vt[3 * c + 2] : 0.f;
+    }
+    // batch 2: the frame's transforms and the static transposed weight lists -> LDS.  Two unrolled passes (all loads, then
+    // all LDS writes): as a load-store loop every trip waits for its own load (measured 16 k cycles for this prologue)
+    {
+        constexpr int KA = (NJ * 12 + 255) / 256, KC = SKS_KC;
+        float va[KA], vw[KC];
+        int vv[KC];
+#pragma unroll
+        for (int k = 0; k < KA; ++k) { const int i = tid + 256 * k; va[k] = i < NJ * 12 ? A[(size_t)r * NJ * 12 + i] : 0.f; }
+#pragma unroll
+        for (int k = 0; k < KC; ++k) { const int i = tid + 256 * k; vw[k] = i < nnz ? sm.csc_w[i] : 0.f; vv[k] = i < nnz ? sm.csc_v[i] : 0; }
+        const int cs = tid <= NJ ? sm.csc_start[tid] : 0;
+#pragma unroll
+        for (int k = 0; k < KA; ++k) { const int i = tid + 256 * k; if (i < NJ * 12) { sAf[i] = va[k]; sdA[i] = 0.f; } }
+#pragma unroll
+        for (int k = 0; k < KC; ++k) { const int i = tid + 256 * k; if (i < nnz) { sCW[i] = vw[k]; sCV[i] = (unsigned short)vv[k]; } }
+        if (tid <= NJ) sCS[tid] = cs;
+    }
+    __syncthreads();
+    FDC_FR_STAMP(2, 1);
+    float acc[SKB_NACC];
+#pragma unroll
+    for (int i = 0; i < SKB_NACC; ++i) acc[i] = 0.f;
+    float cterm = 0.f;
+#pragma unroll
+    for (int u = 0; u < SKS_VPT; ++u) {
+        const int c = tid + 256 * u;
+        if (c < nc) {
+            const size_t qi = (size_t)r * nc + c;
+            // (skin_forward_vertex with its inputs already in registers)
+            SkinFwd f;
+            const float p0 = vtx[u] + vox[u], p1 = vty[u] + voy[u], p2 = vtz[u] + voz[u];
+            f.vp = v3(p0, p1, p2);
+#pragma unroll
+            for (int e = 0; e < 12; ++e) f.T[e] = 0.f;
+            for (int k = 0; k < sm.K; ++k) {
+                const float w = sm.ww[c * sm.K + k];
+                const float* a = sAf + 12 * sm.wj[c * sm.K + k];
+#pragma unroll
+                for (int e = 0; e < 12; ++e) f.T[e] += w * a[e];
+            }
+            const V3 vl = v3(f.T[0] * p0 + f.T[1] * p1 + f.T[2] * p2 + f.T[3], f.T[4] * p0 + f.T[5] * p1 + f.T[6] * p2 + f.T[7],
+                             f.T[8] * p0 + f.T[9] * p1 + f.T[10] * p2 + f.T[11]);
+            f.vb = vl + transl;
+            float dterm;
+            cterm += contact_term(dq[u], &dterm);
+            const float gg = jq[u] >= 0 ? 2.f * cg.coef * dterm : 0.f;          // no neighbour (NaN query): zero gradient
+            float4 pt = pq[u];
+            if (!cg.nnpt && jq[u] >= 0) pt = cg.scene[jq[u]];
+            if (jq[u] < 0) pt = make_float4(0.f, 0.f, 0.f, 0.f);
+            const V3 g = v3(gg * (vwx[u] - pt.x), gg * (vwy[u] - pt.y), gg * (vwz[u] - pt.z));
+            const SkinBwd b = skin_backward_vertex(f, Mr, s, g);
+            dVoff[3 * qi] = b.dvp.x; dVoff[3 * qi + 1] = b.dvp.y; dVoff[3 * qi + 2] = b.dvp.z;
+            acc[NBETA] += b.gv.x; acc[NBETA + 1] += b.gv.y; acc[NBETA + 2] += b.gv.z;
+#pragma unroll
+            for (int e = 0; e < 12; ++e) acc[NBETA + 3 + e] += b.dM[e];
+            acc[NBETA + 15] += b.ds;
+            sGV[3 * c] = b.gv.x; sGV[3 * c + 1] = b.gv.y; sGV[3 * c + 2] = b.gv.z;
+            sVP[3 * c] = p0; sVP[3 * c + 1] = p1; sVP[3 * c + 2] = p2;
+        }
+    }
+    __syncthreads();
+    FDC_FR_STAMP(2, 2);
+    {   // dA_j = sum_v w_vj [gv (x) vp | gv]: the non-empty joints are dealt to the four waves in turn
+        const int jlo = lane < NJ ? sCS[lane] : 0, jhi = lane < NJ ? sCS[lane + 1] : 0;
+        unsigned long long jact = __ballot(jhi > jlo);
+        for (int kact = 0; jact; ++kact) {
+            const int j = __ffsll((long long)jact) - 1;
+            jact &= jact - 1;
+            if ((kact & 3) != wave) continue;               // wave-uniform
+            const int lo = __builtin_amdgcn_readlane(jlo, j), hi = __builtin_amdgcn_readlane(jhi, j);
+            float pa[12];
+#pragma unroll
+            for (int e = 0; e < 12; ++e) pa[e] = 0.f;
+            for (int i = lo + lane; i < hi; i += 64) {
+                const float w = sCW[i];
+                const int v = sCV[i];
+                const float gx = w * sGV[3 * v], gy = w * sGV[3 * v + 1], gz = w * sGV[3 * v + 2];
+                const float px = sVP[3 * v], py = sVP[3 * v + 1], pz = sVP[3 * v + 2];
+                pa[0] += gx * px; pa[1] += gx * py; pa[2] += gx * pz; pa[3] += gx;
+                pa[4] += gy * px; pa[5] += gy * py; pa[6] += gy * pz; pa[7] += gy;
+                pa[8] += gz * px; pa[9] += gz * py; pa[10] += gz * pz; pa[11] += gz;
+            }
+#pragma unroll
+            for (int e = 0; e < 12; ++e) {
+                const float v = wave_sum(pa[e]);
+                if (lane == 0) sdA[j * 12 + e] = v;
+            }
+        }
+    }
+    FDC_FR_STAMP(2, 3);
+#pragma unroll
+    for (int i = NBETA; i < SKB_NACC; ++i) {
+        const float v = wave_sum(acc[i]);
+        if (lane == 0) sred[wave][i] = v;
+    }
+    const float ct = (cg.contact_sum != nullptr) ? wave_sum(cterm) : 0.f;
+    if (cg.contact_sum && lane == 0) sred[wave][0] = ct;
+    __syncthreads();
+    if (cg.contact_sum && tid == 0) atomicAdd(cg.contact_sum, (double)((sred[0][0] + sred[1][0]) + (sred[2][0] + sred[3][0])));
+    for (int i = tid; i < NJ * 12; i += 256) dA[(size_t)r * NJ * 12 + i] = sdA[i];
+    if (tid >= NBETA && tid < SKB_NACC) {
+        const float v = sred[0][tid] + sred[1][tid] + sred[2][tid] + sred[3][tid];
+        if (tid < NBETA + 3) dtransl_v[(size_t)r * 3 + tid - NBETA] = v;
+        else if (tid < NBETA + 15) dMv[(size_t)r * 12 + tid - NBETA - 3] = v;
+        else dsv[r] = v;
+    }
+    FDC_FR_STAMP(2, 4);
 }
 
 // mode 'local', cal_loss2 (:404-405): d/dV of mean |second difference over frames| of ALL world vertices.
@@ -705,7 +875,7 @@ struct DevBuf {
 };
 
 struct SkinSet {          // skinning constants for a vertex set (all V, or the contact subset)
-    int nv = 0, K = 0;
+    int nv = 0, K = 0, nnz = 0;
     int ldp = 0;                                // row stride of posedirs: 3*nv rounded up to a multiple of 4 (16-byte rows)
     DevBuf<float> vt, ww, posedirs, csc_w;      // posedirs [496, ldp] = [posedirs ; shapedirs^T], zero padding
     DevBuf<int> wj, csc_start, csc_v;
@@ -862,6 +1032,7 @@ int build_skin_set(fdcap_ctx* c, const std::vector<int64_t>& ids, SkinSet* out) 
         }
     }
     csc_start[NJ] = (int)csc_v.size();
+    out->nnz = (int)csc_v.size();
     if (csc_v.empty()) { csc_v.push_back(0); csc_w.push_back(0.f); }
     out->nv = nv; out->K = K; out->ldp = ldp;
     HIP_TRY(out->csc_start.upload(csc_start.data(), csc_start.size()));
@@ -976,7 +1147,7 @@ int fdcap_debug_nn_timeline(unsigned long long* out, int n) {
 #ifdef FDC_PN_TIMING
 int fdcap_debug_frame_times(unsigned long long* out) {
     HIP_TRY(hipDeviceSynchronize());
-    HIP_TRY(hipMemcpyFromSymbol(out, HIP_SYMBOL(g_fr_times), sizeof(unsigned long long) * 2 * 2048 * 8));
+    HIP_TRY(hipMemcpyFromSymbol(out, HIP_SYMBOL(g_fr_times), sizeof(unsigned long long) * 3 * 2048 * 8));
     return 0;
 }
 int fdcap_debug_panel_reset(void) {
@@ -1593,6 +1764,16 @@ static int opt_backward_impl(fdcap_ctx* c, const LossWeights& lw, int32_t log_te
         cg.nnpt = o->nnpt_valid ? o->seedpt.p : nullptr;
         cg.coef = lw.contact * cf.weight_contact / ((float)N * nc);
         cg.contact_sum = losses ? losses + 3 : nullptr;
+        if (nc <= SKS_MAXV && c->contact.nnz <= SKS_MAXNNZ) {
+            const int nnz = c->contact.nnz;
+            const size_t lds = (size_t)6 * nc * sizeof(float) + (size_t)nnz * sizeof(float) + (((size_t)nnz * 2 + 15) & ~(size_t)15);
+            if (nc <= 512 && nnz <= 2048)
+                hipLaunchKernelGGL((skin_bwd_small_kernel<2, 8>), dim3(nl), dim3(256), lds, st, c->contact.model(), nc, nnz, o->X.p, o->Voff.p, o->A.p,
+                                   o->M.p, o->scale.p, 2, o->dVoff.p, o->dA.p, o->dtransl_v.p, o->dMv.p, o->dsv.p, cg);
+            else
+                hipLaunchKernelGGL((skin_bwd_small_kernel<4, 16>), dim3(nl), dim3(256), lds, st, c->contact.model(), nc, nnz, o->X.p, o->Voff.p, o->A.p,
+                                   o->M.p, o->scale.p, 2, o->dVoff.p, o->dA.p, o->dtransl_v.p, o->dMv.p, o->dsv.p, cg);
+        } else
         hipLaunchKernelGGL(skin_bwd_kernel<true>, dim3(nl), dim3(256), (size_t)std::min(nc, 1024) * 12 * sizeof(float), st, c->contact.model(), nc, o->X.p, o->Voff.p, o->A.p,
                            o->M.p, o->scale.p, 2, (const float*)nullptr, o->dVoff.p, o->dA.p, (float*)nullptr, o->dtransl_v.p,
                            o->dMv.p, o->dsv.p, cg);

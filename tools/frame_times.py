@@ -21,11 +21,12 @@ fop._mode = "global"; fop.init(x78)
 for ii in range(20):
     capi.check(lib.fdcap_opt_backward(h, ii, 10**6, 0, capi.current_stream()), "bwd"); capi.check(lib.fdcap_opt_step(h, ii, 10**6, capi.current_stream()), "step")
 raw = ctypes.CDLL(capi.LIB_PATH)
-buf = (ctypes.c_ulonglong * (2 * 2048 * 8))()
+buf = (ctypes.c_ulonglong * (3 * 2048 * 8))()
 assert raw.fdcap_debug_frame_times(buf) == 0
-a = np.frombuffer(buf, dtype=np.uint64).reshape(2, 2048, 8).astype(np.int64)
+a = np.frombuffer(buf, dtype=np.uint64).reshape(3, 2048, 8).astype(np.int64)
 names = [("pose_fwd", ["sum partials + topology", "joint rotations + J", "chain", "outputs"], 5),
-         ("pose_bwd", ["topology + param-loss grads", "load + own grads", "products", "subtree sums", "dR/drel", "rot backward", "tail reductions"], 7)]
+         ("pose_bwd", ["stage + param-loss grads", "load + own grads", "products + reverse chain", "dR/drel", "rot backward", "tail reductions"], 7),
+         ("skin_bwd", ["stage A", "vertex loop", "dA reduction", "final sums + stores"], 5)]
 for k, (nm, ph, ns) in enumerate(names):
     t = a[k, :N, :ns]
     t = t[t[:, -1] > 0]
