@@ -65,11 +65,12 @@ def test_fused_vposer_forward_ragged_rows(B):
     ctx.close()
 
 
-@pytest.mark.parametrize("n", [37, 70])
-def test_fused_vposer_backward_in_the_optimiser_gradient(n):
+@pytest.mark.parametrize("n,V,per_part", [(37, 300, 20), (70, 300, 20), (21, 2000, 90)])
+def test_fused_vposer_backward_in_the_optimiser_gradient(n, V, per_part):
     """Phase-1 gradient of a clip that spans several 16-row blocks (ragged last block): the latent columns come out of
-    vposer_bwd_fused_kernel's four partial sums, folded by fdcap_opt_get_grads; compared with fp64 autograd."""
-    fop, bm, vp, clip, scene, vid = _make_fop(n, 300, 800, 20, 500)
+    vposer_bwd_fused_kernel's four partial sums, folded by fdcap_opt_get_grads; compared with fp64 autograd.
+    The third case has a 180-vertex contact set on a 2000-vertex body (blend products with K, N = 540)."""
+    fop, bm, vp, clip, scene, vid = _make_fop(n, V, 800, per_part, 500)
     dt = torch.float64
     f = FittingOracle(SMPLXOracle(bm, dt), VPoserDecoder.from_data(vp, dt), scene, vid, clip.camerapose_lines, n, dtype=dt)
     x78 = rotrepr.convert_to_6D_rot(torch.tensor(clip.body_params, dtype=dt)).detach()

@@ -34,3 +34,15 @@ for k, (nm, ph, ns) in enumerate(names):
     for i in range(ns - 1):
         d = t[:, i + 1] - t[:, i]
         print(f"   {ph[i]:32s} q50 {int(np.median(d)):6d}  q90 {int(np.quantile(d, 0.9)):6d}")
+
+if not hasattr(raw, "fdcap_debug_gemm_times"):
+    sys.exit(0)
+gb = (ctypes.c_ulonglong * (2 * 8192 * 4))()
+assert raw.fdcap_debug_gemm_times(gb) == 0
+g = np.frombuffer(gb, dtype=np.uint64).reshape(2, 8192, 4).astype(np.int64)
+for k, nm in enumerate(["panel_gemm fwd (K=496, N=1500)", "panel_gemm bwd (K=1500, N=496)"]):
+    t = g[k]; t = t[t[:, 3] > 0]
+    print(nm, len(t), "WGs; lifetime q50", int(np.median(t[:, 3] - t[:, 0])), "max", int((t[:, 3] - t[:, 0]).max()), "cycles")
+    for i, ph in enumerate(["stage A (+ first fragments)", "mma", "store"]):
+        d = t[:, i + 1] - t[:, i]
+        print(f"   {ph:32s} q10 {int(np.quantile(d, 0.1)):6d} q50 {int(np.median(d)):6d}  q90 {int(np.quantile(d, 0.9)):6d}")
