@@ -92,6 +92,8 @@ SYMBOLS = {
     "fdcap_panel_gemm": (c_int32, [c_void_p, c_int32, c_int32, c_int32, c_void_p, c_int64, c_int64, c_int32, c_void_p, c_int32,
                                    c_void_p]),
     "fdcap_time_blend_gemm": (c_int32, [c_void_p, c_int32, c_int32, POINTER(c_float), c_void_p]),
+    "fdcap_opt_nn_timing": (c_int32, [c_void_p, c_int32]),
+    "fdcap_opt_nn_timing_read": (c_int32, [c_void_p, POINTER(c_float), POINTER(c_int32)]),
     "fdcap_opt_time_chamfer": (c_int32, [c_void_p, c_int32, c_int32, POINTER(c_float), c_void_p]),
 }
 

@@ -919,6 +919,10 @@ struct OptState {
     DevBuf<int> nn_wg_order;
     int nn_launches = 0;
     bool nn_lpt = true;       // FDCAP_NN_LPT=0 disables
+    // fdcap_opt_nn_timing: HIP events around every in-loop NN launch of a fit (the bench's roofline figure)
+    bool nn_timing = false;
+    std::vector<hipEvent_t> nn_ev;
+    int nn_ev_used = 0;
     NNCache nn_cache(int) { return NNCache{nnc_slack > 0.f ? nnc_ids.p : nullptr, nnc_slack > 0.f ? nnc_hdr.p : nullptr, nnc_anchor.p, nnc_slack,
                                           nn_lpt ? nn_wg_cost.p : nullptr, nn_lpt ? nn_wg_order.p : nullptr}; }
     DevBuf<float> dA, dtransl_v, dMv, dsv, dPF, dJw, dX, dCAM, dscale_row;     // d betas: columns 486.. of dPF
@@ -1600,6 +1604,8 @@ void fdcap_opt_destroy(fdcap_ctx* c) {
     o->dctD.release(); o->dctCoef.release(); o->dctM.release(); o->dctV.release(); o->adam_tab.release();
     o->idx.release(); o->pi.release(); o->seedpt.release(); o->kp2d.release();
     o->nnc_ids.release(); o->nnc_hdr.release(); o->nnc_anchor.release(); o->nn_wg_cost.release(); o->nn_wg_order.release();
+    for (hipEvent_t e : o->nn_ev) (void)hipEventDestroy(e);
+    o->nn_ev.clear();
     delete o;
     c->opt = nullptr;
 }
@@ -1715,9 +1721,13 @@ static int opt_contact_forward(fdcap_ctx* c, hipStream_t st) {
     const int nq = nl * nc;
     // the first contact forward of a fit has no neighbours from a previous iteration yet (idx = -1)
     const NNCache cache = o->nn_cache(0);
+    const bool timed = o->nn_timing && o->nn_ev_used + 2 <= (int)o->nn_ev.size();
+    if (timed) HIP_TRY(hipEventRecord(o->nn_ev[o->nn_ev_used], st));
     HIP_TRY(nn_search(o->Vw.p + off, nq, c->nn_target(o->use_cull), o->dist.p + 2 * nc, o->idx.p + 2 * nc, o->pd.p, o->pi.p,
                       o->nsplit, st, o->use_seed ? o->idx.p + 2 * nc : nullptr, !o->seeded, o->seedpt.p + 2 * nc, &o->nnpt_valid,
-                      &cache, (o->nn_launches++ & 31) == 2));                 // re-rank the dispatch order every 32 launches (16 us each)
+                      &cache, !timed && (o->nn_launches++ & 31) == 2));       // re-rank the dispatch order every 32 launches (16 us each;
+                                                                              // not inside a timed bracket)
+    if (timed) { HIP_TRY(hipEventRecord(o->nn_ev[o->nn_ev_used + 1], st)); o->nn_ev_used += 2; o->nn_launches++; }
     o->seeded = true;
     return 0;
 }
@@ -2156,6 +2166,33 @@ int fdcap_panel_gemm(const float* A, int32_t lda, int32_t M, int32_t K, const fl
     hipError_t e2 = hipStreamSynchronize(st);
     d.release();
     return (int)(e != hipSuccess ? e : e2);
+}
+
+int fdcap_opt_nn_timing(fdcap_ctx* c, int32_t max_launches) {
+    if (!c || !c->opt || max_launches < 0) return FDCAP_E_ARG;
+    OptState* o = c->opt;
+    o->nn_timing = max_launches > 0;
+    o->nn_ev_used = 0;
+    while ((int)o->nn_ev.size() < 2 * max_launches) {
+        hipEvent_t e;
+        HIP_TRY(hipEventCreate(&e));
+        o->nn_ev.push_back(e);
+    }
+    return FDCAP_OK;
+}
+int fdcap_opt_nn_timing_read(fdcap_ctx* c, float* mean_ms, int32_t* launches) {
+    if (!c || !c->opt || !mean_ms || !launches) return FDCAP_E_ARG;
+    OptState* o = c->opt;
+    double sum = 0.0;
+    for (int i = 0; i + 1 < o->nn_ev_used; i += 2) {
+        HIP_TRY(hipEventSynchronize(o->nn_ev[i + 1]));
+        float t = 0.f;
+        HIP_TRY(hipEventElapsedTime(&t, o->nn_ev[i], o->nn_ev[i + 1]));
+        sum += t;
+    }
+    *launches = o->nn_ev_used / 2;
+    *mean_ms = *launches ? (float)(sum / *launches) : 0.f;
+    return FDCAP_OK;
 }
 
 int fdcap_time_blend_gemm(fdcap_ctx* c, int32_t rows, int32_t iters, float* ms, void* stream) {

@@ -285,6 +285,13 @@ int fdcap_time_blend_gemm(fdcap_ctx* ctx, int32_t rows, int32_t iters, float* ms
 int fdcap_panel_gemm(const float* A_d, int32_t lda, int32_t M, int32_t K, const float* B_h, int64_t sk, int64_t sn, int32_t N,
                      float* C_d, int32_t ldc, void* stream);
 
+/* In-loop timing of the Chamfer NN launch: while enabled (max_launches > 0), every contact forward of the optimiser is
+ * bracketed by two HIP events on its launch stream (up to max_launches of them; 0 disables and resets).
+ * fdcap_opt_nn_timing_read waits for the recorded events and returns the mean milliseconds per launch and their number:
+ * the launch as the loop really issues it, iteration by iteration (`roofline.ms_per_launch` of bench.py). */
+int fdcap_opt_nn_timing(fdcap_ctx* ctx, int32_t max_launches);
+int fdcap_opt_nn_timing_read(fdcap_ctx* ctx, float* mean_ms, int32_t* launches);
+
 /* Kernel-level timing of the Chamfer NN launch for the roofline line: runs `iters` launches of
  * the optimiser's Chamfer forward on `stream` between two HIP events and returns the mean
  * milliseconds per launch in *ms.  brute_force = 1: every (query, scene point) pair is visited
