@@ -22,6 +22,8 @@
 #pragma once
 #include <hip/hip_runtime.h>
 
+#include <string.h>
+
 #include <vector>
 
 #include "fdc_frame.h"
@@ -344,13 +346,255 @@ __global__ __launch_bounds__(512) void panel_gemm_kernel(const float* __restrict
     PN_STAMP(3);
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// fp32 products on the bf16 matrix cores: three-way split.
+// An fp32 number is EXACTLY the sum of three bf16 numbers, a = h + m + l (8 + 8 + 8 mantissa bits: h = bf16(a),
+// m = bf16(a - h), l = bf16(a - h - m); both subtractions are exact).  A product a b is then nine bf16 x bf16 partial
+// products (each exact in fp32); the three smallest (m l, l m, l l) are below 2^-23 |a b| together -- one fp32 rounding
+// of the product itself -- and are dropped; the other six go through v_mfma_f32_16x16x32_bf16 with fp32 accumulation,
+// smallest first.  Six bf16 MFMAs cover 32 columns of K in ~100 cycles per SIMD where the fp32 form needs eight
+// v_mfma_f32_16x16x4_f32 = 256 cycles, and the loop's products are bound by exactly that pipe (93 % of its issue slots).
+// Error vs the exact product: <= 2^-22 relative per term, the class of the fp32 fmaf chain's own rounding
+// (tests/test_gpu_panel.py holds both forms to the same bar against fp64).
+typedef __bf16 pn_bf16x8 __attribute__((ext_vector_type(8)));
+typedef float f32x4u_t __attribute__((ext_vector_type(4), aligned(4)));      // 16-byte store at 4-byte alignment (3 V is odd)
+struct PanelB3 {
+    const uint4* f = nullptr;       // f[((tile * nst + s) * 3 + plane) * 64 + lane] = 8 bf16: B(32 s + 8 (lane >> 4) + e, 16 tile + (lane & 15))
+    int ntile = 0, nst = 0;         // ceil(N / 16), ceil(K / 32)
+};
+static inline unsigned pn3_bf_host(float f) { unsigned u; memcpy(&u, &f, 4); u += 0x7FFFu + ((u >> 16) & 1u); return u >> 16; }   // RNE
+static inline float pn3_bff_host(unsigned h) { unsigned u = h << 16; float f; memcpy(&f, &u, 4); return f; }
+static inline void panel_pack3(const float* src, long sk, long sn, int K, int N, std::vector<unsigned>& out, int* ntile, int* nst) {
+    const int nt = (N + 15) / 16, ns = (K + 31) / 32;
+    out.assign((size_t)nt * ns * 3 * 64 * 4, 0u);
+    for (int t = 0; t < nt; ++t)
+        for (int s = 0; s < ns; ++s)
+            for (int l = 0; l < 64; ++l) {
+                const int n = 16 * t + (l & 15);
+                if (n >= N) continue;
+                for (int e = 0; e < 8; ++e) {
+                    const int k = 32 * s + 8 * (l >> 4) + e;
+                    if (k >= K) continue;
+                    const float a = src[(long)k * sk + (long)n * sn];
+                    const unsigned h = pn3_bf_host(a);
+                    const float r1 = a - pn3_bff_host(h);
+                    const unsigned m = pn3_bf_host(r1);
+                    const unsigned lo = pn3_bf_host(r1 - pn3_bff_host(m));
+                    const unsigned part[3] = {h, m, lo};
+                    for (int pl = 0; pl < 3; ++pl) {
+                        unsigned& w = out[((((size_t)t * ns + s) * 3 + pl) * 64 + l) * 4 + (e >> 1)];
+                        w |= part[pl] << (16 * (e & 1));
+                    }
+                }
+            }
+    *ntile = nt;
+    *nst = ns;
+}
+
+__device__ __forceinline__ unsigned pn3_bf(float f) { return (unsigned)__builtin_bit_cast(unsigned short, (__bf16)f); }   // RNE
+__device__ __forceinline__ float pn3_bff(unsigned h) { return __uint_as_float(h << 16); }
+
+// stage rows [r0, r0 + 16) x columns [k0, k0 + kn) of A as three bf16 planes, each [kpad / 8 chunks][16 rows] x 16 bytes
+// (kpad % 32 == 0; rows >= rmax and columns >= kn are zero).  NT threads; one (chunk, row) item = 8 columns.
+template <int NT>
+__device__ __forceinline__ void panel_stage3(uint4* __restrict__ sA3, const float* __restrict__ A, int lda, int r0, int rmax, int k0,
+                                             int kn, int kpad, int tid) {
+    const int nch = kpad >> 3;
+    const bool vec = ((lda & 3) == 0) && ((k0 & 3) == 0) && ((((size_t)A) & 15) == 0);
+    for (int it = tid; it < nch * 16; it += NT) {
+        const int ch = it >> 4, i = it & 15, row = r0 + i, k = 8 * ch;
+        float v[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = 0.f;
+        if (row < rmax && k < kn) {
+            const float* p = A + (size_t)row * lda + k0 + k;
+            if (vec && k + 7 < kn) {
+                const float4 a = *(const float4*)p, b = *(const float4*)(p + 4);
+                v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w;
+            } else {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) if (k + e < kn) v[e] = p[e];
+            }
+        }
+        unsigned h[8], m[8], l[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            h[e] = pn3_bf(v[e]);
+            const float r1 = v[e] - pn3_bff(h[e]);
+            m[e] = pn3_bf(r1);
+            l[e] = pn3_bf(r1 - pn3_bff(m[e]));
+        }
+        sA3[(size_t)0 * nch * 16 + it] = make_uint4(h[0] | (h[1] << 16), h[2] | (h[3] << 16), h[4] | (h[5] << 16), h[6] | (h[7] << 16));
+        sA3[(size_t)1 * nch * 16 + it] = make_uint4(m[0] | (m[1] << 16), m[2] | (m[3] << 16), m[4] | (m[5] << 16), m[6] | (m[7] << 16));
+        sA3[(size_t)2 * nch * 16 + it] = make_uint4(l[0] | (l[1] << 16), l[2] | (l[3] << 16), l[4] | (l[5] << 16), l[6] | (l[7] << 16));
+    }
+}
+
+// acc += A[16 x 32 nst] * B (three-way split, six partial products per 32-column step, smallest first).  sA3: image at the
+// first step (plane stride `pstride` uint4); bf: the tile's fragments at the first step (no lane offset).  Two register
+// sets of PF steps x 3 planes, loads pinned (see panel_mma).
+template <int PF>
+struct PnRing3 { uint4 bA[PF][3]; const uint4* st; };
+template <int PF>
+__device__ __forceinline__ void panel3_prefetch(PnRing3<PF>& rg, const uint4* bf, int nst, int lane) {
+    rg.st = bf + lane;
+    const int last = nst - 1;
+#pragma unroll
+    for (int p = 0; p < PF; ++p)
+#pragma unroll
+        for (int pl = 0; pl < 3; ++pl) rg.bA[p][pl] = rg.st[((size_t)min(p, last) * 3 + pl) * 64];
+}
+__device__ __forceinline__ f32x4_t pn3_step(const uint4* a /*[3] planes h m l of the LDS block*/, const uint4* b /*[3] of the fragment*/, f32x4_t acc) {
+    // static fragment = MFMA A operand (rows = output columns), LDS block = B operand (columns = frames): see pn_step
+#define PN3_MMA(wp, ap) acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(pn_bf16x8, b[wp]), __builtin_bit_cast(pn_bf16x8, a[ap]), acc, 0, 0, 0)
+    PN3_MMA(2, 0); PN3_MMA(0, 2); PN3_MMA(1, 1); PN3_MMA(1, 0); PN3_MMA(0, 1); PN3_MMA(0, 0);
+#undef PN3_MMA
+    return acc;
+}
+// RB row blocks (images `img` uint4 apart) share one fragment stream
+template <int RB, int PF>
+__device__ __forceinline__ void panel3_mma(const uint4* __restrict__ sA3, int pstride, int img, PnRing3<PF>& rg, int nst, f32x4_t* acc, int lane) {
+    uint4 (&bA)[PF][3] = rg.bA;
+    uint4 bB[PF][3];
+    const uint4* const st = rg.st;
+    const int last = nst - 1;
+    auto load_a = [&](uint4 (*a)[3], int step) {
+#pragma unroll
+        for (int rb = 0; rb < RB; ++rb)
+#pragma unroll
+            for (int pl = 0; pl < 3; ++pl) a[rb][pl] = sA3[(size_t)rb * img + (size_t)pl * pstride + (size_t)step * 64 + lane];
+    };
+    auto load_b = [&](uint4* b, int step) {
+#pragma unroll
+        for (int pl = 0; pl < 3; ++pl) b[pl] = st[((size_t)step * 3 + pl) * 64];
+    };
+    uint4 a[RB][3];
+    load_a(a, 0);
+    auto step = [&](const uint4* b, int next) {
+        uint4 an[RB][3];
+        load_a(an, next);
+#pragma unroll
+        for (int rb = 0; rb < RB; ++rb) {
+            acc[rb] = pn3_step(a[rb], b, acc[rb]);
+            a[rb][0] = an[rb][0]; a[rb][1] = an[rb][1]; a[rb][2] = an[rb][2];
+        }
+    };
+    int s = 0;
+    for (; s + 2 * PF <= nst; s += 2 * PF) {
+#pragma unroll
+        for (int p = 0; p < PF; ++p) {
+            load_b(bB[p], s + PF + p);
+            pn_pin();
+            step(bA[p], s + p + 1);
+        }
+#pragma unroll
+        for (int p = 0; p < PF; ++p) {
+            load_b(bA[p], min(s + 2 * PF + p, last));
+            pn_pin();
+            step(bB[p], min(s + PF + p + 1, last));
+        }
+    }
+#pragma unroll
+    for (int p = 0; p < PF; ++p) {
+        if (s + p < nst) {
+            load_b(bB[p], min(s + PF + p, last));
+            step(bA[p], min(s + p + 1, last));
+        }
+    }
+#pragma unroll
+    for (int p = 0; p < PF - 1; ++p)
+        if (s + PF + p < nst) step(bB[p], min(s + PF + p + 1, last));
+}
+
+// C[M, N] = A[M, K] x B on the three-way split (same workgroup shape and XCD-aware map as panel_gemm_kernel<1>; K in one
+// slab: kpad <= 2048).  Dynamic LDS: 3 planes x (kpad / 8) x 16 x 16 bytes = 6 kpad bytes per row block.
+__global__ __launch_bounds__(512) void panel_gemm3_kernel(const float* __restrict__ A, int lda, int M, int K, PanelB3 B,
+                                                          float* __restrict__ C, int ldc, int N, PnMap mp) {
+    extern __shared__ __attribute__((aligned(16))) uint4 pn3_lds[];
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, j = lane & 15, g = lane >> 4;
+    const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+    const int r_in = mp.rfast ? slot % mp.rpg : slot / mp.cpg, c_in = mp.rfast ? slot / mp.rpg : slot % mp.cpg;
+    const int rbk = (xcd / mp.xc) * mp.rpg + r_in, cbk = (xcd % mp.xc) * mp.cpg + c_in;
+    if (r_in >= mp.rpg || c_in >= mp.cpg || rbk >= mp.nrb || cbk >= mp.ncb) return;  // ragged groups (whole workgroup)
+    const int tile = cbk * 8 + wave, m0 = rbk * 16;
+    const bool active = tile < B.ntile;
+    const int kpad = (K + 31) & ~31, nst = kpad >> 5, pstride = (kpad >> 3) * 16;
+    PnRing3<2> rg;
+    panel3_prefetch<2>(rg, B.f + (size_t)(active ? tile : 0) * B.nst * 3 * 64, nst, lane);      // in flight while the A block is staged
+    panel_stage3<512>(pn3_lds, A, lda, m0, M, 0, K, kpad, tid);
+    __syncthreads();
+    f32x4_t acc = {0.f, 0.f, 0.f, 0.f};
+    if (active) panel3_mma<1, 2>(pn3_lds, pstride, 0, rg, nst, &acc, lane);
+    const int n4 = tile * 16 + 4 * g, m = m0 + j;
+    if (active && n4 < N && m < M) {
+        float* dst = C + (size_t)m * ldc + n4;
+        if (((ldc & 3) == 0) && ((((size_t)C) & 15) == 0) && n4 + 3 < N) *(float4*)dst = pn_f4(acc);
+        else {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) if (n4 + r < N) dst[r] = acc[r];
+        }
+    }
+}
+// wide outputs on the split: the column-walking form of panel_gemm_wide_kernel (A staged once per workgroup, all the
+// column blocks of the XCD's share walked; next block's fragments requested before the stores)
+template <int RB>
+__global__ __launch_bounds__(512) void panel_gemm3_wide_kernel(const float* __restrict__ A, int lda, int M, int K, PanelB3 B,
+                                                               float* __restrict__ C, int ldc, int N) {
+    extern __shared__ __attribute__((aligned(16))) uint4 pn3_lds[];
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, j = lane & 15, g = lane >> 4;
+    const int xcd = blockIdx.x & 7, m0 = (int)(blockIdx.x >> 3) * (16 * RB);
+    const int ncb = (B.ntile + 7) / 8, cpg = (ncb + 7) / 8;
+    const int cb0 = xcd * cpg, cb1 = min(ncb, cb0 + cpg);
+    const int kpad = (K + 31) & ~31, nst = kpad >> 5, pstride = (kpad >> 3) * 16, img = 3 * pstride;
+    if (cb0 >= cb1) return;
+    PnRing3<2> rg;
+    panel3_prefetch<2>(rg, B.f + (size_t)min(cb0 * 8 + wave, B.ntile - 1) * B.nst * 3 * 64, nst, lane);
+#pragma unroll
+    for (int rb = 0; rb < RB; ++rb) panel_stage3<512>(pn3_lds + (size_t)rb * img, A, lda, m0 + 16 * rb, M, 0, K, kpad, tid);
+    __syncthreads();
+    for (int cb = cb0; cb < cb1; ++cb) {
+        const int tile = cb * 8 + wave;
+        f32x4_t acc[RB];
+#pragma unroll
+        for (int rb = 0; rb < RB; ++rb) acc[rb] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+        if (tile < B.ntile) panel3_mma<RB, 2>(pn3_lds, pstride, img, rg, nst, acc, lane);
+        if (cb + 1 < cb1) panel3_prefetch<2>(rg, B.f + (size_t)min((cb + 1) * 8 + wave, B.ntile - 1) * B.nst * 3 * 64, nst, lane);
+        const int n4 = tile * 16 + 4 * g;
+        if (tile < B.ntile && n4 < N) {
+#pragma unroll
+            for (int rb = 0; rb < RB; ++rb) {
+                const int m = m0 + 16 * rb + j;
+                if (m < M) {
+                    float* dst = C + (size_t)m * ldc + n4;
+                    if (n4 + 3 < N) *(f32x4u_t*)dst = f32x4u_t{acc[rb][0], acc[rb][1], acc[rb][2], acc[rb][3]};
+                    else {
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) if (n4 + r < N) dst[r] = acc[rb][r];
+                    }
+                }
+            }
+        }
+    }
+}
+
+static inline hipError_t panel_gemm3(const float* A, int lda, int M, int K, const PanelB3& B, float* C, int ldc, int N, hipStream_t st) {
+    if (M <= 0 || N <= 0) return hipSuccess;
+    const int kpad = (K + 31) & ~31;
+    if ((size_t)B.ntile * B.nst * 3 * 1024 > (size_t)(24u << 20) && M >= 32 && kpad <= 768) {
+        hipLaunchKernelGGL(panel_gemm3_wide_kernel<2>, dim3(8 * ((M + 31) / 32)), dim3(512), (size_t)2 * 6 * kpad * 16, st, A, lda, M, K, B, C, ldc, N);
+        return hipGetLastError();
+    }
+    const PnMap mp = panel_map((M + 15) / 16, (B.ntile + 7) / 8, (size_t)M * K * 4, (size_t)B.ntile * B.nst * 3 * 1024);
+    hipLaunchKernelGGL(panel_gemm3_kernel, dim3(8 * mp.rpg * mp.cpg), dim3(512), (size_t)6 * kpad * 16, st, A, lda, M, K, B, C, ldc, N, mp);
+    return hipGetLastError();
+}
+
 // Wide outputs (the full-mesh blend: N = 3 V = 31 425 columns, B = 62 MB): a workgroup keeps its 16 RB rows of A in LDS and
 // walks ALL the column blocks of its XCD's share of B, so A is staged once per workgroup instead of once per (row, column)
 // block (measured with one column block per workgroup: staging 14.7 k of a 45 k-cycle lifetime, exposed because the 127 KB
 // image leaves room for one workgroup per CU) and the workgroups of an XCD stream the same column blocks at the same
 // time: each slice of B crosses the fabric once.  The next column block's first fragments are requested before the
 // current block's stores.  K must fit one slab.  Grid: 8 * ceil(M / (16 RB)) workgroups, blockIdx & 7 = XCD = column share.
-typedef float f32x4u_t __attribute__((ext_vector_type(4), aligned(4)));      // 16-byte store at 4-byte alignment (3 V is odd)
 template <int RB>
 __global__ __launch_bounds__(512) void panel_gemm_wide_kernel(const float* __restrict__ A, int lda, int M, int K, PanelB B,
                                                               float* __restrict__ C, int ldc, int N) {
@@ -420,6 +664,104 @@ static inline hipError_t panel_gemm(const float* A, int lda, int M, int K, const
                            kslab, C, ldc, N, mp);
     }
     return hipGetLastError();
+}
+
+// T tiles share one 16-row LDS block (the fused VPoser kernels' layers)
+template <int T, int PF>
+struct PnRing3T { uint4 bA[T][PF][3]; const uint4* st[T]; };
+template <int T, int PF>
+__device__ __forceinline__ void panel3_prefetch_t(PnRing3T<T, PF>& rg, const uint4* const* bf, int nst, int lane) {
+    const int last = nst - 1;
+#pragma unroll
+    for (int t = 0; t < T; ++t) rg.st[t] = bf[t] + lane;
+#pragma unroll
+    for (int p = 0; p < PF; ++p)
+#pragma unroll
+        for (int t = 0; t < T; ++t)
+#pragma unroll
+            for (int pl = 0; pl < 3; ++pl) rg.bA[t][p][pl] = rg.st[t][((size_t)min(p, last) * 3 + pl) * 64];
+}
+template <int T, int PF>
+__device__ __forceinline__ void panel3_mma_t(const uint4* __restrict__ sA3, int pstride, PnRing3T<T, PF>& rg, int nst, f32x4_t* acc, int lane) {
+    uint4 (&bA)[T][PF][3] = rg.bA;
+    uint4 bB[T][PF][3];
+    const int last = nst - 1;
+    auto load_a = [&](uint4* a, int step) {
+#pragma unroll
+        for (int pl = 0; pl < 3; ++pl) a[pl] = sA3[(size_t)pl * pstride + (size_t)step * 64 + lane];
+    };
+    uint4 a[3];
+    load_a(a, 0);
+    int s = 0;
+    for (; s + 2 * PF <= nst; s += 2 * PF) {
+#pragma unroll
+        for (int p = 0; p < PF; ++p) {
+            uint4 an[3];
+            load_a(an, s + p + 1);
+#pragma unroll
+            for (int t = 0; t < T; ++t) {
+#pragma unroll
+                for (int pl = 0; pl < 3; ++pl) bB[t][p][pl] = rg.st[t][((size_t)(s + PF + p) * 3 + pl) * 64];
+                pn_pin();
+                acc[t] = pn3_step(a, bA[t][p], acc[t]);
+            }
+            a[0] = an[0]; a[1] = an[1]; a[2] = an[2];
+        }
+#pragma unroll
+        for (int p = 0; p < PF; ++p) {
+            uint4 an[3];
+            load_a(an, min(s + PF + p + 1, last));
+#pragma unroll
+            for (int t = 0; t < T; ++t) {
+#pragma unroll
+                for (int pl = 0; pl < 3; ++pl) bA[t][p][pl] = rg.st[t][((size_t)min(s + 2 * PF + p, last) * 3 + pl) * 64];
+                pn_pin();
+                acc[t] = pn3_step(a, bB[t][p], acc[t]);
+            }
+            a[0] = an[0]; a[1] = an[1]; a[2] = an[2];
+        }
+    }
+#pragma unroll
+    for (int p = 0; p < PF; ++p) {
+        if (s + p < nst) {
+            uint4 an[3];
+            load_a(an, min(s + p + 1, last));
+#pragma unroll
+            for (int t = 0; t < T; ++t) {
+#pragma unroll
+                for (int pl = 0; pl < 3; ++pl) bB[t][p][pl] = rg.st[t][((size_t)min(s + PF + p, last) * 3 + pl) * 64];
+                acc[t] = pn3_step(a, bA[t][p], acc[t]);
+            }
+            a[0] = an[0]; a[1] = an[1]; a[2] = an[2];
+        }
+    }
+#pragma unroll
+    for (int p = 0; p < PF - 1; ++p) {
+        if (s + PF + p < nst) {
+            uint4 an[3];
+            load_a(an, min(s + PF + p + 1, last));
+#pragma unroll
+            for (int t = 0; t < T; ++t) acc[t] = pn3_step(a, bB[t][p], acc[t]);
+            a[0] = an[0]; a[1] = an[1]; a[2] = an[2];
+        }
+    }
+}
+// four consecutive columns n4 .. n4 + 3 of frame row j -> the three bf16 planes of an LDS block (8 bytes per plane)
+__device__ __forceinline__ void pn3_store4(uint4* __restrict__ sA3, int pstride, int n4, int j, float4 v) {
+    const float x[4] = {v.x, v.y, v.z, v.w};
+    unsigned h[4], m[4], l[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        h[e] = pn3_bf(x[e]);
+        const float r1 = x[e] - pn3_bff(h[e]);
+        m[e] = pn3_bf(r1);
+        l[e] = pn3_bf(r1 - pn3_bff(m[e]));
+    }
+    const size_t it = (size_t)(n4 >> 3) * 16 + j;
+    const int half = (n4 >> 2) & 1;
+    ((uint2*)(sA3 + (size_t)0 * pstride + it))[half] = make_uint2(h[0] | (h[1] << 16), h[2] | (h[3] << 16));
+    ((uint2*)(sA3 + (size_t)1 * pstride + it))[half] = make_uint2(m[0] | (m[1] << 16), m[2] | (m[3] << 16));
+    ((uint2*)(sA3 + (size_t)2 * pstride + it))[half] = make_uint2(l[0] | (l[1] << 16), l[2] | (l[3] << 16));
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
@@ -597,6 +939,151 @@ __global__ void vposer_fold_dz_kernel(const float* __restrict__ part, size_t par
     if (e >= nrows * VP_Z) return;
     const int row = row_lo + e / VP_Z, c = e % VP_Z;
     dX[(size_t)row * XDIM + X_LATENT + c] += vp_sum_dz(part, part_stride, (size_t)row * VP_Z + c);
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// The fused VPoser kernels on the three-way bf16 split (same decomposition: 16 rows x one quarter of the hidden columns
+// per workgroup, four partial outputs / four partial latent gradients; see vposer_fwd_fused_kernel / vposer_bwd_fused_kernel).
+struct VPoserPanels3 {
+    PanelB3 w1, w2, w3, w3t, w2t, w1t;
+    const float *b1 = nullptr, *b2 = nullptr, *b3 = nullptr;
+};
+constexpr int VP3_PZ = (VP_Z / 8) * 16, VP3_PH = (VP_H / 8) * 16, VP3_PQ = (VP_QW / 8) * 16;     // plane strides (uint4)
+
+__global__ __launch_bounds__(512) void vposer_fwd_split3_kernel(VPoserPanels3 P, const float* __restrict__ Z, int ldx, int row_lo,
+                                                                int row_hi, float* __restrict__ H1, float* __restrict__ H2,
+                                                                float* __restrict__ Opart, size_t part_stride) {
+    __shared__ __attribute__((aligned(16))) uint4 lds3[3 * (VP3_PZ + VP3_PH + VP3_PQ)];
+    uint4* const sZ = lds3;
+    uint4* const sH1 = sZ + 3 * VP3_PZ;
+    uint4* const sH2 = sH1 + 3 * VP3_PH;
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, j = lane & 15, g = lane >> 4;
+    const int q = blockIdx.x & 3, r0 = row_lo + (int)(blockIdx.x >> 2) * 16;
+    PnRing3T<1, 2> rg2, rg3;
+    {   // layer 1, all 512 columns (four tiles per wave), K = 32 = one step
+        f32x4_t acc[4];
+        const uint4* bf[4];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) { acc[t] = f32x4_t{0.f, 0.f, 0.f, 0.f}; bf[t] = P.w1.f + (size_t)(wave * 4 + t) * P.w1.nst * 3 * 64; }
+        PnRing3T<4, 1> rg1;
+        panel3_prefetch_t<4, 1>(rg1, bf, 1, lane);
+        panel_stage3<512>(sZ, Z, ldx, r0, row_hi, 0, VP_Z, VP_Z, tid);
+        __syncthreads();
+        panel3_mma_t<4, 1>(sZ, VP3_PZ, rg1, 1, acc, lane);
+        {
+            const uint4* bf2 = P.w2.f + (size_t)(q * 8 + wave) * P.w2.nst * 3 * 64;
+            panel3_prefetch_t<1, 2>(rg2, &bf2, VP_H / 32, lane);
+        }
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            const int n4 = (wave * 4 + t) * 16 + 4 * g;
+            const float4 bias = *(const float4*)(P.b1 + n4);
+            const float4 v = make_float4(vp_lrelu(acc[t][0] + bias.x), vp_lrelu(acc[t][1] + bias.y), vp_lrelu(acc[t][2] + bias.z),
+                                         vp_lrelu(acc[t][3] + bias.w));
+            pn3_store4(sH1, VP3_PH, n4, j, v);
+            if ((n4 / VP_QW) == q && r0 + j < row_hi) *(float4*)(H1 + (size_t)(r0 + j) * VP_H + n4) = v;
+        }
+    }
+    __syncthreads();
+    {   // layer 2, this quarter's 128 columns (one tile per wave), K = 512 = 16 steps
+        f32x4_t acc = {0.f, 0.f, 0.f, 0.f};
+        const int tile = q * 8 + wave;
+        panel3_mma_t<1, 2>(sH1, VP3_PH, rg2, VP_H / 32, &acc, lane);
+        {
+            const uint4* bf3 = P.w3.f + ((size_t)wave * P.w3.nst + q * (VP_QW / 32)) * 3 * 64;
+            panel3_prefetch_t<1, 2>(rg3, &bf3, VP_QW / 32, lane);
+        }
+        const int n4 = tile * 16 + 4 * g;
+        const float4 bias = *(const float4*)(P.b2 + n4);
+        const float4 v = make_float4(vp_lrelu(acc[0] + bias.x), vp_lrelu(acc[1] + bias.y), vp_lrelu(acc[2] + bias.z), vp_lrelu(acc[3] + bias.w));
+        pn3_store4(sH2, VP3_PQ, n4 - q * VP_QW, j, v);
+        if (r0 + j < row_hi) *(float4*)(H2 + (size_t)(r0 + j) * VP_H + n4) = v;
+    }
+    __syncthreads();
+    {   // output layer: this quarter's K-slice (128 = 4 steps) of all 126 (128) columns
+        f32x4_t acc = {0.f, 0.f, 0.f, 0.f};
+        panel3_mma_t<1, 2>(sH2, VP3_PQ, rg3, VP_QW / 32, &acc, lane);
+        const int n4 = wave * 16 + 4 * g, row = r0 + j;
+        if (row < row_hi) {
+            float* dst = Opart + (size_t)q * part_stride + (size_t)row * ODIM + n4;
+            const float b0 = q == 0 ? P.b3[n4] : 0.f, b1 = q == 0 ? P.b3[n4 + 1] : 0.f;
+            *(float2*)dst = make_float2(acc[0] + b0, acc[1] + b1);
+            if (n4 + 2 < ODIM) {
+                const float b2 = q == 0 ? P.b3[n4 + 2] : 0.f, b3 = q == 0 ? P.b3[n4 + 3] : 0.f;
+                *(float2*)(dst + 2) = make_float2(acc[2] + b2, acc[3] + b3);
+            }
+        }
+    }
+}
+
+__global__ __launch_bounds__(512) void vposer_bwd_split3_kernel(VPoserPanels3 P, const float* __restrict__ dO, int row_lo, int row_hi,
+                                                                const float* __restrict__ H1, const float* __restrict__ H2,
+                                                                float* __restrict__ dZpart, size_t part_stride) {
+    __shared__ __attribute__((aligned(16))) uint4 lds3[3 * (VP3_PQ + VP3_PQ + VP3_PH) + 8 * 64];
+    uint4* const sdO = lds3;                      // K = 126 padded to 128
+    uint4* const sdH2 = sdO + 3 * VP3_PQ;         // this quarter's 128 columns of dH2
+    uint4* const sdH1 = sdH2 + 3 * VP3_PQ;        // partial dH1 (all 512 columns)
+    float* const sred = (float*)(sdH1 + 3 * VP3_PH);
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, j = lane & 15, g = lane >> 4;
+    const int q = blockIdx.x & 3, r0 = row_lo + (int)(blockIdx.x >> 2) * 16;
+    PnRing3T<4, 2> rgB;
+    PnRing3T<1, 2> rgC;
+    {   // dH2[:, quarter] = (dO x W3[:, quarter]) * mask(H2)
+        f32x4_t acc = {0.f, 0.f, 0.f, 0.f};
+        const int tile = q * 8 + wave;
+        const uint4* bf = P.w3t.f + (size_t)tile * P.w3t.nst * 3 * 64;
+        PnRing3T<1, 2> rgA;
+        panel3_prefetch_t<1, 2>(rgA, &bf, 4, lane);
+        panel_stage3<512>(sdO, dO, ODIM, r0, row_hi, 0, ODIM, 128, tid);
+        __syncthreads();
+        panel3_mma_t<1, 2>(sdO, VP3_PQ, rgA, 4, &acc, lane);
+        {
+            const uint4* bfb[4];
+#pragma unroll
+            for (int t = 0; t < 4; ++t) bfb[t] = P.w2t.f + ((size_t)(wave + 8 * t) * P.w2t.nst + q * (VP_QW / 32)) * 3 * 64;
+            panel3_prefetch_t<4, 2>(rgB, bfb, VP_QW / 32, lane);
+        }
+        const int n4 = tile * 16 + 4 * g;
+        const float4 h = (r0 + j < row_hi) ? *(const float4*)(H2 + (size_t)(r0 + j) * VP_H + n4) : make_float4(0.f, 0.f, 0.f, 0.f);
+        pn3_store4(sdH2, VP3_PQ, n4 - q * VP_QW, j,
+                   make_float4(acc[0] * (h.x > 0.f ? 1.f : 0.2f), acc[1] * (h.y > 0.f ? 1.f : 0.2f), acc[2] * (h.z > 0.f ? 1.f : 0.2f),
+                               acc[3] * (h.w > 0.f ? 1.f : 0.2f)));
+    }
+    __syncthreads();
+    {   // partial dH1 = (dH2[:, quarter] x W2[quarter rows, :]) * mask(H1): tiles wave, wave + 8, wave + 16, wave + 24
+        f32x4_t acc[4];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) acc[t] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+        panel3_mma_t<4, 2>(sdH2, VP3_PQ, rgB, VP_QW / 32, acc, lane);
+        {
+            const uint4* bfc = P.w1t.f + ((size_t)(wave & 1) * P.w1t.nst + (wave >> 1) * 4) * 3 * 64;
+            panel3_prefetch_t<1, 2>(rgC, &bfc, 4, lane);
+        }
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            const int n4 = (wave + 8 * t) * 16 + 4 * g;
+            const float4 h = (r0 + j < row_hi) ? *(const float4*)(H1 + (size_t)(r0 + j) * VP_H + n4) : make_float4(0.f, 0.f, 0.f, 0.f);
+            pn3_store4(sdH1, VP3_PH, n4, j,
+                       make_float4(acc[t][0] * (h.x > 0.f ? 1.f : 0.2f), acc[t][1] * (h.y > 0.f ? 1.f : 0.2f),
+                                   acc[t][2] * (h.z > 0.f ? 1.f : 0.2f), acc[t][3] * (h.w > 0.f ? 1.f : 0.2f)));
+        }
+    }
+    __syncthreads();
+    {   // partial d latent = partial dH1 x W1: 2 column tiles x 4 K-slices (128 columns = 4 steps each), slices summed in order
+        f32x4_t acc = {0.f, 0.f, 0.f, 0.f};
+        const int tile = wave & 1, ks = wave >> 1;
+        panel3_mma_t<1, 2>(sdH1 + (size_t)ks * 4 * 64, VP3_PH, rgC, 4, &acc, lane);
+        *(float4*)(sred + (size_t)(ks * 2 + tile) * 256 + lane * 4) = make_float4(acc[0], acc[1], acc[2], acc[3]);
+    }
+    __syncthreads();
+    if (wave < 2) {
+        const float4 s0 = *(const float4*)(sred + (size_t)(0 + wave) * 256 + lane * 4), s1 = *(const float4*)(sred + (size_t)(2 + wave) * 256 + lane * 4);
+        const float4 s2 = *(const float4*)(sred + (size_t)(4 + wave) * 256 + lane * 4), s3 = *(const float4*)(sred + (size_t)(6 + wave) * 256 + lane * 4);
+        const int n4 = wave * 16 + 4 * g, row = r0 + j;
+        if (row < row_hi)
+            *(float4*)(dZpart + (size_t)q * part_stride + (size_t)row * VP_Z + n4) =
+                make_float4(((s0.x + s1.x) + s2.x) + s3.x, ((s0.y + s1.y) + s2.y) + s3.y, ((s0.z + s1.z) + s2.z) + s3.z, ((s0.w + s1.w) + s2.w) + s3.w);
+    }
 }
 
 }  // namespace fdc

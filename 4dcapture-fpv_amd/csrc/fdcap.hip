@@ -883,13 +883,16 @@ struct SkinSet {          // skinning constants for a vertex set (all V, or the 
     // pn_fwd: B(k, n) = posedirs[k, n] (offsets = [pose feature | betas] x B), pn_bwd: B(k, n) = posedirs[n, k] (data gradient)
     DevBuf<float> pn_fwd_f, pn_bwd_f;
     PanelB pn_fwd, pn_bwd;
+    DevBuf<unsigned> pn_fwd3_f, pn_bwd3_f;      // the same two operands as three bf16 planes (panel_gemm3_kernel)
+    PanelB3 pn_fwd3, pn_bwd3;
     SkinModel model() const {
         SkinModel m; m.vt = vt.p; m.S = nullptr; m.wj = wj.p; m.ww = ww.p; m.K = K;
         m.csc_start = csc_start.p; m.csc_v = csc_v.p; m.csc_w = csc_w.p;
         return m;
     }
     void release() { vt.release(); ww.release(); posedirs.release(); wj.release(); csc_w.release(); csc_start.release(); csc_v.release();
-                     pn_fwd_f.release(); pn_bwd_f.release(); pn_fwd = PanelB(); pn_bwd = PanelB(); }
+                     pn_fwd_f.release(); pn_bwd_f.release(); pn_fwd = PanelB(); pn_bwd = PanelB();
+                     pn_fwd3_f.release(); pn_bwd3_f.release(); pn_fwd3 = PanelB3(); pn_bwd3 = PanelB3(); }
 };
 
 struct OptState {
@@ -953,6 +956,8 @@ struct fdcap_ctx {
     DevBuf<float> W1, b1, W2, b2, W3, b3;
     DevBuf<float> vp_pn[6];            // decoder weights in MFMA fragment order: forward w1 w2 w3, backward w3t w2t w1t
     VPoserPanels vp;
+    DevBuf<unsigned> vp_pn3[6];        // ... and as three bf16 planes each (the default form of the products)
+    VPoserPanels3 vp3;
     SkinSet full, contact;
     bool full_ready = false;
     DevBuf<float4> scene;          // original order {x,y,z,bits(i)}: gradient gather by index
@@ -1061,7 +1066,33 @@ int build_skin_set(fdcap_ctx* c, const std::vector<int64_t>& ids, SkinSet* out) 
         HIP_TRY(out->pn_bwd_f.upload(pf.data(), pf.size()));
         out->pn_bwd.f = (const float4*)out->pn_bwd_f.p; out->pn_bwd.ntile = nt; out->pn_bwd.nss = ns;
     }
+    out->pn_fwd3 = PanelB3(); out->pn_bwd3 = PanelB3();
+    if (nv > 0) {                                 // the forward operand of every set also as three bf16 planes
+        std::vector<unsigned> p3;
+        panel_pack3(pd.data(), ldp, 1, NPFX, 3 * nv, p3, &out->pn_fwd3.ntile, &out->pn_fwd3.nst);
+        HIP_TRY(out->pn_fwd3_f.upload(p3.data(), p3.size()));
+        out->pn_fwd3.f = (const uint4*)out->pn_fwd3_f.p;
+    }
+    if (nv > 0 && 3 * nv <= 2048) {               // ... and the data-gradient operand of small sets (K = 3 nv in one LDS image)
+        std::vector<unsigned> p3;
+        panel_pack3(pd.data(), 1, ldp, 3 * nv, NPFX, p3, &out->pn_bwd3.ntile, &out->pn_bwd3.nst);
+        HIP_TRY(out->pn_bwd3_f.upload(p3.data(), p3.size()));
+        out->pn_bwd3.f = (const uint4*)out->pn_bwd3_f.p;
+    }
     return 0;
+}
+
+// dense products on the three-way bf16 split (FDCAP_GEMM_SPLIT3=0: exact-fp32 MFMA chains instead)
+inline bool gemm_split3_enabled() {
+    static int v = -1;
+    if (v < 0) { const char* e = getenv("FDCAP_GEMM_SPLIT3"); v = (e && e[0] == '0') ? 0 : 1; }
+    return v == 1;
+}
+// pose + shape blend offsets of a vertex set: Voff[M, 3 nv] = PF[M, 496] x [posedirs ; shapedirs^T]
+hipError_t blend_forward(const SkinSet& ss, const float* PF, int M, float* Voff, hipStream_t st) {
+    if (gemm_split3_enabled() && ss.pn_fwd3.f) return panel_gemm3(PF, NPFX, M, NPFX, ss.pn_fwd3, Voff, 3 * ss.nv, 3 * ss.nv, st);
+    if (ss.pn_fwd.f) return panel_gemm(PF, NPFX, M, NPFX, ss.pn_fwd, Voff, 3 * ss.nv, 3 * ss.nv, st);
+    return gemm_f32(false, EPI_STORE, PF, NPFX, ss.posedirs.p, ss.ldp, Voff, 3 * ss.nv, M, 3 * ss.nv, NPFX, nullptr, 0, st);
 }
 
 // VPoser decoder forward for rows [row_lo, row_hi) of X (latent read in place at column latent_off): H1, H2 and the four
@@ -1071,8 +1102,12 @@ int vposer_forward(fdcap_ctx* c, const float* X, int ldx, int latent_off, int ro
                    float* Opart, size_t part_stride, float* O, hipStream_t st) {
     const int rows = row_hi - row_lo;
     if (rows <= 0) return 0;
-    hipLaunchKernelGGL(vposer_fwd_fused_kernel, dim3(4 * ((rows + 15) / 16)), dim3(512), 0, st, c->vp, X + latent_off, ldx, row_lo,
-                       row_hi, H1, H2, Opart, part_stride);
+    if (gemm_split3_enabled())
+        hipLaunchKernelGGL(vposer_fwd_split3_kernel, dim3(4 * ((rows + 15) / 16)), dim3(512), 0, st, c->vp3, X + latent_off, ldx, row_lo,
+                           row_hi, H1, H2, Opart, part_stride);
+    else
+        hipLaunchKernelGGL(vposer_fwd_fused_kernel, dim3(4 * ((rows + 15) / 16)), dim3(512), 0, st, c->vp, X + latent_off, ldx, row_lo,
+                           row_hi, H1, H2, Opart, part_stride);
     if (O) {
         const size_t n = (size_t)rows * ODIM;
         hipLaunchKernelGGL(vposer_sum_parts_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, Opart, part_stride,
@@ -1104,8 +1139,12 @@ int opt_vposer_backward(fdcap_ctx* c, bool fold, hipStream_t st) {
     OptState* o = c->opt;
     const int nl = o->cfg.n_local;
     const size_t ps = (size_t)o->R * VP_Z;
-    hipLaunchKernelGGL(vposer_bwd_fused_kernel, dim3(4 * ((nl + 15) / 16)), dim3(512), 0, st, c->vp, o->dO.p, 2, 2 + nl, o->H1.p, o->H2.p,
-                       o->dZpart.p, ps);
+    if (gemm_split3_enabled())
+        hipLaunchKernelGGL(vposer_bwd_split3_kernel, dim3(4 * ((nl + 15) / 16)), dim3(512), 0, st, c->vp3, o->dO.p, 2, 2 + nl, o->H1.p, o->H2.p,
+                           o->dZpart.p, ps);
+    else
+        hipLaunchKernelGGL(vposer_bwd_fused_kernel, dim3(4 * ((nl + 15) / 16)), dim3(512), 0, st, c->vp, o->dO.p, 2, 2 + nl, o->H1.p, o->H2.p,
+                           o->dZpart.p, ps);
     if (fold) {
         hipLaunchKernelGGL(vposer_fold_dz_kernel, dim3((nl * VP_Z + 255) / 256), dim3(256), 0, st, o->dZpart.p, ps, 2, nl, o->dX.p);
         o->dz_pending = false;
@@ -1229,6 +1268,15 @@ int fdcap_ctx_create(const fdcap_model_desc* md, fdcap_ctx** out) {
             pk[i].dst->f = (const float4*)c->vp_pn[i].p; pk[i].dst->ntile = nt; pk[i].dst->nss = ns;
         }
         c->vp.b1 = c->b1.p; c->vp.b2 = c->b2.p; c->vp.b3 = c->b3.p;
+        PanelB3* dst3[6] = {&c->vp3.w1, &c->vp3.w2, &c->vp3.w3, &c->vp3.w3t, &c->vp3.w2t, &c->vp3.w1t};
+        std::vector<unsigned> p3;
+        for (int i = 0; i < 6 && !err; ++i) {
+            panel_pack3(pk[i].w, pk[i].sk, pk[i].sn, pk[i].K, pk[i].N, p3, &dst3[i]->ntile, &dst3[i]->nst);
+            hipError_t e_ = c->vp_pn3[i].upload(p3.data(), p3.size());
+            if (e_ != hipSuccess) err = (int)e_;
+            dst3[i]->f = (const uint4*)c->vp_pn3[i].p;
+        }
+        c->vp3.b1 = c->b1.p; c->vp3.b2 = c->b2.p; c->vp3.b3 = c->b3.p;
     }
     if (err) { fdcap_ctx_destroy(c); return err; }
     *out = c;
@@ -1243,6 +1291,7 @@ void fdcap_ctx_destroy(fdcap_ctx* c) {
     c->parents.release(); c->order.release(); c->level_start.release(); c->child_start.release(); c->child_list.release(); c->depth.release();
     c->W1.release(); c->b1.release(); c->W2.release(); c->b2.release(); c->W3.release(); c->b3.release();
     for (auto& b : c->vp_pn) b.release();
+    for (auto& b : c->vp_pn3) b.release();
     c->full.release(); c->contact.release(); c->contact_vid.release(); c->contact_perm.release(); c->scene.release(); c->scene_sorted.release(); c->scene_bounds.release(); c->scene_sbounds.release(); c->scene_qbounds.release(); c->scene_inv.release(); c->scene_frags.release(); c->scene_centers.release();
     for (auto& b : c->ws_f) b.release();
     c->ws_part.release();
@@ -1541,7 +1590,7 @@ static int body_forward_impl(fdcap_ctx* c, const float* params, int32_t B, const
     if (joints) hipLaunchKernelGGL(joints_out_kernel, dim3((B * NJ + 255) / 256), dim3(256), 0, st, w[7].p, X, XDIM, B, joints);
     if (vertices) {
         HIP_TRY(w[11].ensure((size_t)B * 3 * V));
-        HIP_TRY(panel_gemm(w[6].p, NPFX, B, NPFX, c->full.pn_fwd, w[11].p, 3 * V, 3 * V, st));
+        HIP_TRY(blend_forward(c->full, w[6].p, B, w[11].p, st));
         hipLaunchKernelGGL(skin_fwd_kernel, dim3((V + 255) / 256, B), dim3(256), 0, st, c->full.model(), V, X, XDIM, X_BETAS,
                            X_TRANSL, w[11].p, w[8].p, (const float*)w[1].p, S, 0, world ? 1 : 0, vertices);
     }
@@ -1585,7 +1634,7 @@ int fdcap_smplx_forward(fdcap_ctx* c, const float* go, const float* bp, const fl
     if (joints) hipLaunchKernelGGL(joints_out_kernel, dim3((B * NJ + 255) / 256), dim3(256), 0, st, w[7].p, X, XDIM, B, joints);
     if (vertices) {
         HIP_TRY(w[11].ensure((size_t)B * 3 * V));
-        HIP_TRY(panel_gemm(w[6].p, NPFX, B, NPFX, c->full.pn_fwd, w[11].p, 3 * V, 3 * V, st));
+        HIP_TRY(blend_forward(c->full, w[6].p, B, w[11].p, st));
         hipLaunchKernelGGL(skin_fwd_kernel, dim3((V + 255) / 256, B), dim3(256), 0, st, c->full.model(), V, X, XDIM, X_BETAS,
                            X_TRANSL, w[11].p, w[8].p, (const float*)nullptr, (const float*)nullptr, 0, 0, vertices);
     }
@@ -1711,11 +1760,7 @@ static int opt_contact_forward(fdcap_ctx* c, hipStream_t st) {
     OptState* o = c->opt;
     const int nl = o->cfg.n_local, nc = c->nc;
     const size_t off = (size_t)2 * nc * 3;
-    if (c->contact.pn_fwd.f)
-        HIP_TRY(panel_gemm(o->PF.p + 2 * NPFX, NPFX, nl, NPFX, c->contact.pn_fwd, o->Voff.p + off, 3 * nc, 3 * nc, st));
-    else
-        HIP_TRY(gemm_f32(false, EPI_STORE, o->PF.p + 2 * NPFX, NPFX, c->contact.posedirs.p, c->contact.ldp, o->Voff.p + off, 3 * nc, nl,
-                         3 * nc, NPFX, nullptr, 0, st));
+    HIP_TRY(blend_forward(c->contact, o->PF.p + 2 * NPFX, nl, o->Voff.p + off, st));
     hipLaunchKernelGGL(skin_fwd_kernel, dim3((nc + 255) / 256, nl), dim3(256), 0, st, c->contact.model(), nc, o->X.p, XDIM,
                        X_BETAS, X_TRANSL, o->Voff.p, o->A.p, o->M.p, o->scale.p, 2, 1, o->Vw.p);
     const int nq = nl * nc;
@@ -1787,7 +1832,9 @@ static int opt_backward_impl(fdcap_ctx* c, const LossWeights& lw, int32_t log_te
         hipLaunchKernelGGL(skin_bwd_kernel<true>, dim3(nl), dim3(256), (size_t)std::min(nc, 1024) * 12 * sizeof(float), st, c->contact.model(), nc, o->X.p, o->Voff.p, o->A.p,
                            o->M.p, o->scale.p, 2, (const float*)nullptr, o->dVoff.p, o->dA.p, (float*)nullptr, o->dtransl_v.p,
                            o->dMv.p, o->dsv.p, cg);
-        if (c->contact.pn_bwd.f)
+        if (gemm_split3_enabled() && c->contact.pn_bwd3.f)
+            HIP_TRY(panel_gemm3(o->dVoff.p + (size_t)2 * nc * 3, 3 * nc, nl, 3 * nc, c->contact.pn_bwd3, o->dPF.p + 2 * NPFX, NPFX, NPFX, st));
+        else if (c->contact.pn_bwd.f)
             HIP_TRY(panel_gemm(o->dVoff.p + (size_t)2 * nc * 3, 3 * nc, nl, 3 * nc, c->contact.pn_bwd, o->dPF.p + 2 * NPFX, NPFX, NPFX, st));
         else
             HIP_TRY(gemm_f32(true, EPI_STORE, o->dVoff.p + (size_t)2 * nc * 3, 3 * nc, c->contact.posedirs.p, c->contact.ldp,
@@ -2035,7 +2082,7 @@ int fdcap_opt_backward_local2(fdcap_ctx* c, const float* contact_weight, int32_t
     int e = opt_pose_forward(c, row_lo, row_hi, st);
     if (e) return e;
     // full-mesh world vertices of every row (the vertex stencil needs 2 halo frames each side)
-    HIP_TRY(panel_gemm(o->PF.p, NPFX, R, NPFX, c->full.pn_fwd, o->VoffF.p, 3 * V, 3 * V, st));
+    HIP_TRY(blend_forward(c->full, o->PF.p, R, o->VoffF.p, st));
     hipLaunchKernelGGL(skin_fwd_kernel, dim3((V + 255) / 256, R), dim3(256), 0, st, c->full.model(), V, o->X.p, XDIM, X_BETAS,
                        X_TRANSL, o->VoffF.p, o->A.p, o->M.p, o->scale.p, 0, 1, o->VwF.p);
     // losses [0] rec, [1] z^2, [2] local (parameter) smoothing, [5] vertex smoothing, [6] foot skate
@@ -2156,6 +2203,21 @@ int fdcap_panel_gemm(const float* A, int32_t lda, int32_t M, int32_t K, const fl
                      int32_t ldc, void* stream) {
     if (!A || !B_h || !C || M <= 0 || K <= 0 || N <= 0 || lda < K || ldc < N) return FDCAP_E_ARG;
     hipStream_t st = (hipStream_t)stream;
+    {
+        const char* e3 = getenv("FDCAP_GEMM_SPLIT3");                // (read per call here, so a test can run both forms in one process)
+        if (!(e3 && e3[0] == '0') && K <= 2048) {                    // the three-way bf16 split form of the same product (the default)
+            std::vector<unsigned> p3;
+            PanelB3 B3;
+            panel_pack3(B_h, (long)sk, (long)sn, K, N, p3, &B3.ntile, &B3.nst);
+            DevBuf<unsigned> d3;
+            HIP_TRY(d3.upload(p3.data(), p3.size()));
+            B3.f = (const uint4*)d3.p;
+            hipError_t e = panel_gemm3(A, lda, M, K, B3, C, ldc, N, st);
+            hipError_t e2 = hipStreamSynchronize(st);
+            d3.release();
+            return (int)(e != hipSuccess ? e : e2);
+        }
+    }
     std::vector<float> pf;
     PanelB B;
     panel_pack(B_h, (long)sk, (long)sn, K, N, pf, &B.ntile, &B.nss);
@@ -2212,10 +2274,10 @@ int fdcap_time_blend_gemm(fdcap_ctx* c, int32_t rows, int32_t iters, float* ms, 
     hipEvent_t e0, e1;
     HIP_TRY(hipEventCreate(&e0));
     HIP_TRY(hipEventCreate(&e1));
-    HIP_TRY(panel_gemm(c->ws_f[6].p, NPFX, rows, NPFX, c->full.pn_fwd, c->ws_f[11].p, 3 * V, 3 * V, st));
+    HIP_TRY(blend_forward(c->full, c->ws_f[6].p, rows, c->ws_f[11].p, st));
     HIP_TRY(hipEventRecord(e0, st));
     for (int i = 0; i < iters; ++i)
-        HIP_TRY(panel_gemm(c->ws_f[6].p, NPFX, rows, NPFX, c->full.pn_fwd, c->ws_f[11].p, 3 * V, 3 * V, st));
+        HIP_TRY(blend_forward(c->full, c->ws_f[6].p, rows, c->ws_f[11].p, st));
     HIP_TRY(hipEventRecord(e1, st));
     HIP_TRY(hipEventSynchronize(e1));
     float t = 0.f;

@@ -26,7 +26,11 @@ pytestmark = pytest.mark.gpu
     (1028, 32, 512, True, 0), (257, 126, 512, False, 2),
     (130, 496, 13001, False, 0),        # wide output: four row blocks per fragment stream, column-block-major workgroup order
 ])
-def test_panel_gemm_matches_fp64(M, K, N, transposed, pad):
+@pytest.mark.parametrize("form", ["split3", "fp32"])
+def test_panel_gemm_matches_fp64(M, K, N, transposed, pad, form, monkeypatch):
+    """Both forms of the loop's dense product against fp64: the three-way bf16 split on the bf16 matrix cores (default) and the
+    exact fp32 MFMA chain (FDCAP_GEMM_SPLIT3=0) are held to the SAME bar."""
+    monkeypatch.setenv("FDCAP_GEMM_SPLIT3", "1" if form == "split3" else "0")
     lib = capi.load_library()
     rng = np.random.default_rng(M * 7919 + K * 31 + N)
     A = rng.standard_normal((M, K + pad)).astype(np.float32)
@@ -41,7 +45,8 @@ def test_panel_gemm_matches_fp64(M, K, N, transposed, pad):
                                     capi.dptr(Cd), N + pad, capi.current_stream()), "fdcap_panel_gemm")
     C = Cd.cpu().numpy()
     want = A[:, :K].astype(np.float64) @ Bm.astype(np.float64)
-    # k-ordered fp32 fmaf chain: the error random-walks at ~6e-8 of the partial sums' magnitude; bar = 1e-6 of sum |a||b|
+    # fp32 accumulation of K products: the error random-walks at ~6e-8 of the partial sums' magnitude (measured max 3e-7 of
+    # sum |a||b| for either form); bar = 1e-6 of sum |a||b|
     tol = 1e-6 * (np.abs(A[:, :K]).astype(np.float64) @ np.abs(Bm).astype(np.float64)) + 1e-6
     assert (np.abs(C[:, :N] - want) <= tol).all()
     if pad:
