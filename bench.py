@@ -238,17 +238,31 @@ def main():
     capi.check(fop.ctx.lib.fdcap_time_blend_gemm(fop.ctx.handle, nl, 5, ctypes.byref(ms_g), capi.current_stream()),
                "fdcap_time_blend_gemm")
     gflop = 2.0 * nl * 496 * 3 * args.verts / 1e9         # operand rows [pose feature 486 | betas 10]: pose + shape blendshapes in one product
-    blend = {"kernel": "fdc::panel_gemm_wide_kernel<2> (pose + shape blendshapes [F,496] x [496,3V], v_mfma_f32_16x16x4_f32, "
-                       "static operand in MFMA fragment order)",
-             "ms_per_launch": ms_g.value, "achieved": gflop / ms_g.value, "peak": 157.3, "unit": "TFLOP/s",
-             "frac": gflop / ms_g.value / 157.3, "bound": "mfma",
-             "note": "peak = 64 FLOP/clk/SIMD at the 2.4 GHz maximum clock; the launch sustains ~1.75 GHz (measured: 34.5 cycles per "
-                     "MFMA against the 32-cycle issue interval = 93 % of the matrix pipe's issue slots)"}
+    split3 = os.environ.get("FDCAP_GEMM_SPLIT3", "1") != "0"
+    tf = gflop / ms_g.value                                 # useful fp32 multiply-adds
+    if split3:
+        blend = {"kernel": "fdc::panel_gemm3_wide_kernel<2> (pose + shape blendshapes [F,496] x [496,3V]; fp32 operands as three bf16 "
+                           "parts, six v_mfma_f32_16x16x32_bf16 per 32 columns, fp32 accumulation, static operand in fragment order)",
+                 "ms_per_launch": ms_g.value, "achieved": tf, "peak": 157.3, "unit": "TFLOP/s", "frac": tf / 157.3, "bound": "mfma",
+                 "executed": {"achieved": 6.0 * tf * 512.0 / 496.0, "peak": 2500.0, "unit": "TFLOP/s (bf16 MFMA, dense)",
+                              "frac": 6.0 * tf * 512.0 / 496.0 / 2500.0},
+                 "note": "`achieved` counts the product's fp32 multiply-adds once and `peak` is the fp32 MFMA peak (the pipe an exact-fp32 "
+                         "chain runs on: FDCAP_GEMM_SPLIT3=0 gives 103 TFLOP/s = 65 % there, 93 % of that pipe's issue slots at the "
+                         "sustained clock) -- frac > 1 means the split beats anything the fp32 pipe can do; `executed` prices the bf16 "
+                         "MFMAs actually issued (6 per product term, K padded 496 -> 512) against the dense bf16 peak"}
+    else:
+        blend = {"kernel": "fdc::panel_gemm_wide_kernel<2> (pose + shape blendshapes [F,496] x [496,3V], v_mfma_f32_16x16x4_f32, "
+                           "static operand in MFMA fragment order)",
+                 "ms_per_launch": ms_g.value, "achieved": tf, "peak": 157.3, "unit": "TFLOP/s", "frac": tf / 157.3, "bound": "mfma",
+                 "note": "peak = 64 FLOP/clk/SIMD at the 2.4 GHz maximum clock; the launch sustains ~1.75 GHz (measured: 34.5 cycles per "
+                         "MFMA against the 32-cycle issue interval = 93 % of the matrix pipe's issue slots)"}
     if rank == 0:
         out = {"metric": "frames/sec global-opt (fixed iters), 1024f clip/500k-pt scene; Chamfer GB/s",
                "value": N * args.steps / dt, "unit": "frames/s", "n_gpus": world, "steps": args.steps,
                "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True,
                "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+               "arithmetic": "fp32 values and fp32 accumulation throughout; dense products as exact three-way bf16 splits of the fp32 "
+                             "operands on the bf16 matrix cores (error of the fp32 chain; FDCAP_GEMM_SPLIT3=0: v_mfma_f32 chains)",
                "config": {"workload": f"{'BASELINE config 3' if (N, ns, nc, args.iters) == (1024, 500_000, 500, 500) else 'non-default sizes (not the quoted configuration)'}: {N}-frame clip, {ns}-pt scene, {nc} contact verts, "
                                       f"{args.iters} Adam iterations (phase split 0.8), full loss; frames sharded "
                                       f"over {world} GPU(s)",

@@ -15,3 +15,5 @@ if d.get("with_reference_logging"):
 if "blendshape_gemm" in d:
     g = d["blendshape_gemm"]
     print("   blend GEMM %.3f ms  %.1f TFLOP/s (%.1f%% of fp32 MFMA peak)" % (g["ms_per_launch"], g["achieved"], 100 * g["frac"]))
+    if "executed" in g:
+        print("      executed: %.0f bf16 TFLOP/s = %.1f%% of the dense bf16 MFMA peak" % (g["executed"]["achieved"], 100 * g["executed"]["frac"]))
