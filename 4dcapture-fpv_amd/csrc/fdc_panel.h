@@ -776,7 +776,7 @@ struct VPoserPanels {
 __device__ __forceinline__ float vp_lrelu(float v) { return v > 0.f ? v : 0.2f * v; }
 
 // grid = 4 * ceil(rows / 16): blockIdx & 3 = hidden-column quarter q (blocks of one quarter share an XCD's L2: the
-// dispatcher deals consecutive blocks to the 8 XCDs, so an XCD only ever streams two quarters of W2), blockIdx >> 2 = row block.
+// dispatcher deals consecutive blocks to the 8 XCDs, so XCD x only ever streams quarter x & 3 of W2), blockIdx >> 2 = row block.
 // Z = X + latent column (row stride ldx); rows [row_lo, row_hi).  H1, H2 [*, 512] (kept for the backward's masks),
 // Opart [4][part_stride]: partial decoder outputs (row-major [*, 126]); the bias rides on partial 0.
 __global__ __launch_bounds__(512) void vposer_fwd_fused_kernel(VPoserPanels P, const float* __restrict__ Z, int ldx, int row_lo,

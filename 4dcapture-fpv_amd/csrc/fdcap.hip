@@ -844,12 +844,6 @@ __global__ void unpermute_kernel(const T* __restrict__ src, const int* __restric
     dst[((size_t)r * nc + perm[c]) * w + k] = src[i];
 }
 
-__global__ void copy_rows_kernel(const float* __restrict__ src, int lds, float* __restrict__ dst, int ldd, int rows, int cols) {
-    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= (size_t)rows * cols) return;
-    int r = i / cols, c = i % cols;
-    dst[(size_t)r * ldd + c] = src[(size_t)r * lds + c];
-}
 
 // ------------------------------------------------------------------------------------------
 // host side
@@ -1785,7 +1779,7 @@ struct LossWeights { float rec, smooth, contact, world, dct; bool world_on; };
 static int opt_backward_impl(fdcap_ctx* c, const LossWeights& lw, int32_t log_terms, hipStream_t st) {
     OptState* o = c->opt;
     const fdcap_opt_config& cf = o->cfg;
-    const int R = o->R, nl = cf.n_local, nc = c->nc, N = cf.n_total;
+    const int nl = cf.n_local, nc = c->nc, N = cf.n_total;
     const bool dct_on = lw.dct != 0.f && o->dctW > 0;
     PoseModel pm = c->pose_model();
     double* const losses = log_terms ? o->losses.p : nullptr;       // the partial sums are only formed on logging iterations
@@ -1895,7 +1889,7 @@ int fdcap_opt_dct_fit(fdcap_ctx* c, int32_t iters, int32_t step0, float weight, 
     if (o->dctW <= 0) return FDCAP_E_STATE;
     hipStream_t st = (hipStream_t)stream;
     const fdcap_opt_config& cf = o->cfg;
-    const int T = o->dctT, R = o->R;
+    const int T = o->dctT;
     // windows that lie completely inside this rank's frames (the caller shards on window boundaries)
     const int w0 = (cf.frame0 + T - 1) / T;
     const int w1 = std::min((cf.frame0 + cf.n_local) / T, o->dctW);
@@ -1955,7 +1949,7 @@ int fdcap_opt_backward_fit2d(fdcap_ctx* c, const fdcap_fit2d_stage* sg, int32_t 
     OptState* o = c->opt;
     if (!o->kp2d.p) return FDCAP_E_STATE;
     hipStream_t st = (hipStream_t)stream;
-    const int R = o->R, nl = o->cfg.n_local;
+    const int nl = o->cfg.n_local;
     Fit2dStage s = {sg->fx, sg->fy, sg->cx, sg->cy, sg->rho, sg->w_data, sg->w_pose, sg->w_shape, sg->w_hand};
     PoseModel pm = c->pose_model();
     double* const losses = log_terms ? o->losses.p : nullptr;
@@ -2047,7 +2041,7 @@ int fdcap_opt_detect_contact(fdcap_ctx* c, int32_t n_left, float* weight_left, v
     OptState* o = c->opt;
     if (!o->contact_on) return FDCAP_E_STATE;
     hipStream_t st = (hipStream_t)stream;
-    const int R = o->R, nl = o->cfg.n_local, nc = c->nc;
+    const int nl = o->cfg.n_local, nc = c->nc;
     int row_lo, row_hi;
     opt_row_range(o, 1, &row_lo, &row_hi);
     int e = opt_pose_forward(c, row_lo, row_hi, st);
@@ -2131,7 +2125,7 @@ int fdcap_opt_forward_world(fdcap_ctx* c, float* verts, float* joints, void* str
     if (!c || !c->opt) return FDCAP_E_STATE;
     OptState* o = c->opt;
     hipStream_t st = (hipStream_t)stream;
-    const int R = o->R, nl = o->cfg.n_local, nc = c->nc;
+    const int nl = o->cfg.n_local, nc = c->nc;
     int row_lo, row_hi;
     opt_row_range(o, 1, &row_lo, &row_hi);
     int e = opt_pose_forward(c, row_lo, row_hi, st);
