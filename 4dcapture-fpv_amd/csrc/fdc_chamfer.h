@@ -149,7 +149,7 @@ constexpr float MF_K1 = 1e-4f, MF_K2 = 8e-6f;
 constexpr int MF_MAXCHUNK = 2048;      // chunks per split the survivor list can hold (host keeps splits below it)
 
 #ifdef FDC_NN_TIMELINE
-__device__ unsigned long long g_nn_timeline[8192 * 4];            // instrumentation build only: per workgroup {start, end, xcc}
+__device__ unsigned long long g_nn_timeline[16384 * 4];            // instrumentation build only: per workgroup {start, end, xcc}
 #endif
 #ifdef FDC_NN_STATS
 // instrumentation build only (never shipped): [0] MFMA results reduced, [1] results that entered
@@ -560,18 +560,21 @@ __global__ __launch_bounds__(1024) void nn_lpt_sort_kernel(const unsigned* __res
     }
 }
 
-template <int NQ, int WPG>
-__global__ __launch_bounds__(256, NQ == 1 ? FDC_ST4_OCC : FDC_ST4_OCC2) void nn_stream4_kernel(const float* __restrict__ q, int nq, NNTarget T,
+template <int NQ, int WPG, int WPB = 4>
+__global__ __launch_bounds__(64 * WPB, NQ == 1 ? FDC_ST4_OCC : FDC_ST4_OCC2) void nn_stream4_kernel(const float* __restrict__ q, int nq, NNTarget T,
                                                          const int* __restrict__ seed, float4* __restrict__ seedpt,
                                                          float* __restrict__ dist, int* __restrict__ idx, NNCache cache) {
-    __shared__ unsigned short slist[4][ST4_MAXLIST];             // a wave's work list: quarter chunks 4 k + quarter (chunk WPG k + sub)
-    __shared__ unsigned short clist[4][ST4_MAXCELL];             // ... before that, the chunks that passed the per-query test
-    __shared__ float4 sbox[4][64][2];                            // a wave's near chunk boxes of the current batch {lo, bits(chunk)}, {hi, -}
-    __shared__ float s_d[4][32 * NQ];
-    __shared__ int s_i[4][32 * NQ];
-    __shared__ float4 s_p[4][32 * NQ];
+    // WPB waves per workgroup.  Waves of different groups never talk to each other, and a workgroup's slot on the CU is only
+    // handed on when its slowest wave is done: with one wave per group the launch runs one-wave workgroups (WPB = 1).
+    __shared__ unsigned short slist[WPB][ST4_MAXLIST];           // a wave's work list: quarter chunks 4 k + quarter (chunk WPG k + sub)
+    __shared__ unsigned short clist[WPB][ST4_MAXCELL];           // ... before that, the chunks that passed the per-query test
+    __shared__ float4 sbox[WPB][64][2];                          // a wave's near chunk boxes of the current batch {lo, bits(chunk)}, {hi, -}
+    __shared__ float s_d[WPB][32 * NQ];
+    __shared__ int s_i[WPB][32 * NQ];
+    __shared__ float4 s_p[WPB][32 * NQ];
     static_assert(WPG == 1 || WPG == 2 || WPG == 4, "waves per query group");
-    constexpr int GPW = 4 / WPG;                                 // query groups per workgroup
+    static_assert(WPB % WPG == 0 && WPB <= 4, "a group's waves share a workgroup");
+    constexpr int GPW = WPB / WPG;                               // query groups per workgroup
     constexpr int CPS = ST4_SUPER / WPG;                         // chunks of a super-cell that belong to one wave
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, half = lane >> 5, col = lane & 31;
     const int sub = wave % WPG, gslot = wave / WPG;             // this wave's share of its group's chunks: WPG k + sub
@@ -596,6 +599,40 @@ __global__ __launch_bounds__(256, NQ == 1 ? FDC_ST4_OCC : FDC_ST4_OCC2) void nn_
 #ifdef FDC_NN_STATS
     unsigned st_cnt[8] = {0, 0, 0, 0, 0, 0, 0, 0};
 #endif
+    // Set-up loads, one batch: the queries, their seeds and seed points, and everything a kept work list needs (header, anchors,
+    // ids -- addressed by the group alone).  All unconditional (indices clamped) and consumed together by the empty asm below:
+    // left to itself hipcc sinks each load into the branch that uses it -- seed point behind the seed's validity test, the
+    // list behind the anchors' test -- and the wave pays four dependent round trips instead of one (a wave alone on its SIMD
+    // during the launch's drain is nothing but such round trips).
+    const bool caching = cache.hdr != nullptr && !idle;            // (idle waves have no group: nothing kept for them)
+    const int cidx = group * WPG + sub;
+    float lqx[NQ], lqy[NQ], lqz[NQ];
+    int lsj[NQ];
+    float4 lsp[NQ];
+#pragma unroll
+    for (int n = 0; n < NQ; ++n) {
+        const size_t qc = (size_t)min(wq0 + n * 32 + col, nq - 1);
+        lqx[n] = q[3 * qc]; lqy[n] = q[3 * qc + 1]; lqz[n] = q[3 * qc + 2];
+        lsj[n] = seed[qc];
+        lsp[n] = seedpt[qc];                                      // the seed's coordinates, kept from the launch that found it
+    }
+    int hv_pre = -1;
+    unsigned id_pre = 0;
+    float4 anc_pre[NQ];
+#pragma unroll
+    for (int n = 0; n < NQ; ++n) anc_pre[n] = make_float4(0.f, 0.f, 0.f, -1.f);
+    if (caching) {                                                 // wave-uniform
+        hv_pre = cache.hdr[cidx];
+        id_pre = cache.ids[(size_t)cidx * NN_CACHE_CAP + lane];
+#pragma unroll
+        for (int n = 0; n < NQ; ++n) anc_pre[n] = cache.anchor[(size_t)sub * nq + min(wq0 + n * 32 + col, nq - 1)];
+    }
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll
+    for (int n = 0; n < NQ; ++n)
+        asm volatile("" : "+v"(lqx[n]), "+v"(lqy[n]), "+v"(lqz[n]), "+v"(lsj[n]), "+v"(lsp[n].x), "+v"(lsp[n].y), "+v"(lsp[n].z), "+v"(lsp[n].w),
+                          "+v"(anc_pre[n].x), "+v"(anc_pre[n].y), "+v"(anc_pre[n].z), "+v"(anc_pre[n].w), "+v"(hv_pre), "+v"(id_pre));
+#endif
     float qx[NQ], qy[NQ], qz[NQ], own_d[NQ], sb[NQ];
     int own_i[NQ], qidx[NQ];
     float4 own_p[NQ];          // the current best {x, y, z, bits(position in T.pts)}: it passes the filter by construction and
@@ -605,15 +642,14 @@ __global__ __launch_bounds__(256, NQ == 1 ? FDC_ST4_OCC : FDC_ST4_OCC2) void nn_
     for (int n = 0; n < NQ; ++n) {
         qidx[n] = wq0 + n * 32 + col;
         const bool ok = qidx[n] < nq;
-        qx[n] = ok ? q[3 * (size_t)qidx[n]] : 0.f;
-        qy[n] = ok ? q[3 * (size_t)qidx[n] + 1] : 0.f;
-        qz[n] = ok ? q[3 * (size_t)qidx[n] + 2] : 0.f;
+        qx[n] = ok ? lqx[n] : 0.f;
+        qy[n] = ok ? lqy[n] : 0.f;
+        qz[n] = ok ? lqz[n] : 0.f;
         own_d[n] = INFINITY;
         own_i[n] = -1;
         own_p[n] = make_float4(0.f, 0.f, 0.f, __int_as_float(-1));
-        // three independent loads (not a chain seed -> point): a wave's set-up is latency, not bandwidth
-        const int sj = ok ? seed[qidx[n]] : -1;
-        const float4 p = ok ? seedpt[qidx[n]] : make_float4(0.f, 0.f, 0.f, 0.f);   // the seed's coordinates, kept from the launch that found it
+        const int sj = ok ? lsj[n] : -1;
+        const float4 p = ok ? lsp[n] : make_float4(0.f, 0.f, 0.f, 0.f);
         if (ok) {
             if (sj >= 0 && sj < T.n) {
                 own_p[n] = p;
@@ -647,18 +683,16 @@ __global__ __launch_bounds__(256, NQ == 1 ? FDC_ST4_OCC : FDC_ST4_OCC2) void nn_
     };
 
     // Work-list cache: may this wave take the list it kept?
-    const bool caching = cache.hdr != nullptr && !idle;            // (idle waves have no group: nothing kept for them)
-    const int cidx = group * WPG + sub;
     int n_kept = -1;
     bool inflate = false;                                        // build the list with slack and keep it?
     if (cull && caching) {
-        const int hv = __builtin_amdgcn_readfirstlane(cache.hdr[cidx]);
+        const int hv = __builtin_amdgcn_readfirstlane(hv_pre);
         bool ok = true;
         float dmax = 0.f;
 #pragma unroll
         for (int n = 0; n < NQ; ++n)
             if (qidx[n] < nq) {
-                const float4 a = cache.anchor[(size_t)sub * nq + qidx[n]];
+                const float4 a = anc_pre[n];
                 const float ex = qx[n] - a.x, ey = qy[n] - a.y, ez = qz[n] - a.z;
                 const float dl = __builtin_amdgcn_sqrtf(ez * ez + (ey * ey + ex * ex)) * 1.00001f + 1e-7f;
                 ok &= rq[n] + dl <= a.w;
@@ -735,7 +769,7 @@ __global__ __launch_bounds__(256, NQ == 1 ? FDC_ST4_OCC : FDC_ST4_OCC2) void nn_
         nsurv = n_kept;
         listed = true;
         FDC_STAT(4, lane == 0);
-        if (lane < n_kept) slist[wave][lane] = cache.ids[(size_t)cidx * NN_CACHE_CAP + lane];
+        if (lane < n_kept) slist[wave][lane] = (unsigned short)id_pre;
         __builtin_amdgcn_wave_barrier();
     } else if (cull) {
 #endif
@@ -1036,7 +1070,7 @@ __global__ __launch_bounds__(256, NQ == 1 ? FDC_ST4_OCC : FDC_ST4_OCC2) void nn_
     for (int i = 0; i < 8; ++i) atomicAdd(&g_nn_stats[i], (unsigned long long)st_cnt[i]);
 #endif
 #ifdef FDC_NN_TIMELINE
-    if (tid == 0 && blockIdx.x < 8192) {
+    if (tid == 0 && blockIdx.x < 16384) {
         unsigned xcc; asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
         g_nn_timeline[blockIdx.x * 4 + 0] = tl_t0; g_nn_timeline[blockIdx.x * 4 + 1] = wall_clock64(); g_nn_timeline[blockIdx.x * 4 + 2] = xcc & 15;
     }
@@ -1202,14 +1236,18 @@ static inline hipError_t nn_search(const float* q, int nq, const NNTarget& T, fl
                 nqv = (use_stream % 10 == 2) ? 2 : 1;
                 wpg = (use_stream / 10 == 4) ? 4 : (use_stream / 10 == 2) ? 2 : 1;
             }
+            static int wpb1 = -1;                             // FDCAP_NN_WPB=4 (A/B): four-wave workgroups for one-wave groups too
+            if (wpb1 < 0) { const char* e = getenv("FDCAP_NN_WPB"); wpb1 = (e && atoi(e) == 4) ? 0 : 1; }
             const int groups = (nq + 32 * nqv - 1) / (32 * nqv);
-            const int nwg = (groups * wpg + 3) / 4;
+            const int wpb = (wpg == 1 && nqv == 1 && wpb1) ? 1 : 4;
+            const int nwg = (groups * wpg + wpb - 1) / wpb;
             const dim3 grid((nwg + 7) / 8 * 8);
             NNCache nc = cache ? *cache : NNCache{nullptr, nullptr, nullptr, 0.f, nullptr, nullptr};
-            if (wpg != 1 || nqv != 1) { nc.wg_cost = nullptr; nc.wg_order = nullptr; }     // the schedule arrays are sized for 128-query workgroups
+            if (wpg != 1 || nqv != 1) { nc.wg_cost = nullptr; nc.wg_order = nullptr; }     // the schedule arrays are sized for one-wave groups
 #define FDC_ST4(NQV, WPGV) hipLaunchKernelGGL((nn_stream4_kernel<NQV, WPGV>), grid, dim3(256), 0, st, q, nq, T, seed, seedpt, dist, idx, nc)
             if (nqv == 2 && wpg == 4) FDC_ST4(2, 4); else if (nqv == 2 && wpg == 2) FDC_ST4(2, 2); else if (nqv == 2) FDC_ST4(2, 1);
-            else if (wpg == 4) FDC_ST4(1, 4); else if (wpg == 2) FDC_ST4(1, 2); else FDC_ST4(1, 1);
+            else if (wpg == 4) FDC_ST4(1, 4); else if (wpg == 2) FDC_ST4(1, 2); else if (wpb == 4) FDC_ST4(1, 1);
+            else hipLaunchKernelGGL((nn_stream4_kernel<1, 1, 1>), grid, dim3(64), 0, st, q, nq, T, seed, seedpt, dist, idx, nc);
 #undef FDC_ST4
             if (nc.wg_order && resort && ((nwg + 7) >> 3) <= NN_LPT_MAXSEG) {
                 const int per_xcd = (nwg + 7) >> 3;

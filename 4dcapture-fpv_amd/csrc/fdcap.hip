@@ -1705,7 +1705,7 @@ int fdcap_opt_create(fdcap_ctx* c, const fdcap_opt_config* cfg, float* rows_x, f
     if (!err && o->contact_on) {
         if (const char* e = getenv("FDCAP_NN_LPT")) o->nn_lpt = e[0] != '0';
         o->nn_launches = 0;
-        const size_t nslot = ((((size_t)nq_all + 127) / 128 + 7) / 8) * 8;      // 128-query workgroups, XCD segments
+        const size_t nslot = ((((size_t)nq_all + 31) / 32 + 7) / 8) * 8;        // one-wave workgroups (32 queries), XCD segments
         hipError_t e_ = o->nn_wg_cost.ensure(nslot);
         if (e_ == hipSuccess) e_ = o->nn_wg_order.ensure(nslot);
         if (e_ == hipSuccess) e_ = hipMemset(o->nn_wg_cost.p, 0, nslot * sizeof(unsigned));

@@ -20,11 +20,12 @@ ms = ctypes.c_float()
 if os.environ.get("TIMED", "1") == "1":       # TIMED=0: look at the last launch the loop itself issued
     capi.check(lib.fdcap_opt_time_chamfer(fop.ctx.handle, 1, 0, ctypes.byref(ms), capi.current_stream()), "time")
 raw = ctypes.CDLL(capi.LIB_PATH)
-nwg = (N * 500 + 127) // 128
-nb = min(8192, (nwg + 7) // 8 * 8)
-buf = (ctypes.c_ulonglong * (8192 * 4))()
-assert raw.fdcap_debug_nn_timeline(buf, 8192 * 4) == 0
-a = np.frombuffer(buf, dtype=np.uint64).reshape(8192, 4)[:nb].astype(np.int64)
+CAP = 16384
+nwg = (N * 500 + 31) // 32                    # one-wave workgroups (32 queries)
+nb = min(CAP, (nwg + 7) // 8 * 8)
+buf = (ctypes.c_ulonglong * (CAP * 4))()
+assert raw.fdcap_debug_nn_timeline(buf, CAP * 4) == 0
+a = np.frombuffer(buf, dtype=np.uint64).reshape(CAP, 4)[:nb].astype(np.int64)
 a = a[a[:, 1] > 0]
 t0 = a[:, 0].min()
 st, en, xcc = (a[:, 0] - t0) / 100.0, (a[:, 1] - t0) / 100.0, a[:, 2]     # microseconds
@@ -35,7 +36,7 @@ for x in range(8):
     if m.any(): print(f"  xcc {x}: {m.sum()} WGs, first start {st[m].min():.1f}, last start {st[m].max():.1f}, last end {en[m].max():.1f}, sum of lifetimes {(en[m]-st[m]).sum():.0f} us")
 
 o = np.argsort(-(en - st))[:12]
-idxs = np.nonzero(np.frombuffer(buf, dtype=np.uint64).reshape(8192, 4)[:nb, 1] > 0)[0]
+idxs = np.nonzero(np.frombuffer(buf, dtype=np.uint64).reshape(CAP, 4)[:nb, 1] > 0)[0]
 print("longest workgroups: (blockIdx, xcc, start, end, lifetime us)")
 for k in o: print("  ", int(idxs[k]), int(xcc[k]), f"{st[k]:.1f} {en[k]:.1f} {en[k]-st[k]:.1f}")
 late = np.argsort(-en)[:12]
