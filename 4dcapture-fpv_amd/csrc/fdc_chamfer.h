@@ -477,7 +477,7 @@ constexpr int ST4_MAXCELL = FDC_ST4_MAXCELL;   // chunks one wave can list befor
 #define FDC_ST4_PF 2
 #endif
 #ifndef FDC_ST4_OCC
-#define FDC_ST4_OCC 6
+#define FDC_ST4_OCC 8
 #endif
 #ifndef FDC_ST4_OCC2
 #define FDC_ST4_OCC2 3
