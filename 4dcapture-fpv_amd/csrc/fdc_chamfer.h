@@ -501,64 +501,7 @@ struct NNCache {
     int* hdr;                 // [ngroups * WPG] list length | launches since the anchors were set << 8; -1: no list (anchors one launch old)
     float4* anchor;           // [WPG][nq] {a_i, R_i (validity margin already taken off)}
     float slack;              // metres
-    // Longest-first dispatch (speed only).  A launch is 2.6 "generations" of resident workgroups and ends with a drain in
-    // which a few slow workgroups (specific frames cost 2x the median, every iteration) run alone: measured 48 us of full
-    // machine + 35 us of tail.  Every workgroup leaves its lifetime in wg_cost; every few launches nn_lpt_sort_kernel re-ranks
-    // the workgroups of each XCD's segment by it, and position p of the dispatch order serves workgroup wg_order[p].
-    unsigned* wg_cost;        // [8 * per_xcd] s_memtime ticks of the last launch
-    int* wg_order;            // [8 * per_xcd] permutation inside each XCD segment (null: identity)
 };
-
-// Re-rank the dispatch order of each XCD segment: its K = max(8, n / 16) costliest workgroups go to the front, longest first;
-// all the others keep their natural (frame) order behind them -- neighbouring frames share scene cells, and a fully sorted
-// order lost more to L2 misses early in a fit than it won on the tail.  One 1024-thread block per segment.
-constexpr int NN_LPT_MAXSEG = 8192;
-__global__ __launch_bounds__(1024) void nn_lpt_sort_kernel(const unsigned* __restrict__ cost, int* __restrict__ order, int per_xcd, int nwg) {
-    __shared__ unsigned short s_rank[NN_LPT_MAXSEG];
-    __shared__ __attribute__((aligned(16))) unsigned s_cost[NN_LPT_MAXSEG + 4];
-    __shared__ int s_wsum[16];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int base = blockIdx.x * per_xcd;
-    const int n = max(0, min(per_xcd, nwg - base));              // valid workgroups of this segment
-    const int K = min(n, max(8, n / 16));
-    const int n4 = (n + 3) & ~3;
-    for (int e = tid; e < n4; e += 1024) s_cost[e] = e < n ? cost[base + e] : 0u;    // (padding never outranks: cost 0, index >= n)
-    __syncthreads();
-    // rank = number of workgroups that go before e (higher cost; ties: lower id).  16-byte broadcast reads, four compares
-    // per LDS round trip (one 4-byte read per compare made the launch 40 us: every trip waited for its own read)
-    for (int e = tid; e < n; e += 1024) {
-        const unsigned c = s_cost[e];
-        int rank = 0;
-        for (int o = 0; o < n4; o += 4) {
-            const uint4 co = *(const uint4*)(s_cost + o);
-            rank += (co.x > c) || (co.x == c && o < e);
-            rank += (co.y > c) || (co.y == c && o + 1 < e);
-            rank += (co.z > c) || (co.z == c && o + 2 < e);
-            rank += (co.w > c) || (co.w == c && o + 3 < e);
-        }
-        s_rank[e] = (unsigned short)rank;
-    }
-    __syncthreads();
-    // the K costliest go to position rank; the others follow in natural order: K + (exclusive prefix count of "not in the top K")
-    int running = 0;
-    for (int c0 = 0; c0 < per_xcd; c0 += 1024) {
-        const int e = c0 + tid;
-        const bool valid = e < n;
-        const int r = valid ? (int)s_rank[e] : 0;
-        const bool rest = valid && r >= K;
-        const unsigned long long m = __ballot(rest);
-        if (lane == 0) s_wsum[wave] = __popcll(m);
-        __syncthreads();
-        int before = running;
-        for (int w = 0; w < wave; ++w) before += s_wsum[w];
-        int total = 0;
-        for (int w = 0; w < 16; ++w) total += s_wsum[w];
-        if (valid) order[base + (rest ? K + before + __popcll(m & ((1ull << lane) - 1ull)) : r)] = base + e;
-        else if (e < per_xcd) order[base + e] = base + e;        // idle slots keep their place at the end
-        running += total;
-        __syncthreads();
-    }
-}
 
 template <int NQ, int WPG, int WPB = 4>
 __global__ __launch_bounds__(64 * WPB, NQ == 1 ? FDC_ST4_OCC : FDC_ST4_OCC2) void nn_stream4_kernel(const float* __restrict__ q, int nq, NNTarget T,
@@ -587,10 +530,8 @@ __global__ __launch_bounds__(64 * WPB, NQ == 1 ? FDC_ST4_OCC : FDC_ST4_OCC2) voi
 #ifdef FDC_ST4_RR
     const int wg = blockIdx.x; (void)per_xcd;                    // timing experiment: plain round-robin over the XCDs
 #else
-    const int dpos = (blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);     // position in the dispatch order: XCD-major
-    const int wg = cache.wg_order ? cache.wg_order[dpos] : dpos;
+    const int wg = (blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);       // XCD-major: each XCD serves a contiguous range of frames
 #endif
-    const unsigned long long lpt_t0 = cache.wg_cost ? __builtin_amdgcn_s_memtime() : 0ull;
     const int group = wg * GPW + gslot;
     const bool idle = wg >= nwg || group >= ngroups;            // idle waves still meet the barrier below
     const int wq0 = idle ? nq : group * (32 * NQ);
@@ -1093,7 +1034,6 @@ __global__ __launch_bounds__(64 * WPB, NQ == 1 ? FDC_ST4_OCC : FDC_ST4_OCC2) voi
             seedpt[qo] = s_p[bw][e];
         }
     }
-    if (cache.wg_cost && tid == 0 && wg < nwg) cache.wg_cost[wg] = (unsigned)(__builtin_amdgcn_s_memtime() - lpt_t0);
 }
 
 // Seeds for queries that have none (the first iteration of a fit): any scene point gives a valid upper
@@ -1202,8 +1142,7 @@ static inline int nn_pick_nsplit(int nq, int nt, bool culled = false) {
 // workspace: pd/pi [nsplit*nq]; seed: optional [nq] original indices (may alias idx: read before idx is rewritten)
 static inline hipError_t nn_search(const float* q, int nq, const NNTarget& T, float* dist, int* idx, float* pd, int* pi,
                                    int nsplit, hipStream_t st, const int* seed = nullptr, bool seed_missing = false,
-                                   float4* seedpt = nullptr, bool* seedpt_written = nullptr, const NNCache* cache = nullptr,
-                                   bool resort = false) {
+                                   float4* seedpt = nullptr, bool* seedpt_written = nullptr, const NNCache* cache = nullptr) {
     if (seedpt_written) *seedpt_written = false;             // true: seedpt[q] = coordinates of the neighbour idx[q] after this launch
     if (nq <= 0) return hipSuccess;
     // Query blocks per workgroup: 4 waves x NQ x 32.  A brute-force scan wants NQ = 4 (most MFMAs per
@@ -1242,17 +1181,12 @@ static inline hipError_t nn_search(const float* q, int nq, const NNTarget& T, fl
             const int wpb = (wpg == 1 && nqv == 1 && wpb1) ? 1 : 4;
             const int nwg = (groups * wpg + wpb - 1) / wpb;
             const dim3 grid((nwg + 7) / 8 * 8);
-            NNCache nc = cache ? *cache : NNCache{nullptr, nullptr, nullptr, 0.f, nullptr, nullptr};
-            if (wpg != 1 || nqv != 1) { nc.wg_cost = nullptr; nc.wg_order = nullptr; }     // the schedule arrays are sized for one-wave groups
+            const NNCache nc = cache ? *cache : NNCache{nullptr, nullptr, nullptr, 0.f};
 #define FDC_ST4(NQV, WPGV) hipLaunchKernelGGL((nn_stream4_kernel<NQV, WPGV>), grid, dim3(256), 0, st, q, nq, T, seed, seedpt, dist, idx, nc)
             if (nqv == 2 && wpg == 4) FDC_ST4(2, 4); else if (nqv == 2 && wpg == 2) FDC_ST4(2, 2); else if (nqv == 2) FDC_ST4(2, 1);
             else if (wpg == 4) FDC_ST4(1, 4); else if (wpg == 2) FDC_ST4(1, 2); else if (wpb == 4) FDC_ST4(1, 1);
             else hipLaunchKernelGGL((nn_stream4_kernel<1, 1, 1>), grid, dim3(64), 0, st, q, nq, T, seed, seedpt, dist, idx, nc);
 #undef FDC_ST4
-            if (nc.wg_order && resort && ((nwg + 7) >> 3) <= NN_LPT_MAXSEG) {
-                const int per_xcd = (nwg + 7) >> 3;
-                hipLaunchKernelGGL(nn_lpt_sort_kernel, dim3(8), dim3(1024), 0, st, nc.wg_cost, nc.wg_order, per_xcd, nwg);
-            }
         }
         return hipGetLastError();
     }

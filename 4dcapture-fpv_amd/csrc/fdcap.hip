@@ -912,16 +912,11 @@ struct OptState {
     DevBuf<int> nnc_hdr;
     DevBuf<float4> nnc_anchor;
     float nnc_slack = 0.04f;  // metres; FDCAP_NN_CACHE_SLACK overrides, 0 disables the cache
-    DevBuf<unsigned> nn_wg_cost;   // longest-first dispatch of the in-loop NN launch (NNCache::wg_cost / wg_order)
-    DevBuf<int> nn_wg_order;
-    int nn_launches = 0;
-    bool nn_lpt = true;       // FDCAP_NN_LPT=0 disables
     // fdcap_opt_nn_timing: HIP events around every in-loop NN launch of a fit (the bench's roofline figure)
     bool nn_timing = false;
     std::vector<hipEvent_t> nn_ev;
     int nn_ev_used = 0;
-    NNCache nn_cache(int) { return NNCache{nnc_slack > 0.f ? nnc_ids.p : nullptr, nnc_slack > 0.f ? nnc_hdr.p : nullptr, nnc_anchor.p, nnc_slack,
-                                          nn_lpt ? nn_wg_cost.p : nullptr, nn_lpt ? nn_wg_order.p : nullptr}; }
+    NNCache nn_cache(int) { return NNCache{nnc_slack > 0.f ? nnc_ids.p : nullptr, nnc_slack > 0.f ? nnc_hdr.p : nullptr, nnc_anchor.p, nnc_slack}; }
     DevBuf<float> dA, dtransl_v, dMv, dsv, dPF, dJw, dX, dCAM, dscale_row;     // d betas: columns 486.. of dPF
     DevBuf<float> VoffF, VwF, dVF;      // mode 'local' second loop: full-mesh pose offsets / world vertices / gradient
     int cam_steps = 0;
@@ -1646,7 +1641,7 @@ void fdcap_opt_destroy(fdcap_ctx* c) {
     for (auto* b : fb) b->release();
     o->dctD.release(); o->dctCoef.release(); o->dctM.release(); o->dctV.release(); o->adam_tab.release();
     o->idx.release(); o->pi.release(); o->seedpt.release(); o->kp2d.release();
-    o->nnc_ids.release(); o->nnc_hdr.release(); o->nnc_anchor.release(); o->nn_wg_cost.release(); o->nn_wg_order.release();
+    o->nnc_ids.release(); o->nnc_hdr.release(); o->nnc_anchor.release();
     for (hipEvent_t e : o->nn_ev) (void)hipEventDestroy(e);
     o->nn_ev.clear();
     delete o;
@@ -1703,20 +1698,6 @@ int fdcap_opt_create(fdcap_ctx* c, const fdcap_opt_config* cfg, float* rows_x, f
         if (e_ != hipSuccess) err = (int)e_;
     }
     if (!err && o->contact_on) {
-        if (const char* e = getenv("FDCAP_NN_LPT")) o->nn_lpt = e[0] != '0';
-        o->nn_launches = 0;
-        const size_t nslot = ((((size_t)nq_all + 31) / 32 + 7) / 8) * 8;        // one-wave workgroups (32 queries), XCD segments
-        hipError_t e_ = o->nn_wg_cost.ensure(nslot);
-        if (e_ == hipSuccess) e_ = o->nn_wg_order.ensure(nslot);
-        if (e_ == hipSuccess) e_ = hipMemset(o->nn_wg_cost.p, 0, nslot * sizeof(unsigned));
-        if (e_ == hipSuccess) {
-            std::vector<int> ident(nslot);
-            for (size_t i = 0; i < nslot; ++i) ident[i] = (int)i;
-            e_ = hipMemcpy(o->nn_wg_order.p, ident.data(), nslot * sizeof(int), hipMemcpyHostToDevice);
-        }
-        if (e_ != hipSuccess) err = (int)e_;
-    }
-    if (!err && o->contact_on) {
         if (const char* e = getenv("FDCAP_NN_CACHE_SLACK")) o->nnc_slack = (float)atof(e);
         if (o->nnc_slack > 0.f) {                                        // groups of 32 queries x up to 4 waves per group
             const size_t ng4 = ((size_t)nq_all + 31) / 32 * 4;
@@ -1764,9 +1745,8 @@ static int opt_contact_forward(fdcap_ctx* c, hipStream_t st) {
     if (timed) HIP_TRY(hipEventRecord(o->nn_ev[o->nn_ev_used], st));
     HIP_TRY(nn_search(o->Vw.p + off, nq, c->nn_target(o->use_cull), o->dist.p + 2 * nc, o->idx.p + 2 * nc, o->pd.p, o->pi.p,
                       o->nsplit, st, o->use_seed ? o->idx.p + 2 * nc : nullptr, !o->seeded, o->seedpt.p + 2 * nc, &o->nnpt_valid,
-                      &cache, !timed && (o->nn_launches++ & 31) == 2));       // re-rank the dispatch order every 32 launches (16 us each;
-                                                                              // not inside a timed bracket)
-    if (timed) { HIP_TRY(hipEventRecord(o->nn_ev[o->nn_ev_used + 1], st)); o->nn_ev_used += 2; o->nn_launches++; }
+                      &cache));
+    if (timed) { HIP_TRY(hipEventRecord(o->nn_ev[o->nn_ev_used + 1], st)); o->nn_ev_used += 2; }
     o->seeded = true;
     return 0;
 }

@@ -357,15 +357,14 @@ def test_seeding_the_nn_bound_does_not_change_results():
     assert not torch.equal(res["11"][1][1], res["11"][2][1])     # the stale seeds really were stale
 
 
-@pytest.mark.parametrize("n,per_part", [(64, 40), (256, 200)])       # 5 k queries: four waves per group; 102 k: one (+ dispatch order)
-def test_kept_work_lists_and_dispatch_order_do_not_change_results(n, per_part):
+@pytest.mark.parametrize("n,per_part", [(64, 40), (256, 200)])       # 5 k queries: four waves per group; 102 k: one-wave workgroups
+def test_kept_work_lists_do_not_change_results(n, per_part):
     """The in-loop NN launch keeps each group's work list (built with slack) while the queries stay inside the region it was
-    built for, and dispatches its costliest workgroups first (re-ranked every 32 launches).  Both only prune / reorder:
-    over a sequence of millimetre moves (lists kept), a 3 cm jump (lists rebuilt) and more small moves, every launch must
-    equal the launch without either, bit for bit."""
-    def run(slack, lpt):
+    built for.  That only prunes: over a sequence of millimetre moves (lists kept), a 3 cm jump (lists rebuilt) and more small
+    moves, every launch must equal the launch without kept lists, bit for bit -- for a slack that is never outrun, the
+    default, and one that is outrun at almost every launch."""
+    def run(slack):
         os.environ["FDCAP_NN_CACHE_SLACK"] = slack
-        os.environ["FDCAP_NN_LPT"] = lpt
         try:
             fop, bm, vp, clip, scene, vid = _make_fop(n, 1000, 70_000, per_part, 8, seed=60)
             x78 = torch.empty(n, 78, device="cuda")
@@ -388,13 +387,12 @@ def test_kept_work_lists_and_dispatch_order_do_not_change_results(n, per_part):
             return out
         finally:
             os.environ.pop("FDCAP_NN_CACHE_SLACK")
-            os.environ.pop("FDCAP_NN_LPT")
 
-    base = run("0", "0")
-    for slack, lpt in (("0.04", "1"), ("0.5", "1"), ("0.002", "0")):
-        got = run(slack, lpt)
+    base = run("0")
+    for slack in ("0.04", "0.5", "0.002"):
+        got = run(slack)
         for k, ((d0, i0), (d1, i1)) in enumerate(zip(base, got)):
-            assert torch.equal(d0, d1) and torch.equal(i0, i1), (slack, lpt, k)
+            assert torch.equal(d0, d1) and torch.equal(i0, i1), (slack, k)
     assert not torch.equal(base[24][1], base[25][1])                 # the jump really changed neighbours
 
 
