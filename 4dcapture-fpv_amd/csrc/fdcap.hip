@@ -147,7 +147,12 @@ __global__ __launch_bounds__(64) void pose_fwd_kernel(PoseModel pm, const float*
 }
 
 // optional fused prologue of pose_bwd_kernel (X0 == nullptr: off)
-struct ParamLossIn { const float* X0; const float* mask; const float* Jw; int frame0, n_total; float w_rec, w_sm, w_ws; int world_grad; };
+// loss_rows (optional, logging iterations): this frame's partial sums of the printed terms, [row][LROW] floats in the slots of
+// losses_d (0 rec, 1 z^2, 2 smoothing, 3 contact -- written by the skinning backward --, 4 world smoothing); summed over the
+// rows in a fixed order by loss_rows_reduce_kernel.  (Atomics on the eight doubles serialise: 1024 frames x 4 adds made the
+// separate param_loss_kernel 15 us and the skinning backward 8 us slower on logging iterations.)
+constexpr int LROW = 8;
+struct ParamLossIn { const float* X0; const float* mask; const float* Jw; int frame0, n_total; float w_rec, w_sm, w_ws; int world_grad; float* loss_rows; };
 
 __global__ __launch_bounds__(64) void pose_bwd_kernel(PoseModel pm, const float* __restrict__ X, const float* __restrict__ O,
                                                       const float* __restrict__ CAM, const float* __restrict__ scale,
@@ -167,20 +172,31 @@ __global__ __launch_bounds__(64) void pose_bwd_kernel(PoseModel pm, const float*
         // param_loss_kernel's gradients formed here (non-logging iterations): dX row (=) data + temporal terms on the raw
         // rows, world-smoothing gradient of this frame's joints into LDS instead of a round trip through dJw
         const int g = pl.frame0 + blockIdx.x;
+        float l_rec = 0.f, l_vp = 0.f, l_sm = 0.f, l_ws = 0.f;
         for (int e = threadIdx.x; e < XDIM; e += 64) {
             const float* x = X + (size_t)r * XDIM + e;
-            float rec, sm;
+            float rec = 0.f, sm = 0.f;
             dX[(size_t)r * XDIM + e] = param_loss_grad(g, pl.n_total, g >= 2 ? x[-2 * XDIM] : 0.f, g >= 1 ? x[-XDIM] : 0.f, x[0],
                                                        g + 1 < pl.n_total ? x[XDIM] : 0.f, g + 2 < pl.n_total ? x[2 * XDIM] : 0.f,
                                                        pl.X0[(size_t)r * XDIM + e], pl.mask[r], pl.w_rec, pl.w_sm, &rec, &sm);
+            l_rec += rec; l_sm += sm;
+            if (e >= X_LATENT && e < X_LATENT + 32) l_vp += x[0] * x[0];
         }
-        if (pl.world_grad)
+        if (pl.world_grad || pl.loss_rows)
             for (int e = threadIdx.x; e < NJW * 3; e += 64) {
                 const float* j = pl.Jw + (size_t)r * NJW * 3 + e;
-                float ws;
+                float ws = 0.f;
                 s_dJw[e] = world_smooth_grad(g, pl.n_total, g >= 1 ? j[-NJW * 3] : 0.f, j[0], g + 1 < pl.n_total ? j[NJW * 3] : 0.f,
                                              pl.w_ws, &ws);
+                l_ws += ws;
             }
+        if (pl.loss_rows) {                                  // kernel-uniform: logging iterations only
+            l_rec = wave_sum64(l_rec); l_vp = wave_sum64(l_vp); l_sm = wave_sum64(l_sm); l_ws = wave_sum64(l_ws);
+            if (threadIdx.x == 0) {
+                float* lr = pl.loss_rows + (size_t)r * LROW;
+                lr[0] = l_rec; lr[1] = l_vp; lr[2] = l_sm; lr[4] = l_ws;
+            }
+        }
         __syncthreads();
     }
     const float* dJw_row = (pl.X0 && pl.world_grad) ? s_dJw : (dJw ? dJw + (size_t)r * NJW * 3 : nullptr);
@@ -225,10 +241,10 @@ __device__ __forceinline__ float wave_sum(float v) { return wave_sum64(v); }
 // gradient before it writes the vertex's pose-blend gradient).
 // CONTACT: d loss / d world vertex is the contact robustifier's gradient (:295), formed here from the NN
 // result (Vw, dist, idx -> scene point) instead of being read from dVw; its un-weighted sum goes to
-// *contact_sum when that is non-null (logging iterations only: one double atomic per frame).
+// loss_rows[r][3] when that is non-null (logging iterations only; see ParamLossIn).
 // nnpt (optional): the neighbours' coordinates as the NN kernel keeps them ([q] {x, y, z, -}, coalesced) instead of the
 // dependent gather scene[idx[q]].
-struct ContactGradIn { const float* Vw; const float* dist; const int* idx; const float4* scene; const float4* nnpt; float coef; double* contact_sum; };
+struct ContactGradIn { const float* Vw; const float* dist; const int* idx; const float4* scene; const float4* nnpt; float coef; float* loss_rows; };
 constexpr int SKB_NACC = NBETA + 3 + 12 + 1;   // dbeta, dtransl, dM, ds
 template <bool CONTACT>
 __global__ __launch_bounds__(256) void skin_bwd_kernel(SkinModel sm, int nc, const float* __restrict__ X,
@@ -343,12 +359,12 @@ __global__ __launch_bounds__(256) void skin_bwd_kernel(SkinModel sm, int nc, con
         if ((tid & 63) == 0) sred[tid >> 6][i] = v;
     }
     __syncthreads();
-    if (CONTACT && cg.contact_sum) {                    // wave-uniform
+    if (CONTACT && cg.loss_rows) {                      // wave-uniform
         __shared__ float scon[4];
         const float v = wave_sum(cterm);
         if ((tid & 63) == 0) scon[tid >> 6] = v;
         __syncthreads();
-        if (tid == 0) atomicAdd(cg.contact_sum, (double)((scon[0] + scon[1]) + (scon[2] + scon[3])));
+        if (tid == 0) cg.loss_rows[(size_t)r * LROW + 3] = (scon[0] + scon[1]) + (scon[2] + scon[3]);
     }
     for (int i = tid; i < NJ * 12; i += 256) dA[(size_t)r * NJ * 12 + i] = sdA[i];
     if (tid < SKB_NACC) {
@@ -509,10 +525,10 @@ __global__ __launch_bounds__(256) void skin_bwd_small_kernel(SkinModel sm, int n
         const float v = wave_sum(acc[i]);
         if (lane == 0) sred[wave][i] = v;
     }
-    const float ct = (cg.contact_sum != nullptr) ? wave_sum(cterm) : 0.f;
-    if (cg.contact_sum && lane == 0) sred[wave][0] = ct;
+    const float ct = (cg.loss_rows != nullptr) ? wave_sum(cterm) : 0.f;
+    if (cg.loss_rows && lane == 0) sred[wave][0] = ct;
     __syncthreads();
-    if (cg.contact_sum && tid == 0) atomicAdd(cg.contact_sum, (double)((sred[0][0] + sred[1][0]) + (sred[2][0] + sred[3][0])));
+    if (cg.loss_rows && tid == 0) cg.loss_rows[(size_t)r * LROW + 3] = (sred[0][0] + sred[1][0]) + (sred[2][0] + sred[3][0]);
     for (int i = tid; i < NJ * 12; i += 256) dA[(size_t)r * NJ * 12 + i] = sdA[i];
     if (tid >= NBETA && tid < SKB_NACC) {
         const float v = sred[0][tid] + sred[1][tid] + sred[2][tid] + sred[3][tid];
@@ -607,16 +623,16 @@ __global__ void detect_contact_kernel(const float* __restrict__ dist, const int*
     }
 }
 
-// sum of the contact robustifier only (phase-2 logging)
-__global__ void contact_loss_kernel(const float* __restrict__ dist, size_t n, double* __restrict__ out) {
+// sum of the contact robustifier only (phase-2 logging): block per frame -> loss_rows[r][3]
+__global__ __launch_bounds__(256) void contact_loss_rows_kernel(const float* __restrict__ dist, int nc, int row0, float* __restrict__ loss_rows) {
     __shared__ float sred[4];
-    size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    const int r = row0 + blockIdx.x;
     float v = 0.f;
-    for (; i < n; i += (size_t)gridDim.x * 256) { float d; v += contact_term(dist[i], &d); }
+    for (int c = threadIdx.x; c < nc; c += 256) { float d; v += contact_term(dist[(size_t)r * nc + c], &d); }
     v = wave_sum(v);
     if ((threadIdx.x & 63) == 0) sred[threadIdx.x >> 6] = v;
     __syncthreads();
-    if (threadIdx.x == 0) atomicAdd(out, (double)(sred[0] + sred[1] + sred[2] + sred[3]));
+    if (threadIdx.x == 0) loss_rows[(size_t)r * LROW + 3] = (sred[0] + sred[1]) + (sred[2] + sred[3]);
 }
 
 // block (128 threads) per owned frame: data + temporal terms on the raw rows, optional world
@@ -663,15 +679,43 @@ __global__ __launch_bounds__(128) void param_loss_kernel(const float* __restrict
     }
 }
 
-__global__ void reduce_rows_kernel(const float* __restrict__ v, int row0, int n, float* __restrict__ out) {
-    // fixed-order tree: thread t sums elements t, t+256, ... then a butterfly; deterministic
+// End of a logging backward, one block: the per-frame partials of the slots in `mask` summed over rows [row0, row0 + n) in
+// double, in a fixed order (thread t: rows t, t + 256, ...; then a tree) -- deterministic, unlike the atomics it replaces --
+// and stored to (assign != 0: every slot, the others zero) or added to losses[]; then the sum of the per-frame
+// d loss / d scale partials (thread t: rows t, t + 256, ...; butterfly; the order of the step kernels' own reduction).
+__global__ __launch_bounds__(256) void loss_rows_reduce_kernel(const float* __restrict__ rows, int row0, int n, unsigned mask, int assign,
+                                                               double* __restrict__ losses, const float* __restrict__ dscale_row,
+                                                               float* __restrict__ dscale_out) {
+    __shared__ double sd[LROW][256];
     __shared__ float sred[4];
-    float a = 0.f;
-    for (int i = threadIdx.x; i < n; i += 256) a += v[row0 + i];
-    a = wave_sum(a);
-    if ((threadIdx.x & 63) == 0) sred[threadIdx.x >> 6] = a;
+    const int tid = threadIdx.x;
+    double a[LROW];
+#pragma unroll
+    for (int s = 0; s < LROW; ++s) a[s] = 0.0;
+    float ds = 0.f;
+    for (int i = tid; i < n; i += 256) {
+        const float4 lo = *(const float4*)(rows + (size_t)(row0 + i) * LROW), hi = *(const float4*)(rows + (size_t)(row0 + i) * LROW + 4);
+        a[0] += (double)lo.x; a[1] += (double)lo.y; a[2] += (double)lo.z; a[3] += (double)lo.w;
+        a[4] += (double)hi.x; a[5] += (double)hi.y; a[6] += (double)hi.z; a[7] += (double)hi.w;
+        ds += dscale_row[row0 + i];
+    }
+#pragma unroll
+    for (int s = 0; s < LROW; ++s) sd[s][tid] = a[s];
+    ds = wave_sum(ds);
+    if ((tid & 63) == 0) sred[tid >> 6] = ds;
     __syncthreads();
-    if (threadIdx.x == 0) *out = (sred[0] + sred[1]) + (sred[2] + sred[3]);
+    for (int w = 128; w > 0; w >>= 1) {                      // one tree for all slots
+        if (tid < w) {
+#pragma unroll
+            for (int s = 0; s < LROW; ++s) sd[s][tid] += sd[s][tid + w];
+        }
+        __syncthreads();
+    }
+    if (tid < LROW) {
+        if ((mask >> tid) & 1u) losses[tid] = assign ? sd[tid][0] : losses[tid] + sd[tid][0];
+        else if (assign) losses[tid] = 0.0;
+    }
+    if (tid == 0) *dscale_out = (sred[0] + sred[1]) + (sred[2] + sred[3]);
 }
 
 __global__ void adam_kernel(float* __restrict__ p, float* __restrict__ m, float* __restrict__ v,
@@ -685,7 +729,7 @@ __global__ void adam_kernel(float* __restrict__ p, float* __restrict__ m, float*
 
 // One launch for the whole optimizer.step() of an iteration (:592): blocks [0, nb_x) update body_rotation_rec,
 // [nb_x, nb_x + nb_cam) camera_ext, the last block `scale` -- first reducing the per-frame d loss / d scale
-// partials in reduce_rows_kernel's fixed order when `reduce_n` > 0 (single-GPU; a sharded run gets the sum
+// partials in loss_rows_reduce_kernel's fixed order when `reduce_n` > 0 (single-GPU; a sharded run gets the sum
 // from the exchange instead).
 // Sharded runs: the message of the iteration's one collective -- [first 2 | last 2 owned rows] of (x | camera_ext) +
 // this rank's d loss / d scale -- is written by the same launch (xch != nullptr): every thread that updates a boundary-row
@@ -908,6 +952,7 @@ struct OptState {
     DevBuf<float> kp2d;       // per-frame inner fit: 2D keypoints [n_local,23,3] (u, v, confidence)
     DevBuf<float4> seedpt;    // coordinates (+ position in the sorted scene) of each query's current neighbour: next launch's seed
     // work-list cache of the in-loop NN launch (fdc_chamfer.h NNCache): ids [groups * 4][64], hdr [groups * 4], anchors [4][nq]
+    DevBuf<float> loss_rows;       // [R][LROW] per-frame partial sums of the printed loss terms (logging iterations)
     DevBuf<unsigned short> nnc_ids;
     DevBuf<int> nnc_hdr;
     DevBuf<float4> nnc_anchor;
@@ -1637,7 +1682,7 @@ void fdcap_opt_destroy(fdcap_ctx* c) {
     DevBuf<float>* fb[] = {&o->X0, &o->mask, &o->mX, &o->vX, &o->mCAM, &o->vCAM, &o->mS, &o->vS,
                            &o->H1, &o->H2, &o->O, &o->dO, &o->Opart, &o->dZpart, &o->Rm, &o->PF, &o->Jrest, &o->G, &o->A, &o->M,
                            &o->Jw, &o->Voff, &o->Vw, &o->dist, &o->pd, &o->dVoff, &o->dA, &o->dtransl_v, &o->dMv,
-                           &o->dsv, &o->dPF, &o->dJw, &o->dX, &o->dCAM, &o->dscale_row, &o->VoffF, &o->VwF, &o->dVF};
+                           &o->dsv, &o->dPF, &o->dJw, &o->dX, &o->dCAM, &o->dscale_row, &o->loss_rows, &o->VoffF, &o->VwF, &o->dVF};
     for (auto* b : fb) b->release();
     o->dctD.release(); o->dctCoef.release(); o->dctM.release(); o->dctV.release(); o->adam_tab.release();
     o->idx.release(); o->pi.release(); o->seedpt.release(); o->kp2d.release();
@@ -1687,7 +1732,7 @@ int fdcap_opt_create(fdcap_ctx* c, const fdcap_opt_config* cfg, float* rows_x, f
     AL(o->A, (size_t)R * NJ * 12) AL(o->M, (size_t)R * 12) AL(o->Jw, (size_t)R * NJW * 3)
     AL(o->dA, (size_t)R * NJ * 12) AL(o->dtransl_v, (size_t)R * 3) AL(o->dMv, (size_t)R * 12)
     AL(o->dsv, R) AL(o->dPF, (size_t)R * NPFX) AL(o->dJw, (size_t)R * NJW * 3) AL(o->dX, (size_t)R * XDIM)
-    AL(o->dCAM, (size_t)R * 16) AL(o->dscale_row, R)
+    AL(o->dCAM, (size_t)R * 16) AL(o->dscale_row, R) AL(o->loss_rows, (size_t)R * LROW)
     if (o->contact_on) {
         AL(o->Voff, nq * 3) AL(o->Vw, nq * 3) AL(o->dist, nq) AL(o->idx, nq) AL(o->dVoff, nq * 3) AL(o->seedpt, nq)
         AL(o->pd, (size_t)std::max(o->nsplit, o->nsplit_bf) * nq) AL(o->pi, (size_t)std::max(o->nsplit, o->nsplit_bf) * nq)
@@ -1763,7 +1808,10 @@ static int opt_backward_impl(fdcap_ctx* c, const LossWeights& lw, int32_t log_te
     const bool dct_on = lw.dct != 0.f && o->dctW > 0;
     PoseModel pm = c->pose_model();
     double* const losses = log_terms ? o->losses.p : nullptr;       // the partial sums are only formed on logging iterations
-    if (losses) HIP_TRY(hipMemsetAsync(losses, 0, FDCAP_NUM_LOSSES * sizeof(double), st));
+    // Logging without a DCT term: every printed term leaves per-frame partials in loss_rows (inside the kernels that run
+    // anyway), one small launch sums them.  With the DCT term the separate param_loss_kernel / dct kernel add into losses[].
+    const bool rows_log = losses && o->dctW == 0;
+    if (losses && !rows_log) HIP_TRY(hipMemsetAsync(losses, 0, FDCAP_NUM_LOSSES * sizeof(double), st));
     int row_lo, row_hi;
     opt_row_range(o, 1, &row_lo, &row_hi);
     int e = opt_pose_forward(c, row_lo, row_hi, st);
@@ -1776,9 +1824,10 @@ static int opt_backward_impl(fdcap_ctx* c, const LossWeights& lw, int32_t log_te
     const float w_ws = (lw.world_on && N >= 2) ? lw.world / ((float)(N - 1) * NJW * 3) : 0.f;
     // the parameter-space terms: their own kernel when the loss sums are wanted or the DCT term also writes dJw, else
     // formed inside pose_bwd_kernel (one launch less per iteration)
-    const bool fuse_pl = !losses && !(o->dctW > 0 && dct_on);
+    const bool fuse_pl = (!losses || rows_log) && !(o->dctW > 0 && dct_on);
     ParamLossIn pli = {};
-    if (fuse_pl) pli = ParamLossIn{o->X0.p, o->mask.p, o->Jw.p, cf.frame0, N, w_rec, w_sm, w_ws, lw.world_on ? 1 : 0};
+    if (fuse_pl) pli = ParamLossIn{o->X0.p, o->mask.p, o->Jw.p, cf.frame0, N, w_rec, w_sm, w_ws, lw.world_on ? 1 : 0,
+                                   rows_log ? o->loss_rows.p : nullptr};
     else
         hipLaunchKernelGGL(param_loss_kernel, dim3(nl), dim3(128), 0, st, o->X.p, o->X0.p, o->mask.p, o->Jw.p, 2, cf.frame0, N,
                            w_rec, w_sm, w_ws, lw.world_on ? 1 : 0, o->dX.p, o->dJw.p, losses);
@@ -1792,7 +1841,7 @@ static int opt_backward_impl(fdcap_ctx* c, const LossWeights& lw, int32_t log_te
         cg.Vw = o->Vw.p; cg.dist = o->dist.p; cg.idx = o->idx.p; cg.scene = c->scene.p;
         cg.nnpt = o->nnpt_valid ? o->seedpt.p : nullptr;
         cg.coef = lw.contact * cf.weight_contact / ((float)N * nc);
-        cg.contact_sum = losses ? losses + 3 : nullptr;
+        cg.loss_rows = losses ? o->loss_rows.p : nullptr;
         if (nc <= SKS_MAXV && c->contact.nnz <= SKS_MAXNNZ) {
             const int nnz = c->contact.nnz;
             const size_t lds = (size_t)6 * nc * sizeof(float) + (size_t)nnz * sizeof(float) + (((size_t)nnz * 2 + 15) & ~(size_t)15);
@@ -1814,7 +1863,7 @@ static int opt_backward_impl(fdcap_ctx* c, const LossWeights& lw, int32_t log_te
             HIP_TRY(gemm_f32(true, EPI_STORE, o->dVoff.p + (size_t)2 * nc * 3, 3 * nc, c->contact.posedirs.p, c->contact.ldp,
                              o->dPF.p + 2 * NPFX, NPFX, nl, NPFX, 3 * nc, nullptr, 0, st));
     } else if (contact_fwd && losses) {
-        hipLaunchKernelGGL(contact_loss_kernel, dim3(256), dim3(256), 0, st, o->dist.p + 2 * nc, (size_t)nl * nc, losses + 3);
+        hipLaunchKernelGGL(contact_loss_rows_kernel, dim3(nl), dim3(256), 0, st, o->dist.p, nc, 2, o->loss_rows.p);
     }
     const bool joint_grad = lw.world_on || dct_on;
     hipLaunchKernelGGL(pose_bwd_kernel, dim3(nl), dim3(64), 0, st, pm, o->X.p, o->O.p, o->CAM.p, o->scale.p, 2, o->Rm.p,
@@ -1825,8 +1874,18 @@ static int opt_backward_impl(fdcap_ctx* c, const LossWeights& lw, int32_t log_te
     { int eb = opt_vposer_backward(c, false, st); if (eb) return eb; }
     // d loss / d scale of this rank = sum of the per-frame partials: formed by the step kernels (fused with Adam /
     // the exchange packing); on logging iterations also here, so a caller can read dscale_d right after the backward
-    if (log_terms) hipLaunchKernelGGL(reduce_rows_kernel, dim3(1), dim3(256), 0, st, o->dscale_row.p, 2, nl, o->dscale.p);
+    if (log_terms) {
+        const unsigned mask = (rows_log ? 0x17u : 0u) | (contact_fwd ? 0x8u : 0u);     // 0 rec, 1 z^2, 2 smoothing, 4 world | 3 contact
+        hipLaunchKernelGGL(loss_rows_reduce_kernel, dim3(1), dim3(256), 0, st, o->loss_rows.p, 2, nl, mask, rows_log ? 1 : 0, losses,
+                           o->dscale_row.p, o->dscale.p);
+    }
     return (int)hipGetLastError();
+}
+
+int fdcap_opt_set_loss_output(fdcap_ctx* c, double* losses_d) {
+    if (!c || !c->opt || !losses_d) return FDCAP_E_ARG;
+    c->opt->losses.p = losses_d;
+    return FDCAP_OK;
 }
 
 int fdcap_opt_backward(fdcap_ctx* c, int32_t ii, int32_t P, int32_t log_terms, void* stream) {

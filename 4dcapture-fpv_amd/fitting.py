@@ -219,7 +219,7 @@ class FittingOP:
         if mode == "dct":
             self._dct_loops(lib, h, multi, log_every)
         # The reference prints every loss term in every iteration (:573-575, :587-589) with five .item() syncs.  Here the
-        # partial sums of a logging iteration are copied into a device-side history row (no host sync inside the loop) and
+        # partial sums of a logging iteration are written into a device-side history row (no host sync inside the loop) and
         # read back -- and, when sharded, all-reduced -- once after the last iteration.
         n_log = 0
         logged = []
@@ -229,10 +229,10 @@ class FittingOP:
         for ii in range(self.num_iter if mode != "dct" else 0):                             # :560
             do_log = bool(log_every) and (ii % log_every == 0 or ii == self.num_iter - 1)
             st = capi.current_stream()
-            capi.check(lib.fdcap_opt_backward(h, ii, P, 1 if do_log else 0, st), "fdcap_opt_backward")
-            if do_log:
-                hist[len(logged)].copy_(self._losses, non_blocking=True)
+            if do_log:                                   # this iteration's partial sums go straight into their history row
+                capi.check(lib.fdcap_opt_set_loss_output(h, capi.dptr(hist[len(logged)])), "fdcap_opt_set_loss_output")
                 logged.append(ii)
+            capi.check(lib.fdcap_opt_backward(h, ii, P, 1 if do_log else 0, st), "fdcap_opt_backward")
             if multi:
                 # one collective per iteration: boundary rows (after Adam) + the scale-gradient partial travel
                 # together; every rank then sums the partials in rank order and steps `scale` identically
@@ -243,6 +243,7 @@ class FittingOP:
             else:
                 capi.check(lib.fdcap_opt_step(h, ii, P, st), "fdcap_opt_step")
         if logged:
+            capi.check(lib.fdcap_opt_set_loss_output(h, capi.dptr(self._losses)), "fdcap_opt_set_loss_output")
             if multi:
                 allreduce_scalars(self.shard, torch.zeros(1, device=dev), hist)
             rows = hist.cpu().numpy()

@@ -170,6 +170,10 @@ int fdcap_opt_set_inputs(fdcap_ctx* ctx, const float* data78_d, const float* ini
 int fdcap_opt_backward(fdcap_ctx* ctx, int32_t ii, int32_t first_phase2_iter, int32_t log_terms,
                        void* stream);
 int fdcap_opt_step(fdcap_ctx* ctx, int32_t ii, int32_t first_phase2_iter, void* stream);
+/* Redirect the loss partial sums of the following logging backwards to another [FDCAP_NUM_LOSSES] double buffer (e.g. the
+ * next row of a device-side history, so that a caller logging every iteration -- as the reference prints every
+ * iteration, :573-575 -- needs no copy and no host sync inside the loop).  Host-side only; nothing is launched. */
+int fdcap_opt_set_loss_output(fdcap_ctx* ctx, double* losses_d);
 /* ---- mode 'local' (:499-556).  Its first loop is fdcap_opt_backward / _step with
  * phase1_contact = 0.2 and phase2_world = 0 in the config (:511, :523); then: */
 /* detect_contact (:315-365): weight_left_d [n_local] = left / (left + left) per frame, `left` = mean
