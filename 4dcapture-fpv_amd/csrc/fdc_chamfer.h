@@ -149,7 +149,7 @@ constexpr float MF_K1 = 1e-4f, MF_K2 = 8e-6f;
 constexpr int MF_MAXCHUNK = 2048;      // chunks per split the survivor list can hold (host keeps splits below it)
 
 #ifdef FDC_NN_TIMELINE
-__device__ unsigned long long g_nn_timeline[16384 * 4];            // instrumentation build only: per workgroup {start, end, xcc}
+__device__ unsigned long long g_nn_timeline[16384 * 8];            // instrumentation build only: per workgroup {start, end, xcc, after set-up, after list, after filter, after main loop, work items}
 #endif
 #ifdef FDC_NN_STATS
 // instrumentation build only (never shipped): [0] MFMA results reduced, [1] results that entered
@@ -526,6 +526,10 @@ __global__ __launch_bounds__(64 * WPB, NQ == 1 ? FDC_ST4_OCC : FDC_ST4_OCC2) voi
     const int per_xcd = (nwg + 7) >> 3;
 #ifdef FDC_NN_TIMELINE
     const unsigned long long tl_t0 = wall_clock64();             // instrumentation build only: 100 MHz device-wide clock
+    unsigned long long tl_p[4] = {0, 0, 0, 0};
+#define TL_STAMP(k) tl_p[k] = wall_clock64()
+#else
+#define TL_STAMP(k)
 #endif
 #ifdef FDC_ST4_RR
     const int wg = blockIdx.x; (void)per_xcd;                    // timing experiment: plain round-robin over the XCDs
@@ -613,6 +617,7 @@ __global__ __launch_bounds__(64 * WPB, NQ == 1 ? FDC_ST4_OCC : FDC_ST4_OCC2) voi
         }
     }
     const bool cull = __all(all_seeded && finite);
+    TL_STAMP(0);
     // DPP reductions (fdc_math.h), no LDS traffic; lanes 32-63 repeat lanes 0-31 here, so two of the four row results suffice
     auto min_rows01 = [](float v) {
         v = fminf(v, dpp_move<0xB1>(v)); v = fminf(v, dpp_move<0x4E>(v)); v = fminf(v, dpp_move<0x141>(v)); v = fminf(v, dpp_move<0x140>(v));
@@ -824,6 +829,7 @@ __global__ __launch_bounds__(64 * WPB, NQ == 1 ? FDC_ST4_OCC : FDC_ST4_OCC2) voi
         }
         if (!listed) nsurv = 4 * myn;                           // list overflow: scan this wave's whole share (still exact)
     }
+    TL_STAMP(1);
     // With a cache the list (kept or just built) was made for inflated radii: filter it by the per-query box test with the
     // CURRENT bounds, in place (32 quarters per pass: lane l fetches box half l & 1 of quarter l >> 1, id in lo.w; writes
     // trail reads, and a wave's LDS traffic is in order).
@@ -859,6 +865,10 @@ __global__ __launch_bounds__(64 * WPB, NQ == 1 ? FDC_ST4_OCC : FDC_ST4_OCC2) voi
         nsurv = nout;
         FDC_STAT(7, lane == 0 ? nout : 0);
     }
+    TL_STAMP(2);
+#ifdef FDC_NN_TIMELINE
+    const int tl_nsurv = nsurv;
+#endif
     const f32x16_t zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     constexpr int NT = MF_CH / 32;                               // 16 tiles per chunk (padding rows score 1e30)
     constexpr int QT = NT / 4;                                   // tiles per work item (quarter chunk)
@@ -987,6 +997,7 @@ __global__ __launch_bounds__(64 * WPB, NQ == 1 ? FDC_ST4_OCC : FDC_ST4_OCC2) voi
             fr = fr_next;
         }
     }
+    TL_STAMP(3);
     // the two halves of a wave hold different scene rows of the same queries; then the four waves meet in LDS
 #pragma unroll
     for (int n = 0; n < NQ; ++n) {
@@ -1013,7 +1024,8 @@ __global__ __launch_bounds__(64 * WPB, NQ == 1 ? FDC_ST4_OCC : FDC_ST4_OCC2) voi
 #ifdef FDC_NN_TIMELINE
     if (tid == 0 && blockIdx.x < 16384) {
         unsigned xcc; asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
-        g_nn_timeline[blockIdx.x * 4 + 0] = tl_t0; g_nn_timeline[blockIdx.x * 4 + 1] = wall_clock64(); g_nn_timeline[blockIdx.x * 4 + 2] = xcc & 15;
+        unsigned long long* tl = g_nn_timeline + (size_t)blockIdx.x * 8;
+        tl[0] = tl_t0; tl[1] = wall_clock64(); tl[2] = xcc & 15; tl[3] = tl_p[0]; tl[4] = tl_p[1]; tl[5] = tl_p[2]; tl[6] = tl_p[3]; tl[7] = (unsigned long long)tl_nsurv;
     }
 #endif
     if (tid < GPW * 32 * NQ) {

@@ -23,9 +23,9 @@ raw = ctypes.CDLL(capi.LIB_PATH)
 CAP = 16384
 nwg = (N * 500 + 31) // 32                    # one-wave workgroups (32 queries)
 nb = min(CAP, (nwg + 7) // 8 * 8)
-buf = (ctypes.c_ulonglong * (CAP * 4))()
-assert raw.fdcap_debug_nn_timeline(buf, CAP * 4) == 0
-a = np.frombuffer(buf, dtype=np.uint64).reshape(CAP, 4)[:nb].astype(np.int64)
+buf = (ctypes.c_ulonglong * (CAP * 8))()
+assert raw.fdcap_debug_nn_timeline(buf, CAP * 8) == 0
+a = np.frombuffer(buf, dtype=np.uint64).reshape(CAP, 8)[:nb].astype(np.int64)
 a = a[a[:, 1] > 0]
 t0 = a[:, 0].min()
 st, en, xcc = (a[:, 0] - t0) / 100.0, (a[:, 1] - t0) / 100.0, a[:, 2]     # microseconds
@@ -36,9 +36,18 @@ for x in range(8):
     if m.any(): print(f"  xcc {x}: {m.sum()} WGs, first start {st[m].min():.1f}, last start {st[m].max():.1f}, last end {en[m].max():.1f}, sum of lifetimes {(en[m]-st[m]).sum():.0f} us")
 
 o = np.argsort(-(en - st))[:12]
-idxs = np.nonzero(np.frombuffer(buf, dtype=np.uint64).reshape(CAP, 4)[:nb, 1] > 0)[0]
+idxs = np.nonzero(np.frombuffer(buf, dtype=np.uint64).reshape(CAP, 8)[:nb, 1] > 0)[0]
 print("longest workgroups: (blockIdx, xcc, start, end, lifetime us)")
 for k in o: print("  ", int(idxs[k]), int(xcc[k]), f"{st[k]:.1f} {en[k]:.1f} {en[k]-st[k]:.1f}")
 late = np.argsort(-en)[:12]
 print("last to finish:")
 for k in late: print("  ", int(idxs[k]), int(xcc[k]), f"{st[k]:.1f} {en[k]:.1f} {en[k]-st[k]:.1f}")
+
+# phases of a wave's life (us): set-up loads | list (kept-list check or build) | filter | main loop | merge + stores
+ph = np.stack([a[:, 3] - a[:, 0], a[:, 4] - a[:, 3], a[:, 5] - a[:, 4], a[:, 6] - a[:, 5], a[:, 1] - a[:, 6]], axis=1) / 100.0
+names = ["set-up", "list", "filter", "main loop", "tail"]
+for label, sel in (("started in the first 30 us (full machine)", st < 30), ("started after 38 us (drain)", st > 38)):
+    if sel.sum() == 0: continue
+    print(f"{label}: {sel.sum()} waves, lifetime median {np.median((en - st)[sel]):.1f} us, work items median {np.median(a[sel, 7]):.0f}")
+    for k, nm in enumerate(names):
+        print(f"   {nm:10s} q10 {np.quantile(ph[sel, k], 0.1):5.2f}  q50 {np.quantile(ph[sel, k], 0.5):5.2f}  q90 {np.quantile(ph[sel, k], 0.9):5.2f}")
