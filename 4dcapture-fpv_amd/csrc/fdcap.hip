@@ -539,6 +539,176 @@ __global__ __launch_bounds__(256) void skin_bwd_small_kernel(SkinModel sm, int n
     FDC_FR_STAMP(2, 4);
 }
 
+// skin_bwd_small_kernel<2, 8> with every input staged by 16-byte loads (contact sets with nc % 4 == 0, nc <= 512, nnz <= 2048
+// and the packed constants of SkinModel).  s_memtime had put 13 k of the scalar kernel's 30 k cycles in its prologue: ~57
+// four-byte loads per thread (stride-12 x/y/z components, weight lists entry by entry) keep the CU's address unit busy for
+// that long with four workgroups resident -- the same bytes as float4 are 18 loads.  The frame's world vertices and pose
+// offsets are copied into the LDS regions that later hold gv / vp (a thread reads and overwrites only its own vertices),
+// the pose-blend gradient leaves through LDS as float4 rows.  Arithmetic, summation order and results: unchanged.
+__global__ __launch_bounds__(256) void skin_bwd_vec_kernel(SkinModel sm, int nc, int nnz, const float* __restrict__ X,
+                                                           const float* __restrict__ Voff, const float* __restrict__ A,
+                                                           const float* __restrict__ M, const float* __restrict__ scale,
+                                                           int row0, float* __restrict__ dVoff, float* __restrict__ dA,
+                                                           float* __restrict__ dtransl_v, float* __restrict__ dMv,
+                                                           float* __restrict__ dsv, ContactGradIn cg) {
+    extern __shared__ __attribute__((aligned(16))) float sk_lds[];
+    // dynamic: sGV [nc][3] (Vw, then gv) | sVP [nc][3] (Voff, then vp) | sDV [nc][3] | csc_w [nnz4] | csc_v [nnz8] (ushort)
+    const int nnz4 = (nnz + 3) & ~3, nnz8 = (nnz + 7) & ~7;
+    float* const sGV = sk_lds;
+    float* const sVP = sGV + 3 * nc;
+    float* const sDV = sVP + 3 * nc;
+    float* const sCW = sDV + 3 * nc;
+    unsigned short* const sCV = (unsigned short*)(sCW + nnz4);
+    __shared__ __attribute__((aligned(16))) float sAf[NJ * 12];
+    __shared__ float sdA[NJ * 12];
+    __shared__ float sred[4][SKB_NACC];
+    __shared__ int sCS[NJ + 1];
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int r = row0 + blockIdx.x;
+    FDC_FR_STAMP(2, 0);
+    const float* x = X + (size_t)r * XDIM;
+    const float s = *scale;
+    const V3 transl = v3(x[X_TRANSL], x[X_TRANSL + 1], x[X_TRANSL + 2]);
+    float Mr[12];
+#pragma unroll
+    for (int e = 0; e < 12; ++e) Mr[e] = M[(size_t)r * 12 + e];
+    // one batch of loads, all unconditional (indices clamped; a clamped duplicate stores the same value to the same place)
+    const int n4 = (3 * nc) >> 2, nw4 = nnz4 >> 2, nv8 = nnz8 >> 3;
+    const float4* const gVw = (const float4*)(cg.Vw + (size_t)r * nc * 3);
+    const float4* const gVo = (const float4*)(Voff + (size_t)r * nc * 3);
+    const float4* const gA = (const float4*)(A + (size_t)r * NJ * 12);
+    float4 lvw[2], lvo[2], lcw[2], lvp0[2], lvp1[2], lpq[2];
+    float ldq[2];
+    int ljq[2];
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+        const int i = tid + 256 * k;
+        lvw[k] = gVw[min(i, n4 - 1)];
+        lvo[k] = gVo[min(i, n4 - 1)];
+        lcw[k] = ((const float4*)sm.csc_w)[min(i, nw4 - 1)];
+        const int c = min(i, nc - 1);
+        const size_t qi = (size_t)r * nc + c;
+        lvp0[k] = ((const float4*)sm.vpack)[2 * c];
+        lvp1[k] = ((const float4*)sm.vpack)[2 * c + 1];
+        ldq[k] = cg.dist[qi];
+        // (with the NN launch's own neighbour records -- {x, y, z, bits(position)}, position -1: none -- idx is not needed)
+        lpq[k] = cg.nnpt ? cg.nnpt[qi] : make_float4(0.f, 0.f, 0.f, 0.f);
+        ljq[k] = cg.nnpt ? __float_as_int(lpq[k].w) : cg.idx[qi];
+    }
+    const uint4 lcv = ((const uint4*)sm.csc_v16)[min(tid, nv8 - 1)];
+    const float4 la = gA[min(tid, NJ * 3 - 1)];
+    const int lcs = sm.csc_start[min(tid, NJ)];
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+        const int i = tid + 256 * k;
+        ((float4*)sGV)[min(i, n4 - 1)] = lvw[k];
+        ((float4*)sVP)[min(i, n4 - 1)] = lvo[k];
+        ((float4*)sCW)[min(i, nw4 - 1)] = lcw[k];
+    }
+    ((uint4*)sCV)[min(tid, nv8 - 1)] = lcv;
+    ((float4*)sAf)[min(tid, NJ * 3 - 1)] = la;
+    for (int i = tid; i < NJ * 12; i += 256) sdA[i] = 0.f;
+    sCS[min(tid, NJ)] = lcs;
+    __syncthreads();
+    FDC_FR_STAMP(2, 1);
+    float acc[SKB_NACC];
+#pragma unroll
+    for (int i = 0; i < SKB_NACC; ++i) acc[i] = 0.f;
+    float cterm = 0.f;
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+        const int c = tid + 256 * u;
+        if (c < nc) {
+            SkinFwd f;
+            const float p0 = lvp0[u].x + sVP[3 * c], p1 = lvp0[u].y + sVP[3 * c + 1], p2 = lvp0[u].z + sVP[3 * c + 2];
+            const float vwx = sGV[3 * c], vwy = sGV[3 * c + 1], vwz = sGV[3 * c + 2];
+            f.vp = v3(p0, p1, p2);
+#pragma unroll
+            for (int e = 0; e < 12; ++e) f.T[e] = 0.f;
+            const unsigned jb = __float_as_uint(lvp0[u].w);
+            const float w4[4] = {lvp1[u].x, lvp1[u].y, lvp1[u].z, lvp1[u].w};
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                if (k < sm.K) {                                             // (same terms in the same order as the scalar kernel)
+                    const float w = w4[k];
+                    const float* a = sAf + 12 * ((jb >> (8 * k)) & 255u);
+#pragma unroll
+                    for (int e = 0; e < 12; ++e) f.T[e] += w * a[e];
+                }
+            }
+            const V3 vl = v3(f.T[0] * p0 + f.T[1] * p1 + f.T[2] * p2 + f.T[3], f.T[4] * p0 + f.T[5] * p1 + f.T[6] * p2 + f.T[7],
+                             f.T[8] * p0 + f.T[9] * p1 + f.T[10] * p2 + f.T[11]);
+            f.vb = vl + transl;
+            float dterm;
+            cterm += contact_term(ldq[u], &dterm);
+            const float gg = ljq[u] >= 0 ? 2.f * cg.coef * dterm : 0.f;         // no neighbour (NaN query): zero gradient
+            float4 pt = lpq[u];
+            if (!cg.nnpt && ljq[u] >= 0) pt = cg.scene[ljq[u]];
+            if (ljq[u] < 0) pt = make_float4(0.f, 0.f, 0.f, 0.f);
+            const V3 g = v3(gg * (vwx - pt.x), gg * (vwy - pt.y), gg * (vwz - pt.z));
+            const SkinBwd b = skin_backward_vertex(f, Mr, s, g);
+            sDV[3 * c] = b.dvp.x; sDV[3 * c + 1] = b.dvp.y; sDV[3 * c + 2] = b.dvp.z;
+            acc[NBETA] += b.gv.x; acc[NBETA + 1] += b.gv.y; acc[NBETA + 2] += b.gv.z;
+#pragma unroll
+            for (int e = 0; e < 12; ++e) acc[NBETA + 3 + e] += b.dM[e];
+            acc[NBETA + 15] += b.ds;
+            sGV[3 * c] = b.gv.x; sGV[3 * c + 1] = b.gv.y; sGV[3 * c + 2] = b.gv.z;
+            sVP[3 * c] = p0; sVP[3 * c + 1] = p1; sVP[3 * c + 2] = p2;
+        }
+    }
+    __syncthreads();
+    FDC_FR_STAMP(2, 2);
+    {   // the pose-blend gradient row leaves as float4s
+        float4* const gD = (float4*)(dVoff + (size_t)r * nc * 3);
+        for (int i = tid; i < n4; i += 256) gD[i] = ((const float4*)sDV)[i];
+    }
+    {   // dA_j = sum_v w_vj [gv (x) vp | gv]: the non-empty joints are dealt to the four waves in turn
+        const int jlo = lane < NJ ? sCS[lane] : 0, jhi = lane < NJ ? sCS[lane + 1] : 0;
+        unsigned long long jact = __ballot(jhi > jlo);
+        for (int kact = 0; jact; ++kact) {
+            const int j = __ffsll((long long)jact) - 1;
+            jact &= jact - 1;
+            if ((kact & 3) != wave) continue;               // wave-uniform
+            const int lo = __builtin_amdgcn_readlane(jlo, j), hi = __builtin_amdgcn_readlane(jhi, j);
+            float pa[12];
+#pragma unroll
+            for (int e = 0; e < 12; ++e) pa[e] = 0.f;
+            for (int i = lo + lane; i < hi; i += 64) {
+                const float w = sCW[i];
+                const int v = sCV[i];
+                const float gx = w * sGV[3 * v], gy = w * sGV[3 * v + 1], gz = w * sGV[3 * v + 2];
+                const float px = sVP[3 * v], py = sVP[3 * v + 1], pz = sVP[3 * v + 2];
+                pa[0] += gx * px; pa[1] += gx * py; pa[2] += gx * pz; pa[3] += gx;
+                pa[4] += gy * px; pa[5] += gy * py; pa[6] += gy * pz; pa[7] += gy;
+                pa[8] += gz * px; pa[9] += gz * py; pa[10] += gz * pz; pa[11] += gz;
+            }
+#pragma unroll
+            for (int e = 0; e < 12; ++e) {
+                const float v = wave_sum(pa[e]);
+                if (lane == 0) sdA[j * 12 + e] = v;
+            }
+        }
+    }
+    FDC_FR_STAMP(2, 3);
+#pragma unroll
+    for (int i = NBETA; i < SKB_NACC; ++i) {
+        const float v = wave_sum(acc[i]);
+        if (lane == 0) sred[wave][i] = v;
+    }
+    const float ct = (cg.loss_rows != nullptr) ? wave_sum(cterm) : 0.f;
+    if (cg.loss_rows && lane == 0) sred[wave][0] = ct;
+    __syncthreads();
+    if (cg.loss_rows && tid == 0) cg.loss_rows[(size_t)r * LROW + 3] = (sred[0][0] + sred[1][0]) + (sred[2][0] + sred[3][0]);
+    for (int i = tid; i < NJ * 12; i += 256) dA[(size_t)r * NJ * 12 + i] = sdA[i];
+    if (tid >= NBETA && tid < SKB_NACC) {
+        const float v = sred[0][tid] + sred[1][tid] + sred[2][tid] + sred[3][tid];
+        if (tid < NBETA + 3) dtransl_v[(size_t)r * 3 + tid - NBETA] = v;
+        else if (tid < NBETA + 15) dMv[(size_t)r * 12 + tid - NBETA - 3] = v;
+        else dsv[r] = v;
+    }
+    FDC_FR_STAMP(2, 4);
+}
+
 // mode 'local', cal_loss2 (:404-405): d/dV of mean |second difference over frames| of ALL world vertices.
 // V is [rows, nv3] (nv3 = 3 * vertices); owned rows start at row0, global frame = frame0 + blockIdx.y.
 __global__ void vert_smooth_kernel(const float* __restrict__ V, size_t nv3, int row0, int frame0, int n_total,
@@ -917,6 +1087,8 @@ struct SkinSet {          // skinning constants for a vertex set (all V, or the 
     int ldp = 0;                                // row stride of posedirs: 3*nv rounded up to a multiple of 4 (16-byte rows)
     DevBuf<float> vt, ww, posedirs, csc_w;      // posedirs [496, ldp] = [posedirs ; shapedirs^T], zero padding
     DevBuf<int> wj, csc_start, csc_v;
+    DevBuf<float4> vpack;                       // SkinModel::vpack / csc_v16 (K <= 4 and nv <= 65535 only)
+    DevBuf<unsigned short> csc_v16;
     // the blend matrix in MFMA fragment order (fdc_panel.h), built for vertex sets whose K = 3 nv image fits the LDS slabs:
     // pn_fwd: B(k, n) = posedirs[k, n] (offsets = [pose feature | betas] x B), pn_bwd: B(k, n) = posedirs[n, k] (data gradient)
     DevBuf<float> pn_fwd_f, pn_bwd_f;
@@ -926,9 +1098,11 @@ struct SkinSet {          // skinning constants for a vertex set (all V, or the 
     SkinModel model() const {
         SkinModel m; m.vt = vt.p; m.S = nullptr; m.wj = wj.p; m.ww = ww.p; m.K = K;
         m.csc_start = csc_start.p; m.csc_v = csc_v.p; m.csc_w = csc_w.p;
+        m.vpack = (const float*)vpack.p; m.csc_v16 = csc_v16.p;
         return m;
     }
     void release() { vt.release(); ww.release(); posedirs.release(); wj.release(); csc_w.release(); csc_start.release(); csc_v.release();
+                     vpack.release(); csc_v16.release();
                      pn_fwd_f.release(); pn_bwd_f.release(); pn_fwd = PanelB(); pn_bwd = PanelB();
                      pn_fwd3_f.release(); pn_bwd3_f.release(); pn_fwd3 = PanelB3(); pn_bwd3 = PanelB3(); }
 };
@@ -952,6 +1126,7 @@ struct OptState {
     DevBuf<float> kp2d;       // per-frame inner fit: 2D keypoints [n_local,23,3] (u, v, confidence)
     DevBuf<float4> seedpt;    // coordinates (+ position in the sorted scene) of each query's current neighbour: next launch's seed
     // work-list cache of the in-loop NN launch (fdc_chamfer.h NNCache): ids [groups * 4][64], hdr [groups * 4], anchors [4][nq]
+    bool skin_vec = true;          // FDCAP_SKIN_VEC=0 (read by fdcap_opt_create; A/B): the scalar-load skinning backward
     DevBuf<float> loss_rows;       // [R][LROW] per-frame partial sums of the printed loss terms (logging iterations)
     DevBuf<unsigned short> nnc_ids;
     DevBuf<int> nnc_hdr;
@@ -1077,7 +1252,24 @@ int build_skin_set(fdcap_ctx* c, const std::vector<int64_t>& ids, SkinSet* out) 
     csc_start[NJ] = (int)csc_v.size();
     out->nnz = (int)csc_v.size();
     if (csc_v.empty()) { csc_v.push_back(0); csc_w.push_back(0.f); }
+    while (csc_w.size() & 3) csc_w.push_back(0.f);           // 16-byte staging reads whole float4s
     out->nv = nv; out->K = K; out->ldp = ldp;
+    out->vpack.release(); out->csc_v16.release();
+    if (K <= 4 && nv > 0 && nv <= 65535) {
+        std::vector<float4> vp((size_t)nv * 2);
+        for (int i = 0; i < nv; ++i) {
+            unsigned jb = 0;
+            float w4[4] = {0.f, 0.f, 0.f, 0.f};
+            for (int k = 0; k < K; ++k) { jb |= (unsigned)wj[(size_t)i * K + k] << (8 * k); w4[k] = ww[(size_t)i * K + k]; }
+            float jf; memcpy(&jf, &jb, 4);
+            vp[2 * (size_t)i] = make_float4(vt[3 * i], vt[3 * i + 1], vt[3 * i + 2], jf);
+            vp[2 * (size_t)i + 1] = make_float4(w4[0], w4[1], w4[2], w4[3]);
+        }
+        std::vector<unsigned short> v16((csc_v.size() + 7) & ~(size_t)7, 0);
+        for (size_t i = 0; i < csc_v.size(); ++i) v16[i] = (unsigned short)csc_v[i];
+        HIP_TRY(out->vpack.upload(vp.data(), vp.size()));
+        HIP_TRY(out->csc_v16.upload(v16.data(), v16.size()));
+    }
     HIP_TRY(out->csc_start.upload(csc_start.data(), csc_start.size()));
     HIP_TRY(out->csc_v.upload(csc_v.data(), csc_v.size()));
     HIP_TRY(out->csc_w.upload(csc_w.data(), csc_w.size()));
@@ -1743,6 +1935,7 @@ int fdcap_opt_create(fdcap_ctx* c, const fdcap_opt_config* cfg, float* rows_x, f
         if (e_ != hipSuccess) err = (int)e_;
     }
     if (!err && o->contact_on) {
+        if (const char* e = getenv("FDCAP_SKIN_VEC")) o->skin_vec = e[0] != '0';
         if (const char* e = getenv("FDCAP_NN_CACHE_SLACK")) o->nnc_slack = (float)atof(e);
         if (o->nnc_slack > 0.f) {                                        // groups of 32 queries x up to 4 waves per group
             const size_t ng4 = ((size_t)nq_all + 31) / 32 * 4;
@@ -1845,7 +2038,13 @@ static int opt_backward_impl(fdcap_ctx* c, const LossWeights& lw, int32_t log_te
         if (nc <= SKS_MAXV && c->contact.nnz <= SKS_MAXNNZ) {
             const int nnz = c->contact.nnz;
             const size_t lds = (size_t)6 * nc * sizeof(float) + (size_t)nnz * sizeof(float) + (((size_t)nnz * 2 + 15) & ~(size_t)15);
-            if (nc <= 512 && nnz <= 2048)
+            const SkinModel smc = c->contact.model();
+            if (o->skin_vec && nc <= 512 && nnz <= 2048 && (nc & 3) == 0 && smc.vpack && smc.csc_v16 &&
+                (((size_t)o->Vw.p | (size_t)o->Voff.p | (size_t)o->dVoff.p | (size_t)o->A.p) & 15) == 0) {
+                const size_t ldsv = (size_t)9 * nc * sizeof(float) + (size_t)((nnz + 3) & ~3) * sizeof(float) + (size_t)((nnz + 7) & ~7) * 2;
+                hipLaunchKernelGGL(skin_bwd_vec_kernel, dim3(nl), dim3(256), ldsv, st, smc, nc, nnz, o->X.p, o->Voff.p, o->A.p,
+                                   o->M.p, o->scale.p, 2, o->dVoff.p, o->dA.p, o->dtransl_v.p, o->dMv.p, o->dsv.p, cg);
+            } else if (nc <= 512 && nnz <= 2048)
                 hipLaunchKernelGGL((skin_bwd_small_kernel<2, 8>), dim3(nl), dim3(256), lds, st, c->contact.model(), nc, nnz, o->X.p, o->Voff.p, o->A.p,
                                    o->M.p, o->scale.p, 2, o->dVoff.p, o->dA.p, o->dtransl_v.p, o->dMv.p, o->dsv.p, cg);
             else

@@ -476,6 +476,23 @@ def test_runs_are_bit_reproducible():
     assert torch.equal(outs[0][0], outs[1][0]) and outs[0][1] == outs[1][1] and torch.equal(outs[0][2], outs[1][2])
 
 
+@pytest.mark.parametrize("n,per_part", [(48, 40), (5, 250)])
+def test_vector_staged_skinning_backward_equals_the_scalar_kernel(n, per_part):
+    """skin_bwd_vec_kernel (16-byte staging through LDS, packed per-vertex constants) evaluates the same terms in the same
+    order as skin_bwd_small_kernel: whole fits agree bit for bit (80 and 500 contact vertices; the second is the bench's set)."""
+    outs = []
+    for flag in ("0", "1"):
+        os.environ["FDCAP_SKIN_VEC"] = flag
+        try:
+            fop, bm, vp, clip, scene, vid = _make_fop(n, 1200, 20_000, per_part, 12, seed=71)
+            body, scale, cam = fop.fitting(torch.tensor(clip.body_params).cuda(), "global")
+            outs.append((body.clone(), float(scale), cam.clone()))
+            fop.close()
+        finally:
+            os.environ.pop("FDCAP_SKIN_VEC")
+    assert torch.equal(outs[0][0], outs[1][0]) and outs[0][1] == outs[1][1] and torch.equal(outs[0][2], outs[1][2])
+
+
 def test_no_contact_config_and_ragged_sizes():
     """BASELINE config 1 (8 frames, no scene: rec + temporal only) and awkward sizes."""
     for n, ns in ((8, 0), (3, 0), (17, 1100)):
