@@ -21,7 +21,7 @@ struct SkinModel {
     const int* csc_v;     // [nnz]
     const float* csc_w;   // [nnz] (allocated and zero-padded to a multiple of 4)
     // 16-byte forms of the same constants (K <= 4, V <= 65535; null otherwise) for kernels that stage them with vector loads:
-    const float* vpack = nullptr;            // [V][8], 32-byte aligned: {vt.x, vt.y, vt.z, bits(j0 | j1 << 8 | j2 << 16 | j3 << 24)}, {w0, w1, w2, w3}
+    const float* vpack = nullptr;            // [2][V][4], 16-byte aligned: {vt.x, vt.y, vt.z, bits(j0 | j1 << 8 | j2 << 16 | j3 << 24)} of every vertex, then {w0, w1, w2, w3}
     const unsigned short* csc_v16 = nullptr; // [nnz rounded up to a multiple of 8] csc_v as 16-bit ids
 };
 

@@ -588,8 +588,8 @@ __global__ __launch_bounds__(256) void skin_bwd_vec_kernel(SkinModel sm, int nc,
         lcw[k] = ((const float4*)sm.csc_w)[min(i, nw4 - 1)];
         const int c = min(i, nc - 1);
         const size_t qi = (size_t)r * nc + c;
-        lvp0[k] = ((const float4*)sm.vpack)[2 * c];
-        lvp1[k] = ((const float4*)sm.vpack)[2 * c + 1];
+        lvp0[k] = ((const float4*)sm.vpack)[c];
+        lvp1[k] = ((const float4*)sm.vpack)[nc + c];
         ldq[k] = cg.dist[qi];
         // (with the NN launch's own neighbour records -- {x, y, z, bits(position)}, position -1: none -- idx is not needed)
         lpq[k] = cg.nnpt ? cg.nnpt[qi] : make_float4(0.f, 0.f, 0.f, 0.f);
@@ -1262,8 +1262,8 @@ int build_skin_set(fdcap_ctx* c, const std::vector<int64_t>& ids, SkinSet* out) 
             float w4[4] = {0.f, 0.f, 0.f, 0.f};
             for (int k = 0; k < K; ++k) { jb |= (unsigned)wj[(size_t)i * K + k] << (8 * k); w4[k] = ww[(size_t)i * K + k]; }
             float jf; memcpy(&jf, &jb, 4);
-            vp[2 * (size_t)i] = make_float4(vt[3 * i], vt[3 * i + 1], vt[3 * i + 2], jf);
-            vp[2 * (size_t)i + 1] = make_float4(w4[0], w4[1], w4[2], w4[3]);
+            vp[(size_t)i] = make_float4(vt[3 * i], vt[3 * i + 1], vt[3 * i + 2], jf);
+            vp[(size_t)nv + i] = make_float4(w4[0], w4[1], w4[2], w4[3]);
         }
         std::vector<unsigned short> v16((csc_v.size() + 7) & ~(size_t)7, 0);
         for (size_t i = 0; i < csc_v.size(); ++i) v16[i] = (unsigned short)csc_v[i];
