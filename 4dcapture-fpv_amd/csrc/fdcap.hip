@@ -61,49 +61,64 @@ struct alignas(16) PoseStage {
     float cam[16];
     int parents[NJ + 1], order[NJ + 1], level_start[MAX_LEVELS + 4], child_start[NJ + 1], child_list[NJ + 1], depth[NJ + 1];
 };
-__device__ __forceinline__ PoseModel stage_pose(const PoseModel& pm, PoseStage& t, const float* __restrict__ xrow,
+// 64 threads (one wave).  Every load is issued before the first LDS write (two unrolled passes): written as
+// load-store loops the compiler waits for each trip's load before the next is issued -- 7 serial L2 round trips
+// (measured 16 k cycles for this prologue instead of ~3 k).  Device allocations are 256-byte aligned: 16-byte loads.
+// The two passes are separate functions so that a kernel can put its other cold loads (decoder partial sums, gradient
+// rows) between them: a freshly launched kernel finds none of its inputs in its L2, and every DEPENDENT round trip at
+// its start costs ~2.5 k cycles (s_memtime: three in pose_fwd_kernel's prologue = 8 k of its 23 k cycles).
+constexpr int PS_NJD4 = (NJ * 3 * NBETA) / 4, PS_NHC4 = (2 * 12 * 45) / 4;      // 412, 270
+constexpr int PS_KJD = (PS_NJD4 + 63) / 64, PS_KHC = (PS_NHC4 + 63) / 64;       // 7, 5
+struct PoseStageRegs {
+    float4 vj[PS_KJD], vh[PS_KHC];
+    float vt[3], vm[2], vx[2], vjd_tail, vcam;
+    int ip, io, icl, idp, ics, ils;
+};
+__device__ __forceinline__ void stage_pose_load(const PoseModel& pm, PoseStageRegs& g, const float* __restrict__ xrow,
                                                 const float* __restrict__ camrow) {
-    // 64 threads (one wave).  Every load is issued before the first LDS write (two unrolled passes): written as
-    // load-store loops the compiler waits for each trip's load before the next is issued -- 7 serial L2 round trips
-    // (measured 16 k cycles for this prologue instead of ~3 k).  Device allocations are 256-byte aligned: 16-byte loads.
     const int tid = threadIdx.x;
-    constexpr int NJD4 = (NJ * 3 * NBETA) / 4, NHC4 = (2 * 12 * 45) / 4;      // 412, 270
-    constexpr int KJD = (NJD4 + 63) / 64, KHC = (NHC4 + 63) / 64;             // 7, 5
-    float4 vj[KJD], vh[KHC];
-    float vt[3], vm[2], vx[2];
 #pragma unroll
-    for (int k = 0; k < KJD; ++k) { const int i = tid + 64 * k; vj[k] = i < NJD4 ? ((const float4*)pm.Jd)[i] : make_float4(0.f, 0.f, 0.f, 0.f); }
+    for (int k = 0; k < PS_KJD; ++k) { const int i = tid + 64 * k; g.vj[k] = i < PS_NJD4 ? ((const float4*)pm.Jd)[i] : make_float4(0.f, 0.f, 0.f, 0.f); }
 #pragma unroll
-    for (int k = 0; k < KHC; ++k) { const int i = tid + 64 * k; vh[k] = i < NHC4 ? ((const float4*)pm.hand_comp)[i] : make_float4(0.f, 0.f, 0.f, 0.f); }
+    for (int k = 0; k < PS_KHC; ++k) { const int i = tid + 64 * k; g.vh[k] = i < PS_NHC4 ? ((const float4*)pm.hand_comp)[i] : make_float4(0.f, 0.f, 0.f, 0.f); }
 #pragma unroll
-    for (int k = 0; k < 3; ++k) { const int i = tid + 64 * k; vt[k] = i < NJ * 3 ? pm.Jt[i] : 0.f; }
+    for (int k = 0; k < 3; ++k) { const int i = tid + 64 * k; g.vt[k] = i < NJ * 3 ? pm.Jt[i] : 0.f; }
 #pragma unroll
-    for (int k = 0; k < 2; ++k) { const int i = tid + 64 * k; vm[k] = i < 90 ? pm.hand_mean[i] : 0.f; vx[k] = i < XDIM ? xrow[i] : 0.f; }
-    const float vjd_tail = tid < (NJ * 3 * NBETA) % 4 ? pm.Jd[NJD4 * 4 + tid] : 0.f;
-    const float vcam = tid < 16 ? camrow[tid] : 0.f;
-    const int ip = tid < NJ ? pm.parents[tid] : 0, io = tid < NJ ? pm.order[tid] : 0, icl = tid < NJ - 1 ? pm.child_list[tid] : 0;
-    const int idp = tid < NJ ? pm.depth[tid] : 0;
-    const int ics = tid <= NJ ? pm.child_start[tid] : 0;
-    const int ils = (tid <= pm.nlevels && tid <= MAX_LEVELS) ? pm.level_start[tid] : 0;
+    for (int k = 0; k < 2; ++k) { const int i = tid + 64 * k; g.vm[k] = i < 90 ? pm.hand_mean[i] : 0.f; g.vx[k] = i < XDIM ? xrow[i] : 0.f; }
+    g.vjd_tail = tid < (NJ * 3 * NBETA) % 4 ? pm.Jd[PS_NJD4 * 4 + tid] : 0.f;
+    g.vcam = tid < 16 ? camrow[tid] : 0.f;
+    g.ip = tid < NJ ? pm.parents[tid] : 0; g.io = tid < NJ ? pm.order[tid] : 0; g.icl = tid < NJ - 1 ? pm.child_list[tid] : 0;
+    g.idp = tid < NJ ? pm.depth[tid] : 0;
+    g.ics = tid <= NJ ? pm.child_start[tid] : 0;
+    g.ils = (tid <= pm.nlevels && tid <= MAX_LEVELS) ? pm.level_start[tid] : 0;
+}
+__device__ __forceinline__ PoseModel stage_pose_store(const PoseModel& pm, PoseStage& t, const PoseStageRegs& g) {
+    const int tid = threadIdx.x;
 #pragma unroll
-    for (int k = 0; k < KJD; ++k) { const int i = tid + 64 * k; if (i < NJD4) ((float4*)t.Jd)[i] = vj[k]; }
+    for (int k = 0; k < PS_KJD; ++k) { const int i = tid + 64 * k; if (i < PS_NJD4) ((float4*)t.Jd)[i] = g.vj[k]; }
 #pragma unroll
-    for (int k = 0; k < KHC; ++k) { const int i = tid + 64 * k; if (i < NHC4) ((float4*)t.hand_comp)[i] = vh[k]; }
+    for (int k = 0; k < PS_KHC; ++k) { const int i = tid + 64 * k; if (i < PS_NHC4) ((float4*)t.hand_comp)[i] = g.vh[k]; }
 #pragma unroll
-    for (int k = 0; k < 3; ++k) { const int i = tid + 64 * k; if (i < NJ * 3) t.Jt[i] = vt[k]; }
+    for (int k = 0; k < 3; ++k) { const int i = tid + 64 * k; if (i < NJ * 3) t.Jt[i] = g.vt[k]; }
 #pragma unroll
-    for (int k = 0; k < 2; ++k) { const int i = tid + 64 * k; if (i < 90) t.hand_mean[i] = vm[k]; if (i < XDIM) t.x[i] = vx[k]; }
-    if (tid < (NJ * 3 * NBETA) % 4) t.Jd[NJD4 * 4 + tid] = vjd_tail;
-    if (tid < 16) t.cam[tid] = vcam;
-    if (tid < NJ) { t.parents[tid] = ip; t.order[tid] = io; t.child_list[tid] = icl; t.depth[tid] = idp; }
-    if (tid <= NJ) t.child_start[tid] = ics;
-    if (tid <= pm.nlevels && tid <= MAX_LEVELS) t.level_start[tid] = ils;
+    for (int k = 0; k < 2; ++k) { const int i = tid + 64 * k; if (i < 90) t.hand_mean[i] = g.vm[k]; if (i < XDIM) t.x[i] = g.vx[k]; }
+    if (tid < (NJ * 3 * NBETA) % 4) t.Jd[PS_NJD4 * 4 + tid] = g.vjd_tail;
+    if (tid < 16) t.cam[tid] = g.vcam;
+    if (tid < NJ) { t.parents[tid] = g.ip; t.order[tid] = g.io; t.child_list[tid] = g.icl; t.depth[tid] = g.idp; }
+    if (tid <= NJ) t.child_start[tid] = g.ics;
+    if (tid <= pm.nlevels && tid <= MAX_LEVELS) t.level_start[tid] = g.ils;
     __syncthreads();
     PoseModel l = pm;
     l.Jd = t.Jd; l.Jt = t.Jt; l.hand_comp = t.hand_comp; l.hand_mean = t.hand_mean;
     l.parents = t.parents; l.order = t.order; l.level_start = t.level_start; l.child_start = t.child_start; l.child_list = t.child_list;
     l.depth = t.depth;
     return l;
+}
+__device__ __forceinline__ PoseModel stage_pose(const PoseModel& pm, PoseStage& t, const float* __restrict__ xrow,
+                                                const float* __restrict__ camrow) {
+    PoseStageRegs g;
+    stage_pose_load(pm, g, xrow, camrow);
+    return stage_pose_store(pm, t, g);
 }
 
 // one 64-thread workgroup (one wavefront) per frame.
@@ -120,15 +135,28 @@ __global__ __launch_bounds__(64) void pose_fwd_kernel(PoseModel pm, const float*
     __shared__ float s_O[ODIM + 2];
     FDC_FR_STAMP(0, 0);
     int r = row0 + blockIdx.x;
+    PoseStageRegs rg;
+    stage_pose_load(pm, rg, X + (size_t)r * XDIM, CAM + (size_t)r * 16);
+    float op[2][VP_NQ];                                      // the decoder's partial sums: same batch of loads (indices clamped)
     if (PARTS) {
-        for (int e = threadIdx.x; e < ODIM; e += 64) {
-            const float v = vp_sum_parts(Opart, part_stride, (size_t)r * ODIM + e);
-            s_O[e] = v;
-            O[(size_t)r * ODIM + e] = v;
-        }
+#pragma unroll
+        for (int k = 0; k < 2; ++k)
+#pragma unroll
+            for (int q = 0; q < VP_NQ; ++q) op[k][q] = Opart[(size_t)q * part_stride + (size_t)r * ODIM + min((int)threadIdx.x + 64 * k, ODIM - 1)];
     }
     const float sc_v = *scale;
-    const PoseModel pml = stage_pose(pm, stg, X + (size_t)r * XDIM, CAM + (size_t)r * 16);   // (its barrier also publishes s_O)
+    if (PARTS) {
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+            const int e = threadIdx.x + 64 * k;
+            if (e < ODIM) {
+                const float v = (op[k][0] + op[k][1]) + (op[k][2] + op[k][3]);     // vp_sum_parts' order
+                s_O[e] = v;
+                O[(size_t)r * ODIM + e] = v;
+            }
+        }
+    }
+    const PoseModel pml = stage_pose_store(pm, stg, rg);     // (its barrier also publishes s_O)
     if (PF && threadIdx.x < NBETA) PF[(size_t)r * NPFX + NPF + threadIdx.x] = stg.x[X_BETAS + threadIdx.x];
     if (PARTS) {
         pose_forward(pml, stg.x, s_O, stg.cam, sc_v, sc,
@@ -166,30 +194,57 @@ __global__ __launch_bounds__(64) void pose_bwd_kernel(PoseModel pm, const float*
     __shared__ float s_dJw[NJW * 3];
     FDC_FR_STAMP(1, 0);
     int r = row0 + blockIdx.x;
-    const float sc_v = *scale;
-    const PoseModel pml = stage_pose(pm, stg, X + (size_t)r * XDIM, CAM + (size_t)r * 16);
+    // one batch of cold loads: the staged tables / rows AND what the fused parameter-loss prologue reads (this row's
+    // neighbours, data row, mask, neighbouring joints) -- as loops after the staging they were four more dependent round trips.
+    // Rows r - 2 .. r + 2 exist for every owned row (two halo rows on either side); values outside the clip are masked below.
+    PoseStageRegs rg;
+    stage_pose_load(pm, rg, X + (size_t)r * XDIM, CAM + (size_t)r * 16);
+    float lx[2][4], lx0[2], lj[2][3], lmask = 0.f;
     if (pl.X0) {
-        // param_loss_kernel's gradients formed here (non-logging iterations): dX row (=) data + temporal terms on the raw
-        // rows, world-smoothing gradient of this frame's joints into LDS instead of a round trip through dJw
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+            const int e = min((int)threadIdx.x + 64 * k, XDIM - 1);
+            const float* x = X + (size_t)r * XDIM + e;
+            lx[k][0] = x[-2 * XDIM]; lx[k][1] = x[-XDIM]; lx[k][2] = x[XDIM]; lx[k][3] = x[2 * XDIM];
+            lx0[k] = pl.X0[(size_t)r * XDIM + e];
+            const int ej = min((int)threadIdx.x + 64 * k, NJW * 3 - 1);
+            const float* j = pl.Jw + (size_t)r * NJW * 3 + ej;
+            lj[k][0] = j[-NJW * 3]; lj[k][1] = j[0]; lj[k][2] = j[NJW * 3];
+        }
+        lmask = pl.mask[r];
+    }
+    const float sc_v = *scale;
+    const PoseModel pml = stage_pose_store(pm, stg, rg);
+    if (pl.X0) {
+        // param_loss_kernel's gradients formed here: dX row (=) data + temporal terms on the raw rows, world-smoothing
+        // gradient of this frame's joints into LDS instead of a round trip through dJw
         const int g = pl.frame0 + blockIdx.x;
         float l_rec = 0.f, l_vp = 0.f, l_sm = 0.f, l_ws = 0.f;
-        for (int e = threadIdx.x; e < XDIM; e += 64) {
-            const float* x = X + (size_t)r * XDIM + e;
-            float rec = 0.f, sm = 0.f;
-            dX[(size_t)r * XDIM + e] = param_loss_grad(g, pl.n_total, g >= 2 ? x[-2 * XDIM] : 0.f, g >= 1 ? x[-XDIM] : 0.f, x[0],
-                                                       g + 1 < pl.n_total ? x[XDIM] : 0.f, g + 2 < pl.n_total ? x[2 * XDIM] : 0.f,
-                                                       pl.X0[(size_t)r * XDIM + e], pl.mask[r], pl.w_rec, pl.w_sm, &rec, &sm);
-            l_rec += rec; l_sm += sm;
-            if (e >= X_LATENT && e < X_LATENT + 32) l_vp += x[0] * x[0];
-        }
-        if (pl.world_grad || pl.loss_rows)
-            for (int e = threadIdx.x; e < NJW * 3; e += 64) {
-                const float* j = pl.Jw + (size_t)r * NJW * 3 + e;
-                float ws = 0.f;
-                s_dJw[e] = world_smooth_grad(g, pl.n_total, g >= 1 ? j[-NJW * 3] : 0.f, j[0], g + 1 < pl.n_total ? j[NJW * 3] : 0.f,
-                                             pl.w_ws, &ws);
-                l_ws += ws;
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+            const int e = threadIdx.x + 64 * k;
+            if (e < XDIM) {
+                const float xc = stg.x[e];
+                float rec = 0.f, sm = 0.f;
+                dX[(size_t)r * XDIM + e] = param_loss_grad(g, pl.n_total, g >= 2 ? lx[k][0] : 0.f, g >= 1 ? lx[k][1] : 0.f, xc,
+                                                           g + 1 < pl.n_total ? lx[k][2] : 0.f, g + 2 < pl.n_total ? lx[k][3] : 0.f,
+                                                           lx0[k], lmask, pl.w_rec, pl.w_sm, &rec, &sm);
+                l_rec += rec; l_sm += sm;
+                if (e >= X_LATENT && e < X_LATENT + 32) l_vp += xc * xc;
             }
+        }
+        if (pl.world_grad || pl.loss_rows) {
+#pragma unroll
+            for (int k = 0; k < 2; ++k) {
+                const int e = threadIdx.x + 64 * k;
+                if (e < NJW * 3) {
+                    float ws = 0.f;
+                    s_dJw[e] = world_smooth_grad(g, pl.n_total, g >= 1 ? lj[k][0] : 0.f, lj[k][1], g + 1 < pl.n_total ? lj[k][2] : 0.f,
+                                                 pl.w_ws, &ws);
+                    l_ws += ws;
+                }
+            }
+        }
         if (pl.loss_rows) {                                  // kernel-uniform: logging iterations only
             l_rec = wave_sum64(l_rec); l_vp = wave_sum64(l_vp); l_sm = wave_sum64(l_sm); l_ws = wave_sum64(l_ws);
             if (threadIdx.x == 0) {
