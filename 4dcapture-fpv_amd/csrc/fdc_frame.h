@@ -216,7 +216,7 @@ FDC_HD void pose_backward(const PoseModel& pm, const float* x, const float* o, c
     V3 transl = v3(x[X_TRANSL], x[X_TRANSL + 1], x[X_TRANSL + 2]);
     for (int j = tid; j < NJ; j += nthr) {
         for (int e = 0; e < 9; ++e) sc.R[j][e] = Rm[9 * j + e];
-        { float g12[12]; load12(g12, G + 12 * j); for (int e = 0; e < 12; ++e) sc.G[j][e] = g12[e]; }
+        if (G) { float g12[12]; load12(g12, G + 12 * j); for (int e = 0; e < 12; ++e) sc.G[j][e] = g12[e]; }   // null: the caller has put it into sc.G
         for (int c = 0; c < 3; ++c) sc.J[j][c] = Jrest[3 * j + c];
         M3 GR = g_rot(sc.G[j]);
         V3 Jj = v3(sc.J[j][0], sc.J[j][1], sc.J[j][2]);

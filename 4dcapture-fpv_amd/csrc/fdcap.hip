@@ -61,64 +61,58 @@ struct alignas(16) PoseStage {
     float cam[16];
     int parents[NJ + 1], order[NJ + 1], level_start[MAX_LEVELS + 4], child_start[NJ + 1], child_list[NJ + 1], depth[NJ + 1];
 };
-// 64 threads (one wave).  Every load is issued before the first LDS write (two unrolled passes): written as
-// load-store loops the compiler waits for each trip's load before the next is issued -- 7 serial L2 round trips
-// (measured 16 k cycles for this prologue instead of ~3 k).  Device allocations are 256-byte aligned: 16-byte loads.
-// The two passes are separate functions so that a kernel can put its other cold loads (decoder partial sums, gradient
-// rows) between them: a freshly launched kernel finds none of its inputs in its L2, and every DEPENDENT round trip at
-// its start costs ~2.5 k cycles (s_memtime: three in pose_fwd_kernel's prologue = 8 k of its 23 k cycles).
-constexpr int PS_NJD4 = (NJ * 3 * NBETA) / 4, PS_NHC4 = (2 * 12 * 45) / 4;      // 412, 270
-constexpr int PS_KJD = (PS_NJD4 + 63) / 64, PS_KHC = (PS_NHC4 + 63) / 64;       // 7, 5
-struct PoseStageRegs {
-    float4 vj[PS_KJD], vh[PS_KHC];
-    float vt[3], vm[2], vx[2], vjd_tail, vcam;
-    int ip, io, icl, idp, ics, ils;
-};
-__device__ __forceinline__ void stage_pose_load(const PoseModel& pm, PoseStageRegs& g, const float* __restrict__ xrow,
-                                                const float* __restrict__ camrow) {
-    const int tid = threadIdx.x;
+// Staging by LDS-DMA (global_load_lds: global -> LDS without passing through registers; destination = wave-uniform LDS
+// address + lane x size, source per lane).  A freshly launched kernel finds none of its inputs in its L2 and every DEPENDENT
+// round trip at its start costs ~1-2.5 k cycles (s_memtime); with the copies issued back to back and ONE wait in front of the
+// barrier the whole prologue is a single round trip, whatever else the kernel adds to the batch.  What this replaced, each
+// measured: load-store loops (the compiler waits for each trip's load: 16 k cycles); two unrolled passes through registers
+// (3 k alone, but loads under lane masks are branches whose merges -- and waits -- land between the loads once other code
+// follows, the scheduler pairs unconditional loads with their stores, and any fence that would pin them sends the
+// staging arrays to scratch).
+typedef __attribute__((address_space(1))) const void* fdc_gptr_t;
+typedef __attribute__((address_space(3))) void* fdc_lptr_t;
+// one wave copies n units of 16 / 4 bytes: unit i = 64 k + lane.  g and lds 16- / 4-byte aligned; K = ceil(n / 64) trips.
+template <int K>
+__device__ __forceinline__ void glds16(const void* g, void* lds, int n) {
+    const int lane = threadIdx.x & 63;
 #pragma unroll
-    for (int k = 0; k < PS_KJD; ++k) { const int i = tid + 64 * k; g.vj[k] = i < PS_NJD4 ? ((const float4*)pm.Jd)[i] : make_float4(0.f, 0.f, 0.f, 0.f); }
-#pragma unroll
-    for (int k = 0; k < PS_KHC; ++k) { const int i = tid + 64 * k; g.vh[k] = i < PS_NHC4 ? ((const float4*)pm.hand_comp)[i] : make_float4(0.f, 0.f, 0.f, 0.f); }
-#pragma unroll
-    for (int k = 0; k < 3; ++k) { const int i = tid + 64 * k; g.vt[k] = i < NJ * 3 ? pm.Jt[i] : 0.f; }
-#pragma unroll
-    for (int k = 0; k < 2; ++k) { const int i = tid + 64 * k; g.vm[k] = i < 90 ? pm.hand_mean[i] : 0.f; g.vx[k] = i < XDIM ? xrow[i] : 0.f; }
-    g.vjd_tail = tid < (NJ * 3 * NBETA) % 4 ? pm.Jd[PS_NJD4 * 4 + tid] : 0.f;
-    g.vcam = tid < 16 ? camrow[tid] : 0.f;
-    g.ip = tid < NJ ? pm.parents[tid] : 0; g.io = tid < NJ ? pm.order[tid] : 0; g.icl = tid < NJ - 1 ? pm.child_list[tid] : 0;
-    g.idp = tid < NJ ? pm.depth[tid] : 0;
-    g.ics = tid <= NJ ? pm.child_start[tid] : 0;
-    g.ils = (tid <= pm.nlevels && tid <= MAX_LEVELS) ? pm.level_start[tid] : 0;
+    for (int k = 0; k < K; ++k)
+        if (lane + 64 * k < n)
+            __builtin_amdgcn_global_load_lds((fdc_gptr_t)((const char*)g + 16 * (lane + 64 * k)), (fdc_lptr_t)((char*)lds + 1024 * k), 16, 0, 0);
 }
-__device__ __forceinline__ PoseModel stage_pose_store(const PoseModel& pm, PoseStage& t, const PoseStageRegs& g) {
-    const int tid = threadIdx.x;
+template <int K>
+__device__ __forceinline__ void glds4(const void* g, void* lds, int n) {
+    const int lane = threadIdx.x & 63;
 #pragma unroll
-    for (int k = 0; k < PS_KJD; ++k) { const int i = tid + 64 * k; if (i < PS_NJD4) ((float4*)t.Jd)[i] = g.vj[k]; }
-#pragma unroll
-    for (int k = 0; k < PS_KHC; ++k) { const int i = tid + 64 * k; if (i < PS_NHC4) ((float4*)t.hand_comp)[i] = g.vh[k]; }
-#pragma unroll
-    for (int k = 0; k < 3; ++k) { const int i = tid + 64 * k; if (i < NJ * 3) t.Jt[i] = g.vt[k]; }
-#pragma unroll
-    for (int k = 0; k < 2; ++k) { const int i = tid + 64 * k; if (i < 90) t.hand_mean[i] = g.vm[k]; if (i < XDIM) t.x[i] = g.vx[k]; }
-    if (tid < (NJ * 3 * NBETA) % 4) t.Jd[PS_NJD4 * 4 + tid] = g.vjd_tail;
-    if (tid < 16) t.cam[tid] = g.vcam;
-    if (tid < NJ) { t.parents[tid] = g.ip; t.order[tid] = g.io; t.child_list[tid] = g.icl; t.depth[tid] = g.idp; }
-    if (tid <= NJ) t.child_start[tid] = g.ics;
-    if (tid <= pm.nlevels && tid <= MAX_LEVELS) t.level_start[tid] = g.ils;
-    __syncthreads();
+    for (int k = 0; k < K; ++k)
+        if (lane + 64 * k < n)
+            __builtin_amdgcn_global_load_lds((fdc_gptr_t)((const char*)g + 4 * (lane + 64 * k)), (fdc_lptr_t)((char*)lds + 256 * k), 4, 0, 0);
+}
+constexpr int PS_NJD4 = (NJ * 3 * NBETA) / 4, PS_NHC4 = (2 * 12 * 45) / 4;      // 412, 270
+// issue the copies of the pose tables and this frame's rows (one wave; no wait)
+__device__ __forceinline__ void stage_pose_issue(const PoseModel& pm, PoseStage& t, const float* __restrict__ xrow,
+                                                 const float* __restrict__ camrow) {
+    glds16<(PS_NJD4 + 63) / 64>(pm.Jd, t.Jd, PS_NJD4);
+    glds4<1>(pm.Jd + PS_NJD4 * 4, t.Jd + PS_NJD4 * 4, (NJ * 3 * NBETA) % 4);
+    glds16<(PS_NHC4 + 63) / 64>(pm.hand_comp, t.hand_comp, PS_NHC4);
+    glds4<3>(pm.Jt, t.Jt, NJ * 3);
+    glds4<2>(pm.hand_mean, t.hand_mean, 90);
+    glds4<2>(xrow, t.x, XDIM);
+    glds4<1>(camrow, t.cam, 16);
+    glds4<1>(pm.parents, t.parents, NJ);
+    glds4<1>(pm.order, t.order, NJ);
+    glds4<1>(pm.child_list, t.child_list, NJ - 1);
+    glds4<1>(pm.depth, t.depth, NJ);
+    glds4<1>(pm.child_start, t.child_start, NJ + 1);
+    glds4<1>(pm.level_start, t.level_start, min(pm.nlevels, MAX_LEVELS) + 1);
+}
+// after the barrier that follows the copies: the model with its tables in LDS
+__device__ __forceinline__ PoseModel stage_pose_model(const PoseModel& pm, PoseStage& t) {
     PoseModel l = pm;
     l.Jd = t.Jd; l.Jt = t.Jt; l.hand_comp = t.hand_comp; l.hand_mean = t.hand_mean;
     l.parents = t.parents; l.order = t.order; l.level_start = t.level_start; l.child_start = t.child_start; l.child_list = t.child_list;
     l.depth = t.depth;
     return l;
-}
-__device__ __forceinline__ PoseModel stage_pose(const PoseModel& pm, PoseStage& t, const float* __restrict__ xrow,
-                                                const float* __restrict__ camrow) {
-    PoseStageRegs g;
-    stage_pose_load(pm, g, xrow, camrow);
-    return stage_pose_store(pm, t, g);
 }
 
 // one 64-thread workgroup (one wavefront) per frame.
@@ -133,30 +127,25 @@ __global__ __launch_bounds__(64) void pose_fwd_kernel(PoseModel pm, const float*
     __shared__ PoseScratch sc;
     __shared__ PoseStage stg;
     __shared__ float s_O[ODIM + 2];
+    __shared__ float s_Op[PARTS ? VP_NQ : 1][ODIM + 2];
     FDC_FR_STAMP(0, 0);
     int r = row0 + blockIdx.x;
-    PoseStageRegs rg;
-    stage_pose_load(pm, rg, X + (size_t)r * XDIM, CAM + (size_t)r * 16);
-    float op[2][VP_NQ];                                      // the decoder's partial sums: same batch of loads (indices clamped)
-    if (PARTS) {
+    stage_pose_issue(pm, stg, X + (size_t)r * XDIM, CAM + (size_t)r * 16);
+    if (PARTS) {                                             // the decoder's partial sums ride in the same batch of copies
 #pragma unroll
-        for (int k = 0; k < 2; ++k)
-#pragma unroll
-            for (int q = 0; q < VP_NQ; ++q) op[k][q] = Opart[(size_t)q * part_stride + (size_t)r * ODIM + min((int)threadIdx.x + 64 * k, ODIM - 1)];
+        for (int q = 0; q < VP_NQ; ++q) glds4<2>(Opart + (size_t)q * part_stride + (size_t)r * ODIM, s_Op[q], ODIM);
     }
     const float sc_v = *scale;
+    __syncthreads();                                         // (waits for the copies: vmcnt(0) in front of the barrier)
+    const PoseModel pml = stage_pose_model(pm, stg);
     if (PARTS) {
-#pragma unroll
-        for (int k = 0; k < 2; ++k) {
-            const int e = threadIdx.x + 64 * k;
-            if (e < ODIM) {
-                const float v = (op[k][0] + op[k][1]) + (op[k][2] + op[k][3]);     // vp_sum_parts' order
-                s_O[e] = v;
-                O[(size_t)r * ODIM + e] = v;
-            }
+        for (int e = threadIdx.x; e < ODIM; e += 64) {
+            const float v = (s_Op[0][e] + s_Op[1][e]) + (s_Op[2][e] + s_Op[3][e]);     // vp_sum_parts' order
+            s_O[e] = v;
+            O[(size_t)r * ODIM + e] = v;
         }
+        __syncthreads();
     }
-    const PoseModel pml = stage_pose_store(pm, stg, rg);     // (its barrier also publishes s_O)
     if (PF && threadIdx.x < NBETA) PF[(size_t)r * NPFX + NPF + threadIdx.x] = stg.x[X_BETAS + threadIdx.x];
     if (PARTS) {
         pose_forward(pml, stg.x, s_O, stg.cam, sc_v, sc,
@@ -192,59 +181,64 @@ __global__ __launch_bounds__(64) void pose_bwd_kernel(PoseModel pm, const float*
     __shared__ PoseScratch sc;
     __shared__ PoseStage stg;
     __shared__ float s_dJw[NJW * 3];
+    // Everything this frame reads from global memory arrives in ONE batch of LDS-DMA copies (stage_pose_issue's comment): the
+    // pose tables, the forward pass's per-joint state, the incoming gradient rows, and what the fused parameter-loss prologue
+    // needs (neighbouring rows: two halo rows exist on either side of every owned row).  Fetched phase by phase -- as
+    // pose_backward does for its generic callers -- they were ~8 dependent cold round trips.
+    __shared__ __attribute__((aligned(16))) float s_dPF[NPFX];
+    __shared__ float s_O[ODIM + 2], s_Rm[NJ * 9 + 1], s_Jr[NJ * 3 + 3];
+    __shared__ float s_xn[4][XDIM + 2], s_x0[XDIM + 2], s_jw[3][NJW * 3 + 3], s_misc[32];
+    __shared__ float s_dx[XDIM + 2];      // the parameter-gradient row: accumulated here (pose_backward adds to it from several
+                                          // phases -- read-modify-write round trips on the global row), stored once at the end
     FDC_FR_STAMP(1, 0);
-    int r = row0 + blockIdx.x;
-    // one batch of cold loads: the staged tables / rows AND what the fused parameter-loss prologue reads (this row's
-    // neighbours, data row, mask, neighbouring joints) -- as loops after the staging they were four more dependent round trips.
-    // Rows r - 2 .. r + 2 exist for every owned row (two halo rows on either side); values outside the clip are masked below.
-    PoseStageRegs rg;
-    stage_pose_load(pm, rg, X + (size_t)r * XDIM, CAM + (size_t)r * 16);
-    float lx[2][4], lx0[2], lj[2][3], lmask = 0.f;
+    const int r = row0 + blockIdx.x;
+    stage_pose_issue(pm, stg, X + (size_t)r * XDIM, CAM + (size_t)r * 16);
+    glds4<(NJ * 9 + 63) / 64>(Rm + (size_t)r * NJ * 9, s_Rm, NJ * 9);
+    glds4<(NJ * 3 + 63) / 64>(Jrest + (size_t)r * NJ * 3, s_Jr, NJ * 3);
+    glds16<(NJ * 3 + 63) / 64>(G + (size_t)r * NJ * 12, &sc.G[0][0], NJ * 3);              // rows of sc.G are 12 floats: a flat copy
+    glds4<2>(O + (size_t)r * ODIM, s_O, ODIM);
+    if (dA) glds16<(NJ * 3 + 63) / 64>(dA + (size_t)r * NJ * 12, &sc.dG[0][0], NJ * 3);   // waits in sc.dG: lane j reads row j, then overwrites it
+    if (dPF) glds16<(NPFX / 4 + 63) / 64>(dPF + (size_t)r * NPFX, s_dPF, NPFX / 4);
+    if (dMv) glds4<1>(dMv + (size_t)r * 12, s_misc, 12);
+    if (dsv) glds4<1>(dsv + r, s_misc + 12, 1);
+    if (dtransl_v) glds4<1>(dtransl_v + (size_t)r * 3, s_misc + 13, 3);
+    if (dbeta_v) glds4<1>(dbeta_v + (size_t)r * dbeta_stride, s_misc + 16, NBETA);
     if (pl.X0) {
-#pragma unroll
-        for (int k = 0; k < 2; ++k) {
-            const int e = min((int)threadIdx.x + 64 * k, XDIM - 1);
-            const float* x = X + (size_t)r * XDIM + e;
-            lx[k][0] = x[-2 * XDIM]; lx[k][1] = x[-XDIM]; lx[k][2] = x[XDIM]; lx[k][3] = x[2 * XDIM];
-            lx0[k] = pl.X0[(size_t)r * XDIM + e];
-            const int ej = min((int)threadIdx.x + 64 * k, NJW * 3 - 1);
-            const float* j = pl.Jw + (size_t)r * NJW * 3 + ej;
-            lj[k][0] = j[-NJW * 3]; lj[k][1] = j[0]; lj[k][2] = j[NJW * 3];
-        }
-        lmask = pl.mask[r];
+        const float* x = X + (size_t)r * XDIM;
+        glds4<2>(x - 2 * XDIM, s_xn[0], XDIM); glds4<2>(x - XDIM, s_xn[1], XDIM);
+        glds4<2>(x + XDIM, s_xn[2], XDIM); glds4<2>(x + 2 * XDIM, s_xn[3], XDIM);
+        glds4<2>(pl.X0 + (size_t)r * XDIM, s_x0, XDIM);
+        const float* j = pl.Jw + (size_t)r * NJW * 3;
+        glds4<2>(j - NJW * 3, s_jw[0], NJW * 3); glds4<2>(j, s_jw[1], NJW * 3); glds4<2>(j + NJW * 3, s_jw[2], NJW * 3);
+        glds4<1>(pl.mask + r, s_misc + 27, 1);
+    } else {
+        glds4<2>(dX + (size_t)r * XDIM, s_dx, XDIM);         // the row a separate param_loss_kernel launch initialised
     }
     const float sc_v = *scale;
-    const PoseModel pml = stage_pose_store(pm, stg, rg);
+    __syncthreads();                                         // (waits for the copies: vmcnt(0) in front of the barrier)
+    const PoseModel pml = stage_pose_model(pm, stg);
     if (pl.X0) {
         // param_loss_kernel's gradients formed here: dX row (=) data + temporal terms on the raw rows, world-smoothing
         // gradient of this frame's joints into LDS instead of a round trip through dJw
         const int g = pl.frame0 + blockIdx.x;
+        const float lmask = s_misc[27];
         float l_rec = 0.f, l_vp = 0.f, l_sm = 0.f, l_ws = 0.f;
-#pragma unroll
-        for (int k = 0; k < 2; ++k) {
-            const int e = threadIdx.x + 64 * k;
-            if (e < XDIM) {
-                const float xc = stg.x[e];
-                float rec = 0.f, sm = 0.f;
-                dX[(size_t)r * XDIM + e] = param_loss_grad(g, pl.n_total, g >= 2 ? lx[k][0] : 0.f, g >= 1 ? lx[k][1] : 0.f, xc,
-                                                           g + 1 < pl.n_total ? lx[k][2] : 0.f, g + 2 < pl.n_total ? lx[k][3] : 0.f,
-                                                           lx0[k], lmask, pl.w_rec, pl.w_sm, &rec, &sm);
-                l_rec += rec; l_sm += sm;
-                if (e >= X_LATENT && e < X_LATENT + 32) l_vp += xc * xc;
-            }
+        for (int e = threadIdx.x; e < XDIM; e += 64) {
+            const float xc = stg.x[e];
+            float rec = 0.f, sm = 0.f;
+            s_dx[e] = param_loss_grad(g, pl.n_total, g >= 2 ? s_xn[0][e] : 0.f, g >= 1 ? s_xn[1][e] : 0.f, xc,
+                                      g + 1 < pl.n_total ? s_xn[2][e] : 0.f, g + 2 < pl.n_total ? s_xn[3][e] : 0.f,
+                                      s_x0[e], lmask, pl.w_rec, pl.w_sm, &rec, &sm);
+            l_rec += rec; l_sm += sm;
+            if (e >= X_LATENT && e < X_LATENT + 32) l_vp += xc * xc;
         }
-        if (pl.world_grad || pl.loss_rows) {
-#pragma unroll
-            for (int k = 0; k < 2; ++k) {
-                const int e = threadIdx.x + 64 * k;
-                if (e < NJW * 3) {
-                    float ws = 0.f;
-                    s_dJw[e] = world_smooth_grad(g, pl.n_total, g >= 1 ? lj[k][0] : 0.f, lj[k][1], g + 1 < pl.n_total ? lj[k][2] : 0.f,
-                                                 pl.w_ws, &ws);
-                    l_ws += ws;
-                }
+        if (pl.world_grad || pl.loss_rows)
+            for (int e = threadIdx.x; e < NJW * 3; e += 64) {
+                float ws = 0.f;
+                s_dJw[e] = world_smooth_grad(g, pl.n_total, g >= 1 ? s_jw[0][e] : 0.f, s_jw[1][e], g + 1 < pl.n_total ? s_jw[2][e] : 0.f,
+                                             pl.w_ws, &ws);
+                l_ws += ws;
             }
-        }
         if (pl.loss_rows) {                                  // kernel-uniform: logging iterations only
             l_rec = wave_sum64(l_rec); l_vp = wave_sum64(l_vp); l_sm = wave_sum64(l_sm); l_ws = wave_sum64(l_ws);
             if (threadIdx.x == 0) {
@@ -255,13 +249,15 @@ __global__ __launch_bounds__(64) void pose_bwd_kernel(PoseModel pm, const float*
         __syncthreads();
     }
     const float* dJw_row = (pl.X0 && pl.world_grad) ? s_dJw : (dJw ? dJw + (size_t)r * NJW * 3 : nullptr);
-    pose_backward(pml, stg.x, O + (size_t)r * ODIM, stg.cam, sc_v,
-                  Rm + (size_t)r * NJ * 9, Jrest + (size_t)r * NJ * 3, G + (size_t)r * NJ * 12,
-                  dA ? dA + (size_t)r * NJ * 12 : nullptr, dPF ? dPF + (size_t)r * NPFX : nullptr,
-                  dJw_row, dMv ? dMv + (size_t)r * 12 : nullptr,
-                  dsv ? dsv + r : nullptr, dbeta_v ? dbeta_v + (size_t)r * dbeta_stride : nullptr,
-                  dtransl_v ? dtransl_v + (size_t)r * 3 : nullptr, sc, dX + (size_t)r * XDIM,
+    pose_backward(pml, stg.x, s_O, stg.cam, sc_v,
+                  s_Rm, s_Jr, (const float*)nullptr,                      // (G: already in sc.G)
+                  dA ? &sc.dG[0][0] : nullptr, dPF ? s_dPF : nullptr,
+                  dJw_row, dMv ? s_misc : nullptr,
+                  dsv ? s_misc + 12 : nullptr, dbeta_v ? s_misc + 16 : nullptr,
+                  dtransl_v ? s_misc + 13 : nullptr, sc, s_dx,
                   dO + (size_t)r * ODIM, dCAM + (size_t)r * 16, dscale_row + r, threadIdx.x, 64, SyncBlock());
+    __syncthreads();
+    for (int e = threadIdx.x; e < XDIM; e += 64) dX[(size_t)r * XDIM + e] = s_dx[e];
 }
 
 // thread per (frame, vertex).  Vout layout [rows, nv, 3].  world = 0: body frame (+transl only)
