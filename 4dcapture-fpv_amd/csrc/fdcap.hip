@@ -88,6 +88,20 @@ __device__ __forceinline__ void glds4(const void* g, void* lds, int n) {
         if (lane + 64 * k < n)
             __builtin_amdgcn_global_load_lds((fdc_gptr_t)((const char*)g + 4 * (lane + 64 * k)), (fdc_lptr_t)((char*)lds + 256 * k), 4, 0, 0);
 }
+// the same for a workgroup of NW waves: unit i = 64 NW k + threadIdx.x (each wave's destination is wave-uniform)
+template <int K, int NW, int SZ>
+__device__ __forceinline__ void glds_wg(const void* g, void* lds, int n) {
+    static_assert(SZ == 4 || SZ == 16, "unit size");
+    const int tid = threadIdx.x, wave = tid >> 6;
+#pragma unroll
+    for (int k = 0; k < K; ++k)
+        if (tid + 64 * NW * k < n) {
+            const fdc_gptr_t src = (fdc_gptr_t)((const char*)g + SZ * (tid + 64 * NW * k));
+            const fdc_lptr_t dst = (fdc_lptr_t)((char*)lds + SZ * 64 * (NW * k + wave));
+            if constexpr (SZ == 16) __builtin_amdgcn_global_load_lds(src, dst, 16, 0, 0);
+            else __builtin_amdgcn_global_load_lds(src, dst, 4, 0, 0);
+        }
+}
 constexpr int PS_NJD4 = (NJ * 3 * NBETA) / 4, PS_NHC4 = (2 * 12 * 45) / 4;      // 412, 270
 // issue the copies of the pose tables and this frame's rows (one wave; no wait)
 __device__ __forceinline__ void stage_pose_issue(const PoseModel& pm, PoseStage& t, const float* __restrict__ xrow,
@@ -623,21 +637,21 @@ __global__ __launch_bounds__(256) void skin_bwd_vec_kernel(SkinModel sm, int nc,
     float Mr[12];
 #pragma unroll
     for (int e = 0; e < 12; ++e) Mr[e] = M[(size_t)r * 12 + e];
-    // one batch of loads, all unconditional (indices clamped; a clamped duplicate stores the same value to the same place)
+    // one batch: the rows and lists go global -> LDS by LDS-DMA (stage_pose_issue's comment), this thread's per-vertex
+    // constants and NN results into registers (indices clamped: unconditional loads)
     const int n4 = (3 * nc) >> 2, nw4 = nnz4 >> 2, nv8 = nnz8 >> 3;
-    const float4* const gVw = (const float4*)(cg.Vw + (size_t)r * nc * 3);
-    const float4* const gVo = (const float4*)(Voff + (size_t)r * nc * 3);
-    const float4* const gA = (const float4*)(A + (size_t)r * NJ * 12);
-    float4 lvw[2], lvo[2], lcw[2], lvp0[2], lvp1[2], lpq[2];
+    glds_wg<2, 4, 16>(cg.Vw + (size_t)r * nc * 3, sGV, n4);
+    glds_wg<2, 4, 16>(Voff + (size_t)r * nc * 3, sVP, n4);
+    glds_wg<2, 4, 16>(sm.csc_w, sCW, nw4);
+    glds_wg<1, 4, 16>(sm.csc_v16, sCV, nv8);
+    glds_wg<1, 4, 16>(A + (size_t)r * NJ * 12, sAf, NJ * 3);
+    glds_wg<1, 4, 4>(sm.csc_start, sCS, NJ + 1);
+    float4 lvp0[2], lvp1[2], lpq[2];
     float ldq[2];
     int ljq[2];
 #pragma unroll
     for (int k = 0; k < 2; ++k) {
-        const int i = tid + 256 * k;
-        lvw[k] = gVw[min(i, n4 - 1)];
-        lvo[k] = gVo[min(i, n4 - 1)];
-        lcw[k] = ((const float4*)sm.csc_w)[min(i, nw4 - 1)];
-        const int c = min(i, nc - 1);
+        const int c = min(tid + 256 * k, nc - 1);
         const size_t qi = (size_t)r * nc + c;
         lvp0[k] = ((const float4*)sm.vpack)[c];
         lvp1[k] = ((const float4*)sm.vpack)[nc + c];
@@ -646,20 +660,7 @@ __global__ __launch_bounds__(256) void skin_bwd_vec_kernel(SkinModel sm, int nc,
         lpq[k] = cg.nnpt ? cg.nnpt[qi] : make_float4(0.f, 0.f, 0.f, 0.f);
         ljq[k] = cg.nnpt ? __float_as_int(lpq[k].w) : cg.idx[qi];
     }
-    const uint4 lcv = ((const uint4*)sm.csc_v16)[min(tid, nv8 - 1)];
-    const float4 la = gA[min(tid, NJ * 3 - 1)];
-    const int lcs = sm.csc_start[min(tid, NJ)];
-#pragma unroll
-    for (int k = 0; k < 2; ++k) {
-        const int i = tid + 256 * k;
-        ((float4*)sGV)[min(i, n4 - 1)] = lvw[k];
-        ((float4*)sVP)[min(i, n4 - 1)] = lvo[k];
-        ((float4*)sCW)[min(i, nw4 - 1)] = lcw[k];
-    }
-    ((uint4*)sCV)[min(tid, nv8 - 1)] = lcv;
-    ((float4*)sAf)[min(tid, NJ * 3 - 1)] = la;
     for (int i = tid; i < NJ * 12; i += 256) sdA[i] = 0.f;
-    sCS[min(tid, NJ)] = lcs;
     __syncthreads();
     FDC_FR_STAMP(2, 1);
     float acc[SKB_NACC];
