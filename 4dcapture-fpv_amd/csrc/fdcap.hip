@@ -274,28 +274,59 @@ __global__ __launch_bounds__(64) void pose_bwd_kernel(PoseModel pm, const float*
     for (int e = threadIdx.x; e < XDIM; e += 64) dX[(size_t)r * XDIM + e] = s_dx[e];
 }
 
-// thread per (frame, vertex).  Vout layout [rows, nv, 3].  world = 0: body frame (+transl only)
-__global__ void skin_fwd_kernel(SkinModel sm, int nv, const float* __restrict__ X, int ldx, int beta_off, int transl_off,
+// thread per (frame, vertex), 256-thread workgroups.  Vout layout [rows, nv, 3].  world = 0: body frame (+transl only)
+__global__ __launch_bounds__(256) void skin_fwd_kernel(SkinModel sm, int nv, const float* __restrict__ X, int ldx, int beta_off, int transl_off,
                                 const float* __restrict__ Voff, const float* __restrict__ A,
                                 const float* __restrict__ M, const float* __restrict__ scale, int row0, int world,
                                 float* __restrict__ Vout) {
     // the frame's 55 skinning transforms staged in LDS once per block: per vertex they are reached through its joint
-    // ids (a dependent load chain from global memory otherwise)
-    __shared__ float sA[NJ * 12];
-    int c = blockIdx.x * blockDim.x + threadIdx.x;
-    int r = row0 + blockIdx.y;
-    for (int i = threadIdx.x; i < NJ * 12; i += blockDim.x) sA[i] = A[(size_t)r * NJ * 12 + i];
-    __syncthreads();
-    if (c >= nv) return;
+    // ids (a dependent load chain from global memory otherwise).  By LDS-DMA, with the vertex's own loads issued before
+    // the barrier: one cold round trip (the copy loop that was here waited for each of its three trips, then the
+    // per-vertex loads made a fourth)
+    __shared__ __attribute__((aligned(16))) float sA[NJ * 12];
+    const int c = blockIdx.x * 256 + threadIdx.x, cc = min(c, nv - 1);
+    const int r = row0 + blockIdx.y;
+    glds_wg<1, 4, 16>(A + (size_t)r * NJ * 12, sA, NJ * 3);
     const float* x = X + (size_t)r * ldx;
-    V3 transl = v3(x[transl_off], x[transl_off + 1], x[transl_off + 2]);
+    const V3 transl = v3(x[transl_off], x[transl_off + 1], x[transl_off + 2]);
     float Mr[12] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0};      // registers: a pointer that is either global or a local array turns into flat loads
     if (world) {
 #pragma unroll
         for (int e = 0; e < 12; ++e) Mr[e] = M[(size_t)r * 12 + e];
     }
-    SkinFwd f = skin_forward_vertex(sm, c, x + beta_off, Voff + ((size_t)r * nv + c) * 3, sA, transl, Mr, world ? *scale : 1.f);
+    const float sc_v = world ? *scale : 1.f;
     float* o = Vout + ((size_t)r * nv + c) * 3;
+    if (sm.vpack && !sm.S) {
+        // packed per-vertex constants (two 16-byte loads instead of eleven 4-byte ones); same terms, same order
+        const float4 p0 = ((const float4*)sm.vpack)[cc], p1 = ((const float4*)sm.vpack)[nv + cc];
+        const float* vo = Voff + ((size_t)r * nv + cc) * 3;
+        const float v0 = vo[0], v1 = vo[1], v2 = vo[2];
+        __syncthreads();
+        if (c >= nv) return;
+        const float px = p0.x + v0, py = p0.y + v1, pz = p0.z + v2;
+        const unsigned jb = __float_as_uint(p0.w);
+        const float w4[4] = {p1.x, p1.y, p1.z, p1.w};
+        float T[12];
+#pragma unroll
+        for (int e = 0; e < 12; ++e) T[e] = 0.f;
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+            if (k < sm.K) {
+                const float* a = sA + 12 * ((jb >> (8 * k)) & 255u);
+#pragma unroll
+                for (int e = 0; e < 12; ++e) T[e] += w4[k] * a[e];
+            }
+        const V3 vb = v3(T[0] * px + T[1] * py + T[2] * pz + T[3], T[4] * px + T[5] * py + T[6] * pz + T[7],
+                         T[8] * px + T[9] * py + T[10] * pz + T[11]) + transl;
+        const V3 sv = sc_v * vb;
+        o[0] = Mr[0] * sv.x + Mr[1] * sv.y + Mr[2] * sv.z + Mr[3];
+        o[1] = Mr[4] * sv.x + Mr[5] * sv.y + Mr[6] * sv.z + Mr[7];
+        o[2] = Mr[8] * sv.x + Mr[9] * sv.y + Mr[10] * sv.z + Mr[11];
+        return;
+    }
+    __syncthreads();
+    if (c >= nv) return;
+    SkinFwd f = skin_forward_vertex(sm, c, x + beta_off, Voff + ((size_t)r * nv + c) * 3, sA, transl, Mr, sc_v);
     o[0] = f.vw.x; o[1] = f.vw.y; o[2] = f.vw.z;
 }
 
