@@ -960,6 +960,15 @@ __global__ __launch_bounds__(512) void vposer_fwd_split3_kernel(VPoserPanels3 P,
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, j = lane & 15, g = lane >> 4;
     const int q = blockIdx.x & 3, r0 = row_lo + (int)(blockIdx.x >> 2) * 16;
     PnRing3T<1, 2> rg2, rg3;
+    // the biases of all three layers, requested before the first barrier (the compiler does not move a load across one):
+    // fetched where they are used -- after each layer's products -- every tile's bias was a round trip of its own
+    float4 bias1[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) bias1[t] = *(const float4*)(P.b1 + (wave * 4 + t) * 16 + 4 * g);
+    const float4 bias2 = *(const float4*)(P.b2 + (q * 8 + wave) * 16 + 4 * g);
+    float bias3[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) bias3[e] = P.b3[min(wave * 16 + 4 * g + e, ODIM - 1)];
     {   // layer 1, all 512 columns (four tiles per wave), K = 32 = one step
         f32x4_t acc[4];
         const uint4* bf[4];
@@ -977,7 +986,7 @@ __global__ __launch_bounds__(512) void vposer_fwd_split3_kernel(VPoserPanels3 P,
 #pragma unroll
         for (int t = 0; t < 4; ++t) {
             const int n4 = (wave * 4 + t) * 16 + 4 * g;
-            const float4 bias = *(const float4*)(P.b1 + n4);
+            const float4 bias = bias1[t];
             const float4 v = make_float4(vp_lrelu(acc[t][0] + bias.x), vp_lrelu(acc[t][1] + bias.y), vp_lrelu(acc[t][2] + bias.z),
                                          vp_lrelu(acc[t][3] + bias.w));
             pn3_store4(sH1, VP3_PH, n4, j, v);
@@ -994,7 +1003,7 @@ __global__ __launch_bounds__(512) void vposer_fwd_split3_kernel(VPoserPanels3 P,
             panel3_prefetch_t<1, 2>(rg3, &bf3, VP_QW / 32, lane);
         }
         const int n4 = tile * 16 + 4 * g;
-        const float4 bias = *(const float4*)(P.b2 + n4);
+        const float4 bias = bias2;
         const float4 v = make_float4(vp_lrelu(acc[0] + bias.x), vp_lrelu(acc[1] + bias.y), vp_lrelu(acc[2] + bias.z), vp_lrelu(acc[3] + bias.w));
         pn3_store4(sH2, VP3_PQ, n4 - q * VP_QW, j, v);
         if (r0 + j < row_hi) *(float4*)(H2 + (size_t)(r0 + j) * VP_H + n4) = v;
@@ -1006,10 +1015,10 @@ __global__ __launch_bounds__(512) void vposer_fwd_split3_kernel(VPoserPanels3 P,
         const int n4 = wave * 16 + 4 * g, row = r0 + j;
         if (row < row_hi) {
             float* dst = Opart + (size_t)q * part_stride + (size_t)row * ODIM + n4;
-            const float b0 = q == 0 ? P.b3[n4] : 0.f, b1 = q == 0 ? P.b3[n4 + 1] : 0.f;
+            const float b0 = q == 0 ? bias3[0] : 0.f, b1 = q == 0 ? bias3[1] : 0.f;
             *(float2*)dst = make_float2(acc[0] + b0, acc[1] + b1);
             if (n4 + 2 < ODIM) {
-                const float b2 = q == 0 ? P.b3[n4 + 2] : 0.f, b3 = q == 0 ? P.b3[n4 + 3] : 0.f;
+                const float b2 = q == 0 ? bias3[2] : 0.f, b3 = q == 0 ? bias3[3] : 0.f;
                 *(float2*)(dst + 2) = make_float2(acc[2] + b2, acc[3] + b3);
             }
         }
@@ -1028,6 +1037,13 @@ __global__ __launch_bounds__(512) void vposer_bwd_split3_kernel(VPoserPanels3 P,
     const int q = blockIdx.x & 3, r0 = row_lo + (int)(blockIdx.x >> 2) * 16;
     PnRing3T<4, 2> rgB;
     PnRing3T<1, 2> rgC;
+    // the forward activations whose signs mask this wave's tiles, requested before the first barrier (rows clamped:
+    // unconditional loads).  Fetched after each layer's products they were five dependent round trips on cold data.
+    const size_t hrow = (size_t)min(r0 + j, row_hi - 1) * VP_H;
+    const float4 hm2 = *(const float4*)(H2 + hrow + (q * 8 + wave) * 16 + 4 * g);
+    float4 hm1[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) hm1[t] = *(const float4*)(H1 + hrow + (wave + 8 * t) * 16 + 4 * g);
     {   // dH2[:, quarter] = (dO x W3[:, quarter]) * mask(H2)
         f32x4_t acc = {0.f, 0.f, 0.f, 0.f};
         const int tile = q * 8 + wave;
@@ -1044,7 +1060,7 @@ __global__ __launch_bounds__(512) void vposer_bwd_split3_kernel(VPoserPanels3 P,
             panel3_prefetch_t<4, 2>(rgB, bfb, VP_QW / 32, lane);
         }
         const int n4 = tile * 16 + 4 * g;
-        const float4 h = (r0 + j < row_hi) ? *(const float4*)(H2 + (size_t)(r0 + j) * VP_H + n4) : make_float4(0.f, 0.f, 0.f, 0.f);
+        const float4 h = hm2;
         pn3_store4(sdH2, VP3_PQ, n4 - q * VP_QW, j,
                    make_float4(acc[0] * (h.x > 0.f ? 1.f : 0.2f), acc[1] * (h.y > 0.f ? 1.f : 0.2f), acc[2] * (h.z > 0.f ? 1.f : 0.2f),
                                acc[3] * (h.w > 0.f ? 1.f : 0.2f)));
@@ -1062,7 +1078,7 @@ __global__ __launch_bounds__(512) void vposer_bwd_split3_kernel(VPoserPanels3 P,
 #pragma unroll
         for (int t = 0; t < 4; ++t) {
             const int n4 = (wave + 8 * t) * 16 + 4 * g;
-            const float4 h = (r0 + j < row_hi) ? *(const float4*)(H1 + (size_t)(r0 + j) * VP_H + n4) : make_float4(0.f, 0.f, 0.f, 0.f);
+            const float4 h = hm1[t];
             pn3_store4(sdH1, VP3_PH, n4, j,
                        make_float4(acc[t][0] * (h.x > 0.f ? 1.f : 0.2f), acc[t][1] * (h.y > 0.f ? 1.f : 0.2f),
                                    acc[t][2] * (h.z > 0.f ? 1.f : 0.2f), acc[t][3] * (h.w > 0.f ? 1.f : 0.2f)));
