@@ -790,6 +790,14 @@ __global__ __launch_bounds__(512) void vposer_fwd_fused_kernel(VPoserPanels P, c
     const int q = blockIdx.x & 3, r0 = row_lo + (int)(blockIdx.x >> 2) * 16;
     PN_STAMP(0);
     PnRing<1, 4> rg2, rg3;                             // next layer's first fragments are requested before the barrier in front of it
+    // all three layers' biases before the first barrier (see vposer_fwd_split3_kernel)
+    float4 bias1[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) bias1[t] = *(const float4*)(P.b1 + (wave * 4 + t) * 16 + 4 * g);
+    const float4 bias2 = *(const float4*)(P.b2 + (q * 8 + wave) * 16 + 4 * g);
+    float bias3[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) bias3[e] = P.b3[min(wave * 16 + 4 * g + e, ODIM - 1)];
     {   // layer 1, all 512 columns (four tiles per wave)
         f32x4_t acc[4];
         const float4* bf[4];
@@ -808,7 +816,7 @@ __global__ __launch_bounds__(512) void vposer_fwd_fused_kernel(VPoserPanels P, c
 #pragma unroll
         for (int t = 0; t < 4; ++t) {
             const int n4 = (wave * 4 + t) * 16 + 4 * g;
-            const float4 bias = *(const float4*)(P.b1 + n4);
+            const float4 bias = bias1[t];
             const float4 v = make_float4(vp_lrelu(acc[t][0] + bias.x), vp_lrelu(acc[t][1] + bias.y), vp_lrelu(acc[t][2] + bias.z),
                                          vp_lrelu(acc[t][3] + bias.w));
             *(float4*)(sH1 + (size_t)((n4 >> 2) * 16 + j) * 4) = v;
@@ -826,7 +834,7 @@ __global__ __launch_bounds__(512) void vposer_fwd_fused_kernel(VPoserPanels P, c
             panel_prefetch<1, 4>(rg3, &bf3, VP_QW / 16, lane);
         }
         const int n4 = tile * 16 + 4 * g;
-        const float4 bias = *(const float4*)(P.b2 + n4);
+        const float4 bias = bias2;
         const float4 v = make_float4(vp_lrelu(acc[0] + bias.x), vp_lrelu(acc[1] + bias.y), vp_lrelu(acc[2] + bias.z), vp_lrelu(acc[3] + bias.w));
         *(float4*)(sH2 + (size_t)(((n4 - q * VP_QW) >> 2) * 16 + j) * 4) = v;
         if (r0 + j < row_hi) *(float4*)(H2 + (size_t)(r0 + j) * VP_H + n4) = v;
@@ -839,10 +847,10 @@ __global__ __launch_bounds__(512) void vposer_fwd_fused_kernel(VPoserPanels P, c
         const int n4 = wave * 16 + 4 * g, row = r0 + j;              // ODIM = 126: rows are 8-byte aligned -> two float2 stores
         if (row < row_hi) {
             float* dst = Opart + (size_t)q * part_stride + (size_t)row * ODIM + n4;
-            const float b0 = q == 0 ? P.b3[n4] : 0.f, b1 = q == 0 ? P.b3[n4 + 1] : 0.f;
+            const float b0 = q == 0 ? bias3[0] : 0.f, b1 = q == 0 ? bias3[1] : 0.f;
             *(float2*)dst = make_float2(acc[0] + b0, acc[1] + b1);
             if (n4 + 2 < ODIM) {
-                const float b2 = q == 0 ? P.b3[n4 + 2] : 0.f, b3 = q == 0 ? P.b3[n4 + 3] : 0.f;
+                const float b2 = q == 0 ? bias3[2] : 0.f, b3 = q == 0 ? bias3[3] : 0.f;
                 *(float2*)(dst + 2) = make_float2(acc[2] + b2, acc[3] + b3);
             }
         }
@@ -872,6 +880,12 @@ __global__ __launch_bounds__(512) void vposer_bwd_fused_kernel(VPoserPanels P, c
     const int q = blockIdx.x & 3, r0 = row_lo + (int)(blockIdx.x >> 2) * 16;
     PnRing<4, 4> rgB;
     PnRing<1, 4> rgC;
+    // the masking activations before the first barrier (see vposer_bwd_split3_kernel)
+    const size_t hrow = (size_t)min(r0 + j, row_hi - 1) * VP_H;
+    const float4 hm2 = *(const float4*)(H2 + hrow + (q * 8 + wave) * 16 + 4 * g);
+    float4 hm1[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) hm1[t] = *(const float4*)(H1 + hrow + (wave + 8 * t) * 16 + 4 * g);
     {   // dH2[:, quarter] = (dO x W3[:, quarter]) * mask(H2)
         f32x4_t acc = {0.f, 0.f, 0.f, 0.f};
         const int tile = q * 8 + wave;
@@ -888,7 +902,7 @@ __global__ __launch_bounds__(512) void vposer_bwd_fused_kernel(VPoserPanels P, c
             panel_prefetch<4, 4>(rgB, bfb, VP_QW / 16, lane);
         }
         const int n4 = tile * 16 + 4 * g;
-        const float4 h = (r0 + j < row_hi) ? *(const float4*)(H2 + (size_t)(r0 + j) * VP_H + n4) : make_float4(0.f, 0.f, 0.f, 0.f);
+        const float4 h = hm2;
         *(float4*)(sdH2 + (size_t)(((n4 - q * VP_QW) >> 2) * 16 + j) * 4) =
             make_float4(acc[0] * (h.x > 0.f ? 1.f : 0.2f), acc[1] * (h.y > 0.f ? 1.f : 0.2f), acc[2] * (h.z > 0.f ? 1.f : 0.2f),
                         acc[3] * (h.w > 0.f ? 1.f : 0.2f));
@@ -906,7 +920,7 @@ __global__ __launch_bounds__(512) void vposer_bwd_fused_kernel(VPoserPanels P, c
 #pragma unroll
         for (int t = 0; t < 4; ++t) {
             const int n4 = (wave + 8 * t) * 16 + 4 * g;
-            const float4 h = (r0 + j < row_hi) ? *(const float4*)(H1 + (size_t)(r0 + j) * VP_H + n4) : make_float4(0.f, 0.f, 0.f, 0.f);
+            const float4 h = hm1[t];
             *(float4*)(sdH1 + (size_t)((n4 >> 2) * 16 + j) * 4) =
                 make_float4(acc[t][0] * (h.x > 0.f ? 1.f : 0.2f), acc[t][1] * (h.y > 0.f ? 1.f : 0.2f),
                             acc[t][2] * (h.z > 0.f ? 1.f : 0.2f), acc[t][3] * (h.w > 0.f ? 1.f : 0.2f));
