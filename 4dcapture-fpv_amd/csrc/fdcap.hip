@@ -999,17 +999,24 @@ __global__ __launch_bounds__(256) void adam_step_kernel(AdamTensor x, AdamTensor
     const int b = blockIdx.x;
     if (b < nb_x + nb_cam) {
         const bool is_x = b < nb_x;
-        const AdamTensor& t = is_x ? x : cam;
+        // (field by field: a reference selected between two by-value kernel arguments is an address into the argument
+        // segment, and its fields then arrive one dependent scalar load after the other -- four cold round trips)
+        float* const tp = is_x ? x.p : cam.p;
+        float* const tm = is_x ? x.m : cam.m;
+        float* const tv = is_x ? x.v : cam.v;
+        const float* const tg = is_x ? x.g : cam.g;
+        const size_t tn = is_x ? x.n : cam.n;
+        const AdamScalars ta = is_x ? x.a : cam.a;
         const size_t i = (size_t)(is_x ? b : b - nb_x) * 256 + threadIdx.x;
-        if (i >= t.n) return;
-        float pp = t.p[i], mm = t.m[i], vv = t.v[i];
-        float gg = t.g[i];
+        if (i >= tn) return;
+        float pp = tp[i], mm = tm[i], vv = tv[i];
+        float gg = tg[i];
         if (is_x && dzpart) {                          // latent columns: + the four partials of vposer_bwd_fused_kernel (row0 = first owned row)
             const int lr = (int)(i / XDIM), col = (int)(i % XDIM) - X_LATENT;
             if (col >= 0 && col < VP_Z) gg += vp_sum_dz(dzpart, dz_stride, (size_t)(row0 + lr) * VP_Z + col);
         }
-        adam_update(pp, mm, vv, gg, t.a);
-        t.p[i] = pp; t.m[i] = mm; t.v[i] = vv;
+        adam_update(pp, mm, vv, gg, ta);
+        tp[i] = pp; tm[i] = mm; tv[i] = vv;
         if (xch) {
             const int w = is_x ? XDIM : 16, lr = (int)(i / w), e = (int)(i % w) + (is_x ? 0 : XDIM);
             if (lr < 2) xch[lr * XCH_ROW + e] = pp;                                    // first two owned rows: slots 0, 1
