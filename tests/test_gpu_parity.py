@@ -466,14 +466,19 @@ def _in_loop_nn_state_body(fop, clip, scene, vid, n, lib, h):
 
 
 def test_runs_are_bit_reproducible():
-    """No float atomics on the gradient path: two runs of the same clip give identical bits."""
+    """No float atomics on the gradient path: two runs of the same clip give identical bits -- and, with every loss term
+    logged every iteration (per-frame partial sums + one fixed-order reduction, no atomics either), identical logs; logging
+    does not change the fit."""
     outs = []
-    for _ in range(2):
+    for log_every in (0, 1, 1):
         fop, bm, vp, clip, scene, vid = _make_fop(48, 300, 20_000, 40, 12, seed=70)
-        body, scale, cam = fop.fitting(torch.tensor(clip.body_params).cuda(), "global")
-        outs.append((body.clone(), float(scale), cam.clone()))
+        body, scale, cam = fop.fitting(torch.tensor(clip.body_params).cuda(), "global", log_every=log_every)
+        log = np.array([fop.log.l_rec, fop.log.l_vposer, fop.log.loss_smoothing, fop.log.loss_contact, fop.log.loss_world_smoothing, fop.log.total]) if log_every else None
+        outs.append((body.clone(), float(scale), cam.clone(), log))
         fop.close()
-    assert torch.equal(outs[0][0], outs[1][0]) and outs[0][1] == outs[1][1] and torch.equal(outs[0][2], outs[1][2])
+    for a, b in ((0, 1), (1, 2)):
+        assert torch.equal(outs[a][0], outs[b][0]) and outs[a][1] == outs[b][1] and torch.equal(outs[a][2], outs[b][2])
+    assert outs[1][3].shape[1] == 12 and np.array_equal(outs[1][3], outs[2][3])
 
 
 @pytest.mark.parametrize("n,per_part", [(48, 40), (5, 250)])
