@@ -535,6 +535,50 @@ __global__ __launch_bounds__(512) void panel_gemm3_kernel(const float* __restric
         }
     }
 }
+// Two row blocks per fragment stream, for clip-sized M.  s_memtime in panel_gemm3_kernel (1024 rows): the MFMA phase of the
+// K = 1500 data gradient takes 20.8 k cycles for 282 MFMAs per wave -- 74 cycles each where the pipe needs 16 -- and its eight
+// waves receive 8 x 141 KB of fragments in that time: 54 bytes per clock, against the 64 a CU's vector-memory path returns.
+// The bound is that return path (L1 hit or not: streaming one tile to all eight waves changed nothing), so what helps is
+// fewer fragment bytes per MFMA: every fragment multiplies TWO 16-row blocks.  Twelve waves = twelve column tiles per
+// workgroup, 32 rows, both images in LDS (2 x 6 kpad x 16 bytes: K <= 768); column group = blockIdx & 7 = XCD, so each
+// XCD streams its own eighth of the static operand.  Grid: 8 x ceil(M / 32) workgroups (256 at 1024 rows: one per CU).
+__global__ __launch_bounds__(768) void panel_gemm3_rb2_kernel(const float* __restrict__ A, int lda, int M, int K, PanelB3 B,
+                                                              float* __restrict__ C, int ldc, int N) {
+    extern __shared__ __attribute__((aligned(16))) uint4 pn3_lds[];
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, j = lane & 15, g = lane >> 4;
+    const int xcd = blockIdx.x & 7, m0 = (int)(blockIdx.x >> 3) * 32;
+    const int ncb = (B.ntile + 11) / 12, cpg = (ncb + 7) / 8;            // column blocks of 12 tiles; per XCD
+    const int kpad = (K + 31) & ~31, nst = kpad >> 5, pstride = (kpad >> 3) * 16, img = 3 * pstride;
+    if (xcd * cpg >= ncb) return;
+    PnRing3<2> rg;
+    panel3_prefetch<2>(rg, B.f + (size_t)min((xcd * cpg) * 12 + wave, B.ntile - 1) * B.nst * 3 * 64, nst, lane);
+#pragma unroll
+    for (int rb = 0; rb < 2; ++rb) panel_stage3<768>(pn3_lds + (size_t)rb * img, A, lda, m0 + 16 * rb, M, 0, K, kpad, tid);
+    __syncthreads();
+    for (int cb = xcd * cpg; cb < min(ncb, (xcd + 1) * cpg); ++cb) {
+        const int tile = cb * 12 + wave;
+        f32x4_t acc[2] = {f32x4_t{0.f, 0.f, 0.f, 0.f}, f32x4_t{0.f, 0.f, 0.f, 0.f}};
+        if (tile < B.ntile) panel3_mma<2, 2>(pn3_lds, pstride, img, rg, nst, acc, lane);
+        if (cb + 1 < min(ncb, (xcd + 1) * cpg))
+            panel3_prefetch<2>(rg, B.f + (size_t)min((cb + 1) * 12 + wave, B.ntile - 1) * B.nst * 3 * 64, nst, lane);
+        const int n4 = tile * 16 + 4 * g;
+        if (tile < B.ntile && n4 < N) {
+#pragma unroll
+            for (int rb = 0; rb < 2; ++rb) {
+                const int m = m0 + 16 * rb + j;
+                if (m < M) {
+                    float* dst = C + (size_t)m * ldc + n4;
+                    if (n4 + 3 < N) *(f32x4u_t*)dst = f32x4u_t{acc[rb][0], acc[rb][1], acc[rb][2], acc[rb][3]};
+                    else {
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) if (n4 + r < N) dst[r] = acc[rb][r];
+                    }
+                }
+            }
+        }
+    }
+}
+
 // wide outputs on the split: the column-walking form of panel_gemm_wide_kernel (A staged once per workgroup, all the
 // column blocks of the XCD's share walked; next block's fragments requested before the stores)
 template <int RB>
@@ -582,6 +626,12 @@ static inline hipError_t panel_gemm3(const float* A, int lda, int M, int K, cons
     const int kpad = (K + 31) & ~31;
     if ((size_t)B.ntile * B.nst * 3 * 1024 > (size_t)(24u << 20) && M >= 32 && kpad <= 768) {
         hipLaunchKernelGGL(panel_gemm3_wide_kernel<2>, dim3(8 * ((M + 31) / 32)), dim3(512), (size_t)2 * 6 * kpad * 16, st, A, lda, M, K, B, C, ldc, N);
+        return hipGetLastError();
+    }
+    static int rb2 = -1;                                  // FDCAP_PN_RB2=0 (A/B): one row block per fragment stream everywhere
+    if (rb2 < 0) { const char* e = getenv("FDCAP_PN_RB2"); rb2 = (e && e[0] == '0') ? 0 : 1; }
+    if (rb2 && M >= 512 && kpad <= 768 && B.ntile >= 48) {
+        hipLaunchKernelGGL(panel_gemm3_rb2_kernel, dim3(8 * ((M + 31) / 32)), dim3(768), (size_t)2 * 6 * kpad * 16, st, A, lda, M, K, B, C, ldc, N);
         return hipGetLastError();
     }
     const PnMap mp = panel_map((M + 15) / 16, (B.ntile + 7) / 8, (size_t)M * K * 4, (size_t)B.ntile * B.nst * 3 * 1024);

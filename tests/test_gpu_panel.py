@@ -25,6 +25,8 @@ pytestmark = pytest.mark.gpu
     (70, 2100, 40, False, 5),           # K beyond one LDS slab
     (1028, 32, 512, True, 0), (257, 126, 512, False, 2),
     (130, 496, 13001, False, 0),        # wide output: four row blocks per fragment stream, column-block-major workgroup order
+    (1024, 496, 1500, False, 0),        # clip-sized M: two row blocks per fragment stream (panel_gemm3_rb2_kernel), the bench's product
+    (531, 700, 1000, True, 3),          # ... ragged rows / tiles, unaligned operand and output rows
 ])
 @pytest.mark.parametrize("form", ["split3", "fp32"])
 def test_panel_gemm_matches_fp64(M, K, N, transposed, pad, form, monkeypatch):
