@@ -579,6 +579,59 @@ __global__ __launch_bounds__(768) void panel_gemm3_rb2_kernel(const float* __res
     }
 }
 
+// ... and for long K (the data gradient, K = 1500: two images of all of K do not fit) each workgroup takes HALF of K for two
+// row blocks and leaves a partial product: C = Cpart[0] + Cpart[1], added by the consumer.  XCD = blockIdx & 7 =
+// (K half, column block of 8 tiles): each XCD streams its own eighth of the static operand; slot = blockIdx >> 3 = row pair.
+// N <= 32 tiles (four column blocks), kpad / 2 rounded up to a step <= 768 columns per half.  Grid 8 x ceil(M / 32).
+__global__ __launch_bounds__(512) void panel_gemm3_rb2k_kernel(const float* __restrict__ A, int lda, int M, int K, PanelB3 B,
+                                                               float* __restrict__ Cpart, size_t part_stride, int ldc, int N) {
+    extern __shared__ __attribute__((aligned(16))) uint4 pn3_lds[];
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, j = lane & 15, g = lane >> 4;
+    const int xcd = blockIdx.x & 7, half = xcd >> 2, cb = xcd & 3, m0 = (int)(blockIdx.x >> 3) * 32;
+    const int nst_all = (K + 31) >> 5, s0 = half ? (nst_all + 1) / 2 : 0, s1 = half ? nst_all : (nst_all + 1) / 2;
+    const int nst = s1 - s0, kpad = 32 * nst, k0 = 32 * s0, kn = min(K, 32 * s1) - k0;
+    const int pstride = (kpad >> 3) * 16, img = 3 * pstride;
+    const int tile = cb * 8 + wave;
+    const bool active = tile < B.ntile && nst > 0;
+    PnRing3<2> rg;
+    panel3_prefetch<2>(rg, B.f + ((size_t)(active ? tile : 0) * B.nst + s0) * 3 * 64, max(nst, 1), lane);
+#pragma unroll
+    for (int rb = 0; rb < 2; ++rb) panel_stage3<512>(pn3_lds + (size_t)rb * img, A, lda, m0 + 16 * rb, M, k0, kn, kpad, tid);
+    __syncthreads();
+    f32x4_t acc[2] = {f32x4_t{0.f, 0.f, 0.f, 0.f}, f32x4_t{0.f, 0.f, 0.f, 0.f}};
+    if (active) panel3_mma<2, 2>(pn3_lds, pstride, img, rg, nst, acc, lane);
+    const int n4 = tile * 16 + 4 * g;
+    if (tile < B.ntile && n4 < N) {
+        float* const C = Cpart + (size_t)half * part_stride;
+#pragma unroll
+        for (int rb = 0; rb < 2; ++rb) {
+            const int m = m0 + 16 * rb + j;
+            if (m < M) {
+                float* dst = C + (size_t)m * ldc + n4;
+                if (n4 + 3 < N) *(f32x4u_t*)dst = f32x4u_t{acc[rb][0], acc[rb][1], acc[rb][2], acc[rb][3]};
+                else {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) if (n4 + r < N) dst[r] = acc[rb][r];
+                }
+            }
+        }
+    }
+}
+// may the product take that form?  (the caller then provides the second partial buffer and adds the two)
+static inline bool panel_gemm3_rb2k_ok(int M, int K, const PanelB3& B) {
+    static int rb2 = -1;
+    if (rb2 < 0) { const char* e = getenv("FDCAP_PN_RB2"); rb2 = e ? atoi(e) : 1; }     // 0 off, 1 both forms, 2 forward only, 3 K-split only
+    const int nst_all = (K + 31) >> 5;
+    return (rb2 == 1 || rb2 == 3) && M >= 512 && B.ntile <= 32 && nst_all >= 2 && 32 * ((nst_all + 1) / 2) <= 768;
+}
+static inline hipError_t panel_gemm3_rb2k(const float* A, int lda, int M, int K, const PanelB3& B, float* Cpart, size_t part_stride,
+                                          int ldc, int N, hipStream_t st) {
+    const int kh = 32 * ((((K + 31) >> 5) + 1) / 2);
+    hipLaunchKernelGGL(panel_gemm3_rb2k_kernel, dim3(8 * ((M + 31) / 32)), dim3(512), (size_t)2 * 6 * kh * 16, st, A, lda, M, K, B, Cpart,
+                       part_stride, ldc, N);
+    return hipGetLastError();
+}
+
 // wide outputs on the split: the column-walking form of panel_gemm_wide_kernel (A staged once per workgroup, all the
 // column blocks of the XCD's share walked; next block's fragments requested before the stores)
 template <int RB>
@@ -629,8 +682,8 @@ static inline hipError_t panel_gemm3(const float* A, int lda, int M, int K, cons
         return hipGetLastError();
     }
     static int rb2 = -1;                                  // FDCAP_PN_RB2=0 (A/B): one row block per fragment stream everywhere
-    if (rb2 < 0) { const char* e = getenv("FDCAP_PN_RB2"); rb2 = (e && e[0] == '0') ? 0 : 1; }
-    if (rb2 && M >= 512 && kpad <= 768 && B.ntile >= 48) {
+    if (rb2 < 0) { const char* e = getenv("FDCAP_PN_RB2"); rb2 = e ? atoi(e) : 1; }
+    if ((rb2 == 1 || rb2 == 2) && M >= 512 && kpad <= 768 && B.ntile >= 48) {
         hipLaunchKernelGGL(panel_gemm3_rb2_kernel, dim3(8 * ((M + 31) / 32)), dim3(768), (size_t)2 * 6 * kpad * 16, st, A, lda, M, K, B, C, ldc, N);
         return hipGetLastError();
     }

@@ -191,7 +191,9 @@ __global__ __launch_bounds__(64) void pose_bwd_kernel(PoseModel pm, const float*
                                                       const float* dA, const float* dPF, const float* dJw,
                                                       const float* dMv, const float* dsv, const float* dbeta_v,
                                                       int dbeta_stride, const float* dtransl_v, float* dX, float* dO,
-                                                      float* dCAM, float* dscale_row, ParamLossIn pl) {
+                                                      float* dCAM, float* dscale_row, ParamLossIn pl, const float* dPF2) {
+    // dPF2 (optional): second partial of dPF -- the data-gradient product split over K (panel_gemm3_rb2k_kernel); the row is
+    // dPF + dPF2, d betas its columns NPF.. (dbeta_v must then be dPF + NPF, stride NPFX)
     __shared__ PoseScratch sc;
     __shared__ PoseStage stg;
     __shared__ float s_dJw[NJW * 3];
@@ -213,6 +215,7 @@ __global__ __launch_bounds__(64) void pose_bwd_kernel(PoseModel pm, const float*
     glds4<2>(O + (size_t)r * ODIM, s_O, ODIM);
     if (dA) glds16<(NJ * 3 + 63) / 64>(dA + (size_t)r * NJ * 12, &sc.dG[0][0], NJ * 3);   // waits in sc.dG: lane j reads row j, then overwrites it
     if (dPF) glds16<(NPFX / 4 + 63) / 64>(dPF + (size_t)r * NPFX, s_dPF, NPFX / 4);
+    if (dPF2) glds16<(NPFX / 4 + 63) / 64>(dPF2 + (size_t)r * NPFX, &sc.dR[0][0], NPFX / 4);   // parked in sc.dR (written much later)
     if (dMv) glds4<1>(dMv + (size_t)r * 12, s_misc, 12);
     if (dsv) glds4<1>(dsv + r, s_misc + 12, 1);
     if (dtransl_v) glds4<1>(dtransl_v + (size_t)r * 3, s_misc + 13, 3);
@@ -231,6 +234,11 @@ __global__ __launch_bounds__(64) void pose_bwd_kernel(PoseModel pm, const float*
     const float sc_v = *scale;
     __syncthreads();                                         // (waits for the copies: vmcnt(0) in front of the barrier)
     const PoseModel pml = stage_pose_model(pm, stg);
+    if (dPF2) {
+        const float* p2 = &sc.dR[0][0];
+        for (int e = threadIdx.x; e < NPFX; e += 64) s_dPF[e] += p2[e];
+        __syncthreads();
+    }
     if (pl.X0) {
         // param_loss_kernel's gradients formed here: dX row (=) data + temporal terms on the raw rows, world-smoothing
         // gradient of this frame's joints into LDS instead of a round trip through dJw
@@ -267,7 +275,7 @@ __global__ __launch_bounds__(64) void pose_bwd_kernel(PoseModel pm, const float*
                   s_Rm, s_Jr, (const float*)nullptr,                      // (G: already in sc.G)
                   dA ? &sc.dG[0][0] : nullptr, dPF ? s_dPF : nullptr,
                   dJw_row, dMv ? s_misc : nullptr,
-                  dsv ? s_misc + 12 : nullptr, dbeta_v ? s_misc + 16 : nullptr,
+                  dsv ? s_misc + 12 : nullptr, dbeta_v ? (dPF2 ? s_dPF + NPF : s_misc + 16) : nullptr,
                   dtransl_v ? s_misc + 13 : nullptr, sc, s_dx,
                   dO + (size_t)r * ODIM, dCAM + (size_t)r * 16, dscale_row + r, threadIdx.x, 64, SyncBlock());
     __syncthreads();
@@ -2013,7 +2021,8 @@ int fdcap_opt_create(fdcap_ctx* c, const fdcap_opt_config* cfg, float* rows_x, f
     AL(o->Rm, (size_t)R * NJ * 9) AL(o->PF, (size_t)R * NPFX) AL(o->Jrest, (size_t)R * NJ * 3) AL(o->G, (size_t)R * NJ * 12)
     AL(o->A, (size_t)R * NJ * 12) AL(o->M, (size_t)R * 12) AL(o->Jw, (size_t)R * NJW * 3)
     AL(o->dA, (size_t)R * NJ * 12) AL(o->dtransl_v, (size_t)R * 3) AL(o->dMv, (size_t)R * 12)
-    AL(o->dsv, R) AL(o->dPF, (size_t)R * NPFX) AL(o->dJw, (size_t)R * NJW * 3) AL(o->dX, (size_t)R * XDIM)
+    AL(o->dsv, R) AL(o->dPF, (size_t)2 * R * NPFX)   /* [2][R, 496]: the second half only as the K-split product's second partial */
+    AL(o->dJw, (size_t)R * NJW * 3) AL(o->dX, (size_t)R * XDIM)
     AL(o->dCAM, (size_t)R * 16) AL(o->dscale_row, R) AL(o->loss_rows, (size_t)R * LROW)
     if (o->contact_on) {
         AL(o->Voff, nq * 3) AL(o->Vw, nq * 3) AL(o->dist, nq) AL(o->idx, nq) AL(o->dVoff, nq * 3) AL(o->seedpt, nq)
@@ -2119,6 +2128,7 @@ static int opt_backward_impl(fdcap_ctx* c, const LossWeights& lw, int32_t log_te
                            o->dctC, o->dctW, o->dctD.p, o->dctCoef.p, dct_on ? lw.dct / (69.f * (float)o->dctW) : 0.f,
                            lw.world_on ? 1 : 0, o->dJw.p, losses ? losses + 7 : nullptr);
     o->dct_grad = dct_on;
+    bool dpf_split = false;
     if (contact_grad) {
         ContactGradIn cg;
         cg.Vw = o->Vw.p; cg.dist = o->dist.p; cg.idx = o->idx.p; cg.scene = c->scene.p;
@@ -2144,7 +2154,12 @@ static int opt_backward_impl(fdcap_ctx* c, const LossWeights& lw, int32_t log_te
         hipLaunchKernelGGL(skin_bwd_kernel<true>, dim3(nl), dim3(256), (size_t)std::min(nc, 1024) * 12 * sizeof(float), st, c->contact.model(), nc, o->X.p, o->Voff.p, o->A.p,
                            o->M.p, o->scale.p, 2, (const float*)nullptr, o->dVoff.p, o->dA.p, (float*)nullptr, o->dtransl_v.p,
                            o->dMv.p, o->dsv.p, cg);
-        if (gemm_split3_enabled() && c->contact.pn_bwd3.f)
+        if (gemm_split3_enabled() && c->contact.pn_bwd3.f && panel_gemm3_rb2k_ok(nl, 3 * nc, c->contact.pn_bwd3)) {
+            // two partial products (K halves), added by pose_bwd_kernel: [2][R, 496] in o->dPF
+            dpf_split = true;
+            HIP_TRY(panel_gemm3_rb2k(o->dVoff.p + (size_t)2 * nc * 3, 3 * nc, nl, 3 * nc, c->contact.pn_bwd3, o->dPF.p + 2 * NPFX,
+                                     (size_t)o->R * NPFX, NPFX, NPFX, st));
+        } else if (gemm_split3_enabled() && c->contact.pn_bwd3.f)
             HIP_TRY(panel_gemm3(o->dVoff.p + (size_t)2 * nc * 3, 3 * nc, nl, 3 * nc, c->contact.pn_bwd3, o->dPF.p + 2 * NPFX, NPFX, NPFX, st));
         else if (c->contact.pn_bwd.f)
             HIP_TRY(panel_gemm(o->dVoff.p + (size_t)2 * nc * 3, 3 * nc, nl, 3 * nc, c->contact.pn_bwd, o->dPF.p + 2 * NPFX, NPFX, NPFX, st));
@@ -2159,7 +2174,7 @@ static int opt_backward_impl(fdcap_ctx* c, const LossWeights& lw, int32_t log_te
                        o->Jrest.p, o->G.p, contact_grad ? o->dA.p : nullptr, contact_grad ? o->dPF.p : nullptr,
                        joint_grad ? o->dJw.p : nullptr, contact_grad ? o->dMv.p : nullptr, contact_grad ? o->dsv.p : nullptr,
                        contact_grad ? o->dPF.p + NPF : nullptr, NPFX, contact_grad ? o->dtransl_v.p : nullptr, o->dX.p, o->dO.p,
-                       o->dCAM.p, o->dscale_row.p, pli);
+                       o->dCAM.p, o->dscale_row.p, pli, (contact_grad && dpf_split) ? (const float*)(o->dPF.p + (size_t)o->R * NPFX) : (const float*)nullptr);
     { int eb = opt_vposer_backward(c, false, st); if (eb) return eb; }
     // d loss / d scale of this rank = sum of the per-frame partials: formed by the step kernels (fused with Adam /
     // the exchange packing); on logging iterations also here, so a caller can read dscale_d right after the backward
@@ -2290,7 +2305,7 @@ int fdcap_opt_backward_fit2d(fdcap_ctx* c, const fdcap_fit2d_stage* sg, int32_t 
     hipLaunchKernelGGL(pose_bwd_kernel, dim3(nl), dim3(64), 0, st, pm, o->X.p, o->O.p, o->CAM.p, o->scale.p, 2, o->Rm.p,
                        o->Jrest.p, o->G.p, (const float*)nullptr, (const float*)nullptr, o->dJw.p, (const float*)nullptr,
                        (const float*)nullptr, (const float*)nullptr, 0, (const float*)nullptr, o->dX.p, o->dO.p, o->dCAM.p,
-                       o->dscale_row.p, ParamLossIn());
+                       o->dscale_row.p, ParamLossIn(), (const float*)nullptr);
     { int eb = opt_vposer_backward(c, true, st); if (eb) return eb; }
     return (int)hipGetLastError();
 }
@@ -2424,7 +2439,7 @@ int fdcap_opt_backward_local2(fdcap_ctx* c, const float* contact_weight, int32_t
                      3 * V, nullptr, 0, st));
     hipLaunchKernelGGL(pose_bwd_kernel, dim3(nl), dim3(64), 0, st, pm, o->X.p, o->O.p, o->CAM.p, o->scale.p, 2, o->Rm.p,
                        o->Jrest.p, o->G.p, o->dA.p, o->dPF.p, (const float*)nullptr, o->dMv.p, o->dsv.p, o->dPF.p + NPF, NPFX,
-                       o->dtransl_v.p, o->dX.p, o->dO.p, o->dCAM.p, o->dscale_row.p, ParamLossIn());
+                       o->dtransl_v.p, o->dX.p, o->dO.p, o->dCAM.p, o->dscale_row.p, ParamLossIn(), (const float*)nullptr);
     { int eb = opt_vposer_backward(c, true, st); if (eb) return eb; }
     return (int)hipGetLastError();
 }

@@ -72,11 +72,13 @@ def test_fused_vposer_forward_ragged_rows(B):
     ctx.close()
 
 
-@pytest.mark.parametrize("n,V,per_part", [(37, 300, 20), (70, 300, 20), (21, 2000, 90)])
+@pytest.mark.parametrize("n,V,per_part", [(37, 300, 20), (70, 300, 20), (21, 2000, 90), (530, 300, 20), (523, 2000, 90)])
 def test_fused_vposer_backward_in_the_optimiser_gradient(n, V, per_part):
     """Phase-1 gradient of a clip that spans several 16-row blocks (ragged last block): the latent columns come out of
     vposer_bwd_fused_kernel's four partial sums, folded by fdcap_opt_get_grads; compared with fp64 autograd.
-    The third case has a 180-vertex contact set on a 2000-vertex body (blend products with K, N = 540)."""
+    The third case has a 180-vertex contact set on a 2000-vertex body (blend products with K, N = 540); the last two are
+    clip-sized (>= 512 frames): the data-gradient product runs as two K halves on two row blocks per fragment stream
+    (panel_gemm3_rb2k_kernel: 2 + 2 and 9 + 8 steps), the partial products added by pose_bwd_kernel."""
     fop, bm, vp, clip, scene, vid = _make_fop(n, V, 800, per_part, 500)
     dt = torch.float64
     f = FittingOracle(SMPLXOracle(bm, dt), VPoserDecoder.from_data(vp, dt), scene, vid, clip.camerapose_lines, n, dtype=dt)
