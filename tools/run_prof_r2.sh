@@ -22,7 +22,7 @@ python tools/rocpd_summary.py /tmp/prof_r2_fetch/f_results.db $P/r2_pmc_FETCH_SI
 python tools/rocpd_summary.py /tmp/prof_r2_write/w_results.db $P/r2_pmc_WRITE_SIZE_bench_500it.txt > /dev/null
 python tools/rocpd_summary.py /tmp/prof_r2_mfma/m_results.db $P/r2_pmc_SQ_bench_500it.txt > /dev/null
 python tools/make_traffic_json.py /tmp/prof_r2_fetch/f_results.db /tmp/prof_r2_write/w_results.db $P/r2_pmc_traffic.json 300 > /dev/null
-for k in nn_stream4 panel_gemm3_kernel panel_gemm3_wide vposer_fwd vposer_bwd pose_fwd pose_bwd skin_bwd; do python tools/pmc_kernel.py /tmp/prof_r2_mfma/m_results.db $k 0; done > $P/r2_pmc_SQ_per_kernel.txt
+for k in nn_stream4 panel_gemm3_rb2_kernel panel_gemm3_rb2k panel_gemm3_wide vposer_fwd vposer_bwd pose_fwd pose_bwd skin_fwd skin_bwd; do python tools/pmc_kernel.py /tmp/prof_r2_mfma/m_results.db $k 0; done > $P/r2_pmc_SQ_per_kernel.txt
 python tools/pmc_kernel.py /tmp/prof_r2_mfma/m_results.db nn_stream4 300 > $P/r2_pmc_SQ_nn_in_loop_steady.txt
 python tools/pmc_kernel.py /tmp/prof_r2_mfma/m_results.db nn_mfma_kernel 0 > $P/r2_pmc_SQ_nn_bruteforce.txt
 head -14 $P/r2_kernel_trace_stats_bench_500it.txt; cat $P/r2_pmc_SQ_per_kernel.txt; ls $P
