@@ -622,7 +622,7 @@ static inline bool panel_gemm3_rb2k_ok(int M, int K, const PanelB3& B) {
     static int rb2 = -1;
     if (rb2 < 0) { const char* e = getenv("FDCAP_PN_RB2"); rb2 = e ? atoi(e) : 1; }     // 0 off, 1 both forms, 2 forward only, 3 K-split only
     const int nst_all = (K + 31) >> 5;
-    return (rb2 == 1 || rb2 == 3) && M >= 512 && B.ntile <= 32 && nst_all >= 2 && 32 * ((nst_all + 1) / 2) <= 768;
+    return (rb2 == 1 || rb2 == 3) && M >= 384 && B.ntile <= 32 && nst_all >= 2 && 32 * ((nst_all + 1) / 2) <= 768;
 }
 static inline hipError_t panel_gemm3_rb2k(const float* A, int lda, int M, int K, const PanelB3& B, float* Cpart, size_t part_stride,
                                           int ldc, int N, hipStream_t st) {
@@ -683,7 +683,7 @@ static inline hipError_t panel_gemm3(const float* A, int lda, int M, int K, cons
     }
     static int rb2 = -1;                                  // FDCAP_PN_RB2=0 (A/B): one row block per fragment stream everywhere
     if (rb2 < 0) { const char* e = getenv("FDCAP_PN_RB2"); rb2 = e ? atoi(e) : 1; }
-    if ((rb2 == 1 || rb2 == 2) && M >= 512 && kpad <= 768 && B.ntile >= 48) {
+    if ((rb2 == 1 || rb2 == 2) && M >= 384 && kpad <= 768 && B.ntile >= 48) {   // (measured: 256 rows 50.2 vs 49.8 ms per step, 384 rows 56.7 vs 57.8)
         hipLaunchKernelGGL(panel_gemm3_rb2_kernel, dim3(8 * ((M + 31) / 32)), dim3(768), (size_t)2 * 6 * kpad * 16, st, A, lda, M, K, B, C, ldc, N);
         return hipGetLastError();
     }
