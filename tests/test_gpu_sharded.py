@@ -19,19 +19,19 @@ pytestmark = pytest.mark.gpu
 N, ITERS = 22, 10
 
 
-def _inputs():
+def _inputs(n=N):
     bm = synth.make_body_model(300, seed=31)
     vp = synth.make_vposer(seed=32)
-    clip = synth.make_clip(N, seed=33)
+    clip = synth.make_clip(n, seed=33)
     scene = synth.make_scene(9000, seed=34)
     l, r = synth.make_contact_ids(bm.v_template, per_part=24, seed=35)
     return bm, vp, clip, scene, np.concatenate([l, r])
 
 
-def _fit(group, mode="global"):
+def _fit(group, mode="global", n=N):
     from fdcap_amd.fitting import FittingOP
-    bm, vp, clip, scene, vid = _inputs()
-    fop = FittingOP({"num_iter": ITERS}, {}, N, body_model=bm, vposer=vp, scene_verts=scene, contact_ids=vid,
+    bm, vp, clip, scene, vid = _inputs(n)
+    fop = FittingOP({"num_iter": ITERS}, {}, n, body_model=bm, vposer=vp, scene_verts=scene, contact_ids=vid,
                     camera_ext=read_camerapose(clip.camerapose_lines), group=group)
     body, scale, cam = fop.fitting(torch.tensor(clip.body_params).cuda(), mode, log_every=1)
     tot = np.array(fop.log.total) if mode == "global" else np.array(fop.log2)[:, 5]
@@ -40,13 +40,13 @@ def _fit(group, mode="global"):
     return out
 
 
-def _worker(rank, world, port, q, mode="global"):
+def _worker(rank, world, port, q, mode="global", n=N):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     torch.cuda.set_device(0)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
-        q.put((rank,) + _fit(dist.group.WORLD, mode))
+        q.put((rank,) + _fit(dist.group.WORLD, mode, n))
     finally:
         dist.barrier()
         dist.destroy_process_group()
@@ -60,20 +60,22 @@ def _free_port():
     return p
 
 
-@pytest.mark.parametrize("world,mode", [(2, "global"), (3, "global"), (2, "local")])
-def test_sharded_gpu_run_matches_single_rank(world, mode):
-    ref = _fit(None, mode)
+# (800 frames over two ranks: shards large enough for the clip-sized kernel forms -- two row blocks per fragment stream in
+# the blend products -- next to halo rows)
+@pytest.mark.parametrize("world,mode,n", [(2, "global", N), (3, "global", N), (2, "local", N), (2, "global", 800)])
+def test_sharded_gpu_run_matches_single_rank(world, mode, n):
+    ref = _fit(None, mode, n)
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, world, port, q, mode)) for r in range(world)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q, mode, n)) for r in range(world)]
     for p in procs:
         p.start()
     res = sorted(q.get(timeout=600) for _ in range(world))
     for p in procs:
         p.join(timeout=120)
         assert p.exitcode == 0
-    assert [r[1] for r in res] == [FrameShard(N, None, rank=i, world=world).frame0 for i in range(world)]
+    assert [r[1] for r in res] == [FrameShard(n, None, rank=i, world=world).frame0 for i in range(world)]
     body = np.concatenate([r[2] for r in res])
     cam = np.concatenate([r[4] for r in res])
     # identical per-frame arithmetic; only the order of the scale-gradient sum differs (1 ulp of dscale),
