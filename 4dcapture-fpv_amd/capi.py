@@ -75,6 +75,7 @@ SYMBOLS = {
     "fdcap_opt_set_dct": (c_int32, [c_void_p, c_void_p, c_int32, c_int32, c_void_p, c_void_p]),
     "fdcap_opt_dct_fit": (c_int32, [c_void_p, c_int32, c_int32, c_float, c_void_p, c_int32, c_void_p]),
     "fdcap_opt_backward_dct": (c_int32, [c_void_p, c_float, c_float, c_float, c_int32, c_void_p]),
+    "fdcap_opt_set_dct_coef": (c_int32, [c_void_p, c_void_p, c_void_p]),
     "fdcap_opt_get_dct": (c_int32, [c_void_p, c_void_p, c_void_p]),
     "fdcap_opt_dct_windows": (c_int32, [c_void_p, POINTER(c_int32), POINTER(c_int32)]),
     "fdcap_frame_smoother": (c_int32, [c_void_p, c_void_p, c_int32, c_int32, c_float, c_float, c_float, c_float,

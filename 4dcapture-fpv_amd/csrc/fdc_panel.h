@@ -674,9 +674,14 @@ __global__ __launch_bounds__(512) void panel_gemm3_wide_kernel(const float* __re
     }
 }
 
+// longest K whose single-slab LDS image (6 kpad x 16 bytes per row block) fits the 160 KB of a gfx950 CU: kpad <= 1696
+constexpr int PN3_MAX_K = 1696;
+static inline bool panel_gemm3_fits(int K) { return ((K + 31) & ~31) <= PN3_MAX_K; }
+
 static inline hipError_t panel_gemm3(const float* A, int lda, int M, int K, const PanelB3& B, float* C, int ldc, int N, hipStream_t st) {
     if (M <= 0 || N <= 0) return hipSuccess;
     const int kpad = (K + 31) & ~31;
+    if (kpad > PN3_MAX_K) return hipErrorInvalidValue;       // callers fall back to panel_gemm (K slabs) above this
     if ((size_t)B.ntile * B.nst * 3 * 1024 > (size_t)(24u << 20) && M >= 32 && kpad <= 768) {
         hipLaunchKernelGGL(panel_gemm3_wide_kernel<2>, dim3(8 * ((M + 31) / 32)), dim3(512), (size_t)2 * 6 * kpad * 16, st, A, lda, M, K, B, C, ldc, N);
         return hipGetLastError();

@@ -1397,7 +1397,7 @@ int build_skin_set(fdcap_ctx* c, const std::vector<int64_t>& ids, SkinSet* out) 
         HIP_TRY(out->pn_fwd3_f.upload(p3.data(), p3.size()));
         out->pn_fwd3.f = (const uint4*)out->pn_fwd3_f.p;
     }
-    if (nv > 0 && 3 * nv <= 2048) {               // ... and the data-gradient operand of small sets (K = 3 nv in one LDS image)
+    if (nv > 0 && panel_gemm3_fits(3 * nv)) {     // ... and the data-gradient operand of small sets (K = 3 nv in one LDS image <= 160 KB)
         std::vector<unsigned> p3;
         panel_pack3(pd.data(), 1, ldp, 3 * nv, NPFX, p3, &out->pn_bwd3.ntile, &out->pn_bwd3.nst);
         HIP_TRY(out->pn_bwd3_f.upload(p3.data(), p3.size()));
@@ -1626,6 +1626,8 @@ void fdcap_ctx_destroy(fdcap_ctx* c) {
 
 int fdcap_set_scene(fdcap_ctx* c, const float* xyz, int64_t ns) {
     if (!c || ns < 0 || (ns > 0 && !xyz) || ns > 0x7fffffff) return FDCAP_E_ARG;
+    // a live optimiser holds buffers sized for, and pruning state (seeds, kept work lists) valid for, the registered scene
+    if (c->opt) return FDCAP_E_STATE;
     std::vector<float4> orig((size_t)ns), sorted((size_t)ns);
     for (int64_t i = 0; i < ns; ++i) {
         orig[i] = make_float4(xyz[3 * i], xyz[3 * i + 1], xyz[3 * i + 2], 0.f);
@@ -1758,6 +1760,7 @@ int fdcap_set_scene(fdcap_ctx* c, const float* xyz, int64_t ns) {
 
 int fdcap_set_contact_ids(fdcap_ctx* c, const int64_t* vid, int32_t nc) {
     if (!c || nc < 0 || (nc > 0 && !vid)) return FDCAP_E_ARG;
+    if (c->opt) return FDCAP_E_STATE;                  // (see fdcap_set_scene)
     for (int i = 0; i < nc; ++i) if (vid[i] < 0 || vid[i] >= c->V) return FDCAP_E_ARG;
     // Internal slot order = Morton order of the template positions: the 256 consecutive queries of an NN
     // workgroup are then spatially compact, so far fewer scene chunks survive its bound test (with all
@@ -2237,10 +2240,14 @@ int fdcap_opt_dct_fit(fdcap_ctx* c, int32_t iters, int32_t step0, float weight, 
     const int w0 = (cf.frame0 + T - 1) / T;
     const int w1 = std::min((cf.frame0 + cf.n_local) / T, o->dctW);
     if (iters == 0 || w1 <= w0) return FDCAP_OK;
-    int row_lo, row_hi;
-    opt_row_range(o, 1, &row_lo, &row_hi);
-    int e = opt_pose_forward(c, row_lo, row_hi, st);
-    if (e) return e;
+    // weight 0: every gradient is exactly zero whatever the trajectories are (Adam coasts on its moments: the torch < 2
+    // zero_grad semantics of a frozen c_dct) -- no forward needed
+    if (weight != 0.f) {
+        int row_lo, row_hi;
+        opt_row_range(o, 1, &row_lo, &row_hi);
+        int e = opt_pose_forward(c, row_lo, row_hi, st);
+        if (e) return e;
+    }
     o->adam_tab_h.resize(iters);
     for (int i = 0; i < iters; ++i) o->adam_tab_h[i] = adam_scalars(cf.lr, step0 + i + 1);
     HIP_TRY(o->adam_tab.ensure(iters));
@@ -2257,6 +2264,15 @@ int fdcap_opt_backward_dct(fdcap_ctx* c, float w_dct, float w_rec, float w_conta
     LossWeights lw;
     lw.rec = w_rec; lw.smooth = 0.f; lw.contact = w_contact; lw.world = 0.f; lw.dct = w_dct; lw.world_on = false;
     return opt_backward_impl(c, lw, log_terms, (hipStream_t)stream);
+}
+
+int fdcap_opt_set_dct_coef(fdcap_ctx* c, const float* c_dct_d, void* stream) {
+    if (!c || !c->opt || !c_dct_d) return FDCAP_E_ARG;
+    OptState* o = c->opt;
+    if (o->dctW <= 0) return FDCAP_E_STATE;
+    HIP_TRY(hipMemcpyAsync(o->dctCoef.p, c_dct_d, (size_t)o->dctW * 69 * o->dctC * sizeof(float), hipMemcpyDeviceToDevice,
+                           (hipStream_t)stream));
+    return FDCAP_OK;
 }
 
 int fdcap_opt_get_dct(fdcap_ctx* c, float* c_dct_d, void* stream) {
@@ -2542,7 +2558,7 @@ int fdcap_panel_gemm(const float* A, int32_t lda, int32_t M, int32_t K, const fl
     hipStream_t st = (hipStream_t)stream;
     {
         const char* e3 = getenv("FDCAP_GEMM_SPLIT3");                // (read per call here, so a test can run both forms in one process)
-        if (!(e3 && e3[0] == '0') && K <= 2048) {                    // the three-way bf16 split form of the same product (the default)
+        if (!(e3 && e3[0] == '0') && panel_gemm3_fits(K)) {          // the three-way bf16 split form of the same product (the default)
             std::vector<unsigned> p3;
             PanelB3 B3;
             panel_pack3(B_h, (long)sk, (long)sn, K, N, p3, &B3.ntile, &B3.nst);

@@ -6,9 +6,14 @@ cross-frame coupling is the 3-frame stencil of loss_smoothing (global_optimizati
 and the 2-frame stencil of loss_world_smoothing (:304).  So per iteration each rank needs
   * its neighbours' 2 boundary rows of body_rotation_rec [78] and camera_ext [16]  (halo), and
   * the global sum of d loss / d scale (one float; scale is a shared parameter, :179).
-Both are latency-bound (752 B per neighbour), sent with torch.distributed point-to-point ops --
-backend "nccl" is RCCL over xGMI on ROCm; the CPU tests use "gloo".  No reverse exchange is
-needed: every rank evaluates all loss terms that touch its own frames.
+Both travel in ONE collective per iteration: after Adam on its own rows a rank packs [first two | last two
+owned rows of (x | camera_ext)] + its d loss / d scale partial into one 1.5 KB message (fdcap_opt_step_rows_and_pack),
+`allgather_packed` gathers every rank's message, and fdcap_opt_unpack_and_step_scale copies the neighbours' rows into
+the halo rows and sums the partials in rank order (same bits on every rank) before stepping `scale`.  The exchange is
+latency-bound; backend "nccl" is RCCL over xGMI on ROCm, the CPU tests use "gloo".  No reverse exchange is needed:
+every rank evaluates all loss terms that touch its own frames.  `exchange_halos` (point-to-point) fills the halo rows
+once before the first iteration and after each iteration of mode 'local''s second loop; `allreduce_scalars` sums the
+logged loss terms.
 """
 from __future__ import annotations
 
@@ -94,12 +99,13 @@ def allreduce_scalars(shard: FrameShard, dscale, losses=None) -> None:
 
 
 def allgather_packed(shard: FrameShard, send, gathered) -> None:
-    """gathered[r] = rank r's `send` (one small fixed-size message per rank and iteration)."""
+    """gathered[r] = rank r's `send` (one small fixed-size message per rank and iteration: the iteration's only
+    collective).  `gathered` is [world, len(send)] contiguous; it is handed to the backend as the flat concatenation
+    (RCCL and gloo both take that form; gloo refuses the 2-D view)."""
     import torch.distributed as dist
     if send.is_cuda and dist.get_backend(shard.group) == "gloo":      # tests: gloo cannot gather device tensors
-        parts = [send.cpu().clone() for _ in range(shard.world)]
-        dist.all_gather(parts, send.cpu(), group=shard.group)
-        for r, p in enumerate(parts):
-            gathered[r].copy_(p)
+        flat = gathered.new_empty(gathered.numel(), device="cpu")
+        dist.all_gather_into_tensor(flat, send.cpu(), group=shard.group)
+        gathered.copy_(flat.view_as(gathered))
     else:
-        dist.all_gather_into_tensor(gathered, send, group=shard.group)
+        dist.all_gather_into_tensor(gathered.view(-1), send, group=shard.group)

@@ -25,6 +25,7 @@ PHASE2_WORLD = 1.0
 PHASE2_SMOOTH = 0.5
 SCALE_INIT = 1.8
 OUTLIER_FACTOR = 1.8
+VERBOSE_FLUSH = 50              # a verbose fit reads its device-side loss history back every this many logged iterations
 # mode 'dct' (:41-45, :595-630)
 BATCH_FRAME_NUM = 60            # frames per DCT window (:41)
 DCT_NUM = 5                     # coefficients per trajectory (:43)
@@ -226,29 +227,48 @@ class FittingOP:
         if log_every and mode != "dct":
             n_log = sum(1 for ii in range(self.num_iter) if ii % log_every == 0 or ii == self.num_iter - 1)
             hist = torch.zeros(max(n_log, 1), capi.NUM_LOSSES, device=dev, dtype=torch.float64)
-        for ii in range(self.num_iter if mode != "dct" else 0):                             # :560
-            do_log = bool(log_every) and (ii % log_every == 0 or ii == self.num_iter - 1)
-            st = capi.current_stream()
-            if do_log:                                   # this iteration's partial sums go straight into their history row
-                capi.check(lib.fdcap_opt_set_loss_output(h, capi.dptr(hist[len(logged)])), "fdcap_opt_set_loss_output")
-                logged.append(ii)
-            capi.check(lib.fdcap_opt_backward(h, ii, P, 1 if do_log else 0, st), "fdcap_opt_backward")
+        flushed = 0
+
+        def flush(upto):
+            # history rows [flushed, upto) -> log entries (and the reference's per-iteration print when verbose)
+            nonlocal flushed
+            if upto <= flushed:
+                return
+            part = hist[flushed:upto]
             if multi:
-                # one collective per iteration: boundary rows (after Adam) + the scale-gradient partial travel
-                # together; every rank then sums the partials in rank order and steps `scale` identically
-                capi.check(lib.fdcap_opt_step_rows_and_pack(h, ii, P, capi.dptr(self._xch_send), st), "step_rows_and_pack")
-                allgather_packed(self.shard, self._xch_send, self._xch_all)
-                capi.check(lib.fdcap_opt_unpack_and_step_scale(h, ii, P, capi.dptr(self._xch_all), self.shard.rank,
-                                                               self.shard.world, st), "unpack_and_step_scale")
-            else:
-                capi.check(lib.fdcap_opt_step(h, ii, P, st), "fdcap_opt_step")
-        if logged:
-            capi.check(lib.fdcap_opt_set_loss_output(h, capi.dptr(self._losses)), "fdcap_opt_set_loss_output")
-            if multi:
-                allreduce_scalars(self.shard, torch.zeros(1, device=dev), hist)
-            rows = hist.cpu().numpy()
-            for k, ii in enumerate(logged):
-                self._append_log(log, ii, ii >= P, rows[k])
+                part = part.clone()
+                allreduce_scalars(self.shard, torch.zeros(1, device=dev), part)
+            rows = part.cpu().numpy()
+            for k in range(upto - flushed):
+                self._append_log(log, logged[flushed + k], logged[flushed + k] >= P, rows[k])
+            flushed = upto
+
+        try:
+            for ii in range(self.num_iter if mode != "dct" else 0):                             # :560
+                do_log = bool(log_every) and (ii % log_every == 0 or ii == self.num_iter - 1)
+                st = capi.current_stream()
+                if do_log:                               # this iteration's partial sums go straight into their history row
+                    capi.check(lib.fdcap_opt_set_loss_output(h, capi.dptr(hist[len(logged)])), "fdcap_opt_set_loss_output")
+                    logged.append(ii)
+                capi.check(lib.fdcap_opt_backward(h, ii, P, 1 if do_log else 0, st), "fdcap_opt_backward")
+                if multi:
+                    # one collective per iteration: boundary rows (after Adam) + the scale-gradient partial travel
+                    # together; every rank then sums the partials in rank order and steps `scale` identically
+                    capi.check(lib.fdcap_opt_step_rows_and_pack(h, ii, P, capi.dptr(self._xch_send), st), "step_rows_and_pack")
+                    allgather_packed(self.shard, self._xch_send, self._xch_all)
+                    capi.check(lib.fdcap_opt_unpack_and_step_scale(h, ii, P, capi.dptr(self._xch_all), self.shard.rank,
+                                                                   self.shard.world, st), "unpack_and_step_scale")
+                else:
+                    capi.check(lib.fdcap_opt_step(h, ii, P, st), "fdcap_opt_step")
+                # the reference prints every iteration live (:573-575); a verbose fit shows its progress in batches of
+                # VERBOSE_FLUSH logged iterations (one read-back each) instead of only after the last one
+                if self.verbose and do_log and len(logged) - flushed >= VERBOSE_FLUSH:
+                    flush(len(logged))
+        finally:
+            # never leave the library pointing into `hist` (freed with this frame if the loop raised)
+            if logged:
+                capi.check(lib.fdcap_opt_set_loss_output(h, capi.dptr(self._losses)), "fdcap_opt_set_loss_output")
+        flush(len(logged))
         if mode == "local":
             self._local_second_loop(lib, h, multi, log_every)
         nl = self.shard.n_local
@@ -270,8 +290,10 @@ class FittingOP:
         flipped after its forward, :615-618, so nothing receives a gradient); the rest optimise
         body_rotation_rec + scale with loss_dct*1e-4 + loss_rec*0.5 + loss_contact*0.1 (:620)."""
         import torch
-        if self.legacy_zero_grad:
-            raise NotImplementedError("mode 'dct' reproduces torch >= 2 zero_grad semantics only")
+        # legacy_zero_grad (torch < 2: zero_grad() zeroes gradients instead of dropping them): body / scale / camera never
+        # hold a gradient before the switch, so the first phase is the same; from iteration ceil(0.95 num_iter) on the
+        # frozen c_dct keeps a zero gradient and Adam keeps stepping it on its decaying moments (SURVEY A15).
+        legacy = self.legacy_zero_grad
         N, T, dev = self.num_body, BATCH_FRAME_NUM, self.device
         W = N // T
         if W < 1:
@@ -309,18 +331,23 @@ class FittingOP:
             if multi:
                 allreduce_scalars(sh, torch.zeros(1, device=dev), part)
             self.log_dct = [[k * log_every, float(v) / (69 * W)] for k, v in enumerate(part.cpu().numpy())]
-        if multi:                                              # every rank ends up with all windows' coefficients
+
+        def merge_windows():                                   # every rank ends up with all windows' coefficients
             import torch.distributed as dist
             full = torch.zeros(W, 69 * C, device=dev)
-            capi.check(lib.fdcap_opt_get_dct(h, capi.dptr(full), st), "fdcap_opt_get_dct")
+            capi.check(lib.fdcap_opt_get_dct(h, capi.dptr(full), capi.current_stream()), "fdcap_opt_get_dct")
             own = torch.zeros_like(full)
             own[w0.value:w1.value] = full[w0.value:w1.value]
             if dist.get_backend(self.group) == "gloo":
                 t = own.cpu(); dist.all_reduce(t, group=self.group); own = t.to(dev)
             else:
                 dist.all_reduce(own, group=self.group)
-            capi.check(lib.fdcap_opt_set_dct(h, D.ctypes.data_as(ctypes.c_void_p), D.shape[0], C, capi.dptr(own.contiguous()), st),
-                       "fdcap_opt_set_dct")
+            capi.check(lib.fdcap_opt_set_dct_coef(h, capi.dptr(own.contiguous()), capi.current_stream()), "fdcap_opt_set_dct_coef")
+
+        if multi:
+            merge_windows()
+        if legacy and num_iter > P:                            # iteration P: nothing receives a gradient, c_dct coasts
+            capi.check(lib.fdcap_opt_dct_fit(h, 1, P, 0.0, None, 1, st), "fdcap_opt_dct_fit")
         BIG = 2 ** 30
         wd, wr, wc = DCT_PHASE2
         self.log2 = []
@@ -351,6 +378,10 @@ class FittingOP:
                            "unpack_and_step_scale")
             else:
                 capi.check(lib.fdcap_opt_step(h, k, BIG, st), "fdcap_opt_step")
+            if legacy:                                         # optimizer.step() of this iteration also moves the frozen c_dct
+                capi.check(lib.fdcap_opt_dct_fit(h, 1, ii, 0.0, None, 1, st), "fdcap_opt_dct_fit")
+        if multi and legacy:                                   # (each rank coasted its own windows)
+            merge_windows()
         cd = torch.empty(W, 23, 3, C, device=dev)
         capi.check(lib.fdcap_opt_get_dct(h, capi.dptr(cd), capi.current_stream()), "fdcap_opt_get_dct")
         self.c_dct = cd

@@ -13,12 +13,25 @@ upload is not.  Workload at every N: BASELINE config 3 -- 1024-
 500k-point scene, 500 contact vertices; with N > 1 the SAME clip is sharded over the ranks
 (strong scaling), exchanging 2-frame halos + the scale gradient per iteration over RCCL.
 
-Rank 0 prints ONE JSON line; `roofline` describes the Chamfer NN kernel (timed with HIP events on
-the launch stream), `cpu_baseline` is the oracle timed on this host's cores on a bounded sample.
+Rank 0 prints ONE JSON line.
+  `value`                   loss terms evaluated where they reach a gradient;
+  `with_reference_logging`  the like-for-like figure: every term of every iteration evaluated and kept, as the reference
+                            prints them (:573-575, :587-589) -- read the two as a pair;
+  `exact_fp32`              the same step with the dense products as exact fp32 MFMA chains (FDCAP_GEMM_SPLIT3=0);
+  `roofline`                the dominant kernel (in-loop Chamfer NN launch): its duration is measured live with HIP events
+                            on the launch stream; the counters that say WHICH resource bounds it come from the committed
+                            rocprofv3 PMC summary profiles/r3_pmc_summary.json (tools/run_prof_r3.sh); `contract` keeps
+                            SURVEY §8d's algorithmic-bytes figure;
+  `cpu_baseline`            the oracle timed on this host's cores on a bounded sample.
+
+--dry-run: no GPU, no kernels, `value` null -- only the multi-process plumbing of this file (gloo instead of RCCL: rendezvous,
+LOCAL_RANK, frame shards, the per-iteration all-gather, barriers, max over ranks, rank-0-only JSON); tests/test_bench_plumbing.py
+runs it under torch.distributed.run with two processes.
 """
 import argparse
 import json
 import os
+import subprocess
 import sys
 import time
 
@@ -29,10 +42,18 @@ if ROOT not in sys.path:
 import numpy as np  # noqa: E402
 import torch  # noqa: E402
 
-HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
+# /opt/skills/guides/MI355X_MICROARCH.md
+HBM_PEAK_GBS = 8000.0          # HBM3E 8 TB/s
+BF16_DENSE_TFLOPS = 2500.0     # dense bf16 MFMA
+FP32_MFMA_TFLOPS = 157.3       # fp32 MFMA (64 FLOP/clk/SIMD at 2.4 GHz)
+NUM_SIMD = 1024                # 256 CUs x 4
+NUM_XCD = 8
+WAVES_PER_SIMD = 8
+METRIC = "frames/sec global-opt (fixed iters), 1024f clip/500k-pt scene; Chamfer GB/s"
+PMC_SUMMARY = os.path.join(ROOT, "profiles", "r3_pmc_summary.json")
 
 
-def parse():
+def parse(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=2)
@@ -45,22 +66,135 @@ def parse():
     ap.add_argument("--verts", type=int, default=10475)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-logging-run", action="store_true", help="skip the secondary run that evaluates every loss term every iteration")
-    ap.add_argument("--cpu-sample-frames", type=int, default=0, help="0 = pick from a 15 s budget")
-    return ap.parse_args()
+    ap.add_argument("--no-exact-fp32", action="store_true", help="skip the child run with FDCAP_GEMM_SPLIT3=0")
+    ap.add_argument("--value-only", action="store_true", help="timed steps only: no roofline / secondary figures (child runs)")
+    ap.add_argument("--cpu-sample-frames", type=int, default=0, help="0 = pick from a ~20 s budget")
+    ap.add_argument("--dry-run", action="store_true", help="plumbing only, on CPU with gloo (see the module docstring)")
+    return ap.parse_args(argv)
 
 
+# ---- multi-process plumbing (shared by the real run and --dry-run) -----------------------------------------------------
+class Ranks:
+    def __init__(self, dry):
+        self.world = int(os.environ.get("WORLD_SIZE", "1"))
+        self.rank = int(os.environ.get("RANK", "0"))
+        self.local = int(os.environ.get("LOCAL_RANK", "0"))
+        self.dry = dry
+        self.group = None
+        # FDCAP_FORCE_EXCHANGE=1: a one-rank RCCL group, to measure what the exchange path itself costs
+        if self.world > 1 or os.environ.get("FDCAP_FORCE_EXCHANGE") == "1":
+            import torch.distributed as dist
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            os.environ.setdefault("MASTER_PORT", "29533")
+            if dry:
+                dist.init_process_group("gloo", rank=self.rank, world_size=self.world)
+            else:
+                dist.init_process_group("nccl", rank=self.rank, world_size=self.world, device_id=torch.device("cuda", self.local))
+            self.group = dist.group.WORLD
+
+    def barrier(self):
+        if not self.dry:
+            torch.cuda.synchronize()
+        if self.world > 1:
+            import torch.distributed as dist
+            dist.barrier()
+        if not self.dry:
+            torch.cuda.synchronize()
+
+    def max_over_ranks(self, seconds):
+        if self.world == 1:
+            return seconds
+        import torch.distributed as dist
+        t = torch.tensor([seconds], dtype=torch.float64, device="cpu" if self.dry else "cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return float(t.item())
+
+    def timed(self, fn, steps):
+        """EXACTLY `steps` calls of fn between two barriers; the slowest rank's wall time."""
+        self.barrier()
+        t0 = time.perf_counter()
+        res = None
+        for _ in range(steps):
+            res = fn()
+        self.barrier()
+        return self.max_over_ranks(time.perf_counter() - t0), res
+
+    def finish(self, out):
+        if self.group is not None:
+            import torch.distributed as dist
+            dist.barrier()
+            dist.destroy_process_group()
+        if self.rank == 0:
+            # librccl writes its version banner through C stdio (block-buffered when stdout is a pipe): push it out first
+            # so the JSON line is the last thing this process prints
+            try:
+                import ctypes
+                ctypes.CDLL(None).fflush(None)
+            except OSError:
+                pass
+            print(json.dumps(out), flush=True)
+
+
+def base_line(args, rk, nc, value, dt):
+    N, ns = args.frames, args.scene
+    quoted = (N, ns, nc, args.iters) == (1024, 500_000, 500, 500)
+    return {"metric": METRIC, "value": value, "unit": "frames/s", "n_gpus": rk.world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": dt / max(args.steps, 1) * 1e3, "higher_is_better": True,
+            "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "arithmetic": "fp32 values and fp32 accumulation throughout; dense products as exact three-way bf16 splits of the fp32 "
+                          "operands on the bf16 matrix cores (error of the fp32 chain; FDCAP_GEMM_SPLIT3=0: v_mfma_f32 chains, see exact_fp32)",
+            "config": {"workload": f"{'BASELINE config 3' if quoted else 'non-default sizes (not the quoted configuration)'}: {N}-frame clip, "
+                                   f"{ns}-pt scene, {nc} contact verts, {args.iters} Adam iterations (phase split 0.8), full loss; "
+                                   f"frames sharded over {rk.world} GPU(s)",
+                       "frames": N, "scene_points": ns, "contact_verts": nc, "iters": args.iters, "body_verts": args.verts,
+                       "frame_iterations_per_s": None if value is None else value * args.iters}}
+
+
+def dry_run(args):
+    """The plumbing of main() without a GPU: same rendezvous variables, shards, collectives per iteration and JSON rules."""
+    import fdcap_amd  # noqa: F401
+    from fdcap_amd.dist import FrameShard, allgather_packed
+    rk = Ranks(dry=True)
+    shard = FrameShard(args.frames, rk.group, rank=rk.rank, world=rk.world)
+    xl = 4 * (78 + 16) + 8                                   # fdcap_exchange_len(): the iteration's one message
+    send, gathered = torch.zeros(xl), torch.zeros(rk.world, xl)
+
+    def one_step():
+        for ii in range(min(args.iters, 5)):
+            send.fill_(float(rk.rank * 1000 + ii))
+            if rk.world > 1:
+                allgather_packed(shard, send, gathered)
+                assert [float(gathered[r, 0]) for r in range(rk.world)] == [r * 1000.0 + ii for r in range(rk.world)]
+        return shard.n_local
+
+    for _ in range(args.warmup):
+        one_step()
+    dt, _ = rk.timed(one_step, args.steps)
+    mine = {"rank": rk.rank, "local_rank": rk.local, "device": f"cuda:{rk.local}", "frames": [shard.frame0, shard.frame0 + shard.n_local]}
+    ranks = [mine]
+    if rk.world > 1:
+        import torch.distributed as dist
+        ranks = [None] * rk.world
+        dist.all_gather_object(ranks, mine)
+    out = base_line(args, rk, 2 * args.contacts_per_leg, None, dt)
+    out.update({"dry_run": True, "ranks": ranks, "backend": "gloo"})
+    rk.finish(out)
+
+
+# ---- CPU baseline --------------------------------------------------------------------------------------------------------
 def cpu_baseline(bm, vp, clip, scene, vid, args):
-    """The oracle (PyTorch-CPU restatement of cal_loss + Adam, golden-checked against the
-    reference's own loop) on a bounded sample of the same workload: the first F frames of the
-    clip against the FULL scene, 1 warm-up + 2 timed iterations, extrapolated to the fixed budget."""
-    from oracle.fitting import FittingOracle
+    """The oracle (PyTorch-CPU restatement of cal_loss + Adam, golden-checked against the reference's own loop) on a bounded
+    sample of the same workload: the first F frames of the clip against the FULL scene; 1 warm-up + 3 timed iterations of
+    each phase, weighted by the fixed budget's 400 / 100 split."""
+    from oracle import rotrepr
+    from oracle.chamfer import nn_direct
+    from oracle.fitting import FittingOracle, reference_host_loop_overhead
     from oracle.smplx import SMPLXOracle
     from oracle.vposer import VPoserDecoder
     avail = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
     smpl, vpo = SMPLXOracle(bm), VPoserDecoder.from_data(vp)
-    from oracle.chamfer import nn_direct
-    # torch's intra-op pool degrades badly when it is wider than what these tensor sizes can use:
-    # pick the fastest width on the dominant op (one frame's contact set vs 64k scene points)
+    # torch's intra-op pool degrades badly when it is wider than what these tensor sizes can use (256 threads: 274 s per
+    # iteration against 2-4 s at 16-32): pick the fastest width on the dominant op (one frame's contact set vs 64k scene points)
     qs = torch.randn(len(vid), 3)
     ss = torch.tensor(scene[:65536])
     best_t, cores = None, 1
@@ -73,48 +207,97 @@ def cpu_baseline(bm, vp, clip, scene, vid, args):
         if best_t is None or dt < best_t:
             best_t, cores = dt, cand
     torch.set_num_threads(cores)
+    P = int(np.ceil(args.iters * 0.8 - 1e-12))
 
-    def run(F, iters):
+    def run(F, timed):
         f = FittingOracle(smpl, vpo, scene, vid, clip.camerapose_lines[:F], F, num_iter=args.iters)
-        from oracle import rotrepr
         x78 = rotrepr.convert_to_6D_rot(torch.tensor(clip.body_params[:F]))
         idx1 = f.init(x78)
         x78 = x78.detach()
-        ts = []
-        for ii in range(iters):
+        t1, t2 = [], []
+        for k in range(timed + 1):                             # phase 1 (ii < 0.8 num_iter): contact + smoothing + rec
             t0 = time.perf_counter()
-            f.step(ii, x78, idx1)
-            ts.append(time.perf_counter() - t0)
-        return ts
+            f.step(k, x78, idx1)
+            t1.append(time.perf_counter() - t0)
+        for k in range(timed + 1):                             # phase 2: rec + world smoothing + smoothing (Chamfer still evaluated: it is printed)
+            t0 = time.perf_counter()
+            f.step(P + k, x78, idx1)
+            t2.append(time.perf_counter() - t0)
+        with torch.no_grad():                                  # share of the Chamfer forward in an iteration
+            _, verts, _ = f.forward_world()
+            q = verts[:, vid, :].reshape(-1, 3).contiguous()
+            t0 = time.perf_counter()
+            nn_direct(q, torch.tensor(scene))
+            t_nn = time.perf_counter() - t0
+        return float(np.mean(t1[1:])), float(np.mean(t2[1:])), t_nn
 
     F = args.cpu_sample_frames
     if F <= 0:
-        t_probe = run(2, 2)[1] / 2.0                         # measured seconds per frame-iteration
-        F = int(max(2, min(args.frames, 10.0 / (3 * max(t_probe, 1e-6)))))
-    ts = run(F, 3)
-    t_iter = float(np.mean(ts[1:]))
-    fps = F / (t_iter * args.iters)
+        p1, p2, _ = run(2, 1)
+        per_frame = (p1 + p2) / 2.0 / 2.0                      # measured seconds per frame-iteration
+        F = int(max(2, min(args.frames, 20.0 / (8 * max(per_frame, 1e-6)))))
+    t1, t2, t_nn = run(F, 3)
+    n1, n2 = P, args.iters - P
+    fps = F / (n1 * t1 + n2 * t2)
+    ov = reference_host_loop_overhead(min(args.frames, 300))
     return {"value": fps, "unit": "frames/s", "cores": cores, "kind": "port",
-            "sample": f"oracle (torch CPU fp32, {cores} threads, fastest of 4..64 on {avail} usable cores): first {F} frames of the clip "
-                      f"vs the full {len(scene)}-pt scene, phase-1 loss, 2 timed iterations after 1 warm-up "
-                      f"({t_iter * 1e3:.0f} ms/iter), extrapolated x{args.iters} iterations"}
+            "sample": f"oracle (torch CPU fp32, {cores} threads = fastest of 4..64 on {avail} usable cores): first {F} of the clip's "
+                      f"{args.frames} frames vs the full {len(scene)}-pt scene; 3 timed iterations after 1 warm-up in EACH phase "
+                      f"(phase 1 {t1 * 1e3:.0f} ms/iter, phase 2 {t2 * 1e3:.0f} ms/iter), extrapolated to the fixed budget "
+                      f"{n1} x phase 1 + {n2} x phase 2; the Chamfer forward alone is {t_nn * 1e3:.0f} ms of an iteration "
+                      f"({100 * t_nn / max(t1, 1e-9):.0f} % of phase 1): the baseline is a Chamfer benchmark",
+            "sample_frames": F, "timed_iterations_per_phase": 3, "ms_per_iter_phase1": t1 * 1e3, "ms_per_iter_phase2": t2 * 1e3,
+            "chamfer_forward_ms": t_nn * 1e3,
+            "reference_python_loop_overhead": {
+                "frames": min(args.frames, 300), "ms_per_iter_reference_loops": ov["reference_loops"] * 1e3,
+                "ms_per_iter_vectorised": ov["vectorised"] * 1e3,
+                "note": "forward + backward of the two host loops every reference iteration runs (per-frame body2world, "
+                        "global_optimization.py:191-206; 23 x 3 x W cal_dctloss, :232-246, result unused in mode 'global') around a trivial "
+                        "stand-in body, against the vectorised forms the oracle (and `value` above) uses; not included in `value`"}}
+
+
+# ---- roofline from live durations + the committed PMC summary ---------------------------------------------------------
+def load_pmc():
+    if os.path.exists(PMC_SUMMARY):
+        return json.load(open(PMC_SUMMARY))
+    return {}
+
+
+def counter_fracs(k, live_seconds=None):
+    """What a kernel's PMC totals (summed over the device, per launch) say about the resources it uses.
+    GRBM_GUI_ACTIVE is summed over the 8 XCDs -> /8 = busy cycles of the launch; SQ_WAVE_CYCLES counts quad-cycles."""
+    if not k or not k.get("GRBM_GUI_ACTIVE"):
+        return None
+    cyc = k["GRBM_GUI_ACTIVE"] / NUM_XCD
+    dur = k["duration_us_under_pmc"] * 1e-6
+    out = {"clock_ghz_under_pmc": cyc / dur / 1e9, "duration_us_under_pmc": k["duration_us_under_pmc"], "dispatches": k.get("dispatches")}
+    if k.get("SQ_INSTS_VALU") is not None:
+        out["valu_issue_frac"] = k["SQ_INSTS_VALU"] * 4.0 / (NUM_SIMD * cyc)
+        out["valu_insts_per_launch"] = k["SQ_INSTS_VALU"]
+    if k.get("SQ_WAVES"):
+        out["waves_per_launch"] = k["SQ_WAVES"]
+        if k.get("SQ_INSTS_VALU") is not None:
+            out["valu_insts_per_wave"] = k["SQ_INSTS_VALU"] / k["SQ_WAVES"]
+    if k.get("SQ_VALU_MFMA_BUSY_CYCLES") is not None:
+        out["mfma_busy_frac"] = k["SQ_VALU_MFMA_BUSY_CYCLES"] / (NUM_SIMD * cyc)
+    if k.get("SQ_WAVE_CYCLES") is not None:
+        out["mean_waves_per_simd"] = k["SQ_WAVE_CYCLES"] * 4.0 / (NUM_SIMD * cyc)
+        out["max_waves_per_simd"] = WAVES_PER_SIMD
+    if k.get("hbm_bytes") is not None:
+        out["hbm_bytes_per_launch"] = k["hbm_bytes"]
+        out["hbm_frac_on_counter_bytes"] = k["hbm_bytes"] / (live_seconds or dur) / 1e9 / HBM_PEAK_GBS
+    return out
 
 
 def main():
     args = parse()
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.dry_run:
+        return dry_run(args)
     if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs a GPU (the HIP path has no CPU fallback)")
-    torch.cuda.set_device(local)
-    group = None
-    if world > 1 or os.environ.get("FDCAP_FORCE_EXCHANGE") == "1":   # the latter: one-rank RCCL group, measures the exchange path's cost
-        import torch.distributed as dist
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        os.environ.setdefault("MASTER_PORT", "29533")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
-        group = dist.group.WORLD
+        raise SystemExit("bench.py needs a GPU (the HIP path has no CPU fallback; --dry-run checks the multi-process plumbing only)")
+    rk = Ranks(dry=False)
+    torch.cuda.set_device(rk.local)
+    import ctypes
     import fdcap_amd  # noqa: F401
     from fdcap_amd import capi, synth
     from fdcap_amd.fitting import FittingOP
@@ -128,22 +311,15 @@ def main():
     left, right = synth.make_contact_ids(bm.v_template, per_part=args.contacts_per_leg, seed=4)
     vid = np.arange(args.verts) if args.all_contacts else np.concatenate([left, right])
     fop = FittingOP({"num_iter": args.iters}, {}, N, body_model=bm, vposer=vp, scene_verts=scene, contact_ids=vid,
-                    camera_ext=read_camerapose(clip.camerapose_lines), group=group)
+                    camera_ext=read_camerapose(clip.camerapose_lines), group=rk.group)
     body_gpu = torch.tensor(clip.body_params).cuda()
-    if group is not None:                                  # create the RCCL communicator outside the timed region
+    if rk.group is not None:                               # create the RCCL communicator outside the timed region
         import torch.distributed as dist
         warm = torch.zeros(8, device="cuda")
-        allw = torch.zeros(world, 8, device="cuda")
+        allw = torch.zeros(rk.world, 8, device="cuda")
         dist.all_gather_into_tensor(allw, warm)
         dist.all_reduce(warm)
     torch.cuda.synchronize()
-
-    def barrier():
-        torch.cuda.synchronize()
-        if world > 1:
-            import torch.distributed as dist
-            dist.barrier()
-        torch.cuda.synchronize()
 
     def one_step(log_every=0):
         body_rec, scale, cam = fop.fitting(body_gpu, "global", log_every=log_every)
@@ -151,141 +327,139 @@ def main():
 
     for _ in range(args.warmup):
         one_step()
-    barrier()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        res = one_step()
-    barrier()
-    dt = time.perf_counter() - t0
-    if world > 1:
-        import torch.distributed as dist
-        tmax = torch.tensor([dt], device="cuda", dtype=torch.float64)
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        dt = float(tmax.item())
+    dt, res = rk.timed(one_step, args.steps)
     assert np.isfinite(res[0].numpy()).all()
-    # Secondary figure (never `value`): the same step with EVERY loss term evaluated in EVERY iteration, as the reference's
+    nc, ns, nl = len(vid), len(scene), fop.shard.n_local
+    out = base_line(args, rk, nc, N * args.steps / dt, dt)
+    if args.value_only:
+        return rk.finish(out)
+    # Like-for-like figure (never `value`): the same step with EVERY loss term evaluated in EVERY iteration, as the reference's
     # loop prints them (:573-575, :587-589; phase 2 then also runs the contact forward it otherwise has no use for).  The
     # partial sums go to a device-side history and are read back once, after the last iteration.
-    barrier()
-    t0 = time.perf_counter()
     n_log_steps = 0 if args.no_logging_run else min(args.steps, 2)
-    for _ in range(n_log_steps):
-        one_step(log_every=1)
-    barrier()
-    dt_log = max(time.perf_counter() - t0, 1e-9)
-    if world > 1:
-        import torch.distributed as dist
-        tmax = torch.tensor([dt_log], device="cuda", dtype=torch.float64)
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        dt_log = float(tmax.item())
+    dt_log, _ = rk.timed(lambda: one_step(log_every=1), n_log_steps)
+    if n_log_steps:
+        out["with_reference_logging"] = {
+            "value": N * n_log_steps / dt_log, "unit": "frames/s", "ms_per_step": dt_log / n_log_steps * 1e3,
+            "note": "same step, every loss term of every iteration evaluated and kept (the reference prints them every iteration); "
+                    "`value` evaluates them only where they reach a gradient -- optimised parameters are identical either way"}
 
-    # roofline of the dominant kernel: Chamfer NN forward of this rank's shard, HIP events on the launch stream.
-    #   brute force : every (query, scene point) pair visited -- the launch the algorithmic byte count describes
-    #   in loop     : the same kernel as the optimiser issues it in steady state (seeded by the previous
-    #                 iteration's neighbours, scene chunks out of reach skipped; bit-identical result)
-    import ctypes
-    ms_bf, ms_loop = ctypes.c_float(0), ctypes.c_float(0)
-    if len(scene) == 0:
+    if ns == 0:
         raise SystemExit('bench.py needs a scene (the roofline kernel is the Chamfer NN); BASELINE config 1 is a parity-test case')
-    # the launch as the loop issues it: HIP events around every contact forward of one more (untimed) step
+    lib, h = fop.ctx.lib, fop.ctx.handle
+    # the dominant kernel as the loop issues it: HIP events around every contact forward of one more (untimed) step
     ms_inloop, n_inloop = ctypes.c_float(0), ctypes.c_int32(0)
-    capi.check(fop.ctx.lib.fdcap_opt_nn_timing(fop.ctx.handle, args.iters), "fdcap_opt_nn_timing")
+    capi.check(lib.fdcap_opt_nn_timing(h, args.iters), "fdcap_opt_nn_timing")
     one_step()
-    capi.check(fop.ctx.lib.fdcap_opt_nn_timing_read(fop.ctx.handle, ctypes.byref(ms_inloop), ctypes.byref(n_inloop)), "fdcap_opt_nn_timing_read")
-    capi.check(fop.ctx.lib.fdcap_opt_nn_timing(fop.ctx.handle, 0), "fdcap_opt_nn_timing")
-    capi.check(fop.ctx.lib.fdcap_opt_time_chamfer(fop.ctx.handle, 3, 1, ctypes.byref(ms_bf), capi.current_stream()),
-               "fdcap_opt_time_chamfer")
-    capi.check(fop.ctx.lib.fdcap_opt_time_chamfer(fop.ctx.handle, 10, 0, ctypes.byref(ms_loop), capi.current_stream()),
-               "fdcap_opt_time_chamfer")
-    nl, nc, ns = fop.shard.n_local, len(vid), len(scene)
+    capi.check(lib.fdcap_opt_nn_timing_read(h, ctypes.byref(ms_inloop), ctypes.byref(n_inloop)), "fdcap_opt_nn_timing_read")
+    capi.check(lib.fdcap_opt_nn_timing(h, 0), "fdcap_opt_nn_timing")
+    ms_bf, ms_loop = ctypes.c_float(0), ctypes.c_float(0)
+    capi.check(lib.fdcap_opt_time_chamfer(h, 3, 1, ctypes.byref(ms_bf), capi.current_stream()), "fdcap_opt_time_chamfer")
+    capi.check(lib.fdcap_opt_time_chamfer(h, 10, 0, ctypes.byref(ms_loop), capi.current_stream()), "fdcap_opt_time_chamfer")
     alg_bytes = nl * (12.0 * ns + 20.0 * nc)              # scene once PER FRAME + queries + dist/idx
     pairs = float(nl) * nc * ns
     sec_bf, sec_loop = ms_bf.value * 1e-3, (ms_inloop.value if n_inloop.value else ms_loop.value) * 1e-3
-    traffic = {}
-    for name in ("r2_pmc_traffic.json", "r1_pmc_traffic.json"):   # HBM bytes per launch from the committed rocprofv3 PMC passes
-        tpath = os.path.join(ROOT, "profiles", name)
-        if os.path.exists(tpath):
-            traffic = json.load(open(tpath))
-            break
-    ach = alg_bytes / sec_loop / 1e9
-    # The dominant kernel of the step is the Chamfer NN launch AS THE LOOP ISSUES IT (fdc::nn_stream4_kernel: seeded by the
-    # previous iteration's neighbours, k-d cells out of reach skipped, MFMA filter + exact fp32 re-evaluation; results
-    # bit-identical to the full scan).  `achieved` follows the contract: the ALGORITHMIC bytes of the operator it replaces
-    # (the reference re-reads a scene copy per frame) over this kernel's launch time -- pruning makes that exceed the HBM
-    # peak; `traffic` is what the launch really moves.  `brute_force` is the every-pair launch of the same operator.
-    roofline = {"bound": "hbm",
-                "kernel": "fdc::nn_stream4_kernel (Chamfer body->scene NN forward as issued in the loop: seeded + k-d-cell-culled "
-                          "exact scan, kept work lists, bf16-split MFMA filter + fp32 re-evaluation)",
-                "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
-                "traffic": (traffic.get("nn_in_loop") or {}).get("bytes_per_launch"),
-                "ms_per_launch": sec_loop * 1e3, "launches_timed": n_inloop.value, "algorithmic_bytes_per_launch": alg_bytes,
-                "steady_state_ms_per_launch": ms_loop.value,
-                "note": "ms_per_launch = mean over every NN launch of one whole fit (HIP events around each launch on its stream); "
-                        "steady_state = back-to-back launches at the converged state.  frac > 1 is not a measurement error: exact pruning "
-                        "visits ~1 % of the (query, scene point) pairs the algorithmic byte count pays for; see brute_force for the "
-                        "launch that visits every pair",
-                "brute_force": {"kernel": "fdc::nn_mfma_kernel<4> (every pair visited; not part of the loop any more -- the first "
-                                          "iteration is seeded by fdc::nn_seed_kernel)",
-                                "ms_per_launch": ms_bf.value, "achieved": alg_bytes / sec_bf / 1e9, "unit": "GB/s",
-                                "frac": alg_bytes / sec_bf / 1e9 / HBM_PEAK_GBS,
-                                "traffic": (traffic.get("nn_bruteforce") or {}).get("bytes_per_launch"),
-                                "compute_side": {"pairs_per_s": pairs / sec_bf, "mfma_flop_per_pair": 32,
-                                                 "achieved_tflops_bf16_mfma": 32 * pairs / sec_bf / 1e12,
-                                                 "peak_tflops_bf16_dense": 2500.0, "frac": 32 * pairs / sec_bf / 1e12 / 2500.0}}}
-    # secondary: the full-mesh pose-blendshape GEMM (north-star item; used by the body-model operator / output
-    # meshes -- the optimiser loop itself only needs the contact-vertex columns)
-    ms_g = ctypes.c_float(0)
-    capi.check(fop.ctx.lib.fdcap_time_blend_gemm(fop.ctx.handle, nl, 5, ctypes.byref(ms_g), capi.current_stream()),
-               "fdcap_time_blend_gemm")
-    gflop = 2.0 * nl * 496 * 3 * args.verts / 1e9         # operand rows [pose feature 486 | betas 10]: pose + shape blendshapes in one product
-    split3 = os.environ.get("FDCAP_GEMM_SPLIT3", "1") != "0"
-    tf = gflop / ms_g.value                                 # useful fp32 multiply-adds
-    if split3:
-        blend = {"kernel": "fdc::panel_gemm3_wide_kernel<2> (pose + shape blendshapes [F,496] x [496,3V]; fp32 operands as three bf16 "
-                           "parts, six v_mfma_f32_16x16x32_bf16 per 32 columns, fp32 accumulation, static operand in fragment order)",
-                 "ms_per_launch": ms_g.value, "achieved": tf, "peak": 157.3, "unit": "TFLOP/s", "frac": tf / 157.3, "bound": "mfma",
-                 "executed": {"achieved": 6.0 * tf * 512.0 / 496.0, "peak": 2500.0, "unit": "TFLOP/s (bf16 MFMA, dense)",
-                              "frac": 6.0 * tf * 512.0 / 496.0 / 2500.0},
-                 "note": "`achieved` counts the product's fp32 multiply-adds once and `peak` is the fp32 MFMA peak (the pipe an exact-fp32 "
-                         "chain runs on: FDCAP_GEMM_SPLIT3=0 gives 103 TFLOP/s = 65 % there, 93 % of that pipe's issue slots at the "
-                         "sustained clock) -- frac > 1 means the split beats anything the fp32 pipe can do; `executed` prices the bf16 "
-                         "MFMAs actually issued (6 per product term, K padded 496 -> 512) against the dense bf16 peak"}
+    pmc = load_pmc()
+    pk = pmc.get("kernels", {})
+    quoted = (N, ns, nc, args.iters, rk.world) == (1024, 500_000, 500, 500, 1)     # the configuration the PMC summary was taken on
+    nn = counter_fracs(pk.get("nn_in_loop"), sec_loop) if quoted else None
+    bf = counter_fracs(pk.get("nn_bruteforce"), sec_bf) if quoted else None
+    # The in-loop launch is an exact PRUNED search (seeds, k-d cells, kept work lists; bit-identical to the full scan): it
+    # touches ~1 % of the pairs the algorithmic byte count pays for, so bytes-over-time says nothing about a hardware limit.
+    # What bounds it is VALU issue while the machine is full, then a drain at half occupancy: the top-level
+    # fraction is that resource's, from the PMC counters; `contract` keeps the §8d figure.
+    roofline = {
+        "kernel": "fdc::nn_stream4_kernel (Chamfer body->scene NN forward as issued in the loop: seeded + k-d-cell-culled exact scan, "
+                  "kept work lists, bf16-split MFMA filter + fp32 re-evaluation)",
+        "ms_per_launch": sec_loop * 1e3, "launches_timed": n_inloop.value, "steady_state_ms_per_launch": ms_loop.value,
+        "timing": "HIP events around every NN launch of one whole fit, on its launch stream (mean); steady_state = back-to-back "
+                  "launches at the converged state",
+        "counters_from": os.path.relpath(PMC_SUMMARY, ROOT) if nn else None}
+    if nn:
+        clock = nn["clock_ghz_under_pmc"] * 1e9
+        ach = nn["valu_insts_per_launch"] / sec_loop / 1e9
+        peak = NUM_SIMD * clock / 4.0 / 1e9
+        roofline.update({"bound": "valu_issue", "achieved": ach, "peak": peak, "unit": "G wave-instructions/s (VALU)", "frac": ach / peak,
+                         "traffic": nn.get("hbm_bytes_per_launch"), "hbm_frac_on_counter_bytes": nn.get("hbm_frac_on_counter_bytes"),
+                         "mfma_busy_frac": nn.get("mfma_busy_frac"), "mean_waves_per_simd": nn.get("mean_waves_per_simd"),
+                         "max_waves_per_simd": WAVES_PER_SIMD, "valu_insts_per_wave": nn.get("valu_insts_per_wave"),
+                         "clock_ghz_under_pmc": nn["clock_ghz_under_pmc"],
+                         "note": "peak = 1024 SIMDs x one VALU wave-instruction per 4 cycles at the clock the launch sustained in the PMC "
+                                 "pass; achieved = SQ_INSTS_VALU per launch / live launch time.  HBM and the matrix pipe are far from "
+                                 "their limits (hbm_frac_on_counter_bytes, mfma_busy_frac); mean_waves_per_simd < 8 is the drain"})
     else:
-        blend = {"kernel": "fdc::panel_gemm_wide_kernel<2> (pose + shape blendshapes [F,496] x [496,3V], v_mfma_f32_16x16x4_f32, "
-                           "static operand in MFMA fragment order)",
-                 "ms_per_launch": ms_g.value, "achieved": tf, "peak": 157.3, "unit": "TFLOP/s", "frac": tf / 157.3, "bound": "mfma",
-                 "note": "peak = 64 FLOP/clk/SIMD at the 2.4 GHz maximum clock; the launch sustains ~1.75 GHz (measured: 34.5 cycles per "
-                         "MFMA against the 32-cycle issue interval = 93 % of the matrix pipe's issue slots)"}
-    if rank == 0:
-        out = {"metric": "frames/sec global-opt (fixed iters), 1024f clip/500k-pt scene; Chamfer GB/s",
-               "value": N * args.steps / dt, "unit": "frames/s", "n_gpus": world, "steps": args.steps,
-               "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True,
-               "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-               "arithmetic": "fp32 values and fp32 accumulation throughout; dense products as exact three-way bf16 splits of the fp32 "
-                             "operands on the bf16 matrix cores (error of the fp32 chain; FDCAP_GEMM_SPLIT3=0: v_mfma_f32 chains)",
-               "config": {"workload": f"{'BASELINE config 3' if (N, ns, nc, args.iters) == (1024, 500_000, 500, 500) else 'non-default sizes (not the quoted configuration)'}: {N}-frame clip, {ns}-pt scene, {nc} contact verts, "
-                                      f"{args.iters} Adam iterations (phase split 0.8), full loss; frames sharded "
-                                      f"over {world} GPU(s)",
-                          "frames": N, "scene_points": ns, "contact_verts": nc, "iters": args.iters,
-                          "body_verts": args.verts, "frame_iterations_per_s": N * args.iters * args.steps / dt},
-               "roofline": roofline, "blendshape_gemm": blend,
-               "with_reference_logging": None if n_log_steps == 0 else {"value": N * n_log_steps / dt_log, "unit": "frames/s", "ms_per_step": dt_log / n_log_steps * 1e3,
-                                          "note": "same step, every loss term of every iteration evaluated and kept (the reference "
-                                                  "prints them); `value` above evaluates them only where they reach a gradient"}}
-        if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(bm, vp, clip, scene, vid, args)
-    if group is not None:
-        import torch.distributed as dist
-        dist.barrier()
-        dist.destroy_process_group()
-    if rank == 0:
-        # librccl writes its version banner through C stdio (block-buffered when stdout is a pipe): push it out first so
-        # the JSON line is the last thing this process prints
+        tr = (pk.get("nn_in_loop") or {}).get("hbm_bytes")
+        roofline.update({"bound": "hbm", "achieved": None if tr is None else tr / sec_loop / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": None if tr is None else tr / sec_loop / 1e9 / HBM_PEAK_GBS, "traffic": tr,
+                         "note": "no PMC summary for this configuration: counter bytes of the quoted configuration over this launch time"})
+    roofline["contract"] = {
+        "bound": "hbm", "algorithmic_bytes": alg_bytes, "bytes_per_unit": "F * (12 Ns + 20 Nc): the reference op re-reads a scene copy per frame",
+        "achieved": alg_bytes / sec_loop / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+        "frac_on_algorithmic_bytes": alg_bytes / sec_loop / 1e9 / HBM_PEAK_GBS,
+        "note": "SURVEY §8d's contract figure.  > 1 because exact pruning does not read what the byte count pays for -- an algorithmic win, "
+                "not a bandwidth measurement"}
+    roofline["brute_force"] = {
+        "kernel": "fdc::nn_mfma_kernel<4> (every (query, scene point) pair visited: the launch the algorithmic byte count describes; "
+                  "operator API, not part of the loop)",
+        "ms_per_launch": ms_bf.value, "bound": "mfma", "achieved": 32 * pairs / sec_bf / 1e12, "peak": BF16_DENSE_TFLOPS,
+        "unit": "TFLOP/s (bf16 MFMA, dense)", "frac": 32 * pairs / sec_bf / 1e12 / BF16_DENSE_TFLOPS, "mfma_flop_per_pair": 32,
+        "pairs_per_s": pairs / sec_bf, "mfma_busy_frac": None if not bf else bf.get("mfma_busy_frac"),
+        "traffic": None if not bf else bf.get("hbm_bytes_per_launch"),
+        "hbm": {"achieved": alg_bytes / sec_bf / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": alg_bytes / sec_bf / 1e9 / HBM_PEAK_GBS,
+                "on": "algorithmic bytes"}}
+    out["roofline"] = roofline
+
+    # north-star item: the full-mesh pose + shape blendshape GEMM (body-model operator / output meshes; the loop itself only
+    # needs the contact-vertex columns, whose two products are listed under in_loop)
+    ms_g = ctypes.c_float(0)
+    capi.check(lib.fdcap_time_blend_gemm(h, nl, 5, ctypes.byref(ms_g), capi.current_stream()), "fdcap_time_blend_gemm")
+    gflop = 2.0 * nl * 496 * 3 * args.verts / 1e9         # operand rows [pose feature 486 | betas 10]
+    split3 = os.environ.get("FDCAP_GEMM_SPLIT3", "1") != "0"
+    tf = gflop / ms_g.value                                 # useful fp32 multiply-adds, TFLOP/s
+    wide = counter_fracs(pk.get("blend_wide")) if quoted else None
+    if split3:
+        ex = 6.0 * tf * 512.0 / 496.0                       # six bf16 MFMAs per product term, K padded 496 -> 512
+        blend = {"kernel": "fdc::panel_gemm3_wide_kernel<2> (pose + shape blendshapes [F,496] x [496,3V]; fp32 operands as three bf16 parts, "
+                           "six v_mfma_f32_16x16x32_bf16 per 32 columns, fp32 accumulation, static operand in fragment order)",
+                 "ms_per_launch": ms_g.value, "bound": "mfma", "achieved": ex, "peak": BF16_DENSE_TFLOPS, "unit": "TFLOP/s (bf16 MFMA executed, dense)",
+                 "frac": ex / BF16_DENSE_TFLOPS, "mfma_busy_frac": None if not wide else wide.get("mfma_busy_frac"),
+                 "fp32_equivalent": {"achieved": tf, "unit": "TFLOP/s of fp32 multiply-adds", "fp32_mfma_peak": FP32_MFMA_TFLOPS,
+                                     "ratio_to_fp32_mfma_peak": tf / FP32_MFMA_TFLOPS,
+                                     "note": "the product's useful work against the pipe an exact-fp32 chain would run on (not a fraction of "
+                                             "the pipe that executes it)"}}
+    else:
+        blend = {"kernel": "fdc::panel_gemm_wide_kernel<2> (pose + shape blendshapes [F,496] x [496,3V], v_mfma_f32_16x16x4_f32, static operand "
+                           "in MFMA fragment order)",
+                 "ms_per_launch": ms_g.value, "bound": "mfma", "achieved": tf, "peak": FP32_MFMA_TFLOPS, "unit": "TFLOP/s (fp32 MFMA)",
+                 "frac": tf / FP32_MFMA_TFLOPS, "mfma_busy_frac": None if not wide else wide.get("mfma_busy_frac")}
+    if quoted and split3:
+        loop = {}
+        for key, flop in (("blend_fwd", 2.0 * nl * 512 * 1504), ("blend_bwd", 2.0 * nl * 1504 * 496)):
+            k = pk.get(key)
+            if k and k.get("duration_us_trace"):
+                c = counter_fracs(k) or {}
+                loop[key] = {"kernel": k.get("name"), "us_per_launch": k["duration_us_trace"],
+                             "frac": 6.0 * flop / (k["duration_us_trace"] * 1e-6) / 1e12 / BF16_DENSE_TFLOPS,
+                             "mfma_busy_frac": c.get("mfma_busy_frac"), "source": "kernel-trace average of the committed profile"}
+        blend["in_loop"] = dict(loop, note="the loop's two contact-set products ([F,496]x[496,1500] and its data gradient): launch- and "
+                                          "cold-start-bound at ~13 us each; frac = executed bf16 MFMA flops / dense bf16 peak")
+    out["blendshape_gemm"] = blend
+
+    if rk.world == 1 and split3 and not args.no_exact_fp32:
+        # the same step on exact fp32 MFMA chains: the switch is read once per process, so a child process runs it
+        cmd = [sys.executable, os.path.abspath(__file__), "--steps", str(min(args.steps, 3)), "--warmup", "1", "--value-only",
+               "--frames", str(N), "--scene", str(ns), "--iters", str(args.iters), "--verts", str(args.verts),
+               "--contacts-per-leg", str(args.contacts_per_leg)] + (["--all-contacts"] if args.all_contacts else [])
         try:
-            ctypes.CDLL(None).fflush(None)
-        except OSError:
-            pass
-        print(json.dumps(out), flush=True)
+            p = subprocess.run(cmd, env=dict(os.environ, FDCAP_GEMM_SPLIT3="0"), capture_output=True, text=True, timeout=600)
+            child = json.loads(p.stdout.strip().splitlines()[-1])
+            out["exact_fp32"] = {"value": child["value"], "unit": "frames/s", "ms_per_step": child["ms_per_step"], "steps": child["steps"],
+                                 "note": "FDCAP_GEMM_SPLIT3=0: every dense product as a v_mfma_f32 chain (child process, same workload)"}
+        except Exception as e:  # noqa: BLE001 -- a secondary figure must not take the line down
+            out["exact_fp32"] = {"value": None, "error": repr(e)[:200]}
+    if rk.world == 1 and not args.no_cpu_baseline:
+        out["cpu_baseline"] = cpu_baseline(bm, vp, clip, scene, vid, args)
+    rk.finish(out if rk.rank == 0 else None)
 
 
 if __name__ == "__main__":

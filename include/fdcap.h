@@ -87,7 +87,9 @@ void fdcap_ctx_destroy(fdcap_ctx* ctx);
 const char* fdcap_version(void);
 
 /* Scene vertices, stored ONCE (the reference repeats them per frame, :175-176).  `scene_xyz`
- * is a HOST pointer [ns,3]; registered (copied + packed for the NN kernel). */
+ * is a HOST pointer [ns,3]; registered (copied + packed for the NN kernel).
+ * Both setters return FDCAP_E_STATE while an optimiser exists on the context (fdcap_opt_create .. fdcap_opt_destroy): its
+ * buffers are sized for the registered sets and its pruning state (seeds, kept work lists) is only valid for them. */
 int fdcap_set_scene(fdcap_ctx* ctx, const float* scene_xyz, int64_t ns);
 /* Contact vertex ids = get_contact_id(...) (global_optimization.py:79-94, :288); HOST pointer. */
 int fdcap_set_contact_ids(fdcap_ctx* ctx, const int64_t* vid, int32_t nc);
@@ -200,7 +202,10 @@ int fdcap_opt_set_dct(fdcap_ctx* ctx, const float* dct_mtx, int32_t T, int32_t C
  * run in one launch against the fixed world-joint trajectories of the current state.  Only windows that
  * lie inside this rank's frames are fitted.  obj_hist_d (optional) [ceil(iters/log_stride), 69*(w1-w0)]:
  * each fitted trajectory's objective (sum over the window of e/(e+1)) before the update of iterations
- * 0, log_stride, 2*log_stride ... */
+ * 0, log_stride, 2*log_stride ...
+ * weight = 0: every gradient is exactly zero, so c_dct coasts on its Adam moments -- what torch < 2's
+ * zero_grad() (grads zeroed, not None) does to the frozen c_dct from iteration ceil(0.95 num_iter) on
+ * (legacy_zero_grad = 1 callers issue one such iteration per loop iteration); no forward runs. */
 int fdcap_opt_dct_fit(fdcap_ctx* ctx, int32_t iters, int32_t step0, float weight, float* obj_hist_d,
                       int32_t log_stride, void* stream);
 /* The second phase (:614-626): zero_grad + cal_loss + backward of
@@ -210,7 +215,9 @@ int fdcap_opt_dct_fit(fdcap_ctx* ctx, int32_t iters, int32_t step0, float weight
  * losses_d afterwards: [0] [1] [3] as fdcap_opt_backward, [7] = un-normalised sum of e/(e+1) over this
  * rank's frames (loss_dct = sum / (69 W)). */
 int fdcap_opt_backward_dct(fdcap_ctx* ctx, float w_dct, float w_rec, float w_contact, int32_t log_terms, void* stream);
-/* c_dct_d [W,23,3,C] <- current coefficients (a sharded caller merges the windows each rank fitted). */
+/* c_dct_d [W,23,3,C] <- current coefficients (a sharded caller merges the windows each rank fitted);
+ * fdcap_opt_set_dct_coef writes merged coefficients back without touching the Adam moments. */
+int fdcap_opt_set_dct_coef(fdcap_ctx* ctx, const float* c_dct_d, void* stream);
 int fdcap_opt_get_dct(fdcap_ctx* ctx, float* c_dct_d, void* stream);
 /* Returns W; *w0 / *w1 = first / one-past-last window this rank fits (0 when fdcap_opt_set_dct has not run). */
 int32_t fdcap_opt_dct_windows(fdcap_ctx* ctx, int32_t* w0, int32_t* w1);

@@ -91,3 +91,21 @@ def NN_loss(x, y, dim=0):
     dist = pairwise_dist(x, y)
     values, _ = dist.min(dim=dim)
     return values.mean()
+
+
+def distChamfer(a, b):
+    """chamfer_python.py:18-28, batched expansion form, equal sizes only (x's point count indexes both diagonals, :24-26).
+    Return order as the reference's (:28): min over the x index first -- per-y distances [bs,Ny] -- then per-x [bs,Nx],
+    then the two argmins: (y->x, x->y, idx of x per y, idx of y per x), the OPPOSITE of the CUDA extension's
+    (dist1 = x->y, dist2 = y->x).  Device-free (the reference's `torch.cuda.LongTensor` only builds the diagonal index)."""
+    x, y = a, b
+    bs, num_points, _ = x.size()
+    xx = torch.bmm(x, x.transpose(2, 1))
+    yy = torch.bmm(y, y.transpose(2, 1))
+    zz = torch.bmm(x, y.transpose(2, 1))
+    diag_ind = torch.arange(0, num_points)
+    rx = xx[:, diag_ind, diag_ind].unsqueeze(1).expand_as(xx)
+    ry = yy[:, diag_ind, diag_ind].unsqueeze(1).expand_as(yy)
+    P = rx.transpose(2, 1) + ry - 2 * zz
+    m1, m2 = torch.min(P, 1), torch.min(P, 2)
+    return m1[0], m2[0], m1[1], m2[1]

@@ -17,6 +17,8 @@ Recipe:
   6. call the reference's FittingOP.fitting(body, 'global') and its helper functions.
 
 Usage:  python tests/golden/make_golden.py            (writes tests/golden/*.npz)
+        python tests/golden/make_golden.py --chamfer  (ref_chamfer_python.npz: /root/reference/chamfer_python.py)
+        python tests/golden/make_golden.py --smoother | --dct
 """
 import contextlib
 import hashlib
@@ -271,7 +273,49 @@ def run_smoother(n=12, seed=31):
                 clip_seed=seed)
 
 
+def run_chamfer_python():
+    """SURVEY §8c fixture (8): the reference's own chamfer_python.py (:4-28) on equal-size sets.  The file imports cleanly
+    on CPU; distChamfer builds its diagonal index with `.type(torch.cuda.LongTensor)` (:24), so that one type name is
+    pointed at the CPU LongTensor for the duration of the call -- the function body runs unmodified."""
+    sys.path.insert(0, REF)
+    import chamfer_python as cp
+    rng = np.random.Generator(np.random.PCG64(23))
+    out = {}
+    for tag, n, scale in (("a", 64, 1.0), ("b", 257, 8.0), ("c", 1000, 8.0)):
+        x = (rng.standard_normal((n, 3)) * scale).astype(np.float32)
+        y = (rng.standard_normal((n, 3)) * scale + 0.3).astype(np.float32)
+        tx, ty = torch.tensor(x), torch.tensor(y)
+        out[f"{tag}_x"], out[f"{tag}_y"] = x, y
+        P = cp.pairwise_dist(tx, ty)
+        if n <= 300:
+            out[f"{tag}_P"] = P.numpy()
+        else:                                                              # keep the fixture small: minima of the matrix only
+            for dim in (0, 1):
+                v, i = P.min(dim=dim)
+                out[f"{tag}_Pmin{dim}"], out[f"{tag}_Pargmin{dim}"] = v.numpy(), i.numpy()
+        out[f"{tag}_nn0"] = np.float32(cp.NN_loss(tx, ty, dim=0))
+        out[f"{tag}_nn1"] = np.float32(cp.NN_loss(tx, ty, dim=1))
+    bs, n = 3, 200
+    a = (rng.standard_normal((bs, n, 3)) * 4.0).astype(np.float32)
+    b = (rng.standard_normal((bs, n, 3)) * 4.0 + 0.5).astype(np.float32)
+    saved = torch.cuda.LongTensor
+    torch.cuda.LongTensor = torch.LongTensor
+    try:
+        r = cp.distChamfer(torch.tensor(a), torch.tensor(b))
+    finally:
+        torch.cuda.LongTensor = saved
+    out["d_a"], out["d_b"] = a, b
+    for k, t in enumerate(r):                                              # the function's own return order (:28)
+        out[f"d_ret{k}"] = t.numpy()
+    return out
+
+
 def main():
+    if "--chamfer" in sys.argv:
+        res = run_chamfer_python()
+        np.savez_compressed(os.path.join(HERE, "ref_chamfer_python.npz"), **res)
+        print("wrote ref_chamfer_python", {k: v.shape for k, v in res.items() if k.startswith("d_")})
+        return
     if "--smoother" in sys.argv:
         res = run_smoother()
         np.savez_compressed(os.path.join(HERE, "ref_smoother.npz"), **res)

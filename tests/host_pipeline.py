@@ -45,6 +45,38 @@ def f32(a):
     return np.ascontiguousarray(a, dtype=np.float32)
 
 
+# ---- the sharded iteration's one message (csrc/fdcap.hip adam_step_kernel / unpack_exchange_kernel) ---------------
+XCH_ROW = XDIM + 16            # one boundary row: body_rotation_rec [78] | camera_ext [16]
+XCH_LEN = 4 * XCH_ROW + 8      # [first two | last two owned rows] + this rank's d loss / d scale (+ padding to 32 B)
+
+
+def xch_pack(rows_x, rows_cam, n_local, dscale):
+    """Host mirror of the message fdcap_opt_step_rows_and_pack writes (rows_* include the 2 halo rows each side)."""
+    msg = np.zeros(XCH_LEN, np.float32)
+    for slot, row in enumerate((2, 3, n_local, n_local + 1)):
+        msg[slot * XCH_ROW:slot * XCH_ROW + XDIM] = rows_x[row]
+        msg[slot * XCH_ROW + XDIM:(slot + 1) * XCH_ROW] = rows_cam[row]
+    msg[4 * XCH_ROW] = dscale
+    return msg
+
+
+def xch_unpack(gathered, rank, world, n_local, rows_x, rows_cam):
+    """Host mirror of fdcap_opt_unpack_and_step_scale's data movement: halo rows <- the neighbours' boundary rows (clip ends
+    keep what they hold); returns the scale gradient = the partials summed IN RANK ORDER in fp32 (same bits on every rank)."""
+    g = np.asarray(gathered, dtype=np.float32).reshape(world, XCH_LEN)
+    for k in range(4):
+        src = rank - 1 if k < 2 else rank + 1
+        if 0 <= src < world:
+            slot = 2 + k if k < 2 else k - 2
+            row = k if k < 2 else n_local + k
+            rows_x[row] = g[src, slot * XCH_ROW:slot * XCH_ROW + XDIM]
+            rows_cam[row] = g[src, slot * XCH_ROW + XDIM:(slot + 1) * XCH_ROW]
+    s = np.float32(0)
+    for r in range(world):
+        s = np.float32(s + g[r, 4 * XCH_ROW])
+    return float(s)
+
+
 class HostPipeline:
     def __init__(self, bm, vp, scene, vid):
         self.lib = build()

@@ -1,0 +1,70 @@
+"""bench.py's multi-process plumbing on CPU: the driver launches the 8-GPU scaling run as
+`python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...`;
+`--dry-run` takes exactly that path with gloo in place of RCCL and no kernels (value null), so rendezvous variables, the frame
+partition, the per-iteration all-gather, barrier placement, the max over ranks and the rank-0-only JSON line are covered here."""
+import json
+import os
+import socket
+import subprocess
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _json_lines(text):
+    out = []
+    for line in text.splitlines():
+        line = line.strip()
+        if line.startswith("{") and line.endswith("}"):
+            try:
+                out.append(json.loads(line))
+            except json.JSONDecodeError:
+                pass
+    return out
+
+
+def test_bench_under_torchrun_two_ranks_prints_one_line():
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1",
+           "--dry-run"]
+    env = dict(os.environ, OMP_NUM_THREADS="1")
+    p = subprocess.run(cmd, capture_output=True, text=True, timeout=300, env=env, cwd=ROOT)
+    assert p.returncode == 0, p.stderr[-2000:]
+    lines = _json_lines(p.stdout)
+    assert len(lines) == 1, p.stdout                       # rank 0 only
+    d = lines[0]
+    assert p.stdout.strip().splitlines()[-1].strip().startswith("{")       # ... and it is the last thing printed
+    assert d["n_gpus"] == 2 and d["steps"] == 3 and d["warmup"] == 1 and d["dry_run"] is True and d["value"] is None
+    assert d["scaling"] == "strong" and d["higher_is_better"] is True and d["unit"] == "frames/s"
+    assert d["metric"].startswith("frames/sec global-opt")
+    ranks = sorted(d["ranks"], key=lambda r: r["rank"])
+    assert [r["rank"] for r in ranks] == [0, 1] and [r["local_rank"] for r in ranks] == [0, 1]
+    assert [r["device"] for r in ranks] == ["cuda:0", "cuda:1"]            # one device per process, from LOCAL_RANK
+    assert ranks[0]["frames"] == [0, 512] and ranks[1]["frames"] == [512, 1024]
+    assert d["ms_per_step"] > 0
+
+
+def test_bench_dry_run_single_process():
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--dry-run"], capture_output=True, text=True, timeout=120,
+                       cwd=ROOT)
+    assert p.returncode == 0, p.stderr[-2000:]
+    lines = _json_lines(p.stdout)
+    assert len(lines) == 1 and lines[0]["n_gpus"] == 1 and lines[0]["ranks"][0]["frames"] == [0, 1024]
+
+
+def test_bench_refuses_to_run_the_product_without_a_gpu():
+    import torch
+    if torch.cuda.is_available():
+        return
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "1", "--warmup", "0"], capture_output=True,
+                       text=True, timeout=120, cwd=ROOT)
+    assert p.returncode != 0 and "needs a GPU" in (p.stderr + p.stdout)
+    assert not _json_lines(p.stdout)

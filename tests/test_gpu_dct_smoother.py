@@ -115,6 +115,35 @@ def test_dct_mode_matches_oracle(n, num_iter):
     fop.close()
 
 
+def test_dct_mode_legacy_zero_grad_lets_c_dct_coast():
+    """torch < 2 semantics in mode 'dct': from the 95 % switch on the frozen c_dct keeps a ZERO gradient (not
+    None), so Adam keeps moving it on its decaying moments while body / scale are optimised."""
+    n, num_iter = 120, 200
+    bm, vp, clip, scene, vid, c0 = _dct_case(n, 200, 1500, seed=50 + n)
+    D = load_dct_base(None)
+    out = {}
+    for legacy in (False, True):
+        fop = FittingOP({}, {}, n, body_model=bm, vposer=vp, scene_verts=scene, contact_ids=vid, legacy_zero_grad=legacy,
+                        camera_ext=read_camerapose(clip.camerapose_lines), dct_mtx=D, c_dct_init=c0, dct_num_iter=num_iter)
+        body, scale, cam = fop.fitting(torch.tensor(clip.body_params).cuda(), "dct", log_every=1)
+        out[legacy] = (body.cpu().numpy(), float(scale), fop.c_dct.cpu().numpy(), np.array(fop.log2))
+        fop.close()
+    orc = FittingOracle(SMPLXOracle(bm), VPoserDecoder.from_data(vp), scene, vid, clip.camerapose_lines, n,
+                        dct_mtx=D, c_dct_init=c0, legacy_zero_grad=True)
+    obody, oscale, _ = orc.fitting_dct(torch.tensor(clip.body_params), num_iter=num_iter)
+    body, scale, cd, log2 = out[True]
+    np.testing.assert_allclose(cd, orc.c_dct.detach().numpy(), rtol=0, atol=3e-5)
+    moved = np.abs(cd - out[False][2]).max()
+    assert moved > 1e-3, moved                                   # ten coasting steps at lr 0.005 really moved the coefficients
+    P = int(np.ceil(num_iter * 0.95 - 1e-9))
+    k = num_iter - P - 1
+    err = np.abs(body - obody.numpy())
+    assert err.max() <= 2 * 0.005 * k and np.quantile(err, 0.5) < 1e-6 and np.quantile(err, 0.9) < 1e-4
+    np.testing.assert_allclose(scale, float(oscale), atol=1e-4)
+    olog = np.array(orc.loss_log)
+    np.testing.assert_allclose(log2[:, 5], olog[P + 1:, 4], rtol=5e-5, atol=1e-5)     # loss_dct follows the coasting c_dct
+
+
 def test_dct_gradient_matches_autograd():
     """d(1e-4 dct + 0.5 rec + 0.1 contact)/d(body_rotation_rec, scale) vs fp64 autograd."""
     n = 120

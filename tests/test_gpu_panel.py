@@ -27,6 +27,9 @@ pytestmark = pytest.mark.gpu
     (130, 496, 13001, False, 0),        # wide output: four row blocks per fragment stream, column-block-major workgroup order
     (1024, 496, 1500, False, 0),        # clip-sized M: two row blocks per fragment stream (panel_gemm3_rb2_kernel), the bench's product
     (531, 700, 1000, True, 3),          # ... ragged rows / tiles, unaligned operand and output rows
+    (130, 1690, 496, True, 0),          # longest K whose three-plane LDS image fits a CU's 160 KB (kpad 1696)
+    (130, 2000, 496, True, 0),          # beyond it: the split form must hand over to the K-slabbed fp32 kernel, not fail the launch
+    (400, 1700, 496, True, 0),          # clip-sized M above the K-split kernel's range (K <= 1536)
 ])
 @pytest.mark.parametrize("form", ["split3", "fp32"])
 def test_panel_gemm_matches_fp64(M, K, N, transposed, pad, form, monkeypatch):
@@ -72,13 +75,16 @@ def test_fused_vposer_forward_ragged_rows(B):
     ctx.close()
 
 
-@pytest.mark.parametrize("n,V,per_part", [(37, 300, 20), (70, 300, 20), (21, 2000, 90), (530, 300, 20), (523, 2000, 90)])
+@pytest.mark.parametrize("n,V,per_part", [(37, 300, 20), (70, 300, 20), (21, 2000, 90), (530, 300, 20), (523, 2000, 90),
+                                          (40, 2000, 300), (390, 2000, 283)])
 def test_fused_vposer_backward_in_the_optimiser_gradient(n, V, per_part):
     """Phase-1 gradient of a clip that spans several 16-row blocks (ragged last block): the latent columns come out of
     vposer_bwd_fused_kernel's four partial sums, folded by fdcap_opt_get_grads; compared with fp64 autograd.
     The third case has a 180-vertex contact set on a 2000-vertex body (blend products with K, N = 540); the last two are
     clip-sized (>= 512 frames): the data-gradient product runs as two K halves on two row blocks per fragment stream
-    (panel_gemm3_rb2k_kernel: 2 + 2 and 9 + 8 steps), the partial products added by pose_bwd_kernel."""
+    (panel_gemm3_rb2k_kernel: 2 + 2 and 9 + 8 steps), the partial products added by pose_bwd_kernel.  The 600- / 566-vertex
+    contact sets (K = 1800 / 1698) are past the single-image three-plane form (kpad <= 1696: 160 KB of LDS) and past the
+    K-split kernel: their data gradient runs on the K-slabbed fp32 panel kernel."""
     fop, bm, vp, clip, scene, vid = _make_fop(n, V, 800, per_part, 500)
     dt = torch.float64
     f = FittingOracle(SMPLXOracle(bm, dt), VPoserDecoder.from_data(vp, dt), scene, vid, clip.camerapose_lines, n, dtype=dt)

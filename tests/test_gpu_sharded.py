@@ -116,3 +116,43 @@ def test_exchange_path_over_rccl_on_one_rank_equals_the_plain_loop():
     assert res[2] == ref[2]
     np.testing.assert_array_equal(res[3], ref[3])
     np.testing.assert_allclose(res[4], ref[4], rtol=1e-12)
+
+
+def test_exchange_message_layout_matches_the_host_mirror():
+    """The kernels' message (fdcap_opt_step_rows_and_pack) and its consumption (fdcap_opt_unpack_and_step_scale) against
+    tests/host_pipeline.py xch_pack / xch_unpack -- the layout the CPU (gloo) schedule test of tests/test_dist_cpu.py uses."""
+    from fdcap_amd import capi
+    from fdcap_amd.fitting import FittingOP
+    from tests.host_pipeline import XCH_LEN, XCH_ROW, xch_pack, xch_unpack
+    n = 9
+    bm, vp, clip, scene, vid = _inputs(n)
+    fop = FittingOP({"num_iter": 500}, {}, n, body_model=bm, vposer=vp, scene_verts=scene, contact_ids=vid,
+                    camera_ext=read_camerapose(clip.camerapose_lines))
+    lib, h = fop.ctx.lib, fop.ctx.handle
+    assert int(lib.fdcap_exchange_len()) == XCH_LEN
+    x78 = torch.empty(n, capi.XDIM, device="cuda")
+    capi.check(lib.fdcap_params_75_to_78(capi.dptr(torch.tensor(clip.body_params).cuda()), n, capi.dptr(x78), capi.current_stream()), "75->78")
+    fop._mode = "global"
+    fop.init(x78)
+    for ii, P in ((0, 400), (402, 400)):                              # phase 1 (scale gradient) and phase 2 (camera_ext stepped)
+        capi.check(lib.fdcap_opt_backward(h, ii, P, 0, capi.current_stream()), "backward")
+        send = torch.full((XCH_LEN,), -3.0, device="cuda")
+        capi.check(lib.fdcap_opt_step_rows_and_pack(h, ii, P, capi.dptr(send), capi.current_stream()), "pack")
+        torch.cuda.synchronize()
+        want = xch_pack(fop._rows_x.cpu().numpy(), fop._rows_cam.cpu().numpy(), n, float(fop._dscale.cpu()))
+        got = send.cpu().numpy()
+        np.testing.assert_array_equal(got[:4 * XCH_ROW + 1], want[:4 * XCH_ROW + 1])
+        assert not got[4 * XCH_ROW + 1:].any()
+    # consumption: this context plays rank 1 of 3 against two foreign messages
+    rng = np.random.default_rng(5)
+    gathered = rng.standard_normal((3, XCH_LEN)).astype(np.float32)
+    gathered[1] = got
+    rx, rc = fop._rows_x.cpu().numpy().copy(), fop._rows_cam.cpu().numpy().copy()
+    s = xch_unpack(gathered, 1, 3, n, rx, rc)
+    capi.check(lib.fdcap_opt_unpack_and_step_scale(h, 402, 400, capi.dptr(torch.tensor(gathered).cuda()), 1, 3, capi.current_stream()),
+               "unpack")
+    torch.cuda.synchronize()
+    np.testing.assert_array_equal(fop._rows_x.cpu().numpy(), rx)
+    np.testing.assert_array_equal(fop._rows_cam.cpu().numpy(), rc)
+    assert float(fop._dscale.cpu()) == s
+    fop.close()
