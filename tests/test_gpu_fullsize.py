@@ -148,3 +148,195 @@ np.save(sys.argv[1], dx.cpu().numpy())
     g0, g1 = grads
     assert np.abs(g0).max() > 0
     np.testing.assert_allclose(g1, g0, rtol=2e-4, atol=2e-6 * np.abs(g0).max())
+
+
+# =====================================================================================================================
+# BASELINE configs 5 and 2 at full size (round 3).  Same property set as config 3 above, plus a gradient check against the
+# oracle's fp64 autograd on a frame subset: the Chamfer neighbour of a query is piecewise constant in the parameters, so with
+# the GPU's own neighbour indices (proved exact by the NN properties) the oracle can differentiate the full-size loss of a
+# few frames -- all V vertices, the real scene -- without running its own O(n m) scan.
+# =====================================================================================================================
+from oracle.fitting import FittingOracle  # noqa: E402
+from oracle.smplx import SMPLXOracle  # noqa: E402
+from oracle.vposer import VPoserDecoder  # noqa: E402
+
+CONFIGS = {
+    # BASELINE config 5: 2M-pt dense scene, 512 frames, contact term over ALL 10 475 vertices (5.4 M queries per launch;
+    # nc > 1024: chunked skinning backward, wide blend forward, K = 3V data-gradient GEMM)
+    "C5": dict(n=512, ns=2_000_000, all_contacts=True, sample=1500, grad_frames=[0, 1, 255, 511]),
+    # BASELINE config 2: 256-frame clip, full loss vs a 100k-pt scene, 500 contact vertices (one-row-block blend products
+    # below 384 rows)
+    "C2": dict(n=256, ns=100_000, all_contacts=False, sample=2000, grad_frames=[0, 1, 2, 100, 101, 254, 255]),
+}
+
+
+@pytest.fixture(scope="module", params=sorted(CONFIGS))
+def cfg_assets(request):
+    c = CONFIGS[request.param]
+    bm = synth.make_body_model(V, seed=0)
+    vp = synth.make_vposer(seed=1)
+    clip = synth.make_clip(c["n"], seed=3)
+    scene = synth.make_scene(c["ns"], seed=2)
+    left, right = synth.make_contact_ids(bm.v_template, per_part=PER_PART, seed=4)
+    vid = np.arange(V) if c["all_contacts"] else np.concatenate([left, right])
+    return request.param, c, bm, vp, clip, scene, vid
+
+
+def _cfg_fop(cfg_assets, iters):
+    _, c, bm, vp, clip, scene, vid = cfg_assets
+    return FittingOP({"num_iter": iters}, {}, c["n"], body_model=bm, vposer=vp, scene_verts=scene, contact_ids=vid,
+                     camera_ext=read_camerapose(clip.camerapose_lines))
+
+
+def _cfg_init(fop, clip, n):
+    body = torch.tensor(clip.body_params).cuda()
+    x78 = torch.empty(n, capi.XDIM, device="cuda")
+    capi.check(fop.ctx.lib.fdcap_params_75_to_78(capi.dptr(body), n, capi.dptr(x78), capi.current_stream()), "75->78")
+    fop._mode = "global"
+    fop.init(x78)
+    return x78
+
+
+def _cfg_contact(fop, n):
+    nc = len(fop.vid)
+    verts = torch.empty(n, nc, 3, device="cuda")
+    d = torch.empty(n, nc, device="cuda")
+    i = torch.empty(n, nc, device="cuda", dtype=torch.int32)
+    lib, h = fop.ctx.lib, fop.ctx.handle
+    capi.check(lib.fdcap_opt_forward_world(h, capi.dptr(verts), None, capi.current_stream()), "forward_world")
+    capi.check(lib.fdcap_opt_get_contact(h, capi.dptr(d), capi.dptr(i), capi.current_stream()), "get_contact")
+    torch.cuda.synchronize()
+    return verts, d, i
+
+
+def test_config_in_loop_chamfer_is_exhaustive_and_matches_the_oracle(cfg_assets):
+    name, c, bm, vp, clip, scene, vid = cfg_assets
+    n, ns = c["n"], c["ns"]
+    fop = _cfg_fop(cfg_assets, 500)
+    _cfg_init(fop, clip, n)
+    lib, h = fop.ctx.lib, fop.ctx.handle
+    for ii in range(4):                                  # seeds / kept lists / anchors now come from previous launches
+        capi.check(lib.fdcap_opt_backward(h, ii, 400, 0, capi.current_stream()), "backward")
+        capi.check(lib.fdcap_opt_step(h, ii, 400, capi.current_stream()), "step")
+    verts, d1, i1 = _cfg_contact(fop, n)
+    verts2, d2, i2 = _cfg_contact(fop, n)
+    assert torch.equal(verts, verts2) and torch.equal(d1, d2) and torch.equal(i1, i2)
+    ms = ctypes.c_float()
+    capi.check(lib.fdcap_opt_time_chamfer(h, 1, 1, ctypes.byref(ms), capi.current_stream()), "time_chamfer")   # every pair visited
+    db, ib = torch.empty_like(d1), torch.empty_like(i1)
+    capi.check(lib.fdcap_opt_get_contact(h, capi.dptr(db), capi.dptr(ib), capi.current_stream()), "get_contact")
+    torch.cuda.synchronize()
+    print(f"{name}: exhaustive launch {ms.value:.1f} ms for {n * len(vid)} queries x {ns} points")
+    assert torch.equal(d1, db) and torch.equal(i1, ib)                    # bit for bit, on ALL queries
+    assert int(i1.min()) >= 0 and int(i1.max()) < ns and bool(torch.isfinite(d1).all())
+    rng = np.random.default_rng(0)
+    pick = rng.choice(n * len(vid), c["sample"], replace=False)
+    q = verts.reshape(-1, 3)[torch.tensor(pick, device="cuda")].cpu().numpy()
+    od, oi = nn_direct(torch.from_numpy(q), torch.from_numpy(scene))
+    got_d = d1.reshape(-1).cpu().numpy()[pick]
+    got_i = i1.reshape(-1).cpu().numpy()[pick].astype(np.int64)
+    np.testing.assert_allclose(got_d, od.numpy(), rtol=2e-6, atol=1e-12)
+    diff = got_i != oi.numpy()
+    if diff.any():                                       # an index may differ only between candidates tied to rounding
+        d_at = ((q[diff] - scene[got_i[diff]]) ** 2).sum(1)
+        np.testing.assert_allclose(d_at, od.numpy()[diff], rtol=4e-6, atol=1e-12)
+    assert diff.mean() < 1e-2
+    fop.close()
+
+
+def test_config_phase1_gradient_matches_fp64_autograd_on_a_frame_subset(cfg_assets):
+    """d(0.1 contact + smoothing + rec)/d body_rotation_rec (global_optimization.py:570) of a few frames of the FULL-SIZE
+    problem, from the kernel forms that size selects, against the oracle's fp64 autograd of the same frames."""
+    name, c, bm, vp, clip, scene, vid = cfg_assets
+    n, S = c["n"], c["grad_frames"]
+    fop = _cfg_fop(cfg_assets, 500)
+    x78 = _cfg_init(fop, clip, n)
+    lib, h = fop.ctx.lib, fop.ctx.handle
+    for ii in range(3):                                  # move off the start, where x == x0 sits on every L1 kink of loss_rec
+        capi.check(lib.fdcap_opt_backward(h, ii, 400, 0, capi.current_stream()), "backward")
+        capi.check(lib.fdcap_opt_step(h, ii, 400, capi.current_stream()), "step")
+    capi.check(lib.fdcap_opt_backward(h, 3, 400, 0, capi.current_stream()), "backward")
+    dx = torch.empty(n, 78, device="cuda")
+    capi.check(lib.fdcap_opt_get_grads(h, capi.dptr(dx), None, capi.current_stream()), "grads")
+    _, _, idx = _cfg_contact(fop, n)
+    rows = fop._rows_x[2:2 + n].cpu().double()
+    cam = fop._rows_cam[2:2 + n].cpu().double().reshape(n, 4, 4)
+    scale = float(fop._scale.cpu())
+    got = dx.cpu().numpy()
+    # the oracle on the subset: its own VPoser / SMPL-X / world transform in fp64, Chamfer through the GPU's neighbour indices
+    dt = torch.float64
+    f = FittingOracle(SMPLXOracle(bm, dt), VPoserDecoder.from_data(vp, dt), np.zeros((0, 3), np.float32), vid,
+                      [clip.camerapose_lines[i] for i in S], len(S), dtype=dt)
+    x_full = rows.clone().requires_grad_(True)
+    f.body_rotation_rec = x_full[S]
+    f.camera_ext = cam[S]
+    f.scale = torch.tensor(scale, dtype=dt)
+    _, verts, _ = f.forward_world()
+    P = torch.tensor(scene, dtype=dt)[idx[S].cpu().long()]                   # [|S|, nc, 3] neighbours the kernel found
+    d = ((verts[:, vid, :] - P) ** 2).sum(-1)
+    r = torch.sqrt(d + 1e-4)
+    l_con = 0.1 * (r / (r + 1.0)).sum() / (n * len(vid))                     # weight_contact * mean over the WHOLE clip (:295)
+    x0 = x78.cpu().double()
+    w = torch.ones(n, 78, dtype=dt)
+    w[fop.idx1, :] = 0.0
+    l_rec = torch.mean(torch.abs(x0 - x_full) * w)                          # :259
+    diff = x_full[0:-1, :] - x_full[1:, :]
+    l_sm = torch.mean(torch.abs(diff[0:-1, :] - diff[1:, :]))               # :267
+    g_l1 = torch.autograd.grad(l_sm + l_rec, x_full, retain_graph=True)[0].numpy()[S]
+    (0.1 * l_con + l_sm + l_rec).backward()
+    want = x_full.grad.numpy()[S]
+    g = got[S]
+    # The two L1 terms dominate every element (+-1/(78 N) and multiples of 1/(78 (N-2)): exactly representable sums of a few
+    # terms), the contact term is 10-1000 x smaller.  Subtracting the oracle's L1 part from both sides isolates the contact
+    # gradient -- the part that runs through VPoser, the body model, skinning, the world transform and the Chamfer result --
+    # and holds it to its OWN scale.
+    gc, wc = g - g_l1, want - g_l1
+    w_sm, w_rec = 1.0 / ((n - 2) * 78), 1.0 / (n * 78)
+    flip = np.abs(gc - wc) > 0.4 * min(w_sm, w_rec)      # an L1 sign that differs (fp32 second difference rounding across zero)
+    assert flip.mean() < 2e-3, (name, flip.mean())       # (rare by nature; a real contact-gradient error could not hide in it)
+    assert np.abs(wc).max() > 0 and (np.abs(wc) > 1e-3 * np.abs(wc).max()).mean() > 0.5    # the term reaches most columns
+    np.testing.assert_allclose(gc[~flip], wc[~flip], rtol=2e-3, atol=2e-4 * np.abs(wc).max())
+    fop.close()
+
+
+def test_config_short_fit_is_reproducible_finite_and_descends(cfg_assets):
+    name, c, bm, vp, clip, scene, vid = cfg_assets
+    iters = 15 if name == "C5" else 40
+    outs = []
+    for _ in range(2):
+        fop = _cfg_fop(cfg_assets, iters)
+        body, scale, cam = fop.fitting(torch.tensor(clip.body_params).cuda(), "global", log_every=1)
+        outs.append((body.clone(), float(scale), cam.clone(), np.array(fop.log.total)))
+        fop.close()
+    a, b = outs
+    assert torch.equal(a[0], b[0]) and a[1] == b[1] and torch.equal(a[2], b[2]) and np.array_equal(a[3], b[3])
+    assert bool(torch.isfinite(a[0]).all()) and bool(torch.isfinite(a[2]).all()) and np.isfinite(a[3]).all()
+    p1 = int(np.ceil(iters * 0.8 - 1e-12))
+    assert a[3][p1 - 1] < a[3][0]                        # phase 1 lowers its own total
+
+
+def test_c2_trajectory_on_a_frame_subset_matches_the_oracle():
+    """BASELINE config 2's body (10 475 vertices), scene (100k points) and contact set, on the clip's first 6 frames, 6
+    iterations across the phase switch: the oracle itself can run this one end to end."""
+    c = CONFIGS["C2"]
+    nsub, iters = 6, 6
+    bm = synth.make_body_model(V, seed=0)
+    vp = synth.make_vposer(seed=1)
+    clip = synth.make_clip(c["n"], seed=3)
+    scene = synth.make_scene(c["ns"], seed=2)
+    left, right = synth.make_contact_ids(bm.v_template, per_part=PER_PART, seed=4)
+    vid = np.concatenate([left, right])
+    lines = clip.camerapose_lines[:nsub]
+    fop = FittingOP({"num_iter": iters}, {}, nsub, body_model=bm, vposer=vp, scene_verts=scene, contact_ids=vid,
+                    camera_ext=read_camerapose(lines))
+    body, scale, cam = fop.fitting(torch.tensor(clip.body_params[:nsub]).cuda(), "global", log_every=1)
+    orc = FittingOracle(SMPLXOracle(bm), VPoserDecoder.from_data(vp), scene, vid, lines, nsub, num_iter=iters)
+    obody, oscale, ocam = orc.fitting(torch.tensor(clip.body_params[:nsub]))
+    err = np.abs(body.cpu().numpy() - obody.numpy())
+    olog = np.array(orc.loss_log)
+    print("C2 subset trajectory: max", err.max(), "q99", np.quantile(err, 0.99))
+    assert np.quantile(err, 0.99) < 2e-5 and err.max() <= 2 * 0.005 * iters
+    np.testing.assert_allclose(float(scale), float(oscale), atol=1e-4)
+    np.testing.assert_allclose(np.array(fop.log.total), olog[:, 5], rtol=0, atol=3e-6 + 2e-6 * iters)
+    np.testing.assert_allclose(np.array(fop.log.loss_contact), olog[:, 3], rtol=0, atol=3e-6 + 2e-6 * iters)
+    fop.close()
