@@ -58,6 +58,8 @@ SYMBOLS = {
                                      c_void_p, c_void_p, c_void_p]),
     "fdcap_set_nn_kernel": (c_int32, [c_int32]),
     "fdcap_vposer_decode": (c_int32, [c_void_p, c_void_p, c_int32, c_int32, c_void_p, c_void_p, c_void_p]),
+    "fdcap_vposer_decode_bwd": (c_int32, [c_void_p, c_void_p, c_int32, c_int32, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "fdcap_smplx_backward": (c_int32, [c_void_p] * 7 + [c_int32] + [c_void_p] * 9),
     "fdcap_body_forward": (c_int32, [c_void_p, c_void_p, c_int32, c_void_p, c_void_p, c_void_p]),
     "fdcap_world_mesh": (c_int32, [c_void_p, c_void_p, c_int32, c_void_p, c_void_p, c_void_p, c_void_p]),
     "fdcap_params_75_to_78": (c_int32, [c_void_p, c_int32, c_void_p, c_void_p]),

@@ -203,13 +203,17 @@ FDC_HD void pose_forward(const PoseModel& pm, const float* x, const float* o, co
 //      dA[55*12] (d loss / d skinning transforms, may be null), dPF[486] (may be null),
 //      dJw[23*3] (may be null), dMv[12], dsv, dbeta_v[10], dtransl_v[3]: vertex-side sums (null -> 0)
 // Out: dx[78] += (transl, 6D, betas, hands, cam_t),  dO[126] =,  dcam_ext[16] =,  *dscale =
+// Operator-level extras (fdcap_smplx_backward; all default to null): aa22 -- the forward took global_orient + the 21 body
+// joints as axis-angle (Rodrigues), their gradient goes to daa22[66] instead of dx's 6D slot / dO; dJb[55*3] -- gradient
+// of the posed body-frame joints (G.t + transl) as the body-model operator returns them.
 template <class Sync>
 FDC_HD void pose_backward(const PoseModel& pm, const float* x, const float* o, const float* cam_ext,
                           float scale, const float* Rm, const float* Jrest, const float* G,
                           const float* dA, const float* dPF, const float* dJw, const float* dMv,
                           const float* dsv, const float* dbeta_v, const float* dtransl_v,
                           PoseScratch& sc, float* dx, float* dO, float* dcam_ext, float* dscale,
-                          int tid, int nthr, Sync sync) {
+                          int tid, int nthr, Sync sync, const float* aa22 = nullptr, float* daa22 = nullptr,
+                          const float* dJb = nullptr) {
     FDC_FR_STAMP(1, 1);
     M3 MR; V3 Mt;
     world_matrix(cam_ext, x, scale, &MR, &Mt);
@@ -240,9 +244,11 @@ FDC_HD void pose_backward(const PoseModel& pm, const float* x, const float* o, c
                 q = m3t_vec(MR, g);
                 dGt = dGt + q;
             }
+            if (dJb) q = q + v3(dJb[3 * j], dJb[3 * j + 1], dJb[3 * j + 2]);   // (+ transl: summed with the world joints' share below)
             g_store(sc.dMj[j], dMR, g);
             sc.dTj[j][0] = q.x; sc.dTj[j][1] = q.y; sc.dTj[j][2] = q.z;
         }
+        if (dJb) dGt = dGt + v3(dJb[3 * j], dJb[3 * j + 1], dJb[3 * j + 2]);
         g_store(sc.dG[j], dGR, dGt);
         sc.dJ[j][0] = dJ.x; sc.dJ[j][1] = dJ.y; sc.dJ[j][2] = dJ.z;
     }
@@ -333,7 +339,10 @@ FDC_HD void pose_backward(const PoseModel& pm, const float* x, const float* o, c
         sc.dJ[j][0] = dJ.x; sc.dJ[j][1] = dJ.y; sc.dJ[j][2] = dJ.z;
         M3 dR = load_m3(sc.dR[j]);
         if (dPF && j >= 1) for (int e = 0; e < 9; ++e) dR.m[e] += dPF[9 * (j - 1) + e];
-        if (j == 0) {
+        if (aa22 && j <= 21) {
+            V3 d = rodrigues_backward(v3(aa22[3 * j], aa22[3 * j + 1], aa22[3 * j + 2]), dR);
+            daa22[3 * j] = d.x; daa22[3 * j + 1] = d.y; daa22[3 * j + 2] = d.z;
+        } else if (j == 0) {
             GsCache c; gs_forward(x + X_SIXD, 1, &c);
             float d6[6]; gs_backward(c, dR, d6, 1);
             for (int e = 0; e < 6; ++e) dx[X_SIXD + e] += d6[e];
@@ -380,6 +389,7 @@ FDC_HD void pose_backward(const PoseModel& pm, const float* x, const float* o, c
             int c = t - NBETA - 24;
             float acc = dtransl_v ? dtransl_v[c] : 0.f;
             for (int j = 0; j < NJW; ++j) acc += sc.dTj[j][c];
+            if (dJb) for (int j = NJW; j < NJ; ++j) acc += dJb[3 * j + c];
             dx[X_TRANSL + c] += acc;
         } else if (t == NBETA + 24 + 3) {
             M3 dMR = g_rot(sc.dMs);

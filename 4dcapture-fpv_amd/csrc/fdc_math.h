@@ -229,4 +229,59 @@ FDC_HD V3 tgm_rotmat_to_aa(const M3& R) {
     return v3(qx * k, qy * k, qz * k);
 }
 
+// Gradient of tgm_rotmat_to_aa: g = d loss / d aa -> d loss / d R (row-major), through the branch the forward selects
+// (what autograd of the library's masked blend gives: the unselected candidates are multiplied by 0).  At s2 == 0
+// (R == I) torch's `where` leaves 0/0 = NaN in the gradient; here the selected branch k = 2 is differentiated instead
+// (finite).  Needed by the operator-level VPoser backward only (decode(..., 'aa')); the optimiser loop never goes R -> aa.
+FDC_HD M3 tgm_rotmat_to_aa_backward(const M3& R, V3 g) {
+    // rt[i][j] = R[j][i]
+    float rt[9];
+    for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) rt[3 * i + j] = R.m[3 * j + i];
+    int br;
+    if (rt[8] < 1e-6f) br = rt[0] > rt[4] ? 0 : 1; else br = rt[0] < -rt[4] ? 2 : 3;
+    float t, q[4];                      // q = raw candidate (w, x, y, z)
+    switch (br) {
+    case 0: t = 1.f + rt[0] - rt[4] - rt[8]; q[0] = rt[5] - rt[7]; q[1] = t; q[2] = rt[1] + rt[3]; q[3] = rt[6] + rt[2]; break;
+    case 1: t = 1.f - rt[0] + rt[4] - rt[8]; q[0] = rt[6] - rt[2]; q[1] = rt[1] + rt[3]; q[2] = t; q[3] = rt[5] + rt[7]; break;
+    case 2: t = 1.f - rt[0] - rt[4] + rt[8]; q[0] = rt[1] - rt[3]; q[1] = rt[6] + rt[2]; q[2] = rt[5] + rt[7]; q[3] = t; break;
+    default: t = 1.f + rt[0] + rt[4] + rt[8]; q[0] = t; q[1] = rt[5] - rt[7]; q[2] = rt[6] - rt[2]; q[3] = rt[1] - rt[3]; break;
+    }
+    const float c = 0.5f / sqrtf(t);
+    const float w = q[0] * c, x = q[1] * c, y = q[2] * c, z = q[3] * c;
+    const float s2 = x * x + y * y + z * z, s = sqrtf(s2);
+    float dw = 0.f, dx, dy, dz;
+    if (s2 > 0.f) {
+        const float tt = 2.f * (w < 0.f ? atan2f(-s, -w) : atan2f(s, w));
+        const float k = tt / s;
+        const float dk = g.x * x + g.y * y + g.z * z;
+        const float dtt = dk / s;
+        float ds = -dk * tt / s2;
+        const float den = w * w + s2;
+        ds += dtt * 2.f * w / den;
+        dw = -dtt * 2.f * s / den;
+        const float ds2 = ds / (2.f * s);
+        dx = k * g.x + 2.f * x * ds2; dy = k * g.y + 2.f * y * ds2; dz = k * g.z + 2.f * z * ds2;
+    } else {
+        dx = 2.f * g.x; dy = 2.f * g.y; dz = 2.f * g.z;
+    }
+    // q_scaled = q_raw * c, c = 0.5 t^-1/2
+    const float dq[4] = {dw * c, dx * c, dy * c, dz * c};
+    const float dc = dw * q[0] + dx * q[1] + dy * q[2] + dz * q[3];
+    float dt = dc * (-0.25f) / (t * sqrtf(t));
+    float d[9] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};      // d loss / d rt
+    switch (br) {
+    case 0: d[5] += dq[0]; d[7] -= dq[0]; dt += dq[1]; d[1] += dq[2]; d[3] += dq[2]; d[6] += dq[3]; d[2] += dq[3];
+            d[0] += dt; d[4] -= dt; d[8] -= dt; break;
+    case 1: d[6] += dq[0]; d[2] -= dq[0]; d[1] += dq[1]; d[3] += dq[1]; dt += dq[2]; d[5] += dq[3]; d[7] += dq[3];
+            d[0] -= dt; d[4] += dt; d[8] -= dt; break;
+    case 2: d[1] += dq[0]; d[3] -= dq[0]; d[6] += dq[1]; d[2] += dq[1]; d[5] += dq[2]; d[7] += dq[2]; dt += dq[3];
+            d[0] -= dt; d[4] -= dt; d[8] += dt; break;
+    default: dt += dq[0]; d[5] += dq[1]; d[7] -= dq[1]; d[6] += dq[2]; d[2] -= dq[2]; d[1] += dq[3]; d[3] -= dq[3];
+            d[0] += dt; d[4] += dt; d[8] += dt; break;
+    }
+    M3 dR;
+    for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) dR.m[3 * j + i] = d[3 * i + j];
+    return dR;
+}
+
 }  // namespace fdc

@@ -1144,6 +1144,59 @@ __global__ void assemble_rows_kernel(const float* __restrict__ go, const float* 
     for (int i = 0; i < 63; ++i) a[3 + i] = bp[63 * b + i];
 }
 
+// ---- operator-level backward helpers (fdcap_vposer_decode_bwd / fdcap_smplx_backward; not on the optimiser's path) ----------
+// decoder output O[B,126] + gradients of its rotation matrices (g_rot [n,9], may be null) and / or of their tgm angle-axis
+// form (g_aa [n,3], may be null) -> dO[n,6]: through tgm's R -> aa (fdc_math.h) and the Gram-Schmidt step
+__global__ void vposer_out_bwd_kernel(const float* __restrict__ O, int n, const float* __restrict__ g_rot, const float* __restrict__ g_aa,
+                                      float* __restrict__ dO) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    GsCache c;
+    const M3 R = gs_forward(O + (size_t)i * 6, 1, &c);
+    M3 dR = m3_zero();
+    if (g_rot) for (int e = 0; e < 9; ++e) dR.m[e] = g_rot[(size_t)i * 9 + e];
+    if (g_aa) m3_add(dR, tgm_rotmat_to_aa_backward(R, v3(g_aa[(size_t)i * 3], g_aa[(size_t)i * 3 + 1], g_aa[(size_t)i * 3 + 2])));
+    gs_backward(c, dR, dO + (size_t)i * 6, 1);
+}
+__global__ void vposer_fold_dz_rows_kernel(const float* __restrict__ part, size_t part_stride, int nrows, float* __restrict__ gz) {
+    const int e = blockIdx.x * 256 + threadIdx.x;
+    if (e < nrows * VP_Z) gz[e] = vp_sum_dz(part, part_stride, (size_t)e);
+}
+// one wave per frame: pose_backward on global pointers (generic form; the optimiser's pose_bwd_kernel is the staged one)
+__global__ __launch_bounds__(64) void pose_bwd_op_kernel(PoseModel pm, const float* __restrict__ X, const float* __restrict__ AA,
+                                                         const float* Rm, const float* Jrest, const float* G, const float* dA,
+                                                         const float* dPF, const float* dtransl_v, const float* dJb,
+                                                         float* dX, float* dAA) {
+    __shared__ PoseScratch sc;
+    __shared__ float s_cam[16], s_dO[ODIM], s_dcam[16], s_ds[1];
+    const int r = blockIdx.x;
+    if (threadIdx.x < 16) s_cam[threadIdx.x] = 0.f;
+    __syncthreads();
+    pose_backward(pm, X + (size_t)r * XDIM, (const float*)nullptr, s_cam, 0.f, Rm + (size_t)r * NJ * 9, Jrest + (size_t)r * NJ * 3,
+                  G + (size_t)r * NJ * 12, dA ? dA + (size_t)r * NJ * 12 : nullptr, dPF ? dPF + (size_t)r * NPFX : nullptr,
+                  (const float*)nullptr, (const float*)nullptr, (const float*)nullptr, dPF ? dPF + (size_t)r * NPFX + NPF : nullptr,
+                  dtransl_v ? dtransl_v + (size_t)r * 3 : nullptr, sc, dX + (size_t)r * XDIM, s_dO, s_dcam, s_ds, threadIdx.x, 64,
+                  SyncBlock(), AA + (size_t)r * 66, dAA + (size_t)r * 66, dJb ? dJb + (size_t)r * NJ * 3 : nullptr);
+}
+__global__ void smplx_bwd_split_kernel(const float* __restrict__ dX, const float* __restrict__ dAA, int B, float* g_go, float* g_bp,
+                                       float* g_betas, float* g_lh, float* g_rh, float* g_transl) {
+    int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= B) return;
+    const float* x = dX + (size_t)b * XDIM;
+    const float* a = dAA + (size_t)b * 66;
+    if (g_go) for (int i = 0; i < 3; ++i) g_go[3 * b + i] = a[i];
+    if (g_bp) for (int i = 0; i < 63; ++i) g_bp[63 * b + i] = a[3 + i];
+    if (g_betas) for (int i = 0; i < NBETA; ++i) g_betas[NBETA * b + i] = x[X_BETAS + i];
+    if (g_lh) for (int i = 0; i < 12; ++i) g_lh[12 * b + i] = x[X_LH + i];
+    if (g_rh) for (int i = 0; i < 12; ++i) g_rh[12 * b + i] = x[X_RH + i];
+    if (g_transl) for (int i = 0; i < 3; ++i) g_transl[3 * b + i] = x[X_TRANSL + i];
+}
+__global__ void identity_rows_kernel(float* __restrict__ M, int B, float* __restrict__ one) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i == 0) *one = 1.f;
+    if (i < B * 12) { const int e = i % 12; M[i] = (e == 0 || e == 5 || e == 10) ? 1.f : 0.f; }
+}
+
 // dst[r, perm[c], :] = src[r, c, :]   (internal contact-slot order -> caller's order)
 template <class T>
 __global__ void unpermute_kernel(const T* __restrict__ src, const int* __restrict__ perm, int rows, int nc, int w,
@@ -1289,6 +1342,7 @@ struct fdcap_ctx {
     DevBuf<AdamScalars> ws_adam;
     std::vector<AdamScalars> ws_adam_h;
     DevBuf<float> ws_f[12];
+    DevBuf<float> ws_b[12];         // ... of their backward passes (fdcap_vposer_decode_bwd, fdcap_smplx_backward)
     DevBuf<float> ws_part;          // partial decoder outputs of the stand-alone operators
     DevBuf<int> ws_i[2];
     DevBuf<float4> ws_p;
@@ -1618,6 +1672,7 @@ void fdcap_ctx_destroy(fdcap_ctx* c) {
     for (auto& b : c->vp_pn3) b.release();
     c->full.release(); c->contact.release(); c->contact_vid.release(); c->contact_perm.release(); c->scene.release(); c->scene_sorted.release(); c->scene_bounds.release(); c->scene_sbounds.release(); c->scene_qbounds.release(); c->scene_inv.release(); c->scene_frags.release(); c->scene_centers.release();
     for (auto& b : c->ws_f) b.release();
+    for (auto& b : c->ws_b) b.release();
     c->ws_part.release();
     for (auto& b : c->ws_i) b.release();
     c->ws_p.release();
@@ -1870,6 +1925,28 @@ int fdcap_vposer_decode(fdcap_ctx* c, const float* z, int32_t ldz, int32_t B, fl
     return (int)hipGetLastError();
 }
 
+int fdcap_vposer_decode_bwd(fdcap_ctx* c, const float* z, int32_t ldz, int32_t B, const float* g_rot, const float* g_aa, float* g_z,
+                            void* stream) {
+    if (!c || !z || !g_z || B <= 0 || ldz < 32 || (!g_rot && !g_aa)) return FDCAP_E_ARG;
+    hipStream_t st = (hipStream_t)stream;
+    DevBuf<float>* w = c->ws_b;
+    HIP_TRY(w[0].ensure((size_t)B * 512)); HIP_TRY(w[1].ensure((size_t)B * 512)); HIP_TRY(w[2].ensure((size_t)B * ODIM));
+    HIP_TRY(w[3].ensure((size_t)B * ODIM)); HIP_TRY(w[4].ensure((size_t)4 * B * VP_Z));
+    HIP_TRY(c->ws_part.ensure((size_t)4 * B * ODIM));
+    // recompute the forward's activations (the operator keeps no state between calls), then the data-gradient chain
+    int e = vposer_forward(c, z, ldz, 0, 0, B, w[0].p, w[1].p, c->ws_part.p, (size_t)B * ODIM, w[2].p, st);
+    if (e) return e;
+    const int n = B * 21;
+    hipLaunchKernelGGL(vposer_out_bwd_kernel, dim3((n + 255) / 256), dim3(256), 0, st, w[2].p, n, g_rot, g_aa, w[3].p);
+    const size_t ps = (size_t)B * VP_Z;
+    if (gemm_split3_enabled())
+        hipLaunchKernelGGL(vposer_bwd_split3_kernel, dim3(4 * ((B + 15) / 16)), dim3(512), 0, st, c->vp3, w[3].p, 0, B, w[0].p, w[1].p, w[4].p, ps);
+    else
+        hipLaunchKernelGGL(vposer_bwd_fused_kernel, dim3(4 * ((B + 15) / 16)), dim3(512), 0, st, c->vp, w[3].p, 0, B, w[0].p, w[1].p, w[4].p, ps);
+    hipLaunchKernelGGL(vposer_fold_dz_rows_kernel, dim3((B * VP_Z + 255) / 256), dim3(256), 0, st, w[4].p, ps, B, g_z);
+    return (int)hipGetLastError();
+}
+
 // ---- parameter conversions -------------------------------------------------------------------
 int fdcap_params_75_to_78(const float* p75, int32_t B, float* x78, void* stream) {
     if (!p75 || !x78 || B <= 0) return FDCAP_E_ARG;
@@ -1965,6 +2042,57 @@ int fdcap_smplx_forward(fdcap_ctx* c, const float* go, const float* bp, const fl
         hipLaunchKernelGGL(skin_fwd_kernel, dim3((V + 255) / 256, B), dim3(256), 0, st, c->full.model(), V, X, XDIM, X_BETAS,
                            X_TRANSL, w[11].p, w[8].p, (const float*)nullptr, (const float*)nullptr, 0, 0, vertices);
     }
+    return (int)hipGetLastError();
+}
+
+int fdcap_smplx_backward(fdcap_ctx* c, const float* go, const float* bp, const float* betas, const float* lh, const float* rh,
+                         const float* transl, int32_t B, const float* g_vertices, const float* g_joints, float* g_go, float* g_bp,
+                         float* g_betas, float* g_lh, float* g_rh, float* g_transl, void* stream) {
+    if (!c || !go || !bp || !betas || !lh || !rh || !transl || B <= 0 || (!g_vertices && !g_joints)) return FDCAP_E_ARG;
+    hipStream_t st = (hipStream_t)stream;
+    if (g_vertices && !c->full_ready) {
+        std::vector<int64_t> all(c->V);
+        for (int i = 0; i < c->V; ++i) all[i] = i;
+        int e = build_skin_set(c, all, &c->full);
+        if (e) return e;
+        c->full_ready = true;
+    }
+    const int V = c->V;
+    const size_t nv3 = (size_t)3 * V;
+    DevBuf<float>* w = c->ws_b;
+    // forward state (recomputed: the operator keeps none): X rows, AA, PF, Rm, Jrest, G, A
+    HIP_TRY(w[0].ensure((size_t)B * XDIM)); HIP_TRY(w[1].ensure((size_t)B * 66)); HIP_TRY(w[2].ensure((size_t)B * NPFX));
+    HIP_TRY(w[3].ensure((size_t)B * NJ * 9)); HIP_TRY(w[4].ensure((size_t)B * NJ * 3)); HIP_TRY(w[5].ensure((size_t)B * NJ * 12));
+    HIP_TRY(w[6].ensure((size_t)B * NJ * 12));
+    // gradients: dA, [dtransl_v 3 | dMv 12 | dsv 1 | identity M 12 | cam 16] per row + scale, dPF, dX, dAA
+    HIP_TRY(w[7].ensure((size_t)B * NJ * 12)); HIP_TRY(w[8].ensure((size_t)B * 44 + 4)); HIP_TRY(w[9].ensure((size_t)B * NPFX));
+    HIP_TRY(w[10].ensure((size_t)B * XDIM)); HIP_TRY(w[11].ensure((size_t)B * 66));
+    float* X = w[0].p; float* AA = w[1].p; float* PF = w[2].p;
+    float* dtv = w[8].p; float* dMv = dtv + (size_t)B * 3; float* dsv = dMv + (size_t)B * 12; float* Mid = dsv + B;
+    float* cam0 = Mid + (size_t)B * 12; float* one = cam0 + (size_t)B * 16;
+    hipLaunchKernelGGL(assemble_rows_kernel, dim3((B + 127) / 128), dim3(128), 0, st, go, bp, betas, lh, rh, transl, B, X, AA);
+    HIP_TRY(hipMemsetAsync(cam0, 0, ((size_t)B * 16 + 4) * sizeof(float), st));
+    HIP_TRY(hipMemsetAsync(w[10].p, 0, (size_t)B * XDIM * sizeof(float), st));
+    hipLaunchKernelGGL(pose_fwd_kernel<false>, dim3(B), dim3(64), 0, st, c->pose_model(), X, (float*)nullptr, cam0, one /* = 0 here */, 0,
+                       w[3].p, PF, w[4].p, w[5].p, w[6].p, (float*)nullptr, (float*)nullptr, (const float*)AA, (const float*)nullptr,
+                       (size_t)0);
+    const float* dA = nullptr; const float* dPF = nullptr; const float* dtr = nullptr;
+    if (g_vertices) {
+        // body-frame vertices = the world form with M = [I | 0] and scale = 1
+        hipLaunchKernelGGL(identity_rows_kernel, dim3((B * 12 + 255) / 256), dim3(256), 0, st, Mid, B, one);
+        DevBuf<float>* wf = c->ws_f;
+        HIP_TRY(wf[11].ensure((size_t)B * nv3));                 // pose + shape blend offsets
+        HIP_TRY(wf[0].ensure((size_t)B * nv3));                  // d offsets
+        HIP_TRY(blend_forward(c->full, PF, B, wf[11].p, st));
+        hipLaunchKernelGGL(skin_bwd_kernel<false>, dim3(B), dim3(256), (size_t)std::min(V, 1024) * 12 * sizeof(float), st, c->full.model(), V,
+                           X, wf[11].p, w[6].p, Mid, one, 0, g_vertices, wf[0].p, w[7].p, (float*)nullptr, dtv, dMv, dsv, ContactGradIn());
+        HIP_TRY(gemm_f32(true, EPI_STORE, wf[0].p, 3 * V, c->full.posedirs.p, c->full.ldp, w[9].p, NPFX, B, NPFX, 3 * V, nullptr, 0, st));
+        dA = w[7].p; dPF = w[9].p; dtr = dtv;
+    }
+    hipLaunchKernelGGL(pose_bwd_op_kernel, dim3(B), dim3(64), 0, st, c->pose_model(), X, AA, w[3].p, w[4].p, w[5].p, dA, dPF, dtr,
+                       g_joints, w[10].p, w[11].p);
+    hipLaunchKernelGGL(smplx_bwd_split_kernel, dim3((B + 127) / 128), dim3(128), 0, st, w[10].p, w[11].p, B, g_go, g_bp, g_betas, g_lh,
+                       g_rh, g_transl);
     return (int)hipGetLastError();
 }
 

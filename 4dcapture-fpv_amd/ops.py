@@ -6,8 +6,9 @@ hot path, backed by libfdcap_hip.so:
   Op 3  vposer.decode(z, output_type='aa')                   global_optimization.py:270-271
 
 They exist so reference-style code (and the parity tests, which read like the reference's call
-sites) can call the HIP kernels one operator at a time; the optimiser itself (fitting.py) uses
-the fused iteration and never goes through autograd.
+sites) can call the HIP kernels one operator at a time, keeping its own loop, torch.optim.Adam and
+`loss.backward()` (:591): all three are torch.autograd.Functions over the C-ABI's forward / backward
+pairs.  The optimiser itself (fitting.py) uses the fused iteration and never goes through autograd.
 """
 from __future__ import annotations
 
@@ -92,22 +93,44 @@ class chamferDist(torch.nn.Module):
         return d1, d2
 
 
+class _VPoserFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, z, fctx, want_aa):
+        B = z.shape[0]
+        rot = torch.empty(B, 21, 9, device=z.device)
+        aa = torch.empty(B, 63, device=z.device) if want_aa else None
+        capi.check(fctx.lib.fdcap_vposer_decode(fctx.handle, capi.dptr(z), z.stride(0), B, capi.dptr(rot), capi.dptr(aa),
+                                                capi.current_stream()), "fdcap_vposer_decode")
+        ctx.fctx, ctx.want_aa = fctx, want_aa
+        ctx.save_for_backward(z)
+        return aa if want_aa else rot
+
+    @staticmethod
+    def backward(ctx, g):
+        (z,) = ctx.saved_tensors
+        B = z.shape[0]
+        g = g.contiguous().float()
+        gz = torch.empty(B, 32, device=z.device)
+        fctx = ctx.fctx
+        capi.check(fctx.lib.fdcap_vposer_decode_bwd(fctx.handle, capi.dptr(z), z.stride(0), B,
+                                                    None if ctx.want_aa else capi.dptr(g), capi.dptr(g) if ctx.want_aa else None,
+                                                    capi.dptr(gz), capi.current_stream()), "fdcap_vposer_decode_bwd")
+        return gz, None, None
+
+
 class VPoser:
-    """Decoder half of VPoser v1.0 with the reference's call: decode(z, output_type='aa')."""
+    """Decoder half of VPoser v1.0 with the reference's call: decode(z, output_type='aa'); differentiable."""
 
     def __init__(self, ctx):
         self.fctx = _ctx_of(ctx)
 
     def decode(self, Zin, output_type="matrot"):
-        z = Zin.contiguous() if Zin.stride(-1) == 1 and Zin.dim() == 2 else Zin.reshape(-1, 32).contiguous()
+        z = Zin.reshape(-1, 32).float().contiguous()
         B = z.shape[0]
-        rot = torch.empty(B, 21, 9, device=z.device)
-        aa = torch.empty(B, 63, device=z.device) if output_type == "aa" else None
-        capi.check(self.fctx.lib.fdcap_vposer_decode(self.fctx.handle, capi.dptr(z), z.stride(0), B, capi.dptr(rot),
-                                                     capi.dptr(aa), capi.current_stream()), "fdcap_vposer_decode")
+        out = _VPoserFn.apply(z, self.fctx, output_type == "aa")
         if output_type == "aa":
-            return aa.view(B, 1, 21, 3)
-        return rot.view(B, 1, 21, 9)
+            return out.view(B, 1, 21, 3)
+        return out.view(B, 1, 21, 9)
 
     def to(self, *a, **k):
         return self
@@ -116,8 +139,40 @@ class VPoser:
         return self
 
 
+class _BodyModelFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, go, bp, be, lh, rh, tr, fctx, return_verts):
+        B, dev = bp.shape[0], bp.device
+        V = fctx.num_verts
+        verts = torch.empty(B, V, 3, device=dev) if return_verts else None
+        joints = torch.empty(B, 55, 3, device=dev)
+        capi.check(fctx.lib.fdcap_smplx_forward(fctx.handle, capi.dptr(go), capi.dptr(bp), capi.dptr(be), capi.dptr(lh),
+                                                capi.dptr(rh), capi.dptr(tr), B, capi.dptr(verts), capi.dptr(joints),
+                                                capi.current_stream()), "fdcap_smplx_forward")
+        ctx.fctx, ctx.return_verts = fctx, return_verts
+        ctx.save_for_backward(go, bp, be, lh, rh, tr)
+        if return_verts:
+            return verts, joints
+        return torch.zeros(0, device=dev), joints
+
+    @staticmethod
+    def backward(ctx, gv, gj):
+        go, bp, be, lh, rh, tr = ctx.saved_tensors
+        fctx = ctx.fctx
+        B = bp.shape[0]
+        gv = gv.contiguous().float() if (ctx.return_verts and gv is not None) else None
+        gj = gj.contiguous().float() if gj is not None else None
+        if gv is None and gj is None:
+            return (None,) * 8
+        outs = [torch.empty_like(t) if need else None for t, need in zip((go, bp, be, lh, rh, tr), ctx.needs_input_grad[:6])]
+        capi.check(fctx.lib.fdcap_smplx_backward(fctx.handle, capi.dptr(go), capi.dptr(bp), capi.dptr(be), capi.dptr(lh),
+                                                 capi.dptr(rh), capi.dptr(tr), B, capi.dptr(gv), capi.dptr(gj),
+                                                 *[capi.dptr(o) for o in outs], capi.current_stream()), "fdcap_smplx_backward")
+        return (*outs, None, None)
+
+
 class BodyModel:
-    """smplx.create(..., model_type='smplx', num_pca_comps=12) stand-in: forward only.
+    """smplx.create(..., model_type='smplx', num_pca_comps=12) stand-in, differentiable with respect to all six inputs.
     `joints` holds the 55 posed joints (the reference reads [:, 0:23])."""
 
     def __init__(self, ctx):
@@ -130,13 +185,8 @@ class BodyModel:
         c = lambda t, w: (torch.zeros(B, w, device=dev) if t is None else t.reshape(B, w).float().contiguous())
         go, bp, be = c(global_orient, 3), c(body_pose, 63), c(betas, 10)
         lh, rh, tr = c(left_hand_pose, 12), c(right_hand_pose, 12), c(transl, 3)
-        V = self.fctx.num_verts
-        verts = torch.empty(B, V, 3, device=dev) if return_verts else None
-        joints = torch.empty(B, 55, 3, device=dev)
-        capi.check(self.fctx.lib.fdcap_smplx_forward(self.fctx.handle, capi.dptr(go), capi.dptr(bp), capi.dptr(be),
-                                                     capi.dptr(lh), capi.dptr(rh), capi.dptr(tr), B, capi.dptr(verts),
-                                                     capi.dptr(joints), capi.current_stream()), "fdcap_smplx_forward")
-        return SimpleNamespace(vertices=verts, joints=joints)
+        verts, joints = _BodyModelFn.apply(go, bp, be, lh, rh, tr, self.fctx, bool(return_verts))
+        return SimpleNamespace(vertices=verts if return_verts else None, joints=joints)
 
     def to(self, *a, **k):
         return self

@@ -116,6 +116,12 @@ int fdcap_set_nn_kernel(int32_t mode);
 /* z_d [B,32] with row stride ldz -> rot_d [B,21,9] rotation matrices; aa_d (optional) [B,63]. */
 int fdcap_vposer_decode(fdcap_ctx* ctx, const float* z_d, int32_t ldz, int32_t B, float* rot_d,
                         float* aa_d, void* stream);
+/* Its backward -- what loss.backward() (:591) runs through the reference's vposer.decode: gradients of the rotation
+ * matrices g_rot_d [B,21,9] and / or of the angle-axis output g_aa_d [B,63] (either may be NULL, not both; the aa path
+ * goes through torchgeometry's rotation_matrix_to_angle_axis, cvae.py:83) -> g_z_d [B,32].  The operator keeps no
+ * state: the decoder's activations are recomputed from z_d. */
+int fdcap_vposer_decode_bwd(fdcap_ctx* ctx, const float* z_d, int32_t ldz, int32_t B, const float* g_rot_d,
+                            const float* g_aa_d, float* g_z_d, void* stream);
 
 /* ---- Op 2: body model (self.body_mesh_model(...), global_optimization.py:280-283) ---------- */
 /* params_d [B,75] file layout rows (transl, global_orient aa, betas, latent, lh, rh, cam_t);
@@ -135,6 +141,16 @@ int fdcap_smplx_forward(fdcap_ctx* ctx, const float* global_orient_d, const floa
                         const float* betas_d, const float* left_hand_pose_d,
                         const float* right_hand_pose_d, const float* transl_d, int32_t B,
                         float* vertices_d, float* joints_d, void* stream);
+/* Its backward (loss.backward() through self.body_mesh_model(...), :280-283 / :591): gradients of the outputs
+ * g_vertices_d [B,V,3] and / or g_joints_d [B,55,3] (either may be NULL, not both) -> gradients of the six inputs (any
+ * may be NULL).  Same inputs as the forward; its state is recomputed.  LBS, the K = 3V blend-shape data gradient, the
+ * reverse kinematic chain and Rodrigues' backward are the kernels of mode 'local''s full-mesh backward. */
+int fdcap_smplx_backward(fdcap_ctx* ctx, const float* global_orient_d, const float* body_pose_d,
+                         const float* betas_d, const float* left_hand_pose_d,
+                         const float* right_hand_pose_d, const float* transl_d, int32_t B,
+                         const float* g_vertices_d, const float* g_joints_d, float* g_global_orient_d,
+                         float* g_body_pose_d, float* g_betas_d, float* g_left_hand_pose_d,
+                         float* g_right_hand_pose_d, float* g_transl_d, void* stream);
 
 /* ---- parameter-vector conversions (global_optimization.py:96-115, cvae.py:62-93) ----------- */
 int fdcap_params_75_to_78(const float* p75_d, int32_t B, float* x78_d, void* stream);

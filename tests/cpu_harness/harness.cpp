@@ -280,4 +280,41 @@ void h_rotmat_to_aa(const float* R, int n, float* aa) {
     }
 }
 
+void h_rotmat_to_aa_bwd(const float* R, const float* g, int n, float* dR) {
+    for (int i = 0; i < n; ++i) {
+        M3 m; for (int e = 0; e < 9; ++e) m.m[e] = R[(size_t)i * 9 + e];
+        M3 d = tgm_rotmat_to_aa_backward(m, v3(g[3 * i], g[3 * i + 1], g[3 * i + 2]));
+        for (int e = 0; e < 9; ++e) dR[(size_t)i * 9 + e] = d.m[e];
+    }
+}
+
+// operator-level body model (fdcap_smplx_forward / fdcap_smplx_backward): global_orient + body pose as axis-angle rows AA
+// [rows,66], gradient of the 55 body-frame joints dJb [rows,165] -> dX rows (transl, betas, hands) and dAA [rows,66]
+void h_pose_forward_aa(void* hv, int rows, const float* X, const float* AA, float* Rm, float* PF, float* Jrest, float* G, float* A) {
+    HPose* h = (HPose*)hv;
+    PoseModel pm = h->pm();
+    static PoseScratch sc;
+    const float cam[16] = {0};
+    for (int r = 0; r < rows; ++r)
+        pose_forward(pm, X + (size_t)r * XDIM, (const float*)nullptr, cam, 0.f, sc, Rm + (size_t)r * NJ * 9, PF + (size_t)r * NPF,
+                     Jrest + (size_t)r * NJ * 3, G + (size_t)r * NJ * 12, A + (size_t)r * NJ * 12, (float*)nullptr, (float*)nullptr,
+                     0, 1, NoSync(), AA + (size_t)r * 66);
+}
+void h_pose_backward_aa(void* hv, int rows, const float* X, const float* AA, const float* Rm, const float* Jrest, const float* G,
+                        const float* dA, const float* dPF, const float* dbeta_v, const float* dtransl_v, const float* dJb,
+                        float* dX, float* dAA) {
+    HPose* h = (HPose*)hv;
+    PoseModel pm = h->pm();
+    static PoseScratch sc;
+    const float cam[16] = {0};
+    float dO[ODIM], dcam[16], dsc;
+    for (int r = 0; r < rows; ++r)
+        pose_backward(pm, X + (size_t)r * XDIM, (const float*)nullptr, cam, 0.f, Rm + (size_t)r * NJ * 9, Jrest + (size_t)r * NJ * 3,
+                      G + (size_t)r * NJ * 12, dA ? dA + (size_t)r * NJ * 12 : nullptr, dPF ? dPF + (size_t)r * NPF : nullptr,
+                      (const float*)nullptr, (const float*)nullptr, (const float*)nullptr,
+                      dbeta_v ? dbeta_v + (size_t)r * NBETA : nullptr, dtransl_v ? dtransl_v + (size_t)r * 3 : nullptr, sc,
+                      dX + (size_t)r * XDIM, dO, dcam, &dsc, 0, 1, NoSync(), AA + (size_t)r * 66, dAA + (size_t)r * 66,
+                      dJb ? dJb + (size_t)r * NJ * 3 : nullptr);
+}
+
 }  // extern "C"

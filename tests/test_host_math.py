@@ -74,6 +74,65 @@ def test_rotmat_to_aa_all_quaternion_branches():
     assert min(counts) > 100, counts
 
 
+def test_rotmat_to_aa_backward_matches_autograd_on_every_branch():
+    """tgm_rotmat_to_aa_backward (the operator-level VPoser backward's R -> aa step) against autograd of the oracle's
+    torchgeometry restatement, which blends the four quaternion candidates by 0/1 masks."""
+    from oracle import tgm
+    rng = np.random.default_rng(3)
+    n = 4000
+    aa = rng.standard_normal((n, 3))
+    aa = aa / np.linalg.norm(aa, axis=1, keepdims=True) * rng.uniform(0.05, 3.1, (n, 1))
+    R = tgm.angle_axis_to_rotation_matrix(torch.tensor(aa))[:, :3, :3].detach()
+    R = R + 1e-3 * torch.tensor(rng.standard_normal((n, 3, 3)))           # off SO(3): the gradient is that of the formula
+    Rg = R.clone().requires_grad_(True)
+    out = tgm.rotation_matrix_to_angle_axis(torch.nn.functional.pad(Rg, [0, 1]))
+    g = torch.tensor(rng.standard_normal((n, 3)))
+    (out * g).sum().backward()
+    want = Rg.grad.numpy().reshape(n, 9)
+    got = np.zeros((n, 9), np.float32)
+    hp = HostPipeline(*_setup()[:2], np.zeros((0, 3), np.float32), [0])
+    hp.lib.h_rotmat_to_aa_bwd(hp_ptr(f32(R.numpy().reshape(n, 9))), hp_ptr(f32(g.numpy())), n, hp_ptr(got))
+    rt = R.transpose(1, 2).numpy()
+    d2 = rt[:, 2, 2] < 1e-6
+    br = np.where(d2 & (rt[:, 0, 0] > rt[:, 1, 1]), 0, np.where(d2, 1, np.where(rt[:, 0, 0] < -rt[:, 1, 1], 2, 3)))
+    assert np.bincount(br, minlength=4).min() > 100
+    for k in range(4):
+        w, gk = want[br == k], got[br == k]
+        np.testing.assert_allclose(gk, w, rtol=2e-3, atol=2e-4 * np.abs(w).max())
+
+
+def test_operator_level_pose_backward_matches_smplx_autograd():
+    """pose_backward's operator extras (axis-angle joints in, gradient of the 55 body-frame joints): d sum(w * joints) with
+    respect to global_orient, body_pose, betas, hand PCA coefficients and transl against the oracle's SMPL-X."""
+    bm, vp, clip, scene, vid = _setup(n=5)
+    hp = HostPipeline(bm, vp, np.zeros((0, 3), np.float32), [0])
+    rng = np.random.default_rng(9)
+    n = 5
+    dt = torch.float64
+    inp = {"global_orient": rng.standard_normal((n, 3)) * 0.8, "body_pose": rng.standard_normal((n, 63)) * 0.4,
+           "betas": rng.standard_normal((n, 10)) * 0.5, "left_hand_pose": rng.standard_normal((n, 12)) * 0.3,
+           "right_hand_pose": rng.standard_normal((n, 12)) * 0.3, "transl": rng.standard_normal((n, 3))}
+    t = {k: torch.tensor(v, dtype=dt, requires_grad=True) for k, v in inp.items()}
+    out = SMPLXOracle(bm, dt)(return_verts=True, **t)
+    w = rng.standard_normal((n, 55, 3))
+    (out.joints[:, :55] * torch.tensor(w)).sum().backward()
+    X = np.zeros((n, 78), np.float32)
+    X[:, 0:3], X[:, 9:19], X[:, 51:63], X[:, 63:75] = inp["transl"], inp["betas"], inp["left_hand_pose"], inp["right_hand_pose"]
+    AA = f32(np.concatenate([inp["global_orient"], inp["body_pose"]], 1))
+    Rm, PF, Jr = np.zeros((n, 495), np.float32), np.zeros((n, 486), np.float32), np.zeros((n, 165), np.float32)
+    G, A = np.zeros((n, 660), np.float32), np.zeros((n, 660), np.float32)
+    hp.lib.h_pose_forward_aa(hp.h, n, hp_ptr(X), hp_ptr(AA), hp_ptr(Rm), hp_ptr(PF), hp_ptr(Jr), hp_ptr(G), hp_ptr(A))
+    joints = G.reshape(n, 55, 12)[:, :, [3, 7, 11]] + X[:, None, 0:3]
+    np.testing.assert_allclose(joints, out.joints[:, :55].detach().numpy(), atol=2e-5)
+    dX, dAA = np.zeros((n, 78), np.float32), np.zeros((n, 66), np.float32)
+    hp.lib.h_pose_backward_aa(hp.h, n, hp_ptr(X), hp_ptr(AA), hp_ptr(Rm), hp_ptr(Jr), hp_ptr(G), None, None, None, None,
+                              hp_ptr(f32(w.reshape(n, 165))), hp_ptr(dX), hp_ptr(dAA))
+    for name, got in (("global_orient", dAA[:, 0:3]), ("body_pose", dAA[:, 3:66]), ("betas", dX[:, 9:19]),
+                      ("left_hand_pose", dX[:, 51:63]), ("right_hand_pose", dX[:, 63:75]), ("transl", dX[:, 0:3])):
+        want = t[name].grad.numpy()
+        np.testing.assert_allclose(got, want, rtol=2e-3, atol=2e-4 * np.abs(want).max(), err_msg=name)
+
+
 def test_forward_world_matches_oracle():
     n = 12
     bm, vp, clip, scene, vid = _setup(n)
