@@ -944,9 +944,10 @@ __global__ __launch_bounds__(128) void param_loss_kernel(const float* __restrict
 // double, in a fixed order (thread t: rows t, t + 256, ...; then a tree) -- deterministic, unlike the atomics it replaces --
 // and stored to (assign != 0: every slot, the others zero) or added to losses[]; then the sum of the per-frame
 // d loss / d scale partials (thread t: rows t, t + 256, ...; butterfly; the order of the step kernels' own reduction).
-__global__ __launch_bounds__(256) void loss_rows_reduce_kernel(const float* __restrict__ rows, int row0, int n, unsigned mask, int assign,
-                                                               double* __restrict__ losses, const float* __restrict__ dscale_row,
-                                                               float* __restrict__ dscale_out) {
+// (dscale_out may be null: the launch that also steps `scale` forms that sum itself, in the same order)
+__device__ __forceinline__ void loss_rows_reduce_block(const float* __restrict__ rows, int row0, int n, unsigned mask, int assign,
+                                                       double* __restrict__ losses, const float* __restrict__ dscale_row,
+                                                       float* __restrict__ dscale_out) {
     __shared__ double sd[LROW][256];
     __shared__ float sred[4];
     const int tid = threadIdx.x;
@@ -976,8 +977,15 @@ __global__ __launch_bounds__(256) void loss_rows_reduce_kernel(const float* __re
         if ((mask >> tid) & 1u) losses[tid] = assign ? sd[tid][0] : losses[tid] + sd[tid][0];
         else if (assign) losses[tid] = 0.0;
     }
-    if (tid == 0) *dscale_out = (sred[0] + sred[1]) + (sred[2] + sred[3]);
+    if (tid == 0 && dscale_out) *dscale_out = (sred[0] + sred[1]) + (sred[2] + sred[3]);
 }
+__global__ __launch_bounds__(256) void loss_rows_reduce_kernel(const float* __restrict__ rows, int row0, int n, unsigned mask, int assign,
+                                                               double* __restrict__ losses, const float* __restrict__ dscale_row,
+                                                               float* __restrict__ dscale_out) {
+    loss_rows_reduce_block(rows, row0, n, mask, assign, losses, dscale_row, dscale_out);
+}
+// a logging backward's reduction riding in the step launch that follows it (fdcap_opt_backward log_terms = 2)
+struct LogReduceIn { const float* rows; double* losses; unsigned mask; int assign, n; };
 
 __global__ void adam_kernel(float* __restrict__ p, float* __restrict__ m, float* __restrict__ v,
                             const float* __restrict__ g, size_t n, AdamScalars a, int zero_grad) {
@@ -1003,8 +1011,12 @@ __global__ __launch_bounds__(256) void adam_step_kernel(AdamTensor x, AdamTensor
                                                         const float* __restrict__ dscale_row, int row0, int reduce_n,
                                                         float* __restrict__ dscale, int scale_zero_grad,
                                                         float* __restrict__ xch, int n_local, const float* __restrict__ cam_rows,
-                                                        const float* __restrict__ dzpart, size_t dz_stride) {
+                                                        const float* __restrict__ dzpart, size_t dz_stride, LogReduceIn lg) {
     const int b = blockIdx.x;
+    if (b == nb_x + nb_cam + 1) {                      // (only launched when a logging backward left its sums to this launch)
+        loss_rows_reduce_block(lg.rows, row0, lg.n, lg.mask, lg.assign, lg.losses, dscale_row, nullptr);
+        return;
+    }
     if (b < nb_x + nb_cam) {
         const bool is_x = b < nb_x;
         // (field by field: a reference selected between two by-value kernel arguments is an address into the argument
@@ -1279,6 +1291,10 @@ struct OptState {
     // work-list cache of the in-loop NN launch (fdc_chamfer.h NNCache): ids [groups * 4][64], hdr [groups * 4], anchors [4][nq]
     bool skin_vec = true;          // FDCAP_SKIN_VEC=0 (read by fdcap_opt_create; A/B): the scalar-load skinning backward
     DevBuf<float> loss_rows;       // [R][LROW] per-frame partial sums of the printed loss terms (logging iterations)
+    bool log_pending = false;      // a logging backward (log_terms = 2) left the reduction of loss_rows to the next step launch
+    unsigned log_mask = 0;
+    int log_assign = 0;
+    double* log_dst = nullptr;
     DevBuf<unsigned short> nnc_ids;
     DevBuf<int> nnc_hdr;
     DevBuf<float4> nnc_anchor;
@@ -2125,6 +2141,7 @@ int fdcap_opt_create(fdcap_ctx* c, const fdcap_opt_config* cfg, float* rows_x, f
     o->cfg = *cfg;
     o->cam_steps = 0;
     o->dz_pending = false;
+    o->log_pending = false;
     o->seeded = false;
     o->dctT = o->dctC = o->dctW = 0;
     o->dct_grad = false;
@@ -2230,6 +2247,11 @@ static int opt_backward_impl(fdcap_ctx* c, const LossWeights& lw, int32_t log_te
     const int nl = cf.n_local, nc = c->nc, N = cf.n_total;
     const bool dct_on = lw.dct != 0.f && o->dctW > 0;
     PoseModel pm = c->pose_model();
+    if (o->log_pending) {                               // a deferred reduction nobody stepped after: deliver it before loss_rows is rewritten
+        hipLaunchKernelGGL(loss_rows_reduce_kernel, dim3(1), dim3(256), 0, st, o->loss_rows.p, 2, nl, o->log_mask, o->log_assign, o->log_dst,
+                           o->dscale_row.p, o->dscale.p);
+        o->log_pending = false;
+    }
     double* const losses = log_terms ? o->losses.p : nullptr;       // the partial sums are only formed on logging iterations
     // Logging without a DCT term: every printed term leaves per-frame partials in loss_rows (inside the kernels that run
     // anyway), one small launch sums them.  With the DCT term the separate param_loss_kernel / dct kernel add into losses[].
@@ -2311,8 +2333,11 @@ static int opt_backward_impl(fdcap_ctx* c, const LossWeights& lw, int32_t log_te
     // the exchange packing); on logging iterations also here, so a caller can read dscale_d right after the backward
     if (log_terms) {
         const unsigned mask = (rows_log ? 0x17u : 0u) | (contact_fwd ? 0x8u : 0u);     // 0 rec, 1 z^2, 2 smoothing, 4 world | 3 contact
-        hipLaunchKernelGGL(loss_rows_reduce_kernel, dim3(1), dim3(256), 0, st, o->loss_rows.p, 2, nl, mask, rows_log ? 1 : 0, losses,
-                           o->dscale_row.p, o->dscale.p);
+        if (log_terms == 2 && rows_log) {               // the sums ride in the step launch that follows (one launch less per iteration)
+            o->log_pending = true; o->log_mask = mask; o->log_assign = 1; o->log_dst = losses;
+        } else
+            hipLaunchKernelGGL(loss_rows_reduce_kernel, dim3(1), dim3(256), 0, st, o->loss_rows.p, 2, nl, mask, rows_log ? 1 : 0, losses,
+                               o->dscale_row.p, o->dscale.p);
     }
     return (int)hipGetLastError();
 }
@@ -2514,10 +2539,12 @@ static int opt_step_impl(fdcap_ctx* c, int32_t ii, int32_t P, bool do_rows, bool
     const bool step_scale = do_scale && (o->contact_on || o->dct_grad) && (ii < P || cf.legacy_zero_grad);
     if (step_scale) sc = AdamTensor{o->scale.p, o->mS.p, o->vS.p, o->dscale.p, 1, adam_scalars(cf.lr, ii + 1)};
     const bool tail = step_scale || reduce_scale;                    // the last block: (reduction +) scale (+ message tail)
-    if (nb_x + nb_cam + (tail ? 1 : 0) == 0) return FDCAP_OK;
-    hipLaunchKernelGGL(adam_step_kernel, dim3(nb_x + nb_cam + 1), dim3(256), 0, st, x, cam, sc, nb_x, nb_cam, o->dscale_row.p, 2,
-                       reduce_scale ? nl : 0, o->dscale.p, (step_scale && ii >= P) ? 1 : 0, xch, nl, o->CAM.p,
-                       (do_rows && o->dz_pending) ? (const float*)o->dZpart.p : (const float*)nullptr, (size_t)o->R * VP_Z);
+    if (nb_x + nb_cam + (tail ? 1 : 0) + (o->log_pending ? 1 : 0) == 0) return FDCAP_OK;
+    const LogReduceIn lg = {o->loss_rows.p, o->log_dst, o->log_mask, o->log_assign, nl};
+    hipLaunchKernelGGL(adam_step_kernel, dim3(nb_x + nb_cam + 1 + (o->log_pending ? 1 : 0)), dim3(256), 0, st, x, cam, sc, nb_x, nb_cam,
+                       o->dscale_row.p, 2, reduce_scale ? nl : 0, o->dscale.p, (step_scale && ii >= P) ? 1 : 0, xch, nl, o->CAM.p,
+                       (do_rows && o->dz_pending) ? (const float*)o->dZpart.p : (const float*)nullptr, (size_t)o->R * VP_Z, lg);
+    o->log_pending = false;
     if (do_rows) o->dz_pending = false;
     return (int)hipGetLastError();
 }

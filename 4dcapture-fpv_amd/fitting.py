@@ -250,7 +250,8 @@ class FittingOP:
                 if do_log:                               # this iteration's partial sums go straight into their history row
                     capi.check(lib.fdcap_opt_set_loss_output(h, capi.dptr(hist[len(logged)])), "fdcap_opt_set_loss_output")
                     logged.append(ii)
-                capi.check(lib.fdcap_opt_backward(h, ii, P, 1 if do_log else 0, st), "fdcap_opt_backward")
+                # (2: the logged sums are delivered by the step launch that follows -- one launch less per logged iteration)
+                capi.check(lib.fdcap_opt_backward(h, ii, P, 2 if do_log else 0, st), "fdcap_opt_backward")
                 if multi:
                     # one collective per iteration: boundary rows (after Adam) + the scale-gradient partial travel
                     # together; every rank then sums the partials in rank order and steps `scale` identically

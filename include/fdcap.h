@@ -184,7 +184,10 @@ int fdcap_opt_set_inputs(fdcap_ctx* ctx, const float* data78_d, const float* ini
  * `phase2` = (ii >= 0.8*num_iter) decides the loss total; the requires_grad toggling of
  * :564-568/:577-580 (effective one forward late) is reproduced from ii and first_phase2_iter.
  * log_terms != 0: also evaluate what the reference only prints (:573-575, :587-589) -- the loss partial
- * sums in losses_d, the contact term in phase 2 -- and leave dscale_d valid after the backward. */
+ * sums in losses_d, the contact term in phase 2 -- and leave dscale_d valid after the backward.
+ * log_terms == 2: the same terms, but losses_d is complete only after the fdcap_opt_step / fdcap_opt_step_rows_and_pack call
+ * that follows (the fixed-order reduction of the per-frame partial sums rides in that launch: one launch less per logged
+ * iteration; dscale_d as on a non-logging iteration). */
 int fdcap_opt_backward(fdcap_ctx* ctx, int32_t ii, int32_t first_phase2_iter, int32_t log_terms,
                        void* stream);
 int fdcap_opt_step(fdcap_ctx* ctx, int32_t ii, int32_t first_phase2_iter, void* stream);
