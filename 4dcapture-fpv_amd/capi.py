@@ -70,6 +70,10 @@ SYMBOLS = {
     "fdcap_opt_set_inputs": (c_int32, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "fdcap_opt_backward": (c_int32, [c_void_p, c_int32, c_int32, c_int32, c_void_p]),
     "fdcap_opt_step": (c_int32, [c_void_p, c_int32, c_int32, c_void_p]),
+    "fdcap_opt_state_len": (c_int32, [c_void_p]),
+    "fdcap_opt_export_state": (c_int32, [c_void_p, c_void_p, c_void_p]),
+    "fdcap_opt_import_state": (c_int32, [c_void_p, c_void_p, c_void_p]),
+    "fdcap_opt_check_finite": (c_int32, [c_void_p, c_void_p, c_void_p]),
     "fdcap_opt_set_loss_output": (c_int32, [c_void_p, c_void_p]),
     "fdcap_opt_detect_contact": (c_int32, [c_void_p, c_int32, c_void_p, c_void_p]),
     "fdcap_opt_backward_local2": (c_int32, [c_void_p, c_void_p, c_int32, c_void_p]),

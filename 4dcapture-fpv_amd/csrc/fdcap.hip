@@ -1209,6 +1209,15 @@ __global__ void identity_rows_kernel(float* __restrict__ M, int B, float* __rest
     if (i < B * 12) { const int e = i % 12; M[i] = (e == 0 || e == 5 || e == 10) ? 1.f : 0.f; }
 }
 
+// count of non-finite values in p[0, n) added to *count (optional --check-finite hook; never on by default)
+__global__ void count_nonfinite_kernel(const float* __restrict__ p, size_t n, int* __restrict__ count) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    // (exponent bits all ones -- tested on the bit pattern: the library is built with -fno-honor-nans, which lets isfinite() fold)
+    const bool bad = i < n && (__float_as_uint(p[i]) & 0x7f800000u) == 0x7f800000u;
+    const unsigned long long m = __ballot(bad);
+    if ((threadIdx.x & 63) == 0 && m) atomicAdd(count, __popcll(m));
+}
+
 // dst[r, perm[c], :] = src[r, c, :]   (internal contact-slot order -> caller's order)
 template <class T>
 __global__ void unpermute_kernel(const T* __restrict__ src, const int* __restrict__ perm, int rows, int nc, int w,
@@ -2487,6 +2496,44 @@ int fdcap_opt_reset_adam(fdcap_ctx* c, void* stream) {
     HIP_TRY(hipMemsetAsync(o->mX.p, 0, n, (hipStream_t)stream));
     HIP_TRY(hipMemsetAsync(o->vX.p, 0, n, (hipStream_t)stream));
     return FDCAP_OK;
+}
+
+// ---- checkpoint / resume of the optimiser state, finite check (the reference has neither) -----------
+int32_t fdcap_opt_state_len(fdcap_ctx* c) {
+    if (!c || !c->opt) return 0;
+    return (int32_t)(2 * ((size_t)c->opt->cfg.n_local * (XDIM + 16)) + 2);
+}
+static int opt_state_copy(fdcap_ctx* c, float* state, bool to_state, hipStream_t st) {
+    OptState* o = c->opt;
+    const size_t nl = o->cfg.n_local, nx = nl * XDIM, ncam = nl * 16;
+    struct Part { float* lib; size_t n; } parts[] = {{o->mX.p + 2 * XDIM, nx}, {o->vX.p + 2 * XDIM, nx}, {o->mCAM.p + 2 * 16, ncam},
+                                                     {o->vCAM.p + 2 * 16, ncam}, {o->mS.p, 1}, {o->vS.p, 1}};
+    size_t off = 0;
+    for (const Part& p : parts) {
+        HIP_TRY(hipMemcpyAsync(to_state ? state + off : p.lib, to_state ? p.lib : state + off, p.n * sizeof(float), hipMemcpyDeviceToDevice, st));
+        off += p.n;
+    }
+    return FDCAP_OK;
+}
+int fdcap_opt_export_state(fdcap_ctx* c, float* state_d, void* stream) {
+    if (!c || !c->opt || !state_d) return FDCAP_E_ARG;
+    return opt_state_copy(c, state_d, true, (hipStream_t)stream);
+}
+int fdcap_opt_import_state(fdcap_ctx* c, const float* state_d, void* stream) {
+    if (!c || !c->opt || !state_d) return FDCAP_E_ARG;
+    c->opt->log_pending = false;
+    return opt_state_copy(c, (float*)state_d, false, (hipStream_t)stream);
+}
+int fdcap_opt_check_finite(fdcap_ctx* c, int32_t* count_d, void* stream) {
+    if (!c || !c->opt || !count_d) return FDCAP_E_ARG;
+    OptState* o = c->opt;
+    hipStream_t st = (hipStream_t)stream;
+    const size_t nx = (size_t)o->cfg.n_local * XDIM, ncam = (size_t)o->cfg.n_local * 16;
+    HIP_TRY(hipMemsetAsync(count_d, 0, sizeof(int32_t), st));
+    hipLaunchKernelGGL(count_nonfinite_kernel, dim3((unsigned)((nx + 255) / 256)), dim3(256), 0, st, o->X.p + 2 * XDIM, nx, count_d);
+    hipLaunchKernelGGL(count_nonfinite_kernel, dim3((unsigned)((ncam + 255) / 256)), dim3(256), 0, st, o->CAM.p + 2 * 16, ncam, count_d);
+    hipLaunchKernelGGL(count_nonfinite_kernel, dim3(1), dim3(64), 0, st, o->scale.p, (size_t)1, count_d);
+    return (int)hipGetLastError();
 }
 
 // ---- optimization.py: the per-frame smoother (:185-238, :334-348) ------------------------------

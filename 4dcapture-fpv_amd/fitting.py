@@ -191,13 +191,24 @@ class FittingOP:
         return idx1
 
     # ---- :491-635 -------------------------------------------------------------------------
-    def fitting(self, body_data, mode="global", log_every=0):
+    def fitting(self, body_data, mode="global", log_every=0, checkpoint_every=0, checkpoint_path=None, resume=None,
+                check_finite_every=0):
         """body_data: [N,75] (device tensor or numpy), SMPLify-X layout (:64-76).
         Returns (body_rec [N_local,75] device tensor, scale numpy scalar, camera_ext [N_local,4,4])
-        -- the whole clip when not sharded, exactly the reference's triple (:635)."""
+        -- the whole clip when not sharded, exactly the reference's triple (:635).
+        Not in the reference (mode 'global' only):
+          checkpoint_every=k, checkpoint_path: after every k-th iteration write parameters + Adam moments to
+            `checkpoint_path` (sharded runs: one file per rank, suffix .rank<r>);
+          resume=path: continue such a run from where the file left off -- bit-identical to the uninterrupted run;
+          check_finite_every=k: every k iterations count the non-finite parameters on the device and raise if any
+            (the opt-in counterpart of the reference's set_detect_anomaly(True), :561)."""
         import torch
         if mode not in ("global", "local", "dct"):
             raise ValueError("mode must be 'local', 'global' or 'dct' (global_optimization.py:660)")
+        if (checkpoint_every or resume or check_finite_every) and mode != "global":
+            raise ValueError("checkpoint / resume / check_finite are implemented for mode 'global'")
+        if checkpoint_every and not checkpoint_path:
+            raise ValueError("checkpoint_every needs checkpoint_path")
         self._mode = mode
         lib, h = self.ctx.lib, self.ctx.handle
         dev = self.device
@@ -212,6 +223,7 @@ class FittingOP:
         capi.check(lib.fdcap_params_75_to_78(capi.dptr(body_data), n, capi.dptr(x78), st), "fdcap_params_75_to_78")
         self.init(x78)                                                                      # :495
         P = first_phase2_iter(self.num_iter)
+        ii0 = self._load_checkpoint(resume) if resume else 0
         log = FitLog([], [], [], [], [], [], [])
         # FDCAP_FORCE_EXCHANGE=1: run the sharded iteration tail (pack -> all-gather -> unpack) even on a one-rank
         # group -- lets a single-GPU box exercise the RCCL calls of the multi-GPU path
@@ -225,7 +237,7 @@ class FittingOP:
         n_log = 0
         logged = []
         if log_every and mode != "dct":
-            n_log = sum(1 for ii in range(self.num_iter) if ii % log_every == 0 or ii == self.num_iter - 1)
+            n_log = sum(1 for ii in range(ii0, self.num_iter) if ii % log_every == 0 or ii == self.num_iter - 1)
             hist = torch.zeros(max(n_log, 1), capi.NUM_LOSSES, device=dev, dtype=torch.float64)
         flushed = 0
 
@@ -244,7 +256,7 @@ class FittingOP:
             flushed = upto
 
         try:
-            for ii in range(self.num_iter if mode != "dct" else 0):                             # :560
+            for ii in range(ii0, self.num_iter if mode != "dct" else 0):                        # :560
                 do_log = bool(log_every) and (ii % log_every == 0 or ii == self.num_iter - 1)
                 st = capi.current_stream()
                 if do_log:                               # this iteration's partial sums go straight into their history row
@@ -265,6 +277,10 @@ class FittingOP:
                 # VERBOSE_FLUSH logged iterations (one read-back each) instead of only after the last one
                 if self.verbose and do_log and len(logged) - flushed >= VERBOSE_FLUSH:
                     flush(len(logged))
+                if check_finite_every and (ii + 1) % check_finite_every == 0:
+                    self._check_finite(ii)
+                if checkpoint_every and (ii + 1) % checkpoint_every == 0 and ii + 1 < self.num_iter:
+                    self._save_checkpoint(checkpoint_path, ii + 1)
         finally:
             # never leave the library pointing into `hist` (freed with this frame if the loop raised)
             if logged:
@@ -283,6 +299,56 @@ class FittingOP:
         self.body_rotation_rec = self._rows_x[2:2 + nl]
         self.log = log
         return body_rec, scale.detach().cpu().numpy().squeeze(), self.camera_ext
+
+    # ---- checkpoint / resume / finite check (not in the reference) ---------------------
+    def _ckpt_file(self, path):
+        return path if self.shard.world == 1 else f"{path}.rank{self.shard.rank}"
+
+    def _save_checkpoint(self, path, next_iter):
+        import torch
+        lib, h, nl = self.ctx.lib, self.ctx.handle, self.shard.n_local
+        state = torch.empty(int(lib.fdcap_opt_state_len(h)), device=self.device)
+        capi.check(lib.fdcap_opt_export_state(h, capi.dptr(state), capi.current_stream()), "fdcap_opt_export_state")
+        fn = self._ckpt_file(path)
+        tmp = fn + ".tmp.npz"
+        np.savez(tmp, next_iter=np.int64(next_iter), num_iter=np.int64(self.num_iter), n_total=np.int64(self.num_body),
+                 frame0=np.int64(self.shard.frame0), n_local=np.int64(nl), rows_x=self._rows_x[2:2 + nl].cpu().numpy(),
+                 rows_cam=self._rows_cam[2:2 + nl].cpu().numpy(), scale=self._scale.cpu().numpy(), state=state.cpu().numpy())
+        import os
+        os.replace(tmp, fn)                                      # (a crash mid-write leaves the previous checkpoint intact)
+
+    def _load_checkpoint(self, path):
+        """After init(): parameters and Adam moments <- the file; returns the iteration to continue with."""
+        import torch
+        lib, h, nl = self.ctx.lib, self.ctx.handle, self.shard.n_local
+        with np.load(self._ckpt_file(path)) as ck:
+            if (int(ck["n_total"]), int(ck["frame0"]), int(ck["n_local"]), int(ck["num_iter"])) != \
+                    (self.num_body, self.shard.frame0, nl, int(self.num_iter)):
+                raise capi.FdcapError("checkpoint was written for another clip length / sharding / iteration budget")
+            t = lambda k: torch.from_numpy(np.ascontiguousarray(ck[k], dtype=np.float32)).to(self.device)
+            self._rows_x[2:2 + nl] = t("rows_x")
+            self._rows_cam[2:2 + nl] = t("rows_cam")
+            self._scale.copy_(t("scale"))
+            state = t("state").contiguous()
+            nxt = int(ck["next_iter"])
+        if state.numel() != int(lib.fdcap_opt_state_len(h)):
+            raise capi.FdcapError("checkpoint state has the wrong size")
+        capi.check(lib.fdcap_opt_import_state(h, capi.dptr(state), capi.current_stream()), "fdcap_opt_import_state")
+        torch.cuda.current_stream().synchronize()
+        exchange_halos(self.shard, self._rows_x, self._rows_cam)
+        return nxt
+
+    def _check_finite(self, ii):
+        import torch
+        cnt = torch.zeros(1, device=self.device, dtype=torch.int32)
+        capi.check(self.ctx.lib.fdcap_opt_check_finite(self.ctx.handle, capi.dptr(cnt), capi.current_stream()), "fdcap_opt_check_finite")
+        bad = int(cnt.cpu())
+        if self.shard.world > 1:
+            t = torch.tensor([float(bad)], device=self.device)
+            allreduce_scalars(self.shard, t)
+            bad = int(t.cpu())
+        if bad:
+            raise capi.FdcapError(f"{bad} non-finite optimiser parameters after iteration {ii}")
 
     # ---- :595-630 -------------------------------------------------------------------------
     def _dct_loops(self, lib, h, multi, log_every):

@@ -191,6 +191,19 @@ int fdcap_opt_set_inputs(fdcap_ctx* ctx, const float* data78_d, const float* ini
 int fdcap_opt_backward(fdcap_ctx* ctx, int32_t ii, int32_t first_phase2_iter, int32_t log_terms,
                        void* stream);
 int fdcap_opt_step(fdcap_ctx* ctx, int32_t ii, int32_t first_phase2_iter, void* stream);
+/* Checkpoint / resume (the reference only ever writes its final result, :637-653).  The parameters live in the
+ * caller's registered tensors; these move the rest of the optimiser state -- Adam's moments of the owned rows:
+ * state_d [fdcap_opt_state_len()] floats = [m_x n_local*78 | v_x | m_cam n_local*16 | v_cam | m_scale | v_scale].
+ * The step counters are functions of the iteration index the caller passes to fdcap_opt_step; seeds and kept work lists of
+ * the Chamfer search are pruning state only (results never depend on them) and are not part of a checkpoint.  Mode 'dct''s
+ * c_dct moments are not covered. */
+int32_t fdcap_opt_state_len(fdcap_ctx* ctx);
+int fdcap_opt_export_state(fdcap_ctx* ctx, float* state_d, void* stream);
+int fdcap_opt_import_state(fdcap_ctx* ctx, const float* state_d, void* stream);
+/* count_d [1] int32 <- number of non-finite values among the owned rows of body_rotation_rec / camera_ext and scale
+ * (the reference wraps every iteration in torch.autograd.set_detect_anomaly(True), :561, at ~4x the host cost; this is
+ * the opt-in equivalent: FittingOP.fitting(check_finite_every=k)). */
+int fdcap_opt_check_finite(fdcap_ctx* ctx, int32_t* count_d, void* stream);
 /* Redirect the loss partial sums of the following logging backwards to another [FDCAP_NUM_LOSSES] double buffer (e.g. the
  * next row of a device-side history, so that a caller logging every iteration -- as the reference prints every
  * iteration, :573-575 -- needs no copy and no host sync inside the loop).  Host-side only; nothing is launched. */

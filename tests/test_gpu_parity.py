@@ -728,3 +728,33 @@ def test_world_mesh_export_matches_viewer_math(tmp_path):
         want.append((np.c_[v, np.ones(len(v))] @ body_trans.T)[:, :3])
     np.testing.assert_allclose(got.cpu().numpy(), np.stack(want), atol=5e-5)
     fop.close()
+
+
+def test_checkpoint_resume_is_bit_identical_and_finite_check_fires(tmp_path):
+    """SURVEY §5 items the reference lacks: a fit interrupted after 7 of 12 iterations and resumed by a NEW optimiser from the
+    checkpoint file ends on the uninterrupted run's bits (the phase switch at iteration 10 lies after the resume point, the
+    Chamfer search's seeds / kept lists are rebuilt -- pruning state only); the opt-in finite check raises on NaN input."""
+    n = 40
+    ck = str(tmp_path / "fit.ckpt.npz")
+    fop, bm, vp, clip, scene, vid = _make_fop(n, 300, 3000, 20, 12)
+    body = torch.tensor(clip.body_params).cuda()
+    a = fop.fitting(body, "global", log_every=1, checkpoint_every=7, checkpoint_path=ck, check_finite_every=3)
+    full_log = np.array(fop.log.total)
+    a = (a[0].clone(), float(a[1]), a[2].clone())
+    fop.close()
+    fop2, *_ = _make_fop(n, 300, 3000, 20, 12)
+    b = fop2.fitting(body, "global", log_every=1, resume=ck)
+    assert fop2.log.iters == list(range(7, 12))
+    assert torch.equal(a[0], b[0]) and a[1] == float(b[1]) and torch.equal(a[2], b[2])
+    np.testing.assert_array_equal(np.array(fop2.log.total), full_log[7:])
+    fop2.close()
+    fop3, *_ = _make_fop(n, 300, 3000, 20, 12)
+    bad = clip.body_params.copy()
+    bad[5, 20] = np.nan
+    with pytest.raises(capi.FdcapError, match="non-finite"):
+        fop3.fitting(torch.tensor(bad).cuda(), "global", check_finite_every=2)
+    fop3.close()
+    fop4, *_ = _make_fop(n, 300, 3000, 20, 10)
+    with pytest.raises(capi.FdcapError, match="another clip"):
+        fop4.fitting(body, "global", resume=ck)              # written for a 12-iteration budget
+    fop4.close()
