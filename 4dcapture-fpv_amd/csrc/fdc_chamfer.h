@@ -484,6 +484,7 @@ constexpr int ST4_MAXCELL = FDC_ST4_MAXCELL;   // chunks one wave can list befor
 #endif
 constexpr int ST4_PF = FDC_ST4_PF;     // A fragments in flight per wave
 constexpr int ST4_SUPER = 16;          // chunks per super-cell of the two-level survivor test (consecutive chunks = one k-d subtree)
+constexpr int ST4_QCAP = 8;            // filter survivors a lane can queue for the batched exact evaluation after the main loop
 
 // Work-list cache of the streaming kernel (optional; pruning only -- results never depend on it).
 // The queries move a few millimetres per optimiser iteration, so the set of quarter chunks a group can possibly need
@@ -880,6 +881,10 @@ __global__ __launch_bounds__(64 * WPB, NQ == 1 ? FDC_ST4_OCC : FDC_ST4_OCC2) voi
 #ifdef FDC_NN_STATS
     if (lane == 0 && !idle) atomicAdd(&g_nn_hist[(listed ? 0 : 16) + (nsurv > 0 ? 32 - __clz(nsurv) : 0)], 1ull);
 #endif
+    // queue of filter survivors awaiting their exact evaluation (NQ == 1; see the main loop): per lane up to ST4_QCAP positions
+    // in the LDS the list stages used (sbox: 2 KB per wave, free from here on)
+    unsigned* const cq = (unsigned*)&sbox[wave][0][0];
+    int cq_n = 0;
     if (nsurv > 0) {
         // work items (quarter chunks) are wave-uniform: ids kept in SGPRs (readfirstlane), so fragment addresses are scalar
         // base + lane offset + immediate and the centres come through the scalar cache, one item ahead
@@ -896,9 +901,8 @@ __global__ __launch_bounds__(64 * WPB, NQ == 1 ? FDC_ST4_OCC : FDC_ST4_OCC2) voi
         int cur = -1;                                                      // chunk the queries are centred on
         bf16x8 bfrag[NQ];
         float thr[NQ], X[NQ], X2[NQ], rc = 0.f;
-        bool thr_own[NQ];                                                  // thr[n] was formed from this lane's own best (own_p passes it)
 #pragma unroll
-        for (int n = 0; n < NQ; ++n) { thr[n] = -INFINITY; X[n] = X2[n] = 0.f; thr_own[n] = false; bfrag[n] = __builtin_bit_cast(bf16x8, make_uint4(0u, 0u, 0u, 0u)); }
+        for (int n = 0; n < NQ; ++n) { thr[n] = -INFINITY; X[n] = X2[n] = 0.f; bfrag[n] = __builtin_bit_cast(bf16x8, make_uint4(0u, 0u, 0u, 0u)); }
         for (int s = 0; s < nsurv; ++s) {
             const int s1 = min(s + 1, nsurv - 1);                          // last item: harmless re-fetch of itself
             const int id_next = __builtin_amdgcn_readfirstlane(listed ? (int)slist[wave][s1] : s1);
@@ -925,7 +929,6 @@ __global__ __launch_bounds__(64 * WPB, NQ == 1 ? FDC_ST4_OCC : FDC_ST4_OCC2) voi
                     // this half's own bound (the other half's may be tighter after an exact hit; it is folded in at the next
                     // hit -- a looser threshold only lets more pairs through, and saves a cross-half exchange per cell)
                     thr[n] = (qidx[n] < nq) ? own_d[n] - X2[n] + (MF_K1 * X[n] * rc + MF_K2 * (X2[n] + rc * rc)) : -INFINITY;
-                    thr_own[n] = true;
                 }
             }
             const int base = ch * MF_CH + qd * (QT * 32);
@@ -952,25 +955,63 @@ __global__ __launch_bounds__(64 * WPB, NQ == 1 ? FDC_ST4_OCC : FDC_ST4_OCC2) voi
                     const float t4 = fminf(fminf(acc[12], acc[13]), acc[14]);
                     const float m = fminf(fminf(fminf(t0, t1), t2), fminf(fminf(t3, t4), acc[15]));
                     FDC_STAT(0, lane == 0);
+#if defined(FDC_ST4_ABLATE) && FDC_ST4_ABLATE == -1
+                    asm volatile("" :: "v"(m), "v"(thr[n]));               // (keeps the MFMA + min tree alive)
+                    if (false) {                                           // timing ablation only (wrong results): no slow path
+#elif defined(FDC_ST4_ABLATE) && FDC_ST4_ABLATE == -2
+                    if (__any(m < thr[n])) {                               // timing ablation only: the branch and its wave vote, empty body
+                        asm volatile("" :: "v"(m));
+                        continue;
+#else
                     if (__any(m < thr[n])) {
+#endif
                         FDC_STAT(1, lane == 0);
-                        // In the steady state nearly every entry is a query meeting its own seed (it passes the filter by
-                        // construction; 11 of a wave's 80 tiles).  Row masks as wave-wide ballots (SALU): if every lane
-                        // that passed holds its current best in this tile's rows of its half, passed with exactly one row
-                        // and its threshold is its own bound, that row IS the best and there is nothing to re-evaluate.
-                        unsigned long long seen = 0, twice = 0, mrow[16];
+                        // This lane's rows that passed, as a bit mask: sign(acc[r] - thr) shifted in row by row (v_sub_f32 +
+                        // v_alignbit_b32 per row; a difference of two distinct finite floats is never rounded to zero, an
+                        // invalid lane's thr is -inf).  r3: 13.5 entries per wave, and FDC_NN_STATS shows most of them carry
+                        // a real candidate next to the seeds (about one other point per query lies within the filter's eps
+                        // of the bound), so the r2 form -- 16 wave ballots + ~50 SALU to recognise seed-only entries, then
+                        // 16 64-bit shifts to recover the per-lane bits -- paid both halves nearly every time: half of the
+                        // kernel's VALU cycles (ablation: 79 -> 44 us steady state without the body).
+                        unsigned mask = 0;
 #pragma unroll
-                        for (int r = 0; r < 16; ++r) {
-                            mrow[r] = __ballot(acc[r] < thr[n]);
-                            twice |= seen & mrow[r];
-                            seen |= mrow[r];
-                        }
+                        for (int r = 15; r >= 0; --r)
+                            mask = __builtin_amdgcn_alignbit(mask, __float_as_uint(acc[r] - thr[n]), 31);
+                        // the lane's current best passes by construction (it sits in this tile's rows of this half when
+                        // `mine`) and is never re-evaluated
                         const int spos = __float_as_int(own_p[n].w);
-                        const bool mine = thr_own[n] && (spos >> 5) == (base >> 5) + tile && ((spos >> 2) & 1) == half;
-                        if (((seen & ~__ballot(mine)) | twice) == 0) continue;
-                        unsigned mask = 0;                                 // rare from here on: this lane's bits of the ballots
-#pragma unroll
-                        for (int r = 0; r < 16; ++r) mask |= (unsigned)((mrow[r] >> lane) & 1ull) << r;
+                        const bool mine = (spos >> 5) == (base >> 5) + tile && ((spos >> 2) & 1) == half;
+                        if (mine) mask &= ~(1u << ((spos & 3) + 4 * ((spos >> 3) & 3)));
+                        if (!__any(mask != 0)) continue;
+                        // Real candidates (FDC_NN_STATS over a fit: 84 % of the waves meet at least one per launch, ~13 entries
+                        // per wave -- with bodies hovering above a densely sampled floor about one other point per query lies
+                        // within the filter's eps of the bound).  Evaluated on the spot each one is a dependent L2 round trip
+                        // in the middle of the main loop (nothing else of the wave proceeds meanwhile: ~10 of them in a row are
+                        // most of a lone wave's 11-13 us main loop).  So they are QUEUED -- positions per lane, in
+                        // the LDS the list stages no longer need -- and evaluated together after the loop, all loads in flight at
+                        // once.  The bound is not tightened in between: the filter then lets through a superset of what it would
+                        // have, every member of which is evaluated exactly and merged in (d, index) order -- same result, bit for bit.
+                        if constexpr (NQ == 1) {
+                            while (mask) {
+                                const int r = __ffs(mask) - 1;
+                                mask &= mask - 1;
+                                const int pos = base + tile * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+                                if (pos < T.n && pos != __float_as_int(own_p[n].w)) {
+                                    FDC_STAT(2, 1);
+                                    if (cq_n < ST4_QCAP) { cq[cq_n * 64 + lane] = (unsigned)pos; ++cq_n; }
+                                    else {                                 // queue full (rare): evaluated on the spot
+                                        const float4 p = T.pts[pos];
+                                        const int gi = __float_as_int(p.w);
+                                        const float d = nn_exact_d2(qx[n], qy[n], qz[n], p.x, p.y, p.z);
+                                        if (nn_better(d, gi, own_d[n], own_i[n])) {
+                                            own_d[n] = d; own_i[n] = gi;
+                                            own_p[n] = make_float4(p.x, p.y, p.z, __int_as_float(pos));
+                                        }
+                                    }
+                                }
+                            }
+                            continue;
+                        }
                         while (mask) {                                     // rows of this lane that passed the filter
                             const int r = __ffs(mask) - 1;
                             mask &= mask - 1;
@@ -988,13 +1029,34 @@ __global__ __launch_bounds__(64 * WPB, NQ == 1 ? FDC_ST4_OCC : FDC_ST4_OCC2) voi
                         }
                         const float sbest = fminf(own_d[n], __shfl_xor(own_d[n], 32, 64));
                         if (qidx[n] < nq) thr[n] = sbest - X2[n] + (MF_K1 * X[n] * rc + MF_K2 * (X2[n] + rc * rc));
-                        thr_own[n] = sbest == own_d[n];
                     }
                 }
             }
             ch = ch_next;
             qd = id_next & 3;
             fr = fr_next;
+        }
+    }
+    if constexpr (NQ == 1) {
+        // the queued candidates: up to four loads in flight per lane and round (a wave's LDS traffic is in order: no barrier)
+        for (int k0 = 0; __any(k0 < cq_n); k0 += 4) {
+            float4 p[4];
+            int ps[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                ps[k] = (k0 + k < cq_n) ? (int)cq[(k0 + k) * 64 + lane] : 0;
+                p[k] = T.pts[ps[k]];
+            }
+#pragma unroll
+            for (int k = 0; k < 4; ++k)
+                if (k0 + k < cq_n) {
+                    const int gi = __float_as_int(p[k].w);
+                    const float d = nn_exact_d2(qx[0], qy[0], qz[0], p[k].x, p[k].y, p[k].z);
+                    if (nn_better(d, gi, own_d[0], own_i[0])) {
+                        own_d[0] = d; own_i[0] = gi;
+                        own_p[0] = make_float4(p[k].x, p[k].y, p[k].z, __int_as_float(ps[k]));
+                    }
+                }
         }
     }
     TL_STAMP(3);
