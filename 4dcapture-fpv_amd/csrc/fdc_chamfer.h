@@ -903,6 +903,16 @@ __global__ __launch_bounds__(64 * WPB, NQ == 1 ? FDC_ST4_OCC : FDC_ST4_OCC2) voi
         float thr[NQ], X[NQ], X2[NQ], rc = 0.f;
 #pragma unroll
         for (int n = 0; n < NQ; ++n) { thr[n] = -INFINITY; X[n] = X2[n] = 0.f; bfrag[n] = __builtin_bit_cast(bf16x8, make_uint4(0u, 0u, 0u, 0u)); }
+        // NQ == 1: the tile of this lane's current best (-1: none in this half) and the mask that clears its row's bit --
+        // own_p only changes in the queue-full path below, which refreshes them
+        int seed_tile = -1;
+        unsigned seed_keep = ~0u;
+        auto seed_refresh = [&]() {
+            const int spos = __float_as_int(own_p[0].w);
+            seed_tile = (spos >= 0 && ((spos >> 2) & 1) == half) ? (spos >> 5) : -1;
+            seed_keep = ~(1u << ((spos & 3) + 4 * ((spos >> 3) & 3)));
+        };
+        seed_refresh();
         for (int s = 0; s < nsurv; ++s) {
             const int s1 = min(s + 1, nsurv - 1);                          // last item: harmless re-fetch of itself
             const int id_next = __builtin_amdgcn_readfirstlane(listed ? (int)slist[wave][s1] : s1);
@@ -974,14 +984,23 @@ __global__ __launch_bounds__(64 * WPB, NQ == 1 ? FDC_ST4_OCC : FDC_ST4_OCC2) voi
                         // 16 64-bit shifts to recover the per-lane bits -- paid both halves nearly every time: half of the
                         // kernel's VALU cycles (ablation: 79 -> 44 us steady state without the body).
                         unsigned mask = 0;
+                        typedef float f32x2_t __attribute__((ext_vector_type(2)));
+                        const f32x2_t thr2 = {thr[n], thr[n]};
 #pragma unroll
-                        for (int r = 15; r >= 0; --r)
-                            mask = __builtin_amdgcn_alignbit(mask, __float_as_uint(acc[r] - thr[n]), 31);
+                        for (int r = 14; r >= 0; r -= 2) {                 // (two rows per v_pk_add_f32)
+                            const f32x2_t d2 = f32x2_t{acc[r], acc[r + 1]} - thr2;
+                            mask = __builtin_amdgcn_alignbit(mask, __float_as_uint(d2.y), 31);
+                            mask = __builtin_amdgcn_alignbit(mask, __float_as_uint(d2.x), 31);
+                        }
                         // the lane's current best passes by construction (it sits in this tile's rows of this half when
-                        // `mine`) and is never re-evaluated
-                        const int spos = __float_as_int(own_p[n].w);
-                        const bool mine = (spos >> 5) == (base >> 5) + tile && ((spos >> 2) & 1) == half;
-                        if (mine) mask &= ~(1u << ((spos & 3) + 4 * ((spos >> 3) & 3)));
+                        // its tile comes up) and is never re-evaluated: its row's bit is cleared
+                        if constexpr (NQ == 1) {
+                            mask &= (seed_tile == (base >> 5) + tile) ? seed_keep : ~0u;
+                        } else {
+                            const int spos = __float_as_int(own_p[n].w);
+                            const bool mine = (spos >> 5) == (base >> 5) + tile && ((spos >> 2) & 1) == half;
+                            if (mine) mask &= ~(1u << ((spos & 3) + 4 * ((spos >> 3) & 3)));
+                        }
                         if (!__any(mask != 0)) continue;
                         // Real candidates (FDC_NN_STATS over a fit: 84 % of the waves meet at least one per launch, ~13 entries
                         // per wave -- with bodies hovering above a densely sampled floor about one other point per query lies
@@ -1006,6 +1025,7 @@ __global__ __launch_bounds__(64 * WPB, NQ == 1 ? FDC_ST4_OCC : FDC_ST4_OCC2) voi
                                         if (nn_better(d, gi, own_d[n], own_i[n])) {
                                             own_d[n] = d; own_i[n] = gi;
                                             own_p[n] = make_float4(p.x, p.y, p.z, __int_as_float(pos));
+                                            seed_refresh();
                                         }
                                     }
                                 }

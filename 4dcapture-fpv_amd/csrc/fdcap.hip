@@ -1307,7 +1307,7 @@ struct OptState {
     DevBuf<unsigned short> nnc_ids;
     DevBuf<int> nnc_hdr;
     DevBuf<float4> nnc_anchor;
-    float nnc_slack = 0.04f;  // metres; FDCAP_NN_CACHE_SLACK overrides, 0 disables the cache
+    float nnc_slack = 0.03f;  // metres; FDCAP_NN_CACHE_SLACK overrides, 0 disables the cache
     // fdcap_opt_nn_timing: HIP events around every in-loop NN launch of a fit (the bench's roofline figure)
     bool nn_timing = false;
     std::vector<hipEvent_t> nn_ev;
