@@ -234,9 +234,9 @@ def cpu_baseline(bm, vp, clip, scene, vid, args):
 
     F = args.cpu_sample_frames
     if F <= 0:
-        p1, p2, _ = run(2, 1)
-        per_frame = (p1 + p2) / 2.0 / 2.0                      # measured seconds per frame-iteration
-        F = int(max(2, min(args.frames, 20.0 / (8 * max(per_frame, 1e-6)))))
+        p1, p2, _ = run(4, 1)
+        per_frame = (p1 + p2) / 2.0 / 4.0                      # measured seconds per frame-iteration
+        F = int(max(2, min(args.frames, 12, 15.0 / (8 * max(per_frame, 1e-6)))))   # (2 phases x 4 iterations; bounded: the host is shared)
     t1, t2, t_nn = run(F, 3)
     n1, n2 = P, args.iters - P
     fps = F / (n1 * t1 + n2 * t2)
