@@ -749,7 +749,7 @@ __global__ __launch_bounds__(64 * WPB, NQ == 1 ? FDC_ST4_OCC : FDC_ST4_OCC2) voi
                 // LDS, compacted in chunk order, and every round tests TWO of them -- the two 32-lane halves of the wave hold
                 // the same queries, so each half takes its own chunk (broadcast reads; the wave's own LDS traffic is in order).
                 const unsigned long long m = __ballot(near);
-                const int nnear = __popcll(m);
+                const int nnear = __builtin_amdgcn_readfirstlane(__popcll(m));
                 if (near) {
                     const int k = __builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0));
                     sbox[wave][k][0] = make_float4(lo.x, lo.y, lo.z, __int_as_float(ci));
@@ -784,6 +784,7 @@ __global__ __launch_bounds__(64 * WPB, NQ == 1 ? FDC_ST4_OCC : FDC_ST4_OCC2) voi
         // lane l fetches box part l & 7 of chunk l >> 3 into LDS (one latency per pass), then two rounds per chunk, each
         // half-wave on its own quarter.
         float4* const qbox = &sbox[wave][0][0];
+        ncell = __builtin_amdgcn_readfirstlane(ncell);           // (wave-uniform; see the filter below)
         for (int cb = 0; cb < ncell && listed; cb += 8) {
             const int cs_l = cb + (lane >> 3);
             if (cs_l < ncell) {
@@ -836,7 +837,7 @@ __global__ __launch_bounds__(64 * WPB, NQ == 1 ? FDC_ST4_OCC : FDC_ST4_OCC2) voi
     // trail reads, and a wave's LDS traffic is in order).
     if (cull && caching && listed && (inflate || n_kept >= 0)) {
         float4* const qbox = &sbox[wave][0][0];
-        const int n_raw = nsurv;
+        const int n_raw = __builtin_amdgcn_readfirstlane(nsurv);   // (wave-uniform: keeps the loop's counters and tests on the scalar unit)
         int nout = 0;
         FDC_STAT(6, lane == 0 ? n_raw : 0);
         for (int k0 = 0; k0 < n_raw; k0 += 32) {
