@@ -459,8 +459,8 @@ __global__ __launch_bounds__(256) void nn_mfma_kernel(const float* __restrict__ 
 // eps per cell: |y'| <= cell radius rc, so eps = K1 * X * rc + K2 * (X^2 + rc^2), X = |x - centre|.
 // More waves per group = shorter serial chains and a fuller machine at shard sizes, but the group's set-up is
 // repeated by each of them: the host picks WPG by launch size.
-// blockIdx -> query group is XCD-aware: each XCD serves a contiguous range of groups (frames that follow
-// each other touch the same scene chunks, so an XCD's L2 holds 1/8 of the clip's neighbourhoods).
+// blockIdx -> query group: r1-r2 gave each XCD a contiguous range of groups (an XCD's L2 then holds 1/8 of the clip's
+// neighbourhoods); r3 interleaves (see below) -- load balance between the XCDs is worth more than that locality.
 #ifndef FDC_ST4_MAXLIST
 #define FDC_ST4_MAXLIST 768
 #endif
@@ -532,10 +532,13 @@ __global__ __launch_bounds__(64 * WPB, NQ == 1 ? FDC_ST4_OCC : FDC_ST4_OCC2) voi
 #else
 #define TL_STAMP(k)
 #endif
-#ifdef FDC_ST4_RR
-    const int wg = blockIdx.x; (void)per_xcd;                    // timing experiment: plain round-robin over the XCDs
+#ifdef FDC_ST4_XCDMAJOR
+    const int wg = (blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);       // r1-r2: each XCD serves a contiguous range of frames
 #else
-    const int wg = (blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);       // XCD-major: each XCD serves a contiguous range of frames
+    // r3: plain round-robin over the XCDs (workgroup b runs on XCD b % 8).  Contiguous frame ranges per XCD leave the XCDs with
+    // 13 % different amounts of work (frames near the floor cost more) and the launch ends with its slowest XCD; interleaved,
+    // every XCD sees every part of the clip -- consecutive frames share their scene cells anyway.  72.57 -> 72.31 ms per step.
+    const int wg = blockIdx.x; (void)per_xcd;
 #endif
     const int group = wg * GPW + gslot;
     const bool idle = wg >= nwg || group >= ngroups;            // idle waves still meet the barrier below
