@@ -894,12 +894,18 @@ __global__ __launch_bounds__(64 * WPB, NQ == 1 ? FDC_ST4_OCC : FDC_ST4_OCC2) voi
         // base + lane offset + immediate and the centres come through the scalar cache, one item ahead
         int id = __builtin_amdgcn_readfirstlane(listed ? (int)slist[wave][0] : 0);
         int ch = __builtin_amdgcn_readfirstlane(WPG * (id >> 2) + sub), qd = id & 3;
-        const char* fr = (const char*)(T.frags + ((size_t)ch * NT + qd * QT) * 64);   // [tile][half][col] == [tile][lane]
-        const unsigned lofs = (unsigned)lane * 16u;                        // scalar base + 32-bit lane offset + immediate
+        // The fragment stream goes through BUFFER loads (r3): one resource descriptor for the whole fragment array in SGPRs, the
+        // item's byte offset as the scalar offset, lane * 16 as the vector offset, the tile within the item as the immediate --
+        // `buffer_load_dwordx4 v, v_lane, s[rsrc], s_item offen offset:imm`.  The r2 form (global loads from a scalar base
+        // forced by an empty asm) cost a v_mov per tile and 64-bit scalar address arithmetic per item; left to itself the
+        // compiler turned every tile's address into 64-bit VALU adds.
+        const __amdgpu_buffer_rsrc_t frs = __builtin_amdgcn_make_buffer_rsrc((void*)T.frags, 0, (int)min((size_t)nchunk * NT * 1024, (size_t)0x7fffffff), 0x00020000);
+        unsigned fo = (unsigned)(ch * NT + qd * QT) * 1024u;               // [tile][half][col] == [tile][lane]: 1 KiB per tile
+        const unsigned lofs = (unsigned)lane * 16u;
         typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
         u32x4 f[ST4_PF];
 #pragma unroll
-        for (int j = 0; j < ST4_PF; ++j) f[j] = *(const u32x4*)(fr + j * 1024 + lofs);
+        for (int j = 0; j < ST4_PF; ++j) f[j] = __builtin_amdgcn_raw_buffer_load_b128(frs, lofs, fo + j * 1024, 0);
         float4 cc_next = T.centers[ch];
         nsurv = __builtin_amdgcn_readfirstlane(nsurv);
         int cur = -1;                                                      // chunk the queries are centred on
@@ -921,7 +927,7 @@ __global__ __launch_bounds__(64 * WPB, NQ == 1 ? FDC_ST4_OCC : FDC_ST4_OCC2) voi
             const int s1 = min(s + 1, nsurv - 1);                          // last item: harmless re-fetch of itself
             const int id_next = __builtin_amdgcn_readfirstlane(listed ? (int)slist[wave][s1] : s1);
             const int ch_next = __builtin_amdgcn_readfirstlane(WPG * (id_next >> 2) + sub);
-            const char* fr_next = (const char*)(T.frags + ((size_t)ch_next * NT + (id_next & 3) * QT) * 64);
+            const unsigned fo_next = (unsigned)(ch_next * NT + (id_next & 3) * QT) * 1024u;
             const float4 cc = cc_next;
             cc_next = T.centers[ch_next];
             FDC_STAT(3, lane == 0);
@@ -950,14 +956,8 @@ __global__ __launch_bounds__(64 * WPB, NQ == 1 ? FDC_ST4_OCC : FDC_ST4_OCC2) voi
             for (int tile = 0; tile < QT; ++tile) {
                 const bf16x8 afrag = __builtin_bit_cast(bf16x8, f[tile % ST4_PF]);
                 const int tn = tile + ST4_PF;                               // a quarter's four tiles are within reach of the immediates
-                unsigned long long fb = (unsigned long long)(tn < QT ? fr : fr_next);
-                unsigned lo = lofs;
-#if defined(__HIP_DEVICE_COMPILE__)
-                asm volatile("" : "+s"(fb), "+v"(lo));   // opaque: base + zext(lane offset) stay in this block, so the load takes
-                                                         // the SGPR base directly (otherwise: three 64-bit VALU adds per tile)
-#endif
-                typedef const __attribute__((address_space(1))) u32x4* gptr_t;
-                f[tile % ST4_PF] = *(gptr_t)(fb + lo + (unsigned long long)((tn < QT ? tn : tn - QT) * 1024));
+                // (the tile's offset rides in the SCALAR offset: added to the lane offset it becomes a v_or per tile)
+                f[tile % ST4_PF] = __builtin_amdgcn_raw_buffer_load_b128(frs, lofs, (tn < QT ? fo : fo_next) + (unsigned)(tn < QT ? tn : tn - QT) * 1024u, 0);
                 f32x16_t acc_q[NQ];
 #pragma unroll
                 for (int n = 0; n < NQ; ++n) acc_q[n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afrag, bfrag[n], zero, 0, 0, 0);
@@ -1058,7 +1058,7 @@ __global__ __launch_bounds__(64 * WPB, NQ == 1 ? FDC_ST4_OCC : FDC_ST4_OCC2) voi
             }
             ch = ch_next;
             qd = id_next & 3;
-            fr = fr_next;
+            fo = fo_next;
         }
     }
     if constexpr (NQ == 1) {
