@@ -710,6 +710,27 @@ __global__ __launch_bounds__(64 * WPB, NQ == 1 ? FDC_ST4_OCC : FDC_ST4_OCC2) voi
     // (4 j + wave, j < 4) -- 16 super-cells x 4 chunks per round of lanes -- against the reach and then per query.
     // (Testing all chunk boxes directly costs every workgroup the whole box array through L1/L2: 31 KB x 16000
     // workgroups per launch at 500k points, more than everything else the kernel reads.)
+    // The per-query box tests of the list stages are lane-parallel (r3): the group's queries {x, y, z, squared bound} sit in
+    // LDS, a PAIR of lanes holds one box in registers and each lane of the pair walks half of the queries.
+    float4* const sq = &s_p[wave][0];                            // [32 NQ] queries (s_p is only needed for the final merge)
+    float4* const sbx = &sbox[wave][0][0];                       // [64][2] compacted boxes of a chunk-stage batch
+    auto put_queries = [&](const float* bound) {
+        if (half == 0) {
+#pragma unroll
+            for (int n = 0; n < NQ; ++n) sq[n * 32 + col] = make_float4(qx[n], qy[n], qz[n], bound[n]);
+        }
+        __builtin_amdgcn_wave_barrier();
+    };
+    auto pair_hits = [&](const float4 blo, const float4 bhi) -> bool {
+        const float4* const qs = sq + (lane & 1) * (16 * NQ);
+        bool hit = false;
+#pragma unroll 8
+        for (int i = 0; i < 16 * NQ; ++i) {
+            const float4 v = qs[i];
+            hit |= box_d2(blo, bhi, v.x, v.y, v.z) <= v.w;
+        }
+        return hit;
+    };
     int nsurv = 4 * myn;                                         // work items are quarter chunks: 4 k + quarter
     bool listed = false;
 #if defined(FDC_ST4_ABLATE) && FDC_ST4_ABLATE >= 2
@@ -726,6 +747,7 @@ __global__ __launch_bounds__(64 * WPB, NQ == 1 ? FDC_ST4_OCC : FDC_ST4_OCC2) voi
         nsurv = 0;
         listed = true;
         int ncell = 0;
+        put_queries(sbT);
         const int nsuper = (nchunk + ST4_SUPER - 1) / ST4_SUPER;
         for (int s0 = 0; s0 < nsuper && listed; s0 += 64) {
             const int si = s0 + lane;
@@ -748,75 +770,51 @@ __global__ __launch_bounds__(64 * WPB, NQ == 1 ? FDC_ST4_OCC : FDC_ST4_OCC2) voi
                     hi = T.bounds[2 * ci + 1];
                     near = overlaps(lo, hi);
                 }
-                // Per-query test of the near chunks (27 per wave at 512 k queries, 5 survive): their boxes are staged in
-                // LDS, compacted in chunk order, and every round tests TWO of them -- the two 32-lane halves of the wave hold
-                // the same queries, so each half takes its own chunk (broadcast reads; the wave's own LDS traffic is in order).
+                // Per-query test of the near chunks (17 per wave at 512 k queries, 5 survive), lane-parallel: their boxes are
+                // compacted in chunk order through LDS, a PAIR of lanes takes one chunk and each of the two walks half of the
+                // group's queries (pair_hits) -- up to 32 chunks per pass, no scalar hand-over inside.
                 const unsigned long long m = __ballot(near);
                 const int nnear = __builtin_amdgcn_readfirstlane(__popcll(m));
+                const int k = __builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0));
                 if (near) {
-                    const int k = __builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0));
-                    sbox[wave][k][0] = make_float4(lo.x, lo.y, lo.z, __int_as_float(ci));
-                    sbox[wave][k][1] = hi;
+                    sbx[2 * k] = make_float4(lo.x, lo.y, lo.z, __int_as_float(ci));
+                    sbx[2 * k + 1] = hi;
                 }
                 __builtin_amdgcn_wave_barrier();
-                for (int k0 = 0; k0 < nnear; k0 += 2) {          // wave-uniform
-                    const int k = min(k0 + half, nnear - 1);     // odd count: both halves test the last chunk
-                    const float4 blo = sbox[wave][k][0], bhi = sbox[wave][k][1];
-                    bool hit = false;
-#pragma unroll
-                    for (int n = 0; n < NQ; ++n) hit |= box_d2(blo, bhi, qx[n], qy[n], qz[n]) <= sbT[n];
-                    const unsigned long long hm = __ballot(hit);
-                    const int c0 = __builtin_amdgcn_readlane(__float_as_int(blo.w), 0), c1 = __builtin_amdgcn_readlane(__float_as_int(blo.w), 32);
-                    if ((unsigned)hm) {
-                        if (ncell >= ST4_MAXCELL) { listed = false; break; }
-                        if (lane == 0) clist[wave][ncell] = (unsigned short)(c0 / WPG);    // k of chunk WPG k + sub
-                        ++ncell;
-                    }
-                    if (k0 + 1 < nnear && (unsigned)(hm >> 32)) {
-                        if (ncell >= ST4_MAXCELL) { listed = false; break; }
-                        if (lane == 0) clist[wave][ncell] = (unsigned short)(c1 / WPG);
-                        ++ncell;
-                    }
+                for (int p0 = 0; p0 < nnear && listed; p0 += 32) {
+                    const int j = min(p0 + (lane >> 1), nnear - 1);
+                    const float4 blo = sbx[2 * j], bhi = sbx[2 * j + 1];
+                    const bool hit = (p0 + (lane >> 1) < nnear) && pair_hits(blo, bhi);
+                    unsigned long long hm = __ballot(hit);
+                    hm = (hm | (hm >> 1)) & 0x5555555555555555ull;           // bit 2 j: chunk j of the pass is needed by some query
+                    const int cnt = __popcll(hm);
+                    if (ncell + cnt > ST4_MAXCELL) { listed = false; break; }
+                    if ((lane & 1) == 0 && ((hm >> lane) & 1ull))
+                        clist[wave][ncell + __popcll(hm & ((1ull << lane) - 1ull))] = (unsigned short)(__float_as_int(blo.w) / WPG);   // k of chunk WPG k + sub
+                    ncell += cnt;
                 }
                 __builtin_amdgcn_wave_barrier();
             }
         }
         // Second stage: the QUARTERS (128 points = four MFMA tiles = one k-d node) of the surviving chunks against every
         // query.  Only ~11 of the 80 tiles a wave used to scan hold a point within any query's bound; a chunk is a 30 cm
-        // patch, the part of it some query's ball reaches usually one or two of its quarters.  Eight chunks per pass:
-        // lane l fetches box part l & 7 of chunk l >> 3 into LDS (one latency per pass), then two rounds per chunk, each
-        // half-wave on its own quarter.
-        float4* const qbox = &sbox[wave][0][0];
-        ncell = __builtin_amdgcn_readfirstlane(ncell);           // (wave-uniform; see the filter below)
-        for (int cb = 0; cb < ncell && listed; cb += 8) {
-            const int cs_l = cb + (lane >> 3);
-            if (cs_l < ncell) {
-                const int chq = WPG * (int)clist[wave][cs_l] + sub;
-                qbox[lane] = T.qbounds[(size_t)chq * 8 + (lane & 7)];
-            }
-            __builtin_amdgcn_wave_barrier();
-            const int ncs = min(8, ncell - cb);
-            for (int cs = 0; cs < ncs && listed; ++cs) {         // wave-uniform
-                const int k4 = 4 * __builtin_amdgcn_readfirstlane((int)clist[wave][cb + cs]);
-#pragma unroll
-                for (int rnd = 0; rnd < 2; ++rnd) {
-                    const float4 blo = qbox[cs * 8 + 2 * (2 * rnd + half)], bhi = qbox[cs * 8 + 2 * (2 * rnd + half) + 1];
-                    bool hit = false;
-#pragma unroll
-                    for (int n = 0; n < NQ; ++n) hit |= box_d2(blo, bhi, qx[n], qy[n], qz[n]) <= sbT[n];
-                    const unsigned long long hm = __ballot(hit);
-                    if ((unsigned)hm) {
-                        if (nsurv >= ST4_MAXLIST) { listed = false; break; }
-                        if (lane == 0) slist[wave][nsurv] = (unsigned short)(k4 + 2 * rnd);
-                        ++nsurv;
-                    }
-                    if ((unsigned)(hm >> 32)) {
-                        if (nsurv >= ST4_MAXLIST) { listed = false; break; }
-                        if (lane == 0) slist[wave][nsurv] = (unsigned short)(k4 + 2 * rnd + 1);
-                        ++nsurv;
-                    }
-                }
-            }
+        // patch, the part of it some query's ball reaches usually one or two of its quarters.  A pair of lanes per quarter
+        // (32 quarters = 8 chunks per pass), boxes straight from global memory into the pair's registers.
+        ncell = __builtin_amdgcn_readfirstlane(ncell);
+        for (int p0 = 0; p0 < 4 * ncell && listed; p0 += 32) {
+            const int jq = p0 + (lane >> 1);                      // cell jq >> 2 of the list, its quarter jq & 3
+            const bool valid = jq < 4 * ncell;
+            const int k4 = 4 * (int)clist[wave][valid ? (jq >> 2) : 0];
+            const size_t qb = ((size_t)(WPG * (k4 >> 2) + sub) * 4 + (jq & 3)) * 2;
+            const float4 blo = T.qbounds[qb], bhi = T.qbounds[qb + 1];
+            const bool hit = valid && pair_hits(blo, bhi);
+            unsigned long long hm = __ballot(hit);
+            hm = (hm | (hm >> 1)) & 0x5555555555555555ull;
+            const int cnt = __popcll(hm);
+            if (nsurv + cnt > ST4_MAXLIST) { listed = false; break; }
+            if ((lane & 1) == 0 && ((hm >> lane) & 1ull))
+                slist[wave][nsurv + __popcll(hm & ((1ull << lane) - 1ull))] = (unsigned short)(k4 + (jq & 3));
+            nsurv += cnt;
             __builtin_amdgcn_wave_barrier();
         }
         FDC_STAT(5, lane == 0 && !idle);
@@ -836,35 +834,28 @@ __global__ __launch_bounds__(64 * WPB, NQ == 1 ? FDC_ST4_OCC : FDC_ST4_OCC2) voi
     }
     TL_STAMP(1);
     // With a cache the list (kept or just built) was made for inflated radii: filter it by the per-query box test with the
-    // CURRENT bounds, in place (32 quarters per pass: lane l fetches box half l & 1 of quarter l >> 1, id in lo.w; writes
-    // trail reads, and a wave's LDS traffic is in order).
+    // CURRENT bounds, in place.  r3: lane-parallel -- a pair of lanes per listed quarter (32 quarters per pass), each lane walks
+    // half of the group's queries; ONE ballot and one ordered compaction per pass.  The r2 form tested two quarters per round
+    // with every lane on its own query: 11 rounds of LDS read -> 13 VALU -> compare -> scalar branch -> lane-0 store, ~1150
+    // cycles per round even for a wave alone on its SIMD (timeline stamps: 5.2 of a lone wave's 19.7 us) -- a chain of
+    // VALU / SALU / LDS hand-overs, not work.
     if (cull && caching && listed && (inflate || n_kept >= 0)) {
-        float4* const qbox = &sbox[wave][0][0];
-        const int n_raw = __builtin_amdgcn_readfirstlane(nsurv);   // (wave-uniform: keeps the loop's counters and tests on the scalar unit)
+        const int n_raw = __builtin_amdgcn_readfirstlane(nsurv);
         int nout = 0;
         FDC_STAT(6, lane == 0 ? n_raw : 0);
+        put_queries(sb);
         for (int k0 = 0; k0 < n_raw; k0 += 32) {
             const int kk = k0 + (lane >> 1);
-            if (kk < n_raw) {
-                const int id = slist[wave][kk];
-                const int chq = WPG * (id >> 2) + sub;
-                float4 bx = T.qbounds[((size_t)chq * 4 + (id & 3)) * 2 + (lane & 1)];
-                if (!(lane & 1)) bx.w = __int_as_float(id);
-                qbox[lane] = bx;
-            }
-            __builtin_amdgcn_wave_barrier();
-            const int nb = min(32, n_raw - k0);
-            for (int k = 0; k < nb; k += 2) {                     // wave-uniform; each half-wave on its own quarter
-                const int kq = min(k + half, nb - 1);
-                const float4 blo = qbox[2 * kq], bhi = qbox[2 * kq + 1];
-                bool hit = false;
-#pragma unroll
-                for (int n = 0; n < NQ; ++n) hit |= box_d2(blo, bhi, qx[n], qy[n], qz[n]) <= sb[n];
-                const unsigned long long hm = __ballot(hit);
-                const int i0 = __builtin_amdgcn_readlane(__float_as_int(blo.w), 0), i1 = __builtin_amdgcn_readlane(__float_as_int(blo.w), 32);
-                if ((unsigned)hm) { if (lane == 0) slist[wave][nout] = (unsigned short)i0; ++nout; }
-                if (k + 1 < nb && (unsigned)(hm >> 32)) { if (lane == 0) slist[wave][nout] = (unsigned short)i1; ++nout; }
-            }
+            const bool valid = kk < n_raw;
+            const int id = (int)slist[wave][valid ? kk : 0];
+            const size_t qb = ((size_t)(WPG * (id >> 2) + sub) * 4 + (id & 3)) * 2;
+            const float4 blo = T.qbounds[qb], bhi = T.qbounds[qb + 1];
+            const bool hit = valid && pair_hits(blo, bhi);
+            unsigned long long hm = __ballot(hit);
+            hm = (hm | (hm >> 1)) & 0x5555555555555555ull;
+            if ((lane & 1) == 0 && ((hm >> lane) & 1ull))         // (in place: a pass reads its ids before it writes, and writes trail reads)
+                slist[wave][nout + __popcll(hm & ((1ull << lane) - 1ull))] = (unsigned short)id;
+            nout += __popcll(hm);
             __builtin_amdgcn_wave_barrier();
         }
         nsurv = nout;

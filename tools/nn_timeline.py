@@ -46,7 +46,7 @@ for k in late: print("  ", int(idxs[k]), int(xcc[k]), f"{st[k]:.1f} {en[k]:.1f} 
 # phases of a wave's life (us): set-up loads | list (kept-list check or build) | filter | main loop | merge + stores
 ph = np.stack([a[:, 3] - a[:, 0], a[:, 4] - a[:, 3], a[:, 5] - a[:, 4], a[:, 6] - a[:, 5], a[:, 1] - a[:, 6]], axis=1) / 100.0
 names = ["set-up", "list", "filter", "main loop", "tail"]
-for label, sel in (("started in the first 30 us (full machine)", st < 30), ("started after 38 us (drain)", st > 38)):
+for label, sel in (("started in the first 30 us (full machine)", st < 30), ("started after 28 us (drain)", st > 28)):
     if sel.sum() == 0: continue
     print(f"{label}: {sel.sum()} waves, lifetime median {np.median((en - st)[sel]):.1f} us, work items median {np.median(a[sel, 7]):.0f}")
     for k, nm in enumerate(names):
