@@ -3,6 +3,6 @@
 cd $GRAFT_REPO_ROOT
 for mode in ${MODES:--2}; do
 for f in ${FRAMES:-128 256 512 1024}; do
-  FDCAP_NN_STREAM=$mode python bench.py --frames $f --steps 2 --warmup 1 --no-cpu-baseline 2>/dev/null | tail -1 | python tools/shard_line.py $mode
+  FDCAP_NN_STREAM=$mode python bench.py --frames $f --steps 2 --warmup 1 --no-cpu-baseline --no-exact-fp32 --no-logging-run 2>/dev/null | tail -1 | python tools/shard_line.py $mode
 done
 done
