@@ -1010,7 +1010,8 @@ __global__ __launch_bounds__(64 * WPB, NQ == 1 ? FDC_ST4_OCC : FDC_ST4_OCC2) voi
                                 const int r = __ffs(mask) - 1;
                                 mask &= mask - 1;
                                 const int pos = base + tile * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
-                                {   // (padding rows score 1e30 and never pass; the lane's own best was cleared from the mask)
+                                if (pos < T.n) {   // (a padding row scores 1e30, which still passes an INFINITE bound -- unseeded scans; the
+                                                   // lane's own best was cleared from the mask above)
                                     FDC_STAT(2, 1);
                                     if (cq_n < ST4_QCAP) { cq[cq_n * 64 + lane] = (unsigned)pos; ++cq_n; }
                                     else {                                 // queue full (rare): evaluated on the spot
