@@ -758,3 +758,45 @@ def test_checkpoint_resume_is_bit_identical_and_finite_check_fires(tmp_path):
     with pytest.raises(capi.FdcapError, match="another clip"):
         fop4.fitting(body, "global", resume=ck)              # written for a 12-iteration budget
     fop4.close()
+
+
+def test_every_streaming_kernel_variant_gives_the_same_bits(tmp_path):
+    """FDCAP_NN_STREAM selects the instantiation of the in-loop Chamfer kernel (waves per query group x query blocks per wave;
+    read once per process): 11 / 21 / 41 / 12 / 22 / 42 and the staged kernel (0) against the default choice, after a few
+    optimiser iterations (seeds, kept lists, queued candidates all in play): distances and indices bit for bit."""
+    import subprocess
+    import sys
+    code = r'''
+import sys, numpy as np, torch
+sys.path.insert(0, %r)
+import fdcap_amd
+from fdcap_amd import capi
+from tests.test_gpu_parity import _make_fop
+n = 96
+fop, bm, vp, clip, scene, vid = _make_fop(n, 300, 60_000, 40, 8, seed=60)
+x78 = torch.empty(n, 78, device="cuda")
+lib, h = fop.ctx.lib, fop.ctx.handle
+capi.check(lib.fdcap_params_75_to_78(capi.dptr(torch.tensor(clip.body_params).cuda()), n, capi.dptr(x78), capi.current_stream()), "75->78")
+fop.init(x78)
+for ii in range(4):
+    capi.check(lib.fdcap_opt_backward(h, ii, 400, 0, capi.current_stream()), "backward")
+    capi.check(lib.fdcap_opt_step(h, ii, 400, capi.current_stream()), "step")
+d = torch.empty(n, len(vid), device="cuda"); i = torch.empty(n, len(vid), device="cuda", dtype=torch.int32)
+capi.check(lib.fdcap_opt_forward_world(h, capi.dptr(torch.empty(n, len(vid), 3, device="cuda")), None, capi.current_stream()), "fw")
+capi.check(lib.fdcap_opt_get_contact(h, capi.dptr(d), capi.dptr(i), capi.current_stream()), "gc")
+torch.cuda.synchronize()
+np.savez(sys.argv[1], d=d.cpu().numpy(), i=i.cpu().numpy(), x=fop._rows_x.cpu().numpy())
+''' % os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    res = {}
+    for mode in ("", "11", "21", "41", "12", "22", "42", "0"):
+        out = str(tmp_path / ("nn_%s.npz" % (mode or "default")))
+        env = dict(os.environ)
+        env.pop("FDCAP_NN_STREAM", None)
+        if mode:
+            env["FDCAP_NN_STREAM"] = mode
+        subprocess.run([sys.executable, "-c", code, out], check=True, env=env, timeout=300)
+        res[mode] = np.load(out)
+    ref = res[""]
+    assert np.isfinite(ref["d"]).all() and (ref["i"] >= 0).all()
+    for mode, r in res.items():
+        assert np.array_equal(r["d"], ref["d"]) and np.array_equal(r["i"], ref["i"]) and np.array_equal(r["x"], ref["x"]), mode
