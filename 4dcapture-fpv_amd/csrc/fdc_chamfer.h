@@ -502,6 +502,10 @@ struct NNCache {
     int* hdr;                 // [ngroups * WPG] list length | launches since the anchors were set << 8; -1: no list (anchors one launch old)
     float4* anchor;           // [WPG][nq] {a_i, R_i (validity margin already taken off)}
     float slack;              // metres
+    // launch order (one-wave workgroups only; scheduling, never results): the workgroups are dispatched in blockIdx order, and a
+    // launch ends with whatever started last -- so the groups with the most work go first (nn_order_kernel, NNOrder below)
+    const int* order = nullptr;   // [workgroups] launch position -> query group; null: identity
+    int* work = nullptr;          // [groups] work items the group scanned in this launch (written when set)
 };
 
 template <int NQ, int WPG, int WPB = 4>
@@ -538,7 +542,7 @@ __global__ __launch_bounds__(64 * WPB, NQ == 1 ? FDC_ST4_OCC : FDC_ST4_OCC2) voi
     // r3: plain round-robin over the XCDs (workgroup b runs on XCD b % 8).  Contiguous frame ranges per XCD leave the XCDs with
     // 13 % different amounts of work (frames near the floor cost more) and the launch ends with its slowest XCD; interleaved,
     // every XCD sees every part of the clip -- consecutive frames share their scene cells anyway.  72.57 -> 72.31 ms per step.
-    const int wg = blockIdx.x; (void)per_xcd;
+    const int wg = (cache.order != nullptr && (int)blockIdx.x < nwg) ? cache.order[blockIdx.x] : (int)blockIdx.x; (void)per_xcd;
 #endif
     const int group = wg * GPW + gslot;
     const bool idle = wg >= nwg || group >= ngroups;            // idle waves still meet the barrier below
@@ -862,6 +866,9 @@ __global__ __launch_bounds__(64 * WPB, NQ == 1 ? FDC_ST4_OCC : FDC_ST4_OCC2) voi
         FDC_STAT(7, lane == 0 ? nout : 0);
     }
     TL_STAMP(2);
+    // (the launch order's key.  Also tried: + a bonus when the list was built this launch -- no better, such a wave does not
+    // build again next launch --, and the wave's measured main-loop time -- worse, 70.4 vs 68.6 us: it follows contention)
+    if (cache.work != nullptr && lane == 0 && !idle) cache.work[cidx] = nsurv;
 #ifdef FDC_NN_TIMELINE
     const int tl_nsurv = nsurv;
 #endif
@@ -1246,10 +1253,49 @@ static inline int nn_pick_nsplit(int nq, int nt, bool culled = false) {
     return ns;
 }
 
+// Launch order of nn_stream4_kernel's one-wave workgroups: position -> group, most work items first (counting sort on the
+// counts the last launch wrote; ties in no particular order -- the order decides when a group runs, never what it returns).
+__global__ __launch_bounds__(1024) void nn_order_kernel(const int* __restrict__ work, int n, int* __restrict__ order) {
+    // a histogram per wave: most groups fall into a dozen bins, and LDS atomics on one address serialise
+    __shared__ int cnt[16][256], base[256];
+    const int tid = threadIdx.x, w = tid >> 6;
+    for (int e = tid; e < 16 * 256; e += 1024) (&cnt[0][0])[e] = 0;
+    __syncthreads();
+    for (int i = tid; i < n; i += 1024) atomicAdd(&cnt[w][255 - min(max(work[i], 0), 255)], 1);
+    __syncthreads();
+    if (tid < 256) {                                           // bin tid: the waves' shares become offsets inside the bin
+        int run = 0;
+        for (int k = 0; k < 16; ++k) { const int t = cnt[k][tid]; cnt[k][tid] = run; run += t; }
+        base[tid] = run;
+    }
+    __syncthreads();
+    if (tid < 64) {                                            // exclusive prefix over the 256 bins: four per lane + a wave scan
+        const int a = base[4 * tid], b = base[4 * tid + 1], c = base[4 * tid + 2], d = base[4 * tid + 3];
+        int s = a + b + c + d, incl = s;
+        for (int off = 1; off < 64; off <<= 1) { const int t = __shfl_up(incl, off, 64); if (tid >= off) incl += t; }
+        const int ex = incl - s;
+        base[4 * tid] = ex; base[4 * tid + 1] = ex + a; base[4 * tid + 2] = ex + a + b; base[4 * tid + 3] = ex + a + b + c;
+    }
+    __syncthreads();
+    for (int i = tid; i < n; i += 1024) {
+        const int k = 255 - min(max(work[i], 0), 255);
+        order[base[k] + atomicAdd(&cnt[w][k], 1)] = i;
+    }
+}
+// host-side bookkeeping of the launch order (owned by the optimiser state; buffers hold one int per 32-query group)
+struct NNOrder {
+    int* work = nullptr;
+    int* order = nullptr;
+    int sorted_groups = 0;      // number of groups `order` was last sorted for (0: never)
+    int age = 0;                // launches since then
+    int every = 16;             // re-sort period (work per group drifts over tens of iterations)
+};
+
 // workspace: pd/pi [nsplit*nq]; seed: optional [nq] original indices (may alias idx: read before idx is rewritten)
 static inline hipError_t nn_search(const float* q, int nq, const NNTarget& T, float* dist, int* idx, float* pd, int* pi,
                                    int nsplit, hipStream_t st, const int* seed = nullptr, bool seed_missing = false,
-                                   float4* seedpt = nullptr, bool* seedpt_written = nullptr, const NNCache* cache = nullptr) {
+                                   float4* seedpt = nullptr, bool* seedpt_written = nullptr, const NNCache* cache = nullptr,
+                                   NNOrder* ord = nullptr) {
     if (seedpt_written) *seedpt_written = false;             // true: seedpt[q] = coordinates of the neighbour idx[q] after this launch
     if (nq <= 0) return hipSuccess;
     // Query blocks per workgroup: 4 waves x NQ x 32.  A brute-force scan wants NQ = 4 (most MFMAs per
@@ -1288,12 +1334,20 @@ static inline hipError_t nn_search(const float* q, int nq, const NNTarget& T, fl
             const int wpb = (wpg == 1 && nqv == 1 && wpb1) ? 1 : 4;
             const int nwg = (groups * wpg + wpb - 1) / wpb;
             const dim3 grid((nwg + 7) / 8 * 8);
-            const NNCache nc = cache ? *cache : NNCache{nullptr, nullptr, nullptr, 0.f};
+            NNCache nc = cache ? *cache : NNCache{nullptr, nullptr, nullptr, 0.f};
+            const bool ordered = ord != nullptr && ord->work != nullptr && ord->every > 0 && nqv == 1 && wpg == 1 && wpb == 1;
+            nc.work = ordered ? ord->work : nullptr;
+            nc.order = (ordered && ord->sorted_groups == groups) ? ord->order : nullptr;
 #define FDC_ST4(NQV, WPGV) hipLaunchKernelGGL((nn_stream4_kernel<NQV, WPGV>), grid, dim3(256), 0, st, q, nq, T, seed, seedpt, dist, idx, nc)
             if (nqv == 2 && wpg == 4) FDC_ST4(2, 4); else if (nqv == 2 && wpg == 2) FDC_ST4(2, 2); else if (nqv == 2) FDC_ST4(2, 1);
             else if (wpg == 4) FDC_ST4(1, 4); else if (wpg == 2) FDC_ST4(1, 2); else if (wpb == 4) FDC_ST4(1, 1);
             else hipLaunchKernelGGL((nn_stream4_kernel<1, 1, 1>), grid, dim3(64), 0, st, q, nq, T, seed, seedpt, dist, idx, nc);
 #undef FDC_ST4
+            if (ordered && (ord->sorted_groups != groups || ++ord->age >= ord->every)) {
+                hipLaunchKernelGGL(nn_order_kernel, dim3(1), dim3(1024), 0, st, ord->work, groups, ord->order);
+                ord->sorted_groups = groups;
+                ord->age = 0;
+            }
         }
         return hipGetLastError();
     }

@@ -1307,6 +1307,8 @@ struct OptState {
     DevBuf<unsigned short> nnc_ids;
     DevBuf<int> nnc_hdr;
     DevBuf<float4> nnc_anchor;
+    DevBuf<int> nnc_work, nnc_order;       // launch order of the in-loop NN launch (fdc_chamfer.h NNOrder); FDCAP_NN_ORDER=0 turns it off, =k re-sorts every k launches
+    NNOrder nn_order;
     float nnc_slack = 0.03f;  // metres; FDCAP_NN_CACHE_SLACK overrides, 0 disables the cache
     // fdcap_opt_nn_timing: HIP events around every in-loop NN launch of a fit (the bench's roofline figure)
     bool nn_timing = false;
@@ -2133,6 +2135,7 @@ void fdcap_opt_destroy(fdcap_ctx* c) {
     o->dctD.release(); o->dctCoef.release(); o->dctM.release(); o->dctV.release(); o->adam_tab.release();
     o->idx.release(); o->pi.release(); o->seedpt.release(); o->kp2d.release();
     o->nnc_ids.release(); o->nnc_hdr.release(); o->nnc_anchor.release();
+    o->nnc_work.release(); o->nnc_order.release();
     for (hipEvent_t e : o->nn_ev) (void)hipEventDestroy(e);
     o->nn_ev.clear();
     delete o;
@@ -2202,6 +2205,18 @@ int fdcap_opt_create(fdcap_ctx* c, const fdcap_opt_config* cfg, float* rows_x, f
             if (e_ == hipSuccess) e_ = hipMemset(o->nnc_anchor.p, 0, (size_t)4 * nq_all * sizeof(float4));
             if (e_ != hipSuccess) err = (int)e_;
         }
+        int every = 16;
+        if (const char* e = getenv("FDCAP_NN_ORDER")) every = atoi(e);
+        if (!err && every > 0) {
+            const size_t ng = ((size_t)nq_all + 31) / 32;
+            hipError_t e_ = o->nnc_work.ensure(ng);
+            if (e_ == hipSuccess) e_ = o->nnc_order.ensure(ng);
+            if (e_ == hipSuccess) e_ = hipMemset(o->nnc_work.p, 0, ng * sizeof(int));
+            if (e_ != hipSuccess) err = (int)e_;
+            o->nn_order = NNOrder{o->nnc_work.p, o->nnc_order.p, 0, 0, every};
+        } else {
+            o->nn_order = NNOrder{};
+        }
     }
     if (!err) {
         float s = cfg->scale_init;
@@ -2239,7 +2254,7 @@ static int opt_contact_forward(fdcap_ctx* c, hipStream_t st) {
     if (timed) HIP_TRY(hipEventRecord(o->nn_ev[o->nn_ev_used], st));
     HIP_TRY(nn_search(o->Vw.p + off, nq, c->nn_target(o->use_cull), o->dist.p + 2 * nc, o->idx.p + 2 * nc, o->pd.p, o->pi.p,
                       o->nsplit, st, o->use_seed ? o->idx.p + 2 * nc : nullptr, !o->seeded, o->seedpt.p + 2 * nc, &o->nnpt_valid,
-                      &cache));
+                      &cache, &o->nn_order));
     if (timed) { HIP_TRY(hipEventRecord(o->nn_ev[o->nn_ev_used + 1], st)); o->nn_ev_used += 2; }
     o->seeded = true;
     return 0;
@@ -2863,12 +2878,13 @@ int fdcap_opt_time_chamfer(fdcap_ctx* c, int32_t iters, int32_t brute_force, flo
     // (warm-up launch; after a brute-force launch rewrote idx it also refreshes the neighbours' coordinates)
     const NNCache cache = o->nn_cache(0);
     const NNCache* cp = !brute_force ? &cache : nullptr;
+    NNOrder* const op = !brute_force ? &o->nn_order : nullptr;
     HIP_TRY(nn_search(o->Vw.p + off, nl * nc, T, o->dist.p + 2 * nc, o->idx.p + 2 * nc, o->pd.p, o->pi.p, nsp, st, seed,
-                      !brute_force && !o->seeded, sp, nullptr, cp));
+                      !brute_force && !o->seeded, sp, nullptr, cp, op));
     if (!brute_force) o->seeded = true;
     HIP_TRY(hipEventRecord(e0, st));
     for (int i = 0; i < iters; ++i)
-        HIP_TRY(nn_search(o->Vw.p + off, nl * nc, T, o->dist.p + 2 * nc, o->idx.p + 2 * nc, o->pd.p, o->pi.p, nsp, st, seed, false, sp, nullptr, cp));
+        HIP_TRY(nn_search(o->Vw.p + off, nl * nc, T, o->dist.p + 2 * nc, o->idx.p + 2 * nc, o->pd.p, o->pi.p, nsp, st, seed, false, sp, nullptr, cp, op));
     HIP_TRY(hipEventRecord(e1, st));
     HIP_TRY(hipEventSynchronize(e1));
     float t = 0.f;

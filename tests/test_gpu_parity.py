@@ -763,7 +763,9 @@ def test_checkpoint_resume_is_bit_identical_and_finite_check_fires(tmp_path):
 def test_every_streaming_kernel_variant_gives_the_same_bits(tmp_path):
     """FDCAP_NN_STREAM selects the instantiation of the in-loop Chamfer kernel (waves per query group x query blocks per wave;
     read once per process): 11 / 21 / 41 / 12 / 22 / 42 and the staged kernel (0) against the default choice, after a few
-    optimiser iterations (seeds, kept lists, queued candidates all in play): distances and indices bit for bit."""
+    optimiser iterations (seeds, kept lists, queued candidates all in play): distances and indices bit for bit.  The one-wave
+    variant (11) also runs with its launch order off and re-sorted after every launch (FDCAP_NN_ORDER): the order decides when
+    a query group runs, never what it returns."""
     import subprocess
     import sys
     code = r'''
@@ -788,12 +790,15 @@ torch.cuda.synchronize()
 np.savez(sys.argv[1], d=d.cpu().numpy(), i=i.cpu().numpy(), x=fop._rows_x.cpu().numpy())
 ''' % os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     res = {}
-    for mode in ("", "11", "21", "41", "12", "22", "42", "0"):
-        out = str(tmp_path / ("nn_%s.npz" % (mode or "default")))
+    for mode in ("", "11", "11/0", "11/1", "21", "41", "12", "22", "42", "0"):
+        out = str(tmp_path / ("nn_%s.npz" % (mode.replace("/", "_") or "default")))
         env = dict(os.environ)
         env.pop("FDCAP_NN_STREAM", None)
+        env.pop("FDCAP_NN_ORDER", None)
         if mode:
-            env["FDCAP_NN_STREAM"] = mode
+            env["FDCAP_NN_STREAM"] = mode.split("/")[0]
+        if "/" in mode:
+            env["FDCAP_NN_ORDER"] = mode.split("/")[1]
         subprocess.run([sys.executable, "-c", code, out], check=True, env=env, timeout=300)
         res[mode] = np.load(out)
     ref = res[""]
