@@ -91,6 +91,7 @@ SYMBOLS = {
     "fdcap_opt_reset_adam": (c_int32, [c_void_p, c_void_p]),
     "fdcap_opt_step_rows_and_pack": (c_int32, [c_void_p, c_int32, c_int32, c_void_p, c_void_p]),
     "fdcap_opt_unpack_and_step_scale": (c_int32, [c_void_p, c_int32, c_int32, c_void_p, c_int32, c_int32, c_void_p]),
+    "fdcap_opt_forward_ahead": (c_int32, [c_void_p, c_int32, c_int32, c_int32, c_void_p]),
     "fdcap_exchange_len": (c_int32, []),
     "fdcap_opt_get_results": (c_int32, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "fdcap_opt_destroy": (None, [c_void_p]),

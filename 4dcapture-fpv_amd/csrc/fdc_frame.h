@@ -109,6 +109,10 @@ FDC_HD void world_matrix(const float* cam_ext, const float* x, float scale, M3* 
     *Mt = m3_vec(E, ct) + Et;
 }
 
+// world position of a joint: M (G.t + transl); joints are NOT multiplied by scale (:298-299).  One function for pose_forward's
+// tail and for the rows that only refresh M / Jw after `scale` changed (pose_fwd_kernel's world-only rows): same bits
+FDC_HD V3 world_joint(const M3& MR, V3 Mt, V3 Gt, V3 transl) { return m3_vec(MR, Gt + transl) + Mt; }
+
 // Forward for one frame.  Global outputs (any may be null):
 //   Rm[55*9], PF[486], Jrest[55*3], G[55*12], A[55*12], M[12], Jw[23*3]
 template <class Sync>
@@ -190,7 +194,7 @@ FDC_HD void pose_forward(const PoseModel& pm, const float* x, const float* o, co
         if (PF && j >= 1)
             for (int e = 0; e < 9; ++e) PF[9 * (j - 1) + e] = sc.R[j][e] - ((e == 0 || e == 4 || e == 8) ? 1.f : 0.f);
         if (Jw && j < NJW) {
-            V3 w = m3_vec(MR, Gt + transl) + Mt;        // joints are NOT multiplied by scale (:298-299)
+            V3 w = world_joint(MR, Mt, Gt, transl);
             Jw[3 * j] = w.x; Jw[3 * j + 1] = w.y; Jw[3 * j + 2] = w.z;
         }
     }

@@ -887,15 +887,20 @@ __device__ __forceinline__ float vp_lrelu(float v) { return v > 0.f ? v : 0.2f *
 // dispatcher deals consecutive blocks to the 8 XCDs, so XCD x only ever streams quarter x & 3 of W2), blockIdx >> 2 = row block.
 // Z = X + latent column (row stride ldx); rows [row_lo, row_hi).  H1, H2 [*, 512] (kept for the backward's masks),
 // Opart [4][part_stride]: partial decoder outputs (row-major [*, 126]); the bias rides on partial 0.
+// A launch may cover TWO row ranges (a shard's halo rows on either side of its owned rows, VpRows): row blocks [0, nb1) belong to
+// [row_lo, row_hi), the rest to [row2_lo, row2_hi).  A row's result does not depend on the block it is decoded in.
+struct VpRows { int nb1 = 0x7fffffff, row2_lo = 0, row2_hi = 0; };
 __global__ __launch_bounds__(512) void vposer_fwd_fused_kernel(VPoserPanels P, const float* __restrict__ Z, int ldx, int row_lo,
                                                                int row_hi, float* __restrict__ H1, float* __restrict__ H2,
-                                                               float* __restrict__ Opart, size_t part_stride) {
+                                                               float* __restrict__ Opart, size_t part_stride, VpRows two) {
     __shared__ __attribute__((aligned(16))) float lds[VP_Z * 16 + VP_H * 16 + VP_QW * 16];
     float* const sZ = lds;
     float* const sH1 = lds + VP_Z * 16;
     float* const sH2 = sH1 + VP_H * 16;
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, j = lane & 15, g = lane >> 4;
-    const int q = blockIdx.x & 3, r0 = row_lo + (int)(blockIdx.x >> 2) * 16;
+    int rblk = (int)(blockIdx.x >> 2);
+    if (rblk >= two.nb1) { rblk -= two.nb1; row_lo = two.row2_lo; row_hi = two.row2_hi; }
+    const int q = blockIdx.x & 3, r0 = row_lo + rblk * 16;
     PN_STAMP(0);
     PnRing<1, 4> rg2, rg3;                             // next layer's first fragments are requested before the barrier in front of it
     // all three layers' biases before the first barrier (see vposer_fwd_split3_kernel)
@@ -1074,13 +1079,15 @@ constexpr int VP3_PZ = (VP_Z / 8) * 16, VP3_PH = (VP_H / 8) * 16, VP3_PQ = (VP_Q
 
 __global__ __launch_bounds__(512) void vposer_fwd_split3_kernel(VPoserPanels3 P, const float* __restrict__ Z, int ldx, int row_lo,
                                                                 int row_hi, float* __restrict__ H1, float* __restrict__ H2,
-                                                                float* __restrict__ Opart, size_t part_stride) {
+                                                                float* __restrict__ Opart, size_t part_stride, VpRows two) {
     __shared__ __attribute__((aligned(16))) uint4 lds3[3 * (VP3_PZ + VP3_PH + VP3_PQ)];
     uint4* const sZ = lds3;
     uint4* const sH1 = sZ + 3 * VP3_PZ;
     uint4* const sH2 = sH1 + 3 * VP3_PH;
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, j = lane & 15, g = lane >> 4;
-    const int q = blockIdx.x & 3, r0 = row_lo + (int)(blockIdx.x >> 2) * 16;
+    int rblk = (int)(blockIdx.x >> 2);
+    if (rblk >= two.nb1) { rblk -= two.nb1; row_lo = two.row2_lo; row_hi = two.row2_hi; }
+    const int q = blockIdx.x & 3, r0 = row_lo + rblk * 16;
     PnRing3T<1, 2> rg2, rg3;
     // the biases of all three layers, requested before the first barrier (the compiler does not move a load across one):
     // fetched where they are used -- after each layer's products -- every tile's bias was a round trip of its own

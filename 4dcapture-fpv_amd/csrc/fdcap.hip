@@ -137,13 +137,29 @@ __global__ __launch_bounds__(64) void pose_fwd_kernel(PoseModel pm, const float*
                                                       const float* __restrict__ CAM, const float* __restrict__ scale,
                                                       int row0, float* Rm, float* PF, float* Jrest, float* G, float* A,
                                                       float* M, float* Jw, const float* AA, const float* __restrict__ Opart,
-                                                      size_t part_stride) {
+                                                      size_t part_stride, int wo_lo = 0, int wo_hi = 0) {
     __shared__ PoseScratch sc;
     __shared__ PoseStage stg;
     __shared__ float s_O[ODIM + 2];
     __shared__ float s_Op[PARTS ? VP_NQ : 1][ODIM + 2];
     FDC_FR_STAMP(0, 0);
     int r = row0 + blockIdx.x;
+    if (r >= wo_lo && r < wo_hi) {
+        // world-only rows (fdcap_opt_forward_ahead): the pose state of this row was computed before `scale` was stepped;
+        // only M and the world joints depend on it -- refreshed from the stored joint transforms, pose_forward's own tail
+        const float* x = X + (size_t)r * XDIM;
+        M3 MR; V3 Mt;
+        world_matrix(CAM + (size_t)r * 16, x, *scale, &MR, &Mt);
+        const V3 transl = v3(x[X_TRANSL], x[X_TRANSL + 1], x[X_TRANSL + 2]);
+        const int j = threadIdx.x;
+        if (j < NJW) {
+            const V3 w = world_joint(MR, Mt, g_trn(G + ((size_t)r * NJ + j) * 12), transl);
+            float* o = Jw + ((size_t)r * NJW + j) * 3;
+            o[0] = w.x; o[1] = w.y; o[2] = w.z;
+        }
+        if (j == 0) g_store(M + (size_t)r * 12, MR, Mt);
+        return;
+    }
     stage_pose_issue(pm, stg, X + (size_t)r * XDIM, CAM + (size_t)r * 16);
     if (PARTS) {                                             // the decoder's partial sums ride in the same batch of copies
 #pragma unroll
@@ -1325,6 +1341,9 @@ struct OptState {
     int dctT = 0, dctC = 0, dctW = 0;
     bool dct_grad = false;    // the last backward gave `scale` a gradient through the DCT term
     bool seeded = false;      // a contact forward has run since fdcap_opt_create (idx holds neighbours)
+    // fdcap_opt_forward_ahead ran for the owned rows and nothing has touched them since: the next backward only adds the halo
+    // rows and the scale-dependent outputs (ahead_blend: the contact set's pose-blend product is done as well)
+    bool ahead = false, ahead_blend = false;
     bool nnpt_valid = false;  // the last contact forward left the neighbours' coordinates in seedpt
     bool use_seed = true;     // last iteration's neighbours seed the NN bound (pruning only)
     bool use_cull = true;     // skip k-d cells whose box is out of every query's reach
@@ -1503,16 +1522,22 @@ hipError_t blend_forward(const SkinSet& ss, const float* PF, int M, float* Voff,
 // VPoser decoder forward for rows [row_lo, row_hi) of X (latent read in place at column latent_off): H1, H2 and the four
 // partial outputs Opart (fdc_panel.h); O != nullptr: also the summed output (one more small launch -- the optimiser's
 // pose_fwd_kernel<true> adds the partials itself instead)
+// (row2_lo < row2_hi: a second row range in the same launch -- the halo rows on the far side of a shard's owned rows)
 int vposer_forward(fdcap_ctx* c, const float* X, int ldx, int latent_off, int row_lo, int row_hi, float* H1, float* H2,
-                   float* Opart, size_t part_stride, float* O, hipStream_t st) {
-    const int rows = row_hi - row_lo;
-    if (rows <= 0) return 0;
+                   float* Opart, size_t part_stride, float* O, hipStream_t st, int row2_lo = 0, int row2_hi = 0) {
+    const int rows = row_hi - row_lo, rows2 = std::max(row2_hi - row2_lo, 0);
+    if (rows <= 0 && rows2 <= 0) return 0;
+    if (rows <= 0) { row_lo = row2_lo; row_hi = row2_hi; return vposer_forward(c, X, ldx, latent_off, row_lo, row_hi, H1, H2, Opart, part_stride, O, st); }
+    VpRows two;
+    const int nb1 = (rows + 15) / 16, nb2 = (rows2 + 15) / 16;
+    if (rows2 > 0) { two.nb1 = nb1; two.row2_lo = row2_lo; two.row2_hi = row2_hi; }
+    if (O && rows2 > 0) return FDCAP_E_ARG;                   // (the summed output is only formed for one range)
     if (gemm_split3_enabled())
-        hipLaunchKernelGGL(vposer_fwd_split3_kernel, dim3(4 * ((rows + 15) / 16)), dim3(512), 0, st, c->vp3, X + latent_off, ldx, row_lo,
-                           row_hi, H1, H2, Opart, part_stride);
+        hipLaunchKernelGGL(vposer_fwd_split3_kernel, dim3(4 * (nb1 + nb2)), dim3(512), 0, st, c->vp3, X + latent_off, ldx, row_lo,
+                           row_hi, H1, H2, Opart, part_stride, two);
     else
-        hipLaunchKernelGGL(vposer_fwd_fused_kernel, dim3(4 * ((rows + 15) / 16)), dim3(512), 0, st, c->vp, X + latent_off, ldx, row_lo,
-                           row_hi, H1, H2, Opart, part_stride);
+        hipLaunchKernelGGL(vposer_fwd_fused_kernel, dim3(4 * (nb1 + nb2)), dim3(512), 0, st, c->vp, X + latent_off, ldx, row_lo,
+                           row_hi, H1, H2, Opart, part_stride, two);
     if (O) {
         const size_t n = (size_t)rows * ODIM;
         hipLaunchKernelGGL(vposer_sum_parts_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, Opart, part_stride,
@@ -1531,11 +1556,27 @@ void opt_row_range(const OptState* o, int halo, int* lo, int* hi) {
 // decoder + per-frame pose state (Rm, PF, Jrest, G, A, M, Jw) of rows [lo, hi): two launches
 int opt_pose_forward(fdcap_ctx* c, int lo, int hi, hipStream_t st) {
     OptState* o = c->opt;
+    o->ahead = false;                                       // (whatever ran ahead is recomputed here)
     const size_t ps = (size_t)o->R * ODIM;
     int e = vposer_forward(c, o->X.p, XDIM, X_LATENT, lo, hi, o->H1.p, o->H2.p, o->Opart.p, ps, nullptr, st);
     if (e) return e;
     hipLaunchKernelGGL(pose_fwd_kernel<true>, dim3(hi - lo), dim3(64), 0, st, c->pose_model(), o->X.p, o->O.p, o->CAM.p, o->scale.p, lo,
                        o->Rm.p, o->PF.p, o->Jrest.p, o->G.p, o->A.p, o->M.p, o->Jw.p, (const float*)nullptr, (const float*)o->Opart.p, ps);
+    return (int)hipGetLastError();
+}
+
+// After fdcap_opt_forward_ahead: what is left of opt_pose_forward(lo, hi) -- the halo rows on either side of the owned rows in
+// full (their parameters arrived with the exchange), and M / Jw of the owned rows (`scale` was stepped by the exchange's tail).
+// Two launches, nearly empty.
+int opt_pose_forward_rest(fdcap_ctx* c, int lo, int hi, hipStream_t st) {
+    OptState* o = c->opt;
+    const int nl = o->cfg.n_local;
+    const size_t ps = (size_t)o->R * ODIM;
+    int e = vposer_forward(c, o->X.p, XDIM, X_LATENT, lo, 2, o->H1.p, o->H2.p, o->Opart.p, ps, nullptr, st, 2 + nl, hi);
+    if (e) return e;
+    hipLaunchKernelGGL(pose_fwd_kernel<true>, dim3(hi - lo), dim3(64), 0, st, c->pose_model(), o->X.p, o->O.p, o->CAM.p, o->scale.p, lo,
+                       o->Rm.p, o->PF.p, o->Jrest.p, o->G.p, o->A.p, o->M.p, o->Jw.p, (const float*)nullptr, (const float*)o->Opart.p, ps,
+                       2, 2 + nl);
     return (int)hipGetLastError();
 }
 
@@ -2240,11 +2281,11 @@ int fdcap_opt_set_inputs(fdcap_ctx* c, const float* data78, const float* init78,
     return FDCAP_OK;
 }
 
-static int opt_contact_forward(fdcap_ctx* c, hipStream_t st) {
+static int opt_contact_forward(fdcap_ctx* c, hipStream_t st, bool blend_done = false) {
     OptState* o = c->opt;
     const int nl = o->cfg.n_local, nc = c->nc;
     const size_t off = (size_t)2 * nc * 3;
-    HIP_TRY(blend_forward(c->contact, o->PF.p + 2 * NPFX, nl, o->Voff.p + off, st));
+    if (!blend_done) HIP_TRY(blend_forward(c->contact, o->PF.p + 2 * NPFX, nl, o->Voff.p + off, st));
     hipLaunchKernelGGL(skin_fwd_kernel, dim3((nc + 255) / 256, nl), dim3(256), 0, st, c->contact.model(), nc, o->X.p, XDIM,
                        X_BETAS, X_TRANSL, o->Voff.p, o->A.p, o->M.p, o->scale.p, 2, 1, o->Vw.p);
     const int nq = nl * nc;
@@ -2283,11 +2324,13 @@ static int opt_backward_impl(fdcap_ctx* c, const LossWeights& lw, int32_t log_te
     if (losses && !rows_log) HIP_TRY(hipMemsetAsync(losses, 0, FDCAP_NUM_LOSSES * sizeof(double), st));
     int row_lo, row_hi;
     opt_row_range(o, 1, &row_lo, &row_hi);
-    int e = opt_pose_forward(c, row_lo, row_hi, st);
+    const bool ahead = o->ahead, blend_done = o->ahead && o->ahead_blend;
+    int e = ahead ? opt_pose_forward_rest(c, row_lo, row_hi, st) : opt_pose_forward(c, row_lo, row_hi, st);
+    o->ahead = false;
     if (e) return e;
     const bool contact_grad = o->contact_on && lw.contact != 0.f;
     const bool contact_fwd = o->contact_on && (contact_grad || log_terms);
-    if (contact_fwd) { e = opt_contact_forward(c, st); if (e) return e; }
+    if (contact_fwd) { e = opt_contact_forward(c, st, blend_done); if (e) return e; }
     const float w_rec = lw.rec * cf.weight_loss_rec / ((float)N * XDIM);
     const float w_sm = (N >= 3) ? lw.smooth / ((float)(N - 2) * XDIM) : 0.f;
     const float w_ws = (lw.world_on && N >= 2) ? lw.world / ((float)(N - 1) * NJW * 3) : 0.f;
@@ -2370,6 +2413,24 @@ int fdcap_opt_set_loss_output(fdcap_ctx* c, double* losses_d) {
     if (!c || !c->opt || !losses_d) return FDCAP_E_ARG;
     c->opt->losses.p = losses_d;
     return FDCAP_OK;
+}
+
+// The part of iteration ii's forward that depends neither on `scale` nor on the halo rows, for the owned rows: decoder, pose
+// state, and (when that iteration has a contact term or logs one) the contact set's pose-blend product.  A sharded run issues
+// it between fdcap_opt_step_rows_and_pack and fdcap_opt_unpack_and_step_scale, so that it runs while the all-gather is in
+// flight ("overlap C1 with the start of the next forward"); fdcap_opt_backward(ii) then only adds the rest.
+int fdcap_opt_forward_ahead(fdcap_ctx* c, int32_t ii, int32_t P, int32_t log_terms, void* stream) {
+    if (!c || !c->opt) return FDCAP_E_STATE;
+    OptState* o = c->opt;
+    hipStream_t st = (hipStream_t)stream;
+    const int nl = o->cfg.n_local, nc = c->nc;
+    int e = opt_pose_forward(c, 2, 2 + nl, st);
+    if (e) return e;
+    const bool contact_fwd = o->contact_on && ((ii < P && o->cfg.phase1_contact != 0.f) || log_terms);
+    if (contact_fwd) HIP_TRY(blend_forward(c->contact, o->PF.p + 2 * NPFX, nl, o->Voff.p + (size_t)2 * nc * 3, st));
+    o->ahead = true;
+    o->ahead_blend = contact_fwd;
+    return (int)hipGetLastError();
 }
 
 int fdcap_opt_backward(fdcap_ctx* c, int32_t ii, int32_t P, int32_t log_terms, void* stream) {
@@ -2537,6 +2598,7 @@ int fdcap_opt_export_state(fdcap_ctx* c, float* state_d, void* stream) {
 int fdcap_opt_import_state(fdcap_ctx* c, const float* state_d, void* stream) {
     if (!c || !c->opt || !state_d) return FDCAP_E_ARG;
     c->opt->log_pending = false;
+    c->opt->ahead = false;
     return opt_state_copy(c, (float*)state_d, false, (hipStream_t)stream);
 }
 int fdcap_opt_check_finite(fdcap_ctx* c, int32_t* count_d, void* stream) {
@@ -2582,6 +2644,7 @@ static int opt_step_impl(fdcap_ctx* c, int32_t ii, int32_t P, bool do_rows, bool
     hipStream_t st = (hipStream_t)stream;
     const fdcap_opt_config& cf = o->cfg;
     const int nl = cf.n_local;
+    if (do_rows) o->ahead = false;                         // the rows change: a forward that ran ahead of this step is stale
     AdamTensor x = {}, cam = {}, sc = {};
     int nb_x = 0, nb_cam = 0;
     // body_rotation_rec: every iteration, its own step counter = ii + 1
@@ -2680,6 +2743,7 @@ int fdcap_opt_backward_local2(fdcap_ctx* c, const float* contact_weight, int32_t
 int fdcap_opt_step_x(fdcap_ctx* c, int32_t step, void* stream) {
     if (!c || !c->opt || step <= 0) return FDCAP_E_ARG;
     OptState* o = c->opt;
+    o->ahead = false;
     const size_t nx = (size_t)o->cfg.n_local * XDIM;
     hipLaunchKernelGGL(adam_kernel, dim3((nx + 255) / 256), dim3(256), 0, (hipStream_t)stream, o->X.p + 2 * XDIM,
                        o->mX.p + 2 * XDIM, o->vX.p + 2 * XDIM, o->dX.p + 2 * XDIM, nx, adam_scalars(o->cfg.lr, step), 0);

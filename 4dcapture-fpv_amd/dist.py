@@ -98,14 +98,28 @@ def allreduce_scalars(shard: FrameShard, dscale, losses=None) -> None:
         dist.all_reduce(losses, op=dist.ReduceOp.SUM, group=shard.group)
 
 
-def allgather_packed(shard: FrameShard, send, gathered) -> None:
+def allgather_packed(shard: FrameShard, send, gathered, overlap=None) -> None:
     """gathered[r] = rank r's `send` (one small fixed-size message per rank and iteration: the iteration's only
     collective).  `gathered` is [world, len(send)] contiguous; it is handed to the backend as the flat concatenation
-    (RCCL and gloo both take that form; gloo refuses the 2-D view)."""
+    (RCCL and gloo both take that form; gloo refuses the 2-D view).
+
+    overlap: a callable that enqueues work which does not need the gathered data (fdcap_opt_forward_ahead).  Over RCCL the
+    collective is issued asynchronously -- it runs on the backend's own stream once `send` is complete --, `overlap()` puts
+    its launches on the current stream behind the packing launch, and only then is the current stream made to wait for the
+    collective: the launches run while the messages travel.  (gloo, tests: the same order of calls, no concurrency.)"""
     import torch.distributed as dist
     if send.is_cuda and dist.get_backend(shard.group) == "gloo":      # tests: gloo cannot gather device tensors
         flat = gathered.new_empty(gathered.numel(), device="cpu")
-        dist.all_gather_into_tensor(flat, send.cpu(), group=shard.group)
+        host = send.cpu()
+        if overlap is not None:
+            overlap()
+        dist.all_gather_into_tensor(flat, host, group=shard.group)
         gathered.copy_(flat.view_as(gathered))
+    elif overlap is not None and send.is_cuda:
+        work = dist.all_gather_into_tensor(gathered.view(-1), send, group=shard.group, async_op=True)
+        overlap()
+        work.wait()                                                   # (stream-level: the host does not block)
     else:
         dist.all_gather_into_tensor(gathered.view(-1), send, group=shard.group)
+        if overlap is not None:
+            overlap()

@@ -229,6 +229,17 @@ class FittingOP:
         # group -- lets a single-GPU box exercise the RCCL calls of the multi-GPU path
         import os
         multi = self.shard.world > 1 or (self.group is not None and os.environ.get("FDCAP_FORCE_EXCHANGE") == "1")
+        # Forward ahead of the exchange (fdcap_opt_forward_ahead): FDCAP_XCH_OVERLAP=1 always, =0 never; otherwise the rank
+        # times eight iterations of either schedule early in phase 1 and keeps the faster one.  The two give the same bits,
+        # and the choice is local to a rank (the collective is the same call either way).  Why not simply "always": handing
+        # work between the collective's stream and this one costs ~17 us per iteration on a one-rank RCCL group
+        # (tools/host_issue_probe.py), so the overlap only pays when the all-gather takes longer than that to come back.
+        env_ov = os.environ.get("FDCAP_XCH_OVERLAP", "auto")
+        overlap = multi and env_ov == "1"
+        tune = None
+        if multi and env_ov not in ("0", "1") and mode != "dct" and ii0 + 18 <= min(P, self.num_iter):
+            tune = [torch.cuda.Event(enable_timing=True) for _ in range(3)]
+        self.exchange_overlap = overlap
         if mode == "dct":
             self._dct_loops(lib, h, multi, log_every)
         # The reference prints every loss term in every iteration (:573-575, :587-589) with five .item() syncs.  Here the
@@ -259,6 +270,17 @@ class FittingOP:
             for ii in range(ii0, self.num_iter if mode != "dct" else 0):                        # :560
                 do_log = bool(log_every) and (ii % log_every == 0 or ii == self.num_iter - 1)
                 st = capi.current_stream()
+                if tune is not None:                     # iterations ii0+2..9 plain, ii0+10..17 with the forward ahead
+                    k = ii - ii0
+                    if k in (2, 10, 18):
+                        tune[(k - 2) // 8].record()
+                    if k == 10:
+                        overlap = True
+                    elif k == 18:
+                        tune[2].synchronize()
+                        overlap = tune[1].elapsed_time(tune[2]) < 0.97 * tune[0].elapsed_time(tune[1])
+                        self.exchange_overlap = overlap
+                        tune = None
                 if do_log:                               # this iteration's partial sums go straight into their history row
                     capi.check(lib.fdcap_opt_set_loss_output(h, capi.dptr(hist[len(logged)])), "fdcap_opt_set_loss_output")
                     logged.append(ii)
@@ -268,7 +290,15 @@ class FittingOP:
                     # one collective per iteration: boundary rows (after Adam) + the scale-gradient partial travel
                     # together; every rank then sums the partials in rank order and steps `scale` identically
                     capi.check(lib.fdcap_opt_step_rows_and_pack(h, ii, P, capi.dptr(self._xch_send), st), "step_rows_and_pack")
-                    allgather_packed(self.shard, self._xch_send, self._xch_all)
+                    ahead = None
+                    if overlap and ii + 1 < self.num_iter:
+                        # the next iteration's decoder / pose state / blend product of the owned rows need neither `scale`
+                        # nor the halo rows: they run while the messages travel
+                        nxt_log = bool(log_every) and ((ii + 1) % log_every == 0 or ii + 1 == self.num_iter - 1)
+
+                        def ahead(ii=ii, nxt_log=nxt_log, st=st):
+                            capi.check(lib.fdcap_opt_forward_ahead(h, ii + 1, P, 2 if nxt_log else 0, st), "fdcap_opt_forward_ahead")
+                    allgather_packed(self.shard, self._xch_send, self._xch_all, ahead)
                     capi.check(lib.fdcap_opt_unpack_and_step_scale(h, ii, P, capi.dptr(self._xch_all), self.shard.rank,
                                                                    self.shard.world, st), "unpack_and_step_scale")
                 else:

@@ -301,6 +301,14 @@ int fdcap_opt_step_rows_and_pack(fdcap_ctx* ctx, int32_t ii, int32_t first_phase
 int fdcap_opt_unpack_and_step_scale(fdcap_ctx* ctx, int32_t ii, int32_t first_phase2_iter, const float* gathered_d,
                                     int32_t rank, int32_t world, void* stream);
 int32_t fdcap_exchange_len(void);
+/* Overlap of the exchange with the next forward.  Issued between the two calls above, i.e. while the all-gather is in
+ * flight: the part of iteration ii's forward (ii = the NEXT iteration; log_terms as its fdcap_opt_backward will get) that needs
+ * neither `scale` nor the halo rows -- decoder, pose state and the contact set's pose-blend product of the owned rows
+ * (global_optimization.py:270-283 up to `verts * scale`, :284).  The next fdcap_opt_backward(ii) then only decodes the halo
+ * rows and refreshes the scale-dependent outputs (two nearly empty launches) before it goes on; parameters are bit-identical
+ * to the schedule without this call.  Anything that changes the owned rows in between (a step, fdcap_opt_import_state) drops
+ * what ran ahead. */
+int fdcap_opt_forward_ahead(fdcap_ctx* ctx, int32_t ii, int32_t first_phase2_iter, int32_t log_terms, void* stream);
 
 /* Results: body_rec75_d [n_local,75] (= convert_to_3D_rot, :633), scale_d [1], cam_ext_d [n_local,16]. */
 int fdcap_opt_get_results(fdcap_ctx* ctx, float* body_rec75_d, float* scale_d, float* cam_ext_d,

@@ -28,10 +28,10 @@ def _inputs(n=N):
     return bm, vp, clip, scene, np.concatenate([l, r])
 
 
-def _fit(group, mode="global", n=N):
+def _fit(group, mode="global", n=N, iters=ITERS):
     from fdcap_amd.fitting import FittingOP
     bm, vp, clip, scene, vid = _inputs(n)
-    fop = FittingOP({"num_iter": ITERS}, {}, n, body_model=bm, vposer=vp, scene_verts=scene, contact_ids=vid,
+    fop = FittingOP({"num_iter": iters}, {}, n, body_model=bm, vposer=vp, scene_verts=scene, contact_ids=vid,
                     camera_ext=read_camerapose(clip.camerapose_lines), group=group)
     body, scale, cam = fop.fitting(torch.tensor(clip.body_params).cuda(), mode, log_every=1)
     tot = np.array(fop.log.total) if mode == "global" else np.array(fop.log2)[:, 5]
@@ -40,13 +40,13 @@ def _fit(group, mode="global", n=N):
     return out
 
 
-def _worker(rank, world, port, q, mode="global", n=N):
+def _worker(rank, world, port, q, mode="global", n=N, iters=ITERS):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     torch.cuda.set_device(0)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
-        q.put((rank,) + _fit(dist.group.WORLD, mode, n))
+        q.put((rank,) + _fit(dist.group.WORLD, mode, n, iters))
     finally:
         dist.barrier()
         dist.destroy_process_group()
@@ -85,6 +85,45 @@ def test_sharded_gpu_run_matches_single_rank(world, mode, n):
     for r in res:
         assert abs(r[3] - ref[2]) < 2e-6
         np.testing.assert_allclose(r[5], ref[4], rtol=2e-6)      # all-reduced loss totals, every iteration
+
+
+def _run_ranks(world, mode, n, overlap, iters=ITERS):
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    old = os.environ.get("FDCAP_XCH_OVERLAP")
+    os.environ["FDCAP_XCH_OVERLAP"] = overlap                       # (spawned children inherit the environment)
+    try:
+        procs = [ctx.Process(target=_worker, args=(r, world, port, q, mode, n, iters)) for r in range(world)]
+        for p in procs:
+            p.start()
+        res = sorted(q.get(timeout=600) for _ in range(world))
+        for p in procs:
+            p.join(timeout=120)
+            assert p.exitcode == 0
+    finally:
+        if old is None:
+            os.environ.pop("FDCAP_XCH_OVERLAP", None)
+        else:
+            os.environ["FDCAP_XCH_OVERLAP"] = old
+    return res
+
+
+@pytest.mark.parametrize("world,mode,n,iters,ov", [(3, "global", N, ITERS, "1"), (2, "local", N, ITERS, "1"),
+                                                   (2, "global", 200, ITERS, "1"), (2, "global", N, 40, "auto")])
+def test_forward_ahead_of_the_exchange_gives_the_same_bits(world, mode, n, iters, ov):
+    """fdcap_opt_forward_ahead (the owned rows' decoder / pose state / blend product issued while the all-gather is in flight,
+    the halo rows and the scale-dependent outputs added afterwards) against the plain schedule: every rank's parameters,
+    scale, camera_ext and logged totals bit for bit (both phases; 10 iterations cross the phase switch).  "auto": the rank
+    times both schedules during iterations 2-17 and keeps one -- whichever it keeps, the bits are the plain schedule's."""
+    a = _run_ranks(world, mode, n, ov, iters)
+    b = _run_ranks(world, mode, n, "0", iters)
+    for ra, rb in zip(a, b):
+        assert ra[0] == rb[0] and ra[1] == rb[1]
+        np.testing.assert_array_equal(ra[2], rb[2])
+        assert ra[3] == rb[3]
+        np.testing.assert_array_equal(ra[4], rb[4])
+        np.testing.assert_array_equal(ra[5], rb[5])
 
 
 def _rccl_worker(port, q):

@@ -25,18 +25,20 @@ body = torch.tensor(clip.body_params).cuda()
 fop.fitting(body, "global"); torch.cuda.synchronize()
 from fdcap_amd.dist import allgather_packed
 lib, h = fop.ctx.lib, fop.ctx.handle
-torch.cuda.synchronize()
-t0 = time.perf_counter()
-for ii in range(400):
-    st = capi.current_stream()
-    capi.check(lib.fdcap_opt_backward(h, ii, 10 ** 6, 0, st), "b")
-    if group is not None:
-        capi.check(lib.fdcap_opt_step_rows_and_pack(h, ii, 10 ** 6, capi.dptr(fop._xch_send), st), "p")
-        allgather_packed(fop.shard, fop._xch_send, fop._xch_all)
-        capi.check(lib.fdcap_opt_unpack_and_step_scale(h, ii, 10 ** 6, capi.dptr(fop._xch_all), 0, 1, st), "u")
-    else:
-        capi.check(lib.fdcap_opt_step(h, ii, 10 ** 6, st), "s")
-t1 = time.perf_counter(); torch.cuda.synchronize(); t2 = time.perf_counter()
-print(f"frames {N} exchange {group is not None}: host issued 400 phase-1 iterations in {1e3*(t1-t0):.1f} ms ({(t1-t0)*1e6/400:.1f} us/iter), GPU done after {1e3*(t2-t0):.1f} ms ({(t2-t0)*1e6/400:.1f} us/iter)")
+for overlap in ((False, True, False, True) if group is not None else (False,)):
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for ii in range(400):
+        st = capi.current_stream()
+        capi.check(lib.fdcap_opt_backward(h, ii, 10 ** 6, 0, st), "b")
+        if group is not None:
+            capi.check(lib.fdcap_opt_step_rows_and_pack(h, ii, 10 ** 6, capi.dptr(fop._xch_send), st), "p")
+            ahead = (lambda ii=ii, st=st: capi.check(lib.fdcap_opt_forward_ahead(h, ii + 1, 10 ** 6, 0, st), "a")) if overlap else None
+            allgather_packed(fop.shard, fop._xch_send, fop._xch_all, ahead)
+            capi.check(lib.fdcap_opt_unpack_and_step_scale(h, ii, 10 ** 6, capi.dptr(fop._xch_all), 0, 1, st), "u")
+        else:
+            capi.check(lib.fdcap_opt_step(h, ii, 10 ** 6, st), "s")
+    t1 = time.perf_counter(); torch.cuda.synchronize(); t2 = time.perf_counter()
+    print(f"frames {N} exchange {group is not None} forward-ahead {overlap}: host issued 400 phase-1 iterations in {1e3*(t1-t0):.1f} ms ({(t1-t0)*1e6/400:.1f} us/iter), GPU done after {1e3*(t2-t0):.1f} ms ({(t2-t0)*1e6/400:.1f} us/iter)")
 if group is not None:
     dist.destroy_process_group()
