@@ -337,6 +337,8 @@ def main():
     assert np.isfinite(res[0].numpy()).all()
     nc, ns, nl = len(vid), len(scene), fop.shard.n_local
     out = base_line(args, rk, nc, N * args.steps / dt, dt)
+    if rk.world > 1:          # which iteration schedule rank 0's last fit kept after timing both (same results either way)
+        out["config"]["exchange_schedule"] = "next forward's head under the all-gather" if getattr(fop, "exchange_overlap", False) else "plain"
     if args.value_only:
         return rk.finish(out)
     # Like-for-like figure (never `value`): the same step with EVERY loss term evaluated in EVERY iteration, as the reference's
