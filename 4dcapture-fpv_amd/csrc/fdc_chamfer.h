@@ -503,9 +503,12 @@ struct NNCache {
     float4* anchor;           // [WPG][nq] {a_i, R_i (validity margin already taken off)}
     float slack;              // metres
     // launch order (one-wave workgroups only; scheduling, never results): the workgroups are dispatched in blockIdx order, and a
-    // launch ends with whatever started last -- so the groups with the most work go first (nn_order_kernel, NNOrder below)
-    const int* order = nullptr;   // [workgroups] launch position -> query group; null: identity
-    int* work = nullptr;          // [groups] work items the group scanned in this launch (written when set)
+    // launch ends with whatever started last -- so the groups with the most work go first (nn_order_kernel, NNOrder below).
+    // The tables sit behind hdr in the same allocation (G = ceil(nq / 32) ints each): hdr + 4 G: work items scanned by the
+    // workgroup at launch position b in this launch; hdr + 5 G, hdr + 6 G: launch position -> group, two tables written in turn.
+    // Indexed by POSITION because blockIdx lives in a scalar register for free: the one-wave kernel sits at its 64-register
+    // limit, and keeping the group index (or two more pointer arguments) alive for this store cost 8-10 spilled registers.
+    int order_mode = 0;       // 0: off, 1: record the work items, 2 / 3: record + launch in the order of table 0 / 1
 };
 
 template <int NQ, int WPG, int WPB = 4>
@@ -542,7 +545,7 @@ __global__ __launch_bounds__(64 * WPB, NQ == 1 ? FDC_ST4_OCC : FDC_ST4_OCC2) voi
     // r3: plain round-robin over the XCDs (workgroup b runs on XCD b % 8).  Contiguous frame ranges per XCD leave the XCDs with
     // 13 % different amounts of work (frames near the floor cost more) and the launch ends with its slowest XCD; interleaved,
     // every XCD sees every part of the clip -- consecutive frames share their scene cells anyway.  72.57 -> 72.31 ms per step.
-    const int wg = (cache.order != nullptr && (int)blockIdx.x < nwg) ? cache.order[blockIdx.x] : (int)blockIdx.x; (void)per_xcd;
+    const int wg = (cache.order_mode >= 2 && (int)blockIdx.x < nwg) ? cache.hdr[(3 + cache.order_mode) * ((nq + 31) / 32) + (int)blockIdx.x] : (int)blockIdx.x; (void)per_xcd;
 #endif
     const int group = wg * GPW + gslot;
     const bool idle = wg >= nwg || group >= ngroups;            // idle waves still meet the barrier below
@@ -866,9 +869,6 @@ __global__ __launch_bounds__(64 * WPB, NQ == 1 ? FDC_ST4_OCC : FDC_ST4_OCC2) voi
         FDC_STAT(7, lane == 0 ? nout : 0);
     }
     TL_STAMP(2);
-    // (the launch order's key.  Also tried: + a bonus when the list was built this launch -- no better, such a wave does not
-    // build again next launch --, and the wave's measured main-loop time -- worse, 70.4 vs 68.6 us: it follows contention)
-    if (cache.work != nullptr && lane == 0 && !idle) cache.work[cidx] = nsurv;
 #ifdef FDC_NN_TIMELINE
     const int tl_nsurv = nsurv;
 #endif
@@ -1083,6 +1083,10 @@ __global__ __launch_bounds__(64 * WPB, NQ == 1 ? FDC_ST4_OCC : FDC_ST4_OCC2) voi
         }
     }
     TL_STAMP(3);
+    // (the launch order's key: the work items scanned, filed under the launch position.  Also tried as keys: + a bonus when the list was built this launch -- no
+    // better, such a wave does not build again next launch --, and the wave's measured main-loop time -- worse, 70.4 vs 68.6 us:
+    // it follows contention)
+    if (cache.order_mode != 0 && lane == 0 && !idle) cache.hdr[4 * ((nq + 31) / 32) + (int)blockIdx.x] = nsurv;
     // the two halves of a wave hold different scene rows of the same queries; then the four waves meet in LDS
 #pragma unroll
     for (int n = 0; n < NQ; ++n) {
@@ -1255,7 +1259,9 @@ static inline int nn_pick_nsplit(int nq, int nt, bool culled = false) {
 
 // Launch order of nn_stream4_kernel's one-wave workgroups: position -> group, most work items first (counting sort on the
 // counts the last launch wrote; ties in no particular order -- the order decides when a group runs, never what it returns).
-__global__ __launch_bounds__(1024) void nn_order_kernel(const int* __restrict__ work, int n, int* __restrict__ order) {
+__global__ __launch_bounds__(1024) void nn_order_kernel(const int* __restrict__ work, int n, const int* __restrict__ prev,
+                                                        int* __restrict__ order) {
+    // work[b]: items scanned by the workgroup at launch position b, which served group prev[b] (prev == nullptr: group b)
     // a histogram per wave: most groups fall into a dozen bins, and LDS atomics on one address serialise
     __shared__ int cnt[16][256], base[256];
     const int tid = threadIdx.x, w = tid >> 6;
@@ -1279,15 +1285,15 @@ __global__ __launch_bounds__(1024) void nn_order_kernel(const int* __restrict__ 
     __syncthreads();
     for (int i = tid; i < n; i += 1024) {
         const int k = 255 - min(max(work[i], 0), 255);
-        order[base[k] + atomicAdd(&cnt[w][k], 1)] = i;
+        order[base[k] + atomicAdd(&cnt[w][k], 1)] = prev ? prev[i] : i;
     }
 }
-// host-side bookkeeping of the launch order (owned by the optimiser state; buffers hold one int per 32-query group)
+// host-side bookkeeping of the launch order (owned by the optimiser state)
 struct NNOrder {
-    int* work = nullptr;
-    int* order = nullptr;
-    int sorted_groups = 0;      // number of groups `order` was last sorted for (0: never)
-    int age = 0;                // launches since then
+    bool on = false;            // the cache's hdr allocation has room for the tables (7 ints per 32-query group)
+    int sorted_groups = 0;      // number of groups the current table was sorted for (0: none yet)
+    int cur = 0;                // which of the two order tables is current
+    int age = 0;                // launches since it was written
     int every = 16;             // re-sort period (work per group drifts over tens of iterations)
 };
 
@@ -1335,16 +1341,19 @@ static inline hipError_t nn_search(const float* q, int nq, const NNTarget& T, fl
             const int nwg = (groups * wpg + wpb - 1) / wpb;
             const dim3 grid((nwg + 7) / 8 * 8);
             NNCache nc = cache ? *cache : NNCache{nullptr, nullptr, nullptr, 0.f};
-            const bool ordered = ord != nullptr && ord->work != nullptr && ord->every > 0 && nqv == 1 && wpg == 1 && wpb == 1;
-            nc.work = ordered ? ord->work : nullptr;
-            nc.order = (ordered && ord->sorted_groups == groups) ? ord->order : nullptr;
+            const bool ordered = ord != nullptr && ord->on && nc.hdr != nullptr && ord->every > 0 && nqv == 1 && wpg == 1 && wpb == 1;
+            nc.order_mode = !ordered ? 0 : (ord->sorted_groups == groups ? 2 + ord->cur : 1);
 #define FDC_ST4(NQV, WPGV) hipLaunchKernelGGL((nn_stream4_kernel<NQV, WPGV>), grid, dim3(256), 0, st, q, nq, T, seed, seedpt, dist, idx, nc)
             if (nqv == 2 && wpg == 4) FDC_ST4(2, 4); else if (nqv == 2 && wpg == 2) FDC_ST4(2, 2); else if (nqv == 2) FDC_ST4(2, 1);
             else if (wpg == 4) FDC_ST4(1, 4); else if (wpg == 2) FDC_ST4(1, 2); else if (wpb == 4) FDC_ST4(1, 1);
             else hipLaunchKernelGGL((nn_stream4_kernel<1, 1, 1>), grid, dim3(64), 0, st, q, nq, T, seed, seedpt, dist, idx, nc);
 #undef FDC_ST4
             if (ordered && (ord->sorted_groups != groups || ++ord->age >= ord->every)) {
-                hipLaunchKernelGGL(nn_order_kernel, dim3(1), dim3(1024), 0, st, ord->work, groups, ord->order);
+                const bool had = nc.order_mode >= 2;
+                const int nxt = had ? 1 - ord->cur : 0;
+                hipLaunchKernelGGL(nn_order_kernel, dim3(1), dim3(1024), 0, st, (const int*)(nc.hdr + 4 * groups), groups,
+                                   had ? (const int*)(nc.hdr + (5 + ord->cur) * groups) : (const int*)nullptr, nc.hdr + (5 + nxt) * groups);
+                ord->cur = nxt;
                 ord->sorted_groups = groups;
                 ord->age = 0;
             }

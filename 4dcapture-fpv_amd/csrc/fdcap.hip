@@ -1323,8 +1323,7 @@ struct OptState {
     DevBuf<unsigned short> nnc_ids;
     DevBuf<int> nnc_hdr;
     DevBuf<float4> nnc_anchor;
-    DevBuf<int> nnc_work, nnc_order;       // launch order of the in-loop NN launch (fdc_chamfer.h NNOrder); FDCAP_NN_ORDER=0 turns it off, =k re-sorts every k launches
-    NNOrder nn_order;
+    NNOrder nn_order;                      // launch order of the in-loop NN launch (fdc_chamfer.h NNOrder; its tables sit behind nnc_hdr); FDCAP_NN_ORDER=0 turns it off, =k re-sorts every k launches
     float nnc_slack = 0.03f;  // metres; FDCAP_NN_CACHE_SLACK overrides, 0 disables the cache
     // fdcap_opt_nn_timing: HIP events around every in-loop NN launch of a fit (the bench's roofline figure)
     bool nn_timing = false;
@@ -2176,7 +2175,6 @@ void fdcap_opt_destroy(fdcap_ctx* c) {
     o->dctD.release(); o->dctCoef.release(); o->dctM.release(); o->dctV.release(); o->adam_tab.release();
     o->idx.release(); o->pi.release(); o->seedpt.release(); o->kp2d.release();
     o->nnc_ids.release(); o->nnc_hdr.release(); o->nnc_anchor.release();
-    o->nnc_work.release(); o->nnc_order.release();
     for (hipEvent_t e : o->nn_ev) (void)hipEventDestroy(e);
     o->nn_ev.clear();
     delete o;
@@ -2237,26 +2235,19 @@ int fdcap_opt_create(fdcap_ctx* c, const fdcap_opt_config* cfg, float* rows_x, f
     if (!err && o->contact_on) {
         if (const char* e = getenv("FDCAP_SKIN_VEC")) o->skin_vec = e[0] != '0';
         if (const char* e = getenv("FDCAP_NN_CACHE_SLACK")) o->nnc_slack = (float)atof(e);
-        if (o->nnc_slack > 0.f) {                                        // groups of 32 queries x up to 4 waves per group
-            const size_t ng4 = ((size_t)nq_all + 31) / 32 * 4;
-            hipError_t e_ = o->nnc_ids.ensure(ng4 * NN_CACHE_CAP);
-            if (e_ == hipSuccess) e_ = o->nnc_hdr.ensure(ng4);
-            if (e_ == hipSuccess) e_ = o->nnc_anchor.ensure((size_t)4 * nq_all);
-            if (e_ == hipSuccess) e_ = hipMemset(o->nnc_hdr.p, 0xFF, ng4 * sizeof(int));                       // -1: nothing kept
-            if (e_ == hipSuccess) e_ = hipMemset(o->nnc_anchor.p, 0, (size_t)4 * nq_all * sizeof(float4));
-            if (e_ != hipSuccess) err = (int)e_;
-        }
         int every = 16;
         if (const char* e = getenv("FDCAP_NN_ORDER")) every = atoi(e);
-        if (!err && every > 0) {
-            const size_t ng = ((size_t)nq_all + 31) / 32;
-            hipError_t e_ = o->nnc_work.ensure(ng);
-            if (e_ == hipSuccess) e_ = o->nnc_order.ensure(ng);
-            if (e_ == hipSuccess) e_ = hipMemset(o->nnc_work.p, 0, ng * sizeof(int));
+        o->nn_order = NNOrder{};
+        if (o->nnc_slack > 0.f) {                                        // groups of 32 queries x up to 4 waves per group
+            const size_t ng = ((size_t)nq_all + 31) / 32, ng4 = ng * 4;
+            hipError_t e_ = o->nnc_ids.ensure(ng4 * NN_CACHE_CAP);
+            if (e_ == hipSuccess) e_ = o->nnc_hdr.ensure(ng4 + 3 * ng);                                        // + work counts [ng] + two launch-order tables [ng]
+            if (e_ == hipSuccess) e_ = o->nnc_anchor.ensure((size_t)4 * nq_all);
+            if (e_ == hipSuccess) e_ = hipMemset(o->nnc_hdr.p, 0xFF, ng4 * sizeof(int));                       // -1: nothing kept
+            if (e_ == hipSuccess) e_ = hipMemset(o->nnc_hdr.p + ng4, 0, 3 * ng * sizeof(int));
+            if (e_ == hipSuccess) e_ = hipMemset(o->nnc_anchor.p, 0, (size_t)4 * nq_all * sizeof(float4));
             if (e_ != hipSuccess) err = (int)e_;
-            o->nn_order = NNOrder{o->nnc_work.p, o->nnc_order.p, 0, 0, every};
-        } else {
-            o->nn_order = NNOrder{};
+            if (every > 0) { o->nn_order.on = true; o->nn_order.every = every; }
         }
     }
     if (!err) {
