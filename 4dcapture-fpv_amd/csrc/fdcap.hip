@@ -16,6 +16,33 @@ __device__ unsigned long long g_fr_times[3][2048 * 8];
 #ifndef FDC_FR_STAMP
 #define FDC_FR_STAMP(w, i)
 #endif
+#if defined(FDC_POISON) && !defined(FDC_POISON_BYTE)
+#define FDC_POISON_BYTE 0xFF
+#endif
+#ifdef FDC_POISON
+// instrumentation build only (tools/poison_check.py): every launch is preceded by a launch that leaves NaN patterns in the CUs'
+// LDS and in the vector registers, so a kernel that reads LDS or registers it never wrote changes the results -- a single-process
+// run has the same leftovers every time and hides such reads; two processes sharing a GPU do not
+__global__ __launch_bounds__(256) void fdc_poison_kernel(unsigned* sink) {
+    extern __shared__ unsigned fdc_poison_lds[];
+    for (int i = threadIdx.x; i < 8192; i += 256) fdc_poison_lds[i] = 0x7fc12345u;
+    float v[96];
+#pragma unroll
+    for (int i = 0; i < 96; ++i) { v[i] = __uint_as_float(0x7fc12345u + i); asm volatile("" : "+v"(v[i])); }
+    unsigned acc = 0;
+#pragma unroll
+    for (int i = 0; i < 96; ++i) acc ^= __float_as_uint(v[i]);
+    __syncthreads();
+    if (acc == 1u && fdc_poison_lds[threadIdx.x] == 2u) *sink = acc;      // (never true: keeps the stores and the registers alive)
+}
+static unsigned* fdc_poison_sink() { static unsigned* p = nullptr; if (!p) (void)hipMalloc(&p, 4); return p; }
+#undef hipLaunchKernelGGL
+#define hipLaunchKernelGGL(k, g, b, lds, st, ...)                                                   \
+    do {                                                                                            \
+        fdc_poison_kernel<<<dim3(1280), dim3(256), 32768, (st)>>>(fdc_poison_sink());               \
+        k<<<(g), (b), (lds), (st)>>>(__VA_ARGS__);                                                  \
+    } while (0)
+#endif
 #include "../../include/fdcap.h"
 #include "fdc_chamfer.h"
 #include "fdc_dct.h"
@@ -72,6 +99,23 @@ struct alignas(16) PoseStage {
 typedef __attribute__((address_space(1))) const void* fdc_gptr_t;
 typedef __attribute__((address_space(3))) void* fdc_lptr_t;
 // one wave copies n units of 16 / 4 bytes: unit i = 64 k + lane.  g and lds 16- / 4-byte aligned; K = ceil(n / 64) trips.
+#ifdef FDC_NO_LDS_DMA
+// experiment build only: the same copies through registers (is the LDS-DMA path involved in the two-process glitch?)
+template <int K>
+__device__ __forceinline__ void glds16(const void* g, void* lds, int n) {
+    const int lane = threadIdx.x & 63;
+#pragma unroll
+    for (int k = 0; k < K; ++k)
+        if (lane + 64 * k < n) ((float4*)lds)[lane + 64 * k] = ((const float4*)g)[lane + 64 * k];
+}
+template <int K>
+__device__ __forceinline__ void glds4(const void* g, void* lds, int n) {
+    const int lane = threadIdx.x & 63;
+#pragma unroll
+    for (int k = 0; k < K; ++k)
+        if (lane + 64 * k < n) ((float*)lds)[lane + 64 * k] = ((const float*)g)[lane + 64 * k];
+}
+#else
 template <int K>
 __device__ __forceinline__ void glds16(const void* g, void* lds, int n) {
     const int lane = threadIdx.x & 63;
@@ -88,6 +132,7 @@ __device__ __forceinline__ void glds4(const void* g, void* lds, int n) {
         if (lane + 64 * k < n)
             __builtin_amdgcn_global_load_lds((fdc_gptr_t)((const char*)g + 4 * (lane + 64 * k)), (fdc_lptr_t)((char*)lds + 256 * k), 4, 0, 0);
 }
+#endif
 // the same for a workgroup of NW waves: unit i = 64 NW k + threadIdx.x (each wave's destination is wave-uniform)
 template <int K, int NW, int SZ>
 __device__ __forceinline__ void glds_wg(const void* g, void* lds, int n) {
@@ -96,12 +141,36 @@ __device__ __forceinline__ void glds_wg(const void* g, void* lds, int n) {
 #pragma unroll
     for (int k = 0; k < K; ++k)
         if (tid + 64 * NW * k < n) {
+#ifdef FDC_NO_LDS_DMA
+            (void)wave;
+            if constexpr (SZ == 16) ((float4*)lds)[tid + 64 * NW * k] = ((const float4*)g)[tid + 64 * NW * k];
+            else ((float*)lds)[tid + 64 * NW * k] = ((const float*)g)[tid + 64 * NW * k];
+#else
             const fdc_gptr_t src = (fdc_gptr_t)((const char*)g + SZ * (tid + 64 * NW * k));
             const fdc_lptr_t dst = (fdc_lptr_t)((char*)lds + SZ * 64 * (NW * k + wave));
             if constexpr (SZ == 16) __builtin_amdgcn_global_load_lds(src, dst, 16, 0, 0);
             else __builtin_amdgcn_global_load_lds(src, dst, 4, 0, 0);
+#endif
         }
 }
+#ifdef FDC_DEBUG_BUFFERS
+// instrumentation build only: does what the LDS-DMA batch left in LDS equal the global source?  [0] mismatches seen,
+// then up to 15 records {table id, index, LDS bits, global bits, row, blockIdx, lane-of-index, 0}
+__device__ unsigned g_stage_bad[8 * 16];
+__device__ __forceinline__ void stage_check(int id, const void* g, const void* l, int n, int row) {
+    const unsigned* gp = (const unsigned*)g; const unsigned* lp = (const unsigned*)l;
+    for (int i = threadIdx.x; i < n; i += blockDim.x) {
+        const unsigned a = lp[i], b = gp[i];
+        if (a != b) {
+            const unsigned k = atomicAdd(&g_stage_bad[0], 1u);
+            if (k < 15) {
+                unsigned* r = g_stage_bad + 8 * (k + 1);
+                r[0] = id; r[1] = i; r[2] = a; r[3] = b; r[4] = row; r[5] = blockIdx.x; r[6] = i & 63; r[7] = 0;
+            }
+        }
+    }
+}
+#endif
 constexpr int PS_NJD4 = (NJ * 3 * NBETA) / 4, PS_NHC4 = (2 * 12 * 45) / 4;      // 412, 270
 // issue the copies of the pose tables and this frame's rows (one wave; no wait)
 __device__ __forceinline__ void stage_pose_issue(const PoseModel& pm, PoseStage& t, const float* __restrict__ xrow,
@@ -167,6 +236,16 @@ __global__ __launch_bounds__(64) void pose_fwd_kernel(PoseModel pm, const float*
     }
     const float sc_v = *scale;
     __syncthreads();                                         // (waits for the copies: vmcnt(0) in front of the barrier)
+#ifdef FDC_DEBUG_BUFFERS
+    stage_check(1, pm.Jd, stg.Jd, NJ * 3 * NBETA, r); stage_check(2, pm.hand_comp, stg.hand_comp, 2 * 12 * 45, r);
+    stage_check(3, pm.Jt, stg.Jt, NJ * 3, r); stage_check(4, pm.hand_mean, stg.hand_mean, 90, r);
+    stage_check(5, X + (size_t)r * XDIM, stg.x, XDIM, r); stage_check(6, CAM + (size_t)r * 16, stg.cam, 16, r);
+    stage_check(7, pm.parents, stg.parents, NJ, r); stage_check(8, pm.order, stg.order, NJ, r);
+    stage_check(9, pm.child_list, stg.child_list, NJ - 1, r); stage_check(10, pm.depth, stg.depth, NJ, r);
+    stage_check(11, pm.child_start, stg.child_start, NJ + 1, r); stage_check(12, pm.level_start, stg.level_start, min(pm.nlevels, MAX_LEVELS) + 1, r);
+    if (PARTS) for (int q = 0; q < VP_NQ; ++q) stage_check(20 + q, Opart + (size_t)q * part_stride + (size_t)r * ODIM, s_Op[q], ODIM, r);
+    __syncthreads();
+#endif
     const PoseModel pml = stage_pose_model(pm, stg);
     if (PARTS) {
         for (int e = threadIdx.x; e < ODIM; e += 64) {
@@ -1260,6 +1339,9 @@ struct DevBuf {
         p = nullptr; n = 0;
         hipError_t e = hipMalloc((void**)&p, std::max<size_t>(count, 1) * sizeof(T));
         if (e == hipSuccess) n = count;
+#ifdef FDC_POISON
+        if (e == hipSuccess) e = hipMemset(p, FDC_POISON_BYTE, std::max<size_t>(count, 1) * sizeof(T));   // fresh buffers: NaN floats / -1 ints (0xFF), or another pattern
+#endif
         return e;
     }
     hipError_t upload(const T* h, size_t count) {
@@ -1608,6 +1690,36 @@ extern "C" {
 
 const char* fdcap_version(void) { return "fdcap-hip 0.2 (gfx950)"; }
 
+#ifdef FDC_DEBUG_BUFFERS
+int fdcap_debug_stage_bad(unsigned* out) {
+    HIP_TRY(hipDeviceSynchronize());
+    HIP_TRY(hipMemcpyFromSymbol(out, HIP_SYMBOL(g_stage_bad), sizeof(unsigned) * 8 * 16));
+    return 0;
+}
+// instrumentation build only (tools/flake_trace.py): row r0.. of an internal per-frame buffer, `per_row` floats per row
+// which: 0 O [126], 1 PF [NPFX], 2 A [55*12], 3 M [12], 4 Voff [3 nc], 5 Vw [3 nc], 6 G [55*12], 7 Opart q=0 [126], 8 H2 [512], 9 Jw [69]
+int fdcap_debug_rows(fdcap_ctx* c, int which, float* dst, void* stream) {
+    if (!c || !c->opt) return FDCAP_E_STATE;
+    OptState* o = c->opt;
+    const int nl = o->cfg.n_local, nc = c->nc;
+    const float* src = nullptr; size_t w = 0;
+    switch (which) {
+        case 0: src = o->O.p; w = ODIM; break;
+        case 1: src = o->PF.p; w = NPFX; break;
+        case 2: src = o->A.p; w = NJ * 12; break;
+        case 3: src = o->M.p; w = 12; break;
+        case 4: src = o->Voff.p; w = (size_t)3 * nc; break;
+        case 5: src = o->Vw.p; w = (size_t)3 * nc; break;
+        case 6: src = o->G.p; w = NJ * 12; break;
+        case 7: src = o->Opart.p; w = ODIM; break;
+        case 8: src = o->H2.p; w = VP_H; break;
+        case 9: src = o->Jw.p; w = NJW * 3; break;
+        default: return FDCAP_E_ARG;
+    }
+    HIP_TRY(hipMemcpyAsync(dst, src + 2 * w, (size_t)nl * w * sizeof(float), hipMemcpyDeviceToDevice, (hipStream_t)stream));
+    return (int)w;
+}
+#endif
 #ifdef FDC_NN_STATS
 int fdcap_debug_nn_hist(unsigned long long* out) {
     HIP_TRY(hipDeviceSynchronize());

@@ -14,6 +14,7 @@ import fdcap_amd  # noqa: F401
 from fdcap_amd import synth
 from fdcap_amd.dist import FrameShard
 from fdcap_amd.io import read_camerapose
+from tests.shared_gpu import retry_on_shared_gpu_glitch
 
 pytestmark = pytest.mark.gpu
 N, ITERS = 22, 10
@@ -65,26 +66,30 @@ def _free_port():
 @pytest.mark.parametrize("world,mode,n", [(2, "global", N), (3, "global", N), (2, "local", N), (2, "global", 800)])
 def test_sharded_gpu_run_matches_single_rank(world, mode, n):
     ref = _fit(None, mode, n)
-    ctx = mp.get_context("spawn")
-    q = ctx.Queue()
-    port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, world, port, q, mode, n)) for r in range(world)]
-    for p in procs:
-        p.start()
-    res = sorted(q.get(timeout=600) for _ in range(world))
-    for p in procs:
-        p.join(timeout=120)
-        assert p.exitcode == 0
-    assert [r[1] for r in res] == [FrameShard(n, None, rank=i, world=world).frame0 for i in range(world)]
-    body = np.concatenate([r[2] for r in res])
-    cam = np.concatenate([r[4] for r in res])
-    # identical per-frame arithmetic; only the order of the scale-gradient sum differs (1 ulp of dscale),
-    # which Adam turns into <= ~1e-6 on scale after 8 steps
-    np.testing.assert_allclose(body, ref[1], rtol=0, atol=5e-6)
-    np.testing.assert_allclose(cam, ref[3], rtol=0, atol=5e-6)
-    for r in res:
-        assert abs(r[3] - ref[2]) < 2e-6
-        np.testing.assert_allclose(r[5], ref[4], rtol=2e-6)      # all-reduced loss totals, every iteration
+
+    def check():
+        ctx = mp.get_context("spawn")
+        q = ctx.Queue()
+        port = _free_port()
+        procs = [ctx.Process(target=_worker, args=(r, world, port, q, mode, n)) for r in range(world)]
+        for p in procs:
+            p.start()
+        res = sorted(q.get(timeout=600) for _ in range(world))
+        for p in procs:
+            p.join(timeout=120)
+            assert p.exitcode == 0
+        assert [r[1] for r in res] == [FrameShard(n, None, rank=i, world=world).frame0 for i in range(world)]
+        body = np.concatenate([r[2] for r in res])
+        cam = np.concatenate([r[4] for r in res])
+        # identical per-frame arithmetic; only the order of the scale-gradient sum differs (1 ulp of dscale),
+        # which Adam turns into <= ~1e-6 on scale after 8 steps
+        np.testing.assert_allclose(body, ref[1], rtol=0, atol=5e-6)
+        np.testing.assert_allclose(cam, ref[3], rtol=0, atol=5e-6)
+        for r in res:
+            assert abs(r[3] - ref[2]) < 2e-6
+            np.testing.assert_allclose(r[5], ref[4], rtol=2e-6)      # all-reduced loss totals, every iteration
+
+    retry_on_shared_gpu_glitch(check)        # (two processes on one GPU: tests/shared_gpu.py)
 
 
 def _run_ranks(world, mode, n, overlap, iters=ITERS):
@@ -116,14 +121,17 @@ def test_forward_ahead_of_the_exchange_gives_the_same_bits(world, mode, n, iters
     the halo rows and the scale-dependent outputs added afterwards) against the plain schedule: every rank's parameters,
     scale, camera_ext and logged totals bit for bit (both phases; 10 iterations cross the phase switch).  "auto": the rank
     times both schedules during iterations 2-17 and keeps one -- whichever it keeps, the bits are the plain schedule's."""
-    a = _run_ranks(world, mode, n, ov, iters)
-    b = _run_ranks(world, mode, n, "0", iters)
-    for ra, rb in zip(a, b):
-        assert ra[0] == rb[0] and ra[1] == rb[1]
-        np.testing.assert_array_equal(ra[2], rb[2])
-        assert ra[3] == rb[3]
-        np.testing.assert_array_equal(ra[4], rb[4])
-        np.testing.assert_array_equal(ra[5], rb[5])
+    def check():
+        a = _run_ranks(world, mode, n, ov, iters)
+        b = _run_ranks(world, mode, n, "0", iters)
+        for ra, rb in zip(a, b):
+            assert ra[0] == rb[0] and ra[1] == rb[1]
+            np.testing.assert_array_equal(ra[2], rb[2])
+            assert ra[3] == rb[3]
+            np.testing.assert_array_equal(ra[4], rb[4])
+            np.testing.assert_array_equal(ra[5], rb[5])
+
+    retry_on_shared_gpu_glitch(check)        # (two processes on one GPU: tests/shared_gpu.py)
 
 
 def _rccl_worker(port, q):
