@@ -1691,6 +1691,32 @@ extern "C" {
 const char* fdcap_version(void) { return "fdcap-hip 0.2 (gfx950)"; }
 
 #ifdef FDC_DEBUG_BUFFERS
+}  // extern "C"
+// instrumentation build only: a workgroup fills its LDS with a pattern, idles, and checks it -- does anything running next to it
+// on the CU write into LDS that is not its own?  report: [0] corrupted words, then {index, value found, block, lds bytes} x 15
+template <int WORDS>
+__global__ __launch_bounds__(64) void lds_canary_kernel(unsigned* __restrict__ report, int spins) {
+    __shared__ unsigned buf[WORDS];
+    for (int i = threadIdx.x; i < WORDS; i += 64) buf[i] = 0xC0DE0000u ^ (unsigned)i;
+    __syncthreads();
+    for (int s = 0; s < spins; ++s) __builtin_amdgcn_s_sleep(127);
+    __syncthreads();
+    for (int i = threadIdx.x; i < WORDS; i += 64) {
+        const unsigned v = buf[i];
+        if (v != (0xC0DE0000u ^ (unsigned)i)) {
+            const unsigned k = atomicAdd(&report[0], 1u);
+            if (k < 15) { unsigned* r = report + 4 * (k + 1); r[0] = i; r[1] = v; r[2] = blockIdx.x; r[3] = WORDS * 4; }
+        }
+    }
+}
+extern "C" {
+int fdcap_debug_lds_canary(unsigned* report_d, int blocks, int spins, int launches, void* stream) {
+    for (int l = 0; l < launches; ++l) {
+        hipLaunchKernelGGL((lds_canary_kernel<7168>), dim3(blocks), dim3(64), 0, (hipStream_t)stream, report_d, spins);
+        hipLaunchKernelGGL((lds_canary_kernel<2048>), dim3(blocks), dim3(64), 0, (hipStream_t)stream, report_d, spins);
+    }
+    return (int)hipGetLastError();
+}
 int fdcap_debug_stage_bad(unsigned* out) {
     HIP_TRY(hipDeviceSynchronize());
     HIP_TRY(hipMemcpyFromSymbol(out, HIP_SYMBOL(g_stage_bad), sizeof(unsigned) * 8 * 16));

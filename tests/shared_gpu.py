@@ -1,21 +1,25 @@
 """Helpers for the tests that run TWO rank processes on the ONE GPU of the test box.
 
-Observed in round 3 (tools/flake_trace.py, tools/contention_probe.py): when two processes run this library's
-per-frame pose kernels on the same GPU at the same time, a run occasionally (0-30 % of 10-iteration runs, depending on the box)
-comes back with ONE wrong word in the joint-transform scratch of one frame -- always a finger joint 48-54 of the right hand,
-i.e. lanes 48-54 of the one-wave workgroup -- which is invisible unless the joint's own rotation is hit, in which case the pose
-features move that frame's vertices by ~1e-4 m for one iteration.  It never happens with one process per GPU (the product's
-arrangement: thousands of bit-identical single-process runs, also next to a second process that runs other kernels), it does
-not depend on the sharded schedule, on LDS-DMA staging, on poisoned LDS / registers / fresh buffers, or on the virtual
-addresses of the two processes, and it was not root-caused.  Two ranks sharing a GPU exist only in these tests, so a
-comparison that fails is repeated before it counts."""
+Round 3 found that such runs were not perfectly repeatable, and why (tools/flake_trace.py, tools/two_stream_trace.py; DESIGN.md
+section 7): on the MI355X boxes of this pool a packed fp32 instruction (v_pk_fma_f32 / v_pk_mul_f32 / v_pk_add_f32) now and then
+returns a wrong low element in lanes 48-63 while ANOTHER kernel keeps the matrix pipe of the same CU busy -- a second stream
+or a second process running this library's MFMA kernels next to its one-wave pose kernels.  One process with one stream (the
+product's arrangement) never has two kernels resident at once and never showed it.  The library is now built without packed
+fp32 instructions (__graft_entry__.build), after which 0 of 280 traced two-rank / two-stream fits differ (before: 23-30 of 30).
+
+The comparison helper below stays as a tripwire: a two-rank comparison that fails is run once more, and a pass on the second
+attempt is REPORTED (a warning), not hidden."""
+import warnings
 
 
-def retry_on_shared_gpu_glitch(check, attempts=3):
+def retry_on_shared_gpu_glitch(check, attempts=2):
     """Run `check()` (which raises AssertionError on a mismatch) up to `attempts` times; the last failure propagates."""
     for k in range(attempts):
         try:
-            return check()
+            out = check()
+            if k:
+                warnings.warn("a two-rank comparison on the shared GPU passed only on attempt %d (tests/shared_gpu.py)" % (k + 1))
+            return out
         except AssertionError:
             if k == attempts - 1:
                 raise
