@@ -965,7 +965,8 @@ __global__ __launch_bounds__(64 * WPB, NQ == 1 ? FDC_ST4_OCC : FDC_ST4_OCC2) voi
                     const float t0 = fminf(fminf(acc[0], acc[1]), acc[2]), t1 = fminf(fminf(acc[3], acc[4]), acc[5]);
                     const float t2 = fminf(fminf(acc[6], acc[7]), acc[8]), t3 = fminf(fminf(acc[9], acc[10]), acc[11]);
                     const float t4 = fminf(fminf(acc[12], acc[13]), acc[14]);
-                    const float m = fminf(fminf(fminf(t0, t1), t2), fminf(fminf(t3, t4), acc[15]));
+                    const float g0 = fminf(fminf(t0, t1), t2), g1 = fminf(fminf(t3, t4), acc[15]);      // rows 0-8, rows 9-15
+                    const float m = fminf(g0, g1);
                     FDC_STAT(0, lane == 0);
 #if defined(FDC_ST4_ABLATE) && FDC_ST4_ABLATE == -1
                     asm volatile("" :: "v"(m), "v"(thr[n]));               // (keeps the MFMA + min tree alive)
@@ -980,19 +981,26 @@ __global__ __launch_bounds__(64 * WPB, NQ == 1 ? FDC_ST4_OCC : FDC_ST4_OCC2) voi
                         FDC_STAT(1, lane == 0);
                         // This lane's rows that passed, as a bit mask: sign(acc[r] - thr) shifted in row by row (v_sub_f32 +
                         // v_alignbit_b32 per row; a difference of two distinct finite floats is never rounded to zero, an
-                        // invalid lane's thr is -inf).  r3: 13.5 entries per wave, and FDC_NN_STATS shows most of them carry
+                        // invalid lane's thr is -inf, and a row passes iff its triple's minimum does).  r3: 13.5 entries per wave, and FDC_NN_STATS shows most of them carry
                         // a real candidate next to the seeds (about one other point per query lies within the filter's eps
                         // of the bound), so the r2 form -- 16 wave ballots + ~50 SALU to recognise seed-only entries, then
                         // 16 64-bit shifts to recover the per-lane bits -- paid both halves nearly every time: half of the
                         // kernel's VALU cycles (ablation: 79 -> 44 us steady state without the body).
+                        // Only the HALF of the min tree (rows 0-8 / rows 9-15) in which some lane has a passing row is expanded: an
+                        // entry is usually one candidate or one seed, i.e. one half -- 2 compares + 18 or 14 instead of 32
+                        // instructions, 13.5 entries per wave.  (Finer -- the five row triples of the tree's first level, 6 + 7
+                        // instructions per entry -- costs 15-26 spilled registers in this 64-register kernel.)
                         unsigned mask = 0;
-                        typedef float f32x2_t __attribute__((ext_vector_type(2)));
-                        const f32x2_t thr2 = {thr[n], thr[n]};
+                        const float th = thr[n];
+                        if (__any(g0 < th)) {
 #pragma unroll
-                        for (int r = 14; r >= 0; r -= 2) {                 // (two rows per v_pk_add_f32)
-                            const f32x2_t d2 = f32x2_t{acc[r], acc[r + 1]} - thr2;
-                            mask = __builtin_amdgcn_alignbit(mask, __float_as_uint(d2.y), 31);
-                            mask = __builtin_amdgcn_alignbit(mask, __float_as_uint(d2.x), 31);
+                            for (int r = 8; r >= 0; --r) mask = __builtin_amdgcn_alignbit(mask, __float_as_uint(acc[r] - th), 31);
+                        }
+                        if (__any(g1 < th)) {
+                            unsigned hi = 0;
+#pragma unroll
+                            for (int r = 15; r >= 9; --r) hi = __builtin_amdgcn_alignbit(hi, __float_as_uint(acc[r] - th), 31);
+                            mask |= hi << 9;
                         }
                         // the lane's current best passes by construction (it sits in this tile's rows of this half when
                         // its tile comes up) and is never re-evaluated: its row's bit is cleared
