@@ -1944,7 +1944,7 @@ int fdcap_set_scene(fdcap_ctx* c, const float* xyz, int64_t ns) {
         bounds[2 * ch + 1] = make_float4(bhi[0], bhi[1], bhi[2], 0.f);
     }
     // boxes of the quarter chunks (the k-d recursion goes on below the chunk, so 128 consecutive points are one node);
-    // a quarter past the end of the scene gets the empty box (+inf, -inf): at infinite distance from every query
+    // a quarter past the end of the scene gets the empty box (+inf, +inf): at infinite distance from every query (box_d2)
     std::vector<float4> qbounds((size_t)nchunk * 8);
     for (int64_t qc = 0; qc < nchunk * 4; ++qc) {
         int64_t a = qc * (MF_CH / 4), b = std::min<int64_t>(ns, a + MF_CH / 4);
@@ -1958,6 +1958,8 @@ int fdcap_set_scene(fdcap_ctx* c, const float* xyz, int64_t ns) {
                 float pad = 1e-6f + 1e-6f * std::max(fabsf(blo[k]), fabsf(bhi[k]));
                 blo[k] -= pad; bhi[k] += pad;
             }
+        else
+            for (int k = 0; k < 3; ++k) bhi[k] = INFINITY;
         qbounds[2 * qc] = make_float4(blo[0], blo[1], blo[2], 0.f);
         qbounds[2 * qc + 1] = make_float4(bhi[0], bhi[1], bhi[2], 0.f);
     }
