@@ -1304,7 +1304,7 @@ struct NNOrder {
     int sorted_groups = 0;      // number of groups the current table was sorted for (0: none yet)
     int cur = 0;                // which of the two order tables is current
     int age = 0;                // launches since it was written
-    int every = 16;             // re-sort period (work per group drifts over tens of iterations)
+    int every = 32;             // re-sort period (work per group drifts over tens of iterations)
 };
 
 // workspace: pd/pi [nsplit*nq]; seed: optional [nq] original indices (may alias idx: read before idx is rewritten)

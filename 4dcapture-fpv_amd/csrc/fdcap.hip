@@ -2375,7 +2375,7 @@ int fdcap_opt_create(fdcap_ctx* c, const fdcap_opt_config* cfg, float* rows_x, f
     if (!err && o->contact_on) {
         if (const char* e = getenv("FDCAP_SKIN_VEC")) o->skin_vec = e[0] != '0';
         if (const char* e = getenv("FDCAP_NN_CACHE_SLACK")) o->nnc_slack = (float)atof(e);
-        int every = 16;
+        int every = 32;
         if (const char* e = getenv("FDCAP_NN_ORDER")) every = atoi(e);
         o->nn_order = NNOrder{};
         if (o->nnc_slack > 0.f) {                                        // groups of 32 queries x up to 4 waves per group
