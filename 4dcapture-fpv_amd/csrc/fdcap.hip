@@ -328,6 +328,7 @@ __global__ __launch_bounds__(64) void pose_bwd_kernel(PoseModel pm, const float*
     }
     const float sc_v = *scale;
     __syncthreads();                                         // (waits for the copies: vmcnt(0) in front of the barrier)
+    FDC_FR_STAMP(1, 7);
     const PoseModel pml = stage_pose_model(pm, stg);
     if (dPF2) {
         const float* p2 = &sc.dR[0][0];

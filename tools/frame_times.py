@@ -34,6 +34,10 @@ for k, (nm, ph, ns) in enumerate(names):
     for i in range(ns - 1):
         d = t[:, i + 1] - t[:, i]
         print(f"   {ph[i]:32s} q50 {int(np.median(d)):6d}  q90 {int(np.quantile(d, 0.9)):6d}")
+    if nm == "pose_bwd":
+        tt = a[k, :N, :]; tt = tt[tt[:, 6] > 0]
+        if (tt[:, 7] > 0).all():
+            print(f"   (of the first phase: staging batch until the barrier q50 {int(np.median(tt[:, 7] - tt[:, 0]))} cycles)")
 
 if not hasattr(raw, "fdcap_debug_gemm_times"):
     sys.exit(0)
