@@ -159,7 +159,7 @@ __device__ __forceinline__ void glds_wg(const void* g, void* lds, int n) {
 __device__ unsigned g_stage_bad[8 * 16];
 __device__ __forceinline__ void stage_check(int id, const void* g, const void* l, int n, int row) {
     const unsigned* gp = (const unsigned*)g; const unsigned* lp = (const unsigned*)l;
-    for (int i = threadIdx.x; i < n; i += blockDim.x) {
+    for (int i = threadIdx.x; i < n; i += 64) {             // (called by the first wave only)
         const unsigned a = lp[i], b = gp[i];
         if (a != b) {
             const unsigned k = atomicAdd(&g_stage_bad[0], 1u);
@@ -172,22 +172,32 @@ __device__ __forceinline__ void stage_check(int id, const void* g, const void* l
 }
 #endif
 constexpr int PS_NJD4 = (NJ * 3 * NBETA) / 4, PS_NHC4 = (2 * 12 * 45) / 4;      // 412, 270
-// issue the copies of the pose tables and this frame's rows (one wave; no wait)
-__device__ __forceinline__ void stage_pose_issue(const PoseModel& pm, PoseStage& t, const float* __restrict__ xrow,
-                                                 const float* __restrict__ camrow) {
-    glds16<(PS_NJD4 + 63) / 64>(pm.Jd, t.Jd, PS_NJD4);
-    glds4<1>(pm.Jd + PS_NJD4 * 4, t.Jd + PS_NJD4 * 4, (NJ * 3 * NBETA) % 4);
-    glds16<(PS_NHC4 + 63) / 64>(pm.hand_comp, t.hand_comp, PS_NHC4);
-    glds4<3>(pm.Jt, t.Jt, NJ * 3);
-    glds4<2>(pm.hand_mean, t.hand_mean, 90);
-    glds4<2>(xrow, t.x, XDIM);
-    glds4<1>(camrow, t.cam, 16);
-    glds4<1>(pm.parents, t.parents, NJ);
-    glds4<1>(pm.order, t.order, NJ);
-    glds4<1>(pm.child_list, t.child_list, NJ - 1);
-    glds4<1>(pm.depth, t.depth, NJ);
-    glds4<1>(pm.child_start, t.child_start, NJ + 1);
-    glds4<1>(pm.level_start, t.level_start, min(pm.nlevels, MAX_LEVELS) + 1);
+// Issue the copies of the pose tables and this frame's rows (no wait).  A one-wave kernel issues its whole batch alone at
+// ~100 cycles per copy instruction (s_memtime: 37 instructions = 5.1 k cycles in pose_fwd_kernel, 74 = 9.1 k in
+// pose_bwd_kernel, linear in the count), so the pose kernels run POSE_NW = 4 waves per frame: each issues one PART of the
+// batch under ONE wave-uniform branch (dealing single copies to waves by a running index makes hipcc wait after every copy),
+// three of them only for that.
+constexpr int POSE_NW = 4;
+template <int PART>
+__device__ __forceinline__ void stage_pose_part(const PoseModel& pm, PoseStage& t, const float* __restrict__ xrow,
+                                                const float* __restrict__ camrow) {
+    if constexpr (PART == 0) {
+        glds16<(PS_NJD4 + 63) / 64>(pm.Jd, t.Jd, PS_NJD4);
+        glds4<1>(pm.Jd + PS_NJD4 * 4, t.Jd + PS_NJD4 * 4, (NJ * 3 * NBETA) % 4);
+        glds4<1>(camrow, t.cam, 16);
+    } else if constexpr (PART == 1) {
+        glds16<(PS_NHC4 + 63) / 64>(pm.hand_comp, t.hand_comp, PS_NHC4);
+        glds4<3>(pm.Jt, t.Jt, NJ * 3);
+        glds4<2>(pm.hand_mean, t.hand_mean, 90);
+    } else {
+        glds4<2>(xrow, t.x, XDIM);
+        glds4<1>(pm.parents, t.parents, NJ);
+        glds4<1>(pm.order, t.order, NJ);
+        glds4<1>(pm.child_list, t.child_list, NJ - 1);
+        glds4<1>(pm.depth, t.depth, NJ);
+        glds4<1>(pm.child_start, t.child_start, NJ + 1);
+        glds4<1>(pm.level_start, t.level_start, min(pm.nlevels, MAX_LEVELS) + 1);
+    }
 }
 // after the barrier that follows the copies: the model with its tables in LDS
 __device__ __forceinline__ PoseModel stage_pose_model(const PoseModel& pm, PoseStage& t) {
@@ -198,11 +208,11 @@ __device__ __forceinline__ PoseModel stage_pose_model(const PoseModel& pm, PoseS
     return l;
 }
 
-// one 64-thread workgroup (one wavefront) per frame.
+// One workgroup per frame: POSE_NW waves issue the staging copies, the first one does the frame's arithmetic.
 // PARTS: the decoder output arrives as the four partial sums of vposer_fwd_fused_kernel (Opart, part_stride apart); they are
 // added here in the fixed order of vp_sum_parts, kept in LDS for this frame and written to O for the backward.
 template <bool PARTS>
-__global__ __launch_bounds__(64) void pose_fwd_kernel(PoseModel pm, const float* __restrict__ X, float* __restrict__ O,
+__global__ __launch_bounds__(64 * POSE_NW) void pose_fwd_kernel(PoseModel pm, const float* __restrict__ X, float* __restrict__ O,
                                                       const float* __restrict__ CAM, const float* __restrict__ scale,
                                                       int row0, float* Rm, float* PF, float* Jrest, float* G, float* A,
                                                       float* M, float* Jw, const float* AA, const float* __restrict__ Opart,
@@ -216,6 +226,7 @@ __global__ __launch_bounds__(64) void pose_fwd_kernel(PoseModel pm, const float*
     if (r >= wo_lo && r < wo_hi) {
         // world-only rows (fdcap_opt_forward_ahead): the pose state of this row was computed before `scale` was stepped;
         // only M and the world joints depend on it -- refreshed from the stored joint transforms, pose_forward's own tail
+        if (threadIdx.x >= 64) return;
         const float* x = X + (size_t)r * XDIM;
         M3 MR; V3 Mt;
         world_matrix(CAM + (size_t)r * 16, x, *scale, &MR, &Mt);
@@ -229,13 +240,19 @@ __global__ __launch_bounds__(64) void pose_fwd_kernel(PoseModel pm, const float*
         if (j == 0) g_store(M + (size_t)r * 12, MR, Mt);
         return;
     }
-    stage_pose_issue(pm, stg, X + (size_t)r * XDIM, CAM + (size_t)r * 16);
-    if (PARTS) {                                             // the decoder's partial sums ride in the same batch of copies
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const float* const xrow = X + (size_t)r * XDIM;
+    const float* const camrow = CAM + (size_t)r * 16;
+    if (wave == 0) stage_pose_part<0>(pm, stg, xrow, camrow);
+    else if (wave == 1) stage_pose_part<1>(pm, stg, xrow, camrow);
+    else if (wave == 2) stage_pose_part<2>(pm, stg, xrow, camrow);
+    else if (PARTS) {                                        // the decoder's partial sums ride in the same batch of copies
 #pragma unroll
         for (int q = 0; q < VP_NQ; ++q) glds4<2>(Opart + (size_t)q * part_stride + (size_t)r * ODIM, s_Op[q], ODIM);
     }
     const float sc_v = *scale;
-    __syncthreads();                                         // (waits for the copies: vmcnt(0) in front of the barrier)
+    __syncthreads();                                         // (every wave waits for its copies: vmcnt(0) in front of the barrier)
+    if (threadIdx.x >= 64) return;                           // the other waves were only here to issue copies
 #ifdef FDC_DEBUG_BUFFERS
     stage_check(1, pm.Jd, stg.Jd, NJ * 3 * NBETA, r); stage_check(2, pm.hand_comp, stg.hand_comp, 2 * 12 * 45, r);
     stage_check(3, pm.Jt, stg.Jt, NJ * 3, r); stage_check(4, pm.hand_mean, stg.hand_mean, 90, r);
@@ -280,7 +297,7 @@ __global__ __launch_bounds__(64) void pose_fwd_kernel(PoseModel pm, const float*
 constexpr int LROW = 8;
 struct ParamLossIn { const float* X0; const float* mask; const float* Jw; int frame0, n_total; float w_rec, w_sm, w_ws; int world_grad; float* loss_rows; };
 
-__global__ __launch_bounds__(64) void pose_bwd_kernel(PoseModel pm, const float* __restrict__ X, const float* __restrict__ O,
+__global__ __launch_bounds__(64 * POSE_NW) void pose_bwd_kernel(PoseModel pm, const float* __restrict__ X, const float* __restrict__ O,
                                                       const float* __restrict__ CAM, const float* __restrict__ scale,
                                                       int row0, const float* Rm, const float* Jrest, const float* G,
                                                       const float* dA, const float* dPF, const float* dJw,
@@ -303,20 +320,28 @@ __global__ __launch_bounds__(64) void pose_bwd_kernel(PoseModel pm, const float*
                                           // phases -- read-modify-write round trips on the global row), stored once at the end
     FDC_FR_STAMP(1, 0);
     const int r = row0 + blockIdx.x;
-    stage_pose_issue(pm, stg, X + (size_t)r * XDIM, CAM + (size_t)r * 16);
-    glds4<(NJ * 9 + 63) / 64>(Rm + (size_t)r * NJ * 9, s_Rm, NJ * 9);
-    glds4<(NJ * 3 + 63) / 64>(Jrest + (size_t)r * NJ * 3, s_Jr, NJ * 3);
-    glds16<(NJ * 3 + 63) / 64>(G + (size_t)r * NJ * 12, &sc.G[0][0], NJ * 3);              // rows of sc.G are 12 floats: a flat copy
-    glds4<2>(O + (size_t)r * ODIM, s_O, ODIM);
-    if (dA) glds16<(NJ * 3 + 63) / 64>(dA + (size_t)r * NJ * 12, &sc.dG[0][0], NJ * 3);   // waits in sc.dG: lane j reads row j, then overwrites it
-    if (dPF) glds16<(NPFX / 4 + 63) / 64>(dPF + (size_t)r * NPFX, s_dPF, NPFX / 4);
-    if (dPF2) glds16<(NPFX / 4 + 63) / 64>(dPF2 + (size_t)r * NPFX, &sc.dR[0][0], NPFX / 4);   // parked in sc.dR (written much later)
-    if (dMv) glds4<1>(dMv + (size_t)r * 12, s_misc, 12);
-    if (dsv) glds4<1>(dsv + r, s_misc + 12, 1);
-    if (dtransl_v) glds4<1>(dtransl_v + (size_t)r * 3, s_misc + 13, 3);
-    if (dbeta_v) glds4<1>(dbeta_v + (size_t)r * dbeta_stride, s_misc + 16, NBETA);
-    if (pl.X0) {
-        const float* x = X + (size_t)r * XDIM;
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const float* const xrow = X + (size_t)r * XDIM;
+    const float* const camrow = CAM + (size_t)r * 16;
+    if (wave == 0) {
+        stage_pose_part<0>(pm, stg, xrow, camrow);
+        glds4<(NJ * 9 + 63) / 64>(Rm + (size_t)r * NJ * 9, s_Rm, NJ * 9);
+    } else if (wave == 1) {
+        stage_pose_part<1>(pm, stg, xrow, camrow);
+        glds4<(NJ * 3 + 63) / 64>(Jrest + (size_t)r * NJ * 3, s_Jr, NJ * 3);
+        glds16<(NJ * 3 + 63) / 64>(G + (size_t)r * NJ * 12, &sc.G[0][0], NJ * 3);              // rows of sc.G are 12 floats: a flat copy
+        glds4<2>(O + (size_t)r * ODIM, s_O, ODIM);
+    } else if (wave == 2) {
+        stage_pose_part<2>(pm, stg, xrow, camrow);
+        if (dA) glds16<(NJ * 3 + 63) / 64>(dA + (size_t)r * NJ * 12, &sc.dG[0][0], NJ * 3);   // waits in sc.dG: lane j reads row j, then overwrites it
+        if (dPF) glds16<(NPFX / 4 + 63) / 64>(dPF + (size_t)r * NPFX, s_dPF, NPFX / 4);
+        if (dPF2) glds16<(NPFX / 4 + 63) / 64>(dPF2 + (size_t)r * NPFX, &sc.dR[0][0], NPFX / 4);   // parked in sc.dR (written much later)
+        if (dMv) glds4<1>(dMv + (size_t)r * 12, s_misc, 12);
+        if (dsv) glds4<1>(dsv + r, s_misc + 12, 1);
+        if (dtransl_v) glds4<1>(dtransl_v + (size_t)r * 3, s_misc + 13, 3);
+        if (dbeta_v) glds4<1>(dbeta_v + (size_t)r * dbeta_stride, s_misc + 16, NBETA);
+    } else if (pl.X0) {
+        const float* x = xrow;
         glds4<2>(x - 2 * XDIM, s_xn[0], XDIM); glds4<2>(x - XDIM, s_xn[1], XDIM);
         glds4<2>(x + XDIM, s_xn[2], XDIM); glds4<2>(x + 2 * XDIM, s_xn[3], XDIM);
         glds4<2>(pl.X0 + (size_t)r * XDIM, s_x0, XDIM);
@@ -327,7 +352,8 @@ __global__ __launch_bounds__(64) void pose_bwd_kernel(PoseModel pm, const float*
         glds4<2>(dX + (size_t)r * XDIM, s_dx, XDIM);         // the row a separate param_loss_kernel launch initialised
     }
     const float sc_v = *scale;
-    __syncthreads();                                         // (waits for the copies: vmcnt(0) in front of the barrier)
+    __syncthreads();                                         // (every wave waits for its copies: vmcnt(0) in front of the barrier)
+    if (threadIdx.x >= 64) return;                           // the other waves were only here to issue copies
     FDC_FR_STAMP(1, 7);
     const PoseModel pml = stage_pose_model(pm, stg);
     if (dPF2) {
@@ -1642,7 +1668,7 @@ int opt_pose_forward(fdcap_ctx* c, int lo, int hi, hipStream_t st) {
     const size_t ps = (size_t)o->R * ODIM;
     int e = vposer_forward(c, o->X.p, XDIM, X_LATENT, lo, hi, o->H1.p, o->H2.p, o->Opart.p, ps, nullptr, st);
     if (e) return e;
-    hipLaunchKernelGGL(pose_fwd_kernel<true>, dim3(hi - lo), dim3(64), 0, st, c->pose_model(), o->X.p, o->O.p, o->CAM.p, o->scale.p, lo,
+    hipLaunchKernelGGL(pose_fwd_kernel<true>, dim3(hi - lo), dim3(64 * POSE_NW), 0, st, c->pose_model(), o->X.p, o->O.p, o->CAM.p, o->scale.p, lo,
                        o->Rm.p, o->PF.p, o->Jrest.p, o->G.p, o->A.p, o->M.p, o->Jw.p, (const float*)nullptr, (const float*)o->Opart.p, ps);
     return (int)hipGetLastError();
 }
@@ -1656,7 +1682,7 @@ int opt_pose_forward_rest(fdcap_ctx* c, int lo, int hi, hipStream_t st) {
     const size_t ps = (size_t)o->R * ODIM;
     int e = vposer_forward(c, o->X.p, XDIM, X_LATENT, lo, 2, o->H1.p, o->H2.p, o->Opart.p, ps, nullptr, st, 2 + nl, hi);
     if (e) return e;
-    hipLaunchKernelGGL(pose_fwd_kernel<true>, dim3(hi - lo), dim3(64), 0, st, c->pose_model(), o->X.p, o->O.p, o->CAM.p, o->scale.p, lo,
+    hipLaunchKernelGGL(pose_fwd_kernel<true>, dim3(hi - lo), dim3(64 * POSE_NW), 0, st, c->pose_model(), o->X.p, o->O.p, o->CAM.p, o->scale.p, lo,
                        o->Rm.p, o->PF.p, o->Jrest.p, o->G.p, o->A.p, o->M.p, o->Jw.p, (const float*)nullptr, (const float*)o->Opart.p, ps,
                        2, 2 + nl);
     return (int)hipGetLastError();
@@ -2196,7 +2222,7 @@ static int body_forward_impl(fdcap_ctx* c, const float* params, int32_t B, const
     }
     const float* CAM = world ? cam_ext : w[9].p;
     const float* S = world ? scale : w[10].p;
-    hipLaunchKernelGGL(pose_fwd_kernel<false>, dim3(B), dim3(64), 0, st, c->pose_model(), X, w[4].p, CAM, S, 0,
+    hipLaunchKernelGGL(pose_fwd_kernel<false>, dim3(B), dim3(64 * POSE_NW), 0, st, c->pose_model(), X, w[4].p, CAM, S, 0,
                        (float*)nullptr, w[6].p, (float*)nullptr, w[7].p, w[8].p, w[1].p, (float*)nullptr, (const float*)nullptr,
                        (const float*)nullptr, (size_t)0);
     if (joints) hipLaunchKernelGGL(joints_out_kernel, dim3((B * NJ + 255) / 256), dim3(256), 0, st, w[7].p, X, XDIM, B, joints);
@@ -2240,7 +2266,7 @@ int fdcap_smplx_forward(fdcap_ctx* c, const float* go, const float* bp, const fl
     hipLaunchKernelGGL(assemble_rows_kernel, dim3((B + 127) / 128), dim3(128), 0, st, go, bp, betas, lh, rh, transl, B, X, w[4].p);
     HIP_TRY(hipMemsetAsync(w[9].p, 0, (size_t)B * 16 * sizeof(float), st));
     HIP_TRY(hipMemsetAsync(w[10].p, 0, sizeof(float), st));
-    hipLaunchKernelGGL(pose_fwd_kernel<false>, dim3(B), dim3(64), 0, st, c->pose_model(), X, (float*)nullptr, w[9].p, w[10].p, 0,
+    hipLaunchKernelGGL(pose_fwd_kernel<false>, dim3(B), dim3(64 * POSE_NW), 0, st, c->pose_model(), X, (float*)nullptr, w[9].p, w[10].p, 0,
                        (float*)nullptr, w[6].p, (float*)nullptr, w[7].p, w[8].p, (float*)nullptr, (float*)nullptr, (const float*)w[4].p,
                        (const float*)nullptr, (size_t)0);
     if (joints) hipLaunchKernelGGL(joints_out_kernel, dim3((B * NJ + 255) / 256), dim3(256), 0, st, w[7].p, X, XDIM, B, joints);
@@ -2281,7 +2307,7 @@ int fdcap_smplx_backward(fdcap_ctx* c, const float* go, const float* bp, const f
     hipLaunchKernelGGL(assemble_rows_kernel, dim3((B + 127) / 128), dim3(128), 0, st, go, bp, betas, lh, rh, transl, B, X, AA);
     HIP_TRY(hipMemsetAsync(cam0, 0, ((size_t)B * 16 + 4) * sizeof(float), st));
     HIP_TRY(hipMemsetAsync(w[10].p, 0, (size_t)B * XDIM * sizeof(float), st));
-    hipLaunchKernelGGL(pose_fwd_kernel<false>, dim3(B), dim3(64), 0, st, c->pose_model(), X, (float*)nullptr, cam0, one /* = 0 here */, 0,
+    hipLaunchKernelGGL(pose_fwd_kernel<false>, dim3(B), dim3(64 * POSE_NW), 0, st, c->pose_model(), X, (float*)nullptr, cam0, one /* = 0 here */, 0,
                        w[3].p, PF, w[4].p, w[5].p, w[6].p, (float*)nullptr, (float*)nullptr, (const float*)AA, (const float*)nullptr,
                        (size_t)0);
     const float* dA = nullptr; const float* dPF = nullptr; const float* dtr = nullptr;
@@ -2522,7 +2548,7 @@ static int opt_backward_impl(fdcap_ctx* c, const LossWeights& lw, int32_t log_te
         hipLaunchKernelGGL(contact_loss_rows_kernel, dim3(nl), dim3(256), 0, st, o->dist.p, nc, 2, o->loss_rows.p);
     }
     const bool joint_grad = lw.world_on || dct_on;
-    hipLaunchKernelGGL(pose_bwd_kernel, dim3(nl), dim3(64), 0, st, pm, o->X.p, o->O.p, o->CAM.p, o->scale.p, 2, o->Rm.p,
+    hipLaunchKernelGGL(pose_bwd_kernel, dim3(nl), dim3(64 * POSE_NW), 0, st, pm, o->X.p, o->O.p, o->CAM.p, o->scale.p, 2, o->Rm.p,
                        o->Jrest.p, o->G.p, contact_grad ? o->dA.p : nullptr, contact_grad ? o->dPF.p : nullptr,
                        joint_grad ? o->dJw.p : nullptr, contact_grad ? o->dMv.p : nullptr, contact_grad ? o->dsv.p : nullptr,
                        contact_grad ? o->dPF.p + NPF : nullptr, NPFX, contact_grad ? o->dtransl_v.p : nullptr, o->dX.p, o->dO.p,
@@ -2688,7 +2714,7 @@ int fdcap_opt_backward_fit2d(fdcap_ctx* c, const fdcap_fit2d_stage* sg, int32_t 
     int e = opt_pose_forward(c, row_lo, row_hi, st);
     if (e) return e;
     hipLaunchKernelGGL(fit2d_loss_kernel, dim3(nl), dim3(128), 0, st, s, o->X.p, o->Jw.p, o->kp2d.p, 2, o->dX.p, o->dJw.p, losses);
-    hipLaunchKernelGGL(pose_bwd_kernel, dim3(nl), dim3(64), 0, st, pm, o->X.p, o->O.p, o->CAM.p, o->scale.p, 2, o->Rm.p,
+    hipLaunchKernelGGL(pose_bwd_kernel, dim3(nl), dim3(64 * POSE_NW), 0, st, pm, o->X.p, o->O.p, o->CAM.p, o->scale.p, 2, o->Rm.p,
                        o->Jrest.p, o->G.p, (const float*)nullptr, (const float*)nullptr, o->dJw.p, (const float*)nullptr,
                        (const float*)nullptr, (const float*)nullptr, 0, (const float*)nullptr, o->dX.p, o->dO.p, o->dCAM.p,
                        o->dscale_row.p, ParamLossIn(), (const float*)nullptr);
@@ -2865,7 +2891,7 @@ int fdcap_opt_backward_local2(fdcap_ctx* c, const float* contact_weight, int32_t
                        o->scale.p, 2, o->dVF.p, o->dVF.p, o->dA.p, (float*)nullptr, o->dtransl_v.p, o->dMv.p, o->dsv.p, ContactGradIn());
     HIP_TRY(gemm_f32(true, EPI_STORE, o->dVF.p + 2 * nv3, 3 * V, c->full.posedirs.p, c->full.ldp, o->dPF.p + 2 * NPFX, NPFX, nl, NPFX,
                      3 * V, nullptr, 0, st));
-    hipLaunchKernelGGL(pose_bwd_kernel, dim3(nl), dim3(64), 0, st, pm, o->X.p, o->O.p, o->CAM.p, o->scale.p, 2, o->Rm.p,
+    hipLaunchKernelGGL(pose_bwd_kernel, dim3(nl), dim3(64 * POSE_NW), 0, st, pm, o->X.p, o->O.p, o->CAM.p, o->scale.p, 2, o->Rm.p,
                        o->Jrest.p, o->G.p, o->dA.p, o->dPF.p, (const float*)nullptr, o->dMv.p, o->dsv.p, o->dPF.p + NPF, NPFX,
                        o->dtransl_v.p, o->dX.p, o->dO.p, o->dCAM.p, o->dscale_row.p, ParamLossIn(), (const float*)nullptr);
     { int eb = opt_vposer_backward(c, true, st); if (eb) return eb; }
