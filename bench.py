@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """bench.py -- frames/s of the fixed-budget global optimisation on MI355X (BASELINE.json metric).
 
-  python bench.py [--gpus N] [--steps K] [--warmup W]
+  python bench.py [--gpus N] [--steps K] [--warmup W]        (N > 1 without a launcher: starts the N ranks itself, as below)
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
          --master-port P bench.py --gpus N --steps K --warmup W
 
@@ -74,11 +74,38 @@ def parse(argv=None):
 
 
 # ---- multi-process plumbing (shared by the real run and --dry-run) -----------------------------------------------------
+def self_launch(args, argv):
+    """`python bench.py --gpus N` with N > 1 and no launcher around it (WORLD_SIZE unset): start the N rank processes here --
+    the same `python -m torch.distributed.run` line the driver uses for the scaling run -- as a CHILD of this process, before
+    anything in this process has touched a GPU, pass its output through and return its exit code.  (Never exec: a process
+    that has initialised the GPU must not be replaced; this one has not, and a child is right either way.)"""
+    import socket
+    if not args.dry_run:
+        have = torch.cuda.device_count()                       # counting devices does not initialise the runtime on this image
+        if have < args.gpus:
+            raise SystemExit(f"bench.py --gpus {args.gpus}: this node shows {have} GPU(s); one rank per GPU is the only arrangement "
+                             f"the metric is defined for (no ranks were started)")
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus), "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + list(argv)
+    env = dict(os.environ)
+    env.setdefault("OMP_NUM_THREADS", "1")
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")          # (the host driver only supports dmabuf IPC: RCCL needs it)
+    p = subprocess.run(cmd, env=env)
+    return p.returncode
+
+
 class Ranks:
-    def __init__(self, dry):
+    def __init__(self, dry, gpus=None):
         self.world = int(os.environ.get("WORLD_SIZE", "1"))
         self.rank = int(os.environ.get("RANK", "0"))
         self.local = int(os.environ.get("LOCAL_RANK", "0"))
+        if gpus is not None and gpus != self.world:
+            raise SystemExit(f"bench.py --gpus {gpus} inside a launcher that started WORLD_SIZE={self.world} ranks: the two must agree "
+                             f"(n_gpus in the JSON line is the number of ranks that ran)")
         self.dry = dry
         self.group = None
         # FDCAP_FORCE_EXCHANGE=1: a one-rank RCCL group, to measure what the exchange path itself costs
@@ -91,6 +118,7 @@ class Ranks:
             else:
                 dist.init_process_group("nccl", rank=self.rank, world_size=self.world, device_id=torch.device("cuda", self.local))
             self.group = dist.group.WORLD
+            assert dist.get_world_size() == self.world, (dist.get_world_size(), self.world)
 
     def barrier(self):
         if not self.dry:
@@ -154,7 +182,7 @@ def dry_run(args):
     """The plumbing of main() without a GPU: same rendezvous variables, shards, collectives per iteration and JSON rules."""
     import fdcap_amd  # noqa: F401
     from fdcap_amd.dist import FrameShard, allgather_packed
-    rk = Ranks(dry=True)
+    rk = Ranks(dry=True, gpus=args.gpus)
     shard = FrameShard(args.frames, rk.group, rank=rk.rank, world=rk.world)
     xl = 4 * (78 + 16) + 8                                   # fdcap_exchange_len(): the iteration's one message
     send, gathered = torch.zeros(xl), torch.zeros(rk.world, xl)
@@ -297,11 +325,15 @@ def counter_fracs(k, live_seconds=None):
 
 def main():
     args = parse()
+    if args.gpus < 1:
+        raise SystemExit("--gpus must be >= 1")
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:       # no launcher around us: be the launcher (before any GPU call)
+        sys.exit(self_launch(args, sys.argv[1:]))
     if args.dry_run:
         return dry_run(args)
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (the HIP path has no CPU fallback; --dry-run checks the multi-process plumbing only)")
-    rk = Ranks(dry=False)
+    rk = Ranks(dry=False, gpus=args.gpus)
     torch.cuda.set_device(rk.local)
     import ctypes
     import fdcap_amd  # noqa: F401

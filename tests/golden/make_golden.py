@@ -18,7 +18,7 @@ Recipe:
 
 Usage:  python tests/golden/make_golden.py            (writes tests/golden/*.npz)
         python tests/golden/make_golden.py --chamfer  (ref_chamfer_python.npz: /root/reference/chamfer_python.py)
-        python tests/golden/make_golden.py --smoother | --dct
+        python tests/golden/make_golden.py --smoother | --dct | --g500 (ref_global_500it.npz: the fixed budget, :672)
 """
 import contextlib
 import hashlib
@@ -110,7 +110,7 @@ LOG2_RE = re.compile(r"iter=(\d+), l_rec=([-\d.e]+), loss_local_smoothing=([-\d.
 
 
 def run_global(g, num_iter, num_verts, ns, model_seed, vposer_seed, clip_seed, scene_seed,
-               contact_seed, per_part, tmp, mode="global"):
+               contact_seed, per_part, tmp, mode="global", snapshot_at=()):
     n = 300  # the reference hard-codes 300 (:465, :472, :41-42)
     bm = synth.make_body_model(num_verts, seed=model_seed)
     vp = synth.make_vposer(seed=vposer_seed)
@@ -152,6 +152,20 @@ def run_global(g, num_iter, num_verts, ns, model_seed, vposer_seed, clip_seed, s
     f.optimizer = torch.optim.Adam([f.body_rotation_rec, f.scale, f.camera_ext, f.c_dct],
                                    lr=f.init_lr_h)
 
+    snaps = {}
+    if snapshot_at:
+        # the optimiser object is ours to supply (:188 builds a plain Adam): this one also keeps copies of the leaves after
+        # chosen steps, so the fixture shows WHERE along the 500 iterations two implementations part -- no reference code changes
+        class RecordingAdam(torch.optim.Adam):
+            def step(self, *a, **k):
+                r = super().step(*a, **k)
+                self._n = getattr(self, "_n", 0) + 1
+                if self._n in snapshot_at:
+                    snaps[self._n] = (f.body_rotation_rec.detach().clone().numpy(), np.float32(f.scale.detach().item()),
+                                      f.camera_ext.detach().clone().numpy())
+                return r
+        f.optimizer = RecordingAdam([f.body_rotation_rec, f.scale, f.camera_ext, f.c_dct], lr=f.init_lr_h)
+
     vid_ref, _ = g.get_contact_id(seg, ["L_Leg", "R_Leg"])
     body = torch.tensor(clip.body_params, dtype=torch.float32)
     c_dct0 = f.c_dct.detach().clone().numpy()
@@ -188,7 +202,14 @@ def run_global(g, num_iter, num_verts, ns, model_seed, vposer_seed, clip_seed, s
         assert log2.shape[0] == int(0.4 * num_iter), log2.shape
     idx_line = text.splitlines()[0]
     idx1 = np.array([int(t) for t in re.findall(r"\d+", idx_line)], dtype=np.int64)
+    extra = {}
+    if snaps:
+        ks = sorted(snaps)
+        extra = dict(snap_iters=np.array(ks, dtype=np.int64), snap_x78=np.stack([snaps[k][0] for k in ks]),
+                     snap_scale=np.array([snaps[k][1] for k in ks], dtype=np.float32),
+                     snap_cam=np.stack([snaps[k][2] for k in ks]))
     return dict(
+        **extra,
         num_iter=num_iter, num_verts=num_verts, ns=ns, model_seed=model_seed,
         vposer_seed=vposer_seed, clip_seed=clip_seed, scene_seed=scene_seed,
         contact_seed=contact_seed, per_part=per_part,
@@ -322,6 +343,15 @@ def main():
         print("wrote ref_smoother", res["body_out"].shape, float(np.abs(res["body_out"] - res["body_in"]).max()))
         return
     g = import_reference()
+    if "--g500" in sys.argv:           # the reference's own loop at its real budget (num_iter 500, :672): minutes of CPU
+        torch.set_num_threads(4)
+        with tempfile.TemporaryDirectory() as tmp:
+            res = run_global(g, tmp=tmp, num_iter=500, num_verts=640, ns=3000, model_seed=40, vposer_seed=41,
+                             clip_seed=42, scene_seed=43, contact_seed=44, per_part=24,
+                             snapshot_at=(5, 20, 50, 100, 200, 300, 400, 401, 420, 450, 500))
+            np.savez_compressed(os.path.join(HERE, "ref_global_500it.npz"), **res)
+            print("wrote ref_global_500it", "idx1", res["idx1"], "scale", res["scale"], "last log", res["log"][-1])
+        return
     if "--dct" in sys.argv:            # ~20 min of CPU: the reference's own 10000-iteration 'dct' run
         torch.set_num_threads(2)
         with tempfile.TemporaryDirectory() as tmp:

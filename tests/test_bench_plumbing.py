@@ -52,6 +52,40 @@ def test_bench_under_torchrun_two_ranks_prints_one_line():
     assert d["ms_per_step"] > 0
 
 
+def test_plain_bench_with_gpus_2_starts_two_ranks_itself():
+    """`python bench.py --gpus 2 ...` with no launcher around it (the shape of the driver's 1-GPU command line with another N):
+    the file starts its own ranks; n_gpus is the number of ranks that ran, not the flag echoed back."""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--dry-run"],
+                       capture_output=True, text=True, timeout=300, env=env, cwd=ROOT)
+    assert p.returncode == 0, p.stderr[-2000:]
+    lines = _json_lines(p.stdout)
+    assert len(lines) == 1, p.stdout
+    d = lines[0]
+    assert d["n_gpus"] == 2 and d["dry_run"] is True
+    ranks = sorted(d["ranks"], key=lambda r: r["rank"])
+    assert [r["rank"] for r in ranks] == [0, 1] and [r["device"] for r in ranks] == ["cuda:0", "cuda:1"]
+    assert ranks[0]["frames"] == [0, 512] and ranks[1]["frames"] == [512, 1024]
+
+
+def test_gpus_flag_must_agree_with_the_launcher():
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"), "--gpus", "4", "--dry-run"]
+    p = subprocess.run(cmd, capture_output=True, text=True, timeout=300, env=dict(os.environ, OMP_NUM_THREADS="1"), cwd=ROOT)
+    assert p.returncode != 0 and "must agree" in (p.stderr + p.stdout)
+    assert not _json_lines(p.stdout)
+
+
+def test_more_gpus_than_the_node_has_is_refused_before_any_rank_starts():
+    import torch
+    if torch.cuda.device_count() >= 64:
+        return
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "64", "--steps", "1"], capture_output=True, text=True,
+                       timeout=120, env=env, cwd=ROOT)
+    assert p.returncode != 0 and "no ranks were started" in (p.stderr + p.stdout)
+
+
 def test_bench_dry_run_single_process():
     p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--dry-run"], capture_output=True, text=True, timeout=120,
                        cwd=ROOT)
