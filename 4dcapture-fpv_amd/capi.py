@@ -48,6 +48,7 @@ class OptConfig(ctypes.Structure):
 # every symbol include/fdcap.h declares: name -> (restype, argtypes)
 SYMBOLS = {
     "fdcap_version": (c_char_p, []),
+    "fdcap_build_info": (c_char_p, []),
     "fdcap_ctx_create": (c_int32, [POINTER(ModelDesc), POINTER(c_void_p)]),
     "fdcap_ctx_destroy": (None, [c_void_p]),
     "fdcap_set_scene": (c_int32, [c_void_p, c_void_p, c_int64]),
@@ -123,9 +124,38 @@ def load_library(path: str | None = None) -> ctypes.CDLL:
         fn = getattr(lib, name)            # AttributeError if the symbol is not exported
         fn.restype = res
         fn.argtypes = args
+    info = lib.fdcap_build_info().decode()
+    if "packed_fp32=off" not in info and os.environ.get("FDCAP_ALLOW_PK_F32") != "1":
+        raise FdcapError(f"{p} was built with packed fp32 instructions ({info}): results are not reliable next to another kernel's "
+                         "MFMAs on the same CU (DESIGN.md section 7).  Rebuild with __graft_entry__.build(), or set "
+                         "FDCAP_ALLOW_PK_F32=1 for an instrumentation variant.")
     if path is None:
         _lib = lib
     return lib
+
+
+def count_packed_fp32(path: str | None = None) -> int:
+    """Number of v_pk_{fma,mul,add}_f32 instructions in the library's gfx950 code object (llvm-objdump of the extracted
+    bundle, ~1 s).  The build requirement of csrc/fdcap.hip says 0; __graft_entry__.build() and tests/test_io_and_abi.py check."""
+    import re
+    import shutil
+    import subprocess
+    import tempfile
+    objdump = os.environ.get("LLVM_OBJDUMP", "/opt/rocm/lib/llvm/bin/llvm-objdump")
+    if not os.path.exists(objdump):
+        raise FdcapError(f"{objdump} not found (set LLVM_OBJDUMP)")
+    with tempfile.TemporaryDirectory() as tmp:
+        so = os.path.join(tmp, "lib.so")
+        shutil.copy(path or LIB_PATH, so)
+        subprocess.run([objdump, "--offloading", so], check=True, capture_output=True, cwd=tmp)     # writes lib.so.<k>.<triple>
+        objs = [f for f in os.listdir(tmp) if "amdgcn" in f]
+        if not objs:
+            raise FdcapError("no gfx950 code object found in the library")
+        n = 0
+        for f in objs:
+            txt = subprocess.run([objdump, "-d", os.path.join(tmp, f)], check=True, capture_output=True, text=True).stdout
+            n += len(re.findall(r"\bv_pk_(?:fma|mul|add)_f32\b", txt))
+        return n
 
 
 def check(code: int, what: str) -> None:

@@ -8,6 +8,16 @@
 #include <algorithm>
 #include <vector>
 
+// Build requirement: this file is compiled WITHOUT packed fp32 instructions
+//   -Xclang -target-feature -Xclang -packed-fp32-ops -DFDC_BUILD_NO_PK_F32
+// (on the MI355X boxes this was developed on, v_pk_{fma,mul,add}_f32 now and then return a wrong low element while another
+// kernel's MFMAs share the CU: tools/pk_f32_mfma_repro.hip).  The define travels with the flag so that a build script which
+// drops one drops both and stops here; capi.load_library() reads it back through fdcap_build_info(), and
+// tests/test_io_and_abi.py disassembles the library to check the flag really took effect.
+#if !defined(FDC_BUILD_NO_PK_F32) && !defined(FDC_BUILD_ALLOW_PK_F32)
+#error "build fdcap.hip with: -Xclang -target-feature -Xclang -packed-fp32-ops -DFDC_BUILD_NO_PK_F32 (see __graft_entry__.build)"
+#endif
+
 #ifdef FDC_PN_TIMING
 // instrumentation build only: per-frame s_memtime stamps of the pose kernels [which][block][8]
 __device__ unsigned long long g_fr_times[3][2048 * 8];
@@ -1715,7 +1725,14 @@ int opt_vposer_backward(fdcap_ctx* c, bool fold, hipStream_t st) {
 // ------------------------------------------------------------------------------------------
 extern "C" {
 
-const char* fdcap_version(void) { return "fdcap-hip 0.2 (gfx950)"; }
+const char* fdcap_version(void) { return "fdcap-hip 0.3 (gfx950)"; }
+const char* fdcap_build_info(void) {
+#ifdef FDC_BUILD_NO_PK_F32
+    return "packed_fp32=off";
+#else
+    return "packed_fp32=on";
+#endif
+}
 
 #ifdef FDC_DEBUG_BUFFERS
 }  // extern "C"
@@ -1912,7 +1929,9 @@ void fdcap_ctx_destroy(fdcap_ctx* c) {
 }
 
 int fdcap_set_scene(fdcap_ctx* c, const float* xyz, int64_t ns) {
-    if (!c || ns < 0 || (ns > 0 && !xyz) || ns > 0x7fffffff) return FDCAP_E_ARG;
+    // FDCAP_MAX_SCENE_POINTS: the in-loop NN launch streams the scene's MFMA fragments (32 B per point) through one buffer
+    // resource with 32-bit byte offsets; beyond 2 GiB of fragments its loads would silently return zeros
+    if (!c || ns < 0 || (ns > 0 && !xyz) || ns > FDCAP_MAX_SCENE_POINTS) return FDCAP_E_ARG;
     // a live optimiser holds buffers sized for, and pruning state (seeds, kept work lists) valid for, the registered scene
     if (c->opt) return FDCAP_E_STATE;
     std::vector<float4> orig((size_t)ns), sorted((size_t)ns);
@@ -2432,6 +2451,7 @@ int fdcap_opt_set_inputs(fdcap_ctx* c, const float* data78, const float* init78,
     OptState* o = c->opt;
     hipStream_t st = (hipStream_t)stream;
     const size_t n = o->cfg.n_local;
+    o->log_pending = false; o->log_dst = nullptr;
     HIP_TRY(hipMemcpyAsync(o->X0.p + 2 * XDIM, data78, n * XDIM * sizeof(float), hipMemcpyDeviceToDevice, st));
     HIP_TRY(hipMemcpyAsync(o->X.p + 2 * XDIM, init78, n * XDIM * sizeof(float), hipMemcpyDeviceToDevice, st));
     HIP_TRY(hipMemcpyAsync(o->mask.p + 2, mask, n * sizeof(float), hipMemcpyDeviceToDevice, st));
@@ -2569,6 +2589,10 @@ static int opt_backward_impl(fdcap_ctx* c, const LossWeights& lw, int32_t log_te
 
 int fdcap_opt_set_loss_output(fdcap_ctx* c, double* losses_d) {
     if (!c || !c->opt || !losses_d) return FDCAP_E_ARG;
+    // a logging backward (log_terms = 2) that no step followed left its reduction pending, aimed at the OLD output: that
+    // memory may be gone by now (a caller's history row) -- the pending delivery is dropped, never redirected or kept
+    c->opt->log_pending = false;
+    c->opt->log_dst = nullptr;
     c->opt->losses.p = losses_d;
     return FDCAP_OK;
 }
@@ -2727,6 +2751,7 @@ int fdcap_opt_reset_adam(fdcap_ctx* c, void* stream) {
     if (!c || !c->opt) return FDCAP_E_STATE;
     OptState* o = c->opt;
     const size_t n = (size_t)o->R * XDIM * sizeof(float);
+    o->log_pending = false; o->log_dst = nullptr;
     HIP_TRY(hipMemsetAsync(o->mX.p, 0, n, (hipStream_t)stream));
     HIP_TRY(hipMemsetAsync(o->vX.p, 0, n, (hipStream_t)stream));
     return FDCAP_OK;

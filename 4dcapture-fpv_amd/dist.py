@@ -123,3 +123,37 @@ def allgather_packed(shard: FrameShard, send, gathered, overlap=None) -> None:
         dist.all_gather_into_tensor(gathered.view(-1), send, group=shard.group)
         if overlap is not None:
             overlap()
+
+
+def agree_on(shard: FrameShard, value: int) -> int:
+    """Rank 0's `value` on every rank (one tiny broadcast).  For per-rank configuration that decides WHETHER a collective is
+    issued -- e.g. `verbose`, which makes a fit read its loss history back (an all-reduce) every few logged iterations:
+    a rank that disagreed would issue another sequence of collectives than its peers and hang the group."""
+    if shard.world == 1:
+        return int(value)
+    import torch
+    import torch.distributed as dist
+    t = torch.tensor([int(value)], dtype=torch.int64)
+    if dist.get_backend(shard.group) != "gloo":
+        t = t.cuda()
+    dist.broadcast(t, src=shard.global_rank(0), group=shard.group)
+    return int(t.item())
+
+
+def same_on_all_ranks(shard: FrameShard, value: int):
+    """(min, max) of `value` over the ranks -- equal when every rank holds the same number."""
+    if shard.world == 1:
+        return int(value), int(value)
+    import torch
+    import torch.distributed as dist
+    t = torch.tensor([int(value), -int(value)], dtype=torch.int64)
+    if dist.get_backend(shard.group) != "gloo":
+        t = t.cuda()
+    dist.all_reduce(t, op=dist.ReduceOp.MIN, group=shard.group)
+    return int(t[0].item()), -int(t[1].item())
+
+
+def barrier(shard: FrameShard) -> None:
+    if shard.world > 1:
+        import torch.distributed as dist
+        dist.barrier(group=shard.group)

@@ -13,7 +13,7 @@ from dataclasses import dataclass
 import numpy as np
 
 from . import capi, io
-from .dist import FrameShard, allgather_packed, allreduce_scalars, exchange_halos
+from .dist import FrameShard, agree_on, allgather_packed, allreduce_scalars, barrier, exchange_halos, same_on_all_ranks
 
 # loss-total constants buried in fitting() (global_optimization.py:564, :570, :582)
 PHASE_SPLIT = 0.8
@@ -201,7 +201,10 @@ class FittingOP:
             `checkpoint_path` (sharded runs: one file per rank, suffix .rank<r>);
           resume=path: continue such a run from where the file left off -- bit-identical to the uninterrupted run;
           check_finite_every=k: every k iterations count the non-finite parameters on the device and raise if any
-            (the opt-in counterpart of the reference's set_detect_anomaly(True), :561)."""
+            (the opt-in counterpart of the reference's set_detect_anomaly(True), :561).
+        Sharded runs: every argument of this call and `num_iter` must be the same on all ranks (they decide which collectives
+        are issued).  `verbose` may differ -- prints come from rank 0 only, and rank 0's flag alone decides whether the loss
+        history is read back (all-reduced) during the loop, so a rank-0-only verbose run is legal."""
         import torch
         if mode not in ("global", "local", "dct"):
             raise ValueError("mode must be 'local', 'global' or 'dct' (global_optimization.py:660)")
@@ -247,6 +250,8 @@ class FittingOP:
         # read back -- and, when sharded, all-reduced -- once after the last iteration.
         n_log = 0
         logged = []
+        # in-loop read-backs of the loss history are collectives when sharded: one flag for the whole group (rank 0's)
+        flush_in_loop = bool(agree_on(self.shard, 1 if self.verbose else 0)) if multi else bool(self.verbose)
         if log_every and mode != "dct":
             n_log = sum(1 for ii in range(ii0, self.num_iter) if ii % log_every == 0 or ii == self.num_iter - 1)
             hist = torch.zeros(max(n_log, 1), capi.NUM_LOSSES, device=dev, dtype=torch.float64)
@@ -305,7 +310,7 @@ class FittingOP:
                     capi.check(lib.fdcap_opt_step(h, ii, P, st), "fdcap_opt_step")
                 # the reference prints every iteration live (:573-575); a verbose fit shows its progress in batches of
                 # VERBOSE_FLUSH logged iterations (one read-back each) instead of only after the last one
-                if self.verbose and do_log and len(logged) - flushed >= VERBOSE_FLUSH:
+                if flush_in_loop and do_log and len(logged) - flushed >= VERBOSE_FLUSH:
                     flush(len(logged))
                 if check_finite_every and (ii + 1) % check_finite_every == 0:
                     self._check_finite(ii)
@@ -345,6 +350,9 @@ class FittingOP:
                  frame0=np.int64(self.shard.frame0), n_local=np.int64(nl), rows_x=self._rows_x[2:2 + nl].cpu().numpy(),
                  rows_cam=self._rows_cam[2:2 + nl].cpu().numpy(), scale=self._scale.cpu().numpy(), state=state.cpu().numpy())
         import os
+        # sharded: nobody replaces its file before every rank has written its new one (a crash during the writes leaves the
+        # previous, mutually consistent set); a crash between the renames is caught on resume (next_iter must agree)
+        barrier(self.shard)
         os.replace(tmp, fn)                                      # (a crash mid-write leaves the previous checkpoint intact)
 
     def _load_checkpoint(self, path):
@@ -363,6 +371,10 @@ class FittingOP:
             nxt = int(ck["next_iter"])
         if state.numel() != int(lib.fdcap_opt_state_len(h)):
             raise capi.FdcapError("checkpoint state has the wrong size")
+        lo, hi = same_on_all_ranks(self.shard, nxt)
+        if lo != hi:
+            raise capi.FdcapError(f"the ranks' checkpoint files are from different iterations ({lo} .. {hi}): a run died between "
+                                  f"two ranks' writes; resume from an older, complete set")
         capi.check(lib.fdcap_opt_import_state(h, capi.dptr(state), capi.current_stream()), "fdcap_opt_import_state")
         torch.cuda.current_stream().synchronize()
         exchange_halos(self.shard, self._rows_x, self._rows_cam)

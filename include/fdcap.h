@@ -34,6 +34,7 @@ extern "C" {
 #define FDCAP_NUM_JOINTS 55
 #define FDCAP_XDIM 78         /* optimised row: transl3 6D6 betas10 latent32 lh12 rh12 camt3 */
 #define FDCAP_PDIM 75         /* file row:      transl3 aa3 betas10 latent32 lh12 rh12 camt3 */
+#define FDCAP_MAX_SCENE_POINTS 67000000   /* fdcap_set_scene refuses more (FDCAP_E_ARG): 32 B of MFMA fragments per point, 32-bit offsets */
 #define FDCAP_NUM_LOSSES 8    /* rec, vposer, smoothing, contact, world_smoothing, total, 2 spare */
 
 typedef struct fdcap_ctx fdcap_ctx;
@@ -85,9 +86,12 @@ typedef struct fdcap_opt_config {
 int fdcap_ctx_create(const fdcap_model_desc* model, fdcap_ctx** out);
 void fdcap_ctx_destroy(fdcap_ctx* ctx);
 const char* fdcap_version(void);
+/* "packed_fp32=off" for a product build (compiled without v_pk_*_f32, see csrc/fdcap.hip's build requirement); the Python
+ * binding refuses a library that says otherwise unless FDCAP_ALLOW_PK_F32=1 (instrumentation variants). */
+const char* fdcap_build_info(void);
 
 /* Scene vertices, stored ONCE (the reference repeats them per frame, :175-176).  `scene_xyz`
- * is a HOST pointer [ns,3]; registered (copied + packed for the NN kernel).
+ * is a HOST pointer [ns,3]; registered (copied + packed for the NN kernel); ns <= FDCAP_MAX_SCENE_POINTS.
  * Both setters return FDCAP_E_STATE while an optimiser exists on the context (fdcap_opt_create .. fdcap_opt_destroy): its
  * buffers are sized for the registered sets and its pruning state (seeds, kept work lists) is only valid for them. */
 int fdcap_set_scene(fdcap_ctx* ctx, const float* scene_xyz, int64_t ns);

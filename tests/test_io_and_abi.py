@@ -27,6 +27,23 @@ def test_header_symbols_are_exported_and_bound():
     assert lib.fdcap_version().startswith(b"fdcap-hip")
 
 
+def test_library_is_built_without_packed_fp32_instructions():
+    """The build requirement at the top of csrc/fdcap.hip, enforced on the artefact that ships: the
+    library says so (fdcap_build_info, which capi.load_library also insists on) AND its gfx950 code object holds no
+    v_pk_{fma,mul,add}_f32 -- a build script that passed the define without the target feature would fail here."""
+    lib = capi.load_library()
+    assert b"packed_fp32=off" in lib.fdcap_build_info()
+    assert capi.count_packed_fp32() == 0
+
+
+def test_scene_size_limit_is_refused_not_truncated():
+    hdr = open(os.path.join(ROOT, "include", "fdcap.h")).read()
+    lim = int(re.search(r"#define FDCAP_MAX_SCENE_POINTS (\d+)", hdr).group(1))
+    assert lim * 32 < 2 ** 31            # the fragment stream (32 B per point) stays addressable with 32-bit offsets
+    src = open(os.path.join(ROOT, "4dcapture-fpv_amd", "csrc", "fdcap.hip")).read()
+    assert "ns > FDCAP_MAX_SCENE_POINTS) return FDCAP_E_ARG" in src
+
+
 def test_struct_layouts_match_header():
     # 18 pointers/ints of fdcap_model_desc and 13 fields of fdcap_opt_config, natural alignment
     assert ctypes.sizeof(capi.OptConfig) == 13 * 4

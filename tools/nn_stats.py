@@ -6,7 +6,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 lib = os.path.join(ROOT, "gpurun_out", "libfdcap_hip_stats.so")
 subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-mllvm",
-                       "-amdgpu-mfma-vgpr-form", "-fno-honor-nans", "-Xclang", "-target-feature", "-Xclang", "-packed-fp32-ops", "-DFDC_NN_STATS", *(["-DFDC_NN_EXP=" + os.environ["FDC_NN_EXP"]] if os.environ.get("FDC_NN_EXP") else []), "-o", lib,
+                       "-amdgpu-mfma-vgpr-form", "-fno-honor-nans", "-Xclang", "-target-feature", "-Xclang", "-packed-fp32-ops", "-DFDC_BUILD_NO_PK_F32", "-DFDC_NN_STATS", *(["-DFDC_NN_EXP=" + os.environ["FDC_NN_EXP"]] if os.environ.get("FDC_NN_EXP") else []), "-o", lib,
                        os.path.join(ROOT, "4dcapture-fpv_amd", "csrc", "fdcap.hip")])
 os.environ["FDCAP_LIB"] = lib
 import numpy as np, torch
