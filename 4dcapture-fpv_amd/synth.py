@@ -75,7 +75,10 @@ class BodyModelData:
         return int(self.v_template.shape[0])
 
 
-def make_body_model(num_verts: int = NUM_VERTS_SMPLX, seed: int = 0) -> BodyModelData:
+def make_body_model(num_verts: int = NUM_VERTS_SMPLX, seed: int = 0, lbs_nnz: int = 4) -> BodyModelData:
+    """`lbs_nnz`: non-zero skinning weights per vertex (nearest joints).  4 is the SURVEY §8d spec; the real SMPLX_NEUTRAL.npz
+    is not promised to be 4-sparse (global_optimization.py:154-168 loads whatever the file holds), so 8 / 12 exercise the
+    general-K skinning paths.  Every other array is identical for every lbs_nnz."""
     rng = np.random.Generator(np.random.PCG64(seed))
     J = _rest_skeleton()
     parents = SMPLX_PARENTS
@@ -128,7 +131,7 @@ def make_body_model(num_verts: int = NUM_VERTS_SMPLX, seed: int = 0) -> BodyMode
         w = rng.random(nnz) + 0.1
         J_regressor[j, idx] = w / w.sum()
     lbs = np.zeros((num_verts, NUM_JOINTS), dtype=np.float64)
-    near = np.argpartition(d2.T, 3, axis=1)[:, :4]              # [V,4]
+    near = np.argpartition(d2.T, lbs_nnz - 1, axis=1)[:, :lbs_nnz]   # [V,lbs_nnz]
     dn = np.take_along_axis(d2.T, near, axis=1)
     w = np.exp(-dn / (2 * 0.08 ** 2)) + 1e-6
     w /= w.sum(1, keepdims=True)
