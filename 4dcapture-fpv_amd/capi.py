@@ -71,6 +71,13 @@ SYMBOLS = {
     "fdcap_opt_set_inputs": (c_int32, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "fdcap_opt_backward": (c_int32, [c_void_p, c_int32, c_int32, c_int32, c_void_p]),
     "fdcap_opt_step": (c_int32, [c_void_p, c_int32, c_int32, c_void_p]),
+    "fdcap_comm_unique_id": (c_int32, [c_void_p]),
+    "fdcap_comm_create": (c_int32, [c_void_p, c_void_p, c_int32, c_int32]),
+    "fdcap_comm_destroy": (c_int32, [c_void_p]),
+    "fdcap_comm_last_error": (c_char_p, [c_void_p]),
+    "fdcap_opt_halo_exchange": (c_int32, [c_void_p, c_void_p]),
+    "fdcap_opt_exchange": (c_int32, [c_void_p, c_int32, c_int32, c_void_p]),
+    "fdcap_comm_allreduce_f64": (c_int32, [c_void_p, c_void_p, c_int32, c_void_p]),
     "fdcap_opt_state_len": (c_int32, [c_void_p]),
     "fdcap_opt_export_state": (c_int32, [c_void_p, c_void_p, c_void_p]),
     "fdcap_opt_import_state": (c_int32, [c_void_p, c_void_p, c_void_p]),
@@ -162,7 +169,7 @@ def check(code: int, what: str) -> None:
     if code == 0:
         return
     if code < 0:
-        names = {-1: "FDCAP_E_ARG", -2: "FDCAP_E_STATE", -3: "FDCAP_E_NODEVICE"}
+        names = {-1: "FDCAP_E_ARG", -2: "FDCAP_E_STATE", -3: "FDCAP_E_NODEVICE", -4: "FDCAP_E_COMM (RCCL)"}
         raise FdcapError(f"{what}: {names.get(code, code)}")
     raise FdcapError(f"{what}: hipError_t {code}")
 

@@ -20,10 +20,15 @@ struct SkinModel {
     const int* csc_start; // [56]
     const int* csc_v;     // [nnz]
     const float* csc_w;   // [nnz] (allocated and zero-padded to a multiple of 4)
-    // 16-byte forms of the same constants (K <= 4, V <= 65535; null otherwise) for kernels that stage them with vector loads:
-    const float* vpack = nullptr;            // [2][V][4], 16-byte aligned: {vt.x, vt.y, vt.z, bits(j0 | j1 << 8 | j2 << 16 | j3 << 24)} of every vertex, then {w0, w1, w2, w3}
+    // 16-byte forms of the same constants (K <= 12, V <= 65535; null otherwise) for kernels that stage them with vector loads:
+    // [skin_vpack_planes(K)][V][4], 16-byte aligned.  Plane 0: {vt.x, vt.y, vt.z, bits(j0 | j1 << 8 | j2 << 16 | j3 << 24)} of every
+    // vertex; plane 1: {w0, w1, w2, w3}; K > 4: planes 2 (, 3): {w4..w7} (, {w8..w11}), last plane {bits(j4..j7), bits(j8..j11), 0, 0}.
+    // (K <= 4 is the two-plane layout of r2; a real SMPLX_NEUTRAL.npz is not promised to be 4-sparse.)
+    const float* vpack = nullptr;
     const unsigned short* csc_v16 = nullptr; // [nnz rounded up to a multiple of 8] csc_v as 16-bit ids
 };
+
+FDC_HD int skin_vpack_planes(int K) { const int G = (K + 3) / 4; return G <= 1 ? 2 : G + 2; }
 
 struct SkinFwd { V3 vp, vb, vw; float T[12]; };
 

@@ -55,6 +55,7 @@ static unsigned* fdc_poison_sink() { static unsigned* p = nullptr; if (!p) (void
 #endif
 #include "../../include/fdcap.h"
 #include "fdc_chamfer.h"
+#include "fdc_comm.h"
 #include "fdc_dct.h"
 #include "fdc_fit2d.h"
 #include "fdc_frame.h"
@@ -438,23 +439,28 @@ __global__ __launch_bounds__(256) void skin_fwd_kernel(SkinModel sm, int nv, con
     float* o = Vout + ((size_t)r * nv + c) * 3;
     if (sm.vpack && !sm.S) {
         // packed per-vertex constants (two 16-byte loads instead of eleven 4-byte ones); same terms, same order
-        const float4 p0 = ((const float4*)sm.vpack)[cc], p1 = ((const float4*)sm.vpack)[nv + cc];
+        const float4* const vp4 = (const float4*)sm.vpack;
+        const int G = (sm.K + 3) >> 2;                                       // (wave-uniform)
+        const float4 p0 = vp4[cc], p1 = vp4[nv + cc];
+        float4 p2 = make_float4(0.f, 0.f, 0.f, 0.f), p3 = p2, pj = p2;       // K > 4: more weight planes + the ids' plane
+        if (G >= 2) { p2 = vp4[(size_t)2 * nv + cc]; pj = vp4[(size_t)(G + 1) * nv + cc]; }
+        if (G >= 3) p3 = vp4[(size_t)3 * nv + cc];
         const float* vo = Voff + ((size_t)r * nv + cc) * 3;
         const float v0 = vo[0], v1 = vo[1], v2 = vo[2];
         __syncthreads();
         if (c >= nv) return;
         const float px = p0.x + v0, py = p0.y + v1, pz = p0.z + v2;
-        const unsigned jb = __float_as_uint(p0.w);
-        const float w4[4] = {p1.x, p1.y, p1.z, p1.w};
+        const unsigned jb[3] = {__float_as_uint(p0.w), __float_as_uint(pj.x), __float_as_uint(pj.y)};
+        const float w12[12] = {p1.x, p1.y, p1.z, p1.w, p2.x, p2.y, p2.z, p2.w, p3.x, p3.y, p3.z, p3.w};
         float T[12];
 #pragma unroll
         for (int e = 0; e < 12; ++e) T[e] = 0.f;
 #pragma unroll
-        for (int k = 0; k < 4; ++k)
+        for (int k = 0; k < 12; ++k)
             if (k < sm.K) {
-                const float* a = sA + 12 * ((jb >> (8 * k)) & 255u);
+                const float* a = sA + 12 * ((jb[k >> 2] >> (8 * (k & 3))) & 255u);
 #pragma unroll
-                for (int e = 0; e < 12; ++e) T[e] += w4[k] * a[e];
+                for (int e = 0; e < 12; ++e) T[e] += w12[k] * a[e];
             }
         const V3 vb = v3(T[0] * px + T[1] * py + T[2] * pz + T[3], T[4] * px + T[5] * py + T[6] * pz + T[7],
                          T[8] * px + T[9] * py + T[10] * pz + T[11]) + transl;
@@ -623,7 +629,7 @@ __global__ __launch_bounds__(256) void skin_bwd_kernel(SkinModel sm, int nc, con
 // The dA sums run joint by joint over ascending vertices with the same wave-sum tree: run-to-run reproducible.
 // (VPT vertices and KC weight-list entries per thread in registers: 130 VGPRs for 4 / 16 cost a wave per SIMD -- the launch
 // then needs a second generation of workgroups; the loop's 500 vertices / 2000 weights take the 2 / 8 instance)
-constexpr int SKS_MAXV = 1024, SKS_MAXNNZ = 4096;
+constexpr int SKS_MAXV = 1024, SKS_MAXNNZ = 6144;
 template <int SKS_VPT, int SKS_KC>
 __global__ __launch_bounds__(256) void skin_bwd_small_kernel(SkinModel sm, int nc, int nnz, const float* __restrict__ X,
                                                              const float* __restrict__ Voff, const float* __restrict__ A,
@@ -781,6 +787,8 @@ __global__ __launch_bounds__(256) void skin_bwd_small_kernel(SkinModel sm, int n
 // that long with four workgroups resident -- the same bytes as float4 are 18 loads.  The frame's world vertices and pose
 // offsets are copied into the LDS regions that later hold gv / vp (a thread reads and overwrites only its own vertices),
 // the pose-blend gradient leaves through LDS as float4 rows.  Arithmetic, summation order and results: unchanged.
+// G = ceil(K / 4) weight groups per vertex (1..3: up to 12 skinning weights per vertex; the transposed lists grow with it)
+template <int G>
 __global__ __launch_bounds__(256) void skin_bwd_vec_kernel(SkinModel sm, int nc, int nnz, const float* __restrict__ X,
                                                            const float* __restrict__ Voff, const float* __restrict__ A,
                                                            const float* __restrict__ M, const float* __restrict__ scale,
@@ -813,11 +821,11 @@ __global__ __launch_bounds__(256) void skin_bwd_vec_kernel(SkinModel sm, int nc,
     const int n4 = (3 * nc) >> 2, nw4 = nnz4 >> 2, nv8 = nnz8 >> 3;
     glds_wg<2, 4, 16>(cg.Vw + (size_t)r * nc * 3, sGV, n4);
     glds_wg<2, 4, 16>(Voff + (size_t)r * nc * 3, sVP, n4);
-    glds_wg<2, 4, 16>(sm.csc_w, sCW, nw4);
-    glds_wg<1, 4, 16>(sm.csc_v16, sCV, nv8);
+    glds_wg<2 * G, 4, 16>(sm.csc_w, sCW, nw4);                 // (nnz <= 2048 G)
+    glds_wg<G, 4, 16>(sm.csc_v16, sCV, nv8);
     glds_wg<1, 4, 16>(A + (size_t)r * NJ * 12, sAf, NJ * 3);
     glds_wg<1, 4, 4>(sm.csc_start, sCS, NJ + 1);
-    float4 lvp0[2], lvp1[2], lpq[2];
+    float4 lvp0[2], lvp1[2][G], lvpj[2], lpq[2];
     float ldq[2];
     int ljq[2];
 #pragma unroll
@@ -825,7 +833,9 @@ __global__ __launch_bounds__(256) void skin_bwd_vec_kernel(SkinModel sm, int nc,
         const int c = min(tid + 256 * k, nc - 1);
         const size_t qi = (size_t)r * nc + c;
         lvp0[k] = ((const float4*)sm.vpack)[c];
-        lvp1[k] = ((const float4*)sm.vpack)[nc + c];
+#pragma unroll
+        for (int g = 0; g < G; ++g) lvp1[k][g] = ((const float4*)sm.vpack)[(size_t)(1 + g) * nc + c];
+        lvpj[k] = G > 1 ? ((const float4*)sm.vpack)[(size_t)(1 + G) * nc + c] : make_float4(0.f, 0.f, 0.f, 0.f);
         ldq[k] = cg.dist[qi];
         // (with the NN launch's own neighbour records -- {x, y, z, bits(position)}, position -1: none -- idx is not needed)
         lpq[k] = cg.nnpt ? cg.nnpt[qi] : make_float4(0.f, 0.f, 0.f, 0.f);
@@ -848,13 +858,13 @@ __global__ __launch_bounds__(256) void skin_bwd_vec_kernel(SkinModel sm, int nc,
             f.vp = v3(p0, p1, p2);
 #pragma unroll
             for (int e = 0; e < 12; ++e) f.T[e] = 0.f;
-            const unsigned jb = __float_as_uint(lvp0[u].w);
-            const float w4[4] = {lvp1[u].x, lvp1[u].y, lvp1[u].z, lvp1[u].w};
+            const unsigned jb[3] = {__float_as_uint(lvp0[u].w), __float_as_uint(lvpj[u].x), __float_as_uint(lvpj[u].y)};
 #pragma unroll
-            for (int k = 0; k < 4; ++k) {
+            for (int k = 0; k < 4 * G; ++k) {
                 if (k < sm.K) {                                             // (same terms in the same order as the scalar kernel)
-                    const float w = w4[k];
-                    const float* a = sAf + 12 * ((jb >> (8 * k)) & 255u);
+                    const float4 wq = lvp1[u][k >> 2];
+                    const float w = (k & 3) == 0 ? wq.x : (k & 3) == 1 ? wq.y : (k & 3) == 2 ? wq.z : wq.w;
+                    const float* a = sAf + 12 * ((jb[k >> 2] >> (8 * (k & 3))) & 255u);
 #pragma unroll
                     for (int e = 0; e < 12; ++e) f.T[e] += w * a[e];
                 }
@@ -1222,7 +1232,7 @@ __global__ void unpack_exchange_kernel(const float* __restrict__ all, int rank, 
     } else if (t == 4 * XCH_ROW) {
         float s = 0.f;
         for (int r = 0; r < world; ++r) s += all[(size_t)r * XCH_LEN + 4 * XCH_ROW];
-        *dscale = s;
+        if (dscale) *dscale = s;                                 // (null: halo rows only, fdcap_opt_halo_exchange)
         if (sc.p) {
             float pp = *sc.p, mm = *sc.m, vv = *sc.v;
             adam_update(pp, mm, vv, scale_zero_grad ? 0.f : s, sc.a);
@@ -1511,6 +1521,9 @@ struct fdcap_ctx {
     DevBuf<int> ws_i[2];
     DevBuf<float4> ws_p;
     OptState* opt = nullptr;
+    Comm comm;                      // fdcap_comm_create: RCCL communicator of the sharded optimiser
+    DevBuf<float> xch_send, xch_all;
+    std::string comm_err;
 
     PoseModel pose_model() const {
         PoseModel pm;
@@ -1571,15 +1584,19 @@ int build_skin_set(fdcap_ctx* c, const std::vector<int64_t>& ids, SkinSet* out) 
     while (csc_w.size() & 3) csc_w.push_back(0.f);           // 16-byte staging reads whole float4s
     out->nv = nv; out->K = K; out->ldp = ldp;
     out->vpack.release(); out->csc_v16.release();
-    if (K <= 4 && nv > 0 && nv <= 65535) {
-        std::vector<float4> vp((size_t)nv * 2);
+    if (K <= 12 && nv > 0 && nv <= 65535) {
+        // planes of float4 per vertex (SkinModel::vpack): {template xyz, ids 0-3 as bytes}, {w0..w3}; for K > 4 also {w4..w7}
+        // (, {w8..w11}) and last {bits(ids 4-7), bits(ids 8-11), 0, 0} -- skin_vpack_planes(K) planes in all
+        const int G = (K + 3) / 4, NP = skin_vpack_planes(K);
+        std::vector<float4> vp((size_t)nv * NP);
         for (int i = 0; i < nv; ++i) {
-            unsigned jb = 0;
-            float w4[4] = {0.f, 0.f, 0.f, 0.f};
-            for (int k = 0; k < K; ++k) { jb |= (unsigned)wj[(size_t)i * K + k] << (8 * k); w4[k] = ww[(size_t)i * K + k]; }
-            float jf; memcpy(&jf, &jb, 4);
-            vp[(size_t)i] = make_float4(vt[3 * i], vt[3 * i + 1], vt[3 * i + 2], jf);
-            vp[(size_t)nv + i] = make_float4(w4[0], w4[1], w4[2], w4[3]);
+            unsigned jb[3] = {0, 0, 0};
+            float w12[12] = {0.f};
+            for (int k = 0; k < K; ++k) { jb[k >> 2] |= (unsigned)wj[(size_t)i * K + k] << (8 * (k & 3)); w12[k] = ww[(size_t)i * K + k]; }
+            float jf[3]; memcpy(jf, jb, 12);
+            vp[(size_t)i] = make_float4(vt[3 * i], vt[3 * i + 1], vt[3 * i + 2], jf[0]);
+            for (int g = 0; g < G; ++g) vp[(size_t)(1 + g) * nv + i] = make_float4(w12[4 * g], w12[4 * g + 1], w12[4 * g + 2], w12[4 * g + 3]);
+            if (G > 1) vp[(size_t)(1 + G) * nv + i] = make_float4(jf[1], jf[2], 0.f, 0.f);
         }
         std::vector<unsigned short> v16((csc_v.size() + 7) & ~(size_t)7, 0);
         for (size_t i = 0; i < csc_v.size(); ++i) v16[i] = (unsigned short)csc_v[i];
@@ -1913,6 +1930,8 @@ int fdcap_ctx_create(const fdcap_model_desc* md, fdcap_ctx** out) {
 void fdcap_ctx_destroy(fdcap_ctx* c) {
     if (!c) return;
     fdcap_opt_destroy(c);
+    (void)fdcap_comm_destroy(c);
+    c->xch_send.release(); c->xch_all.release();
     c->ws_adam.release();
     c->Jt.release(); c->Jd.release(); c->hand_comp.release(); c->hand_mean.release();
     c->parents.release(); c->order.release(); c->level_start.release(); c->child_start.release(); c->child_list.release(); c->depth.release();
@@ -2533,20 +2552,30 @@ static int opt_backward_impl(fdcap_ctx* c, const LossWeights& lw, int32_t log_te
         cg.nnpt = o->nnpt_valid ? o->seedpt.p : nullptr;
         cg.coef = lw.contact * cf.weight_contact / ((float)N * nc);
         cg.loss_rows = losses ? o->loss_rows.p : nullptr;
-        if (nc <= SKS_MAXV && c->contact.nnz <= SKS_MAXNNZ) {
+        const size_t lds_small = (size_t)6 * nc * sizeof(float) + (size_t)c->contact.nnz * sizeof(float) + (((size_t)c->contact.nnz * 2 + 15) & ~(size_t)15);
+        if (nc <= SKS_MAXV && c->contact.nnz <= SKS_MAXNNZ && lds_small <= 57000) {      // (+ 6.4 KB of static LDS <= 64 KB)
             const int nnz = c->contact.nnz;
-            const size_t lds = (size_t)6 * nc * sizeof(float) + (size_t)nnz * sizeof(float) + (((size_t)nnz * 2 + 15) & ~(size_t)15);
+            const size_t lds = lds_small;
             const SkinModel smc = c->contact.model();
-            if (o->skin_vec && nc <= 512 && nnz <= 2048 && (nc & 3) == 0 && smc.vpack && smc.csc_v16 &&
+            const int G = (smc.K + 3) / 4;                           // weight groups per vertex: the packed layout covers K <= 12
+            const size_t ldsv = (size_t)9 * nc * sizeof(float) + (size_t)((nnz + 3) & ~3) * sizeof(float) + (size_t)((nnz + 7) & ~7) * 2;
+            if (o->skin_vec && nc <= 512 && G <= 3 && nnz <= 2048 * G && ldsv <= 60000 && (nc & 3) == 0 && smc.vpack && smc.csc_v16 &&
                 (((size_t)o->Vw.p | (size_t)o->Voff.p | (size_t)o->dVoff.p | (size_t)o->A.p) & 15) == 0) {
-                const size_t ldsv = (size_t)9 * nc * sizeof(float) + (size_t)((nnz + 3) & ~3) * sizeof(float) + (size_t)((nnz + 7) & ~7) * 2;
-                hipLaunchKernelGGL(skin_bwd_vec_kernel, dim3(nl), dim3(256), ldsv, st, smc, nc, nnz, o->X.p, o->Voff.p, o->A.p,
-                                   o->M.p, o->scale.p, 2, o->dVoff.p, o->dA.p, o->dtransl_v.p, o->dMv.p, o->dsv.p, cg);
+#define FDC_SKV(GG) hipLaunchKernelGGL(skin_bwd_vec_kernel<GG>, dim3(nl), dim3(256), ldsv, st, smc, nc, nnz, o->X.p, o->Voff.p, o->A.p, \
+                                   o->M.p, o->scale.p, 2, o->dVoff.p, o->dA.p, o->dtransl_v.p, o->dMv.p, o->dsv.p, cg)
+                if (G == 1) FDC_SKV(1); else if (G == 2) FDC_SKV(2); else FDC_SKV(3);
+#undef FDC_SKV
             } else if (nc <= 512 && nnz <= 2048)
                 hipLaunchKernelGGL((skin_bwd_small_kernel<2, 8>), dim3(nl), dim3(256), lds, st, c->contact.model(), nc, nnz, o->X.p, o->Voff.p, o->A.p,
                                    o->M.p, o->scale.p, 2, o->dVoff.p, o->dA.p, o->dtransl_v.p, o->dMv.p, o->dsv.p, cg);
-            else
+            else if (nc <= 512)                                       // (K > 4 at the loop's contact-set size: up to 6144 list entries)
+                hipLaunchKernelGGL((skin_bwd_small_kernel<2, 24>), dim3(nl), dim3(256), lds, st, c->contact.model(), nc, nnz, o->X.p, o->Voff.p, o->A.p,
+                                   o->M.p, o->scale.p, 2, o->dVoff.p, o->dA.p, o->dtransl_v.p, o->dMv.p, o->dsv.p, cg);
+            else if (nnz <= 4096)
                 hipLaunchKernelGGL((skin_bwd_small_kernel<4, 16>), dim3(nl), dim3(256), lds, st, c->contact.model(), nc, nnz, o->X.p, o->Voff.p, o->A.p,
+                                   o->M.p, o->scale.p, 2, o->dVoff.p, o->dA.p, o->dtransl_v.p, o->dMv.p, o->dsv.p, cg);
+            else
+                hipLaunchKernelGGL((skin_bwd_small_kernel<4, 24>), dim3(nl), dim3(256), lds, st, c->contact.model(), nc, nnz, o->X.p, o->Voff.p, o->A.p,
                                    o->M.p, o->scale.p, 2, o->dVoff.p, o->dA.p, o->dtransl_v.p, o->dMv.p, o->dsv.p, cg);
         } else
         hipLaunchKernelGGL(skin_bwd_kernel<true>, dim3(nl), dim3(256), (size_t)std::min(nc, 1024) * 12 * sizeof(float), st, c->contact.model(), nc, o->X.p, o->Voff.p, o->A.p,
@@ -2987,6 +3016,99 @@ int fdcap_opt_unpack_and_step_scale(fdcap_ctx* c, int32_t ii, int32_t P, const f
     return (int)hipGetLastError();
 }
 int32_t fdcap_exchange_len(void) { return XCH_LEN; }
+
+// ---- the exchange inside the library (SURVEY 8b "halo_exchange", 8e): RCCL on the compute stream ----------------
+namespace {
+__global__ void pack_exchange_kernel(const float* __restrict__ X, const float* __restrict__ CAM, int n_local, float* __restrict__ xch) {
+    const int t = threadIdx.x;                                          // boundary rows as they are (no step): slots 0,1 first two, 2,3 last two owned rows
+    if (t < 4 * XCH_ROW) {
+        const int slot = t / XCH_ROW, e = t % XCH_ROW;
+        const int row = slot < 2 ? 2 + slot : n_local + slot - 2;
+        xch[t] = e < XDIM ? X[(size_t)row * XDIM + e] : CAM[(size_t)row * 16 + e - XDIM];
+    } else if (t < XCH_LEN) xch[t] = 0.f;
+}
+int comm_fail(fdcap_ctx* c, ncclResult_t r, const char* what) {
+    c->comm_err = std::string(what) + ": " + (rccl().GetErrorString ? rccl().GetErrorString(r) : "?");
+    return FDCAP_E_COMM;
+}
+int comm_buffers(fdcap_ctx* c) {
+    HIP_TRY(c->xch_send.ensure(XCH_LEN));
+    HIP_TRY(c->xch_all.ensure((size_t)c->comm.world * XCH_LEN));
+    return 0;
+}
+}  // namespace
+
+int fdcap_comm_unique_id(uint8_t* id128) {
+    if (!id128) return FDCAP_E_ARG;
+    static_assert(sizeof(ncclUniqueId) == FDCAP_UNIQUE_ID_BYTES, "ncclUniqueId size");
+    if (!rccl().load()) return FDCAP_E_COMM;
+    ncclUniqueId id;
+    if (rccl().GetUniqueId(&id) != ncclSuccess) return FDCAP_E_COMM;
+    memcpy(id128, &id, sizeof(id));
+    return FDCAP_OK;
+}
+
+int fdcap_comm_create(fdcap_ctx* c, const uint8_t* id128, int32_t rank, int32_t world) {
+    if (!c || !id128 || world <= 0 || rank < 0 || rank >= world) return FDCAP_E_ARG;
+    if (c->comm.comm) return FDCAP_E_STATE;
+    if (!rccl().load()) { c->comm_err = rccl().err; return FDCAP_E_COMM; }
+    ncclUniqueId id;
+    memcpy(&id, id128, sizeof(id));
+    ncclComm_t comm = nullptr;
+    const ncclResult_t r = rccl().CommInitRank(&comm, world, id, rank);          // (on the calling thread's current HIP device)
+    if (r != ncclSuccess) return comm_fail(c, r, "ncclCommInitRank");
+    c->comm.comm = comm; c->comm.rank = rank; c->comm.world = world;
+    return FDCAP_OK;
+}
+
+int fdcap_comm_destroy(fdcap_ctx* c) {
+    if (!c) return FDCAP_E_ARG;
+    if (c->comm.comm) { (void)rccl().CommDestroy(c->comm.comm); c->comm = Comm(); }
+    return FDCAP_OK;
+}
+
+const char* fdcap_comm_last_error(fdcap_ctx* c) { return c ? c->comm_err.c_str() : ""; }
+
+// Fill the halo rows from the neighbouring ranks (before the first iteration, after fdcap_opt_import_state, after each
+// iteration of mode 'local''s second loop): boundary rows as they are -> all-gather -> unpack, three enqueues on `stream`.
+int fdcap_opt_halo_exchange(fdcap_ctx* c, void* stream) {
+    if (!c || !c->opt) return FDCAP_E_STATE;
+    if (!c->comm.comm) return FDCAP_E_STATE;
+    OptState* o = c->opt;
+    hipStream_t st = (hipStream_t)stream;
+    int e = comm_buffers(c);
+    if (e) return e;
+    hipLaunchKernelGGL(pack_exchange_kernel, dim3(1), dim3(384), 0, st, o->X.p, o->CAM.p, o->cfg.n_local, c->xch_send.p);
+    const ncclResult_t r = rccl().AllGather(c->xch_send.p, c->xch_all.p, XCH_LEN, ncclFloat, c->comm.comm, st);
+    if (r != ncclSuccess) return comm_fail(c, r, "ncclAllGather");
+    hipLaunchKernelGGL(unpack_exchange_kernel, dim3(1), dim3(384), 0, st, c->xch_all.p, c->comm.rank, c->comm.world, o->cfg.n_local,
+                       o->X.p, o->CAM.p, (float*)nullptr, AdamTensor{}, 0);
+    return (int)hipGetLastError();
+}
+
+// The sharded iteration tail, whole: Adam on this rank's rows + message -> ONE ncclAllGather on `stream` -> halo rows, the
+// rank-ordered sum of the scale-gradient partials, Adam on `scale`.  Replaces the caller-side sequence
+// fdcap_opt_step_rows_and_pack / all-gather / fdcap_opt_unpack_and_step_scale (same kernels, same bits).
+int fdcap_opt_exchange(fdcap_ctx* c, int32_t ii, int32_t P, void* stream) {
+    if (!c || !c->opt) return FDCAP_E_STATE;
+    if (!c->comm.comm) return FDCAP_E_STATE;
+    int e = comm_buffers(c);
+    if (e) return e;
+    e = fdcap_opt_step_rows_and_pack(c, ii, P, c->xch_send.p, stream);
+    if (e) return e;
+    const ncclResult_t r = rccl().AllGather(c->xch_send.p, c->xch_all.p, XCH_LEN, ncclFloat, c->comm.comm, (hipStream_t)stream);
+    if (r != ncclSuccess) return comm_fail(c, r, "ncclAllGather");
+    return fdcap_opt_unpack_and_step_scale(c, ii, P, c->xch_all.p, c->comm.rank, c->comm.world, stream);
+}
+
+// Sum of n doubles over the ranks, in place (the logged loss partial sums; d loss / d scale never travels this way).
+int fdcap_comm_allreduce_f64(fdcap_ctx* c, double* buf_d, int32_t n, void* stream) {
+    if (!c || !buf_d || n <= 0) return FDCAP_E_ARG;
+    if (!c->comm.comm) return FDCAP_E_STATE;
+    const ncclResult_t r = rccl().AllReduce(buf_d, buf_d, (size_t)n, ncclDouble, ncclSum, c->comm.comm, (hipStream_t)stream);
+    if (r != ncclSuccess) return comm_fail(c, r, "ncclAllReduce");
+    return FDCAP_OK;
+}
 
 int fdcap_opt_get_contact(fdcap_ctx* c, float* dist, int32_t* idx, void* stream) {
     if (!c || !c->opt) return FDCAP_E_STATE;

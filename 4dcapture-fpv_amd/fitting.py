@@ -130,6 +130,15 @@ class FittingOP:
         self._camera_ext_init = None if camera_ext is None else np.asarray(camera_ext, np.float32).reshape(-1, 4, 4)
         self.shard = FrameShard(self.num_body, group)
         self.group = group
+        # The exchange inside the library (fdcap_comm_* / fdcap_opt_exchange: RCCL on the compute stream, two C calls per
+        # iteration) whenever the group runs over RCCL; FDCAP_C_COMM=0 keeps torch.distributed's collectives (the path the
+        # gloo tests -- ranks sharing one GPU, which RCCL refuses -- always take).
+        self._c_comm = False
+        if group is not None:
+            import os
+            import torch.distributed as dist
+            if dist.get_backend(group) == "nccl" and os.environ.get("FDCAP_C_COMM", "1") != "0":
+                self._init_c_comm()
         self.dct_mtx = None if dct_mtx is None else np.ascontiguousarray(dct_mtx, dtype=np.float32)
         self._c_dct_init = c_dct_init
         self.dct_num_iter = int(dct_num_iter)
@@ -139,6 +148,40 @@ class FittingOP:
         self.body_rotation_rec = None
         self.log = None
         self.idx1 = None
+
+    def _init_c_comm(self):
+        """Rank 0 draws the RCCL unique id, torch.distributed carries it to the other ranks (the out-of-band channel any
+        launcher has), every rank joins the library's own communicator."""
+        import ctypes
+        import torch
+        import torch.distributed as dist
+        lib, h = self.ctx.lib, self.ctx.handle
+        idb = (ctypes.c_uint8 * 128)()
+        if self.shard.rank == 0:
+            capi.check(lib.fdcap_comm_unique_id(idb), "fdcap_comm_unique_id")
+        t = torch.tensor(list(idb), dtype=torch.uint8, device=self.device)
+        dist.broadcast(t, src=self.shard.global_rank(0), group=self.group)
+        idb = (ctypes.c_uint8 * 128)(*t.cpu().tolist())
+        rc = lib.fdcap_comm_create(h, idb, self.shard.rank, self.shard.world)
+        if rc:
+            raise capi.FdcapError(f"fdcap_comm_create: {rc} {lib.fdcap_comm_last_error(h).decode()}")
+        self._c_comm = True
+
+    def _halos(self):
+        """Halo rows <- the neighbouring ranks' boundary rows as they are."""
+        if self._c_comm:
+            capi.check(self.ctx.lib.fdcap_opt_halo_exchange(self.ctx.handle, capi.current_stream()), "fdcap_opt_halo_exchange")
+        else:
+            exchange_halos(self.shard, self._rows_x, self._rows_cam)
+
+    def _sum_over_ranks(self, t64):
+        """In-place sum of a float64 device tensor over the ranks (logged loss partial sums)."""
+        import torch
+        if self._c_comm:
+            capi.check(self.ctx.lib.fdcap_comm_allreduce_f64(self.ctx.handle, capi.dptr(t64), t64.numel(), capi.current_stream()),
+                       "fdcap_comm_allreduce_f64")
+        else:
+            allreduce_scalars(self.shard, torch.zeros(1, device=self.device), t64)
 
     # ---- :450-489 -------------------------------------------------------------------------
     def init(self, body_data_rotation):
@@ -183,7 +226,7 @@ class FittingOP:
         capi.check(lib.fdcap_opt_set_inputs(self.ctx.handle, capi.dptr(d_data), capi.dptr(d_init), capi.dptr(d_mask),
                                             capi.dptr(d_cam), st), "fdcap_opt_set_inputs")
         torch.cuda.current_stream().synchronize()
-        exchange_halos(self.shard, self._rows_x, self._rows_cam)
+        self._halos()
         xl = int(lib.fdcap_exchange_len())
         self._xch_send = torch.zeros(xl, device=dev)
         self._xch_all = torch.zeros(self.shard.world, xl, device=dev)
@@ -192,7 +235,7 @@ class FittingOP:
 
     # ---- :491-635 -------------------------------------------------------------------------
     def fitting(self, body_data, mode="global", log_every=0, checkpoint_every=0, checkpoint_path=None, resume=None,
-                check_finite_every=0):
+                check_finite_every=0, snapshot_at=()):
         """body_data: [N,75] (device tensor or numpy), SMPLify-X layout (:64-76).
         Returns (body_rec [N_local,75] device tensor, scale numpy scalar, camera_ext [N_local,4,4])
         -- the whole clip when not sharded, exactly the reference's triple (:635).
@@ -201,14 +244,18 @@ class FittingOP:
             `checkpoint_path` (sharded runs: one file per rank, suffix .rank<r>);
           resume=path: continue such a run from where the file left off -- bit-identical to the uninterrupted run;
           check_finite_every=k: every k iterations count the non-finite parameters on the device and raise if any
-            (the opt-in counterpart of the reference's set_detect_anomaly(True), :561).
+            (the opt-in counterpart of the reference's set_detect_anomaly(True), :561);
+          snapshot_at=(k, ...): after the k-th optimiser step keep device copies of (body_rotation_rec [N_local,78], scale,
+            camera_ext [N_local,16]) in self.snapshots[k] -- no host sync; for trajectory comparisons (tests/test_gpu_parity500.py).
         Sharded runs: every argument of this call and `num_iter` must be the same on all ranks (they decide which collectives
         are issued).  `verbose` may differ -- prints come from rank 0 only, and rank 0's flag alone decides whether the loss
         history is read back (all-reduced) during the loop, so a rank-0-only verbose run is legal."""
         import torch
         if mode not in ("global", "local", "dct"):
             raise ValueError("mode must be 'local', 'global' or 'dct' (global_optimization.py:660)")
-        if (checkpoint_every or resume or check_finite_every) and mode != "global":
+        snapshot_at = frozenset(int(k) for k in snapshot_at)
+        self.snapshots = {}
+        if (checkpoint_every or resume or check_finite_every or snapshot_at) and mode != "global":
             raise ValueError("checkpoint / resume / check_finite are implemented for mode 'global'")
         if checkpoint_every and not checkpoint_path:
             raise ValueError("checkpoint_every needs checkpoint_path")
@@ -238,9 +285,9 @@ class FittingOP:
         # work between the collective's stream and this one costs ~17 us per iteration on a one-rank RCCL group
         # (tools/host_issue_probe.py), so the overlap only pays when the all-gather takes longer than that to come back.
         env_ov = os.environ.get("FDCAP_XCH_OVERLAP", "auto")
-        overlap = multi and env_ov == "1"
+        overlap = multi and env_ov == "1" and not self._c_comm        # (the library's own exchange runs on the compute stream: nothing to overlap)
         tune = None
-        if multi and env_ov not in ("0", "1") and mode != "dct" and ii0 + 18 <= min(P, self.num_iter):
+        if multi and not self._c_comm and env_ov not in ("0", "1") and mode != "dct" and ii0 + 18 <= min(P, self.num_iter):
             tune = [torch.cuda.Event(enable_timing=True) for _ in range(3)]
         self.exchange_overlap = overlap
         if mode == "dct":
@@ -265,7 +312,7 @@ class FittingOP:
             part = hist[flushed:upto]
             if multi:
                 part = part.clone()
-                allreduce_scalars(self.shard, torch.zeros(1, device=dev), part)
+                self._sum_over_ranks(part)
             rows = part.cpu().numpy()
             for k in range(upto - flushed):
                 self._append_log(log, logged[flushed + k], logged[flushed + k] >= P, rows[k])
@@ -291,7 +338,10 @@ class FittingOP:
                     logged.append(ii)
                 # (2: the logged sums are delivered by the step launch that follows -- one launch less per logged iteration)
                 capi.check(lib.fdcap_opt_backward(h, ii, P, 2 if do_log else 0, st), "fdcap_opt_backward")
-                if multi:
+                if multi and self._c_comm:
+                    # the same tail inside the library: Adam on the rows + message, ncclAllGather on this stream, unpack + scale
+                    capi.check(lib.fdcap_opt_exchange(h, ii, P, st), "fdcap_opt_exchange")
+                elif multi:
                     # one collective per iteration: boundary rows (after Adam) + the scale-gradient partial travel
                     # together; every rank then sums the partials in rank order and steps `scale` identically
                     capi.check(lib.fdcap_opt_step_rows_and_pack(h, ii, P, capi.dptr(self._xch_send), st), "step_rows_and_pack")
@@ -312,6 +362,9 @@ class FittingOP:
                 # VERBOSE_FLUSH logged iterations (one read-back each) instead of only after the last one
                 if flush_in_loop and do_log and len(logged) - flushed >= VERBOSE_FLUSH:
                     flush(len(logged))
+                if ii + 1 in snapshot_at:
+                    nl_ = self.shard.n_local
+                    self.snapshots[ii + 1] = (self._rows_x[2:2 + nl_].clone(), self._scale.clone(), self._rows_cam[2:2 + nl_].clone())
                 if check_finite_every and (ii + 1) % check_finite_every == 0:
                     self._check_finite(ii)
                 if checkpoint_every and (ii + 1) % checkpoint_every == 0 and ii + 1 < self.num_iter:
@@ -377,7 +430,7 @@ class FittingOP:
                                   f"two ranks' writes; resume from an older, complete set")
         capi.check(lib.fdcap_opt_import_state(h, capi.dptr(state), capi.current_stream()), "fdcap_opt_import_state")
         torch.cuda.current_stream().synchronize()
-        exchange_halos(self.shard, self._rows_x, self._rows_cam)
+        self._halos()
         return nxt
 
     def _check_finite(self, ii):
@@ -480,7 +533,9 @@ class FittingOP:
                 if self.verbose and sh.rank == 0:
                     print('[INFO][fitting] iter={:d}, l_rec={:f}, l_vposer={:f}, loss_smoothing={:f}, loss_contact={:f}, '
                           'loss_dct={:f}, total_loss={:f}'.format(*self.log2[-1]))
-            if multi:
+            if multi and self._c_comm:
+                capi.check(lib.fdcap_opt_exchange(h, k, BIG, st), "fdcap_opt_exchange")
+            elif multi:
                 capi.check(lib.fdcap_opt_step_rows_and_pack(h, k, BIG, capi.dptr(self._xch_send), st), "step_rows_and_pack")
                 allgather_packed(sh, self._xch_send, self._xch_all)
                 capi.check(lib.fdcap_opt_unpack_and_step_scale(h, k, BIG, capi.dptr(self._xch_all), sh.rank, sh.world, st),
@@ -536,7 +591,7 @@ class FittingOP:
                           'loss_contact_smoothing={:f}, total_loss={:f}'.format(*self.log2[-1]))
             capi.check(lib.fdcap_opt_step_x(h, self.num_iter + jj + 1, st), "fdcap_opt_step_x")
             if multi:
-                exchange_halos(self.shard, self._rows_x, self._rows_cam)
+                self._halos()
 
     def _append_log(self, log, ii, phase2, s=None):
         s = self._losses.cpu().numpy() if s is None else s

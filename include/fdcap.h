@@ -30,6 +30,8 @@ extern "C" {
 #define FDCAP_E_ARG (-1)      /* null pointer / bad size */
 #define FDCAP_E_STATE (-2)    /* call order (e.g. no scene registered) */
 #define FDCAP_E_NODEVICE (-3) /* no HIP device visible */
+#define FDCAP_E_COMM (-4)     /* RCCL not loadable, or an RCCL call failed: fdcap_comm_last_error() */
+#define FDCAP_UNIQUE_ID_BYTES 128
 
 #define FDCAP_NUM_JOINTS 55
 #define FDCAP_XDIM 78         /* optimised row: transl3 6D6 betas10 latent32 lh12 rh12 camt3 */
@@ -305,6 +307,27 @@ int fdcap_opt_step_rows_and_pack(fdcap_ctx* ctx, int32_t ii, int32_t first_phase
 int fdcap_opt_unpack_and_step_scale(fdcap_ctx* ctx, int32_t ii, int32_t first_phase2_iter, const float* gathered_d,
                                     int32_t rank, int32_t world, void* stream);
 int32_t fdcap_exchange_len(void);
+
+/* ---- the exchange INSIDE the library (SURVEY 8b "halo_exchange", 8e) -----------------------------------------------------
+ * The reference has no distributed code; this is the communicator of the frame-sharded optimiser for callers that are not
+ * Python (and for Python: two calls per iteration instead of five, no stream hand-over).  RCCL is bound at run time
+ * (dlopen librccl.so.1; FDCAP_RCCL_LIB overrides): FDCAP_E_COMM when it is not there.  One communicator per context, created
+ * on the calling thread's current HIP device; every rank of the job calls fdcap_comm_create with the SAME id.
+ *   fdcap_comm_unique_id : rank 0 only; `id128` [FDCAP_UNIQUE_ID_BYTES] host bytes to hand to the other ranks out of band
+ *   fdcap_comm_create    : ncclCommInitRank (collective: blocks until all `world` ranks arrive)
+ *   fdcap_opt_halo_exchange : halo rows <- the neighbours' boundary rows as they are (before the first iteration, after
+ *                          fdcap_opt_import_state, after each fdcap_opt_step_x of mode 'local')
+ *   fdcap_opt_exchange   : the sharded iteration tail, whole -- fdcap_opt_step_rows_and_pack, ONE ncclAllGather of
+ *                          fdcap_exchange_len() floats per rank on `stream`, fdcap_opt_unpack_and_step_scale -- in place of
+ *                          fdcap_opt_step; same kernels, same bits as the caller-side sequence above
+ *   fdcap_comm_allreduce_f64 : in-place sum over the ranks (the logged loss partial sums) */
+int fdcap_comm_unique_id(uint8_t* id128);
+int fdcap_comm_create(fdcap_ctx* ctx, const uint8_t* id128, int32_t rank, int32_t world);
+int fdcap_comm_destroy(fdcap_ctx* ctx);
+const char* fdcap_comm_last_error(fdcap_ctx* ctx);
+int fdcap_opt_halo_exchange(fdcap_ctx* ctx, void* stream);
+int fdcap_opt_exchange(fdcap_ctx* ctx, int32_t ii, int32_t first_phase2_iter, void* stream);
+int fdcap_comm_allreduce_f64(fdcap_ctx* ctx, double* buf_d, int32_t n, void* stream);
 /* Overlap of the exchange with the next forward.  Issued between the two calls above, i.e. while the all-gather is in
  * flight: the part of iteration ii's forward (ii = the NEXT iteration; log_terms as its fdcap_opt_backward will get) that needs
  * neither `scale` nor the halo rows -- decoder, pose state and the contact set's pose-blend product of the owned rows

@@ -19,6 +19,8 @@ Recipe:
 Usage:  python tests/golden/make_golden.py            (writes tests/golden/*.npz)
         python tests/golden/make_golden.py --chamfer  (ref_chamfer_python.npz: /root/reference/chamfer_python.py)
         python tests/golden/make_golden.py --smoother | --dct | --g500 (ref_global_500it.npz: the fixed budget, :672)
+        python tests/golden/make_golden.py --yardstick500 f64 | f32t1   (oracle_global_500it_*.npz: the ORACLE on the same inputs in
+                                                                         fp64 / in fp32 on one thread -- yardsticks, not goldens)
 """
 import contextlib
 import hashlib
@@ -110,7 +112,7 @@ LOG2_RE = re.compile(r"iter=(\d+), l_rec=([-\d.e]+), loss_local_smoothing=([-\d.
 
 
 def run_global(g, num_iter, num_verts, ns, model_seed, vposer_seed, clip_seed, scene_seed,
-               contact_seed, per_part, tmp, mode="global", snapshot_at=()):
+               contact_seed, per_part, tmp, mode="global", snapshot_at=(), state_at=()):
     n = 300  # the reference hard-codes 300 (:465, :472, :41-42)
     bm = synth.make_body_model(num_verts, seed=model_seed)
     vp = synth.make_vposer(seed=vposer_seed)
@@ -152,7 +154,7 @@ def run_global(g, num_iter, num_verts, ns, model_seed, vposer_seed, clip_seed, s
     f.optimizer = torch.optim.Adam([f.body_rotation_rec, f.scale, f.camera_ext, f.c_dct],
                                    lr=f.init_lr_h)
 
-    snaps = {}
+    snaps, states = {}, {}
     if snapshot_at:
         # the optimiser object is ours to supply (:188 builds a plain Adam): this one also keeps copies of the leaves after
         # chosen steps, so the fixture shows WHERE along the 500 iterations two implementations part -- no reference code changes
@@ -163,6 +165,14 @@ def run_global(g, num_iter, num_verts, ns, model_seed, vposer_seed, clip_seed, s
                 if self._n in snapshot_at:
                     snaps[self._n] = (f.body_rotation_rec.detach().clone().numpy(), np.float32(f.scale.detach().item()),
                                       f.camera_ext.detach().clone().numpy())
+                if self._n in state_at:                       # torch.optim.Adam's own per-parameter state (exp_avg, exp_avg_sq, step)
+                    st = {}
+                    for nm, prm in (("x", f.body_rotation_rec), ("s", f.scale), ("c", f.camera_ext)):
+                        e = self.state.get(prm, {})
+                        st[nm + "_m"] = e["exp_avg"].detach().clone().numpy() if "exp_avg" in e else np.zeros(tuple(prm.shape), np.float32)
+                        st[nm + "_v"] = e["exp_avg_sq"].detach().clone().numpy() if "exp_avg_sq" in e else np.zeros(tuple(prm.shape), np.float32)
+                        st[nm + "_step"] = np.int64(int(e["step"])) if "step" in e else np.int64(0)
+                    states[self._n] = st
                 return r
         f.optimizer = RecordingAdam([f.body_rotation_rec, f.scale, f.camera_ext, f.c_dct], lr=f.init_lr_h)
 
@@ -208,6 +218,10 @@ def run_global(g, num_iter, num_verts, ns, model_seed, vposer_seed, clip_seed, s
         extra = dict(snap_iters=np.array(ks, dtype=np.int64), snap_x78=np.stack([snaps[k][0] for k in ks]),
                      snap_scale=np.array([snaps[k][1] for k in ks], dtype=np.float32),
                      snap_cam=np.stack([snaps[k][2] for k in ks]))
+        for k, st in states.items():                         # Adam state after step k: a run can be RE-SYNCHRONISED there (tests/test_gpu_parity500.py)
+            for nm, v in st.items():
+                extra[f"adam{k}_{nm}"] = v
+        extra["state_iters"] = np.array(sorted(states), dtype=np.int64)
     return dict(
         **extra,
         num_iter=num_iter, num_verts=num_verts, ns=ns, model_seed=model_seed,
@@ -331,7 +345,43 @@ def run_chamfer_python():
     return out
 
 
+SNAP500 = (5, 20, 50, 100, 105, 200, 300, 305, 400, 401, 405, 420, 450, 455, 495, 500)
+STATE500 = (100, 300, 400, 450, 495)      # windows of 5 steps start here: (100 -> 105), (300 -> 305), (400 -> 405: the phase switch), (450 -> 455), (495 -> 500)
+
+
+def run_yardstick500(dtype, threads):
+    """NOT the reference: the ORACLE's loop on ref_global_500it.npz's inputs, in another precision / reduction order.  It says
+    how far two correct implementations of the same 500 Adam iterations land from each other (three L1 terms: a rounding-level
+    sign flip moves a parameter by up to 2 lr per step) -- the yardstick the GPU-vs-reference distance is read against."""
+    from oracle.fitting import FittingOracle
+    g = np.load(os.path.join(HERE, "ref_global_500it.npz"))
+    torch.set_num_threads(threads)
+    bm = synth.make_body_model(int(g["num_verts"]), seed=int(g["model_seed"]))
+    vp = synth.make_vposer(seed=int(g["vposer_seed"]))
+    f = FittingOracle(SMPLXOracle(bm, dtype), VPoserDecoder.from_data(vp, dtype), g["scene"], g["vid"], list(g["camerapose"]), 300,
+                      num_iter=500, dtype=dtype, one_direction_chamfer=False)
+    from oracle import rotrepr
+    x78 = rotrepr.convert_to_6D_rot(torch.as_tensor(g["body_in"]).to(dtype))
+    idx1 = f.init(x78)
+    x78 = x78.detach()
+    snaps = {}
+    for ii in range(500):
+        f.step(ii, x78, idx1)
+        if ii + 1 in SNAP500:
+            snaps[ii + 1] = (f.body_rotation_rec.detach().clone().numpy(), float(f.scale.detach()), f.camera_ext.detach().clone().numpy())
+    ks = sorted(snaps)
+    return dict(snap_iters=np.array(ks, dtype=np.int64), snap_x78=np.stack([snaps[k][0] for k in ks]).astype(np.float32 if dtype == torch.float32 else np.float64),
+                snap_scale=np.array([snaps[k][1] for k in ks]), snap_cam=np.stack([snaps[k][2] for k in ks]),
+                log=np.array(f.loss_log, dtype=np.float64), idx1=np.asarray(idx1, dtype=np.int64), threads=np.int64(threads))
+
+
 def main():
+    if "--yardstick500" in sys.argv:      # after --g500; ~10 min of CPU each
+        which = sys.argv[sys.argv.index("--yardstick500") + 1]
+        res = run_yardstick500(torch.float64 if which == "f64" else torch.float32, 4 if which == "f64" else 1)
+        np.savez_compressed(os.path.join(HERE, f"oracle_global_500it_{which}.npz"), **res)
+        print("wrote oracle_global_500it_" + which, "scale", res["snap_scale"][-1], "last log", res["log"][-1])
+        return
     if "--chamfer" in sys.argv:
         res = run_chamfer_python()
         np.savez_compressed(os.path.join(HERE, "ref_chamfer_python.npz"), **res)
@@ -348,7 +398,7 @@ def main():
         with tempfile.TemporaryDirectory() as tmp:
             res = run_global(g, tmp=tmp, num_iter=500, num_verts=640, ns=3000, model_seed=40, vposer_seed=41,
                              clip_seed=42, scene_seed=43, contact_seed=44, per_part=24,
-                             snapshot_at=(5, 20, 50, 100, 200, 300, 400, 401, 420, 450, 500))
+                             snapshot_at=SNAP500, state_at=STATE500)
             np.savez_compressed(os.path.join(HERE, "ref_global_500it.npz"), **res)
             print("wrote ref_global_500it", "idx1", res["idx1"], "scale", res["scale"], "last log", res["log"][-1])
         return

@@ -170,3 +170,35 @@ def test_sharded_run_matches_single_rank(world, n):
     for r in res:
         assert abs(r[5] - ref[4]) < 1e-6
         np.testing.assert_allclose(r[6][:5], ref[5][:5], rtol=1e-6)
+
+
+def _agree_worker(rank, world, port, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from fdcap_amd.dist import agree_on, same_on_all_ranks
+        sh = FrameShard(40, dist.group.WORLD)
+        # per-rank configuration that differs (verbose on rank 0 only): every rank takes rank 0's value
+        got = agree_on(sh, 1 if rank == 0 else 0)
+        lo, hi = same_on_all_ranks(sh, 100 + rank)          # (checkpoint files from different iterations: min != max)
+        lo2, hi2 = same_on_all_ranks(sh, 250)
+        q.put((rank, got, lo, hi, lo2, hi2))
+    finally:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def test_rank_zero_decides_collective_schedules_and_checkpoint_sets_are_checked():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    procs = [ctx.Process(target=_agree_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=120) for _ in range(2))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert [r[1] for r in res] == [1, 1]                    # rank 1 said 0, follows rank 0
+    assert all(r[2:4] == (100, 101) for r in res) and all(r[4:6] == (250, 250) for r in res)
