@@ -324,9 +324,6 @@ __global__ __launch_bounds__(256) void nn_mfma_kernel(const float* __restrict__ 
             __syncthreads();
         }
     }
-#if defined(FDC_NN_EXP) && FDC_NN_EXP == 6
-    nsurv = 0;                                              // experiment: prologue + survivor list only
-#endif
     auto chunk_base = [&](int s) -> int { return t_begin + (cull ? (int)slist[s] : s) * MF_CH; };
 
     // staging (issue-early / write-late): the global loads of the next chunk are issued before the
@@ -389,16 +386,7 @@ __global__ __launch_bounds__(256) void nn_mfma_kernel(const float* __restrict__ 
                 const float t4 = fminf(fminf(acc[12], acc[13]), acc[14]);
                 const float m = fminf(fminf(fminf(t0, t1), t2), fminf(fminf(t3, t4), acc[15]));
                 FDC_STAT(0, lane == 0);
-#if defined(FDC_NN_EXP) && FDC_NN_EXP >= 1
-#if FDC_NN_EXP == 2 || FDC_NN_EXP == 4
-                own_d[n] = fminf(own_d[n], m);         // experiment: no branch at all
-#else
-                if (m < -1e30f) own_d[n] = m;          // experiment: fast path only (results wrong)
-#endif
-                if (false) {
-#else
                 if (__any(m < thr[n])) {
-#endif
                     FDC_STAT(1, lane == 0);
                     // rare path: exact fp32 re-evaluation of the surviving rows
 #pragma unroll
@@ -533,7 +521,6 @@ __global__ __launch_bounds__(64 * WPB, NQ == 1 ? FDC_ST4_OCC : FDC_ST4_OCC2) voi
     const int sub = wave % WPG, gslot = wave / WPG;             // this wave's share of its group's chunks: WPG k + sub
     const int ngroups = (nq + 32 * NQ - 1) / (32 * NQ);
     const int nwg = (ngroups + GPW - 1) / GPW;
-    const int per_xcd = (nwg + 7) >> 3;
 #ifdef FDC_NN_TIMELINE
     const unsigned long long tl_t0 = wall_clock64();             // instrumentation build only: 100 MHz device-wide clock
     unsigned long long tl_p[4] = {0, 0, 0, 0};
@@ -541,14 +528,10 @@ __global__ __launch_bounds__(64 * WPB, NQ == 1 ? FDC_ST4_OCC : FDC_ST4_OCC2) voi
 #else
 #define TL_STAMP(k)
 #endif
-#ifdef FDC_ST4_XCDMAJOR
-    const int wg = (blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);       // r1-r2: each XCD serves a contiguous range of frames
-#else
     // r3: plain round-robin over the XCDs (workgroup b runs on XCD b % 8).  Contiguous frame ranges per XCD leave the XCDs with
     // 13 % different amounts of work (frames near the floor cost more) and the launch ends with its slowest XCD; interleaved,
     // every XCD sees every part of the clip -- consecutive frames share their scene cells anyway.  72.57 -> 72.31 ms per step.
-    const int wg = (cache.order_mode >= 2 && (int)blockIdx.x < nwg) ? cache.hdr[(3 + cache.order_mode) * ((nq + 31) / 32) + (int)blockIdx.x] : (int)blockIdx.x; (void)per_xcd;
-#endif
+    const int wg = (cache.order_mode >= 2 && (int)blockIdx.x < nwg) ? cache.hdr[(3 + cache.order_mode) * ((nq + 31) / 32) + (int)blockIdx.x] : (int)blockIdx.x;
     const int group = wg * GPW + gslot;
     const bool idle = wg >= nwg || group >= ngroups;            // idle waves still meet the barrier below
     const int wq0 = idle ? nq : group * (32 * NQ);
@@ -742,9 +725,6 @@ __global__ __launch_bounds__(64 * WPB, NQ == 1 ? FDC_ST4_OCC : FDC_ST4_OCC2) voi
     };
     int nsurv = 4 * myn;                                         // work items are quarter chunks: 4 k + quarter
     bool listed = false;
-#if defined(FDC_ST4_ABLATE) && FDC_ST4_ABLATE >= 2
-    if (false) {                                                 // timing ablation only: no survivor list either
-#else
     if (cull && n_kept >= 0) {                                    // the kept list is still a superset of what this launch can need
         nsurv = n_kept;
         listed = true;
@@ -752,7 +732,6 @@ __global__ __launch_bounds__(64 * WPB, NQ == 1 ? FDC_ST4_OCC : FDC_ST4_OCC2) voi
         if (lane < n_kept) slist[wave][lane] = (unsigned short)id_pre;
         __builtin_amdgcn_wave_barrier();
     } else if (cull) {
-#endif
         nsurv = 0;
         listed = true;
         int ncell = 0;
@@ -879,9 +858,6 @@ __global__ __launch_bounds__(64 * WPB, NQ == 1 ? FDC_ST4_OCC : FDC_ST4_OCC2) voi
     constexpr int QT = NT / 4;                                   // tiles per work item (quarter chunk)
     static_assert(QT % ST4_PF == 0, "the prefetch ring turns a whole number of times per work item");
 
-#if defined(FDC_ST4_ABLATE) && FDC_ST4_ABLATE >= 1
-    nsurv = 0;                                                   // timing ablation only (wrong results): no main loop
-#endif
 #ifdef FDC_NN_STATS
     if (lane == 0 && !idle) atomicAdd(&g_nn_hist[(listed ? 0 : 16) + (nsurv > 0 ? 32 - __clz(nsurv) : 0)], 1ull);
 #endif
@@ -970,16 +946,7 @@ __global__ __launch_bounds__(64 * WPB, NQ == 1 ? FDC_ST4_OCC : FDC_ST4_OCC2) voi
                     const float g0 = fminf(fminf(t0, t1), t2), g1 = fminf(fminf(t3, t4), acc[15]);      // rows 0-8, rows 9-15
                     const float m = fminf(g0, g1);
                     FDC_STAT(0, lane == 0);
-#if defined(FDC_ST4_ABLATE) && FDC_ST4_ABLATE == -1
-                    asm volatile("" :: "v"(m), "v"(thr[n]));               // (keeps the MFMA + min tree alive)
-                    if (false) {                                           // timing ablation only (wrong results): no slow path
-#elif defined(FDC_ST4_ABLATE) && FDC_ST4_ABLATE == -2
-                    if (__any(m < thr[n])) {                               // timing ablation only: the branch and its wave vote, empty body
-                        asm volatile("" :: "v"(m));
-                        continue;
-#else
                     if (__any(m < thr[n])) {
-#endif
                         FDC_STAT(1, lane == 0);
                         // This lane's rows that passed, as a bit mask: sign(acc[r] - thr) shifted in row by row (v_sub_f32 +
                         // v_alignbit_b32 per row; a difference of two distinct finite floats is never rounded to zero, an

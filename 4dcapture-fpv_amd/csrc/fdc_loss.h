@@ -42,6 +42,30 @@ FDC_HD float world_smooth_grad(int g, int n_total, float jm1, float j0, float jp
 }
 
 struct AdamScalars { float one_minus_b1, b2, one_minus_b2, step_size, bc2_sqrt, eps; };
+struct AdamTensor { float* p; float* m; float* v; const float* g; size_t n; AdamScalars a; };
+
+// A DEFERRED optimiser step (fdcap_opt_backward_and_step): the Adam update of iteration ii is not a launch of its own.
+//   `scale`            : stepped in place by one extra workgroup of the backward's LAST launch (ScaleTail below: the per-frame
+//                        partials of d loss / d scale are complete by then, and no kernel of that launch reads `scale`);
+//   body_rotation_rec, : applied by the next iteration's first two launches where they read the parameters anyway --
+//   camera_ext           vposer_fwd_*_kernel steps the latent columns of its 16 rows on the way into LDS (nothing written back:
+//                        four quarter-workgroups share a row block), pose_fwd_kernel steps its frame's whole row of both
+//                        tensors, uses it and writes parameters and moments back (a frame's row has no other reader there).
+// Same arithmetic (adam_update, vp_sum_dz, the 256-thread reduction) as adam_step_kernel: same bits.
+struct DeferredStep {
+    int on = 0;
+    AdamTensor x = {}, cam = {};             // as opt_step_plan builds them (first OWNED row; cam.p == nullptr: not stepped)
+    int row0 = 2;
+    const float* dzpart = nullptr;           // four partial latent gradients (vposer_bwd_*), dz_stride apart; null: dX is complete
+    size_t dz_stride = 0;
+};
+struct ScaleTail {
+    int block = -1;                          // index of the extra workgroup (-1: none)
+    AdamTensor sc = {};
+    const float* dscale_row = nullptr;       // [rows] per-frame partials of d loss / d scale
+    float* dscale = nullptr;                 // this rank's sum (kept for callers that read it)
+    int row0 = 2, n = 0, zero_grad = 0;
+};
 
 // torch.optim.Adam defaults: betas (0.9, 0.999), eps 1e-8; the bias corrections are evaluated
 // in double exactly like torch's python scalars and then applied in fp32.
@@ -70,5 +94,32 @@ FDC_HD void adam_update(float& p, float& m, float& v, float g, const AdamScalars
     float denom = sqrtf(v) / a.bc2_sqrt + a.eps;      // sqrt(v)/sqrt(bc2) + eps
     p = p - a.step_size * (m / denom);                // addcdiv_(m, denom, -step_size)
 }
+
+#if defined(__HIPCC__)
+// d loss / d scale = sum of the per-frame partials in a fixed order (256 strided partial sums, wave sums, (s0 + s1) + (s2 + s3)),
+// then Adam on `scale` in place.  One workgroup of >= 256 threads; the tail block of adam_step_kernel and the extra workgroup
+// of the backward's last launch (ScaleTail) run exactly this.
+__device__ __forceinline__ float scale_grad_block(const float* __restrict__ dscale_row, int row0, int n, float* sred) {
+    float a = 0.f;
+    if (threadIdx.x < 256)
+        for (int i = threadIdx.x; i < n; i += 256) a += dscale_row[row0 + i];
+    a = wave_sum64(a);
+    if (threadIdx.x < 256 && (threadIdx.x & 63) == 0) sred[threadIdx.x >> 6] = a;
+    __syncthreads();
+    return (sred[0] + sred[1]) + (sred[2] + sred[3]);
+}
+__device__ __forceinline__ void scale_tail_block(const ScaleTail& t) {
+    __shared__ float s_tail[4];
+    const float g = scale_grad_block(t.dscale_row, t.row0, t.n, s_tail);
+    if (threadIdx.x == 0) {
+        if (t.dscale) *t.dscale = g;
+        if (t.sc.p) {
+            float pp = *t.sc.p, mm = *t.sc.m, vv = *t.sc.v;
+            adam_update(pp, mm, vv, t.zero_grad ? 0.f : g, t.sc.a);
+            *t.sc.p = pp; *t.sc.m = mm; *t.sc.v = vv;
+        }
+    }
+}
+#endif
 
 }  // namespace fdc

@@ -27,6 +27,7 @@
 #include <vector>
 
 #include "fdc_frame.h"
+#include "fdc_loss.h"
 
 namespace fdc {
 
@@ -883,6 +884,27 @@ struct VPoserPanels {
 
 __device__ __forceinline__ float vp_lrelu(float v) { return v > 0.f ? v : 0.2f * v; }
 
+// dX[row, latent columns] += ((p0 + p1) + (p2 + p3))   (the order the Adam kernel uses when it folds the partials itself)
+__device__ __forceinline__ float vp_sum_dz(const float* __restrict__ part, size_t part_stride, size_t e) {
+    return (part[e] + part[part_stride + e]) + (part[2 * part_stride + e] + part[3 * part_stride + e]);
+}
+
+// DeferredStep (fdc_loss.h), decoder side: element (row r0 + tid / 32, latent column tid % 32) of the 16 x 32 block AFTER the
+// pending Adam step -- one element per thread of the 512-thread workgroup, rows >= row_hi zero.  Nothing is written back: the
+// four quarter-workgroups of a row block all do this, pose_fwd_kernel repeats it for its row and stores parameters and moments.
+__device__ __forceinline__ float vp_deferred_latent(const DeferredStep& ds, int r0, int row_hi, int tid) {
+    const int i = tid >> 5, col = tid & 31, row = r0 + i;
+    float pp = 0.f;
+    if (row < row_hi) {
+        const size_t e = (size_t)(row - ds.row0) * XDIM + X_LATENT + col;
+        float mm = ds.x.m[e], vv = ds.x.v[e], gg = ds.x.g[e];
+        pp = ds.x.p[e];
+        if (ds.dzpart) gg += vp_sum_dz(ds.dzpart, ds.dz_stride, (size_t)row * VP_Z + col);
+        adam_update(pp, mm, vv, gg, ds.x.a);
+    }
+    return pp;
+}
+
 // grid = 4 * ceil(rows / 16): blockIdx & 3 = hidden-column quarter q (blocks of one quarter share an XCD's L2: the
 // dispatcher deals consecutive blocks to the 8 XCDs, so XCD x only ever streams quarter x & 3 of W2), blockIdx >> 2 = row block.
 // Z = X + latent column (row stride ldx); rows [row_lo, row_hi).  H1, H2 [*, 512] (kept for the backward's masks),
@@ -892,7 +914,7 @@ __device__ __forceinline__ float vp_lrelu(float v) { return v > 0.f ? v : 0.2f *
 struct VpRows { int nb1 = 0x7fffffff, row2_lo = 0, row2_hi = 0; };
 __global__ __launch_bounds__(512) void vposer_fwd_fused_kernel(VPoserPanels P, const float* __restrict__ Z, int ldx, int row_lo,
                                                                int row_hi, float* __restrict__ H1, float* __restrict__ H2,
-                                                               float* __restrict__ Opart, size_t part_stride, VpRows two) {
+                                                               float* __restrict__ Opart, size_t part_stride, VpRows two, DeferredStep ds) {
     __shared__ __attribute__((aligned(16))) float lds[VP_Z * 16 + VP_H * 16 + VP_QW * 16];
     float* const sZ = lds;
     float* const sH1 = lds + VP_Z * 16;
@@ -918,7 +940,11 @@ __global__ __launch_bounds__(512) void vposer_fwd_fused_kernel(VPoserPanels P, c
         for (int t = 0; t < 4; ++t) { acc[t] = f32x4_t{0.f, 0.f, 0.f, 0.f}; bf[t] = P.w1.f + (size_t)(wave * 4 + t) * P.w1.nss * 64; }
         PnRing<4, 2> rg1;
         panel_prefetch<4, 2>(rg1, bf, VP_Z / 16, lane);
-        panel_stage<512>(sZ, Z, ldx, r0, row_hi, 0, VP_Z, VP_Z, tid);
+        if (ds.on) {                                       // (wave-uniform) the latent rows after the pending optimiser step,
+            const int i = tid >> 5, k = tid & 31;          // straight into panel_stage's k-blocked image: [k / 4][row][k % 4]
+            sZ[((k >> 2) * 16 + i) * 4 + (k & 3)] = vp_deferred_latent(ds, r0, row_hi, tid);
+        } else
+            panel_stage<512>(sZ, Z, ldx, r0, row_hi, 0, VP_Z, VP_Z, tid);
         __syncthreads();
         PN_STAMP(1);
         panel_mma<4, 2>(sZ, rg1, VP_Z / 16, acc, lane);
@@ -983,14 +1009,18 @@ __global__ void vposer_sum_parts_kernel(const float* __restrict__ part, size_t p
 // dO [*, 126] -> dZpart [4][part_stride] ([*, 32] row-major): partial latent gradients of rows [row_lo, row_hi).
 __global__ __launch_bounds__(512) void vposer_bwd_fused_kernel(VPoserPanels P, const float* __restrict__ dO, int row_lo, int row_hi,
                                                                const float* __restrict__ H1, const float* __restrict__ H2,
-                                                               float* __restrict__ dZpart, size_t part_stride) {
+                                                               float* __restrict__ dZpart, size_t part_stride, ScaleTail tail) {
+    // (tail.block == 0: one extra workgroup, FIRST in the grid -- these kernels keep one workgroup per CU (LDS), a 261st at the
+    //  end would wait for a CU to come free and then run alone; first, it is done in a microsecond and hands its CU to the rest)
+    if ((int)blockIdx.x == tail.block) { scale_tail_block(tail); return; }
+    const unsigned bid = blockIdx.x - (tail.block == 0 ? 1u : 0u);
     __shared__ __attribute__((aligned(16))) float lds[VP_QW * 16 + VP_QW * 16 + VP_H * 16 + 8 * 256];
     float* const sdO = lds;                       // K = 126 padded to 128
     float* const sdH2 = sdO + VP_QW * 16;         // this quarter's 128 columns of dH2
     float* const sdH1 = sdH2 + VP_QW * 16;        // partial dH1 (all 512 columns)
     float* const sred = sdH1 + VP_H * 16;
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, j = lane & 15, g = lane >> 4;
-    const int q = blockIdx.x & 3, r0 = row_lo + (int)(blockIdx.x >> 2) * 16;
+    const int q = bid & 3, r0 = row_lo + (int)(bid >> 2) * 16;
     PnRing<4, 4> rgB;
     PnRing<1, 4> rgC;
     // the masking activations before the first barrier (see vposer_bwd_split3_kernel)
@@ -1057,10 +1087,6 @@ __global__ __launch_bounds__(512) void vposer_bwd_fused_kernel(VPoserPanels P, c
     }
 }
 
-// dX[row, latent columns] += ((p0 + p1) + (p2 + p3))   (the order the Adam kernel uses when it folds the partials itself)
-__device__ __forceinline__ float vp_sum_dz(const float* __restrict__ part, size_t part_stride, size_t e) {
-    return (part[e] + part[part_stride + e]) + (part[2 * part_stride + e] + part[3 * part_stride + e]);
-}
 __global__ void vposer_fold_dz_kernel(const float* __restrict__ part, size_t part_stride, int row_lo, int nrows, float* __restrict__ dX) {
     const int e = blockIdx.x * 256 + threadIdx.x;
     if (e >= nrows * VP_Z) return;
@@ -1079,7 +1105,7 @@ constexpr int VP3_PZ = (VP_Z / 8) * 16, VP3_PH = (VP_H / 8) * 16, VP3_PQ = (VP_Q
 
 __global__ __launch_bounds__(512) void vposer_fwd_split3_kernel(VPoserPanels3 P, const float* __restrict__ Z, int ldx, int row_lo,
                                                                 int row_hi, float* __restrict__ H1, float* __restrict__ H2,
-                                                                float* __restrict__ Opart, size_t part_stride, VpRows two) {
+                                                                float* __restrict__ Opart, size_t part_stride, VpRows two, DeferredStep ds) {
     __shared__ __attribute__((aligned(16))) uint4 lds3[3 * (VP3_PZ + VP3_PH + VP3_PQ)];
     uint4* const sZ = lds3;
     uint4* const sH1 = sZ + 3 * VP3_PZ;
@@ -1105,7 +1131,19 @@ __global__ __launch_bounds__(512) void vposer_fwd_split3_kernel(VPoserPanels3 P,
         for (int t = 0; t < 4; ++t) { acc[t] = f32x4_t{0.f, 0.f, 0.f, 0.f}; bf[t] = P.w1.f + (size_t)(wave * 4 + t) * P.w1.nst * 3 * 64; }
         PnRing3T<4, 1> rg1;
         panel3_prefetch_t<4, 1>(rg1, bf, 1, lane);
-        panel_stage3<512>(sZ, Z, ldx, r0, row_hi, 0, VP_Z, VP_Z, tid);
+        if (ds.on) {                                       // (wave-uniform) the latent rows after the pending optimiser step,
+            const int i = tid >> 5, k = tid & 31;          // straight into panel_stage3's image: three planes of [k / 8][row] x eight bf16
+            const float v = vp_deferred_latent(ds, r0, row_hi, tid);
+            const unsigned h = pn3_bf(v);
+            const float r1 = v - pn3_bff(h);
+            const unsigned m = pn3_bf(r1), l = pn3_bf(r1 - pn3_bff(m));
+            unsigned short* const img = (unsigned short*)sZ;
+            const int it = (k >> 3) * 16 + i, e = k & 7;   // (plane stride VP3_PZ uint4 = (VP_Z / 8) * 16 items)
+            img[(size_t)(0 * VP3_PZ + it) * 8 + e] = (unsigned short)h;
+            img[(size_t)(1 * VP3_PZ + it) * 8 + e] = (unsigned short)m;
+            img[(size_t)(2 * VP3_PZ + it) * 8 + e] = (unsigned short)l;
+        } else
+            panel_stage3<512>(sZ, Z, ldx, r0, row_hi, 0, VP_Z, VP_Z, tid);
         __syncthreads();
         panel3_mma_t<4, 1>(sZ, VP3_PZ, rg1, 1, acc, lane);
         {
@@ -1156,14 +1194,18 @@ __global__ __launch_bounds__(512) void vposer_fwd_split3_kernel(VPoserPanels3 P,
 
 __global__ __launch_bounds__(512) void vposer_bwd_split3_kernel(VPoserPanels3 P, const float* __restrict__ dO, int row_lo, int row_hi,
                                                                 const float* __restrict__ H1, const float* __restrict__ H2,
-                                                                float* __restrict__ dZpart, size_t part_stride) {
+                                                                float* __restrict__ dZpart, size_t part_stride, ScaleTail tail) {
+    // (tail.block == 0: one extra workgroup, FIRST in the grid -- these kernels keep one workgroup per CU (LDS), a 261st at the
+    //  end would wait for a CU to come free and then run alone; first, it is done in a microsecond and hands its CU to the rest)
+    if ((int)blockIdx.x == tail.block) { scale_tail_block(tail); return; }
+    const unsigned bid = blockIdx.x - (tail.block == 0 ? 1u : 0u);
     __shared__ __attribute__((aligned(16))) uint4 lds3[3 * (VP3_PQ + VP3_PQ + VP3_PH) + 8 * 64];
     uint4* const sdO = lds3;                      // K = 126 padded to 128
     uint4* const sdH2 = sdO + 3 * VP3_PQ;         // this quarter's 128 columns of dH2
     uint4* const sdH1 = sdH2 + 3 * VP3_PQ;        // partial dH1 (all 512 columns)
     float* const sred = (float*)(sdH1 + 3 * VP3_PH);
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, j = lane & 15, g = lane >> 4;
-    const int q = blockIdx.x & 3, r0 = row_lo + (int)(blockIdx.x >> 2) * 16;
+    const int q = bid & 3, r0 = row_lo + (int)(bid >> 2) * 16;
     PnRing3T<4, 2> rgB;
     PnRing3T<1, 2> rgC;
     // the forward activations whose signs mask this wave's tiles, requested before the first barrier (rows clamped:

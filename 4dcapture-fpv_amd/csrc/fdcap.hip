@@ -191,17 +191,17 @@ constexpr int PS_NJD4 = (NJ * 3 * NBETA) / 4, PS_NHC4 = (2 * 12 * 45) / 4;      
 constexpr int POSE_NW = 4;
 template <int PART>
 __device__ __forceinline__ void stage_pose_part(const PoseModel& pm, PoseStage& t, const float* __restrict__ xrow,
-                                                const float* __restrict__ camrow) {
+                                                const float* __restrict__ camrow, bool rows = true) {
     if constexpr (PART == 0) {
         glds16<(PS_NJD4 + 63) / 64>(pm.Jd, t.Jd, PS_NJD4);
         glds4<1>(pm.Jd + PS_NJD4 * 4, t.Jd + PS_NJD4 * 4, (NJ * 3 * NBETA) % 4);
-        glds4<1>(camrow, t.cam, 16);
+        if (rows) glds4<1>(camrow, t.cam, 16);
     } else if constexpr (PART == 1) {
         glds16<(PS_NHC4 + 63) / 64>(pm.hand_comp, t.hand_comp, PS_NHC4);
         glds4<3>(pm.Jt, t.Jt, NJ * 3);
         glds4<2>(pm.hand_mean, t.hand_mean, 90);
     } else {
-        glds4<2>(xrow, t.x, XDIM);
+        if (rows) glds4<2>(xrow, t.x, XDIM);
         glds4<1>(pm.parents, t.parents, NJ);
         glds4<1>(pm.order, t.order, NJ);
         glds4<1>(pm.child_list, t.child_list, NJ - 1);
@@ -222,12 +222,17 @@ __device__ __forceinline__ PoseModel stage_pose_model(const PoseModel& pm, PoseS
 // One workgroup per frame: POSE_NW waves issue the staging copies, the first one does the frame's arithmetic.
 // PARTS: the decoder output arrives as the four partial sums of vposer_fwd_fused_kernel (Opart, part_stride apart); they are
 // added here in the fixed order of vp_sum_parts, kept in LDS for this frame and written to O for the backward.
+#if defined(FDC_PKX) && FDC_PKX == 3
+#define FDC_PKX_ATTR __attribute__((target("no-packed-fp32-ops")))
+#else
+#define FDC_PKX_ATTR
+#endif
 template <bool PARTS>
-__global__ __launch_bounds__(64 * POSE_NW) void pose_fwd_kernel(PoseModel pm, const float* __restrict__ X, float* __restrict__ O,
+FDC_PKX_ATTR __global__ __launch_bounds__(64 * POSE_NW) void pose_fwd_kernel(PoseModel pm, const float* __restrict__ X, float* __restrict__ O,
                                                       const float* __restrict__ CAM, const float* __restrict__ scale,
                                                       int row0, float* Rm, float* PF, float* Jrest, float* G, float* A,
                                                       float* M, float* Jw, const float* AA, const float* __restrict__ Opart,
-                                                      size_t part_stride, int wo_lo = 0, int wo_hi = 0) {
+                                                      size_t part_stride, int wo_lo = 0, int wo_hi = 0, DeferredStep ds = DeferredStep()) {
     __shared__ PoseScratch sc;
     __shared__ PoseStage stg;
     __shared__ float s_O[ODIM + 2];
@@ -254,17 +259,44 @@ __global__ __launch_bounds__(64 * POSE_NW) void pose_fwd_kernel(PoseModel pm, co
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const float* const xrow = X + (size_t)r * XDIM;
     const float* const camrow = CAM + (size_t)r * 16;
-    if (wave == 0) stage_pose_part<0>(pm, stg, xrow, camrow);
-    else if (wave == 1) stage_pose_part<1>(pm, stg, xrow, camrow);
-    else if (wave == 2) stage_pose_part<2>(pm, stg, xrow, camrow);
+    // (ds.on: the frame's own rows are not copied -- the deferred step below writes the stepped rows into their LDS places)
+    if (wave == 0) stage_pose_part<0>(pm, stg, xrow, camrow, !ds.on);
+    else if (wave == 1) stage_pose_part<1>(pm, stg, xrow, camrow, !ds.on);
+    else if (wave == 2) stage_pose_part<2>(pm, stg, xrow, camrow, !ds.on);
     else if (PARTS) {                                        // the decoder's partial sums ride in the same batch of copies
 #pragma unroll
         for (int q = 0; q < VP_NQ; ++q) glds4<2>(Opart + (size_t)q * part_stride + (size_t)r * ODIM, s_Op[q], ODIM);
     }
     const float sc_v = *scale;
+    // A deferred optimiser step (DeferredStep, fdc_loss.h): this frame's row of body_rotation_rec / camera_ext takes its pending
+    // Adam update here -- the loads ride in the staging batch, the stepped row goes to LDS (where the copy of the old one would
+    // have gone) and back to global memory with both moments.
+    if (ds.on) {                                             // (wave-uniform)
+        const int t = (int)threadIdx.x;
+        if (t < XDIM) {
+            const size_t e = (size_t)(r - ds.row0) * XDIM + t;
+            float pp = ds.x.p[e], mm = ds.x.m[e], vv = ds.x.v[e], gg = ds.x.g[e];
+            const int col = t - X_LATENT;
+            if (ds.dzpart && col >= 0 && col < VP_Z) gg += vp_sum_dz(ds.dzpart, ds.dz_stride, (size_t)r * VP_Z + col);
+            adam_update(pp, mm, vv, gg, ds.x.a);
+            ds.x.p[e] = pp; ds.x.m[e] = mm; ds.x.v[e] = vv;
+            stg.x[t] = pp;
+        } else if (t < XDIM + 16) {
+            const int ec = t - XDIM;
+            if (ds.cam.p) {
+                const size_t e = (size_t)(r - ds.row0) * 16 + ec;
+                float pp = ds.cam.p[e], mm = ds.cam.m[e], vv = ds.cam.v[e];
+                adam_update(pp, mm, vv, ds.cam.g[e], ds.cam.a);
+                ds.cam.p[e] = pp; ds.cam.m[e] = mm; ds.cam.v[e] = vv;
+                stg.cam[ec] = pp;
+            } else
+                stg.cam[ec] = camrow[ec];
+        }
+    }
     __syncthreads();                                         // (every wave waits for its copies: vmcnt(0) in front of the barrier)
-    if (threadIdx.x >= 64) return;                           // the other waves were only here to issue copies
+    if (threadIdx.x >= 64) return;                           // the other waves were only here to issue copies (and step parameters)
 #ifdef FDC_DEBUG_BUFFERS
+    if (!ds.on) {
     stage_check(1, pm.Jd, stg.Jd, NJ * 3 * NBETA, r); stage_check(2, pm.hand_comp, stg.hand_comp, 2 * 12 * 45, r);
     stage_check(3, pm.Jt, stg.Jt, NJ * 3, r); stage_check(4, pm.hand_mean, stg.hand_mean, 90, r);
     stage_check(5, X + (size_t)r * XDIM, stg.x, XDIM, r); stage_check(6, CAM + (size_t)r * 16, stg.cam, 16, r);
@@ -272,6 +304,7 @@ __global__ __launch_bounds__(64 * POSE_NW) void pose_fwd_kernel(PoseModel pm, co
     stage_check(9, pm.child_list, stg.child_list, NJ - 1, r); stage_check(10, pm.depth, stg.depth, NJ, r);
     stage_check(11, pm.child_start, stg.child_start, NJ + 1, r); stage_check(12, pm.level_start, stg.level_start, min(pm.nlevels, MAX_LEVELS) + 1, r);
     if (PARTS) for (int q = 0; q < VP_NQ; ++q) stage_check(20 + q, Opart + (size_t)q * part_stride + (size_t)r * ODIM, s_Op[q], ODIM, r);
+    }
     __syncthreads();
 #endif
     const PoseModel pml = stage_pose_model(pm, stg);
@@ -1148,7 +1181,6 @@ __global__ void adam_kernel(float* __restrict__ p, float* __restrict__ m, float*
 // camera_ext is not being stepped).
 constexpr int XCH_ROW = XDIM + 16;                 // 94 floats
 constexpr int XCH_LEN = 4 * XCH_ROW + 8;           // + dscale partial (+ padding to 32 B)
-struct AdamTensor { float* p; float* m; float* v; const float* g; size_t n; AdamScalars a; };
 __global__ __launch_bounds__(256) void adam_step_kernel(AdamTensor x, AdamTensor cam, AdamTensor sc, int nb_x, int nb_cam,
                                                         const float* __restrict__ dscale_row, int row0, int reduce_n,
                                                         float* __restrict__ dscale, int scale_zero_grad,
@@ -1433,6 +1465,9 @@ struct OptState {
     struct Ext { float* p = nullptr; } X, CAM, scale, dscale;   // caller-owned, registered
     struct ExtD { double* p = nullptr; } losses;
     DevBuf<float> X0, mask, mX, vX, mCAM, vCAM, mS, vS;
+    // fdcap_opt_backward_and_step: the rows' part of iteration ii's optimiser step, to be applied by the next forward's first two
+    // launches (DeferredStep, fdc_loss.h; `scale` was stepped by the backward's last launch) -- or by opt_sync()
+    struct { bool on = false; int ii = 0, P = 0; } pend;
     DevBuf<float> H1, H2, O, dO;
     DevBuf<float> Opart, dZpart;       // [4][R*126] partial decoder outputs, [4][R*32] partial latent gradients (fdc_panel.h)
     bool dz_pending = false;           // the last backward left the latent gradient as partials: the next Adam launch (or
@@ -1659,20 +1694,21 @@ hipError_t blend_forward(const SkinSet& ss, const float* PF, int M, float* Voff,
 // pose_fwd_kernel<true> adds the partials itself instead)
 // (row2_lo < row2_hi: a second row range in the same launch -- the halo rows on the far side of a shard's owned rows)
 int vposer_forward(fdcap_ctx* c, const float* X, int ldx, int latent_off, int row_lo, int row_hi, float* H1, float* H2,
-                   float* Opart, size_t part_stride, float* O, hipStream_t st, int row2_lo = 0, int row2_hi = 0) {
+                   float* Opart, size_t part_stride, float* O, hipStream_t st, int row2_lo = 0, int row2_hi = 0,
+                   const DeferredStep& ds = DeferredStep()) {
     const int rows = row_hi - row_lo, rows2 = std::max(row2_hi - row2_lo, 0);
     if (rows <= 0 && rows2 <= 0) return 0;
-    if (rows <= 0) { row_lo = row2_lo; row_hi = row2_hi; return vposer_forward(c, X, ldx, latent_off, row_lo, row_hi, H1, H2, Opart, part_stride, O, st); }
+    if (rows <= 0) { row_lo = row2_lo; row_hi = row2_hi; return vposer_forward(c, X, ldx, latent_off, row_lo, row_hi, H1, H2, Opart, part_stride, O, st, 0, 0, ds); }
     VpRows two;
     const int nb1 = (rows + 15) / 16, nb2 = (rows2 + 15) / 16;
     if (rows2 > 0) { two.nb1 = nb1; two.row2_lo = row2_lo; two.row2_hi = row2_hi; }
     if (O && rows2 > 0) return FDCAP_E_ARG;                   // (the summed output is only formed for one range)
     if (gemm_split3_enabled())
         hipLaunchKernelGGL(vposer_fwd_split3_kernel, dim3(4 * (nb1 + nb2)), dim3(512), 0, st, c->vp3, X + latent_off, ldx, row_lo,
-                           row_hi, H1, H2, Opart, part_stride, two);
+                           row_hi, H1, H2, Opart, part_stride, two, ds);
     else
         hipLaunchKernelGGL(vposer_fwd_fused_kernel, dim3(4 * (nb1 + nb2)), dim3(512), 0, st, c->vp, X + latent_off, ldx, row_lo,
-                           row_hi, H1, H2, Opart, part_stride, two);
+                           row_hi, H1, H2, Opart, part_stride, two, ds);
     if (O) {
         const size_t n = (size_t)rows * ODIM;
         hipLaunchKernelGGL(vposer_sum_parts_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, Opart, part_stride,
@@ -1688,15 +1724,67 @@ void opt_row_range(const OptState* o, int halo, int* lo, int* hi) {
     *hi = cf.n_local + 2 + (cf.frame0 + cf.n_local < cf.n_total ? halo : 0);
 }
 
-// decoder + per-frame pose state (Rm, PF, Jrest, G, A, M, Jw) of rows [lo, hi): two launches
+// The optimiser step of iteration ii as tensors for the Adam kernels (global_optimization.py:563-568, :577-580, :592 restated as
+// arithmetic): which parameters are stepped, with which bias corrections.
+struct StepPlan { AdamTensor x = {}, cam = {}, sc = {}; int nb_x = 0, nb_cam = 0; bool step_scale = false; };
+StepPlan opt_step_plan(const OptState* o, int ii, int P, bool do_rows, bool do_scale) {
+    const fdcap_opt_config& cf = o->cfg;
+    const int nl = cf.n_local;
+    StepPlan sp;
+    // body_rotation_rec: every iteration, its own step counter = ii + 1
+    if (do_rows) {
+        sp.x = AdamTensor{o->X.p + 2 * XDIM, o->mX.p + 2 * XDIM, o->vX.p + 2 * XDIM, o->dX.p + 2 * XDIM, (size_t)nl * XDIM, adam_scalars(cf.lr, ii + 1)};
+        sp.nb_x = (int)((sp.x.n + 255) / 256);
+    }
+    // camera_ext: first gradient at ii = P + 1 (flag flips after the forward of ii = P); mode 'local': the late-phase
+    // loss has no camera_ext path -> grad None, never stepped
+    if (do_rows && ii >= P + 1 && cf.phase2_world != 0.f) {
+        sp.cam = AdamTensor{o->CAM.p + 2 * 16, o->mCAM.p + 2 * 16, o->vCAM.p + 2 * 16, o->dCAM.p + 2 * 16, (size_t)nl * 16, adam_scalars(cf.lr, ii - P)};
+        sp.nb_cam = (int)((sp.cam.n + 255) / 256);
+    }
+    // scale: receives a gradient while ii < P (and only if a term that reaches it exists)
+    sp.step_scale = do_scale && (o->contact_on || o->dct_grad) && (ii < P || cf.legacy_zero_grad);
+    if (sp.step_scale) sp.sc = AdamTensor{o->scale.p, o->mS.p, o->vS.p, o->dscale.p, 1, adam_scalars(cf.lr, ii + 1)};
+    return sp;
+}
+int opt_step_launch(fdcap_ctx* c, int32_t ii, int32_t P, bool do_rows, bool do_scale, bool reduce_scale, hipStream_t st, float* xch);
+
+// Everything the caller registered (rows_x_d, rows_cam_d) and the Adam moments are current after this: the rows' part of a
+// deferred step that no forward has consumed is applied by the ordinary Adam launch (`scale` was stepped with the backward).
+int opt_sync(fdcap_ctx* c, hipStream_t st) {
+    OptState* o = c->opt;
+    if (!o || !o->pend.on) return 0;
+    o->pend.on = false;
+    return opt_step_launch(c, o->pend.ii, o->pend.P, true, false, false, st, nullptr);
+}
+
+// decoder + per-frame pose state (Rm, PF, Jrest, G, A, M, Jw) of rows [lo, hi): two launches.  A deferred optimiser step is
+// applied by these two launches when they cover exactly the frames it steps (no halo rows: one rank), else by its own launch first.
 int opt_pose_forward(fdcap_ctx* c, int lo, int hi, hipStream_t st) {
     OptState* o = c->opt;
     o->ahead = false;                                       // (whatever ran ahead is recomputed here)
     const size_t ps = (size_t)o->R * ODIM;
-    int e = vposer_forward(c, o->X.p, XDIM, X_LATENT, lo, hi, o->H1.p, o->H2.p, o->Opart.p, ps, nullptr, st);
+    const int nl = o->cfg.n_local;
+    DeferredStep ds;
+    if (o->pend.on) {
+        if (lo == 2 && hi == 2 + nl && o->cfg.frame0 == 0 && nl == o->cfg.n_total && !o->log_pending) {
+            const StepPlan sp = opt_step_plan(o, o->pend.ii, o->pend.P, true, false);
+            ds.on = 1; ds.x = sp.x; ds.cam = sp.cam; ds.row0 = 2;
+            ds.dzpart = o->dz_pending ? o->dZpart.p : nullptr; ds.dz_stride = (size_t)o->R * VP_Z;
+        } else {
+            int e = opt_sync(c, st);
+            if (e) return e;
+        }
+    }
+    int e = vposer_forward(c, o->X.p, XDIM, X_LATENT, lo, hi, o->H1.p, o->H2.p, o->Opart.p, ps, nullptr, st, 0, 0, ds);
     if (e) return e;
     hipLaunchKernelGGL(pose_fwd_kernel<true>, dim3(hi - lo), dim3(64 * POSE_NW), 0, st, c->pose_model(), o->X.p, o->O.p, o->CAM.p, o->scale.p, lo,
-                       o->Rm.p, o->PF.p, o->Jrest.p, o->G.p, o->A.p, o->M.p, o->Jw.p, (const float*)nullptr, (const float*)o->Opart.p, ps);
+                       o->Rm.p, o->PF.p, o->Jrest.p, o->G.p, o->A.p, o->M.p, o->Jw.p, (const float*)nullptr, (const float*)o->Opart.p, ps,
+                       0, 0, ds);
+    if (ds.on) {                                            // the step has been issued: the launches that follow see its results
+        o->pend.on = false;
+        o->dz_pending = false;
+    }
     return (int)hipGetLastError();
 }
 
@@ -1716,16 +1804,19 @@ int opt_pose_forward_rest(fdcap_ctx* c, int lo, int hi, hipStream_t st) {
 }
 
 // VPoser data-gradient dO -> d latent of the owned rows, left as four partials in dZpart (fold = true: added into dX here)
-int opt_vposer_backward(fdcap_ctx* c, bool fold, hipStream_t st) {
+// (tail.block >= 0: one more workgroup that steps `scale` -- ScaleTail, fdc_loss.h)
+int opt_vposer_backward(fdcap_ctx* c, bool fold, hipStream_t st, ScaleTail tail = ScaleTail()) {
     OptState* o = c->opt;
     const int nl = o->cfg.n_local;
     const size_t ps = (size_t)o->R * VP_Z;
+    const int nb = 4 * ((nl + 15) / 16);
+    if (tail.block >= 0) tail.block = 0;                   // (first in the grid: fdc_panel.h)
     if (gemm_split3_enabled())
-        hipLaunchKernelGGL(vposer_bwd_split3_kernel, dim3(4 * ((nl + 15) / 16)), dim3(512), 0, st, c->vp3, o->dO.p, 2, 2 + nl, o->H1.p, o->H2.p,
-                           o->dZpart.p, ps);
+        hipLaunchKernelGGL(vposer_bwd_split3_kernel, dim3(nb + (tail.block >= 0 ? 1 : 0)), dim3(512), 0, st, c->vp3, o->dO.p, 2, 2 + nl, o->H1.p, o->H2.p,
+                           o->dZpart.p, ps, tail);
     else
-        hipLaunchKernelGGL(vposer_bwd_fused_kernel, dim3(4 * ((nl + 15) / 16)), dim3(512), 0, st, c->vp, o->dO.p, 2, 2 + nl, o->H1.p, o->H2.p,
-                           o->dZpart.p, ps);
+        hipLaunchKernelGGL(vposer_bwd_fused_kernel, dim3(nb + (tail.block >= 0 ? 1 : 0)), dim3(512), 0, st, c->vp, o->dO.p, 2, 2 + nl, o->H1.p, o->H2.p,
+                           o->dZpart.p, ps, tail);
     if (fold) {
         hipLaunchKernelGGL(vposer_fold_dz_kernel, dim3((nl * VP_Z + 255) / 256), dim3(256), 0, st, o->dZpart.p, ps, 2, nl, o->dX.p);
         o->dz_pending = false;
@@ -1801,6 +1892,8 @@ int fdcap_debug_rows(fdcap_ctx* c, int which, float* dst, void* stream) {
         case 7: src = o->Opart.p; w = ODIM; break;
         case 8: src = o->H2.p; w = VP_H; break;
         case 9: src = o->Jw.p; w = NJW * 3; break;
+        case 10: src = o->Rm.p; w = NJ * 9; break;
+        case 11: src = o->Jrest.p; w = NJ * 3; break;
         default: return FDCAP_E_ARG;
     }
     HIP_TRY(hipMemcpyAsync(dst, src + 2 * w, (size_t)nl * w * sizeof(float), hipMemcpyDeviceToDevice, (hipStream_t)stream));
@@ -2212,9 +2305,9 @@ int fdcap_vposer_decode_bwd(fdcap_ctx* c, const float* z, int32_t ldz, int32_t B
     hipLaunchKernelGGL(vposer_out_bwd_kernel, dim3((n + 255) / 256), dim3(256), 0, st, w[2].p, n, g_rot, g_aa, w[3].p);
     const size_t ps = (size_t)B * VP_Z;
     if (gemm_split3_enabled())
-        hipLaunchKernelGGL(vposer_bwd_split3_kernel, dim3(4 * ((B + 15) / 16)), dim3(512), 0, st, c->vp3, w[3].p, 0, B, w[0].p, w[1].p, w[4].p, ps);
+        hipLaunchKernelGGL(vposer_bwd_split3_kernel, dim3(4 * ((B + 15) / 16)), dim3(512), 0, st, c->vp3, w[3].p, 0, B, w[0].p, w[1].p, w[4].p, ps, ScaleTail());
     else
-        hipLaunchKernelGGL(vposer_bwd_fused_kernel, dim3(4 * ((B + 15) / 16)), dim3(512), 0, st, c->vp, w[3].p, 0, B, w[0].p, w[1].p, w[4].p, ps);
+        hipLaunchKernelGGL(vposer_bwd_fused_kernel, dim3(4 * ((B + 15) / 16)), dim3(512), 0, st, c->vp, w[3].p, 0, B, w[0].p, w[1].p, w[4].p, ps, ScaleTail());
     hipLaunchKernelGGL(vposer_fold_dz_rows_kernel, dim3((B * VP_Z + 255) / 256), dim3(256), 0, st, w[4].p, ps, B, g_z);
     return (int)hipGetLastError();
 }
@@ -2417,6 +2510,7 @@ int fdcap_opt_create(fdcap_ctx* c, const fdcap_opt_config* cfg, float* rows_x, f
     int err = 0;
 #define AL(buf, cnt) if (!err) { hipError_t e_ = (buf).ensure(cnt); if (e_ != hipSuccess) err = (int)e_; else e_ = hipMemset((buf).p, 0, (size_t)(cnt) * sizeof(*(buf).p)); }
     o->X.p = rows_x; o->CAM.p = rows_cam; o->scale.p = scale_d; o->dscale.p = dscale_d; o->losses.p = losses_d;
+    o->pend.on = false;
     AL(o->X0, (size_t)R * XDIM) AL(o->mask, R)
     AL(o->mX, (size_t)R * XDIM) AL(o->vX, (size_t)R * XDIM) AL(o->mCAM, (size_t)R * 16) AL(o->vCAM, (size_t)R * 16)
     AL(o->mS, 1) AL(o->vS, 1)
@@ -2467,6 +2561,7 @@ int fdcap_opt_create(fdcap_ctx* c, const fdcap_opt_config* cfg, float* rows_x, f
 int fdcap_opt_set_inputs(fdcap_ctx* c, const float* data78, const float* init78, const float* mask, const float* cam,
                          void* stream) {
     if (!c || !c->opt || !data78 || !init78 || !mask || !cam) return FDCAP_E_ARG;
+    { int es_ = opt_sync(c, (hipStream_t)stream); if (es_) return es_; }
     OptState* o = c->opt;
     hipStream_t st = (hipStream_t)stream;
     const size_t n = o->cfg.n_local;
@@ -2503,7 +2598,9 @@ namespace {
 struct LossWeights { float rec, smooth, contact, world, dct; bool world_on; };
 }
 
-static int opt_backward_impl(fdcap_ctx* c, const LossWeights& lw, int32_t log_terms, hipStream_t st) {
+// fuse_ii >= 0 (fdcap_opt_backward_and_step): this backward is followed by the optimiser step of iteration fuse_ii -- `scale`
+// is stepped by one more workgroup of the last launch, the rows' part is left pending for the next forward (DeferredStep)
+static int opt_backward_impl(fdcap_ctx* c, const LossWeights& lw, int32_t log_terms, hipStream_t st, int fuse_ii = -1, int fuse_P = 0) {
     OptState* o = c->opt;
     const fdcap_opt_config& cf = o->cfg;
     const int nl = cf.n_local, nc = c->nc, N = cf.n_total;
@@ -2602,7 +2699,19 @@ static int opt_backward_impl(fdcap_ctx* c, const LossWeights& lw, int32_t log_te
                        joint_grad ? o->dJw.p : nullptr, contact_grad ? o->dMv.p : nullptr, contact_grad ? o->dsv.p : nullptr,
                        contact_grad ? o->dPF.p + NPF : nullptr, NPFX, contact_grad ? o->dtransl_v.p : nullptr, o->dX.p, o->dO.p,
                        o->dCAM.p, o->dscale_row.p, pli, (contact_grad && dpf_split) ? (const float*)(o->dPF.p + (size_t)o->R * NPFX) : (const float*)nullptr);
-    { int eb = opt_vposer_backward(c, false, st); if (eb) return eb; }
+    {
+        ScaleTail tail;
+        if (fuse_ii >= 0) {
+            const StepPlan sp = opt_step_plan(o, fuse_ii, fuse_P, false, true);
+            if (sp.step_scale) {
+                tail.block = 0; tail.sc = sp.sc; tail.dscale_row = o->dscale_row.p; tail.dscale = o->dscale.p; tail.row0 = 2; tail.n = nl;
+                tail.zero_grad = fuse_ii >= fuse_P ? 1 : 0;
+            }
+        }
+        int eb = opt_vposer_backward(c, false, st, tail);
+        if (eb) return eb;
+        if (fuse_ii >= 0) { o->pend.on = true; o->pend.ii = fuse_ii; o->pend.P = fuse_P; }
+    }
     // d loss / d scale of this rank = sum of the per-frame partials: formed by the step kernels (fused with Adam /
     // the exchange packing); on logging iterations also here, so a caller can read dscale_d right after the backward
     if (log_terms) {
@@ -2632,6 +2741,7 @@ int fdcap_opt_set_loss_output(fdcap_ctx* c, double* losses_d) {
 // flight ("overlap C1 with the start of the next forward"); fdcap_opt_backward(ii) then only adds the rest.
 int fdcap_opt_forward_ahead(fdcap_ctx* c, int32_t ii, int32_t P, int32_t log_terms, void* stream) {
     if (!c || !c->opt) return FDCAP_E_STATE;
+    { int es_ = opt_sync(c, (hipStream_t)stream); if (es_) return es_; }
     OptState* o = c->opt;
     hipStream_t st = (hipStream_t)stream;
     const int nl = o->cfg.n_local, nc = c->nc;
@@ -2658,6 +2768,32 @@ int fdcap_opt_backward(fdcap_ctx* c, int32_t ii, int32_t P, int32_t log_terms, v
     return opt_backward_impl(c, lw, log_terms, (hipStream_t)stream);
 }
 
+// loss.backward() + optimizer.step() of iteration ii (:591-592) in one call and WITHOUT a launch for the step: `scale` is stepped by
+// one more workgroup of the backward's last launch; the rows of body_rotation_rec / camera_ext take their Adam update in the first
+// two launches of the NEXT forward, where they are read anyway (DeferredStep, csrc/fdc_loss.h) -- or in the ordinary Adam launch as
+// soon as anything else needs them (every other entry point; fdcap_opt_sync).  Same arithmetic in the same order: same bits as
+// fdcap_opt_backward + fdcap_opt_step, which is also what this call falls back to where the deferral cannot apply (sharded runs:
+// the exchange needs the stepped rows; log_terms == 2: the logged sums ride in the step launch).
+int fdcap_opt_backward_and_step(fdcap_ctx* c, int32_t ii, int32_t P, int32_t log_terms, void* stream) {
+    if (!c || !c->opt) return FDCAP_E_STATE;
+    OptState* o = c->opt;
+    const fdcap_opt_config& cf = o->cfg;
+    const bool fuse = cf.frame0 == 0 && cf.n_local == cf.n_total && log_terms != 2 && o->dctW == 0;
+    if (!fuse) {
+        const int e = fdcap_opt_backward(c, ii, P, log_terms, stream);
+        return e ? e : fdcap_opt_step(c, ii, P, stream);
+    }
+    const bool phase2 = ii >= P;
+    LossWeights lw;
+    lw.rec = 1.f;
+    lw.smooth = phase2 ? cf.phase2_smooth : cf.phase1_smooth;
+    lw.contact = phase2 ? 0.f : cf.phase1_contact;
+    lw.world = phase2 ? cf.phase2_world : 0.f;
+    lw.dct = 0.f;
+    lw.world_on = phase2;
+    return opt_backward_impl(c, lw, log_terms, (hipStream_t)stream, ii, P);
+}
+
 // ---- mode 'dct' (global_optimization.py:595-630) -----------------------------------------------
 int fdcap_opt_set_dct(fdcap_ctx* c, const float* dct_mtx, int32_t T, int32_t C, const float* c_dct_d, void* stream) {
     if (!c || !c->opt || !dct_mtx || !c_dct_d || T <= 0 || T > DCT_MAXT || C <= 0 || C > DCT_MAXC) return FDCAP_E_ARG;
@@ -2680,6 +2816,7 @@ int fdcap_opt_set_dct(fdcap_ctx* c, const float* dct_mtx, int32_t T, int32_t C, 
 int fdcap_opt_dct_fit(fdcap_ctx* c, int32_t iters, int32_t step0, float weight, float* obj_hist, int32_t log_stride,
                       void* stream) {
     if (!c || !c->opt || iters < 0 || step0 < 0 || (obj_hist && log_stride <= 0)) return FDCAP_E_ARG;
+    { int es_ = opt_sync(c, (hipStream_t)stream); if (es_) return es_; }
     OptState* o = c->opt;
     if (o->dctW <= 0) return FDCAP_E_STATE;
     hipStream_t st = (hipStream_t)stream;
@@ -2754,6 +2891,7 @@ int fdcap_opt_set_keypoints(fdcap_ctx* c, const float* kp_d, void* stream) {
 
 int fdcap_opt_backward_fit2d(fdcap_ctx* c, const fdcap_fit2d_stage* sg, int32_t log_terms, void* stream) {
     if (!c || !c->opt || !sg) return FDCAP_E_ARG;
+    { int es_ = opt_sync(c, (hipStream_t)stream); if (es_) return es_; }
     OptState* o = c->opt;
     if (!o->kp2d.p) return FDCAP_E_STATE;
     hipStream_t st = (hipStream_t)stream;
@@ -2778,6 +2916,7 @@ int fdcap_opt_backward_fit2d(fdcap_ctx* c, const fdcap_fit2d_stage* sg, int32_t 
 // zero Adam's moments of body_rotation_rec (SMPLify-X builds a fresh optimiser for every stage of the fit)
 int fdcap_opt_reset_adam(fdcap_ctx* c, void* stream) {
     if (!c || !c->opt) return FDCAP_E_STATE;
+    { int es_ = opt_sync(c, (hipStream_t)stream); if (es_) return es_; }
     OptState* o = c->opt;
     const size_t n = (size_t)o->R * XDIM * sizeof(float);
     o->log_pending = false; o->log_dst = nullptr;
@@ -2805,16 +2944,19 @@ static int opt_state_copy(fdcap_ctx* c, float* state, bool to_state, hipStream_t
 }
 int fdcap_opt_export_state(fdcap_ctx* c, float* state_d, void* stream) {
     if (!c || !c->opt || !state_d) return FDCAP_E_ARG;
+    { int es_ = opt_sync(c, (hipStream_t)stream); if (es_) return es_; }
     return opt_state_copy(c, state_d, true, (hipStream_t)stream);
 }
 int fdcap_opt_import_state(fdcap_ctx* c, const float* state_d, void* stream) {
     if (!c || !c->opt || !state_d) return FDCAP_E_ARG;
+    { int es_ = opt_sync(c, (hipStream_t)stream); if (es_) return es_; }
     c->opt->log_pending = false;
     c->opt->ahead = false;
     return opt_state_copy(c, (float*)state_d, false, (hipStream_t)stream);
 }
 int fdcap_opt_check_finite(fdcap_ctx* c, int32_t* count_d, void* stream) {
     if (!c || !c->opt || !count_d) return FDCAP_E_ARG;
+    { int es_ = opt_sync(c, (hipStream_t)stream); if (es_) return es_; }
     OptState* o = c->opt;
     hipStream_t st = (hipStream_t)stream;
     const size_t nx = (size_t)o->cfg.n_local * XDIM, ncam = (size_t)o->cfg.n_local * 16;
@@ -2849,41 +2991,35 @@ int fdcap_frame_smoother(fdcap_ctx* c, const float* data78, int32_t N, int32_t i
     return (int)hipGetLastError();
 }
 
-static int opt_step_impl(fdcap_ctx* c, int32_t ii, int32_t P, bool do_rows, bool do_scale, bool reduce_scale, void* stream,
-                         float* xch = nullptr) {
-    if (!c || !c->opt) return FDCAP_E_STATE;
+namespace {
+int opt_step_launch(fdcap_ctx* c, int32_t ii, int32_t P, bool do_rows, bool do_scale, bool reduce_scale, hipStream_t st, float* xch) {
     OptState* o = c->opt;
-    hipStream_t st = (hipStream_t)stream;
-    const fdcap_opt_config& cf = o->cfg;
-    const int nl = cf.n_local;
+    const int nl = o->cfg.n_local;
     if (do_rows) o->ahead = false;                         // the rows change: a forward that ran ahead of this step is stale
-    AdamTensor x = {}, cam = {}, sc = {};
-    int nb_x = 0, nb_cam = 0;
-    // body_rotation_rec: every iteration, its own step counter = ii + 1
-    if (do_rows) {
-        x = AdamTensor{o->X.p + 2 * XDIM, o->mX.p + 2 * XDIM, o->vX.p + 2 * XDIM, o->dX.p + 2 * XDIM, (size_t)nl * XDIM,
-                       adam_scalars(cf.lr, ii + 1)};
-        nb_x = (int)((x.n + 255) / 256);
-    }
-    // camera_ext: first gradient at ii = P + 1 (flag flips after the forward of ii = P); mode 'local': the late-phase
-    // loss has no camera_ext path -> grad None, never stepped
-    if (do_rows && ii >= P + 1 && cf.phase2_world != 0.f) {
-        cam = AdamTensor{o->CAM.p + 2 * 16, o->mCAM.p + 2 * 16, o->vCAM.p + 2 * 16, o->dCAM.p + 2 * 16, (size_t)nl * 16,
-                         adam_scalars(cf.lr, ii - P)};
-        nb_cam = (int)((cam.n + 255) / 256);
-    }
-    // scale: receives a gradient while ii < P (and only if a term that reaches it exists)
-    const bool step_scale = do_scale && (o->contact_on || o->dct_grad) && (ii < P || cf.legacy_zero_grad);
-    if (step_scale) sc = AdamTensor{o->scale.p, o->mS.p, o->vS.p, o->dscale.p, 1, adam_scalars(cf.lr, ii + 1)};
-    const bool tail = step_scale || reduce_scale;                    // the last block: (reduction +) scale (+ message tail)
-    if (nb_x + nb_cam + (tail ? 1 : 0) + (o->log_pending ? 1 : 0) == 0) return FDCAP_OK;
+    const StepPlan sp = opt_step_plan(o, ii, P, do_rows, do_scale);
+    const bool tail = sp.step_scale || reduce_scale;                 // the last block: (reduction +) scale (+ message tail)
+    if (sp.nb_x + sp.nb_cam + (tail ? 1 : 0) + (o->log_pending ? 1 : 0) == 0) return FDCAP_OK;
     const LogReduceIn lg = {o->loss_rows.p, o->log_dst, o->log_mask, o->log_assign, nl};
-    hipLaunchKernelGGL(adam_step_kernel, dim3(nb_x + nb_cam + 1 + (o->log_pending ? 1 : 0)), dim3(256), 0, st, x, cam, sc, nb_x, nb_cam,
-                       o->dscale_row.p, 2, reduce_scale ? nl : 0, o->dscale.p, (step_scale && ii >= P) ? 1 : 0, xch, nl, o->CAM.p,
+    hipLaunchKernelGGL(adam_step_kernel, dim3(sp.nb_x + sp.nb_cam + 1 + (o->log_pending ? 1 : 0)), dim3(256), 0, st, sp.x, sp.cam, sp.sc, sp.nb_x, sp.nb_cam,
+                       o->dscale_row.p, 2, reduce_scale ? nl : 0, o->dscale.p, (sp.step_scale && ii >= P) ? 1 : 0, xch, nl, o->CAM.p,
                        (do_rows && o->dz_pending) ? (const float*)o->dZpart.p : (const float*)nullptr, (size_t)o->R * VP_Z, lg);
     o->log_pending = false;
     if (do_rows) o->dz_pending = false;
     return (int)hipGetLastError();
+}
+}  // namespace
+
+static int opt_step_impl(fdcap_ctx* c, int32_t ii, int32_t P, bool do_rows, bool do_scale, bool reduce_scale, void* stream,
+                         float* xch = nullptr) {
+    if (!c || !c->opt) return FDCAP_E_STATE;
+    int e = opt_sync(c, (hipStream_t)stream);              // (a deferred step nobody consumed comes first)
+    if (e) return e;
+    return opt_step_launch(c, ii, P, do_rows, do_scale, reduce_scale, (hipStream_t)stream, xch);
+}
+
+int fdcap_opt_sync(fdcap_ctx* c, void* stream) {
+    if (!c || !c->opt) return FDCAP_E_STATE;
+    return opt_sync(c, (hipStream_t)stream);
 }
 
 // ---- mode 'local' (global_optimization.py:499-556) --------------------------------------------
@@ -2905,6 +3041,7 @@ int fdcap_opt_detect_contact(fdcap_ctx* c, int32_t n_left, float* weight_left, v
 
 int fdcap_opt_backward_local2(fdcap_ctx* c, const float* contact_weight, int32_t n_left, void* stream) {
     if (!c || !c->opt || !contact_weight || n_left <= 0 || n_left >= c->nc) return FDCAP_E_ARG;
+    { int es_ = opt_sync(c, (hipStream_t)stream); if (es_) return es_; }
     OptState* o = c->opt;
     hipStream_t st = (hipStream_t)stream;
     const fdcap_opt_config& cf = o->cfg;
@@ -2954,6 +3091,7 @@ int fdcap_opt_backward_local2(fdcap_ctx* c, const float* contact_weight, int32_t
 
 int fdcap_opt_step_x(fdcap_ctx* c, int32_t step, void* stream) {
     if (!c || !c->opt || step <= 0) return FDCAP_E_ARG;
+    { int es_ = opt_sync(c, (hipStream_t)stream); if (es_) return es_; }
     OptState* o = c->opt;
     o->ahead = false;
     const size_t nx = (size_t)o->cfg.n_local * XDIM;
@@ -2964,6 +3102,7 @@ int fdcap_opt_step_x(fdcap_ctx* c, int32_t step, void* stream) {
 
 int fdcap_opt_get_results(fdcap_ctx* c, float* body75, float* scale, float* cam, void* stream) {
     if (!c || !c->opt) return FDCAP_E_STATE;
+    { int es_ = opt_sync(c, (hipStream_t)stream); if (es_) return es_; }
     OptState* o = c->opt;
     hipStream_t st = (hipStream_t)stream;
     const int nl = o->cfg.n_local;
@@ -3005,6 +3144,7 @@ int fdcap_opt_step_rows_and_pack(fdcap_ctx* c, int32_t ii, int32_t P, float* sen
 int fdcap_opt_unpack_and_step_scale(fdcap_ctx* c, int32_t ii, int32_t P, const float* gathered, int32_t rank, int32_t world,
                                     void* stream) {
     if (!c || !c->opt || !gathered || world <= 0 || rank < 0 || rank >= world) return FDCAP_E_ARG;
+    { int es_ = opt_sync(c, (hipStream_t)stream); if (es_) return es_; }
     OptState* o = c->opt;
     const fdcap_opt_config& cf = o->cfg;
     // scale: same rule as opt_step_impl (receives a gradient while ii < P, if a term that reaches it exists)
@@ -3073,6 +3213,7 @@ const char* fdcap_comm_last_error(fdcap_ctx* c) { return c ? c->comm_err.c_str()
 // iteration of mode 'local''s second loop): boundary rows as they are -> all-gather -> unpack, three enqueues on `stream`.
 int fdcap_opt_halo_exchange(fdcap_ctx* c, void* stream) {
     if (!c || !c->opt) return FDCAP_E_STATE;
+    { int es_ = opt_sync(c, (hipStream_t)stream); if (es_) return es_; }
     if (!c->comm.comm) return FDCAP_E_STATE;
     OptState* o = c->opt;
     hipStream_t st = (hipStream_t)stream;
@@ -3126,6 +3267,7 @@ int fdcap_opt_get_contact(fdcap_ctx* c, float* dist, int32_t* idx, void* stream)
 
 int fdcap_opt_get_grads(fdcap_ctx* c, float* dx, float* dcam, void* stream) {
     if (!c || !c->opt) return FDCAP_E_STATE;
+    { int es_ = opt_sync(c, (hipStream_t)stream); if (es_) return es_; }
     OptState* o = c->opt;
     hipStream_t st = (hipStream_t)stream;
     const int nl = o->cfg.n_local;
@@ -3229,6 +3371,7 @@ int fdcap_time_blend_gemm(fdcap_ctx* c, int32_t rows, int32_t iters, float* ms, 
 
 int fdcap_opt_time_chamfer(fdcap_ctx* c, int32_t iters, int32_t brute_force, float* ms, void* stream) {
     if (!c || !c->opt || !ms || iters <= 0) return FDCAP_E_ARG;
+    { int es_ = opt_sync(c, (hipStream_t)stream); if (es_) return es_; }
     OptState* o = c->opt;
     if (!o->contact_on) return FDCAP_E_STATE;
     hipStream_t st = (hipStream_t)stream;

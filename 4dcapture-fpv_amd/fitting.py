@@ -295,6 +295,8 @@ class FittingOP:
         # The reference prints every loss term in every iteration (:573-575, :587-589) with five .item() syncs.  Here the
         # partial sums of a logging iteration are written into a device-side history row (no host sync inside the loop) and
         # read back -- and, when sharded, all-reduced -- once after the last iteration.
+        # FDCAP_DEFER_STEP=0: every optimiser step as its own launch (A/B; the results are the same bits either way)
+        defer = os.environ.get("FDCAP_DEFER_STEP", "1") != "0"
         n_log = 0
         logged = []
         # in-loop read-backs of the loss history are collectives when sharded: one flag for the whole group (rank 0's)
@@ -336,9 +338,19 @@ class FittingOP:
                 if do_log:                               # this iteration's partial sums go straight into their history row
                     capi.check(lib.fdcap_opt_set_loss_output(h, capi.dptr(hist[len(logged)])), "fdcap_opt_set_loss_output")
                     logged.append(ii)
-                # (2: the logged sums are delivered by the step launch that follows -- one launch less per logged iteration)
-                capi.check(lib.fdcap_opt_backward(h, ii, P, 2 if do_log else 0, st), "fdcap_opt_backward")
-                if multi and self._c_comm:
+                if defer and not multi and not do_log and ii + 1 < self.num_iter:
+                    # loss.backward() + optimizer.step() in one call, the step without a launch of its own (fdcap.h): `scale` rides in
+                    # the backward's last launch, the rows are stepped by the next iteration's first two launches; whoever reads
+                    # the registered tensors before that calls fdcap_opt_sync first (snapshots below; export_state does it itself)
+                    capi.check(lib.fdcap_opt_backward_and_step(h, ii, P, 0, st), "fdcap_opt_backward_and_step")
+                    stepped = True
+                else:
+                    # (2: the logged sums are delivered by the step launch that follows -- one launch less per logged iteration)
+                    capi.check(lib.fdcap_opt_backward(h, ii, P, 2 if do_log else 0, st), "fdcap_opt_backward")
+                    stepped = False
+                if stepped:
+                    pass
+                elif multi and self._c_comm:
                     # the same tail inside the library: Adam on the rows + message, ncclAllGather on this stream, unpack + scale
                     capi.check(lib.fdcap_opt_exchange(h, ii, P, st), "fdcap_opt_exchange")
                 elif multi:
@@ -363,6 +375,7 @@ class FittingOP:
                 if flush_in_loop and do_log and len(logged) - flushed >= VERBOSE_FLUSH:
                     flush(len(logged))
                 if ii + 1 in snapshot_at:
+                    capi.check(lib.fdcap_opt_sync(h, st), "fdcap_opt_sync")
                     nl_ = self.shard.n_local
                     self.snapshots[ii + 1] = (self._rows_x[2:2 + nl_].clone(), self._scale.clone(), self._rows_cam[2:2 + nl_].clone())
                 if check_finite_every and (ii + 1) % check_finite_every == 0:
@@ -396,7 +409,7 @@ class FittingOP:
         import torch
         lib, h, nl = self.ctx.lib, self.ctx.handle, self.shard.n_local
         state = torch.empty(int(lib.fdcap_opt_state_len(h)), device=self.device)
-        capi.check(lib.fdcap_opt_export_state(h, capi.dptr(state), capi.current_stream()), "fdcap_opt_export_state")
+        capi.check(lib.fdcap_opt_export_state(h, capi.dptr(state), capi.current_stream()), "fdcap_opt_export_state")   # (applies a deferred step first)
         fn = self._ckpt_file(path)
         tmp = fn + ".tmp.npz"
         np.savez(tmp, next_iter=np.int64(next_iter), num_iter=np.int64(self.num_iter), n_total=np.int64(self.num_body),

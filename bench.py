@@ -50,7 +50,13 @@ NUM_SIMD = 1024                # 256 CUs x 4
 NUM_XCD = 8
 WAVES_PER_SIMD = 8
 METRIC = "frames/sec global-opt (fixed iters), 1024f clip/500k-pt scene; Chamfer GB/s"
-PMC_SUMMARY = os.path.join(ROOT, "profiles", "r3_pmc_summary.json")
+PMC_SUMMARY = os.path.join(ROOT, "profiles", "r4_pmc_summary.json")
+# VALU issue cost per wave64 instruction on one gfx950 SIMD, MEASURED (tools/valu_issue_probe.hip, 8 waves per SIMD, per physical
+# SIMD; profiles/r4_valu_issue_probe.txt): v_fma / v_add / v_mul / v_sub_f32, v_and_b32, v_add_u32 issue every ~2.2 cycles (the
+# guide's "2 cycles"); v_min3 / v_min / v_med3 / v_cmp_f32, v_alignbit_b32, 64-bit shifts and the packed fp32 forms every ~4.16.
+# There is no single "VALU peak": a kernel is priced by its own mix (SQ_INSTS_VALU_{FMA,ADD,MUL}_F32 + _INT32 counted in the fast
+# class -- an upper bound on it, some integer forms are slow --, everything else that is not an MFMA in the slow class).
+VALU_CYC_FAST, VALU_CYC_SLOW = 2.22, 4.16
 
 
 def parse(argv=None):
@@ -309,8 +315,21 @@ def counter_fracs(k, live_seconds=None):
         return {"duration_us_under_pmc": k["duration_us_under_pmc"], "dispatches": k.get("dispatches"),
                 "note": "launch too short for cycle-normalised counter fractions"}
     if k.get("SQ_INSTS_VALU") is not None:
-        out["valu_issue_frac"] = k["SQ_INSTS_VALU"] * 4.0 / (NUM_SIMD * cyc)
         out["valu_insts_per_launch"] = k["SQ_INSTS_VALU"]
+        mix = [k.get(n) for n in ("SQ_INSTS_VALU_FMA_F32", "SQ_INSTS_VALU_ADD_F32", "SQ_INSTS_VALU_MUL_F32", "SQ_INSTS_VALU_INT32")]
+        if all(v is not None for v in mix) and k.get("SQ_INSTS_MFMA") is not None:
+            fast = float(sum(mix))
+            slow = k["SQ_INSTS_VALU"] - fast - k["SQ_INSTS_MFMA"]          # (SQ_INSTS_VALU counts the MFMAs too; they issue on the matrix pipe)
+            busy = fast * VALU_CYC_FAST + slow * VALU_CYC_SLOW
+            out.update({"valu_busy_simd_cycles_per_launch": busy, "valu_issue_frac": busy / (NUM_SIMD * cyc),
+                        "valu_mix": {"fast_class_2.2cyc": fast, "slow_class_4.16cyc": slow, "mfma": k["SQ_INSTS_MFMA"]}})
+        else:
+            # no instruction-mix pass: bounds only (every instruction in the fast / in the slow class)
+            out["valu_issue_frac_bounds"] = [k["SQ_INSTS_VALU"] * VALU_CYC_FAST / (NUM_SIMD * cyc), k["SQ_INSTS_VALU"] * VALU_CYC_SLOW / (NUM_SIMD * cyc)]
+        if k.get("SQ_ACTIVE_INST_ANY") is not None and k.get("SQ_WAVE_CYCLES"):
+            wc = k["SQ_WAVE_CYCLES"]
+            out["wave_time_split"] = {"issuing": k["SQ_ACTIVE_INST_ANY"] / wc, "waiting_to_issue": (k.get("SQ_WAIT_INST_ANY") or 0) / wc,
+                                      "waiting_on_waitcnt": (k.get("SQ_WAIT_ANY") or 0) / wc}
     if k.get("SQ_WAVES"):
         out["waves_per_launch"] = k["SQ_WAVES"]
         if k.get("SQ_INSTS_VALU") is not None:
@@ -405,7 +424,8 @@ def main():
     pmc = load_pmc()
     pk = pmc.get("kernels", {})
     quoted = (N, ns, nc, args.iters, rk.world, args.lbs_nnz) == (1024, 500_000, 500, 500, 1, 4)     # the configuration the PMC summary was taken on
-    nn = counter_fracs(pk.get("nn_in_loop"), sec_loop) if quoted else None
+    # (counters averaged over EVERY in-loop launch of the profiled fits -- like the live mean launch time they are divided by)
+    nn = counter_fracs(pk.get("nn_in_loop_all") or pk.get("nn_in_loop"), sec_loop) if quoted else None
     bf = counter_fracs(pk.get("nn_bruteforce"), sec_bf) if quoted else None
     # The in-loop launch is an exact PRUNED search (seeds, k-d cells, kept work lists; bit-identical to the full scan): it
     # touches ~1 % of the pairs the algorithmic byte count pays for, so bytes-over-time says nothing about a hardware limit.
@@ -418,18 +438,23 @@ def main():
         "timing": "HIP events around every NN launch of one whole fit, on its launch stream (mean); steady_state = back-to-back "
                   "launches at the converged state",
         "counters_from": os.path.relpath(PMC_SUMMARY, ROOT) if nn else None}
-    if nn:
+    if nn and nn.get("valu_busy_simd_cycles_per_launch"):
         clock = nn["clock_ghz_under_pmc"] * 1e9
-        ach = nn["valu_insts_per_launch"] / sec_loop / 1e9
-        peak = NUM_SIMD * clock / 4.0 / 1e9
-        roofline.update({"bound": "valu_issue", "achieved": ach, "peak": peak, "unit": "G wave-instructions/s (VALU)", "frac": ach / peak,
+        ach = nn["valu_busy_simd_cycles_per_launch"] / sec_loop / 1e9
+        peak = NUM_SIMD * clock / 1e9
+        roofline.update({"bound": "valu_issue", "achieved": ach, "peak": peak, "unit": "G SIMD-cycles/s of VALU issue", "frac": ach / peak,
                          "traffic": nn.get("hbm_bytes_per_launch"), "hbm_frac_on_counter_bytes": nn.get("hbm_frac_on_counter_bytes"),
                          "mfma_busy_frac": nn.get("mfma_busy_frac"), "mean_waves_per_simd": nn.get("mean_waves_per_simd"),
                          "max_waves_per_simd": WAVES_PER_SIMD, "valu_insts_per_wave": nn.get("valu_insts_per_wave"),
+                         "valu_mix": nn.get("valu_mix"), "wave_time_split": nn.get("wave_time_split"),
+                         "valu_cycles_per_instruction": {"fast_class": VALU_CYC_FAST, "slow_class": VALU_CYC_SLOW,
+                                                         "measured_by": "tools/valu_issue_probe.hip -> profiles/r4_valu_issue_probe.txt"},
                          "clock_ghz_under_pmc": nn["clock_ghz_under_pmc"],
-                         "note": "peak = 1024 SIMDs x one VALU wave-instruction per 4 cycles at the clock the launch sustained in the PMC "
-                                 "pass; achieved = SQ_INSTS_VALU per launch / live launch time.  HBM and the matrix pipe are far from "
-                                 "their limits (hbm_frac_on_counter_bytes, mfma_busy_frac); mean_waves_per_simd < 8 is the drain"})
+                         "note": "achieved = cycles one SIMD's VALU port is occupied per launch (instruction counts of the PMC mix pass x the measured "
+                                 "cycles of their class, summed over the SIMDs) / live launch time; peak = 1024 SIMDs x the clock the launch "
+                                 "sustained in the PMC pass.  frac is the mean over the whole launch: the port is saturated while all 8 wave "
+                                 "slots per SIMD are filled and idles through the drain (mean_waves_per_simd); HBM and the matrix pipe are far "
+                                 "from their limits"})
     else:
         tr = (pk.get("nn_in_loop") or {}).get("hbm_bytes")
         roofline.update({"bound": "hbm", "achieved": None if tr is None else tr / sec_loop / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",

@@ -197,6 +197,14 @@ int fdcap_opt_set_inputs(fdcap_ctx* ctx, const float* data78_d, const float* ini
 int fdcap_opt_backward(fdcap_ctx* ctx, int32_t ii, int32_t first_phase2_iter, int32_t log_terms,
                        void* stream);
 int fdcap_opt_step(fdcap_ctx* ctx, int32_t ii, int32_t first_phase2_iter, void* stream);
+/* loss.backward() + optimizer.step() of iteration ii (:591-592) in ONE call and without a launch for the step (r4): `scale` is
+ * stepped by one more workgroup of the backward's last launch, the rows of body_rotation_rec / camera_ext take their update in
+ * the first two launches of the next backward, where they are read anyway -- same arithmetic, same bits as fdcap_opt_backward
+ * followed by fdcap_opt_step.  Until then rows_x_d / rows_cam_d and their Adam moments hold the PRE-step values: every other entry
+ * point of this group applies a still-pending update first (an ordinary Adam launch), and a caller that reads the registered
+ * buffers itself calls fdcap_opt_sync before it does.  Sharded runs and log_terms == 2 take the two-call path, silently. */
+int fdcap_opt_backward_and_step(fdcap_ctx* ctx, int32_t ii, int32_t first_phase2_iter, int32_t log_terms, void* stream);
+int fdcap_opt_sync(fdcap_ctx* ctx, void* stream);
 /* Checkpoint / resume (the reference only ever writes its final result, :637-653).  The parameters live in the
  * caller's registered tensors; these move the rest of the optimiser state -- Adam's moments of the owned rows:
  * state_d [fdcap_opt_state_len()] floats = [m_x n_local*78 | v_x | m_cam n_local*16 | v_cam | m_scale | v_scale].

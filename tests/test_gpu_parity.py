@@ -511,6 +511,39 @@ def test_runs_are_bit_reproducible():
     assert outs[1][3].shape[1] == 12 and np.array_equal(outs[1][3], outs[2][3])
 
 
+@pytest.mark.parametrize("mode,legacy", [("global", False), ("global", True), ("local", False)])
+def test_deferred_optimiser_step_gives_the_same_bits(mode, legacy):
+    """fdcap_opt_step_deferred (r4): optimizer.step() (:592) without a launch of its own -- the next iteration's decoder and
+    per-frame pose kernels apply the Adam update where they read the parameters.  Same arithmetic in the same order as the Adam
+    kernel: whole fits (30 iterations across the phase switch; torch < 2 zero_grad semantics, where `scale` keeps coasting in
+    phase 2; mode 'local' with its second loop behind it) agree bit for bit with FDCAP_DEFER_STEP=0, and a snapshot taken in
+    the middle of the deferred run (which forces the pending step out through the ordinary launch) equals the same snapshot of
+    the other run."""
+    outs = []
+    for flag in ("0", "1"):
+        os.environ["FDCAP_DEFER_STEP"] = flag
+        try:
+            n = 37
+            bm = synth.make_body_model(300, seed=72)
+            vp = synth.make_vposer(seed=73)
+            clip = synth.make_clip(n, seed=74)
+            scene = synth.make_scene(6000, seed=75)
+            left, right = synth.make_contact_ids(bm.v_template, per_part=20, seed=76)
+            fop = FittingOP({"num_iter": 30}, {}, n, body_model=bm, vposer=vp, scene_verts=scene, contact_ids=np.concatenate([left, right]),
+                            camera_ext=read_camerapose(clip.camerapose_lines), legacy_zero_grad=legacy, n_left=len(left))
+            kw = {"snapshot_at": [7, 26]} if mode == "global" else {}
+            body, scale, cam = fop.fitting(torch.tensor(clip.body_params).cuda(), mode, **kw)
+            snaps = [tuple(t.clone() for t in fop.snapshots[k]) for k in sorted(fop.snapshots)]
+            outs.append((body.clone(), float(scale), cam.clone(), snaps))
+            fop.close()
+        finally:
+            os.environ.pop("FDCAP_DEFER_STEP")
+    a, b = outs
+    assert torch.equal(a[0], b[0]) and a[1] == b[1] and torch.equal(a[2], b[2])
+    for sa, sb in zip(a[3], b[3]):
+        assert all(torch.equal(x, y) for x, y in zip(sa, sb))
+
+
 @pytest.mark.parametrize("n,per_part", [(48, 40), (5, 250)])
 def test_vector_staged_skinning_backward_equals_the_scalar_kernel(n, per_part):
     """skin_bwd_vec_kernel (16-byte staging through LDS, packed per-vertex constants) evaluates the same terms in the same

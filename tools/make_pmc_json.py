@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""profiles/r3_pmc_summary.json: per-launch PMC totals of the kernels bench.py's `roofline` / `blendshape_gemm` blocks describe,
+"""profiles/r<N>_pmc_summary.json: per-launch PMC totals of the kernels bench.py's `roofline` / `blendshape_gemm` blocks describe,
 from the rocprofv3 passes of tools/run_prof_r3.sh (each counter set its own pass, kernel-trace only):
   trace.db  --kernel-trace --stats            -> duration_us_trace (average over the run)
   fetch.db  --pmc FETCH_SIZE                  -> FETCH_SIZE_KB
@@ -8,13 +8,17 @@ from the rocprofv3 passes of tools/run_prof_r3.sh (each counter set its own pass
 Counters are summed over their instances (XCD x SE) per dispatch and averaged over the dispatches after `skip` (in-loop NN
 kernel: steady state of a fit) or over all of them.  gfx950 correction (MI355X_MICROARCH.md, HBM / rocprofv3 section):
 FETCH_SIZE is in KB and counts wide coalesced reads at half -> x 1024 x 2; WRITE_SIZE in KB -> x 1024.
-usage: make_pmc_json.py trace.db fetch.db write.db sq.db out.json [skip]"""
+r4: further SQ passes may follow (issue / wait split: SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_ANY SQ_WAIT_INST_ANY ...; instruction mix:
+SQ_INSTS_VALU_FMA_F32 SQ_INSTS_VALU_ADD_F32 SQ_INSTS_VALU_MUL_F32 SQ_INSTS_VALU_INT32 SQ_INSTS_VALU_CVT SQ_INSTS_VALU_TRANS_F32 SQ_INSTS_MFMA):
+their counters are merged into the same per-kernel records (a counter present in several passes keeps the first pass's value).
+usage: make_pmc_json.py trace.db fetch.db write.db sq.db out.json [skip] [more_sq.db ...]"""
 import json
 import sqlite3
 import sys
 
 KERNELS = {   # key -> (substring of the kernel name, skip the first `skip` dispatches?)
-    "nn_in_loop": ("nn_stream4", True),
+    "nn_in_loop": ("nn_stream4", True),          # steady state: dispatches after the first `skip`
+    "nn_in_loop_all": ("nn_stream4", False),     # every launch of the fits (what bench.py's live mean launch time covers)
     "nn_bruteforce": ("nn_mfma_kernel", False),
     "blend_fwd": ("panel_gemm3_rb2_kernel", False),
     "blend_bwd": ("panel_gemm3_rb2k", False),
@@ -47,9 +51,9 @@ def trace_avg(db, sub):
     return short, calls, avg / 1e3 if avg > 1e4 else avg       # top_kernels reports ns in some builds, us in others
 
 
-def main(trace_db, fetch_db, write_db, sq_db, out, skip=300):
+def main(trace_db, fetch_db, write_db, sq_db, out, skip=300, *more):
     skip = int(skip)
-    res = {"source": "rocprofv3 passes of tools/run_prof_r3.sh on `python3 bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-logging-run "
+    res = {"source": "rocprofv3 passes of tools/run_prof_r4.sh (r3: run_prof_r3.sh) on `python3 bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-logging-run "
                      "--no-exact-fp32` (two fits: the timed step and the step whose NN launches carry HIP events), 1 x MI355X; per-dispatch "
                      f"sums over XCD x SE instances, mean over the dispatches after the first {skip} for the in-loop NN kernel "
                      "(steady state), over all dispatches for the others",
@@ -65,6 +69,10 @@ def main(trace_db, fetch_db, write_db, sq_db, out, skip=300):
         name, calls, avg_us = trace_avg(trace_db, sub)
         k = {"name": name, "dispatches": n, "duration_us_under_pmc": dur, "duration_us_trace": avg_us, "trace_calls": calls}
         k.update(sq)
+        for db in more:                                          # further SQ passes: new counters only
+            extra, _, _ = per_launch(db, sub, sk)
+            for name, val in extra.items():
+                k.setdefault(name, val)
         if "FETCH_SIZE" in f and "WRITE_SIZE" in w:
             k["FETCH_SIZE_KB"], k["WRITE_SIZE_KB"] = f["FETCH_SIZE"], w["WRITE_SIZE"]
             k["hbm_bytes"] = 2 * 1024 * f["FETCH_SIZE"] + 1024 * w["WRITE_SIZE"]
@@ -74,4 +82,4 @@ def main(trace_db, fetch_db, write_db, sq_db, out, skip=300):
 
 
 if __name__ == "__main__":
-    main(*sys.argv[1:7])
+    main(*sys.argv[1:])

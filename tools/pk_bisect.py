@@ -68,8 +68,11 @@ if VARIANT == "pk":
                            os.path.join(ROOT, "tools", "pk_f32_mfma_repro.hip")], stderr=subprocess.DEVNULL)
     vic = ctypes.CDLL(so)
     vic.pk_chain_launch.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_uint, ctypes.c_int, ctypes.c_void_p]
+    vic.pk_war_launch.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_uint, ctypes.c_void_p]
     rec = torch.zeros(128, dtype=torch.int32, device="cuda")
-    for lds in (0, 1):
+    vic.pk_tree_launch.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_uint, ctypes.c_void_p]
+    vic.pk_swz_launch.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_uint, ctypes.c_int, ctypes.c_void_p]
+    for lds in (0, 3, 9, 16):
         for nb in (False, True):
             rec.zero_()
             stop.clear()
@@ -78,7 +81,14 @@ if VARIANT == "pk":
                 bg.start()
             with torch.cuda.stream(s1):
                 for k in range(REPS * 4):
-                    vic.pk_chain_launch(ctypes.c_void_p(rec.data_ptr()), 600, 17 * k, lds, capi.current_stream())
+                    if lds == 16:
+                        vic.pk_swz_launch(ctypes.c_void_p(rec.data_ptr()), 600, 17 * k, 55, capi.current_stream())
+                    elif lds == 3:
+                        vic.pk_tree_launch(ctypes.c_void_p(rec.data_ptr()), 40, 17 * k, capi.current_stream())
+                    elif lds == 2:
+                        vic.pk_war_launch(ctypes.c_void_p(rec.data_ptr()), 600, 17 * k, capi.current_stream())
+                    else:
+                        vic.pk_chain_launch(ctypes.c_void_p(rec.data_ptr()), 600, 17 * k, lds, capi.current_stream())
                     if k % 16 == 15:
                         s1.synchronize()
                 s1.synchronize()
@@ -86,7 +96,9 @@ if VARIANT == "pk":
             if bg:
                 bg.join()
             r = rec.cpu().numpy().view(np.uint32)
-            print(f"B. stand-alone victim ({'LDS hand-overs' if lds else 'registers only'}) {'next to the blend product' if nb else 'alone'}: "
+            kind = {0: 'registers only', 1: 'LDS hand-overs', 2: 'C: sources reloaded behind the packed ops', 3: 'D: kinematic chain handed through LDS',
+                    5: 'E: LDS hand-overs, lanes 55-63 masked off', 9: 'F: LDS hand-overs, lanes 25, 28, ..., 52 only', 16: 'H: op_sel-swizzled packed sequence, lanes 0-54'}[lds]
+            print(f"B. stand-alone victim ({kind}) {'next to the blend product' if nb else 'alone'}: "
                   f"{REPS * 4} launches, {int(r[0])} mismatches", [tuple(int(v) for v in r[8 * (k + 1):8 * (k + 1) + 7]) for k in range(min(int(r[0]), 4))], flush=True)
 
 # ---- A: the library's own forward

@@ -29,6 +29,30 @@ __global__ __launch_bounds__(256) void probe(unsigned long long* t, float* sink,
                         : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]), "+v"(a[4]), "+v"(a[5]), "+v"(a[6]), "+v"(a[7]) : "v"(b), "v"(c));) }
         if (OP == 4) { R8(asm volatile("v_pk_fma_f32 %0, %0, %4, %4\n v_pk_fma_f32 %1, %1, %4, %4\n v_pk_fma_f32 %2, %2, %4, %4\n v_pk_fma_f32 %3, %3, %4, %4"
                         : "+v"(p[0]), "+v"(p[1]), "+v"(p[2]), "+v"(p[3]) : "v"(p[0]));) }
+#define TWO(op) R4(asm volatile(op " %0, %0, %8\n " op " %1, %1, %8\n " op " %2, %2, %8\n " op " %3, %3, %8\n " op " %4, %4, %8\n " op " %5, %5, %8\n " op " %6, %6, %8\n " op " %7, %7, %8" \
+                        : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]), "+v"(a[4]), "+v"(a[5]), "+v"(a[6]), "+v"(a[7]) : "v"(b), "v"(c));)
+#define THREE(op) R4(asm volatile(op " %0, %0, %8, %9\n " op " %1, %1, %8, %9\n " op " %2, %2, %8, %9\n " op " %3, %3, %8, %9\n " op " %4, %4, %8, %9\n " op " %5, %5, %8, %9\n " op " %6, %6, %8, %9\n " op " %7, %7, %8, %9" \
+                        : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]), "+v"(a[4]), "+v"(a[5]), "+v"(a[6]), "+v"(a[7]) : "v"(b), "v"(c));)
+        if (OP == 6) { TWO("v_add_f32") }
+        if (OP == 7) { TWO("v_mul_f32") }
+        if (OP == 8) { TWO("v_sub_f32") }
+        if (OP == 9) { TWO("v_min_f32") }
+        if (OP == 10) { TWO("v_and_b32") }
+        if (OP == 11) { THREE("v_med3_f32") }
+        if (OP == 12) { TWO("v_add_u32") }
+        if (OP == 13) { R4(asm volatile("v_cndmask_b32 %0, %0, %8, vcc\n v_cndmask_b32 %1, %1, %8, vcc\n v_cndmask_b32 %2, %2, %8, vcc\n v_cndmask_b32 %3, %3, %8, vcc\n v_cndmask_b32 %4, %4, %8, vcc\n v_cndmask_b32 %5, %5, %8, vcc\n v_cndmask_b32 %6, %6, %8, vcc\n v_cndmask_b32 %7, %7, %8, vcc"
+                        : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]), "+v"(a[4]), "+v"(a[5]), "+v"(a[6]), "+v"(a[7]) : "v"(b), "v"(c) : "vcc");) }
+        if (OP == 14) { TWO("v_min_u32") }
+        if (OP == 15) { THREE("v_min3_u32") }
+        if (OP == 16) { TWO("v_min_i32") }
+        if (OP == 17) { TWO("v_max_f32") }
+        if (OP == 18) { TWO("v_lshlrev_b32") }
+        if (OP == 19) { TWO("v_xor_b32") }
+        if (OP == 20) { THREE("v_bfe_u32") }
+        if (OP == 21) { THREE("v_perm_b32") }
+        if (OP == 22) { THREE("v_mad_u32_u24") }
+        if (OP == 23) { THREE("v_min3_i32") }
+        if (OP == 24) { THREE("v_and_or_b32") }
         if (OP == 5) { R8(asm volatile("v_lshrrev_b64 %0, 1, %0\n v_lshrrev_b64 %1, 1, %1\n v_lshrrev_b64 %2, 1, %2\n v_lshrrev_b64 %3, 1, %3"
                         : "+v"(p[0]), "+v"(p[1]), "+v"(p[2]), "+v"(p[3]));) }
     }
@@ -74,5 +98,8 @@ template <int OP> void run(const char* name) {
 int main() {
     printf("shader cycles per wave64 instruction per physical SIMD (median over SIMDs holding >= W waves); launch = 256 x W workgroups of 4 waves\n");
     run<0>("v_fma_f32"); run<1>("v_min3_f32"); run<2>("v_cmp_lt_f32"); run<3>("v_alignbit_b32"); run<4>("v_pk_fma_f32"); run<5>("v_lshrrev_b64");
+    run<6>("v_add_f32"); run<7>("v_mul_f32"); run<8>("v_sub_f32"); run<9>("v_min_f32"); run<10>("v_and_b32"); run<11>("v_med3_f32"); run<12>("v_add_u32"); run<13>("v_cndmask_b32");
+    run<14>("v_min_u32"); run<15>("v_min3_u32"); run<16>("v_min_i32"); run<17>("v_max_f32"); run<18>("v_lshlrev_b32"); run<19>("v_xor_b32");
+    run<20>("v_bfe_u32"); run<21>("v_perm_b32"); run<22>("v_mad_u32_u24"); run<23>("v_min3_i32"); run<24>("v_and_or_b32");
     return 0;
 }
