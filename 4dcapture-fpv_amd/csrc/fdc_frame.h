@@ -69,7 +69,7 @@ FDC_HD void g_store(float* g, const M3& R, V3 t) {
 }
 // 12 floats at a 16-byte aligned address (rows of the per-frame [55,12] arrays): three 16-byte accesses on the GPU
 FDC_HD void store12(float* dst, const float* v) {
-#if defined(__HIP_DEVICE_COMPILE__) && !(defined(FDC_PKX) && FDC_PKX == 2)
+#if defined(__HIP_DEVICE_COMPILE__)
     ((float4*)dst)[0] = make_float4(v[0], v[1], v[2], v[3]);
     ((float4*)dst)[1] = make_float4(v[4], v[5], v[6], v[7]);
     ((float4*)dst)[2] = make_float4(v[8], v[9], v[10], v[11]);
@@ -121,13 +121,7 @@ FDC_HD void pose_forward(const PoseModel& pm, const float* x, const float* o, co
                          float* A, float* M, float* Jw, int tid, int nthr, Sync sync,
                          const float* aa22 = nullptr) {
     FDC_FR_STAMP(0, 1);
-#if defined(FDC_PKX) && FDC_PKX == 7
-    // experiment: lanes 55..63 compute too (joint 54's inputs, nothing stored): the arithmetic below runs with a FULL exec mask
-    for (int j0 = tid; j0 < 64; j0 += nthr) {
-        const int j = j0 < NJ ? j0 : NJ - 1;
-#else
     for (int j = tid; j < NJ; j += nthr) {
-#endif
         M3 R;
         // aa22 (operator-level API only): global_orient + 21 body joints given as axis-angle
         if (aa22 && j <= 21) R = rodrigues_forward(v3(aa22[3 * j], aa22[3 * j + 1], aa22[3 * j + 2]));
@@ -135,9 +129,6 @@ FDC_HD void pose_forward(const PoseModel& pm, const float* x, const float* o, co
         else if (j <= 21) R = gs_forward(o + 6 * (j - 1), 1, nullptr);
         else if (j < 25) R = m3_identity();          // jaw / eyes: zero Parameters, never optimised
         else R = rodrigues_forward(hand_aa(pm, x, j));
-#if defined(FDC_PKX) && FDC_PKX == 7
-        if (j0 >= NJ) continue;
-#endif
         store_m3(sc.R[j], R);
         for (int c = 0; c < 3; ++c) {
             float acc = pm.Jt[3 * j + c];
@@ -161,26 +152,12 @@ FDC_HD void pose_forward(const PoseModel& pm, const float* x, const float* o, co
         const V3 rel = (act && p >= 0) ? Jj - v3(sc.J[p][0], sc.J[p][1], sc.J[p][2]) : Jj;
         for (int L = 0; L < pm.nlevels; ++L) {
             if (dep == L) {
-#if defined(FDC_PKX) && FDC_PKX == 2
-                float gg[12];                                  // experiment: twelve 4-byte LDS stores instead of three 16-byte ones
-                if (p < 0) g_store(gg, R, Jj);
-                else { const M3 Rp = g_rot(sc.G[p]); g_store(gg, m3_mul(Rp, R), m3_vec(Rp, rel) + g_trn(sc.G[p])); }
-                for (int e = 0; e < 12; ++e) ((volatile float*)sc.G[j])[e] = gg[e];
-#else
                 if (p < 0) g_store(sc.G[j], R, Jj);
                 else {
                     const M3 Rp = g_rot(sc.G[p]);
                     g_store(sc.G[j], m3_mul(Rp, R), m3_vec(Rp, rel) + g_trn(sc.G[p]));
                 }
-#endif
             }
-#if defined(FDC_PKX) && FDC_PKX == 1
-            __syncthreads();
-#elif defined(FDC_PKX) && FDC_PKX == 5
-            asm volatile("s_waitcnt lgkmcnt(0)\n s_nop 7\n s_nop 7" ::: "memory");
-#elif defined(FDC_PKX) && FDC_PKX == 6
-            __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
-#endif
             __builtin_amdgcn_wave_barrier();
         }
         sync();

@@ -222,13 +222,8 @@ __device__ __forceinline__ PoseModel stage_pose_model(const PoseModel& pm, PoseS
 // One workgroup per frame: POSE_NW waves issue the staging copies, the first one does the frame's arithmetic.
 // PARTS: the decoder output arrives as the four partial sums of vposer_fwd_fused_kernel (Opart, part_stride apart); they are
 // added here in the fixed order of vp_sum_parts, kept in LDS for this frame and written to O for the backward.
-#if defined(FDC_PKX) && FDC_PKX == 3
-#define FDC_PKX_ATTR __attribute__((target("no-packed-fp32-ops")))
-#else
-#define FDC_PKX_ATTR
-#endif
 template <bool PARTS>
-FDC_PKX_ATTR __global__ __launch_bounds__(64 * POSE_NW) void pose_fwd_kernel(PoseModel pm, const float* __restrict__ X, float* __restrict__ O,
+__global__ __launch_bounds__(64 * POSE_NW) void pose_fwd_kernel(PoseModel pm, const float* __restrict__ X, float* __restrict__ O,
                                                       const float* __restrict__ CAM, const float* __restrict__ scale,
                                                       int row0, float* Rm, float* PF, float* Jrest, float* G, float* A,
                                                       float* M, float* Jw, const float* AA, const float* __restrict__ Opart,

@@ -1,276 +1,64 @@
-// Stand-alone reproducer attempt for DESIGN.md section 7: does a packed fp32 instruction return a wrong element
-// while ANOTHER kernel's MFMAs share the CU?  No library code: kernel A = one-wave workgroups, every lane runs chains of
-// v_pk_fma_f32 / v_pk_mul_f32 / v_pk_add_f32 and, from the same inputs, the two scalar instructions each packed one stands for,
-// and compares the bits in place; kernel B = MFMA loops on a second stream.  Phases: A alone, A next to B, A next to a VALU-only B.
-//   hipcc --offload-arch=gfx950 -O2 -o /tmp/pk_repro tools/pk_f32_mfma_repro.hip && /tmp/pk_repro [rounds]
+// Stand-alone reproducer of DESIGN.md section 7: on the MI355X boxes of this pool a packed fp32 instruction whose
+// op_sel modifier makes the LOW result take the HIGH half of src2,
+//     v_pk_fma_f32 K, B, B, R op_sel:[0,0,1] op_sel_hi:[1,1,0]        (K.lo = B.lo * B.lo + R.hi,  K.hi = B.hi * B.hi + R.lo)
+// returns K.lo = B.lo * B.lo + 0 -- the addend is dropped -- in lanes 48-63 of the wave, now and then, WHILE ANOTHER KERNEL'S MFMAs
+// run on the same CU.  Alone, or next to a VALU-only kernel: never.  No library code here: kernel A runs the sequence hipcc emits for
+// the library's Rodrigues formula (k.k of the rotation axis; pose_forward, csrc/fdc_frame.h, built with packed fp32) as inline asm
+// and checks every result against scalar instructions on the same inputs; kernel B keeps the matrix pipe (and LDS) busy on a
+// second stream.  s_nop 7 in front of the instruction does not help; replacing the v_pk_add that follows by scalar adds does not
+// help; replacing THIS instruction by two v_fma_f32 does.  The library is therefore built without packed fp32 instructions
+// (-Xclang -target-feature -Xclang -packed-fp32-ops: hipcc forms op_sel swizzles freely and offers no finer switch).
+//   hipcc --offload-arch=gfx950 -O3 -o /tmp/pk_repro tools/pk_f32_mfma_repro.hip && /tmp/pk_repro [rounds]
+// Measured (profiles/r4_pk_f32_repro.txt): alone 0 of 1.3e10; next to the MFMA kernel 2-6 million, all in lanes 48-63, all K.lo, all equal
+// to the result with the addend dropped; next to the VALU-only kernel 0.
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <cstdlib>
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));       // a 64-bit register pair {lo, hi}
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
-
-// every float operation outside the three packed instructions under test is a scalar instruction by construction (hipcc would
-// otherwise fuse pairs of them into packed ones itself)
+// scalar reference arithmetic as explicit instructions (hipcc would fuse pairs of C operations into packed ones itself)
 __device__ __forceinline__ float sfma(float a, float b, float c) { float r; asm volatile("v_fma_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c)); return r; }
-// rec[0] = mismatches; then up to 15 records {lane, chain step, which (0 fma 1 mul 2 add), element, packed bits, scalar bits, block, 0}
-// (use_lds & 4: only lanes 0..54 take part -- the library's kernel runs lane = joint with 55 joints, so the last quarter of its
-//  wave executes the packed instructions with lanes 55..63 masked off)
-__global__ __launch_bounds__(64) void pk_chain_kernel(unsigned* rec, int steps, unsigned seed, int use_lds) {
-    __shared__ float sh[64 * 2];
-    const int lane = threadIdx.x;
-    if ((use_lds & 4) && lane >= 55) return;
-    // (use_lds & 8: only the lanes of the tree's depth-9 joints run -- 25, 28, ..., 49, 52: the exec mask under which the library's
-    //  kernel computes the two transforms that come out wrong)
-    if ((use_lds & 8) && !(lane >= 25 && lane <= 52 && (lane - 25) % 3 == 0)) return;
-    use_lds &= 3;
-    // lane-dependent, block-dependent operands (the library's failing lanes were 48-63 of a one-wave workgroup)
-    float a0 = 1.0f + 0.001f * lane + 1e-6f * (blockIdx.x & 255), a1 = 0.75f - 0.002f * lane;
-    float b0 = 0.999f + 1e-4f * ((seed + lane) & 31), b1 = 1.001f - 1e-4f * ((seed >> 3) & 31);
-    float c0 = 0.01f * lane, c1 = -0.02f * lane;
-    for (int s = 0; s < steps; ++s) {
-        const f32x2 pa = {a0, a1}, pb = {b0, b1}, pc = {c0, c1};
-        f32x2 pr;
-        float q0, q1;
-        const int which = s % 3;
-        if (which == 0) {
-            asm volatile("v_pk_fma_f32 %0, %1, %2, %3" : "=v"(pr) : "v"(pa), "v"(pb), "v"(pc));
-            asm volatile("v_fma_f32 %0, %1, %2, %3" : "=v"(q0) : "v"(a0), "v"(b0), "v"(c0));
-            asm volatile("v_fma_f32 %0, %1, %2, %3" : "=v"(q1) : "v"(a1), "v"(b1), "v"(c1));
-        } else if (which == 1) {
-            asm volatile("v_pk_mul_f32 %0, %1, %2" : "=v"(pr) : "v"(pa), "v"(pb));
-            asm volatile("v_mul_f32 %0, %1, %2" : "=v"(q0) : "v"(a0), "v"(b0));
-            asm volatile("v_mul_f32 %0, %1, %2" : "=v"(q1) : "v"(a1), "v"(b1));
-        } else {
-            asm volatile("v_pk_add_f32 %0, %1, %2" : "=v"(pr) : "v"(pa), "v"(pc));
-            asm volatile("v_add_f32 %0, %1, %2" : "=v"(q0) : "v"(a0), "v"(c0));
-            asm volatile("v_add_f32 %0, %1, %2" : "=v"(q1) : "v"(a1), "v"(c1));
-        }
-        const float r0 = pr.x, r1 = pr.y;
-        if (__float_as_uint(r0) != __float_as_uint(q0) || __float_as_uint(r1) != __float_as_uint(q1)) {
-            const unsigned k = atomicAdd(&rec[0], 1u);
-            if (k < 15) {
-                unsigned* r = rec + 8 * (k + 1);
-                const int el = __float_as_uint(r0) != __float_as_uint(q0) ? 0 : 1;
-                r[0] = lane; r[1] = s; r[2] = which; r[3] = el; r[4] = __float_as_uint(el ? r1 : r0); r[5] = __float_as_uint(el ? q1 : q0); r[6] = blockIdx.x; r[7] = 0;
-            }
-        }
-        a0 = sfma(q0, 0.5f, 0.6f); a1 = sfma(q1, 0.5f, 0.4f);   // keep the chain bounded and data-dependent
-        if (use_lds) {                                        // the library's kernel hands values between lanes through LDS between its packed groups
-            sh[lane] = a0; sh[64 + lane] = a1;
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-            a0 = sfma(sh[(lane + 1) & 63], 0.25f, sfma(a0, 0.75f, 0.f)); a1 = sfma(sh[64 + ((lane + 63) & 63)], 0.25f, sfma(a1, 0.75f, 0.f));
-        }
-        c0 = sfma(c0, 1.f, 0.001f); c1 = sfma(c1, 1.f, -0.001f);
-    }
-    if (a0 == 123.f) rec[127] = 1;
-}
-// Variant C -- the pattern of the library's failing code (pose_forward's hand-PCA sums under packed codegen, ISA in DESIGN.md 7):
-// a packed instruction whose SOURCE register pair is the destination of an LDS load issued right BEHIND it (write-after-read
-// through the LDS return path).  Legal: the loads' data cannot come back before an instruction in front of them has read its
-// operands -- unless that instruction sits in a queue.  Per step: load the good pair, wait, three packed instructions that use it
-// as src2 / src1 / src0, then IMMEDIATELY a load of another pair into the same registers; the packed results are compared with
-// scalar arithmetic on a second copy of the good pair.  A mismatch = the packed instruction saw (part of) the later load's data.
-__global__ __launch_bounds__(64) void pk_war_kernel(unsigned* rec, int steps, unsigned seed) {
-    __shared__ __attribute__((aligned(8))) float good[2][64 * 2], poison[64 * 2];
-    const int lane = threadIdx.x;
-    float x0 = 1.0f + 0.001f * lane, x1 = 0.75f - 0.002f * lane, y0 = 0.999f + 1e-4f * ((seed + lane) & 31), y1 = 1.001f - 1e-4f * ((seed >> 3) & 31);
-    for (int s = 0; s < steps; ++s) {
-        const float g0 = 0.01f * lane + 0.001f * s, g1 = -0.02f * lane + 0.002f * s;
-        good[s & 1][2 * lane] = g0; good[s & 1][2 * lane + 1] = g1;
-        poison[2 * lane] = 1000.f + lane + s; poison[2 * lane + 1] = -1000.f - lane - s;
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        const f32x2 px = {x0, x1}, py = {y0, y1};
-        f32x2 r2, r1, r0, src;
-        const unsigned a1 = (unsigned)(size_t)&good[s & 1][2 * lane], a2 = (unsigned)(size_t)&poison[2 * lane];
-        asm volatile("ds_read_b64 %[src], %[a1]\n"
-                     "s_waitcnt lgkmcnt(0)\n"
-                     "v_pk_fma_f32 %[r2], %[x], %[y], %[src]\n"
-                     "v_pk_fma_f32 %[r1], %[x], %[src], %[y]\n"
-                     "v_pk_fma_f32 %[r0], %[src], %[x], %[y] op_sel_hi:[0,1,1]\n"
-                     "ds_read_b64 %[src], %[a2]\n"
-                     "s_waitcnt lgkmcnt(0)\n"
-                     : [r2] "=&v"(r2), [r1] "=&v"(r1), [r0] "=&v"(r0), [src] "=&v"(src) : [x] "v"(px), [y] "v"(py), [a1] "v"(a1), [a2] "v"(a2) : "memory");
-        const float e[6] = {sfma(x0, y0, g0), sfma(x1, y1, g1), sfma(x0, g0, y0), sfma(x1, g1, y1), sfma(g0, x0, y0), sfma(g0, x1, y1)};
-        const float got[6] = {r2.x, r2.y, r1.x, r1.y, r0.x, r0.y};
-        for (int k = 0; k < 6; ++k)
-            if (__float_as_uint(e[k]) != __float_as_uint(got[k])) {
-                const unsigned n = atomicAdd(&rec[0], 1u);
-                if (n < 15) { unsigned* r = rec + 8 * (n + 1); r[0] = lane; r[1] = s; r[2] = 3 + k / 2; r[3] = k & 1; r[4] = __float_as_uint(got[k]); r[5] = __float_as_uint(e[k]); r[6] = blockIdx.x; r[7] = 0; }
-            }
-        if (src.x != poison[2 * lane] || src.y != poison[2 * lane + 1]) atomicAdd(&rec[120], 1u);     // (the second load must land, and keeps it alive)
-        x0 = sfma(r2.x, 0.001f, x0); x1 = sfma(r2.y, 0.001f, x1);
-    }
-    if (x0 == 123.f) rec[127] = 1;
-}
-// Variant D -- the library's failing CONSTRUCT, written out again without library code: one wave, lane j = joint j of the 55-joint
-// SMPL-X tree, a kinematic chain by depth levels with the parent's 3x4 transform handed from lane to lane through LDS
-// (ds_write_b128 x 3 by the parent's lane at level L, ds_read_b128 x 3 by the child's lane at level L + 1, nothing but program
-// order between them: "a wave's LDS operations execute in order").  hipcc turns the 3x3 products into v_pk_fma_f32 / v_pk_mul_f32 /
-// v_pk_add_f32 and moves the loop-carried rows with v_mov_b64, as in the library's pose_forward.  Each lane then recomputes its own
-// whole chain is run twice by the same instructions into two LDS arrays and the two are compared bit for bit (a re-computation
-// in registers is no yardstick: hipcc contracts its multiply-adds differently from the chain's, 1-ulp differences everywhere).
-struct M3r { float m[9]; };
-__device__ __forceinline__ M3r m3r_mul(const M3r& a, const M3r& b) {
-    M3r r;
-    for (int i = 0; i < 3; ++i)
-        for (int j = 0; j < 3; ++j) r.m[3 * i + j] = a.m[3 * i] * b.m[j] + a.m[3 * i + 1] * b.m[3 + j] + a.m[3 * i + 2] * b.m[6 + j];
-    return r;
-}
-__device__ __forceinline__ void m3r_vec(const M3r& a, const float* v, const float* t, float* o) {
-    for (int i = 0; i < 3; ++i) o[i] = a.m[3 * i] * v[0] + a.m[3 * i + 1] * v[1] + a.m[3 * i + 2] * v[2] + t[i];
-}
-__constant__ int c_parents[55] = {-1, 0, 0, 0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 9, 9, 12, 13, 14, 16, 17, 18, 19, 15, 15, 15, 20, 25, 26, 20, 28, 29, 20, 31, 32,
-                                  20, 34, 35, 20, 37, 38, 21, 40, 41, 21, 43, 44, 21, 46, 47, 21, 49, 50, 21, 52, 53};
-#ifdef PK_TREE_NOPK
-#define PK_TREE_ATTR __attribute__((target("no-packed-fp32-ops")))
-#else
-#define PK_TREE_ATTR
-#endif
-// (nlev = 12 arrives as a kernel argument so that the level loop stays a LOOP, as in the library, where the tree depth is data;
-//  four waves per workgroup of which three leave after the first barrier, as in the library's pose kernels)
-PK_TREE_ATTR __global__ __launch_bounds__(256) void pk_tree_kernel(unsigned* rec, int steps, unsigned seed, int nlev) {
-    __shared__ __attribute__((aligned(16))) float sG[2][64][12];    // the hand-over: row-major [R | t] per joint; two passes
-    __syncthreads();
-    if (threadIdx.x >= 64) return;
-    const int j = threadIdx.x;
-    const bool act = j < 55;
-    const int p = act ? c_parents[j] : -1;
-    int dep = 0;
-    for (int a = p; a >= 0; a = c_parents[a]) ++dep;
-    if (!act) dep = -1;
-    for (int s = 0; s < steps; ++s) {
-        // a rotation about a lane- and step-dependent axis (Rodrigues), offsets of a few centimetres
-        const float ax = 0.3f + 0.01f * j, ay = -0.2f + 0.02f * ((j + s) & 15), az = 0.1f + 0.001f * ((seed + s) & 63);
-        const float th = sqrtf(ax * ax + ay * ay + az * az), c = cosf(th), sn = sinf(th), k = (1.f - c) / (th * th), q = sn / th;
-        M3r R = {{c + k * ax * ax, k * ax * ay - q * az, k * ax * az + q * ay, k * ax * ay + q * az, c + k * ay * ay, k * ay * az - q * ax,
-                  k * ax * az - q * ay, k * ay * az + q * ax, c + k * az * az}};
-        float rel[3] = {0.02f + 0.001f * j, 0.1f - 0.002f * j, 0.01f * ((s & 7) - 3)};
-        // The chain by levels, lane-resident (the construct under test), run TWICE by the same instructions (the pass loop is not
-        // unrolled): whatever the code generation is, the two passes must leave the same bits.
-#pragma clang loop unroll(disable)
-        for (int pass = 0; pass < 2; ++pass) {
-            for (int e = 0; e < 9; ++e) asm volatile("" : "+v"(R.m[e]));       // (opaque: nothing of pass 0 is reused in pass 1)
-            for (int e = 0; e < 3; ++e) asm volatile("" : "+v"(rel[e]));
-            float (*G)[12] = sG[pass];
-            for (int L = 0; L < nlev; ++L) {
-                if (dep == L) {
-                    float g[12];
-                    if (p < 0) { for (int i = 0; i < 3; ++i) { for (int e = 0; e < 3; ++e) g[4 * i + e] = R.m[3 * i + e]; g[4 * i + 3] = rel[i]; } }
-                    else {
-                        M3r Rp; float tp[3];
-                        for (int i = 0; i < 3; ++i) { for (int e = 0; e < 3; ++e) Rp.m[3 * i + e] = G[p][4 * i + e]; tp[i] = G[p][4 * i + 3]; }
-                        const M3r Rc = m3r_mul(Rp, R);
-                        float tc[3]; m3r_vec(Rp, rel, tp, tc);
-                        for (int i = 0; i < 3; ++i) { for (int e = 0; e < 3; ++e) g[4 * i + e] = Rc.m[3 * i + e]; g[4 * i + 3] = tc[i]; }
-                    }
-                    ((float4*)G[j])[0] = make_float4(g[0], g[1], g[2], g[3]);
-                    ((float4*)G[j])[1] = make_float4(g[4], g[5], g[6], g[7]);
-                    ((float4*)G[j])[2] = make_float4(g[8], g[9], g[10], g[11]);
-                }
-                __builtin_amdgcn_wave_barrier();
-            }
-            __builtin_amdgcn_s_barrier();
-        }
-        if (act)
-            for (int e = 0; e < 12; ++e) {
-                const float got = sG[0][j][e], want = sG[1][j][e];
-                if (__float_as_uint(want) != __float_as_uint(got)) {
-                    const unsigned n = atomicAdd(&rec[0], 1u);
-                    if (n < 15) { unsigned* r = rec + 8 * (n + 1); r[0] = j; r[1] = s; r[2] = 6; r[3] = e; r[4] = __float_as_uint(got); r[5] = __float_as_uint(want); r[6] = blockIdx.x; r[7] = 0; }
-                }
-            }
-        __builtin_amdgcn_s_barrier();
-    }
-}
-// Variant H -- the instruction sequence found where the library's wrong word is born (tools/pk_where.py: the local rotations of
-// the hand joints in lanes 48-54, their diagonal = 1 + (1 - cos)(k_i^2 - k.k), i.e. the axis' squared norm k.k): packed
-// instructions whose op_sel modifiers read the OTHER half of a register pair -- a broadcast of the low element
-// (op_sel_hi:[1,0]), a pair that is overwritten by the very next packed instruction, and a packed fma / add that swap the halves of
-// a pair produced two instructions earlier (op_sel:[0,0,1] op_sel_hi:[1,1,0]; op_sel:[1,0] op_sel_hi:[0,1]) -- with the
-// library's scalar fillers in between.  Every result is compared with scalar instructions on the same inputs.
 __device__ __forceinline__ float smul(float a, float b) { float r; asm volatile("v_mul_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
 __device__ __forceinline__ float sadd(float a, float b) { float r; asm volatile("v_add_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
-// V: 0 the sequence as found; 1 s_nop 7 in front of the swizzled v_pk_fma; 2 s_nop 7 in front of the swizzled v_pk_add; 3 no fillers;
-//    4 the swizzled v_pk_add replaced by two scalar adds (is the v_pk_fma's swizzled read the one that fails?);
-//    5 the swizzled v_pk_fma replaced by two scalar fmas (... or the v_pk_add's?)
-template <int V>
-__global__ __launch_bounds__(64) void pk_swz_kernel(unsigned* rec, int steps, unsigned seed, int nlanes) {
+
+// rec[0] mismatches, rec[1] of them in lanes 48-63, rec[2] of them K.lo, rec[3] of them equal to "addend dropped";
+// then up to 15 records {lane, step, element (0-1 A, 2-3 B, 4-5 R, 6-7 K), got, want, block}
+// FIX = 1: the swizzled v_pk_fma_f32 replaced by two v_fma_f32
+template <int FIX>
+__global__ __launch_bounds__(64) void pk_swz_kernel(unsigned* rec, int steps, unsigned seed) {
     const int lane = threadIdx.x;
-    if (lane >= nlanes) return;
     float a0 = 0.31f + 0.011f * lane, a1 = -0.27f + 0.007f * lane, b0 = 0.12f + 0.003f * ((seed + lane) & 31), b1 = 0.45f - 0.004f * lane;
-    float t = 0.5f + 0.001f * lane, u = 0.9f, x = 0.25f;
-    unsigned w = lane;
     for (int s = 0; s < steps; ++s) {
-        const float r = 1.0f / (0.8f + 0.01f * ((s + lane) & 15));          // the 1 / theta of the library's code
+        const float r = 1.0f / (0.8f + 0.01f * ((s + lane) & 15));          // (the 1 / theta of the library's code)
         f32x2 vA = {a0, a1}, vB = {b0, b1}, vR = {r, -7.f}, vS, vK;
-        float t1 = t, t2; unsigned w2;
-#define PK_SWZ_HEAD "v_pk_mul_f32 %[A], %[A], %[R] op_sel_hi:[1,0]\n v_fma_f32 %[t1], %[t1], %[u], 1.0\n v_cmp_eq_u32 vcc, 0, %[w]\n" \
-                    "v_pk_mul_f32 %[B], %[B], %[R] op_sel_hi:[1,0]\n v_pk_mul_f32 %[R], %[A], %[A]\n"
-#define PK_SWZ_FILL "v_cndmask_b32 %[t2], -%[x], %[t1], vcc\n v_lshlrev_b32 %[w2], 30, %[w]\n"
-#define PK_SWZ_S "v_pk_mul_f32 %[S], %[B], %[B]\n"
-#define PK_SWZ_FMA "v_pk_fma_f32 %[K], %[B], %[B], %[R] op_sel:[0,0,1] op_sel_hi:[1,1,0]\n"
-#define PK_SWZ_ADD "v_pk_add_f32 %[K], %[S], %[K] op_sel:[1,0] op_sel_hi:[0,1]\n"
-#define PK_SWZ_OPS : [A] "+v"(vA), [B] "+v"(vB), [R] "+v"(vR), [S] "=&v"(vS), [K] "=&v"(vK), [t1] "+v"(t1), [t2] "=&v"(t2), [w2] "=&v"(w2) \
-                   : [u] "v"(u), [w] "v"(w), [x] "v"(x) : "vcc"
-        t2 = 0.f; w2 = 0u;
-        if (V == 0) asm volatile(PK_SWZ_HEAD PK_SWZ_FILL PK_SWZ_S PK_SWZ_FMA PK_SWZ_ADD PK_SWZ_OPS);
-        if (V == 1) asm volatile(PK_SWZ_HEAD PK_SWZ_FILL PK_SWZ_S "s_nop 7\n" PK_SWZ_FMA PK_SWZ_ADD PK_SWZ_OPS);
-        if (V == 2) asm volatile(PK_SWZ_HEAD PK_SWZ_FILL PK_SWZ_S PK_SWZ_FMA "s_nop 7\n" PK_SWZ_ADD PK_SWZ_OPS);
-        if (V == 3) asm volatile(PK_SWZ_HEAD PK_SWZ_S PK_SWZ_FMA PK_SWZ_ADD PK_SWZ_OPS);
-        if (V == 4) {
-            asm volatile(PK_SWZ_HEAD PK_SWZ_FILL PK_SWZ_S PK_SWZ_FMA PK_SWZ_OPS);
-            vK = f32x2{sadd(vS.y, vK.x), sadd(vS.x, vK.y)};
-        }
-        if (V == 5) {
-            asm volatile(PK_SWZ_HEAD PK_SWZ_FILL PK_SWZ_S PK_SWZ_OPS);
-            vK = f32x2{sfma(vB.x, vB.x, vR.y), sfma(vB.y, vB.y, vR.x)};
-            asm volatile(PK_SWZ_ADD PK_SWZ_OPS);
-        }
+        asm volatile("v_pk_mul_f32 %[A], %[A], %[R] op_sel_hi:[1,0]\n"     // A *= R.lo
+                     "v_pk_mul_f32 %[B], %[B], %[R] op_sel_hi:[1,0]\n"     // B *= R.lo
+                     "v_pk_mul_f32 %[R], %[A], %[A]\n"                     // R = A^2
+                     "v_pk_mul_f32 %[S], %[B], %[B]\n"                     // S = B^2
+                     : [A] "+v"(vA), [B] "+v"(vB), [R] "+v"(vR), [S] "=&v"(vS));
+        if (FIX) vK = f32x2{sfma(vB.x, vB.x, vR.y), sfma(vB.y, vB.y, vR.x)};
+        else asm volatile("v_pk_fma_f32 %[K], %[B], %[B], %[R] op_sel:[0,0,1] op_sel_hi:[1,1,0]\n" : [K] "=&v"(vK) : [B] "v"(vB), [R] "v"(vR));
+        asm volatile("v_pk_add_f32 %[K], %[S], %[K] op_sel:[1,0] op_sel_hi:[0,1]\n" : [K] "+v"(vK) : [S] "v"(vS));     // K = {S.hi + K.lo, S.lo + K.hi}
         const float A0 = smul(a0, r), A1 = smul(a1, r), B0 = smul(b0, r), B1 = smul(b1, r);
         const float R0 = smul(A0, A0), R1 = smul(A1, A1), S0 = smul(B0, B0), S1 = smul(B1, B1);
-        const float K0 = sadd(S1, sfma(B0, B0, R1)), K1 = sadd(S0, sfma(B1, B1, R0));
-        const float want[8] = {A0, A1, B0, B1, R0, R1, K0, K1}, got[8] = {vA.x, vA.y, vB.x, vB.y, vR.x, vR.y, vK.x, vK.y};
+        const float want[8] = {A0, A1, B0, B1, R0, R1, sadd(S1, sfma(B0, B0, R1)), sadd(S0, sfma(B1, B1, R0))};
+        const float got[8] = {vA.x, vA.y, vB.x, vB.y, vR.x, vR.y, vK.x, vK.y};
         for (int k = 0; k < 8; ++k)
             if (__float_as_uint(want[k]) != __float_as_uint(got[k])) {
                 const unsigned n = atomicAdd(&rec[0], 1u);
-                if (n < 15) {
-                    // what did the failing half read instead?  q[7]: 1 = S.lo in place of S.hi, 2 = R.lo in place of R.hi, 3 = the pair R held BEFORE v_pk_mul overwrote it
-                    unsigned why = 0;
-                    if (k == 6) {
-                        if (__float_as_uint(got[k]) == __float_as_uint(sadd(S0, sfma(B0, B0, R1)))) why = 1;
-                        else if (__float_as_uint(got[k]) == __float_as_uint(sadd(S1, sfma(B0, B0, R0)))) why = 2;
-                        else if (__float_as_uint(got[k]) == __float_as_uint(sadd(S1, sfma(B0, B0, -7.f)))) why = 3;
-                        else if (__float_as_uint(got[k]) == __float_as_uint(sadd(S1, sfma(B0, B0, r)))) why = 4;
-                    }
-                    unsigned* q = rec + 8 * (n + 1); q[0] = lane; q[1] = s; q[2] = 7; q[3] = k; q[4] = __float_as_uint(got[k]); q[5] = __float_as_uint(want[k]); q[6] = blockIdx.x; q[7] = why;
-                }
+                if (lane >= 48) atomicAdd(&rec[1], 1u);
+                if (k == 6) atomicAdd(&rec[2], 1u);
+                if (k == 6 && __float_as_uint(got[k]) == __float_as_uint(sadd(S1, sfma(B0, B0, 0.f)))) atomicAdd(&rec[3], 1u);
+                if (n < 15) { unsigned* q = rec + 8 * (n + 1); q[0] = lane; q[1] = s; q[2] = k; q[3] = __float_as_uint(got[k]); q[4] = __float_as_uint(want[k]); q[5] = blockIdx.x; }
             }
-        a0 = sfma(K0, 0.01f, a0 * 0.99f); a1 = sfma(K1, -0.01f, a1 * 0.99f); t = sfma(t2, 0.001f, 0.5f); w = (w2 >> 30) + lane + s;
+        a0 = sfma(want[6], 0.01f, smul(a0, 0.99f)); a1 = sfma(want[7], -0.01f, smul(a1, 0.99f));
     }
     if (a0 == 123.f) rec[127] = 1;
 }
-#ifdef PK_VICTIM_LIB
-extern "C" int pk_swz_launch(unsigned* rec, int steps, unsigned seed, int nlanes, void* stream) {
-    pk_swz_kernel<0><<<1028, 64, 0, (hipStream_t)stream>>>(rec, steps, seed, nlanes);
-    return (int)hipGetLastError();
-}
-extern "C" int pk_tree_launch(unsigned* rec, int steps, unsigned seed, void* stream) {
-    pk_tree_kernel<<<1028, 256, 0, (hipStream_t)stream>>>(rec, steps, seed, 12);
-    return (int)hipGetLastError();
-}
-extern "C" int pk_war_launch(unsigned* rec, int steps, unsigned seed, void* stream) {
-    pk_war_kernel<<<1028, 64, 0, (hipStream_t)stream>>>(rec, steps, seed);
-    return (int)hipGetLastError();
-}
-// tools/pk_bisect.py: the victim alone as a shared library, launched next to the real library's kernels
-extern "C" int pk_chain_launch(unsigned* rec, int steps, unsigned seed, int use_lds, void* stream) {
-    pk_chain_kernel<<<1028, 64, 0, (hipStream_t)stream>>>(rec, steps, seed, use_lds);
-    return (int)hipGetLastError();
-}
-#endif
+// the neighbours: MFMA loops with some LDS traffic (what the library's panel products look like to the CU) / VALU only
 __global__ __launch_bounds__(256) void mfma_load_kernel(float* sink, int iters) {
-    __shared__ __attribute__((aligned(16))) float4 lbuf[2048];     // + LDS traffic (the library's neighbours stream their operands through LDS)
+    __shared__ __attribute__((aligned(16))) float4 lbuf[2048];
     for (int i = threadIdx.x; i < 2048; i += 256) lbuf[i] = make_float4(0.001f * i, 1.f, 2.f, 3.f);
     __syncthreads();
     float4 lacc = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -279,73 +67,42 @@ __global__ __launch_bounds__(256) void mfma_load_kernel(float* sink, int iters) 
     f32x4 acc[4] = {{0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}};
     for (int i = 0; i < iters; ++i) {
         for (int k = 0; k < 4; ++k) acc[k] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, acc[k], 0, 0, 0);
-        const float4 v0 = lbuf[(threadIdx.x + 17 * i) & 2047], v1 = lbuf[(threadIdx.x * 3 + i) & 2047];
-        lacc.x += v0.x * v1.y; lacc.y += v0.z; lacc.z += v1.w;
+        const float4 v0 = lbuf[(threadIdx.x + 17 * i) & 2047];
+        lacc.x += v0.x; lacc.y += v0.z;
         if ((i & 63) == 0) { lbuf[(threadIdx.x + i) & 2047] = lacc; __syncthreads(); }
     }
-    if (acc[0][0] + acc[1][1] + acc[2][2] + acc[3][3] + lacc.x + lacc.y + lacc.z == 12345.f) *sink = 1.f;
+    if (acc[0][0] + acc[1][1] + acc[2][2] + acc[3][3] + lacc.x + lacc.y == 12345.f) *sink = 1.f;
 }
 __global__ __launch_bounds__(256) void valu_load_kernel(float* sink, int iters) {
     float x = threadIdx.x, y = 1.0001f;
     for (int i = 0; i < iters * 16; ++i) x = fmaf(x, y, 0.5f);
     if (x == 12345.f) *sink = x;
 }
-static unsigned phase(const char* name, int rounds, int neighbour, int use_lds, unsigned* rec, float* sink, hipStream_t sa, hipStream_t sb) {
+template <int FIX>
+static unsigned phase(const char* name, int rounds, int neighbour, unsigned* rec, float* sink, hipStream_t sa, hipStream_t sb) {
     (void)hipMemsetAsync(rec, 0, 128 * 4, sa); (void)hipStreamSynchronize(sa);
     for (int r = 0; r < rounds; ++r) {
-        if (neighbour == 1) mfma_load_kernel<<<512, 256, 0, sb>>>(sink, 40000);      // ~ms of matrix-pipe work on 512 x 4 waves
+        if (neighbour == 1) mfma_load_kernel<<<512, 256, 0, sb>>>(sink, 40000);       // ~ms of matrix-pipe work, two workgroups per CU
         if (neighbour == 2) valu_load_kernel<<<512, 256, 0, sb>>>(sink, 40000);
-        for (int k = 0; k < 16; ++k) {
-            if (use_lds == 6) pk_swz_kernel<0><<<1028, 64, 0, sa>>>(rec, 600, 17u * r + k, 55);
-            else if (use_lds == 7) pk_swz_kernel<0><<<1028, 64, 0, sa>>>(rec, 600, 17u * r + k, 64);
-            else if (use_lds == 8) pk_swz_kernel<1><<<1028, 64, 0, sa>>>(rec, 600, 17u * r + k, 55);
-            else if (use_lds == 9) pk_swz_kernel<2><<<1028, 64, 0, sa>>>(rec, 600, 17u * r + k, 55);
-            else if (use_lds == 10) pk_swz_kernel<3><<<1028, 64, 0, sa>>>(rec, 600, 17u * r + k, 55);
-            else if (use_lds == 11) pk_swz_kernel<4><<<1028, 64, 0, sa>>>(rec, 600, 17u * r + k, 55);
-            else if (use_lds == 12) pk_swz_kernel<5><<<1028, 64, 0, sa>>>(rec, 600, 17u * r + k, 55);
-            else if (use_lds == 3) pk_tree_kernel<<<1028, 256, 0, sa>>>(rec, 40, 17u * r + k, 12);
-            else if (use_lds == 2) pk_war_kernel<<<1028, 64, 0, sa>>>(rec, 600, 17u * r + k);
-            else pk_chain_kernel<<<1028, 64, 0, sa>>>(rec, 600, 17u * r + k, use_lds == 4 ? 5 : use_lds == 5 ? 9 : use_lds);
-        }
+        for (int k = 0; k < 16; ++k) pk_swz_kernel<FIX><<<1028, 64, 0, sa>>>(rec, 600, 17u * r + k);
         (void)hipStreamSynchronize(sa); (void)hipStreamSynchronize(sb);
     }
     unsigned h[128]; (void)hipMemcpy(h, rec, sizeof(h), hipMemcpyDeviceToHost);
-    printf("%-44s launches %5d  packed results checked %.2e  mismatches %u\n", name, rounds * 16, (double)rounds * 16 * 1028 * 64 * 600, h[0]);
-    for (unsigned k = 0; k < (h[0] < 15 ? h[0] : 15); ++k) {
-        const unsigned* r = h + 8 * (k + 1);
-        const char* what[] = {"v_pk_fma_f32", "v_pk_mul_f32", "v_pk_add_f32", "v_pk_fma_f32 (reloaded pair = src2)", "v_pk_fma_f32 (reloaded pair = src1)", "v_pk_fma_f32 (reloaded pair = src0, op_sel)", "D: joint transform handed through LDS, pass 0 vs pass 1 (lane = joint, element = r[3])",
-                              "H: op_sel-swizzled packed sequence (element: 0-1 A, 2-3 B, 4-5 R = A^2, 6-7 K)"};
-        printf("    lane %2u step %3u %s element %u packed %08x scalar %08x block %u why %u\n", r[0], r[1], what[r[2] < 8 ? r[2] : 0], r[3], r[4], r[5], r[6], r[7]);
+    printf("%-62s results checked %.2e  mismatches %u (lanes 48-63: %u, K.lo: %u, = addend dropped: %u)\n", name, (double)rounds * 16 * 1028 * 64 * 600 * 8,
+           h[0], h[1], h[2], h[3]);
+    for (unsigned k = 0; k < (h[0] < 4 ? h[0] : 4); ++k) {
+        const unsigned* q = h + 8 * (k + 1);
+        printf("    lane %2u step %3u element %u got %08x want %08x block %u\n", q[0], q[1], q[2], q[3], q[4], q[5]);
     }
     return h[0];
 }
-#ifndef PK_VICTIM_LIB
 int main(int argc, char** argv) {
-    const int rounds = argc > 1 ? atoi(argv[1]) : 40;
+    const int rounds = argc > 1 ? atoi(argv[1]) : 20;
     unsigned* rec; float* sink; hipStream_t sa, sb;
     (void)hipMalloc(&rec, 128 * 4); (void)hipMalloc(&sink, 4); (void)hipStreamCreate(&sa); (void)hipStreamCreate(&sb);
-    unsigned bad = 0;
-    const char* names[13][3] = {{"alone", "next to MFMA kernel", "next to VALU-only kernel"},
-                               {"alone, LDS hand-overs", "next to MFMA kernel, LDS hand-overs", "next to VALU-only kernel, LDS hand-overs"},
-                               {"C: sources reloaded behind the packed ops, alone", "C: sources reloaded ..., next to MFMA kernel", "C: sources reloaded ..., next to VALU-only kernel"},
-                               {"D: kinematic chain through LDS, alone", "D: kinematic chain ..., next to MFMA + LDS kernel", "D: kinematic chain ..., next to VALU-only kernel"},
-                               {"E: A with lanes 55-63 masked off, alone", "E: ... next to MFMA + LDS kernel", "E: ... next to VALU-only kernel"},
-                               {"F: A on lanes 25, 28, ..., 52 only, alone", "F: ... next to MFMA + LDS kernel", "F: ... next to VALU-only kernel"},
-                               {"H: op_sel-swizzled packed sequence, alone", "H: ... next to MFMA + LDS kernel", "H: ... next to VALU-only kernel"},
-                               {"H, all 64 lanes, alone", "H, all 64 lanes, next to MFMA + LDS kernel", "H, all 64 lanes, next to VALU-only kernel"},
-                               {"H + s_nop 7 before the swizzled v_pk_fma, alone", "H + s_nop 7 before v_pk_fma, next to MFMA + LDS", "... next to VALU-only"},
-                               {"H + s_nop 7 before the swizzled v_pk_add, alone", "H + s_nop 7 before v_pk_add, next to MFMA + LDS", "... next to VALU-only"},
-                               {"H without the scalar fillers, alone", "H without fillers, next to MFMA + LDS", "... next to VALU-only"},
-                               {"H, v_pk_add -> two v_add_f32, alone", "H, v_pk_add -> scalar, next to MFMA + LDS", "... next to VALU-only"},
-                               {"H, v_pk_fma -> two v_fma_f32, alone", "H, v_pk_fma -> scalar, next to MFMA + LDS", "... next to VALU-only"}};
-#ifdef PK_TREE_NOPK
-    const int first = 3;          // variant D compiled WITHOUT packed fp32 (per-function target attribute): the control
-#else
-    const int first = 0;
-#endif
-    for (int lds = first; lds < 13; ++lds)
-        for (int nb = 0; nb < 3; ++nb) bad += phase(names[lds][nb], rounds, nb, lds, rec, sink, sa, sb);
-    printf("total mismatches %u\n", bad);
+    phase<0>("swizzled v_pk_fma_f32, alone", rounds, 0, rec, sink, sa, sb);
+    phase<0>("swizzled v_pk_fma_f32, next to the MFMA kernel", rounds, 1, rec, sink, sa, sb);
+    phase<0>("swizzled v_pk_fma_f32, next to the VALU-only kernel", rounds, 2, rec, sink, sa, sb);
+    phase<1>("two v_fma_f32 in its place, next to the MFMA kernel", rounds, 1, rec, sink, sa, sb);
     return 0;
 }
-#endif

@@ -27,3 +27,5 @@ for db in sq sq2 mix; do
 done
 python tools/pmc_kernel.py /tmp/prof_r4_sq/m_results.db nn_mfma_kernel 0 > $P/r4_pmc_sq_nn_bruteforce.txt
 head -16 $P/r4_kernel_trace_stats_bench_500it.txt; cat $P/r4_pmc_sq2_nn_in_loop_steady.txt; ls $P
+hipcc --offload-arch=gfx950 -O3 -o /tmp/pk_repro tools/pk_f32_mfma_repro.hip 2>/dev/null && timeout 600 /tmp/pk_repro 20 > $P/r4_pk_f32_repro.txt 2>&1
+cat $P/r4_pk_f32_repro.txt
