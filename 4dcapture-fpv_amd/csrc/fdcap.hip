@@ -26,33 +26,6 @@ __device__ unsigned long long g_fr_times[3][2048 * 8];
 #ifndef FDC_FR_STAMP
 #define FDC_FR_STAMP(w, i)
 #endif
-#if defined(FDC_POISON) && !defined(FDC_POISON_BYTE)
-#define FDC_POISON_BYTE 0xFF
-#endif
-#ifdef FDC_POISON
-// instrumentation build only (tools/poison_check.py): every launch is preceded by a launch that leaves NaN patterns in the CUs'
-// LDS and in the vector registers, so a kernel that reads LDS or registers it never wrote changes the results -- a single-process
-// run has the same leftovers every time and hides such reads; two processes sharing a GPU do not
-__global__ __launch_bounds__(256) void fdc_poison_kernel(unsigned* sink) {
-    extern __shared__ unsigned fdc_poison_lds[];
-    for (int i = threadIdx.x; i < 8192; i += 256) fdc_poison_lds[i] = 0x7fc12345u;
-    float v[96];
-#pragma unroll
-    for (int i = 0; i < 96; ++i) { v[i] = __uint_as_float(0x7fc12345u + i); asm volatile("" : "+v"(v[i])); }
-    unsigned acc = 0;
-#pragma unroll
-    for (int i = 0; i < 96; ++i) acc ^= __float_as_uint(v[i]);
-    __syncthreads();
-    if (acc == 1u && fdc_poison_lds[threadIdx.x] == 2u) *sink = acc;      // (never true: keeps the stores and the registers alive)
-}
-static unsigned* fdc_poison_sink() { static unsigned* p = nullptr; if (!p) (void)hipMalloc(&p, 4); return p; }
-#undef hipLaunchKernelGGL
-#define hipLaunchKernelGGL(k, g, b, lds, st, ...)                                                   \
-    do {                                                                                            \
-        fdc_poison_kernel<<<dim3(1280), dim3(256), 32768, (st)>>>(fdc_poison_sink());               \
-        k<<<(g), (b), (lds), (st)>>>(__VA_ARGS__);                                                  \
-    } while (0)
-#endif
 #include "../../include/fdcap.h"
 #include "fdc_chamfer.h"
 #include "fdc_comm.h"
@@ -110,23 +83,6 @@ struct alignas(16) PoseStage {
 typedef __attribute__((address_space(1))) const void* fdc_gptr_t;
 typedef __attribute__((address_space(3))) void* fdc_lptr_t;
 // one wave copies n units of 16 / 4 bytes: unit i = 64 k + lane.  g and lds 16- / 4-byte aligned; K = ceil(n / 64) trips.
-#ifdef FDC_NO_LDS_DMA
-// experiment build only: the same copies through registers (is the LDS-DMA path involved in the two-process glitch?)
-template <int K>
-__device__ __forceinline__ void glds16(const void* g, void* lds, int n) {
-    const int lane = threadIdx.x & 63;
-#pragma unroll
-    for (int k = 0; k < K; ++k)
-        if (lane + 64 * k < n) ((float4*)lds)[lane + 64 * k] = ((const float4*)g)[lane + 64 * k];
-}
-template <int K>
-__device__ __forceinline__ void glds4(const void* g, void* lds, int n) {
-    const int lane = threadIdx.x & 63;
-#pragma unroll
-    for (int k = 0; k < K; ++k)
-        if (lane + 64 * k < n) ((float*)lds)[lane + 64 * k] = ((const float*)g)[lane + 64 * k];
-}
-#else
 template <int K>
 __device__ __forceinline__ void glds16(const void* g, void* lds, int n) {
     const int lane = threadIdx.x & 63;
@@ -143,7 +99,6 @@ __device__ __forceinline__ void glds4(const void* g, void* lds, int n) {
         if (lane + 64 * k < n)
             __builtin_amdgcn_global_load_lds((fdc_gptr_t)((const char*)g + 4 * (lane + 64 * k)), (fdc_lptr_t)((char*)lds + 256 * k), 4, 0, 0);
 }
-#endif
 // the same for a workgroup of NW waves: unit i = 64 NW k + threadIdx.x (each wave's destination is wave-uniform)
 template <int K, int NW, int SZ>
 __device__ __forceinline__ void glds_wg(const void* g, void* lds, int n) {
@@ -152,16 +107,10 @@ __device__ __forceinline__ void glds_wg(const void* g, void* lds, int n) {
 #pragma unroll
     for (int k = 0; k < K; ++k)
         if (tid + 64 * NW * k < n) {
-#ifdef FDC_NO_LDS_DMA
-            (void)wave;
-            if constexpr (SZ == 16) ((float4*)lds)[tid + 64 * NW * k] = ((const float4*)g)[tid + 64 * NW * k];
-            else ((float*)lds)[tid + 64 * NW * k] = ((const float*)g)[tid + 64 * NW * k];
-#else
             const fdc_gptr_t src = (fdc_gptr_t)((const char*)g + SZ * (tid + 64 * NW * k));
             const fdc_lptr_t dst = (fdc_lptr_t)((char*)lds + SZ * 64 * (NW * k + wave));
             if constexpr (SZ == 16) __builtin_amdgcn_global_load_lds(src, dst, 16, 0, 0);
             else __builtin_amdgcn_global_load_lds(src, dst, 4, 0, 0);
-#endif
         }
 }
 #ifdef FDC_DEBUG_BUFFERS
@@ -1413,9 +1362,6 @@ struct DevBuf {
         p = nullptr; n = 0;
         hipError_t e = hipMalloc((void**)&p, std::max<size_t>(count, 1) * sizeof(T));
         if (e == hipSuccess) n = count;
-#ifdef FDC_POISON
-        if (e == hipSuccess) e = hipMemset(p, FDC_POISON_BYTE, std::max<size_t>(count, 1) * sizeof(T));   // fresh buffers: NaN floats / -1 ints (0xFF), or another pattern
-#endif
         return e;
     }
     hipError_t upload(const T* h, size_t count) {
@@ -1838,39 +1784,13 @@ const char* fdcap_build_info(void) {
 }
 
 #ifdef FDC_DEBUG_BUFFERS
-}  // extern "C"
-// instrumentation build only: a workgroup fills its LDS with a pattern, idles, and checks it -- does anything running next to it
-// on the CU write into LDS that is not its own?  report: [0] corrupted words, then {index, value found, block, lds bytes} x 15
-template <int WORDS>
-__global__ __launch_bounds__(64) void lds_canary_kernel(unsigned* __restrict__ report, int spins) {
-    __shared__ unsigned buf[WORDS];
-    for (int i = threadIdx.x; i < WORDS; i += 64) buf[i] = 0xC0DE0000u ^ (unsigned)i;
-    __syncthreads();
-    for (int s = 0; s < spins; ++s) __builtin_amdgcn_s_sleep(127);
-    __syncthreads();
-    for (int i = threadIdx.x; i < WORDS; i += 64) {
-        const unsigned v = buf[i];
-        if (v != (0xC0DE0000u ^ (unsigned)i)) {
-            const unsigned k = atomicAdd(&report[0], 1u);
-            if (k < 15) { unsigned* r = report + 4 * (k + 1); r[0] = i; r[1] = v; r[2] = blockIdx.x; r[3] = WORDS * 4; }
-        }
-    }
-}
-extern "C" {
-int fdcap_debug_lds_canary(unsigned* report_d, int blocks, int spins, int launches, void* stream) {
-    for (int l = 0; l < launches; ++l) {
-        hipLaunchKernelGGL((lds_canary_kernel<7168>), dim3(blocks), dim3(64), 0, (hipStream_t)stream, report_d, spins);
-        hipLaunchKernelGGL((lds_canary_kernel<2048>), dim3(blocks), dim3(64), 0, (hipStream_t)stream, report_d, spins);
-    }
-    return (int)hipGetLastError();
-}
 int fdcap_debug_stage_bad(unsigned* out) {
     HIP_TRY(hipDeviceSynchronize());
     HIP_TRY(hipMemcpyFromSymbol(out, HIP_SYMBOL(g_stage_bad), sizeof(unsigned) * 8 * 16));
     return 0;
 }
-// instrumentation build only (tools/flake_trace.py): row r0.. of an internal per-frame buffer, `per_row` floats per row
-// which: 0 O [126], 1 PF [NPFX], 2 A [55*12], 3 M [12], 4 Voff [3 nc], 5 Vw [3 nc], 6 G [55*12], 7 Opart q=0 [126], 8 H2 [512], 9 Jw [69]
+// instrumentation build only (tools/pk_where.py): row r0.. of an internal per-frame buffer, `per_row` floats per row
+// which: 0 O [126], 1 PF [NPFX], 2 A [55*12], 3 M [12], 4 Voff [3 nc], 5 Vw [3 nc], 6 G [55*12], 7 Opart q=0 [126], 8 H2 [512], 9 Jw [69], 10 Rm [55*9], 11 Jrest [55*3]
 int fdcap_debug_rows(fdcap_ctx* c, int which, float* dst, void* stream) {
     if (!c || !c->opt) return FDCAP_E_STATE;
     OptState* o = c->opt;

@@ -25,20 +25,39 @@ body = torch.tensor(clip.body_params).cuda()
 fop.fitting(body, "global"); torch.cuda.synchronize()
 from fdcap_amd.dist import allgather_packed
 lib, h = fop.ctx.lib, fop.ctx.handle
-for overlap in ((False, True, False, True) if group is not None else (False,)):
+def run(label, body_fn):
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for ii in range(400):
-        st = capi.current_stream()
-        capi.check(lib.fdcap_opt_backward(h, ii, 10 ** 6, 0, st), "b")
-        if group is not None:
-            capi.check(lib.fdcap_opt_step_rows_and_pack(h, ii, 10 ** 6, capi.dptr(fop._xch_send), st), "p")
-            ahead = (lambda ii=ii, st=st: capi.check(lib.fdcap_opt_forward_ahead(h, ii + 1, 10 ** 6, 0, st), "a")) if overlap else None
-            allgather_packed(fop.shard, fop._xch_send, fop._xch_all, ahead)
-            capi.check(lib.fdcap_opt_unpack_and_step_scale(h, ii, 10 ** 6, capi.dptr(fop._xch_all), 0, 1, st), "u")
-        else:
-            capi.check(lib.fdcap_opt_step(h, ii, 10 ** 6, st), "s")
+        body_fn(ii, capi.current_stream())
     t1 = time.perf_counter(); torch.cuda.synchronize(); t2 = time.perf_counter()
-    print(f"frames {N} exchange {group is not None} forward-ahead {overlap}: host issued 400 phase-1 iterations in {1e3*(t1-t0):.1f} ms ({(t1-t0)*1e6/400:.1f} us/iter), GPU done after {1e3*(t2-t0):.1f} ms ({(t2-t0)*1e6/400:.1f} us/iter)")
-if group is not None:
+    capi.check(lib.fdcap_opt_sync(h, capi.current_stream()), "sync")
+    print(f"frames {N} {label}: host issued 400 phase-1 iterations in {1e3*(t1-t0):.1f} ms ({(t1-t0)*1e6/400:.1f} us/iter), GPU done after {1e3*(t2-t0):.1f} ms ({(t2-t0)*1e6/400:.1f} us/iter)", flush=True)
+
+
+BIG = 10 ** 6
+if group is None:
+    def two_calls(ii, st):
+        capi.check(lib.fdcap_opt_backward(h, ii, BIG, 0, st), "b")
+        capi.check(lib.fdcap_opt_step(h, ii, BIG, st), "s")
+    run("one GPU, fdcap_opt_backward + fdcap_opt_step (r3: 10 launches, 2 calls)", two_calls)
+    run("one GPU, fdcap_opt_backward_and_step (r4: 9 launches, 1 call)", lambda ii, st: capi.check(lib.fdcap_opt_backward_and_step(h, ii, BIG, 0, st), "bs"))
+else:
+    def torch_tail(overlap):
+        def f(ii, st):
+            capi.check(lib.fdcap_opt_backward(h, ii, BIG, 0, st), "b")
+            capi.check(lib.fdcap_opt_step_rows_and_pack(h, ii, BIG, capi.dptr(fop._xch_send), st), "p")
+            ahead = (lambda ii=ii, st=st: capi.check(lib.fdcap_opt_forward_ahead(h, ii + 1, BIG, 0, st), "a")) if overlap else None
+            allgather_packed(fop.shard, fop._xch_send, fop._xch_all, ahead)
+            capi.check(lib.fdcap_opt_unpack_and_step_scale(h, ii, BIG, capi.dptr(fop._xch_all), 0, 1, st), "u")
+        return f
+
+    def c_tail(ii, st):
+        capi.check(lib.fdcap_opt_backward(h, ii, BIG, 0, st), "b")
+        capi.check(lib.fdcap_opt_exchange(h, ii, BIG, st), "x")
+    run("one-rank RCCL group, torch.distributed all-gather between pack and unpack (r3)", torch_tail(False))
+    run("one-rank RCCL group, the same + forward ahead of the exchange (asynchronous collective, r3)", torch_tail(True))
+    if fop._c_comm:
+        run("one-rank RCCL group, fdcap_opt_exchange: ncclAllGather on the compute stream from C (r4)", c_tail)
+        run("one-rank RCCL group, fdcap_opt_exchange again", c_tail)
     dist.destroy_process_group()

@@ -6,7 +6,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 lib = os.path.join(ROOT, "gpurun_out", "libfdcap_hip_stats.so")
 subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-mllvm",
-                       "-amdgpu-mfma-vgpr-form", "-fno-honor-nans", "-Xclang", "-target-feature", "-Xclang", "-packed-fp32-ops", "-DFDC_BUILD_NO_PK_F32", "-DFDC_NN_STATS", *(["-DFDC_NN_EXP=" + os.environ["FDC_NN_EXP"]] if os.environ.get("FDC_NN_EXP") else []), "-o", lib,
+                       "-amdgpu-mfma-vgpr-form", "-fno-honor-nans", "-Xclang", "-target-feature", "-Xclang", "-packed-fp32-ops", "-DFDC_BUILD_NO_PK_F32", "-DFDC_NN_STATS", "-o", lib,
                        os.path.join(ROOT, "4dcapture-fpv_amd", "csrc", "fdcap.hip")])
 os.environ["FDCAP_LIB"] = lib
 import numpy as np, torch
@@ -19,15 +19,6 @@ bm = synth.make_body_model(10475, seed=0); vp = synth.make_vposer(seed=1); clip 
 scene = synth.make_scene(ns, seed=2); l, r = synth.make_contact_ids(bm.v_template, per_part=250, seed=4)
 fop = FittingOP({"num_iter": int(os.environ.get("NN_ITERS", "2"))}, {}, N, body_model=bm, vposer=vp, scene_verts=scene, contact_ids=np.concatenate([l, r]),
                 camera_ext=read_camerapose(clip.camerapose_lines))
-if os.environ.get("FDC_NN_EXP") and os.environ["FDC_NN_EXP"] != "6":
-    import time
-    from fdcap_amd import ops
-    q = (torch.rand(N, 500, 3, device="cuda") * torch.tensor([2.0, 2.0, 1.5], device="cuda"))
-    sc = torch.tensor(scene).cuda().unsqueeze(0).expand(N, -1, -1)
-    cd = ops.chamferDist(fop.ctx, both=False)
-    cd(q, sc); torch.cuda.synchronize(); t0 = time.perf_counter()
-    for _ in range(3): cd(q, sc)
-    torch.cuda.synchronize(); print("EXP", os.environ["FDC_NN_EXP"], "ms/launch", (time.perf_counter() - t0) / 3 * 1e3); sys.exit(0)
 fop.fitting(torch.tensor(clip.body_params).cuda(), "global")
 L = capi.load_library()
 out = (ctypes.c_ulonglong * 4)()

@@ -40,8 +40,6 @@ __global__ __launch_bounds__(256) void probe(unsigned long long* t, float* sink,
         if (OP == 10) { TWO("v_and_b32") }
         if (OP == 11) { THREE("v_med3_f32") }
         if (OP == 12) { TWO("v_add_u32") }
-        if (OP == 13) { R4(asm volatile("v_cndmask_b32 %0, %0, %8, vcc\n v_cndmask_b32 %1, %1, %8, vcc\n v_cndmask_b32 %2, %2, %8, vcc\n v_cndmask_b32 %3, %3, %8, vcc\n v_cndmask_b32 %4, %4, %8, vcc\n v_cndmask_b32 %5, %5, %8, vcc\n v_cndmask_b32 %6, %6, %8, vcc\n v_cndmask_b32 %7, %7, %8, vcc"
-                        : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]), "+v"(a[4]), "+v"(a[5]), "+v"(a[6]), "+v"(a[7]) : "v"(b), "v"(c) : "vcc");) }
         if (OP == 14) { TWO("v_min_u32") }
         if (OP == 15) { THREE("v_min3_u32") }
         if (OP == 16) { TWO("v_min_i32") }
@@ -98,7 +96,7 @@ template <int OP> void run(const char* name) {
 int main() {
     printf("shader cycles per wave64 instruction per physical SIMD (median over SIMDs holding >= W waves); launch = 256 x W workgroups of 4 waves\n");
     run<0>("v_fma_f32"); run<1>("v_min3_f32"); run<2>("v_cmp_lt_f32"); run<3>("v_alignbit_b32"); run<4>("v_pk_fma_f32"); run<5>("v_lshrrev_b64");
-    run<6>("v_add_f32"); run<7>("v_mul_f32"); run<8>("v_sub_f32"); run<9>("v_min_f32"); run<10>("v_and_b32"); run<11>("v_med3_f32"); run<12>("v_add_u32"); run<13>("v_cndmask_b32");
+    run<6>("v_add_f32"); run<7>("v_mul_f32"); run<8>("v_sub_f32"); run<9>("v_min_f32"); run<10>("v_and_b32"); run<11>("v_med3_f32"); run<12>("v_add_u32");
     run<14>("v_min_u32"); run<15>("v_min3_u32"); run<16>("v_min_i32"); run<17>("v_max_f32"); run<18>("v_lshlrev_b32"); run<19>("v_xor_b32");
     run<20>("v_bfe_u32"); run<21>("v_perm_b32"); run<22>("v_mad_u32_u24"); run<23>("v_min3_i32"); run<24>("v_and_or_b32");
     return 0;
