@@ -169,7 +169,7 @@ def test_reference_shaped_loop_lands_on_the_reference_run(golden_dir):
     q50, q90, q99 = np.quantile(err, [0.5, 0.9, 0.99])
     print("reference-shaped loop vs the reference run: max", err.max(), "q50/q90/q99", q50, q90, q99)
     # the bars of test_trajectory_matches_reference_golden (Adam + L1 kinks: tests/test_host_math.py)
-    assert err.max() <= 2 * 0.005 * num_iter
+    assert err.max() <= 6 * 0.005          # (three sign flips of one entry at most; 2 lr num_iter would hold for any Adam run)
     assert q50 < 1e-6 and q90 < 1e-4 and q99 < 3e-3, (q50, q90, q99)
     assert err[:, 48:72].max() <= 2e-6                                    # kink-free columns (hands)
     assert (err <= 2e-5).mean() > 0.995                                   # (measured 0.9977: a few L1 sign flips, +-lr each)

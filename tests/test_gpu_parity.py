@@ -325,7 +325,7 @@ def test_trajectory_matches_reference_golden(golden_dir, name):
     np.testing.assert_array_equal(fop.idx1, g["idx1"])
     err = np.abs(body.cpu().numpy() - g["body_rec"])
     q50, q90, q99 = np.quantile(err, [0.5, 0.9, 0.99])
-    assert err.max() <= 2 * 0.005 * num_iter
+    assert err.max() <= 6 * 0.005          # (three sign flips of one entry; measured <= 1.1e-2.  The r3 bound 2 lr num_iter held for ANY Adam run)
     assert q50 < 1e-6 and q90 < 1e-4 and q99 < 3e-3, (q50, q90, q99)
     assert err[:, 48:72].max() <= 2e-6
     np.testing.assert_allclose(float(scale), float(g["scale"]), atol=1e-4)
