@@ -134,6 +134,74 @@ def test_forward_ahead_of_the_exchange_gives_the_same_bits(world, mode, n, iters
     retry_on_shared_gpu_glitch(check)        # (two processes on one GPU: tests/shared_gpu.py)
 
 
+def _ckpt_worker(rank, world, port, q, path, stage):
+    """stage 0: an uninterrupted 12-iteration fit that also checkpoints after iteration 7; stage 1: a fresh optimiser resumed from
+    the files; stage 2: rank 1's file swapped for one of ANOTHER iteration -- the resume must refuse."""
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from fdcap_amd import capi
+        from fdcap_amd.fitting import FittingOP
+        bm, vp, clip, scene, vid = _inputs(N)
+        mk = lambda: FittingOP({"num_iter": 12}, {}, N, body_model=bm, vposer=vp, scene_verts=scene, contact_ids=vid,
+                               camera_ext=read_camerapose(clip.camerapose_lines), group=dist.group.WORLD)
+        body = torch.tensor(clip.body_params).cuda()
+        fop = mk()
+        if stage == 0:
+            b, s, c = fop.fitting(body, "global", checkpoint_every=7, checkpoint_path=path)
+            q.put((rank, b.cpu().numpy(), float(s), c.cpu().numpy()))
+        elif stage == 1:
+            b, s, c = fop.fitting(body, "global", resume=path)
+            q.put((rank, b.cpu().numpy(), float(s), c.cpu().numpy()))
+        else:
+            try:
+                fop.fitting(body, "global", resume=path)
+                q.put((rank, "no error"))
+            except capi.FdcapError as e:
+                q.put((rank, str(e)))
+        fop.close()
+    finally:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def test_sharded_checkpoint_set_resumes_bit_identically_and_a_mixed_set_is_refused(tmp_path):
+    """sharded checkpoints are one file per rank.  A resumed two-rank fit ends on the uninterrupted run's bits; a set
+    whose files come from different iterations (a run that died between two ranks' writes) is refused on resume by every rank --
+    before, the ranks would have started at different iterations and issued different numbers of all-gathers."""
+    ctx = mp.get_context("spawn")
+    path = str(tmp_path / "shard.ckpt.npz")
+
+    def run(stage):
+        q = ctx.Queue()
+        port = _free_port()
+        procs = [ctx.Process(target=_ckpt_worker, args=(r, 2, port, q, path, stage)) for r in range(2)]
+        for p in procs:
+            p.start()
+        res = sorted(q.get(timeout=600) for _ in range(2))
+        for p in procs:
+            p.join(timeout=120)
+            assert p.exitcode == 0
+        return res
+
+    full = run(0)
+    assert os.path.exists(path + ".rank0") and os.path.exists(path + ".rank1")
+    resumed = run(1)
+    for a, b in zip(full, resumed):
+        np.testing.assert_array_equal(a[1], b[1])
+        assert a[2] == b[2]
+        np.testing.assert_array_equal(a[3], b[3])
+    with np.load(path + ".rank1") as ck:                                  # rank 1's file "from an older iteration"
+        d = {k: ck[k] for k in ck.files}
+    d["next_iter"] = np.int64(5)
+    np.savez(path + ".rank1.npz", **d)
+    os.replace(path + ".rank1.npz", path + ".rank1")
+    refused = run(2)
+    assert all("different iterations" in r[1] for r in refused), refused
+
+
 def test_verbose_on_rank_zero_only_keeps_the_ranks_collectives_in_step():
     """a verbose fit reads its loss history back (an all-reduce when sharded) every 50 logged iterations.  With
     `verbose` set on rank 0 only -- which the rank-0-only prints invite -- rank 0 used to issue that all-reduce while rank 1
