@@ -59,7 +59,12 @@ struct DeferredStep {
     const float* dzpart = nullptr;           // four partial latent gradients (vposer_bwd_*), dz_stride apart; null: dX is complete
     size_t dz_stride = 0;
 };
+// per-frame partial sums of the printed loss terms (logging iterations): [row][LROW] floats in the slots of losses_d
+constexpr int LROW = 8;
+// a logging backward's reduction riding in a later launch (the step launch that follows it, or the backward's own extra workgroup)
+struct LogReduceIn { const float* rows; double* losses; unsigned mask; int assign, n; };
 struct ScaleTail {
+    LogReduceIn lg = {nullptr, nullptr, 0u, 0, 0};   // rows != nullptr: this workgroup also sums the logged loss terms (fixed order, double)
     int block = -1;                          // index of the extra workgroup (-1: none)
     AdamTensor sc = {};
     const float* dscale_row = nullptr;       // [rows] per-frame partials of d loss / d scale
@@ -108,8 +113,47 @@ __device__ __forceinline__ float scale_grad_block(const float* __restrict__ dsca
     __syncthreads();
     return (sred[0] + sred[1]) + (sred[2] + sred[3]);
 }
+// the printed loss terms of a logging iteration: per-frame partials -> losses[], one fixed-order tree in double (no atomics)
+__device__ __forceinline__ void loss_rows_reduce_block(const float* __restrict__ rows, int row0, int n, unsigned mask, int assign,
+                                                       double* __restrict__ losses, const float* __restrict__ dscale_row,
+                                                       float* __restrict__ dscale_out) {
+    __shared__ double sd[LROW][256];
+    __shared__ float sred[4];
+    const int tid = threadIdx.x;                             // (workgroups of 256 threads or more: the first 256 work)
+    double a[LROW];
+#pragma unroll
+    for (int s = 0; s < LROW; ++s) a[s] = 0.0;
+    float ds = 0.f;
+    for (int i = tid; i < n && tid < 256; i += 256) {
+        const float4 lo = *(const float4*)(rows + (size_t)(row0 + i) * LROW), hi = *(const float4*)(rows + (size_t)(row0 + i) * LROW + 4);
+        a[0] += (double)lo.x; a[1] += (double)lo.y; a[2] += (double)lo.z; a[3] += (double)lo.w;
+        a[4] += (double)hi.x; a[5] += (double)hi.y; a[6] += (double)hi.z; a[7] += (double)hi.w;
+        ds += dscale_row[row0 + i];
+    }
+    if (tid < 256) {
+#pragma unroll
+        for (int s = 0; s < LROW; ++s) sd[s][tid] = a[s];
+    }
+    ds = wave_sum64(ds);
+    if (tid < 256 && (tid & 63) == 0) sred[tid >> 6] = ds;
+    __syncthreads();
+    for (int w = 128; w > 0; w >>= 1) {                      // one tree for all slots
+        if (tid < w) {
+#pragma unroll
+            for (int s = 0; s < LROW; ++s) sd[s][tid] += sd[s][tid + w];
+        }
+        __syncthreads();
+    }
+    if (tid < LROW) {
+        if ((mask >> tid) & 1u) losses[tid] = assign ? sd[tid][0] : losses[tid] + sd[tid][0];
+        else if (assign) losses[tid] = 0.0;
+    }
+    if (tid == 0 && dscale_out) *dscale_out = (sred[0] + sred[1]) + (sred[2] + sred[3]);
+}
 __device__ __forceinline__ void scale_tail_block(const ScaleTail& t) {
     __shared__ float s_tail[4];
+    if (t.lg.rows) loss_rows_reduce_block(t.lg.rows, t.row0, t.lg.n, t.lg.mask, t.lg.assign, t.lg.losses, t.dscale_row, nullptr);
+    if (t.n <= 0) return;                                    // (only the logged sums this time: `scale` has no step)
     const float g = scale_grad_block(t.dscale_row, t.row0, t.n, s_tail);
     if (threadIdx.x == 0) {
         if (t.dscale) *t.dscale = g;

@@ -282,7 +282,6 @@ __global__ __launch_bounds__(64 * POSE_NW) void pose_fwd_kernel(PoseModel pm, co
 // losses_d (0 rec, 1 z^2, 2 smoothing, 3 contact -- written by the skinning backward --, 4 world smoothing); summed over the
 // rows in a fixed order by loss_rows_reduce_kernel.  (Atomics on the eight doubles serialise: 1024 frames x 4 adds made the
 // separate param_loss_kernel 15 us and the skinning backward 8 us slower on logging iterations.)
-constexpr int LROW = 8;
 struct ParamLossIn { const float* X0; const float* mask; const float* Jw; int frame0, n_total; float w_rec, w_sm, w_ws; int world_grad; float* loss_rows; };
 
 __global__ __launch_bounds__(64 * POSE_NW) void pose_bwd_kernel(PoseModel pm, const float* __restrict__ X, const float* __restrict__ O,
@@ -1064,47 +1063,11 @@ __global__ __launch_bounds__(128) void param_loss_kernel(const float* __restrict
 // and stored to (assign != 0: every slot, the others zero) or added to losses[]; then the sum of the per-frame
 // d loss / d scale partials (thread t: rows t, t + 256, ...; butterfly; the order of the step kernels' own reduction).
 // (dscale_out may be null: the launch that also steps `scale` forms that sum itself, in the same order)
-__device__ __forceinline__ void loss_rows_reduce_block(const float* __restrict__ rows, int row0, int n, unsigned mask, int assign,
-                                                       double* __restrict__ losses, const float* __restrict__ dscale_row,
-                                                       float* __restrict__ dscale_out) {
-    __shared__ double sd[LROW][256];
-    __shared__ float sred[4];
-    const int tid = threadIdx.x;
-    double a[LROW];
-#pragma unroll
-    for (int s = 0; s < LROW; ++s) a[s] = 0.0;
-    float ds = 0.f;
-    for (int i = tid; i < n; i += 256) {
-        const float4 lo = *(const float4*)(rows + (size_t)(row0 + i) * LROW), hi = *(const float4*)(rows + (size_t)(row0 + i) * LROW + 4);
-        a[0] += (double)lo.x; a[1] += (double)lo.y; a[2] += (double)lo.z; a[3] += (double)lo.w;
-        a[4] += (double)hi.x; a[5] += (double)hi.y; a[6] += (double)hi.z; a[7] += (double)hi.w;
-        ds += dscale_row[row0 + i];
-    }
-#pragma unroll
-    for (int s = 0; s < LROW; ++s) sd[s][tid] = a[s];
-    ds = wave_sum(ds);
-    if ((tid & 63) == 0) sred[tid >> 6] = ds;
-    __syncthreads();
-    for (int w = 128; w > 0; w >>= 1) {                      // one tree for all slots
-        if (tid < w) {
-#pragma unroll
-            for (int s = 0; s < LROW; ++s) sd[s][tid] += sd[s][tid + w];
-        }
-        __syncthreads();
-    }
-    if (tid < LROW) {
-        if ((mask >> tid) & 1u) losses[tid] = assign ? sd[tid][0] : losses[tid] + sd[tid][0];
-        else if (assign) losses[tid] = 0.0;
-    }
-    if (tid == 0 && dscale_out) *dscale_out = (sred[0] + sred[1]) + (sred[2] + sred[3]);
-}
 __global__ __launch_bounds__(256) void loss_rows_reduce_kernel(const float* __restrict__ rows, int row0, int n, unsigned mask, int assign,
                                                                double* __restrict__ losses, const float* __restrict__ dscale_row,
                                                                float* __restrict__ dscale_out) {
     loss_rows_reduce_block(rows, row0, n, mask, assign, losses, dscale_row, dscale_out);
 }
-// a logging backward's reduction riding in the step launch that follows it (fdcap_opt_backward log_terms = 2)
-struct LogReduceIn { const float* rows; double* losses; unsigned mask; int assign, n; };
 
 __global__ void adam_kernel(float* __restrict__ p, float* __restrict__ m, float* __restrict__ v,
                             const float* __restrict__ g, size_t n, AdamScalars a, int zero_grad) {
@@ -2614,13 +2577,20 @@ static int opt_backward_impl(fdcap_ctx* c, const LossWeights& lw, int32_t log_te
                        joint_grad ? o->dJw.p : nullptr, contact_grad ? o->dMv.p : nullptr, contact_grad ? o->dsv.p : nullptr,
                        contact_grad ? o->dPF.p + NPF : nullptr, NPFX, contact_grad ? o->dtransl_v.p : nullptr, o->dX.p, o->dO.p,
                        o->dCAM.p, o->dscale_row.p, pli, (contact_grad && dpf_split) ? (const float*)(o->dPF.p + (size_t)o->R * NPFX) : (const float*)nullptr);
+    const unsigned log_mask = (rows_log ? 0x17u : 0u) | (contact_fwd ? 0x8u : 0u);     // 0 rec, 1 z^2, 2 smoothing, 4 world | 3 contact
+    bool log_in_tail = false;
     {
         ScaleTail tail;
         if (fuse_ii >= 0) {
             const StepPlan sp = opt_step_plan(o, fuse_ii, fuse_P, false, true);
+            tail.dscale_row = o->dscale_row.p; tail.row0 = 2;
             if (sp.step_scale) {
-                tail.block = 0; tail.sc = sp.sc; tail.dscale_row = o->dscale_row.p; tail.dscale = o->dscale.p; tail.row0 = 2; tail.n = nl;
+                tail.block = 0; tail.sc = sp.sc; tail.dscale = o->dscale.p; tail.n = nl;
                 tail.zero_grad = fuse_ii >= fuse_P ? 1 : 0;
+            }
+            if (log_terms == 2 && rows_log) {           // the printed sums: same extra workgroup (loss_rows is complete before this launch)
+                tail.block = 0; tail.lg = LogReduceIn{o->loss_rows.p, losses, log_mask, 1, nl};
+                log_in_tail = true;
             }
         }
         int eb = opt_vposer_backward(c, false, st, tail);
@@ -2629,12 +2599,11 @@ static int opt_backward_impl(fdcap_ctx* c, const LossWeights& lw, int32_t log_te
     }
     // d loss / d scale of this rank = sum of the per-frame partials: formed by the step kernels (fused with Adam /
     // the exchange packing); on logging iterations also here, so a caller can read dscale_d right after the backward
-    if (log_terms) {
-        const unsigned mask = (rows_log ? 0x17u : 0u) | (contact_fwd ? 0x8u : 0u);     // 0 rec, 1 z^2, 2 smoothing, 4 world | 3 contact
+    if (log_terms && !log_in_tail) {
         if (log_terms == 2 && rows_log) {               // the sums ride in the step launch that follows (one launch less per iteration)
-            o->log_pending = true; o->log_mask = mask; o->log_assign = 1; o->log_dst = losses;
+            o->log_pending = true; o->log_mask = log_mask; o->log_assign = 1; o->log_dst = losses;
         } else
-            hipLaunchKernelGGL(loss_rows_reduce_kernel, dim3(1), dim3(256), 0, st, o->loss_rows.p, 2, nl, mask, rows_log ? 1 : 0, losses,
+            hipLaunchKernelGGL(loss_rows_reduce_kernel, dim3(1), dim3(256), 0, st, o->loss_rows.p, 2, nl, log_mask, rows_log ? 1 : 0, losses,
                                o->dscale_row.p, o->dscale.p);
     }
     return (int)hipGetLastError();
@@ -2693,7 +2662,7 @@ int fdcap_opt_backward_and_step(fdcap_ctx* c, int32_t ii, int32_t P, int32_t log
     if (!c || !c->opt) return FDCAP_E_STATE;
     OptState* o = c->opt;
     const fdcap_opt_config& cf = o->cfg;
-    const bool fuse = cf.frame0 == 0 && cf.n_local == cf.n_total && log_terms != 2 && o->dctW == 0;
+    const bool fuse = cf.frame0 == 0 && cf.n_local == cf.n_total && o->dctW == 0;
     if (!fuse) {
         const int e = fdcap_opt_backward(c, ii, P, log_terms, stream);
         return e ? e : fdcap_opt_step(c, ii, P, stream);

@@ -338,11 +338,12 @@ class FittingOP:
                 if do_log:                               # this iteration's partial sums go straight into their history row
                     capi.check(lib.fdcap_opt_set_loss_output(h, capi.dptr(hist[len(logged)])), "fdcap_opt_set_loss_output")
                     logged.append(ii)
-                if defer and not multi and not do_log and ii + 1 < self.num_iter:
-                    # loss.backward() + optimizer.step() in one call, the step without a launch of its own (fdcap.h): `scale` rides in
-                    # the backward's last launch, the rows are stepped by the next iteration's first two launches; whoever reads
-                    # the registered tensors before that calls fdcap_opt_sync first (snapshots below; export_state does it itself)
-                    capi.check(lib.fdcap_opt_backward_and_step(h, ii, P, 0, st), "fdcap_opt_backward_and_step")
+                if defer and not multi and ii + 1 < self.num_iter:
+                    # loss.backward() + optimizer.step() in one call, the step without a launch of its own (fdcap.h): `scale` (and a
+                    # logging iteration's printed sums) ride in the backward's last launch, the rows are stepped by the next
+                    # iteration's first two launches; whoever reads the registered tensors before that calls fdcap_opt_sync first
+                    # (snapshots below; export_state does it itself)
+                    capi.check(lib.fdcap_opt_backward_and_step(h, ii, P, 2 if do_log else 0, st), "fdcap_opt_backward_and_step")
                     stepped = True
                 else:
                     # (2: the logged sums are delivered by the step launch that follows -- one launch less per logged iteration)

@@ -202,7 +202,8 @@ int fdcap_opt_step(fdcap_ctx* ctx, int32_t ii, int32_t first_phase2_iter, void* 
  * the first two launches of the next backward, where they are read anyway -- same arithmetic, same bits as fdcap_opt_backward
  * followed by fdcap_opt_step.  Until then rows_x_d / rows_cam_d and their Adam moments hold the PRE-step values: every other entry
  * point of this group applies a still-pending update first (an ordinary Adam launch), and a caller that reads the registered
- * buffers itself calls fdcap_opt_sync before it does.  Sharded runs and log_terms == 2 take the two-call path, silently. */
+ * buffers itself calls fdcap_opt_sync before it does.  log_terms == 2 here: the printed sums are reduced by that same extra
+ * workgroup (losses_d complete when this call's work is).  Sharded runs and mode 'dct' take the two-call path, silently. */
 int fdcap_opt_backward_and_step(fdcap_ctx* ctx, int32_t ii, int32_t first_phase2_iter, int32_t log_terms, void* stream);
 int fdcap_opt_sync(fdcap_ctx* ctx, void* stream);
 /* Checkpoint / resume (the reference only ever writes its final result, :637-653).  The parameters live in the

@@ -511,14 +511,16 @@ def test_runs_are_bit_reproducible():
     assert outs[1][3].shape[1] == 12 and np.array_equal(outs[1][3], outs[2][3])
 
 
-@pytest.mark.parametrize("mode,legacy", [("global", False), ("global", True), ("local", False)])
-def test_deferred_optimiser_step_gives_the_same_bits(mode, legacy):
+@pytest.mark.parametrize("mode,legacy,log_every", [("global", False, 0), ("global", True, 0), ("local", False, 0), ("global", False, 1),
+                                                   ("global", True, 3), ("local", False, 1)])
+def test_deferred_optimiser_step_gives_the_same_bits(mode, legacy, log_every):
     """fdcap_opt_step_deferred (r4): optimizer.step() (:592) without a launch of its own -- the next iteration's decoder and
     per-frame pose kernels apply the Adam update where they read the parameters.  Same arithmetic in the same order as the Adam
     kernel: whole fits (30 iterations across the phase switch; torch < 2 zero_grad semantics, where `scale` keeps coasting in
     phase 2; mode 'local' with its second loop behind it) agree bit for bit with FDCAP_DEFER_STEP=0, and a snapshot taken in
     the middle of the deferred run (which forces the pending step out through the ordinary launch) equals the same snapshot of
-    the other run."""
+    the other run.  log_every > 0: the printed sums of a logging iteration are reduced by the extra workgroup that steps
+    `scale` (phase 2: by that workgroup alone) instead of the Adam launch -- the same fixed-order tree, the same log."""
     outs = []
     for flag in ("0", "1"):
         os.environ["FDCAP_DEFER_STEP"] = flag
@@ -532,9 +534,9 @@ def test_deferred_optimiser_step_gives_the_same_bits(mode, legacy):
             fop = FittingOP({"num_iter": 30}, {}, n, body_model=bm, vposer=vp, scene_verts=scene, contact_ids=np.concatenate([left, right]),
                             camera_ext=read_camerapose(clip.camerapose_lines), legacy_zero_grad=legacy, n_left=len(left))
             kw = {"snapshot_at": [7, 26]} if mode == "global" else {}
-            body, scale, cam = fop.fitting(torch.tensor(clip.body_params).cuda(), mode, **kw)
+            body, scale, cam = fop.fitting(torch.tensor(clip.body_params).cuda(), mode, log_every=log_every, **kw)
             snaps = [tuple(t.clone() for t in fop.snapshots[k]) for k in sorted(fop.snapshots)]
-            outs.append((body.clone(), float(scale), cam.clone(), snaps))
+            outs.append((body.clone(), float(scale), cam.clone(), snaps, fop.log))
             fop.close()
         finally:
             os.environ.pop("FDCAP_DEFER_STEP")
@@ -542,6 +544,12 @@ def test_deferred_optimiser_step_gives_the_same_bits(mode, legacy):
     assert torch.equal(a[0], b[0]) and a[1] == b[1] and torch.equal(a[2], b[2])
     for sa, sb in zip(a[3], b[3]):
         assert all(torch.equal(x, y) for x, y in zip(sa, sb))
+    if log_every:
+        import dataclasses
+        la, lb = dataclasses.asdict(a[4]), dataclasses.asdict(b[4])
+        assert len(la["iters"]) >= 30 // log_every and la["iters"][-1] == 29
+        for k in la:                                                       # (NaN-safe: phase-1 rows carry no world term)
+            np.testing.assert_array_equal(np.asarray(la[k], dtype=np.float64), np.asarray(lb[k], dtype=np.float64), err_msg=k)
 
 
 @pytest.mark.parametrize("n,per_part", [(48, 40), (5, 250)])
