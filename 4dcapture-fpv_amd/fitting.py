@@ -137,8 +137,10 @@ class FittingOP:
         if group is not None:
             import os
             import torch.distributed as dist
-            if dist.get_backend(group) == "nccl" and os.environ.get("FDCAP_C_COMM", "1") != "0":
-                self._init_c_comm()
+            if dist.get_backend(group) == "nccl":
+                from .dist import agree_on
+                if agree_on(self.shard, int(os.environ.get("FDCAP_C_COMM", "1") != "0")):      # (rank 0's setting, for everyone)
+                    self._init_c_comm()
         self.dct_mtx = None if dct_mtx is None else np.ascontiguousarray(dct_mtx, dtype=np.float32)
         self._c_dct_init = c_dct_init
         self.dct_num_iter = int(dct_num_iter)
@@ -151,20 +153,46 @@ class FittingOP:
 
     def _init_c_comm(self):
         """Rank 0 draws the RCCL unique id, torch.distributed carries it to the other ranks (the out-of-band channel any
-        launcher has), every rank joins the library's own communicator."""
+        launcher has), every rank joins the library's own communicator.  Whether the library's exchange is used is ONE decision
+        for the whole group (a rank on the other path would issue other collectives and hang its peers): every step that can
+        fail on one rank alone -- binding librccl, creating the communicator, a first sum over it -- is followed by an
+        agreement over torch.distributed, and any failure anywhere sends every rank to torch.distributed's collectives
+        (RCCL as well; same kernels either side of the all-gather, same results), with a warning on rank 0."""
         import ctypes
+        import warnings
         import torch
         import torch.distributed as dist
+        from .dist import same_on_all_ranks
         lib, h = self.ctx.lib, self.ctx.handle
+        sh = self.shard
+
+        def all_ok(rc, what):
+            lo, hi = same_on_all_ranks(sh, int(rc))
+            if lo == 0 and hi == 0:
+                return True
+            if sh.rank == 0:
+                warnings.warn(f"fdcap: {what} failed on some rank (codes {lo}..{hi}; this rank: {rc} "
+                              f"{lib.fdcap_comm_last_error(h).decode()!r}); using torch.distributed's collectives instead")
+            return False
+
         idb = (ctypes.c_uint8 * 128)()
-        if self.shard.rank == 0:
-            capi.check(lib.fdcap_comm_unique_id(idb), "fdcap_comm_unique_id")
+        rc = lib.fdcap_comm_unique_id(idb)                  # (every rank: this is where librccl is bound; only rank 0's id is used)
+        if not all_ok(rc, "binding librccl (fdcap_comm_unique_id)"):
+            return
         t = torch.tensor(list(idb), dtype=torch.uint8, device=self.device)
-        dist.broadcast(t, src=self.shard.global_rank(0), group=self.group)
+        dist.broadcast(t, src=sh.global_rank(0), group=self.group)
         idb = (ctypes.c_uint8 * 128)(*t.cpu().tolist())
-        rc = lib.fdcap_comm_create(h, idb, self.shard.rank, self.shard.world)
-        if rc:
-            raise capi.FdcapError(f"fdcap_comm_create: {rc} {lib.fdcap_comm_last_error(h).decode()}")
+        rc = lib.fdcap_comm_create(h, idb, sh.rank, sh.world)
+        if not all_ok(rc, "fdcap_comm_create"):
+            lib.fdcap_comm_destroy(h)
+            return
+        # first use: sum of (rank + 1) over the communicator, on every rank
+        probe = torch.tensor([float(sh.rank + 1)], dtype=torch.float64, device=self.device)
+        rc = lib.fdcap_comm_allreduce_f64(h, capi.dptr(probe), 1, capi.current_stream())
+        got = float(probe.item()) if rc == 0 else -1.0
+        if not all_ok(rc if rc else int(got != sh.world * (sh.world + 1) / 2), "the first all-reduce over the library's communicator"):
+            lib.fdcap_comm_destroy(h)
+            return
         self._c_comm = True
 
     def _halos(self):

@@ -76,6 +76,8 @@ def parse(argv=None):
     ap.add_argument("--no-logging-run", action="store_true", help="skip the secondary run that evaluates every loss term every iteration")
     ap.add_argument("--no-exact-fp32", action="store_true", help="skip the child run with FDCAP_GEMM_SPLIT3=0")
     ap.add_argument("--value-only", action="store_true", help="timed steps only: no roofline / secondary figures (child runs)")
+    ap.add_argument("--profile-logging", action="store_true", help="profiling aid, with --value-only: the timed steps are the "
+                    "every-iteration-logging step (the line says so in config.workload; never the headline)")
     ap.add_argument("--cpu-sample-frames", type=int, default=0, help="0 = pick from a ~20 s budget")
     ap.add_argument("--dry-run", action="store_true", help="plumbing only, on CPU with gloo (see the module docstring)")
     return ap.parse_args(argv)
@@ -385,15 +387,20 @@ def main():
         body_rec, scale, cam = fop.fitting(body_gpu, "global", log_every=log_every)
         return body_rec.cpu(), scale, cam.cpu()          # D->H of the results is part of the step
 
+    if args.profile_logging and not args.value_only:
+        raise SystemExit("--profile-logging goes with --value-only")
+    timed_step = (lambda: one_step(log_every=1)) if args.profile_logging else one_step
     for _ in range(args.warmup):
-        one_step()
-    dt, res = rk.timed(one_step, args.steps)
+        timed_step()
+    dt, res = rk.timed(timed_step, args.steps)
     assert np.isfinite(res[0].numpy()).all()
     nc, ns, nl = len(vid), len(scene), fop.shard.n_local
     out = base_line(args, rk, nc, N * args.steps / dt, dt)
     if rk.world > 1:          # which iteration schedule rank 0's last fit kept after timing both (same results either way)
         out["config"]["exchange_schedule"] = "next forward's head under the all-gather" if getattr(fop, "exchange_overlap", False) else "plain"
     if args.value_only:
+        if args.profile_logging:
+            out["config"]["workload"] += " [--profile-logging: every loss term of every iteration evaluated and kept]"
         return rk.finish(out)
     # Like-for-like figure (never `value`): the same step with EVERY loss term evaluated in EVERY iteration, as the reference's
     # loop prints them (:573-575, :587-589; phase 2 then also runs the contact forward it otherwise has no use for).  The

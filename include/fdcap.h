@@ -322,7 +322,8 @@ int32_t fdcap_exchange_len(void);
  * Python (and for Python: two calls per iteration instead of five, no stream hand-over).  RCCL is bound at run time
  * (dlopen librccl.so.1; FDCAP_RCCL_LIB overrides): FDCAP_E_COMM when it is not there.  One communicator per context, created
  * on the calling thread's current HIP device; every rank of the job calls fdcap_comm_create with the SAME id.
- *   fdcap_comm_unique_id : rank 0 only; `id128` [FDCAP_UNIQUE_ID_BYTES] host bytes to hand to the other ranks out of band
+ *   fdcap_comm_unique_id : `id128` [FDCAP_UNIQUE_ID_BYTES] host bytes; rank 0's go to the other ranks out of band (any rank may
+ *                          call it: it is also the cheap test that librccl can be bound in this process)
  *   fdcap_comm_create    : ncclCommInitRank (collective: blocks until all `world` ranks arrive)
  *   fdcap_opt_halo_exchange : halo rows <- the neighbours' boundary rows as they are (before the first iteration, after
  *                          fdcap_opt_import_state, after each fdcap_opt_step_x of mode 'local')

@@ -234,22 +234,34 @@ def _rccl_worker(port, q, c_comm="1", mode="global"):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     os.environ["FDCAP_FORCE_EXCHANGE"] = "1"
-    os.environ["FDCAP_C_COMM"] = c_comm
+    os.environ["FDCAP_C_COMM"] = "1" if c_comm == "broken" else c_comm
     torch.cuda.set_device(0)
     dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
     try:
-        q.put(_fit(dist.group.WORLD, mode))
+        if c_comm == "broken":                       # the library's communicator cannot be created on this "node"
+            import warnings
+            from fdcap_amd import capi
+            lib = capi.load_library()
+            lib.fdcap_comm_create = lambda *a: -4            # FDCAP_E_COMM
+            with warnings.catch_warnings(record=True) as w:
+                warnings.simplefilter("always")
+                out = _fit(dist.group.WORLD, mode)
+            assert any("torch.distributed's collectives instead" in str(x.message) for x in w), [str(x.message) for x in w]
+            q.put(out)
+        else:
+            q.put(_fit(dist.group.WORLD, mode))
     finally:
         dist.barrier()
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("c_comm,mode", [("1", "global"), ("0", "global"), ("1", "local")])
+@pytest.mark.parametrize("c_comm,mode", [("1", "global"), ("0", "global"), ("1", "local"), ("broken", "global")])
 def test_exchange_path_over_rccl_on_one_rank_equals_the_plain_loop(c_comm, mode):
     """The multi-GPU iteration tail (Adam on rows + pack, RCCL all-gather, unpack + Adam on scale, logging all-reduce) on a
     one-rank RCCL group: same arithmetic as the single-GPU loop, so results must be identical -- through the library's own
     communicator (SURVEY 8b `halo_exchange`: fdcap_comm_* / fdcap_opt_exchange / fdcap_opt_halo_exchange, the default over
-    RCCL) and through torch.distributed's collective."""
+    RCCL) and through torch.distributed's collective.  "broken": fdcap_comm_create fails -- the group agrees to fall back to
+    torch.distributed's collectives, says so once, and the fit is the same."""
     ref = _fit(None, mode)
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
