@@ -113,42 +113,44 @@ __device__ __forceinline__ float scale_grad_block(const float* __restrict__ dsca
     __syncthreads();
     return (sred[0] + sred[1]) + (sred[2] + sred[3]);
 }
-// the printed loss terms of a logging iteration: per-frame partials -> losses[], one fixed-order tree in double (no atomics)
+// the printed loss terms of a logging iteration: per-frame partials -> losses[], in double, in one fixed order whatever the
+// workgroup's size (no atomics, no LDS, no barrier): ONE WAVE PER TERM -- lane l adds rows l, l + 64, ... ascending (+0.0 past the end), then a
+// butterfly over the lanes.  (r4: the 256-thread LDS tree this replaces held the backward's extra workgroup for ~4 us.)
+__device__ __forceinline__ double wave_sum_f64(double v) {
+#pragma unroll
+    for (int m = 32; m; m >>= 1) v += __shfl_xor(v, m);
+    return v;
+}
 __device__ __forceinline__ void loss_rows_reduce_block(const float* __restrict__ rows, int row0, int n, unsigned mask, int assign,
                                                        double* __restrict__ losses, const float* __restrict__ dscale_row,
                                                        float* __restrict__ dscale_out) {
-    __shared__ double sd[LROW][256];
-    __shared__ float sred[4];
-    const int tid = threadIdx.x;                             // (workgroups of 256 threads or more: the first 256 work)
-    double a[LROW];
-#pragma unroll
-    for (int s = 0; s < LROW; ++s) a[s] = 0.0;
-    float ds = 0.f;
-    for (int i = tid; i < n && tid < 256; i += 256) {
-        const float4 lo = *(const float4*)(rows + (size_t)(row0 + i) * LROW), hi = *(const float4*)(rows + (size_t)(row0 + i) * LROW + 4);
-        a[0] += (double)lo.x; a[1] += (double)lo.y; a[2] += (double)lo.z; a[3] += (double)lo.w;
-        a[4] += (double)hi.x; a[5] += (double)hi.y; a[6] += (double)hi.z; a[7] += (double)hi.w;
-        ds += dscale_row[row0 + i];
-    }
-    if (tid < 256) {
-#pragma unroll
-        for (int s = 0; s < LROW; ++s) sd[s][tid] = a[s];
-    }
-    ds = wave_sum64(ds);
-    if (tid < 256 && (tid & 63) == 0) sred[tid >> 6] = ds;
-    __syncthreads();
-    for (int w = 128; w > 0; w >>= 1) {                      // one tree for all slots
-        if (tid < w) {
-#pragma unroll
-            for (int s = 0; s < LROW; ++s) sd[s][tid] += sd[s][tid + w];
+    const int tid = threadIdx.x, lane = tid & 63, nw = (int)blockDim.x >> 6;
+    const int wave = nw - 1 - (tid >> 6);                    // (the last waves first: the first four also sum d loss / d scale)
+    for (int s = wave; s < LROW; s += nw) {                  // (wave-uniform)
+        if (!((mask >> s) & 1u)) {
+            if (assign && lane == 0) losses[s] = 0.0;
+            continue;
         }
-        __syncthreads();
+        const float* col = rows + (size_t)row0 * LROW + s;
+        double a = 0.0;
+        for (int i0 = 0; i0 < n; i0 += 1024) {               // sixteen loads in flight per trip (one trip at the quoted size)
+            float r[16];
+#pragma unroll
+            for (int k = 0; k < 16; ++k) {
+                const int i = i0 + 64 * k + lane;
+                r[k] = col[(size_t)min(i, n - 1) * LROW];
+            }
+#pragma unroll
+            for (int k = 0; k < 16; ++k) a += (i0 + 64 * k + lane < n) ? (double)r[k] : 0.0;
+        }
+        a = wave_sum_f64(a);
+        if (lane == 0) losses[s] = assign ? a : losses[s] + a;
     }
-    if (tid < LROW) {
-        if ((mask >> tid) & 1u) losses[tid] = assign ? sd[tid][0] : losses[tid] + sd[tid][0];
-        else if (assign) losses[tid] = 0.0;
+    if (dscale_out) {                                        // (the stand-alone launch only: workgroup-uniform)
+        __shared__ float sred[4];
+        const float g = scale_grad_block(dscale_row, row0, n, sred);
+        if (tid == 0) *dscale_out = g;
     }
-    if (tid == 0 && dscale_out) *dscale_out = (sred[0] + sred[1]) + (sred[2] + sred[3]);
 }
 __device__ __forceinline__ void scale_tail_block(const ScaleTail& t) {
     __shared__ float s_tail[4];

@@ -38,6 +38,7 @@ __device__ unsigned long long g_fr_times[3][2048 * 8];
 #include "fdc_math.h"
 #include "fdc_panel.h"
 #include "fdc_skin.h"
+#include "fdc_trace.h"
 
 using namespace fdc;
 
@@ -1588,6 +1589,7 @@ inline bool gemm_split3_enabled() {
 }
 // pose + shape blend offsets of a vertex set: Voff[M, 3 nv] = PF[M, 496] x [posedirs ; shapedirs^T]
 hipError_t blend_forward(const SkinSet& ss, const float* PF, int M, float* Voff, hipStream_t st) {
+    TraceRange tr_("fdcap:blend_fwd(K8)");
     if (gemm_split3_enabled() && ss.pn_fwd3.f) return panel_gemm3(PF, NPFX, M, NPFX, ss.pn_fwd3, Voff, 3 * ss.nv, 3 * ss.nv, st);
     if (ss.pn_fwd.f) return panel_gemm(PF, NPFX, M, NPFX, ss.pn_fwd, Voff, 3 * ss.nv, 3 * ss.nv, st);
     return gemm_f32(false, EPI_STORE, PF, NPFX, ss.posedirs.p, ss.ldp, Voff, 3 * ss.nv, M, 3 * ss.nv, NPFX, nullptr, 0, st);
@@ -2463,9 +2465,12 @@ static int opt_contact_forward(fdcap_ctx* c, hipStream_t st, bool blend_done = f
     const NNCache cache = o->nn_cache(0);
     const bool timed = o->nn_timing && o->nn_ev_used + 2 <= (int)o->nn_ev.size();
     if (timed) HIP_TRY(hipEventRecord(o->nn_ev[o->nn_ev_used], st));
-    HIP_TRY(nn_search(o->Vw.p + off, nq, c->nn_target(o->use_cull), o->dist.p + 2 * nc, o->idx.p + 2 * nc, o->pd.p, o->pi.p,
-                      o->nsplit, st, o->use_seed ? o->idx.p + 2 * nc : nullptr, !o->seeded, o->seedpt.p + 2 * nc, &o->nnpt_valid,
-                      &cache, &o->nn_order));
+    {
+        TraceRange tr_("fdcap:chamfer_nn(K14)");
+        HIP_TRY(nn_search(o->Vw.p + off, nq, c->nn_target(o->use_cull), o->dist.p + 2 * nc, o->idx.p + 2 * nc, o->pd.p, o->pi.p,
+                          o->nsplit, st, o->use_seed ? o->idx.p + 2 * nc : nullptr, !o->seeded, o->seedpt.p + 2 * nc, &o->nnpt_valid,
+                          &cache, &o->nn_order));
+    }
     if (timed) { HIP_TRY(hipEventRecord(o->nn_ev[o->nn_ev_used + 1], st)); o->nn_ev_used += 2; }
     o->seeded = true;
     return 0;
@@ -2484,6 +2489,7 @@ static int opt_backward_impl(fdcap_ctx* c, const LossWeights& lw, int32_t log_te
     const int nl = cf.n_local, nc = c->nc, N = cf.n_total;
     const bool dct_on = lw.dct != 0.f && o->dctW > 0;
     PoseModel pm = c->pose_model();
+    TraceRange tr_(fuse_ii >= 0 ? "fdcap:backward_and_step" : "fdcap:backward");
     if (o->log_pending) {                               // a deferred reduction nobody stepped after: deliver it before loss_rows is rewritten
         hipLaunchKernelGGL(loss_rows_reduce_kernel, dim3(1), dim3(256), 0, st, o->loss_rows.p, 2, nl, o->log_mask, o->log_assign, o->log_dst,
                            o->dscale_row.p, o->dscale.p);
@@ -2556,6 +2562,7 @@ static int opt_backward_impl(fdcap_ctx* c, const LossWeights& lw, int32_t log_te
         hipLaunchKernelGGL(skin_bwd_kernel<true>, dim3(nl), dim3(256), (size_t)std::min(nc, 1024) * 12 * sizeof(float), st, c->contact.model(), nc, o->X.p, o->Voff.p, o->A.p,
                            o->M.p, o->scale.p, 2, (const float*)nullptr, o->dVoff.p, o->dA.p, (float*)nullptr, o->dtransl_v.p,
                            o->dMv.p, o->dsv.p, cg);
+        TraceRange tr_b("fdcap:blend_bwd(K8)");
         if (gemm_split3_enabled() && c->contact.pn_bwd3.f && panel_gemm3_rb2k_ok(nl, 3 * nc, c->contact.pn_bwd3)) {
             // two partial products (K halves), added by pose_bwd_kernel: [2][R, 496] in o->dPF
             dpf_split = true;
@@ -2883,6 +2890,7 @@ int opt_step_launch(fdcap_ctx* c, int32_t ii, int32_t P, bool do_rows, bool do_s
     const StepPlan sp = opt_step_plan(o, ii, P, do_rows, do_scale);
     const bool tail = sp.step_scale || reduce_scale;                 // the last block: (reduction +) scale (+ message tail)
     if (sp.nb_x + sp.nb_cam + (tail ? 1 : 0) + (o->log_pending ? 1 : 0) == 0) return FDCAP_OK;
+    TraceRange tr_("fdcap:adam(K22)");
     const LogReduceIn lg = {o->loss_rows.p, o->log_dst, o->log_mask, o->log_assign, nl};
     hipLaunchKernelGGL(adam_step_kernel, dim3(sp.nb_x + sp.nb_cam + 1 + (o->log_pending ? 1 : 0)), dim3(256), 0, st, sp.x, sp.cam, sp.sc, sp.nb_x, sp.nb_cam,
                        o->dscale_row.p, 2, reduce_scale ? nl : 0, o->dscale.p, (sp.step_scale && ii >= P) ? 1 : 0, xch, nl, o->CAM.p,

@@ -846,3 +846,33 @@ np.savez(sys.argv[1], d=d.cpu().numpy(), i=i.cpu().numpy(), x=fop._rows_x.cpu().
     assert np.isfinite(ref["d"]).all() and (ref["i"] >= 0).all()
     for mode, r in res.items():
         assert np.array_equal(r["d"], ref["d"]) and np.array_equal(r["i"], ref["i"]) and np.array_equal(r["x"], ref["x"]), mode
+
+
+def test_roctx_ranges_are_bound_on_request_and_change_nothing(tmp_path):
+    """FDCAP_ROCTX=1 makes the library bracket the blend products, the Chamfer search, the
+    optimiser step and every backward with roctx ranges (csrc/fdc_trace.h; the marker library is bound at run time).  Without
+    a profiler attached the ranges go nowhere: a child process runs a short fit with the switch on and must report the
+    marker library loaded (/proc/self/maps) and the same parameters, bit for bit, as this process without it."""
+    import subprocess
+    import sys
+    fop, bm, vp, clip, scene, vid = _make_fop(9, 300, 2000, 20, 12, seed=91)
+    body, scale, cam = fop.fitting(torch.tensor(clip.body_params).cuda(), "global", log_every=2)
+    ref = body.cpu().numpy()
+    fop.close()
+    out = tmp_path / "roctx.npy"
+    code = f"""
+import numpy as np, torch, sys
+sys.path.insert(0, {os.path.dirname(os.path.dirname(os.path.abspath(__file__)))!r})
+import fdcap_amd
+from tests.test_gpu_parity import _make_fop
+fop, bm, vp, clip, scene, vid = _make_fop(9, 300, 2000, 20, 12, seed=91)
+body, scale, cam = fop.fitting(torch.tensor(clip.body_params).cuda(), "global", log_every=2)
+np.save({str(out)!r}, body.cpu().numpy())
+maps = open("/proc/self/maps").read()
+print("ROCTX_BOUND", int("roctx" in maps))
+"""
+    env = dict(os.environ, FDCAP_ROCTX="1")
+    r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert "ROCTX_BOUND 1" in r.stdout, r.stdout[-500:]
+    np.testing.assert_array_equal(np.load(out), ref)

@@ -51,6 +51,17 @@ __global__ __launch_bounds__(256) void probe(unsigned long long* t, float* sink,
         if (OP == 22) { THREE("v_mad_u32_u24") }
         if (OP == 23) { THREE("v_min3_i32") }
         if (OP == 24) { THREE("v_and_or_b32") }
+        if (OP == 25) { TWO("v_or_b32") }
+        if (OP == 26) { THREE("v_or3_b32") }
+        if (OP == 27) { THREE("v_add3_u32") }
+        if (OP == 28) { THREE("v_lshl_or_b32") }
+        if (OP == 29) { THREE("v_bfi_b32") }
+        if (OP == 30) { TWO("v_sub_u32") }
+        if (OP == 31) { TWO("v_fmac_f32") }
+        if (OP == 32) { THREE("v_xad_u32") }
+        if (OP == 33) { TWO("v_mul_u32_u24") }
+        if (OP == 34) { TWO("v_max_u32") }
+        if (OP == 35) { TWO("v_subrev_f32") }
         if (OP == 5) { R8(asm volatile("v_lshrrev_b64 %0, 1, %0\n v_lshrrev_b64 %1, 1, %1\n v_lshrrev_b64 %2, 1, %2\n v_lshrrev_b64 %3, 1, %3"
                         : "+v"(p[0]), "+v"(p[1]), "+v"(p[2]), "+v"(p[3]));) }
     }
@@ -99,5 +110,7 @@ int main() {
     run<6>("v_add_f32"); run<7>("v_mul_f32"); run<8>("v_sub_f32"); run<9>("v_min_f32"); run<10>("v_and_b32"); run<11>("v_med3_f32"); run<12>("v_add_u32");
     run<14>("v_min_u32"); run<15>("v_min3_u32"); run<16>("v_min_i32"); run<17>("v_max_f32"); run<18>("v_lshlrev_b32"); run<19>("v_xor_b32");
     run<20>("v_bfe_u32"); run<21>("v_perm_b32"); run<22>("v_mad_u32_u24"); run<23>("v_min3_i32"); run<24>("v_and_or_b32");
+    run<25>("v_or_b32"); run<26>("v_or3_b32"); run<27>("v_add3_u32"); run<28>("v_lshl_or_b32"); run<29>("v_bfi_b32"); run<30>("v_sub_u32");
+    run<31>("v_fmac_f32"); run<32>("v_xad_u32"); run<33>("v_mul_u32_u24"); run<34>("v_max_u32"); run<35>("v_subrev_f32");
     return 0;
 }
