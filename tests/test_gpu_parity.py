@@ -584,6 +584,31 @@ def test_no_contact_config_and_ragged_sizes():
         fop.close()
 
 
+@pytest.mark.parametrize("n", [1, 2, 63, 65, 1100])
+def test_logged_sums_at_ragged_clip_lengths(n):
+    """The printed loss terms (:573-575, :587-589) are per-frame partial sums reduced on the device, one wave per term, lane l
+    taking frames l, l + 64, ... (csrc/fdc_loss.h loss_rows_reduce_block): clips shorter than a wave, one frame past it, and longer
+    than one trip of its sixteen-load batch (1024 frames) against the oracle's means -- five logged iterations, the last one in
+    phase 2, BASELINE config 1's loss (no scene).  N < 3 / N < 2: the smoothing means are means over nothing (nan), as in the
+    reference."""
+    fop, bm, vp, clip, scene, vid = _make_fop(n, 200, 0, 7, 5, seed=300 + n)
+    fop.fitting(torch.tensor(clip.body_params).cuda(), "global", log_every=1)
+    orc = FittingOracle(SMPLXOracle(bm), VPoserDecoder.from_data(vp), scene, vid, clip.camerapose_lines, n, num_iter=5)
+    orc.fitting(torch.tensor(clip.body_params))
+    want = np.array(orc.loss_log, dtype=np.float64)                     # [5, (l_rec, l_vp, l_sm, l_con, l_ws, total)]
+    got = np.array([fop.log.l_rec, fop.log.l_vposer, fop.log.loss_smoothing, fop.log.loss_contact, fop.log.loss_world_smoothing,
+                    fop.log.total], dtype=np.float64).T
+    assert got.shape == want.shape == (5, 6) and fop.log.iters == [0, 1, 2, 3, 4] and first_phase2_iter(5) == 4
+    for it in range(5):
+        for c in (0, 1, 2, 4, 5):
+            if np.isnan(want[it, c]):
+                assert np.isnan(got[it, c]), (n, it, c, got[it, c])
+            else:
+                # iteration 0 to rounding; later ones within what one differently-rounded Adam step can move a mean
+                np.testing.assert_allclose(got[it, c], want[it, c], rtol=2e-5 if it == 0 else 2e-3, atol=1e-7, err_msg=f"n={n} it={it} term={c}")
+    fop.close()
+
+
 def test_library_fails_loudly_without_gpu_fallback(small):
     _, _, ctx = small
     with pytest.raises(capi.FdcapError):
