@@ -127,8 +127,8 @@ __device__ __forceinline__ void loss_rows_reduce_block(const float* __restrict__
     const int tid = threadIdx.x, lane = tid & 63, nw = (int)blockDim.x >> 6;
     const int wave = nw - 1 - (tid >> 6);                    // (the last waves first: the first four also sum d loss / d scale)
     for (int s = wave; s < LROW; s += nw) {                  // (wave-uniform)
-        if (!((mask >> s) & 1u)) {                            // (bits 8..15 of `mask`: slots somebody else writes -- left alone)
-            if (assign && !((mask >> (8 + s)) & 1u) && lane == 0) losses[s] = 0.0;
+        if (!((mask >> s) & 1u)) {
+            if (assign && lane == 0) losses[s] = 0.0;
             continue;
         }
         const float* col = rows + (size_t)row0 * LROW + s;

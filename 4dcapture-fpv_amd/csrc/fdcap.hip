@@ -177,8 +177,7 @@ __global__ __launch_bounds__(64 * POSE_NW) void pose_fwd_kernel(PoseModel pm, co
                                                       const float* __restrict__ CAM, const float* __restrict__ scale,
                                                       int row0, float* Rm, float* PF, float* Jrest, float* G, float* A,
                                                       float* M, float* Jw, const float* AA, const float* __restrict__ Opart,
-                                                      size_t part_stride, int wo_lo = 0, int wo_hi = 0, DeferredStep ds = DeferredStep(),
-                                                      float* __restrict__ aux = nullptr) {
+                                                      size_t part_stride, int wo_lo = 0, int wo_hi = 0, DeferredStep ds = DeferredStep()) {
     __shared__ PoseScratch sc;
     __shared__ PoseStage stg;
     __shared__ float s_O[ODIM + 2];
@@ -263,8 +262,6 @@ __global__ __launch_bounds__(64 * POSE_NW) void pose_fwd_kernel(PoseModel pm, co
         __syncthreads();
     }
     if (PF && threadIdx.x < NBETA) PF[(size_t)r * NPFX + NPF + threadIdx.x] = stg.x[X_BETAS + threadIdx.x];
-    // (aux: the frame's translation for a consumer that runs after the parameter row has been stepped again: OptState::Side)
-    if (aux && threadIdx.x < 4) aux[(size_t)r * 4 + threadIdx.x] = threadIdx.x < 3 ? stg.x[X_TRANSL + threadIdx.x] : 0.f;
     if (PARTS) {
         pose_forward(pml, stg.x, s_O, stg.cam, sc_v, sc,
                      Rm ? Rm + (size_t)r * NJ * 9 : nullptr, PF ? PF + (size_t)r * NPFX : nullptr,
@@ -1418,22 +1415,6 @@ struct OptState {
     bool nnpt_valid = false;  // the last contact forward left the neighbours' coordinates in seedpt
     bool use_seed = true;     // last iteration's neighbours seed the NN bound (pruning only)
     bool use_cull = true;     // skip k-d cells whose box is out of every query's reach
-    // The logged contact term of phase 2 on a stream of its own (r4).  A logging iteration of phase 2 runs the contact forward
-    // (blend product, skinning, Chamfer search, per-frame sums: ~120 us) only to PRINT the term (:587-589) -- nothing of the
-    // iteration waits for it.  It is enqueued on `st` behind an event of the compute stream, reads the pose state from one of
-    // TWO buffer sets (set 0: the ordinary PF / A / M; set 1: the copies below; aux: the frame's translation, which the
-    // deferred step of the NEXT iteration overwrites in the parameter rows) that pose_fwd_kernel fills by iteration parity,
-    // and the compute stream only waits for it two iterations later, before that set is written again, or when somebody needs
-    // what the chain owns (the search's seeds and lists, the history row): opt_side_join.
-    struct Side {
-        hipStream_t st = nullptr;
-        hipEvent_t fwd[2] = {nullptr, nullptr};     // compute stream: pose state of set p is complete
-        hipEvent_t done[2] = {nullptr, nullptr};    // side stream: the chain that read set p is through
-        bool busy[2] = {false, false};
-        DevBuf<float> PF, A, M;                     // set 1
-        DevBuf<float> aux[2];                       // [R][4]: {transl.xyz, 0} of set p
-        bool ready = false, failed = false;
-    } side;
 };
 
 }  // namespace
@@ -1676,57 +1657,17 @@ int opt_step_launch(fdcap_ctx* c, int32_t ii, int32_t P, bool do_rows, bool do_s
 
 // Everything the caller registered (rows_x_d, rows_cam_d) and the Adam moments are current after this: the rows' part of a
 // deferred step that no forward has consumed is applied by the ordinary Adam launch (`scale` was stepped with the backward).
-// `st` waits for whatever the side chain (OptState::Side) still has in flight (set p only, or both)
-int opt_side_join(OptState* o, hipStream_t st, int only_set = -1) {
-    for (int p = 0; p < 2; ++p)
-        if (o->side.busy[p] && (only_set < 0 || only_set == p)) {
-            const hipError_t e = hipStreamWaitEvent(st, o->side.done[p], 0);
-            if (e != hipSuccess) return (int)e;
-            o->side.busy[p] = false;
-        }
-    return 0;
-}
-// FDCAP_LOG_OVERLAP=0: a logging phase-2 iteration runs its contact forward in line, as every other iteration does (A/B)
-static bool log_overlap_enabled() {
-    const char* e = getenv("FDCAP_LOG_OVERLAP");
-    return !(e && e[0] == '0');
-}
-// stream, events and the second buffer set, on first use (false: could not be had -- the caller runs the chain in line)
-bool opt_side_setup(OptState* o) {
-    OptState::Side& sd = o->side;
-    if (sd.ready) return true;
-    if (sd.failed) return false;
-    sd.failed = true;
-    if (hipStreamCreateWithFlags(&sd.st, hipStreamNonBlocking) != hipSuccess) { sd.st = nullptr; return false; }
-    for (int p = 0; p < 2; ++p) {
-        if (hipEventCreateWithFlags(&sd.fwd[p], hipEventDisableTiming) != hipSuccess) return false;
-        if (hipEventCreateWithFlags(&sd.done[p], hipEventDisableTiming) != hipSuccess) return false;
-        if (sd.aux[p].ensure((size_t)o->R * 4) != hipSuccess) return false;
-    }
-    if (sd.PF.ensure((size_t)o->R * NPFX) != hipSuccess || sd.A.ensure((size_t)o->R * NJ * 12) != hipSuccess ||
-        sd.M.ensure((size_t)o->R * 12) != hipSuccess)
-        return false;
-    if (hipMemset(sd.PF.p, 0, (size_t)o->R * NPFX * sizeof(float)) != hipSuccess) return false;
-    sd.failed = false;
-    sd.ready = true;
-    return true;
-}
-
 int opt_sync(fdcap_ctx* c, hipStream_t st) {
     OptState* o = c->opt;
-    if (!o) return 0;
-    { const int e = opt_side_join(o, st); if (e) return e; }
-    if (!o->pend.on) return 0;
+    if (!o || !o->pend.on) return 0;
     o->pend.on = false;
     return opt_step_launch(c, o->pend.ii, o->pend.P, true, false, false, st, nullptr);
 }
 
 // decoder + per-frame pose state (Rm, PF, Jrest, G, A, M, Jw) of rows [lo, hi): two launches.  A deferred optimiser step is
 // applied by these two launches when they cover exactly the frames it steps (no halo rows: one rank), else by its own launch first.
-// set >= 0: PF / A / M go to buffer set `set` of the side chain and the frames' translations to its aux rows (OptState::Side)
-int opt_pose_forward(fdcap_ctx* c, int lo, int hi, hipStream_t st, int set = -1) {
+int opt_pose_forward(fdcap_ctx* c, int lo, int hi, hipStream_t st) {
     OptState* o = c->opt;
-    { const int ej = opt_side_join(o, st, set); if (ej) return ej; }      // (the set written here may still be read; set < 0: everything in line from here on)
     o->ahead = false;                                       // (whatever ran ahead is recomputed here)
     const size_t ps = (size_t)o->R * ODIM;
     const int nl = o->cfg.n_local;
@@ -1743,12 +1684,9 @@ int opt_pose_forward(fdcap_ctx* c, int lo, int hi, hipStream_t st, int set = -1)
     }
     int e = vposer_forward(c, o->X.p, XDIM, X_LATENT, lo, hi, o->H1.p, o->H2.p, o->Opart.p, ps, nullptr, st, 0, 0, ds);
     if (e) return e;
-    float* const PFp = set == 1 ? o->side.PF.p : o->PF.p;
-    float* const Ap = set == 1 ? o->side.A.p : o->A.p;
-    float* const Mp = set == 1 ? o->side.M.p : o->M.p;
     hipLaunchKernelGGL(pose_fwd_kernel<true>, dim3(hi - lo), dim3(64 * POSE_NW), 0, st, c->pose_model(), o->X.p, o->O.p, o->CAM.p, o->scale.p, lo,
-                       o->Rm.p, PFp, o->Jrest.p, o->G.p, Ap, Mp, o->Jw.p, (const float*)nullptr, (const float*)o->Opart.p, ps,
-                       0, 0, ds, set >= 0 ? o->side.aux[set].p : (float*)nullptr);
+                       o->Rm.p, o->PF.p, o->Jrest.p, o->G.p, o->A.p, o->M.p, o->Jw.p, (const float*)nullptr, (const float*)o->Opart.p, ps,
+                       0, 0, ds);
     if (ds.on) {                                            // the step has been issued: the launches that follow see its results
         o->pend.on = false;
         o->dz_pending = false;
@@ -2417,16 +2355,6 @@ void fdcap_opt_destroy(fdcap_ctx* c) {
     o->nnc_ids.release(); o->nnc_hdr.release(); o->nnc_anchor.release();
     for (hipEvent_t e : o->nn_ev) (void)hipEventDestroy(e);
     o->nn_ev.clear();
-    if (o->side.st) {
-        (void)hipStreamSynchronize(o->side.st);
-        (void)hipStreamDestroy(o->side.st);
-    }
-    for (int p = 0; p < 2; ++p) {
-        if (o->side.fwd[p]) (void)hipEventDestroy(o->side.fwd[p]);
-        if (o->side.done[p]) (void)hipEventDestroy(o->side.done[p]);
-        o->side.aux[p].release();
-    }
-    o->side.PF.release(); o->side.A.release(); o->side.M.release();
     delete o;
     c->opt = nullptr;
 }
@@ -2525,19 +2453,11 @@ int fdcap_opt_set_inputs(fdcap_ctx* c, const float* data78, const float* init78,
     return FDCAP_OK;
 }
 
-// set >= 0: on the side chain's stream, from buffer set `set` (OptState::Side; the translations come from its aux rows)
-static int opt_contact_forward(fdcap_ctx* c, hipStream_t st, bool blend_done = false, int set = -1) {
+static int opt_contact_forward(fdcap_ctx* c, hipStream_t st, bool blend_done = false) {
     OptState* o = c->opt;
     const int nl = o->cfg.n_local, nc = c->nc;
     const size_t off = (size_t)2 * nc * 3;
-    const float* const PFp = set == 1 ? o->side.PF.p : o->PF.p;
-    const float* const Ap = set == 1 ? o->side.A.p : o->A.p;
-    const float* const Mp = set == 1 ? o->side.M.p : o->M.p;
-    if (!blend_done) HIP_TRY(blend_forward(c->contact, PFp + 2 * NPFX, nl, o->Voff.p + off, st));
-    if (set >= 0)
-        hipLaunchKernelGGL(skin_fwd_kernel, dim3((nc + 255) / 256, nl), dim3(256), 0, st, c->contact.model(), nc, (const float*)o->side.aux[set].p, 4,
-                           0, 0, o->Voff.p, Ap, Mp, o->scale.p, 2, 1, o->Vw.p);
-    else
+    if (!blend_done) HIP_TRY(blend_forward(c->contact, o->PF.p + 2 * NPFX, nl, o->Voff.p + off, st));
     hipLaunchKernelGGL(skin_fwd_kernel, dim3((nc + 255) / 256, nl), dim3(256), 0, st, c->contact.model(), nc, o->X.p, XDIM,
                        X_BETAS, X_TRANSL, o->Voff.p, o->A.p, o->M.p, o->scale.p, 2, 1, o->Vw.p);
     const int nq = nl * nc;
@@ -2583,31 +2503,11 @@ static int opt_backward_impl(fdcap_ctx* c, const LossWeights& lw, int32_t log_te
     int row_lo, row_hi;
     opt_row_range(o, 1, &row_lo, &row_hi);
     const bool ahead = o->ahead, blend_done = o->ahead && o->ahead_blend;
-    const bool contact_grad = o->contact_on && lw.contact != 0.f;
-    // A contact forward that is only PRINTED (phase 2 of a logging fit) goes to the side chain (OptState::Side): nothing of this
-    // iteration waits for it.  Not with torch < 2 zero_grad semantics (`scale` keeps moving in phase 2 and the chain reads it).
-    const bool side = fuse_ii >= 0 && log_terms == 2 && rows_log && o->contact_on && !contact_grad && !cf.legacy_zero_grad && !ahead &&
-                      log_overlap_enabled() && opt_side_setup(o);
-    const int set = side ? (fuse_ii & 1) : -1;
-    // whoever writes a buffer set (or, in line, the search's state) waits for the chain that still reads it
-    { const int ej = opt_side_join(o, st, set); if (ej) return ej; }
-    int e = ahead ? opt_pose_forward_rest(c, row_lo, row_hi, st) : opt_pose_forward(c, row_lo, row_hi, st, set);
+    int e = ahead ? opt_pose_forward_rest(c, row_lo, row_hi, st) : opt_pose_forward(c, row_lo, row_hi, st);
     o->ahead = false;
     if (e) return e;
-    if (side) {
-        OptState::Side& sd = o->side;
-        HIP_TRY(hipEventRecord(sd.fwd[set], st));
-        HIP_TRY(hipStreamWaitEvent(sd.st, sd.fwd[set], 0));
-        e = opt_contact_forward(c, sd.st, false, set);
-        if (e) return e;
-        hipLaunchKernelGGL(contact_loss_rows_kernel, dim3(nl), dim3(256), 0, sd.st, o->dist.p, nc, 2, o->loss_rows.p);
-        // slot 3 of this iteration's history row, and nothing else of it (the other slots come from the backward's extra workgroup)
-        hipLaunchKernelGGL(loss_rows_reduce_kernel, dim3(1), dim3(256), 0, sd.st, o->loss_rows.p, 2, nl, 0x08u | (0xF7u << 8), 1, losses,
-                           o->dscale_row.p, (float*)nullptr);
-        HIP_TRY(hipEventRecord(sd.done[set], sd.st));
-        sd.busy[set] = true;
-    }
-    const bool contact_fwd = o->contact_on && (contact_grad || log_terms) && !side;
+    const bool contact_grad = o->contact_on && lw.contact != 0.f;
+    const bool contact_fwd = o->contact_on && (contact_grad || log_terms);
     if (contact_fwd) { e = opt_contact_forward(c, st, blend_done); if (e) return e; }
     const float w_rec = lw.rec * cf.weight_loss_rec / ((float)N * XDIM);
     const float w_sm = (N >= 3) ? lw.smooth / ((float)(N - 2) * XDIM) : 0.f;
@@ -2684,8 +2584,7 @@ static int opt_backward_impl(fdcap_ctx* c, const LossWeights& lw, int32_t log_te
                        joint_grad ? o->dJw.p : nullptr, contact_grad ? o->dMv.p : nullptr, contact_grad ? o->dsv.p : nullptr,
                        contact_grad ? o->dPF.p + NPF : nullptr, NPFX, contact_grad ? o->dtransl_v.p : nullptr, o->dX.p, o->dO.p,
                        o->dCAM.p, o->dscale_row.p, pli, (contact_grad && dpf_split) ? (const float*)(o->dPF.p + (size_t)o->R * NPFX) : (const float*)nullptr);
-    // 0 rec, 1 z^2, 2 smoothing, 4 world | 3 contact (bits 8..15: slots this reduction leaves alone -- the side chain delivers slot 3)
-    const unsigned log_mask = (rows_log ? 0x17u : 0u) | (contact_fwd ? 0x8u : 0u) | (side ? 0x8u << 8 : 0u);
+    const unsigned log_mask = (rows_log ? 0x17u : 0u) | (contact_fwd ? 0x8u : 0u);     // 0 rec, 1 z^2, 2 smoothing, 4 world | 3 contact
     bool log_in_tail = false;
     {
         ScaleTail tail;

@@ -339,8 +339,6 @@ class FittingOP:
             nonlocal flushed
             if upto <= flushed:
                 return
-            # (a logging phase-2 iteration's contact sum is delivered by a chain on the library's own stream: fdcap_opt_sync joins it)
-            capi.check(lib.fdcap_opt_sync(h, capi.current_stream()), "fdcap_opt_sync")
             part = hist[flushed:upto]
             if multi:
                 part = part.clone()
@@ -414,10 +412,8 @@ class FittingOP:
                 if checkpoint_every and (ii + 1) % checkpoint_every == 0 and ii + 1 < self.num_iter:
                     self._save_checkpoint(checkpoint_path, ii + 1)
         finally:
-            # never leave the library pointing into `hist` (freed with this frame if the loop raised) -- nor a chain on its side
-            # stream still writing there: the compute stream, on which the allocator orders the reuse of `hist`, waits for it
+            # never leave the library pointing into `hist` (freed with this frame if the loop raised)
             if logged:
-                lib.fdcap_opt_sync(h, capi.current_stream())
                 capi.check(lib.fdcap_opt_set_loss_output(h, capi.dptr(self._losses)), "fdcap_opt_set_loss_output")
         flush(len(logged))
         if mode == "local":

@@ -552,42 +552,6 @@ def test_deferred_optimiser_step_gives_the_same_bits(mode, legacy, log_every):
             np.testing.assert_array_equal(np.asarray(la[k], dtype=np.float64), np.asarray(lb[k], dtype=np.float64), err_msg=k)
 
 
-@pytest.mark.parametrize("mode,log_every,n", [("global", 1, 37), ("global", 3, 37), ("local", 1, 21), ("global", 1, 300)])
-def test_printed_contact_term_on_the_side_stream_gives_the_same_log(mode, log_every, n):
-    """Phase 2 of a logging fit runs the contact forward only to PRINT the term (:587-589).  By default that chain (blend product,
-    skinning, Chamfer search, per-frame sums, its slot of the history row) runs on a stream of the library's own, from one of two
-    buffer sets filled by iteration parity, and the compute stream waits for it only where it must (OptState::Side, csrc/fdcap.hip);
-    FDCAP_LOG_OVERLAP=0 keeps it in line.  Same kernels on the same inputs in the same order on their stream: parameters AND the
-    whole log are equal bit for bit -- every iteration logged, every third (logging and plain iterations alternate in phase 2),
-    mode 'local', and a clip long enough that the two streams really overlap."""
-    outs = []
-    for flag in ("0", "1"):
-        os.environ["FDCAP_LOG_OVERLAP"] = flag
-        try:
-            bm = synth.make_body_model(300, seed=82)
-            vp = synth.make_vposer(seed=83)
-            clip = synth.make_clip(n, seed=84)
-            scene = synth.make_scene(20000, seed=85)
-            left, right = synth.make_contact_ids(bm.v_template, per_part=24, seed=86)
-            fop = FittingOP({"num_iter": 40}, {}, n, body_model=bm, vposer=vp, scene_verts=scene, contact_ids=np.concatenate([left, right]),
-                            camera_ext=read_camerapose(clip.camerapose_lines), n_left=len(left))
-            body, scale, cam = fop.fitting(torch.tensor(clip.body_params).cuda(), mode, log_every=log_every, snapshot_at=[35] if mode == "global" else ())
-            import dataclasses
-            outs.append((body.clone(), float(scale), cam.clone(), dataclasses.asdict(fop.log),
-                         [tuple(t.clone() for t in fop.snapshots[k]) for k in sorted(fop.snapshots)]))
-            fop.close()
-        finally:
-            os.environ.pop("FDCAP_LOG_OVERLAP")
-    a, b = outs
-    assert torch.equal(a[0], b[0]) and a[1] == b[1] and torch.equal(a[2], b[2])
-    assert a[3]["iters"] == b[3]["iters"] and a[3]["iters"][-1] == 39 and len(a[3]["iters"]) >= 40 // log_every
-    for k in a[3]:
-        np.testing.assert_array_equal(np.asarray(a[3][k], dtype=np.float64), np.asarray(b[3][k], dtype=np.float64), err_msg=k)
-    assert np.all(np.asarray(a[3]["loss_contact"])[-3:] > 0)                # (the phase-2 values are real sums, not zeros)
-    for sa, sb in zip(a[4], b[4]):
-        assert all(torch.equal(x, y) for x, y in zip(sa, sb))
-
-
 @pytest.mark.parametrize("n,per_part", [(48, 40), (5, 250)])
 def test_vector_staged_skinning_backward_equals_the_scalar_kernel(n, per_part):
     """skin_bwd_vec_kernel (16-byte staging through LDS, packed per-vertex constants) evaluates the same terms in the same
