@@ -11,24 +11,22 @@
 namespace fdc {
 
 struct RoctxApi {
-    int state = -1;                                          // -1 not looked at, 0 off, 1 on
+    bool enabled = false;
     int (*push)(const char*) = nullptr;
     int (*pop)() = nullptr;
-    bool on() {
-        if (state >= 0) return state == 1;
-        state = 0;
+    RoctxApi() {                                             // (runs once, under the function-local static's lock)
         const char* e = getenv("FDCAP_ROCTX");
-        if (!e || e[0] != '1') return false;
+        if (!e || e[0] != '1') return;
         const char* names[] = {"librocprofiler-sdk-roctx.so.1", "librocprofiler-sdk-roctx.so", "libroctx64.so.4", "libroctx64.so"};
         for (const char* n : names) {
             void* lib = dlopen(n, RTLD_NOW | RTLD_GLOBAL);
             if (!lib) continue;
             push = (int (*)(const char*))dlsym(lib, "roctxRangePushA");
             pop = (int (*)())dlsym(lib, "roctxRangePop");
-            if (push && pop) { state = 1; return true; }
+            if (push && pop) { enabled = true; return; }
         }
-        return false;
     }
+    bool on() const { return enabled; }
 };
 inline RoctxApi& roctx() { static RoctxApi api; return api; }
 

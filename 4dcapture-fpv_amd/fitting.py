@@ -171,8 +171,9 @@ class FittingOP:
             if lo == 0 and hi == 0:
                 return True
             if sh.rank == 0:
-                warnings.warn(f"fdcap: {what} failed on some rank (codes {lo}..{hi}; this rank: {rc} "
-                              f"{lib.fdcap_comm_last_error(h).decode()!r}); using torch.distributed's collectives instead")
+                why = lib.fdcap_comm_last_error(h) or b""
+                warnings.warn(f"fdcap: {what} failed on some rank (codes {lo}..{hi}; this rank: {rc} {why.decode()!r}); "
+                              "using torch.distributed's collectives instead")
             return False
 
         idb = (ctypes.c_uint8 * 128)()
