@@ -73,6 +73,7 @@ SYMBOLS = {
     "fdcap_opt_step": (c_int32, [c_void_p, c_int32, c_int32, c_void_p]),
     "fdcap_opt_backward_and_step": (c_int32, [c_void_p, c_int32, c_int32, c_int32, c_void_p]),
     "fdcap_opt_sync": (c_int32, [c_void_p, c_void_p]),
+    "fdcap_opt_run": (c_int32, [c_void_p, c_int32, c_int32, c_int32, c_int32, c_int32, c_void_p, c_int32, c_int32, c_void_p, c_void_p]),
     "fdcap_comm_unique_id": (c_int32, [c_void_p]),
     "fdcap_comm_create": (c_int32, [c_void_p, c_void_p, c_int32, c_int32]),
     "fdcap_comm_destroy": (c_int32, [c_void_p]),

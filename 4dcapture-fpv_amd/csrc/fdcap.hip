@@ -3134,6 +3134,51 @@ int fdcap_opt_exchange(fdcap_ctx* c, int32_t ii, int32_t P, void* stream) {
     return fdcap_opt_unpack_and_step_scale(c, ii, P, c->xch_all.p, c->comm.rank, c->comm.world, stream);
 }
 
+// The loop :560-593 itself, iterations [ii0, ii1) of a fit of num_iter, in ONE call (r4): what FittingOP.fitting's Python `for` issues --
+// every iteration but the fit's last as fdcap_opt_backward_and_step, the last as fdcap_opt_backward + fdcap_opt_step; a sharded
+// context (which must hold a communicator) as fdcap_opt_backward + fdcap_opt_exchange.  Logging iterations (log_every > 0:
+// ii % log_every == 0, and the fit's last) write their partial sums to consecutive rows of hist_d [hist_rows][FDCAP_NUM_LOSSES]
+// (device memory, filled without a host sync; *n_logged rows used).  flags bit 0: every optimiser step as its own launch;
+// bit 1: the exchange tail even though the context holds the whole clip (a one-rank group: tests, probes).
+// Nothing here waits for the device: the call returns when the launches are enqueued.
+int fdcap_opt_run(fdcap_ctx* c, int32_t ii0, int32_t ii1, int32_t num_iter, int32_t P, int32_t log_every, double* hist_d,
+                  int32_t hist_rows, int32_t flags, int32_t* n_logged, void* stream) {
+    if (n_logged) *n_logged = 0;
+    if (!c || !c->opt) return FDCAP_E_STATE;
+    if (ii0 < 0 || ii1 < ii0 || ii1 > num_iter || log_every < 0) return FDCAP_E_ARG;
+    OptState* o = c->opt;
+    const fdcap_opt_config& cf = o->cfg;
+    const bool sharded = (flags & 2) != 0 || !(cf.frame0 == 0 && cf.n_local == cf.n_total);
+    if (sharded && !c->comm.comm) return FDCAP_E_STATE;
+    double* const keep = o->losses.p;
+    int k = 0, e = 0;
+    for (int ii = ii0; ii < ii1 && !e; ++ii) {
+        const bool do_log = log_every > 0 && (ii % log_every == 0 || ii == num_iter - 1);
+        if (do_log) {
+            if (!hist_d || k >= hist_rows) { e = FDCAP_E_ARG; break; }      // (a stretch without logging iterations needs no history)
+            e = fdcap_opt_set_loss_output(c, hist_d + (size_t)k * FDCAP_NUM_LOSSES);
+            if (e) break;
+            ++k;
+        }
+        const int lt = do_log ? 2 : 0;
+        if (sharded) {
+            e = fdcap_opt_backward(c, ii, P, lt, stream);
+            if (!e) e = fdcap_opt_exchange(c, ii, P, stream);
+        } else if (!(flags & 1) && ii + 1 < num_iter) {
+            e = fdcap_opt_backward_and_step(c, ii, P, lt, stream);
+        } else {
+            e = fdcap_opt_backward(c, ii, P, lt, stream);
+            if (!e) e = fdcap_opt_step(c, ii, P, stream);
+        }
+    }
+    if (k) {                                            // (never leave the library pointing into the caller's history)
+        const int e2 = fdcap_opt_set_loss_output(c, keep);
+        if (!e) e = e2;
+    }
+    if (n_logged) *n_logged = k;
+    return e;
+}
+
 // Sum of n doubles over the ranks, in place (the logged loss partial sums; d loss / d scale never travels this way).
 int fdcap_comm_allreduce_f64(fdcap_ctx* c, double* buf_d, int32_t n, void* stream) {
     if (!c || !buf_d || n <= 0) return FDCAP_E_ARG;

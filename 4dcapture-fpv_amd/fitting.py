@@ -349,8 +349,55 @@ class FittingOP:
                 self._append_log(log, logged[flushed + k], logged[flushed + k] >= P, rows[k])
             flushed = upto
 
+        # The loop inside the library (fdcap_opt_run: one C call per stretch of iterations between two things THIS side has to do --
+        # a verbose flush, a snapshot, a finite check, a checkpoint; none of them in a plain fit: one call for all 500) wherever the
+        # iteration is C calls only: one rank, or ranks exchanging through the library's communicator.  FDCAP_C_LOOP=0 keeps the
+        # Python `for` below (same calls in the same order: same bits).
+        c_loop = os.environ.get("FDCAP_C_LOOP", "1") != "0" and mode != "dct" and (not multi or self._c_comm)
+        if c_loop:
+            import ctypes
+            n_done = ctypes.c_int32(0)
+            st = capi.current_stream()
+
+            def is_log(i):
+                return bool(log_every) and (i % log_every == 0 or i == self.num_iter - 1)
+
+            ii = ii0
+            try:
+                while ii < self.num_iter:
+                    # the stretch [ii, end): ends after the first iteration that leaves this side something to do
+                    end, pending_rows = ii, len(logged) - flushed
+                    while end < self.num_iter:
+                        end += 1
+                        pending_rows += 1 if is_log(end - 1) else 0
+                        if (end in snapshot_at or (check_finite_every and end % check_finite_every == 0) or
+                                (checkpoint_every and end % checkpoint_every == 0 and end < self.num_iter) or
+                                (flush_in_loop and is_log(end - 1) and pending_rows >= VERBOSE_FLUSH)):
+                            break
+                    rows = [i for i in range(ii, end) if is_log(i)]
+                    k0 = len(logged)
+                    capi.check(lib.fdcap_opt_run(h, ii, end, self.num_iter, P, int(log_every or 0),
+                                                 capi.dptr(hist[k0]) if rows else None, len(rows), (0 if defer else 1) | (2 if multi else 0),
+                                                 ctypes.byref(n_done), st), "fdcap_opt_run")
+                    assert n_done.value == len(rows)
+                    logged.extend(rows)
+                    last = end - 1
+                    if flush_in_loop and is_log(last) and len(logged) - flushed >= VERBOSE_FLUSH:
+                        flush(len(logged))
+                    if end in snapshot_at:
+                        capi.check(lib.fdcap_opt_sync(h, st), "fdcap_opt_sync")
+                        nl_ = self.shard.n_local
+                        self.snapshots[end] = (self._rows_x[2:2 + nl_].clone(), self._scale.clone(), self._rows_cam[2:2 + nl_].clone())
+                    if check_finite_every and end % check_finite_every == 0:
+                        self._check_finite(last)
+                    if checkpoint_every and end % checkpoint_every == 0 and end < self.num_iter:
+                        self._save_checkpoint(checkpoint_path, end)
+                    ii = end
+            finally:
+                if logged:                                   # (fdcap_opt_run re-registers the old output itself; after an error, make sure)
+                    capi.check(lib.fdcap_opt_set_loss_output(h, capi.dptr(self._losses)), "fdcap_opt_set_loss_output")
         try:
-            for ii in range(ii0, self.num_iter if mode != "dct" else 0):                        # :560
+            for ii in range(ii0, self.num_iter if (mode != "dct" and not c_loop) else 0):       # :560
                 do_log = bool(log_every) and (ii % log_every == 0 or ii == self.num_iter - 1)
                 st = capi.current_stream()
                 if tune is not None:                     # iterations ii0+2..9 plain, ii0+10..17 with the forward ahead

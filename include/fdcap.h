@@ -206,6 +206,16 @@ int fdcap_opt_step(fdcap_ctx* ctx, int32_t ii, int32_t first_phase2_iter, void* 
  * workgroup (losses_d complete when this call's work is).  Sharded runs and mode 'dct' take the two-call path, silently. */
 int fdcap_opt_backward_and_step(fdcap_ctx* ctx, int32_t ii, int32_t first_phase2_iter, int32_t log_terms, void* stream);
 int fdcap_opt_sync(fdcap_ctx* ctx, void* stream);
+/* The loop :560-593 itself -- iterations [ii0, ii1) of a fit of num_iter iterations -- in ONE call (r4): the sequence of the calls
+ * above that FittingOP.fitting issues (fdcap_opt_backward_and_step; the fit's last iteration as fdcap_opt_backward + fdcap_opt_step;
+ * on a sharded context, which must hold a communicator, fdcap_opt_backward + fdcap_opt_exchange), so the same bits.  Logging
+ * iterations (log_every > 0: ii % log_every == 0, and ii == num_iter - 1; the reference prints every iteration) leave their partial
+ * sums in consecutive rows of hist_d [hist_rows][FDCAP_NUM_LOSSES] on the device, *n_logged of them, with no host sync; the output
+ * registered before the call is registered again after it.  flags bit 0: every optimiser step as its own launch; bit 1: the
+ * exchange tail although the context holds the whole clip (a communicator of one rank).  Returns when the
+ * work is enqueued.  A caller with something to do between iterations (snapshots, checkpoints, a finite check) calls it per stretch. */
+int fdcap_opt_run(fdcap_ctx* ctx, int32_t ii0, int32_t ii1, int32_t num_iter, int32_t first_phase2_iter, int32_t log_every,
+                  double* hist_d, int32_t hist_rows, int32_t flags, int32_t* n_logged, void* stream);
 /* Checkpoint / resume (the reference only ever writes its final result, :637-653).  The parameters live in the
  * caller's registered tensors; these move the rest of the optimiser state -- Adam's moments of the owned rows:
  * state_d [fdcap_opt_state_len()] floats = [m_x n_local*78 | v_x | m_cam n_local*16 | v_cam | m_scale | v_scale].

@@ -552,6 +552,53 @@ def test_deferred_optimiser_step_gives_the_same_bits(mode, legacy, log_every):
             np.testing.assert_array_equal(np.asarray(la[k], dtype=np.float64), np.asarray(lb[k], dtype=np.float64), err_msg=k)
 
 
+@pytest.mark.parametrize("mode,log_every,extras", [("global", 0, False), ("global", 1, True), ("global", 7, True), ("local", 1, False)])
+def test_the_loop_inside_the_library_gives_the_same_bits(mode, log_every, extras, tmp_path, capsys):
+    """fdcap_opt_run (r4): the loop :560-593 as ONE C call per stretch of iterations -- the Python `for` (FDCAP_C_LOOP=0) issues the
+    same entry points in the same order, so parameters, log, snapshots and checkpoints agree bit for bit.  extras: everything that
+    cuts the loop into stretches at once -- snapshots, a finite check every 5 iterations, a checkpoint every 11, and a verbose fit
+    long enough (120 iterations) for in-loop flushes of the loss history."""
+    import dataclasses
+    outs = []
+    for flag in ("0", "1"):
+        os.environ["FDCAP_C_LOOP"] = flag
+        try:
+            n = 23
+            bm = synth.make_body_model(300, seed=92)
+            vp = synth.make_vposer(seed=93)
+            clip = synth.make_clip(n, seed=94)
+            scene = synth.make_scene(5000, seed=95)
+            left, right = synth.make_contact_ids(bm.v_template, per_part=16, seed=96)
+            fop = FittingOP({"num_iter": 120 if extras else 30}, {}, n, body_model=bm, vposer=vp, scene_verts=scene,
+                            contact_ids=np.concatenate([left, right]), camera_ext=read_camerapose(clip.camerapose_lines), n_left=len(left))
+            kw = {}
+            if extras:
+                fop.verbose = True
+                kw = dict(snapshot_at=[1, 50, 97, 120], check_finite_every=5, checkpoint_every=11, checkpoint_path=str(tmp_path / f"ck{flag}.npz"))
+            body, scale, cam = fop.fitting(torch.tensor(clip.body_params).cuda(), mode, log_every=log_every, **kw)
+            printed = capsys.readouterr().out
+            ck = dict(np.load(tmp_path / f"ck{flag}.npz")) if extras else {}
+            outs.append((body.clone(), float(scale), cam.clone(), dataclasses.asdict(fop.log) if log_every else {},
+                         {k: tuple(t.clone() for t in v) for k, v in fop.snapshots.items()}, ck, printed))
+            fop.close()
+        finally:
+            os.environ.pop("FDCAP_C_LOOP")
+    a, b = outs
+    assert torch.equal(a[0], b[0]) and a[1] == b[1] and torch.equal(a[2], b[2])
+    assert a[3].keys() == b[3].keys()
+    for k in a[3]:
+        np.testing.assert_array_equal(np.asarray(a[3][k], dtype=np.float64), np.asarray(b[3][k], dtype=np.float64), err_msg=k)
+    assert sorted(a[4]) == sorted(b[4]) == ([1, 50, 97, 120] if extras else [])
+    for k in a[4]:
+        assert all(torch.equal(x, y) for x, y in zip(a[4][k], b[4][k])), k
+    assert a[5].keys() == b[5].keys()
+    for k in a[5]:
+        np.testing.assert_array_equal(a[5][k], b[5][k], err_msg=k)
+    if extras:
+        assert int(a[5]["next_iter"]) == 110                       # (the last checkpoint before the end)
+        assert a[6] == b[6] and a[6].count("[INFO][fitting] iter=") == len(a[3]["iters"])
+
+
 @pytest.mark.parametrize("n,per_part", [(48, 40), (5, 250)])
 def test_vector_staged_skinning_backward_equals_the_scalar_kernel(n, per_part):
     """skin_bwd_vec_kernel (16-byte staging through LDS, packed per-vertex constants) evaluates the same terms in the same

@@ -36,12 +36,26 @@ def run(label, body_fn):
 
 
 BIG = 10 ** 6
+
+
+def run_c_loop(label, flags=0):
+    import ctypes
+    torch.cuda.synchronize()
+    nl = ctypes.c_int32(0)
+    t0 = time.perf_counter()
+    capi.check(lib.fdcap_opt_run(h, 0, 400, BIG, BIG, 0, None, 0, flags, ctypes.byref(nl), capi.current_stream()), "run")
+    t1 = time.perf_counter(); torch.cuda.synchronize(); t2 = time.perf_counter()
+    capi.check(lib.fdcap_opt_sync(h, capi.current_stream()), "sync")
+    print(f"frames {N} {label}: host issued 400 phase-1 iterations in {1e3*(t1-t0):.1f} ms ({(t1-t0)*1e6/400:.1f} us/iter), GPU done after {1e3*(t2-t0):.1f} ms ({(t2-t0)*1e6/400:.1f} us/iter)", flush=True)
+
+
 if group is None:
     def two_calls(ii, st):
         capi.check(lib.fdcap_opt_backward(h, ii, BIG, 0, st), "b")
         capi.check(lib.fdcap_opt_step(h, ii, BIG, st), "s")
     run("one GPU, fdcap_opt_backward + fdcap_opt_step (r3: 10 launches, 2 calls)", two_calls)
     run("one GPU, fdcap_opt_backward_and_step (r4: 9 launches, 1 call)", lambda ii, st: capi.check(lib.fdcap_opt_backward_and_step(h, ii, BIG, 0, st), "bs"))
+    run_c_loop("one GPU, fdcap_opt_run (r4: the loop in the library, ONE call for the 400 iterations)")
 else:
     def torch_tail(overlap):
         def f(ii, st):
@@ -60,4 +74,5 @@ else:
     if fop._c_comm:
         run("one-rank RCCL group, fdcap_opt_exchange: ncclAllGather on the compute stream from C (r4)", c_tail)
         run("one-rank RCCL group, fdcap_opt_exchange again", c_tail)
+        run_c_loop("one-rank RCCL group, fdcap_opt_run (backward + fdcap_opt_exchange per iteration, one call for the 400)", 2)
     dist.destroy_process_group()
