@@ -49,6 +49,29 @@ def first_phase2_iter(num_iter: int) -> int:
     return int(math.ceil(num_iter * PHASE_SPLIT - 1e-12))
 
 
+def is_logging_iteration(ii: int, num_iter: int, log_every: int) -> bool:
+    """Every log_every-th iteration and the fit's last one (the reference prints every iteration: log_every = 1)."""
+    return bool(log_every) and (ii % log_every == 0 or ii == num_iter - 1)
+
+
+def stretch_end(ii: int, num_iter: int, log_every: int = 0, snapshot_at=frozenset(), check_finite_every: int = 0,
+                checkpoint_every: int = 0, flush_every: int = 0, unflushed_rows: int = 0) -> int:
+    """The loop runs inside the library (fdcap_opt_run) in stretches [ii, end): `end` is the number of iterations done when this
+    side next has something to do -- a snapshot after `end` steps, a finite check or a checkpoint every k-th iteration (no
+    checkpoint after the last one), or a read-back of the loss history once `flush_every` logged rows wait (0: never inside the
+    loop; `unflushed_rows` wait already) -- else num_iter.  Pure host logic (tests/test_host_math.py)."""
+    end, rows = ii, unflushed_rows
+    while end < num_iter:
+        end += 1
+        logged = is_logging_iteration(end - 1, num_iter, log_every)
+        rows += 1 if logged else 0
+        if (end in snapshot_at or (check_finite_every and end % check_finite_every == 0) or
+                (checkpoint_every and end % checkpoint_every == 0 and end < num_iter) or
+                (flush_every and logged and rows >= flush_every)):
+            break
+    return end
+
+
 def find_outliers(x78: np.ndarray):
     """init() :459-487.  x78 [N,78] fp32 (6D form).  Returns (idx1 outlier rows, pos nearest
     inlier for each, ties -> lower index).  Generalised from the hard-coded 300 to N."""
@@ -360,20 +383,14 @@ class FittingOP:
             st = capi.current_stream()
 
             def is_log(i):
-                return bool(log_every) and (i % log_every == 0 or i == self.num_iter - 1)
+                return is_logging_iteration(i, self.num_iter, log_every)
 
             ii = ii0
             try:
                 while ii < self.num_iter:
                     # the stretch [ii, end): ends after the first iteration that leaves this side something to do
-                    end, pending_rows = ii, len(logged) - flushed
-                    while end < self.num_iter:
-                        end += 1
-                        pending_rows += 1 if is_log(end - 1) else 0
-                        if (end in snapshot_at or (check_finite_every and end % check_finite_every == 0) or
-                                (checkpoint_every and end % checkpoint_every == 0 and end < self.num_iter) or
-                                (flush_in_loop and is_log(end - 1) and pending_rows >= VERBOSE_FLUSH)):
-                            break
+                    end = stretch_end(ii, self.num_iter, log_every, snapshot_at, check_finite_every, checkpoint_every,
+                                      VERBOSE_FLUSH if flush_in_loop else 0, len(logged) - flushed)
                     rows = [i for i in range(ii, end) if is_log(i)]
                     k0 = len(logged)
                     capi.check(lib.fdcap_opt_run(h, ii, end, self.num_iter, P, int(log_every or 0),

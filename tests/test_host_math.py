@@ -272,3 +272,46 @@ def test_host_trajectory_matches_reference_golden(golden_dir, name):
     P = first_phase2_iter(num_iter)
     assert np.all(np.abs(0.1 * logs[:P, 3] / (N * nc) - g["log"][:P, 4]) <= tol[:P])
     assert np.all(np.abs(logs[P:, 4] / ((N - 1) * 69) - g["log"][P:, 5]) <= tol[P:])
+
+
+def test_stretches_of_the_library_side_loop_stop_where_the_python_loop_acts():
+    """fitting.stretch_end plans the fdcap_opt_run calls: its stops must be exactly the iterations after which the plain
+    Python `for` (FDCAP_C_LOOP=0) does something besides issuing the iteration -- a verbose flush, a snapshot, a finite check, a
+    checkpoint -- simulated here event by event for a grid of settings; a plain fit is one stretch."""
+    from fdcap_amd.fitting import VERBOSE_FLUSH, is_logging_iteration, stretch_end
+    assert stretch_end(0, 500) == 500 and stretch_end(0, 500, log_every=1) == 500 and stretch_end(137, 500, log_every=3) == 500
+    rng = np.random.default_rng(0)
+    for trial in range(60):
+        num_iter = int(rng.integers(1, 160))
+        log_every = int(rng.choice([0, 1, 1, 2, 7]))
+        snaps = frozenset(int(k) for k in rng.integers(1, num_iter + 1, size=int(rng.integers(0, 4))))
+        cf = int(rng.choice([0, 0, 3, 10]))
+        ck = int(rng.choice([0, 0, 4, 11]))
+        fl = int(rng.choice([0, 5, VERBOSE_FLUSH]))
+        ii0 = int(rng.integers(0, num_iter))
+        # the Python loop: after iteration ii, does it act?
+        stops, logged, flushed = [], 0, 0
+        for ii in range(ii0, num_iter):
+            do_log = is_logging_iteration(ii, num_iter, log_every)
+            logged += 1 if do_log else 0
+            acts = False
+            if fl and do_log and logged - flushed >= fl:
+                flushed = logged
+                acts = True
+            if ii + 1 in snaps or (cf and (ii + 1) % cf == 0) or (ck and (ii + 1) % ck == 0 and ii + 1 < num_iter):
+                acts = True
+            if acts:
+                stops.append(ii + 1)
+        if not stops or stops[-1] != num_iter:
+            stops.append(num_iter)
+        # the stretches
+        got, ii, logged, flushed = [], ii0, 0, 0
+        while ii < num_iter:
+            end = stretch_end(ii, num_iter, log_every, snaps, cf, ck, fl, logged - flushed)
+            assert ii < end <= num_iter
+            logged += sum(1 for i in range(ii, end) if is_logging_iteration(i, num_iter, log_every))
+            if fl and is_logging_iteration(end - 1, num_iter, log_every) and logged - flushed >= fl:
+                flushed = logged
+            got.append(end)
+            ii = end
+        assert got == stops, (trial, num_iter, log_every, sorted(snaps), cf, ck, fl, ii0, got, stops)
