@@ -119,9 +119,16 @@ template <class Sync>
 FDC_HD void pose_forward(const PoseModel& pm, const float* x, const float* o, const float* cam_ext,
                          float scale, PoseScratch& sc, float* Rm, float* PF, float* Jrest, float* G,
                          float* A, float* M, float* Jw, int tid, int nthr, Sync sync,
-                         const float* aa22 = nullptr) {
-    FDC_FR_STAMP(0, 1);
-    for (int j = tid; j < NJ; j += nthr) {
+                         const float* aa22 = nullptr, int split = 0) {
+    // split = 1 (the staged GPU kernels, r4): THREE waves call this, tid 0..191 with nthr = 64.  The kinematic chain stays one
+    // wave's job; around it the independent pieces run side by side on the workgroup's other SIMDs instead of one after the
+    // other in one lone wave (~5.4 cycles per instruction whatever the SIMD could issue): before the chain the 6D / axis-angle
+    // rotations of the body joints, the hand joints' PCA pose + Rodrigues, and the joint regression; during the chain the
+    // outputs that only need those (Rm, PF, Jrest); after it A / G on one wave and the world joints on another.  Every number
+    // is computed by the same expression as before: same bits.
+    const int wv = split ? (tid >> 6) : 0;
+    const int ln = split ? (tid & 63) : tid;
+    auto joint_rotation = [&](int j) {
         M3 R;
         // aa22 (operator-level API only): global_orient + 21 body joints given as axis-angle
         if (aa22 && j <= 21) R = rodrigues_forward(v3(aa22[3 * j], aa22[3 * j + 1], aa22[3 * j + 2]));
@@ -130,13 +137,34 @@ FDC_HD void pose_forward(const PoseModel& pm, const float* x, const float* o, co
         else if (j < 25) R = m3_identity();          // jaw / eyes: zero Parameters, never optimised
         else R = rodrigues_forward(hand_aa(pm, x, j));
         store_m3(sc.R[j], R);
+    };
+    auto joint_rest = [&](int j) {
         for (int c = 0; c < 3; ++c) {
             float acc = pm.Jt[3 * j + c];
             for (int l = 0; l < NBETA; ++l) acc += pm.Jd[(3 * j + c) * NBETA + l] * x[X_BETAS + l];
             sc.J[j][c] = acc;
         }
+    };
+    FDC_FR_STAMP(0, 1);
+    if (split) {
+        if (wv == 0) { if (ln < 25) joint_rotation(ln); }
+        else if (wv == 1) { if (ln + 25 < NJ) joint_rotation(ln + 25); }
+        else if (ln < NJ) joint_rest(ln);
+    } else {
+        for (int j = tid; j < NJ; j += nthr) { joint_rotation(j); joint_rest(j); }
     }
     sync();
+    if (split) {
+        // while the first wave walks the chain: what needs only the rotations and rest joints
+        if (wv == 1 && ln < NJ) {
+            const int j = ln;
+            if (Rm) for (int e = 0; e < 9; ++e) Rm[9 * j + e] = sc.R[j][e];
+            if (PF && j >= 1)
+                for (int e = 0; e < 9; ++e) PF[9 * (j - 1) + e] = sc.R[j][e] - ((e == 0 || e == 4 || e == 8) ? 1.f : 0.f);
+        }
+        if (wv == 2 && ln < NJ && Jrest) for (int c = 0; c < 3; ++c) Jrest[3 * ln + c] = sc.J[ln][c];
+        if (wv != 0) tid = 1 << 20;                      // (no joint in the chain below; these waves only meet its barrier)
+    }
     FDC_FR_STAMP(0, 2);
 #if defined(__HIP_DEVICE_COMPILE__)
     if (nthr == 64 && pm.depth != nullptr) {
@@ -183,6 +211,25 @@ FDC_HD void pose_forward(const PoseModel& pm, const float* x, const float* o, co
     M3 MR; V3 Mt;
     world_matrix(cam_ext, x, scale, &MR, &Mt);
     V3 transl = v3(x[X_TRANSL], x[X_TRANSL + 1], x[X_TRANSL + 2]);
+    if (split) {
+        if (wv == 0 && ln < NJ) {
+            const int j = ln;
+            M3 GR = g_rot(sc.G[j]);
+            V3 Gt = g_trn(sc.G[j]);
+            V3 Jj = v3(sc.J[j][0], sc.J[j][1], sc.J[j][2]);
+            if (A) { float a12[12]; g_store(a12, GR, Gt - m3_vec(GR, Jj)); store12(A + 12 * j, a12); }
+            if (G) store12(G + 12 * j, sc.G[j]);
+        }
+        if (wv == 1) {
+            if (Jw && ln < NJW) {
+                V3 w = world_joint(MR, Mt, g_trn(sc.G[ln]), transl);
+                Jw[3 * ln] = w.x; Jw[3 * ln + 1] = w.y; Jw[3 * ln + 2] = w.z;
+            }
+            if (M && ln == 0) g_store(M, MR, Mt);
+        }
+        FDC_FR_STAMP(0, 4);
+        return;
+    }
     for (int j = tid; j < NJ; j += nthr) {
         M3 GR = g_rot(sc.G[j]);
         V3 Gt = g_trn(sc.G[j]);
@@ -217,7 +264,16 @@ FDC_HD void pose_backward(const PoseModel& pm, const float* x, const float* o, c
                           const float* dsv, const float* dbeta_v, const float* dtransl_v,
                           PoseScratch& sc, float* dx, float* dO, float* dcam_ext, float* dscale,
                           int tid, int nthr, Sync sync, const float* aa22 = nullptr, float* daa22 = nullptr,
-                          const float* dJb = nullptr) {
+                          const float* dJb = nullptr, int split = 0) {
+    // split = 1 (the optimiser's staged kernel, r4): THREE waves call this, tid 0..191 with nthr = 64.  The second wave idles
+    // through the chain (it only meets the barriers) and then forms everything of the tail reductions that does not need the
+    // rotation gradients -- d betas, d M, d transl, the camera row -- WHILE the first wave runs the body joints' rotation backward
+    // and the third the fingers' (6D and Rodrigues: two code paths one wave would walk one after the other):
+    // independent instruction streams of one lone wave each, now side by side (a lone wave issues one VALU
+    // instruction per ~5.4 cycles: a second wave on the workgroup's next SIMD costs the first nothing).  Same terms in the same
+    // order: same bits.
+    const int tid_all = tid;
+    if (split && tid >= 64) tid = 1 << 20;              // (the second wave: no joint, no row -- every loop below is empty for it)
     FDC_FR_STAMP(1, 1);
     M3 MR; V3 Mt;
     world_matrix(cam_ext, x, scale, &MR, &Mt);
@@ -333,37 +389,18 @@ FDC_HD void pose_backward(const PoseModel& pm, const float* x, const float* o, c
     for (int i = tid; i < 90; i += nthr) (&sc.daa[0][0])[i] = 0.f;
     sync();
     FDC_FR_STAMP(1, 4);
-    for (int j = tid; j < NJ; j += nthr) {
-        // rel_j = J_j - J_parent
+    // rel_j = J_j - J_parent: d J_j = own + drel_j - the children's drel (split: the second wave's job, below)
+    auto joint_offset_grad = [&](int j) {
         V3 dJ = v3(sc.dJ[j][0] + sc.drel[j][0], sc.dJ[j][1] + sc.drel[j][1], sc.dJ[j][2] + sc.drel[j][2]);
         for (int ci = pm.child_start[j]; ci < pm.child_start[j + 1]; ++ci) {
             int c = pm.child_list[ci];
             dJ = dJ - v3(sc.drel[c][0], sc.drel[c][1], sc.drel[c][2]);
         }
         sc.dJ[j][0] = dJ.x; sc.dJ[j][1] = dJ.y; sc.dJ[j][2] = dJ.z;
-        M3 dR = load_m3(sc.dR[j]);
-        if (dPF && j >= 1) for (int e = 0; e < 9; ++e) dR.m[e] += dPF[9 * (j - 1) + e];
-        if (aa22 && j <= 21) {
-            V3 d = rodrigues_backward(v3(aa22[3 * j], aa22[3 * j + 1], aa22[3 * j + 2]), dR);
-            daa22[3 * j] = d.x; daa22[3 * j + 1] = d.y; daa22[3 * j + 2] = d.z;
-        } else if (j == 0) {
-            GsCache c; gs_forward(x + X_SIXD, 1, &c);
-            float d6[6]; gs_backward(c, dR, d6, 1);
-            for (int e = 0; e < 6; ++e) dx[X_SIXD + e] += d6[e];
-        } else if (j <= 21) {
-            GsCache c; gs_forward(o + 6 * (j - 1), 1, &c);
-            gs_backward(c, dR, dO + 6 * (j - 1), 1);
-        } else if (j >= 25) {
-            V3 d = rodrigues_backward(hand_aa(pm, x, j), dR);
-            int h = (j - 25) / 15, f = (j - 25) % 15;
-            sc.daa[h][3 * f] = d.x; sc.daa[h][3 * f + 1] = d.y; sc.daa[h][3 * f + 2] = d.z;
-        }
-    }
-    sync();
-    FDC_FR_STAMP(1, 5);
-    // small per-frame reductions with a fixed summation order, in two steps so that no thread walks more than ~30 terms
-    // (one output element per thread made thread t < 10 sum 165 products for d betas and one thread 276 terms for d M)
-    for (int t = tid; t < 6 * NBETA + 12; t += nthr) {
+    };
+    // the small per-frame reductions, in two steps so that no thread walks more than ~30 terms (one output element per thread made
+    // thread t < 10 sum 165 products for d betas and one thread 276 terms for d M); fixed summation order
+    auto reduce_step1 = [&](int t) {
         if (t < 6 * NBETA) {
             const int part = t / NBETA, b = t % NBETA;
             float acc = 0.f;
@@ -376,14 +413,13 @@ FDC_HD void pose_backward(const PoseModel& pm, const float* x, const float* o, c
             for (int j = 0; j < NJW; ++j) acc += sc.dMj[j][e];
             sc.dMs[e] = acc;
         }
-    }
-    sync();
-    for (int t = tid; t < 64; t += nthr) {
+    };
+    auto reduce_step2 = [&](int t) {
         if (t < NBETA) {
             float acc = dbeta_v ? dbeta_v[t] : 0.f;
             for (int part = 0; part < 6; ++part) acc += sc.red[part][t];
             dx[X_BETAS + t] += acc;
-        } else if (t < NBETA + 24) {
+        } else if (t < NBETA + 24) {                      // (needs the fingers' rotation gradients)
             int i = t - NBETA, h = i / 12, ii = i % 12;
             const float* comp = pm.hand_comp + (h * 12 + ii) * 45;
             float acc = 0.f;
@@ -407,6 +443,54 @@ FDC_HD void pose_backward(const PoseModel& pm, const float* x, const float* o, c
             g_store(dcam_ext, dER, dMt);
             dcam_ext[12] = dcam_ext[13] = dcam_ext[14] = dcam_ext[15] = 0.f;   // bottom row never used
         }
+    };
+#if defined(__HIP_DEVICE_COMPILE__)
+    if (split && tid_all >= 64 && tid_all < 128) {
+        // the second wave, beside the first wave's rotation backward: a wave's LDS operations execute in order, so its own
+        // hand-overs need a compiler barrier only
+        const int l = tid_all - 64;
+        if (l < NJ) joint_offset_grad(l);
+        __builtin_amdgcn_wave_barrier();
+        reduce_step1(l);
+        if (l + 64 < 6 * NBETA + 12) reduce_step1(l + 64);
+        __builtin_amdgcn_wave_barrier();
+        if (l < NBETA || (l >= NBETA + 24 && l <= NBETA + 24 + 3)) reduce_step2(l);
+    }
+#endif
+    auto rot_backward = [&](int j) {
+        M3 dR = load_m3(sc.dR[j]);
+        if (dPF && j >= 1) for (int e = 0; e < 9; ++e) dR.m[e] += dPF[9 * (j - 1) + e];
+        if (aa22 && j <= 21) {
+            V3 d = rodrigues_backward(v3(aa22[3 * j], aa22[3 * j + 1], aa22[3 * j + 2]), dR);
+            daa22[3 * j] = d.x; daa22[3 * j + 1] = d.y; daa22[3 * j + 2] = d.z;
+        } else if (j == 0) {
+            GsCache c; gs_forward(x + X_SIXD, 1, &c);
+            float d6[6]; gs_backward(c, dR, d6, 1);
+            for (int e = 0; e < 6; ++e) dx[X_SIXD + e] += d6[e];
+        } else if (j <= 21) {
+            GsCache c; gs_forward(o + 6 * (j - 1), 1, &c);
+            gs_backward(c, dR, dO + 6 * (j - 1), 1);
+        } else if (j >= 25) {
+            V3 d = rodrigues_backward(hand_aa(pm, x, j), dR);
+            int h = (j - 25) / 15, f = (j - 25) % 15;
+            sc.daa[h][3 * f] = d.x; sc.daa[h][3 * f + 1] = d.y; sc.daa[h][3 * f + 2] = d.z;
+        }
+    };
+    if (split) {                                         // the body joints' 6D backward on the first wave, the fingers' Rodrigues backward on the third
+        if (tid_all < 25) rot_backward(tid_all);
+        else if (tid_all >= 128 && tid_all - 128 + 25 < NJ) rot_backward(tid_all - 128 + 25);
+    } else {
+        for (int j = tid; j < NJ; j += nthr) { joint_offset_grad(j); rot_backward(j); }
+    }
+    sync();
+    FDC_FR_STAMP(1, 5);
+    if (split) {                                         // only the hand components are left: 24 sums of 45 products
+        const int t = tid_all - 64 + NBETA;
+        if (tid_all >= 64 && tid_all < 128 && t < NBETA + 24) reduce_step2(t);
+    } else {
+        for (int t = tid; t < 6 * NBETA + 12; t += nthr) reduce_step1(t);
+        sync();
+        for (int t = tid; t < 64; t += nthr) reduce_step2(t);
     }
     FDC_FR_STAMP(1, 6);
 }

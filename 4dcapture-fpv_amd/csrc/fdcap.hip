@@ -239,9 +239,9 @@ __global__ __launch_bounds__(64 * POSE_NW) void pose_fwd_kernel(PoseModel pm, co
         }
     }
     __syncthreads();                                         // (every wave waits for its copies: vmcnt(0) in front of the barrier)
-    if (threadIdx.x >= 64) return;                           // the other waves were only here to issue copies (and step parameters)
+    if (threadIdx.x >= 192) return;                          // the fourth wave was only here to issue copies; three share the arithmetic (pose_forward, split)
 #ifdef FDC_DEBUG_BUFFERS
-    if (!ds.on) {
+    if (!ds.on && threadIdx.x < 64) {
     stage_check(1, pm.Jd, stg.Jd, NJ * 3 * NBETA, r); stage_check(2, pm.hand_comp, stg.hand_comp, 2 * 12 * 45, r);
     stage_check(3, pm.Jt, stg.Jt, NJ * 3, r); stage_check(4, pm.hand_mean, stg.hand_mean, 90, r);
     stage_check(5, X + (size_t)r * XDIM, stg.x, XDIM, r); stage_check(6, CAM + (size_t)r * 16, stg.cam, 16, r);
@@ -254,7 +254,7 @@ __global__ __launch_bounds__(64 * POSE_NW) void pose_fwd_kernel(PoseModel pm, co
 #endif
     const PoseModel pml = stage_pose_model(pm, stg);
     if (PARTS) {
-        for (int e = threadIdx.x; e < ODIM; e += 64) {
+        for (int e = threadIdx.x; e < ODIM; e += 192) {
             const float v = (s_Op[0][e] + s_Op[1][e]) + (s_Op[2][e] + s_Op[3][e]);     // vp_sum_parts' order
             s_O[e] = v;
             O[(size_t)r * ODIM + e] = v;
@@ -267,14 +267,14 @@ __global__ __launch_bounds__(64 * POSE_NW) void pose_fwd_kernel(PoseModel pm, co
                      Rm ? Rm + (size_t)r * NJ * 9 : nullptr, PF ? PF + (size_t)r * NPFX : nullptr,
                      Jrest ? Jrest + (size_t)r * NJ * 3 : nullptr, G ? G + (size_t)r * NJ * 12 : nullptr,
                      A ? A + (size_t)r * NJ * 12 : nullptr, M ? M + (size_t)r * 12 : nullptr,
-                     Jw ? Jw + (size_t)r * NJW * 3 : nullptr, threadIdx.x, 64, SyncBlock(), nullptr);
+                     Jw ? Jw + (size_t)r * NJW * 3 : nullptr, threadIdx.x, 64, SyncBlock(), nullptr, 1);
     } else {
         pose_forward(pml, stg.x, O ? O + (size_t)r * ODIM : nullptr, stg.cam, sc_v, sc,
                      Rm ? Rm + (size_t)r * NJ * 9 : nullptr, PF ? PF + (size_t)r * NPFX : nullptr,
                      Jrest ? Jrest + (size_t)r * NJ * 3 : nullptr, G ? G + (size_t)r * NJ * 12 : nullptr,
                      A ? A + (size_t)r * NJ * 12 : nullptr, M ? M + (size_t)r * 12 : nullptr,
                      Jw ? Jw + (size_t)r * NJW * 3 : nullptr, threadIdx.x, 64, SyncBlock(),
-                     AA ? AA + (size_t)r * 66 : nullptr);
+                     AA ? AA + (size_t)r * 66 : nullptr, 1);
     }
 }
 
@@ -341,12 +341,13 @@ __global__ __launch_bounds__(64 * POSE_NW) void pose_bwd_kernel(PoseModel pm, co
     }
     const float sc_v = *scale;
     __syncthreads();                                         // (every wave waits for its copies: vmcnt(0) in front of the barrier)
-    if (threadIdx.x >= 64) return;                           // the other waves were only here to issue copies
+    if (threadIdx.x >= 192) return;                          // the fourth wave was only here to issue copies; waves 1, 2 stay for their share of pose_backward (split)
     FDC_FR_STAMP(1, 7);
     const PoseModel pml = stage_pose_model(pm, stg);
+    const bool w0 = threadIdx.x < 64;
     if (dPF2) {
         const float* p2 = &sc.dR[0][0];
-        for (int e = threadIdx.x; e < NPFX; e += 64) s_dPF[e] += p2[e];
+        if (w0) for (int e = threadIdx.x; e < NPFX; e += 64) s_dPF[e] += p2[e];
         __syncthreads();
     }
     if (pl.X0) {
@@ -355,27 +356,34 @@ __global__ __launch_bounds__(64 * POSE_NW) void pose_bwd_kernel(PoseModel pm, co
         const int g = pl.frame0 + blockIdx.x;
         const float lmask = s_misc[27];
         float l_rec = 0.f, l_vp = 0.f, l_sm = 0.f, l_ws = 0.f;
-        for (int e = threadIdx.x; e < XDIM; e += 64) {
-            const float xc = stg.x[e];
-            float rec = 0.f, sm = 0.f;
-            s_dx[e] = param_loss_grad(g, pl.n_total, g >= 2 ? s_xn[0][e] : 0.f, g >= 1 ? s_xn[1][e] : 0.f, xc,
-                                      g + 1 < pl.n_total ? s_xn[2][e] : 0.f, g + 2 < pl.n_total ? s_xn[3][e] : 0.f,
-                                      s_x0[e], lmask, pl.w_rec, pl.w_sm, &rec, &sm);
-            l_rec += rec; l_sm += sm;
-            if (e >= X_LATENT && e < X_LATENT + 32) l_vp += xc * xc;
-        }
-        if (pl.world_grad || pl.loss_rows)
-            for (int e = threadIdx.x; e < NJW * 3; e += 64) {
+        // (two waves side by side: the first takes the parameter row's terms, the second the world joints')
+        if (w0) {
+            for (int e = threadIdx.x; e < XDIM; e += 64) {
+                const float xc = stg.x[e];
+                float rec = 0.f, sm = 0.f;
+                s_dx[e] = param_loss_grad(g, pl.n_total, g >= 2 ? s_xn[0][e] : 0.f, g >= 1 ? s_xn[1][e] : 0.f, xc,
+                                          g + 1 < pl.n_total ? s_xn[2][e] : 0.f, g + 2 < pl.n_total ? s_xn[3][e] : 0.f,
+                                          s_x0[e], lmask, pl.w_rec, pl.w_sm, &rec, &sm);
+                l_rec += rec; l_sm += sm;
+                if (e >= X_LATENT && e < X_LATENT + 32) l_vp += xc * xc;
+            }
+            if (pl.loss_rows) {                              // kernel-uniform: logging iterations only
+                l_rec = wave_sum64(l_rec); l_vp = wave_sum64(l_vp); l_sm = wave_sum64(l_sm);
+                if (threadIdx.x == 0) {
+                    float* lr = pl.loss_rows + (size_t)r * LROW;
+                    lr[0] = l_rec; lr[1] = l_vp; lr[2] = l_sm;
+                }
+            }
+        } else if (threadIdx.x < 128 && (pl.world_grad || pl.loss_rows)) {
+            for (int e = threadIdx.x - 64; e < NJW * 3; e += 64) {
                 float ws = 0.f;
                 s_dJw[e] = world_smooth_grad(g, pl.n_total, g >= 1 ? s_jw[0][e] : 0.f, s_jw[1][e], g + 1 < pl.n_total ? s_jw[2][e] : 0.f,
                                              pl.w_ws, &ws);
                 l_ws += ws;
             }
-        if (pl.loss_rows) {                                  // kernel-uniform: logging iterations only
-            l_rec = wave_sum64(l_rec); l_vp = wave_sum64(l_vp); l_sm = wave_sum64(l_sm); l_ws = wave_sum64(l_ws);
-            if (threadIdx.x == 0) {
-                float* lr = pl.loss_rows + (size_t)r * LROW;
-                lr[0] = l_rec; lr[1] = l_vp; lr[2] = l_sm; lr[4] = l_ws;
+            if (pl.loss_rows) {
+                l_ws = wave_sum64(l_ws);
+                if (threadIdx.x == 64) pl.loss_rows[(size_t)r * LROW + 4] = l_ws;
             }
         }
         __syncthreads();
@@ -387,9 +395,10 @@ __global__ __launch_bounds__(64 * POSE_NW) void pose_bwd_kernel(PoseModel pm, co
                   dJw_row, dMv ? s_misc : nullptr,
                   dsv ? s_misc + 12 : nullptr, dbeta_v ? (dPF2 ? s_dPF + NPF : s_misc + 16) : nullptr,
                   dtransl_v ? s_misc + 13 : nullptr, sc, s_dx,
-                  dO + (size_t)r * ODIM, dCAM + (size_t)r * 16, dscale_row + r, threadIdx.x, 64, SyncBlock());
+                  dO + (size_t)r * ODIM, dCAM + (size_t)r * 16, dscale_row + r, threadIdx.x, 64, SyncBlock(),
+                  nullptr, nullptr, nullptr, 1);
     __syncthreads();
-    for (int e = threadIdx.x; e < XDIM; e += 64) dX[(size_t)r * XDIM + e] = s_dx[e];
+    for (int e = threadIdx.x; e < XDIM; e += 192) dX[(size_t)r * XDIM + e] = s_dx[e];
 }
 
 // thread per (frame, vertex), 256-thread workgroups.  Vout layout [rows, nv, 3].  world = 0: body frame (+transl only)
