@@ -38,6 +38,7 @@ struct PoseModel {
     const int* child_start;   // [56] CSR of children
     const int* child_list;    // [54]
     const int* depth = nullptr;   // [55] level of each joint (optional: enables the lane-resident chains of the GPU kernels)
+    const float* tab = nullptr;   // GPU library: every table above as one image in the staging struct's layout (fdcap.hip PoseStage)
     const float* hand_comp;   // [2,12,45]
     const float* hand_mean;   // [2,45]
     int nlevels;
@@ -120,7 +121,7 @@ FDC_HD void pose_forward(const PoseModel& pm, const float* x, const float* o, co
                          float scale, PoseScratch& sc, float* Rm, float* PF, float* Jrest, float* G,
                          float* A, float* M, float* Jw, int tid, int nthr, Sync sync,
                          const float* aa22 = nullptr, int split = 0) {
-    // split = 1 (the staged GPU kernels, r4): THREE waves call this, tid 0..191 with nthr = 64.  The kinematic chain stays one
+    // split = 1 (the staged GPU kernels, r4): FOUR waves call this, tid 0..255 with nthr = 64.  The kinematic chain stays one
     // wave's job; around it the independent pieces run side by side on the workgroup's other SIMDs instead of one after the
     // other in one lone wave (~5.4 cycles per instruction whatever the SIMD could issue): before the chain the 6D / axis-angle
     // rotations of the body joints, the hand joints' PCA pose + Rodrigues, and the joint regression; during the chain the
@@ -146,28 +147,61 @@ FDC_HD void pose_forward(const PoseModel& pm, const float* x, const float* o, co
         }
     };
     FDC_FR_STAMP(0, 1);
-    if (split) {
-        if (wv == 0) { if (ln < 25) joint_rotation(ln); }
+    if (split) {                                         // (global_orient on the fourth wave: its code path is not the body joints', whose wave then walks one path only)
+        if (wv == 0) { if (ln >= 1 && ln < 25) joint_rotation(ln); }
         else if (wv == 1) { if (ln + 25 < NJ) joint_rotation(ln + 25); }
-        else if (ln < NJ) joint_rest(ln);
+        else if (wv == 2) { if (ln < NJ) joint_rest(ln); }
+        else if (ln == 0) joint_rotation(0);
     } else {
         for (int j = tid; j < NJ; j += nthr) { joint_rotation(j); joint_rest(j); }
     }
     sync();
     if (split) {
-        // while the first wave walks the chain: what needs only the rotations and rest joints
-        if (wv == 1 && ln < NJ) {
+        // while three waves walk the chain, the fourth writes what needs only the rotations and rest joints
+        if (wv == 3 && ln < NJ) {
             const int j = ln;
             if (Rm) for (int e = 0; e < 9; ++e) Rm[9 * j + e] = sc.R[j][e];
             if (PF && j >= 1)
                 for (int e = 0; e < 9; ++e) PF[9 * (j - 1) + e] = sc.R[j][e] - ((e == 0 || e == 4 || e == 8) ? 1.f : 0.f);
+            if (Jrest) for (int c = 0; c < 3; ++c) Jrest[3 * j + c] = sc.J[j][c];
         }
-        if (wv == 2 && ln < NJ && Jrest) for (int c = 0; c < 3; ++c) Jrest[3 * ln + c] = sc.J[ln][c];
-        if (wv != 0) tid = 1 << 20;                      // (no joint in the chain below; these waves only meet its barrier)
+        if (wv != 0) tid = 1 << 20;                      // (the generic loops below are the first wave's)
     }
     FDC_FR_STAMP(0, 2);
 #if defined(__HIP_DEVICE_COMPILE__)
-    if (nthr == 64 && pm.depth != nullptr) {
+    if (split && pm.depth != nullptr) {
+        // The chain on three waves (late r4): wave i keeps ROW i of every joint's 3x4 transform -- row i of G_c = (row i of G_p) [R | rel]
+        // + (0, 0, 0, t_p[i]) needs row i of the parent only, so the waves never meet inside the chain, and a level is one 16-byte
+        // read, twelve multiply-adds and one 16-byte write per lane instead of three, thirty-six and three.  Same expressions as
+        // m3_mul / m3_vec element by element.
+        const int j = ln;
+        const bool act = wv < 3 && j < NJ;
+        const int p = act ? pm.parents[j] : -1, dep = act ? pm.depth[j] : -1;
+        const M3 R = act ? load_m3(sc.R[j]) : m3_identity();
+        const V3 Jj = act ? v3(sc.J[j][0], sc.J[j][1], sc.J[j][2]) : v3(0.f, 0.f, 0.f);
+        const V3 rel = (act && p >= 0) ? Jj - v3(sc.J[p][0], sc.J[p][1], sc.J[p][2]) : Jj;
+        const int row = wv < 3 ? wv : 0;
+        for (int L = 0; L < pm.nlevels; ++L) {
+            if (dep == L) {
+                float4 out;
+                if (p < 0) {
+                    out.x = row == 0 ? R.m[0] : row == 1 ? R.m[3] : R.m[6];
+                    out.y = row == 0 ? R.m[1] : row == 1 ? R.m[4] : R.m[7];
+                    out.z = row == 0 ? R.m[2] : row == 1 ? R.m[5] : R.m[8];
+                    out.w = row == 0 ? Jj.x : row == 1 ? Jj.y : Jj.z;
+                } else {
+                    const float4 g = *(const float4*)&sc.G[p][4 * row];
+                    out.x = g.x * R.m[0] + g.y * R.m[3] + g.z * R.m[6];
+                    out.y = g.x * R.m[1] + g.y * R.m[4] + g.z * R.m[7];
+                    out.z = g.x * R.m[2] + g.y * R.m[5] + g.z * R.m[8];
+                    out.w = (g.x * rel.x + g.y * rel.y + g.z * rel.z) + g.w;
+                }
+                *(float4*)&sc.G[j][4 * row] = out;
+            }
+            __builtin_amdgcn_wave_barrier();
+        }
+        sync();
+    } else if (nthr == 64 && pm.depth != nullptr) {
         // One wave per frame, lane j = joint j: the joint's rotation, rest position, parent and level stay in registers and
         // a level costs one hand-over through LDS (read the parent's transform, write one's own) -- the generic loop below
         // re-reads level_start -> order -> parents -> R / J from LDS at every level (measured 970 cycles per level, ten levels).
@@ -265,7 +299,7 @@ FDC_HD void pose_backward(const PoseModel& pm, const float* x, const float* o, c
                           PoseScratch& sc, float* dx, float* dO, float* dcam_ext, float* dscale,
                           int tid, int nthr, Sync sync, const float* aa22 = nullptr, float* daa22 = nullptr,
                           const float* dJb = nullptr, int split = 0) {
-    // split = 1 (the optimiser's staged kernel, r4): THREE waves call this, tid 0..191 with nthr = 64.  The second wave idles
+    // split = 1 (the optimiser's staged kernel, r4): FOUR waves call this, tid 0..255 with nthr = 64.  The second wave idles
     // through the chain (it only meets the barriers) and then forms everything of the tail reductions that does not need the
     // rotation gradients -- d betas, d M, d transl, the camera row -- WHILE the first wave runs the body joints' rotation backward
     // and the third the fingers' (6D and Rodrigues: two code paths one wave would walk one after the other):
@@ -329,7 +363,32 @@ FDC_HD void pose_backward(const PoseModel& pm, const float* x, const float* o, c
     }
     sync();
 #if defined(__HIP_DEVICE_COMPILE__)
-    if (nthr == 64 && pm.depth != nullptr) {
+    if (split && pm.depth != nullptr) {
+        // The subtree sums on three waves (late r4): they are twelve independent sums per joint, wave w takes numbers 4w .. 4w + 3 --
+        // one 16-byte read and four adds per child instead of three and twelve; the waves never meet inside the chain.
+        const int cw = tid_all >> 6, p = tid_all & 63;
+        const bool act = cw < 3 && p < NJ;
+        const int dep = act ? pm.depth[p] : -1;
+        const int c_lo = act ? pm.child_start[p] : 0, nch = act ? pm.child_start[p + 1] - c_lo : 0;
+        const int c0 = nch > 0 ? pm.child_list[c_lo] : 0, c1 = nch > 1 ? pm.child_list[c_lo + 1] : 0, c2 = nch > 2 ? pm.child_list[c_lo + 2] : 0;
+        const int c3 = nch > 3 ? pm.child_list[c_lo + 3] : 0, c4 = nch > 4 ? pm.child_list[c_lo + 4] : 0;
+        const int e0 = 4 * (cw < 3 ? cw : 0);
+        auto add4 = [](float4& a, const float4 b) { a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w; };
+        for (int L = pm.nlevels - 1; L >= 1; --L) {
+            if (dep == L - 1 && nch > 0) {
+                float4 a = *(const float4*)&sc.dG[p][e0];
+                add4(a, *(const float4*)&sc.dG[c0][e0]);
+                if (nch > 1) add4(a, *(const float4*)&sc.dG[c1][e0]);
+                if (nch > 2) add4(a, *(const float4*)&sc.dG[c2][e0]);
+                if (nch > 3) add4(a, *(const float4*)&sc.dG[c3][e0]);
+                if (nch > 4) add4(a, *(const float4*)&sc.dG[c4][e0]);
+                for (int ci = c_lo + 5; ci < c_lo + nch; ++ci) add4(a, *(const float4*)&sc.dG[pm.child_list[ci]][e0]);
+                *(float4*)&sc.dG[p][e0] = a;
+            }
+            __builtin_amdgcn_wave_barrier();
+        }
+        sync();
+    } else if (nthr == 64 && pm.depth != nullptr) {
         // lane p = joint p with its (at most five) children in registers: a level is "add the children's sums to one's own"
         const int p = tid;
         const bool act = p < NJ;
@@ -448,13 +507,20 @@ FDC_HD void pose_backward(const PoseModel& pm, const float* x, const float* o, c
     if (split && tid_all >= 64 && tid_all < 128) {
         // the second wave, beside the first wave's rotation backward: a wave's LDS operations execute in order, so its own
         // hand-overs need a compiler barrier only
-        const int l = tid_all - 64;
+        const int l = tid_all - 64;                     // d betas: needs the joints' offset gradients
         if (l < NJ) joint_offset_grad(l);
         __builtin_amdgcn_wave_barrier();
-        reduce_step1(l);
-        if (l + 64 < 6 * NBETA + 12) reduce_step1(l + 64);
+        if (l < 6 * NBETA) reduce_step1(l);
         __builtin_amdgcn_wave_barrier();
-        if (l < NBETA || (l >= NBETA + 24 && l <= NBETA + 24 + 3)) reduce_step2(l);
+        if (l < NBETA) reduce_step2(l);
+    }
+    if (split && tid_all >= 192) {
+        // the fourth wave, after global_orient's lane (below) or rather around it: d M, d transl and the camera row need nothing
+        // of this phase
+        const int l = tid_all - 192;
+        if (l < 12) reduce_step1(6 * NBETA + l);
+        __builtin_amdgcn_wave_barrier();
+        if (l < 4) reduce_step2(NBETA + 24 + l);
     }
 #endif
     auto rot_backward = [&](int j) {
@@ -476,9 +542,12 @@ FDC_HD void pose_backward(const PoseModel& pm, const float* x, const float* o, c
             sc.daa[h][3 * f] = d.x; sc.daa[h][3 * f + 1] = d.y; sc.daa[h][3 * f + 2] = d.z;
         }
     };
-    if (split) {                                         // the body joints' 6D backward on the first wave, the fingers' Rodrigues backward on the third
-        if (tid_all < 25) rot_backward(tid_all);
-        else if (tid_all >= 128 && tid_all - 128 + 25 < NJ) rot_backward(tid_all - 128 + 25);
+    if (split) {
+        // the 21 body joints' 6D backward on the first wave, the fingers' Rodrigues backward on the third, global_orient (the body
+        // joints' arithmetic on other pointers: another code path, which their wave would walk after its own) on the fourth
+        if (tid_all >= 1 && tid_all < 25) rot_backward(tid_all);
+        else if (tid_all >= 128 && tid_all < 192) { if (tid_all - 128 + 25 < NJ) rot_backward(tid_all - 128 + 25); }
+        else if (tid_all == 192) rot_backward(0);
     } else {
         for (int j = tid; j < NJ; j += nthr) { joint_offset_grad(j); rot_backward(j); }
     }

@@ -65,14 +65,25 @@ struct SyncBlock {
 // took 5.5 k (forward: rotations + joints), 6.5 k (backward: rotation gradients) and 14 k cycles (backward: the serial
 // reductions over Jd / the PCA basis) of 25 k / 42 k-cycle kernels.
 struct alignas(16) PoseStage {
-    float Jd[NJ * 3 * NBETA + 2];   // 1650 (+ padding: the arrays below stay 16-byte aligned)
+    // the static part: ONE contiguous image (fdcap_ctx::pose_tab holds it in exactly this layout, built once per context), so that
+    // it arrives as 13 sixteen-byte copy instructions instead of 24 of mixed sizes (late r4: the batch is bound by the CU's rate
+    // of copy INSTRUCTIONS, ~24 cycles each with four workgroups staging at once, not by bytes)
+    float Jd[NJ * 3 * NBETA + 2];   // 1650 (+ padding: every array stays 16-byte aligned)
     float hand_comp[2 * 12 * 45];   // 1080
     float Jt[NJ * 3 + 3];           // 165
     float hand_mean[90 + 2];
+    int parents[NJ + 1], order[NJ + 1], level_start[MAX_LEVELS + 4], child_start[NJ + 1], child_list[NJ + 1], depth[NJ + 1];
+    // the frame's own rows
     float x[XDIM + 2];
     float cam[16];
-    int parents[NJ + 1], order[NJ + 1], level_start[MAX_LEVELS + 4], child_start[NJ + 1], child_list[NJ + 1], depth[NJ + 1];
 };
+constexpr int PS_STATIC_FLOATS = (NJ * 3 * NBETA + 2) + 2 * 12 * 45 + (NJ * 3 + 3) + 92 + 5 * (NJ + 1) + (MAX_LEVELS + 4);
+static_assert(PS_STATIC_FLOATS % 4 == 0 && offsetof(PoseStage, x) == PS_STATIC_FLOATS * 4, "the static image must end where the frame's rows begin");
+constexpr int PS_STATIC_U16 = PS_STATIC_FLOATS / 4;          // 16-byte units: 823
+// row strides of the forward's per-frame state that the backward stages: padded to 16-byte multiples so a row is 2 / 1 / 1 copy
+// instructions instead of 8 / 3 / 2 (the optimiser's own buffers only: the operator-level workspaces keep the dense strides)
+constexpr int RM_LD = NJ * 9 + 1, JR_LD = NJ * 3 + 3, O_LD = ODIM + 2;       // 496, 168, 128
+static_assert(RM_LD % 4 == 0 && JR_LD % 4 == 0 && O_LD % 4 == 0, "16-byte rows");
 // Staging by LDS-DMA (global_load_lds: global -> LDS without passing through registers; destination = wave-uniform LDS
 // address + lane x size, source per lane).  A freshly launched kernel finds none of its inputs in its L2 and every DEPENDENT
 // round trip at its start costs ~1-2.5 k cycles (s_memtime); with the copies issued back to back and ONE wait in front of the
@@ -142,22 +153,14 @@ constexpr int POSE_NW = 4;
 template <int PART>
 __device__ __forceinline__ void stage_pose_part(const PoseModel& pm, PoseStage& t, const float* __restrict__ xrow,
                                                 const float* __restrict__ camrow, bool rows = true) {
+    // this wave's quarter of the static image (256 units of 16 bytes; the last quarter is short)
+    static_assert(PS_STATIC_U16 <= 4 * 256, "four waves x four trips");
+    constexpr int n = PS_STATIC_U16 - 256 * PART < 256 ? PS_STATIC_U16 - 256 * PART : 256;
+    glds16<(n + 63) / 64>((const char*)pm.tab + 4096 * PART, (char*)&t + 4096 * PART, n);
     if constexpr (PART == 0) {
-        glds16<(PS_NJD4 + 63) / 64>(pm.Jd, t.Jd, PS_NJD4);
-        glds4<1>(pm.Jd + PS_NJD4 * 4, t.Jd + PS_NJD4 * 4, (NJ * 3 * NBETA) % 4);
         if (rows) glds4<1>(camrow, t.cam, 16);
-    } else if constexpr (PART == 1) {
-        glds16<(PS_NHC4 + 63) / 64>(pm.hand_comp, t.hand_comp, PS_NHC4);
-        glds4<3>(pm.Jt, t.Jt, NJ * 3);
-        glds4<2>(pm.hand_mean, t.hand_mean, 90);
-    } else {
+    } else if constexpr (PART == 2) {
         if (rows) glds4<2>(xrow, t.x, XDIM);
-        glds4<1>(pm.parents, t.parents, NJ);
-        glds4<1>(pm.order, t.order, NJ);
-        glds4<1>(pm.child_list, t.child_list, NJ - 1);
-        glds4<1>(pm.depth, t.depth, NJ);
-        glds4<1>(pm.child_start, t.child_start, NJ + 1);
-        glds4<1>(pm.level_start, t.level_start, min(pm.nlevels, MAX_LEVELS) + 1);
     }
 }
 // after the barrier that follows the copies: the model with its tables in LDS
@@ -208,9 +211,12 @@ __global__ __launch_bounds__(64 * POSE_NW) void pose_fwd_kernel(PoseModel pm, co
     if (wave == 0) stage_pose_part<0>(pm, stg, xrow, camrow, !ds.on);
     else if (wave == 1) stage_pose_part<1>(pm, stg, xrow, camrow, !ds.on);
     else if (wave == 2) stage_pose_part<2>(pm, stg, xrow, camrow, !ds.on);
-    else if (PARTS) {                                        // the decoder's partial sums ride in the same batch of copies
+    else {
+        stage_pose_part<3>(pm, stg, xrow, camrow, !ds.on);
+        if (PARTS) {                                         // the decoder's partial sums ride in the same batch of copies
 #pragma unroll
-        for (int q = 0; q < VP_NQ; ++q) glds4<2>(Opart + (size_t)q * part_stride + (size_t)r * ODIM, s_Op[q], ODIM);
+            for (int q = 0; q < VP_NQ; ++q) glds4<2>(Opart + (size_t)q * part_stride + (size_t)r * ODIM, s_Op[q], ODIM);
+        }
     }
     const float sc_v = *scale;
     // A deferred optimiser step (DeferredStep, fdc_loss.h): this frame's row of body_rotation_rec / camera_ext takes its pending
@@ -239,7 +245,7 @@ __global__ __launch_bounds__(64 * POSE_NW) void pose_fwd_kernel(PoseModel pm, co
         }
     }
     __syncthreads();                                         // (every wave waits for its copies: vmcnt(0) in front of the barrier)
-    if (threadIdx.x >= 192) return;                          // the fourth wave was only here to issue copies; three share the arithmetic (pose_forward, split)
+    // (all four waves stay: they share the frame's arithmetic -- pose_forward, split)
 #ifdef FDC_DEBUG_BUFFERS
     if (!ds.on && threadIdx.x < 64) {
     stage_check(1, pm.Jd, stg.Jd, NJ * 3 * NBETA, r); stage_check(2, pm.hand_comp, stg.hand_comp, 2 * 12 * 45, r);
@@ -254,18 +260,18 @@ __global__ __launch_bounds__(64 * POSE_NW) void pose_fwd_kernel(PoseModel pm, co
 #endif
     const PoseModel pml = stage_pose_model(pm, stg);
     if (PARTS) {
-        for (int e = threadIdx.x; e < ODIM; e += 192) {
+        for (int e = threadIdx.x; e < ODIM; e += 256) {
             const float v = (s_Op[0][e] + s_Op[1][e]) + (s_Op[2][e] + s_Op[3][e]);     // vp_sum_parts' order
             s_O[e] = v;
-            O[(size_t)r * ODIM + e] = v;
+            O[(size_t)r * O_LD + e] = v;
         }
         __syncthreads();
     }
     if (PF && threadIdx.x < NBETA) PF[(size_t)r * NPFX + NPF + threadIdx.x] = stg.x[X_BETAS + threadIdx.x];
     if (PARTS) {
         pose_forward(pml, stg.x, s_O, stg.cam, sc_v, sc,
-                     Rm ? Rm + (size_t)r * NJ * 9 : nullptr, PF ? PF + (size_t)r * NPFX : nullptr,
-                     Jrest ? Jrest + (size_t)r * NJ * 3 : nullptr, G ? G + (size_t)r * NJ * 12 : nullptr,
+                     Rm ? Rm + (size_t)r * RM_LD : nullptr, PF ? PF + (size_t)r * NPFX : nullptr,
+                     Jrest ? Jrest + (size_t)r * JR_LD : nullptr, G ? G + (size_t)r * NJ * 12 : nullptr,
                      A ? A + (size_t)r * NJ * 12 : nullptr, M ? M + (size_t)r * 12 : nullptr,
                      Jw ? Jw + (size_t)r * NJW * 3 : nullptr, threadIdx.x, 64, SyncBlock(), nullptr, 1);
     } else {
@@ -302,7 +308,7 @@ __global__ __launch_bounds__(64 * POSE_NW) void pose_bwd_kernel(PoseModel pm, co
     // needs (neighbouring rows: two halo rows exist on either side of every owned row).  Fetched phase by phase -- as
     // pose_backward does for its generic callers -- they were ~8 dependent cold round trips.
     __shared__ __attribute__((aligned(16))) float s_dPF[NPFX];
-    __shared__ float s_O[ODIM + 2], s_Rm[NJ * 9 + 1], s_Jr[NJ * 3 + 3];
+    __shared__ __attribute__((aligned(16))) float s_O[O_LD], s_Rm[RM_LD], s_Jr[JR_LD];
     __shared__ float s_xn[4][XDIM + 2], s_x0[XDIM + 2], s_jw[3][NJW * 3 + 3], s_misc[32];
     __shared__ float s_dx[XDIM + 2];      // the parameter-gradient row: accumulated here (pose_backward adds to it from several
                                           // phases -- read-modify-write round trips on the global row), stored once at the end
@@ -313,35 +319,39 @@ __global__ __launch_bounds__(64 * POSE_NW) void pose_bwd_kernel(PoseModel pm, co
     const float* const camrow = CAM + (size_t)r * 16;
     if (wave == 0) {
         stage_pose_part<0>(pm, stg, xrow, camrow);
-        glds4<(NJ * 9 + 63) / 64>(Rm + (size_t)r * NJ * 9, s_Rm, NJ * 9);
+        glds16<(RM_LD / 4 + 63) / 64>(Rm + (size_t)r * RM_LD, s_Rm, RM_LD / 4);
+        if (pl.X0) {                                         // (the copies are dealt so that every wave issues 12-13 of them)
+            const float* j = pl.Jw + (size_t)r * NJW * 3;
+            glds4<2>(j - NJW * 3, s_jw[0], NJW * 3); glds4<2>(j, s_jw[1], NJW * 3); glds4<2>(j + NJW * 3, s_jw[2], NJW * 3);
+        }
     } else if (wave == 1) {
         stage_pose_part<1>(pm, stg, xrow, camrow);
-        glds4<(NJ * 3 + 63) / 64>(Jrest + (size_t)r * NJ * 3, s_Jr, NJ * 3);
+        glds16<1>(Jrest + (size_t)r * JR_LD, s_Jr, JR_LD / 4);
         glds16<(NJ * 3 + 63) / 64>(G + (size_t)r * NJ * 12, &sc.G[0][0], NJ * 3);              // rows of sc.G are 12 floats: a flat copy
-        glds4<2>(O + (size_t)r * ODIM, s_O, ODIM);
+        glds16<1>(O + (size_t)r * O_LD, s_O, O_LD / 4);
+        if (dMv) glds4<1>(dMv + (size_t)r * 12, s_misc, 12);
+        if (dsv) glds4<1>(dsv + r, s_misc + 12, 1);
+        if (dtransl_v) glds4<1>(dtransl_v + (size_t)r * 3, s_misc + 13, 3);
+        if (dbeta_v) glds4<1>(dbeta_v + (size_t)r * dbeta_stride, s_misc + 16, NBETA);
     } else if (wave == 2) {
         stage_pose_part<2>(pm, stg, xrow, camrow);
         if (dA) glds16<(NJ * 3 + 63) / 64>(dA + (size_t)r * NJ * 12, &sc.dG[0][0], NJ * 3);   // waits in sc.dG: lane j reads row j, then overwrites it
         if (dPF) glds16<(NPFX / 4 + 63) / 64>(dPF + (size_t)r * NPFX, s_dPF, NPFX / 4);
         if (dPF2) glds16<(NPFX / 4 + 63) / 64>(dPF2 + (size_t)r * NPFX, &sc.dR[0][0], NPFX / 4);   // parked in sc.dR (written much later)
-        if (dMv) glds4<1>(dMv + (size_t)r * 12, s_misc, 12);
-        if (dsv) glds4<1>(dsv + r, s_misc + 12, 1);
-        if (dtransl_v) glds4<1>(dtransl_v + (size_t)r * 3, s_misc + 13, 3);
-        if (dbeta_v) glds4<1>(dbeta_v + (size_t)r * dbeta_stride, s_misc + 16, NBETA);
     } else if (pl.X0) {
+        stage_pose_part<3>(pm, stg, xrow, camrow);
         const float* x = xrow;
         glds4<2>(x - 2 * XDIM, s_xn[0], XDIM); glds4<2>(x - XDIM, s_xn[1], XDIM);
         glds4<2>(x + XDIM, s_xn[2], XDIM); glds4<2>(x + 2 * XDIM, s_xn[3], XDIM);
         glds4<2>(pl.X0 + (size_t)r * XDIM, s_x0, XDIM);
-        const float* j = pl.Jw + (size_t)r * NJW * 3;
-        glds4<2>(j - NJW * 3, s_jw[0], NJW * 3); glds4<2>(j, s_jw[1], NJW * 3); glds4<2>(j + NJW * 3, s_jw[2], NJW * 3);
         glds4<1>(pl.mask + r, s_misc + 27, 1);
     } else {
+        stage_pose_part<3>(pm, stg, xrow, camrow);
         glds4<2>(dX + (size_t)r * XDIM, s_dx, XDIM);         // the row a separate param_loss_kernel launch initialised
     }
     const float sc_v = *scale;
     __syncthreads();                                         // (every wave waits for its copies: vmcnt(0) in front of the barrier)
-    if (threadIdx.x >= 192) return;                          // the fourth wave was only here to issue copies; waves 1, 2 stay for their share of pose_backward (split)
+    // (all four waves stay for their share of pose_backward, split)
     FDC_FR_STAMP(1, 7);
     const PoseModel pml = stage_pose_model(pm, stg);
     const bool w0 = threadIdx.x < 64;
@@ -398,7 +408,7 @@ __global__ __launch_bounds__(64 * POSE_NW) void pose_bwd_kernel(PoseModel pm, co
                   dO + (size_t)r * ODIM, dCAM + (size_t)r * 16, dscale_row + r, threadIdx.x, 64, SyncBlock(),
                   nullptr, nullptr, nullptr, 1);
     __syncthreads();
-    for (int e = threadIdx.x; e < XDIM; e += 192) dX[(size_t)r * XDIM + e] = s_dx[e];
+    for (int e = threadIdx.x; e < XDIM; e += 256) dX[(size_t)r * XDIM + e] = s_dx[e];
 }
 
 // thread per (frame, vertex), 256-thread workgroups.  Vout layout [rows, nv, 3].  world = 0: body frame (+transl only)
@@ -1435,6 +1445,7 @@ struct fdcap_ctx {
     // device constants
     DevBuf<float> Jt, Jd, hand_comp, hand_mean;
     DevBuf<int> parents, order, level_start, child_start, child_list, depth;
+    DevBuf<float> pose_tab;        // all of the above as ONE image in PoseStage's layout (what the staged pose kernels copy)
     int nlevels = 0;
     DevBuf<float> W1, b1, W2, b2, W3, b3;
     DevBuf<float> vp_pn[6];            // decoder weights in MFMA fragment order: forward w1 w2 w3, backward w3t w2t w1t
@@ -1476,6 +1487,7 @@ struct fdcap_ctx {
 
     PoseModel pose_model() const {
         PoseModel pm;
+        pm.tab = pose_tab.p;
         pm.Jt = Jt.p; pm.Jd = Jd.p; pm.parents = parents.p; pm.order = order.p; pm.level_start = level_start.p;
         pm.child_start = child_start.p; pm.child_list = child_list.p; pm.hand_comp = hand_comp.p;
         pm.hand_mean = hand_mean.p; pm.nlevels = nlevels; pm.depth = depth.p;
@@ -1771,7 +1783,7 @@ int fdcap_debug_rows(fdcap_ctx* c, int which, float* dst, void* stream) {
     const int nl = o->cfg.n_local, nc = c->nc;
     const float* src = nullptr; size_t w = 0;
     switch (which) {
-        case 0: src = o->O.p; w = ODIM; break;
+        case 0: src = o->O.p; w = O_LD; break;       // (padded rows)
         case 1: src = o->PF.p; w = NPFX; break;
         case 2: src = o->A.p; w = NJ * 12; break;
         case 3: src = o->M.p; w = 12; break;
@@ -1781,8 +1793,8 @@ int fdcap_debug_rows(fdcap_ctx* c, int which, float* dst, void* stream) {
         case 7: src = o->Opart.p; w = ODIM; break;
         case 8: src = o->H2.p; w = VP_H; break;
         case 9: src = o->Jw.p; w = NJW * 3; break;
-        case 10: src = o->Rm.p; w = NJ * 9; break;
-        case 11: src = o->Jrest.p; w = NJ * 3; break;
+        case 10: src = o->Rm.p; w = RM_LD; break;
+        case 11: src = o->Jrest.p; w = JR_LD; break;
         default: return FDCAP_E_ARG;
     }
     HIP_TRY(hipMemcpyAsync(dst, src + 2 * w, (size_t)nl * w * sizeof(float), hipMemcpyDeviceToDevice, (hipStream_t)stream));
@@ -1874,6 +1886,21 @@ int fdcap_ctx_create(const fdcap_model_desc* md, fdcap_ctx** out) {
     UP(c->child_start, child_start.data(), child_start.size()) UP(c->child_list, child_list.data(), child_list.size())
     UP(c->depth, hs.depth.data(), hs.depth.size())
     UP(c->hand_comp, hc.data(), hc.size()) UP(c->hand_mean, hm.data(), hm.size())
+    {   // the same tables once more, laid out as PoseStage's static part
+        std::vector<float> img((size_t)PS_STATIC_FLOATS, 0.f);
+        auto put = [&](size_t off_bytes, const void* src, size_t n_words) { memcpy((char*)img.data() + off_bytes, src, n_words * 4); };
+        put(offsetof(PoseStage, Jd), Jd.data(), Jd.size());
+        put(offsetof(PoseStage, hand_comp), hc.data(), hc.size());
+        put(offsetof(PoseStage, Jt), Jt.data(), Jt.size());
+        put(offsetof(PoseStage, hand_mean), hm.data(), hm.size());
+        put(offsetof(PoseStage, parents), parents.data(), parents.size());
+        put(offsetof(PoseStage, order), order.data(), order.size());
+        put(offsetof(PoseStage, level_start), level_start.data(), std::min<size_t>(level_start.size(), MAX_LEVELS + 4));
+        put(offsetof(PoseStage, child_start), child_start.data(), child_start.size());
+        put(offsetof(PoseStage, child_list), child_list.data(), child_list.size());
+        put(offsetof(PoseStage, depth), hs.depth.data(), hs.depth.size());
+        UP(c->pose_tab, img.data(), img.size())
+    }
     UP(c->W1, md->vp_fc1_w, 512 * 32) UP(c->b1, md->vp_fc1_b, 512)
     UP(c->W2, md->vp_fc2_w, 512 * 512) UP(c->b2, md->vp_fc2_b, 512)
     UP(c->W3, md->vp_out_w, ODIM * 512) UP(c->b3, md->vp_out_b, ODIM)
@@ -1917,6 +1944,7 @@ void fdcap_ctx_destroy(fdcap_ctx* c) {
     c->ws_adam.release();
     c->Jt.release(); c->Jd.release(); c->hand_comp.release(); c->hand_mean.release();
     c->parents.release(); c->order.release(); c->level_start.release(); c->child_start.release(); c->child_list.release(); c->depth.release();
+    c->pose_tab.release();
     c->W1.release(); c->b1.release(); c->W2.release(); c->b2.release(); c->W3.release(); c->b3.release();
     for (auto& b : c->vp_pn) b.release();
     for (auto& b : c->vp_pn3) b.release();
@@ -2403,9 +2431,9 @@ int fdcap_opt_create(fdcap_ctx* c, const fdcap_opt_config* cfg, float* rows_x, f
     AL(o->X0, (size_t)R * XDIM) AL(o->mask, R)
     AL(o->mX, (size_t)R * XDIM) AL(o->vX, (size_t)R * XDIM) AL(o->mCAM, (size_t)R * 16) AL(o->vCAM, (size_t)R * 16)
     AL(o->mS, 1) AL(o->vS, 1)
-    AL(o->H1, (size_t)R * 512) AL(o->H2, (size_t)R * 512) AL(o->O, (size_t)R * ODIM) AL(o->dO, (size_t)R * ODIM)
+    AL(o->H1, (size_t)R * 512) AL(o->H2, (size_t)R * 512) AL(o->O, (size_t)R * O_LD) AL(o->dO, (size_t)R * ODIM)
     AL(o->Opart, (size_t)4 * R * ODIM) AL(o->dZpart, (size_t)4 * R * VP_Z)
-    AL(o->Rm, (size_t)R * NJ * 9) AL(o->PF, (size_t)R * NPFX) AL(o->Jrest, (size_t)R * NJ * 3) AL(o->G, (size_t)R * NJ * 12)
+    AL(o->Rm, (size_t)R * RM_LD) AL(o->PF, (size_t)R * NPFX) AL(o->Jrest, (size_t)R * JR_LD) AL(o->G, (size_t)R * NJ * 12)
     AL(o->A, (size_t)R * NJ * 12) AL(o->M, (size_t)R * 12) AL(o->Jw, (size_t)R * NJW * 3)
     AL(o->dA, (size_t)R * NJ * 12) AL(o->dtransl_v, (size_t)R * 3) AL(o->dMv, (size_t)R * 12)
     AL(o->dsv, R) AL(o->dPF, (size_t)2 * R * NPFX)   /* [2][R, 496]: the second half only as the K-split product's second partial */
