@@ -355,13 +355,20 @@ FDC_HD void pose_backward(const PoseModel& pm, const float* x, const float* o, c
     // (g = the joints' own gradients formed above; R(p->d)^T = G_d.R^T G_p.R and a (x) (R^T v) = (a (x) v) R).
     // So the level-ordered part is a plain subtree sum of 12 numbers per joint -- three b128 reads and 12 adds per child
     // instead of a 3x3 product, an outer product and 24 scalar reads -- and the products run once, for all joints at once.
-    for (int d = tid; d < NJ; d += nthr) {
-        M3 U = m3_mul_bt(g_rot(sc.dG[d]), g_rot(sc.G[d]));
-        V3 gt = g_trn(sc.dG[d]);
-        m3_add_outer(U, gt, g_trn(sc.G[d]));
-        g_store(sc.dG[d], U, gt);
+#if defined(__HIP_DEVICE_COMPILE__)
+    const bool rows_split = split && pm.depth != nullptr;
+#else
+    const bool rows_split = false;
+#endif
+    if (!rows_split) {
+        for (int d = tid; d < NJ; d += nthr) {
+            M3 U = m3_mul_bt(g_rot(sc.dG[d]), g_rot(sc.G[d]));
+            V3 gt = g_trn(sc.dG[d]);
+            m3_add_outer(U, gt, g_trn(sc.G[d]));
+            g_store(sc.dG[d], U, gt);
+        }
+        sync();
     }
-    sync();
 #if defined(__HIP_DEVICE_COMPILE__)
     if (split && pm.depth != nullptr) {
         // The subtree sums on three waves (late r4): they are twelve independent sums per joint, wave w takes numbers 4w .. 4w + 3 --
@@ -374,6 +381,19 @@ FDC_HD void pose_backward(const PoseModel& pm, const float* x, const float* o, c
         const int c3 = nch > 3 ? pm.child_list[c_lo + 3] : 0, c4 = nch > 4 ? pm.child_list[c_lo + 4] : 0;
         const int e0 = 4 * (cw < 3 ? cw : 0);
         auto add4 = [](float4& a, const float4 b) { a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w; };
+        if (act) {
+            // the products above, row cw of [U | gt] only (m3_mul_bt / m3_add_outer element by element): this wave's chain reads
+            // nothing else, so no barrier between the products and the chain
+            const float4 a = *(const float4*)&sc.dG[p][e0];
+            const float4 b0 = *(const float4*)&sc.G[p][0], b1 = *(const float4*)&sc.G[p][4], b2 = *(const float4*)&sc.G[p][8];
+            float4 u;
+            u.x = a.x * b0.x + a.y * b0.y + a.z * b0.z; u.x += a.w * b0.w;
+            u.y = a.x * b1.x + a.y * b1.y + a.z * b1.z; u.y += a.w * b1.w;
+            u.z = a.x * b2.x + a.y * b2.y + a.z * b2.z; u.z += a.w * b2.w;
+            u.w = a.w;
+            *(float4*)&sc.dG[p][e0] = u;
+        }
+        __builtin_amdgcn_wave_barrier();
         for (int L = pm.nlevels - 1; L >= 1; --L) {
             if (dep == L - 1 && nch > 0) {
                 float4 a = *(const float4*)&sc.dG[p][e0];

@@ -357,8 +357,8 @@ __global__ __launch_bounds__(64 * POSE_NW) void pose_bwd_kernel(PoseModel pm, co
     const bool w0 = threadIdx.x < 64;
     if (dPF2) {
         const float* p2 = &sc.dR[0][0];
-        if (w0) for (int e = threadIdx.x; e < NPFX; e += 64) s_dPF[e] += p2[e];
-        __syncthreads();
+        for (int e = threadIdx.x; e < NPFX; e += 64 * POSE_NW) s_dPF[e] += p2[e];
+        if (!pl.X0) __syncthreads();                         // (else: the barrier behind the loss prologue covers it)
     }
     if (pl.X0) {
         // param_loss_kernel's gradients formed here: dX row (=) data + temporal terms on the raw rows, world-smoothing
