@@ -1,6 +1,9 @@
 #!/usr/bin/env python3
-"""Per-workgroup phase times (s_memtime) of the panel kernels; needs the -DFDC_PN_TIMING build (FDCAP_LIB)."""
+"""Per-workgroup phase times (s_memtime) of the panel kernels; needs the -DFDC_PN_TIMING build (FDCAP_LIB).
+The stamps live in the exact-fp32 kernels (panel_gemm_kernel, panel_gemm_wide_kernel, vposer_*_fused_kernel), the FDCAP_GEMM_SPLIT3=0
+twins of the default three-way-split ones: this tool selects them."""
 import ctypes, os, sys
+os.environ.setdefault("FDCAP_GEMM_SPLIT3", "0")
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import numpy as np, torch
@@ -14,6 +17,8 @@ def stamps(nblk, nst):
     a = np.frombuffer(buf, dtype=np.uint64).reshape(8192, 8)[:nblk, :nst].astype(np.int64)
     return a
 def report(name, a):
+    if len(a) == 0:
+        print(f"{name}: no stamps (this shape runs a kernel without them)"); return
     t0 = a[:, 0].min()
     span = a[:, -1].max() - t0
     print(f"{name}: {len(a)} WGs, span {span} ticks; start skew q50/q90/max {np.quantile(a[:,0]-t0,0.5):.0f}/{np.quantile(a[:,0]-t0,0.9):.0f}/{(a[:,0]-t0).max()}")
