@@ -20,7 +20,7 @@ Rank 0 prints ONE JSON line.
   `exact_fp32`              the same step with the dense products as exact fp32 MFMA chains (FDCAP_GEMM_SPLIT3=0);
   `roofline`                the dominant kernel (in-loop Chamfer NN launch): its duration is measured live with HIP events
                             on the launch stream; the counters that say WHICH resource bounds it come from the committed
-                            rocprofv3 PMC summary profiles/r3_pmc_summary.json (tools/run_prof_r3.sh); `contract` keeps
+                            rocprofv3 PMC summary profiles/r4_pmc_summary.json (tools/run_prof_r4.sh); `contract` keeps
                             SURVEY §8d's algorithmic-bytes figure;
   `cpu_baseline`            the oracle timed on this host's cores on a bounded sample.
 
