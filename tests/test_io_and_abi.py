@@ -122,3 +122,20 @@ def test_colmap_helpers_follow_reference_scripts(tmp_path):
     xyz = io.colmap_points_to_xyz(str(pts), str(tmp_path / "xyz.xyz"))
     np.testing.assert_allclose(xyz, [[0.5, 1.5, 2.5], [-0.5, -1.5, -2.5]])
     np.testing.assert_allclose(io.read_scene_points(str(tmp_path / "xyz.xyz")), xyz)
+
+
+def test_the_header_is_plain_c_and_the_c_host_program_compiles_against_it(tmp_path):
+    """include/fdcap.h is the boundary a non-Python caller binds: tests/c_abi_fit.c (the whole optimisation from a C host; run on
+    the GPU by tests/test_gpu_c_host.py) must compile as C11 with -Wall -Wextra -Werror and link against the built library --
+    no C++-isms in the header, every entry point it uses exported."""
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    from fdcap_amd import capi
+    pkg = os.path.dirname(capi.LIB_PATH)
+    exe = str(tmp_path / "c_abi_fit")
+    r = subprocess.run(["gcc", "-std=c11", "-Wall", "-Wextra", "-Werror", "-I", os.path.join(root, "include"), "-I", "/opt/rocm/include",
+                        os.path.join(root, "tests", "c_abi_fit.c"), "-o", exe, "-L", pkg, "-lfdcap_hip", "-L", "/opt/rocm/lib", "-lamdhip64",
+                        f"-Wl,-rpath,{pkg}", "-Wl,-rpath,/opt/rocm/lib"], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-3000:]
+    r = subprocess.run([exe], capture_output=True, text=True)
+    assert r.returncode == 1 and "usage" in r.stderr
