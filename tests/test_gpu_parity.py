@@ -948,3 +948,26 @@ print("ROCTX_BOUND", int("roctx" in maps))
     assert r.returncode == 0, r.stderr[-2000:]
     assert "ROCTX_BOUND 1" in r.stdout, r.stdout[-500:]
     np.testing.assert_array_equal(np.load(out), ref)
+
+
+def test_the_library_side_loop_refuses_what_it_cannot_run():
+    """fdcap_opt_run's argument checks (include/fdcap.h): a range outside the fit, a logging iteration without a history (or with a
+    history too short), the exchange tail without a communicator -- error codes, no launches, and the context still fits afterwards."""
+    import ctypes
+    fop, bm, vp, clip, scene, vid = _make_fop(9, 300, 2000, 20, 10, seed=97)
+    body = torch.tensor(clip.body_params).cuda()
+    ref = fop.fitting(body, "global")[0].clone()
+    lib, h, st = fop.ctx.lib, fop.ctx.handle, capi.current_stream()
+    n = ctypes.c_int32(-1)
+    hist = torch.zeros(2, capi.NUM_LOSSES, dtype=torch.float64, device="cuda")
+    E_ARG, E_STATE = -1, -2
+    assert lib.fdcap_opt_run(h, 0, 11, 10, 8, 0, None, 0, 0, ctypes.byref(n), st) == E_ARG and n.value == 0       # ii1 > num_iter
+    assert lib.fdcap_opt_run(h, 5, 3, 10, 8, 0, None, 0, 0, ctypes.byref(n), st) == E_ARG                          # ii1 < ii0
+    assert lib.fdcap_opt_run(h, 0, 2, 10, 8, 1, None, 0, 0, ctypes.byref(n), st) == E_ARG and n.value == 0        # logging, no history
+    assert lib.fdcap_opt_run(h, 0, 1, 10, 8, 0, None, 0, 2, ctypes.byref(n), st) == E_STATE                        # exchange tail, no communicator
+    # a history of two rows takes two logged iterations, the third is refused (and says how many it wrote)
+    assert lib.fdcap_opt_run(h, 0, 3, 10, 8, 1, capi.dptr(hist), 2, 0, ctypes.byref(n), st) == E_ARG and n.value == 2
+    assert lib.fdcap_opt_run(h, 4, 4, 10, 8, 0, None, 0, 0, ctypes.byref(n), st) == 0 and n.value == 0             # an empty stretch is fine
+    again = fop.fitting(body, "global")[0]
+    assert torch.equal(again, ref)
+    fop.close()
