@@ -1102,6 +1102,15 @@ struct VPoserPanels3 {
     const float *b1 = nullptr, *b2 = nullptr, *b3 = nullptr;
 };
 constexpr int VP3_PZ = (VP_Z / 8) * 16, VP3_PH = (VP_H / 8) * 16, VP3_PQ = (VP_QW / 8) * 16;     // plane strides (uint4)
+// What the backward needs of the hidden activations is their SIGNS (LeakyReLU's slope): the split kernels keep one byte per four
+// columns in H1 / H2 -- bit e = column 4 b + e is positive -- 128 bytes per row instead of 2 KB (late r4: what a kernel leaves dirty in
+// L2 is written back when it ends, ~0.2 us per MB, tools/launch_overhead_probe.hip; the forward wrote 4 MB of activations per launch
+// and the four quarter-workgroups of a row block read H1 four times over).  Indexed by absolute row: the forward's and the backward's
+// 16-row blocks need not coincide (sharded runs).  The exact-fp32 twins keep floats in the same buffers.
+constexpr int VP3_MROW = VP_H / 4;
+__device__ __forceinline__ unsigned char vp3_signs(const float4 v) {
+    return (unsigned char)((v.x > 0.f ? 1u : 0u) | (v.y > 0.f ? 2u : 0u) | (v.z > 0.f ? 4u : 0u) | (v.w > 0.f ? 8u : 0u));
+}
 
 __global__ __launch_bounds__(512) void vposer_fwd_split3_kernel(VPoserPanels3 P, const float* __restrict__ Z, int ldx, int row_lo,
                                                                 int row_hi, float* __restrict__ H1, float* __restrict__ H2,
@@ -1157,7 +1166,7 @@ __global__ __launch_bounds__(512) void vposer_fwd_split3_kernel(VPoserPanels3 P,
             const float4 v = make_float4(vp_lrelu(acc[t][0] + bias.x), vp_lrelu(acc[t][1] + bias.y), vp_lrelu(acc[t][2] + bias.z),
                                          vp_lrelu(acc[t][3] + bias.w));
             pn3_store4(sH1, VP3_PH, n4, j, v);
-            if ((n4 / VP_QW) == q && r0 + j < row_hi) *(float4*)(H1 + (size_t)(r0 + j) * VP_H + n4) = v;
+            if ((n4 / VP_QW) == q && r0 + j < row_hi) ((unsigned char*)H1)[(size_t)(r0 + j) * VP3_MROW + (n4 >> 2)] = vp3_signs(v);
         }
     }
     __syncthreads();
@@ -1173,7 +1182,7 @@ __global__ __launch_bounds__(512) void vposer_fwd_split3_kernel(VPoserPanels3 P,
         const float4 bias = bias2;
         const float4 v = make_float4(vp_lrelu(acc[0] + bias.x), vp_lrelu(acc[1] + bias.y), vp_lrelu(acc[2] + bias.z), vp_lrelu(acc[3] + bias.w));
         pn3_store4(sH2, VP3_PQ, n4 - q * VP_QW, j, v);
-        if (r0 + j < row_hi) *(float4*)(H2 + (size_t)(r0 + j) * VP_H + n4) = v;
+        if (r0 + j < row_hi) ((unsigned char*)H2)[(size_t)(r0 + j) * VP3_MROW + (n4 >> 2)] = vp3_signs(v);
     }
     __syncthreads();
     {   // output layer: this quarter's K-slice (128 = 4 steps) of all 126 (128) columns
@@ -1210,11 +1219,11 @@ __global__ __launch_bounds__(512) void vposer_bwd_split3_kernel(VPoserPanels3 P,
     PnRing3T<1, 2> rgC;
     // the forward activations whose signs mask this wave's tiles, requested before the first barrier (rows clamped:
     // unconditional loads).  Fetched after each layer's products they were five dependent round trips on cold data.
-    const size_t hrow = (size_t)min(r0 + j, row_hi - 1) * VP_H;
-    const float4 hm2 = *(const float4*)(H2 + hrow + (q * 8 + wave) * 16 + 4 * g);
-    float4 hm1[4];
+    const size_t hrow = (size_t)min(r0 + j, row_hi - 1) * VP3_MROW;          // (sign bytes: vp3_signs)
+    const unsigned hm2 = ((const unsigned char*)H2)[hrow + (q * 8 + wave) * 4 + g];
+    unsigned hm1[4];
 #pragma unroll
-    for (int t = 0; t < 4; ++t) hm1[t] = *(const float4*)(H1 + hrow + (wave + 8 * t) * 16 + 4 * g);
+    for (int t = 0; t < 4; ++t) hm1[t] = ((const unsigned char*)H1)[hrow + (wave + 8 * t) * 4 + g];
     {   // dH2[:, quarter] = (dO x W3[:, quarter]) * mask(H2)
         f32x4_t acc = {0.f, 0.f, 0.f, 0.f};
         const int tile = q * 8 + wave;
@@ -1231,10 +1240,10 @@ __global__ __launch_bounds__(512) void vposer_bwd_split3_kernel(VPoserPanels3 P,
             panel3_prefetch_t<4, 2>(rgB, bfb, VP_QW / 32, lane);
         }
         const int n4 = tile * 16 + 4 * g;
-        const float4 h = hm2;
+        const unsigned h = hm2;
         pn3_store4(sdH2, VP3_PQ, n4 - q * VP_QW, j,
-                   make_float4(acc[0] * (h.x > 0.f ? 1.f : 0.2f), acc[1] * (h.y > 0.f ? 1.f : 0.2f), acc[2] * (h.z > 0.f ? 1.f : 0.2f),
-                               acc[3] * (h.w > 0.f ? 1.f : 0.2f)));
+                   make_float4(acc[0] * ((h & 1u) ? 1.f : 0.2f), acc[1] * ((h & 2u) ? 1.f : 0.2f), acc[2] * ((h & 4u) ? 1.f : 0.2f),
+                               acc[3] * ((h & 8u) ? 1.f : 0.2f)));
     }
     __syncthreads();
     {   // partial dH1 = (dH2[:, quarter] x W2[quarter rows, :]) * mask(H1): tiles wave, wave + 8, wave + 16, wave + 24
@@ -1249,10 +1258,10 @@ __global__ __launch_bounds__(512) void vposer_bwd_split3_kernel(VPoserPanels3 P,
 #pragma unroll
         for (int t = 0; t < 4; ++t) {
             const int n4 = (wave + 8 * t) * 16 + 4 * g;
-            const float4 h = hm1[t];
+            const unsigned h = hm1[t];
             pn3_store4(sdH1, VP3_PH, n4, j,
-                       make_float4(acc[t][0] * (h.x > 0.f ? 1.f : 0.2f), acc[t][1] * (h.y > 0.f ? 1.f : 0.2f),
-                                   acc[t][2] * (h.z > 0.f ? 1.f : 0.2f), acc[t][3] * (h.w > 0.f ? 1.f : 0.2f)));
+                       make_float4(acc[t][0] * ((h & 1u) ? 1.f : 0.2f), acc[t][1] * ((h & 2u) ? 1.f : 0.2f),
+                                   acc[t][2] * ((h & 4u) ? 1.f : 0.2f), acc[t][3] * ((h & 8u) ? 1.f : 0.2f)));
         }
     }
     __syncthreads();

@@ -1,15 +1,9 @@
 #!/bin/bash
-# A/B of two builds of the library on one box in one call: libfdcap_hip.so (the tree) against libfdcap_hip_base.so
+# A/B of two builds of the library on one box in one call: libfdcap_hip.so (the tree) against libfdcap_hip_base.so (build it from
+# another commit: git worktree add /tmp/base_wt <commit>; hipcc ... -o 4dcapture-fpv_amd/libfdcap_hip_base.so /tmp/base_wt/.../fdcap.hip)
 cd /root/repo; mkdir -p gpurun_out; O=/root/repo/gpurun_out
-for i in 1 2 3; do
-python bench.py --steps 5 --warmup 2 --value-only 2>/dev/null | tail -1 > $O/b_ab_new_$i.json
-FDCAP_LIB=$PWD/4dcapture-fpv_amd/libfdcap_hip_base.so python bench.py --steps 5 --warmup 2 --value-only 2>/dev/null | tail -1 > $O/b_ab_base_$i.json
-done
-python - <<'PY'
-import json,glob
-for f in sorted(glob.glob('gpurun_out/b_ab_*.json')):
-    d=json.loads(open(f).read()); print(f, round(d['value']), round(d['ms_per_step'],2))
-PY
+python tools/compare_builds.py 4dcapture-fpv_amd/libfdcap_hip.so 4dcapture-fpv_amd/libfdcap_hip_base.so 2>&1 | grep -v amdgpu.ids | tail -3
+timeout 1200 python -m pytest tests/test_gpu_parity.py tests/test_gpu_ops_autograd.py tests/test_gpu_sharded.py -x -q 2>&1 | tail -2
 cd /tmp; export TMPDIR=/tmp
 for m in new base; do
   rm -rf /tmp/prof_$m
