@@ -1687,7 +1687,9 @@ int opt_sync(fdcap_ctx* c, hipStream_t st) {
 
 // decoder + per-frame pose state (Rm, PF, Jrest, G, A, M, Jw) of rows [lo, hi): two launches.  A deferred optimiser step is
 // applied by these two launches when they cover exactly the frames it steps (no halo rows: one rank), else by its own launch first.
-int opt_pose_forward(fdcap_ctx* c, int lo, int hi, hipStream_t st) {
+// contact_state = false: the pose feature PF and the skinning transforms A -- read by the contact forward only -- are not written
+// (phase 2 of a fit that does not log: 4.7 MB less for the end of the launch to write back, tools/launch_overhead_probe.hip)
+int opt_pose_forward(fdcap_ctx* c, int lo, int hi, hipStream_t st, bool contact_state = true) {
     OptState* o = c->opt;
     o->ahead = false;                                       // (whatever ran ahead is recomputed here)
     const size_t ps = (size_t)o->R * ODIM;
@@ -1706,8 +1708,8 @@ int opt_pose_forward(fdcap_ctx* c, int lo, int hi, hipStream_t st) {
     int e = vposer_forward(c, o->X.p, XDIM, X_LATENT, lo, hi, o->H1.p, o->H2.p, o->Opart.p, ps, nullptr, st, 0, 0, ds);
     if (e) return e;
     hipLaunchKernelGGL(pose_fwd_kernel<true>, dim3(hi - lo), dim3(64 * POSE_NW), 0, st, c->pose_model(), o->X.p, o->O.p, o->CAM.p, o->scale.p, lo,
-                       o->Rm.p, o->PF.p, o->Jrest.p, o->G.p, o->A.p, o->M.p, o->Jw.p, (const float*)nullptr, (const float*)o->Opart.p, ps,
-                       0, 0, ds);
+                       o->Rm.p, contact_state ? o->PF.p : (float*)nullptr, o->Jrest.p, o->G.p, contact_state ? o->A.p : (float*)nullptr, o->M.p, o->Jw.p,
+                       (const float*)nullptr, (const float*)o->Opart.p, ps, 0, 0, ds);
     if (ds.on) {                                            // the step has been issued: the launches that follow see its results
         o->pend.on = false;
         o->dz_pending = false;
@@ -2540,11 +2542,11 @@ static int opt_backward_impl(fdcap_ctx* c, const LossWeights& lw, int32_t log_te
     int row_lo, row_hi;
     opt_row_range(o, 1, &row_lo, &row_hi);
     const bool ahead = o->ahead, blend_done = o->ahead && o->ahead_blend;
-    int e = ahead ? opt_pose_forward_rest(c, row_lo, row_hi, st) : opt_pose_forward(c, row_lo, row_hi, st);
-    o->ahead = false;
-    if (e) return e;
     const bool contact_grad = o->contact_on && lw.contact != 0.f;
     const bool contact_fwd = o->contact_on && (contact_grad || log_terms);
+    int e = ahead ? opt_pose_forward_rest(c, row_lo, row_hi, st) : opt_pose_forward(c, row_lo, row_hi, st, contact_fwd || (dct_on || o->dctW > 0));
+    o->ahead = false;
+    if (e) return e;
     if (contact_fwd) { e = opt_contact_forward(c, st, blend_done); if (e) return e; }
     const float w_rec = lw.rec * cf.weight_loss_rec / ((float)N * XDIM);
     const float w_sm = (N >= 3) ? lw.smooth / ((float)(N - 2) * XDIM) : 0.f;
