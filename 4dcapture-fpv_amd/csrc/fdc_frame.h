@@ -284,7 +284,8 @@ FDC_HD void pose_forward(const PoseModel& pm, const float* x, const float* o, co
 }
 
 // Backward for one frame.
-// In : x, o, cam_ext, scale; stored Rm / Jrest / G from the forward;
+// In : x, o, cam_ext, scale; stored Jrest / G from the forward (Rm: no longer read -- the subtree-sum form of the reverse chain works
+//      on the world transforms alone; the parameter stays for the callers' sake and may be null);
 //      dA[55*12] (d loss / d skinning transforms, may be null), dPF[486] (may be null),
 //      dJw[23*3] (may be null), dMv[12], dsv, dbeta_v[10], dtransl_v[3]: vertex-side sums (null -> 0)
 // Out: dx[78] += (transl, 6D, betas, hands, cam_t),  dO[126] =,  dcam_ext[16] =,  *dscale =
@@ -313,7 +314,6 @@ FDC_HD void pose_backward(const PoseModel& pm, const float* x, const float* o, c
     world_matrix(cam_ext, x, scale, &MR, &Mt);
     V3 transl = v3(x[X_TRANSL], x[X_TRANSL + 1], x[X_TRANSL + 2]);
     for (int j = tid; j < NJ; j += nthr) {
-        for (int e = 0; e < 9; ++e) sc.R[j][e] = Rm[9 * j + e];
         if (G) { float g12[12]; load12(g12, G + 12 * j); for (int e = 0; e < 12; ++e) sc.G[j][e] = g12[e]; }   // null: the caller has put it into sc.G
         for (int c = 0; c < 3; ++c) sc.J[j][c] = Jrest[3 * j + c];
         M3 GR = g_rot(sc.G[j]);

@@ -308,7 +308,7 @@ __global__ __launch_bounds__(64 * POSE_NW) void pose_bwd_kernel(PoseModel pm, co
     // needs (neighbouring rows: two halo rows exist on either side of every owned row).  Fetched phase by phase -- as
     // pose_backward does for its generic callers -- they were ~8 dependent cold round trips.
     __shared__ __attribute__((aligned(16))) float s_dPF[NPFX];
-    __shared__ __attribute__((aligned(16))) float s_O[O_LD], s_Rm[RM_LD], s_Jr[JR_LD];
+    __shared__ __attribute__((aligned(16))) float s_O[O_LD], s_Jr[JR_LD];
     __shared__ float s_xn[4][XDIM + 2], s_x0[XDIM + 2], s_jw[3][NJW * 3 + 3], s_misc[32];
     __shared__ float s_dx[XDIM + 2];      // the parameter-gradient row: accumulated here (pose_backward adds to it from several
                                           // phases -- read-modify-write round trips on the global row), stored once at the end
@@ -319,7 +319,6 @@ __global__ __launch_bounds__(64 * POSE_NW) void pose_bwd_kernel(PoseModel pm, co
     const float* const camrow = CAM + (size_t)r * 16;
     if (wave == 0) {
         stage_pose_part<0>(pm, stg, xrow, camrow);
-        glds16<(RM_LD / 4 + 63) / 64>(Rm + (size_t)r * RM_LD, s_Rm, RM_LD / 4);
         if (pl.X0) {                                         // (the copies are dealt so that every wave issues 12-13 of them)
             const float* j = pl.Jw + (size_t)r * NJW * 3;
             glds4<2>(j - NJW * 3, s_jw[0], NJW * 3); glds4<2>(j, s_jw[1], NJW * 3); glds4<2>(j + NJW * 3, s_jw[2], NJW * 3);
@@ -400,7 +399,7 @@ __global__ __launch_bounds__(64 * POSE_NW) void pose_bwd_kernel(PoseModel pm, co
     }
     const float* dJw_row = (pl.X0 && pl.world_grad) ? s_dJw : (dJw ? dJw + (size_t)r * NJW * 3 : nullptr);
     pose_backward(pml, stg.x, s_O, stg.cam, sc_v,
-                  s_Rm, s_Jr, (const float*)nullptr,                      // (G: already in sc.G)
+                  (const float*)nullptr, s_Jr, (const float*)nullptr,     // (Rm: not read any more; G: already in sc.G)
                   dA ? &sc.dG[0][0] : nullptr, dPF ? s_dPF : nullptr,
                   dJw_row, dMv ? s_misc : nullptr,
                   dsv ? s_misc + 12 : nullptr, dbeta_v ? (dPF2 ? s_dPF + NPF : s_misc + 16) : nullptr,
@@ -1708,7 +1707,12 @@ int opt_pose_forward(fdcap_ctx* c, int lo, int hi, hipStream_t st, bool contact_
     int e = vposer_forward(c, o->X.p, XDIM, X_LATENT, lo, hi, o->H1.p, o->H2.p, o->Opart.p, ps, nullptr, st, 0, 0, ds);
     if (e) return e;
     hipLaunchKernelGGL(pose_fwd_kernel<true>, dim3(hi - lo), dim3(64 * POSE_NW), 0, st, c->pose_model(), o->X.p, o->O.p, o->CAM.p, o->scale.p, lo,
-                       o->Rm.p, contact_state ? o->PF.p : (float*)nullptr, o->Jrest.p, o->G.p, contact_state ? o->A.p : (float*)nullptr, o->M.p, o->Jw.p,
+#ifdef FDC_DEBUG_BUFFERS
+                       o->Rm.p,                                // (the per-joint rotations: nobody reads them back but fdcap_debug_rows)
+#else
+                       (float*)nullptr,
+#endif
+                       contact_state ? o->PF.p : (float*)nullptr, o->Jrest.p, o->G.p, contact_state ? o->A.p : (float*)nullptr, o->M.p, o->Jw.p,
                        (const float*)nullptr, (const float*)o->Opart.p, ps, 0, 0, ds);
     if (ds.on) {                                            // the step has been issued: the launches that follow see its results
         o->pend.on = false;
@@ -1727,7 +1731,7 @@ int opt_pose_forward_rest(fdcap_ctx* c, int lo, int hi, hipStream_t st) {
     int e = vposer_forward(c, o->X.p, XDIM, X_LATENT, lo, 2, o->H1.p, o->H2.p, o->Opart.p, ps, nullptr, st, 2 + nl, hi);
     if (e) return e;
     hipLaunchKernelGGL(pose_fwd_kernel<true>, dim3(hi - lo), dim3(64 * POSE_NW), 0, st, c->pose_model(), o->X.p, o->O.p, o->CAM.p, o->scale.p, lo,
-                       o->Rm.p, o->PF.p, o->Jrest.p, o->G.p, o->A.p, o->M.p, o->Jw.p, (const float*)nullptr, (const float*)o->Opart.p, ps,
+                       (float*)nullptr /* Rm: see opt_pose_forward */, o->PF.p, o->Jrest.p, o->G.p, o->A.p, o->M.p, o->Jw.p, (const float*)nullptr, (const float*)o->Opart.p, ps,
                        2, 2 + nl);
     return (int)hipGetLastError();
 }
