@@ -289,7 +289,10 @@ __global__ __launch_bounds__(64 * POSE_NW) void pose_fwd_kernel(PoseModel pm, co
 // losses_d (0 rec, 1 z^2, 2 smoothing, 3 contact -- written by the skinning backward --, 4 world smoothing); summed over the
 // rows in a fixed order by loss_rows_reduce_kernel.  (Atomics on the eight doubles serialise: 1024 frames x 4 adds made the
 // separate param_loss_kernel 15 us and the skinning backward 8 us slower on logging iterations.)
-struct ParamLossIn { const float* X0; const float* mask; const float* Jw; int frame0, n_total; float w_rec, w_sm, w_ws; int world_grad; float* loss_rows; };
+struct ParamLossIn { const float* X0; const float* mask; const float* Jw; int frame0, n_total; float w_rec, w_sm, w_ws; int world_grad; float* loss_rows;
+                     // (logging phase 2) the contact term that is only printed: this frame's sum of the robustified distances goes
+                     // to slot 3 of loss_rows -- contact_loss_rows_kernel's 256-thread sum, thread for thread, without its launch
+                     const float* cdist = nullptr; int cnc = 0; };
 
 __global__ __launch_bounds__(64 * POSE_NW) void pose_bwd_kernel(PoseModel pm, const float* __restrict__ X, const float* __restrict__ O,
                                                       const float* __restrict__ CAM, const float* __restrict__ scale,
@@ -349,7 +352,15 @@ __global__ __launch_bounds__(64 * POSE_NW) void pose_bwd_kernel(PoseModel pm, co
         glds4<2>(dX + (size_t)r * XDIM, s_dx, XDIM);         // the row a separate param_loss_kernel launch initialised
     }
     const float sc_v = *scale;
+    __shared__ float s_csum[POSE_NW];
+    if (pl.cdist) {                                          // (kernel-uniform) contact_loss_rows_kernel's sum, same threads, same order
+        float v = 0.f;
+        for (int c = threadIdx.x; c < pl.cnc; c += 256) { float d; v += contact_term(pl.cdist[(size_t)r * pl.cnc + c], &d); }
+        v = wave_sum64(v);
+        if ((threadIdx.x & 63) == 0) s_csum[threadIdx.x >> 6] = v;
+    }
     __syncthreads();                                         // (every wave waits for its copies: vmcnt(0) in front of the barrier)
+    if (pl.cdist && threadIdx.x == 0) pl.loss_rows[(size_t)r * LROW + 3] = (s_csum[0] + s_csum[1]) + (s_csum[2] + s_csum[3]);
     // (all four waves stay for their share of pose_backward, split)
     FDC_FR_STAMP(1, 7);
     const PoseModel pml = stage_pose_model(pm, stg);
@@ -2619,7 +2630,8 @@ static int opt_backward_impl(fdcap_ctx* c, const LossWeights& lw, int32_t log_te
             HIP_TRY(gemm_f32(true, EPI_STORE, o->dVoff.p + (size_t)2 * nc * 3, 3 * nc, c->contact.posedirs.p, c->contact.ldp,
                              o->dPF.p + 2 * NPFX, NPFX, nl, NPFX, 3 * nc, nullptr, 0, st));
     } else if (contact_fwd && losses) {
-        hipLaunchKernelGGL(contact_loss_rows_kernel, dim3(nl), dim3(256), 0, st, o->dist.p, nc, 2, o->loss_rows.p);
+        if (fuse_pl && rows_log) { pli.cdist = o->dist.p; pli.cnc = nc; }        // (rides in pose_bwd_kernel's prologue: one launch less)
+        else hipLaunchKernelGGL(contact_loss_rows_kernel, dim3(nl), dim3(256), 0, st, o->dist.p, nc, 2, o->loss_rows.p);
     }
     const bool joint_grad = lw.world_on || dct_on;
     hipLaunchKernelGGL(pose_bwd_kernel, dim3(nl), dim3(64 * POSE_NW), 0, st, pm, o->X.p, o->O.p, o->CAM.p, o->scale.p, 2, o->Rm.p,
