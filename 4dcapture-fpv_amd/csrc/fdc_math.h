@@ -21,8 +21,7 @@ namespace fdc {
 
 #if defined(__HIPCC__)
 // Sum over the 64 lanes of a wavefront, the same bits in every lane, fixed order.  Four DPP steps (quad_perm x2,
-// row_half_mirror, row_mirror: no LDS traffic) leave every 16-lane row with its row sum, then ((r0 + r1) + r2) + r3 via
-// v_readlane.  The obvious __shfl_xor butterfly compiles to six ds_bpermute_b32 (LDS crossbar round trips) per sum.
+// row_half_mirror, row_mirror: no LDS traffic) leave every 16-lane row with its row sum, then ((r0 + r1) + r2) + r3 down the rows.  The obvious __shfl_xor butterfly compiles to six ds_bpermute_b32 (LDS crossbar round trips) per sum.
 template <int CTRL>
 __device__ __forceinline__ float dpp_move(float v) {
     return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xF, 0xF, false));
@@ -32,11 +31,13 @@ __device__ __forceinline__ float wave_sum64(float v) {
     v += dpp_move<0x4E>(v);      // quad_perm [2,3,0,1]
     v += dpp_move<0x141>(v);     // row_half_mirror
     v += dpp_move<0x140>(v);     // row_mirror
-    const float r0 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 0));
-    const float r1 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 16));
-    const float r2 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 32));
-    const float r3 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 48));
-    return ((r0 + r1) + r2) + r3;
+    // ((r0 + r1) + r2) + r3 down the rows (late r4): row_bcast15 hands lane 15 of row k - 1 to row k; one row at a time (row_mask), so
+    // row 1 becomes r1 + r0, row 2 r2 + (r0 + r1), row 3 r3 + ((r0 + r1) + r2) -- the sums of the four-readlane form bit for bit
+    // (an unselected row adds +0.0), in three DPP adds and one v_readlane instead of four readlanes and three adds on scalars.
+    v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x142, 0x2, 0xF, false));
+    v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x142, 0x4, 0xF, false));
+    v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x142, 0x8, 0xF, false));
+    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
 }
 __device__ __forceinline__ float wave_min64(float v) {
     v = fminf(v, dpp_move<0xB1>(v)); v = fminf(v, dpp_move<0x4E>(v)); v = fminf(v, dpp_move<0x141>(v)); v = fminf(v, dpp_move<0x140>(v));
