@@ -395,6 +395,22 @@ static inline void panel_pack3(const float* src, long sk, long sn, int K, int N,
 __device__ __forceinline__ unsigned pn3_bf(float f) { return (unsigned)__builtin_bit_cast(unsigned short, (__bf16)f); }   // RNE
 __device__ __forceinline__ float pn3_bff(unsigned h) { return __uint_as_float(h << 16); }
 
+// The three-way split of TWO values at once (late r4): v_cvt_pk_bf16_f32 converts a pair and packs it -- low half the first value --
+// so a plane's dword needs no shift / or to assemble; the parts are the same round-to-nearest-even conversions of the same
+// residuals as pn3_bf / pn3_bff element by element (46 instead of ~68 VALU instructions per eight values).
+typedef __bf16 pn_bf16x2 __attribute__((ext_vector_type(2)));
+typedef float pn_f32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ unsigned pn3_pk2(float a, float b) {
+    const pn_f32x2 f = {a, b};
+    return __builtin_bit_cast(unsigned, __builtin_convertvector(f, pn_bf16x2));
+}
+__device__ __forceinline__ void pn3_split2(float a, float b, unsigned& H, unsigned& M, unsigned& L) {
+    H = pn3_pk2(a, b);
+    const float ra = a - __uint_as_float(H << 16), rb = b - __uint_as_float(H & 0xffff0000u);
+    M = pn3_pk2(ra, rb);
+    L = pn3_pk2(ra - __uint_as_float(M << 16), rb - __uint_as_float(M & 0xffff0000u));
+}
+
 // stage rows [r0, r0 + 16) x columns [k0, k0 + kn) of A as three bf16 planes, each [kpad / 8 chunks][16 rows] x 16 bytes
 // (kpad % 32 == 0; rows >= rmax and columns >= kn are zero).  NT threads; one (chunk, row) item = 8 columns.
 template <int NT>
@@ -417,17 +433,12 @@ __device__ __forceinline__ void panel_stage3(uint4* __restrict__ sA3, const floa
                 for (int e = 0; e < 8; ++e) if (k + e < kn) v[e] = p[e];
             }
         }
-        unsigned h[8], m[8], l[8];
+        unsigned h[4], m[4], l[4];
 #pragma unroll
-        for (int e = 0; e < 8; ++e) {
-            h[e] = pn3_bf(v[e]);
-            const float r1 = v[e] - pn3_bff(h[e]);
-            m[e] = pn3_bf(r1);
-            l[e] = pn3_bf(r1 - pn3_bff(m[e]));
-        }
-        sA3[(size_t)0 * nch * 16 + it] = make_uint4(h[0] | (h[1] << 16), h[2] | (h[3] << 16), h[4] | (h[5] << 16), h[6] | (h[7] << 16));
-        sA3[(size_t)1 * nch * 16 + it] = make_uint4(m[0] | (m[1] << 16), m[2] | (m[3] << 16), m[4] | (m[5] << 16), m[6] | (m[7] << 16));
-        sA3[(size_t)2 * nch * 16 + it] = make_uint4(l[0] | (l[1] << 16), l[2] | (l[3] << 16), l[4] | (l[5] << 16), l[6] | (l[7] << 16));
+        for (int e = 0; e < 4; ++e) pn3_split2(v[2 * e], v[2 * e + 1], h[e], m[e], l[e]);
+        sA3[(size_t)0 * nch * 16 + it] = make_uint4(h[0], h[1], h[2], h[3]);
+        sA3[(size_t)1 * nch * 16 + it] = make_uint4(m[0], m[1], m[2], m[3]);
+        sA3[(size_t)2 * nch * 16 + it] = make_uint4(l[0], l[1], l[2], l[3]);
     }
 }
 
@@ -857,20 +868,14 @@ __device__ __forceinline__ void panel3_mma_t(const uint4* __restrict__ sA3, int 
 }
 // four consecutive columns n4 .. n4 + 3 of frame row j -> the three bf16 planes of an LDS block (8 bytes per plane)
 __device__ __forceinline__ void pn3_store4(uint4* __restrict__ sA3, int pstride, int n4, int j, float4 v) {
-    const float x[4] = {v.x, v.y, v.z, v.w};
-    unsigned h[4], m[4], l[4];
-#pragma unroll
-    for (int e = 0; e < 4; ++e) {
-        h[e] = pn3_bf(x[e]);
-        const float r1 = x[e] - pn3_bff(h[e]);
-        m[e] = pn3_bf(r1);
-        l[e] = pn3_bf(r1 - pn3_bff(m[e]));
-    }
+    unsigned h[2], m[2], l[2];
+    pn3_split2(v.x, v.y, h[0], m[0], l[0]);
+    pn3_split2(v.z, v.w, h[1], m[1], l[1]);
     const size_t it = (size_t)(n4 >> 3) * 16 + j;
     const int half = (n4 >> 2) & 1;
-    ((uint2*)(sA3 + (size_t)0 * pstride + it))[half] = make_uint2(h[0] | (h[1] << 16), h[2] | (h[3] << 16));
-    ((uint2*)(sA3 + (size_t)1 * pstride + it))[half] = make_uint2(m[0] | (m[1] << 16), m[2] | (m[3] << 16));
-    ((uint2*)(sA3 + (size_t)2 * pstride + it))[half] = make_uint2(l[0] | (l[1] << 16), l[2] | (l[3] << 16));
+    ((uint2*)(sA3 + (size_t)0 * pstride + it))[half] = make_uint2(h[0], h[1]);
+    ((uint2*)(sA3 + (size_t)1 * pstride + it))[half] = make_uint2(m[0], m[1]);
+    ((uint2*)(sA3 + (size_t)2 * pstride + it))[half] = make_uint2(l[0], l[1]);
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
