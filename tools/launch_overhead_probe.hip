@@ -29,6 +29,27 @@ static void run(const char* what, int grid, int block, int lds_bytes, float us, 
            lds_bytes / 1024, us, out_mb, ms * 1e3 / n, ms * 1e3 / n - us);
     hipFree(out); hipFree(sink);
 }
+// The same chain of dependent launches captured once into a hipGraph and replayed: is the per-kernel cost any lower than in a stream?
+static void run_graph(const char* what, int grid, int block, int lds_bytes, float us, double out_mb = 0.0) {
+    float* sink; hipMalloc(&sink, 4);
+    const int f4 = (int)(out_mb * 1e6 / 16 / grid);
+    float4* out; hipMalloc(&out, (size_t)grid * (f4 + 1) * 16);
+    hipStream_t st; hipStreamCreate(&st);
+    const int n = 300, ticks = (int)(us * 100);
+    hipGraph_t g; hipGraphExec_t ge;
+    hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal);
+    for (int i = 0; i < n; ++i) hipLaunchKernelGGL(body, dim3(grid), dim3(block), lds_bytes, st, ticks, sink, out, f4);
+    if (hipStreamEndCapture(st, &g) != hipSuccess || hipGraphInstantiate(&ge, g, nullptr, nullptr, 0) != hipSuccess) { printf("graph capture failed\n"); return; }
+    hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+    hipGraphLaunch(ge, st); hipStreamSynchronize(st);
+    hipEventRecord(e0, st);
+    hipGraphLaunch(ge, st);
+    hipEventRecord(e1, st); hipStreamSynchronize(st);
+    float ms; hipEventElapsedTime(&ms, e0, e1);
+    printf("%-58s grid %5d x %4d threads, %3d KB LDS, body %.1f us, %4.1f MB written: %.2f us per node   = body + %.2f   (hipGraph of %d nodes)\n", what, grid,
+           block, lds_bytes / 1024, us, out_mb, ms * 1e3 / n, ms * 1e3 / n - us, n);
+    hipGraphExecDestroy(ge); hipGraphDestroy(g); hipStreamDestroy(st); hipFree(out); hipFree(sink);
+}
 int main() {
     for (float us : {0.f, 4.f}) {
         run("one workgroup", 1, 64, 1024, us);
@@ -42,5 +63,10 @@ int main() {
     }
     for (double mb : {1.0, 2.0, 5.0, 10.0, 20.0}) run("pose kernels' shape, writing", 1024, 256, 32 * 1024, 4.f, mb);
     for (double mb : {2.0, 6.0}) run("VPoser kernels' shape, writing", 256, 512, 82 * 1024, 4.f, mb);
+    for (float us : {0.f, 4.f}) {
+        run_graph("graph: pose kernels' shape (1024 frames)", 1024, 256, 32 * 1024, us);
+        run_graph("graph: VPoser kernels' shape", 256, 512, 82 * 1024, us);
+    }
+    run_graph("graph: pose kernels' shape, writing", 1024, 256, 32 * 1024, 4.f, 5.0);
     return 0;
 }
