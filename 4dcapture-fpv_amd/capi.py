@@ -38,6 +38,13 @@ class Fit2dStage(ctypes.Structure):
                 ("w_data", c_float), ("w_pose", c_float), ("w_shape", c_float), ("w_hand", c_float)]
 
 
+class LbfgsConfig(ctypes.Structure):
+    """include/fdcap.h fdcap_lbfgs_config: torch.optim.LBFGS's arguments + SMPLify-X's loop around optimizer.step()."""
+    _fields_ = [("dim", c_int32), ("history", c_int32), ("max_iter", c_int32), ("max_eval", c_int32), ("max_steps", c_int32),
+                ("max_ls", c_int32), ("lr", c_float), ("tolerance_grad", c_float), ("tolerance_change", c_float),
+                ("ftol", c_float), ("gtol", c_float)]
+
+
 class OptConfig(ctypes.Structure):
     _fields_ = [("n_total", c_int32), ("n_local", c_int32), ("frame0", c_int32), ("lr", c_float),
                 ("weight_loss_rec", c_float), ("weight_loss_vposer", c_float), ("weight_contact", c_float),
@@ -100,6 +107,13 @@ SYMBOLS = {
     "fdcap_opt_set_keypoints": (c_int32, [c_void_p, c_void_p, c_void_p]),
     "fdcap_opt_backward_fit2d": (c_int32, [c_void_p, POINTER(Fit2dStage), c_int32, c_void_p]),
     "fdcap_opt_reset_adam": (c_int32, [c_void_p, c_void_p]),
+    "fdcap_lbfgs_create": (c_int32, [c_int32, POINTER(LbfgsConfig), POINTER(c_void_p)]),
+    "fdcap_lbfgs_destroy": (None, [c_void_p]),
+    "fdcap_lbfgs_reset": (c_int32, [c_void_p, c_void_p]),
+    "fdcap_lbfgs_advance": (c_int32, [c_void_p, c_void_p, c_int32, c_void_p, c_void_p, c_int32, c_void_p, c_void_p]),
+    "fdcap_lbfgs_get_stats": (c_int32, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "fdcap_opt_fit2d_lbfgs": (c_int32, [c_void_p, POINTER(Fit2dStage), POINTER(LbfgsConfig), c_int32, POINTER(c_int32), c_void_p]),
+    "fdcap_opt_fit2d_lbfgs_stats": (c_int32, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "fdcap_opt_step_rows_and_pack": (c_int32, [c_void_p, c_int32, c_int32, c_void_p, c_void_p]),
     "fdcap_opt_unpack_and_step_scale": (c_int32, [c_void_p, c_int32, c_int32, c_void_p, c_int32, c_int32, c_void_p]),
     "fdcap_opt_forward_ahead": (c_int32, [c_void_p, c_int32, c_int32, c_int32, c_void_p]),

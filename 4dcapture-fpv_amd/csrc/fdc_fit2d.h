@@ -49,10 +49,12 @@ FDC_HD float fit2d_prior_grad(const Fit2dStage& s, int e, float x, float* val) {
 
 #if defined(__HIPCC__)
 // block (128 threads) per frame: dX (=) prior gradients, dJw (=) reprojection gradients of the 23 joints;
-// losses (optional, logging): [0] += data term, [1] += priors
+// losses (optional, logging): [0] += data term, [1] += priors; floss (optional) [frame] = this frame's data term + priors
+// (the value a per-frame line search needs: fdcap_opt_fit2d_lbfgs)
 __global__ __launch_bounds__(128) void fit2d_loss_kernel(Fit2dStage s, const float* __restrict__ X, const float* __restrict__ Jw,
                                                          const float* __restrict__ kp, int row0, float* __restrict__ dX,
-                                                         float* __restrict__ dJw, double* __restrict__ losses) {
+                                                         float* __restrict__ dJw, double* __restrict__ losses,
+                                                         float* __restrict__ floss = nullptr) {
     __shared__ float sred[2][2];
     const int tid = threadIdx.x, r = row0 + blockIdx.x;
     float data = 0.f, prior = 0.f;
@@ -65,7 +67,7 @@ __global__ __launch_bounds__(128) void fit2d_loss_kernel(Fit2dStage s, const flo
         float* o = dJw + ((size_t)r * NJW + tid) * 3;
         o[0] = dJ.x; o[1] = dJ.y; o[2] = dJ.z;
     }
-    if (!losses) return;
+    if (!losses && !floss) return;
     float vals[2] = {data, prior};
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
@@ -75,7 +77,8 @@ __global__ __launch_bounds__(128) void fit2d_loss_kernel(Fit2dStage s, const flo
         if ((tid & 63) == 0) sred[tid >> 6][i] = v;
     }
     __syncthreads();
-    if (tid < 2) atomicAdd(&losses[tid], (double)(sred[0][tid] + sred[1][tid]));
+    if (floss && tid == 0) floss[blockIdx.x] = (sred[0][0] + sred[1][0]) + (sred[0][1] + sred[1][1]);
+    if (losses && tid < 2) atomicAdd(&losses[tid], (double)(sred[0][tid] + sred[1][tid]));
 }
 #endif
 

@@ -34,6 +34,7 @@ __device__ unsigned long long g_fr_times[3][2048 * 8];
 #include "fdc_frame.h"
 #include "fdc_gemm.h"
 #include "fdc_host_setup.h"
+#include "fdc_lbfgs.h"
 #include "fdc_loss.h"
 #include "fdc_math.h"
 #include "fdc_panel.h"
@@ -1410,6 +1411,8 @@ struct OptState {
     DevBuf<float> Voff, Vw, dist, pd, dVoff;
     DevBuf<int> idx, pi;
     DevBuf<float> kp2d;       // per-frame inner fit: 2D keypoints [n_local,23,3] (u, v, confidence)
+    DevBuf<float> floss;      // ... and the per-frame objective of its L-BFGS variant
+    fdcap_lbfgs* lbfgs = nullptr;
     DevBuf<float4> seedpt;    // coordinates (+ position in the sorted scene) of each query's current neighbour: next launch's seed
     // work-list cache of the in-loop NN launch (fdc_chamfer.h NNCache): ids [groups * 4][64], hdr [groups * 4], anchors [4][nq]
     bool skin_vec = true;          // FDCAP_SKIN_VEC=0 (read by fdcap_opt_create; A/B): the scalar-load skinning backward
@@ -1447,6 +1450,16 @@ struct OptState {
 };
 
 }  // namespace
+
+struct fdcap_lbfgs {          // batched L-BFGS (csrc/fdc_lbfgs.h): n independent problems
+    int n = 0;
+    LbfgsCfg cf{};
+    DevBuf<LbfgsScalars> S;
+    DevBuf<float> W, RO;      // per problem: vector workspace, 1 / (y . s) of the history pairs
+    DevBuf<int> active;
+    int* active_h = nullptr;  // pinned
+    int round = 0;            // rounds since the last reset: active[round & 1] is the counter of the current one
+};
 
 struct fdcap_ctx {
     int V = 0;
@@ -2405,7 +2418,8 @@ void fdcap_opt_destroy(fdcap_ctx* c) {
                            &o->dsv, &o->dPF, &o->dJw, &o->dX, &o->dCAM, &o->dscale_row, &o->loss_rows, &o->VoffF, &o->VwF, &o->dVF};
     for (auto* b : fb) b->release();
     o->dctD.release(); o->dctCoef.release(); o->dctM.release(); o->dctV.release(); o->adam_tab.release();
-    o->idx.release(); o->pi.release(); o->seedpt.release(); o->kp2d.release();
+    o->idx.release(); o->pi.release(); o->seedpt.release(); o->kp2d.release(); o->floss.release();
+    if (o->lbfgs) { fdcap_lbfgs_destroy(o->lbfgs); o->lbfgs = nullptr; }
     o->nnc_ids.release(); o->nnc_hdr.release(); o->nnc_anchor.release();
     for (hipEvent_t e : o->nn_ev) (void)hipEventDestroy(e);
     o->nn_ev.clear();
@@ -2857,6 +2871,134 @@ int fdcap_opt_backward_fit2d(fdcap_ctx* c, const fdcap_fit2d_stage* sg, int32_t 
                        o->dscale_row.p, ParamLossIn(), (const float*)nullptr);
     { int eb = opt_vposer_backward(c, true, st); if (eb) return eb; }
     return (int)hipGetLastError();
+}
+
+// ---- batched L-BFGS (csrc/fdc_lbfgs.h) ------------------------------------------------------------------------------
+static int lbfgs_cfg_ok(const fdcap_lbfgs_config* cf) {
+    return cf && cf->dim > 0 && cf->dim <= LB_DPAD && cf->history > 0 && cf->history <= LB_HMAX && cf->max_iter > 0 && cf->max_steps > 0 &&
+           cf->max_ls > 0 && cf->lr > 0.f;
+}
+int fdcap_lbfgs_create(int32_t n, const fdcap_lbfgs_config* cf, fdcap_lbfgs** out) {
+    if (!out || n <= 0 || !lbfgs_cfg_ok(cf)) return FDCAP_E_ARG;
+    { int nd = 0; if (hipGetDeviceCount(&nd) != hipSuccess || nd <= 0) return FDCAP_E_NODEVICE; }
+    fdcap_lbfgs* L = new (std::nothrow) fdcap_lbfgs();
+    if (!L) return FDCAP_E_ARG;
+    L->n = n;
+    L->cf = {cf->dim, cf->history, cf->max_iter, cf->max_eval > 0 ? cf->max_eval : cf->max_iter * 5 / 4, cf->max_steps, cf->max_ls,
+             cf->lr, cf->tolerance_grad, cf->tolerance_change, cf->ftol, cf->gtol};
+    hipError_t e = L->S.ensure(n);
+    if (e == hipSuccess) e = L->W.ensure((size_t)n * lbfgs_ws_floats(cf->history));
+    if (e == hipSuccess) e = L->RO.ensure((size_t)n * LB_HMAX);
+    if (e == hipSuccess) e = L->active.ensure(2);
+    if (e == hipSuccess) e = hipHostMalloc((void**)&L->active_h, sizeof(int), hipHostMallocDefault);
+    if (e == hipSuccess) { int r = fdcap_lbfgs_reset(L, nullptr); if (r == 0) e = hipDeviceSynchronize(); else e = (hipError_t)r; }
+    if (e != hipSuccess) { fdcap_lbfgs_destroy(L); return (int)e; }
+    *out = L;
+    return FDCAP_OK;
+}
+void fdcap_lbfgs_destroy(fdcap_lbfgs* L) {
+    if (!L) return;
+    L->S.release(); L->W.release(); L->RO.release(); L->active.release();
+    if (L->active_h) (void)hipHostFree(L->active_h);
+    delete L;
+}
+int fdcap_lbfgs_reset(fdcap_lbfgs* L, void* stream) {
+    if (!L) return FDCAP_E_ARG;
+    hipStream_t st = (hipStream_t)stream;
+    HIP_TRY(hipMemsetAsync(L->S.p, 0, (size_t)L->n * sizeof(LbfgsScalars), st));      // phase 0 = LB_INIT
+    HIP_TRY(hipMemsetAsync(L->W.p, 0, (size_t)L->n * lbfgs_ws_floats(L->cf.hist) * sizeof(float), st));
+    HIP_TRY(hipMemsetAsync(L->RO.p, 0, (size_t)L->n * LB_HMAX * sizeof(float), st));
+    HIP_TRY(hipMemsetAsync(L->active.p, 0, 2 * sizeof(int), st));
+    L->round = 0;
+    return FDCAP_OK;
+}
+int fdcap_lbfgs_advance(fdcap_lbfgs* L, float* x, int32_t x_stride, const float* f, const float* g, int32_t g_stride, int32_t* n_active,
+                        void* stream) {
+    if (!L || !x || !f || !g || x_stride < L->cf.dim || g_stride < L->cf.dim) return FDCAP_E_ARG;
+    hipStream_t st = (hipStream_t)stream;
+    int* const cnt = L->active.p + (L->round & 1);            // this round's counter was zeroed by the previous round's launch
+    hipLaunchKernelGGL(lbfgs_advance_kernel, dim3(L->n), dim3(64), 0, st, L->cf, L->S.p, L->W.p, L->RO.p, x, x_stride, f, g, g_stride, cnt,
+                       L->active.p + ((L->round + 1) & 1));
+    L->round++;
+    if (n_active) HIP_TRY(hipMemcpyAsync(n_active, cnt, sizeof(int32_t), hipMemcpyDeviceToDevice, st));
+    return (int)hipGetLastError();
+}
+namespace {
+__global__ void lbfgs_stats_kernel(const LbfgsScalars* __restrict__ S, int n, int* __restrict__ it, int* __restrict__ ev, float* __restrict__ loss) {
+    const int p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= n) return;
+    if (it) it[p] = S[p].n_iter_total;
+    if (ev) ev[p] = S[p].evals_total;
+    if (loss) loss[p] = S[p].loss;
+}
+}
+int fdcap_lbfgs_get_stats(fdcap_lbfgs* L, int32_t* it, int32_t* ev, float* loss, void* stream) {
+    if (!L) return FDCAP_E_ARG;
+    hipLaunchKernelGGL(lbfgs_stats_kernel, dim3((L->n + 127) / 128), dim3(128), 0, (hipStream_t)stream, L->S.p, L->n, it, ev, loss);
+    return (int)hipGetLastError();
+}
+
+// one evaluation of the inner fit's objective: forward, loss (+ per-frame value), backward
+static int fit2d_eval(fdcap_ctx* c, const fdcap_fit2d_stage* sg, double* losses, float* floss, hipStream_t st) {
+    OptState* o = c->opt;
+    const int nl = o->cfg.n_local;
+    Fit2dStage s = {sg->fx, sg->fy, sg->cx, sg->cy, sg->rho, sg->w_data, sg->w_pose, sg->w_shape, sg->w_hand};
+    PoseModel pm = c->pose_model();
+    int row_lo, row_hi;
+    opt_row_range(o, 1, &row_lo, &row_hi);
+    int e = opt_pose_forward(c, row_lo, row_hi, st);
+    if (e) return e;
+    hipLaunchKernelGGL(fit2d_loss_kernel, dim3(nl), dim3(128), 0, st, s, o->X.p, o->Jw.p, o->kp2d.p, 2, o->dX.p, o->dJw.p, losses, floss);
+    hipLaunchKernelGGL(pose_bwd_kernel, dim3(nl), dim3(64 * POSE_NW), 0, st, pm, o->X.p, o->O.p, o->CAM.p, o->scale.p, 2, o->Rm.p,
+                       o->Jrest.p, o->G.p, (const float*)nullptr, (const float*)nullptr, o->dJw.p, (const float*)nullptr,
+                       (const float*)nullptr, (const float*)nullptr, 0, (const float*)nullptr, o->dX.p, o->dO.p, o->dCAM.p,
+                       o->dscale_row.p, ParamLossIn(), (const float*)nullptr);
+    { int eb = opt_vposer_backward(c, true, st); if (eb) return eb; }
+    return (int)hipGetLastError();
+}
+
+int fdcap_opt_fit2d_lbfgs(fdcap_ctx* c, const fdcap_fit2d_stage* sg, const fdcap_lbfgs_config* cfg, int32_t max_rounds, int32_t* rounds_out,
+                          void* stream) {
+    if (!c || !c->opt || !sg || !cfg || max_rounds <= 0) return FDCAP_E_ARG;
+    { int es_ = opt_sync(c, (hipStream_t)stream); if (es_) return es_; }
+    OptState* o = c->opt;
+    if (!o->kp2d.p) return FDCAP_E_STATE;
+    hipStream_t st = (hipStream_t)stream;
+    const int nl = o->cfg.n_local;
+    fdcap_lbfgs_config cf = *cfg;
+    cf.dim = XDIM;
+    if (!lbfgs_cfg_ok(&cf)) return FDCAP_E_ARG;
+    if (o->lbfgs && (o->lbfgs->n != nl || o->lbfgs->cf.hist != cf.history)) { fdcap_lbfgs_destroy(o->lbfgs); o->lbfgs = nullptr; }
+    if (!o->lbfgs) { int e = fdcap_lbfgs_create(nl, &cf, &o->lbfgs); if (e) return e; }
+    fdcap_lbfgs* L = o->lbfgs;
+    L->cf = {cf.dim, cf.history, cf.max_iter, cf.max_eval > 0 ? cf.max_eval : cf.max_iter * 5 / 4, cf.max_steps, cf.max_ls,
+             cf.lr, cf.tolerance_grad, cf.tolerance_change, cf.ftol, cf.gtol};
+    { int e = fdcap_lbfgs_reset(L, st); if (e) return e; }
+    HIP_TRY(o->floss.ensure(nl));
+    o->ahead = false; o->log_pending = false; o->log_dst = nullptr;
+    int rounds = 0, e = 0;
+    const int poll = 8;                                       // rounds between two looks at the number of frames still running
+    while (rounds < max_rounds) {
+        e = fit2d_eval(c, sg, nullptr, o->floss.p, st);
+        if (e) break;
+        e = fdcap_lbfgs_advance(L, o->X.p + 2 * XDIM, XDIM, o->floss.p, o->dX.p + 2 * XDIM, XDIM, nullptr, st);
+        if (e) break;
+        ++rounds;
+        if (rounds % poll == 0 || rounds == max_rounds) {
+            HIP_TRY(hipMemcpyAsync(L->active_h, L->active.p + ((L->round - 1) & 1), sizeof(int), hipMemcpyDeviceToHost, st));
+            HIP_TRY(hipStreamSynchronize(st));
+            if (*L->active_h == 0) break;
+        }
+    }
+    if (rounds_out) *rounds_out = rounds;
+    if (e) return e;
+    HIP_TRY(hipStreamSynchronize(st));
+    return FDCAP_OK;
+}
+
+int fdcap_opt_fit2d_lbfgs_stats(fdcap_ctx* c, int32_t* it, int32_t* ev, float* loss, void* stream) {
+    if (!c || !c->opt || !c->opt->lbfgs) return FDCAP_E_STATE;
+    return fdcap_lbfgs_get_stats(c->opt->lbfgs, it, ev, loss, stream);
 }
 
 // zero Adam's moments of body_rotation_rec (SMPLify-X builds a fresh optimiser for every stage of the fit)

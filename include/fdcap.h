@@ -314,6 +314,44 @@ int fdcap_opt_set_keypoints(fdcap_ctx* ctx, const float* kp_d, void* stream);
 int fdcap_opt_backward_fit2d(fdcap_ctx* ctx, const fdcap_fit2d_stage* stage, int32_t log_terms, void* stream);
 int fdcap_opt_reset_adam(fdcap_ctx* ctx, void* stream);
 
+/* ---- batched L-BFGS with a strong-Wolfe line search (csrc/fdc_lbfgs.h) ----
+ * SMPLify-X fits every frame with L-BFGS (its `optimizer.step(closure)` loop with line_search_fn = "strong_wolfe"), not Adam;
+ * neither is in the reference repository (README.md:14-17 delegates the per-frame fit).  The algorithm is the published one
+ * of torch.optim.LBFGS, restated as a resumable state machine per problem: n_problems INDEPENDENT problems of `dim` <= 128
+ * unknowns advance together, one launch between two evaluations of the caller's objective.
+ *   max_iter / max_eval / history / lr / tolerance_grad / tolerance_change: torch.optim.LBFGS's arguments (max_eval <= 0:
+ *       max_iter * 5 / 4; history <= 128);  max_ls: evaluations per line search (torch: 25);
+ *   max_steps, ftol, gtol: SMPLify-X's loop around optimizer.step(): at most max_steps calls, stop when the loss at the start
+ *       of two successive calls differs by <= ftol relative to max(|a|, |b|, 1) or every gradient entry is below gtol
+ *       (max_steps = 1, ftol = gtol = 0: exactly one optimizer.step()). */
+typedef struct fdcap_lbfgs_config {
+    int32_t dim, history, max_iter, max_eval, max_steps, max_ls;
+    float lr, tolerance_grad, tolerance_change, ftol, gtol;
+} fdcap_lbfgs_config;
+typedef struct fdcap_lbfgs fdcap_lbfgs;
+int fdcap_lbfgs_create(int32_t n_problems, const fdcap_lbfgs_config* cfg, fdcap_lbfgs** out);
+void fdcap_lbfgs_destroy(fdcap_lbfgs* opt);
+/* forget everything (a fresh optimiser, as SMPLify-X builds for every stage) */
+int fdcap_lbfgs_reset(fdcap_lbfgs* opt, void* stream);
+/* One round.  In: f_d DEVICE [n_problems], g_d DEVICE [n_problems rows of g_stride floats] = objective and gradient at the
+ * points in x_d DEVICE [n_problems rows of x_stride floats] (the first call after create / reset: at the starting points).
+ * Out: x_d = the next points to evaluate (for a finished problem: its result, no longer touched); n_active_d DEVICE int32 (may
+ * be NULL) = problems that want another round.  Call until n_active is 0. */
+int fdcap_lbfgs_advance(fdcap_lbfgs* opt, float* x_d, int32_t x_stride, const float* f_d, const float* g_d, int32_t g_stride,
+                        int32_t* n_active_d, void* stream);
+/* per problem, DEVICE, any may be NULL: iterations [n] (L-BFGS directions taken), evaluations [n] (objective calls consumed),
+ * loss [n] (objective at the accepted point) */
+int fdcap_lbfgs_get_stats(fdcap_lbfgs* opt, int32_t* iterations_d, int32_t* evaluations_d, float* loss_d, void* stream);
+
+/* The inner fit of one stage with L-BFGS instead of Adam: rounds of (forward, fit2d loss, backward, fdcap_lbfgs_advance on the
+ * n_local rows of body_rotation_rec) until every frame has stopped or max_rounds evaluations were made; a fresh optimiser per
+ * call; cfg->dim is ignored (78).  *rounds_out (may be NULL) = evaluations made.  Synchronises `stream` every few rounds (to
+ * read the number of frames still running) and before it returns. */
+int fdcap_opt_fit2d_lbfgs(fdcap_ctx* ctx, const fdcap_fit2d_stage* stage, const fdcap_lbfgs_config* cfg, int32_t max_rounds,
+                          int32_t* rounds_out, void* stream);
+/* fdcap_lbfgs_get_stats of the last fdcap_opt_fit2d_lbfgs call, per frame [n_local] (FDCAP_E_STATE before the first) */
+int fdcap_opt_fit2d_lbfgs_stats(fdcap_ctx* ctx, int32_t* iterations_d, int32_t* evaluations_d, float* loss_d, void* stream);
+
 /* Multi-GPU iteration tail with ONE collective per iteration (instead of an all-reduce before the
  * step and point-to-point halo messages after it):
  *   fdcap_opt_step_rows_and_pack : Adam on body_rotation_rec / camera_ext of the owned rows, then writes

@@ -4,8 +4,10 @@ TEST INFRASTRUCTURE (see oracle/__init__.py).  NOT restated from /root/reference
 SMPLify-X step there (README.md:14-17).  **Parity unpinned**: the objective is written down from the published SMPLify-X
 data term (GMoF-robust, confidence-weighted joint reprojection through a pinhole camera; the in-repo viewers use
 fx = fy = 692, cx = 640, cy = 360, vis.py:358-360) and its L2 priors on the VPoser latent, betas and hand PCA
-coefficients, in five weight stages; the optimiser is Adam with a fresh state per stage (SMPLify-X uses L-BFGS with a
-strong-Wolfe line search -- a documented deviation).  This file is the autograd twin of csrc/fdc_fit2d.h."""
+coefficients, in five weight stages; the optimiser is Adam with a fresh state per stage (`fitting`, round 3) or, as in
+SMPLify-X, L-BFGS with a strong-Wolfe line search (`fitting_lbfgs`: torch.optim.LBFGS ITSELF, one instance per frame and
+stage, inside SMPLify-X's loop around optimizer.step() -- the checker of csrc/fdc_lbfgs.h).  This file is the autograd twin
+of csrc/fdc_fit2d.h."""
 import torch
 
 from . import rotrepr
@@ -60,3 +62,51 @@ class InnerFitOracle:
                 opt.step()
         self.x78 = x.detach()
         return rotrepr.convert_to_3D_rot(x).detach()
+
+    def fitting_lbfgs(self, rows75, keypoints, stages=DEFAULT_STAGES, history=100, max_iter=30, max_eval=0, max_steps=30, lr=1.0,
+                      tolerance_grad=1e-7, tolerance_change=1e-9, ftol=2e-9, gtol=1e-9):
+        """Every frame its own problem, as SMPLify-X fits it: per stage a fresh torch.optim.LBFGS(strong_wolfe) and
+        [upstream-recall: smplifyx FittingMonitor.run_fitting] `for n in range(maxiters): loss = optimizer.step(closure)`, stopping
+        when the loss is not finite, when n > 0 and |prev - loss| / max(|prev|, |loss|, 1) <= ftol, or when every gradient entry is
+        below gtol.  (gtol is tested on the ACCEPTED point's gradient here and in the kernel; SMPLify-X reads param.grad, which
+        holds the last line-search trial's.)  -> rows75 [N,75]; self.evals [stage][frame] = closure calls."""
+        x_all = rotrepr.convert_to_6D_rot(torch.as_tensor(rows75).to(self.dtype)).detach().clone()
+        kp_all = torch.as_tensor(keypoints).to(self.dtype)
+        self.evals, self.final_loss = [], []
+        for stage in stages:
+            ev, fl = [], []
+            for f in range(x_all.shape[0]):
+                x = x_all[f:f + 1].clone().requires_grad_(True)
+                kp = kp_all[f:f + 1]
+                opt = torch.optim.LBFGS([x], lr=lr, max_iter=max_iter, max_eval=max_eval if max_eval > 0 else None,
+                                        history_size=history, tolerance_grad=tolerance_grad, tolerance_change=tolerance_change,
+                                        line_search_fn="strong_wolfe")
+                calls = [0]
+
+                def closure():
+                    opt.zero_grad()
+                    data, prior = self.loss(x, kp, stage)
+                    loss = data + prior
+                    loss.backward()
+                    calls[0] += 1
+                    return loss
+                prev = None
+                for n in range(max_steps):
+                    loss = float(opt.step(closure).detach())
+                    if not (abs(loss) < float("inf")):
+                        break
+                    if n > 0 and prev is not None and ftol > 0 and abs(prev - loss) / max(abs(prev), abs(loss), 1.0) <= ftol:
+                        break
+                    with torch.enable_grad():
+                        g = torch.autograd.grad(sum(self.loss(x, kp, stage)), x)[0]
+                    if float(g.abs().max()) < gtol:
+                        break
+                    prev = loss
+                x_all[f] = x.detach()[0]
+                ev.append(calls[0])
+                with torch.no_grad():
+                    fl.append(float(sum(self.loss(x, kp, stage))))
+            self.evals.append(ev)
+            self.final_loss.append(fl)
+        self.x78 = x_all
+        return rotrepr.convert_to_3D_rot(x_all).detach()

@@ -1,0 +1,266 @@
+"""GPU tests of the batched L-BFGS / strong-Wolfe state machine (csrc/fdc_lbfgs.h, include/fdcap.h fdcap_lbfgs_*) and of
+the inner fit that uses it (fdcap_opt_fit2d_lbfgs).
+
+The checker is torch.optim.LBFGS(line_search_fn="strong_wolfe") ITSELF, on the CPU, one instance per problem, fed the same
+objective: the kernel restates that published algorithm, so the two must take the same decisions.  Objective values and
+gradients are computed by the SAME CPU code for both sides (the state machine only consumes f and g), so what differs is
+the optimiser's own arithmetic: the summation order of its dot products and torch's mixed float / double scalars."""
+import ctypes
+
+import numpy as np
+import pytest
+import torch
+
+import fdcap_amd  # noqa: F401
+from fdcap_amd import capi
+
+pytestmark = pytest.mark.gpu
+
+
+class Quadratic:
+    """f = 1/2 x'Ax - b'x, A symmetric positive definite with condition number ~ 300"""
+    dim = 78
+
+    def __init__(self, rng):
+        q, _ = np.linalg.qr(rng.standard_normal((self.dim, self.dim)))
+        self.A = torch.tensor((q * np.geomspace(1.0, 300.0, self.dim)) @ q.T, dtype=torch.float32)
+        self.b = torch.tensor(rng.standard_normal(self.dim), dtype=torch.float32)
+        self.x0 = torch.tensor(rng.standard_normal(self.dim), dtype=torch.float32)
+
+    def __call__(self, x):
+        return 0.5 * x @ (self.A @ x) - self.b @ x
+
+
+class Rosenbrock:
+    dim = 10
+
+    def __init__(self, rng):
+        self.x0 = torch.tensor(rng.uniform(-1.5, 1.5, self.dim), dtype=torch.float32)
+
+    def __call__(self, x):
+        return torch.sum(100.0 * (x[1:] - x[:-1] ** 2) ** 2 + (1.0 - x[:-1]) ** 2)
+
+
+class RobustFit:
+    """Geman-McClure residuals of a linear model + an L2 prior: the shape of the inner fit's objective"""
+    dim = 40
+
+    def __init__(self, rng):
+        self.M = torch.tensor(rng.standard_normal((120, self.dim)), dtype=torch.float32)
+        xt = rng.standard_normal(self.dim)
+        y = self.M.numpy() @ xt + 0.05 * rng.standard_normal(120)
+        y[::9] += 8.0                                               # outliers
+        self.y = torch.tensor(y, dtype=torch.float32)
+        self.x0 = torch.tensor(xt + 0.7 * rng.standard_normal(self.dim), dtype=torch.float32)
+
+    def __call__(self, x):
+        r2 = (self.M @ x - self.y) ** 2
+        return torch.sum(4.0 * r2 / (r2 + 4.0)) + 0.01 * torch.sum(x ** 2)
+
+
+def _value_and_grad(fun, x):
+    x = x.detach().clone().requires_grad_(True)
+    f = fun(x)
+    f.backward()
+    return float(f.detach()), x.grad.detach()
+
+
+def _torch_lbfgs(fun, cfg):
+    """SMPLify-X's loop around torch.optim.LBFGS.step (oracle/innerfit.py fitting_lbfgs has the same loop)."""
+    x = fun.x0.clone().requires_grad_(True)
+    opt = torch.optim.LBFGS([x], lr=cfg["lr"], max_iter=cfg["max_iter"], max_eval=None, history_size=cfg["history"],
+                            tolerance_grad=cfg["tolerance_grad"], tolerance_change=cfg["tolerance_change"], line_search_fn="strong_wolfe")
+    calls = [0]
+
+    def closure():
+        opt.zero_grad()
+        f = fun(x)
+        f.backward()
+        calls[0] += 1
+        return f
+    prev, steps = None, 0
+    for n in range(cfg["max_steps"]):
+        loss = float(opt.step(closure).detach())
+        steps += 1
+        if not np.isfinite(loss):
+            break
+        if n > 0 and cfg["ftol"] > 0 and abs(prev - loss) / max(abs(prev), abs(loss), 1.0) <= cfg["ftol"]:
+            break
+        if float(_value_and_grad(fun, x)[1].abs().max()) < cfg["gtol"]:
+            break
+        prev = loss
+    f_end = float(fun(x.detach()))
+    return x.detach().clone(), f_end, opt.state[x]["n_iter"], calls[0] - (steps - 1)      # (the kernel does not repeat the closure call that opens a later step)
+
+
+def _run_kernel(funs, cfg, max_rounds=5000):
+    lib = capi.load_library()
+    n, dim = len(funs), funs[0].dim
+    stride = dim + 3                                                # rows wider than the problem: the strides are honoured
+    cf = capi.LbfgsConfig(dim, cfg["history"], cfg["max_iter"], 0, cfg["max_steps"], 25, cfg["lr"], cfg["tolerance_grad"],
+                          cfg["tolerance_change"], cfg["ftol"], cfg["gtol"])
+    h = ctypes.c_void_p()
+    capi.check(lib.fdcap_lbfgs_create(n, ctypes.byref(cf), ctypes.byref(h)), "fdcap_lbfgs_create")
+    X = torch.full((n, stride), 7.0, device="cuda")
+    X[:, :dim] = torch.stack([f.x0 for f in funs]).cuda()
+    active = torch.zeros(1, dtype=torch.int32, device="cuda")
+    rounds = 0
+    try:
+        while rounds < max_rounds:
+            xc = X[:, :dim].cpu()
+            fg = [_value_and_grad(f, xc[i]) for i, f in enumerate(funs)]
+            F = torch.tensor([v for v, _ in fg], dtype=torch.float32, device="cuda")
+            G = torch.zeros(n, stride, device="cuda")
+            G[:, :dim] = torch.stack([g for _, g in fg]).cuda()
+            capi.check(lib.fdcap_lbfgs_advance(h, capi.dptr(X), stride, capi.dptr(F), capi.dptr(G), stride, capi.dptr(active),
+                                               capi.current_stream()), "fdcap_lbfgs_advance")
+            rounds += 1
+            if int(active.item()) == 0:
+                break
+        it = torch.zeros(n, dtype=torch.int32, device="cuda")
+        ev = torch.zeros(n, dtype=torch.int32, device="cuda")
+        loss = torch.zeros(n, device="cuda")
+        capi.check(lib.fdcap_lbfgs_get_stats(h, capi.dptr(it), capi.dptr(ev), capi.dptr(loss), capi.current_stream()), "fdcap_lbfgs_get_stats")
+        torch.cuda.synchronize()
+        assert torch.all(X[:, dim:] == 7.0), "the kernel wrote outside its problem's columns"
+        return X[:, :dim].cpu(), it.cpu().numpy(), ev.cpu().numpy(), loss.cpu().numpy(), rounds
+    finally:
+        lib.fdcap_lbfgs_destroy(h)
+
+
+CFG = dict(history=100, max_iter=30, max_steps=1, lr=1.0, tolerance_grad=1e-7, tolerance_change=1e-9, ftol=0.0, gtol=0.0)
+
+
+@pytest.mark.parametrize("family,cfg", [
+    (Quadratic, dict(CFG, max_iter=40)),
+    (Quadratic, dict(CFG, max_iter=40, history=5)),                 # the ring buffer turns over
+    (Rosenbrock, dict(CFG, max_iter=15)),                           # the first directions of a curved valley: the same path
+    (Rosenbrock, dict(CFG, max_iter=400)),                          # ... and run to convergence: the same minimum
+    (RobustFit, dict(CFG, max_iter=50)),
+], ids=["quadratic", "quadratic-history5", "rosenbrock-first15", "rosenbrock-converged", "robust"])
+def test_one_optimizer_step_takes_torchs_decisions(family, cfg):
+    """One optimizer.step(closure) of up to max_iter directions: same number of directions and objective calls, same point."""
+    rng = np.random.Generator(np.random.PCG64(11))
+    funs = [family(rng) for _ in range(12)]
+    x, it, ev, loss, rounds = _run_kernel(funs, cfg)
+    same_counts, any_converged = 0, False
+    for i, f in enumerate(funs):
+        xr, fr, itr, evr = _torch_lbfgs(f, cfg)
+        err = float((x[i] - xr).abs().max()) / max(1.0, float(xr.abs().max()))
+        print(f"{family.__name__} {i}: directions {it[i]} / {itr}, objective calls {ev[i]} / {evr}, loss {loss[i]:.6g} / {fr:.6g}, |dx| {err:.2e}")
+        same = it[i] == itr and ev[i] == evr
+        same_counts += int(same)
+        converged = itr < cfg["max_iter"]                           # torch stopped on a tolerance, not on the cap
+        any_converged |= converged
+        # Stopped on a tolerance: the same minimum (the last, rounding-sized steps need not be the same in number).
+        # Stopped by the cap: the same decisions all the way, hence the same point -- unless a comparison sat within rounding
+        # of a tie and sent the two down different, equally valid, paths (counted below).
+        if converged or same:
+            assert abs(float(f(x[i])) - fr) <= 1e-4 * max(1.0, abs(fr)) + 1e-5
+            assert err < (1e-3 if converged else 2e-3)
+    if not any_converged:
+        assert same_counts >= len(funs) - 2, "more than two of twelve problems left torch.optim.LBFGS's path"
+    assert rounds == ev.max()                                        # one objective call per round for the slowest problem, no more
+
+
+def test_the_loop_around_optimizer_step_stops_where_smplifyx_would():
+    """max_steps > 1 with SMPLify-X's ftol rule: a problem stops when two successive step() calls start at (nearly) the same loss."""
+    rng = np.random.Generator(np.random.PCG64(5))
+    cfg = dict(CFG, max_iter=8, max_steps=30, ftol=2e-9, gtol=1e-9)
+    funs = [RobustFit(rng) for _ in range(6)]
+    x, it, ev, loss, rounds = _run_kernel(funs, cfg)
+    for i, f in enumerate(funs):
+        xr, fr, itr, evr = _torch_lbfgs(f, cfg)
+        print(f"robust {i}: directions {it[i]} / {itr}, objective calls {ev[i]} / {evr}, loss {loss[i]:.6g} / {fr:.6g}")
+        assert abs(float(f(x[i])) - fr) <= 1e-4 * max(1.0, abs(fr))
+        assert abs(int(it[i]) - itr) <= max(3, itr // 5)
+    assert it.max() < 8 * 30                                          # nobody ran to the cap: the stopping rules work
+
+
+def test_finished_problems_stay_put_and_bad_arguments_are_refused():
+    lib = capi.load_library()
+    h = ctypes.c_void_p()
+    E_ARG = -1
+    bad = capi.LbfgsConfig(200, 100, 30, 0, 1, 25, 1.0, 1e-7, 1e-9, 0.0, 0.0)              # dim > 128
+    assert lib.fdcap_lbfgs_create(4, ctypes.byref(bad), ctypes.byref(h)) == E_ARG
+    bad = capi.LbfgsConfig(10, 500, 30, 0, 1, 25, 1.0, 1e-7, 1e-9, 0.0, 0.0)               # history > 128
+    assert lib.fdcap_lbfgs_create(4, ctypes.byref(bad), ctypes.byref(h)) == E_ARG
+    rng = np.random.Generator(np.random.PCG64(3))
+    funs = [Quadratic(rng) for _ in range(3)]
+    cfg = dict(CFG, max_iter=3)
+    x, it, ev, loss, rounds = _run_kernel(funs, cfg)
+    for i, f in enumerate(funs):                                     # (max_eval = 3 * 5 // 4 ends the step after one direction, as in torch)
+        xr, fr, itr, evr = _torch_lbfgs(f, cfg)
+        assert it[i] == itr and ev[i] == evr and float((x[i] - xr).abs().max()) < 1e-5
+    # a problem whose gradient is already zero finishes in its first round without moving
+    class Flat:
+        dim = 10
+        x0 = torch.arange(10, dtype=torch.float32)
+        def __call__(self, x):
+            return torch.sum(x * 0.0) + 1.5
+    x, it, ev, loss, rounds = _run_kernel([Flat()], CFG)
+    assert rounds == 1 and it[0] == 0 and torch.equal(x[0], Flat.x0) and loss[0] == 1.5
+
+
+def _px_err(orc, rows, kp):
+    from oracle import rotrepr
+    with torch.no_grad():
+        uv = orc.project(orc.joints_cam(rotrepr.convert_to_6D_rot(torch.tensor(rows)))).numpy()
+    w = kp[..., 2] > 0
+    return float(np.sqrt(((uv - kp[..., :2]) ** 2).sum(-1))[w].mean())
+
+
+def test_inner_fit_with_lbfgs_ends_where_torchs_lbfgs_ends_on_the_oracles_objective():
+    """fdcap_opt_fit2d_lbfgs (every frame its own L-BFGS problem) against oracle/innerfit.py fitting_lbfgs = torch.optim.LBFGS
+    per frame on the oracle's autograd objective, SMPLify-X's settings (30 x 30, ftol 2e-9), in the first stage: its strong priors
+    make the minimum unique enough that two arithmetics reach the same one (the oracle in fp32 and in fp64: objective within
+    1.5e-4, parameters within 4.5e-3 of each other)."""
+    from fdcap_amd.innerfit import DEFAULT_STAGES, InnerFitOP
+    from oracle.innerfit import InnerFitOracle
+    from oracle.smplx import SMPLXOracle
+    from oracle.vposer import VPoserDecoder
+    from tests.test_gpu_innerfit import _case
+    n = 8
+    bm, vp, gt, init, kp = _case(n, 21)
+    stages = DEFAULT_STAGES[0:1]
+    op = InnerFitOP(bm, vp, n, stages=stages, optimizer="lbfgs")
+    out = op.fitting(init, kp, log_every=1).cpu().numpy()
+    orc = InnerFitOracle(SMPLXOracle(bm), VPoserDecoder.from_data(vp))
+    ref = orc.fitting_lbfgs(init, kp, stages).numpy()
+    err = np.abs(out - ref)
+    fl, ofl = op.frame_loss[0], np.array(orc.final_loss[0])
+    print("L-BFGS inner fit, stage 1, vs torch.optim.LBFGS on the oracle: parameters max", err.max(), "q90", np.quantile(err, 0.9),
+          "| objective per frame, worst relative difference", np.abs(fl / ofl - 1).max(), "| evaluation rounds", op.rounds,
+          "oracle closure calls (max over frames)", max(orc.evals[0]), "| directions per frame", op.frame_iterations[0])
+    np.testing.assert_allclose(fl, ofl, rtol=1e-3)
+    np.testing.assert_allclose(op.log[0][0] + op.log[0][1], ofl.sum(), rtol=1e-3)      # re-evaluated at the returned rows
+    assert np.quantile(err, 0.9) < 2e-3 and err.max() < 3e-2
+    assert op.rounds[0] < 30 * 38                                                       # stopped by the rules, not by the cap
+    op.close()
+
+
+def test_five_stage_lbfgs_fit_reduces_the_reprojection_error_like_the_oracles():
+    """BASELINE config 4's schedule with L-BFGS.  The late stages' weak priors leave a flat, non-convex objective: the minimum a
+    run ends in depends on rounding (the oracle in fp32 and fp64: parameters up to 0.7 apart, objective 2.5 %), so the comparison
+    is of the objective reached and of the reprojection error, with that yardstick."""
+    from fdcap_amd.innerfit import DEFAULT_STAGES, InnerFitOP
+    from oracle.innerfit import InnerFitOracle
+    from oracle.smplx import SMPLXOracle
+    from oracle.vposer import VPoserDecoder
+    from tests.test_gpu_innerfit import _case
+    n = 4
+    bm, vp, gt, init, kp = _case(n, 21)
+    op = InnerFitOP(bm, vp, n, optimizer="lbfgs")
+    out = op.fitting(init, kp).cpu().numpy()
+    orc = InnerFitOracle(SMPLXOracle(bm), VPoserDecoder.from_data(vp))
+    ref = orc.fitting_lbfgs(init, kp, DEFAULT_STAGES).numpy()
+    fl, ofl = op.frame_loss[-1], np.array(orc.final_loss[-1])
+    e0, e1, e1o = _px_err(orc, init, kp), _px_err(orc, out, kp), _px_err(orc, ref, kp)
+    print("five stages: objective per frame", fl, "oracle", ofl, "| rounds per stage", op.rounds, "oracle closure calls per stage",
+          [max(e) for e in orc.evals], "| mean reprojection error (px): start", e0, "end", e1, "oracle", e1o)
+    # (measured: one of four frames has two minima, 274 and 312: this library and the fp64 oracle end in the lower one, the fp32
+    # oracle in either depending on the host CPU -- so no frame may end WORSE than the oracle's by more than the yardstick, and the
+    # clip's total agrees to it)
+    assert np.all(fl <= 1.08 * ofl) and abs(fl.sum() / ofl.sum() - 1) < 0.08
+    assert e1 < 0.5 * e0 and abs(e1 - e1o) < 0.25 * e1o + 0.5
+    op.close()
