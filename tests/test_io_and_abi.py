@@ -50,6 +50,33 @@ def test_struct_layouts_match_header():
     assert ctypes.sizeof(capi.ModelDesc) == 8 + 2 * 8 + 8 + 14 * 8   # int32+pad, 2 ptr, int32+pad, 14 ptr
 
 
+def test_ctypes_structs_have_the_c_compilers_layout(tmp_path):
+    """Every struct that crosses the boundary by value or by pointer: field offsets and size as gcc lays out include/fdcap.h,
+    against the ctypes mirrors in capi.py (a field added on one side only shows here, not as a wrong number on the GPU)."""
+    import subprocess
+    pairs = {"fdcap_opt_config": capi.OptConfig, "fdcap_fit2d_stage": capi.Fit2dStage, "fdcap_lbfgs_config": capi.LbfgsConfig,
+             "fdcap_model_desc": capi.ModelDesc}
+    lines = ["#include <stddef.h>", "#include <stdio.h>", '#include "fdcap.h"', "int main(void) {"]
+    for cname, ct in pairs.items():
+        lines.append(f'    printf("{cname} size %zu\\n", sizeof({cname}));')
+        for fname, _ in ct._fields_:
+            lines.append(f'    printf("{cname} {fname} %zu\\n", offsetof({cname}, {fname}));')
+    lines += ["    return 0;", "}"]
+    src = tmp_path / "layout.c"
+    src.write_text("\n".join(lines) + "\n")
+    exe = str(tmp_path / "layout")
+    r = subprocess.run(["gcc", "-std=c11", "-I", os.path.join(ROOT, "include"), str(src), "-o", exe], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    got = {}
+    for ln in subprocess.run([exe], capture_output=True, text=True, check=True).stdout.splitlines():
+        c, f, v = ln.split()
+        got[(c, f)] = int(v)
+    for cname, ct in pairs.items():
+        assert got[(cname, "size")] == ctypes.sizeof(ct), cname
+        for fname, _ in ct._fields_:
+            assert got[(cname, fname)] == getattr(ct, fname).offset, (cname, fname)
+
+
 def test_body_gen_roundtrip_and_output_schema(tmp_path):
     clip = synth.make_clip(6, seed=1)
     io.write_body_gen(clip.body_params, str(tmp_path / "sample" / "body_gen"))
