@@ -20,7 +20,9 @@ namespace fdc {
 
 constexpr int LB_DPAD = 128;     // floats per stored vector: dim <= 128 (an optimiser row is 78)
 constexpr int LB_HMAX = 128;     // history entries at most (torch's default is 100)
-constexpr int LB_PF = 8;         // history pairs fetched ahead of the two-loop recursion's arithmetic
+constexpr int LB_PF = 4;         // history pairs read ahead of the two-loop recursion's arithmetic
+constexpr int LB_NT = 256;       // threads of a workgroup: four waves load the history, the first runs the state machine
+FDC_HD inline size_t lbfgs_lds_bytes(int hist) { return (size_t)(2 * hist + 7) * LB_DPAD * sizeof(float); }    // + LV_NUM work vectors
 
 struct LbfgsCfg {
     int dim, hist, max_iter, max_eval, max_steps, max_ls;
@@ -38,6 +40,7 @@ struct LbfgsScalars {
 
 // vector slots of a problem's workspace, followed by `hist` y vectors and `hist` s vectors
 enum { LV_G = 0, LV_PREVG, LV_D, LV_XINIT, LV_GPREV, LV_BG0, LV_BG1, LV_NUM };
+static_assert(LV_NUM == 7, "lbfgs_lds_bytes counts seven work vectors");
 FDC_HD inline size_t lbfgs_ws_floats(int hist) { return (size_t)(LV_NUM + 2 * hist) * LB_DPAD; }
 
 #if defined(__HIPCC__)
@@ -71,44 +74,76 @@ __device__ __forceinline__ float lb_cubic(float x1, float f1, float g1, float x2
 // counting needs no launch of its own).
 // X [nprob rows of x_stride]: the caller's parameters (read for x_init, written with the next trial point / the accepted point);
 // F [nprob], G [nprob rows of g_stride]: the objective and its gradient at X as the previous call left it.
-__global__ __launch_bounds__(64) void lbfgs_advance_kernel(LbfgsCfg cf, LbfgsScalars* __restrict__ S, float* __restrict__ W,
+__global__ __launch_bounds__(LB_NT) void lbfgs_advance_kernel(LbfgsCfg cf, LbfgsScalars* __restrict__ S, float* __restrict__ W,
                                                            float* __restrict__ RO, float* __restrict__ X, int x_stride,
                                                            const float* __restrict__ F, const float* __restrict__ G, int g_stride,
                                                            int* __restrict__ n_active, int* __restrict__ n_active_next) {
-    __shared__ float s_ro[LB_HMAX], s_al[LB_HMAX];
-    const int p = blockIdx.x, lane = threadIdx.x;
-    if (p == 0 && lane == 0 && n_active_next) *n_active_next = 0;      // the NEXT round's counter (nobody adds to it in this launch)
+    __shared__ float s_ro[LB_HMAX], s_al[LB_HMAX], s_x[LB_DPAD];
+    extern __shared__ float4 s_hist4[];                      // the problem's history: [hist] y vectors, [hist] s vectors; then the work vectors
+    float* const s_hist = (float*)s_hist4;
+    const int p = blockIdx.x;
+    if (p == 0 && threadIdx.x == 0 && n_active_next) *n_active_next = 0;      // the NEXT round's counter (nobody adds to it in this launch)
     LbfgsScalars s = S[p];
     if (s.phase == LB_DONE) return;
     float* const w = W + (size_t)p * lbfgs_ws_floats(cf.hist);
     float* const ro = RO + (size_t)p * LB_HMAX;
-    s_ro[lane] = ro[lane]; s_ro[lane + 64] = ro[lane + 64];
-    __syncthreads();
-    float* const x = X + (size_t)p * x_stride;
+    // All four waves bring the history into LDS in one burst (whether this round ends a line search and needs it is only known
+    // later; read pair by pair when needed, it was 26 dependent round trips of a lone wave: most of the kernel's 30 us).  Until the
+    // ring is full its pairs are slots 0 .. nh-1.
+    {
+        const float4* const gy = (const float4*)(w + (size_t)LV_NUM * LB_DPAD);
+        const float4* const gs = (const float4*)(w + (size_t)(LV_NUM + cf.hist) * LB_DPAD);
+        const int n4 = s.nh * (LB_DPAD / 4), so = cf.hist * (LB_DPAD / 4);
+        for (int i0 = threadIdx.x; i0 < n4; i0 += 4 * LB_NT) {
+            float4 a[4], b[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) { const int i = min(i0 + k * LB_NT, n4 - 1); a[k] = gy[i]; b[k] = gs[i]; }
+#pragma unroll
+            for (int k = 0; k < 4; ++k) { const int i = i0 + k * LB_NT; if (i < n4) { s_hist4[i] = a[k]; s_hist4[so + i] = b[k]; } }
+        }
+        if (threadIdx.x < LB_HMAX) s_ro[threadIdx.x] = ro[threadIdx.x];
+        // ... and the work vectors and the x row with it: read one by one along the state machine they were another six to
+        // eight dependent round trips
+        if (threadIdx.x < LV_NUM * (LB_DPAD / 4)) s_hist4[2 * so + threadIdx.x] = ((const float4*)w)[threadIdx.x];
+        if (threadIdx.x < LB_DPAD) s_x[threadIdx.x] = (int)threadIdx.x < cf.dim ? X[(size_t)p * x_stride + threadIdx.x] : 0.f;
+    }
+    const int lane = threadIdx.x & 63;
     const float* const gr = G + (size_t)p * g_stride;
     const float f_new = F[p];
     const LV g_new = {lane < cf.dim ? gr[lane] : 0.f, lane + 64 < cf.dim ? gr[lane + 64] : 0.f};
+    __syncthreads();
+    if (threadIdx.x >= 64) return;                           // the state machine itself is one wave's work
+    float* const x = X + (size_t)p * x_stride;
     const float c1 = 1e-4f, c2 = 0.9f;
+    float* const s_work = s_hist + (size_t)2 * cf.hist * LB_DPAD;        // the LV_NUM work vectors' copies in LDS
+    auto wld = [&](int slot) -> LV { return {s_work[slot * LB_DPAD + lane], s_work[slot * LB_DPAD + lane + 64]}; };
+    auto wst = [&](int slot, LV v) {                                     // to HBM for the next launch, to LDS for this one
+        lv_st(w + slot * LB_DPAD, v);
+        s_work[slot * LB_DPAD + lane] = v.a; s_work[slot * LB_DPAD + lane + 64] = v.b;
+    };
 
     enum { STEP_BEGIN, ITER_BEGIN, BRACKET_EVALD, ZOOM_ENTER, ZOOM_LOOP, ZOOM_EVALD, ZOOM_EXIT, LS_DONE, STEP_END };
     int st;
     LV g, d;                                                 // the accepted point's gradient; the search direction
     if (s.phase == LB_INIT) {
-        s.loss = f_new; g = g_new; lv_st(w + LV_G * LB_DPAD, g);
+        s.loss = f_new; g = g_new; wst(LV_G, g);
         d = {0.f, 0.f};
         s.evals_total = 1; s.step = 0; s.n_iter_total = 0; s.nh = 0; s.h0 = 0; s.prev_orig = f_new;
         st = STEP_BEGIN;
     } else {
-        g = lv_ld(w + LV_G * LB_DPAD);
-        d = lv_ld(w + LV_D * LB_DPAD);
+        g = wld(LV_G);
+        d = wld(LV_D);
         st = s.phase == LB_WAIT_BRACKET ? BRACKET_EVALD : ZOOM_EVALD;
     }
     auto write_point = [&](float t) {                        // x = x_init + t d
-        const LV xi = lv_ld(w + LV_XINIT * LB_DPAD);
-        if (lane < cf.dim) x[lane] = fmaf(t, d.a, xi.a);
-        if (lane + 64 < cf.dim) x[lane + 64] = fmaf(t, d.b, xi.b);
+        const LV xi = wld(LV_XINIT);
+        const float xa = fmaf(t, d.a, xi.a), xb = fmaf(t, d.b, xi.b);
+        if (lane < cf.dim) x[lane] = xa;
+        if (lane + 64 < cf.dim) x[lane + 64] = xb;
+        s_x[lane] = xa; s_x[lane + 64] = xb;                 // (the next line search of this launch starts from here)
     };
     auto set_low_high = [&]() { s.low = s.bf0 <= s.bf1 ? 0 : 1; };
+    auto ring = [&](int i) { return i >= cf.hist ? i - cf.hist : i; };      // slot of ring position i < 2 hist (no integer division)
 
     bool running = true;
     while (running) {
@@ -123,14 +158,16 @@ __global__ __launch_bounds__(64) void lbfgs_advance_kernel(LbfgsCfg cf, LbfgsSca
             if (s.n_iter_total == 1) {
                 d = {-g.a, -g.b}; s.nh = 0; s.h0 = 0; s.H_diag = 1.f;
             } else {
-                const LV pg = lv_ld(w + LV_PREVG * LB_DPAD);
+                const LV pg = wld(LV_PREVG);
                 const LV y = {g.a - pg.a, g.b - pg.b}, sv = {d.a * s.t, d.b * s.t};
                 const float ys = lv_dot(y, sv);
                 if (ys > 1e-10f) {
-                    if (s.nh == cf.hist) { s.h0 = (s.h0 + 1) % cf.hist; s.nh--; }      // the oldest pair leaves
-                    const int slot = (s.h0 + s.nh) % cf.hist;
+                    if (s.nh == cf.hist) { s.h0 = ring(s.h0 + 1); s.nh--; }      // the oldest pair leaves
+                    const int slot = ring(s.h0 + s.nh);
                     lv_st(w + (size_t)(LV_NUM + slot) * LB_DPAD, y);
                     lv_st(w + (size_t)(LV_NUM + cf.hist + slot) * LB_DPAD, sv);
+                    s_hist[slot * LB_DPAD + lane] = y.a; s_hist[slot * LB_DPAD + lane + 64] = y.b;
+                    s_hist[(cf.hist + slot) * LB_DPAD + lane] = sv.a; s_hist[(cf.hist + slot) * LB_DPAD + lane + 64] = sv.b;
                     const float r = 1.f / ys;
                     s_ro[slot] = r;
                     if (lane == 0) ro[slot] = r;
@@ -138,57 +175,58 @@ __global__ __launch_bounds__(64) void lbfgs_advance_kernel(LbfgsCfg cf, LbfgsSca
                     s.H_diag = ys / lv_dot(y, y);
                 }
                 // The two-loop recursion is a chain of 2 nh dependent dot products; the history pairs it walks over are not part of
-                // the chain, so they are fetched LB_PF pairs at a time ahead of the arithmetic (a lone wave pays a full memory
-                // round trip for every load it waits on: fetched one by one the loads were most of this kernel's 32 us).
+                // the chain: they are read from LDS LB_PF pairs at a time ahead of the arithmetic.
+                // (the ring's position and length as wave-uniform scalars: index arithmetic on the scalar unit, uniform branches)
+                const int nh = __builtin_amdgcn_readfirstlane(s.nh), h0 = __builtin_amdgcn_readfirstlane(s.h0);
                 LV q = {-g.a, -g.b};
-                for (int i0 = s.nh - 1; i0 >= 0; i0 -= LB_PF) {
+                for (int i0 = nh - 1; i0 >= 0; i0 -= LB_PF) {
                     LV yy[LB_PF], sy[LB_PF];
 #pragma unroll
                     for (int k = 0; k < LB_PF; ++k) {
-                        const int slot = (s.h0 + max(i0 - k, 0)) % cf.hist;
-                        yy[k] = lv_ld(w + (size_t)(LV_NUM + slot) * LB_DPAD);
-                        sy[k] = lv_ld(w + (size_t)(LV_NUM + cf.hist + slot) * LB_DPAD);
+                        const int slot = ring(h0 + max(i0 - k, 0));
+                        yy[k] = {s_hist[slot * LB_DPAD + lane], s_hist[slot * LB_DPAD + lane + 64]};
+                        sy[k] = {s_hist[(cf.hist + slot) * LB_DPAD + lane], s_hist[(cf.hist + slot) * LB_DPAD + lane + 64]};
                     }
 #pragma unroll
                     for (int k = 0; k < LB_PF; ++k) {
                         const int i = i0 - k;
                         if (i < 0) break;
-                        const float al = lv_dot(sy[k], q) * s_ro[(s.h0 + i) % cf.hist];
+                        const float al = lv_dot(sy[k], q) * s_ro[ring(h0 + i)];
                         s_al[i] = al;
                         q = {fmaf(-al, yy[k].a, q.a), fmaf(-al, yy[k].b, q.b)};
                     }
                 }
                 LV r = {q.a * s.H_diag, q.b * s.H_diag};
-                for (int i0 = 0; i0 < s.nh; i0 += LB_PF) {
+                for (int i0 = 0; i0 < nh; i0 += LB_PF) {
                     LV yy[LB_PF], sy[LB_PF];
 #pragma unroll
                     for (int k = 0; k < LB_PF; ++k) {
-                        const int slot = (s.h0 + min(i0 + k, s.nh - 1)) % cf.hist;
-                        yy[k] = lv_ld(w + (size_t)(LV_NUM + slot) * LB_DPAD);
-                        sy[k] = lv_ld(w + (size_t)(LV_NUM + cf.hist + slot) * LB_DPAD);
+                        const int slot = ring(h0 + min(i0 + k, nh - 1));
+                        yy[k] = {s_hist[slot * LB_DPAD + lane], s_hist[slot * LB_DPAD + lane + 64]};
+                        sy[k] = {s_hist[(cf.hist + slot) * LB_DPAD + lane], s_hist[(cf.hist + slot) * LB_DPAD + lane + 64]};
                     }
 #pragma unroll
                     for (int k = 0; k < LB_PF; ++k) {
                         const int i = i0 + k;
-                        if (i >= s.nh) break;
-                        const float be = lv_dot(yy[k], r) * s_ro[(s.h0 + i) % cf.hist];
+                        if (i >= nh) break;
+                        const float be = lv_dot(yy[k], r) * s_ro[ring(h0 + i)];
                         const float c = s_al[i] - be;
                         r = {fmaf(c, sy[k].a, r.a), fmaf(c, sy[k].b, r.b)};
                     }
                 }
                 d = r;
             }
-            lv_st(w + LV_PREVG * LB_DPAD, g);
+            wst(LV_PREVG, g);
             s.prev_loss = s.loss;
             s.t = s.n_iter_total == 1 ? fminf(1.f, 1.f / lv_abssum(g)) * cf.lr : cf.lr;
             s.gtd = lv_dot(g, d);
-            lv_st(w + LV_D * LB_DPAD, d);
+            wst(LV_D, d);
             if (s.gtd > -cf.tol_change) { st = STEP_END; break; }
             // the line search starts: remember where from
-            lv_st(w + LV_XINIT * LB_DPAD, LV{lane < cf.dim ? x[lane] : 0.f, lane + 64 < cf.dim ? x[lane + 64] : 0.f});
+            wst(LV_XINIT, LV{s_x[lane], s_x[lane + 64]});
             s.d_norm = lv_absmax(d);
             s.t_prev = 0.f; s.f_prev = s.loss; s.gtd_prev = s.gtd;
-            lv_st(w + LV_GPREV * LB_DPAD, g);
+            wst(LV_GPREV, g);
             s.ls_iter = 0; s.ls_evals = 0;
             write_point(s.t);
             s.phase = LB_WAIT_BRACKET; running = false;
@@ -198,7 +236,7 @@ __global__ __launch_bounds__(64) void lbfgs_advance_kernel(LbfgsCfg cf, LbfgsSca
             const float gtd_new = lv_dot(g_new, d);
             if (s.ls_iter >= cf.max_ls) {                    // out of evaluations while still extrapolating
                 s.b0 = 0.f; s.b1 = s.t; s.bf0 = s.loss; s.bf1 = f_new; s.bgtd0 = s.gtd; s.bgtd1 = gtd_new;
-                lv_st(w + LV_BG0 * LB_DPAD, g); lv_st(w + LV_BG1 * LB_DPAD, g_new);
+                wst(LV_BG0, g); wst(LV_BG1, g_new);
                 st = ZOOM_ENTER; break;
             }
             const bool up = f_new > s.loss + (c1 * s.t) * s.gtd || (s.ls_iter > 1 && f_new >= s.f_prev);
@@ -206,16 +244,16 @@ __global__ __launch_bounds__(64) void lbfgs_advance_kernel(LbfgsCfg cf, LbfgsSca
             const bool rising = !up && !wolfe && gtd_new >= 0.f;
             if (up || rising) {
                 s.b0 = s.t_prev; s.b1 = s.t; s.bf0 = s.f_prev; s.bf1 = f_new; s.bgtd0 = s.gtd_prev; s.bgtd1 = gtd_new;
-                lv_st(w + LV_BG0 * LB_DPAD, lv_ld(w + LV_GPREV * LB_DPAD)); lv_st(w + LV_BG1 * LB_DPAD, g_new);
+                wst(LV_BG0, wld(LV_GPREV)); wst(LV_BG1, g_new);
                 st = ZOOM_ENTER;
             } else if (wolfe) {                              // accepted where it stands
-                s.loss = f_new; g = g_new; lv_st(w + LV_G * LB_DPAD, g);
+                s.loss = f_new; g = g_new; wst(LV_G, g);
                 st = LS_DONE;
             } else {
                 const float min_step = s.t + 0.01f * (s.t - s.t_prev), max_step = s.t * 10.f;
                 const float tn = lb_cubic(s.t_prev, s.f_prev, s.gtd_prev, s.t, f_new, gtd_new, true, min_step, max_step);
                 s.t_prev = s.t; s.f_prev = f_new; s.gtd_prev = gtd_new;
-                lv_st(w + LV_GPREV * LB_DPAD, g_new);
+                wst(LV_GPREV, g_new);
                 s.t = tn; s.ls_iter++;
                 write_point(s.t);
                 s.phase = LB_WAIT_BRACKET; running = false;
@@ -244,29 +282,28 @@ __global__ __launch_bounds__(64) void lbfgs_advance_kernel(LbfgsCfg cf, LbfgsSca
             const float gtd_new = lv_dot(g_new, d), t = s.t;
             const float b_low = s.low ? s.b1 : s.b0, bf_low = s.low ? s.bf1 : s.bf0, bgtd_low = s.low ? s.bgtd1 : s.bgtd0;
             const float b_high = s.low ? s.b0 : s.b1;
-            float* const BGlow = w + (s.low ? LV_BG1 : LV_BG0) * LB_DPAD;
-            float* const BGhigh = w + (s.low ? LV_BG0 : LV_BG1) * LB_DPAD;
+            const int BGlow = s.low ? LV_BG1 : LV_BG0, BGhigh = s.low ? LV_BG0 : LV_BG1;
             if (f_new > s.loss + (c1 * t) * s.gtd || f_new >= bf_low) {            // the new point replaces the high end
                 if (s.low) { s.b0 = t; s.bf0 = f_new; s.bgtd0 = gtd_new; } else { s.b1 = t; s.bf1 = f_new; s.bgtd1 = gtd_new; }
-                lv_st(BGhigh, g_new);
+                wst(BGhigh, g_new);
                 set_low_high();
                 st = ZOOM_LOOP;
             } else {
                 const bool done = fabsf(gtd_new) <= -c2 * s.gtd;
                 if (!done && gtd_new * (b_high - b_low) >= 0.f) {                   // the old low end becomes the high end
                     if (s.low) { s.b0 = b_low; s.bf0 = bf_low; s.bgtd0 = bgtd_low; } else { s.b1 = b_low; s.bf1 = bf_low; s.bgtd1 = bgtd_low; }
-                    lv_st(BGhigh, lv_ld(BGlow));
+                    wst(BGhigh, wld(BGlow));
                 }
                 if (s.low) { s.b1 = t; s.bf1 = f_new; s.bgtd1 = gtd_new; } else { s.b0 = t; s.bf0 = f_new; s.bgtd0 = gtd_new; }
-                lv_st(BGlow, g_new);
+                wst(BGlow, g_new);
                 st = done ? ZOOM_EXIT : ZOOM_LOOP;
             }
         } break;
         case ZOOM_EXIT: {                                    // the low end of the bracket is the step taken
             s.t = s.low ? s.b1 : s.b0;
             s.loss = s.low ? s.bf1 : s.bf0;
-            g = lv_ld(w + (s.low ? LV_BG1 : LV_BG0) * LB_DPAD);
-            lv_st(w + LV_G * LB_DPAD, g);
+            g = wld(s.low ? LV_BG1 : LV_BG0);
+            wst(LV_G, g);
             write_point(s.t);
             st = LS_DONE;
         } break;

@@ -2891,6 +2891,8 @@ int fdcap_lbfgs_create(int32_t n, const fdcap_lbfgs_config* cf, fdcap_lbfgs** ou
     if (e == hipSuccess) e = L->RO.ensure((size_t)n * LB_HMAX);
     if (e == hipSuccess) e = L->active.ensure(2);
     if (e == hipSuccess) e = hipHostMalloc((void**)&L->active_h, sizeof(int), hipHostMallocDefault);
+    if (e == hipSuccess) e = hipFuncSetAttribute((const void*)lbfgs_advance_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                                 (int)lbfgs_lds_bytes(LB_HMAX));
     if (e == hipSuccess) { int r = fdcap_lbfgs_reset(L, nullptr); if (r == 0) e = hipDeviceSynchronize(); else e = (hipError_t)r; }
     if (e != hipSuccess) { fdcap_lbfgs_destroy(L); return (int)e; }
     *out = L;
@@ -2917,8 +2919,8 @@ int fdcap_lbfgs_advance(fdcap_lbfgs* L, float* x, int32_t x_stride, const float*
     if (!L || !x || !f || !g || x_stride < L->cf.dim || g_stride < L->cf.dim) return FDCAP_E_ARG;
     hipStream_t st = (hipStream_t)stream;
     int* const cnt = L->active.p + (L->round & 1);            // this round's counter was zeroed by the previous round's launch
-    hipLaunchKernelGGL(lbfgs_advance_kernel, dim3(L->n), dim3(64), 0, st, L->cf, L->S.p, L->W.p, L->RO.p, x, x_stride, f, g, g_stride, cnt,
-                       L->active.p + ((L->round + 1) & 1));
+    hipLaunchKernelGGL(lbfgs_advance_kernel, dim3(L->n), dim3(LB_NT), lbfgs_lds_bytes(L->cf.hist), st, L->cf, L->S.p, L->W.p, L->RO.p, x, x_stride,
+                       f, g, g_stride, cnt, L->active.p + ((L->round + 1) & 1));
     L->round++;
     if (n_active) HIP_TRY(hipMemcpyAsync(n_active, cnt, sizeof(int32_t), hipMemcpyDeviceToDevice, st));
     return (int)hipGetLastError();
