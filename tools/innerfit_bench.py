@@ -48,10 +48,15 @@ def main():
             dt = time.perf_counter() - t0
             best = dt if best is None else min(best, dt)
             rounds = sum(op.rounds) if op.rounds else 5 * kw["iters_per_stage"]
+            worst = ""
+            if op.frame_loss:                                  # the three frames that ended highest, and how many directions they took
+                fl = op.frame_loss[-1]
+                top = np.argsort(-fl)[:3]
+                worst = "; highest frames " + ", ".join(f"#{i}: {fl[i]:.0f} ({sum(int(it[i]) for it in op.frame_iterations)} directions)" for i in top)
             op.close()
         out = out.cpu().numpy()
         print(f"{name:70s}: {best * 1e3:8.1f} ms = {n / best:7.1f} frames/s, {rounds:5d} objective evaluations ({best / rounds * 1e6:6.1f} us each), "
-              f"objective {objective(out):.1f}, reprojection error {px(out):.2f} px")
+              f"objective {objective(out):.1f}, reprojection error {px(out):.2f} px{worst}")
 
 
 if __name__ == "__main__":
