@@ -1,5 +1,5 @@
-// Batched L-BFGS with a strong-Wolfe line search: one INDEPENDENT problem per workgroup (one wave), all problems advanced by
-// one launch between two evaluations of the caller's objective (SMPLify-X fits every frame with L-BFGS +
+// Batched L-BFGS with a strong-Wolfe line search: one INDEPENDENT problem per workgroup (four waves stage its state in LDS, one
+// runs it), all problems advanced by one launch between two evaluations of the caller's objective (SMPLify-X fits every frame with L-BFGS +
 // strong Wolfe; round 3 shipped the inner fit with Adam and listed this as its deviation).
 //
 // Not in the reference repository (the per-frame fit is the external SMPLify-X step, /root/reference/README.md:14-17).
