@@ -47,14 +47,25 @@ FDC_HD inline size_t lbfgs_ws_floats(int hist) { return (size_t)(LV_NUM + 2 * hi
 struct LV { float a, b; };       // a lane's two elements of a 128-padded vector: [lane], [lane + 64]
 __device__ __forceinline__ LV lv_ld(const float* v) { return {v[threadIdx.x], v[threadIdx.x + 64]}; }
 __device__ __forceinline__ void lv_st(float* v, LV x) { v[threadIdx.x] = x.a; v[threadIdx.x + 64] = x.b; }
-__device__ __forceinline__ float lv_dot(LV x, LV y) { return wave_sum64(fmaf(x.a, y.a, x.b * y.b)); }
+// wave_sum64's sum, bit for bit (((r0 + r1) + r2) + r3 over the four rows), with the row sums read out side by side: this
+// kernel's cost is a lone wave's chain of DEPENDENT instructions, and four readlanes + three adds are four deep where the three
+// row_bcast steps + readlane are seven (the other kernels count issued instructions instead and use wave_sum64)
+__device__ __forceinline__ float lb_sum(float v) {
+    v += dpp_move<0xB1>(v); v += dpp_move<0x4E>(v); v += dpp_move<0x141>(v); v += dpp_move<0x140>(v);
+    const float r0 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 0));
+    const float r1 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 16));
+    const float r2 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 32));
+    const float r3 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 48));
+    return ((r0 + r1) + r2) + r3;
+}
+__device__ __forceinline__ float lv_dot(LV x, LV y) { return lb_sum(fmaf(x.a, y.a, x.b * y.b)); }
 __device__ __forceinline__ float lv_absmax(LV x) {
     float m = fmaxf(fabsf(x.a), fabsf(x.b));
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) m = fmaxf(m, __shfl_xor(m, off, 64));
     return m;
 }
-__device__ __forceinline__ float lv_abssum(LV x) { return wave_sum64(fabsf(x.a) + fabsf(x.b)); }
+__device__ __forceinline__ float lv_abssum(LV x) { return lb_sum(fabsf(x.a) + fabsf(x.b)); }
 
 // minimiser of the cubic through (x1, f1, g1), (x2, f2, g2), clipped to [lo, hi] (to the two abscissae without bounds)
 __device__ __forceinline__ float lb_cubic(float x1, float f1, float g1, float x2, float f2, float g2, bool bounded, float lo, float hi) {
