@@ -20,7 +20,6 @@ namespace fdc {
 
 constexpr int LB_DPAD = 128;     // floats per stored vector: dim <= 128 (an optimiser row is 78)
 constexpr int LB_HMAX = 128;     // history entries at most (torch's default is 100)
-constexpr int LB_PF = 4;         // history pairs read ahead of the two-loop recursion's arithmetic
 constexpr int LB_NT = 256;       // threads of a workgroup: four waves load the history, the first runs the state machine
 FDC_HD inline size_t lbfgs_lds_bytes(int hist) { return (size_t)(2 * hist + 7) * LB_DPAD * sizeof(float); }    // + LV_NUM work vectors
 
@@ -99,20 +98,26 @@ __global__ __launch_bounds__(LB_NT) void lbfgs_advance_kernel(LbfgsCfg cf, Lbfgs
     float* const w = W + (size_t)p * lbfgs_ws_floats(cf.hist);
     float* const ro = RO + (size_t)p * LB_HMAX;
     // All four waves bring the history into LDS in one burst (whether this round ends a line search and needs it is only known
-    // later; read pair by pair when needed, it was 26 dependent round trips of a lone wave: most of the kernel's 30 us).  Until the
-    // ring is full its pairs are slots 0 .. nh-1.
+    // later; read pair by pair when needed, it was 26 dependent round trips of a lone wave).  The ring is unrolled on the way: LDS
+    // position i holds the i-th oldest pair, so that the recursion below walks positions and does no ring arithmetic.
+    const int nh0 = __builtin_amdgcn_readfirstlane(s.nh), h00 = __builtin_amdgcn_readfirstlane(s.h0);
     {
         const float4* const gy = (const float4*)(w + (size_t)LV_NUM * LB_DPAD);
         const float4* const gs = (const float4*)(w + (size_t)(LV_NUM + cf.hist) * LB_DPAD);
-        const int n4 = s.nh * (LB_DPAD / 4), so = cf.hist * (LB_DPAD / 4);
+        const int n4 = nh0 * (LB_DPAD / 4), so = cf.hist * (LB_DPAD / 4);
         for (int i0 = threadIdx.x; i0 < n4; i0 += 4 * LB_NT) {
             float4 a[4], b[4];
 #pragma unroll
-            for (int k = 0; k < 4; ++k) { const int i = min(i0 + k * LB_NT, n4 - 1); a[k] = gy[i]; b[k] = gs[i]; }
+            for (int k = 0; k < 4; ++k) {
+                const int i = min(i0 + k * LB_NT, n4 - 1);
+                int slot = h00 + (i >> 5);
+                slot = slot >= cf.hist ? slot - cf.hist : slot;
+                a[k] = gy[slot * (LB_DPAD / 4) + (i & 31)]; b[k] = gs[slot * (LB_DPAD / 4) + (i & 31)];
+            }
 #pragma unroll
             for (int k = 0; k < 4; ++k) { const int i = i0 + k * LB_NT; if (i < n4) { s_hist4[i] = a[k]; s_hist4[so + i] = b[k]; } }
         }
-        if (threadIdx.x < LB_HMAX) s_ro[threadIdx.x] = ro[threadIdx.x];
+        if ((int)threadIdx.x < nh0) { const int slot = h00 + threadIdx.x; s_ro[threadIdx.x] = ro[slot >= cf.hist ? slot - cf.hist : slot]; }
         // ... and the work vectors and the x row with it: read one by one along the state machine they were another six to
         // eight dependent round trips
         if (threadIdx.x < LV_NUM * (LB_DPAD / 4)) s_hist4[2 * so + threadIdx.x] = ((const float4*)w)[threadIdx.x];
@@ -156,6 +161,9 @@ __global__ __launch_bounds__(LB_NT) void lbfgs_advance_kernel(LbfgsCfg cf, Lbfgs
     auto set_low_high = [&]() { s.low = s.bf0 <= s.bf1 ? 0 : 1; };
     auto ring = [&](int i) { return i >= cf.hist ? i - cf.hist : i; };      // slot of ring position i < 2 hist (no integer division)
 
+    // the two-loop recursion's pairs as LDS positions: lo .. hi in age order, and (once the ring is full) the pair pushed in this
+    // launch at position pnew = 0, where the oldest was
+    int lo = 0, hi = nh0 - 1, pnew = -1;
     bool running = true;
     while (running) {
         switch (st) {
@@ -172,59 +180,45 @@ __global__ __launch_bounds__(LB_NT) void lbfgs_advance_kernel(LbfgsCfg cf, Lbfgs
                 const LV pg = wld(LV_PREVG);
                 const LV y = {g.a - pg.a, g.b - pg.b}, sv = {d.a * s.t, d.b * s.t};
                 const float ys = lv_dot(y, sv);
-                if (ys > 1e-10f) {
-                    if (s.nh == cf.hist) { s.h0 = ring(s.h0 + 1); s.nh--; }      // the oldest pair leaves
-                    const int slot = ring(s.h0 + s.nh);
+                if (ys > 1e-10f) {                                       // (at most once per launch: a second direction here has y = 0)
+                    const bool full = s.nh == cf.hist;
+                    if (full) { s.h0 = ring(s.h0 + 1); s.nh--; }          // the oldest pair leaves
+                    const int slot = ring(s.h0 + s.nh);                   // where the pair lives in HBM
                     lv_st(w + (size_t)(LV_NUM + slot) * LB_DPAD, y);
                     lv_st(w + (size_t)(LV_NUM + cf.hist + slot) * LB_DPAD, sv);
-                    s_hist[slot * LB_DPAD + lane] = y.a; s_hist[slot * LB_DPAD + lane + 64] = y.b;
-                    s_hist[(cf.hist + slot) * LB_DPAD + lane] = sv.a; s_hist[(cf.hist + slot) * LB_DPAD + lane + 64] = sv.b;
+                    int pos;                                              // ... and in LDS
+                    if (full) { pos = 0; pnew = 0; lo = 1; } else { pos = ++hi; }
+                    s_hist[pos * LB_DPAD + lane] = y.a; s_hist[pos * LB_DPAD + lane + 64] = y.b;
+                    s_hist[(cf.hist + pos) * LB_DPAD + lane] = sv.a; s_hist[(cf.hist + pos) * LB_DPAD + lane + 64] = sv.b;
                     const float r = 1.f / ys;
-                    s_ro[slot] = r;
+                    s_ro[pos] = r;
                     if (lane == 0) ro[slot] = r;
                     s.nh++;
                     s.H_diag = ys / lv_dot(y, y);
                 }
-                // The two-loop recursion is a chain of 2 nh dependent dot products; the history pairs it walks over are not part of
-                // the chain: they are read from LDS LB_PF pairs at a time ahead of the arithmetic.
-                // (the ring's position and length as wave-uniform scalars: index arithmetic on the scalar unit, uniform branches)
-                const int nh = __builtin_amdgcn_readfirstlane(s.nh), h0 = __builtin_amdgcn_readfirstlane(s.h0);
+                // The two-loop recursion: a chain of 2 nh dependent dot products, newest pair to oldest and back.  A lone wave issues
+                // an instruction every ~5 cycles whatever its kind, so what counts is how few there are per pair: positions, no ring.
+                lo = __builtin_amdgcn_readfirstlane(lo); hi = __builtin_amdgcn_readfirstlane(hi); pnew = __builtin_amdgcn_readfirstlane(pnew);
                 LV q = {-g.a, -g.b};
-                for (int i0 = nh - 1; i0 >= 0; i0 -= LB_PF) {
-                    LV yy[LB_PF], sy[LB_PF];
-#pragma unroll
-                    for (int k = 0; k < LB_PF; ++k) {
-                        const int slot = ring(h0 + max(i0 - k, 0));
-                        yy[k] = {s_hist[slot * LB_DPAD + lane], s_hist[slot * LB_DPAD + lane + 64]};
-                        sy[k] = {s_hist[(cf.hist + slot) * LB_DPAD + lane], s_hist[(cf.hist + slot) * LB_DPAD + lane + 64]};
-                    }
-#pragma unroll
-                    for (int k = 0; k < LB_PF; ++k) {
-                        const int i = i0 - k;
-                        if (i < 0) break;
-                        const float al = lv_dot(sy[k], q) * s_ro[ring(h0 + i)];
-                        s_al[i] = al;
-                        q = {fmaf(-al, yy[k].a, q.a), fmaf(-al, yy[k].b, q.b)};
-                    }
-                }
+                auto down = [&](int pos) {
+                    const LV yy = {s_hist[pos * LB_DPAD + lane], s_hist[pos * LB_DPAD + lane + 64]};
+                    const LV sy = {s_hist[(cf.hist + pos) * LB_DPAD + lane], s_hist[(cf.hist + pos) * LB_DPAD + lane + 64]};
+                    const float al = lv_dot(sy, q) * s_ro[pos];
+                    s_al[pos] = al;
+                    q = {fmaf(-al, yy.a, q.a), fmaf(-al, yy.b, q.b)};
+                };
+                if (pnew >= 0) down(pnew);
+                for (int pos = hi; pos >= lo; --pos) down(pos);          // (reading a pair's LDS words one pair ahead: measured slower)
                 LV r = {q.a * s.H_diag, q.b * s.H_diag};
-                for (int i0 = 0; i0 < nh; i0 += LB_PF) {
-                    LV yy[LB_PF], sy[LB_PF];
-#pragma unroll
-                    for (int k = 0; k < LB_PF; ++k) {
-                        const int slot = ring(h0 + min(i0 + k, nh - 1));
-                        yy[k] = {s_hist[slot * LB_DPAD + lane], s_hist[slot * LB_DPAD + lane + 64]};
-                        sy[k] = {s_hist[(cf.hist + slot) * LB_DPAD + lane], s_hist[(cf.hist + slot) * LB_DPAD + lane + 64]};
-                    }
-#pragma unroll
-                    for (int k = 0; k < LB_PF; ++k) {
-                        const int i = i0 + k;
-                        if (i >= nh) break;
-                        const float be = lv_dot(yy[k], r) * s_ro[ring(h0 + i)];
-                        const float c = s_al[i] - be;
-                        r = {fmaf(c, sy[k].a, r.a), fmaf(c, sy[k].b, r.b)};
-                    }
-                }
+                auto up = [&](int pos) {
+                    const LV yy = {s_hist[pos * LB_DPAD + lane], s_hist[pos * LB_DPAD + lane + 64]};
+                    const LV sy = {s_hist[(cf.hist + pos) * LB_DPAD + lane], s_hist[(cf.hist + pos) * LB_DPAD + lane + 64]};
+                    const float be = lv_dot(yy, r) * s_ro[pos];
+                    const float c = s_al[pos] - be;
+                    r = {fmaf(c, sy.a, r.a), fmaf(c, sy.b, r.b)};
+                };
+                for (int pos = lo; pos <= hi; ++pos) up(pos);
+                if (pnew >= 0) up(pnew);
                 d = r;
             }
             wst(LV_PREVG, g);
