@@ -125,6 +125,7 @@ class FittingOP:
             setattr(self, k, v)
         for k, v in lcfg.items():
             setattr(self, k, v)
+        self.snapshot_hook = None      # tools: called with k right after the snapshot of step k was taken (`fitting(snapshot_at=...)`)
         self.batch_size = self.num_body = int(num_body)
         self.legacy_zero_grad = bool(legacy_zero_grad)
         if not torch.cuda.is_available():
@@ -405,6 +406,8 @@ class FittingOP:
                         capi.check(lib.fdcap_opt_sync(h, st), "fdcap_opt_sync")
                         nl_ = self.shard.n_local
                         self.snapshots[end] = (self._rows_x[2:2 + nl_].clone(), self._scale.clone(), self._rows_cam[2:2 + nl_].clone())
+                        if self.snapshot_hook:
+                            self.snapshot_hook(end)
                     if check_finite_every and end % check_finite_every == 0:
                         self._check_finite(last)
                     if checkpoint_every and end % checkpoint_every == 0 and end < self.num_iter:
@@ -472,6 +475,8 @@ class FittingOP:
                     capi.check(lib.fdcap_opt_sync(h, st), "fdcap_opt_sync")
                     nl_ = self.shard.n_local
                     self.snapshots[ii + 1] = (self._rows_x[2:2 + nl_].clone(), self._scale.clone(), self._rows_cam[2:2 + nl_].clone())
+                    if self.snapshot_hook:
+                        self.snapshot_hook(ii + 1)
                 if check_finite_every and (ii + 1) % check_finite_every == 0:
                     self._check_finite(ii)
                 if checkpoint_every and (ii + 1) % checkpoint_every == 0 and ii + 1 < self.num_iter:

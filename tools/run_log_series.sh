@@ -13,5 +13,11 @@ d = [r[0] / 1e3 for r in c.execute(f"select d.end-d.start from {t} d join {sy} s
 print(f"nn_stream4 in one logging fit: {len(d)} launches, mean {sum(d)/len(d):.1f} us")
 print("per block of 25:", " ".join(f"{sum(d[i:i+25])/len(d[i:i+25]):.1f}" for i in range(0, len(d), 25)))
 print("launches 400..:", " ".join(f"{x:.0f}" for x in d[400:]))
+rows = c.execute(f"select s.kernel_name, d.start, d.end, d.grid_size_x, d.workgroup_size_x from {t} d join {sy} s on d.kernel_id = s.id order by d.start").fetchall()
+nn = [i for i, r in enumerate(rows) if 'nn_stream4' in r[0]]
+print("dispatch sequence from the 399th to the 404th search (name, duration us, gap before it us, grid, workgroup):")
+for i in range(nn[398], nn[404] + 1):
+    n, a, b, g, wg = rows[i]
+    print(f"  {n.split('(')[0][-44:]:44s} {(b - a) / 1e3:8.1f} {(a - rows[i - 1][2]) / 1e3:7.1f} {g:9d} {wg:5d}")
 PY
 cat /root/repo/gpurun_out/nn_logging_series.txt
