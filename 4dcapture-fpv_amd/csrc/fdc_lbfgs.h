@@ -30,6 +30,12 @@ struct LbfgsCfg {
 
 enum { LB_INIT = 0, LB_WAIT_BRACKET = 1, LB_WAIT_ZOOM = 2, LB_DONE = 3 };
 
+// Optional: columns [col0, col0 + n) of every gradient row still lack an addend that lies in FOUR partial arrays (the VPoser
+// backward's quarter workgroups leave the latent gradient that way; the clip optimiser's Adam folds them itself, and so does this
+// kernel for the inner fit -- one launch less per evaluation): g[p][col0 + c] += (part0 + part1) + (part2 + part3) at [p * n + c],
+// the partials `stride` floats apart.  part = nullptr: nothing to add.
+struct LbfgsFold { const float* part = nullptr; size_t stride = 0; int col0 = 0, n = 0; };
+
 struct LbfgsScalars {
     int phase, step, n_inner, n_iter_total, evals_step, evals_total, ls_iter, ls_evals, nh, h0, low, insuf;
     float loss, orig_loss, prev_orig, prev_loss, t, gtd, d_norm, H_diag;
@@ -87,7 +93,7 @@ __device__ __forceinline__ float lb_cubic(float x1, float f1, float g1, float x2
 __global__ __launch_bounds__(LB_NT) void lbfgs_advance_kernel(LbfgsCfg cf, LbfgsScalars* __restrict__ S, float* __restrict__ W,
                                                            float* __restrict__ RO, float* __restrict__ X, int x_stride,
                                                            const float* __restrict__ F, const float* __restrict__ G, int g_stride,
-                                                           int* __restrict__ n_active, int* __restrict__ n_active_next) {
+                                                           int* __restrict__ n_active, int* __restrict__ n_active_next, LbfgsFold fold) {
     __shared__ float s_ro[LB_HMAX], s_al[LB_HMAX], s_x[LB_DPAD];
     extern __shared__ float4 s_hist4[];                      // the problem's history: [hist] y vectors, [hist] s vectors; then the work vectors
     float* const s_hist = (float*)s_hist4;
@@ -126,7 +132,20 @@ __global__ __launch_bounds__(LB_NT) void lbfgs_advance_kernel(LbfgsCfg cf, Lbfgs
     const int lane = threadIdx.x & 63;
     const float* const gr = G + (size_t)p * g_stride;
     const float f_new = F[p];
-    const LV g_new = {lane < cf.dim ? gr[lane] : 0.f, lane + 64 < cf.dim ? gr[lane + 64] : 0.f};
+    LV g_new = {lane < cf.dim ? gr[lane] : 0.f, lane + 64 < cf.dim ? gr[lane + 64] : 0.f};
+    if (fold.part) {
+        auto addend = [&](int col) -> float {
+            const int c = col - fold.col0;
+            if (c < 0 || c >= fold.n) return 0.f;
+            const float* const e = fold.part + (size_t)p * fold.n + c;
+            return (e[0] + e[fold.stride]) + (e[2 * fold.stride] + e[3 * fold.stride]);
+        };
+        if (lane >= fold.col0 - 64 && lane < fold.col0 + fold.n) {       // (the few lanes that hold such a column)
+            const float a0 = addend(lane), a1 = addend(lane + 64);
+            if (lane - fold.col0 >= 0 && lane - fold.col0 < fold.n) g_new.a += a0;
+            if (lane + 64 - fold.col0 >= 0 && lane + 64 - fold.col0 < fold.n) g_new.b += a1;
+        }
+    }
     __syncthreads();
     if (threadIdx.x >= 64) return;                           // the state machine itself is one wave's work
     float* const x = X + (size_t)p * x_stride;

@@ -2914,13 +2914,19 @@ int fdcap_lbfgs_reset(fdcap_lbfgs* L, void* stream) {
     L->round = 0;
     return FDCAP_OK;
 }
+static int lbfgs_advance_impl(fdcap_lbfgs* L, float* x, int32_t x_stride, const float* f, const float* g, int32_t g_stride, int32_t* n_active,
+                              LbfgsFold fold, void* stream);
 int fdcap_lbfgs_advance(fdcap_lbfgs* L, float* x, int32_t x_stride, const float* f, const float* g, int32_t g_stride, int32_t* n_active,
                         void* stream) {
+    return lbfgs_advance_impl(L, x, x_stride, f, g, g_stride, n_active, LbfgsFold(), stream);
+}
+static int lbfgs_advance_impl(fdcap_lbfgs* L, float* x, int32_t x_stride, const float* f, const float* g, int32_t g_stride, int32_t* n_active,
+                              LbfgsFold fold, void* stream) {
     if (!L || !x || !f || !g || x_stride < L->cf.dim || g_stride < L->cf.dim) return FDCAP_E_ARG;
     hipStream_t st = (hipStream_t)stream;
     int* const cnt = L->active.p + (L->round & 1);            // this round's counter was zeroed by the previous round's launch
     hipLaunchKernelGGL(lbfgs_advance_kernel, dim3(L->n), dim3(LB_NT), lbfgs_lds_bytes(L->cf.hist), st, L->cf, L->S.p, L->W.p, L->RO.p, x, x_stride,
-                       f, g, g_stride, cnt, L->active.p + ((L->round + 1) & 1));
+                       f, g, g_stride, cnt, L->active.p + ((L->round + 1) & 1), fold);
     L->round++;
     if (n_active) HIP_TRY(hipMemcpyAsync(n_active, cnt, sizeof(int32_t), hipMemcpyDeviceToDevice, st));
     return (int)hipGetLastError();
@@ -2941,7 +2947,7 @@ int fdcap_lbfgs_get_stats(fdcap_lbfgs* L, int32_t* it, int32_t* ev, float* loss,
 }
 
 // one evaluation of the inner fit's objective: forward, loss (+ per-frame value), backward
-static int fit2d_eval(fdcap_ctx* c, const fdcap_fit2d_stage* sg, double* losses, float* floss, hipStream_t st) {
+static int fit2d_eval(fdcap_ctx* c, const fdcap_fit2d_stage* sg, double* losses, float* floss, hipStream_t st, bool fold = true) {
     OptState* o = c->opt;
     const int nl = o->cfg.n_local;
     Fit2dStage s = {sg->fx, sg->fy, sg->cx, sg->cy, sg->rho, sg->w_data, sg->w_pose, sg->w_shape, sg->w_hand};
@@ -2955,7 +2961,7 @@ static int fit2d_eval(fdcap_ctx* c, const fdcap_fit2d_stage* sg, double* losses,
                        o->Jrest.p, o->G.p, (const float*)nullptr, (const float*)nullptr, o->dJw.p, (const float*)nullptr,
                        (const float*)nullptr, (const float*)nullptr, 0, (const float*)nullptr, o->dX.p, o->dO.p, o->dCAM.p,
                        o->dscale_row.p, ParamLossIn(), (const float*)nullptr);
-    { int eb = opt_vposer_backward(c, true, st); if (eb) return eb; }
+    { int eb = opt_vposer_backward(c, fold, st); if (eb) return eb; }
     return (int)hipGetLastError();
 }
 
@@ -2981,9 +2987,11 @@ int fdcap_opt_fit2d_lbfgs(fdcap_ctx* c, const fdcap_fit2d_stage* sg, const fdcap
     int rounds = 0, e = 0;
     const int poll = 8;                                       // rounds between two looks at the number of frames still running
     while (rounds < max_rounds) {
-        e = fit2d_eval(c, sg, nullptr, o->floss.p, st);
+        e = fit2d_eval(c, sg, nullptr, o->floss.p, st, false);   // (the latent gradient's four partials are folded by the advance kernel)
         if (e) break;
-        e = fdcap_lbfgs_advance(L, o->X.p + 2 * XDIM, XDIM, o->floss.p, o->dX.p + 2 * XDIM, XDIM, nullptr, st);
+        LbfgsFold fold;
+        fold.part = o->dZpart.p + (size_t)2 * VP_Z; fold.stride = (size_t)o->R * VP_Z; fold.col0 = X_LATENT; fold.n = VP_Z;
+        e = lbfgs_advance_impl(L, o->X.p + 2 * XDIM, XDIM, o->floss.p, o->dX.p + 2 * XDIM, XDIM, nullptr, fold, st);
         if (e) break;
         ++rounds;
         if (rounds % poll == 0 || rounds == max_rounds) {
@@ -2993,6 +3001,10 @@ int fdcap_opt_fit2d_lbfgs(fdcap_ctx* c, const fdcap_fit2d_stage* sg, const fdcap
         }
     }
     if (rounds_out) *rounds_out = rounds;
+    if (o->dz_pending) {                                      // leave dX complete, as every other backward of the API does
+        hipLaunchKernelGGL(vposer_fold_dz_kernel, dim3((nl * VP_Z + 255) / 256), dim3(256), 0, st, o->dZpart.p, (size_t)o->R * VP_Z, 2, nl, o->dX.p);
+        o->dz_pending = false;
+    }
     if (e) return e;
     HIP_TRY(hipStreamSynchronize(st));
     return FDCAP_OK;
