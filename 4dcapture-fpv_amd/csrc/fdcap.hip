@@ -1100,12 +1100,20 @@ __global__ __launch_bounds__(256) void loss_rows_reduce_kernel(const float* __re
     loss_rows_reduce_block(rows, row0, n, mask, assign, losses, dscale_row, dscale_out);
 }
 
+// dzpart != nullptr: p is body_rotation_rec from row `row0` on, and the latent columns' gradient still lacks the VPoser backward's
+// four partials (vp_sum_dz: the sum the fold kernel would have added to g first, in its order)
 __global__ void adam_kernel(float* __restrict__ p, float* __restrict__ m, float* __restrict__ v,
-                            const float* __restrict__ g, size_t n, AdamScalars a, int zero_grad) {
+                            const float* __restrict__ g, size_t n, AdamScalars a, int zero_grad,
+                            const float* __restrict__ dzpart = nullptr, size_t dz_stride = 0, int row0 = 0) {
     size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     float pp = p[i], mm = m[i], vv = v[i];
-    adam_update(pp, mm, vv, zero_grad ? 0.f : g[i], a);
+    float gg = zero_grad ? 0.f : g[i];
+    if (dzpart) {
+        const int row = (int)(i / XDIM), col = (int)(i % XDIM) - X_LATENT;
+        if (col >= 0 && col < VP_Z) gg += vp_sum_dz(dzpart, dz_stride, (size_t)(row0 + row) * VP_Z + col);
+    }
+    adam_update(pp, mm, vv, gg, a);
     p[i] = pp; m[i] = mm; v[i] = vv;
 }
 
@@ -2849,28 +2857,17 @@ int fdcap_opt_set_keypoints(fdcap_ctx* c, const float* kp_d, void* stream) {
     return FDCAP_OK;
 }
 
+static int fit2d_eval(fdcap_ctx* c, const fdcap_fit2d_stage* sg, double* losses, float* floss, hipStream_t st, bool fold = true);
 int fdcap_opt_backward_fit2d(fdcap_ctx* c, const fdcap_fit2d_stage* sg, int32_t log_terms, void* stream) {
     if (!c || !c->opt || !sg) return FDCAP_E_ARG;
     { int es_ = opt_sync(c, (hipStream_t)stream); if (es_) return es_; }
     OptState* o = c->opt;
     if (!o->kp2d.p) return FDCAP_E_STATE;
     hipStream_t st = (hipStream_t)stream;
-    const int nl = o->cfg.n_local;
-    Fit2dStage s = {sg->fx, sg->fy, sg->cx, sg->cy, sg->rho, sg->w_data, sg->w_pose, sg->w_shape, sg->w_hand};
-    PoseModel pm = c->pose_model();
     double* const losses = log_terms ? o->losses.p : nullptr;
     if (losses) HIP_TRY(hipMemsetAsync(losses, 0, FDCAP_NUM_LOSSES * sizeof(double), st));
-    int row_lo, row_hi;
-    opt_row_range(o, 1, &row_lo, &row_hi);
-    int e = opt_pose_forward(c, row_lo, row_hi, st);
-    if (e) return e;
-    hipLaunchKernelGGL(fit2d_loss_kernel, dim3(nl), dim3(128), 0, st, s, o->X.p, o->Jw.p, o->kp2d.p, 2, o->dX.p, o->dJw.p, losses);
-    hipLaunchKernelGGL(pose_bwd_kernel, dim3(nl), dim3(64 * POSE_NW), 0, st, pm, o->X.p, o->O.p, o->CAM.p, o->scale.p, 2, o->Rm.p,
-                       o->Jrest.p, o->G.p, (const float*)nullptr, (const float*)nullptr, o->dJw.p, (const float*)nullptr,
-                       (const float*)nullptr, (const float*)nullptr, 0, (const float*)nullptr, o->dX.p, o->dO.p, o->dCAM.p,
-                       o->dscale_row.p, ParamLossIn(), (const float*)nullptr);
-    { int eb = opt_vposer_backward(c, true, st); if (eb) return eb; }
-    return (int)hipGetLastError();
+    // (the latent gradient stays in the VPoser backward's four partials: fdcap_opt_step_x / fdcap_opt_get_grads add them)
+    return fit2d_eval(c, sg, losses, nullptr, st, false);
 }
 
 // ---- batched L-BFGS (csrc/fdc_lbfgs.h) ------------------------------------------------------------------------------
@@ -2947,7 +2944,7 @@ int fdcap_lbfgs_get_stats(fdcap_lbfgs* L, int32_t* it, int32_t* ev, float* loss,
 }
 
 // one evaluation of the inner fit's objective: forward, loss (+ per-frame value), backward
-static int fit2d_eval(fdcap_ctx* c, const fdcap_fit2d_stage* sg, double* losses, float* floss, hipStream_t st, bool fold = true) {
+static int fit2d_eval(fdcap_ctx* c, const fdcap_fit2d_stage* sg, double* losses, float* floss, hipStream_t st, bool fold) {
     OptState* o = c->opt;
     const int nl = o->cfg.n_local;
     Fit2dStage s = {sg->fx, sg->fy, sg->cx, sg->cy, sg->rho, sg->w_data, sg->w_pose, sg->w_shape, sg->w_hand};
@@ -3199,7 +3196,9 @@ int fdcap_opt_step_x(fdcap_ctx* c, int32_t step, void* stream) {
     o->ahead = false;
     const size_t nx = (size_t)o->cfg.n_local * XDIM;
     hipLaunchKernelGGL(adam_kernel, dim3((nx + 255) / 256), dim3(256), 0, (hipStream_t)stream, o->X.p + 2 * XDIM,
-                       o->mX.p + 2 * XDIM, o->vX.p + 2 * XDIM, o->dX.p + 2 * XDIM, nx, adam_scalars(o->cfg.lr, step), 0);
+                       o->mX.p + 2 * XDIM, o->vX.p + 2 * XDIM, o->dX.p + 2 * XDIM, nx, adam_scalars(o->cfg.lr, step), 0,
+                       o->dz_pending ? (const float*)o->dZpart.p : (const float*)nullptr, (size_t)o->R * VP_Z, 2);
+    o->dz_pending = false;                                   // (consumed; dX itself stays without the partials: fdcap_opt_get_grads reads before the step)
     return (int)hipGetLastError();
 }
 

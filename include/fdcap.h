@@ -310,7 +310,8 @@ typedef struct fdcap_fit2d_stage {
 /* kp_d DEVICE [n_local,23,3]: (u, v, confidence) of SMPL-X joints 0..22 (the joints[:, 0:23] the reference reads, :298). */
 int fdcap_opt_set_keypoints(fdcap_ctx* ctx, const float* kp_d, void* stream);
 /* zero_grad + loss + backward; only body_rotation_rec gets a gradient.  log_terms != 0: losses_d [0] = data term,
- * [1] = priors (both already weighted, summed over this rank's frames). */
+ * [1] = priors (both already weighted, summed over this rank's frames).  (The latent columns' gradient is left in the VPoser
+ * backward's four partial arrays; fdcap_opt_step_x and fdcap_opt_get_grads add them -- one launch less per iteration.) */
 int fdcap_opt_backward_fit2d(fdcap_ctx* ctx, const fdcap_fit2d_stage* stage, int32_t log_terms, void* stream);
 int fdcap_opt_reset_adam(fdcap_ctx* ctx, void* stream);
 
