@@ -93,3 +93,16 @@ def test_a_c_host_lands_on_the_python_hosts_bits(tmp_path, n, num_iter, log_ever
     np.testing.assert_array_equal(fop.weight_loss_rec * hist[:, 0] / (n * capi.XDIM), np.asarray(want_log.l_rec))
     np.testing.assert_array_equal(hist[:, 2] / ((n - 2) * capi.XDIM), np.asarray(want_log.loss_smoothing))
     np.testing.assert_array_equal(fop.weight_contact * hist[:, 3] / (n * len(vid)), np.asarray(want_log.loss_contact))
+
+
+def test_the_batched_lbfgs_from_a_c_host(tmp_path):
+    """fdcap_lbfgs_* from plain C (tests/c_abi_lbfgs.c): nine problems whose objective the C host evaluates itself."""
+    exe = str(tmp_path / "c_abi_lbfgs")
+    pkg = os.path.dirname(capi.LIB_PATH)
+    r = subprocess.run(["gcc", "-std=c11", "-Wall", "-Wextra", "-Werror", "-I", os.path.join(ROOT, "include"), "-I", "/opt/rocm/include",
+                        os.path.join(ROOT, "tests", "c_abi_lbfgs.c"), "-o", exe, "-L", pkg, "-lfdcap_hip", "-L", "/opt/rocm/lib", "-lamdhip64",
+                        "-lm", f"-Wl,-rpath,{pkg}", "-Wl,-rpath,/opt/rocm/lib"], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-3000:]
+    r = subprocess.run([exe], capture_output=True, text=True, timeout=300)
+    print(r.stdout.strip())
+    assert r.returncode == 0, (r.stdout, r.stderr[-2000:])

@@ -166,3 +166,9 @@ def test_the_header_is_plain_c_and_the_c_host_program_compiles_against_it(tmp_pa
     assert r.returncode == 0, r.stderr[-3000:]
     r = subprocess.run([exe], capture_output=True, text=True)
     assert r.returncode == 1 and "usage" in r.stderr
+    # ... and the batched L-BFGS's C host (tests/c_abi_lbfgs.c; compile and link only: it needs a GPU to run)
+    exe2 = str(tmp_path / "c_abi_lbfgs")
+    r = subprocess.run(["gcc", "-std=c11", "-Wall", "-Wextra", "-Werror", "-I", os.path.join(root, "include"), "-I", "/opt/rocm/include",
+                        os.path.join(root, "tests", "c_abi_lbfgs.c"), "-o", exe2, "-L", pkg, "-lfdcap_hip", "-L", "/opt/rocm/lib", "-lamdhip64",
+                        "-lm", f"-Wl,-rpath,{pkg}", "-Wl,-rpath,/opt/rocm/lib"], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-3000:]
