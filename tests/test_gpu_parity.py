@@ -254,8 +254,19 @@ def _make_fop(n, V, ns, per_part, num_iter, seed=0, weight_contact=0.1):
 
 @pytest.mark.parametrize("phase2", [False, True])
 def test_optimiser_gradients_match_autograd(phase2):
-    n = 12
-    fop, bm, vp, clip, scene, vid = _make_fop(n, 300, 800, 20, 500)
+    _gradient_check(12, 300, 800, 20, 0, phase2)
+
+
+@pytest.mark.parametrize("n,V,ns,per_part,seed", [(4, 120, 50, 1, 11), (7, 777, 801, 7, 12), (19, 300, 5000, 40, 13), (33, 150, 333, 3, 14),
+                                                   (65, 512, 2049, 17, 15), (130, 240, 1000, 9, 16)])
+def test_optimiser_gradients_match_autograd_at_ragged_shapes(n, V, ns, per_part, seed):
+    """The same check at shapes nobody tuned for: frames not a multiple of the 16-row blocks, vertex counts not a multiple of
+    anything, one contact vertex per leg, scenes smaller than a k-d chunk and just past a power of two; both phases."""
+    _gradient_check(n, V, ns, per_part, seed, seed % 2 == 0)
+
+
+def _gradient_check(n, V, ns, per_part, seed, phase2):
+    fop, bm, vp, clip, scene, vid = _make_fop(n, V, ns, per_part, 500, seed=seed)
     dt = torch.float64
     f = FittingOracle(SMPLXOracle(bm, dt), VPoserDecoder.from_data(vp, dt), scene, vid, clip.camerapose_lines, n, dtype=dt)
     x78 = rotrepr.convert_to_6D_rot(torch.tensor(clip.body_params, dtype=dt)).detach()
