@@ -159,7 +159,9 @@ def test_one_optimizer_step_takes_torchs_decisions(family, cfg):
             assert abs(float(f(x[i])) - fr) <= 1e-4 * max(1.0, abs(fr)) + 1e-5
             assert err < (1e-3 if converged else 2e-3)
     if not any_converged:
-        assert same_counts >= len(funs) - 2, "more than two of twelve problems left torch.optim.LBFGS's path"
+        # (measured on this pool's hosts: 11, 12 and 11 of 12 in the three cap-limited families; torch's CPU dot products sum in
+        # an order that depends on the host's vector width, so the bar leaves room for a few more ties elsewhere)
+        assert same_counts >= len(funs) - 4, "more than four of twelve problems left torch.optim.LBFGS's path"
     assert rounds == ev.max()                                        # one objective call per round for the slowest problem, no more
 
 
