@@ -23,6 +23,13 @@ KERNELS = {   # key -> (substring of the kernel name, skip the first `skip` disp
     "blend_fwd": ("panel_gemm3_rb2_kernel", False),
     "blend_bwd": ("panel_gemm3_rb2k", False),
     "blend_wide": ("panel_gemm3_wide", False),
+    # r5: the other launches of an iteration (bench.py's roofline.per_kernel)
+    "vposer_fwd": ("vposer_fwd", False),
+    "vposer_bwd": ("vposer_bwd", False),
+    "pose_fwd": ("pose_fwd_kernel", False),
+    "pose_bwd": ("pose_bwd_kernel", False),
+    "skin_fwd": ("skin_fwd_kernel", False),
+    "skin_bwd": ("skin_bwd", False),
 }
 
 
@@ -53,8 +60,8 @@ def trace_avg(db, sub):
 
 def main(trace_db, fetch_db, write_db, sq_db, out, skip=300, *more):
     skip = int(skip)
-    res = {"source": "rocprofv3 passes of tools/run_prof_r4.sh (r3: run_prof_r3.sh) on `python3 bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-logging-run "
-                     "--no-exact-fp32` (two fits: the timed step and the step whose NN launches carry HIP events), 1 x MI355X; per-dispatch "
+    res = {"source": "rocprofv3 passes of tools/run_prof_r5.sh / run_prof_r4.sh on one bench.py command (r5: recorded under `command`; r4: `--steps 1 --warmup 0 "
+                     "--no-cpu-baseline --no-logging-run --no-exact-fp32`, two fits), 1 x MI355X; per-dispatch "
                      f"sums over XCD x SE instances, mean over the dispatches after the first {skip} for the in-loop NN kernel "
                      "(steady state), over all dispatches for the others",
            "correction": "gfx950: hbm_bytes = FETCH_SIZE x 1024 x 2 (KB; wide coalesced reads counted at half) + WRITE_SIZE x 1024 (KB)",
