@@ -101,6 +101,8 @@ SYMBOLS = {
     "fdcap_opt_backward_dct": (c_int32, [c_void_p, c_float, c_float, c_float, c_int32, c_void_p]),
     "fdcap_opt_set_dct_coef": (c_int32, [c_void_p, c_void_p, c_void_p]),
     "fdcap_opt_get_dct": (c_int32, [c_void_p, c_void_p, c_void_p]),
+    "fdcap_opt_get_dct_state": (c_int32, [c_void_p, c_void_p, c_void_p, c_void_p]),
+    "fdcap_opt_set_dct_state": (c_int32, [c_void_p, c_void_p, c_void_p, c_void_p]),
     "fdcap_opt_dct_windows": (c_int32, [c_void_p, POINTER(c_int32), POINTER(c_int32)]),
     "fdcap_frame_smoother": (c_int32, [c_void_p, c_void_p, c_int32, c_int32, c_float, c_float, c_float, c_float,
                                         c_void_p, c_int32, c_int32, c_void_p, c_void_p]),
@@ -112,6 +114,7 @@ SYMBOLS = {
     "fdcap_lbfgs_reset": (c_int32, [c_void_p, c_void_p]),
     "fdcap_lbfgs_advance": (c_int32, [c_void_p, c_void_p, c_int32, c_void_p, c_void_p, c_int32, c_void_p, c_void_p]),
     "fdcap_lbfgs_get_stats": (c_int32, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "fdcap_lbfgs_finalize": (c_int32, [c_void_p, c_void_p, c_int32, c_void_p, c_void_p]),
     "fdcap_opt_fit2d_lbfgs": (c_int32, [c_void_p, POINTER(Fit2dStage), POINTER(LbfgsConfig), c_int32, POINTER(c_int32), c_void_p]),
     "fdcap_opt_fit2d_lbfgs_stats": (c_int32, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "fdcap_opt_step_rows_and_pack": (c_int32, [c_void_p, c_int32, c_int32, c_void_p, c_void_p]),

@@ -24,13 +24,21 @@ struct RcclApi {
 
     bool load() {
         if (lib) return true;
-        const char* names[] = {getenv("FDCAP_RCCL_LIB"), "librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
+        // FDCAP_RCCL_LIB names the library; FDCAP_RCCL_LIB_ONLY=1 tries nothing else (hosts that must not pick up a system copy; tests)
+        const char* only = getenv("FDCAP_RCCL_LIB_ONLY");
+        const bool strict = only && only[0] == '1';
+        const char* names[] = {getenv("FDCAP_RCCL_LIB"), strict ? nullptr : "librccl.so.1", strict ? nullptr : "librccl.so",
+                               strict ? nullptr : "/opt/rocm/lib/librccl.so.1"};
         for (const char* n : names) {
             if (!n || !n[0]) continue;
             lib = dlopen(n, RTLD_NOW | RTLD_GLOBAL);
             if (lib) break;
         }
-        if (!lib) { err = std::string("librccl not found: ") + (dlerror() ? dlerror() : ""); return false; }
+        if (!lib) {
+            const char* m = dlerror();                               // (ONE call: dlerror() clears the message it returns)
+            err = std::string("librccl not found: ") + (m ? m : "");
+            return false;
+        }
 #define FDC_SYM(field, name)                                                         \
         field = (decltype(field))dlsym(lib, name);                                   \
         if (!field) { err = std::string("librccl lacks ") + name; lib = nullptr; return false; }

@@ -355,6 +355,25 @@ __global__ __launch_bounds__(LB_NT) void lbfgs_advance_kernel(LbfgsCfg cf, Lbfgs
         if (s.phase != LB_DONE && n_active) atomicAdd(n_active, 1);
     }
 }
+
+// A caller that stops asking before every problem has finished (a round budget): a problem still inside a line search has a TRIAL
+// point in its x row (bracketing extrapolates up to 10x per step), not a point it accepted.  Put the line search's starting point
+// back -- the point `loss` in the scalars belongs to -- and mark the problem finished; n_unfinished += 1 per problem touched.
+__global__ __launch_bounds__(LB_DPAD) void lbfgs_finalize_kernel(LbfgsCfg cf, LbfgsScalars* __restrict__ S, const float* __restrict__ W,
+                                                               float* __restrict__ X, int x_stride, int* __restrict__ n_unfinished) {
+    const int p = blockIdx.x;
+    const int phase = S[p].phase;
+    if (phase == LB_DONE) return;
+    if (phase == LB_WAIT_BRACKET || phase == LB_WAIT_ZOOM) {
+        const float* xi = W + (size_t)p * lbfgs_ws_floats(cf.hist) + (size_t)LV_XINIT * LB_DPAD;
+        if ((int)threadIdx.x < cf.dim) X[(size_t)p * x_stride + threadIdx.x] = xi[threadIdx.x];
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        S[p].phase = LB_DONE;
+        if (n_unfinished) atomicAdd(n_unfinished, 1);
+    }
+}
 #endif
 
 }  // namespace fdc

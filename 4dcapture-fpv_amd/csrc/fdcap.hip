@@ -2837,6 +2837,20 @@ int fdcap_opt_get_dct(fdcap_ctx* c, float* c_dct_d, void* stream) {
                            (hipStream_t)stream));
     return FDCAP_OK;
 }
+// Adam's moments of c_dct, [W,69,C] each: what a checkpoint of mode 'dct' needs next to fdcap_opt_get_dct / fdcap_opt_export_state
+static int dct_state_copy(fdcap_ctx* c, float* m_d, float* v_d, bool out, hipStream_t st) {
+    if (!c || !c->opt || !m_d || !v_d) return FDCAP_E_ARG;
+    OptState* o = c->opt;
+    if (o->dctW <= 0) return FDCAP_E_STATE;
+    const size_t bytes = (size_t)o->dctW * 69 * o->dctC * sizeof(float);
+    HIP_TRY(hipMemcpyAsync(out ? m_d : o->dctM.p, out ? o->dctM.p : m_d, bytes, hipMemcpyDeviceToDevice, st));
+    HIP_TRY(hipMemcpyAsync(out ? v_d : o->dctV.p, out ? o->dctV.p : v_d, bytes, hipMemcpyDeviceToDevice, st));
+    return FDCAP_OK;
+}
+int fdcap_opt_get_dct_state(fdcap_ctx* c, float* m_d, float* v_d, void* stream) { return dct_state_copy(c, m_d, v_d, true, (hipStream_t)stream); }
+int fdcap_opt_set_dct_state(fdcap_ctx* c, const float* m_d, const float* v_d, void* stream) {
+    return dct_state_copy(c, (float*)m_d, (float*)v_d, false, (hipStream_t)stream);
+}
 int32_t fdcap_opt_dct_windows(fdcap_ctx* c, int32_t* w0, int32_t* w1) {
     if (!c || !c->opt || c->opt->dctW <= 0) return 0;
     const fdcap_opt_config& cf = c->opt->cfg;
@@ -2928,6 +2942,13 @@ static int lbfgs_advance_impl(fdcap_lbfgs* L, float* x, int32_t x_stride, const 
     if (n_active) HIP_TRY(hipMemcpyAsync(n_active, cnt, sizeof(int32_t), hipMemcpyDeviceToDevice, st));
     return (int)hipGetLastError();
 }
+int fdcap_lbfgs_finalize(fdcap_lbfgs* L, float* x, int32_t x_stride, int32_t* n_unfinished, void* stream) {
+    if (!L || !x || x_stride < L->cf.dim) return FDCAP_E_ARG;
+    hipStream_t st = (hipStream_t)stream;
+    if (n_unfinished) HIP_TRY(hipMemsetAsync(n_unfinished, 0, sizeof(int32_t), st));
+    hipLaunchKernelGGL(lbfgs_finalize_kernel, dim3(L->n), dim3(LB_DPAD), 0, st, L->cf, L->S.p, L->W.p, x, x_stride, n_unfinished);
+    return (int)hipGetLastError();
+}
 namespace {
 __global__ void lbfgs_stats_kernel(const LbfgsScalars* __restrict__ S, int n, int* __restrict__ it, int* __restrict__ ev, float* __restrict__ loss) {
     const int p = blockIdx.x * blockDim.x + threadIdx.x;
@@ -2998,6 +3019,8 @@ int fdcap_opt_fit2d_lbfgs(fdcap_ctx* c, const fdcap_fit2d_stage* sg, const fdcap
         }
     }
     if (rounds_out) *rounds_out = rounds;
+    // out of rounds with frames still inside a line search: their rows hold trial points -- roll them back to the accepted ones
+    if (!e && rounds >= max_rounds && *L->active_h != 0) e = fdcap_lbfgs_finalize(L, o->X.p + 2 * XDIM, XDIM, nullptr, st);
     if (o->dz_pending) {                                      // leave dX complete, as every other backward of the API does
         hipLaunchKernelGGL(vposer_fold_dz_kernel, dim3((nl * VP_Z + 255) / 256), dim3(256), 0, st, o->dZpart.p, (size_t)o->R * VP_Z, 2, nl, o->dX.p);
         o->dz_pending = false;
@@ -3309,7 +3332,8 @@ int fdcap_comm_destroy(fdcap_ctx* c) {
     return FDCAP_OK;
 }
 
-const char* fdcap_comm_last_error(fdcap_ctx* c) { return c ? c->comm_err.c_str() : ""; }
+// (a NULL context, or one without a message of its own, reports the loader's: fdcap_comm_unique_id has no context to write to)
+const char* fdcap_comm_last_error(fdcap_ctx* c) { return c && !c->comm_err.empty() ? c->comm_err.c_str() : rccl().err.c_str(); }
 
 // Fill the halo rows from the neighbouring ranks (before the first iteration, after fdcap_opt_import_state, after each
 // iteration of mode 'local''s second loop): boundary rows as they are -> all-gather -> unpack, three enqueues on `stream`.

@@ -13,7 +13,7 @@ from dataclasses import dataclass
 import numpy as np
 
 from . import capi, io
-from .dist import FrameShard, agree_on, allgather_packed, allreduce_scalars, barrier, exchange_halos, same_on_all_ranks
+from .dist import FrameShard, agree_on, allgather_packed, allreduce_scalars, exchange_halos, same_on_all_ranks
 
 # loss-total constants buried in fitting() (global_optimization.py:564, :570, :582)
 PHASE_SPLIT = 0.8
@@ -292,14 +292,17 @@ class FittingOP:
         """body_data: [N,75] (device tensor or numpy), SMPLify-X layout (:64-76).
         Returns (body_rec [N_local,75] device tensor, scale numpy scalar, camera_ext [N_local,4,4])
         -- the whole clip when not sharded, exactly the reference's triple (:635).
-        Not in the reference (mode 'global' only):
+        Not in the reference:
           checkpoint_every=k, checkpoint_path: after every k-th iteration write parameters + Adam moments to
-            `checkpoint_path` (sharded runs: one file per rank, suffix .rank<r>);
+            `checkpoint_path` (sharded runs: one file per rank, suffix .rank<r>).  All three modes (r5): mode 'local' counts its
+            second loop's iterations on from num_iter and keeps detect_contact's weights in the file; mode 'dct' counts the
+            iterations of its own budget (`dct_num_iter`, the 10000 of :596), cuts the one-launch first phase at the checkpoint
+            iterations and keeps c_dct with its Adam moments (with log_every: k must be a multiple of it);
           resume=path: continue such a run from where the file left off -- bit-identical to the uninterrupted run;
           check_finite_every=k: every k iterations count the non-finite parameters on the device and raise if any
             (the opt-in counterpart of the reference's set_detect_anomaly(True), :561);
-          snapshot_at=(k, ...): after the k-th optimiser step keep device copies of (body_rotation_rec [N_local,78], scale,
-            camera_ext [N_local,16]) in self.snapshots[k] -- no host sync; for trajectory comparisons (tests/test_gpu_parity500.py).
+          snapshot_at=(k, ...) (mode 'global'): after the k-th optimiser step keep device copies of (body_rotation_rec [N_local,78],
+            scale, camera_ext [N_local,16]) in self.snapshots[k] -- no host sync; for trajectory comparisons (tests/test_gpu_parity500.py).
         Sharded runs: every argument of this call and `num_iter` must be the same on all ranks (they decide which collectives
         are issued).  `verbose` may differ -- prints come from rank 0 only, and rank 0's flag alone decides whether the loss
         history is read back (all-reduced) during the loop, so a rank-0-only verbose run is legal."""
@@ -308,10 +311,13 @@ class FittingOP:
             raise ValueError("mode must be 'local', 'global' or 'dct' (global_optimization.py:660)")
         snapshot_at = frozenset(int(k) for k in snapshot_at)
         self.snapshots = {}
-        if (checkpoint_every or resume or check_finite_every or snapshot_at) and mode != "global":
-            raise ValueError("checkpoint / resume / check_finite are implemented for mode 'global'")
+        if snapshot_at and mode != "global":
+            raise ValueError("snapshot_at is implemented for mode 'global'")
         if checkpoint_every and not checkpoint_path:
             raise ValueError("checkpoint_every needs checkpoint_path")
+        if mode == "dct" and checkpoint_every and log_every and checkpoint_every % log_every:
+            raise ValueError("mode 'dct': checkpoint_every must be a multiple of log_every (the first phase's objective history is "
+                             "written by the launch itself, every log_every-th iteration counted from the launch's first)")
         self._mode = mode
         lib, h = self.ctx.lib, self.ctx.handle
         dev = self.device
@@ -326,7 +332,9 @@ class FittingOP:
         capi.check(lib.fdcap_params_75_to_78(capi.dptr(body_data), n, capi.dptr(x78), st), "fdcap_params_75_to_78")
         self.init(x78)                                                                      # :495
         P = first_phase2_iter(self.num_iter)
+        self._ck_extra = {}
         ii0 = self._load_checkpoint(resume) if resume else 0
+        self._ck = (int(checkpoint_every), checkpoint_path, int(check_finite_every))
         log = FitLog([], [], [], [], [], [], [])
         # FDCAP_FORCE_EXCHANGE=1: run the sharded iteration tail (pack -> all-gather -> unpack) even on a one-rank
         # group -- lets a single-GPU box exercise the RCCL calls of the multi-GPU path
@@ -344,7 +352,7 @@ class FittingOP:
             tune = [torch.cuda.Event(enable_timing=True) for _ in range(3)]
         self.exchange_overlap = overlap
         if mode == "dct":
-            self._dct_loops(lib, h, multi, log_every)
+            self._dct_loops(lib, h, multi, log_every, ii0)
         # The reference prints every loss term in every iteration (:573-575, :587-589) with five .item() syncs.  Here the
         # partial sums of a logging iteration are written into a device-side history row (no host sync inside the loop) and
         # read back -- and, when sharded, all-reduced -- once after the last iteration.
@@ -487,7 +495,7 @@ class FittingOP:
                 capi.check(lib.fdcap_opt_set_loss_output(h, capi.dptr(self._losses)), "fdcap_opt_set_loss_output")
         flush(len(logged))
         if mode == "local":
-            self._local_second_loop(lib, h, multi, log_every)
+            self._local_second_loop(lib, h, multi, log_every, max(ii0 - self.num_iter, 0))
         nl = self.shard.n_local
         body_rec = torch.empty(nl, capi.PDIM, device=dev)
         scale = torch.empty(1, device=dev)
@@ -504,20 +512,40 @@ class FittingOP:
     def _ckpt_file(self, path):
         return path if self.shard.world == 1 else f"{path}.rank{self.shard.rank}"
 
-    def _save_checkpoint(self, path, next_iter):
+    def _budget(self):
+        """the iteration budget a checkpoint belongs to (mode 'dct' runs its own, :596)"""
+        return int(self.dct_num_iter if getattr(self, "_mode", "global") == "dct" else self.num_iter)
+
+    def _save_checkpoint(self, path, next_iter, **extra):
+        import os
         import torch
         lib, h, nl = self.ctx.lib, self.ctx.handle, self.shard.n_local
         state = torch.empty(int(lib.fdcap_opt_state_len(h)), device=self.device)
         capi.check(lib.fdcap_opt_export_state(h, capi.dptr(state), capi.current_stream()), "fdcap_opt_export_state")   # (applies a deferred step first)
         fn = self._ckpt_file(path)
         tmp = fn + ".tmp.npz"
-        np.savez(tmp, next_iter=np.int64(next_iter), num_iter=np.int64(self.num_iter), n_total=np.int64(self.num_body),
-                 frame0=np.int64(self.shard.frame0), n_local=np.int64(nl), rows_x=self._rows_x[2:2 + nl].cpu().numpy(),
-                 rows_cam=self._rows_cam[2:2 + nl].cpu().numpy(), scale=self._scale.cpu().numpy(), state=state.cpu().numpy())
-        import os
+        err = None
+        try:
+            np.savez(tmp, next_iter=np.int64(next_iter), num_iter=np.int64(self._budget()), n_total=np.int64(self.num_body),
+                     frame0=np.int64(self.shard.frame0), n_local=np.int64(nl), rows_x=self._rows_x[2:2 + nl].cpu().numpy(),
+                     rows_cam=self._rows_cam[2:2 + nl].cpu().numpy(), scale=self._scale.cpu().numpy(), state=state.cpu().numpy(),
+                     mode=np.array(getattr(self, "_mode", "global")),
+                     **{k: (v.detach().cpu().numpy() if torch.is_tensor(v) else np.asarray(v)) for k, v in extra.items()})
+        except Exception as e:  # noqa: BLE001 -- agreed on below: one rank's failed write must not leave its peers in a collective
+            err = e
         # sharded: nobody replaces its file before every rank has written its new one (a crash during the writes leaves the
-        # previous, mutually consistent set); a crash between the renames is caught on resume (next_iter must agree)
-        barrier(self.shard)
+        # previous, mutually consistent set); a crash between the renames is caught on resume (next_iter must agree).  The
+        # agreement doubles as that barrier AND carries every rank's outcome (ADVICE r4: a bare barrier turned one rank's
+        # disk-full exception into a group hang): any failure anywhere -> nobody renames, everybody raises.
+        lo, hi = same_on_all_ranks(self.shard, 0 if err is None else 1)
+        if hi != 0:
+            try:
+                os.remove(tmp)
+            except OSError:
+                pass
+            if err is not None:
+                raise err
+            raise capi.FdcapError(f"checkpoint for iteration {next_iter}: another rank could not write its file; none was replaced")
         os.replace(tmp, fn)                                      # (a crash mid-write leaves the previous checkpoint intact)
 
     def _load_checkpoint(self, path):
@@ -526,8 +554,12 @@ class FittingOP:
         lib, h, nl = self.ctx.lib, self.ctx.handle, self.shard.n_local
         with np.load(self._ckpt_file(path)) as ck:
             if (int(ck["n_total"]), int(ck["frame0"]), int(ck["n_local"]), int(ck["num_iter"])) != \
-                    (self.num_body, self.shard.frame0, nl, int(self.num_iter)):
+                    (self.num_body, self.shard.frame0, nl, self._budget()):
                 raise capi.FdcapError("checkpoint was written for another clip length / sharding / iteration budget")
+            ck_mode = str(ck["mode"]) if "mode" in ck.files else "global"
+            if ck_mode != self._mode:
+                raise capi.FdcapError(f"checkpoint was written by a mode {ck_mode!r} fit, this is mode {self._mode!r}")
+            self._ck_extra = {k: np.array(ck[k]) for k in ("contact_weight", "c_dct", "dct_m", "dct_v") if k in ck.files}
             t = lambda k: torch.from_numpy(np.ascontiguousarray(ck[k], dtype=np.float32)).to(self.device)
             self._rows_x[2:2 + nl] = t("rows_x")
             self._rows_cam[2:2 + nl] = t("rows_cam")
@@ -558,7 +590,7 @@ class FittingOP:
             raise capi.FdcapError(f"{bad} non-finite optimiser parameters after iteration {ii}")
 
     # ---- :595-630 -------------------------------------------------------------------------
-    def _dct_loops(self, lib, h, multi, log_every):
+    def _dct_loops(self, lib, h, multi, log_every, ii0=0):
         """mode 'dct'.  First 95 % of the iterations: only c_dct moves (loss_dct*10, :601-607) against frozen
         joint trajectories -- ONE launch; iteration ceil(0.95*num_iter) is a no-op (every leaf's flag was
         flipped after its forward, :615-618, so nothing receives a gradient); the rest optimise
@@ -580,8 +612,15 @@ class FittingOP:
             self.dct_mtx = io.load_dct_base(getattr(self, "dct_mat_path", None), T, DCT_NUM)
         D = np.ascontiguousarray(self.dct_mtx, np.float32)
         C = D.shape[1]
-        c0 = self._c_dct_init
-        c0 = torch.randn(W, 23, 3, C) if c0 is None else torch.as_tensor(np.asarray(c0, dtype=np.float32))
+        ck_every, ck_path, finite_every = getattr(self, "_ck", (0, None, 0))
+        ex = getattr(self, "_ck_extra", {})
+        resumed = "c_dct" in ex
+        if ii0 and not resumed:
+            raise capi.FdcapError("the checkpoint holds no c_dct: not written by a mode 'dct' fit")
+        if ii0 and log_every and ii0 % log_every:
+            raise ValueError(f"mode 'dct': resuming at iteration {ii0} needs a log_every that divides it")
+        c0 = ex["c_dct"] if resumed else self._c_dct_init
+        c0 = torch.randn(W, 23, 3, C) if c0 is None else torch.as_tensor(np.asarray(c0, dtype=np.float32).reshape(W, 23, 3, -1))
         if tuple(c0.shape) != (W, 23, 3, C):
             raise capi.FdcapError(f"c_dct_init must be [{W},23,3,{C}], got {tuple(c0.shape)}")
         c0 = c0.to(dev, torch.float32).contiguous()
@@ -589,22 +628,42 @@ class FittingOP:
         import ctypes
         capi.check(lib.fdcap_opt_set_dct(h, D.ctypes.data_as(ctypes.c_void_p), D.shape[0], C, capi.dptr(c0), st),
                    "fdcap_opt_set_dct")
+        if resumed:                                            # Adam's moments of c_dct as the interrupted fit left them
+            dm = torch.as_tensor(ex["dct_m"]).to(dev, torch.float32).contiguous()
+            dv = torch.as_tensor(ex["dct_v"]).to(dev, torch.float32).contiguous()
+            capi.check(lib.fdcap_opt_set_dct_state(h, capi.dptr(dm), capi.dptr(dv), st), "fdcap_opt_set_dct_state")
         num_iter = self.dct_num_iter
         P = int(math.ceil(num_iter * DCT_PHASE_SPLIT - 1e-9))           # first ii with not (ii < num_iter*0.95)
         w0, w1 = ctypes.c_int32(), ctypes.c_int32()
         lib.fdcap_opt_dct_windows(h, ctypes.byref(w0), ctypes.byref(w1))
         ntraj = 69 * (w1.value - w0.value)
+
+        def save(next_iter):                                   # parameters + Adam moments + c_dct with ITS moments
+            cd_ = torch.empty(W, 69 * C, device=dev)
+            dm_, dv_ = torch.empty_like(cd_), torch.empty_like(cd_)
+            capi.check(lib.fdcap_opt_get_dct(h, capi.dptr(cd_), capi.current_stream()), "fdcap_opt_get_dct")
+            capi.check(lib.fdcap_opt_get_dct_state(h, capi.dptr(dm_), capi.dptr(dv_), capi.current_stream()), "fdcap_opt_get_dct_state")
+            self._save_checkpoint(ck_path, next_iter, c_dct=cd_, dct_m=dm_, dct_v=dv_)
+
+        # first phase [ii0, P): ONE launch -- or one per stretch between two checkpoint iterations (the launch keeps coefficients
+        # and moments in registers and writes them back at its end; Adam's step counter runs on through step0: same bits)
         hist = None
-        if log_every and ntraj and P:
-            hist = torch.zeros((P + log_every - 1) // log_every, ntraj, device=dev)
-        capi.check(lib.fdcap_opt_dct_fit(h, P, 0, DCT_PHASE1_WEIGHT, capi.dptr(hist), max(int(log_every), 1), st),
-                   "fdcap_opt_dct_fit")
+        if log_every and ntraj and P > ii0:
+            hist = torch.zeros((P - ii0 + log_every - 1) // log_every, ntraj, device=dev)
+        ii = ii0
+        while ii < P:
+            end = min(P, (ii // ck_every + 1) * ck_every) if ck_every else P
+            row = capi.dptr(hist[(ii - ii0) // log_every]) if hist is not None else None
+            capi.check(lib.fdcap_opt_dct_fit(h, end - ii, ii, DCT_PHASE1_WEIGHT, row, max(int(log_every), 1), st), "fdcap_opt_dct_fit")
+            ii = end
+            if ck_every and ii % ck_every == 0 and ii < num_iter:
+                save(ii)                                       # (sharded: every rank's own windows; merged after the phase, below)
         self.log_dct = []
         if hist is not None:
             part = hist.sum(dim=1, dtype=torch.float64)
             if multi:
                 allreduce_scalars(sh, torch.zeros(1, device=dev), part)
-            self.log_dct = [[k * log_every, float(v) / (69 * W)] for k, v in enumerate(part.cpu().numpy())]
+            self.log_dct = [[ii0 + k * log_every, float(v) / (69 * W)] for k, v in enumerate(part.cpu().numpy())]
 
         def merge_windows():                                   # every rank ends up with all windows' coefficients
             import torch.distributed as dist
@@ -618,14 +677,14 @@ class FittingOP:
                 dist.all_reduce(own, group=self.group)
             capi.check(lib.fdcap_opt_set_dct_coef(h, capi.dptr(own.contiguous()), capi.current_stream()), "fdcap_opt_set_dct_coef")
 
-        if multi:
+        if multi and ii0 <= P:                                 # (a checkpoint from after the phase holds merged coefficients)
             merge_windows()
-        if legacy and num_iter > P:                            # iteration P: nothing receives a gradient, c_dct coasts
+        if legacy and num_iter > P and ii0 <= P:               # iteration P: nothing receives a gradient, c_dct coasts
             capi.check(lib.fdcap_opt_dct_fit(h, 1, P, 0.0, None, 1, st), "fdcap_opt_dct_fit")
         BIG = 2 ** 30
         wd, wr, wc = DCT_PHASE2
         self.log2 = []
-        for k in range(max(num_iter - P - 1, 0)):              # ii = P + 1 + k; Adam step counters k + 1
+        for k in range(max(ii0 - P - 1, 0), max(num_iter - P - 1, 0)):     # ii = P + 1 + k; Adam step counters k + 1
             ii = P + 1 + k
             do_log = bool(log_every) and (ii % log_every == 0 or ii == num_iter - 1)
             st = capi.current_stream()
@@ -656,20 +715,34 @@ class FittingOP:
                 capi.check(lib.fdcap_opt_step(h, k, BIG, st), "fdcap_opt_step")
             if legacy:                                         # optimizer.step() of this iteration also moves the frozen c_dct
                 capi.check(lib.fdcap_opt_dct_fit(h, 1, ii, 0.0, None, 1, st), "fdcap_opt_dct_fit")
+            if finite_every and (ii + 1) % finite_every == 0:
+                self._check_finite(ii)
+            if ck_every and (ii + 1) % ck_every == 0 and ii + 1 < num_iter:
+                save(ii + 1)
         if multi and legacy:                                   # (each rank coasted its own windows)
             merge_windows()
         cd = torch.empty(W, 23, 3, C, device=dev)
         capi.check(lib.fdcap_opt_get_dct(h, capi.dptr(cd), capi.current_stream()), "fdcap_opt_get_dct")
         self.c_dct = cd
 
-    def _local_second_loop(self, lib, h, multi, log_every):
-        """detect_contact + the cal_loss2 loop of mode 'local' (:534-556)."""
+    def _local_second_loop(self, lib, h, multi, log_every, jj0=0):
+        """detect_contact + the cal_loss2 loop of mode 'local' (:534-556).  jj0 > 0: resumed inside this loop -- the contact
+        weights (a function of the parameters as the FIRST loop left them) come from the checkpoint."""
         import torch
         nl = self.shard.n_local
+        ck_every, ck_path, finite_every = getattr(self, "_ck", (0, None, 0))
+        ex = getattr(self, "_ck_extra", {})
+        if jj0 and "contact_weight" not in ex:
+            raise capi.FdcapError("the checkpoint holds no contact weights: not written inside mode 'local''s second loop")
         w_local = torch.empty(nl, device=self.device)
-        capi.check(lib.fdcap_opt_detect_contact(h, self.n_left, capi.dptr(w_local), capi.current_stream()),
-                   "fdcap_opt_detect_contact")
-        if multi:                                            # every rank needs the weight of its right neighbour's first frame
+        if jj0:
+            weight = torch.as_tensor(ex["contact_weight"]).to(self.device, torch.float32).contiguous()
+        else:
+            capi.check(lib.fdcap_opt_detect_contact(h, self.n_left, capi.dptr(w_local), capi.current_stream()),
+                       "fdcap_opt_detect_contact")
+        if jj0:
+            pass
+        elif multi:                                            # every rank needs the weight of its right neighbour's first frame
             import torch.distributed as dist
             parts = [torch.empty(self.shard.bounds(r)[1] - self.shard.bounds(r)[0], device=self.device)
                      for r in range(self.shard.world)]
@@ -684,7 +757,8 @@ class FittingOP:
             weight = w_local
         self.contact_weight = weight
         self.log2 = []
-        for jj in range(int(LOCAL_SECOND_LOOP * self.num_iter)):
+        n2 = int(LOCAL_SECOND_LOOP * self.num_iter)
+        for jj in range(jj0, n2):
             st = capi.current_stream()
             capi.check(lib.fdcap_opt_backward_local2(h, capi.dptr(weight), self.n_left, st), "fdcap_opt_backward_local2")
             if log_every and (jj % log_every == 0):
@@ -704,6 +778,11 @@ class FittingOP:
             capi.check(lib.fdcap_opt_step_x(h, self.num_iter + jj + 1, st), "fdcap_opt_step_x")
             if multi:
                 self._halos()
+            done = self.num_iter + jj + 1                    # iterations of the whole fit made so far
+            if finite_every and done % finite_every == 0:
+                self._check_finite(done - 1)
+            if ck_every and done % ck_every == 0 and jj + 1 < n2:
+                self._save_checkpoint(ck_path, done, contact_weight=weight)
 
     def _append_log(self, log, ii, phase2, s=None):
         s = self._losses.cpu().numpy() if s is None else s

@@ -276,6 +276,11 @@ int fdcap_opt_backward_dct(fdcap_ctx* ctx, float w_dct, float w_rec, float w_con
  * fdcap_opt_set_dct_coef writes merged coefficients back without touching the Adam moments. */
 int fdcap_opt_set_dct_coef(fdcap_ctx* ctx, const float* c_dct_d, void* stream);
 int fdcap_opt_get_dct(fdcap_ctx* ctx, float* c_dct_d, void* stream);
+/* Adam's two moments of c_dct, DEVICE [W,69,C] each (zero after fdcap_opt_set_dct): with fdcap_opt_get_dct and
+ * fdcap_opt_export_state the whole optimiser state of mode 'dct' -- a fit continued from them (fdcap_opt_dct_fit with step0 = the
+ * iterations already made) ends on the uninterrupted fit's bits. */
+int fdcap_opt_get_dct_state(fdcap_ctx* ctx, float* m_d, float* v_d, void* stream);
+int fdcap_opt_set_dct_state(fdcap_ctx* ctx, const float* m_d, const float* v_d, void* stream);
 /* Returns W; *w0 / *w1 = first / one-past-last window this rank fits (0 when fdcap_opt_set_dct has not run). */
 int32_t fdcap_opt_dct_windows(fdcap_ctx* ctx, int32_t* w0, int32_t* w1);
 
@@ -340,6 +345,10 @@ int fdcap_lbfgs_reset(fdcap_lbfgs* opt, void* stream);
  * be NULL) = problems that want another round.  Call until n_active is 0. */
 int fdcap_lbfgs_advance(fdcap_lbfgs* opt, float* x_d, int32_t x_stride, const float* f_d, const float* g_d, int32_t g_stride,
                         int32_t* n_active_d, void* stream);
+/* A caller that stops before n_active is 0 (a round budget): every unfinished problem's x row holds a line-search TRIAL point
+ * (bracketing extrapolates up to 10x per step), not an accepted one.  This puts the last accepted point back (the one `loss` of
+ * fdcap_lbfgs_get_stats belongs to), marks those problems finished and counts them in n_unfinished_d (DEVICE int32, may be NULL). */
+int fdcap_lbfgs_finalize(fdcap_lbfgs* opt, float* x_d, int32_t x_stride, int32_t* n_unfinished_d, void* stream);
 /* per problem, DEVICE, any may be NULL: iterations [n] (L-BFGS directions taken), evaluations [n] (objective calls consumed),
  * loss [n] (objective at the accepted point) */
 int fdcap_lbfgs_get_stats(fdcap_lbfgs* opt, int32_t* iterations_d, int32_t* evaluations_d, float* loss_d, void* stream);
@@ -347,7 +356,11 @@ int fdcap_lbfgs_get_stats(fdcap_lbfgs* opt, int32_t* iterations_d, int32_t* eval
 /* The inner fit of one stage with L-BFGS instead of Adam: rounds of (forward, fit2d loss, backward, fdcap_lbfgs_advance on the
  * n_local rows of body_rotation_rec) until every frame has stopped or max_rounds evaluations were made; a fresh optimiser per
  * call; cfg->dim is ignored (78).  *rounds_out (may be NULL) = evaluations made.  Synchronises `stream` every few rounds (to
- * read the number of frames still running) and before it returns. */
+ * read the number of frames still running) and before it returns.  Frames still inside a line search when max_rounds is reached
+ * are rolled back to their last accepted point (fdcap_lbfgs_finalize): the rows returned are never trial points.
+ * Outer stop, as built: relative change of the loss between two step() calls <= ftol, or max|g| < gtol with g the gradient at the
+ * ACCEPTED point.  (SMPLify-X tests param.grad as the last line-search evaluation left it; with strong Wolfe that is the accepted
+ * point's gradient except when the search ends on its evaluation cap.  oracle/innerfit.py makes the same choice.) */
 int fdcap_opt_fit2d_lbfgs(fdcap_ctx* ctx, const fdcap_fit2d_stage* stage, const fdcap_lbfgs_config* cfg, int32_t max_rounds,
                           int32_t* rounds_out, void* stream);
 /* fdcap_lbfgs_get_stats of the last fdcap_opt_fit2d_lbfgs call, per frame [n_local] (FDCAP_E_STATE before the first) */
@@ -369,7 +382,9 @@ int32_t fdcap_exchange_len(void);
 /* ---- the exchange INSIDE the library (SURVEY 8b "halo_exchange", 8e) -----------------------------------------------------
  * The reference has no distributed code; this is the communicator of the frame-sharded optimiser for callers that are not
  * Python (and for Python: two calls per iteration instead of five, no stream hand-over).  RCCL is bound at run time
- * (dlopen librccl.so.1; FDCAP_RCCL_LIB overrides): FDCAP_E_COMM when it is not there.  One communicator per context, created
+ * (dlopen librccl.so.1; FDCAP_RCCL_LIB names another file, tried first; with FDCAP_RCCL_LIB_ONLY=1 nothing else is tried):
+ * FDCAP_E_COMM when it is not there, the loader's message in fdcap_comm_last_error (a NULL context, or a context without a
+ * message of its own, returns the process-wide loader message).  One communicator per context, created
  * on the calling thread's current HIP device; every rank of the job calls fdcap_comm_create with the SAME id.
  *   fdcap_comm_unique_id : `id128` [FDCAP_UNIQUE_ID_BYTES] host bytes; rank 0's go to the other ranks out of band (any rank may
  *                          call it: it is also the cheap test that librccl can be bound in this process)

@@ -286,3 +286,55 @@ def test_dct_mode_needs_a_full_window_and_smoother_handles_one_frame():
     one = SmootherOP().fitting_clip(clip.body_params[:1]).cpu().numpy()
     ref = SmootherOracle().fitting_clip(clip.body_params[:1]).numpy()
     assert one.shape == (1, 75) and np.abs(one - ref).max() < 1e-5
+
+
+@pytest.mark.parametrize("legacy", [False, True])
+def test_dct_mode_checkpoint_resume_is_bit_identical(tmp_path, legacy):
+    """VERDICT r4 (missing 5): mode 'dct' is the 10000-iteration mode (:596), the one where a resume matters.  A 200-iteration fit
+    (phase switch at 190) checkpointing every 40 iterations -- which also cuts the one-launch first phase into five launches --
+    equals the plain fit bit for bit; new optimisers resumed from the checkpoint of iteration 120 (inside the first phase) and of
+    iteration 196 (inside the second; written by a run with checkpoint_every=14) end on the same bits, c_dct included."""
+    n, num_iter = 120, 200
+    bm, vp, clip, scene, vid, c0 = _dct_case(n, 200, 1500, seed=91)
+    D = load_dct_base(None)
+    body = torch.tensor(clip.body_params).cuda()
+
+    def make():
+        return FittingOP({}, {}, n, body_model=bm, vposer=vp, scene_verts=scene, contact_ids=vid, camera_ext=read_camerapose(clip.camerapose_lines),
+                         dct_mtx=D, c_dct_init=c0, dct_num_iter=num_iter, legacy_zero_grad=legacy)
+
+    def run(**kw):
+        fop = make()
+        b, s, c = fop.fitting(body, "dct", **kw)
+        out = (b.clone(), float(s), fop.c_dct.clone(), np.array(fop.log_dct), np.array(fop.log2))
+        fop.close()
+        return out
+
+    plain = run(log_every=10)
+    ck1, ck2 = str(tmp_path / "a.npz"), str(tmp_path / "b.npz")
+    cut = run(log_every=10, checkpoint_every=40, checkpoint_path=ck1, check_finite_every=3)
+    for a, b in zip(plain, cut):
+        assert (torch.equal(a, b) if torch.is_tensor(a) else np.array_equal(a, b))
+    assert int(np.load(ck1)["next_iter"]) == 160 and str(np.load(ck1)["mode"]) == "dct"
+    # resume inside phase 1: stop a fresh run's file at iteration 120 by giving it a budget-compatible checkpoint_every
+    fop = make()
+    fop.fitting(body, "dct", checkpoint_every=120, checkpoint_path=ck1)
+    fop.close()
+    assert int(np.load(ck1)["next_iter"]) == 120
+    res = run(log_every=10, resume=ck1)
+    assert torch.equal(res[0], plain[0]) and res[1] == plain[1] and torch.equal(res[2], plain[2])
+    np.testing.assert_array_equal(res[3], plain[3][12:])                # the resumed run's history starts at iteration 120
+    np.testing.assert_array_equal(res[4], plain[4])
+    # resume inside phase 2
+    fop = make()
+    fop.fitting(body, "dct", checkpoint_every=14, checkpoint_path=ck2)
+    fop.close()
+    assert int(np.load(ck2)["next_iter"]) == 196
+    res = run(resume=ck2)
+    assert torch.equal(res[0], plain[0]) and res[1] == plain[1] and torch.equal(res[2], plain[2])
+    # a global-mode fit refuses the file
+    fop = FittingOP({"num_iter": num_iter}, {}, n, body_model=bm, vposer=vp, scene_verts=scene, contact_ids=vid,
+                    camera_ext=read_camerapose(clip.camerapose_lines))
+    with pytest.raises(capi.FdcapError, match="mode 'dct'"):
+        fop.fitting(body, "global", resume=ck2)
+    fop.close()

@@ -65,6 +65,16 @@ def _value_and_grad(fun, x):
     return float(f.detach()), x.grad.detach()
 
 
+def _as_double(fun):
+    """The same objective with every tensor it holds in float64 (torch.optim.LBFGS then runs in float64 throughout)."""
+    import copy
+    f64 = copy.copy(fun)
+    for k, v in vars(fun).items():
+        if torch.is_tensor(v):
+            setattr(f64, k, v.double())
+    return f64
+
+
 def _torch_lbfgs(fun, cfg):
     """SMPLify-X's loop around torch.optim.LBFGS.step (oracle/innerfit.py fitting_lbfgs has the same loop)."""
     x = fun.x0.clone().requires_grad_(True)
@@ -93,7 +103,7 @@ def _torch_lbfgs(fun, cfg):
     return x.detach().clone(), f_end, opt.state[x]["n_iter"], calls[0] - (steps - 1)      # (the kernel does not repeat the closure call that opens a later step)
 
 
-def _run_kernel(funs, cfg, max_rounds=5000):
+def _run_kernel(funs, cfg, max_rounds=5000, finalize=False):
     lib = capi.load_library()
     n, dim = len(funs), funs[0].dim
     stride = dim + 3                                                # rows wider than the problem: the strides are honoured
@@ -117,12 +127,18 @@ def _run_kernel(funs, cfg, max_rounds=5000):
             rounds += 1
             if int(active.item()) == 0:
                 break
+        if finalize:
+            x_trial = X[:, :dim].cpu()
+            unf = torch.zeros(1, dtype=torch.int32, device="cuda")
+            capi.check(lib.fdcap_lbfgs_finalize(h, capi.dptr(X), stride, capi.dptr(unf), capi.current_stream()), "fdcap_lbfgs_finalize")
         it = torch.zeros(n, dtype=torch.int32, device="cuda")
         ev = torch.zeros(n, dtype=torch.int32, device="cuda")
         loss = torch.zeros(n, device="cuda")
         capi.check(lib.fdcap_lbfgs_get_stats(h, capi.dptr(it), capi.dptr(ev), capi.dptr(loss), capi.current_stream()), "fdcap_lbfgs_get_stats")
         torch.cuda.synchronize()
         assert torch.all(X[:, dim:] == 7.0), "the kernel wrote outside its problem's columns"
+        if finalize:
+            return X[:, :dim].cpu(), it.cpu().numpy(), ev.cpu().numpy(), loss.cpu().numpy(), rounds, int(unf.item()), x_trial
         return X[:, :dim].cpu(), it.cpu().numpy(), ev.cpu().numpy(), loss.cpu().numpy(), rounds
     finally:
         lib.fdcap_lbfgs_destroy(h)
@@ -143,15 +159,25 @@ def test_one_optimizer_step_takes_torchs_decisions(family, cfg):
     rng = np.random.Generator(np.random.PCG64(11))
     funs = [family(rng) for _ in range(12)]
     x, it, ev, loss, rounds = _run_kernel(funs, cfg)
-    same_counts, any_converged = 0, False
+    same_counts, any_converged, off_path, ties = 0, False, 0, 0
     for i, f in enumerate(funs):
         xr, fr, itr, evr = _torch_lbfgs(f, cfg)
         err = float((x[i] - xr).abs().max()) / max(1.0, float(xr.abs().max()))
-        print(f"{family.__name__} {i}: directions {it[i]} / {itr}, objective calls {ev[i]} / {evr}, loss {loss[i]:.6g} / {fr:.6g}, |dx| {err:.2e}")
         same = it[i] == itr and ev[i] == evr
         same_counts += int(same)
         converged = itr < cfg["max_iter"]                           # torch stopped on a tolerance, not on the cap
         any_converged |= converged
+        note = ""
+        if not same and not converged:
+            # Host-independent classification: the same problem through torch.optim.LBFGS in float64.  Where torch's
+            # own two precisions take different decisions, a comparison on the path sits within fp32 rounding of a tie and no fp32
+            # implementation is "the" path; where they agree and the kernel does not, the kernel left the path.
+            _, _, it64, ev64 = _torch_lbfgs(_as_double(f), cfg)
+            tie = (it64, ev64) != (itr, evr)
+            ties += int(tie)
+            off_path += int(not tie)
+            note = f"  [torch float64: {it64} / {ev64} -> {'tie-sensitive problem' if tie else 'KERNEL OFF THE PATH'}]"
+        print(f"{family.__name__} {i}: directions {it[i]} / {itr}, objective calls {ev[i]} / {evr}, loss {loss[i]:.6g} / {fr:.6g}, |dx| {err:.2e}{note}")
         # Stopped on a tolerance: the same minimum (the last, rounding-sized steps need not be the same in number).
         # Stopped by the cap: the same decisions all the way, hence the same point -- unless a comparison sat within rounding
         # of a tie and sent the two down different, equally valid, paths (counted below).
@@ -159,9 +185,12 @@ def test_one_optimizer_step_takes_torchs_decisions(family, cfg):
             assert abs(float(f(x[i])) - fr) <= 1e-4 * max(1.0, abs(fr)) + 1e-5
             assert err < (1e-3 if converged else 2e-3)
     if not any_converged:
-        # (measured on this pool's hosts: 11, 12 and 11 of 12 in the three cap-limited families; torch's CPU dot products sum in
-        # an order that depends on the host's vector width, so the bar leaves room for a few more ties elsewhere)
-        assert same_counts >= len(funs) - 4, "more than four of twelve problems left torch.optim.LBFGS's path"
+        # (measured on this pool's hosts: 11, 12 and 11 of 12 equal in the three cap-limited families.)  The bar does not depend
+        # on the host's summation order: a count mismatch is excused only where torch in float64 disagrees with torch in float32
+        # on the same problem; elsewhere at most two of twelve may differ (the bar before r4's widening).
+        print(f"{family.__name__}: {same_counts} of {len(funs)} on torch's path, {ties} tie-sensitive, {off_path} off the path")
+        assert off_path <= 2, f"{off_path} of {len(funs)} problems left torch.optim.LBFGS's path where torch's own precisions agree"
+        assert same_counts + ties >= len(funs) - 2
     assert rounds == ev.max()                                        # one objective call per round for the slowest problem, no more
 
 
@@ -202,6 +231,23 @@ def test_finished_problems_stay_put_and_bad_arguments_are_refused():
             return torch.sum(x * 0.0) + 1.5
     x, it, ev, loss, rounds = _run_kernel([Flat()], CFG)
     assert rounds == 1 and it[0] == 0 and torch.equal(x[0], Flat.x0) and loss[0] == 1.5
+
+
+def test_a_round_budget_returns_accepted_points_not_trial_points():
+    """a caller that stops asking mid line search used to keep the TRIAL point in its rows.  fdcap_lbfgs_finalize puts
+    the last accepted point back: the objective there equals the `loss` the stats report, and it is not above the start's."""
+    rng = np.random.Generator(np.random.PCG64(17))
+    funs = [Rosenbrock(rng) for _ in range(8)]
+    for budget in (2, 3, 5, 9):
+        x, it, ev, loss, rounds, unfinished, x_trial = _run_kernel(funs, dict(CFG, max_iter=400), max_rounds=budget, finalize=True)
+        assert rounds == budget and unfinished > 0
+        moved = 0
+        for i, f in enumerate(funs):
+            fx = float(f(x[i]))
+            assert abs(fx - float(loss[i])) <= 1e-5 * max(1.0, abs(fx)), (budget, i, fx, float(loss[i]))
+            assert fx <= float(f(f.x0)) * (1 + 1e-6)
+            moved += int(not torch.equal(x[i], x_trial[i]))
+        assert moved > 0, "no row held a trial point: the case under test did not occur"
 
 
 def _px_err(orc, rows, kp):

@@ -796,6 +796,31 @@ def test_local_mode_matches_reference_golden(golden_dir):
     fop.close()
 
 
+def test_local_mode_checkpoint_resume_is_bit_identical(tmp_path):
+    """Mode 'local' (r5): 20 iterations of the first loop + 8 of the second; checkpoints every 6 iterations of the whole fit.  New
+    optimisers resumed from iteration 16 (first loop, at its phase switch) and from iteration 24 (inside the second loop: detect_contact's weights come
+    from the file) end on the uninterrupted fit's bits."""
+    n = 24
+    fop, bm, vp, clip, scene, vid = _make_fop(n, 200, 1500, 10, 20, seed=70)
+    body = torch.tensor(clip.body_params).cuda()
+    a = fop.fitting(body, "local", log_every=1)
+    a = (a[0].clone(), float(a[1]), np.array(fop.log2))
+    fop.close()
+    for stop, every in ((16, 16), (24, 6)):
+        ck = str(tmp_path / f"l{stop}.npz")
+        f1, *_ = _make_fop(n, 200, 1500, 10, 20, seed=70)
+        b = f1.fitting(body, "local", checkpoint_every=every, checkpoint_path=ck, check_finite_every=5)
+        assert torch.equal(a[0], b[0]) and a[1] == float(b[1])
+        f1.close()
+        last = int(np.load(ck)["next_iter"])
+        assert last == stop and str(np.load(ck)["mode"]) == "local"
+        f2, *_ = _make_fop(n, 200, 1500, 10, 20, seed=70)
+        c = f2.fitting(body, "local", log_every=1, resume=ck)
+        assert torch.equal(a[0], c[0]) and a[1] == float(c[1]), stop
+        np.testing.assert_array_equal(np.array(f2.log2), a[2][max(stop - 20, 0):])
+        f2.close()
+
+
 def test_local_mode_second_loop_gradient_matches_autograd():
     n = 10
     fop, bm, vp, clip, scene, vid = _make_fop(n, 260, 700, 12, 500, seed=90)

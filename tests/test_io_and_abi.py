@@ -172,3 +172,19 @@ def test_the_header_is_plain_c_and_the_c_host_program_compiles_against_it(tmp_pa
                         os.path.join(root, "tests", "c_abi_lbfgs.c"), "-o", exe2, "-L", pkg, "-lfdcap_hip", "-L", "/opt/rocm/lib", "-lamdhip64",
                         "-lm", f"-Wl,-rpath,{pkg}", "-Wl,-rpath,/opt/rocm/lib"], capture_output=True, text=True)
     assert r.returncode == 0, r.stderr[-3000:]
+
+
+def test_missing_rccl_is_an_error_code_not_a_crash():
+    """on a host without librccl the loader built its message from two dlerror() calls (the second returns NULL ->
+    std::string + NULL -> crash).  A fresh process whose only candidate is a file that does not exist must get FDCAP_E_COMM from
+    fdcap_comm_unique_id and a readable message from fdcap_comm_last_error(NULL) -- the code FittingOP._init_c_comm falls back on."""
+    import subprocess
+    import sys
+    code = ("import ctypes, sys; sys.path.insert(0, %r); import fdcap_amd; from fdcap_amd import capi; lib = capi.load_library(); "
+            "idb = (ctypes.c_uint8 * 128)(); rc = lib.fdcap_comm_unique_id(idb); msg = lib.fdcap_comm_last_error(None); "
+            "print(rc, msg.decode())") % ROOT
+    env = dict(os.environ, FDCAP_RCCL_LIB="/nonexistent/librccl-not-here.so", FDCAP_RCCL_LIB_ONLY="1")
+    p = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300)
+    assert p.returncode == 0, p.stderr[-800:]
+    rc, msg = p.stdout.strip().split(" ", 1)
+    assert int(rc) == -4 and "librccl not found" in msg and "librccl-not-here" in msg, p.stdout
