@@ -466,6 +466,15 @@ constexpr int ST4_MAXCELL = FDC_ST4_MAXCELL;   // chunks one wave can list befor
 #ifndef FDC_ST4_PF
 #define FDC_ST4_PF 2
 #endif
+#ifndef FDC_ST4_ADAPTIVE_SLACK
+#define FDC_ST4_ADAPTIVE_SLACK 1
+#endif
+#ifndef FDC_AS_MULT
+#define FDC_AS_MULT 4.f
+#endif
+#ifndef FDC_AS_MAX
+#define FDC_AS_MAX 3.f
+#endif
 #ifndef FDC_ST4_OCC
 #define FDC_ST4_OCC 8
 #endif
@@ -627,6 +636,7 @@ __global__ __launch_bounds__(64 * WPB, NQ == 1 ? FDC_ST4_OCC : FDC_ST4_OCC2) voi
     // Work-list cache: may this wave take the list it kept?
     int n_kept = -1;
     bool inflate = false;                                        // build the list with slack and keep it?
+    int slk = __builtin_amdgcn_readfirstlane(__float_as_int(cache.slack));   // ... with how much (wave-uniform; bits of a float)
     if (cull && caching) {
         const int hv = __builtin_amdgcn_readfirstlane(hv_pre);
         bool ok = true;
@@ -649,7 +659,17 @@ __global__ __launch_bounds__(64 * WPB, NQ == 1 ? FDC_ST4_OCC : FDC_ST4_OCC2) voi
             dmax = max_rows01(dmax);
             dmax = fmaxf(dmax, __shfl_xor(dmax, 32, 64));
             const float age = hv >= 0 ? (float)max(hv >> 8, 1) : 1.f;
+#if FDC_ST4_ADAPTIVE_SLACK
+            // r5: the slack follows the queries' speed -- 4 launches' worth of motion, between the configured slack and 3 x that --
+            // so that lists are also kept while the bodies move centimetres per launch (the first ~150 iterations of a fit; all
+            // of phase 2 when its contact term is logged: camera_ext turns the bodies ~1 cm per iteration and no list survived,
+            // every wave rebuilt its list in every launch, 14 us of a 26 us lifetime: tools/phase_switch_timeline.py)
+            const float speed = dmax / age;
+            slk = __builtin_amdgcn_readfirstlane(__float_as_int(fminf(fmaxf(FDC_AS_MULT * speed, cache.slack), FDC_AS_MAX * cache.slack)));
+            inflate = 3.f * speed <= __int_as_float(slk);
+#else
             inflate = dmax * 6.f <= cache.slack * age;
+#endif
         }
     }
     // the radii / squared bounds the list is BUILT for: inflated by the slack when the list is going to be kept
@@ -660,7 +680,7 @@ __global__ __launch_bounds__(64 * WPB, NQ == 1 ? FDC_ST4_OCC : FDC_ST4_OCC2) voi
         float rT[NQ];
 #pragma unroll
         for (int n = 0; n < NQ; ++n) {
-            rT[n] = inflate ? rq[n] + cache.slack : rq[n];
+            rT[n] = inflate ? rq[n] + __int_as_float(slk) : rq[n];
             sbT[n] = (qidx[n] < nq) ? (inflate ? rT[n] * rT[n] * 1.00002f : sb[n]) : -INFINITY;
         }
         // Group bound for the box tests: the axis-aligned box around the queries' balls (centre x_i, radius r_i).
@@ -815,7 +835,7 @@ __global__ __launch_bounds__(64 * WPB, NQ == 1 ? FDC_ST4_OCC : FDC_ST4_OCC2) voi
                 for (int n = 0; n < NQ; ++n)
                     if (qidx[n] < nq)                              // R_i with the validity test's rounding margin taken off; no list: never valid
                         cache.anchor[(size_t)sub * nq + qidx[n]] =
-                            make_float4(qx[n], qy[n], qz[n], keep ? (rq[n] + cache.slack) * 0.99998f - 2e-6f : -1.f);
+                            make_float4(qx[n], qy[n], qz[n], keep ? (rq[n] + __int_as_float(slk)) * 0.99998f - 2e-6f : -1.f);
             }
         }
         if (!listed) nsurv = 4 * myn;                           // list overflow: scan this wave's whole share (still exact)
@@ -882,13 +902,31 @@ __global__ __launch_bounds__(64 * WPB, NQ == 1 ? FDC_ST4_OCC : FDC_ST4_OCC2) voi
         u32x4 f[ST4_PF];
 #pragma unroll
         for (int j = 0; j < ST4_PF; ++j) f[j] = __builtin_amdgcn_raw_buffer_load_b128(frs, lofs, fo + j * 1024, 0);
-        float4 cc_next = T.centers[ch];
+        // The cell centres are wave-uniform and static per scene: read through the CONSTANT address space they become s_load_dwordx4
+        // into four SGPRs.  (r5: as a plain global load the compiler kept the next centre in four VGPRs across the whole item --
+        // with one more live value in this 64-register kernel it spilled exactly those, behind an s_waitcnt vmcnt(0): a scratch
+        // round trip and a drained fragment ring per work item, +20 us per launch.)
+        typedef float cf4_t __attribute__((ext_vector_type(4)));
+        typedef const cf4_t __attribute__((address_space(4)))* cf4_ptr;
+        const cf4_ptr centers_c = (cf4_ptr)(const void*)T.centers;
+        cf4_t cc_next = centers_c[ch];
         nsurv = __builtin_amdgcn_readfirstlane(nsurv);
         int cur = -1;                                                      // chunk the queries are centred on
         bf16x8 bfrag[NQ];
-        float thr[NQ], X[NQ], X2[NQ], rc = 0.f;
+        // Per query and current cell: thr (rows with a score below it pass), e2 = 2.01 eps and c2 = eps - |x'|^2, with
+        // eps = K1 |x'| rc + K2 (|x'|^2 + rc^2) the filter's error bound for this cell (|score + |x'|^2 - d| <= eps / 1.5).
+        // r5: the SCORES tighten the threshold, without an exact evaluation.  The error bound cuts both ways: a row with score s lies
+        // at d <= s + |x'|^2 + eps, so once a tile shows a row with score m the neighbour is no further than that -- and every row
+        // with s >= m + 2.01 eps is out, whatever the seed promised.  With a tight seed (steady state) nothing changes; with a loose
+        // one -- a seed that moved centimetres since it was found: the first iterations of a fit, the iterations after the phase
+        // switch, when camera_ext turns the bodies about the world origin -- the rows inside the seed's ball used to be evaluated
+        // exactly one by one (23 per query and launch against 0.1, most of them as dependent round trips once a lane's queue was
+        // full: launches of 150-290 us, tools/phase_switch_probe.py / phase_switch_timeline.py); now only the rows within 2 eps
+        // of the tile's best are.  Pruning only: every row that can win or tie still passes.  (What a cell's scores proved is not
+        // carried to the next cell: one more live register in this 64-register kernel spills a fragment of the ring.)
+        float thr[NQ], e2[NQ], c2[NQ];
 #pragma unroll
-        for (int n = 0; n < NQ; ++n) { thr[n] = -INFINITY; X[n] = X2[n] = 0.f; bfrag[n] = __builtin_bit_cast(bf16x8, make_uint4(0u, 0u, 0u, 0u)); }
+        for (int n = 0; n < NQ; ++n) { thr[n] = -INFINITY; e2[n] = c2[n] = 0.f; bfrag[n] = __builtin_bit_cast(bf16x8, make_uint4(0u, 0u, 0u, 0u)); }
         // NQ == 1: the tile of this lane's current best (-1: none in this half) and the mask that clears its row's bit --
         // own_p only changes in the queue-full path below, which refreshes them
         int seed_tile = -1;
@@ -904,27 +942,30 @@ __global__ __launch_bounds__(64 * WPB, NQ == 1 ? FDC_ST4_OCC : FDC_ST4_OCC2) voi
             const int id_next = __builtin_amdgcn_readfirstlane(listed ? (int)slist[wave][s1] : s1);
             const int ch_next = __builtin_amdgcn_readfirstlane(WPG * (id_next >> 2) + sub);
             const unsigned fo_next = (unsigned)(ch_next * NT + (id_next & 3) * QT) * 1024u;
-            const float4 cc = cc_next;
-            cc_next = T.centers[ch_next];
+            const cf4_t cc = cc_next;
+            cc_next = centers_c[ch_next];
             FDC_STAT(3, lane == 0);
             if (ch != cur) {                                               // wave-uniform: quarters of one chunk follow each other
                 cur = ch;
                 // re-centre the queries on the chunk centre
-                rc = cc.w;
+                const float rc = cc.w;
 #pragma unroll
                 for (int n = 0; n < NQ; ++n) {
                     const float xx = qx[n] - cc.x, xy = qy[n] - cc.y, xz = qz[n] - cc.z;
-                    X2[n] = __fmaf_rn(xz, xz, __fmaf_rn(xy, xy, xx * xx));
-                    X[n] = __builtin_amdgcn_sqrtf(X2[n]) * 1.000001f;       // only feeds eps: 1-ulp v_sqrt_f32, rounded up
+                    const float X2 = __fmaf_rn(xz, xz, __fmaf_rn(xy, xy, xx * xx));
+                    const float X = __builtin_amdgcn_sqrtf(X2) * 1.000001f;  // only feeds eps: 1-ulp v_sqrt_f32, rounded up
                     const unsigned hx = f2bf(xx), hy = f2bf(xy), hz = f2bf(xz);
                     const unsigned lx = f2bf(xx - bf2f(hx)), ly = f2bf(xy - bf2f(hy)), lz = f2bf(xz - bf2f(hz));
                     const unsigned px = hx | (lx << 16), py = hy | (ly << 16), pz = hz | (lz << 16);   // (the factor -2 is in the A fragments)
                     const unsigned one = 0x3F80u;
                     const uint4 u = half == 0 ? make_uint4(px, px, py, py) : make_uint4(pz, pz, one | (one << 16), one);
                     bfrag[n] = __builtin_bit_cast(bf16x8, u);
+                    const float eps = MF_K1 * X * rc + MF_K2 * (X2 + rc * rc);
+                    e2[n] = 2.01f * eps;
+                    c2[n] = eps - X2;
                     // this half's own bound (the other half's may be tighter after an exact hit; it is folded in at the next
                     // hit -- a looser threshold only lets more pairs through, and saves a cross-half exchange per cell)
-                    thr[n] = (qidx[n] < nq) ? own_d[n] - X2[n] + (MF_K1 * X[n] * rc + MF_K2 * (X2[n] + rc * rc)) : -INFINITY;
+                    thr[n] = (qidx[n] < nq) ? own_d[n] + c2[n] : -INFINITY;
                 }
             }
             const int base = ch * MF_CH + qd * (QT * 32);
@@ -961,6 +1002,7 @@ __global__ __launch_bounds__(64 * WPB, NQ == 1 ? FDC_ST4_OCC : FDC_ST4_OCC2) voi
                         // instructions per entry -- costs 15-26 spilled registers in this 64-register kernel; nested under the
                         // halves it fits, and the extra wave votes and branches make the launch 3 % slower: 67.8 vs 65.9 us.)
                         unsigned mask = 0;
+                        if (qidx[n] < nq) thr[n] = fminf(thr[n], m + e2[n]);               // (a lane without a passing row: m >= thr, no change)
                         const float th = thr[n];
                         if (__any(g0 < th)) {
 #pragma unroll
@@ -1029,7 +1071,7 @@ __global__ __launch_bounds__(64 * WPB, NQ == 1 ? FDC_ST4_OCC : FDC_ST4_OCC2) voi
                             }
                         }
                         const float sbest = fminf(own_d[n], __shfl_xor(own_d[n], 32, 64));
-                        if (qidx[n] < nq) thr[n] = sbest - X2[n] + (MF_K1 * X[n] * rc + MF_K2 * (X2[n] + rc * rc));
+                        if (qidx[n] < nq) thr[n] = fminf(thr[n], sbest + c2[n]);
                     }
                 }
             }

@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
 """bench.py -- frames/s of the fixed-budget global optimisation on MI355X (BASELINE.json metric).
 
-  python bench.py [--gpus N] [--steps K] [--warmup W]        (N > 1 without a launcher: starts the N ranks itself, as below)
+  python bench.py [--gpus N] [--steps K] [--warmup W] [--config c3|c5|c2] [--scaling strong|weak]
+                                                            (N > 1 without a launcher: starts the N ranks itself, as below)
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
          --master-port P bench.py --gpus N --steps K --warmup W
 
@@ -12,6 +13,9 @@ conversion and the device->host copy of the results are inside the timed region,
 upload is not.  Workload at every N: BASELINE config 3 -- 1024-frame clip,
 500k-point scene, 500 contact vertices; with N > 1 the SAME clip is sharded over the ranks
 (strong scaling), exchanging 2-frame halos + the scale gradient per iteration over RCCL.
+--config c5 / c2: BASELINE config 5 (512 frames, 2 M-point scene, all 10 475 vertices as contacts) / config 2 (256 frames,
+100 k points) instead; --scaling weak: every rank fits its OWN whole clip (no data-path collective; `value` = all ranks'
+frames over the slowest rank's time) -- the arrangement that pays on 8 GPUs for a clip one GPU already fits.
 
 Rank 0 prints ONE JSON line.
   `value`                   loss terms evaluated where they reach a gradient;
@@ -20,8 +24,12 @@ Rank 0 prints ONE JSON line.
   `exact_fp32`              the same step with the dense products as exact fp32 MFMA chains (FDCAP_GEMM_SPLIT3=0);
   `roofline`                the dominant kernel (in-loop Chamfer NN launch): its duration is measured live with HIP events
                             on the launch stream; the counters that say WHICH resource bounds it come from the committed
-                            rocprofv3 PMC summary profiles/r4_pmc_summary.json (tools/run_prof_r4.sh); `contract` keeps
-                            SURVEY §8d's algorithmic-bytes figure;
+                            rocprofv3 PMC summary of the configuration (profiles/r5_<config>_pmc_summary.json,
+                            tools/run_prof_r5.sh); `contract` keeps SURVEY §8d's algorithmic-bytes figure;
+                            `roofline.per_kernel`: ALL NINE launches of a phase-1 iteration -- microseconds from the committed
+                            kernel trace, executed flops or algorithmic bytes, fraction of the peak that binds each;
+  `other_configs`           BASELINE configs 2 and 5 measured in the same run (ms per fit, us per iteration, their Chamfer
+                            launch and what bounds it, from their own PMC summaries);
   `cpu_baseline`            the oracle timed on this host's cores on a bounded sample.
 
 --dry-run: no GPU, no kernels, `value` null -- only the multi-process plumbing of this file (gloo instead of RCCL: rendezvous,
@@ -50,7 +58,13 @@ NUM_SIMD = 1024                # 256 CUs x 4
 NUM_XCD = 8
 WAVES_PER_SIMD = 8
 METRIC = "frames/sec global-opt (fixed iters), 1024f clip/500k-pt scene; Chamfer GB/s"
-PMC_SUMMARY = os.path.join(ROOT, "profiles", "r4_pmc_summary.json")
+# BASELINE.json configs that fit one GPU, by the names DESIGN.md uses: (frames, scene points, all mesh vertices as contacts?)
+CONFIGS = {"c3": (1024, 500_000, False), "c5": (512, 2_000_000, True), "c2": (256, 100_000, False)}
+CONFIG_NAMES = {"c3": "BASELINE config 3", "c5": "BASELINE config 5 (Chamfer stress: dense scene, every vertex a contact)", "c2": "BASELINE config 2"}
+
+
+def pmc_summary_path(cfg):
+    return os.path.join(ROOT, "profiles", f"r5_{cfg}_pmc_summary.json")
 # VALU issue cost per wave64 instruction on one gfx950 SIMD, MEASURED (tools/valu_issue_probe.hip, 8 waves per SIMD, per physical
 # SIMD; profiles/r4_valu_issue_probe.txt): v_fma / v_add / v_mul / v_sub_f32, v_and_b32, v_add_u32 issue every ~2.2 cycles (the
 # guide's "2 cycles"); v_min3 / v_min / v_med3 / v_cmp_f32, v_alignbit_b32, 64-bit shifts and the packed fp32 forms every ~4.16.
@@ -64,8 +78,13 @@ def parse(argv=None):
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=2)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--frames", type=int, default=1024)
-    ap.add_argument("--scene", type=int, default=500_000)
+    ap.add_argument("--config", choices=sorted(CONFIGS), default="c3", help="BASELINE configuration: sets --frames / --scene / --all-contacts "
+                    "(c3 = the quoted one; explicit size flags override)")
+    ap.add_argument("--scaling", choices=("strong", "weak"), default="strong", help="N > 1: strong = ONE clip sharded over the ranks with the "
+                    "per-iteration halo exchange (BASELINE config 3's arrangement); weak = one whole clip per rank, no data-path collective")
+    ap.add_argument("--no-other-configs", action="store_true", help="skip the other_configs block (configs 2 and 5 measured in the same run)")
+    ap.add_argument("--frames", type=int, default=None)
+    ap.add_argument("--scene", type=int, default=None)
     ap.add_argument("--contacts-per-leg", type=int, default=250)
     ap.add_argument("--all-contacts", action="store_true", help="every mesh vertex is a contact vertex (BASELINE config 5)")
     ap.add_argument("--iters", type=int, default=500)
@@ -80,7 +99,22 @@ def parse(argv=None):
                     "every-iteration-logging step (the line says so in config.workload; never the headline)")
     ap.add_argument("--cpu-sample-frames", type=int, default=0, help="0 = pick from a ~20 s budget")
     ap.add_argument("--dry-run", action="store_true", help="plumbing only, on CPU with gloo (see the module docstring)")
-    return ap.parse_args(argv)
+    args = ap.parse_args(argv)
+    f, ns, allc = CONFIGS[args.config]
+    if args.frames is None:
+        args.frames = f
+    if args.scene is None:
+        args.scene = ns
+    args.all_contacts = args.all_contacts or allc
+    return args
+
+
+def which_config(N, ns, nc, verts, lbs_nnz):
+    """name of the BASELINE configuration these sizes are (None: none of them)"""
+    for name, (f, s_, allc) in CONFIGS.items():
+        if (N, ns) == (f, s_) and nc == (verts if allc else 500) and verts == 10475 and lbs_nnz == 4:
+            return name
+    return None
 
 
 # ---- multi-process plumbing (shared by the real run and --dry-run) -----------------------------------------------------
@@ -175,15 +209,18 @@ class Ranks:
 
 def base_line(args, rk, nc, value, dt):
     N, ns = args.frames, args.scene
-    quoted = (N, ns, nc, args.iters, args.lbs_nnz) == (1024, 500_000, 500, 500, 4)
+    cfg = which_config(N, ns, nc, args.verts, args.lbs_nnz) if args.iters == 500 else None
+    weak = args.scaling == "weak"
     return {"metric": METRIC, "value": value, "unit": "frames/s", "n_gpus": rk.world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": dt / max(args.steps, 1) * 1e3, "higher_is_better": True,
-            "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "scaling": args.scaling, "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "arithmetic": "fp32 values and fp32 accumulation throughout; dense products as exact three-way bf16 splits of the fp32 "
                           "operands on the bf16 matrix cores (error of the fp32 chain; FDCAP_GEMM_SPLIT3=0: v_mfma_f32 chains, see exact_fp32)",
-            "config": {"workload": f"{'BASELINE config 3' if quoted else 'non-default sizes (not the quoted configuration)'}: {N}-frame clip, "
+            "config": {"workload": f"{CONFIG_NAMES[cfg] if cfg else 'non-default sizes (not a BASELINE configuration)'}: {N}-frame clip, "
                                    f"{ns}-pt scene, {nc} contact verts, {args.iters} Adam iterations (phase split 0.8), full loss; "
-                                   f"frames sharded over {rk.world} GPU(s)",
+                                   + (f"one whole clip per GPU, {rk.world} GPU(s), no data-path collective" if weak else
+                                      f"frames sharded over {rk.world} GPU(s)"),
+                       "name": cfg,
                        "frames": N, "scene_points": ns, "contact_verts": nc, "iters": args.iters, "body_verts": args.verts,
                        "lbs_weights_per_vertex": args.lbs_nnz,
                        "frame_iterations_per_s": None if value is None else value * args.iters}}
@@ -297,12 +334,6 @@ def cpu_baseline(bm, vp, clip, scene, vid, args):
 
 
 # ---- roofline from live durations + the committed PMC summary ---------------------------------------------------------
-def load_pmc():
-    if os.path.exists(PMC_SUMMARY):
-        return json.load(open(PMC_SUMMARY))
-    return {}
-
-
 def counter_fracs(k, live_seconds=None):
     """What a kernel's PMC totals (summed over the device, per launch) say about the resources it uses.
     GRBM_GUI_ACTIVE is summed over the 8 XCDs -> /8 = busy cycles of the launch; SQ_WAVE_CYCLES counts quad-cycles."""
@@ -347,6 +378,180 @@ def counter_fracs(k, live_seconds=None):
     return out
 
 
+def load_pmc(cfg):
+    """the committed PMC summary of a BASELINE configuration (tools/run_prof_r5.sh): {} when there is none"""
+    path = pmc_summary_path(cfg) if cfg else None
+    if path and os.path.exists(path):
+        return json.load(open(path)), os.path.relpath(path, ROOT)
+    return {}, None
+
+
+def build_problem(frames, scene_pts, all_contacts, verts, lbs_nnz, contacts_per_leg, iters, group):
+    import fdcap_amd  # noqa: F401
+    from fdcap_amd import synth
+    from fdcap_amd.fitting import FittingOP
+    from fdcap_amd.io import read_camerapose
+    bm = synth.make_body_model(verts, seed=0, lbs_nnz=lbs_nnz)
+    vp = synth.make_vposer(seed=1)
+    clip = synth.make_clip(frames, seed=3)
+    scene = synth.make_scene(scene_pts, seed=2)
+    left, right = synth.make_contact_ids(bm.v_template, per_part=contacts_per_leg, seed=4)
+    vid = np.arange(verts) if all_contacts else np.concatenate([left, right])
+    fop = FittingOP({"num_iter": iters}, {}, frames, body_model=bm, vposer=vp, scene_verts=scene, contact_ids=vid,
+                    camera_ext=read_camerapose(clip.camerapose_lines), group=group)
+    return fop, torch.tensor(clip.body_params).cuda(), bm, vp, clip, scene, vid
+
+
+def time_nn_launches(fop, one_step, iters):
+    """HIP events around every in-loop Chamfer launch of one more (untimed) fit + the two stand-alone timings"""
+    import ctypes
+    from fdcap_amd import capi
+    lib, h = fop.ctx.lib, fop.ctx.handle
+    ms_inloop, n_inloop = ctypes.c_float(0), ctypes.c_int32(0)
+    capi.check(lib.fdcap_opt_nn_timing(h, iters), "fdcap_opt_nn_timing")
+    one_step()
+    capi.check(lib.fdcap_opt_nn_timing_read(h, ctypes.byref(ms_inloop), ctypes.byref(n_inloop)), "fdcap_opt_nn_timing_read")
+    capi.check(lib.fdcap_opt_nn_timing(h, 0), "fdcap_opt_nn_timing")
+    ms_loop = ctypes.c_float(0)
+    capi.check(lib.fdcap_opt_time_chamfer(h, 10, 0, ctypes.byref(ms_loop), capi.current_stream()), "fdcap_opt_time_chamfer")
+    return ms_inloop.value, n_inloop.value, ms_loop.value
+
+
+def nn_roofline(pk, src, sec_loop, ms_steady, n_timed, alg_bytes):
+    """The in-loop launch is an exact PRUNED search (seeds, k-d cells, kept work lists; bit-identical to the full scan): it touches
+    ~1 % of the pairs the algorithmic byte count pays for, so bytes-over-time says nothing about a hardware limit.  What bounds it
+    is VALU issue while the machine is full, then a drain at part occupancy: the top-level fraction is that
+    resource's, from the PMC counters; `contract` keeps the §8d figure."""
+    nn = counter_fracs(pk.get("nn_in_loop_all") or pk.get("nn_in_loop"), sec_loop) if pk else None
+    roofline = {
+        "kernel": "fdc::nn_stream4_kernel (Chamfer body->scene NN forward as issued in the loop: seeded + k-d-cell-culled exact scan, "
+                  "kept work lists, bf16-split MFMA filter + fp32 re-evaluation)",
+        "ms_per_launch": sec_loop * 1e3, "launches_timed": n_timed, "steady_state_ms_per_launch": ms_steady,
+        "timing": "HIP events around every NN launch of one whole fit, on its launch stream (mean); steady_state = back-to-back "
+                  "launches at the converged state",
+        "counters_from": src if nn else None}
+    if nn and nn.get("valu_busy_simd_cycles_per_launch"):
+        clock = nn["clock_ghz_under_pmc"] * 1e9
+        ach = nn["valu_busy_simd_cycles_per_launch"] / sec_loop / 1e9
+        peak = NUM_SIMD * clock / 1e9
+        roofline.update({"bound": "valu_issue", "achieved": ach, "peak": peak, "unit": "G SIMD-cycles/s of VALU issue", "frac": ach / peak,
+                         "traffic": nn.get("hbm_bytes_per_launch"), "hbm_frac_on_counter_bytes": nn.get("hbm_frac_on_counter_bytes"),
+                         "mfma_busy_frac": nn.get("mfma_busy_frac"), "mean_waves_per_simd": nn.get("mean_waves_per_simd"),
+                         "max_waves_per_simd": WAVES_PER_SIMD, "valu_insts_per_wave": nn.get("valu_insts_per_wave"),
+                         "valu_mix": nn.get("valu_mix"), "wave_time_split": nn.get("wave_time_split"),
+                         "valu_cycles_per_instruction": {"fast_class": VALU_CYC_FAST, "slow_class": VALU_CYC_SLOW,
+                                                         "measured_by": "tools/valu_issue_probe.hip -> profiles/r4_valu_issue_probe.txt"},
+                         "clock_ghz_under_pmc": nn["clock_ghz_under_pmc"],
+                         "note": "achieved = cycles one SIMD's VALU port is occupied per launch (instruction counts of the PMC mix pass x the measured "
+                                 "cycles of their class, summed over the SIMDs) / live launch time; peak = 1024 SIMDs x the clock the launch "
+                                 "sustained in the PMC pass.  frac is the mean over the whole launch: the port is saturated while all 8 wave "
+                                 "slots per SIMD are filled and idles through the drain (mean_waves_per_simd); HBM and the matrix pipe are far "
+                                 "from their limits"})
+    else:
+        roofline.update({"bound": "hbm", "achieved": None, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": None, "traffic": None,
+                         "note": "no committed PMC summary for these sizes (profiles/r5_<config>_pmc_summary.json exist for BASELINE configs 3, 5 "
+                                 "and 2 at 500 iterations on one GPU): only the live launch time and the contract figure below"})
+    roofline["contract"] = {
+        "bound": "hbm", "algorithmic_bytes": alg_bytes, "bytes_per_unit": "F * (12 Ns + 20 Nc): the reference op re-reads a scene copy per frame",
+        "achieved": alg_bytes / sec_loop / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+        "frac_on_algorithmic_bytes": alg_bytes / sec_loop / 1e9 / HBM_PEAK_GBS,
+        "note": "SURVEY §8d's contract figure.  > 1 because exact pruning does not read what the byte count pays for -- an algorithmic win, "
+                "not a bandwidth measurement"}
+    return roofline, nn
+
+
+def per_kernel_table(pk, F, nc, K, src):
+    """Every launch of a phase-1 iteration next to the peak that binds it.  Microseconds: kernel-trace averages of the committed
+    profile (the same command's rocprofv3 --kernel-trace --stats).  Dense products: EXECUTED bf16 MFMA flops (SQ_INSTS_MFMA of
+    the PMC mix pass x 16 384 flop per v_mfma_f32_16x16x32_bf16 wave instruction; the fp32-equivalent useful flops beside them)
+    against the dense bf16 peak.  Per-frame kernels: ALGORITHMIC bytes (what the launch must read and write once; formulas
+    in DESIGN §5) against HBM, with the counter traffic (FETCH x 2 + WRITE, guide's gfx950 correction) beside them."""
+    if not pk:
+        return None
+    fl = lambda *dims: 2.0 * F * sum(a * b for a, b in dims)
+    rows = [
+        # key, what, bound, useful fp32 flops | algorithmic bytes
+        ("vposer_fwd", "VPoser decode 32-512-512-126 (A7)", "mfma", fl((32, 512), (512, 512), (512, 126))),
+        ("pose_fwd", "6D/PCA -> rotations, joint regression, kinematic chain, world joints (A8 K5-K9, A9)", "hbm", 4.0 * F * 2791),
+        ("blend_fwd", "pose+shape blend offsets of the contact set [F,496]x[496,3Nc] (A8 K6/K8)", "mfma", fl((496, 3 * nc))),
+        ("skin_fwd", "linear-blend skinning + scale + world transform of the contact set (A8 K10, A10)", "hbm", F * (24.0 * nc + 2720)),
+        ("nn_in_loop_all", "Chamfer NN forward (A12): see the top-level roofline", "valu_issue", None),
+        ("skin_bwd", "contact robustifier + skinning backward (A13, A8 K10 bwd)", "hbm", F * ((52.0 + 4.0 * (K > 4)) * nc + 5344)),
+        ("blend_bwd", "data gradient of the blend product [F,3Nc]x[3Nc,496]", "mfma", fl((3 * nc, 496))),
+        ("pose_bwd", "chain / rotation / joint-regression backward + parameter-space losses (A14)", "hbm", 4.0 * F * 3224),
+        ("vposer_bwd", "VPoser data gradient 126-512-512-32", "mfma", fl((126, 512), (512, 512), (512, 32))),
+    ]
+    out, total = [], 0.0
+    for key, what, bound, work in rows:
+        k = pk.get(key)
+        if not k or not k.get("duration_us_trace"):
+            continue
+        us = k["duration_us_trace"]
+        total += us
+        e = {"kernel": k.get("name"), "computes": what, "us": us, "bound": bound, "traffic": k.get("hbm_bytes")}
+        c = counter_fracs(k) or {}
+        if c.get("mfma_busy_frac") is not None:
+            e["mfma_busy_frac"] = c["mfma_busy_frac"]
+        if c.get("mean_waves_per_simd") is not None:
+            e["mean_waves_per_simd"] = c["mean_waves_per_simd"]
+        if bound == "mfma":
+            ex = k.get("SQ_INSTS_MFMA")
+            e.update({"useful_fp32_flop": work, "unit": "TFLOP/s (bf16 MFMA executed, dense)", "peak": BF16_DENSE_TFLOPS})
+            if ex is not None:
+                e.update({"executed_bf16_flop": ex * 16384.0, "achieved": ex * 16384.0 / us / 1e6, "frac": ex * 16384.0 / us / 1e6 / BF16_DENSE_TFLOPS})
+            e["floor_us"] = None if ex is None else ex * 16384.0 / (BF16_DENSE_TFLOPS * 1e6)
+        elif bound == "hbm":
+            e.update({"algorithmic_bytes": work, "unit": "GB/s", "peak": HBM_PEAK_GBS, "achieved": work / us / 1e3, "frac": work / us / 1e3 / HBM_PEAK_GBS,
+                      "floor_us": work / (HBM_PEAK_GBS * 1e3),
+                      "traffic_over_algorithmic": None if not k.get("hbm_bytes") else k["hbm_bytes"] / work})
+        else:
+            e.update({"frac": None, "note": "priced on VALU issue in the top-level roofline block (live launch time)"})
+        out.append(e)
+    return {"source": src, "phase1_iteration_us": total, "kernels": out,
+            "note": "floor_us = the kernel's work at the binding peak; every launch also pays ~1.2 us fixed + ~0.2 us per MB it leaves dirty in "
+                    "L2 (profiles/r4_launch_overhead_probe.txt).  Phase 2 of a fit issues four of the nine (VPoser and pose, both ways)"}
+
+
+def other_config(name, args):
+    """One more BASELINE configuration in the same run: a fresh optimiser of its sizes, 1 warm-up + 1 timed fit, the Chamfer
+    launch timed in the loop, its own committed PMC summary for the bound."""
+    f, ns, allc = CONFIGS[name]
+    fop, body_gpu, bm, vp, clip, scene, vid = build_problem(f, ns, allc, 10475, 4, 250, args.iters, None)
+
+    def one_step():
+        b, sc, cam = fop.fitting(body_gpu, "global")
+        return b.cpu(), sc, cam.cpu()
+    one_step()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    res = one_step()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    assert np.isfinite(res[0].numpy()).all()
+    ms_in, n_in, ms_steady = time_nn_launches(fop, one_step, args.iters)
+    nc = len(vid)
+    pmc, src = load_pmc(name if args.iters == 500 else None)
+    pk = pmc.get("kernels", {})
+    alg = f * (12.0 * ns + 20.0 * nc)
+    rl, nn = nn_roofline(pk, src, (ms_in if n_in else ms_steady) * 1e-3, ms_steady, n_in, alg)
+    P = int(np.ceil(args.iters * 0.8 - 1e-12))
+    out = {"workload": f"{CONFIG_NAMES[name]}: {f}-frame clip, {ns}-pt scene, {nc} contact verts, {args.iters} iterations, 1 GPU",
+           "value": f / dt, "unit": "frames/s", "ms_per_step": dt * 1e3, "us_per_iteration": dt * 1e6 / args.iters,
+           "chamfer_launch_us": rl["ms_per_launch"] * 1e3, "chamfer_launch_steady_us": ms_steady * 1e3,
+           "chamfer_share_of_step": rl["ms_per_launch"] * P / (dt * 1e3),
+           "bound": rl.get("bound"), "frac": rl.get("frac"), "hbm_frac_on_counter_bytes": rl.get("hbm_frac_on_counter_bytes"),
+           "mfma_busy_frac": rl.get("mfma_busy_frac"), "mean_waves_per_simd": rl.get("mean_waves_per_simd"),
+           "traffic": rl.get("traffic"), "contract_frac_on_algorithmic_bytes": rl["contract"]["frac_on_algorithmic_bytes"],
+           "counters_from": rl.get("counters_from")}
+    pkt = per_kernel_table(pk, f, nc, 4, src) if name == "c2" else None
+    if pkt:
+        out["phase1_iteration_us_by_trace"] = pkt["phase1_iteration_us"]
+    fop.close()
+    del fop
+    torch.cuda.empty_cache()
+    return out
+
+
 def main():
     args = parse()
     if args.gpus < 1:
@@ -361,20 +566,13 @@ def main():
     torch.cuda.set_device(rk.local)
     import ctypes
     import fdcap_amd  # noqa: F401
-    from fdcap_amd import capi, synth
-    from fdcap_amd.fitting import FittingOP
-    from fdcap_amd.io import read_camerapose
+    from fdcap_amd import capi
 
     N = args.frames
-    bm = synth.make_body_model(args.verts, seed=0, lbs_nnz=args.lbs_nnz)
-    vp = synth.make_vposer(seed=1)
-    clip = synth.make_clip(N, seed=3)
-    scene = synth.make_scene(args.scene, seed=2)
-    left, right = synth.make_contact_ids(bm.v_template, per_part=args.contacts_per_leg, seed=4)
-    vid = np.arange(args.verts) if args.all_contacts else np.concatenate([left, right])
-    fop = FittingOP({"num_iter": args.iters}, {}, N, body_model=bm, vposer=vp, scene_verts=scene, contact_ids=vid,
-                    camera_ext=read_camerapose(clip.camerapose_lines), group=rk.group)
-    body_gpu = torch.tensor(clip.body_params).cuda()
+    weak = args.scaling == "weak"
+    # weak: every rank owns a whole clip (the same synthetic one) -- the process group only serves the barriers and the max over ranks
+    fop, body_gpu, bm, vp, clip, scene, vid = build_problem(N, args.scene, args.all_contacts, args.verts, args.lbs_nnz,
+                                                            args.contacts_per_leg, args.iters, None if weak else rk.group)
     if rk.group is not None:                               # create the RCCL communicator outside the timed region
         import torch.distributed as dist
         warm = torch.zeros(8, device="cuda")
@@ -395,9 +593,13 @@ def main():
     dt, res = rk.timed(timed_step, args.steps)
     assert np.isfinite(res[0].numpy()).all()
     nc, ns, nl = len(vid), len(scene), fop.shard.n_local
-    out = base_line(args, rk, nc, N * args.steps / dt, dt)
-    if rk.world > 1:          # which iteration schedule rank 0's last fit kept after timing both (same results either way)
-        out["config"]["exchange_schedule"] = "next forward's head under the all-gather" if getattr(fop, "exchange_overlap", False) else "plain"
+    clips = rk.world if weak else 1
+    out = base_line(args, rk, nc, clips * N * args.steps / dt, dt)
+    if rk.world > 1:
+        out["config"]["ranks_seen_by_rccl"] = int(torch.distributed.get_world_size())
+        if not weak:      # which iteration schedule rank 0's last fit kept after timing both (same results either way)
+            out["config"]["exchange_schedule"] = "next forward's head under the all-gather" if getattr(fop, "exchange_overlap", False) else "plain"
+            out["config"]["exchange_inside_library"] = bool(getattr(fop, "_c_comm", False))
     if args.value_only:
         if args.profile_logging:
             out["config"]["workload"] += " [--profile-logging: every loss term of every iteration evaluated and kept]"
@@ -409,7 +611,7 @@ def main():
     dt_log, _ = rk.timed(lambda: one_step(log_every=1), n_log_steps)
     if n_log_steps:
         out["with_reference_logging"] = {
-            "value": N * n_log_steps / dt_log, "unit": "frames/s", "ms_per_step": dt_log / n_log_steps * 1e3,
+            "value": clips * N * n_log_steps / dt_log, "unit": "frames/s", "ms_per_step": dt_log / n_log_steps * 1e3,
             "note": "same step, every loss term of every iteration evaluated and kept (the reference prints them every iteration); "
                     "`value` evaluates them only where they reach a gradient -- optimised parameters are identical either way"}
 
@@ -417,81 +619,47 @@ def main():
         raise SystemExit('bench.py needs a scene (the roofline kernel is the Chamfer NN); BASELINE config 1 is a parity-test case')
     lib, h = fop.ctx.lib, fop.ctx.handle
     # the dominant kernel as the loop issues it: HIP events around every contact forward of one more (untimed) step
-    ms_inloop, n_inloop = ctypes.c_float(0), ctypes.c_int32(0)
-    capi.check(lib.fdcap_opt_nn_timing(h, args.iters), "fdcap_opt_nn_timing")
-    one_step()
-    capi.check(lib.fdcap_opt_nn_timing_read(h, ctypes.byref(ms_inloop), ctypes.byref(n_inloop)), "fdcap_opt_nn_timing_read")
-    capi.check(lib.fdcap_opt_nn_timing(h, 0), "fdcap_opt_nn_timing")
-    ms_bf, ms_loop = ctypes.c_float(0), ctypes.c_float(0)
-    capi.check(lib.fdcap_opt_time_chamfer(h, 3, 1, ctypes.byref(ms_bf), capi.current_stream()), "fdcap_opt_time_chamfer")
-    capi.check(lib.fdcap_opt_time_chamfer(h, 10, 0, ctypes.byref(ms_loop), capi.current_stream()), "fdcap_opt_time_chamfer")
+    ms_inloop, n_inloop, ms_steady = time_nn_launches(fop, one_step, args.iters)
+    ms_bf = ctypes.c_float(0)
+    capi.check(lib.fdcap_opt_time_chamfer(h, 3 if nc <= 1000 else 1, 1, ctypes.byref(ms_bf), capi.current_stream()), "fdcap_opt_time_chamfer")
     alg_bytes = nl * (12.0 * ns + 20.0 * nc)              # scene once PER FRAME + queries + dist/idx
     pairs = float(nl) * nc * ns
-    sec_bf, sec_loop = ms_bf.value * 1e-3, (ms_inloop.value if n_inloop.value else ms_loop.value) * 1e-3
-    pmc = load_pmc()
+    sec_bf, sec_loop = ms_bf.value * 1e-3, (ms_inloop if n_inloop else ms_steady) * 1e-3
+    # the committed counters describe ONE GPU holding the whole clip at the fixed budget: sharded runs get live times only
+    cfg = which_config(N, ns, nc, args.verts, args.lbs_nnz) if (args.iters == 500 and nl == N) else None
+    pmc, pmc_src = load_pmc(cfg)
     pk = pmc.get("kernels", {})
-    quoted = (N, ns, nc, args.iters, rk.world, args.lbs_nnz) == (1024, 500_000, 500, 500, 1, 4)     # the configuration the PMC summary was taken on
-    # (counters averaged over EVERY in-loop launch of the profiled fits -- like the live mean launch time they are divided by)
-    nn = counter_fracs(pk.get("nn_in_loop_all") or pk.get("nn_in_loop"), sec_loop) if quoted else None
+    quoted = cfg == "c3"
+    roofline, nn = nn_roofline(pk, pmc_src, sec_loop, ms_steady, n_inloop, alg_bytes)
     bf = counter_fracs(pk.get("nn_bruteforce"), sec_bf) if quoted else None
-    # The in-loop launch is an exact PRUNED search (seeds, k-d cells, kept work lists; bit-identical to the full scan): it
-    # touches ~1 % of the pairs the algorithmic byte count pays for, so bytes-over-time says nothing about a hardware limit.
-    # What bounds it is VALU issue while the machine is full, then a drain at half occupancy: the top-level
-    # fraction is that resource's, from the PMC counters; `contract` keeps the §8d figure.
-    roofline = {
-        "kernel": "fdc::nn_stream4_kernel (Chamfer body->scene NN forward as issued in the loop: seeded + k-d-cell-culled exact scan, "
-                  "kept work lists, bf16-split MFMA filter + fp32 re-evaluation)",
-        "ms_per_launch": sec_loop * 1e3, "launches_timed": n_inloop.value, "steady_state_ms_per_launch": ms_loop.value,
-        "timing": "HIP events around every NN launch of one whole fit, on its launch stream (mean); steady_state = back-to-back "
-                  "launches at the converged state",
-        "counters_from": os.path.relpath(PMC_SUMMARY, ROOT) if nn else None}
-    if nn and nn.get("valu_busy_simd_cycles_per_launch"):
-        clock = nn["clock_ghz_under_pmc"] * 1e9
-        ach = nn["valu_busy_simd_cycles_per_launch"] / sec_loop / 1e9
-        peak = NUM_SIMD * clock / 1e9
-        roofline.update({"bound": "valu_issue", "achieved": ach, "peak": peak, "unit": "G SIMD-cycles/s of VALU issue", "frac": ach / peak,
-                         "traffic": nn.get("hbm_bytes_per_launch"), "hbm_frac_on_counter_bytes": nn.get("hbm_frac_on_counter_bytes"),
-                         "mfma_busy_frac": nn.get("mfma_busy_frac"), "mean_waves_per_simd": nn.get("mean_waves_per_simd"),
-                         "max_waves_per_simd": WAVES_PER_SIMD, "valu_insts_per_wave": nn.get("valu_insts_per_wave"),
-                         "valu_mix": nn.get("valu_mix"), "wave_time_split": nn.get("wave_time_split"),
-                         "valu_cycles_per_instruction": {"fast_class": VALU_CYC_FAST, "slow_class": VALU_CYC_SLOW,
-                                                         "measured_by": "tools/valu_issue_probe.hip -> profiles/r4_valu_issue_probe.txt"},
-                         "clock_ghz_under_pmc": nn["clock_ghz_under_pmc"],
-                         "note": "achieved = cycles one SIMD's VALU port is occupied per launch (instruction counts of the PMC mix pass x the measured "
-                                 "cycles of their class, summed over the SIMDs) / live launch time; peak = 1024 SIMDs x the clock the launch "
-                                 "sustained in the PMC pass.  frac is the mean over the whole launch: the port is saturated while all 8 wave "
-                                 "slots per SIMD are filled and idles through the drain (mean_waves_per_simd); HBM and the matrix pipe are far "
-                                 "from their limits"})
-    else:
-        tr = (pk.get("nn_in_loop") or {}).get("hbm_bytes")
-        roofline.update({"bound": "hbm", "achieved": None if tr is None else tr / sec_loop / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": None if tr is None else tr / sec_loop / 1e9 / HBM_PEAK_GBS, "traffic": tr,
-                         "note": "no PMC summary for this configuration: counter bytes of the quoted configuration over this launch time"})
-    roofline["contract"] = {
-        "bound": "hbm", "algorithmic_bytes": alg_bytes, "bytes_per_unit": "F * (12 Ns + 20 Nc): the reference op re-reads a scene copy per frame",
-        "achieved": alg_bytes / sec_loop / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-        "frac_on_algorithmic_bytes": alg_bytes / sec_loop / 1e9 / HBM_PEAK_GBS,
-        "note": "SURVEY §8d's contract figure.  > 1 because exact pruning does not read what the byte count pays for -- an algorithmic win, "
-                "not a bandwidth measurement"}
+    if not bf and quoted:                                  # (the brute-force launch is not in the r5 passes' command: r4's summary has it)
+        old = os.path.join(ROOT, "profiles", "r4_pmc_summary.json")
+        if os.path.exists(old):
+            bf = counter_fracs(json.load(open(old)).get("kernels", {}).get("nn_bruteforce"), sec_bf)
     roofline["brute_force"] = {
         "kernel": "fdc::nn_mfma_kernel<4> (every (query, scene point) pair visited: the launch the algorithmic byte count describes; "
-                  "operator API, not part of the loop)",
+                  "operator API for foreign targets, not part of the loop)",
         "ms_per_launch": ms_bf.value, "bound": "mfma", "achieved": 32 * pairs / sec_bf / 1e12, "peak": BF16_DENSE_TFLOPS,
         "unit": "TFLOP/s (bf16 MFMA, dense)", "frac": 32 * pairs / sec_bf / 1e12 / BF16_DENSE_TFLOPS, "mfma_flop_per_pair": 32,
         "pairs_per_s": pairs / sec_bf, "mfma_busy_frac": None if not bf else bf.get("mfma_busy_frac"),
         "traffic": None if not bf else bf.get("hbm_bytes_per_launch"),
         "hbm": {"achieved": alg_bytes / sec_bf / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": alg_bytes / sec_bf / 1e9 / HBM_PEAK_GBS,
                 "on": "algorithmic bytes"}}
+    roofline["per_kernel"] = per_kernel_table(pk, nl, nc, args.lbs_nnz, pmc_src)
     out["roofline"] = roofline
 
     # north-star item: the full-mesh pose + shape blendshape GEMM (body-model operator / output meshes; the loop itself only
-    # needs the contact-vertex columns, whose two products are listed under in_loop)
+    # needs the contact-vertex columns, whose two products are listed under roofline.per_kernel)
     ms_g = ctypes.c_float(0)
     capi.check(lib.fdcap_time_blend_gemm(h, nl, 5, ctypes.byref(ms_g), capi.current_stream()), "fdcap_time_blend_gemm")
     gflop = 2.0 * nl * 496 * 3 * args.verts / 1e9         # operand rows [pose feature 486 | betas 10]
     split3 = os.environ.get("FDCAP_GEMM_SPLIT3", "1") != "0"
     tf = gflop / ms_g.value                                 # useful fp32 multiply-adds, TFLOP/s
-    wide = counter_fracs(pk.get("blend_wide")) if quoted else None
+    wide = counter_fracs(pk.get("blend_wide")) if cfg else None
+    if not wide and quoted:
+        old = os.path.join(ROOT, "profiles", "r4_pmc_summary.json")
+        if os.path.exists(old):
+            wide = counter_fracs(json.load(open(old)).get("kernels", {}).get("blend_wide"))
     if split3:
         ex = 6.0 * tf * 512.0 / 496.0                       # six bf16 MFMAs per product term, K padded 496 -> 512
         blend = {"kernel": "fdc::panel_gemm3_wide_kernel<2> (pose + shape blendshapes [F,496] x [496,3V]; fp32 operands as three bf16 parts, "
@@ -507,20 +675,10 @@ def main():
                            "in MFMA fragment order)",
                  "ms_per_launch": ms_g.value, "bound": "mfma", "achieved": tf, "peak": FP32_MFMA_TFLOPS, "unit": "TFLOP/s (fp32 MFMA)",
                  "frac": tf / FP32_MFMA_TFLOPS, "mfma_busy_frac": None if not wide else wide.get("mfma_busy_frac")}
-    if quoted and split3:
-        loop = {}
-        for key, flop in (("blend_fwd", 2.0 * nl * 512 * 1504), ("blend_bwd", 2.0 * nl * 1504 * 496)):
-            k = pk.get(key)
-            if k and k.get("duration_us_trace"):
-                c = counter_fracs(k) or {}
-                loop[key] = {"kernel": k.get("name"), "us_per_launch": k["duration_us_trace"],
-                             "frac": 6.0 * flop / (k["duration_us_trace"] * 1e-6) / 1e12 / BF16_DENSE_TFLOPS,
-                             "mfma_busy_frac": c.get("mfma_busy_frac"), "source": "kernel-trace average of the committed profile"}
-        blend["in_loop"] = dict(loop, note="the loop's two contact-set products ([F,496]x[496,1500] and its data gradient): launch- and "
-                                          "cold-start-bound at ~13 us each; frac = executed bf16 MFMA flops / dense bf16 peak")
     out["blendshape_gemm"] = blend
 
-    if rk.world == 1 and split3 and not args.no_exact_fp32:
+    single = rk.world == 1
+    if single and split3 and not args.no_exact_fp32:
         # the same step on exact fp32 MFMA chains: the switch is read once per process, so a child process runs it
         cmd = [sys.executable, os.path.abspath(__file__), "--steps", str(min(args.steps, 3)), "--warmup", "1", "--value-only",
                "--frames", str(N), "--scene", str(ns), "--iters", str(args.iters), "--verts", str(args.verts),
@@ -532,7 +690,18 @@ def main():
                                  "note": "FDCAP_GEMM_SPLIT3=0: every dense product as a v_mfma_f32 chain (child process, same workload)"}
         except Exception as e:  # noqa: BLE001 -- a secondary figure must not take the line down
             out["exact_fp32"] = {"value": None, "error": repr(e)[:200]}
-    if rk.world == 1 and not args.no_cpu_baseline:
+    if single and quoted and not args.no_other_configs:
+        # the other one-GPU configurations of BASELINE.json, measured here so that the driver's one line carries them
+        fop.close()
+        torch.cuda.empty_cache()
+        oc = {}
+        for name in ("c2", "c5"):
+            try:
+                oc[name] = other_config(name, args)
+            except Exception as e:  # noqa: BLE001 -- secondary figures must not take the line down
+                oc[name] = {"error": repr(e)[:300]}
+        out["other_configs"] = oc
+    if single and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(bm, vp, clip, scene, vid, args)
     rk.finish(out if rk.rank == 0 else None)
 

@@ -1,0 +1,40 @@
+"""TEST INFRASTRUCTURE: one rank of tests/test_gpu_multi.py, started by `python -m torch.distributed.run` (one process per GPU,
+RCCL).  Fits the shared test clip sharded over the ranks THROUGH THE LIBRARY'S OWN COMMUNICATOR (fdcap_comm_create /
+fdcap_opt_exchange -- asserted, not assumed) and writes this rank's rows to <outdir>/rank<r>.npz.
+usage: multi_gpu_worker.py <outdir> <mode> <frames> <iters>"""
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+
+def main(outdir, mode, frames, iters):
+    rank, world, local = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"]), int(os.environ["LOCAL_RANK"])
+    torch.cuda.set_device(local)
+    dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
+    try:
+        from fdcap_amd.fitting import FittingOP
+        from fdcap_amd.io import read_camerapose
+        from tests.test_gpu_sharded import _inputs
+        bm, vp, clip, scene, vid = _inputs(frames)
+        fop = FittingOP({"num_iter": iters}, {}, frames, body_model=bm, vposer=vp, scene_verts=scene, contact_ids=vid,
+                        camera_ext=read_camerapose(clip.camerapose_lines), group=dist.group.WORLD)
+        c_comm = bool(fop._c_comm)
+        body, scale, cam = fop.fitting(torch.tensor(clip.body_params).cuda(), mode, log_every=1)
+        tot = np.array(fop.log.total) if mode == "global" else np.array(fop.log2)[:, 5]
+        np.savez(os.path.join(outdir, f"rank{rank}.npz"), frame0=fop.shard.frame0, body=body.cpu().numpy(), scale=float(scale),
+                 cam=cam.cpu().numpy(), total=tot, c_comm=c_comm, world=dist.get_world_size(), device=torch.cuda.current_device())
+        fop.close()
+    finally:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main(sys.argv[1], sys.argv[2], int(sys.argv[3]), int(sys.argv[4]))

@@ -1,0 +1,88 @@
+"""The first real multi-GPU run as a TEST: ranks on DIFFERENT GPUs, one process each, started through
+`python -m torch.distributed.run` as the driver starts bench.py, exchanging through the library's RCCL communicator
+(fdcap_comm_create / fdcap_opt_exchange).  Skipped unless the box shows that many GPUs -- the one-GPU boxes of this pool run
+the one-rank form of the SAME worker (a one-rank RCCL group with the exchange forced on), so that the day two GPUs are visible
+the only new thing is the second rank.  The sharded arithmetic itself is covered on one GPU by tests/test_gpu_sharded.py (gloo)."""
+import json
+import os
+import socket
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+import fdcap_amd  # noqa: F401
+from fdcap_amd.dist import FrameShard
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+NGPU = torch.cuda.device_count()                 # (counting devices does not initialise the runtime)
+
+
+def _port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _launch(world, outdir, mode, frames, iters, extra_env=None):
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world), "--master-addr", "127.0.0.1",
+           "--master-port", str(_port()), os.path.join(ROOT, "tests", "multi_gpu_worker.py"), str(outdir), mode, str(frames), str(iters)]
+    env = dict(os.environ, OMP_NUM_THREADS="1", HSA_ENABLE_IPC_MODE_LEGACY="0", **(extra_env or {}))
+    p = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900)    # a CHILD process: nothing here is replaced
+    assert p.returncode == 0, (p.stdout[-1500:], p.stderr[-3000:])
+    return [np.load(os.path.join(outdir, f"rank{r}.npz")) for r in range(world)]
+
+
+def _single(mode, frames, iters):
+    from tests.test_gpu_sharded import _fit
+    return _fit(None, mode, frames, iters)
+
+
+def _compare(res, ref, frames, world):
+    assert [int(r["frame0"]) for r in res] == [FrameShard(frames, None, rank=i, world=world).frame0 for i in range(world)]
+    assert all(bool(r["c_comm"]) for r in res), "the ranks did not exchange through the library's communicator"
+    assert all(int(r["world"]) == world for r in res)
+    body = np.concatenate([r["body"] for r in res])
+    cam = np.concatenate([r["cam"] for r in res])
+    # identical per-frame arithmetic; only the order of the scale-gradient sum differs (tests/test_gpu_sharded.py's bar)
+    np.testing.assert_allclose(body, ref[1], rtol=0, atol=5e-6)
+    np.testing.assert_allclose(cam, ref[3], rtol=0, atol=5e-6)
+    for r in res:
+        assert abs(float(r["scale"]) - ref[2]) < 2e-6
+        np.testing.assert_allclose(r["total"], ref[4], rtol=2e-6)
+
+
+def test_one_rank_through_the_launcher_and_the_librarys_communicator(tmp_path):
+    """What runs on a one-GPU box: the same worker under the same launcher, one rank, the exchange tail forced on."""
+    res = _launch(1, tmp_path, "global", 22, 10, {"FDCAP_FORCE_EXCHANGE": "1"})
+    ref = _single("global", 22, 10)
+    assert bool(res[0]["c_comm"])
+    np.testing.assert_array_equal(res[0]["body"], ref[1])          # one rank: the same sums in the same order
+    assert float(res[0]["scale"]) == ref[2]
+
+
+@pytest.mark.skipif(NGPU < 2, reason="needs two GPUs: ranks of an RCCL communicator cannot share a device")
+@pytest.mark.parametrize("world,mode,frames", [(2, "global", 22), (2, "local", 22), (2, "global", 800)] + ([(4, "global", 801)] if NGPU >= 4 else []) +
+                         ([(8, "global", 1024)] if NGPU >= 8 else []))
+def test_ranks_on_separate_gpus_over_rccl_match_the_single_rank_run(tmp_path, world, mode, frames):
+    res = _launch(world, tmp_path, mode, frames, 10)
+    assert sorted(int(r["device"]) for r in res) == list(range(world))
+    _compare(res, _single(mode, frames, 10), frames, world)
+
+
+@pytest.mark.skipif(NGPU < 2, reason="needs two GPUs")
+@pytest.mark.parametrize("scaling", ["strong", "weak"])
+def test_bench_line_on_two_gpus(scaling):
+    """bench.py --gpus 2 as the driver launches it: one JSON line, n_gpus = the ranks RCCL saw, both arrangements."""
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "1", "--frames", "256", "--scene", "50000",
+           "--iters", "40", "--scaling", scaling, "--value-only"]
+    p = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0"))
+    assert p.returncode == 0, p.stderr[-3000:]
+    line = json.loads(p.stdout.strip().splitlines()[-1])
+    assert line["n_gpus"] == 2 and line["config"]["ranks_seen_by_rccl"] == 2 and line["scaling"] == scaling
+    assert line["value"] > 0
