@@ -64,6 +64,8 @@ SYMBOLS = {
                                      c_void_p, c_void_p, c_void_p, c_void_p]),
     "fdcap_chamfer_bwd": (c_int32, [c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_int32, c_int64, c_void_p,
                                      c_void_p, c_void_p, c_void_p]),
+    "fdcap_chamfer_fwd_scene": (c_int32, [c_void_p, c_void_p, c_int32, c_int32, c_void_p, c_void_p, c_int32, c_void_p]),
+    "fdcap_chamfer_bwd_scene": (c_int32, [c_void_p, c_void_p, c_int32, c_int32, c_void_p, c_void_p, c_void_p, c_void_p]),
     "fdcap_set_nn_kernel": (c_int32, [c_int32]),
     "fdcap_vposer_decode": (c_int32, [c_void_p, c_void_p, c_int32, c_int32, c_void_p, c_void_p, c_void_p]),
     "fdcap_vposer_decode_bwd": (c_int32, [c_void_p, c_void_p, c_int32, c_int32, c_void_p, c_void_p, c_void_p, c_void_p]),
@@ -253,6 +255,8 @@ class Context:
         s = _f32(np.asarray(scene_xyz).reshape(-1, 3))
         check(self.lib.fdcap_set_scene(self.handle, s.ctypes.data_as(c_void_p), s.shape[0]), "fdcap_set_scene")
         self.num_scene = s.shape[0]
+        self._scene_host = s                   # (ops.chamferDist recognises a target tensor that holds exactly these points)
+        self._scene_dev = None
 
     def set_contact_ids(self, vid):
         v = np.ascontiguousarray(vid, dtype=np.int64)

@@ -1511,6 +1511,15 @@ struct fdcap_ctx {
     DevBuf<float> ws_part;          // partial decoder outputs of the stand-alone operators
     DevBuf<int> ws_i[2];
     DevBuf<float4> ws_p;
+    // Op 1 against the registered scene (fdcap_chamfer_fwd_scene): the previous call's neighbours = the next call's seeds
+    struct SceneOp {
+        DevBuf<float> dist;
+        DevBuf<int> idx, hdr;
+        DevBuf<float4> seedpt, anchor;
+        DevBuf<unsigned short> ids;
+        int nq = 0;                 // queries of the call that left the state (0: none)
+        void release() { dist.release(); idx.release(); hdr.release(); seedpt.release(); anchor.release(); ids.release(); nq = 0; }
+    } sop;
     OptState* opt = nullptr;
     Comm comm;                      // fdcap_comm_create: RCCL communicator of the sharded optimiser
     DevBuf<float> xch_send, xch_all;
@@ -1986,7 +1995,7 @@ void fdcap_ctx_destroy(fdcap_ctx* c) {
     c->W1.release(); c->b1.release(); c->W2.release(); c->b2.release(); c->W3.release(); c->b3.release();
     for (auto& b : c->vp_pn) b.release();
     for (auto& b : c->vp_pn3) b.release();
-    c->full.release(); c->contact.release(); c->contact_vid.release(); c->contact_perm.release(); c->scene.release(); c->scene_sorted.release(); c->scene_bounds.release(); c->scene_sbounds.release(); c->scene_qbounds.release(); c->scene_inv.release(); c->scene_frags.release(); c->scene_centers.release();
+    c->full.release(); c->contact.release(); c->contact_vid.release(); c->contact_perm.release(); c->scene.release(); c->scene_sorted.release(); c->scene_bounds.release(); c->scene_sbounds.release(); c->scene_qbounds.release(); c->scene_inv.release(); c->scene_frags.release(); c->scene_centers.release(); c->sop.release();
     for (auto& b : c->ws_f) b.release();
     for (auto& b : c->ws_b) b.release();
     c->ws_part.release();
@@ -2001,6 +2010,7 @@ int fdcap_set_scene(fdcap_ctx* c, const float* xyz, int64_t ns) {
     if (!c || ns < 0 || (ns > 0 && !xyz) || ns > FDCAP_MAX_SCENE_POINTS) return FDCAP_E_ARG;
     // a live optimiser holds buffers sized for, and pruning state (seeds, kept work lists) valid for, the registered scene
     if (c->opt) return FDCAP_E_STATE;
+    c->sop.nq = 0;                                          // (the scene operator's seeds / kept lists were for the old scene)
     std::vector<float4> orig((size_t)ns), sorted((size_t)ns);
     for (int64_t i = 0; i < ns; ++i) {
         orig[i] = make_float4(xyz[3 * i], xyz[3 * i + 1], xyz[3 * i + 2], 0.f);
@@ -2175,13 +2185,13 @@ int fdcap_set_contact_ids(fdcap_ctx* c, const int64_t* vid, int32_t nc) {
 // ---- Op 1 ----------------------------------------------------------------------------------
 int fdcap_chamfer_fwd(fdcap_ctx* c, const float* xyz1, const float* xyz2, int32_t B, int32_t n, int32_t m,
                       int64_t stride2, float* dist1, int32_t* idx1, float* dist2, int32_t* idx2, void* stream) {
-    if (!c || !xyz1 || !xyz2 || !dist1 || !idx1 || B <= 0 || n <= 0 || m <= 0) return FDCAP_E_ARG;
-    if (dist2 && !idx2) return FDCAP_E_ARG;
+    if (!c || !xyz1 || !xyz2 || B <= 0 || n <= 0 || m <= 0) return FDCAP_E_ARG;
+    if ((dist1 && !idx1) || (dist2 && !idx2) || (!dist1 && !dist2)) return FDCAP_E_ARG;
     hipStream_t st = (hipStream_t)stream;
     const bool shared = (stride2 == 0);
     size_t big = (size_t)std::max(n, m);
     HIP_TRY(c->ws_p.ensure(shared ? (size_t)m + (dist2 ? big : 0) : big));
-    if (shared) {
+    if (shared && dist1) {
         hipLaunchKernelGGL(pack_points_kernel, dim3((m + 255) / 256), dim3(256), 0, st, xyz2, m, c->ws_p.p);
         int nq = B * n;
         int nsplit = nn_pick_nsplit(nq, m);
@@ -2193,7 +2203,7 @@ int fdcap_chamfer_fwd(fdcap_ctx* c, const float* xyz1, const float* xyz2, int32_
         const float* x1 = xyz1 + (size_t)b * n * 3;
         const float* x2 = xyz2 + (size_t)b * stride2;
         float4* pk = c->ws_p.p + (shared ? m : 0);
-        if (!shared) {
+        if (!shared && dist1) {
             hipLaunchKernelGGL(pack_points_kernel, dim3((m + 255) / 256), dim3(256), 0, st, x2, m, pk);
             int nsplit = nn_pick_nsplit(n, m);
             HIP_TRY(c->ws_f[0].ensure((size_t)nsplit * n));
@@ -2227,6 +2237,59 @@ int fdcap_chamfer_bwd(fdcap_ctx* c, const float* xyz1, const float* xyz2, int32_
                                gdist1 + (size_t)b * n, idx1 + (size_t)b * n, n, gxyz1 + (size_t)b * n * 3);
         }
     }
+    return (int)hipGetLastError();
+}
+
+
+// Op 1 against the REGISTERED scene.  The operator API's call site (:292-294) passes the same scene in every iteration of the
+// caller's loop; fdcap_chamfer_fwd has to treat it as a foreign point set (unsorted: every pair visited, nn_mfma_kernel).  A caller
+// that says "xyz2 is the scene I registered" gets the optimiser loop's search: the k-d-sorted scene with its cell boxes and
+// precomputed fragments, seeds from nn_seed_kernel in the first call and from the previous call's neighbours afterwards (while
+// B * n stays the same), kept work lists in between.  Results: the same (dist, lowest index among ties) bit for bit.
+int fdcap_chamfer_fwd_scene(fdcap_ctx* c, const float* xyz1, int32_t B, int32_t n, float* dist1, int32_t* idx1, int32_t forget,
+                            void* stream) {
+    if (!c || !xyz1 || !dist1 || !idx1 || B <= 0 || n <= 0 || (int64_t)B * n > 0x7fffffff) return FDCAP_E_ARG;
+    if (c->ns <= 0 || !c->scene_sorted.p) return FDCAP_E_STATE;
+    hipStream_t st = (hipStream_t)stream;
+    fdcap_ctx::SceneOp& so = c->sop;
+    const int nq = B * n;
+    const bool fresh = forget || so.nq != nq;
+    if (so.nq != nq) {
+        const size_t ng = ((size_t)nq + 31) / 32, ng4 = 4 * ng;
+        HIP_TRY(so.dist.ensure(nq)); HIP_TRY(so.idx.ensure(nq)); HIP_TRY(so.seedpt.ensure(nq));
+        HIP_TRY(so.ids.ensure(ng4 * NN_CACHE_CAP)); HIP_TRY(so.hdr.ensure(ng4 + 3 * ng)); HIP_TRY(so.anchor.ensure((size_t)4 * nq));
+    }
+    if (fresh) {
+        const size_t ng = ((size_t)nq + 31) / 32, ng4 = 4 * ng;
+        HIP_TRY(hipMemsetAsync(so.idx.p, 0xFF, (size_t)nq * sizeof(int), st));                 // -1: no seed
+        HIP_TRY(hipMemsetAsync(so.hdr.p, 0xFF, ng4 * sizeof(int), st));                        // -1: nothing kept
+        HIP_TRY(hipMemsetAsync(so.hdr.p + ng4, 0, 3 * ng * sizeof(int), st));
+        HIP_TRY(hipMemsetAsync(so.anchor.p, 0, (size_t)4 * nq * sizeof(float4), st));
+    }
+    so.nq = nq;
+    const NNTarget T = c->nn_target(true);
+    const int nsplit = nn_pick_nsplit(nq, (int)c->ns, true);
+    HIP_TRY(c->ws_f[0].ensure((size_t)nsplit * nq));
+    HIP_TRY(c->ws_i[0].ensure((size_t)nsplit * nq));
+    static float slack = -1.f;
+    if (slack < 0.f) { const char* e = getenv("FDCAP_NN_CACHE_SLACK"); slack = e ? (float)atof(e) : 0.03f; }
+    const NNCache cache{slack > 0.f ? so.ids.p : nullptr, slack > 0.f ? so.hdr.p : nullptr, so.anchor.p, slack};
+    bool pt_written = false;
+    HIP_TRY(nn_search(xyz1, nq, T, so.dist.p, so.idx.p, c->ws_f[0].p, c->ws_i[0].p, nsplit, st, so.idx.p, fresh, so.seedpt.p, &pt_written,
+                      &cache, nullptr));
+    if (!pt_written) so.nq = 0;                             // (a size the streaming search does not take: the next call re-seeds)
+    HIP_TRY(hipMemcpyAsync(dist1, so.dist.p, (size_t)nq * sizeof(float), hipMemcpyDeviceToDevice, st));
+    HIP_TRY(hipMemcpyAsync(idx1, so.idx.p, (size_t)nq * sizeof(int), hipMemcpyDeviceToDevice, st));
+    return (int)hipGetLastError();
+}
+
+// ... and its gradient wrt the queries: the scene points come from the library's own copy (no pack pass per call)
+int fdcap_chamfer_bwd_scene(fdcap_ctx* c, const float* xyz1, int32_t B, int32_t n, const float* gdist1, const int32_t* idx1, float* gxyz1,
+                            void* stream) {
+    if (!c || !xyz1 || !gdist1 || !idx1 || !gxyz1 || B <= 0 || n <= 0) return FDCAP_E_ARG;
+    if (c->ns <= 0 || !c->scene.p) return FDCAP_E_STATE;
+    const int nq = B * n;
+    hipLaunchKernelGGL(nn_grad_kernel, dim3((nq + 255) / 256), dim3(256), 0, (hipStream_t)stream, xyz1, c->scene.p, gdist1, idx1, nq, gxyz1);
     return (int)hipGetLastError();
 }
 

@@ -26,9 +26,24 @@ def _ctx_of(obj):
     return obj.ctx
 
 
+def _is_registered_scene(fctx, x2, memo):
+    """Does the [m,3] device tensor x2 hold exactly the points registered with fctx.set_scene?  Compared ON THE DEVICE once per
+    (storage, version) of the tensor -- the caller's loop passes the same tensor every iteration (:176, :293) -- and remembered in
+    `memo`; any in-place write to the tensor bumps its version and is looked at again."""
+    host = getattr(fctx, "_scene_host", None)
+    if host is None or tuple(x2.shape) != tuple(host.shape):
+        return False
+    key = (x2.data_ptr(), x2._version, x2.device)
+    if memo.get("key") != key:
+        if getattr(fctx, "_scene_dev", None) is None or fctx._scene_dev.device != x2.device:
+            fctx._scene_dev = torch.from_numpy(host).to(x2.device)
+        memo["key"], memo["same"] = key, bool(torch.equal(x2, fctx._scene_dev))
+    return memo["same"]
+
+
 class _ChamferFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, xyz1, xyz2, fctx, both):
+    def forward(ctx, xyz1, xyz2, fctx, both, memo):
         B, n, _ = xyz1.shape
         m = xyz2.shape[1]
         shared = xyz2.stride(0) == 0 or xyz2.shape[0] == 1
@@ -40,10 +55,16 @@ class _ChamferFn(torch.autograd.Function):
         i1 = torch.empty(B, n, device=dev, dtype=torch.int32)
         d2 = torch.zeros(B, m, device=dev) if both else None
         i2 = torch.zeros(B, m, device=dev, dtype=torch.int32) if both else None
-        capi.check(fctx.lib.fdcap_chamfer_fwd(fctx.handle, capi.dptr(x1), capi.dptr(x2), B, n, m, stride2,
-                                              capi.dptr(d1), capi.dptr(i1), capi.dptr(d2), capi.dptr(i2),
-                                              capi.current_stream()), "fdcap_chamfer_fwd")
-        ctx.fctx, ctx.shared, ctx.both = fctx, shared, both
+        # the shared target IS the registered scene: body -> scene through the optimiser loop's culled, seeded search (same bits)
+        scene = memo is not None and shared and _is_registered_scene(fctx, x2, memo)
+        if scene:
+            capi.check(fctx.lib.fdcap_chamfer_fwd_scene(fctx.handle, capi.dptr(x1), B, n, capi.dptr(d1), capi.dptr(i1), 0,
+                                                        capi.current_stream()), "fdcap_chamfer_fwd_scene")
+        if not scene or both:
+            capi.check(fctx.lib.fdcap_chamfer_fwd(fctx.handle, capi.dptr(x1), capi.dptr(x2), B, n, m, stride2,
+                                                  None if scene else capi.dptr(d1), None if scene else capi.dptr(i1),
+                                                  capi.dptr(d2), capi.dptr(i2), capi.current_stream()), "fdcap_chamfer_fwd")
+        ctx.fctx, ctx.shared, ctx.both, ctx.scene = fctx, shared, both, scene
         ctx.save_for_backward(x1, x2, i1, i2 if both else i1)
         ctx.mark_non_differentiable(i1)
         if both:
@@ -57,10 +78,14 @@ class _ChamferFn(torch.autograd.Function):
         m = x2.shape[-2]
         fctx = ctx.fctx
         gx1 = torch.empty_like(x1)
-        capi.check(fctx.lib.fdcap_chamfer_bwd(fctx.handle, capi.dptr(x1), capi.dptr(x2), B, n, m,
-                                              0 if ctx.shared else m * 3, capi.dptr(g1.contiguous()),
-                                              capi.dptr(i1), capi.dptr(gx1), capi.current_stream()),
-                   "fdcap_chamfer_bwd")
+        if ctx.scene:
+            capi.check(fctx.lib.fdcap_chamfer_bwd_scene(fctx.handle, capi.dptr(x1), B, n, capi.dptr(g1.contiguous()), capi.dptr(i1),
+                                                        capi.dptr(gx1), capi.current_stream()), "fdcap_chamfer_bwd_scene")
+        else:
+            capi.check(fctx.lib.fdcap_chamfer_bwd(fctx.handle, capi.dptr(x1), capi.dptr(x2), B, n, m,
+                                                  0 if ctx.shared else m * 3, capi.dptr(g1.contiguous()),
+                                                  capi.dptr(i1), capi.dptr(gx1), capi.current_stream()),
+                       "fdcap_chamfer_bwd")
         gx2 = None
         if ctx.needs_input_grad[1] or ctx.both:
             # cold compatibility path (the reference never differentiates through the scene):
@@ -73,7 +98,7 @@ class _ChamferFn(torch.autograd.Function):
                 u = 2.0 * g2.unsqueeze(-1) * (x2b - nb)
                 gx2 = gx2 + u
                 gx1 = gx1.scatter_add(1, i2.long().unsqueeze(-1).expand(-1, -1, 3), -u)
-        return gx1, gx2, None, None
+        return gx1, gx2, None, None, None
 
 
 class chamferDist(torch.nn.Module):
@@ -81,14 +106,19 @@ class chamferDist(torch.nn.Module):
     squared distances.  `both=False` skips the scene->body half the reference discards (dist2 is
     returned as zeros).  xyz2 may be an expand()ed [1,m,3] scene: it is then read once."""
 
-    def __init__(self, ctx, both: bool = True):
+    def __init__(self, ctx, both: bool = True, use_registered_scene: bool = True):
+        """use_registered_scene: when xyz2 is one shared point set that equals the scene registered on the context
+        (Context.set_scene), dist1 comes from the optimiser loop's culled, seeded search instead of the every-pair scan --
+        the same values and indices bit for bit, found ~two orders of magnitude faster at scene sizes.  False: always the
+        generic scan (what a foreign target gets)."""
         super().__init__()
         self.fctx = _ctx_of(ctx)
         self.both = both
         self.last_idx1 = None
+        self._memo = {} if use_registered_scene else None
 
     def forward(self, input1, input2):
-        d1, d2, i1 = _ChamferFn.apply(input1, input2, self.fctx, self.both)
+        d1, d2, i1 = _ChamferFn.apply(input1, input2, self.fctx, self.both, self._memo)
         self.last_idx1 = i1
         return d1, d2
 

@@ -108,6 +108,17 @@ int fdcap_set_contact_ids(fdcap_ctx* ctx, const int64_t* vid, int32_t nc);
 int fdcap_chamfer_fwd(fdcap_ctx* ctx, const float* xyz1_d, const float* xyz2_d, int32_t B,
                       int32_t n, int32_t m, int64_t stride2, float* dist1_d, int32_t* idx1_d,
                       float* dist2_d, int32_t* idx2_d, void* stream);
+/* The same operator when xyz2 IS the scene registered with fdcap_set_scene -- the call site :292-294 passes the one scene in every
+ * iteration of the caller's loop.  dist1_d / idx1_d [B,n] as fdcap_chamfer_fwd writes them, bit for bit (idx: original scene
+ * indices, lowest among ties), found by the optimiser loop's search instead of visiting every pair: k-d-sorted scene, cell boxes,
+ * seeds from the previous call's neighbours while B * n stays the same (first call / forget != 0: cheap fresh seeds), kept work
+ * lists.  Library-owned state, one per context: calls on one context are serialised by the caller as everywhere.  FDCAP_E_STATE
+ * without a registered scene.  fdcap_chamfer_bwd_scene: the matching gradient wrt the queries (fdcap_chamfer_bwd's formula, the
+ * scene points read from the library's copy).  fdcap_chamfer_fwd itself accepts dist1_d == NULL (only the reverse direction). */
+int fdcap_chamfer_fwd_scene(fdcap_ctx* ctx, const float* xyz1_d, int32_t B, int32_t n, float* dist1_d, int32_t* idx1_d, int32_t forget,
+                            void* stream);
+int fdcap_chamfer_bwd_scene(fdcap_ctx* ctx, const float* xyz1_d, int32_t B, int32_t n, const float* gdist1_d, const int32_t* idx1_d,
+                            float* gxyz1_d, void* stream);
 /* grad wrt the queries only (the scene needs none): gxyz1_d[b,i] = 2 g1[b,i] (x1[b,i]-x2[b,idx]) */
 int fdcap_chamfer_bwd(fdcap_ctx* ctx, const float* xyz1_d, const float* xyz2_d, int32_t B,
                       int32_t n, int32_t m, int64_t stride2, const float* gdist1_d,

@@ -197,3 +197,55 @@ def test_operators_accept_inputs_without_grad_and_propagate_none(small):
     with torch.no_grad():
         out2 = ops.BodyModel(ctx)(return_verts=False, body_pose=aa.view(4, -1))
     assert out2.vertices is None and not out2.joints.requires_grad
+
+
+@pytest.mark.parametrize("B,n,ns", [(64, 200, 120_000), (3, 17, 5000), (256, 500, 100_000)])
+def test_chamfer_operator_takes_the_culled_search_for_the_registered_scene(B, n, ns):
+    """VERDICT r4 (next 6): ops.chamferDist with the registered scene as xyz2 goes through the optimiser loop's search
+    (fdcap_chamfer_fwd_scene: k-d-sorted scene, cell boxes, the previous call's neighbours as seeds, kept work lists) -- and
+    returns what the every-pair scan of a foreign target returns, values and indices, bit for bit, call after call while the
+    queries move (millimetres, then a jump of 30 cm, then a change of shape); the gradient is the same as well."""
+    bm = synth.make_body_model(300, seed=0)
+    ctx = capi.Context(bm, synth.make_vposer(seed=1))
+    scene = synth.make_scene(ns, seed=9)
+    ctx.set_scene(scene)
+    s_dev = torch.tensor(scene, device="cuda")
+    s_batch = s_dev.unsqueeze(0).expand(B, -1, -1)                      # the reference's repeat(N,1,1) without the copies (:176)
+    fast, slow = ops.chamferDist(ctx, both=False), ops.chamferDist(ctx, both=False, use_registered_scene=False)
+    rng = np.random.default_rng(B)
+    base = scene[rng.integers(0, ns, size=(B, n))] + rng.normal(0, 0.02, size=(B, n, 3)).astype(np.float32)
+    x = torch.tensor(base, dtype=torch.float32, device="cuda")
+    for step, move in enumerate([0.0, 0.001, 0.002, 0.3, 0.001, 0.05]):
+        x = (x + move * torch.randn_like(x)).detach().requires_grad_(True)
+        xs = x.detach().clone().requires_grad_(True)
+        d_f, _ = fast(x, s_batch)
+        d_s, _ = slow(xs, s_batch)
+        assert torch.equal(d_f, d_s), (step, float((d_f - d_s).abs().max()))
+        assert torch.equal(fast.last_idx1, slow.last_idx1), step
+        w = torch.randn_like(d_f)
+        (d_f * w).sum().backward()
+        (d_s * w).sum().backward()
+        assert torch.equal(x.grad, xs.grad), step
+    # another shape: fresh seeds, same answers
+    x2 = x.detach()[: max(B // 2, 1), : n - 3].contiguous()
+    d_f, _ = fast(x2, s_batch[: x2.shape[0]])
+    d_s, _ = slow(x2, s_batch[: x2.shape[0]])
+    assert torch.equal(d_f, d_s) and torch.equal(fast.last_idx1, slow.last_idx1)
+    # a target that is NOT the registered scene (one point moved) is recognised and takes the generic path
+    other = s_dev.clone()
+    other[7] += 0.5
+    d_o, _ = fast(x2, other.unsqueeze(0).expand(x2.shape[0], -1, -1))
+    d_r, _ = slow(x2, other.unsqueeze(0).expand(x2.shape[0], -1, -1))
+    assert torch.equal(d_o, d_r)
+    # ... and an in-place edit of the recognised tensor is noticed (its version changed)
+    s_dev[11] += 0.25
+    d_e, _ = fast(x2, s_dev.unsqueeze(0).expand(x2.shape[0], -1, -1))
+    d_g, _ = slow(x2, s_dev.unsqueeze(0).expand(x2.shape[0], -1, -1))
+    assert torch.equal(d_e, d_g)
+    # without a registered scene the C entry point says so
+    ctx2 = capi.Context(bm, synth.make_vposer(seed=1))
+    d1 = torch.empty(2, 5, device="cuda"); i1 = torch.empty(2, 5, device="cuda", dtype=torch.int32)
+    rc = ctx2.lib.fdcap_chamfer_fwd_scene(ctx2.handle, capi.dptr(x2), 2, 5, capi.dptr(d1), capi.dptr(i1), 0, capi.current_stream())
+    assert rc == -2
+    ctx2.close()
+    ctx.close()
