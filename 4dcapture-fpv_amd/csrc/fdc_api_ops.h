@@ -1,0 +1,679 @@
+// C-ABI, part 1 (include/fdcap.h): context, scene and contact-set registration, the three operators (Chamfer, VPoser decode,
+// body model) with their backward passes, parameter conversions.  Part of csrc/fdcap.hip.
+#pragma once
+
+extern "C" {
+
+const char* fdcap_version(void) { return "fdcap-hip 0.3 (gfx950)"; }
+const char* fdcap_build_info(void) {
+#ifdef FDC_BUILD_NO_PK_F32
+    return "packed_fp32=off";
+#else
+    return "packed_fp32=on";
+#endif
+}
+
+#ifdef FDC_DEBUG_BUFFERS
+int fdcap_debug_stage_bad(unsigned* out) {
+    HIP_TRY(hipDeviceSynchronize());
+    HIP_TRY(hipMemcpyFromSymbol(out, HIP_SYMBOL(g_stage_bad), sizeof(unsigned) * 8 * 16));
+    return 0;
+}
+// instrumentation build only (tools/pk_where.py): row r0.. of an internal per-frame buffer, `per_row` floats per row
+// which: 0 O [126], 1 PF [NPFX], 2 A [55*12], 3 M [12], 4 Voff [3 nc], 5 Vw [3 nc], 6 G [55*12], 7 Opart q=0 [126], 8 H2 [512], 9 Jw [69], 10 Rm [55*9], 11 Jrest [55*3]
+int fdcap_debug_rows(fdcap_ctx* c, int which, float* dst, void* stream) {
+    if (!c || !c->opt) return FDCAP_E_STATE;
+    OptState* o = c->opt;
+    const int nl = o->cfg.n_local, nc = c->nc;
+    const float* src = nullptr; size_t w = 0;
+    switch (which) {
+        case 0: src = o->O.p; w = O_LD; break;       // (padded rows)
+        case 1: src = o->PF.p; w = NPFX; break;
+        case 2: src = o->A.p; w = NJ * 12; break;
+        case 3: src = o->M.p; w = 12; break;
+        case 4: src = o->Voff.p; w = (size_t)3 * nc; break;
+        case 5: src = o->Vw.p; w = (size_t)3 * nc; break;
+        case 6: src = o->G.p; w = NJ * 12; break;
+        case 7: src = o->Opart.p; w = ODIM; break;
+        case 8: src = o->H2.p; w = VP_H; break;
+        case 9: src = o->Jw.p; w = NJW * 3; break;
+        case 10: src = o->Rm.p; w = RM_LD; break;
+        case 11: src = o->Jrest.p; w = JR_LD; break;
+        default: return FDCAP_E_ARG;
+    }
+    HIP_TRY(hipMemcpyAsync(dst, src + 2 * w, (size_t)nl * w * sizeof(float), hipMemcpyDeviceToDevice, (hipStream_t)stream));
+    return (int)w;
+}
+#endif
+#ifdef FDC_NN_STATS
+int fdcap_debug_nn_hist(unsigned long long* out) {
+    HIP_TRY(hipDeviceSynchronize());
+    HIP_TRY(hipMemcpyFromSymbol(out, HIP_SYMBOL(g_nn_hist), 96 * sizeof(unsigned long long)));
+    unsigned long long z[96] = {0};
+    HIP_TRY(hipMemcpyToSymbol(HIP_SYMBOL(g_nn_hist), z, sizeof(z)));
+    return 0;
+}
+int fdcap_debug_nn_stats(unsigned long long* out) {
+    HIP_TRY(hipDeviceSynchronize());
+    HIP_TRY(hipMemcpyFromSymbol(out, HIP_SYMBOL(g_nn_stats), 8 * sizeof(unsigned long long)));
+    unsigned long long z[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    HIP_TRY(hipMemcpyToSymbol(HIP_SYMBOL(g_nn_stats), z, sizeof(z)));
+    return 0;
+}
+#endif
+
+#ifdef FDC_NN_TIMELINE
+int fdcap_debug_nn_timeline(unsigned long long* out, int n) {
+    HIP_TRY(hipDeviceSynchronize());
+    HIP_TRY(hipMemcpyFromSymbol(out, HIP_SYMBOL(g_nn_timeline), (size_t)n * sizeof(unsigned long long)));
+    return 0;
+}
+#endif
+#ifdef FDC_PN_TIMING
+int fdcap_debug_frame_times(unsigned long long* out) {
+    HIP_TRY(hipDeviceSynchronize());
+    HIP_TRY(hipMemcpyFromSymbol(out, HIP_SYMBOL(g_fr_times), sizeof(unsigned long long) * 3 * 2048 * 8));
+    return 0;
+}
+int fdcap_debug_panel_reset(void) {
+    HIP_TRY(hipDeviceSynchronize());
+    static std::vector<unsigned long long> z(8192 * 8, 0ull);
+    HIP_TRY(hipMemcpyToSymbol(HIP_SYMBOL(g_pn_times), z.data(), z.size() * sizeof(unsigned long long)));
+    return 0;
+}
+int fdcap_debug_panel_times(unsigned long long* out, int n) {
+    HIP_TRY(hipDeviceSynchronize());
+    HIP_TRY(hipMemcpyFromSymbol(out, HIP_SYMBOL(g_pn_times), (size_t)n * sizeof(unsigned long long)));
+    return 0;
+}
+#endif
+
+int fdcap_set_nn_kernel(int32_t mode) {
+    if (mode < 0 || mode > 2) return FDCAP_E_ARG;
+    nn_mode_ref() = mode;
+    return FDCAP_OK;
+}
+
+int fdcap_ctx_create(const fdcap_model_desc* md, fdcap_ctx** out) {
+    if (!md || !out || md->num_verts <= 0 || md->num_shape < NBETA) return FDCAP_E_ARG;
+    if (!md->v_template || !md->shapedirs || !md->posedirs || !md->J_regressor || !md->parents ||
+        !md->lbs_weights || !md->hands_componentsl || !md->hands_componentsr || !md->hands_meanl ||
+        !md->hands_meanr || !md->vp_fc1_w || !md->vp_fc1_b || !md->vp_fc2_w || !md->vp_fc2_b || !md->vp_out_w ||
+        !md->vp_out_b)
+        return FDCAP_E_ARG;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) return FDCAP_E_NODEVICE;
+    fdcap_ctx* c = new fdcap_ctx();
+    const int V = c->V = md->num_verts;
+    c->h_vt.assign(md->v_template, md->v_template + (size_t)V * 3);
+    c->h_S10.resize((size_t)V * 30);
+    for (size_t i = 0; i < (size_t)V * 3; ++i)
+        for (int l = 0; l < NBETA; ++l) c->h_S10[i * NBETA + l] = md->shapedirs[i * md->num_shape + l];
+    c->h_posedirs.assign(md->posedirs, md->posedirs + (size_t)NPF * 3 * V);
+    c->h_lbs.assign(md->lbs_weights, md->lbs_weights + (size_t)V * NJ);
+    HostPoseSetup hs;
+    if (!host_pose_setup(V, c->h_vt.data(), c->h_S10.data(), md->J_regressor, md->parents, &hs)) { delete c; return FDCAP_E_ARG; }
+    std::vector<float>&Jt = hs.Jt, &Jd = hs.Jd;
+    std::vector<int>&parents = hs.parents, &order = hs.order, &level_start = hs.level_start,
+                    &child_start = hs.child_start, &child_list = hs.child_list;
+    c->nlevels = hs.nlevels;
+    std::vector<float> hc(2 * 12 * 45), hm(90);
+    memcpy(hc.data(), md->hands_componentsl, 12 * 45 * sizeof(float));
+    memcpy(hc.data() + 12 * 45, md->hands_componentsr, 12 * 45 * sizeof(float));
+    memcpy(hm.data(), md->hands_meanl, 45 * sizeof(float));
+    memcpy(hm.data() + 45, md->hands_meanr, 45 * sizeof(float));
+    int err = 0;
+#define UP(buf, ptr, cnt) if (!err) { hipError_t e_ = (buf).upload(ptr, cnt); if (e_ != hipSuccess) err = (int)e_; }
+    UP(c->Jt, Jt.data(), Jt.size()) UP(c->Jd, Jd.data(), Jd.size())
+    UP(c->parents, parents.data(), parents.size()) UP(c->order, order.data(), order.size())
+    UP(c->level_start, level_start.data(), level_start.size())
+    UP(c->child_start, child_start.data(), child_start.size()) UP(c->child_list, child_list.data(), child_list.size())
+    UP(c->depth, hs.depth.data(), hs.depth.size())
+    UP(c->hand_comp, hc.data(), hc.size()) UP(c->hand_mean, hm.data(), hm.size())
+    {   // the same tables once more, laid out as PoseStage's static part
+        std::vector<float> img((size_t)PS_STATIC_FLOATS, 0.f);
+        auto put = [&](size_t off_bytes, const void* src, size_t n_words) { memcpy((char*)img.data() + off_bytes, src, n_words * 4); };
+        put(offsetof(PoseStage, Jd), Jd.data(), Jd.size());
+        put(offsetof(PoseStage, hand_comp), hc.data(), hc.size());
+        put(offsetof(PoseStage, Jt), Jt.data(), Jt.size());
+        put(offsetof(PoseStage, hand_mean), hm.data(), hm.size());
+        put(offsetof(PoseStage, parents), parents.data(), parents.size());
+        put(offsetof(PoseStage, order), order.data(), order.size());
+        put(offsetof(PoseStage, level_start), level_start.data(), std::min<size_t>(level_start.size(), MAX_LEVELS + 4));
+        put(offsetof(PoseStage, child_start), child_start.data(), child_start.size());
+        put(offsetof(PoseStage, child_list), child_list.data(), child_list.size());
+        put(offsetof(PoseStage, depth), hs.depth.data(), hs.depth.size());
+        UP(c->pose_tab, img.data(), img.size())
+    }
+    UP(c->W1, md->vp_fc1_w, 512 * 32) UP(c->b1, md->vp_fc1_b, 512)
+    UP(c->W2, md->vp_fc2_w, 512 * 512) UP(c->b2, md->vp_fc2_b, 512)
+    UP(c->W3, md->vp_out_w, ODIM * 512) UP(c->b3, md->vp_out_b, ODIM)
+#undef UP
+    if (!err) {
+        // decoder weights in MFMA fragment order.  torch Linear weights are [out, in]: forward y = x W^T -> B(k, n) = W[n][k];
+        // data gradient dx = dy W -> B(k, n) = W[k][n]
+        struct { const float* w; long sk, sn; int K, N; PanelB* dst; } pk[6] = {
+            {md->vp_fc1_w, 1, VP_Z, VP_Z, VP_H, &c->vp.w1}, {md->vp_fc2_w, 1, VP_H, VP_H, VP_H, &c->vp.w2},
+            {md->vp_out_w, 1, VP_H, VP_H, ODIM, &c->vp.w3}, {md->vp_out_w, VP_H, 1, ODIM, VP_H, &c->vp.w3t},
+            {md->vp_fc2_w, VP_H, 1, VP_H, VP_H, &c->vp.w2t}, {md->vp_fc1_w, VP_Z, 1, VP_H, VP_Z, &c->vp.w1t}};
+        std::vector<float> pf;
+        for (int i = 0; i < 6 && !err; ++i) {
+            int nt = 0, ns = 0;
+            panel_pack(pk[i].w, pk[i].sk, pk[i].sn, pk[i].K, pk[i].N, pf, &nt, &ns);
+            hipError_t e_ = c->vp_pn[i].upload(pf.data(), pf.size());
+            if (e_ != hipSuccess) err = (int)e_;
+            pk[i].dst->f = (const float4*)c->vp_pn[i].p; pk[i].dst->ntile = nt; pk[i].dst->nss = ns;
+        }
+        c->vp.b1 = c->b1.p; c->vp.b2 = c->b2.p; c->vp.b3 = c->b3.p;
+        PanelB3* dst3[6] = {&c->vp3.w1, &c->vp3.w2, &c->vp3.w3, &c->vp3.w3t, &c->vp3.w2t, &c->vp3.w1t};
+        std::vector<unsigned> p3;
+        for (int i = 0; i < 6 && !err; ++i) {
+            panel_pack3(pk[i].w, pk[i].sk, pk[i].sn, pk[i].K, pk[i].N, p3, &dst3[i]->ntile, &dst3[i]->nst);
+            hipError_t e_ = c->vp_pn3[i].upload(p3.data(), p3.size());
+            if (e_ != hipSuccess) err = (int)e_;
+            dst3[i]->f = (const uint4*)c->vp_pn3[i].p;
+        }
+        c->vp3.b1 = c->b1.p; c->vp3.b2 = c->b2.p; c->vp3.b3 = c->b3.p;
+    }
+    if (err) { fdcap_ctx_destroy(c); return err; }
+    *out = c;
+    return FDCAP_OK;
+}
+
+void fdcap_ctx_destroy(fdcap_ctx* c) {
+    if (!c) return;
+    fdcap_opt_destroy(c);
+    (void)fdcap_comm_destroy(c);
+    c->xch_send.release(); c->xch_all.release();
+    c->ws_adam.release();
+    c->Jt.release(); c->Jd.release(); c->hand_comp.release(); c->hand_mean.release();
+    c->parents.release(); c->order.release(); c->level_start.release(); c->child_start.release(); c->child_list.release(); c->depth.release();
+    c->pose_tab.release();
+    c->W1.release(); c->b1.release(); c->W2.release(); c->b2.release(); c->W3.release(); c->b3.release();
+    for (auto& b : c->vp_pn) b.release();
+    for (auto& b : c->vp_pn3) b.release();
+    c->full.release(); c->contact.release(); c->contact_vid.release(); c->contact_perm.release(); c->scene.release(); c->scene_sorted.release(); c->scene_bounds.release(); c->scene_sbounds.release(); c->scene_qbounds.release(); c->scene_inv.release(); c->scene_frags.release(); c->scene_centers.release(); c->sop.release();
+    for (auto& b : c->ws_f) b.release();
+    for (auto& b : c->ws_b) b.release();
+    c->ws_part.release();
+    for (auto& b : c->ws_i) b.release();
+    c->ws_p.release();
+    delete c;
+}
+
+int fdcap_set_scene(fdcap_ctx* c, const float* xyz, int64_t ns) {
+    // FDCAP_MAX_SCENE_POINTS: the in-loop NN launch streams the scene's MFMA fragments (32 B per point) through one buffer
+    // resource with 32-bit byte offsets; beyond 2 GiB of fragments its loads would silently return zeros
+    if (!c || ns < 0 || (ns > 0 && !xyz) || ns > FDCAP_MAX_SCENE_POINTS) return FDCAP_E_ARG;
+    // a live optimiser holds buffers sized for, and pruning state (seeds, kept work lists) valid for, the registered scene
+    if (c->opt) return FDCAP_E_STATE;
+    c->sop.nq = 0;                                          // (the scene operator's seeds / kept lists were for the old scene)
+    std::vector<float4> orig((size_t)ns), sorted((size_t)ns);
+    for (int64_t i = 0; i < ns; ++i) {
+        orig[i] = make_float4(xyz[3 * i], xyz[3 * i + 1], xyz[3 * i + 2], 0.f);
+        int ii = (int)i;
+        memcpy(&orig[i].w, &ii, 4);
+    }
+    // Spatial order by recursive median splits (k-d cells): every MF_CH-point chunk is one cell and every
+    // 32-point MFMA tile inside it a sub-cell, so the chunk boxes the NN scan culls with are compact and
+    // disjoint (runs of a Morton curve jump across quadrant borders and give long, overlapping boxes).
+    // A node of n points is cut at a multiple of the unit below it (chunks above MF_CH, tiles below), along
+    // its longest axis; ties by index, so the order is deterministic.  Results never depend on this order.
+    std::vector<int> order((size_t)ns), inv((size_t)ns);
+    for (int64_t i = 0; i < ns; ++i) order[i] = (int)i;
+    {
+        std::vector<std::pair<int64_t, int64_t>> stack;
+        if (ns > 0) stack.push_back({0, ns});
+        while (!stack.empty()) {
+            const int64_t a = stack.back().first, b = stack.back().second;
+            stack.pop_back();
+            const int64_t n = b - a;
+            if (n <= 32) continue;
+            const int64_t unit = n > MF_CH ? MF_CH : 32;
+            const int64_t units = (n + unit - 1) / unit;
+            const int64_t nleft = std::min(n - 1, (units / 2) * unit);
+            if (nleft <= 0) continue;
+            float blo[3] = {1e30f, 1e30f, 1e30f}, bhi[3] = {-1e30f, -1e30f, -1e30f};
+            for (int64_t p = a; p < b; ++p)
+                for (int k = 0; k < 3; ++k) { float v = xyz[3 * (int64_t)order[p] + k]; blo[k] = std::min(blo[k], v); bhi[k] = std::max(bhi[k], v); }
+            int ax = 0;
+            for (int k = 1; k < 3; ++k) if (bhi[k] - blo[k] > bhi[ax] - blo[ax]) ax = k;
+            std::nth_element(order.begin() + a, order.begin() + a + nleft, order.begin() + b, [&](int i, int j) {
+                const float vi = xyz[3 * (int64_t)i + ax], vj = xyz[3 * (int64_t)j + ax];
+                return vi < vj || (vi == vj && i < j);
+            });
+            stack.push_back({a, a + nleft});
+            stack.push_back({a + nleft, b});
+        }
+    }
+    for (int64_t p = 0; p < ns; ++p) { sorted[p] = orig[order[p]]; inv[order[p]] = (int)p; }
+    const int64_t nchunk = (ns + MF_CH - 1) / MF_CH;
+    std::vector<float4> bounds((size_t)nchunk * 2);           // axis-aligned box per chunk, slightly inflated
+    for (int64_t ch = 0; ch < nchunk; ++ch) {
+        int64_t a = ch * MF_CH, b = std::min<int64_t>(ns, a + MF_CH);
+        float blo[3] = {1e30f, 1e30f, 1e30f}, bhi[3] = {-1e30f, -1e30f, -1e30f};
+        for (int64_t p = a; p < b; ++p) {
+            const float v[3] = {sorted[p].x, sorted[p].y, sorted[p].z};
+            for (int k = 0; k < 3; ++k) { blo[k] = std::min(blo[k], v[k]); bhi[k] = std::max(bhi[k], v[k]); }
+        }
+        for (int k = 0; k < 3; ++k) {
+            float pad = 1e-6f + 1e-6f * std::max(fabsf(blo[k]), fabsf(bhi[k]));
+            blo[k] -= pad; bhi[k] += pad;
+        }
+        bounds[2 * ch] = make_float4(blo[0], blo[1], blo[2], 0.f);
+        bounds[2 * ch + 1] = make_float4(bhi[0], bhi[1], bhi[2], 0.f);
+    }
+    // boxes of the quarter chunks (the k-d recursion goes on below the chunk, so 128 consecutive points are one node);
+    // a quarter past the end of the scene gets the empty box (+inf, +inf): at infinite distance from every query (box_d2)
+    std::vector<float4> qbounds((size_t)nchunk * 8);
+    for (int64_t qc = 0; qc < nchunk * 4; ++qc) {
+        int64_t a = qc * (MF_CH / 4), b = std::min<int64_t>(ns, a + MF_CH / 4);
+        float blo[3] = {INFINITY, INFINITY, INFINITY}, bhi[3] = {-INFINITY, -INFINITY, -INFINITY};
+        for (int64_t p = a; p < b; ++p) {
+            const float v[3] = {sorted[p].x, sorted[p].y, sorted[p].z};
+            for (int k = 0; k < 3; ++k) { blo[k] = std::min(blo[k], v[k]); bhi[k] = std::max(bhi[k], v[k]); }
+        }
+        if (a < b)
+            for (int k = 0; k < 3; ++k) {
+                float pad = 1e-6f + 1e-6f * std::max(fabsf(blo[k]), fabsf(bhi[k]));
+                blo[k] -= pad; bhi[k] += pad;
+            }
+        else
+            for (int k = 0; k < 3; ++k) bhi[k] = INFINITY;
+        qbounds[2 * qc] = make_float4(blo[0], blo[1], blo[2], 0.f);
+        qbounds[2 * qc + 1] = make_float4(bhi[0], bhi[1], bhi[2], 0.f);
+    }
+    // chunk-centred bf16 hi/lo fragments in MFMA A layout (see nn_stream4_kernel)
+    auto bf = [](float f) -> uint32_t { uint32_t u; memcpy(&u, &f, 4); u += 0x7FFFu + ((u >> 16) & 1u); return u >> 16; };   // RNE
+    auto bff = [](uint32_t h) -> float { uint32_t u = h << 16; float f; memcpy(&f, &u, 4); return f; };
+    std::vector<uint4> frags((size_t)nchunk * (MF_CH / 32) * 64);
+    std::vector<float4> centers((size_t)nchunk);
+    for (int64_t ch = 0; ch < nchunk; ++ch) {
+        const float4 lo = bounds[2 * ch], hi = bounds[2 * ch + 1];
+        const float cx = 0.5f * (lo.x + hi.x), cy = 0.5f * (lo.y + hi.y), cz = 0.5f * (lo.z + hi.z);
+        float r2 = 0.f;
+        for (int j = 0; j < MF_CH; ++j) {
+            const int64_t p = ch * MF_CH + j;
+            float yx = 0.f, yy = 0.f, yz = 0.f, n2 = 1e30f;      // padding rows: score 1e30
+            if (p < ns) {
+                yx = sorted[p].x - cx; yy = sorted[p].y - cy; yz = sorted[p].z - cz;
+                n2 = yz * yz + (yy * yy + yx * yx);
+                r2 = std::max(r2, n2);
+            }
+            uint32_t hx = bf(yx), hy = bf(yy), hz = bf(yz);
+            uint32_t lx = bf(yx - bff(hx)), ly = bf(yy - bff(hy)), lz = bf(yz - bff(hz));
+            // the score's factor -2 (|y|^2 - 2 x.y) rides on the static side: exact in bf16, and the per-chunk query
+            // fragment is the plain hi | lo split
+            hx = bf(-2.f * bff(hx)); hy = bf(-2.f * bff(hy)); hz = bf(-2.f * bff(hz));
+            lx = bf(-2.f * bff(lx)); ly = bf(-2.f * bff(ly)); lz = bf(-2.f * bff(lz));
+            const uint32_t nh = bf(n2);
+            const float r1 = n2 - bff(nh);
+            const uint32_t nm = bf(r1), nl = bf(r1 - bff(nm));
+            const int tile = j >> 5, pt = j & 31;
+            uint4* t = frags.data() + ((size_t)ch * (MF_CH / 32) + tile) * 64;
+            t[pt] = make_uint4(hx | (hx << 16), lx | (lx << 16), hy | (hy << 16), ly | (ly << 16));
+            t[32 + pt] = make_uint4(hz | (hz << 16), lz | (lz << 16), nh | (nm << 16), nl);
+        }
+        centers[ch] = make_float4(cx, cy, cz, sqrtf(r2) * 1.00001f + 1e-6f);
+    }
+    HIP_TRY(c->scene_frags.upload(frags.data(), frags.size()));
+    HIP_TRY(c->scene_centers.upload(centers.data(), centers.size()));
+    HIP_TRY(c->scene.upload(orig.data(), orig.size()));
+    HIP_TRY(c->scene_sorted.upload(sorted.data(), sorted.size()));
+    HIP_TRY(c->scene_bounds.upload(bounds.data(), bounds.size()));
+    {
+        const int64_t nsuper = (nchunk + ST4_SUPER - 1) / ST4_SUPER;
+        std::vector<float4> sb((size_t)std::max<int64_t>(nsuper, 1) * 2, make_float4(0.f, 0.f, 0.f, 0.f));
+        for (int64_t su = 0; su < nsuper; ++su) {
+            float4 lo = make_float4(1e30f, 1e30f, 1e30f, 0.f), hi = make_float4(-1e30f, -1e30f, -1e30f, 0.f);
+            for (int64_t ch = su * ST4_SUPER; ch < std::min(nchunk, (su + 1) * ST4_SUPER); ++ch) {
+                lo.x = std::min(lo.x, bounds[2 * ch].x); lo.y = std::min(lo.y, bounds[2 * ch].y); lo.z = std::min(lo.z, bounds[2 * ch].z);
+                hi.x = std::max(hi.x, bounds[2 * ch + 1].x); hi.y = std::max(hi.y, bounds[2 * ch + 1].y); hi.z = std::max(hi.z, bounds[2 * ch + 1].z);
+            }
+            sb[2 * su] = lo; sb[2 * su + 1] = hi;
+        }
+        HIP_TRY(c->scene_sbounds.upload(sb.data(), sb.size()));
+        HIP_TRY(c->scene_qbounds.upload(qbounds.data(), qbounds.size()));
+    }
+    HIP_TRY(c->scene_inv.upload(inv.data(), inv.size()));
+    c->ns = ns;
+    return FDCAP_OK;
+}
+
+int fdcap_set_contact_ids(fdcap_ctx* c, const int64_t* vid, int32_t nc) {
+    if (!c || nc < 0 || (nc > 0 && !vid)) return FDCAP_E_ARG;
+    if (c->opt) return FDCAP_E_STATE;                  // (see fdcap_set_scene)
+    for (int i = 0; i < nc; ++i) if (vid[i] < 0 || vid[i] >= c->V) return FDCAP_E_ARG;
+    // Internal slot order = Morton order of the template positions: the 256 consecutive queries of an NN
+    // workgroup are then spatially compact, so far fewer scene chunks survive its bound test (with all
+    // 10 475 vertices as contacts a workgroup would otherwise span the whole body).  The loss is a mean
+    // over the contact set, so the order is free; outputs go back in the caller's order via contact_perm.
+    float lo[3] = {1e30f, 1e30f, 1e30f}, hi[3] = {-1e30f, -1e30f, -1e30f};
+    for (int i = 0; i < nc; ++i)
+        for (int k = 0; k < 3; ++k) {
+            float v = c->h_vt[3 * vid[i] + k];
+            lo[k] = std::min(lo[k], v); hi[k] = std::max(hi[k], v);
+        }
+    auto spread = [](uint32_t v) { v &= 1023; v = (v | (v << 16)) & 0x030000FF; v = (v | (v << 8)) & 0x0300F00F;
+                                   v = (v | (v << 4)) & 0x030C30C3; v = (v | (v << 2)) & 0x09249249; return v; };
+    std::vector<std::pair<uint32_t, int>> key((size_t)nc);
+    for (int i = 0; i < nc; ++i) {
+        uint32_t code = 0;
+        for (int k = 0; k < 3; ++k) {
+            float ext = hi[k] - lo[k];
+            float u = ext > 0.f ? (c->h_vt[3 * vid[i] + k] - lo[k]) / ext : 0.f;
+            code |= spread((uint32_t)std::min(1023.f, std::max(0.f, u * 1023.f))) << k;
+        }
+        key[i] = {code, i};
+    }
+    std::sort(key.begin(), key.end());
+    std::vector<int64_t> ids((size_t)nc);
+    std::vector<int> perm((size_t)std::max(nc, 1), 0), v32((size_t)std::max(nc, 1), 0);
+    for (int sl = 0; sl < nc; ++sl) { ids[sl] = vid[key[sl].second]; perm[sl] = key[sl].second; }
+    for (int i = 0; i < nc; ++i) v32[i] = (int)vid[i];
+    int e = build_skin_set(c, ids, &c->contact);
+    if (e) return e;
+    HIP_TRY(c->contact_vid.upload(v32.data(), v32.size()));
+    HIP_TRY(c->contact_perm.upload(perm.data(), perm.size()));
+    c->nc = nc;
+    return FDCAP_OK;
+}
+
+// ---- Op 1 ----------------------------------------------------------------------------------
+int fdcap_chamfer_fwd(fdcap_ctx* c, const float* xyz1, const float* xyz2, int32_t B, int32_t n, int32_t m,
+                      int64_t stride2, float* dist1, int32_t* idx1, float* dist2, int32_t* idx2, void* stream) {
+    if (!c || !xyz1 || !xyz2 || B <= 0 || n <= 0 || m <= 0) return FDCAP_E_ARG;
+    if ((dist1 && !idx1) || (dist2 && !idx2) || (!dist1 && !dist2)) return FDCAP_E_ARG;
+    hipStream_t st = (hipStream_t)stream;
+    const bool shared = (stride2 == 0);
+    size_t big = (size_t)std::max(n, m);
+    HIP_TRY(c->ws_p.ensure(shared ? (size_t)m + (dist2 ? big : 0) : big));
+    if (shared && dist1) {
+        hipLaunchKernelGGL(pack_points_kernel, dim3((m + 255) / 256), dim3(256), 0, st, xyz2, m, c->ws_p.p);
+        int nq = B * n;
+        int nsplit = nn_pick_nsplit(nq, m);
+        HIP_TRY(c->ws_f[0].ensure((size_t)nsplit * nq));
+        HIP_TRY(c->ws_i[0].ensure((size_t)nsplit * nq));
+        { NNTarget T{c->ws_p.p, m, nullptr, nullptr, nullptr, nullptr, nullptr}; HIP_TRY(nn_search(xyz1, nq, T, dist1, idx1, c->ws_f[0].p, c->ws_i[0].p, nsplit, st)); }
+    }
+    for (int b = 0; b < B && (!shared || dist2); ++b) {
+        const float* x1 = xyz1 + (size_t)b * n * 3;
+        const float* x2 = xyz2 + (size_t)b * stride2;
+        float4* pk = c->ws_p.p + (shared ? m : 0);
+        if (!shared && dist1) {
+            hipLaunchKernelGGL(pack_points_kernel, dim3((m + 255) / 256), dim3(256), 0, st, x2, m, pk);
+            int nsplit = nn_pick_nsplit(n, m);
+            HIP_TRY(c->ws_f[0].ensure((size_t)nsplit * n));
+            HIP_TRY(c->ws_i[0].ensure((size_t)nsplit * n));
+            { NNTarget T{pk, m, nullptr, nullptr, nullptr, nullptr, nullptr}; HIP_TRY(nn_search(x1, n, T, dist1 + (size_t)b * n, idx1 + (size_t)b * n, c->ws_f[0].p, c->ws_i[0].p, nsplit, st)); }
+        }
+        if (dist2) {
+            hipLaunchKernelGGL(pack_points_kernel, dim3((n + 255) / 256), dim3(256), 0, st, x1, n, pk);
+            int nsplit = nn_pick_nsplit(m, n);
+            HIP_TRY(c->ws_f[1].ensure((size_t)nsplit * m));
+            HIP_TRY(c->ws_i[1].ensure((size_t)nsplit * m));
+            { NNTarget T{pk, n, nullptr, nullptr, nullptr, nullptr, nullptr}; HIP_TRY(nn_search(x2, m, T, dist2 + (size_t)b * m, idx2 + (size_t)b * m, c->ws_f[1].p, c->ws_i[1].p, nsplit, st)); }
+        }
+    }
+    return (int)hipGetLastError();
+}
+
+int fdcap_chamfer_bwd(fdcap_ctx* c, const float* xyz1, const float* xyz2, int32_t B, int32_t n, int32_t m,
+                      int64_t stride2, const float* gdist1, const int32_t* idx1, float* gxyz1, void* stream) {
+    if (!c || !xyz1 || !xyz2 || !gdist1 || !idx1 || !gxyz1 || B <= 0 || n <= 0 || m <= 0) return FDCAP_E_ARG;
+    hipStream_t st = (hipStream_t)stream;
+    HIP_TRY(c->ws_p.ensure(m));
+    if (stride2 == 0) {
+        hipLaunchKernelGGL(pack_points_kernel, dim3((m + 255) / 256), dim3(256), 0, st, xyz2, m, c->ws_p.p);
+        int nq = B * n;
+        hipLaunchKernelGGL(nn_grad_kernel, dim3((nq + 255) / 256), dim3(256), 0, st, xyz1, c->ws_p.p, gdist1, idx1, nq, gxyz1);
+    } else {
+        for (int b = 0; b < B; ++b) {
+            hipLaunchKernelGGL(pack_points_kernel, dim3((m + 255) / 256), dim3(256), 0, st, xyz2 + (size_t)b * stride2, m, c->ws_p.p);
+            hipLaunchKernelGGL(nn_grad_kernel, dim3((n + 255) / 256), dim3(256), 0, st, xyz1 + (size_t)b * n * 3, c->ws_p.p,
+                               gdist1 + (size_t)b * n, idx1 + (size_t)b * n, n, gxyz1 + (size_t)b * n * 3);
+        }
+    }
+    return (int)hipGetLastError();
+}
+
+
+// Op 1 against the REGISTERED scene.  The operator API's call site (:292-294) passes the same scene in every iteration of the
+// caller's loop; fdcap_chamfer_fwd has to treat it as a foreign point set (unsorted: every pair visited, nn_mfma_kernel).  A caller
+// that says "xyz2 is the scene I registered" gets the optimiser loop's search: the k-d-sorted scene with its cell boxes and
+// precomputed fragments, seeds from nn_seed_kernel in the first call and from the previous call's neighbours afterwards (while
+// B * n stays the same), kept work lists in between.  Results: the same (dist, lowest index among ties) bit for bit.
+int fdcap_chamfer_fwd_scene(fdcap_ctx* c, const float* xyz1, int32_t B, int32_t n, float* dist1, int32_t* idx1, int32_t forget,
+                            void* stream) {
+    if (!c || !xyz1 || !dist1 || !idx1 || B <= 0 || n <= 0 || (int64_t)B * n > 0x7fffffff) return FDCAP_E_ARG;
+    if (c->ns <= 0 || !c->scene_sorted.p) return FDCAP_E_STATE;
+    hipStream_t st = (hipStream_t)stream;
+    fdcap_ctx::SceneOp& so = c->sop;
+    const int nq = B * n;
+    const bool fresh = forget || so.nq != nq;
+    if (so.nq != nq) {
+        const size_t ng = ((size_t)nq + 31) / 32, ng4 = 4 * ng;
+        HIP_TRY(so.dist.ensure(nq)); HIP_TRY(so.idx.ensure(nq)); HIP_TRY(so.seedpt.ensure(nq));
+        HIP_TRY(so.ids.ensure(ng4 * NN_CACHE_CAP)); HIP_TRY(so.hdr.ensure(ng4 + 3 * ng)); HIP_TRY(so.anchor.ensure((size_t)4 * nq));
+    }
+    if (fresh) {
+        const size_t ng = ((size_t)nq + 31) / 32, ng4 = 4 * ng;
+        HIP_TRY(hipMemsetAsync(so.idx.p, 0xFF, (size_t)nq * sizeof(int), st));                 // -1: no seed
+        HIP_TRY(hipMemsetAsync(so.hdr.p, 0xFF, ng4 * sizeof(int), st));                        // -1: nothing kept
+        HIP_TRY(hipMemsetAsync(so.hdr.p + ng4, 0, 3 * ng * sizeof(int), st));
+        HIP_TRY(hipMemsetAsync(so.anchor.p, 0, (size_t)4 * nq * sizeof(float4), st));
+    }
+    so.nq = nq;
+    const NNTarget T = c->nn_target(true);
+    const int nsplit = nn_pick_nsplit(nq, (int)c->ns, true);
+    HIP_TRY(c->ws_f[0].ensure((size_t)nsplit * nq));
+    HIP_TRY(c->ws_i[0].ensure((size_t)nsplit * nq));
+    static float slack = -1.f;
+    if (slack < 0.f) { const char* e = getenv("FDCAP_NN_CACHE_SLACK"); slack = e ? (float)atof(e) : 0.03f; }
+    const NNCache cache{slack > 0.f ? so.ids.p : nullptr, slack > 0.f ? so.hdr.p : nullptr, so.anchor.p, slack};
+    bool pt_written = false;
+    HIP_TRY(nn_search(xyz1, nq, T, so.dist.p, so.idx.p, c->ws_f[0].p, c->ws_i[0].p, nsplit, st, so.idx.p, fresh, so.seedpt.p, &pt_written,
+                      &cache, nullptr));
+    if (!pt_written) so.nq = 0;                             // (a size the streaming search does not take: the next call re-seeds)
+    HIP_TRY(hipMemcpyAsync(dist1, so.dist.p, (size_t)nq * sizeof(float), hipMemcpyDeviceToDevice, st));
+    HIP_TRY(hipMemcpyAsync(idx1, so.idx.p, (size_t)nq * sizeof(int), hipMemcpyDeviceToDevice, st));
+    return (int)hipGetLastError();
+}
+
+// ... and its gradient wrt the queries: the scene points come from the library's own copy (no pack pass per call)
+int fdcap_chamfer_bwd_scene(fdcap_ctx* c, const float* xyz1, int32_t B, int32_t n, const float* gdist1, const int32_t* idx1, float* gxyz1,
+                            void* stream) {
+    if (!c || !xyz1 || !gdist1 || !idx1 || !gxyz1 || B <= 0 || n <= 0) return FDCAP_E_ARG;
+    if (c->ns <= 0 || !c->scene.p) return FDCAP_E_STATE;
+    const int nq = B * n;
+    hipLaunchKernelGGL(nn_grad_kernel, dim3((nq + 255) / 256), dim3(256), 0, (hipStream_t)stream, xyz1, c->scene.p, gdist1, idx1, nq, gxyz1);
+    return (int)hipGetLastError();
+}
+
+// ---- Op 3 ----------------------------------------------------------------------------------
+int fdcap_vposer_decode(fdcap_ctx* c, const float* z, int32_t ldz, int32_t B, float* rot, float* aa, void* stream) {
+    if (!c || !z || B <= 0 || ldz < 32 || (!rot && !aa)) return FDCAP_E_ARG;
+    hipStream_t st = (hipStream_t)stream;
+    HIP_TRY(c->ws_f[2].ensure((size_t)B * 512));
+    HIP_TRY(c->ws_f[3].ensure((size_t)B * 512));
+    HIP_TRY(c->ws_f[4].ensure((size_t)B * ODIM));
+    HIP_TRY(c->ws_part.ensure((size_t)4 * B * ODIM));
+    int e = vposer_forward(c, z, ldz, 0, 0, B, c->ws_f[2].p, c->ws_f[3].p, c->ws_part.p, (size_t)B * ODIM, c->ws_f[4].p, st);
+    if (e) return e;
+    int n = B * 21;
+    hipLaunchKernelGGL(sixd_to_rot_kernel, dim3((n + 255) / 256), dim3(256), 0, st, c->ws_f[4].p, n, rot, aa);
+    return (int)hipGetLastError();
+}
+
+int fdcap_vposer_decode_bwd(fdcap_ctx* c, const float* z, int32_t ldz, int32_t B, const float* g_rot, const float* g_aa, float* g_z,
+                            void* stream) {
+    if (!c || !z || !g_z || B <= 0 || ldz < 32 || (!g_rot && !g_aa)) return FDCAP_E_ARG;
+    hipStream_t st = (hipStream_t)stream;
+    DevBuf<float>* w = c->ws_b;
+    HIP_TRY(w[0].ensure((size_t)B * 512)); HIP_TRY(w[1].ensure((size_t)B * 512)); HIP_TRY(w[2].ensure((size_t)B * ODIM));
+    HIP_TRY(w[3].ensure((size_t)B * ODIM)); HIP_TRY(w[4].ensure((size_t)4 * B * VP_Z));
+    HIP_TRY(c->ws_part.ensure((size_t)4 * B * ODIM));
+    // recompute the forward's activations (the operator keeps no state between calls), then the data-gradient chain
+    int e = vposer_forward(c, z, ldz, 0, 0, B, w[0].p, w[1].p, c->ws_part.p, (size_t)B * ODIM, w[2].p, st);
+    if (e) return e;
+    const int n = B * 21;
+    hipLaunchKernelGGL(vposer_out_bwd_kernel, dim3((n + 255) / 256), dim3(256), 0, st, w[2].p, n, g_rot, g_aa, w[3].p);
+    const size_t ps = (size_t)B * VP_Z;
+    if (gemm_split3_enabled())
+        hipLaunchKernelGGL(vposer_bwd_split3_kernel, dim3(4 * ((B + 15) / 16)), dim3(512), 0, st, c->vp3, w[3].p, 0, B, w[0].p, w[1].p, w[4].p, ps, ScaleTail());
+    else
+        hipLaunchKernelGGL(vposer_bwd_fused_kernel, dim3(4 * ((B + 15) / 16)), dim3(512), 0, st, c->vp, w[3].p, 0, B, w[0].p, w[1].p, w[4].p, ps, ScaleTail());
+    hipLaunchKernelGGL(vposer_fold_dz_rows_kernel, dim3((B * VP_Z + 255) / 256), dim3(256), 0, st, w[4].p, ps, B, g_z);
+    return (int)hipGetLastError();
+}
+
+// ---- parameter conversions -------------------------------------------------------------------
+int fdcap_params_75_to_78(const float* p75, int32_t B, float* x78, void* stream) {
+    if (!p75 || !x78 || B <= 0) return FDCAP_E_ARG;
+    hipLaunchKernelGGL(p75_to_78_kernel, dim3((B + 127) / 128), dim3(128), 0, (hipStream_t)stream, p75, B, x78);
+    return (int)hipGetLastError();
+}
+int fdcap_params_78_to_75(const float* x78, int32_t B, float* p75, void* stream) {
+    if (!p75 || !x78 || B <= 0) return FDCAP_E_ARG;
+    hipLaunchKernelGGL(p78_to_75_kernel, dim3((B + 127) / 128), dim3(128), 0, (hipStream_t)stream, x78, B, p75);
+    return (int)hipGetLastError();
+}
+
+// ---- Op 2 ----------------------------------------------------------------------------------
+// shared by fdcap_body_forward (body frame) and fdcap_world_mesh (scale + camera_ext @ T(cam_t * scale))
+static int body_forward_impl(fdcap_ctx* c, const float* params, int32_t B, const float* cam_ext, const float* scale,
+                             float* vertices, float* joints, hipStream_t st) {
+    if (vertices && !c->full_ready) {
+        std::vector<int64_t> all(c->V);
+        for (int i = 0; i < c->V; ++i) all[i] = i;
+        int e = build_skin_set(c, all, &c->full);
+        if (e) return e;
+        c->full_ready = true;
+    }
+    const int V = c->V;
+    const bool world = cam_ext != nullptr && scale != nullptr;
+    DevBuf<float>* w = c->ws_f;
+    HIP_TRY(w[2].ensure((size_t)B * 512)); HIP_TRY(w[3].ensure((size_t)B * 512)); HIP_TRY(w[4].ensure((size_t)B * ODIM));
+    HIP_TRY(w[5].ensure((size_t)B * XDIM)); HIP_TRY(w[6].ensure((size_t)B * NPFX)); HIP_TRY(w[7].ensure((size_t)B * NJ * 12));
+    HIP_TRY(w[8].ensure((size_t)B * NJ * 12)); HIP_TRY(w[9].ensure((size_t)B * 16)); HIP_TRY(w[10].ensure(1));
+    HIP_TRY(w[1].ensure((size_t)B * 12));
+    float* X = w[5].p;
+    hipLaunchKernelGGL(p75_to_78_kernel, dim3((B + 127) / 128), dim3(128), 0, st, params, B, X);
+    HIP_TRY(c->ws_part.ensure((size_t)4 * B * ODIM));
+    int e = vposer_forward(c, X, XDIM, X_LATENT, 0, B, w[2].p, w[3].p, c->ws_part.p, (size_t)B * ODIM, w[4].p, st);
+    if (e) return e;
+    if (!world) {
+        HIP_TRY(hipMemsetAsync(w[9].p, 0, (size_t)B * 16 * sizeof(float), st));
+        HIP_TRY(hipMemsetAsync(w[10].p, 0, sizeof(float), st));
+    }
+    const float* CAM = world ? cam_ext : w[9].p;
+    const float* S = world ? scale : w[10].p;
+    hipLaunchKernelGGL(pose_fwd_kernel<false>, dim3(B), dim3(64 * POSE_NW), 0, st, c->pose_model(), X, w[4].p, CAM, S, 0,
+                       (float*)nullptr, w[6].p, (float*)nullptr, w[7].p, w[8].p, w[1].p, (float*)nullptr, (const float*)nullptr,
+                       (const float*)nullptr, (size_t)0);
+    if (joints) hipLaunchKernelGGL(joints_out_kernel, dim3((B * NJ + 255) / 256), dim3(256), 0, st, w[7].p, X, XDIM, B, joints);
+    if (vertices) {
+        HIP_TRY(w[11].ensure((size_t)B * 3 * V));
+        HIP_TRY(blend_forward(c->full, w[6].p, B, w[11].p, st));
+        hipLaunchKernelGGL(skin_fwd_kernel, dim3((V + 255) / 256, B), dim3(256), 0, st, c->full.model(), V, X, XDIM, X_BETAS,
+                           X_TRANSL, w[11].p, w[8].p, (const float*)w[1].p, S, 0, world ? 1 : 0, vertices);
+    }
+    return (int)hipGetLastError();
+}
+
+int fdcap_body_forward(fdcap_ctx* c, const float* params, int32_t B, float* vertices, float* joints, void* stream) {
+    if (!c || !params || B <= 0 || (!vertices && !joints)) return FDCAP_E_ARG;
+    return body_forward_impl(c, params, B, nullptr, nullptr, vertices, joints, (hipStream_t)stream);
+}
+
+int fdcap_world_mesh(fdcap_ctx* c, const float* params, int32_t B, const float* cam_ext, const float* scale, float* vertices,
+                     void* stream) {
+    if (!c || !params || B <= 0 || !cam_ext || !scale || !vertices) return FDCAP_E_ARG;
+    return body_forward_impl(c, params, B, cam_ext, scale, vertices, nullptr, (hipStream_t)stream);
+}
+
+int fdcap_smplx_forward(fdcap_ctx* c, const float* go, const float* bp, const float* betas, const float* lh, const float* rh,
+                        const float* transl, int32_t B, float* vertices, float* joints, void* stream) {
+    if (!c || !go || !bp || !betas || !lh || !rh || !transl || B <= 0 || (!vertices && !joints)) return FDCAP_E_ARG;
+    hipStream_t st = (hipStream_t)stream;
+    if (vertices && !c->full_ready) {
+        std::vector<int64_t> all(c->V);
+        for (int i = 0; i < c->V; ++i) all[i] = i;
+        int e = build_skin_set(c, all, &c->full);
+        if (e) return e;
+        c->full_ready = true;
+    }
+    const int V = c->V;
+    DevBuf<float>* w = c->ws_f;
+    HIP_TRY(w[4].ensure((size_t)B * 66));
+    HIP_TRY(w[5].ensure((size_t)B * XDIM)); HIP_TRY(w[6].ensure((size_t)B * NPFX)); HIP_TRY(w[7].ensure((size_t)B * NJ * 12));
+    HIP_TRY(w[8].ensure((size_t)B * NJ * 12)); HIP_TRY(w[9].ensure((size_t)B * 16)); HIP_TRY(w[10].ensure(1));
+    float* X = w[5].p;
+    hipLaunchKernelGGL(assemble_rows_kernel, dim3((B + 127) / 128), dim3(128), 0, st, go, bp, betas, lh, rh, transl, B, X, w[4].p);
+    HIP_TRY(hipMemsetAsync(w[9].p, 0, (size_t)B * 16 * sizeof(float), st));
+    HIP_TRY(hipMemsetAsync(w[10].p, 0, sizeof(float), st));
+    hipLaunchKernelGGL(pose_fwd_kernel<false>, dim3(B), dim3(64 * POSE_NW), 0, st, c->pose_model(), X, (float*)nullptr, w[9].p, w[10].p, 0,
+                       (float*)nullptr, w[6].p, (float*)nullptr, w[7].p, w[8].p, (float*)nullptr, (float*)nullptr, (const float*)w[4].p,
+                       (const float*)nullptr, (size_t)0);
+    if (joints) hipLaunchKernelGGL(joints_out_kernel, dim3((B * NJ + 255) / 256), dim3(256), 0, st, w[7].p, X, XDIM, B, joints);
+    if (vertices) {
+        HIP_TRY(w[11].ensure((size_t)B * 3 * V));
+        HIP_TRY(blend_forward(c->full, w[6].p, B, w[11].p, st));
+        hipLaunchKernelGGL(skin_fwd_kernel, dim3((V + 255) / 256, B), dim3(256), 0, st, c->full.model(), V, X, XDIM, X_BETAS,
+                           X_TRANSL, w[11].p, w[8].p, (const float*)nullptr, (const float*)nullptr, 0, 0, vertices);
+    }
+    return (int)hipGetLastError();
+}
+
+int fdcap_smplx_backward(fdcap_ctx* c, const float* go, const float* bp, const float* betas, const float* lh, const float* rh,
+                         const float* transl, int32_t B, const float* g_vertices, const float* g_joints, float* g_go, float* g_bp,
+                         float* g_betas, float* g_lh, float* g_rh, float* g_transl, void* stream) {
+    if (!c || !go || !bp || !betas || !lh || !rh || !transl || B <= 0 || (!g_vertices && !g_joints)) return FDCAP_E_ARG;
+    hipStream_t st = (hipStream_t)stream;
+    if (g_vertices && !c->full_ready) {
+        std::vector<int64_t> all(c->V);
+        for (int i = 0; i < c->V; ++i) all[i] = i;
+        int e = build_skin_set(c, all, &c->full);
+        if (e) return e;
+        c->full_ready = true;
+    }
+    const int V = c->V;
+    const size_t nv3 = (size_t)3 * V;
+    DevBuf<float>* w = c->ws_b;
+    // forward state (recomputed: the operator keeps none): X rows, AA, PF, Rm, Jrest, G, A
+    HIP_TRY(w[0].ensure((size_t)B * XDIM)); HIP_TRY(w[1].ensure((size_t)B * 66)); HIP_TRY(w[2].ensure((size_t)B * NPFX));
+    HIP_TRY(w[3].ensure((size_t)B * NJ * 9)); HIP_TRY(w[4].ensure((size_t)B * NJ * 3)); HIP_TRY(w[5].ensure((size_t)B * NJ * 12));
+    HIP_TRY(w[6].ensure((size_t)B * NJ * 12));
+    // gradients: dA, [dtransl_v 3 | dMv 12 | dsv 1 | identity M 12 | cam 16] per row + scale, dPF, dX, dAA
+    HIP_TRY(w[7].ensure((size_t)B * NJ * 12)); HIP_TRY(w[8].ensure((size_t)B * 44 + 4)); HIP_TRY(w[9].ensure((size_t)B * NPFX));
+    HIP_TRY(w[10].ensure((size_t)B * XDIM)); HIP_TRY(w[11].ensure((size_t)B * 66));
+    float* X = w[0].p; float* AA = w[1].p; float* PF = w[2].p;
+    float* dtv = w[8].p; float* dMv = dtv + (size_t)B * 3; float* dsv = dMv + (size_t)B * 12; float* Mid = dsv + B;
+    float* cam0 = Mid + (size_t)B * 12; float* one = cam0 + (size_t)B * 16;
+    hipLaunchKernelGGL(assemble_rows_kernel, dim3((B + 127) / 128), dim3(128), 0, st, go, bp, betas, lh, rh, transl, B, X, AA);
+    HIP_TRY(hipMemsetAsync(cam0, 0, ((size_t)B * 16 + 4) * sizeof(float), st));
+    HIP_TRY(hipMemsetAsync(w[10].p, 0, (size_t)B * XDIM * sizeof(float), st));
+    hipLaunchKernelGGL(pose_fwd_kernel<false>, dim3(B), dim3(64 * POSE_NW), 0, st, c->pose_model(), X, (float*)nullptr, cam0, one /* = 0 here */, 0,
+                       w[3].p, PF, w[4].p, w[5].p, w[6].p, (float*)nullptr, (float*)nullptr, (const float*)AA, (const float*)nullptr,
+                       (size_t)0);
+    const float* dA = nullptr; const float* dPF = nullptr; const float* dtr = nullptr;
+    if (g_vertices) {
+        // body-frame vertices = the world form with M = [I | 0] and scale = 1
+        hipLaunchKernelGGL(identity_rows_kernel, dim3((B * 12 + 255) / 256), dim3(256), 0, st, Mid, B, one);
+        DevBuf<float>* wf = c->ws_f;
+        HIP_TRY(wf[11].ensure((size_t)B * nv3));                 // pose + shape blend offsets
+        HIP_TRY(wf[0].ensure((size_t)B * nv3));                  // d offsets
+        HIP_TRY(blend_forward(c->full, PF, B, wf[11].p, st));
+        hipLaunchKernelGGL(skin_bwd_kernel<false>, dim3(B), dim3(256), (size_t)std::min(V, 1024) * 12 * sizeof(float), st, c->full.model(), V,
+                           X, wf[11].p, w[6].p, Mid, one, 0, g_vertices, wf[0].p, w[7].p, (float*)nullptr, dtv, dMv, dsv, ContactGradIn());
+        HIP_TRY(gemm_f32(true, EPI_STORE, wf[0].p, 3 * V, c->full.posedirs.p, c->full.ldp, w[9].p, NPFX, B, NPFX, 3 * V, nullptr, 0, st));
+        dA = w[7].p; dPF = w[9].p; dtr = dtv;
+    }
+    hipLaunchKernelGGL(pose_bwd_op_kernel, dim3(B), dim3(64), 0, st, c->pose_model(), X, AA, w[3].p, w[4].p, w[5].p, dA, dPF, dtr,
+                       g_joints, w[10].p, w[11].p);
+    hipLaunchKernelGGL(smplx_bwd_split_kernel, dim3((B + 127) / 128), dim3(128), 0, st, w[10].p, w[11].p, B, g_go, g_bp, g_betas, g_lh,
+                       g_rh, g_transl);
+    return (int)hipGetLastError();
+}
+
+}  // extern "C"

@@ -32,8 +32,14 @@ pytestmark = pytest.mark.gpu
 LR = 0.005
 
 
-def _setup(golden_dir):
-    g = np.load(os.path.join(golden_dir, "ref_global_500it.npz"))
+# Two fixtures (r5): "" = r4's (seeds 40-44, 640 vertices, 3000 scene points, 2 x 24 contact vertices); "_b" = a second run of the
+# reference's loop with other seeds throughout, 800 vertices, 4000 scene points and a DENSER contact set, 2 x 110 vertices
+# (tests/golden/make_golden.py --g500b) -- is the distance of r4's fixture a property of the problem class or an accident of one seed?
+FIXTURES = ["", "_b"]
+
+
+def _setup(golden_dir, sfx=""):
+    g = np.load(os.path.join(golden_dir, f"ref_global_500it{sfx}.npz"))
     bm = synth.make_body_model(int(g["num_verts"]), seed=int(g["model_seed"]))
     vp = synth.make_vposer(seed=int(g["vposer_seed"]))
     fop = FittingOP({"num_iter": 500}, {}, 300, body_model=bm, vposer=vp, scene_verts=g["scene"], contact_ids=g["vid"],
@@ -46,12 +52,13 @@ def _snap(d, k, pre=""):
     return d[pre + "snap_x78"][i], d[pre + "snap_scale"][i], d[pre + "snap_cam"][i]
 
 
-def test_fixed_budget_distance_from_the_reference_run(golden_dir):
-    g, bm, vp, fop = _setup(golden_dir)
+@pytest.mark.parametrize("sfx", FIXTURES)
+def test_fixed_budget_distance_from_the_reference_run(golden_dir, sfx):
+    g, bm, vp, fop = _setup(golden_dir, sfx)
     lines = list(g["camerapose"])
     body, scale, cam = fop.fitting(torch.tensor(g["body_in"]).cuda(), "global", log_every=1, snapshot_at=[100, 400, 500])
     np.testing.assert_array_equal(fop.idx1, g["idx1"])
-    yard = {k: np.load(os.path.join(golden_dir, f"oracle_global_500it_{k}.npz")) for k in ("f64", "f32t1")}
+    yard = {k: np.load(os.path.join(golden_dir, f"oracle_global_500it{sfx}_{k}.npz")) for k in ("f64", "f32t1")}
     rep = {}
     for k in (100, 400, 500):
         s = fop.snapshots[k]
@@ -84,9 +91,10 @@ def test_fixed_budget_distance_from_the_reference_run(golden_dir):
     fop.close()
 
 
+@pytest.mark.parametrize("sfx", FIXTURES)
 @pytest.mark.parametrize("k0", [100, 300, 400, 450, 495])
-def test_resynchronised_five_step_windows_along_the_real_budget(golden_dir, tmp_path, k0):
-    g, bm, vp, fop = _setup(golden_dir)
+def test_resynchronised_five_step_windows_along_the_real_budget(golden_dir, tmp_path, k0, sfx):
+    g, bm, vp, fop = _setup(golden_dir, sfx)
     P = first_phase2_iter(500)
     assert int(g[f"adam{k0}_x_step"]) == k0 and int(g[f"adam{k0}_c_step"]) == max(k0 - P - 1, 0) and int(g[f"adam{k0}_s_step"]) == min(k0, P)
     x, s, c = _snap(g, k0)

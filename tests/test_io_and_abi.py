@@ -40,7 +40,8 @@ def test_scene_size_limit_is_refused_not_truncated():
     hdr = open(os.path.join(ROOT, "include", "fdcap.h")).read()
     lim = int(re.search(r"#define FDCAP_MAX_SCENE_POINTS (\d+)", hdr).group(1))
     assert lim * 32 < 2 ** 31            # the fragment stream (32 B per point) stays addressable with 32-bit offsets
-    src = open(os.path.join(ROOT, "4dcapture-fpv_amd", "csrc", "fdcap.hip")).read()
+    csrc = os.path.join(ROOT, "4dcapture-fpv_amd", "csrc")        # (the translation unit: fdcap.hip + the parts it includes)
+    src = "".join(open(os.path.join(csrc, f)).read() for f in sorted(os.listdir(csrc)))
     assert "ns > FDCAP_MAX_SCENE_POINTS) return FDCAP_E_ARG" in src
 
 
