@@ -192,7 +192,7 @@ void fdcap_ctx_destroy(fdcap_ctx* c) {
     c->W1.release(); c->b1.release(); c->W2.release(); c->b2.release(); c->W3.release(); c->b3.release();
     for (auto& b : c->vp_pn) b.release();
     for (auto& b : c->vp_pn3) b.release();
-    c->full.release(); c->contact.release(); c->contact_vid.release(); c->contact_perm.release(); c->scene.release(); c->scene_sorted.release(); c->scene_bounds.release(); c->scene_sbounds.release(); c->scene_qbounds.release(); c->scene_inv.release(); c->scene_frags.release(); c->scene_centers.release(); c->sop.release();
+    c->full.release(); c->contact.release(); c->contact_vid.release(); c->contact_perm.release(); c->scene.release(); c->scene_sorted.release(); c->scene_bounds.release(); c->scene_sbounds.release(); c->scene_qbounds.release(); c->scene_inv.release(); c->scene_frags.release(); c->scene_centers.release(); c->sop.release(); c->ws_skin.release();
     for (auto& b : c->ws_f) b.release();
     for (auto& b : c->ws_b) b.release();
     c->ws_part.release();
@@ -664,8 +664,8 @@ int fdcap_smplx_backward(fdcap_ctx* c, const float* go, const float* bp, const f
         HIP_TRY(wf[11].ensure((size_t)B * nv3));                 // pose + shape blend offsets
         HIP_TRY(wf[0].ensure((size_t)B * nv3));                  // d offsets
         HIP_TRY(blend_forward(c->full, PF, B, wf[11].p, st));
-        hipLaunchKernelGGL(skin_bwd_kernel<false>, dim3(B), dim3(256), (size_t)std::min(V, 1024) * 12 * sizeof(float), st, c->full.model(), V,
-                           X, wf[11].p, w[6].p, Mid, one, 0, g_vertices, wf[0].p, w[7].p, (float*)nullptr, dtv, dMv, dsv, ContactGradIn());
+        { int es = skin_bwd_any<false>(c->ws_skin, st, B, c->full.model(), V, X, wf[11].p, w[6].p, Mid, one, 0, g_vertices, wf[0].p, w[7].p,
+                                       (float*)nullptr, dtv, dMv, dsv, ContactGradIn()); if (es) return es; }
         HIP_TRY(gemm_f32(true, EPI_STORE, wf[0].p, 3 * V, c->full.posedirs.p, c->full.ldp, w[9].p, NPFX, B, NPFX, 3 * V, nullptr, 0, st));
         dA = w[7].p; dPF = w[9].p; dtr = dtv;
     }

@@ -223,9 +223,9 @@ static int opt_backward_impl(fdcap_ctx* c, const LossWeights& lw, int32_t log_te
                 hipLaunchKernelGGL((skin_bwd_small_kernel<4, 24>), dim3(nl), dim3(256), lds, st, c->contact.model(), nc, nnz, o->X.p, o->Voff.p, o->A.p,
                                    o->M.p, o->scale.p, 2, o->dVoff.p, o->dA.p, o->dtransl_v.p, o->dMv.p, o->dsv.p, cg);
         } else
-        hipLaunchKernelGGL(skin_bwd_kernel<true>, dim3(nl), dim3(256), (size_t)std::min(nc, 1024) * 12 * sizeof(float), st, c->contact.model(), nc, o->X.p, o->Voff.p, o->A.p,
-                           o->M.p, o->scale.p, 2, (const float*)nullptr, o->dVoff.p, o->dA.p, (float*)nullptr, o->dtransl_v.p,
-                           o->dMv.p, o->dsv.p, cg);
+        { int es = skin_bwd_any<true>(c->ws_skin, st, nl, c->contact.model(), nc, o->X.p, o->Voff.p, o->A.p, o->M.p, o->scale.p, 2,
+                                      (const float*)nullptr, o->dVoff.p, o->dA.p, (float*)nullptr, o->dtransl_v.p, o->dMv.p, o->dsv.p, cg);
+          if (es) return es; }
         TraceRange tr_b("fdcap:blend_bwd(K8)");
         if (gemm_split3_enabled() && c->contact.pn_bwd3.f && panel_gemm3_rb2k_ok(nl, 3 * nc, c->contact.pn_bwd3)) {
             // two partial products (K halves), added by pose_bwd_kernel: [2][R, 496] in o->dPF

@@ -78,15 +78,23 @@ __device__ __forceinline__ float wave_sum(float v) { return wave_sum64(v); }
 // dependent gather scene[idx[q]].
 struct ContactGradIn { const float* Vw; const float* dist; const int* idx; const float4* scene; const float4* nnpt; float coef; float* loss_rows; };
 constexpr int SKB_NACC = NBETA + 3 + 12 + 1;   // dbeta, dtransl, dM, ds
-template <bool CONTACT>
+constexpr int SKB_VCH = 1024;                  // vertices per LDS chunk
+constexpr int SKP_STRIDE = 688;                // floats of a (frame, chunk) partial of the split form: dA [660] | the SKB_NACC sums | contact term | pad
+static_assert(NJ * 12 + SKB_NACC + 1 <= SKP_STRIDE, "partial record");
+// SPLIT (r5; vertex sets of more than one chunk: the full mesh -- BASELINE config 5's contact set, mode 'local', the body-model
+// operator's backward): grid (frames, chunks), a workgroup takes ONE chunk of one frame and leaves its sums in `part`
+// [frame][chunk][SKP_STRIDE]; skin_bwd_reduce_kernel adds the chunks in ascending order.  One workgroup per frame walking all
+// 10 475 vertices (41 per thread, eleven dA reductions in a row) put two workgroups on a CU for half a millisecond: 541 us per
+// launch at 512 frames, 17 % of a config-5 iteration (profiles/r5_c5_kernel_trace_stats.txt).
+template <bool CONTACT, bool SPLIT = false>
 __global__ __launch_bounds__(256) void skin_bwd_kernel(SkinModel sm, int nc, const float* __restrict__ X,
                                                        const float* __restrict__ Voff, const float* __restrict__ A,
                                                        const float* __restrict__ M, const float* __restrict__ scale,
                                                        int row0, const float* dVw, float* dVoff,
                                                        float* __restrict__ dA, float* __restrict__ dbeta_v,
                                                        float* __restrict__ dtransl_v, float* __restrict__ dMv,
-                                                       float* __restrict__ dsv, ContactGradIn cg) {
-    constexpr int VCH = 1024;                      // vertices per LDS chunk
+                                                       float* __restrict__ dsv, ContactGradIn cg, float* __restrict__ part = nullptr) {
+    constexpr int VCH = SKB_VCH;
     extern __shared__ float sdT[];                 // [min(nc, VCH) * 12] (dynamic: 500 contact vertices leave room for 6 workgroups per CU)
     __shared__ float sdA[NJ * 12];
     __shared__ float sred[4][SKB_NACC];
@@ -107,8 +115,9 @@ __global__ __launch_bounds__(256) void skin_bwd_kernel(SkinModel sm, int nc, con
     for (int i = tid; i < NJ * 12; i += 256) sdA[i] = 0.f;
     __syncthreads();
     FDC_FR_STAMP(2, 1);
-    for (int c0 = 0; c0 < nc; c0 += VCH) {
-        const int c1 = min(nc, c0 + VCH);
+    const int c_lo = SPLIT ? (int)blockIdx.y * VCH : 0, c_hi = SPLIT ? min(nc, c_lo + VCH) : nc;
+    for (int c0 = c_lo; c0 < c_hi; c0 += VCH) {
+        const int c1 = min(c_hi, c0 + VCH);
         for (int c = c0 + tid; c < c1; c += 256) {
             size_t qi = (size_t)r * nc + c;
             // every global load of this vertex goes out before the first use (the kernel is a chain of latencies: four
@@ -147,6 +156,12 @@ __global__ __launch_bounds__(256) void skin_bwd_kernel(SkinModel sm, int nc, con
 #pragma unroll
             for (int e = 0; e < 12; ++e) sdT[(c - c0) * 12 + e] = b.dT[e];
         }
+        // lane j: where joint j's list enters / leaves this chunk (loaded while the vertex phase's stores drain)
+        int clo = 0, chi = 0;
+        if (nc > VCH && lane < NJ) {
+            const int* t = sm.csc_chunk + (size_t)lane * (sm.nch + 1) + c0 / VCH;
+            clo = t[0]; chi = t[1];
+        }
         __syncthreads();
         FDC_FR_STAMP(2, 2);
         // dA_j += sum_v w_vj dT_v, ordered and atomic-free (run-to-run reproducible): the joints are dealt
@@ -159,12 +174,8 @@ __global__ __launch_bounds__(256) void skin_bwd_kernel(SkinModel sm, int nc, con
             jact &= jact - 1;
             if ((kact & 3) != wave) continue;               // wave-uniform
             int lo = __builtin_amdgcn_readlane(jlo, j), hi = __builtin_amdgcn_readlane(jhi, j);
-            if (nc > VCH) {
-                int a = lo, bnd = hi;
-                while (a < bnd) { int m = (a + bnd) >> 1; if (sm.csc_v[m] < c0) a = m + 1; else bnd = m; }
-                lo = a; bnd = hi;
-                while (a < bnd) { int m = (a + bnd) >> 1; if (sm.csc_v[m] < c1) a = m + 1; else bnd = m; }
-                hi = a;
+            if (nc > VCH) {                                 // this chunk's part of the list: two table entries (r5; was two binary searches)
+                lo = __builtin_amdgcn_readlane(clo, j); hi = __builtin_amdgcn_readlane(chi, j);
                 if (lo == hi) continue;
             }
             float pa[12];
@@ -191,6 +202,18 @@ __global__ __launch_bounds__(256) void skin_bwd_kernel(SkinModel sm, int nc, con
         if ((tid & 63) == 0) sred[tid >> 6][i] = v;
     }
     __syncthreads();
+    if (SPLIT) {                                        // this chunk's sums: added up (ascending chunks) by skin_bwd_reduce_kernel
+        __shared__ float scon[4];
+        float* const rec = part + ((size_t)blockIdx.x * gridDim.y + blockIdx.y) * SKP_STRIDE;
+        const float v = wave_sum(cterm);
+        if ((tid & 63) == 0) scon[tid >> 6] = v;
+        __syncthreads();
+        for (int i = tid; i < NJ * 12; i += 256) rec[i] = sdA[i];
+        if (tid < SKB_NACC) rec[NJ * 12 + tid] = sred[0][tid] + sred[1][tid] + sred[2][tid] + sred[3][tid];
+        if (tid == 0) rec[NJ * 12 + SKB_NACC] = (scon[0] + scon[1]) + (scon[2] + scon[3]);
+        FDC_FR_STAMP(2, 4);
+        return;
+    }
     if (CONTACT && cg.loss_rows) {                      // wave-uniform
         __shared__ float scon[4];
         const float v = wave_sum(cterm);
@@ -207,6 +230,25 @@ __global__ __launch_bounds__(256) void skin_bwd_kernel(SkinModel sm, int nc, con
         else dsv[r] = v;
     }
     FDC_FR_STAMP(2, 4);
+}
+
+// the split form's second launch: per frame, the chunk partials added in ascending chunk order (run-to-run reproducible)
+__global__ __launch_bounds__(256) void skin_bwd_reduce_kernel(const float* __restrict__ part, int nch, int row0, float* __restrict__ dA,
+                                                              float* __restrict__ dbeta_v, float* __restrict__ dtransl_v,
+                                                              float* __restrict__ dMv, float* __restrict__ dsv, float* __restrict__ loss_rows) {
+    const int r = row0 + blockIdx.x;
+    const float* p = part + (size_t)blockIdx.x * nch * SKP_STRIDE;
+    for (int i = threadIdx.x; i < NJ * 12 + SKB_NACC + 1; i += 256) {
+        float s = 0.f;
+        for (int ch = 0; ch < nch; ++ch) s += p[(size_t)ch * SKP_STRIDE + i];
+        const int t = i - NJ * 12;
+        if (t < 0) dA[(size_t)r * NJ * 12 + i] = s;
+        else if (t < NBETA) { if (dbeta_v) dbeta_v[(size_t)r * NBETA + t] = s; }
+        else if (t < NBETA + 3) dtransl_v[(size_t)r * 3 + t - NBETA] = s;
+        else if (t < NBETA + 15) dMv[(size_t)r * 12 + t - NBETA - 3] = s;
+        else if (t < SKB_NACC) dsv[r] = s;
+        else if (loss_rows) loss_rows[(size_t)r * LROW + 3] = s;
+    }
 }
 
 // Contact-set form of skin_bwd_kernel<true> (vertex sets of at most SKS_MAXV vertices / SKS_MAXNNZ skinning weights: the

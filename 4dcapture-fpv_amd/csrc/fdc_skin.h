@@ -26,6 +26,11 @@ struct SkinModel {
     // (K <= 4 is the two-plane layout of r2; a real SMPLX_NEUTRAL.npz is not promised to be 4-sparse.)
     const float* vpack = nullptr;
     const unsigned short* csc_v16 = nullptr; // [nnz rounded up to a multiple of 8] csc_v as 16-bit ids
+    // [55][nch + 1], nch = ceil(V / 1024): where joint j's list enters each 1024-vertex chunk (r5: the chunked backward of large
+    // vertex sets looked these up with two binary searches per joint and chunk -- ~26 dependent global round trips each, 80 % of
+    // its 540 us at 10 475 vertices)
+    const int* csc_chunk = nullptr;
+    int nch = 0;
 };
 
 FDC_HD int skin_vpack_planes(int K) { const int G = (K + 3) / 4; return G <= 1 ? 2 : G + 2; }

@@ -27,11 +27,36 @@ struct DevBuf {
     void release() { if (p) (void)hipFree(p); p = nullptr; n = 0; }
 };
 
+// skin_bwd_kernel for any vertex set: one workgroup per frame up to a chunk of vertices, the split form + its reduction beyond
+// (`part`: workspace, grown as needed).  Same arguments as the kernel.
+template <bool CONTACT>
+static int skin_bwd_any(DevBuf<float>& part, hipStream_t st, int nrows, SkinModel sm, int nc, const float* X, const float* Voff, const float* A,
+                        const float* M, const float* scale, int row0, const float* dVw, float* dVoff, float* dA, float* dbeta_v,
+                        float* dtransl_v, float* dMv, float* dsv, ContactGradIn cg) {
+    static int split_on = -1;                              // FDCAP_SKIN_SPLIT=0: the one-workgroup-per-frame form at every size (A/B)
+    if (split_on < 0) { const char* e = getenv("FDCAP_SKIN_SPLIT"); split_on = (e && e[0] == '0') ? 0 : 1; }
+    const size_t lds = (size_t)std::min(nc, SKB_VCH) * 12 * sizeof(float);
+    if (nc <= SKB_VCH || !split_on) {
+        hipLaunchKernelGGL((skin_bwd_kernel<CONTACT, false>), dim3(nrows), dim3(256), lds, st, sm, nc, X, Voff, A, M, scale, row0, dVw, dVoff, dA,
+                           dbeta_v, dtransl_v, dMv, dsv, cg, (float*)nullptr);
+        return (int)hipGetLastError();
+    }
+    const int nch = (nc + SKB_VCH - 1) / SKB_VCH;
+    hipError_t e = part.ensure((size_t)nrows * nch * SKP_STRIDE);
+    if (e != hipSuccess) return (int)e;
+    hipLaunchKernelGGL((skin_bwd_kernel<CONTACT, true>), dim3(nrows, nch), dim3(256), lds, st, sm, nc, X, Voff, A, M, scale, row0, dVw, dVoff, dA,
+                       dbeta_v, dtransl_v, dMv, dsv, cg, part.p);
+    hipLaunchKernelGGL(skin_bwd_reduce_kernel, dim3(nrows), dim3(256), 0, st, part.p, nch, row0, dA, dbeta_v, dtransl_v, dMv, dsv,
+                       CONTACT ? cg.loss_rows : (float*)nullptr);
+    return (int)hipGetLastError();
+}
+
 struct SkinSet {          // skinning constants for a vertex set (all V, or the contact subset)
     int nv = 0, K = 0, nnz = 0;
     int ldp = 0;                                // row stride of posedirs: 3*nv rounded up to a multiple of 4 (16-byte rows)
     DevBuf<float> vt, ww, posedirs, csc_w;      // posedirs [496, ldp] = [posedirs ; shapedirs^T], zero padding
-    DevBuf<int> wj, csc_start, csc_v;
+    DevBuf<int> wj, csc_start, csc_v, csc_chunk;
+    int nch = 0;
     DevBuf<float4> vpack;                       // SkinModel::vpack / csc_v16 (K <= 4 and nv <= 65535 only)
     DevBuf<unsigned short> csc_v16;
     // the blend matrix in MFMA fragment order (fdc_panel.h), built for vertex sets whose K = 3 nv image fits the LDS slabs:
@@ -44,10 +69,11 @@ struct SkinSet {          // skinning constants for a vertex set (all V, or the 
         SkinModel m; m.vt = vt.p; m.S = nullptr; m.wj = wj.p; m.ww = ww.p; m.K = K;
         m.csc_start = csc_start.p; m.csc_v = csc_v.p; m.csc_w = csc_w.p;
         m.vpack = (const float*)vpack.p; m.csc_v16 = csc_v16.p;
+        m.csc_chunk = csc_chunk.p; m.nch = nch;
         return m;
     }
     void release() { vt.release(); ww.release(); posedirs.release(); wj.release(); csc_w.release(); csc_start.release(); csc_v.release();
-                     vpack.release(); csc_v16.release();
+                     vpack.release(); csc_v16.release(); csc_chunk.release();
                      pn_fwd_f.release(); pn_bwd_f.release(); pn_fwd = PanelB(); pn_bwd = PanelB();
                      pn_fwd3_f.release(); pn_bwd3_f.release(); pn_fwd3 = PanelB3(); pn_bwd3 = PanelB3(); }
 };
@@ -164,6 +190,7 @@ struct fdcap_ctx {
     DevBuf<float> ws_part;          // partial decoder outputs of the stand-alone operators
     DevBuf<int> ws_i[2];
     DevBuf<float4> ws_p;
+    DevBuf<float> ws_skin;          // chunk partials of the split skinning backward (skin_bwd_any)
     // Op 1 against the registered scene (fdcap_chamfer_fwd_scene): the previous call's neighbours = the next call's seeds
     struct SceneOp {
         DevBuf<float> dist;
@@ -256,6 +283,19 @@ int build_skin_set(fdcap_ctx* c, const std::vector<int64_t>& ids, SkinSet* out) 
         for (size_t i = 0; i < csc_v.size(); ++i) v16[i] = (unsigned short)csc_v[i];
         HIP_TRY(out->vpack.upload(vp.data(), vp.size()));
         HIP_TRY(out->csc_v16.upload(v16.data(), v16.size()));
+    }
+    {   // chunk entry points of every joint's list (skin_bwd_kernel's chunks of SKB_VCH vertices)
+        const int nch = std::max(1, (nv + SKB_VCH - 1) / SKB_VCH);
+        std::vector<int> cc((size_t)NJ * (nch + 1), 0);
+        for (int j = 0; j < NJ; ++j) {
+            int i = csc_start[j];
+            for (int ch = 0; ch <= nch; ++ch) {
+                while (i < csc_start[j + 1] && csc_v[i] < ch * SKB_VCH) ++i;
+                cc[(size_t)j * (nch + 1) + ch] = ch == nch ? csc_start[j + 1] : i;
+            }
+        }
+        out->nch = nch;
+        HIP_TRY(out->csc_chunk.upload(cc.data(), cc.size()));
     }
     HIP_TRY(out->csc_start.upload(csc_start.data(), csc_start.size()));
     HIP_TRY(out->csc_v.upload(csc_v.data(), csc_v.size()));

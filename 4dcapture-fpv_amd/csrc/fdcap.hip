@@ -21,7 +21,7 @@
 #ifdef FDC_PN_TIMING
 // instrumentation build only: per-frame s_memtime stamps of the pose kernels [which][block][8]
 __device__ unsigned long long g_fr_times[3][2048 * 8];
-#define FDC_FR_STAMP(w, i) do { if (threadIdx.x == 0 && blockIdx.x < 2048) g_fr_times[w][blockIdx.x * 8 + (i)] = __builtin_amdgcn_s_memtime(); } while (0)
+#define FDC_FR_STAMP(w, i) do { const unsigned fb_ = blockIdx.x * gridDim.y + blockIdx.y; if (threadIdx.x == 0 && fb_ < 2048) g_fr_times[w][fb_ * 8 + (i)] = __builtin_amdgcn_s_memtime(); } while (0)
 #endif
 #ifndef FDC_FR_STAMP
 #define FDC_FR_STAMP(w, i)

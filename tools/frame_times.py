@@ -8,10 +8,10 @@ import fdcap_amd  # noqa
 from fdcap_amd import capi, synth
 from fdcap_amd.fitting import FittingOP
 from fdcap_amd.io import read_camerapose
-N = 1024
+N = int(os.environ.get("FRAMES", "1024"))          # (FRAMES=128 SCENE=2000000 ALLC=1: BASELINE config 5's kernels, 11 chunk workgroups per frame)
 bm = synth.make_body_model(10475, seed=0); vp = synth.make_vposer(seed=1); clip = synth.make_clip(N, seed=3)
-scene = synth.make_scene(500000, seed=2); l, r = synth.make_contact_ids(bm.v_template, per_part=250, seed=4)
-fop = FittingOP({"num_iter": 40}, {}, N, body_model=bm, vposer=vp, scene_verts=scene, contact_ids=np.concatenate([l, r]),
+scene = synth.make_scene(int(os.environ.get("SCENE", "500000")), seed=2); l, r = synth.make_contact_ids(bm.v_template, per_part=250, seed=4)
+fop = FittingOP({"num_iter": 40}, {}, N, body_model=bm, vposer=vp, scene_verts=scene, contact_ids=np.arange(10475) if os.environ.get("ALLC") == "1" else np.concatenate([l, r]),
                 camera_ext=read_camerapose(clip.camerapose_lines))
 body = torch.tensor(clip.body_params).cuda()
 lib, h = fop.ctx.lib, fop.ctx.handle
@@ -28,7 +28,7 @@ names = [("pose_fwd", ["sum partials + topology", "joint rotations + J", "chain"
          ("pose_bwd", ["stage + param-loss grads", "load + own grads", "products + reverse chain", "dR/drel", "rot backward", "tail reductions"], 7),
          ("skin_bwd", ["stage A", "vertex loop", "dA reduction", "final sums + stores"], 5)]
 for k, (nm, ph, ns) in enumerate(names):
-    t = a[k, :N, :ns]
+    t = a[k, :, :ns]
     t = t[t[:, -1] > 0]
     print(nm, len(t), "frames; lifetime q50", int(np.median(t[:, -1] - t[:, 0])), "cycles")
     for i in range(ns - 1):
