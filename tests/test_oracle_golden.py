@@ -108,14 +108,15 @@ def test_local_mode_trajectory_matches_reference(golden_dir):
         np.testing.assert_allclose(log2[:, k], ref2[:, k + 1], atol=2e-6)
 
 
-def test_500_iteration_fixture_is_the_oracles_trajectory_and_the_yardsticks_say_what_design_says(golden_dir):
+@pytest.mark.parametrize("sfx", ["", "_b"])
+def test_500_iteration_fixture_is_the_oracles_trajectory_and_the_yardsticks_say_what_design_says(golden_dir, sfx):
     """ref_global_500it.npz (the reference's own loop at its real budget, global_optimization.py:672) against the oracle: the
     first 20 iterations are re-run here and must land on the fixture's snapshot to rounding (the whole 500 take 8 minutes:
     tests/golden/make_golden.py --yardstick500 ran them and committed oracle_global_500it_*.npz).  The yardstick fixtures then
     carry the statement DESIGN.md section 7 makes: the SAME oracle code in fp32 on one thread instead of four agrees with the
     reference's run to rounding for 20 iterations and is centimetres away after 500 -- as far as the fp64 run is."""
     from tests.parity500 import distance_report
-    g = _load(golden_dir, "ref_global_500it.npz")
+    g = _load(golden_dir, f"ref_global_500it{sfx}.npz")      # ("_b", r5: a second run of the reference's loop -- other seeds, 220 contact vertices)
     bm = synth.make_body_model(int(g["num_verts"]), seed=int(g["model_seed"]))
     vp = synth.make_vposer(seed=int(g["vposer_seed"]))
     assert sha(bm.posedirs) == str(g["sha_posedirs"]) and sha(vp.fc2_w) == str(g["sha_fc2"])
@@ -135,9 +136,9 @@ def test_500_iteration_fixture_is_the_oracles_trajectory_and_the_yardsticks_say_
     snap = lambda d, k: (d["snap_x78"][[int(v) for v in d["snap_iters"]].index(k)], d["snap_scale"][[int(v) for v in d["snap_iters"]].index(k)],
                          d["snap_cam"][[int(v) for v in d["snap_iters"]].index(k)])
     for name in ("f64", "f32t1"):
-        y = _load(golden_dir, f"oracle_global_500it_{name}.npz")
+        y = _load(golden_dir, f"oracle_global_500it{sfx}_{name}.npz")
         r20, r400, r500 = (distance_report(bm, vp, lines, snap(y, k), snap(g, k)) for k in (20, 400, 500))
-        assert r20["vert_mm_mean"] < 0.05, (name, r20)                     # (fp64 vs fp32: 0.009 mm; one thread: 0)
+        assert r20["vert_mm_mean"] < (0.05 if sfx == "" else 0.2), (name, r20)   # (fp64 vs fp32: 0.009 mm; one thread: 0; fixture b: 0.10 / 0)
         assert 2.0 < r400["vert_mm_mean"] < 12.0 and r400["cam_max"] < 1e-6, (name, r400)
         assert 8.0 < r500["vert_mm_mean"] < 40.0 and r500["vert_mm_max"] > 30.0, (name, r500)
         rel = np.abs(y["log"][:, 5] - g["log"][:, 6]) / g["log"][:, 6]
