@@ -191,6 +191,7 @@ static int opt_backward_impl(fdcap_ctx* c, const LossWeights& lw, int32_t log_te
                            lw.world_on ? 1 : 0, o->dJw.p, losses ? losses + 7 : nullptr);
     o->dct_grad = dct_on;
     bool dpf_split = false;
+    int dA_rows = NJ;                                       // rows of dA the skinning backward writes (the others are zero and skipped)
     if (contact_grad) {
         ContactGradIn cg;
         cg.Vw = o->Vw.p; cg.dist = o->dist.p; cg.idx = o->idx.p; cg.scene = c->scene.p;
@@ -201,6 +202,7 @@ static int opt_backward_impl(fdcap_ctx* c, const LossWeights& lw, int32_t log_te
         if (nc <= SKS_MAXV && c->contact.nnz <= SKS_MAXNNZ && lds_small <= 57000) {      // (+ 6.4 KB of static LDS <= 64 KB)
             const int nnz = c->contact.nnz;
             const size_t lds = lds_small;
+            dA_rows = c->contact.ja_hi;
             const SkinModel smc = c->contact.model();
             const int G = (smc.K + 3) / 4;                           // weight groups per vertex: the packed layout covers K <= 12
             const size_t ldsv = (size_t)9 * nc * sizeof(float) + (size_t)((nnz + 3) & ~3) * sizeof(float) + (size_t)((nnz + 7) & ~7) * 2;
@@ -248,7 +250,8 @@ static int opt_backward_impl(fdcap_ctx* c, const LossWeights& lw, int32_t log_te
                        o->Jrest.p, o->G.p, contact_grad ? o->dA.p : nullptr, contact_grad ? o->dPF.p : nullptr,
                        joint_grad ? o->dJw.p : nullptr, contact_grad ? o->dMv.p : nullptr, contact_grad ? o->dsv.p : nullptr,
                        contact_grad ? o->dPF.p + NPF : nullptr, NPFX, contact_grad ? o->dtransl_v.p : nullptr, o->dX.p, o->dO.p,
-                       o->dCAM.p, o->dscale_row.p, pli, (contact_grad && dpf_split) ? (const float*)(o->dPF.p + (size_t)o->R * NPFX) : (const float*)nullptr);
+                       o->dCAM.p, o->dscale_row.p, pli, (contact_grad && dpf_split) ? (const float*)(o->dPF.p + (size_t)o->R * NPFX) : (const float*)nullptr,
+                       dA_rows);
     const unsigned log_mask = (rows_log ? 0x17u : 0u) | (contact_fwd ? 0x8u : 0u);     // 0 rec, 1 z^2, 2 smoothing, 4 world | 3 contact
     bool log_in_tail = false;
     {

@@ -255,7 +255,8 @@ __global__ __launch_bounds__(64 * POSE_NW) void pose_bwd_kernel(PoseModel pm, co
                                                       const float* dA, const float* dPF, const float* dJw,
                                                       const float* dMv, const float* dsv, const float* dbeta_v,
                                                       int dbeta_stride, const float* dtransl_v, float* dX, float* dO,
-                                                      float* dCAM, float* dscale_row, ParamLossIn pl, const float* dPF2) {
+                                                      float* dCAM, float* dscale_row, ParamLossIn pl, const float* dPF2, int dA_nj = NJ) {
+    // dA_nj: rows of dA that were written (the rest are zero: SkinModel::ja_hi)
     // dPF2 (optional): second partial of dPF -- the data-gradient product split over K (panel_gemm3_rb2k_kernel); the row is
     // dPF + dPF2, d betas its columns NPF.. (dbeta_v must then be dPF + NPF, stride NPFX)
     __shared__ PoseScratch sc;
@@ -292,7 +293,10 @@ __global__ __launch_bounds__(64 * POSE_NW) void pose_bwd_kernel(PoseModel pm, co
         if (dbeta_v) glds4<1>(dbeta_v + (size_t)r * dbeta_stride, s_misc + 16, NBETA);
     } else if (wave == 2) {
         stage_pose_part<2>(pm, stg, xrow, camrow);
-        if (dA) glds16<(NJ * 3 + 63) / 64>(dA + (size_t)r * NJ * 12, &sc.dG[0][0], NJ * 3);   // waits in sc.dG: lane j reads row j, then overwrites it
+        if (dA) {                                          // waits in sc.dG: lane j reads row j, then overwrites it
+            glds16<(NJ * 3 + 63) / 64>(dA + (size_t)r * NJ * 12, &sc.dG[0][0], dA_nj * 3);
+            for (int e = dA_nj * 12 + (int)(threadIdx.x & 63); e < NJ * 12; e += 64) (&sc.dG[0][0])[e] = 0.f;   // rows nobody wrote
+        }
         if (dPF) glds16<(NPFX / 4 + 63) / 64>(dPF + (size_t)r * NPFX, s_dPF, NPFX / 4);
         if (dPF2) glds16<(NPFX / 4 + 63) / 64>(dPF2 + (size_t)r * NPFX, &sc.dR[0][0], NPFX / 4);   // parked in sc.dR (written much later)
     } else if (pl.X0) {

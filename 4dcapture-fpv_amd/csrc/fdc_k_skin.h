@@ -403,7 +403,7 @@ __global__ __launch_bounds__(256) void skin_bwd_small_kernel(SkinModel sm, int n
     if (cg.loss_rows && lane == 0) sred[wave][0] = ct;
     __syncthreads();
     if (cg.loss_rows && tid == 0) cg.loss_rows[(size_t)r * LROW + 3] = (sred[0][0] + sred[1][0]) + (sred[2][0] + sred[3][0]);
-    for (int i = tid; i < NJ * 12; i += 256) dA[(size_t)r * NJ * 12 + i] = sdA[i];
+    for (int i = tid; i < sm.ja_hi * 12; i += 256) dA[(size_t)r * NJ * 12 + i] = sdA[i];   // (rows >= ja_hi: zero, never read -- SkinModel::ja_hi)
     if (tid >= NBETA && tid < SKB_NACC) {
         const float v = sred[0][tid] + sred[1][tid] + sred[2][tid] + sred[3][tid];
         if (tid < NBETA + 3) dtransl_v[(size_t)r * 3 + tid - NBETA] = v;
@@ -564,7 +564,7 @@ __global__ __launch_bounds__(256) void skin_bwd_vec_kernel(SkinModel sm, int nc,
     if (cg.loss_rows && lane == 0) sred[wave][0] = ct;
     __syncthreads();
     if (cg.loss_rows && tid == 0) cg.loss_rows[(size_t)r * LROW + 3] = (sred[0][0] + sred[1][0]) + (sred[2][0] + sred[3][0]);
-    for (int i = tid; i < NJ * 12; i += 256) dA[(size_t)r * NJ * 12 + i] = sdA[i];
+    for (int i = tid; i < sm.ja_hi * 12; i += 256) dA[(size_t)r * NJ * 12 + i] = sdA[i];   // (rows >= ja_hi: zero, never read -- SkinModel::ja_hi)
     if (tid >= NBETA && tid < SKB_NACC) {
         const float v = sred[0][tid] + sred[1][tid] + sred[2][tid] + sred[3][tid];
         if (tid < NBETA + 3) dtransl_v[(size_t)r * 3 + tid - NBETA] = v;

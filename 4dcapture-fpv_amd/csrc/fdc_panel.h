@@ -1113,6 +1113,10 @@ constexpr int VP3_PZ = (VP_Z / 8) * 16, VP3_PH = (VP_H / 8) * 16, VP3_PQ = (VP_Q
 // and the four quarter-workgroups of a row block read H1 four times over).  Indexed by absolute row: the forward's and the backward's
 // 16-row blocks need not coincide (sharded runs).  The exact-fp32 twins keep floats in the same buffers.
 constexpr int VP3_MROW = VP_H / 4;
+#ifndef FDC_VP3_PF2
+#define FDC_VP3_PF2 4
+#endif
+constexpr int VP3_PF2 = FDC_VP3_PF2;          // fragments of layer 2's stream in flight per wave (16 steps; the ring turns every 2 PF)
 __device__ __forceinline__ unsigned char vp3_signs(const float4 v) {
     return (unsigned char)((v.x > 0.f ? 1u : 0u) | (v.y > 0.f ? 2u : 0u) | (v.z > 0.f ? 4u : 0u) | (v.w > 0.f ? 8u : 0u));
 }
@@ -1128,7 +1132,8 @@ __global__ __launch_bounds__(512) void vposer_fwd_split3_kernel(VPoserPanels3 P,
     int rblk = (int)(blockIdx.x >> 2);
     if (rblk >= two.nb1) { rblk -= two.nb1; row_lo = two.row2_lo; row_hi = two.row2_hi; }
     const int q = blockIdx.x & 3, r0 = row_lo + rblk * 16;
-    PnRing3T<1, 2> rg2, rg3;
+    PnRing3T<1, VP3_PF2> rg2;
+    PnRing3T<1, 2> rg3;
     // the biases of all three layers, requested before the first barrier (the compiler does not move a load across one):
     // fetched where they are used -- after each layer's products -- every tile's bias was a round trip of its own
     float4 bias1[4];
@@ -1162,7 +1167,7 @@ __global__ __launch_bounds__(512) void vposer_fwd_split3_kernel(VPoserPanels3 P,
         panel3_mma_t<4, 1>(sZ, VP3_PZ, rg1, 1, acc, lane);
         {
             const uint4* bf2 = P.w2.f + (size_t)(q * 8 + wave) * P.w2.nst * 3 * 64;
-            panel3_prefetch_t<1, 2>(rg2, &bf2, VP_H / 32, lane);
+            panel3_prefetch_t<1, VP3_PF2>(rg2, &bf2, VP_H / 32, lane);
         }
 #pragma unroll
         for (int t = 0; t < 4; ++t) {
@@ -1178,7 +1183,7 @@ __global__ __launch_bounds__(512) void vposer_fwd_split3_kernel(VPoserPanels3 P,
     {   // layer 2, this quarter's 128 columns (one tile per wave), K = 512 = 16 steps
         f32x4_t acc = {0.f, 0.f, 0.f, 0.f};
         const int tile = q * 8 + wave;
-        panel3_mma_t<1, 2>(sH1, VP3_PH, rg2, VP_H / 32, &acc, lane);
+        panel3_mma_t<1, VP3_PF2>(sH1, VP3_PH, rg2, VP_H / 32, &acc, lane);
         {
             const uint4* bf3 = P.w3.f + ((size_t)wave * P.w3.nst + q * (VP_QW / 32)) * 3 * 64;
             panel3_prefetch_t<1, 2>(rg3, &bf3, VP_QW / 32, lane);

@@ -56,7 +56,7 @@ struct SkinSet {          // skinning constants for a vertex set (all V, or the 
     int ldp = 0;                                // row stride of posedirs: 3*nv rounded up to a multiple of 4 (16-byte rows)
     DevBuf<float> vt, ww, posedirs, csc_w;      // posedirs [496, ldp] = [posedirs ; shapedirs^T], zero padding
     DevBuf<int> wj, csc_start, csc_v, csc_chunk;
-    int nch = 0;
+    int nch = 0, ja_hi = NJ;
     DevBuf<float4> vpack;                       // SkinModel::vpack / csc_v16 (K <= 4 and nv <= 65535 only)
     DevBuf<unsigned short> csc_v16;
     // the blend matrix in MFMA fragment order (fdc_panel.h), built for vertex sets whose K = 3 nv image fits the LDS slabs:
@@ -69,7 +69,7 @@ struct SkinSet {          // skinning constants for a vertex set (all V, or the 
         SkinModel m; m.vt = vt.p; m.S = nullptr; m.wj = wj.p; m.ww = ww.p; m.K = K;
         m.csc_start = csc_start.p; m.csc_v = csc_v.p; m.csc_w = csc_w.p;
         m.vpack = (const float*)vpack.p; m.csc_v16 = csc_v16.p;
-        m.csc_chunk = csc_chunk.p; m.nch = nch;
+        m.csc_chunk = csc_chunk.p; m.nch = nch; m.ja_hi = ja_hi;
         return m;
     }
     void release() { vt.release(); ww.release(); posedirs.release(); wj.release(); csc_w.release(); csc_start.release(); csc_v.release();
@@ -295,6 +295,8 @@ int build_skin_set(fdcap_ctx* c, const std::vector<int64_t>& ids, SkinSet* out) 
             }
         }
         out->nch = nch;
+        out->ja_hi = 1;
+        for (int j = 0; j < NJ; ++j) if (csc_start[j + 1] > csc_start[j]) out->ja_hi = j + 1;
         HIP_TRY(out->csc_chunk.upload(cc.data(), cc.size()));
     }
     HIP_TRY(out->csc_start.upload(csc_start.data(), csc_start.size()));
