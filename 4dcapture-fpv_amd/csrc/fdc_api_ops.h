@@ -192,7 +192,7 @@ void fdcap_ctx_destroy(fdcap_ctx* c) {
     c->W1.release(); c->b1.release(); c->W2.release(); c->b2.release(); c->W3.release(); c->b3.release();
     for (auto& b : c->vp_pn) b.release();
     for (auto& b : c->vp_pn3) b.release();
-    c->full.release(); c->contact.release(); c->contact_vid.release(); c->contact_perm.release(); c->scene.release(); c->scene_sorted.release(); c->scene_bounds.release(); c->scene_sbounds.release(); c->scene_qbounds.release(); c->scene_inv.release(); c->scene_frags.release(); c->scene_centers.release(); c->sop.release(); c->ws_skin.release();
+    c->full.release(); c->contact.release(); c->contact_vid.release(); c->contact_perm.release(); c->scene.release(); c->scene_sorted.release(); c->scene_bounds.release(); c->scene_sbounds.release(); c->scene_qbounds.release(); c->scene_inv.release(); c->scene_frags.release(); c->scene_centers.release(); c->sop.release(); c->ws_skin.release(); c->ws_kpart.release();
     for (auto& b : c->ws_f) b.release();
     for (auto& b : c->ws_b) b.release();
     c->ws_part.release();
@@ -666,7 +666,7 @@ int fdcap_smplx_backward(fdcap_ctx* c, const float* go, const float* bp, const f
         HIP_TRY(blend_forward(c->full, PF, B, wf[11].p, st));
         { int es = skin_bwd_any<false>(c->ws_skin, st, B, c->full.model(), V, X, wf[11].p, w[6].p, Mid, one, 0, g_vertices, wf[0].p, w[7].p,
                                        (float*)nullptr, dtv, dMv, dsv, ContactGradIn()); if (es) return es; }
-        HIP_TRY(gemm_f32(true, EPI_STORE, wf[0].p, 3 * V, c->full.posedirs.p, c->full.ldp, w[9].p, NPFX, B, NPFX, 3 * V, nullptr, 0, st));
+        HIP_TRY(blend_backward(c->full, wf[0].p, B, w[9].p, 0, c->ws_kpart, st));
         dA = w[7].p; dPF = w[9].p; dtr = dtv;
     }
     hipLaunchKernelGGL(pose_bwd_op_kernel, dim3(B), dim3(64), 0, st, c->pose_model(), X, AA, w[3].p, w[4].p, w[5].p, dA, dPF, dtr,

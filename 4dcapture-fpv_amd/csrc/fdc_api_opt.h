@@ -228,19 +228,7 @@ static int opt_backward_impl(fdcap_ctx* c, const LossWeights& lw, int32_t log_te
         { int es = skin_bwd_any<true>(c->ws_skin, st, nl, c->contact.model(), nc, o->X.p, o->Voff.p, o->A.p, o->M.p, o->scale.p, 2,
                                       (const float*)nullptr, o->dVoff.p, o->dA.p, (float*)nullptr, o->dtransl_v.p, o->dMv.p, o->dsv.p, cg);
           if (es) return es; }
-        TraceRange tr_b("fdcap:blend_bwd(K8)");
-        if (gemm_split3_enabled() && c->contact.pn_bwd3.f && panel_gemm3_rb2k_ok(nl, 3 * nc, c->contact.pn_bwd3)) {
-            // two partial products (K halves), added by pose_bwd_kernel: [2][R, 496] in o->dPF
-            dpf_split = true;
-            HIP_TRY(panel_gemm3_rb2k(o->dVoff.p + (size_t)2 * nc * 3, 3 * nc, nl, 3 * nc, c->contact.pn_bwd3, o->dPF.p + 2 * NPFX,
-                                     (size_t)o->R * NPFX, NPFX, NPFX, st));
-        } else if (gemm_split3_enabled() && c->contact.pn_bwd3.f)
-            HIP_TRY(panel_gemm3(o->dVoff.p + (size_t)2 * nc * 3, 3 * nc, nl, 3 * nc, c->contact.pn_bwd3, o->dPF.p + 2 * NPFX, NPFX, NPFX, st));
-        else if (c->contact.pn_bwd.f)
-            HIP_TRY(panel_gemm(o->dVoff.p + (size_t)2 * nc * 3, 3 * nc, nl, 3 * nc, c->contact.pn_bwd, o->dPF.p + 2 * NPFX, NPFX, NPFX, st));
-        else
-            HIP_TRY(gemm_f32(true, EPI_STORE, o->dVoff.p + (size_t)2 * nc * 3, 3 * nc, c->contact.posedirs.p, c->contact.ldp,
-                             o->dPF.p + 2 * NPFX, NPFX, nl, NPFX, 3 * nc, nullptr, 0, st));
+        HIP_TRY(blend_backward(c->contact, o->dVoff.p + (size_t)2 * nc * 3, nl, o->dPF.p + 2 * NPFX, (size_t)o->R * NPFX, c->ws_kpart, st, &dpf_split));
     } else if (contact_fwd && losses) {
         if (fuse_pl && rows_log) { pli.cdist = o->dist.p; pli.cnc = nc; }        // (rides in pose_bwd_kernel's prologue: one launch less)
         else hipLaunchKernelGGL(contact_loss_rows_kernel, dim3(nl), dim3(256), 0, st, o->dist.p, nc, 2, o->loss_rows.p);

@@ -62,8 +62,7 @@ int fdcap_opt_backward_local2(fdcap_ctx* c, const float* contact_weight, int32_t
                            nc, n_left, contact_weight, 2, cf.frame0, N, o->dVF.p, o->losses.p + 6);
     { int es = skin_bwd_any<false>(c->ws_skin, st, nl, c->full.model(), V, o->X.p, o->VoffF.p, o->A.p, o->M.p, o->scale.p, 2, o->dVF.p, o->dVF.p,
                                    o->dA.p, (float*)nullptr, o->dtransl_v.p, o->dMv.p, o->dsv.p, ContactGradIn()); if (es) return es; }
-    HIP_TRY(gemm_f32(true, EPI_STORE, o->dVF.p + 2 * nv3, 3 * V, c->full.posedirs.p, c->full.ldp, o->dPF.p + 2 * NPFX, NPFX, nl, NPFX,
-                     3 * V, nullptr, 0, st));
+    HIP_TRY(blend_backward(c->full, o->dVF.p + 2 * nv3, nl, o->dPF.p + 2 * NPFX, 0, c->ws_kpart, st));
     hipLaunchKernelGGL(pose_bwd_kernel, dim3(nl), dim3(64 * POSE_NW), 0, st, pm, o->X.p, o->O.p, o->CAM.p, o->scale.p, 2, o->Rm.p,
                        o->Jrest.p, o->G.p, o->dA.p, o->dPF.p, (const float*)nullptr, o->dMv.p, o->dsv.p, o->dPF.p + NPF, NPFX,
                        o->dtransl_v.p, o->dX.p, o->dO.p, o->dCAM.p, o->dscale_row.p, ParamLossIn(), (const float*)nullptr);

@@ -644,16 +644,120 @@ static inline hipError_t panel_gemm3_rb2k(const float* A, int lda, int M, int K,
     return hipGetLastError();
 }
 
+// ... and for K far beyond any LDS image (r5: the FULL mesh's data gradient, K = 3 V = 31 425 -- BASELINE config 5's contact set, mode
+// 'local', the body-model operator's backward; it ran on the generic fp32 tiles, 387 us at 512 rows and 214 us at 128): K in `ks`
+// parts, a workgroup = (part, column block of 8 tiles, row pair) walks its part slab by slab -- stage the slab's two 16-row images,
+// stream the slab's fragments, accumulate in registers -- and leaves one partial product; panel_part_sum_kernel adds the parts in
+// ascending order.  Workgroup b: role = b % (ks ncb) = (part, column block) -> consecutive workgroups = consecutive roles, so with
+// ks ncb a multiple of 8 an XCD keeps streaming the same eighth of the static operand; row pair = b / (ks ncb).
+template <int RB>
+__global__ __launch_bounds__(512) void panel_gemm3_kloop_kernel(const float* __restrict__ A, int lda, int M, int K, PanelB3 B,
+                                                                float* __restrict__ Cpart, size_t part_stride, int ldc, int N, int ks,
+                                                                int slab_steps) {
+    extern __shared__ __attribute__((aligned(16))) uint4 pn3_lds[];
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, j = lane & 15, g = lane >> 4;
+    const int ncb = (B.ntile + 7) / 8, nrole = ks * ncb;
+    const int role = (int)blockIdx.x % nrole, m0 = ((int)blockIdx.x / nrole) * (16 * RB), part = role / ncb, cb = role % ncb;
+    const int nst_all = (K + 31) >> 5, per = (nst_all + ks - 1) / ks, s_lo = part * per, s_hi = min(nst_all, s_lo + per);
+    const int tile = cb * 8 + wave;
+    const bool active = tile < B.ntile;
+    const int kpad = 32 * slab_steps, pstride = (kpad >> 3) * 16, img = 3 * pstride;
+    f32x4_t acc[RB];
+#pragma unroll
+    for (int rb = 0; rb < RB; ++rb) acc[rb] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+    for (int s0 = s_lo; s0 < s_hi; s0 += slab_steps) {
+        const int nst = min(slab_steps, s_hi - s0), k0 = 32 * s0, kn = min(K, 32 * (s0 + nst)) - k0;
+        PnRing3<2> rg;                                          // (requested before the staging: the first round trip hides behind it)
+        panel3_prefetch<2>(rg, B.f + ((size_t)(active ? tile : 0) * B.nst + s0) * 3 * 64, nst, lane);
+        if (s0 > s_lo) __syncthreads();                         // every wave is done with the previous slab's images
+#pragma unroll
+        for (int rb = 0; rb < RB; ++rb) panel_stage3<512>(pn3_lds + (size_t)rb * img, A, lda, m0 + 16 * rb, M, k0, kn, kpad, tid);
+        __syncthreads();
+        if (active) panel3_mma<RB, 2>(pn3_lds, pstride, img, rg, nst, acc, lane);
+    }
+    const int n4 = tile * 16 + 4 * g;
+    if (active && n4 < N) {
+        float* const C = Cpart + (size_t)part * part_stride;
+#pragma unroll
+        for (int rb = 0; rb < RB; ++rb) {
+            const int m = m0 + 16 * rb + j;
+            if (m < M) {
+                float* dst = C + (size_t)m * ldc + n4;
+                if (n4 + 3 < N) *(f32x4u_t*)dst = f32x4u_t{acc[rb][0], acc[rb][1], acc[rb][2], acc[rb][3]};
+                else {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) if (n4 + r < N) dst[r] = acc[rb][r];
+                }
+            }
+        }
+    }
+}
+__global__ void panel_part_sum_kernel(const float* __restrict__ part, int ks, size_t part_stride, size_t n, float* __restrict__ out) {
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    float s = part[i];
+    for (int p = 1; p < ks; ++p) s += part[(size_t)p * part_stride + i];
+    out[i] = s;
+}
+constexpr int PN3_KLOOP_SLAB = 24;                               // steps (32 columns each) per slab: two 16-row images of 768 columns = 144 KB
+// parts of K for M rows and B's tiles: enough workgroups for 256 CUs, ks x column blocks a multiple of 8 (XCD <-> slice of B), <= 32
+inline int& panel_gemm3_kloop_slab() {                          // FDCAP_KLOOP_SLAB (A/B): steps per slab, 4..24
+    static int v = -1;
+    if (v < 0) { const char* e = getenv("FDCAP_KLOOP_SLAB"); v = e ? std::min(24, std::max(4, atoi(e))) : PN3_KLOOP_SLAB; }
+    return v;
+}
+inline int& panel_gemm3_kloop_rb() {                             // FDCAP_KLOOP_RB (A/B): 16-row blocks per fragment stream, 2 or 4
+    static int v = -1;
+    if (v < 0) { const char* e = getenv("FDCAP_KLOOP_RB"); v = (e && atoi(e) == 2) ? 2 : 4; }
+    return v;
+}
+static inline int panel_gemm3_kloop_parts(int M, const PanelB3& B) {
+    const int rb = panel_gemm3_kloop_rb(), ncb = (B.ntile + 7) / 8, nrp = (M + 16 * rb - 1) / (16 * rb);
+    static int wgs = -1;                                         // FDCAP_KLOOP_WGS (A/B): workgroups to aim for
+    if (wgs < 0) { const char* e = getenv("FDCAP_KLOOP_WGS"); wgs = e ? atoi(e) : 256; }
+    int ks = std::max(1, (wgs + ncb * nrp - 1) / (ncb * nrp));
+    while ((ks * ncb) % 8 != 0 && ks < 64) ++ks;
+    return std::min(ks, 64);
+}
+// C [M rows of ldc] = sum of the parts; `part` must hold ks x M x ldc floats (panel_gemm3_kloop_parts)
+static inline hipError_t panel_gemm3_kloop(const float* A, int lda, int M, int K, const PanelB3& B, float* part, float* C, int ldc, int N,
+                                           hipStream_t st) {
+    if (M <= 0 || N <= 0) return hipSuccess;
+    const int rb = panel_gemm3_kloop_rb(), ks = panel_gemm3_kloop_parts(M, B), ncb = (B.ntile + 7) / 8, nrp = (M + 16 * rb - 1) / (16 * rb);
+    const size_t stride = (size_t)M * ldc;
+    // steps per slab: RB images of 32 x slab columns, 6 bytes each, in <= 147 KB
+    const int slab = std::min(panel_gemm3_kloop_slab(), rb == 4 ? 12 : 24);
+    const size_t lds = (size_t)rb * 6 * 32 * slab * 16;
+    static bool attr = false;
+    if (!attr) {
+        hipError_t e = hipFuncSetAttribute((const void*)panel_gemm3_kloop_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
+        if (e == hipSuccess) e = hipFuncSetAttribute((const void*)panel_gemm3_kloop_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
+        if (e != hipSuccess) return e;
+        attr = true;
+    }
+    if (rb == 4)
+        hipLaunchKernelGGL(panel_gemm3_kloop_kernel<4>, dim3(ks * ncb * nrp), dim3(512), lds, st, A, lda, M, K, B, part, stride, ldc, N, ks, slab);
+    else
+        hipLaunchKernelGGL(panel_gemm3_kloop_kernel<2>, dim3(ks * ncb * nrp), dim3(512), lds, st, A, lda, M, K, B, part, stride, ldc, N, ks, slab);
+    hipLaunchKernelGGL(panel_part_sum_kernel, dim3((unsigned)((stride + 255) / 256)), dim3(256), 0, st, part, ks, stride, stride, C);
+    return hipGetLastError();
+}
+
 // wide outputs on the split: the column-walking form of panel_gemm_wide_kernel (A staged once per workgroup, all the
 // column blocks of the XCD's share walked; next block's fragments requested before the stores)
 template <int RB>
 __global__ __launch_bounds__(512) void panel_gemm3_wide_kernel(const float* __restrict__ A, int lda, int M, int K, PanelB3 B,
-                                                               float* __restrict__ C, int ldc, int N) {
+                                                               float* __restrict__ C, int ldc, int N, int cs) {
+    // cs (r5): an XCD's share of the column blocks is cut into cs parts, one workgroup each per row block -- grid 8 x row blocks x cs.
+    // With cs = 1 a 512-row product (BASELINE config 5) ran on 128 workgroups and a 128-row shard of it on 32: every workgroup
+    // walks an eighth of the 93 MB operand through ONE CU's 64 B / clock, 205-214 us whatever M is (profiles/r5_c5_*).
     extern __shared__ __attribute__((aligned(16))) uint4 pn3_lds[];
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, j = lane & 15, g = lane >> 4;
-    const int xcd = blockIdx.x & 7, m0 = (int)(blockIdx.x >> 3) * (16 * RB);
+    const int nrb = (M + 16 * RB - 1) / (16 * RB);
+    const int xcd = blockIdx.x & 7, slot = (int)(blockIdx.x >> 3), m0 = (slot % nrb) * (16 * RB), part = slot / nrb;
     const int ncb = (B.ntile + 7) / 8, cpg = (ncb + 7) / 8;
-    const int cb0 = xcd * cpg, cb1 = min(ncb, cb0 + cpg);
+    const int xb0 = xcd * cpg, xb1 = min(ncb, xb0 + cpg), per = (max(xb1 - xb0, 0) + cs - 1) / cs;
+    const int cb0 = xb0 + part * per, cb1 = min(xb1, cb0 + per);
     const int kpad = (K + 31) & ~31, nst = kpad >> 5, pstride = (kpad >> 3) * 16, img = 3 * pstride;
     if (cb0 >= cb1) return;
     PnRing3<2> rg;
@@ -695,7 +799,12 @@ static inline hipError_t panel_gemm3(const float* A, int lda, int M, int K, cons
     const int kpad = (K + 31) & ~31;
     if (kpad > PN3_MAX_K) return hipErrorInvalidValue;       // callers fall back to panel_gemm (K slabs) above this
     if ((size_t)B.ntile * B.nst * 3 * 1024 > (size_t)(24u << 20) && M >= 32 && kpad <= 768) {
-        hipLaunchKernelGGL(panel_gemm3_wide_kernel<2>, dim3(8 * ((M + 31) / 32)), dim3(512), (size_t)2 * 6 * kpad * 16, st, A, lda, M, K, B, C, ldc, N);
+        // one workgroup per CU (the 98 KB image leaves room for one): as many column parts as it takes to reach 256 workgroups
+        const int nrb = (M + 31) / 32, ncb = (B.ntile + 7) / 8, cpg = (ncb + 7) / 8;
+        static int cs_env = -1;                          // FDCAP_PN_WIDE_CS=1 (A/B): the r2-r4 form, one part
+        if (cs_env < 0) { const char* e = getenv("FDCAP_PN_WIDE_CS"); cs_env = e ? atoi(e) : 0; }
+        const int cs = cs_env > 0 ? cs_env : std::max(1, std::min(cpg, (256 + 8 * nrb - 1) / (8 * nrb)));
+        hipLaunchKernelGGL(panel_gemm3_wide_kernel<2>, dim3(8 * nrb * cs), dim3(512), (size_t)2 * 6 * kpad * 16, st, A, lda, M, K, B, C, ldc, N, cs);
         return hipGetLastError();
     }
     static int rb2 = -1;                                  // FDCAP_PN_RB2=0 (A/B): one row block per fragment stream everywhere

@@ -191,6 +191,7 @@ struct fdcap_ctx {
     DevBuf<int> ws_i[2];
     DevBuf<float4> ws_p;
     DevBuf<float> ws_skin;          // chunk partials of the split skinning backward (skin_bwd_any)
+    DevBuf<float> ws_kpart;         // K-part partial products of the full-mesh data gradient (blend_backward)
     // Op 1 against the registered scene (fdcap_chamfer_fwd_scene): the previous call's neighbours = the next call's seeds
     struct SceneOp {
         DevBuf<float> dist;
@@ -328,7 +329,7 @@ int build_skin_set(fdcap_ctx* c, const std::vector<int64_t>& ids, SkinSet* out) 
         HIP_TRY(out->pn_fwd3_f.upload(p3.data(), p3.size()));
         out->pn_fwd3.f = (const uint4*)out->pn_fwd3_f.p;
     }
-    if (nv > 0 && panel_gemm3_fits(3 * nv)) {     // ... and the data-gradient operand of small sets (K = 3 nv in one LDS image <= 160 KB)
+    if (nv > 0) {                                 // ... and the data-gradient operand (one LDS image up to K = 1696: panel_gemm3 / _rb2k; beyond: panel_gemm3_kloop)
         std::vector<unsigned> p3;
         panel_pack3(pd.data(), 1, ldp, 3 * nv, NPFX, p3, &out->pn_bwd3.ntile, &out->pn_bwd3.nst);
         HIP_TRY(out->pn_bwd3_f.upload(p3.data(), p3.size()));
@@ -349,6 +350,27 @@ hipError_t blend_forward(const SkinSet& ss, const float* PF, int M, float* Voff,
     if (gemm_split3_enabled() && ss.pn_fwd3.f) return panel_gemm3(PF, NPFX, M, NPFX, ss.pn_fwd3, Voff, 3 * ss.nv, 3 * ss.nv, st);
     if (ss.pn_fwd.f) return panel_gemm(PF, NPFX, M, NPFX, ss.pn_fwd, Voff, 3 * ss.nv, 3 * ss.nv, st);
     return gemm_f32(false, EPI_STORE, PF, NPFX, ss.posedirs.p, ss.ldp, Voff, 3 * ss.nv, M, 3 * ss.nv, NPFX, nullptr, 0, st);
+}
+
+// its data gradient: dPF[M, 496] = dVoff[M, 3 nv] x [posedirs ; shapedirs^T]^T.  *split (optional): the product was left as TWO partial
+// sums, dPF and dPF + part2_stride (the consumer adds them: pose_bwd_kernel's dPF2); without it the sum is formed here.
+hipError_t blend_backward(const SkinSet& ss, const float* dV, int M, float* dPF, size_t part2_stride, DevBuf<float>& ws, hipStream_t st,
+                          bool* split = nullptr) {
+    TraceRange tr_("fdcap:blend_bwd(K8)");
+    if (split) *split = false;
+    const int K = 3 * ss.nv;
+    if (gemm_split3_enabled() && ss.pn_bwd3.f) {
+        if (split && part2_stride && panel_gemm3_rb2k_ok(M, K, ss.pn_bwd3)) {
+            *split = true;
+            return panel_gemm3_rb2k(dV, K, M, K, ss.pn_bwd3, dPF, part2_stride, NPFX, NPFX, st);
+        }
+        if (panel_gemm3_fits(K)) return panel_gemm3(dV, K, M, K, ss.pn_bwd3, dPF, NPFX, NPFX, st);
+        hipError_t e = ws.ensure((size_t)panel_gemm3_kloop_parts(M, ss.pn_bwd3) * M * NPFX);
+        if (e != hipSuccess) return e;
+        return panel_gemm3_kloop(dV, K, M, K, ss.pn_bwd3, ws.p, dPF, NPFX, NPFX, st);
+    }
+    if (ss.pn_bwd.f) return panel_gemm(dV, K, M, K, ss.pn_bwd, dPF, NPFX, NPFX, st);
+    return gemm_f32(true, EPI_STORE, dV, K, ss.posedirs.p, ss.ldp, dPF, NPFX, M, NPFX, K, nullptr, 0, st);
 }
 
 // VPoser decoder forward for rows [row_lo, row_hi) of X (latent read in place at column latent_off): H1, H2 and the four
