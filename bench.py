@@ -631,11 +631,15 @@ def main():
     pk = pmc.get("kernels", {})
     quoted = cfg == "c3"
     roofline, nn = nn_roofline(pk, pmc_src, sec_loop, ms_steady, n_inloop, alg_bytes)
-    bf = counter_fracs(pk.get("nn_bruteforce"), sec_bf) if quoted else None
-    if not bf and quoted:                                  # (the brute-force launch is not in the r5 passes' command: r4's summary has it)
-        old = os.path.join(ROOT, "profiles", "r4_pmc_summary.json")
-        if os.path.exists(old):
-            bf = counter_fracs(json.load(open(old)).get("kernels", {}).get("nn_bruteforce"), sec_bf)
+    # (the brute-force launch and the wide GEMM are not in the r5 per-configuration command: their counters come from the passes of
+    #  the full bench command, profiles/r5_c3_ops_pmc_summary.json -- r4's summary before that file existed)
+    ops_pk = {}
+    for name in ("r5_c3_ops_pmc_summary.json", "r4_pmc_summary.json"):
+        fn = os.path.join(ROOT, "profiles", name)
+        if quoted and os.path.exists(fn):
+            ops_pk = json.load(open(fn)).get("kernels", {})
+            break
+    bf = counter_fracs(pk.get("nn_bruteforce") or ops_pk.get("nn_bruteforce"), sec_bf) if quoted else None
     roofline["brute_force"] = {
         "kernel": "fdc::nn_mfma_kernel<4> (every (query, scene point) pair visited: the launch the algorithmic byte count describes; "
                   "operator API for foreign targets, not part of the loop)",
@@ -655,11 +659,7 @@ def main():
     gflop = 2.0 * nl * 496 * 3 * args.verts / 1e9         # operand rows [pose feature 486 | betas 10]
     split3 = os.environ.get("FDCAP_GEMM_SPLIT3", "1") != "0"
     tf = gflop / ms_g.value                                 # useful fp32 multiply-adds, TFLOP/s
-    wide = counter_fracs(pk.get("blend_wide")) if cfg else None
-    if not wide and quoted:
-        old = os.path.join(ROOT, "profiles", "r4_pmc_summary.json")
-        if os.path.exists(old):
-            wide = counter_fracs(json.load(open(old)).get("kernels", {}).get("blend_wide"))
+    wide = counter_fracs(ops_pk.get("blend_wide")) if quoted else None
     if split3:
         ex = 6.0 * tf * 512.0 / 496.0                       # six bf16 MFMAs per product term, K padded 496 -> 512
         blend = {"kernel": "fdc::panel_gemm3_wide_kernel<2> (pose + shape blendshapes [F,496] x [496,3V]; fp32 operands as three bf16 parts, "

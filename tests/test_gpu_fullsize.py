@@ -114,7 +114,7 @@ def test_short_fit_is_reproducible_finite_and_descends(assets):
                                      # eight iterations of it need not be monotone)
 
 
-def test_clip_sized_kernel_forms_give_the_same_gradient(assets):
+def test_clip_sized_kernel_forms_give_the_same_gradient(assets, tmp_path):
     """At this size the blend products run on two row blocks per fragment stream (the data gradient as two K halves added by
     pose_bwd_kernel); FDCAP_PN_RB2=0 selects the one-row-block kernels.  Same products, another summation order in the data
     gradient: gradients agree to rounding of the sums."""
@@ -140,7 +140,7 @@ np.save(sys.argv[1], dx.cpu().numpy())
 ''' % os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     grads = []
     for flag in ("0", "1"):
-        out = "/tmp/fdcap_fullsize_grad_%s.npy" % flag
+        out = str(tmp_path / ("fullsize_grad_%s.npy" % flag))        # (pytest's per-test directory: two suites on one box do not collide)
         env = dict(os.environ, FDCAP_PN_RB2=flag)
         subprocess.run([sys.executable, "-c", code, out], check=True, env=env, timeout=600)   # (the switch is read once per process)
         grads.append(np.load(out))
