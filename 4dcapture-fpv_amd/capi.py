@@ -156,7 +156,7 @@ def load_library(path: str | None = None) -> ctypes.CDLL:
     info = lib.fdcap_build_info().decode()
     if "packed_fp32=off" not in info and os.environ.get("FDCAP_ALLOW_PK_F32") != "1":
         raise FdcapError(f"{p} was built with packed fp32 instructions ({info}): results are not reliable next to another kernel's "
-                         "MFMAs on the same CU (DESIGN.md section 7).  Rebuild with __graft_entry__.build(), or set "
+                         "MFMAs on the same CU (NOTES.md section 6).  Rebuild with __graft_entry__.build(), or set "
                          "FDCAP_ALLOW_PK_F32=1 for an instrumentation variant.")
     if path is None:
         _lib = lib

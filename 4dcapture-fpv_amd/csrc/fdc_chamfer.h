@@ -2,7 +2,7 @@
 // Replaces ChamferDistancePytorch's NmDistanceKernel as called at
 // /root/reference/global_optimization.py:292-294 (only dist1 = query -> scene is consumed).
 //
-// Layout decisions (DESIGN.md §5):
+// Layout decisions (DESIGN.md §4, §5.1):
 //   * the scene is stored ONCE as float4 {x, y, z, bits(index)} and shared by every frame; all
 //     frames' contact vertices form one flat query array, so a scene tile staged in LDS is
 //     reused by every query of a workgroup, whatever frame it belongs to (the reference re-reads a

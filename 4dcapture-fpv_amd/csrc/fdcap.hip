@@ -8,7 +8,7 @@
 #include <algorithm>
 #include <vector>
 
-// Build requirement: this file is compiled WITHOUT packed fp32 instructions
+// Build requirement (the finding: NOTES.md section 6): this file is compiled WITHOUT packed fp32 instructions
 //   -Xclang -target-feature -Xclang -packed-fp32-ops -DFDC_BUILD_NO_PK_F32
 // (on the MI355X boxes this was developed on, v_pk_{fma,mul,add}_f32 now and then return a wrong low element while another
 // kernel's MFMAs share the CU: tools/pk_f32_mfma_repro.hip).  The define travels with the flag so that a build script which

@@ -1,6 +1,6 @@
 """Helpers for the tests that run TWO rank processes on the ONE GPU of the test box.
 
-Round 3 found that such runs were not perfectly repeatable; round 4 found why, down to the instruction (DESIGN.md section 7,
+Round 3 found that such runs were not perfectly repeatable; round 4 found why, down to the instruction (NOTES.md section 6,
 tools/pk_f32_mfma_repro.hip): on the MI355X boxes of this pool `v_pk_fma_f32` with an op_sel modifier that makes the low result
 take the HIGH half of src2 now and then drops its addend in lanes 48-63 while ANOTHER kernel's MFMAs run on the same CU -- a
 second stream or a second process running this library's matrix kernels next to its one-wave pose kernels.  The library is built

@@ -1,6 +1,6 @@
 """Two kernels of this library resident on the GPU at once must not change anybody's results.
 
-Round 3: built WITH packed fp32 instructions, work that ran next to the full-mesh blend product on a
+Round 3 (NOTES.md section 6): built WITH packed fp32 instructions, work that ran next to the full-mesh blend product on a
 second stream came back with a wrong word in a finger joint's transform now and then on the boxes of this pool (30 of 30
 100-iteration fits had at least one; the parameters moved whenever the joint's own rotation was hit); built without them,
 never.  This test is the tripwire for that build flag (__graft_entry__.build) and for anything else that makes co-resident

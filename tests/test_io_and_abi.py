@@ -28,7 +28,7 @@ def test_header_symbols_are_exported_and_bound():
 
 
 def test_library_is_built_without_packed_fp32_instructions():
-    """The build requirement at the top of csrc/fdcap.hip, enforced on the artefact that ships: the
+    """The build requirement at the top of csrc/fdcap.hip (NOTES.md section 6), enforced on the artefact that ships: the
     library says so (fdcap_build_info, which capi.load_library also insists on) AND its gfx950 code object holds no
     v_pk_{fma,mul,add}_f32 -- a build script that passed the define without the target feature would fail here."""
     lib = capi.load_library()

@@ -1,4 +1,4 @@
-// Stand-alone reproducer of DESIGN.md section 7: on the MI355X boxes of this pool a packed fp32 instruction whose
+// Stand-alone reproducer of NOTES.md section 6: on the MI355X boxes of this pool a packed fp32 instruction whose
 // op_sel modifier makes the LOW result take the HIGH half of src2,
 //     v_pk_fma_f32 K, B, B, R op_sel:[0,0,1] op_sel_hi:[1,1,0]        (K.lo = B.lo * B.lo + R.hi,  K.hi = B.hi * B.hi + R.lo)
 // returns K.lo = B.lo * B.lo + 0 -- the addend is dropped -- in lanes 48-63 of the wave, now and then, WHILE ANOTHER KERNEL'S MFMAs

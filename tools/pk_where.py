@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Which of pose_fwd_kernel's outputs carries the wrong word of DESIGN.md section 7?  Library built with packed fp32 AND the debug
+"""Which of pose_fwd_kernel's outputs carries the wrong word of NOTES.md section 6?  Library built with packed fp32 AND the debug
 buffer taps (FDC_PK=+ tools/build_variant.sh pkdbg -DFDC_DEBUG_BUFFERS): the optimiser's forward on stream 1 next to the full-mesh
 blend product on stream 2, every repetition's Rm (local rotations), Jrest (rest joints), G (world transforms), A (skinning
 transforms), PF (pose features) compared with the same forward run alone."""
