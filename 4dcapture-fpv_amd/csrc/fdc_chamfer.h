@@ -475,6 +475,9 @@ constexpr int ST4_MAXCELL = FDC_ST4_MAXCELL;   // chunks one wave can list befor
 #ifndef FDC_AS_MAX
 #define FDC_AS_MAX 3.f
 #endif
+#ifndef FDC_AS_NEAR
+#define FDC_AS_NEAR 0.8f
+#endif
 #ifndef FDC_ST4_OCC
 #define FDC_ST4_OCC 8
 #endif
@@ -672,6 +675,15 @@ __global__ __launch_bounds__(64 * WPB, NQ == 1 ? FDC_ST4_OCC : FDC_ST4_OCC2) voi
 #endif
         }
     }
+    // The slack of ONE query: the wave's (speed-adaptive) slack for a query near its neighbour; for a far one scaled down by
+    // FDC_AS_NEAR / radius, never below the configured slack.  A ball of radius r inflated by s reaches sqrt(2 r s) sideways over a
+    // surface it hovers above: with 9 cm on a query 1.5 m from the floor that is half a metre of floor in every direction -- BASELINE
+    // config 5's lists (every vertex a query, most of them far) grew past what is kept and its mean launch 10 % (1154 -> 1272 us).
+    // (FDC_AS_NEAR 0.8 m: config 5 789 -> 770 ms per fit, config 3 unchanged; 0.4: 764, config 3 within noise; 0.15: config 3 +1.3 %)
+    auto slack_of = [&](float r) -> float {
+        const float sw = __int_as_float(slk);
+        return r <= FDC_AS_NEAR ? sw : fmaxf(cache.slack, sw * (FDC_AS_NEAR / r));
+    };
     // the radii / squared bounds the list is BUILT for: inflated by the slack when the list is going to be kept
     float sbT[NQ];
     float glx = INFINITY, gly = INFINITY, glz = INFINITY, ghx = -INFINITY, ghy = -INFINITY, ghz = -INFINITY;
@@ -680,7 +692,7 @@ __global__ __launch_bounds__(64 * WPB, NQ == 1 ? FDC_ST4_OCC : FDC_ST4_OCC2) voi
         float rT[NQ];
 #pragma unroll
         for (int n = 0; n < NQ; ++n) {
-            rT[n] = inflate ? rq[n] + __int_as_float(slk) : rq[n];
+            rT[n] = inflate ? rq[n] + slack_of(rq[n]) : rq[n];
             sbT[n] = (qidx[n] < nq) ? (inflate ? rT[n] * rT[n] * 1.00002f : sb[n]) : -INFINITY;
         }
         // Group bound for the box tests: the axis-aligned box around the queries' balls (centre x_i, radius r_i).
@@ -835,7 +847,7 @@ __global__ __launch_bounds__(64 * WPB, NQ == 1 ? FDC_ST4_OCC : FDC_ST4_OCC2) voi
                 for (int n = 0; n < NQ; ++n)
                     if (qidx[n] < nq)                              // R_i with the validity test's rounding margin taken off; no list: never valid
                         cache.anchor[(size_t)sub * nq + qidx[n]] =
-                            make_float4(qx[n], qy[n], qz[n], keep ? (rq[n] + __int_as_float(slk)) * 0.99998f - 2e-6f : -1.f);
+                            make_float4(qx[n], qy[n], qz[n], keep ? (rq[n] + slack_of(rq[n])) * 0.99998f - 2e-6f : -1.f);
             }
         }
         if (!listed) nsurv = 4 * myn;                           // list overflow: scan this wave's whole share (still exact)
