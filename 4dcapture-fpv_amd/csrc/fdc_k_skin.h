@@ -168,20 +168,54 @@ __global__ __launch_bounds__(256) void skin_bwd_kernel(SkinModel sm, int nc, con
         // to the 4 waves; a wave's lanes stride over joint j's vertex list (ascending, restricted to this
         // chunk by two binary searches) and are combined by a butterfly
         // the non-empty joints (one ballot over the preloaded list bounds) are dealt to the four waves in turn
-        unsigned long long jact = __ballot(jhi > jlo);
-        for (int kact = 0; jact; ++kact) {
-            const int j = __ffsll((long long)jact) - 1;
-            jact &= jact - 1;
-            if ((kact & 3) != wave) continue;               // wave-uniform
-            int lo = __builtin_amdgcn_readlane(jlo, j), hi = __builtin_amdgcn_readlane(jhi, j);
-            if (nc > VCH) {                                 // this chunk's part of the list: two table entries (r5; was two binary searches)
-                lo = __builtin_amdgcn_readlane(clo, j); hi = __builtin_amdgcn_readlane(chi, j);
-                if (lo == hi) continue;
+        // r5: the lists live in global memory here (any vertex set, any size), and a joint's walk was two dependent round trips -- the
+        // entries, then the LDS rows they name -- in front of its twelve wave sums: 40 of a chunk workgroup's 64 k cycles at 10 475
+        // vertices.  The first 128 entries of the NEXT joint of this wave are requested before the current joint is summed.
+        unsigned long long jact = __ballot(nc > VCH ? chi > clo : jhi > jlo);
+        int kact = 0;
+        auto next_joint = [&](int* lo, int* hi) -> int {    // this wave's next non-empty joint (wave-uniform), -1: none
+            while (jact) {
+                const int j = __ffsll((long long)jact) - 1;
+                jact &= jact - 1;
+                if ((kact++ & 3) != wave) continue;
+                *lo = __builtin_amdgcn_readlane(nc > VCH ? clo : jlo, j);
+                *hi = __builtin_amdgcn_readlane(nc > VCH ? chi : jhi, j);
+                return j;
             }
+            return -1;
+        };
+        auto fetch = [&](int lo, int hi, float* w, int* v) {  // entries lo + lane, lo + 64 + lane (clamped: unconditional loads)
+#pragma unroll
+            for (int k = 0; k < 2; ++k) {
+                const int i = min(lo + 64 * k + lane, max(hi - 1, lo));
+                w[k] = sm.csc_w[i];
+                v[k] = sm.csc_v[i];
+            }
+        };
+        int lo = 0, hi = 0, lo_n = 0, hi_n = 0;
+        float wn[2] = {0.f, 0.f};
+        int vn[2] = {0, 0};
+        int j = next_joint(&lo, &hi);
+        if (j >= 0) fetch(lo, hi, wn, vn);
+        while (j >= 0) {
+            const float w0 = wn[0], w1 = wn[1];
+            const int v0 = vn[0], v1 = vn[1];
+            const int jn = next_joint(&lo_n, &hi_n);
+            if (jn >= 0) fetch(lo_n, hi_n, wn, vn);
             float pa[12];
 #pragma unroll
             for (int e = 0; e < 12; ++e) pa[e] = 0.f;
-            for (int i = lo + lane; i < hi; i += 64) {
+            if (lo + lane < hi) {
+                const float* t = sdT + (v0 - c0) * 12;
+#pragma unroll
+                for (int e = 0; e < 12; ++e) pa[e] += w0 * t[e];
+            }
+            if (lo + 64 + lane < hi) {
+                const float* t = sdT + (v1 - c0) * 12;
+#pragma unroll
+                for (int e = 0; e < 12; ++e) pa[e] += w1 * t[e];
+            }
+            for (int i = lo + 128 + lane; i < hi; i += 64) {
                 const float w = sm.csc_w[i];
                 const float* t = sdT + (sm.csc_v[i] - c0) * 12;
 #pragma unroll
@@ -192,6 +226,7 @@ __global__ __launch_bounds__(256) void skin_bwd_kernel(SkinModel sm, int nc, con
                 float v = wave_sum(pa[e]);
                 if (lane == 0) sdA[j * 12 + e] += v;
             }
+            j = jn; lo = lo_n; hi = hi_n;
         }
         __syncthreads();
     }

@@ -644,105 +644,6 @@ static inline hipError_t panel_gemm3_rb2k(const float* A, int lda, int M, int K,
     return hipGetLastError();
 }
 
-// ... and for K far beyond any LDS image (r5: the FULL mesh's data gradient, K = 3 V = 31 425 -- BASELINE config 5's contact set, mode
-// 'local', the body-model operator's backward; it ran on the generic fp32 tiles, 387 us at 512 rows and 214 us at 128): K in `ks`
-// parts, a workgroup = (part, column block of 8 tiles, row pair) walks its part slab by slab -- stage the slab's two 16-row images,
-// stream the slab's fragments, accumulate in registers -- and leaves one partial product; panel_part_sum_kernel adds the parts in
-// ascending order.  Workgroup b: role = b % (ks ncb) = (part, column block) -> consecutive workgroups = consecutive roles, so with
-// ks ncb a multiple of 8 an XCD keeps streaming the same eighth of the static operand; row pair = b / (ks ncb).
-template <int RB>
-__global__ __launch_bounds__(512) void panel_gemm3_kloop_kernel(const float* __restrict__ A, int lda, int M, int K, PanelB3 B,
-                                                                float* __restrict__ Cpart, size_t part_stride, int ldc, int N, int ks,
-                                                                int slab_steps) {
-    extern __shared__ __attribute__((aligned(16))) uint4 pn3_lds[];
-    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, j = lane & 15, g = lane >> 4;
-    const int ncb = (B.ntile + 7) / 8, nrole = ks * ncb;
-    const int role = (int)blockIdx.x % nrole, m0 = ((int)blockIdx.x / nrole) * (16 * RB), part = role / ncb, cb = role % ncb;
-    const int nst_all = (K + 31) >> 5, per = (nst_all + ks - 1) / ks, s_lo = part * per, s_hi = min(nst_all, s_lo + per);
-    const int tile = cb * 8 + wave;
-    const bool active = tile < B.ntile;
-    const int kpad = 32 * slab_steps, pstride = (kpad >> 3) * 16, img = 3 * pstride;
-    f32x4_t acc[RB];
-#pragma unroll
-    for (int rb = 0; rb < RB; ++rb) acc[rb] = f32x4_t{0.f, 0.f, 0.f, 0.f};
-    for (int s0 = s_lo; s0 < s_hi; s0 += slab_steps) {
-        const int nst = min(slab_steps, s_hi - s0), k0 = 32 * s0, kn = min(K, 32 * (s0 + nst)) - k0;
-        PnRing3<2> rg;                                          // (requested before the staging: the first round trip hides behind it)
-        panel3_prefetch<2>(rg, B.f + ((size_t)(active ? tile : 0) * B.nst + s0) * 3 * 64, nst, lane);
-        if (s0 > s_lo) __syncthreads();                         // every wave is done with the previous slab's images
-#pragma unroll
-        for (int rb = 0; rb < RB; ++rb) panel_stage3<512>(pn3_lds + (size_t)rb * img, A, lda, m0 + 16 * rb, M, k0, kn, kpad, tid);
-        __syncthreads();
-        if (active) panel3_mma<RB, 2>(pn3_lds, pstride, img, rg, nst, acc, lane);
-    }
-    const int n4 = tile * 16 + 4 * g;
-    if (active && n4 < N) {
-        float* const C = Cpart + (size_t)part * part_stride;
-#pragma unroll
-        for (int rb = 0; rb < RB; ++rb) {
-            const int m = m0 + 16 * rb + j;
-            if (m < M) {
-                float* dst = C + (size_t)m * ldc + n4;
-                if (n4 + 3 < N) *(f32x4u_t*)dst = f32x4u_t{acc[rb][0], acc[rb][1], acc[rb][2], acc[rb][3]};
-                else {
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) if (n4 + r < N) dst[r] = acc[rb][r];
-                }
-            }
-        }
-    }
-}
-__global__ void panel_part_sum_kernel(const float* __restrict__ part, int ks, size_t part_stride, size_t n, float* __restrict__ out) {
-    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
-    if (i >= n) return;
-    float s = part[i];
-    for (int p = 1; p < ks; ++p) s += part[(size_t)p * part_stride + i];
-    out[i] = s;
-}
-constexpr int PN3_KLOOP_SLAB = 24;                               // steps (32 columns each) per slab: two 16-row images of 768 columns = 144 KB
-// parts of K for M rows and B's tiles: enough workgroups for 256 CUs, ks x column blocks a multiple of 8 (XCD <-> slice of B), <= 32
-inline int& panel_gemm3_kloop_slab() {                          // FDCAP_KLOOP_SLAB (A/B): steps per slab, 4..24
-    static int v = -1;
-    if (v < 0) { const char* e = getenv("FDCAP_KLOOP_SLAB"); v = e ? std::min(24, std::max(4, atoi(e))) : PN3_KLOOP_SLAB; }
-    return v;
-}
-inline int& panel_gemm3_kloop_rb() {                             // FDCAP_KLOOP_RB (A/B): 16-row blocks per fragment stream, 2 or 4
-    static int v = -1;
-    if (v < 0) { const char* e = getenv("FDCAP_KLOOP_RB"); v = (e && atoi(e) == 2) ? 2 : 4; }
-    return v;
-}
-static inline int panel_gemm3_kloop_parts(int M, const PanelB3& B) {
-    const int rb = panel_gemm3_kloop_rb(), ncb = (B.ntile + 7) / 8, nrp = (M + 16 * rb - 1) / (16 * rb);
-    static int wgs = -1;                                         // FDCAP_KLOOP_WGS (A/B): workgroups to aim for
-    if (wgs < 0) { const char* e = getenv("FDCAP_KLOOP_WGS"); wgs = e ? atoi(e) : 256; }
-    int ks = std::max(1, (wgs + ncb * nrp - 1) / (ncb * nrp));
-    while ((ks * ncb) % 8 != 0 && ks < 64) ++ks;
-    return std::min(ks, 64);
-}
-// C [M rows of ldc] = sum of the parts; `part` must hold ks x M x ldc floats (panel_gemm3_kloop_parts)
-static inline hipError_t panel_gemm3_kloop(const float* A, int lda, int M, int K, const PanelB3& B, float* part, float* C, int ldc, int N,
-                                           hipStream_t st) {
-    if (M <= 0 || N <= 0) return hipSuccess;
-    const int rb = panel_gemm3_kloop_rb(), ks = panel_gemm3_kloop_parts(M, B), ncb = (B.ntile + 7) / 8, nrp = (M + 16 * rb - 1) / (16 * rb);
-    const size_t stride = (size_t)M * ldc;
-    // steps per slab: RB images of 32 x slab columns, 6 bytes each, in <= 147 KB
-    const int slab = std::min(panel_gemm3_kloop_slab(), rb == 4 ? 12 : 24);
-    const size_t lds = (size_t)rb * 6 * 32 * slab * 16;
-    static bool attr = false;
-    if (!attr) {
-        hipError_t e = hipFuncSetAttribute((const void*)panel_gemm3_kloop_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
-        if (e == hipSuccess) e = hipFuncSetAttribute((const void*)panel_gemm3_kloop_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
-        if (e != hipSuccess) return e;
-        attr = true;
-    }
-    if (rb == 4)
-        hipLaunchKernelGGL(panel_gemm3_kloop_kernel<4>, dim3(ks * ncb * nrp), dim3(512), lds, st, A, lda, M, K, B, part, stride, ldc, N, ks, slab);
-    else
-        hipLaunchKernelGGL(panel_gemm3_kloop_kernel<2>, dim3(ks * ncb * nrp), dim3(512), lds, st, A, lda, M, K, B, part, stride, ldc, N, ks, slab);
-    hipLaunchKernelGGL(panel_part_sum_kernel, dim3((unsigned)((stride + 255) / 256)), dim3(256), 0, st, part, ks, stride, stride, C);
-    return hipGetLastError();
-}
-
 // wide outputs on the split: the column-walking form of panel_gemm_wide_kernel (A staged once per workgroup, all the
 // column blocks of the XCD's share walked; next block's fragments requested before the stores)
 template <int RB>
@@ -810,6 +711,8 @@ static inline hipError_t panel_gemm3(const float* A, int lda, int M, int K, cons
     static int rb2 = -1;                                  // FDCAP_PN_RB2=0 (A/B): one row block per fragment stream everywhere
     if (rb2 < 0) { const char* e = getenv("FDCAP_PN_RB2"); rb2 = e ? atoi(e) : 1; }
     if ((rb2 == 1 || rb2 == 2) && M >= 384 && kpad <= 768 && B.ntile >= 48) {   // (measured: 256 rows 50.2 vs 49.8 ms per step, 384 rows 56.7 vs 57.8)
+        // (r5: six waves x two tiles over the same 32 x 192 block -- half the LDS bytes per MFMA, the lever that took the K-loop
+        //  product from 192 to 139 us -- is SLOWER here: 14.4 vs 12.8 us; with K = 512 the twelve waves' latency hiding is worth more)
         hipLaunchKernelGGL(panel_gemm3_rb2_kernel, dim3(8 * ((M + 31) / 32)), dim3(768), (size_t)2 * 6 * kpad * 16, st, A, lda, M, K, B, C, ldc, N);
         return hipGetLastError();
     }
@@ -975,6 +878,200 @@ __device__ __forceinline__ void panel3_mma_t(const uint4* __restrict__ sA3, int 
         }
     }
 }
+// RB row blocks x T tiles per wave (r5, the K-loop product): a step's RB LDS fragments are read ONCE for T tiles and its T static
+// fragments once for RB row blocks -- RB T products per (RB LDS reads + T fragment loads).  acc[rb * T + t].
+template <int RB, int T, int PF>
+__device__ __forceinline__ void panel3_mma_rt(const uint4* __restrict__ sA3, int pstride, int img, PnRing3T<T, PF>& rg, int nst, f32x4_t* acc, int lane) {
+    uint4 (&bA)[T][PF][3] = rg.bA;
+    uint4 bB[T][PF][3];
+    const int last = nst - 1;
+    auto load_a = [&](uint4 (*a)[3], int step) {
+#pragma unroll
+        for (int rb = 0; rb < RB; ++rb)
+#pragma unroll
+            for (int pl = 0; pl < 3; ++pl) a[rb][pl] = sA3[(size_t)rb * img + (size_t)pl * pstride + (size_t)step * 64 + lane];
+    };
+    uint4 a[RB][3];
+    load_a(a, 0);
+    auto mma = [&](uint4 (*b)[PF][3], int p) {
+#pragma unroll
+        for (int t = 0; t < T; ++t)
+#pragma unroll
+            for (int rb = 0; rb < RB; ++rb) acc[rb * T + t] = pn3_step(a[rb], b[t][p], acc[rb * T + t]);
+    };
+    auto next_a = [&](int step) {
+        uint4 an[RB][3];
+        load_a(an, step);
+        return an;
+    };
+    int s = 0;
+    for (; s + 2 * PF <= nst; s += 2 * PF) {
+#pragma unroll
+        for (int p = 0; p < PF; ++p) {
+            uint4 an[RB][3];
+            load_a(an, s + p + 1);
+#pragma unroll
+            for (int t = 0; t < T; ++t)
+#pragma unroll
+                for (int pl = 0; pl < 3; ++pl) bB[t][p][pl] = rg.st[t][((size_t)(s + PF + p) * 3 + pl) * 64];
+            pn_pin();
+            mma(bA, p);
+#pragma unroll
+            for (int rb = 0; rb < RB; ++rb) { a[rb][0] = an[rb][0]; a[rb][1] = an[rb][1]; a[rb][2] = an[rb][2]; }
+        }
+#pragma unroll
+        for (int p = 0; p < PF; ++p) {
+            uint4 an[RB][3];
+            load_a(an, min(s + PF + p + 1, last));
+#pragma unroll
+            for (int t = 0; t < T; ++t)
+#pragma unroll
+                for (int pl = 0; pl < 3; ++pl) bA[t][p][pl] = rg.st[t][((size_t)min(s + 2 * PF + p, last) * 3 + pl) * 64];
+            pn_pin();
+            mma(bB, p);
+#pragma unroll
+            for (int rb = 0; rb < RB; ++rb) { a[rb][0] = an[rb][0]; a[rb][1] = an[rb][1]; a[rb][2] = an[rb][2]; }
+        }
+    }
+#pragma unroll
+    for (int p = 0; p < PF; ++p) {
+        if (s + p < nst) {
+            uint4 an[RB][3];
+            load_a(an, min(s + p + 1, last));
+#pragma unroll
+            for (int t = 0; t < T; ++t)
+#pragma unroll
+                for (int pl = 0; pl < 3; ++pl) bB[t][p][pl] = rg.st[t][((size_t)min(s + PF + p, last) * 3 + pl) * 64];
+            mma(bA, p);
+#pragma unroll
+            for (int rb = 0; rb < RB; ++rb) { a[rb][0] = an[rb][0]; a[rb][1] = an[rb][1]; a[rb][2] = an[rb][2]; }
+        }
+    }
+#pragma unroll
+    for (int p = 0; p < PF - 1; ++p) {
+        if (s + PF + p < nst) {
+            uint4 an[RB][3];
+            load_a(an, min(s + PF + p + 1, last));
+            mma(bB, p);
+#pragma unroll
+            for (int rb = 0; rb < RB; ++rb) { a[rb][0] = an[rb][0]; a[rb][1] = an[rb][1]; a[rb][2] = an[rb][2]; }
+        }
+    }
+    (void)next_a;
+}
+// ... and for K far beyond any LDS image (r5: the FULL mesh's data gradient, K = 3 V = 31 425 -- BASELINE config 5's contact set, mode
+// 'local', the body-model operator's backward; it ran on the generic fp32 tiles, 387 us at 512 rows and 214 us at 128): K in `ks`
+// parts, a workgroup = (part, column block of 8 tiles, row pair) walks its part slab by slab -- stage the slab's two 16-row images,
+// stream the slab's fragments, accumulate in registers -- and leaves one partial product; panel_part_sum_kernel adds the parts in
+// ascending order.  Workgroup b: role = b % (ks ncb) = (part, column block) -> consecutive workgroups = consecutive roles, so with
+// ks ncb a multiple of 8 an XCD keeps streaming the same eighth of the static operand; row pair = b / (ks ncb).
+template <int RB, int T>
+__global__ __launch_bounds__(512) void panel_gemm3_kloop_kernel(const float* __restrict__ A, int lda, int M, int K, PanelB3 B,
+                                                                float* __restrict__ Cpart, size_t part_stride, int ldc, int N, int ks,
+                                                                int slab_steps) {
+    extern __shared__ __attribute__((aligned(16))) uint4 pn3_lds[];
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, j = lane & 15, g = lane >> 4;
+    const int ncb = (B.ntile + 8 * T - 1) / (8 * T), nrole = ks * ncb;
+    const int role = (int)blockIdx.x % nrole, m0 = ((int)blockIdx.x / nrole) * (16 * RB), part = role / ncb, cb = role % ncb;
+    const int nst_all = (K + 31) >> 5, per = (nst_all + ks - 1) / ks, s_lo = part * per, s_hi = min(nst_all, s_lo + per);
+    const int tile0 = (cb * 8 + wave) * T;                      // this wave's T consecutive column tiles
+    const int kpad = 32 * slab_steps, pstride = (kpad >> 3) * 16, img = 3 * pstride;
+    f32x4_t acc[RB * T];
+#pragma unroll
+    for (int i = 0; i < RB * T; ++i) acc[i] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+    for (int s0 = s_lo; s0 < s_hi; s0 += slab_steps) {
+        const int nst = min(slab_steps, s_hi - s0), k0 = 32 * s0, kn = min(K, 32 * (s0 + nst)) - k0;
+        PnRing3T<T, 2> rg;                                      // (requested before the staging: the first round trip hides behind it)
+        const uint4* bf[T];
+#pragma unroll
+        for (int t = 0; t < T; ++t) bf[t] = B.f + ((size_t)min(tile0 + t, B.ntile - 1) * B.nst + s0) * 3 * 64;
+        panel3_prefetch_t<T, 2>(rg, bf, nst, lane);
+        if (s0 > s_lo) __syncthreads();                         // every wave is done with the previous slab's images
+#pragma unroll
+        for (int rb = 0; rb < RB; ++rb) panel_stage3<512>(pn3_lds + (size_t)rb * img, A, lda, m0 + 16 * rb, M, k0, kn, kpad, tid);
+        __syncthreads();
+        if (tile0 < B.ntile) panel3_mma_rt<RB, T, 2>(pn3_lds, pstride, img, rg, nst, acc, lane);
+    }
+    float* const C = Cpart + (size_t)part * part_stride;
+#pragma unroll
+    for (int t = 0; t < T; ++t) {
+        const int n4 = (tile0 + t) * 16 + 4 * g;
+        if (tile0 + t < B.ntile && n4 < N) {
+#pragma unroll
+            for (int rb = 0; rb < RB; ++rb) {
+                const int m = m0 + 16 * rb + j;
+                if (m < M) {
+                    float* dst = C + (size_t)m * ldc + n4;
+                    const f32x4_t v = acc[rb * T + t];
+                    if (n4 + 3 < N) *(f32x4u_t*)dst = f32x4u_t{v[0], v[1], v[2], v[3]};
+                    else {
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) if (n4 + r < N) dst[r] = v[r];
+                    }
+                }
+            }
+        }
+    }
+}
+__global__ void panel_part_sum_kernel(const float* __restrict__ part, int ks, size_t part_stride, size_t n, float* __restrict__ out) {
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    float s = part[i];
+    for (int p = 1; p < ks; ++p) s += part[(size_t)p * part_stride + i];
+    out[i] = s;
+}
+constexpr int PN3_KLOOP_SLAB = 24;                               // steps (32 columns each) per slab: two 16-row images of 768 columns = 144 KB
+// parts of K for M rows and B's tiles: enough workgroups for 256 CUs, ks x column blocks a multiple of 8 (XCD <-> slice of B), <= 32
+inline int& panel_gemm3_kloop_slab() {                          // FDCAP_KLOOP_SLAB (A/B): steps per slab, 4..24
+    static int v = -1;
+    if (v < 0) { const char* e = getenv("FDCAP_KLOOP_SLAB"); v = e ? std::min(24, std::max(4, atoi(e))) : PN3_KLOOP_SLAB; }
+    return v;
+}
+inline int& panel_gemm3_kloop_rb() {                             // FDCAP_KLOOP_RB (A/B): 16-row blocks per fragment stream, 2 or 4
+    static int v = -1;
+    if (v < 0) { const char* e = getenv("FDCAP_KLOOP_RB"); v = (e && atoi(e) == 4) ? 4 : 2; }
+    return v;
+}
+inline int& panel_gemm3_kloop_t() {                              // FDCAP_KLOOP_T (A/B): column tiles per wave, 1 or 2
+    static int v = -1;
+    if (v < 0) { const char* e = getenv("FDCAP_KLOOP_T"); v = (e && atoi(e) == 1) ? 1 : 2; }
+    return v;
+}
+static inline int panel_gemm3_kloop_parts(int M, const PanelB3& B) {
+    const int rb = panel_gemm3_kloop_rb(), T = panel_gemm3_kloop_t(), ncb = (B.ntile + 8 * T - 1) / (8 * T), nrp = (M + 16 * rb - 1) / (16 * rb);
+    static int wgs = -1;                                         // FDCAP_KLOOP_WGS (A/B): workgroups to aim for
+    if (wgs < 0) { const char* e = getenv("FDCAP_KLOOP_WGS"); wgs = e ? atoi(e) : 256; }
+    int ks = std::max(1, (wgs + ncb * nrp - 1) / (ncb * nrp));
+    while ((ks * ncb) % 8 != 0 && ks < 64) ++ks;
+    return std::min(ks, 64);
+}
+// C [M rows of ldc] = sum of the parts; `part` must hold ks x M x ldc floats (panel_gemm3_kloop_parts)
+static inline hipError_t panel_gemm3_kloop(const float* A, int lda, int M, int K, const PanelB3& B, float* part, float* C, int ldc, int N,
+                                           hipStream_t st) {
+    if (M <= 0 || N <= 0) return hipSuccess;
+    const int rb = panel_gemm3_kloop_rb(), T = panel_gemm3_kloop_t(), ks = panel_gemm3_kloop_parts(M, B), ncb = (B.ntile + 8 * T - 1) / (8 * T), nrp = (M + 16 * rb - 1) / (16 * rb);
+    const size_t stride = (size_t)M * ldc;
+    // steps per slab: RB images of 32 x slab columns, 6 bytes each, in <= 147 KB
+    const int slab = std::min(panel_gemm3_kloop_slab(), rb == 4 ? 12 : 24);   // (measured at 512 / 128 rows: RB 4 T 1 192 / 55 us, RB 2 T 2 139 / 44, RB 4 T 2 166 / 57 with 55 spilled registers)
+    const size_t lds = (size_t)rb * 6 * 32 * slab * 16;
+    static bool attr = false;
+    if (!attr) {
+        hipError_t e = hipSuccess;
+        const void* fs[] = {(const void*)panel_gemm3_kloop_kernel<2, 1>, (const void*)panel_gemm3_kloop_kernel<4, 1>,
+                            (const void*)panel_gemm3_kloop_kernel<2, 2>, (const void*)panel_gemm3_kloop_kernel<4, 2>};
+        for (const void* f : fs)
+            if (e == hipSuccess) e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
+        if (e != hipSuccess) return e;
+        attr = true;
+    }
+    const dim3 grid(ks * ncb * nrp);
+#define FDC_KLOOP(RBV, TV) hipLaunchKernelGGL((panel_gemm3_kloop_kernel<RBV, TV>), grid, dim3(512), lds, st, A, lda, M, K, B, part, stride, ldc, N, ks, slab)
+    if (rb == 4 && T == 2) FDC_KLOOP(4, 2); else if (rb == 4) FDC_KLOOP(4, 1); else if (T == 2) FDC_KLOOP(2, 2); else FDC_KLOOP(2, 1);
+#undef FDC_KLOOP
+    hipLaunchKernelGGL(panel_part_sum_kernel, dim3((unsigned)((stride + 255) / 256)), dim3(256), 0, st, part, ks, stride, stride, C);
+    return hipGetLastError();
+}
+
 // four consecutive columns n4 .. n4 + 3 of frame row j -> the three bf16 planes of an LDS block (8 bytes per plane)
 __device__ __forceinline__ void pn3_store4(uint4* __restrict__ sA3, int pstride, int n4, int j, float4 v) {
     unsigned h[2], m[2], l[2];
