@@ -520,7 +520,11 @@ __device__ __forceinline__ void panel3_mma(const uint4* __restrict__ sA3, int ps
 
 // C[M, N] = A[M, K] x B on the three-way split (same workgroup shape and XCD-aware map as panel_gemm_kernel<1>; K in one
 // slab: kpad <= 2048).  Dynamic LDS: 3 planes x (kpad / 8) x 16 x 16 bytes = 6 kpad bytes per row block.
-__global__ __launch_bounds__(512) void panel_gemm3_kernel(const float* __restrict__ A, int lda, int M, int K, PanelB3 B,
+// NW waves per workgroup = NW column tiles (r5; 8 until then).  A 128-frame shard's products ran on 96 (forward) and 32 (data
+// gradient) workgroups of eight waves -- the gradient's 32 each pulled 1.1 MB of fragments through one CU's return path, 11.5 us
+// for a product of 0.2 GFLOP; with fewer waves per workgroup there are enough workgroups for the chip (launcher: panel_gemm3).
+template <int NW>
+__global__ __launch_bounds__(64 * NW) void panel_gemm3_kernel(const float* __restrict__ A, int lda, int M, int K, PanelB3 B,
                                                           float* __restrict__ C, int ldc, int N, PnMap mp) {
     extern __shared__ __attribute__((aligned(16))) uint4 pn3_lds[];
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, j = lane & 15, g = lane >> 4;
@@ -528,12 +532,12 @@ __global__ __launch_bounds__(512) void panel_gemm3_kernel(const float* __restric
     const int r_in = mp.rfast ? slot % mp.rpg : slot / mp.cpg, c_in = mp.rfast ? slot / mp.rpg : slot % mp.cpg;
     const int rbk = (xcd / mp.xc) * mp.rpg + r_in, cbk = (xcd % mp.xc) * mp.cpg + c_in;
     if (r_in >= mp.rpg || c_in >= mp.cpg || rbk >= mp.nrb || cbk >= mp.ncb) return;  // ragged groups (whole workgroup)
-    const int tile = cbk * 8 + wave, m0 = rbk * 16;
+    const int tile = cbk * NW + wave, m0 = rbk * 16;
     const bool active = tile < B.ntile;
     const int kpad = (K + 31) & ~31, nst = kpad >> 5, pstride = (kpad >> 3) * 16;
     PnRing3<2> rg;
     panel3_prefetch<2>(rg, B.f + (size_t)(active ? tile : 0) * B.nst * 3 * 64, nst, lane);      // in flight while the A block is staged
-    panel_stage3<512>(pn3_lds, A, lda, m0, M, 0, K, kpad, tid);
+    panel_stage3<64 * NW>(pn3_lds, A, lda, m0, M, 0, K, kpad, tid);
     __syncthreads();
     f32x4_t acc = {0.f, 0.f, 0.f, 0.f};
     if (active) panel3_mma<1, 2>(pn3_lds, pstride, 0, rg, nst, &acc, lane);
@@ -717,8 +721,19 @@ static inline hipError_t panel_gemm3(const float* A, int lda, int M, int K, cons
         hipLaunchKernelGGL(panel_gemm3_rb2_kernel, dim3(8 * ((M + 31) / 32)), dim3(768), (size_t)2 * 6 * kpad * 16, st, A, lda, M, K, B, C, ldc, N);
         return hipGetLastError();
     }
-    const PnMap mp = panel_map((M + 15) / 16, (B.ntile + 7) / 8, (size_t)M * K * 4, (size_t)B.ntile * B.nst * 3 * 1024);
-    hipLaunchKernelGGL(panel_gemm3_kernel, dim3(8 * mp.rpg * mp.cpg), dim3(512), (size_t)6 * kpad * 16, st, A, lda, M, K, B, C, ldc, N, mp);
+    // waves per workgroup: eight while that gives >= 192 workgroups, else four, else two (FDCAP_PN_NW pins it: A/B)
+    static int nw_env = -1;
+    if (nw_env < 0) { const char* e = getenv("FDCAP_PN_NW"); nw_env = e ? atoi(e) : 0; }
+    const int nrb = (M + 15) / 16;
+    int nw = 8;                                            // (measured at 128 rows: forward 7.8 -> 6.6 us with four waves; two waves stage too slowly)
+    if (nrb * ((B.ntile + 7) / 8) < 128 && nrb * ((B.ntile + 3) / 4) >= 128) nw = 4;
+    if (nw_env == 8 || nw_env == 4 || nw_env == 2) nw = nw_env;
+    const PnMap mp = panel_map(nrb, (B.ntile + nw - 1) / nw, (size_t)M * K * 4, (size_t)B.ntile * B.nst * 3 * 1024);
+    const dim3 grid(8 * mp.rpg * mp.cpg);
+    const size_t lds = (size_t)6 * kpad * 16;
+    if (nw == 8) hipLaunchKernelGGL(panel_gemm3_kernel<8>, grid, dim3(512), lds, st, A, lda, M, K, B, C, ldc, N, mp);
+    else if (nw == 4) hipLaunchKernelGGL(panel_gemm3_kernel<4>, grid, dim3(256), lds, st, A, lda, M, K, B, C, ldc, N, mp);
+    else hipLaunchKernelGGL(panel_gemm3_kernel<2>, grid, dim3(128), lds, st, A, lda, M, K, B, C, ldc, N, mp);
     return hipGetLastError();
 }
 
@@ -960,6 +975,81 @@ __device__ __forceinline__ void panel3_mma_rt(const uint4* __restrict__ sA3, int
     }
     (void)next_a;
 }
+// Long K, few rows (r5: the data gradient [M,1500] x [1500,496] of a SHARD, M = 128..383 -- too few rows for the two-K-halves form,
+// and as a plain one-row-block product 32 workgroups that each pull 1.1 MB of fragments through one CU: 15 us for 0.2 GFLOP).  K is
+// split over the EIGHT WAVES of a workgroup: every wave streams its eighth of K for the workgroup's T column tiles, the eight partial
+// tiles meet in LDS and are added in wave order -- one output, no partial products in global memory, M / 16 x tiles / T workgroups.
+template <int T>
+__global__ __launch_bounds__(512) void panel_gemm3_ksw_kernel(const float* __restrict__ A, int lda, int M, int K, PanelB3 B,
+                                                              float* __restrict__ C, int ldc, int N, PnMap mp) {
+    extern __shared__ __attribute__((aligned(16))) uint4 pn3_lds[];
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, j = lane & 15, g = lane >> 4;
+    const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+    const int r_in = mp.rfast ? slot % mp.rpg : slot / mp.cpg, c_in = mp.rfast ? slot / mp.rpg : slot % mp.cpg;
+    const int rbk = (xcd / mp.xc) * mp.rpg + r_in, cbk = (xcd % mp.xc) * mp.cpg + c_in;
+    if (r_in >= mp.rpg || c_in >= mp.cpg || rbk >= mp.nrb || cbk >= mp.ncb) return;  // ragged groups (whole workgroup)
+    const int tile0 = cbk * T, m0 = rbk * 16;
+    const int kpad = (K + 31) & ~31, nst_all = kpad >> 5, pstride = (kpad >> 3) * 16;
+    const int per = (nst_all + 7) >> 3, s_lo = min(nst_all, wave * per), nst = min(nst_all, s_lo + per) - s_lo;
+    PnRing3T<T, 2> rg;
+    if (nst > 0) {                                             // (wave-uniform) in flight while the A block is staged
+        const uint4* bf[T];
+#pragma unroll
+        for (int t = 0; t < T; ++t) bf[t] = B.f + ((size_t)min(tile0 + t, B.ntile - 1) * B.nst + s_lo) * 3 * 64;
+        panel3_prefetch_t<T, 2>(rg, bf, nst, lane);
+    }
+    panel_stage3<512>(pn3_lds, A, lda, m0, M, 0, K, kpad, tid);
+    __syncthreads();
+    f32x4_t acc[T];
+#pragma unroll
+    for (int t = 0; t < T; ++t) acc[t] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+    if (nst > 0) panel3_mma_rt<1, T, 2>(pn3_lds + (size_t)s_lo * 64, pstride, 0, rg, nst, acc, lane);
+    __syncthreads();                                           // every wave is done with the image: its head becomes the meeting place
+    float4* const red = (float4*)pn3_lds;
+#pragma unroll
+    for (int t = 0; t < T; ++t) red[(size_t)(wave * T + t) * 64 + lane] = make_float4(acc[t][0], acc[t][1], acc[t][2], acc[t][3]);
+    __syncthreads();
+    if (wave < T) {                                            // wave t adds tile t's eight parts in wave order
+        float4 sum = red[(size_t)wave * 64 + lane];
+#pragma unroll
+        for (int w = 1; w < 8; ++w) {
+            const float4 v = red[(size_t)(w * T + wave) * 64 + lane];
+            sum.x += v.x; sum.y += v.y; sum.z += v.z; sum.w += v.w;
+        }
+        const int tile = tile0 + wave, n4 = tile * 16 + 4 * g, m = m0 + j;
+        if (tile < B.ntile && n4 < N && m < M) {
+            float* dst = C + (size_t)m * ldc + n4;
+            if (n4 + 3 < N) *(f32x4u_t*)dst = f32x4u_t{sum.x, sum.y, sum.z, sum.w};
+            else {
+                const float r[4] = {sum.x, sum.y, sum.z, sum.w};
+#pragma unroll
+                for (int e = 0; e < 4; ++e) if (n4 + e < N) dst[e] = r[e];
+            }
+        }
+    }
+}
+// when the form pays: a long K in one LDS image, few row blocks (FDCAP_PN_KSW=0: never)
+static inline bool panel_gemm3_ksw_ok(int M, int K, const PanelB3& B) {
+    static int on = -1;
+    if (on < 0) { const char* e = getenv("FDCAP_PN_KSW"); on = (e && e[0] == '0') ? 0 : 1; }
+    const int kpad = (K + 31) & ~31;
+    return on && kpad <= PN3_MAX_K && kpad >= 768 && ((M + 15) / 16) * ((B.ntile + 7) / 8) < 128;
+}
+static inline hipError_t panel_gemm3_ksw(const float* A, int lda, int M, int K, const PanelB3& B, float* C, int ldc, int N, hipStream_t st) {
+    if (M <= 0 || N <= 0) return hipSuccess;
+    const int kpad = (K + 31) & ~31;
+    constexpr int T = 2;
+    static bool attr = false;
+    if (!attr) {
+        hipError_t e = hipFuncSetAttribute((const void*)panel_gemm3_ksw_kernel<T>, hipFuncAttributeMaxDynamicSharedMemorySize, 6 * PN3_MAX_K * 16);
+        if (e != hipSuccess) return e;
+        attr = true;
+    }
+    const PnMap mp = panel_map((M + 15) / 16, (B.ntile + T - 1) / T, (size_t)M * K * 4, (size_t)B.ntile * B.nst * 3 * 1024);
+    hipLaunchKernelGGL(panel_gemm3_ksw_kernel<T>, dim3(8 * mp.rpg * mp.cpg), dim3(512), (size_t)6 * kpad * 16, st, A, lda, M, K, B, C, ldc, N, mp);
+    return hipGetLastError();
+}
+
 // ... and for K far beyond any LDS image (r5: the FULL mesh's data gradient, K = 3 V = 31 425 -- BASELINE config 5's contact set, mode
 // 'local', the body-model operator's backward; it ran on the generic fp32 tiles, 387 us at 512 rows and 214 us at 128): K in `ks`
 // parts, a workgroup = (part, column block of 8 tiles, row pair) walks its part slab by slab -- stage the slab's two 16-row images,

@@ -364,6 +364,7 @@ hipError_t blend_backward(const SkinSet& ss, const float* dV, int M, float* dPF,
             *split = true;
             return panel_gemm3_rb2k(dV, K, M, K, ss.pn_bwd3, dPF, part2_stride, NPFX, NPFX, st);
         }
+        if (panel_gemm3_ksw_ok(M, K, ss.pn_bwd3)) return panel_gemm3_ksw(dV, K, M, K, ss.pn_bwd3, dPF, NPFX, NPFX, st);
         if (panel_gemm3_fits(K)) return panel_gemm3(dV, K, M, K, ss.pn_bwd3, dPF, NPFX, NPFX, st);
         hipError_t e = ws.ensure((size_t)panel_gemm3_kloop_parts(M, ss.pn_bwd3) * M * NPFX);
         if (e != hipSuccess) return e;

@@ -340,3 +340,43 @@ def test_c2_trajectory_on_a_frame_subset_matches_the_oracle():
     np.testing.assert_allclose(np.array(fop.log.total), olog[:, 5], rtol=0, atol=3e-6 + 2e-6 * iters)
     np.testing.assert_allclose(np.array(fop.log.loss_contact), olog[:, 3], rtol=0, atol=3e-6 + 2e-6 * iters)
     fop.close()
+
+
+@pytest.mark.parametrize("frames", [128, 200])
+def test_shard_sized_kernel_forms_give_the_same_gradient(tmp_path, frames):
+    """r5: at a shard's size (fewer than 384 rows) the data gradient of the blend product splits K over the eight waves of a
+    workgroup (panel_gemm3_ksw_kernel) and the forward runs four-wave workgroups; FDCAP_PN_KSW=0 / FDCAP_PN_NW=8 select the
+    eight-wave one-row-block products of r2-r4.  Same products, another summation order over K in the gradient: the optimiser's
+    gradient agrees to rounding of the sums (the bar of the clip-sized forms' test); 200 frames: ragged last row block."""
+    import subprocess
+    import sys
+    code = r'''
+import sys, numpy as np, torch
+sys.path.insert(0, %r)
+import fdcap_amd
+from fdcap_amd import capi, synth
+from fdcap_amd.fitting import FittingOP
+from fdcap_amd.io import read_camerapose
+n = int(sys.argv[2])
+bm = synth.make_body_model(10475, seed=0); vp = synth.make_vposer(seed=1); clip = synth.make_clip(n, seed=3)
+scene = synth.make_scene(60000, seed=2); l, r = synth.make_contact_ids(bm.v_template, per_part=250, seed=4)
+fop = FittingOP({"num_iter": 500}, {}, n, body_model=bm, vposer=vp, scene_verts=scene, contact_ids=np.concatenate([l, r]),
+                camera_ext=read_camerapose(clip.camerapose_lines))
+x78 = torch.empty(n, capi.XDIM, device="cuda")
+capi.check(fop.ctx.lib.fdcap_params_75_to_78(capi.dptr(torch.tensor(clip.body_params).cuda()), n, capi.dptr(x78), capi.current_stream()), "75->78")
+fop._mode = "global"; fop.init(x78)
+lib, h = fop.ctx.lib, fop.ctx.handle
+capi.check(lib.fdcap_opt_backward(h, 0, 400, 0, capi.current_stream()), "backward")
+dx = torch.empty(n, 78, device="cuda")
+capi.check(lib.fdcap_opt_get_grads(h, capi.dptr(dx), None, capi.current_stream()), "grads")
+torch.cuda.synchronize()
+np.save(sys.argv[1], dx.cpu().numpy())
+''' % os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    grads = []
+    for env_extra in ({"FDCAP_PN_KSW": "0", "FDCAP_PN_NW": "8"}, {}):
+        out = str(tmp_path / ("shard_grad_%d.npy" % len(grads)))
+        subprocess.run([sys.executable, "-c", code, out, str(frames)], check=True, env=dict(os.environ, **env_extra), timeout=600)
+        grads.append(np.load(out))
+    g0, g1 = grads
+    assert np.abs(g0).max() > 0
+    np.testing.assert_allclose(g1, g0, rtol=2e-4, atol=2e-6 * np.abs(g0).max())
