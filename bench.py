@@ -344,9 +344,12 @@ def counter_fracs(k, live_seconds=None):
     out = {"clock_ghz_under_pmc": cyc / dur / 1e9, "duration_us_under_pmc": k["duration_us_under_pmc"], "dispatches": k.get("dispatches")}
     if out["clock_ghz_under_pmc"] > 2.45:
         # GRBM_GUI_ACTIVE also counts the front end's activity around a launch: for kernels of a few microseconds the implied
-        # clock exceeds the chip's 2.4 GHz maximum and cycle-normalised fractions would be understated -- report none
-        return {"duration_us_under_pmc": k["duration_us_under_pmc"], "dispatches": k.get("dispatches"),
-                "note": "launch too short for cycle-normalised counter fractions"}
+        # clock exceeds the chip's 2.4 GHz maximum.  Then the launch's cycles are taken as duration x 2.4 GHz -- the most the
+        # chip can have run -- so every cycle-normalised fraction below is a LOWER bound, and says so.
+        cyc = dur * 2.4e9
+        out["clock_ghz_under_pmc"] = 2.4
+        out["note"] = ("launch too short for GRBM_GUI_ACTIVE to give its clock: cycles = duration x the 2.4 GHz maximum, "
+                       "cycle-normalised fractions are lower bounds")
     if k.get("SQ_INSTS_VALU") is not None:
         out["valu_insts_per_launch"] = k["SQ_INSTS_VALU"]
         mix = [k.get(n) for n in ("SQ_INSTS_VALU_FMA_F32", "SQ_INSTS_VALU_ADD_F32", "SQ_INSTS_VALU_MUL_F32", "SQ_INSTS_VALU_INT32")]
