@@ -438,6 +438,8 @@ def nn_roofline(pk, src, sec_loop, ms_steady, n_timed, alg_bytes):
         ach = nn["valu_busy_simd_cycles_per_launch"] / sec_loop / 1e9
         peak = NUM_SIMD * clock / 1e9
         roofline.update({"bound": "valu_issue", "achieved": ach, "peak": peak, "unit": "G SIMD-cycles/s of VALU issue", "frac": ach / peak,
+                         "frac_under_counters": nn.get("valu_issue_frac"),        # the same busy cycles over the launch's own cycles in the PMC pass
+                         "us_per_launch_under_counters": nn.get("duration_us_under_pmc"),
                          "traffic": nn.get("hbm_bytes_per_launch"), "hbm_frac_on_counter_bytes": nn.get("hbm_frac_on_counter_bytes"),
                          "mfma_busy_frac": nn.get("mfma_busy_frac"), "mean_waves_per_simd": nn.get("mean_waves_per_simd"),
                          "max_waves_per_simd": WAVES_PER_SIMD, "valu_insts_per_wave": nn.get("valu_insts_per_wave"),
