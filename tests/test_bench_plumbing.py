@@ -102,3 +102,42 @@ def test_bench_refuses_to_run_the_product_without_a_gpu():
                        text=True, timeout=120, cwd=ROOT)
     assert p.returncode != 0 and "needs a GPU" in (p.stderr + p.stdout)
     assert not _json_lines(p.stdout)
+
+
+def _bench_module():
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("bench_under_test", os.path.join(ROOT, "bench.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod
+
+
+def test_config_presets_and_the_blocks_built_from_the_committed_profiles():
+    """r5: `--config` presets, and the two blocks of the line that are arithmetic on COMMITTED files (no GPU needed to check them):
+    `roofline.per_kernel` from profiles/r5_c3_pmc_summary.json -- all nine launches of a phase-1 iteration, each with its time, its
+    work and a fraction of its binding peak in (0, 1) -- and the counter fractions of configs 5 and 2 (`other_configs`)."""
+    b = _bench_module()
+    a = b.parse(["--config", "c5"])
+    assert (a.frames, a.scene, a.all_contacts, a.scaling) == (512, 2_000_000, True, "strong")
+    a = b.parse(["--config", "c2", "--scaling", "weak", "--frames", "64"])
+    assert (a.frames, a.scene, a.all_contacts, a.scaling) == (64, 100_000, False, "weak")
+    assert b.which_config(1024, 500_000, 500, 10475, 4) == "c3" and b.which_config(512, 2_000_000, 10475, 10475, 4) == "c5"
+    assert b.which_config(1024, 500_000, 500, 10475, 8) is None and b.which_config(1000, 500_000, 500, 10475, 4) is None
+    pmc, src = b.load_pmc("c3")
+    assert src == os.path.join("profiles", "r5_c3_pmc_summary.json")
+    t = b.per_kernel_table(pmc["kernels"], 1024, 500, 4, src)
+    ks = t["kernels"]
+    assert len(ks) == 9 and abs(sum(k["us"] for k in ks) - t["phase1_iteration_us"]) < 1e-6
+    assert 120.0 < t["phase1_iteration_us"] < 170.0
+    assert [k["bound"] for k in ks] == ["mfma", "hbm", "mfma", "hbm", "valu_issue", "hbm", "mfma", "hbm", "mfma"]
+    for k in ks:
+        if k["bound"] != "valu_issue":
+            assert 0.0 < k["frac"] < 1.0 and 0.0 < k["floor_us"] < k["us"], k
+    rl, _ = b.nn_roofline(pmc["kernels"], src, 60e-6, 0.052, 400, 1024 * (12.0 * 500_000 + 20.0 * 500))
+    assert rl["bound"] == "valu_issue" and 0.3 < rl["frac"] < 1.0 and rl["contract"]["frac_on_algorithmic_bytes"] > 1.0
+    for cfg, t_launch in (("c5", 1.15e-3), ("c2", 18e-6)):
+        pk, s2 = b.load_pmc(cfg)
+        rl, nn = b.nn_roofline(pk["kernels"], s2, t_launch, t_launch * 1e3, 400, 1.0)
+        assert rl["bound"] == "valu_issue" and 0.1 < rl["frac"] < 1.0 and 0.0 < rl["hbm_frac_on_counter_bytes"] < 1.0, (cfg, rl)
+    # (config 2's launch is too short for the clock counter: its fractions are lower bounds and say so)
+    assert "lower bounds" in (nn.get("note") or "")
