@@ -21,7 +21,7 @@ namespace fdc {
 constexpr int LB_DPAD = 128;     // floats per stored vector: dim <= 128 (an optimiser row is 78)
 constexpr int LB_HMAX = 128;     // history entries at most (torch's default is 100)
 constexpr int LB_NT = 256;       // threads of a workgroup: four waves load the history, the first runs the state machine
-FDC_HD inline size_t lbfgs_lds_bytes(int hist) { return (size_t)(2 * hist + 7) * LB_DPAD * sizeof(float); }    // + LV_NUM work vectors
+FDC_HD size_t lbfgs_lds_bytes(int hist) { return (size_t)(2 * hist + 7) * LB_DPAD * sizeof(float); }    // + LV_NUM work vectors
 
 struct LbfgsCfg {
     int dim, hist, max_iter, max_eval, max_steps, max_ls;
@@ -46,7 +46,7 @@ struct LbfgsScalars {
 // vector slots of a problem's workspace, followed by `hist` y vectors and `hist` s vectors
 enum { LV_G = 0, LV_PREVG, LV_D, LV_XINIT, LV_GPREV, LV_BG0, LV_BG1, LV_NUM };
 static_assert(LV_NUM == 7, "lbfgs_lds_bytes counts seven work vectors");
-FDC_HD inline size_t lbfgs_ws_floats(int hist) { return (size_t)(LV_NUM + 2 * hist) * LB_DPAD; }
+FDC_HD size_t lbfgs_ws_floats(int hist) { return (size_t)(LV_NUM + 2 * hist) * LB_DPAD; }
 
 #if defined(__HIPCC__)
 struct LV { float a, b; };       // a lane's two elements of a 128-padded vector: [lane], [lane + 64]

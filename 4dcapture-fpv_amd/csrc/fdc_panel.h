@@ -915,11 +915,6 @@ __device__ __forceinline__ void panel3_mma_rt(const uint4* __restrict__ sA3, int
 #pragma unroll
             for (int rb = 0; rb < RB; ++rb) acc[rb * T + t] = pn3_step(a[rb], b[t][p], acc[rb * T + t]);
     };
-    auto next_a = [&](int step) {
-        uint4 an[RB][3];
-        load_a(an, step);
-        return an;
-    };
     int s = 0;
     for (; s + 2 * PF <= nst; s += 2 * PF) {
 #pragma unroll
@@ -973,7 +968,6 @@ __device__ __forceinline__ void panel3_mma_rt(const uint4* __restrict__ sA3, int
             for (int rb = 0; rb < RB; ++rb) { a[rb][0] = an[rb][0]; a[rb][1] = an[rb][1]; a[rb][2] = an[rb][2]; }
         }
     }
-    (void)next_a;
 }
 // Long K, few rows (r5: the data gradient [M,1500] x [1500,496] of a SHARD, M = 128..383 -- too few rows for the two-K-halves form,
 // and as a plain one-row-block product 32 workgroups that each pull 1.1 MB of fragments through one CU: 15 us for 0.2 GFLOP).  K is
@@ -1038,15 +1032,24 @@ static inline bool panel_gemm3_ksw_ok(int M, int K, const PanelB3& B) {
 static inline hipError_t panel_gemm3_ksw(const float* A, int lda, int M, int K, const PanelB3& B, float* C, int ldc, int N, hipStream_t st) {
     if (M <= 0 || N <= 0) return hipSuccess;
     const int kpad = (K + 31) & ~31;
-    constexpr int T = 2;
     static bool attr = false;
     if (!attr) {
-        hipError_t e = hipFuncSetAttribute((const void*)panel_gemm3_ksw_kernel<T>, hipFuncAttributeMaxDynamicSharedMemorySize, 6 * PN3_MAX_K * 16);
+        hipError_t e = hipFuncSetAttribute((const void*)panel_gemm3_ksw_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, 6 * PN3_MAX_K * 16);
+        if (e == hipSuccess) e = hipFuncSetAttribute((const void*)panel_gemm3_ksw_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 6 * PN3_MAX_K * 16);
         if (e != hipSuccess) return e;
         attr = true;
     }
-    const PnMap mp = panel_map((M + 15) / 16, (B.ntile + T - 1) / T, (size_t)M * K * 4, (size_t)B.ntile * B.nst * 3 * 1024);
-    hipLaunchKernelGGL(panel_gemm3_ksw_kernel<T>, dim3(8 * mp.rpg * mp.cpg), dim3(512), (size_t)6 * kpad * 16, st, A, lda, M, K, B, C, ldc, N, mp);
+    // column tiles per workgroup: two while that still gives >= 192 workgroups, else one (FDCAP_PN_KSW_T pins it: A/B)
+    static int t_env = -1;
+    if (t_env < 0) { const char* e = getenv("FDCAP_PN_KSW_T"); t_env = e ? atoi(e) : 0; }
+    const int nrb = (M + 15) / 16;
+    int T = nrb * ((B.ntile + 1) / 2) >= 192 ? 2 : 1;
+    if (t_env == 1 || t_env == 2) T = t_env;
+    const PnMap mp = panel_map(nrb, (B.ntile + T - 1) / T, (size_t)M * K * 4, (size_t)B.ntile * B.nst * 3 * 1024);
+    if (T == 2)
+        hipLaunchKernelGGL(panel_gemm3_ksw_kernel<2>, dim3(8 * mp.rpg * mp.cpg), dim3(512), (size_t)6 * kpad * 16, st, A, lda, M, K, B, C, ldc, N, mp);
+    else
+        hipLaunchKernelGGL(panel_gemm3_ksw_kernel<1>, dim3(8 * mp.rpg * mp.cpg), dim3(512), (size_t)6 * kpad * 16, st, A, lda, M, K, B, C, ldc, N, mp);
     return hipGetLastError();
 }
 
