@@ -498,7 +498,12 @@ constexpr int ST4_QCAP = 8;            // filter survivors a lane can queue for 
 // then filtered by the per-query box test with the CURRENT bounds, so the scan visits the same quarters as without a cache.
 // Measured on the bench clip (tools/motion_probe.py): with 4 cm of slack 14 % of the groups rebuild per iteration on
 // average (33 % during the first 100 iterations, 1.4 % during the last 100).
-constexpr int NN_CACHE_CAP = 64;        // quarter ids kept per (group, wave share); longer lists are not cached
+#ifndef FDC_NN_CACHE_CAP
+#define FDC_NN_CACHE_CAP 128
+#endif
+constexpr int NN_CACHE_CAP = FDC_NN_CACHE_CAP;   // quarter ids kept per (group, wave share); longer lists are not cached.  64 or 128 (r5: a lane
+                                        // carries TWO 16-bit ids in its one set-up register: BASELINE config 5's far queries list 60-120 quarters)
+static_assert(NN_CACHE_CAP == 64 || NN_CACHE_CAP == 128, "one or two ids per lane");
 struct NNCache {
     unsigned short* ids;      // [ngroups * WPG][NN_CACHE_CAP]
     int* hdr;                 // [ngroups * WPG] list length | launches since the anchors were set << 8; -1: no list (anchors one launch old)
@@ -576,7 +581,8 @@ __global__ __launch_bounds__(64 * WPB, NQ == 1 ? FDC_ST4_OCC : FDC_ST4_OCC2) voi
     for (int n = 0; n < NQ; ++n) anc_pre[n] = make_float4(0.f, 0.f, 0.f, -1.f);
     if (caching) {                                                 // wave-uniform
         hv_pre = cache.hdr[cidx];
-        id_pre = cache.ids[(size_t)cidx * NN_CACHE_CAP + lane];
+        id_pre = NN_CACHE_CAP == 64 ? (unsigned)cache.ids[(size_t)cidx * NN_CACHE_CAP + lane]
+                                    : ((const unsigned*)cache.ids)[(size_t)cidx * (NN_CACHE_CAP / 2) + lane];
 #pragma unroll
         for (int n = 0; n < NQ; ++n) anc_pre[n] = cache.anchor[(size_t)sub * nq + min(wq0 + n * 32 + col, nq - 1)];
     }
@@ -761,7 +767,12 @@ __global__ __launch_bounds__(64 * WPB, NQ == 1 ? FDC_ST4_OCC : FDC_ST4_OCC2) voi
         nsurv = n_kept;
         listed = true;
         FDC_STAT(4, lane == 0);
-        if (lane < n_kept) slist[wave][lane] = (unsigned short)id_pre;
+        if (NN_CACHE_CAP == 64) {
+            if (lane < n_kept) slist[wave][lane] = (unsigned short)id_pre;
+        } else {
+            if (2 * lane < n_kept) slist[wave][2 * lane] = (unsigned short)(id_pre & 0xFFFFu);
+            if (2 * lane + 1 < n_kept) slist[wave][2 * lane + 1] = (unsigned short)(id_pre >> 16);
+        }
         __builtin_amdgcn_wave_barrier();
     } else if (cull) {
         nsurv = 0;
@@ -840,7 +851,11 @@ __global__ __launch_bounds__(64 * WPB, NQ == 1 ? FDC_ST4_OCC : FDC_ST4_OCC2) voi
         FDC_STAT(5, lane == 0 && !idle);
         if (caching) {                                            // keep the (inflated) list and what it was built for
             const bool keep = inflate && listed && nsurv <= NN_CACHE_CAP;
-            if (keep && lane < nsurv) cache.ids[(size_t)cidx * NN_CACHE_CAP + lane] = slist[wave][lane];
+            if (NN_CACHE_CAP == 64) {
+                if (keep && lane < nsurv) cache.ids[(size_t)cidx * NN_CACHE_CAP + lane] = slist[wave][lane];
+            } else if (keep && 2 * lane < nsurv)
+                ((unsigned*)cache.ids)[(size_t)cidx * (NN_CACHE_CAP / 2) + lane] =
+                    (unsigned)slist[wave][2 * lane] | ((2 * lane + 1 < nsurv ? (unsigned)slist[wave][2 * lane + 1] : 0u) << 16);
             if (lane == 0) cache.hdr[cidx] = keep ? (nsurv | 256) : -1;
             if (half == 0) {
 #pragma unroll
