@@ -317,14 +317,17 @@ int fdcap_panel_gemm(const float* A, int32_t lda, int32_t M, int32_t K, const fl
         const char* e3 = getenv("FDCAP_GEMM_SPLIT3");                // (read per call here, so a test can run both forms in one process)
         if (!(e3 && e3[0] == '0') && panel_gemm3_fits(K)) {          // the three-way bf16 split form of the same product (the default)
             std::vector<unsigned> p3;
+            std::vector<float> sc;
             PanelB3 B3;
-            panel_pack3(B_h, (long)sk, (long)sn, K, N, p3, &B3.ntile, &B3.nst);
+            PnF::pack(B_h, (long)sk, (long)sn, K, N, p3, sc, &B3.ntile, &B3.nst);
             DevBuf<unsigned> d3;
+            DevBuf<float> ds;
             HIP_TRY(d3.upload(p3.data(), p3.size()));
-            B3.f = (const uint4*)d3.p;
+            HIP_TRY(ds.upload(sc.data(), sc.size()));
+            B3.f = (const uint4*)d3.p; B3.isc = ds.p;
             hipError_t e = panel_gemm3(A, lda, M, K, B3, C, ldc, N, st);
             hipError_t e2 = hipStreamSynchronize(st);
-            d3.release();
+            d3.release(); ds.release();
             return (int)(e != hipSuccess ? e : e2);
         }
     }

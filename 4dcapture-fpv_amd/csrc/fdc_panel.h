@@ -362,6 +362,7 @@ typedef float f32x4u_t __attribute__((ext_vector_type(4), aligned(4)));      // 
 struct PanelB3 {
     const uint4* f = nullptr;       // f[((tile * nst + s) * 3 + plane) * 64 + lane] = 8 bf16: B(32 s + 8 (lane >> 4) + e, 16 tile + (lane & 15))
     int ntile = 0, nst = 0;         // ceil(N / 16), ceil(K / 32)
+    const float* isc = nullptr;     // PnH2 panels: isc[16 tile + c] = 1 / (the power-of-two scale of output column c of the tile); two planes there
 };
 static inline unsigned pn3_bf_host(float f) { unsigned u; memcpy(&u, &f, 4); u += 0x7FFFu + ((u >> 16) & 1u); return u >> 16; }   // RNE
 static inline float pn3_bff_host(unsigned h) { unsigned u = h << 16; float f; memcpy(&f, &u, 4); return f; }
@@ -442,11 +443,248 @@ __device__ __forceinline__ void panel_stage3(uint4* __restrict__ sA3, const floa
     }
 }
 
-// acc += A[16 x 32 nst] * B (three-way split, six partial products per 32-column step, smallest first).  sA3: image at the
-// first step (plane stride `pstride` uint4); bf: the tile's fragments at the first step (no lane offset).  Two register
-// sets of PF steps x 3 planes, loads pinned (see panel_mma).
+__device__ __forceinline__ f32x4_t pn3_step(const uint4* a /*[3] planes h m l of the LDS block*/, const uint4* b /*[3] of the fragment*/, f32x4_t acc) {
+    // static fragment = MFMA A operand (rows = output columns), LDS block = B operand (columns = frames): see pn_step
+#define PN3_MMA(wp, ap) acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(pn_bf16x8, b[wp]), __builtin_bit_cast(pn_bf16x8, a[ap]), acc, 0, 0, 0)
+#ifdef FDC_PN_EXP2      /* timing only: what two planes / three products per step would cost */
+    PN3_MMA(1, 0); PN3_MMA(0, 1); PN3_MMA(0, 0);
+#else
+    PN3_MMA(2, 0); PN3_MMA(0, 2); PN3_MMA(1, 1); PN3_MMA(1, 0); PN3_MMA(0, 1); PN3_MMA(0, 0);
+#endif
+#undef PN3_MMA
+    return acc;
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Operand formats of the split products.  PnB3: the three bf16 planes above (six products per step; the fused VPoser kernels).
+// PnH2 (late r5; the blend products): TWO fp16 planes and THREE products per step.
+//   a s = h + 2^-11 l,  h = fp16(a s),  l = fp16((a s - h) 2^11)   (both conversions round to nearest even; a s - h is exact)
+// with s a power of two per frame row of the dynamic operand (its largest |a| lands in [2^13, 2^14): found while the block is
+// staged, one extra barrier) and per output column of the static one (host).  |a - (h + 2^-11 l) / s| <= 2^-22 |a| for every element
+// within 2^-27 of its row's largest (below that: 2^-50 of the largest, absolutely).  Products h h -> one accumulator, l h + h l ->
+// a second one, joined as (acc_h + 2^-11 acc_l) / (s_a s_b) in the epilogue (exact scalings, one rounding); l l (<= 2^-22 |a b|)
+// is dropped.  Error <= 3 x 2^-22 |a||b| per term: above PnB3's 2^-22, far below the K 2^-24 bound of an fp32 fmaf chain, and
+// tests/test_gpu_panel.py holds it to the same 1e-6 sum|a||b| bar against fp64.  What it buys: half the MFMA issue, two thirds
+// of the fragment bytes and of the LDS reads per 32 columns of K -- all three of the resources these kernels sit on at once.
+#ifndef FDC_PN_H2
+#define FDC_PN_H2 1
+#endif
+typedef _Float16 pn_f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 pn_f16x2 __attribute__((ext_vector_type(2)));
+static inline unsigned pn2_f16_host(float f) {                  // fp32 -> fp16 bits, round to nearest even (no libgcc soft-float call)
+    unsigned u; memcpy(&u, &f, 4);
+    const unsigned sign = (u >> 16) & 0x8000u, ex = (u >> 23) & 255u;
+    unsigned man = u & 0x7FFFFFu;
+    if (ex == 255u) return sign | 0x7C00u | (man ? 0x200u : 0u);
+    const int e = (int)ex - 127 + 15;
+    if (e >= 31) return sign | 0x7C00u;
+    if (e <= 0) {                                               // subnormal or zero
+        if (e < -10) return sign;
+        man |= 0x800000u;
+        const int sh = 14 - e;                                  // 14 .. 24
+        const unsigned q = man >> sh, rem = man & ((1u << sh) - 1u), half = 1u << (sh - 1);
+        return sign | (q + ((rem > half || (rem == half && (q & 1u))) ? 1u : 0u));
+    }
+    const unsigned q = ((unsigned)e << 10) | (man >> 13), rem = man & 0x1FFFu;
+    return sign | (q + ((rem > 0x1000u || (rem == 0x1000u && (q & 1u))) ? 1u : 0u));   // a carry into the exponent is the right answer
+}
+static inline float pn2_f16f_host(unsigned h) {
+    const unsigned sign = (h & 0x8000u) << 16, ex = (h >> 10) & 31u, man = h & 0x3FFu;
+    float f;
+    if (ex == 0) { f = ldexpf((float)man, -24); unsigned u; memcpy(&u, &f, 4); u |= sign; memcpy(&f, &u, 4); return f; }
+    const unsigned u = sign | (ex == 31u ? 0x7F800000u : ((ex + 112u) << 23)) | (man << 13);
+    memcpy(&f, &u, 4);
+    return f;
+}
+struct PnB3 {
+    static constexpr int NP = 3, SC_U4 = 0;                     // planes; uint4 of per-row scales (+ scratch) behind an image's planes
+    typedef f32x4_t Acc;
+    static __device__ __forceinline__ Acc zero() { return f32x4_t{0.f, 0.f, 0.f, 0.f}; }
+    static __device__ __forceinline__ Acc step(const uint4* a, const uint4* b, Acc acc) { return pn3_step(a, b, acc); }
+    static __device__ __forceinline__ f32x4_t value(const Acc& a, float, const f32x4_t&) { return a; }
+    static __device__ __forceinline__ float row_isc(const uint4*, int, int) { return 1.f; }
+    static __device__ __forceinline__ f32x4_t tile_isc(const PanelB3&, int, int) { return f32x4_t{1.f, 1.f, 1.f, 1.f}; }
+    template <int NT, int RB, int MAXIT>
+    static __device__ __forceinline__ void stage(uint4* __restrict__ lds, int img, const float* __restrict__ A, int lda, int m0, int M, int k0,
+                                                 int kn, int kpad, int tid) {
+#pragma unroll
+        for (int rb = 0; rb < RB; ++rb) panel_stage3<NT>(lds + (size_t)rb * img, A, lda, m0 + 16 * rb, M, k0, kn, kpad, tid);
+    }
+    static inline void pack(const float* src, long sk, long sn, int K, int N, std::vector<unsigned>& out, std::vector<float>& isc, int* ntile,
+                            int* nst) {
+        panel_pack3(src, sk, sn, K, N, out, ntile, nst);
+        isc.assign((size_t)*ntile * 16, 1.f);
+    }
+};
+__device__ __forceinline__ unsigned pn2_pk2(float a, float b) {
+    const pn_f32x2 f = {a, b};
+    return __builtin_bit_cast(unsigned, __builtin_convertvector(f, pn_f16x2));
+}
+struct PnH2 {
+    static constexpr int NP = 2, SC_U4 = 4 + 4 * 12;            // 16 inverse row scales + 16 partial maxima per wave (<= 12 waves)
+    struct Acc { f32x4_t h, l; };
+    static __device__ __forceinline__ Acc zero() { return Acc{f32x4_t{0.f, 0.f, 0.f, 0.f}, f32x4_t{0.f, 0.f, 0.f, 0.f}}; }
+    static __device__ __forceinline__ Acc step(const uint4* a /*[2] planes h l of the LDS block*/, const uint4* b /*[2] of the fragment*/, Acc acc) {
+#define PN2_MMA(dst, wp, ap) dst = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(pn_f16x8, b[wp]), __builtin_bit_cast(pn_f16x8, a[ap]), dst, 0, 0, 0)
+        PN2_MMA(acc.l, 1, 0); PN2_MMA(acc.h, 0, 0); PN2_MMA(acc.l, 0, 1);
+#undef PN2_MMA
+        return acc;
+    }
+    static __device__ __forceinline__ f32x4_t value(const Acc& a, float row_isc, const f32x4_t& col_isc) {
+        f32x4_t v;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[r] = fmaf(a.l[r], 0x1p-11f, a.h[r]) * row_isc * col_isc[r];   // (powers of two: exact; one after the other: their product alone may leave fp32's range)
+        return v;
+    }
+    static __device__ __forceinline__ float row_isc(const uint4* image, int pstride, int j) { return ((const float*)(image + (size_t)NP * pstride))[j]; }
+    static __device__ __forceinline__ f32x4_t tile_isc(const PanelB3& B, int tile, int g);    // the lane's four columns 16 tile + 4 g ..
+    // rows [m0, m0 + 16 RB) x columns [k0, k0 + kn) of A as RB images of two fp16 planes, each [kpad / 8 chunks][16 rows] x 16 bytes,
+    // + the 16 inverse row scales behind each image's planes.  NT threads (a multiple of 64); contains ONE __syncthreads (every thread
+    // of the workgroup must call); the caller's barrier after it publishes the images.  A thread's items all belong to row (tid & 15):
+    // up to MAXIT items per image stay in registers between the maximum and the conversion, longer blocks are read twice.
+    template <int NT, int RB, int MAXIT>
+    static __device__ __forceinline__ void stage(uint4* __restrict__ lds, int img, const float* __restrict__ A, int lda, int m0, int M, int k0,
+                                                 int kn, int kpad, int tid) {
+        const int nch = kpad >> 3, nit = nch * 16, pstride = nit, wave = tid >> 6, lane = tid & 63, i = tid & 15;
+        const bool vec = ((lda & 3) == 0) && ((k0 & 3) == 0) && ((((size_t)A) & 15) == 0);
+        auto load8 = [&](int rb, int it, float* v) {
+            const int ch = it >> 4, row = m0 + 16 * rb + i, k = 8 * ch;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] = 0.f;
+            if (row < M && k < kn) {
+                const float* p = A + (size_t)row * lda + k0 + k;
+                if (vec && k + 7 < kn) {
+                    const float4 a = *(const float4*)p, b = *(const float4*)(p + 4);
+                    v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w;
+                } else {
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) if (k + e < kn) v[e] = p[e];
+                }
+            }
+        };
+        auto amax8 = [&](const float* v, float m) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) m = fmaxf(m, fabsf(v[e]));
+            return m;
+        };
+        auto put = [&](int rb, int it, const float* v, float sc) {
+            unsigned h[4], l[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float x0 = v[2 * e] * sc, x1 = v[2 * e + 1] * sc;
+                h[e] = pn2_pk2(x0, x1);
+                const pn_f16x2 hh = __builtin_bit_cast(pn_f16x2, h[e]);
+                l[e] = pn2_pk2((x0 - (float)hh[0]) * 2048.f, (x1 - (float)hh[1]) * 2048.f);
+            }
+            uint4* const im = lds + (size_t)rb * img;
+            im[(size_t)0 * pstride + it] = make_uint4(h[0], h[1], h[2], h[3]);
+            im[(size_t)1 * pstride + it] = make_uint4(l[0], l[1], l[2], l[3]);
+        };
+        const bool keep = nit <= MAXIT * NT;
+        float kv[RB][MAXIT][8], mx[RB];
+#pragma unroll
+        for (int rb = 0; rb < RB; ++rb) mx[rb] = 0.f;
+        if (keep) {
+#pragma unroll
+            for (int rb = 0; rb < RB; ++rb)
+#pragma unroll
+                for (int n = 0; n < MAXIT; ++n) {
+                    const int it = tid + n * NT;
+                    if (it < nit) { load8(rb, it, kv[rb][n]); mx[rb] = amax8(kv[rb][n], mx[rb]); }
+                }
+        } else {
+#pragma unroll
+            for (int rb = 0; rb < RB; ++rb)
+                for (int it = tid; it < nit; it += NT) { float v[8]; load8(rb, it, v); mx[rb] = amax8(v, mx[rb]); }
+        }
+#pragma unroll
+        for (int rb = 0; rb < RB; ++rb) {
+            float m = mx[rb];
+            m = fmaxf(m, __shfl_xor(m, 16));
+            m = fmaxf(m, __shfl_xor(m, 32));
+            float* const sc = (float*)(lds + (size_t)rb * img + (size_t)NP * pstride);
+            if (lane < 16) sc[16 + wave * 16 + lane] = m;
+        }
+        __syncthreads();
+        float scl[RB];
+#pragma unroll
+        for (int rb = 0; rb < RB; ++rb) {
+            float* const sc = (float*)(lds + (size_t)rb * img + (size_t)NP * pstride);
+            float m = 0.f;
+#pragma unroll
+            for (int w = 0; w < NT / 64; ++w) m = fmaxf(m, sc[16 + w * 16 + i]);
+            // the row's largest |a| -> [2^13, 2^14): scale 2^(140 - biased exponent); an all-zero row keeps 1, the ends are clamped
+            const int se = m == 0.f ? 127 : min(max(267 - (int)((__float_as_uint(m) >> 23) & 255u), 4), 250);
+            scl[rb] = __uint_as_float((unsigned)se << 23);
+            if (tid < 16) sc[tid] = __uint_as_float((unsigned)(254 - se) << 23);
+        }
+        if (keep) {
+#pragma unroll
+            for (int rb = 0; rb < RB; ++rb)
+#pragma unroll
+                for (int n = 0; n < MAXIT; ++n) {
+                    const int it = tid + n * NT;
+                    if (it < nit) put(rb, it, kv[rb][n], scl[rb]);
+                }
+        } else {
+#pragma unroll
+            for (int rb = 0; rb < RB; ++rb)
+                for (int it = tid; it < nit; it += NT) { float v[8]; load8(rb, it, v); put(rb, it, v, scl[rb]); }
+        }
+    }
+    static inline void pack(const float* src, long sk, long sn, int K, int N, std::vector<unsigned>& out, std::vector<float>& isc, int* ntile,
+                            int* nst) {
+        const int nt = (N + 15) / 16, ns = (K + 31) / 32;
+        out.assign((size_t)nt * ns * NP * 64 * 4, 0u);
+        isc.assign((size_t)nt * 16, 1.f);
+        std::vector<float> scl((size_t)nt * 16, 1.f);
+        for (int n = 0; n < N; ++n) {
+            float mx = 0.f;
+            for (int k = 0; k < K; ++k) mx = std::max(mx, fabsf(src[(long)k * sk + (long)n * sn]));
+            int ex = 0;
+            if (mx > 0.f && std::isfinite(mx)) { frexpf(mx, &ex); ex = std::min(std::max(14 - ex, -100), 100); }   // mx in [2^(ex-1), 2^ex) -> [2^13, 2^14)
+            scl[(size_t)n] = ldexpf(1.f, ex);
+            isc[(size_t)n] = ldexpf(1.f, -ex);
+        }
+        for (int t = 0; t < nt; ++t) {
+            for (int s = 0; s < ns; ++s)
+                for (int l = 0; l < 64; ++l) {
+                    const int n = 16 * t + (l & 15);
+                    if (n >= N) continue;
+                    for (int e = 0; e < 8; ++e) {
+                        const int k = 32 * s + 8 * (l >> 4) + e;
+                        if (k >= K) continue;
+                        const float x = src[(long)k * sk + (long)n * sn] * scl[(size_t)n];
+                        const unsigned h = pn2_f16_host(x);
+                        const unsigned lo = pn2_f16_host((x - pn2_f16f_host(h)) * 2048.f);
+                        const unsigned part[2] = {h, lo};
+                        for (int pl = 0; pl < NP; ++pl) {
+                            unsigned& w = out[((((size_t)t * ns + s) * NP + pl) * 64 + l) * 4 + (e >> 1)];
+                            w |= part[pl] << (16 * (e & 1));
+                        }
+                    }
+                }
+        }
+        *ntile = nt;
+        *nst = ns;
+    }
+};
+#if FDC_PN_H2
+typedef PnH2 PnF;                                               // the format of the panel_gemm3_* family
+#else
+typedef PnB3 PnF;
+#endif
+__device__ __forceinline__ f32x4_t PnH2::tile_isc(const PanelB3& B, int tile, int g) { return ((const f32x4_t*)B.isc)[(size_t)min(tile, B.ntile - 1) * 4 + g]; }
+constexpr int PNF = PnF::NP;
+// uint4 per 16-row image of kpad columns; bytes of RB of them
+constexpr __host__ __device__ int pnf_img_u4(int kpad) { return PnF::NP * (kpad >> 3) * 16 + PnF::SC_U4; }
+constexpr __host__ __device__ size_t pnf_lds_bytes(int kpad, int rb) { return (size_t)rb * pnf_img_u4(kpad) * 16; }
+
+// acc += A[16 x 32 nst] * B (split operands, PnF::step per 32-column step).  sA3: image at the first step (plane stride
+// `pstride` uint4); bf: the tile's fragments at the first step (no lane offset).  Two register sets of PF steps x planes, loads
+// pinned (see panel_mma).
 template <int PF>
-struct PnRing3 { uint4 bA[PF][3]; const uint4* st; };
+struct PnRing3 { uint4 bA[PF][PNF]; const uint4* st; };
 template <int PF>
 __device__ __forceinline__ void panel3_prefetch(PnRing3<PF>& rg, const uint4* bf, int nst, int lane) {
     rg.st = bf + lane;
@@ -454,41 +692,35 @@ __device__ __forceinline__ void panel3_prefetch(PnRing3<PF>& rg, const uint4* bf
 #pragma unroll
     for (int p = 0; p < PF; ++p)
 #pragma unroll
-        for (int pl = 0; pl < 3; ++pl) rg.bA[p][pl] = rg.st[((size_t)min(p, last) * 3 + pl) * 64];
-}
-__device__ __forceinline__ f32x4_t pn3_step(const uint4* a /*[3] planes h m l of the LDS block*/, const uint4* b /*[3] of the fragment*/, f32x4_t acc) {
-    // static fragment = MFMA A operand (rows = output columns), LDS block = B operand (columns = frames): see pn_step
-#define PN3_MMA(wp, ap) acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(pn_bf16x8, b[wp]), __builtin_bit_cast(pn_bf16x8, a[ap]), acc, 0, 0, 0)
-    PN3_MMA(2, 0); PN3_MMA(0, 2); PN3_MMA(1, 1); PN3_MMA(1, 0); PN3_MMA(0, 1); PN3_MMA(0, 0);
-#undef PN3_MMA
-    return acc;
+        for (int pl = 0; pl < PNF; ++pl) rg.bA[p][pl] = rg.st[((size_t)min(p, last) * PNF + pl) * 64];
 }
 // RB row blocks (images `img` uint4 apart) share one fragment stream
 template <int RB, int PF>
-__device__ __forceinline__ void panel3_mma(const uint4* __restrict__ sA3, int pstride, int img, PnRing3<PF>& rg, int nst, f32x4_t* acc, int lane) {
-    uint4 (&bA)[PF][3] = rg.bA;
-    uint4 bB[PF][3];
+__device__ __forceinline__ void panel3_mma(const uint4* __restrict__ sA3, int pstride, int img, PnRing3<PF>& rg, int nst, PnF::Acc* acc, int lane) {
+    uint4 (&bA)[PF][PNF] = rg.bA;
+    uint4 bB[PF][PNF];
     const uint4* const st = rg.st;
     const int last = nst - 1;
-    auto load_a = [&](uint4 (*a)[3], int step) {
+    auto load_a = [&](uint4 (*a)[PNF], int step) {
 #pragma unroll
         for (int rb = 0; rb < RB; ++rb)
 #pragma unroll
-            for (int pl = 0; pl < 3; ++pl) a[rb][pl] = sA3[(size_t)rb * img + (size_t)pl * pstride + (size_t)step * 64 + lane];
+            for (int pl = 0; pl < PNF; ++pl) a[rb][pl] = sA3[(size_t)rb * img + (size_t)pl * pstride + (size_t)step * 64 + lane];
     };
     auto load_b = [&](uint4* b, int step) {
 #pragma unroll
-        for (int pl = 0; pl < 3; ++pl) b[pl] = st[((size_t)step * 3 + pl) * 64];
+        for (int pl = 0; pl < PNF; ++pl) b[pl] = st[((size_t)step * PNF + pl) * 64];
     };
-    uint4 a[RB][3];
+    uint4 a[RB][PNF];
     load_a(a, 0);
     auto step = [&](const uint4* b, int next) {
-        uint4 an[RB][3];
+        uint4 an[RB][PNF];
         load_a(an, next);
 #pragma unroll
         for (int rb = 0; rb < RB; ++rb) {
-            acc[rb] = pn3_step(a[rb], b, acc[rb]);
-            a[rb][0] = an[rb][0]; a[rb][1] = an[rb][1]; a[rb][2] = an[rb][2];
+            acc[rb] = PnF::step(a[rb], b, acc[rb]);
+#pragma unroll
+            for (int pl = 0; pl < PNF; ++pl) a[rb][pl] = an[rb][pl];
         }
     };
     int s = 0;
@@ -517,9 +749,18 @@ __device__ __forceinline__ void panel3_mma(const uint4* __restrict__ sA3, int ps
     for (int p = 0; p < PF - 1; ++p)
         if (s + PF + p < nst) step(bB[p], min(s + PF + p + 1, last));
 }
+// a lane's four results of one tile: columns n4 .. n4 + 3 of row m
+__device__ __forceinline__ void pnf_store4(float* __restrict__ C, int ldc, int N, int m, int n4, const f32x4_t v) {
+    float* dst = C + (size_t)m * ldc + n4;
+    if (n4 + 3 < N) *(f32x4u_t*)dst = f32x4u_t{v[0], v[1], v[2], v[3]};
+    else {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) if (n4 + r < N) dst[r] = v[r];
+    }
+}
 
-// C[M, N] = A[M, K] x B on the three-way split (same workgroup shape and XCD-aware map as panel_gemm_kernel<1>; K in one
-// slab: kpad <= 2048).  Dynamic LDS: 3 planes x (kpad / 8) x 16 x 16 bytes = 6 kpad bytes per row block.
+// C[M, N] = A[M, K] x B on the split (same workgroup shape and XCD-aware map as panel_gemm_kernel<1>; K in one slab).
+// Dynamic LDS: pnf_lds_bytes(kpad, 1) per row block.
 // NW waves per workgroup = NW column tiles (r5; 8 until then).  A 128-frame shard's products ran on 96 (forward) and 32 (data
 // gradient) workgroups of eight waves -- the gradient's 32 each pulled 1.1 MB of fragments through one CU's return path, 11.5 us
 // for a product of 0.2 GFLOP; with fewer waves per workgroup there are enough workgroups for the chip (launcher: panel_gemm3).
@@ -536,27 +777,20 @@ __global__ __launch_bounds__(64 * NW) void panel_gemm3_kernel(const float* __res
     const bool active = tile < B.ntile;
     const int kpad = (K + 31) & ~31, nst = kpad >> 5, pstride = (kpad >> 3) * 16;
     PnRing3<2> rg;
-    panel3_prefetch<2>(rg, B.f + (size_t)(active ? tile : 0) * B.nst * 3 * 64, nst, lane);      // in flight while the A block is staged
-    panel_stage3<64 * NW>(pn3_lds, A, lda, m0, M, 0, K, kpad, tid);
+    panel3_prefetch<2>(rg, B.f + (size_t)(active ? tile : 0) * B.nst * PNF * 64, nst, lane);      // in flight while the A block is staged
+    PnF::stage<64 * NW, 1, (NW == 8 ? 6 : 4)>(pn3_lds, 0, A, lda, m0, M, 0, K, kpad, tid);
     __syncthreads();
-    f32x4_t acc = {0.f, 0.f, 0.f, 0.f};
+    PnF::Acc acc = PnF::zero();
     if (active) panel3_mma<1, 2>(pn3_lds, pstride, 0, rg, nst, &acc, lane);
     const int n4 = tile * 16 + 4 * g, m = m0 + j;
-    if (active && n4 < N && m < M) {
-        float* dst = C + (size_t)m * ldc + n4;
-        if (((ldc & 3) == 0) && ((((size_t)C) & 15) == 0) && n4 + 3 < N) *(float4*)dst = pn_f4(acc);
-        else {
-#pragma unroll
-            for (int r = 0; r < 4; ++r) if (n4 + r < N) dst[r] = acc[r];
-        }
-    }
+    if (active && n4 < N && m < M) pnf_store4(C, ldc, N, m, n4, PnF::value(acc, PnF::row_isc(pn3_lds, pstride, j), PnF::tile_isc(B, tile, g)));
 }
 // Two row blocks per fragment stream, for clip-sized M.  s_memtime in panel_gemm3_kernel (1024 rows): the MFMA phase of the
 // K = 1500 data gradient takes 20.8 k cycles for 282 MFMAs per wave -- 74 cycles each where the pipe needs 16 -- and its eight
 // waves receive 8 x 141 KB of fragments in that time: 54 bytes per clock, against the 64 a CU's vector-memory path returns.
 // The bound is that return path (L1 hit or not: streaming one tile to all eight waves changed nothing), so what helps is
 // fewer fragment bytes per MFMA: every fragment multiplies TWO 16-row blocks.  Twelve waves = twelve column tiles per
-// workgroup, 32 rows, both images in LDS (2 x 6 kpad x 16 bytes: K <= 768); column group = blockIdx & 7 = XCD, so each
+// workgroup, 32 rows, both images in LDS (K <= 768); column group = blockIdx & 7 = XCD, so each
 // XCD streams its own eighth of the static operand.  Grid: 8 x ceil(M / 32) workgroups (256 at 1024 rows: one per CU).
 __global__ __launch_bounds__(768) void panel_gemm3_rb2_kernel(const float* __restrict__ A, int lda, int M, int K, PanelB3 B,
                                                               float* __restrict__ C, int ldc, int N) {
@@ -564,32 +798,26 @@ __global__ __launch_bounds__(768) void panel_gemm3_rb2_kernel(const float* __res
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, j = lane & 15, g = lane >> 4;
     const int xcd = blockIdx.x & 7, m0 = (int)(blockIdx.x >> 3) * 32;
     const int ncb = (B.ntile + 11) / 12, cpg = (ncb + 7) / 8;            // column blocks of 12 tiles; per XCD
-    const int kpad = (K + 31) & ~31, nst = kpad >> 5, pstride = (kpad >> 3) * 16, img = 3 * pstride;
+    const int kpad = (K + 31) & ~31, nst = kpad >> 5, pstride = (kpad >> 3) * 16, img = pnf_img_u4(kpad);
     if (xcd * cpg >= ncb) return;
     PnRing3<2> rg;
-    panel3_prefetch<2>(rg, B.f + (size_t)min((xcd * cpg) * 12 + wave, B.ntile - 1) * B.nst * 3 * 64, nst, lane);
-#pragma unroll
-    for (int rb = 0; rb < 2; ++rb) panel_stage3<768>(pn3_lds + (size_t)rb * img, A, lda, m0 + 16 * rb, M, 0, K, kpad, tid);
+    panel3_prefetch<2>(rg, B.f + (size_t)min((xcd * cpg) * 12 + wave, B.ntile - 1) * B.nst * PNF * 64, nst, lane);
+    PnF::stage<768, 2, 2>(pn3_lds, img, A, lda, m0, M, 0, K, kpad, tid);
     __syncthreads();
+    const float rs[2] = {PnF::row_isc(pn3_lds, pstride, j), PnF::row_isc(pn3_lds + img, pstride, j)};
     for (int cb = xcd * cpg; cb < min(ncb, (xcd + 1) * cpg); ++cb) {
         const int tile = cb * 12 + wave;
-        f32x4_t acc[2] = {f32x4_t{0.f, 0.f, 0.f, 0.f}, f32x4_t{0.f, 0.f, 0.f, 0.f}};
+        PnF::Acc acc[2] = {PnF::zero(), PnF::zero()};
         if (tile < B.ntile) panel3_mma<2, 2>(pn3_lds, pstride, img, rg, nst, acc, lane);
         if (cb + 1 < min(ncb, (xcd + 1) * cpg))
-            panel3_prefetch<2>(rg, B.f + (size_t)min((cb + 1) * 12 + wave, B.ntile - 1) * B.nst * 3 * 64, nst, lane);
+            panel3_prefetch<2>(rg, B.f + (size_t)min((cb + 1) * 12 + wave, B.ntile - 1) * B.nst * PNF * 64, nst, lane);
         const int n4 = tile * 16 + 4 * g;
         if (tile < B.ntile && n4 < N) {
+            const f32x4_t ts = PnF::tile_isc(B, tile, g);
 #pragma unroll
             for (int rb = 0; rb < 2; ++rb) {
                 const int m = m0 + 16 * rb + j;
-                if (m < M) {
-                    float* dst = C + (size_t)m * ldc + n4;
-                    if (n4 + 3 < N) *(f32x4u_t*)dst = f32x4u_t{acc[rb][0], acc[rb][1], acc[rb][2], acc[rb][3]};
-                    else {
-#pragma unroll
-                        for (int r = 0; r < 4; ++r) if (n4 + r < N) dst[r] = acc[rb][r];
-                    }
-                }
+                if (m < M) pnf_store4(C, ldc, N, m, n4, PnF::value(acc[rb], rs[rb], ts));
             }
         }
     }
@@ -606,30 +834,23 @@ __global__ __launch_bounds__(512) void panel_gemm3_rb2k_kernel(const float* __re
     const int xcd = blockIdx.x & 7, half = xcd >> 2, cb = xcd & 3, m0 = (int)(blockIdx.x >> 3) * 32;
     const int nst_all = (K + 31) >> 5, s0 = half ? (nst_all + 1) / 2 : 0, s1 = half ? nst_all : (nst_all + 1) / 2;
     const int nst = s1 - s0, kpad = 32 * nst, k0 = 32 * s0, kn = min(K, 32 * s1) - k0;
-    const int pstride = (kpad >> 3) * 16, img = 3 * pstride;
+    const int pstride = (kpad >> 3) * 16, img = pnf_img_u4(kpad);
     const int tile = cb * 8 + wave;
     const bool active = tile < B.ntile && nst > 0;
     PnRing3<2> rg;
-    panel3_prefetch<2>(rg, B.f + ((size_t)(active ? tile : 0) * B.nst + s0) * 3 * 64, max(nst, 1), lane);
-#pragma unroll
-    for (int rb = 0; rb < 2; ++rb) panel_stage3<512>(pn3_lds + (size_t)rb * img, A, lda, m0 + 16 * rb, M, k0, kn, kpad, tid);
+    panel3_prefetch<2>(rg, B.f + ((size_t)(active ? tile : 0) * B.nst + s0) * PNF * 64, max(nst, 1), lane);
+    PnF::stage<512, 2, 3>(pn3_lds, img, A, lda, m0, M, k0, kn, kpad, tid);
     __syncthreads();
-    f32x4_t acc[2] = {f32x4_t{0.f, 0.f, 0.f, 0.f}, f32x4_t{0.f, 0.f, 0.f, 0.f}};
+    PnF::Acc acc[2] = {PnF::zero(), PnF::zero()};
     if (active) panel3_mma<2, 2>(pn3_lds, pstride, img, rg, nst, acc, lane);
     const int n4 = tile * 16 + 4 * g;
     if (tile < B.ntile && n4 < N) {
         float* const C = Cpart + (size_t)half * part_stride;
+        const f32x4_t ts = PnF::tile_isc(B, tile, g);
 #pragma unroll
         for (int rb = 0; rb < 2; ++rb) {
             const int m = m0 + 16 * rb + j;
-            if (m < M) {
-                float* dst = C + (size_t)m * ldc + n4;
-                if (n4 + 3 < N) *(f32x4u_t*)dst = f32x4u_t{acc[rb][0], acc[rb][1], acc[rb][2], acc[rb][3]};
-                else {
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) if (n4 + r < N) dst[r] = acc[rb][r];
-                }
-            }
+            if (m < M) pnf_store4(C, ldc, N, m, n4, PnF::value(acc[rb], PnF::row_isc(pn3_lds + (size_t)rb * img, pstride, j), ts));
         }
     }
 }
@@ -643,7 +864,7 @@ static inline bool panel_gemm3_rb2k_ok(int M, int K, const PanelB3& B) {
 static inline hipError_t panel_gemm3_rb2k(const float* A, int lda, int M, int K, const PanelB3& B, float* Cpart, size_t part_stride,
                                           int ldc, int N, hipStream_t st) {
     const int kh = 32 * ((((K + 31) >> 5) + 1) / 2);
-    hipLaunchKernelGGL(panel_gemm3_rb2k_kernel, dim3(8 * ((M + 31) / 32)), dim3(512), (size_t)2 * 6 * kh * 16, st, A, lda, M, K, B, Cpart,
+    hipLaunchKernelGGL(panel_gemm3_rb2k_kernel, dim3(8 * ((M + 31) / 32)), dim3(512), pnf_lds_bytes(kh, 2), st, A, lda, M, K, B, Cpart,
                        part_stride, ldc, N);
     return hipGetLastError();
 }
@@ -663,54 +884,51 @@ __global__ __launch_bounds__(512) void panel_gemm3_wide_kernel(const float* __re
     const int ncb = (B.ntile + 7) / 8, cpg = (ncb + 7) / 8;
     const int xb0 = xcd * cpg, xb1 = min(ncb, xb0 + cpg), per = (max(xb1 - xb0, 0) + cs - 1) / cs;
     const int cb0 = xb0 + part * per, cb1 = min(xb1, cb0 + per);
-    const int kpad = (K + 31) & ~31, nst = kpad >> 5, pstride = (kpad >> 3) * 16, img = 3 * pstride;
+    const int kpad = (K + 31) & ~31, nst = kpad >> 5, pstride = (kpad >> 3) * 16, img = pnf_img_u4(kpad);
     if (cb0 >= cb1) return;
     PnRing3<2> rg;
-    panel3_prefetch<2>(rg, B.f + (size_t)min(cb0 * 8 + wave, B.ntile - 1) * B.nst * 3 * 64, nst, lane);
-#pragma unroll
-    for (int rb = 0; rb < RB; ++rb) panel_stage3<512>(pn3_lds + (size_t)rb * img, A, lda, m0 + 16 * rb, M, 0, K, kpad, tid);
+    panel3_prefetch<2>(rg, B.f + (size_t)min(cb0 * 8 + wave, B.ntile - 1) * B.nst * PNF * 64, nst, lane);
+    PnF::stage<512, RB, 3>(pn3_lds, img, A, lda, m0, M, 0, K, kpad, tid);
     __syncthreads();
+    float rs[RB];
+#pragma unroll
+    for (int rb = 0; rb < RB; ++rb) rs[rb] = PnF::row_isc(pn3_lds + (size_t)rb * img, pstride, j);
     for (int cb = cb0; cb < cb1; ++cb) {
         const int tile = cb * 8 + wave;
-        f32x4_t acc[RB];
+        PnF::Acc acc[RB];
 #pragma unroll
-        for (int rb = 0; rb < RB; ++rb) acc[rb] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+        for (int rb = 0; rb < RB; ++rb) acc[rb] = PnF::zero();
         if (tile < B.ntile) panel3_mma<RB, 2>(pn3_lds, pstride, img, rg, nst, acc, lane);
-        if (cb + 1 < cb1) panel3_prefetch<2>(rg, B.f + (size_t)min((cb + 1) * 8 + wave, B.ntile - 1) * B.nst * 3 * 64, nst, lane);
+        if (cb + 1 < cb1) panel3_prefetch<2>(rg, B.f + (size_t)min((cb + 1) * 8 + wave, B.ntile - 1) * B.nst * PNF * 64, nst, lane);
         const int n4 = tile * 16 + 4 * g;
         if (tile < B.ntile && n4 < N) {
+            const f32x4_t ts = PnF::tile_isc(B, tile, g);
 #pragma unroll
             for (int rb = 0; rb < RB; ++rb) {
                 const int m = m0 + 16 * rb + j;
-                if (m < M) {
-                    float* dst = C + (size_t)m * ldc + n4;
-                    if (n4 + 3 < N) *(f32x4u_t*)dst = f32x4u_t{acc[rb][0], acc[rb][1], acc[rb][2], acc[rb][3]};
-                    else {
-#pragma unroll
-                        for (int r = 0; r < 4; ++r) if (n4 + r < N) dst[r] = acc[rb][r];
-                    }
-                }
+                if (m < M) pnf_store4(C, ldc, N, m, n4, PnF::value(acc[rb], rs[rb], ts));
             }
         }
     }
 }
 
-// longest K whose single-slab LDS image (6 kpad x 16 bytes per row block) fits the 160 KB of a gfx950 CU: kpad <= 1696
-constexpr int PN3_MAX_K = 1696;
+// longest K whose single-slab LDS image (pnf_lds_bytes(kpad, 1)) fits the 160 KB of a gfx950 CU
+constexpr int PN3_MAX_K = FDC_PN_H2 ? 2528 : 1696;
+static_assert(pnf_lds_bytes(PN3_MAX_K, 1) <= 160 * 1024, "one image per CU");
 static inline bool panel_gemm3_fits(int K) { return ((K + 31) & ~31) <= PN3_MAX_K; }
 
 static inline hipError_t panel_gemm3(const float* A, int lda, int M, int K, const PanelB3& B, float* C, int ldc, int N, hipStream_t st) {
     if (M <= 0 || N <= 0) return hipSuccess;
     const int kpad = (K + 31) & ~31;
     if (kpad > PN3_MAX_K) return hipErrorInvalidValue;       // callers fall back to panel_gemm (K slabs) above this
-    if ((size_t)B.ntile * B.nst * 3 * 1024 > (size_t)(24u << 20) && M >= 32 && kpad <= 768) {
+    if ((size_t)B.ntile * B.nst * PNF * 1024 > (size_t)(16u << 20) && M >= 32 && kpad <= 768) {
         // one workgroup per CU (the 98 KB image leaves room for one): as many column parts as it takes to reach 256 workgroups
         const int nrb = (M + 31) / 32, ncb = (B.ntile + 7) / 8, cpg = (ncb + 7) / 8;
         static int cs_env = -1;                          // FDCAP_PN_WIDE_CS=1 (A/B): the r2-r4 form, one part
         if (cs_env < 0) { const char* e = getenv("FDCAP_PN_WIDE_CS"); cs_env = e ? atoi(e) : 0; }
         // (r5: two column tiles per wave, as in the K-loop product, measured no faster here: 0.186 vs 0.179 ms at 1024 rows, equal at 512)
         const int cs = cs_env > 0 ? cs_env : std::max(1, std::min(cpg, (256 + 8 * nrb - 1) / (8 * nrb)));
-        hipLaunchKernelGGL(panel_gemm3_wide_kernel<2>, dim3(8 * nrb * cs), dim3(512), (size_t)2 * 6 * kpad * 16, st, A, lda, M, K, B, C, ldc, N, cs);
+        hipLaunchKernelGGL(panel_gemm3_wide_kernel<2>, dim3(8 * nrb * cs), dim3(512), pnf_lds_bytes(kpad, 2), st, A, lda, M, K, B, C, ldc, N, cs);
         return hipGetLastError();
     }
     static int rb2 = -1;                                  // FDCAP_PN_RB2=0 (A/B): one row block per fragment stream everywhere
@@ -718,7 +936,7 @@ static inline hipError_t panel_gemm3(const float* A, int lda, int M, int K, cons
     if ((rb2 == 1 || rb2 == 2) && M >= 384 && kpad <= 768 && B.ntile >= 48) {   // (measured: 256 rows 50.2 vs 49.8 ms per step, 384 rows 56.7 vs 57.8)
         // (r5: six waves x two tiles over the same 32 x 192 block -- half the LDS bytes per MFMA, the lever that took the K-loop
         //  product from 192 to 139 us -- is SLOWER here: 14.4 vs 12.8 us; with K = 512 the twelve waves' latency hiding is worth more)
-        hipLaunchKernelGGL(panel_gemm3_rb2_kernel, dim3(8 * ((M + 31) / 32)), dim3(768), (size_t)2 * 6 * kpad * 16, st, A, lda, M, K, B, C, ldc, N);
+        hipLaunchKernelGGL(panel_gemm3_rb2_kernel, dim3(8 * ((M + 31) / 32)), dim3(768), pnf_lds_bytes(kpad, 2), st, A, lda, M, K, B, C, ldc, N);
         return hipGetLastError();
     }
     // waves per workgroup: eight while that gives >= 192 workgroups, else four, else two (FDCAP_PN_NW pins it: A/B)
@@ -728,9 +946,9 @@ static inline hipError_t panel_gemm3(const float* A, int lda, int M, int K, cons
     int nw = 8;                                            // (measured at 128 rows: forward 7.8 -> 6.6 us with four waves; two waves stage too slowly)
     if (nrb * ((B.ntile + 7) / 8) < 128 && nrb * ((B.ntile + 3) / 4) >= 128) nw = 4;
     if (nw_env == 8 || nw_env == 4 || nw_env == 2) nw = nw_env;
-    const PnMap mp = panel_map(nrb, (B.ntile + nw - 1) / nw, (size_t)M * K * 4, (size_t)B.ntile * B.nst * 3 * 1024);
+    const PnMap mp = panel_map(nrb, (B.ntile + nw - 1) / nw, (size_t)M * K * 4, (size_t)B.ntile * B.nst * PNF * 1024);
     const dim3 grid(8 * mp.rpg * mp.cpg);
-    const size_t lds = (size_t)6 * kpad * 16;
+    const size_t lds = pnf_lds_bytes(kpad, 1);
     if (nw == 8) hipLaunchKernelGGL(panel_gemm3_kernel<8>, grid, dim3(512), lds, st, A, lda, M, K, B, C, ldc, N, mp);
     else if (nw == 4) hipLaunchKernelGGL(panel_gemm3_kernel<4>, grid, dim3(256), lds, st, A, lda, M, K, B, C, ldc, N, mp);
     else hipLaunchKernelGGL(panel_gemm3_kernel<2>, grid, dim3(128), lds, st, A, lda, M, K, B, C, ldc, N, mp);
@@ -815,10 +1033,10 @@ static inline hipError_t panel_gemm(const float* A, int lda, int M, int K, const
 }
 
 // T tiles share one 16-row LDS block (the fused VPoser kernels' layers)
-template <int T, int PF>
-struct PnRing3T { uint4 bA[T][PF][3]; const uint4* st[T]; };
-template <int T, int PF>
-__device__ __forceinline__ void panel3_prefetch_t(PnRing3T<T, PF>& rg, const uint4* const* bf, int nst, int lane) {
+template <int T, int PF, class F = PnB3>
+struct PnRing3T { uint4 bA[T][PF][F::NP]; const uint4* st[T]; };
+template <int T, int PF, class F = PnB3>
+__device__ __forceinline__ void panel3_prefetch_t(PnRing3T<T, PF, F>& rg, const uint4* const* bf, int nst, int lane) {
     const int last = nst - 1;
 #pragma unroll
     for (int t = 0; t < T; ++t) rg.st[t] = bf[t] + lane;
@@ -827,7 +1045,7 @@ __device__ __forceinline__ void panel3_prefetch_t(PnRing3T<T, PF>& rg, const uin
 #pragma unroll
         for (int t = 0; t < T; ++t)
 #pragma unroll
-            for (int pl = 0; pl < 3; ++pl) rg.bA[t][p][pl] = rg.st[t][((size_t)min(p, last) * 3 + pl) * 64];
+            for (int pl = 0; pl < F::NP; ++pl) rg.bA[t][p][pl] = rg.st[t][((size_t)min(p, last) * F::NP + pl) * 64];
 }
 template <int T, int PF>
 __device__ __forceinline__ void panel3_mma_t(const uint4* __restrict__ sA3, int pstride, PnRing3T<T, PF>& rg, int nst, f32x4_t* acc, int lane) {
@@ -895,77 +1113,76 @@ __device__ __forceinline__ void panel3_mma_t(const uint4* __restrict__ sA3, int 
     }
 }
 // RB row blocks x T tiles per wave (r5, the K-loop product): a step's RB LDS fragments are read ONCE for T tiles and its T static
-// fragments once for RB row blocks -- RB T products per (RB LDS reads + T fragment loads).  acc[rb * T + t].
+// fragments once for RB row blocks -- RB T products per (RB LDS reads + T fragment loads).  acc[rb * T + t].  Format PnF.
 template <int RB, int T, int PF>
-__device__ __forceinline__ void panel3_mma_rt(const uint4* __restrict__ sA3, int pstride, int img, PnRing3T<T, PF>& rg, int nst, f32x4_t* acc, int lane) {
-    uint4 (&bA)[T][PF][3] = rg.bA;
-    uint4 bB[T][PF][3];
+__device__ __forceinline__ void panel3_mma_rt(const uint4* __restrict__ sA3, int pstride, int img, PnRing3T<T, PF, PnF>& rg, int nst, PnF::Acc* acc, int lane) {
+    uint4 (&bA)[T][PF][PNF] = rg.bA;
+    uint4 bB[T][PF][PNF];
     const int last = nst - 1;
-    auto load_a = [&](uint4 (*a)[3], int step) {
+    auto load_a = [&](uint4 (*a)[PNF], int step) {
 #pragma unroll
         for (int rb = 0; rb < RB; ++rb)
 #pragma unroll
-            for (int pl = 0; pl < 3; ++pl) a[rb][pl] = sA3[(size_t)rb * img + (size_t)pl * pstride + (size_t)step * 64 + lane];
+            for (int pl = 0; pl < PNF; ++pl) a[rb][pl] = sA3[(size_t)rb * img + (size_t)pl * pstride + (size_t)step * 64 + lane];
     };
-    uint4 a[RB][3];
-    load_a(a, 0);
-    auto mma = [&](uint4 (*b)[PF][3], int p) {
+    auto load_b = [&](uint4 (*b)[PF][PNF], int p, int step) {
 #pragma unroll
         for (int t = 0; t < T; ++t)
 #pragma unroll
-            for (int rb = 0; rb < RB; ++rb) acc[rb * T + t] = pn3_step(a[rb], b[t][p], acc[rb * T + t]);
+            for (int pl = 0; pl < PNF; ++pl) b[t][p][pl] = rg.st[t][((size_t)step * PNF + pl) * 64];
+    };
+    auto keep = [&](uint4 (*a)[PNF], uint4 (*an)[PNF]) {
+#pragma unroll
+        for (int rb = 0; rb < RB; ++rb)
+#pragma unroll
+            for (int pl = 0; pl < PNF; ++pl) a[rb][pl] = an[rb][pl];
+    };
+    uint4 a[RB][PNF];
+    load_a(a, 0);
+    auto mma = [&](uint4 (*b)[PF][PNF], int p) {
+#pragma unroll
+        for (int t = 0; t < T; ++t)
+#pragma unroll
+            for (int rb = 0; rb < RB; ++rb) acc[rb * T + t] = PnF::step(a[rb], b[t][p], acc[rb * T + t]);
     };
     int s = 0;
     for (; s + 2 * PF <= nst; s += 2 * PF) {
 #pragma unroll
         for (int p = 0; p < PF; ++p) {
-            uint4 an[RB][3];
+            uint4 an[RB][PNF];
             load_a(an, s + p + 1);
-#pragma unroll
-            for (int t = 0; t < T; ++t)
-#pragma unroll
-                for (int pl = 0; pl < 3; ++pl) bB[t][p][pl] = rg.st[t][((size_t)(s + PF + p) * 3 + pl) * 64];
+            load_b(bB, p, s + PF + p);
             pn_pin();
             mma(bA, p);
-#pragma unroll
-            for (int rb = 0; rb < RB; ++rb) { a[rb][0] = an[rb][0]; a[rb][1] = an[rb][1]; a[rb][2] = an[rb][2]; }
+            keep(a, an);
         }
 #pragma unroll
         for (int p = 0; p < PF; ++p) {
-            uint4 an[RB][3];
+            uint4 an[RB][PNF];
             load_a(an, min(s + PF + p + 1, last));
-#pragma unroll
-            for (int t = 0; t < T; ++t)
-#pragma unroll
-                for (int pl = 0; pl < 3; ++pl) bA[t][p][pl] = rg.st[t][((size_t)min(s + 2 * PF + p, last) * 3 + pl) * 64];
+            load_b(bA, p, min(s + 2 * PF + p, last));
             pn_pin();
             mma(bB, p);
-#pragma unroll
-            for (int rb = 0; rb < RB; ++rb) { a[rb][0] = an[rb][0]; a[rb][1] = an[rb][1]; a[rb][2] = an[rb][2]; }
+            keep(a, an);
         }
     }
 #pragma unroll
     for (int p = 0; p < PF; ++p) {
         if (s + p < nst) {
-            uint4 an[RB][3];
+            uint4 an[RB][PNF];
             load_a(an, min(s + p + 1, last));
-#pragma unroll
-            for (int t = 0; t < T; ++t)
-#pragma unroll
-                for (int pl = 0; pl < 3; ++pl) bB[t][p][pl] = rg.st[t][((size_t)min(s + PF + p, last) * 3 + pl) * 64];
+            load_b(bB, p, min(s + PF + p, last));
             mma(bA, p);
-#pragma unroll
-            for (int rb = 0; rb < RB; ++rb) { a[rb][0] = an[rb][0]; a[rb][1] = an[rb][1]; a[rb][2] = an[rb][2]; }
+            keep(a, an);
         }
     }
 #pragma unroll
     for (int p = 0; p < PF - 1; ++p) {
         if (s + PF + p < nst) {
-            uint4 an[RB][3];
+            uint4 an[RB][PNF];
             load_a(an, min(s + PF + p + 1, last));
             mma(bB, p);
-#pragma unroll
-            for (int rb = 0; rb < RB; ++rb) { a[rb][0] = an[rb][0]; a[rb][1] = an[rb][1]; a[rb][2] = an[rb][2]; }
+            keep(a, an);
         }
     }
 }
@@ -985,23 +1202,27 @@ __global__ __launch_bounds__(512) void panel_gemm3_ksw_kernel(const float* __res
     const int tile0 = cbk * T, m0 = rbk * 16;
     const int kpad = (K + 31) & ~31, nst_all = kpad >> 5, pstride = (kpad >> 3) * 16;
     const int per = (nst_all + 7) >> 3, s_lo = min(nst_all, wave * per), nst = min(nst_all, s_lo + per) - s_lo;
-    PnRing3T<T, 2> rg;
+    PnRing3T<T, 2, PnF> rg;
     if (nst > 0) {                                             // (wave-uniform) in flight while the A block is staged
         const uint4* bf[T];
 #pragma unroll
-        for (int t = 0; t < T; ++t) bf[t] = B.f + ((size_t)min(tile0 + t, B.ntile - 1) * B.nst + s_lo) * 3 * 64;
-        panel3_prefetch_t<T, 2>(rg, bf, nst, lane);
+        for (int t = 0; t < T; ++t) bf[t] = B.f + ((size_t)min(tile0 + t, B.ntile - 1) * B.nst + s_lo) * PNF * 64;
+        panel3_prefetch_t<T, 2, PnF>(rg, bf, nst, lane);
     }
-    panel_stage3<512>(pn3_lds, A, lda, m0, M, 0, K, kpad, tid);
+    PnF::stage<512, 1, 6>(pn3_lds, 0, A, lda, m0, M, 0, K, kpad, tid);
     __syncthreads();
-    f32x4_t acc[T];
+    PnF::Acc acc[T];
 #pragma unroll
-    for (int t = 0; t < T; ++t) acc[t] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+    for (int t = 0; t < T; ++t) acc[t] = PnF::zero();
     if (nst > 0) panel3_mma_rt<1, T, 2>(pn3_lds + (size_t)s_lo * 64, pstride, 0, rg, nst, acc, lane);
+    const float rs = PnF::row_isc(pn3_lds, pstride, j);        // (behind the planes: the meeting place below does not reach it)
     __syncthreads();                                           // every wave is done with the image: its head becomes the meeting place
     float4* const red = (float4*)pn3_lds;
 #pragma unroll
-    for (int t = 0; t < T; ++t) red[(size_t)(wave * T + t) * 64 + lane] = make_float4(acc[t][0], acc[t][1], acc[t][2], acc[t][3]);
+    for (int t = 0; t < T; ++t) {
+        const f32x4_t v = PnF::value(acc[t], rs, PnF::tile_isc(B, tile0 + t, g));
+        red[(size_t)(wave * T + t) * 64 + lane] = make_float4(v[0], v[1], v[2], v[3]);
+    }
     __syncthreads();
     if (wave < T) {                                            // wave t adds tile t's eight parts in wave order
         float4 sum = red[(size_t)wave * 64 + lane];
@@ -1034,8 +1255,8 @@ static inline hipError_t panel_gemm3_ksw(const float* A, int lda, int M, int K, 
     const int kpad = (K + 31) & ~31;
     static bool attr = false;
     if (!attr) {
-        hipError_t e = hipFuncSetAttribute((const void*)panel_gemm3_ksw_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, 6 * PN3_MAX_K * 16);
-        if (e == hipSuccess) e = hipFuncSetAttribute((const void*)panel_gemm3_ksw_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 6 * PN3_MAX_K * 16);
+        hipError_t e = hipFuncSetAttribute((const void*)panel_gemm3_ksw_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)pnf_lds_bytes(PN3_MAX_K, 1));
+        if (e == hipSuccess) e = hipFuncSetAttribute((const void*)panel_gemm3_ksw_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)pnf_lds_bytes(PN3_MAX_K, 1));
         if (e != hipSuccess) return e;
         attr = true;
     }
@@ -1045,11 +1266,11 @@ static inline hipError_t panel_gemm3_ksw(const float* A, int lda, int M, int K, 
     const int nrb = (M + 15) / 16;
     int T = nrb * ((B.ntile + 1) / 2) >= 192 ? 2 : 1;
     if (t_env == 1 || t_env == 2) T = t_env;
-    const PnMap mp = panel_map(nrb, (B.ntile + T - 1) / T, (size_t)M * K * 4, (size_t)B.ntile * B.nst * 3 * 1024);
+    const PnMap mp = panel_map(nrb, (B.ntile + T - 1) / T, (size_t)M * K * 4, (size_t)B.ntile * B.nst * PNF * 1024);
     if (T == 2)
-        hipLaunchKernelGGL(panel_gemm3_ksw_kernel<2>, dim3(8 * mp.rpg * mp.cpg), dim3(512), (size_t)6 * kpad * 16, st, A, lda, M, K, B, C, ldc, N, mp);
+        hipLaunchKernelGGL(panel_gemm3_ksw_kernel<2>, dim3(8 * mp.rpg * mp.cpg), dim3(512), pnf_lds_bytes(kpad, 1), st, A, lda, M, K, B, C, ldc, N, mp);
     else
-        hipLaunchKernelGGL(panel_gemm3_ksw_kernel<1>, dim3(8 * mp.rpg * mp.cpg), dim3(512), (size_t)6 * kpad * 16, st, A, lda, M, K, B, C, ldc, N, mp);
+        hipLaunchKernelGGL(panel_gemm3_ksw_kernel<1>, dim3(8 * mp.rpg * mp.cpg), dim3(512), pnf_lds_bytes(kpad, 1), st, A, lda, M, K, B, C, ldc, N, mp);
     return hipGetLastError();
 }
 
@@ -1069,22 +1290,37 @@ __global__ __launch_bounds__(512) void panel_gemm3_kloop_kernel(const float* __r
     const int role = (int)blockIdx.x % nrole, m0 = ((int)blockIdx.x / nrole) * (16 * RB), part = role / ncb, cb = role % ncb;
     const int nst_all = (K + 31) >> 5, per = (nst_all + ks - 1) / ks, s_lo = part * per, s_hi = min(nst_all, s_lo + per);
     const int tile0 = (cb * 8 + wave) * T;                      // this wave's T consecutive column tiles
-    const int kpad = 32 * slab_steps, pstride = (kpad >> 3) * 16, img = 3 * pstride;
-    f32x4_t acc[RB * T];
+    const int kpad = 32 * slab_steps, pstride = (kpad >> 3) * 16, img = pnf_img_u4(kpad);
+    f32x4_t tot[RB * T];                                        // the slabs' products at the tile's scale (PnH2: a row's scale is per slab)
 #pragma unroll
-    for (int i = 0; i < RB * T; ++i) acc[i] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+    for (int i = 0; i < RB * T; ++i) tot[i] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+    PnF::Acc acc[RB * T];
+#pragma unroll
+    for (int i = 0; i < RB * T; ++i) acc[i] = PnF::zero();
     for (int s0 = s_lo; s0 < s_hi; s0 += slab_steps) {
         const int nst = min(slab_steps, s_hi - s0), k0 = 32 * s0, kn = min(K, 32 * (s0 + nst)) - k0;
-        PnRing3T<T, 2> rg;                                      // (requested before the staging: the first round trip hides behind it)
+        PnRing3T<T, 2, PnF> rg;                                 // (requested before the staging: the first round trip hides behind it)
         const uint4* bf[T];
 #pragma unroll
-        for (int t = 0; t < T; ++t) bf[t] = B.f + ((size_t)min(tile0 + t, B.ntile - 1) * B.nst + s0) * 3 * 64;
-        panel3_prefetch_t<T, 2>(rg, bf, nst, lane);
+        for (int t = 0; t < T; ++t) bf[t] = B.f + ((size_t)min(tile0 + t, B.ntile - 1) * B.nst + s0) * PNF * 64;
+        panel3_prefetch_t<T, 2, PnF>(rg, bf, nst, lane);
         if (s0 > s_lo) __syncthreads();                         // every wave is done with the previous slab's images
-#pragma unroll
-        for (int rb = 0; rb < RB; ++rb) panel_stage3<512>(pn3_lds + (size_t)rb * img, A, lda, m0 + 16 * rb, M, k0, kn, kpad, tid);
+        PnF::stage<512, RB, 3>(pn3_lds, img, A, lda, m0, M, k0, kn, kpad, tid);
         __syncthreads();
         if (tile0 < B.ntile) panel3_mma_rt<RB, T, 2>(pn3_lds, pstride, img, rg, nst, acc, lane);
+        if (PnF::SC_U4) {                                       // fold the slab in at its rows' scales
+#pragma unroll
+            for (int rb = 0; rb < RB; ++rb) {
+                const float rs = PnF::row_isc(pn3_lds + (size_t)rb * img, pstride, j);
+#pragma unroll
+                for (int t = 0; t < T; ++t) {
+                    const f32x4_t v = PnF::value(acc[rb * T + t], rs, f32x4_t{1.f, 1.f, 1.f, 1.f});
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) tot[rb * T + t][r] += v[r];
+                    acc[rb * T + t] = PnF::zero();
+                }
+            }
+        }
     }
     float* const C = Cpart + (size_t)part * part_stride;
 #pragma unroll
@@ -1095,13 +1331,13 @@ __global__ __launch_bounds__(512) void panel_gemm3_kloop_kernel(const float* __r
             for (int rb = 0; rb < RB; ++rb) {
                 const int m = m0 + 16 * rb + j;
                 if (m < M) {
-                    float* dst = C + (size_t)m * ldc + n4;
-                    const f32x4_t v = acc[rb * T + t];
-                    if (n4 + 3 < N) *(f32x4u_t*)dst = f32x4u_t{v[0], v[1], v[2], v[3]};
-                    else {
+                    f32x4_t v;
+                    if (PnF::SC_U4) {
+                        const f32x4_t ts = PnF::tile_isc(B, tile0 + t, g);
 #pragma unroll
-                        for (int r = 0; r < 4; ++r) if (n4 + r < N) dst[r] = v[r];
-                    }
+                        for (int r = 0; r < 4; ++r) v[r] = tot[rb * T + t][r] * ts[r];
+                    } else v = PnF::value(acc[rb * T + t], 1.f, f32x4_t{1.f, 1.f, 1.f, 1.f});
+                    pnf_store4(C, ldc, N, m, n4, v);
                 }
             }
         }
@@ -1147,7 +1383,7 @@ static inline hipError_t panel_gemm3_kloop(const float* A, int lda, int M, int K
     const size_t stride = (size_t)M * ldc;
     // steps per slab: RB images of 32 x slab columns, 6 bytes each, in <= 147 KB
     const int slab = std::min(panel_gemm3_kloop_slab(), rb == 4 ? 12 : 24);   // (measured at 512 / 128 rows: RB 4 T 1 192 / 55 us, RB 2 T 2 139 / 44, RB 4 T 2 166 / 57 with 55 spilled registers)
-    const size_t lds = (size_t)rb * 6 * 32 * slab * 16;
+    const size_t lds = pnf_lds_bytes(32 * slab, rb);
     static bool attr = false;
     if (!attr) {
         hipError_t e = hipSuccess;

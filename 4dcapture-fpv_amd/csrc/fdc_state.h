@@ -63,7 +63,8 @@ struct SkinSet {          // skinning constants for a vertex set (all V, or the 
     // pn_fwd: B(k, n) = posedirs[k, n] (offsets = [pose feature | betas] x B), pn_bwd: B(k, n) = posedirs[n, k] (data gradient)
     DevBuf<float> pn_fwd_f, pn_bwd_f;
     PanelB pn_fwd, pn_bwd;
-    DevBuf<unsigned> pn_fwd3_f, pn_bwd3_f;      // the same two operands as three bf16 planes (panel_gemm3_kernel)
+    DevBuf<unsigned> pn_fwd3_f, pn_bwd3_f;      // the same two operands as split planes (format PnF: panel_gemm3_* kernels)
+    DevBuf<float> pn_fwd3_s, pn_bwd3_s;         // their column tiles' inverse scales (PnH2)
     PanelB3 pn_fwd3, pn_bwd3;
     SkinModel model() const {
         SkinModel m; m.vt = vt.p; m.S = nullptr; m.wj = wj.p; m.ww = ww.p; m.K = K;
@@ -75,7 +76,7 @@ struct SkinSet {          // skinning constants for a vertex set (all V, or the 
     void release() { vt.release(); ww.release(); posedirs.release(); wj.release(); csc_w.release(); csc_start.release(); csc_v.release();
                      vpack.release(); csc_v16.release(); csc_chunk.release();
                      pn_fwd_f.release(); pn_bwd_f.release(); pn_fwd = PanelB(); pn_bwd = PanelB();
-                     pn_fwd3_f.release(); pn_bwd3_f.release(); pn_fwd3 = PanelB3(); pn_bwd3 = PanelB3(); }
+                     pn_fwd3_f.release(); pn_bwd3_f.release(); pn_fwd3_s.release(); pn_bwd3_s.release(); pn_fwd3 = PanelB3(); pn_bwd3 = PanelB3(); }
 };
 
 struct OptState {
@@ -325,15 +326,19 @@ int build_skin_set(fdcap_ctx* c, const std::vector<int64_t>& ids, SkinSet* out) 
     out->pn_fwd3 = PanelB3(); out->pn_bwd3 = PanelB3();
     if (nv > 0) {                                 // the forward operand of every set also as three bf16 planes
         std::vector<unsigned> p3;
-        panel_pack3(pd.data(), ldp, 1, NPFX, 3 * nv, p3, &out->pn_fwd3.ntile, &out->pn_fwd3.nst);
+        std::vector<float> sc;
+        PnF::pack(pd.data(), ldp, 1, NPFX, 3 * nv, p3, sc, &out->pn_fwd3.ntile, &out->pn_fwd3.nst);
         HIP_TRY(out->pn_fwd3_f.upload(p3.data(), p3.size()));
-        out->pn_fwd3.f = (const uint4*)out->pn_fwd3_f.p;
+        HIP_TRY(out->pn_fwd3_s.upload(sc.data(), sc.size()));
+        out->pn_fwd3.f = (const uint4*)out->pn_fwd3_f.p; out->pn_fwd3.isc = out->pn_fwd3_s.p;
     }
     if (nv > 0) {                                 // ... and the data-gradient operand (one LDS image up to K = 1696: panel_gemm3 / _rb2k; beyond: panel_gemm3_kloop)
         std::vector<unsigned> p3;
-        panel_pack3(pd.data(), 1, ldp, 3 * nv, NPFX, p3, &out->pn_bwd3.ntile, &out->pn_bwd3.nst);
+        std::vector<float> sc;
+        PnF::pack(pd.data(), 1, ldp, 3 * nv, NPFX, p3, sc, &out->pn_bwd3.ntile, &out->pn_bwd3.nst);
         HIP_TRY(out->pn_bwd3_f.upload(p3.data(), p3.size()));
-        out->pn_bwd3.f = (const uint4*)out->pn_bwd3_f.p;
+        HIP_TRY(out->pn_bwd3_s.upload(sc.data(), sc.size()));
+        out->pn_bwd3.f = (const uint4*)out->pn_bwd3_f.p; out->pn_bwd3.isc = out->pn_bwd3_s.p;
     }
     return 0;
 }

@@ -28,7 +28,8 @@ pytestmark = pytest.mark.gpu
     (1024, 496, 1500, False, 0),        # clip-sized M: two row blocks per fragment stream (panel_gemm3_rb2_kernel), the bench's product
     (531, 700, 1000, True, 3),          # ... ragged rows / tiles, unaligned operand and output rows
     (130, 1690, 496, True, 0),          # longest K whose three-plane LDS image fits a CU's 160 KB (kpad 1696)
-    (130, 2000, 496, True, 0),          # beyond it: the split form must hand over to the K-slabbed fp32 kernel, not fail the launch
+    (130, 2000, 496, True, 0),          # (beyond the three-plane image; the two-plane fp16 image reaches kpad 2528)
+    (130, 2600, 496, True, 0),          # beyond it: the split form must hand over to the K-slabbed fp32 kernel, not fail the launch
     (400, 1700, 496, True, 0),          # clip-sized M above the K-split kernel's range (K <= 1536)
 ])
 @pytest.mark.parametrize("form", ["split3", "fp32"])
@@ -56,6 +57,42 @@ def test_panel_gemm_matches_fp64(M, K, N, transposed, pad, form, monkeypatch):
     assert (np.abs(C[:, :N] - want) <= tol).all()
     if pad:
         assert (C[:, N:] == -7.0).all()                                  # nothing written past the N columns
+
+
+@pytest.mark.parametrize("case", ["rows_and_columns_over_18_decades", "one_element_13_decades_above_its_row", "zero_rows_and_columns"])
+def test_split_product_on_badly_scaled_operands(case, monkeypatch):
+    """The two-plane fp16 form (csrc/fdc_panel.h, PnH2) scales every frame row of the dynamic operand (in the kernel) and every output
+    column of the static one (host) by a power of two before the split; fp16's narrow exponent must not show in the result: rows from
+    1e-12 to 1e6, columns from 1e-8 to 1e4, elements spread over five decades inside them -- same bar as the well-scaled product
+    (measured 5.5e-7 of sum |a||b|; the exact fp32 MFMA chain: 1.4e-6)."""
+    monkeypatch.setenv("FDCAP_GEMM_SPLIT3", "1")
+    lib = capi.load_library()
+    rng = np.random.default_rng(5)
+    if case == "rows_and_columns_over_18_decades":
+        M, K, N = 1024, 496, 1500
+        A = (rng.standard_normal((M, K)) * 10.0 ** rng.uniform(-5, 0, (M, K)) * 10.0 ** rng.uniform(-12, 6, (M, 1))).astype(np.float32)
+        Bm = (rng.standard_normal((K, N)) * 10.0 ** rng.uniform(-5, 0, (K, N)) * 10.0 ** rng.uniform(-8, 4, (1, N))).astype(np.float32)
+    elif case == "one_element_13_decades_above_its_row":
+        M, K, N = 130, 1500, 496
+        A = rng.standard_normal((M, K)).astype(np.float32) * np.float32(1e-9)
+        A[:, 7] = 3.0e4
+        Bm = rng.standard_normal((K, N)).astype(np.float32)
+    else:
+        M, K, N = 70, 496, 100
+        A = rng.standard_normal((M, K)).astype(np.float32)
+        Bm = rng.standard_normal((K, N)).astype(np.float32)
+        A[3] = 0.0; A[40:60] = 0.0; Bm[:, 17] = 0.0; Bm[:, 32:48] = 0.0
+    Ad = torch.tensor(A).cuda()
+    Cd = torch.full((M, N), -7.0, device="cuda")
+    capi.check(lib.fdcap_panel_gemm(capi.dptr(Ad), K, M, K, Bm.ctypes.data_as(ctypes.c_void_p), N, 1, N, capi.dptr(Cd), N,
+                                    capi.current_stream()), "fdcap_panel_gemm")
+    C = Cd.cpu().numpy()
+    want = A.astype(np.float64) @ Bm.astype(np.float64)
+    den = np.abs(A).astype(np.float64) @ np.abs(Bm).astype(np.float64)
+    assert np.isfinite(C).all()
+    assert (np.abs(C - want) <= 1e-6 * den).all(), float((np.abs(C - want) / (den + 1e-300)).max())
+    if case == "zero_rows_and_columns":
+        assert (C[3] == 0).all() and (C[40:60] == 0).all() and (C[:, 17] == 0).all() and (C[:, 32:48] == 0).all()
 
 
 @pytest.mark.parametrize("B", [1, 15, 16, 17, 63, 1028])
