@@ -167,12 +167,25 @@ int fdcap_ctx_create(const fdcap_model_desc* md, fdcap_ctx** out) {
         c->vp.b1 = c->b1.p; c->vp.b2 = c->b2.p; c->vp.b3 = c->b3.p;
         PanelB3* dst3[6] = {&c->vp3.w1, &c->vp3.w2, &c->vp3.w3, &c->vp3.w3t, &c->vp3.w2t, &c->vp3.w1t};
         std::vector<unsigned> p3;
+        std::vector<float> sc3;
+        float c1n[6];                                                      // largest column 1-norm of each operand (VPoserPanels3::c1 ...)
         for (int i = 0; i < 6 && !err; ++i) {
-            panel_pack3(pk[i].w, pk[i].sk, pk[i].sn, pk[i].K, pk[i].N, p3, &dst3[i]->ntile, &dst3[i]->nst);
+            VpF::pack(pk[i].w, pk[i].sk, pk[i].sn, pk[i].K, pk[i].N, p3, sc3, &dst3[i]->ntile, &dst3[i]->nst);
             hipError_t e_ = c->vp_pn3[i].upload(p3.data(), p3.size());
+            if (e_ == hipSuccess) e_ = c->vp_pn3s[i].upload(sc3.data(), sc3.size());
             if (e_ != hipSuccess) err = (int)e_;
-            dst3[i]->f = (const uint4*)c->vp_pn3[i].p;
+            dst3[i]->f = (const uint4*)c->vp_pn3[i].p; dst3[i]->isc = c->vp_pn3s[i].p;
+            double mx = 0.0;
+            for (int n = 0; n < pk[i].N; ++n) {
+                double a = 0.0;
+                for (int k = 0; k < pk[i].K; ++k) a += fabs((double)pk[i].w[(long)k * pk[i].sk + (long)n * pk[i].sn]);
+                mx = std::max(mx, a);
+            }
+            c1n[i] = (float)(mx * 1.001);
         }
+        auto amax = [](const float* b, int n) { float m = 0.f; for (int i = 0; i < n; ++i) m = std::max(m, fabsf(b[i])); return m * 1.001f; };
+        c->vp3.c1 = c1n[0]; c->vp3.c2 = c1n[1]; c->vp3.c3t = c1n[3]; c->vp3.c2t = c1n[4];
+        c->vp3.b1max = amax(md->vp_fc1_b, 512); c->vp3.b2max = amax(md->vp_fc2_b, 512);
         c->vp3.b1 = c->b1.p; c->vp3.b2 = c->b2.p; c->vp3.b3 = c->b3.p;
     }
     if (err) { fdcap_ctx_destroy(c); return err; }
@@ -192,6 +205,7 @@ void fdcap_ctx_destroy(fdcap_ctx* c) {
     c->W1.release(); c->b1.release(); c->W2.release(); c->b2.release(); c->W3.release(); c->b3.release();
     for (auto& b : c->vp_pn) b.release();
     for (auto& b : c->vp_pn3) b.release();
+    for (auto& b : c->vp_pn3s) b.release();
     c->full.release(); c->contact.release(); c->contact_vid.release(); c->contact_perm.release(); c->scene.release(); c->scene_sorted.release(); c->scene_bounds.release(); c->scene_sbounds.release(); c->scene_qbounds.release(); c->scene_inv.release(); c->scene_frags.release(); c->scene_centers.release(); c->sop.release(); c->ws_skin.release(); c->ws_kpart.release();
     for (auto& b : c->ws_f) b.release();
     for (auto& b : c->ws_b) b.release();

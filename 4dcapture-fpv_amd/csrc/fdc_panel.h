@@ -510,6 +510,7 @@ struct PnB3 {
 #pragma unroll
         for (int rb = 0; rb < RB; ++rb) panel_stage3<NT>(lds + (size_t)rb * img, A, lda, m0 + 16 * rb, M, k0, kn, kpad, tid);
     }
+    static __device__ __forceinline__ void pow2(float, float& sc, float& isc) { sc = 1.f; isc = 1.f; }
     static inline void pack(const float* src, long sk, long sn, int K, int N, std::vector<unsigned>& out, std::vector<float>& isc, int* ntile,
                             int* nst) {
         panel_pack3(src, sk, sn, K, N, out, ntile, nst);
@@ -537,6 +538,12 @@ struct PnH2 {
         return v;
     }
     static __device__ __forceinline__ float row_isc(const uint4* image, int pstride, int j) { return ((const float*)(image + (size_t)NP * pstride))[j]; }
+    // the power of two that takes `bound` (>= every |a| of a row; 0: an all-zero row) into [2^13, 2^14), and its inverse
+    static __device__ __forceinline__ void pow2(float bound, float& sc, float& isc) {
+        const int se = bound == 0.f ? 127 : min(max(267 - (int)((__float_as_uint(bound) >> 23) & 255u), 4), 250);
+        sc = __uint_as_float((unsigned)se << 23);
+        isc = __uint_as_float((unsigned)(254 - se) << 23);
+    }
     static __device__ __forceinline__ f32x4_t tile_isc(const PanelB3& B, int tile, int g);    // the lane's four columns 16 tile + 4 g ..
     // rows [m0, m0 + 16 RB) x columns [k0, k0 + kn) of A as RB images of two fp16 planes, each [kpad / 8 chunks][16 rows] x 16 bytes,
     // + the 16 inverse row scales behind each image's planes.  NT threads (a multiple of 64); contains ONE __syncthreads (every thread
@@ -613,10 +620,9 @@ struct PnH2 {
             float m = 0.f;
 #pragma unroll
             for (int w = 0; w < NT / 64; ++w) m = fmaxf(m, sc[16 + w * 16 + i]);
-            // the row's largest |a| -> [2^13, 2^14): scale 2^(140 - biased exponent); an all-zero row keeps 1, the ends are clamped
-            const int se = m == 0.f ? 127 : min(max(267 - (int)((__float_as_uint(m) >> 23) & 255u), 4), 250);
-            scl[rb] = __uint_as_float((unsigned)se << 23);
-            if (tid < 16) sc[tid] = __uint_as_float((unsigned)(254 - se) << 23);
+            float isc;                                          // the row's largest |a| -> [2^13, 2^14); an all-zero row keeps 1, the ends are clamped
+            pow2(m, scl[rb], isc);
+            if (tid < 16) sc[tid] = isc;
         }
         if (keep) {
 #pragma unroll
@@ -1047,68 +1053,73 @@ __device__ __forceinline__ void panel3_prefetch_t(PnRing3T<T, PF, F>& rg, const 
 #pragma unroll
             for (int pl = 0; pl < F::NP; ++pl) rg.bA[t][p][pl] = rg.st[t][((size_t)min(p, last) * F::NP + pl) * 64];
 }
-template <int T, int PF>
-__device__ __forceinline__ void panel3_mma_t(const uint4* __restrict__ sA3, int pstride, PnRing3T<T, PF>& rg, int nst, f32x4_t* acc, int lane) {
-    uint4 (&bA)[T][PF][3] = rg.bA;
-    uint4 bB[T][PF][3];
+template <int T, int PF, class F = PnB3>
+__device__ __forceinline__ void panel3_mma_t(const uint4* __restrict__ sA3, int pstride, PnRing3T<T, PF, F>& rg, int nst, typename F::Acc* acc, int lane) {
+    constexpr int NP = F::NP;
+    uint4 (&bA)[T][PF][NP] = rg.bA;
+    uint4 bB[T][PF][NP];
     const int last = nst - 1;
     auto load_a = [&](uint4* a, int step) {
 #pragma unroll
-        for (int pl = 0; pl < 3; ++pl) a[pl] = sA3[(size_t)pl * pstride + (size_t)step * 64 + lane];
+        for (int pl = 0; pl < NP; ++pl) a[pl] = sA3[(size_t)pl * pstride + (size_t)step * 64 + lane];
     };
-    uint4 a[3];
+    auto keep = [&](uint4* a, const uint4* an) {
+#pragma unroll
+        for (int pl = 0; pl < NP; ++pl) a[pl] = an[pl];
+    };
+    uint4 a[NP];
     load_a(a, 0);
     int s = 0;
     for (; s + 2 * PF <= nst; s += 2 * PF) {
 #pragma unroll
         for (int p = 0; p < PF; ++p) {
-            uint4 an[3];
+            uint4 an[NP];
             load_a(an, s + p + 1);
 #pragma unroll
             for (int t = 0; t < T; ++t) {
 #pragma unroll
-                for (int pl = 0; pl < 3; ++pl) bB[t][p][pl] = rg.st[t][((size_t)(s + PF + p) * 3 + pl) * 64];
+                for (int pl = 0; pl < NP; ++pl) bB[t][p][pl] = rg.st[t][((size_t)(s + PF + p) * NP + pl) * 64];
                 pn_pin();
-                acc[t] = pn3_step(a, bA[t][p], acc[t]);
+                acc[t] = F::step(a, bA[t][p], acc[t]);
             }
-            a[0] = an[0]; a[1] = an[1]; a[2] = an[2];
+            keep(a, an);
         }
 #pragma unroll
         for (int p = 0; p < PF; ++p) {
-            uint4 an[3];
+            uint4 an[NP];
             load_a(an, min(s + PF + p + 1, last));
 #pragma unroll
             for (int t = 0; t < T; ++t) {
 #pragma unroll
-                for (int pl = 0; pl < 3; ++pl) bA[t][p][pl] = rg.st[t][((size_t)min(s + 2 * PF + p, last) * 3 + pl) * 64];
+                for (int pl = 0; pl < NP; ++pl) bA[t][p][pl] = rg.st[t][((size_t)min(s + 2 * PF + p, last) * NP + pl) * 64];
                 pn_pin();
-                acc[t] = pn3_step(a, bB[t][p], acc[t]);
+                acc[t] = F::step(a, bB[t][p], acc[t]);
             }
-            a[0] = an[0]; a[1] = an[1]; a[2] = an[2];
+            keep(a, an);
         }
     }
 #pragma unroll
     for (int p = 0; p < PF; ++p) {
         if (s + p < nst) {
-            uint4 an[3];
+            uint4 an[NP];
             load_a(an, min(s + p + 1, last));
 #pragma unroll
             for (int t = 0; t < T; ++t) {
 #pragma unroll
-                for (int pl = 0; pl < 3; ++pl) bB[t][p][pl] = rg.st[t][((size_t)min(s + PF + p, last) * 3 + pl) * 64];
-                acc[t] = pn3_step(a, bA[t][p], acc[t]);
+                for (int pl = 0; pl < NP; ++pl) bB[t][p][pl] = rg.st[t][((size_t)min(s + PF + p, last) * NP + pl) * 64];
+                acc[t] = F::step(a, bA[t][p], acc[t]);
             }
-            a[0] = an[0]; a[1] = an[1]; a[2] = an[2];
+            keep(a, an);
         }
     }
 #pragma unroll
     for (int p = 0; p < PF - 1; ++p) {
         if (s + PF + p < nst) {
-            uint4 an[3];
+            uint4 an[NP];
             load_a(an, min(s + PF + p + 1, last));
 #pragma unroll
-            for (int t = 0; t < T; ++t) acc[t] = pn3_step(a, bB[t][p], acc[t]);
-            a[0] = an[0]; a[1] = an[1]; a[2] = an[2];
+            for (int t = 0; t < T; ++t) acc[t] = F::step(a, bB[t][p], acc[t]);
+            keep(a, an);
         }
     }
 }
@@ -1402,7 +1413,7 @@ static inline hipError_t panel_gemm3_kloop(const float* A, int lda, int M, int K
     return hipGetLastError();
 }
 
-// four consecutive columns n4 .. n4 + 3 of frame row j -> the three bf16 planes of an LDS block (8 bytes per plane)
+// four consecutive columns n4 .. n4 + 3 of frame row j -> the planes of an LDS block (8 bytes per plane); sc: the row's scale (PnH2)
 __device__ __forceinline__ void pn3_store4(uint4* __restrict__ sA3, int pstride, int n4, int j, float4 v) {
     unsigned h[2], m[2], l[2];
     pn3_split2(v.x, v.y, h[0], m[0], l[0]);
@@ -1413,6 +1424,53 @@ __device__ __forceinline__ void pn3_store4(uint4* __restrict__ sA3, int pstride,
     ((uint2*)(sA3 + (size_t)1 * pstride + it))[half] = make_uint2(m[0], m[1]);
     ((uint2*)(sA3 + (size_t)2 * pstride + it))[half] = make_uint2(l[0], l[1]);
 }
+__device__ __forceinline__ void pnf_lds_store4(PnB3*, uint4* __restrict__ sA3, int pstride, int n4, int j, float4 v, float) { pn3_store4(sA3, pstride, n4, j, v); }
+__device__ __forceinline__ void pnf_lds_store4(PnH2*, uint4* __restrict__ sA, int pstride, int n4, int j, float4 v, float sc) {
+    const float x[4] = {v.x * sc, v.y * sc, v.z * sc, v.w * sc};
+    unsigned h[2], l[2];
+#pragma unroll
+    for (int e = 0; e < 2; ++e) {
+        h[e] = pn2_pk2(x[2 * e], x[2 * e + 1]);
+        const pn_f16x2 hh = __builtin_bit_cast(pn_f16x2, h[e]);
+        l[e] = pn2_pk2((x[2 * e] - (float)hh[0]) * 2048.f, (x[2 * e + 1] - (float)hh[1]) * 2048.f);
+    }
+    const size_t it = (size_t)(n4 >> 3) * 16 + j;
+    const int half = (n4 >> 2) & 1;
+    ((uint2*)(sA + (size_t)0 * pstride + it))[half] = make_uint2(h[0], h[1]);
+    ((uint2*)(sA + (size_t)1 * pstride + it))[half] = make_uint2(l[0], l[1]);
+}
+// one latent value per thread (row i = tid >> 5, column k = tid & 31) straight into a 32-column image (plane stride `pstride`)
+__device__ __forceinline__ void pnf_put_latent(PnB3*, uint4* __restrict__ sZ, int pstride, int i, int k, float v) {
+    const unsigned h = pn3_bf(v);
+    const float r1 = v - pn3_bff(h);
+    const unsigned m = pn3_bf(r1), l = pn3_bf(r1 - pn3_bff(m));
+    unsigned short* const img = (unsigned short*)sZ;
+    const int it = (k >> 3) * 16 + i, e = k & 7;
+    img[(size_t)(0 * pstride + it) * 8 + e] = (unsigned short)h;
+    img[(size_t)(1 * pstride + it) * 8 + e] = (unsigned short)m;
+    img[(size_t)(2 * pstride + it) * 8 + e] = (unsigned short)l;
+}
+#define PN_DPP_MAX(m, ctrl) fmaxf(m, __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(m), ctrl, 0xF, 0xF, false)))
+__device__ __forceinline__ void pnf_put_latent(PnH2*, uint4* __restrict__ sZ, int pstride, int i, int k, float v) {
+    // the row's largest |z|: its 32 values sit in one half of a wave -- four DPP steps inside each row of 16 lanes, one exchange between rows
+    float m = fabsf(v);
+    m = PN_DPP_MAX(m, 0xB1);                                     // quad_perm [1,0,3,2]
+    m = PN_DPP_MAX(m, 0x4E);                                     // quad_perm [2,3,0,1]
+    m = PN_DPP_MAX(m, 0x141);                                    // row_half_mirror
+    m = PN_DPP_MAX(m, 0x140);                                    // row_mirror
+    m = fmaxf(m, __shfl_xor(m, 16));
+    float sc, isc;
+    PnH2::pow2(m, sc, isc);
+    const float x = v * sc;
+    const _Float16 h = (_Float16)x;
+    const _Float16 l = (_Float16)((x - (float)h) * 2048.f);
+    unsigned short* const img = (unsigned short*)sZ;
+    const int it = (k >> 3) * 16 + i, e = k & 7;
+    img[(size_t)(0 * pstride + it) * 8 + e] = __builtin_bit_cast(unsigned short, h);
+    img[(size_t)(1 * pstride + it) * 8 + e] = __builtin_bit_cast(unsigned short, l);
+    if (k == 0) ((float*)(sZ + (size_t)PnH2::NP * pstride))[i] = isc;
+}
+#undef PN_DPP_MAX
 
 // ---------------------------------------------------------------------------------------------------------------------
 // VPoser decoder (fc1 32 -> 512, LeakyReLU(0.2), fc2 512 -> 512, LeakyReLU(0.2), out 512 -> 126)
@@ -1641,7 +1699,11 @@ __global__ void vposer_fold_dz_kernel(const float* __restrict__ part, size_t par
 struct VPoserPanels3 {
     PanelB3 w1, w2, w3, w3t, w2t, w1t;
     const float *b1 = nullptr, *b2 = nullptr, *b3 = nullptr;
+    // PnH2: what bounds a hidden row from the row before it -- |x W + b| <= c max|x| + bmax with c = the largest column 1-norm of W --
+    // so every row's power-of-two scale follows from its latent's (its output gradient's) largest entry without a reduction
+    float c1 = 0.f, b1max = 0.f, c2 = 0.f, b2max = 0.f, c3t = 0.f, c2t = 0.f;
 };
+typedef PnF VpF;                                  // operand format of the fused VPoser kernels
 constexpr int VP3_PZ = (VP_Z / 8) * 16, VP3_PH = (VP_H / 8) * 16, VP3_PQ = (VP_QW / 8) * 16;     // plane strides (uint4)
 // What the backward needs of the hidden activations is their SIGNS (LeakyReLU's slope): the split kernels keep one byte per four
 // columns in H1 / H2 -- bit e = column 4 b + e is positive -- 128 bytes per row instead of 2 KB (late r4: what a kernel leaves dirty in
@@ -1660,88 +1722,90 @@ __device__ __forceinline__ unsigned char vp3_signs(const float4 v) {
 __global__ __launch_bounds__(512) void vposer_fwd_split3_kernel(VPoserPanels3 P, const float* __restrict__ Z, int ldx, int row_lo,
                                                                 int row_hi, float* __restrict__ H1, float* __restrict__ H2,
                                                                 float* __restrict__ Opart, size_t part_stride, VpRows two, DeferredStep ds) {
-    __shared__ __attribute__((aligned(16))) uint4 lds3[3 * (VP3_PZ + VP3_PH + VP3_PQ)];
-    uint4* const sZ = lds3;
-    uint4* const sH1 = sZ + 3 * VP3_PZ;
-    uint4* const sH2 = sH1 + 3 * VP3_PH;
+    constexpr int NP = VpF::NP;
+    __shared__ __attribute__((aligned(16))) uint4 lds3[NP * (VP3_PZ + VP3_PH + VP3_PQ) + VpF::SC_U4];
+    uint4* const sZ = lds3;                                      // (PnH2: the latent rows' inverse scales right behind its planes)
+    uint4* const sH1 = sZ + NP * VP3_PZ + VpF::SC_U4;
+    uint4* const sH2 = sH1 + NP * VP3_PH;
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, j = lane & 15, g = lane >> 4;
     int rblk = (int)(blockIdx.x >> 2);
     if (rblk >= two.nb1) { rblk -= two.nb1; row_lo = two.row2_lo; row_hi = two.row2_hi; }
     const int q = blockIdx.x & 3, r0 = row_lo + rblk * 16;
-    PnRing3T<1, VP3_PF2> rg2;
-    PnRing3T<1, 2> rg3;
-    // the biases of all three layers, requested before the first barrier (the compiler does not move a load across one):
-    // fetched where they are used -- after each layer's products -- every tile's bias was a round trip of its own
+    PnRing3T<1, VP3_PF2, VpF> rg2;
+    PnRing3T<1, 2, VpF> rg3;
+    // the biases (and column scales) of all three layers, requested before the first barrier (the compiler does not move a load across
+    // one): fetched where they are used -- after each layer's products -- every tile's bias was a round trip of its own
     float4 bias1[4];
+    f32x4_t cs1[4];
 #pragma unroll
-    for (int t = 0; t < 4; ++t) bias1[t] = *(const float4*)(P.b1 + (wave * 4 + t) * 16 + 4 * g);
+    for (int t = 0; t < 4; ++t) { bias1[t] = *(const float4*)(P.b1 + (wave * 4 + t) * 16 + 4 * g); cs1[t] = VpF::tile_isc(P.w1, wave * 4 + t, g); }
     const float4 bias2 = *(const float4*)(P.b2 + (q * 8 + wave) * 16 + 4 * g);
+    const f32x4_t cs2 = VpF::tile_isc(P.w2, q * 8 + wave, g), cs3 = VpF::tile_isc(P.w3, wave, g);
     float bias3[4];
 #pragma unroll
     for (int e = 0; e < 4; ++e) bias3[e] = P.b3[min(wave * 16 + 4 * g + e, ODIM - 1)];
+    float bnd1, s1, is1;
     {   // layer 1, all 512 columns (four tiles per wave), K = 32 = one step
-        f32x4_t acc[4];
+        VpF::Acc acc[4];
         const uint4* bf[4];
 #pragma unroll
-        for (int t = 0; t < 4; ++t) { acc[t] = f32x4_t{0.f, 0.f, 0.f, 0.f}; bf[t] = P.w1.f + (size_t)(wave * 4 + t) * P.w1.nst * 3 * 64; }
-        PnRing3T<4, 1> rg1;
-        panel3_prefetch_t<4, 1>(rg1, bf, 1, lane);
-        if (ds.on) {                                       // (wave-uniform) the latent rows after the pending optimiser step,
-            const int i = tid >> 5, k = tid & 31;          // straight into panel_stage3's image: three planes of [k / 8][row] x eight bf16
-            const float v = vp_deferred_latent(ds, r0, row_hi, tid);
-            const unsigned h = pn3_bf(v);
-            const float r1 = v - pn3_bff(h);
-            const unsigned m = pn3_bf(r1), l = pn3_bf(r1 - pn3_bff(m));
-            unsigned short* const img = (unsigned short*)sZ;
-            const int it = (k >> 3) * 16 + i, e = k & 7;   // (plane stride VP3_PZ uint4 = (VP_Z / 8) * 16 items)
-            img[(size_t)(0 * VP3_PZ + it) * 8 + e] = (unsigned short)h;
-            img[(size_t)(1 * VP3_PZ + it) * 8 + e] = (unsigned short)m;
-            img[(size_t)(2 * VP3_PZ + it) * 8 + e] = (unsigned short)l;
-        } else
-            panel_stage3<512>(sZ, Z, ldx, r0, row_hi, 0, VP_Z, VP_Z, tid);
+        for (int t = 0; t < 4; ++t) { acc[t] = VpF::zero(); bf[t] = P.w1.f + (size_t)(wave * 4 + t) * P.w1.nst * NP * 64; }
+        PnRing3T<4, 1, VpF> rg1;
+        panel3_prefetch_t<4, 1, VpF>(rg1, bf, 1, lane);
+        if (ds.on)                                         // (wave-uniform) the latent rows after the pending optimiser step, straight into the image
+            pnf_put_latent((VpF*)nullptr, sZ, VP3_PZ, tid >> 5, tid & 31, vp_deferred_latent(ds, r0, row_hi, tid));
+        else
+            VpF::stage<512, 1, 1>(sZ, 0, Z, ldx, r0, row_hi, 0, VP_Z, VP_Z, tid);
         __syncthreads();
-        panel3_mma_t<4, 1>(sZ, VP3_PZ, rg1, 1, acc, lane);
+        panel3_mma_t<4, 1, VpF>(sZ, VP3_PZ, rg1, 1, acc, lane);
         {
-            const uint4* bf2 = P.w2.f + (size_t)(q * 8 + wave) * P.w2.nst * 3 * 64;
-            panel3_prefetch_t<1, VP3_PF2>(rg2, &bf2, VP_H / 32, lane);
+            const uint4* bf2 = P.w2.f + (size_t)(q * 8 + wave) * P.w2.nst * NP * 64;
+            panel3_prefetch_t<1, VP3_PF2, VpF>(rg2, &bf2, VP_H / 32, lane);
         }
+        const float zis = VpF::row_isc(sZ, VP3_PZ, j);
+        bnd1 = P.c1 * (16384.f * zis) + P.b1max;           // >= every |H1| of row j (2^14 zis >= its largest |z|)
+        VpF::pow2(bnd1, s1, is1);
 #pragma unroll
         for (int t = 0; t < 4; ++t) {
             const int n4 = (wave * 4 + t) * 16 + 4 * g;
             const float4 bias = bias1[t];
-            const float4 v = make_float4(vp_lrelu(acc[t][0] + bias.x), vp_lrelu(acc[t][1] + bias.y), vp_lrelu(acc[t][2] + bias.z),
-                                         vp_lrelu(acc[t][3] + bias.w));
-            pn3_store4(sH1, VP3_PH, n4, j, v);
+            const f32x4_t o = VpF::value(acc[t], zis, cs1[t]);
+            const float4 v = make_float4(vp_lrelu(o[0] + bias.x), vp_lrelu(o[1] + bias.y), vp_lrelu(o[2] + bias.z), vp_lrelu(o[3] + bias.w));
+            pnf_lds_store4((VpF*)nullptr, sH1, VP3_PH, n4, j, v, s1);
             if ((n4 / VP_QW) == q && r0 + j < row_hi) ((unsigned char*)H1)[(size_t)(r0 + j) * VP3_MROW + (n4 >> 2)] = vp3_signs(v);
         }
     }
     __syncthreads();
+    float s2, is2;
     {   // layer 2, this quarter's 128 columns (one tile per wave), K = 512 = 16 steps
-        f32x4_t acc = {0.f, 0.f, 0.f, 0.f};
+        VpF::Acc acc = VpF::zero();
         const int tile = q * 8 + wave;
-        panel3_mma_t<1, VP3_PF2>(sH1, VP3_PH, rg2, VP_H / 32, &acc, lane);
+        panel3_mma_t<1, VP3_PF2, VpF>(sH1, VP3_PH, rg2, VP_H / 32, &acc, lane);
         {
-            const uint4* bf3 = P.w3.f + ((size_t)wave * P.w3.nst + q * (VP_QW / 32)) * 3 * 64;
-            panel3_prefetch_t<1, 2>(rg3, &bf3, VP_QW / 32, lane);
+            const uint4* bf3 = P.w3.f + ((size_t)wave * P.w3.nst + q * (VP_QW / 32)) * NP * 64;
+            panel3_prefetch_t<1, 2, VpF>(rg3, &bf3, VP_QW / 32, lane);
         }
+        VpF::pow2(P.c2 * bnd1 + P.b2max, s2, is2);
         const int n4 = tile * 16 + 4 * g;
         const float4 bias = bias2;
-        const float4 v = make_float4(vp_lrelu(acc[0] + bias.x), vp_lrelu(acc[1] + bias.y), vp_lrelu(acc[2] + bias.z), vp_lrelu(acc[3] + bias.w));
-        pn3_store4(sH2, VP3_PQ, n4 - q * VP_QW, j, v);
+        const f32x4_t o = VpF::value(acc, is1, cs2);
+        const float4 v = make_float4(vp_lrelu(o[0] + bias.x), vp_lrelu(o[1] + bias.y), vp_lrelu(o[2] + bias.z), vp_lrelu(o[3] + bias.w));
+        pnf_lds_store4((VpF*)nullptr, sH2, VP3_PQ, n4 - q * VP_QW, j, v, s2);
         if (r0 + j < row_hi) ((unsigned char*)H2)[(size_t)(r0 + j) * VP3_MROW + (n4 >> 2)] = vp3_signs(v);
     }
     __syncthreads();
     {   // output layer: this quarter's K-slice (128 = 4 steps) of all 126 (128) columns
-        f32x4_t acc = {0.f, 0.f, 0.f, 0.f};
-        panel3_mma_t<1, 2>(sH2, VP3_PQ, rg3, VP_QW / 32, &acc, lane);
+        VpF::Acc acc = VpF::zero();
+        panel3_mma_t<1, 2, VpF>(sH2, VP3_PQ, rg3, VP_QW / 32, &acc, lane);
+        const f32x4_t o = VpF::value(acc, is2, cs3);
         const int n4 = wave * 16 + 4 * g, row = r0 + j;
         if (row < row_hi) {
             float* dst = Opart + (size_t)q * part_stride + (size_t)row * ODIM + n4;
             const float b0 = q == 0 ? bias3[0] : 0.f, b1 = q == 0 ? bias3[1] : 0.f;
-            *(float2*)dst = make_float2(acc[0] + b0, acc[1] + b1);
+            *(float2*)dst = make_float2(o[0] + b0, o[1] + b1);
             if (n4 + 2 < ODIM) {
                 const float b2 = q == 0 ? bias3[2] : 0.f, b3 = q == 0 ? bias3[3] : 0.f;
-                *(float2*)(dst + 2) = make_float2(acc[2] + b2, acc[3] + b3);
+                *(float2*)(dst + 2) = make_float2(o[2] + b2, o[3] + b3);
             }
         }
     }
@@ -1754,68 +1818,80 @@ __global__ __launch_bounds__(512) void vposer_bwd_split3_kernel(VPoserPanels3 P,
     //  end would wait for a CU to come free and then run alone; first, it is done in a microsecond and hands its CU to the rest)
     if ((int)blockIdx.x == tail.block) { scale_tail_block(tail); return; }
     const unsigned bid = blockIdx.x - (tail.block == 0 ? 1u : 0u);
-    __shared__ __attribute__((aligned(16))) uint4 lds3[3 * (VP3_PQ + VP3_PQ + VP3_PH) + 8 * 64];
-    uint4* const sdO = lds3;                      // K = 126 padded to 128
-    uint4* const sdH2 = sdO + 3 * VP3_PQ;         // this quarter's 128 columns of dH2
-    uint4* const sdH1 = sdH2 + 3 * VP3_PQ;        // partial dH1 (all 512 columns)
-    float* const sred = (float*)(sdH1 + 3 * VP3_PH);
+    constexpr int NP = VpF::NP;
+    __shared__ __attribute__((aligned(16))) uint4 lds3[NP * (VP3_PQ + VP3_PQ + VP3_PH) + VpF::SC_U4 + 8 * 64];
+    uint4* const sdO = lds3;                      // K = 126 padded to 128 (PnH2: + the rows' inverse scales behind the planes)
+    uint4* const sdH2 = sdO + NP * VP3_PQ + VpF::SC_U4;   // this quarter's 128 columns of dH2
+    uint4* const sdH1 = sdH2 + NP * VP3_PQ;       // partial dH1 (all 512 columns)
+    float* const sred = (float*)(sdH1 + NP * VP3_PH);
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, j = lane & 15, g = lane >> 4;
     const int q = bid & 3, r0 = row_lo + (int)(bid >> 2) * 16;
-    PnRing3T<4, 2> rgB;
-    PnRing3T<1, 2> rgC;
+    PnRing3T<4, 2, VpF> rgB;
+    PnRing3T<1, 2, VpF> rgC;
     // the forward activations whose signs mask this wave's tiles, requested before the first barrier (rows clamped:
     // unconditional loads).  Fetched after each layer's products they were five dependent round trips on cold data.
     const size_t hrow = (size_t)min(r0 + j, row_hi - 1) * VP3_MROW;          // (sign bytes: vp3_signs)
     const unsigned hm2 = ((const unsigned char*)H2)[hrow + (q * 8 + wave) * 4 + g];
     unsigned hm1[4];
+    f32x4_t csB[4];
 #pragma unroll
-    for (int t = 0; t < 4; ++t) hm1[t] = ((const unsigned char*)H1)[hrow + (wave + 8 * t) * 4 + g];
+    for (int t = 0; t < 4; ++t) { hm1[t] = ((const unsigned char*)H1)[hrow + (wave + 8 * t) * 4 + g]; csB[t] = VpF::tile_isc(P.w2t, wave + 8 * t, g); }
+    const f32x4_t csA = VpF::tile_isc(P.w3t, q * 8 + wave, g), csC = VpF::tile_isc(P.w1t, wave & 1, g);
+    float bd2, sd2, isd2;
     {   // dH2[:, quarter] = (dO x W3[:, quarter]) * mask(H2)
-        f32x4_t acc = {0.f, 0.f, 0.f, 0.f};
+        VpF::Acc acc = VpF::zero();
         const int tile = q * 8 + wave;
-        const uint4* bf = P.w3t.f + (size_t)tile * P.w3t.nst * 3 * 64;
-        PnRing3T<1, 2> rgA;
-        panel3_prefetch_t<1, 2>(rgA, &bf, 4, lane);
-        panel_stage3<512>(sdO, dO, ODIM, r0, row_hi, 0, ODIM, 128, tid);
+        const uint4* bf = P.w3t.f + (size_t)tile * P.w3t.nst * NP * 64;
+        PnRing3T<1, 2, VpF> rgA;
+        panel3_prefetch_t<1, 2, VpF>(rgA, &bf, 4, lane);
+        VpF::stage<512, 1, 1>(sdO, 0, dO, ODIM, r0, row_hi, 0, ODIM, 128, tid);
         __syncthreads();
-        panel3_mma_t<1, 2>(sdO, VP3_PQ, rgA, 4, &acc, lane);
+        panel3_mma_t<1, 2, VpF>(sdO, VP3_PQ, rgA, 4, &acc, lane);
         {
             const uint4* bfb[4];
 #pragma unroll
-            for (int t = 0; t < 4; ++t) bfb[t] = P.w2t.f + ((size_t)(wave + 8 * t) * P.w2t.nst + q * (VP_QW / 32)) * 3 * 64;
-            panel3_prefetch_t<4, 2>(rgB, bfb, VP_QW / 32, lane);
+            for (int t = 0; t < 4; ++t) bfb[t] = P.w2t.f + ((size_t)(wave + 8 * t) * P.w2t.nst + q * (VP_QW / 32)) * NP * 64;
+            panel3_prefetch_t<4, 2, VpF>(rgB, bfb, VP_QW / 32, lane);
         }
+        const float dois = VpF::row_isc(sdO, VP3_PQ, j);
+        bd2 = P.c3t * (16384.f * dois);                   // >= every |dH2| of row j
+        VpF::pow2(bd2, sd2, isd2);
+        const f32x4_t o = VpF::value(acc, dois, csA);
         const int n4 = tile * 16 + 4 * g;
         const unsigned h = hm2;
-        pn3_store4(sdH2, VP3_PQ, n4 - q * VP_QW, j,
-                   make_float4(acc[0] * ((h & 1u) ? 1.f : 0.2f), acc[1] * ((h & 2u) ? 1.f : 0.2f), acc[2] * ((h & 4u) ? 1.f : 0.2f),
-                               acc[3] * ((h & 8u) ? 1.f : 0.2f)));
+        pnf_lds_store4((VpF*)nullptr, sdH2, VP3_PQ, n4 - q * VP_QW, j,
+                       make_float4(o[0] * ((h & 1u) ? 1.f : 0.2f), o[1] * ((h & 2u) ? 1.f : 0.2f), o[2] * ((h & 4u) ? 1.f : 0.2f),
+                                   o[3] * ((h & 8u) ? 1.f : 0.2f)), sd2);
     }
     __syncthreads();
+    float sd1, isd1;
     {   // partial dH1 = (dH2[:, quarter] x W2[quarter rows, :]) * mask(H1): tiles wave, wave + 8, wave + 16, wave + 24
-        f32x4_t acc[4];
+        VpF::Acc acc[4];
 #pragma unroll
-        for (int t = 0; t < 4; ++t) acc[t] = f32x4_t{0.f, 0.f, 0.f, 0.f};
-        panel3_mma_t<4, 2>(sdH2, VP3_PQ, rgB, VP_QW / 32, acc, lane);
+        for (int t = 0; t < 4; ++t) acc[t] = VpF::zero();
+        panel3_mma_t<4, 2, VpF>(sdH2, VP3_PQ, rgB, VP_QW / 32, acc, lane);
         {
-            const uint4* bfc = P.w1t.f + ((size_t)(wave & 1) * P.w1t.nst + (wave >> 1) * 4) * 3 * 64;
-            panel3_prefetch_t<1, 2>(rgC, &bfc, 4, lane);
+            const uint4* bfc = P.w1t.f + ((size_t)(wave & 1) * P.w1t.nst + (wave >> 1) * 4) * NP * 64;
+            panel3_prefetch_t<1, 2, VpF>(rgC, &bfc, 4, lane);
         }
+        VpF::pow2(P.c2t * bd2, sd1, isd1);
 #pragma unroll
         for (int t = 0; t < 4; ++t) {
             const int n4 = (wave + 8 * t) * 16 + 4 * g;
             const unsigned h = hm1[t];
-            pn3_store4(sdH1, VP3_PH, n4, j,
-                       make_float4(acc[t][0] * ((h & 1u) ? 1.f : 0.2f), acc[t][1] * ((h & 2u) ? 1.f : 0.2f),
-                                   acc[t][2] * ((h & 4u) ? 1.f : 0.2f), acc[t][3] * ((h & 8u) ? 1.f : 0.2f)));
+            const f32x4_t o = VpF::value(acc[t], isd2, csB[t]);
+            pnf_lds_store4((VpF*)nullptr, sdH1, VP3_PH, n4, j,
+                           make_float4(o[0] * ((h & 1u) ? 1.f : 0.2f), o[1] * ((h & 2u) ? 1.f : 0.2f),
+                                       o[2] * ((h & 4u) ? 1.f : 0.2f), o[3] * ((h & 8u) ? 1.f : 0.2f)), sd1);
         }
     }
     __syncthreads();
     {   // partial d latent = partial dH1 x W1: 2 column tiles x 4 K-slices (128 columns = 4 steps each), slices summed in order
-        f32x4_t acc = {0.f, 0.f, 0.f, 0.f};
+        VpF::Acc acc = VpF::zero();
         const int tile = wave & 1, ks = wave >> 1;
-        panel3_mma_t<1, 2>(sdH1 + (size_t)ks * 4 * 64, VP3_PH, rgC, 4, &acc, lane);
-        *(float4*)(sred + (size_t)(ks * 2 + tile) * 256 + lane * 4) = make_float4(acc[0], acc[1], acc[2], acc[3]);
+        panel3_mma_t<1, 2, VpF>(sdH1 + (size_t)ks * 4 * 64, VP3_PH, rgC, 4, &acc, lane);
+        const f32x4_t o = VpF::value(acc, isd1, csC);
+        *(float4*)(sred + (size_t)(ks * 2 + tile) * 256 + lane * 4) = make_float4(o[0], o[1], o[2], o[3]);
     }
     __syncthreads();
     if (wave < 2) {

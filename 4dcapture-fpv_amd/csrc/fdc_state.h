@@ -161,7 +161,8 @@ struct fdcap_ctx {
     DevBuf<float> W1, b1, W2, b2, W3, b3;
     DevBuf<float> vp_pn[6];            // decoder weights in MFMA fragment order: forward w1 w2 w3, backward w3t w2t w1t
     VPoserPanels vp;
-    DevBuf<unsigned> vp_pn3[6];        // ... and as three bf16 planes each (the default form of the products)
+    DevBuf<unsigned> vp_pn3[6];        // ... and as split planes each (format VpF; the default form of the products)
+    DevBuf<float> vp_pn3s[6];          // their output columns' inverse scales (PnH2)
     VPoserPanels3 vp3;
     SkinSet full, contact;
     bool full_ready = false;
