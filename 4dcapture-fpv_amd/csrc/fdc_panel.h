@@ -784,12 +784,13 @@ __global__ __launch_bounds__(64 * NW) void panel_gemm3_kernel(const float* __res
     const int kpad = (K + 31) & ~31, nst = kpad >> 5, pstride = (kpad >> 3) * 16;
     PnRing3<2> rg;
     panel3_prefetch<2>(rg, B.f + (size_t)(active ? tile : 0) * B.nst * PNF * 64, nst, lane);      // in flight while the A block is staged
+    const f32x4_t ts = PnF::tile_isc(B, tile, g);                // (with the first fragments: at the epilogue it would be a cold round trip of its own)
     PnF::stage<64 * NW, 1, (NW == 8 ? 6 : 4)>(pn3_lds, 0, A, lda, m0, M, 0, K, kpad, tid);
     __syncthreads();
     PnF::Acc acc = PnF::zero();
     if (active) panel3_mma<1, 2>(pn3_lds, pstride, 0, rg, nst, &acc, lane);
     const int n4 = tile * 16 + 4 * g, m = m0 + j;
-    if (active && n4 < N && m < M) pnf_store4(C, ldc, N, m, n4, PnF::value(acc, PnF::row_isc(pn3_lds, pstride, j), PnF::tile_isc(B, tile, g)));
+    if (active && n4 < N && m < M) pnf_store4(C, ldc, N, m, n4, PnF::value(acc, PnF::row_isc(pn3_lds, pstride, j), ts));
 }
 // Two row blocks per fragment stream, for clip-sized M.  s_memtime in panel_gemm3_kernel (1024 rows): the MFMA phase of the
 // K = 1500 data gradient takes 20.8 k cycles for 282 MFMAs per wave -- 74 cycles each where the pipe needs 16 -- and its eight
@@ -808,6 +809,7 @@ __global__ __launch_bounds__(768) void panel_gemm3_rb2_kernel(const float* __res
     if (xcd * cpg >= ncb) return;
     PnRing3<2> rg;
     panel3_prefetch<2>(rg, B.f + (size_t)min((xcd * cpg) * 12 + wave, B.ntile - 1) * B.nst * PNF * 64, nst, lane);
+    f32x4_t ts = PnF::tile_isc(B, (xcd * cpg) * 12 + wave, g);   // (requested with the fragments: see panel_gemm3_kernel)
     PnF::stage<768, 2, 2>(pn3_lds, img, A, lda, m0, M, 0, K, kpad, tid);
     __syncthreads();
     const float rs[2] = {PnF::row_isc(pn3_lds, pstride, j), PnF::row_isc(pn3_lds + img, pstride, j)};
@@ -815,15 +817,17 @@ __global__ __launch_bounds__(768) void panel_gemm3_rb2_kernel(const float* __res
         const int tile = cb * 12 + wave;
         PnF::Acc acc[2] = {PnF::zero(), PnF::zero()};
         if (tile < B.ntile) panel3_mma<2, 2>(pn3_lds, pstride, img, rg, nst, acc, lane);
-        if (cb + 1 < min(ncb, (xcd + 1) * cpg))
+        const f32x4_t tsc = ts;
+        if (cb + 1 < min(ncb, (xcd + 1) * cpg)) {
             panel3_prefetch<2>(rg, B.f + (size_t)min((cb + 1) * 12 + wave, B.ntile - 1) * B.nst * PNF * 64, nst, lane);
+            ts = PnF::tile_isc(B, (cb + 1) * 12 + wave, g);
+        }
         const int n4 = tile * 16 + 4 * g;
         if (tile < B.ntile && n4 < N) {
-            const f32x4_t ts = PnF::tile_isc(B, tile, g);
 #pragma unroll
             for (int rb = 0; rb < 2; ++rb) {
                 const int m = m0 + 16 * rb + j;
-                if (m < M) pnf_store4(C, ldc, N, m, n4, PnF::value(acc[rb], rs[rb], ts));
+                if (m < M) pnf_store4(C, ldc, N, m, n4, PnF::value(acc[rb], rs[rb], tsc));
             }
         }
     }
@@ -845,6 +849,7 @@ __global__ __launch_bounds__(512) void panel_gemm3_rb2k_kernel(const float* __re
     const bool active = tile < B.ntile && nst > 0;
     PnRing3<2> rg;
     panel3_prefetch<2>(rg, B.f + ((size_t)(active ? tile : 0) * B.nst + s0) * PNF * 64, max(nst, 1), lane);
+    const f32x4_t ts = PnF::tile_isc(B, tile, g);               // (requested with the fragments: see panel_gemm3_kernel)
     PnF::stage<512, 2, 3>(pn3_lds, img, A, lda, m0, M, k0, kn, kpad, tid);
     __syncthreads();
     PnF::Acc acc[2] = {PnF::zero(), PnF::zero()};
@@ -852,7 +857,6 @@ __global__ __launch_bounds__(512) void panel_gemm3_rb2k_kernel(const float* __re
     const int n4 = tile * 16 + 4 * g;
     if (tile < B.ntile && n4 < N) {
         float* const C = Cpart + (size_t)half * part_stride;
-        const f32x4_t ts = PnF::tile_isc(B, tile, g);
 #pragma unroll
         for (int rb = 0; rb < 2; ++rb) {
             const int m = m0 + 16 * rb + j;
@@ -894,6 +898,7 @@ __global__ __launch_bounds__(512) void panel_gemm3_wide_kernel(const float* __re
     if (cb0 >= cb1) return;
     PnRing3<2> rg;
     panel3_prefetch<2>(rg, B.f + (size_t)min(cb0 * 8 + wave, B.ntile - 1) * B.nst * PNF * 64, nst, lane);
+    f32x4_t ts = PnF::tile_isc(B, cb0 * 8 + wave, g);           // (requested with the fragments: see panel_gemm3_kernel)
     PnF::stage<512, RB, 3>(pn3_lds, img, A, lda, m0, M, 0, K, kpad, tid);
     __syncthreads();
     float rs[RB];
@@ -905,14 +910,17 @@ __global__ __launch_bounds__(512) void panel_gemm3_wide_kernel(const float* __re
 #pragma unroll
         for (int rb = 0; rb < RB; ++rb) acc[rb] = PnF::zero();
         if (tile < B.ntile) panel3_mma<RB, 2>(pn3_lds, pstride, img, rg, nst, acc, lane);
-        if (cb + 1 < cb1) panel3_prefetch<2>(rg, B.f + (size_t)min((cb + 1) * 8 + wave, B.ntile - 1) * B.nst * PNF * 64, nst, lane);
+        const f32x4_t tsc = ts;
+        if (cb + 1 < cb1) {
+            panel3_prefetch<2>(rg, B.f + (size_t)min((cb + 1) * 8 + wave, B.ntile - 1) * B.nst * PNF * 64, nst, lane);
+            ts = PnF::tile_isc(B, (cb + 1) * 8 + wave, g);
+        }
         const int n4 = tile * 16 + 4 * g;
         if (tile < B.ntile && n4 < N) {
-            const f32x4_t ts = PnF::tile_isc(B, tile, g);
 #pragma unroll
             for (int rb = 0; rb < RB; ++rb) {
                 const int m = m0 + 16 * rb + j;
-                if (m < M) pnf_store4(C, ldc, N, m, n4, PnF::value(acc[rb], rs[rb], ts));
+                if (m < M) pnf_store4(C, ldc, N, m, n4, PnF::value(acc[rb], rs[rb], tsc));
             }
         }
     }
@@ -1220,6 +1228,9 @@ __global__ __launch_bounds__(512) void panel_gemm3_ksw_kernel(const float* __res
         for (int t = 0; t < T; ++t) bf[t] = B.f + ((size_t)min(tile0 + t, B.ntile - 1) * B.nst + s_lo) * PNF * 64;
         panel3_prefetch_t<T, 2, PnF>(rg, bf, nst, lane);
     }
+    f32x4_t ts[T];
+#pragma unroll
+    for (int t = 0; t < T; ++t) ts[t] = PnF::tile_isc(B, tile0 + t, g);
     PnF::stage<512, 1, 6>(pn3_lds, 0, A, lda, m0, M, 0, K, kpad, tid);
     __syncthreads();
     PnF::Acc acc[T];
@@ -1231,7 +1242,7 @@ __global__ __launch_bounds__(512) void panel_gemm3_ksw_kernel(const float* __res
     float4* const red = (float4*)pn3_lds;
 #pragma unroll
     for (int t = 0; t < T; ++t) {
-        const f32x4_t v = PnF::value(acc[t], rs, PnF::tile_isc(B, tile0 + t, g));
+        const f32x4_t v = PnF::value(acc[t], rs, ts[t]);
         red[(size_t)(wave * T + t) * 64 + lane] = make_float4(v[0], v[1], v[2], v[3]);
     }
     __syncthreads();
@@ -1308,6 +1319,9 @@ __global__ __launch_bounds__(512) void panel_gemm3_kloop_kernel(const float* __r
     PnF::Acc acc[RB * T];
 #pragma unroll
     for (int i = 0; i < RB * T; ++i) acc[i] = PnF::zero();
+    f32x4_t ts[T];
+#pragma unroll
+    for (int t = 0; t < T; ++t) ts[t] = PnF::tile_isc(B, tile0 + t, g);
     for (int s0 = s_lo; s0 < s_hi; s0 += slab_steps) {
         const int nst = min(slab_steps, s_hi - s0), k0 = 32 * s0, kn = min(K, 32 * (s0 + nst)) - k0;
         PnRing3T<T, 2, PnF> rg;                                 // (requested before the staging: the first round trip hides behind it)
@@ -1344,9 +1358,8 @@ __global__ __launch_bounds__(512) void panel_gemm3_kloop_kernel(const float* __r
                 if (m < M) {
                     f32x4_t v;
                     if (PnF::SC_U4) {
-                        const f32x4_t ts = PnF::tile_isc(B, tile0 + t, g);
 #pragma unroll
-                        for (int r = 0; r < 4; ++r) v[r] = tot[rb * T + t][r] * ts[r];
+                        for (int r = 0; r < 4; ++r) v[r] = tot[rb * T + t][r] * ts[t][r];
                     } else v = PnF::value(acc[rb * T + t], 1.f, f32x4_t{1.f, 1.f, 1.f, 1.f});
                     pnf_store4(C, ldc, N, m, n4, v);
                 }
