@@ -52,7 +52,7 @@ import torch  # noqa: E402
 
 # /opt/skills/guides/MI355X_MICROARCH.md
 HBM_PEAK_GBS = 8000.0          # HBM3E 8 TB/s
-BF16_DENSE_TFLOPS = 2500.0     # dense bf16 MFMA
+BF16_DENSE_TFLOPS = 2500.0     # dense bf16 / fp16 MFMA (same rate on gfx950)
 FP32_MFMA_TFLOPS = 157.3       # fp32 MFMA (64 FLOP/clk/SIMD at 2.4 GHz)
 NUM_SIMD = 1024                # 256 CUs x 4
 NUM_XCD = 8
@@ -214,8 +214,9 @@ def base_line(args, rk, nc, value, dt):
     return {"metric": METRIC, "value": value, "unit": "frames/s", "n_gpus": rk.world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": dt / max(args.steps, 1) * 1e3, "higher_is_better": True,
             "scaling": args.scaling, "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "arithmetic": "fp32 values and fp32 accumulation throughout; dense products as exact three-way bf16 splits of the fp32 "
-                          "operands on the bf16 matrix cores (error of the fp32 chain; FDCAP_GEMM_SPLIT3=0: v_mfma_f32 chains, see exact_fp32)",
+            "arithmetic": "fp32 values and fp32 accumulation throughout; dense products on the 16-bit matrix cores as two-plane fp16 splits of "
+                          "the power-of-two-scaled fp32 operands, three products per term (measured error below the fp32 MFMA chain's: "
+                          "tools/panel_error_probe.py; FDCAP_GEMM_SPLIT3=0: v_mfma_f32 chains, see exact_fp32)",
             "config": {"workload": f"{CONFIG_NAMES[cfg] if cfg else 'non-default sizes (not a BASELINE configuration)'}: {N}-frame clip, "
                                    f"{ns}-pt scene, {nc} contact verts, {args.iters} Adam iterations (phase split 0.8), full loss; "
                                    + (f"one whole clip per GPU, {rk.world} GPU(s), no data-path collective" if weak else
@@ -467,9 +468,9 @@ def nn_roofline(pk, src, sec_loop, ms_steady, n_timed, alg_bytes):
 
 def per_kernel_table(pk, F, nc, K, src):
     """Every launch of a phase-1 iteration next to the peak that binds it.  Microseconds: kernel-trace averages of the committed
-    profile (the same command's rocprofv3 --kernel-trace --stats).  Dense products: EXECUTED bf16 MFMA flops (SQ_INSTS_MFMA of
-    the PMC mix pass x 16 384 flop per v_mfma_f32_16x16x32_bf16 wave instruction; the fp32-equivalent useful flops beside them)
-    against the dense bf16 peak.  Per-frame kernels: ALGORITHMIC bytes (what the launch must read and write once; formulas
+    profile (the same command's rocprofv3 --kernel-trace --stats).  Dense products: EXECUTED 16-bit MFMA flops (SQ_INSTS_MFMA of
+    the PMC mix pass x 16 384 flop per v_mfma_f32_16x16x32_f16 wave instruction; the fp32-equivalent useful flops beside them)
+    against the dense fp16 / bf16 peak.  Per-frame kernels: ALGORITHMIC bytes (what the launch must read and write once; formulas
     in DESIGN §5) against HBM, with the counter traffic (FETCH x 2 + WRITE, guide's gfx950 correction) beside them."""
     if not pk:
         return None
@@ -501,9 +502,9 @@ def per_kernel_table(pk, F, nc, K, src):
             e["mean_waves_per_simd"] = c["mean_waves_per_simd"]
         if bound == "mfma":
             ex = k.get("SQ_INSTS_MFMA")
-            e.update({"useful_fp32_flop": work, "unit": "TFLOP/s (bf16 MFMA executed, dense)", "peak": BF16_DENSE_TFLOPS})
+            e.update({"useful_fp32_flop": work, "unit": "TFLOP/s (fp16 MFMA executed, dense)", "peak": BF16_DENSE_TFLOPS})
             if ex is not None:
-                e.update({"executed_bf16_flop": ex * 16384.0, "achieved": ex * 16384.0 / us / 1e6, "frac": ex * 16384.0 / us / 1e6 / BF16_DENSE_TFLOPS})
+                e.update({"executed_mfma_flop": ex * 16384.0, "achieved": ex * 16384.0 / us / 1e6, "frac": ex * 16384.0 / us / 1e6 / BF16_DENSE_TFLOPS})
             e["floor_us"] = None if ex is None else ex * 16384.0 / (BF16_DENSE_TFLOPS * 1e6)
         elif bound == "hbm":
             e.update({"algorithmic_bytes": work, "unit": "GB/s", "peak": HBM_PEAK_GBS, "achieved": work / us / 1e3, "frac": work / us / 1e3 / HBM_PEAK_GBS,
@@ -666,10 +667,10 @@ def main():
     tf = gflop / ms_g.value                                 # useful fp32 multiply-adds, TFLOP/s
     wide = counter_fracs(ops_pk.get("blend_wide")) if quoted else None
     if split3:
-        ex = 6.0 * tf * 512.0 / 496.0                       # six bf16 MFMAs per product term, K padded 496 -> 512
-        blend = {"kernel": "fdc::panel_gemm3_wide_kernel<2> (pose + shape blendshapes [F,496] x [496,3V]; fp32 operands as three bf16 parts, "
-                           "six v_mfma_f32_16x16x32_bf16 per 32 columns, fp32 accumulation, static operand in fragment order)",
-                 "ms_per_launch": ms_g.value, "bound": "mfma", "achieved": ex, "peak": BF16_DENSE_TFLOPS, "unit": "TFLOP/s (bf16 MFMA executed, dense)",
+        ex = 3.0 * tf * 512.0 / 496.0                       # three fp16 MFMAs per product term (r5; six bf16 ones until then), K padded 496 -> 512
+        blend = {"kernel": "fdc::panel_gemm3_wide_kernel<2> (pose + shape blendshapes [F,496] x [496,3V]; fp32 operands as two scaled fp16 parts, "
+                           "three v_mfma_f32_16x16x32_f16 per 32 columns, fp32 accumulation, static operand in fragment order)",
+                 "ms_per_launch": ms_g.value, "bound": "mfma", "achieved": ex, "peak": BF16_DENSE_TFLOPS, "unit": "TFLOP/s (fp16 MFMA executed, dense)",
                  "frac": ex / BF16_DENSE_TFLOPS, "mfma_busy_frac": None if not wide else wide.get("mfma_busy_frac"),
                  "fp32_equivalent": {"achieved": tf, "unit": "TFLOP/s of fp32 multiply-adds", "fp32_mfma_peak": FP32_MFMA_TFLOPS,
                                      "ratio_to_fp32_mfma_peak": tf / FP32_MFMA_TFLOPS,
