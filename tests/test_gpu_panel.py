@@ -95,6 +95,29 @@ def test_split_product_on_badly_scaled_operands(case, monkeypatch):
         assert (C[3] == 0).all() and (C[40:60] == 0).all() and (C[:, 17] == 0).all() and (C[:, 32:48] == 0).all()
 
 
+@pytest.mark.parametrize("M,K,N", [(70, 496, 100), (1024, 496, 1500), (130, 1500, 496)])
+def test_split_product_propagates_nan_and_inf(M, K, N, monkeypatch):
+    """A non-finite entry of the dynamic operand must reach every output of its row (FittingOP's check_finite relies on it) and no
+    other row: the row scales of the fp16-plane form come from the rows' largest FINITE magnitudes."""
+    monkeypatch.setenv("FDCAP_GEMM_SPLIT3", "1")
+    lib = capi.load_library()
+    rng = np.random.default_rng(9)
+    A = rng.standard_normal((M, K)).astype(np.float32)
+    Bm = rng.standard_normal((K, N)).astype(np.float32)
+    A[3, 17] = np.nan
+    A[40, K - 1] = np.inf
+    Ad = torch.tensor(A).cuda()
+    Cd = torch.zeros((M, N), device="cuda")
+    capi.check(lib.fdcap_panel_gemm(capi.dptr(Ad), K, M, K, Bm.ctypes.data_as(ctypes.c_void_p), N, 1, N, capi.dptr(Cd), N,
+                                    capi.current_stream()), "fdcap_panel_gemm")
+    C = Cd.cpu().numpy()
+    assert not np.isfinite(C[3]).any() and not np.isfinite(C[40]).any()
+    ok = np.ones(M, bool); ok[[3, 40]] = False
+    want = A[ok].astype(np.float64) @ Bm.astype(np.float64)
+    den = np.abs(A[ok]).astype(np.float64) @ np.abs(Bm).astype(np.float64)
+    assert (np.abs(C[ok] - want) <= 1e-6 * den).all()
+
+
 @pytest.mark.parametrize("B", [1, 15, 16, 17, 63, 1028])
 def test_fused_vposer_forward_ragged_rows(B):
     vp = synth.make_vposer(seed=11)
