@@ -1223,15 +1223,42 @@ __global__ __launch_bounds__(256) void nn_seed_kernel(const float* __restrict__ 
         }
     }
     if (bc < 0) return;                                       // NaN query: stays unseeded (the scan handles it)
-    p0 = bc * MF_CH;
-    p1 = min(T.n, p0 + MF_CH);
     float bd = INFINITY;
     int bi = -1;
     float4 bp = make_float4(0.f, 0.f, 0.f, __int_as_float(-1));
-    for (int p = p0; p < p1; ++p) {
-        const float4 pt = T.pts[p];
-        const float d = nn_exact_d2(x, y, z, pt.x, pt.y, pt.z);
-        if (d < bd) { bd = d; bi = __float_as_int(pt.w); bp = make_float4(pt.x, pt.y, pt.z, __int_as_float(p)); }
+    auto scan = [&](int c) {
+        p0 = c * MF_CH;
+        p1 = min(T.n, p0 + MF_CH);
+        for (int p = p0; p < p1; ++p) {
+            const float4 pt = T.pts[p];
+            const float d = nn_exact_d2(x, y, z, pt.x, pt.y, pt.z);
+            if (d < bd) { bd = d; bi = __float_as_int(pt.w); bp = make_float4(pt.x, pt.y, pt.z, __int_as_float(p)); }
+        }
+    };
+    scan(bc);
+    // r5: the nearest BOX can be a poor choice far from every surface -- a cell at the scene's rim is a large box with its points at
+    // the far end -- and the first launch of a fit pays for a loose seed with a ball that reaches thousands of quarters (BASELINE
+    // config 5, 5.4 M queries most of them metres from anything: the first search launch took 83 ms, every later one ~1).  A cell's
+    // centre and radius bound its farthest point: the cell with the smallest |x - c| + r is scanned as well when that bound beats the
+    // first cell's best.
+    if (T.centers) {
+        float bm = INFINITY;
+        int bc2 = -1;
+        auto centre = [&](int c) {
+            const float4 cc = T.centers[c];
+            const float dx = x - cc.x, dy = y - cc.y, dz = z - cc.z;
+            const float m = __builtin_amdgcn_sqrtf(fmaf(dz, dz, fmaf(dy, dy, dx * dx))) + cc.w;
+            if (m < bm) { bm = m; bc2 = c; }
+        };
+        if (T.sbounds) {                                      // (a subtree's box distance is a lower bound of every |x - c| + r in it)
+            const int nsuper = (nchunk + ST4_SUPER - 1) / ST4_SUPER;
+            for (int sb = 0; sb < nsuper; ++sb) {
+                if (!(box_d2(T.sbounds[2 * sb], T.sbounds[2 * sb + 1], x, y, z) < bm * bm)) continue;
+                for (int c = sb * ST4_SUPER; c < min(nchunk, (sb + 1) * ST4_SUPER); ++c) centre(c);
+            }
+        } else
+            for (int c = 0; c < nchunk; ++c) centre(c);
+        if (bc2 >= 0 && bc2 != bc && bm * bm < bd) scan(bc2);
     }
     seed[qi] = bi;
     seedpt[qi] = bp;

@@ -18,10 +18,10 @@ from fdcap_amd import capi, synth
 from fdcap_amd.fitting import FittingOP
 from fdcap_amd.io import read_camerapose
 lo, hi = (int(sys.argv[1]) if len(sys.argv) > 1 else 396), (int(sys.argv[2]) if len(sys.argv) > 2 else 440)
-N, ns = 1024, 500000
+N, ns = int(os.environ.get("FRAMES", "1024")), int(os.environ.get("SCENE", "500000"))       # (FRAMES=512 SCENE=2000000 ALLC=1: BASELINE config 5)
 bm = synth.make_body_model(10475, seed=0); vp = synth.make_vposer(seed=1); clip = synth.make_clip(N, seed=3)
 scene = synth.make_scene(ns, seed=2); l, r = synth.make_contact_ids(bm.v_template, per_part=250, seed=4)
-fop = FittingOP({"num_iter": 500}, {}, N, body_model=bm, vposer=vp, scene_verts=scene, contact_ids=np.concatenate([l, r]),
+fop = FittingOP({"num_iter": 500}, {}, N, body_model=bm, vposer=vp, scene_verts=scene, contact_ids=np.arange(10475) if os.environ.get("ALLC") == "1" else np.concatenate([l, r]),
                 camera_ext=read_camerapose(clip.camerapose_lines))
 L = capi.load_library()
 L.fdcap_debug_nn_stats.argtypes = [ctypes.POINTER(ctypes.c_ulonglong)]
@@ -36,4 +36,4 @@ def hook(k):
     print(f"{k:4d} {1e6 * (t - t_last[0]):9.0f} {out[4]:10d} {out[5]:10d} {out[6]:9d} {out[7]:10d} {out[0]:12d} {out[1]:12d} {out[2]:8d}")
     t_last[0] = time.perf_counter()
 fop.snapshot_hook = hook
-fop.fitting(torch.tensor(clip.body_params).cuda(), "global", log_every=1, snapshot_at=list(range(lo, hi)) + [1, 2, 3, 10, 11, 50, 51, 200, 201])
+fop.fitting(torch.tensor(clip.body_params).cuda(), "global", log_every=1, snapshot_at=list(range(lo, hi)) + [int(v) for v in os.environ.get("EXTRA", "1,2,3,10,11,50,51,200,201").split(",")])
