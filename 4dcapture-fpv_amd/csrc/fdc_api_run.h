@@ -315,7 +315,7 @@ int fdcap_panel_gemm(const float* A, int32_t lda, int32_t M, int32_t K, const fl
     hipStream_t st = (hipStream_t)stream;
     {
         const char* e3 = getenv("FDCAP_GEMM_SPLIT3");                // (read per call here, so a test can run both forms in one process)
-        if (!(e3 && e3[0] == '0') && panel_gemm3_fits(K)) {          // the three-way bf16 split form of the same product (the default)
+        if (!(e3 && e3[0] == '0') && panel_gemm3_fits(K)) {          // the split form of the same product on the 16-bit matrix cores (format PnF; the default)
             std::vector<unsigned> p3;
             std::vector<float> sc;
             PanelB3 B3;

@@ -456,7 +456,7 @@ __device__ __forceinline__ f32x4_t pn3_step(const uint4* a /*[3] planes h m l of
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
-// Operand formats of the split products.  PnB3: the three bf16 planes above (six products per step; the fused VPoser kernels).
+// Operand formats of the split products.  PnB3: the three bf16 planes above (six products per step; -DFDC_PN_H2=0 builds everything on it).
 // PnH2 (late r5; the blend products): TWO fp16 planes and THREE products per step.
 //   a s = h + 2^-11 l,  h = fp16(a s),  l = fp16((a s - h) 2^11)   (both conversions round to nearest even; a s - h is exact)
 // with s a power of two per frame row of the dynamic operand (its largest |a| lands in [2^13, 2^14): found while the block is
@@ -1707,7 +1707,7 @@ __global__ void vposer_fold_dz_kernel(const float* __restrict__ part, size_t par
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
-// The fused VPoser kernels on the three-way bf16 split (same decomposition: 16 rows x one quarter of the hidden columns
+// The fused VPoser kernels on the split format VpF (= PnF: two scaled fp16 planes, r5; three bf16 planes until then) (same decomposition: 16 rows x one quarter of the hidden columns
 // per workgroup, four partial outputs / four partial latent gradients; see vposer_fwd_fused_kernel / vposer_bwd_fused_kernel).
 struct VPoserPanels3 {
     PanelB3 w1, w2, w3, w3t, w2t, w1t;

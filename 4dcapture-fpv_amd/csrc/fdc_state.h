@@ -325,7 +325,7 @@ int build_skin_set(fdcap_ctx* c, const std::vector<int64_t>& ids, SkinSet* out) 
         out->pn_bwd.f = (const float4*)out->pn_bwd_f.p; out->pn_bwd.ntile = nt; out->pn_bwd.nss = ns;
     }
     out->pn_fwd3 = PanelB3(); out->pn_bwd3 = PanelB3();
-    if (nv > 0) {                                 // the forward operand of every set also as three bf16 planes
+    if (nv > 0) {                                 // the forward operand of every set also as split planes (format PnF)
         std::vector<unsigned> p3;
         std::vector<float> sc;
         PnF::pack(pd.data(), ldp, 1, NPFX, 3 * nv, p3, sc, &out->pn_fwd3.ntile, &out->pn_fwd3.nst);
@@ -344,7 +344,7 @@ int build_skin_set(fdcap_ctx* c, const std::vector<int64_t>& ids, SkinSet* out) 
     return 0;
 }
 
-// dense products on the three-way bf16 split (FDCAP_GEMM_SPLIT3=0: exact-fp32 MFMA chains instead)
+// dense products on the split formats of fdc_panel.h (FDCAP_GEMM_SPLIT3=0: exact-fp32 MFMA chains instead)
 inline bool gemm_split3_enabled() {
     static int v = -1;
     if (v < 0) { const char* e = getenv("FDCAP_GEMM_SPLIT3"); v = (e && e[0] == '0') ? 0 : 1; }
