@@ -26,6 +26,8 @@ fop = FittingOP({"num_iter": 500}, {}, N, body_model=bm, vposer=vp, scene_verts=
 L = capi.load_library()
 L.fdcap_debug_nn_stats.argtypes = [ctypes.POINTER(ctypes.c_ulonglong)]
 out = (ctypes.c_ulonglong * 8)()
+L.fdcap_debug_nn_hist.argtypes = [ctypes.POINTER(ctypes.c_ulonglong)]
+hist = (ctypes.c_ulonglong * 96)()
 import time
 t_last = [time.perf_counter()]
 print("iter   wall_us  kept_waves built_waves raw_items kept_items  mfma_results exact_entries rows")
@@ -34,6 +36,9 @@ def hook(k):
     t = time.perf_counter()
     L.fdcap_debug_nn_stats(out)
     print(f"{k:4d} {1e6 * (t - t_last[0]):9.0f} {out[4]:10d} {out[5]:10d} {out[6]:9d} {out[7]:10d} {out[0]:12d} {out[1]:12d} {out[2]:8d}")
+    if os.environ.get("HIST") == "1":                     # waves by log2(work items) since the last look (bins: 0, 1, 2-3, 4-7, ...)
+        L.fdcap_debug_nn_hist(hist)
+        print("      waves by work items (0 | 1 | 2-3 | 4-7 | 8-15 | 16-31 | 32-63 | 64-127 | 128-255 | ...):", " ".join(str(hist[i]) for i in range(12)))
     t_last[0] = time.perf_counter()
 fop.snapshot_hook = hook
 fop.fitting(torch.tensor(clip.body_params).cuda(), "global", log_every=1, snapshot_at=list(range(lo, hi)) + [int(v) for v in os.environ.get("EXTRA", "1,2,3,10,11,50,51,200,201").split(",")])
