@@ -70,6 +70,10 @@ struct ScaleTail {
     const float* dscale_row = nullptr;       // [rows] per-frame partials of d loss / d scale
     float* dscale = nullptr;                 // this rank's sum (kept for callers that read it)
     int row0 = 2, n = 0, zero_grad = 0;
+    // r5: the logged sums are formed by the launch's REGULAR workgroups 0 .. LROW - 1 (one wave, one term each, before their first
+    // barrier) instead of the extra workgroup: that one has a CU to itself (these kernels fit once per CU) and a regular workgroup
+    // waits for it -- two cold reads and eight double-precision reductions there made every logging launch 1.3-3 us longer
+    int lg_spread = 0;
 };
 
 // torch.optim.Adam defaults: betas (0.9, 0.999), eps 1e-8; the bias corrections are evaluated
@@ -104,10 +108,26 @@ FDC_HD void adam_update(float& p, float& m, float& v, float g, const AdamScalars
 // d loss / d scale = sum of the per-frame partials in a fixed order (256 strided partial sums, wave sums, (s0 + s1) + (s2 + s3)),
 // then Adam on `scale` in place.  One workgroup of >= 256 threads; the tail block of adam_step_kernel and the extra workgroup
 // of the backward's last launch (ScaleTail) run exactly this.
-__device__ __forceinline__ float scale_grad_block(const float* __restrict__ dscale_row, int row0, int n, float* sred) {
+// (pre != nullptr: the first SCALE_PRE partials of this thread -- rows tid, tid + 256, ... -- were loaded by the caller ahead of other
+//  work, scale_grad_prefetch; the sum is formed in the same order either way)
+constexpr int SCALE_PRE = 4;
+__device__ __forceinline__ void scale_grad_prefetch(const float* __restrict__ dscale_row, int row0, int n, float* pre) {
+#pragma unroll
+    for (int k = 0; k < SCALE_PRE; ++k) {
+        const int i = (int)threadIdx.x + 256 * k;
+        pre[k] = (threadIdx.x < 256 && i < n) ? dscale_row[row0 + i] : 0.f;
+    }
+}
+__device__ __forceinline__ float scale_grad_block(const float* __restrict__ dscale_row, int row0, int n, float* sred, const float* pre = nullptr) {
     float a = 0.f;
-    if (threadIdx.x < 256)
-        for (int i = threadIdx.x; i < n; i += 256) a += dscale_row[row0 + i];
+    if (threadIdx.x < 256) {
+        int i = threadIdx.x;
+        if (pre) {
+#pragma unroll
+            for (int k = 0; k < SCALE_PRE; ++k, i += 256) if (i < n) a += pre[k];
+        }
+        for (; i < n; i += 256) a += dscale_row[row0 + i];
+    }
     a = wave_sum64(a);
     if (threadIdx.x < 256 && (threadIdx.x & 63) == 0) sred[threadIdx.x >> 6] = a;
     __syncthreads();
@@ -121,31 +141,34 @@ __device__ __forceinline__ double wave_sum_f64(double v) {
     for (int m = 32; m; m >>= 1) v += __shfl_xor(v, m);
     return v;
 }
+// one term (slot s of the rows), one wave
+__device__ __forceinline__ void loss_rows_reduce_slot(const float* __restrict__ rows, int row0, int n, unsigned mask, int assign,
+                                                      double* __restrict__ losses, int s, int lane) {
+    if (!((mask >> s) & 1u)) {
+        if (assign && lane == 0) losses[s] = 0.0;
+        return;
+    }
+    const float* col = rows + (size_t)row0 * LROW + s;
+    double a = 0.0;
+    for (int i0 = 0; i0 < n; i0 += 1024) {                   // sixteen loads in flight per trip (one trip at the quoted size)
+        float r[16];
+#pragma unroll
+        for (int k = 0; k < 16; ++k) {
+            const int i = i0 + 64 * k + lane;
+            r[k] = col[(size_t)min(i, n - 1) * LROW];
+        }
+#pragma unroll
+        for (int k = 0; k < 16; ++k) a += (i0 + 64 * k + lane < n) ? (double)r[k] : 0.0;
+    }
+    a = wave_sum_f64(a);
+    if (lane == 0) losses[s] = assign ? a : losses[s] + a;
+}
 __device__ __forceinline__ void loss_rows_reduce_block(const float* __restrict__ rows, int row0, int n, unsigned mask, int assign,
                                                        double* __restrict__ losses, const float* __restrict__ dscale_row,
                                                        float* __restrict__ dscale_out) {
     const int tid = threadIdx.x, lane = tid & 63, nw = (int)blockDim.x >> 6;
     const int wave = nw - 1 - (tid >> 6);                    // (the last waves first: the first four also sum d loss / d scale)
-    for (int s = wave; s < LROW; s += nw) {                  // (wave-uniform)
-        if (!((mask >> s) & 1u)) {
-            if (assign && lane == 0) losses[s] = 0.0;
-            continue;
-        }
-        const float* col = rows + (size_t)row0 * LROW + s;
-        double a = 0.0;
-        for (int i0 = 0; i0 < n; i0 += 1024) {               // sixteen loads in flight per trip (one trip at the quoted size)
-            float r[16];
-#pragma unroll
-            for (int k = 0; k < 16; ++k) {
-                const int i = i0 + 64 * k + lane;
-                r[k] = col[(size_t)min(i, n - 1) * LROW];
-            }
-#pragma unroll
-            for (int k = 0; k < 16; ++k) a += (i0 + 64 * k + lane < n) ? (double)r[k] : 0.0;
-        }
-        a = wave_sum_f64(a);
-        if (lane == 0) losses[s] = assign ? a : losses[s] + a;
-    }
+    for (int s = wave; s < LROW; s += nw) loss_rows_reduce_slot(rows, row0, n, mask, assign, losses, s, lane);   // (wave-uniform)
     if (dscale_out) {                                        // (the stand-alone launch only: workgroup-uniform)
         __shared__ float sred[4];
         const float g = scale_grad_block(dscale_row, row0, n, sred);
@@ -154,9 +177,14 @@ __device__ __forceinline__ void loss_rows_reduce_block(const float* __restrict__
 }
 __device__ __forceinline__ void scale_tail_block(const ScaleTail& t) {
     __shared__ float s_tail[4];
+    // (a logging iteration: the scale partials are requested BEFORE the printed sums are formed -- both are cold reads of what the
+    //  previous launch wrote, one after the other they held this workgroup, and with it the launch, 2.4 us longer)
+    float pre[SCALE_PRE];
+    const bool prefetched = t.lg.rows && t.n > 0;
+    if (prefetched) scale_grad_prefetch(t.dscale_row, t.row0, t.n, pre);
     if (t.lg.rows) loss_rows_reduce_block(t.lg.rows, t.row0, t.lg.n, t.lg.mask, t.lg.assign, t.lg.losses, t.dscale_row, nullptr);
     if (t.n <= 0) return;                                    // (only the logged sums this time: `scale` has no step)
-    const float g = scale_grad_block(t.dscale_row, t.row0, t.n, s_tail);
+    const float g = scale_grad_block(t.dscale_row, t.row0, t.n, s_tail, prefetched ? pre : nullptr);
     if (threadIdx.x == 0) {
         if (t.dscale) *t.dscale = g;
         if (t.sc.p) {

@@ -1829,7 +1829,12 @@ __global__ __launch_bounds__(512) void vposer_bwd_split3_kernel(VPoserPanels3 P,
                                                                 float* __restrict__ dZpart, size_t part_stride, ScaleTail tail) {
     // (tail.block == 0: one extra workgroup, FIRST in the grid -- these kernels keep one workgroup per CU (LDS), a 261st at the
     //  end would wait for a CU to come free and then run alone; first, it is done in a microsecond and hands its CU to the rest)
-    if ((int)blockIdx.x == tail.block) { scale_tail_block(tail); return; }
+    if ((int)blockIdx.x == tail.block) {
+        ScaleTail t2 = tail;
+        if (tail.lg_spread) t2.lg.rows = nullptr;            // (the logged sums: regular workgroups, below)
+        scale_tail_block(t2);
+        return;
+    }
     const unsigned bid = blockIdx.x - (tail.block == 0 ? 1u : 0u);
     constexpr int NP = VpF::NP;
     __shared__ __attribute__((aligned(16))) uint4 lds3[NP * (VP3_PQ + VP3_PQ + VP3_PH) + VpF::SC_U4 + 8 * 64];
@@ -1857,6 +1862,8 @@ __global__ __launch_bounds__(512) void vposer_bwd_split3_kernel(VPoserPanels3 P,
         const uint4* bf = P.w3t.f + (size_t)tile * P.w3t.nst * NP * 64;
         PnRing3T<1, 2, VpF> rgA;
         panel3_prefetch_t<1, 2, VpF>(rgA, &bf, 4, lane);
+        if (tail.lg_spread && bid < (unsigned)LROW && wave == 0)     // (wave-uniform) one logged term: ScaleTail::lg_spread
+            loss_rows_reduce_slot(tail.lg.rows, tail.row0, tail.lg.n, tail.lg.mask, tail.lg.assign, tail.lg.losses, (int)bid, lane);
         VpF::stage<512, 1, 1>(sdO, 0, dO, ODIM, r0, row_hi, 0, ODIM, 128, tid);
         __syncthreads();
         panel3_mma_t<1, 2, VpF>(sdO, VP3_PQ, rgA, 4, &acc, lane);

@@ -509,6 +509,10 @@ int opt_vposer_backward(fdcap_ctx* c, bool fold, hipStream_t st, ScaleTail tail 
     const size_t ps = (size_t)o->R * VP_Z;
     const int nb = 4 * ((nl + 15) / 16);
     if (tail.block >= 0) tail.block = 0;                   // (first in the grid: fdc_panel.h)
+    if (gemm_split3_enabled() && tail.lg.rows && nb >= LROW) {
+        tail.lg_spread = 1;                                // the logged sums: one regular workgroup per term (ScaleTail::lg_spread)
+        if (tail.n <= 0) tail.block = -1;                  // ... and with no `scale` step there is nothing left for an extra workgroup
+    }
     if (gemm_split3_enabled())
         hipLaunchKernelGGL(vposer_bwd_split3_kernel, dim3(nb + (tail.block >= 0 ? 1 : 0)), dim3(512), 0, st, c->vp3, o->dO.p, 2, 2 + nl, o->H1.p, o->H2.p,
                            o->dZpart.p, ps, tail);
