@@ -77,6 +77,7 @@ int fdcap_opt_create(fdcap_ctx* c, const fdcap_opt_config* cfg, float* rows_x, f
     }
     if (!err && o->contact_on) {
         if (const char* e = getenv("FDCAP_SKIN_VEC")) o->skin_vec = e[0] != '0';
+        if (const char* e = getenv("FDCAP_FUSE_SKIN")) o->fuse_skin = e[0] != '0';
         if (const char* e = getenv("FDCAP_NN_CACHE_SLACK")) o->nnc_slack = (float)atof(e);
         int every = 32;
         if (const char* e = getenv("FDCAP_NN_ORDER")) every = atoi(e);
@@ -121,9 +122,23 @@ static int opt_contact_forward(fdcap_ctx* c, hipStream_t st, bool blend_done = f
     OptState* o = c->opt;
     const int nl = o->cfg.n_local, nc = c->nc;
     const size_t off = (size_t)2 * nc * 3;
-    if (!blend_done) HIP_TRY(blend_forward(c->contact, o->PF.p + 2 * NPFX, nl, o->Voff.p + off, st));
-    hipLaunchKernelGGL(skin_fwd_kernel, dim3((nc + 255) / 256, nl), dim3(256), 0, st, c->contact.model(), nc, o->X.p, XDIM,
-                       X_BETAS, X_TRANSL, o->Voff.p, o->A.p, o->M.p, o->scale.p, 2, 1, o->Vw.p);
+    // clip-sized shares: the blend product and the skinning in one launch (blend_skin_fwd_kernel; FDCAP_FUSE_SKIN=0: two launches)
+    const SkinModel smf = c->contact.model();
+    const bool fused = !blend_done && o->fuse_skin && gemm_split3_enabled() && c->contact.pn_fwdS.f && smf.vpack && smf.K <= 4 && nl >= 384 &&
+                       blend_skin_lds_bytes(smf.ja_hi) <= (size_t)150 * 1024;
+    if (fused) {
+        static bool attr = false;
+        if (!attr) {
+            HIP_TRY(hipFuncSetAttribute((const void*)blend_skin_fwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
+            attr = true;
+        }
+        hipLaunchKernelGGL(blend_skin_fwd_kernel, dim3(8 * ((nl + 31) / 32)), dim3(768), blend_skin_lds_bytes(smf.ja_hi), st, o->PF.p, nl,
+                           c->contact.pn_fwdS, smf, nc, smf.ja_hi, o->X.p, XDIM, X_TRANSL, o->A.p, o->M.p, o->scale.p, 2, o->Voff.p, o->Vw.p);
+    } else {
+        if (!blend_done) HIP_TRY(blend_forward(c->contact, o->PF.p + 2 * NPFX, nl, o->Voff.p + off, st));
+        hipLaunchKernelGGL(skin_fwd_kernel, dim3((nc + 255) / 256, nl), dim3(256), 0, st, smf, nc, o->X.p, XDIM,
+                           X_BETAS, X_TRANSL, o->Voff.p, o->A.p, o->M.p, o->scale.p, 2, 1, o->Vw.p);
+    }
     const int nq = nl * nc;
     // the first contact forward of a fit has no neighbours from a previous iteration yet (idx = -1)
     const NNCache cache = o->nn_cache(0);

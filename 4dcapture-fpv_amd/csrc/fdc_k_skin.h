@@ -66,6 +66,116 @@ __global__ __launch_bounds__(256) void skin_fwd_kernel(SkinModel sm, int nv, con
     o[0] = f.vw.x; o[1] = f.vw.y; o[2] = f.vw.z;
 }
 
+
+// Blend product + skinning of the contact set in ONE launch (r5): panel_gemm3_rb2_kernel's product for a block of 32 frames x 64
+// vertices, then skin_fwd_kernel's arithmetic on the block while it is still in LDS -- the offsets leave once (Voff, for the
+// backward) next to the world vertices (Vw), and the separate skinning launch (5.5 us: launch, a cold read of the 6 MB just
+// written, its own 6 MB left dirty) is gone.  For that a lane must see x, y and z of a vertex: the static operand's columns are
+// permuted on the host (SkinSet::pn_fwdS) -- column block b = vertices 64 b .. 64 b + 63, tile 3 g + c of the block = component c of
+// vertices 64 b + 16 g .. + 15 -- and the three component tiles of a vertex group meet in LDS.  Same products in the same order
+// per column, same skinning expressions: Voff and Vw bit for bit those of the two launches (tests/test_gpu_parity.py).
+// Grid 8 x ceil(M / 32) (blockIdx & 7 = column block = XCD: nv <= 512), 768 threads; K <= 4 weights per vertex (two vpack planes),
+// joints < ja staged per frame.  Dynamic LDS: 2 images | sA [32][ja][12] | sM [32][12] | sT [32][4] | sVP [2][64][4] | sX [3][32][64].
+__global__ __launch_bounds__(768) void blend_skin_fwd_kernel(const float* __restrict__ PF, int M, PanelB3 B, SkinModel sm, int nv, int ja,
+                                                             const float* __restrict__ X, int ldx, int transl_off,
+                                                             const float* __restrict__ A, const float* __restrict__ Mw,
+                                                             const float* __restrict__ scale, int row0, float* __restrict__ Voff,
+                                                             float* __restrict__ Vw) {
+    extern __shared__ __attribute__((aligned(16))) uint4 bs_lds[];
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, j = lane & 15, g = lane >> 4;
+    const int cb = blockIdx.x & 7, m0 = (int)(blockIdx.x >> 3) * 32;
+    const int ncb = (B.ntile + 11) / 12;
+    if (cb >= ncb) return;
+    constexpr int K = NPFX, kpad = (NPFX + 31) & ~31, nst = kpad >> 5, pstride = (kpad >> 3) * 16;
+    const int img = pnf_img_u4(kpad);
+    float* const sA = (float*)(bs_lds + 2 * img);
+    float* const sM = sA + 32 * ja * 12;
+    float* const sT = sM + 32 * 12;
+    float* const sVP = sT + 32 * 4;                             // [2][64] float4
+    float* const sX = sVP + 2 * 64 * 4;
+    const float* const PFr = PF + (size_t)row0 * NPFX;
+    PnRing3<2> rg;
+    const int tile = cb * 12 + wave;
+    panel3_prefetch<2>(rg, B.f + (size_t)min(tile, B.ntile - 1) * B.nst * PNF * 64, nst, lane);
+    const f32x4_t ts = PnF::tile_isc(B, tile, g);
+    // the same batch: the frames' skinning transforms (joints < ja), world transforms and translations by LDS-DMA, this thread's
+    // vertex constants into registers (a thread serves vertex tid & 63 of the block for every frame it is dealt)
+    {
+        const int nu = 32 * ja * 3;                              // 16-byte units of sA: unit u = frame f (u / (3 ja)), word w
+        for (int u0 = 0; u0 < nu; u0 += 768) {
+            const int u = u0 + tid;
+            if (u < nu) {
+                const int f = u / (3 * ja), w = u - f * 3 * ja;
+                const float* src = A + (size_t)(row0 + min(m0 + f, M - 1)) * NJ * 12 + 4 * w;
+                __builtin_amdgcn_global_load_lds((fdc_gptr_t)src, (fdc_lptr_t)((char*)sA + 16 * (u0 + 64 * wave)), 16, 0, 0);
+            }
+        }
+        if (tid < 96) {                                          // (waves 0, 1: wave-uniform destinations)
+            const int f = tid / 3, w = tid - 3 * f;
+            const float* src = Mw + (size_t)(row0 + min(m0 + f, M - 1)) * 12 + 4 * w;
+            __builtin_amdgcn_global_load_lds((fdc_gptr_t)src, (fdc_lptr_t)((char*)sM + 16 * 64 * wave), 16, 0, 0);
+        } else if (tid >= 128 && tid < 128 + 128) {              // (waves 2, 3) translations: [32][4] words, the fourth unused
+            const int q = tid - 128, f = q >> 2, w = min(q & 3, 2);
+            const float* src = X + (size_t)(row0 + min(m0 + f, M - 1)) * ldx + transl_off + w;
+            __builtin_amdgcn_global_load_lds((fdc_gptr_t)src, (fdc_lptr_t)((char*)sT + 4 * 64 * (wave - 2)), 4, 0, 0);
+        } else if (tid >= 256 && tid < 256 + 128) {              // (waves 4, 5) the block's 64 vertices' packed constants, two planes
+            const int q = tid - 256;
+            const float* src = sm.vpack + 4 * ((size_t)(q >> 6) * nv + min(cb * 64 + (q & 63), nv - 1));
+            __builtin_amdgcn_global_load_lds((fdc_gptr_t)src, (fdc_lptr_t)((char*)sVP + 16 * 64 * (wave - 4)), 16, 0, 0);
+        }
+    }
+    const int vv = tid & 63, v = cb * 64 + vv;
+    const float sc_v = *scale;
+    PnF::stage<768, 2, 2>(bs_lds, img, PFr, NPFX, m0, M, 0, K, kpad, tid);
+    __syncthreads();
+    PnF::Acc acc[2] = {PnF::zero(), PnF::zero()};
+    if (tile < B.ntile) panel3_mma<2, 2>(bs_lds, pstride, img, rg, nst, acc, lane);
+    {   // component c = wave % 3 of vertices 16 (wave / 3) + 4 g .. + 3, frames 16 rb + j
+        const int c = wave % 3, vg = wave / 3;
+#pragma unroll
+        for (int rb = 0; rb < 2; ++rb) {
+            const f32x4_t o = PnF::value(acc[rb], PnF::row_isc(bs_lds + (size_t)rb * img, pstride, j), ts);
+            *(float4*)(sX + (size_t)((c * 32 + 16 * rb + j) * 64 + vg * 16 + 4 * g)) = make_float4(o[0], o[1], o[2], o[3]);
+        }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        const int p = tid + 768 * k, f = p >> 6;                 // pair (frame f of the block, vertex vv): 2048 pairs
+        if (f < 32 && m0 + f < M && v < nv) {
+            const size_t r = (size_t)(row0 + m0 + f);
+            const float v0 = sX[(0 * 32 + f) * 64 + vv], v1 = sX[(1 * 32 + f) * 64 + vv], v2 = sX[(2 * 32 + f) * 64 + vv];
+            const float4 p0 = ((const float4*)sVP)[vv], p1 = ((const float4*)sVP)[64 + vv];
+            float* const vo = Voff + (r * nv + v) * 3;
+            vo[0] = v0; vo[1] = v1; vo[2] = v2;
+            // skin_fwd_kernel's packed path, K <= 4, term by term
+            const float px = p0.x + v0, py = p0.y + v1, pz = p0.z + v2;
+            const unsigned jb = __float_as_uint(p0.w);
+            const float w4[4] = {p1.x, p1.y, p1.z, p1.w};
+            float T[12];
+#pragma unroll
+            for (int e = 0; e < 12; ++e) T[e] = 0.f;
+#pragma unroll
+            for (int kk = 0; kk < 4; ++kk)
+                if (kk < sm.K) {
+                    const float* a = sA + (size_t)(f * ja + (int)((jb >> (8 * kk)) & 255u)) * 12;
+#pragma unroll
+                    for (int e = 0; e < 12; ++e) T[e] += w4[kk] * a[e];
+                }
+            const V3 transl = v3(sT[4 * f], sT[4 * f + 1], sT[4 * f + 2]);
+            const V3 vb = v3(T[0] * px + T[1] * py + T[2] * pz + T[3], T[4] * px + T[5] * py + T[6] * pz + T[7],
+                             T[8] * px + T[9] * py + T[10] * pz + T[11]) + transl;
+            const V3 sv = sc_v * vb;
+            const float* Mr = sM + 12 * f;
+            float* const o = Vw + (r * nv + v) * 3;
+            o[0] = Mr[0] * sv.x + Mr[1] * sv.y + Mr[2] * sv.z + Mr[3];
+            o[1] = Mr[4] * sv.x + Mr[5] * sv.y + Mr[6] * sv.z + Mr[7];
+            o[2] = Mr[8] * sv.x + Mr[9] * sv.y + Mr[10] * sv.z + Mr[11];
+        }
+    }
+}
+static inline size_t blend_skin_lds_bytes(int ja) { return pnf_lds_bytes((NPFX + 31) & ~31, 2) + (size_t)(32 * ja * 12 + 32 * 12 + 32 * 4 + 2 * 64 * 4 + 3 * 32 * 64) * sizeof(float); }
+
 __device__ __forceinline__ float wave_sum(float v) { return wave_sum64(v); }
 
 // workgroup per frame: skinning + world-transform backward of d loss / d world vertices, reduced over

@@ -65,6 +65,8 @@ struct SkinSet {          // skinning constants for a vertex set (all V, or the 
     PanelB pn_fwd, pn_bwd;
     DevBuf<unsigned> pn_fwd3_f, pn_bwd3_f;      // the same two operands as split planes (format PnF: panel_gemm3_* kernels)
     DevBuf<float> pn_fwd3_s, pn_bwd3_s;         // their column tiles' inverse scales (PnH2)
+    // the forward operand once more with its columns permuted for blend_skin_fwd_kernel (fdc_k_skin.h): sets of <= 512 vertices, K <= 4
+    DevBuf<unsigned> pn_fwdS_f; DevBuf<float> pn_fwdS_s; PanelB3 pn_fwdS;
     PanelB3 pn_fwd3, pn_bwd3;
     SkinModel model() const {
         SkinModel m; m.vt = vt.p; m.S = nullptr; m.wj = wj.p; m.ww = ww.p; m.K = K;
@@ -76,7 +78,7 @@ struct SkinSet {          // skinning constants for a vertex set (all V, or the 
     void release() { vt.release(); ww.release(); posedirs.release(); wj.release(); csc_w.release(); csc_start.release(); csc_v.release();
                      vpack.release(); csc_v16.release(); csc_chunk.release();
                      pn_fwd_f.release(); pn_bwd_f.release(); pn_fwd = PanelB(); pn_bwd = PanelB();
-                     pn_fwd3_f.release(); pn_bwd3_f.release(); pn_fwd3_s.release(); pn_bwd3_s.release(); pn_fwd3 = PanelB3(); pn_bwd3 = PanelB3(); }
+                     pn_fwd3_f.release(); pn_bwd3_f.release(); pn_fwd3_s.release(); pn_bwd3_s.release(); pn_fwdS_f.release(); pn_fwdS_s.release(); pn_fwdS = PanelB3(); pn_fwd3 = PanelB3(); pn_bwd3 = PanelB3(); }
 };
 
 struct OptState {
@@ -104,6 +106,7 @@ struct OptState {
     DevBuf<float4> seedpt;    // coordinates (+ position in the sorted scene) of each query's current neighbour: next launch's seed
     // work-list cache of the in-loop NN launch (fdc_chamfer.h NNCache): ids [groups * 4][64], hdr [groups * 4], anchors [4][nq]
     bool skin_vec = true;          // FDCAP_SKIN_VEC=0 (read by fdcap_opt_create; A/B): the scalar-load skinning backward
+    bool fuse_skin = true;         // FDCAP_FUSE_SKIN=0 (read by fdcap_opt_create; A/B): blend product and skinning forward as two launches
     DevBuf<float> loss_rows;       // [R][LROW] per-frame partial sums of the printed loss terms (logging iterations)
     bool log_pending = false;      // a logging backward (log_terms = 2) left the reduction of loss_rows to the next step launch
     unsigned log_mask = 0;
@@ -332,6 +335,25 @@ int build_skin_set(fdcap_ctx* c, const std::vector<int64_t>& ids, SkinSet* out) 
         HIP_TRY(out->pn_fwd3_f.upload(p3.data(), p3.size()));
         HIP_TRY(out->pn_fwd3_s.upload(sc.data(), sc.size()));
         out->pn_fwd3.f = (const uint4*)out->pn_fwd3_f.p; out->pn_fwd3.isc = out->pn_fwd3_s.p;
+    }
+    out->pn_fwdS = PanelB3();
+    if (nv > 0 && nv <= 512 && K <= 4) {          // ... and with permuted columns: block b = vertices 64 b .. + 63, tile 3 g + c = component c of vertices 64 b + 16 g .. + 15
+        const int nb = (nv + 63) / 64, ncs = nb * 192;
+        std::vector<float> ps((size_t)NPFX * ncs, 0.f);
+        for (int b = 0; b < nb; ++b)
+            for (int t = 0; t < 12; ++t)
+                for (int jj = 0; jj < 16; ++jj) {
+                    const int v = 64 * b + 16 * (t / 3) + jj;
+                    if (v >= nv) continue;
+                    const int src = 3 * v + (t % 3), dst = b * 192 + t * 16 + jj;
+                    for (int k = 0; k < NPFX; ++k) ps[(size_t)k * ncs + dst] = pd[(size_t)k * ldp + src];
+                }
+        std::vector<unsigned> p3;
+        std::vector<float> sc;
+        PnF::pack(ps.data(), ncs, 1, NPFX, ncs, p3, sc, &out->pn_fwdS.ntile, &out->pn_fwdS.nst);
+        HIP_TRY(out->pn_fwdS_f.upload(p3.data(), p3.size()));
+        HIP_TRY(out->pn_fwdS_s.upload(sc.data(), sc.size()));
+        out->pn_fwdS.f = (const uint4*)out->pn_fwdS_f.p; out->pn_fwdS.isc = out->pn_fwdS_s.p;
     }
     if (nv > 0) {                                 // ... and the data-gradient operand (one LDS image up to K = 1696: panel_gemm3 / _rb2k; beyond: panel_gemm3_kloop)
         std::vector<unsigned> p3;

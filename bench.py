@@ -479,6 +479,8 @@ def per_kernel_table(pk, F, nc, K, src):
         # key, what, bound, useful fp32 flops | algorithmic bytes
         ("vposer_fwd", "VPoser decode 32-512-512-126 (A7)", "mfma", fl((32, 512), (512, 512), (512, 126))),
         ("pose_fwd", "6D/PCA -> rotations, joint regression, kinematic chain, world joints (A8 K5-K9, A9)", "hbm", 4.0 * F * 2791),
+        ("blend_skin_fwd", "pose+shape blend offsets [F,496]x[496,3Nc] + linear-blend skinning + scale + world transform of the contact set, "
+                           "one launch (A8 K6/K8/K10, A10; r5: blend_skin_fwd_kernel)", "mfma", fl((496, 3 * nc))),
         ("blend_fwd", "pose+shape blend offsets of the contact set [F,496]x[496,3Nc] (A8 K6/K8)", "mfma", fl((496, 3 * nc))),
         ("skin_fwd", "linear-blend skinning + scale + world transform of the contact set (A8 K10, A10)", "hbm", F * (24.0 * nc + 2720)),
         ("nn_in_loop_all", "Chamfer NN forward (A12): see the top-level roofline", "valu_issue", None),

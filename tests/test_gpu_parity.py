@@ -627,6 +627,26 @@ def test_vector_staged_skinning_backward_equals_the_scalar_kernel(n, per_part):
     assert torch.equal(outs[0][0], outs[1][0]) and outs[0][1] == outs[1][1] and torch.equal(outs[0][2], outs[1][2])
 
 
+@pytest.mark.parametrize("n,per_part", [(384, 250), (417, 40), (1000, 6)])
+def test_fused_blend_and_skinning_launch_equals_the_two_launches(n, per_part):
+    """blend_skin_fwd_kernel (clip-sized shares: the contact set's blend product and its skinning in one launch, the static operand's
+    columns permuted so that x, y and z of a vertex meet in LDS) against panel_gemm3_rb2_kernel + skin_fwd_kernel
+    (FDCAP_FUSE_SKIN=0): the same products in the same order per column and the same skinning expressions -- whole fits bit for
+    bit, logs included (ragged frame counts, vertex sets that do not fill their last block of 64)."""
+    outs = []
+    for flag in ("0", "1"):
+        os.environ["FDCAP_FUSE_SKIN"] = flag
+        try:
+            fop, bm, vp, clip, scene, vid = _make_fop(n, 1200, 20_000, per_part, 12, seed=73)
+            body, scale, cam = fop.fitting(torch.tensor(clip.body_params).cuda(), "global", log_every=1)
+            outs.append((body.clone(), float(scale), cam.clone(), np.array(fop.log.loss_contact)))
+            fop.close()
+        finally:
+            os.environ.pop("FDCAP_FUSE_SKIN")
+    assert torch.equal(outs[0][0], outs[1][0]) and outs[0][1] == outs[1][1] and torch.equal(outs[0][2], outs[1][2])
+    assert np.array_equal(outs[0][3], outs[1][3]) and np.isfinite(outs[0][3]).all() and (outs[0][3] > 0).all()
+
+
 def test_no_contact_config_and_ragged_sizes():
     """BASELINE config 1 (8 frames, no scene: rec + temporal only) and awkward sizes."""
     for n, ns in ((8, 0), (3, 0), (17, 1100)):

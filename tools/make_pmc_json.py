@@ -28,7 +28,8 @@ KERNELS = {   # key -> (substring of the kernel name, skip the first `skip` disp
     "vposer_bwd": ("vposer_bwd", False),
     "pose_fwd": ("pose_fwd_kernel", False),
     "pose_bwd": ("pose_bwd_kernel", False),
-    "skin_fwd": ("skin_fwd_kernel", False),
+    "skin_fwd": ("::skin_fwd_kernel", False),
+    "blend_skin_fwd": ("blend_skin_fwd_kernel", False),   # r5 (late): the contact set's blend product + skinning in one launch
     "skin_bwd": ("skin_bwd", False),
 }
 
