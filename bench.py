@@ -26,7 +26,7 @@ Rank 0 prints ONE JSON line.
                             on the launch stream; the counters that say WHICH resource bounds it come from the committed
                             rocprofv3 PMC summary of the configuration (profiles/r5_<config>_pmc_summary.json,
                             tools/run_prof_r5.sh); `contract` keeps SURVEY §8d's algorithmic-bytes figure;
-                            `roofline.per_kernel`: ALL NINE launches of a phase-1 iteration -- microseconds from the committed
+                            `roofline.per_kernel`: EVERY launch of a phase-1 iteration (eight since the blend forward and the skinning forward are one) -- microseconds from the committed
                             kernel trace, executed flops or algorithmic bytes, fraction of the peak that binds each;
   `other_configs`           BASELINE configs 2 and 5 measured in the same run (ms per fit, us per iteration, their Chamfer
                             launch and what bounds it, from their own PMC summaries);
@@ -517,7 +517,7 @@ def per_kernel_table(pk, F, nc, K, src):
         out.append(e)
     return {"source": src, "phase1_iteration_us": total, "kernels": out,
             "note": "floor_us = the kernel's work at the binding peak; every launch also pays ~1.2 us fixed + ~0.2 us per MB it leaves dirty in "
-                    "L2 (profiles/r4_launch_overhead_probe.txt).  Phase 2 of a fit issues four of the nine (VPoser and pose, both ways)"}
+                    "L2 (profiles/r4_launch_overhead_probe.txt).  Phase 2 of a fit issues four of them (VPoser and pose, both ways)"}
 
 
 def other_config(name, args):
