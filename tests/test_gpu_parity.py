@@ -647,6 +647,35 @@ def test_fused_blend_and_skinning_launch_equals_the_two_launches(n, per_part):
     assert np.array_equal(outs[0][3], outs[1][3]) and np.isfinite(outs[0][3]).all() and (outs[0][3] > 0).all()
 
 
+@pytest.mark.parametrize("jmax,count", [(24, 256), (36, 500), (55, 300)])
+def test_fused_contact_forward_with_wider_joint_ranges(jmax, count):
+    """The fused launch stages the skinning transforms of joints < ja_hi for 32 frames in LDS (1.5 KB per joint): contact sets that reach
+    24 and 36 joints still take it, one that reaches all 55 does not fit and takes the two launches -- either way the fit equals the
+    two-launch form bit for bit."""
+    n, V = 400, 3000
+    bm = synth.make_body_model(V, seed=81)
+    top = (bm.lbs_weights > 0).astype(np.int64) * np.arange(55)[None, :]
+    vid = np.nonzero(top.max(axis=1) < jmax)[0]
+    assert vid.size >= count and (top[vid].max() >= min(jmax, 55) - 8)
+    vid = vid[np.linspace(0, vid.size - 1, count).astype(np.int64)]
+    vp = synth.make_vposer(seed=82)
+    clip = synth.make_clip(n, seed=83)
+    scene = synth.make_scene(20_000, seed=84)
+    outs = []
+    for flag in ("0", "1"):
+        os.environ["FDCAP_FUSE_SKIN"] = flag
+        try:
+            fop = FittingOP({"num_iter": 8}, {}, n, body_model=bm, vposer=vp, scene_verts=scene, contact_ids=vid,
+                            camera_ext=read_camerapose(clip.camerapose_lines))
+            body, scale, cam = fop.fitting(torch.tensor(clip.body_params).cuda(), "global", log_every=1)
+            outs.append((body.clone(), float(scale), cam.clone(), np.array(fop.log.loss_contact)))
+            fop.close()
+        finally:
+            os.environ.pop("FDCAP_FUSE_SKIN")
+    assert torch.equal(outs[0][0], outs[1][0]) and outs[0][1] == outs[1][1] and torch.equal(outs[0][2], outs[1][2])
+    assert np.array_equal(outs[0][3], outs[1][3]) and np.isfinite(outs[0][3]).all()
+
+
 def test_no_contact_config_and_ragged_sizes():
     """BASELINE config 1 (8 frames, no scene: rec + temporal only) and awkward sizes."""
     for n, ns in ((8, 0), (3, 0), (17, 1100)):
