@@ -196,6 +196,7 @@ static_assert(NJ * 12 + SKB_NACC + 1 <= SKP_STRIDE, "partial record");
 // [frame][chunk][SKP_STRIDE]; skin_bwd_reduce_kernel adds the chunks in ascending order.  One workgroup per frame walking all
 // 10 475 vertices (41 per thread, eleven dA reductions in a row) put two workgroups on a CU for half a millisecond: 541 us per
 // launch at 512 frames, 17 % of a config-5 iteration (profiles/r5_c5_kernel_trace_stats.txt).
+constexpr int SKB_WFQ = 8;                   // quads (of four steps) per block of the matrix-form dA: 32 fragments in flight per wave
 template <bool CONTACT, bool SPLIT = false>
 __global__ __launch_bounds__(256) void skin_bwd_kernel(SkinModel sm, int nc, const float* __restrict__ X,
                                                        const float* __restrict__ Voff, const float* __restrict__ A,
@@ -281,62 +282,109 @@ __global__ __launch_bounds__(256) void skin_bwd_kernel(SkinModel sm, int nc, con
         // r5: the lists live in global memory here (any vertex set, any size), and a joint's walk was two dependent round trips -- the
         // entries, then the LDS rows they name -- in front of its twelve wave sums: 40 of a chunk workgroup's 64 k cycles at 10 475
         // vertices.  The first 128 entries of the NEXT joint of this wave are requested before the current joint is summed.
-        unsigned long long jact = __ballot(nc > VCH ? chi > clo : jhi > jlo);
-        int kact = 0;
-        auto next_joint = [&](int* lo, int* hi) -> int {    // this wave's next non-empty joint (wave-uniform), -1: none
-            while (jact) {
-                const int j = __ffsll((long long)jact) - 1;
-                jact &= jact - 1;
-                if ((kact++ & 3) != wave) continue;
-                *lo = __builtin_amdgcn_readlane(nc > VCH ? clo : jlo, j);
-                *hi = __builtin_amdgcn_readlane(nc > VCH ? chi : jhi, j);
-                return j;
-            }
-            return -1;
-        };
-        auto fetch = [&](int lo, int hi, float* w, int* v) {  // entries lo + lane, lo + 64 + lane (clamped: unconditional loads)
+        if (sm.wf_tab) {
+            // r5 (late): dA = W^T dT as a matrix product -- v_mfma_f32_16x16x4_f32 (exact fp32 products, fp32 accumulation), four vertices
+            // per step, wave w = the chunk's w-th quarter, the 16-joint tiles one after the other over the steps that touch them
+            // (SkinModel::wf_*: one 16-byte load per lane = four steps' fragments, their step numbers through the scalar cache), the four
+            // waves' partial tiles added in wave order.  The list form spends 34 k of a chunk workgroup's 55 k cycles here (55 joints x
+            // twelve wave sums per chunk, lists fetched joint by joint); a first matrix form with one 4-byte load per step took as
+            // long -- 1000 vector-memory instructions per workgroup: their NUMBER binds, not their bytes.  Same terms, another order.
+            float* const sPart = sdT + (size_t)min(nc, VCH) * 12;             // [4 waves][64 joints][16]
+            const int e = lane & 15, kk = lane >> 4;
+            const int tb = ((c0 / VCH) * 4 + wave) * 4;
+            typedef unsigned wf_u2 __attribute__((ext_vector_type(2)));
+            typedef const wf_u2 __attribute__((address_space(4)))* wf_sp_t;    // (wave-uniform: s_load)
+            const wf_sp_t steps_c = (wf_sp_t)(const void*)sm.wf_step;
 #pragma unroll
-            for (int k = 0; k < 2; ++k) {
-                const int i = min(lo + 64 * k + lane, max(hi - 1, lo));
-                w[k] = sm.csc_w[i];
-                v[k] = sm.csc_v[i];
-            }
-        };
-        int lo = 0, hi = 0, lo_n = 0, hi_n = 0;
-        float wn[2] = {0.f, 0.f};
-        int vn[2] = {0, 0};
-        int j = next_joint(&lo, &hi);
-        if (j >= 0) fetch(lo, hi, wn, vn);
-        while (j >= 0) {
-            const float w0 = wn[0], w1 = wn[1];
-            const int v0 = vn[0], v1 = vn[1];
-            const int jn = next_joint(&lo_n, &hi_n);
-            if (jn >= 0) fetch(lo_n, hi_n, wn, vn);
-            float pa[12];
+            for (int jt = 0; jt < 4; ++jt) {
+                const int g_lo = sm.wf_tab[tb + jt], g_hi = sm.wf_tab[tb + jt + 1];     // (wave-uniform) quads
+                f32x4_t dacc = {0.f, 0.f, 0.f, 0.f};
+                for (int g0 = g_lo; g0 < g_hi; g0 += SKB_WFQ) {                  // blocks of SKB_WFQ quads: all their loads first
+                    float4 a[SKB_WFQ];
+                    wf_u2 st[SKB_WFQ];
 #pragma unroll
-            for (int e = 0; e < 12; ++e) pa[e] = 0.f;
-            if (lo + lane < hi) {
-                const float* t = sdT + (v0 - c0) * 12;
+                    for (int u = 0; u < SKB_WFQ; ++u) {
+                        const int gc = min(g0 + u, g_hi - 1);
+                        a[u] = ((const float4*)sm.wf_frag)[(size_t)gc * 64 + lane];
+                        st[u] = steps_c[gc];
+                    }
 #pragma unroll
-                for (int e = 0; e < 12; ++e) pa[e] += w0 * t[e];
-            }
-            if (lo + 64 + lane < hi) {
-                const float* t = sdT + (v1 - c0) * 12;
+                    for (int u = 0; u < SKB_WFQ; ++u) {
+                        const bool on = g0 + u < g_hi && e < 12;
+                        const int v0 = 4 * (int)(st[u].x & 0xFFFFu) + kk, v1 = 4 * (int)(st[u].x >> 16) + kk;
+                        const int v2 = 4 * (int)(st[u].y & 0xFFFFu) + kk, v3 = 4 * (int)(st[u].y >> 16) + kk;
+                        dacc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[u].x, (on && c0 + v0 < c1) ? sdT[v0 * 12 + e] : 0.f, dacc, 0, 0, 0);
+                        dacc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[u].y, (on && c0 + v1 < c1) ? sdT[v1 * 12 + e] : 0.f, dacc, 0, 0, 0);
+                        dacc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[u].z, (on && c0 + v2 < c1) ? sdT[v2 * 12 + e] : 0.f, dacc, 0, 0, 0);
+                        dacc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[u].w, (on && c0 + v3 < c1) ? sdT[v3 * 12 + e] : 0.f, dacc, 0, 0, 0);
+                    }
+                }
 #pragma unroll
-                for (int e = 0; e < 12; ++e) pa[e] += w1 * t[e];
+                for (int i = 0; i < 4; ++i) sPart[(size_t)((wave * 64 + jt * 16 + 4 * kk + i) * 16) + e] = dacc[i];
             }
-            for (int i = lo + 128 + lane; i < hi; i += 64) {
-                const float w = sm.csc_w[i];
-                const float* t = sdT + (sm.csc_v[i] - c0) * 12;
+            __syncthreads();
+            for (int i = tid; i < NJ * 12; i += 256) {
+                const int j = i / 12, o = j * 16 + (i - 12 * j);
+                sdA[i] += ((sPart[o] + sPart[1024 + o]) + sPart[2048 + o]) + sPart[3072 + o];
+            }
+        } else {
+            unsigned long long jact = __ballot(nc > VCH ? chi > clo : jhi > jlo);
+            int kact = 0;
+            auto next_joint = [&](int* lo, int* hi) -> int {    // this wave's next non-empty joint (wave-uniform), -1: none
+                while (jact) {
+                    const int j = __ffsll((long long)jact) - 1;
+                    jact &= jact - 1;
+                    if ((kact++ & 3) != wave) continue;
+                    *lo = __builtin_amdgcn_readlane(nc > VCH ? clo : jlo, j);
+                    *hi = __builtin_amdgcn_readlane(nc > VCH ? chi : jhi, j);
+                    return j;
+                }
+                return -1;
+            };
+            auto fetch = [&](int lo, int hi, float* w, int* v) {  // entries lo + lane, lo + 64 + lane (clamped: unconditional loads)
 #pragma unroll
-                for (int e = 0; e < 12; ++e) pa[e] += w * t[e];
-            }
+                for (int k = 0; k < 2; ++k) {
+                    const int i = min(lo + 64 * k + lane, max(hi - 1, lo));
+                    w[k] = sm.csc_w[i];
+                    v[k] = sm.csc_v[i];
+                }
+            };
+            int lo = 0, hi = 0, lo_n = 0, hi_n = 0;
+            float wn[2] = {0.f, 0.f};
+            int vn[2] = {0, 0};
+            int j = next_joint(&lo, &hi);
+            if (j >= 0) fetch(lo, hi, wn, vn);
+            while (j >= 0) {
+                const float w0 = wn[0], w1 = wn[1];
+                const int v0 = vn[0], v1 = vn[1];
+                const int jn = next_joint(&lo_n, &hi_n);
+                if (jn >= 0) fetch(lo_n, hi_n, wn, vn);
+                float pa[12];
 #pragma unroll
-            for (int e = 0; e < 12; ++e) {
-                float v = wave_sum(pa[e]);
-                if (lane == 0) sdA[j * 12 + e] += v;
+                for (int e = 0; e < 12; ++e) pa[e] = 0.f;
+                if (lo + lane < hi) {
+                    const float* t = sdT + (v0 - c0) * 12;
+#pragma unroll
+                    for (int e = 0; e < 12; ++e) pa[e] += w0 * t[e];
+                }
+                if (lo + 64 + lane < hi) {
+                    const float* t = sdT + (v1 - c0) * 12;
+#pragma unroll
+                    for (int e = 0; e < 12; ++e) pa[e] += w1 * t[e];
+                }
+                for (int i = lo + 128 + lane; i < hi; i += 64) {
+                    const float w = sm.csc_w[i];
+                    const float* t = sdT + (sm.csc_v[i] - c0) * 12;
+#pragma unroll
+                    for (int e = 0; e < 12; ++e) pa[e] += w * t[e];
+                }
+#pragma unroll
+                for (int e = 0; e < 12; ++e) {
+                    float v = wave_sum(pa[e]);
+                    if (lane == 0) sdA[j * 12 + e] += v;
+                }
+                j = jn; lo = lo_n; hi = hi_n;
             }
-            j = jn; lo = lo_n; hi = hi_n;
         }
         __syncthreads();
     }

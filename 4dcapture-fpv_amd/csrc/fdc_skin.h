@@ -35,6 +35,15 @@ struct SkinModel {
     // the contact-set kernels do not write them and pose_bwd_kernel does not read them (a leg-only contact set: 12 of 55 rows,
     // 2.1 MB less written and 2.1 MB less read per iteration at 1024 frames)
     int ja_hi = 55;
+    // (r5, late) the weights as v_mfma_f32_16x16x4_f32 A operands for the chunked backward's dA = W^T dT: per 1024-vertex chunk, per
+    // quarter q of it (256 vertices = 64 steps of four vertices: one wave's share) and per 16-joint tile jt the steps whose vertices touch
+    // the tile, in QUADS of four (padded with zero fragments): wf_tab[(chunk 4 + q) 4 + jt] .. [+1) = range of quads; wf_step[quad] = the
+    // four steps (within the chunk, 0..255) as 16-bit fields; wf_frag[64 quad + lane] = {W(vertex 1024 chunk + 4 step_i + (lane >> 4),
+    // joint 16 jt + (lane & 15)), i = 0..3}: ONE 16-byte load per lane and four products -- the phase is bound by the number of
+    // vector-memory instructions, not by their bytes.  null: the ordered list form.
+    const int* wf_tab = nullptr;
+    const unsigned* wf_step = nullptr;      // [quads][2]
+    const float* wf_frag = nullptr;         // [quads][64][4]
 };
 
 FDC_HD int skin_vpack_planes(int K) { const int G = (K + 3) / 4; return G <= 1 ? 2 : G + 2; }

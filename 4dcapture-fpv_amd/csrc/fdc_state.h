@@ -35,7 +35,7 @@ static int skin_bwd_any(DevBuf<float>& part, hipStream_t st, int nrows, SkinMode
                         float* dtransl_v, float* dMv, float* dsv, ContactGradIn cg) {
     static int split_on = -1;                              // FDCAP_SKIN_SPLIT=0: the one-workgroup-per-frame form at every size (A/B)
     if (split_on < 0) { const char* e = getenv("FDCAP_SKIN_SPLIT"); split_on = (e && e[0] == '0') ? 0 : 1; }
-    const size_t lds = (size_t)std::min(nc, SKB_VCH) * 12 * sizeof(float);
+    const size_t lds = (size_t)std::min(nc, SKB_VCH) * 12 * sizeof(float) + (sm.wf_tab ? (size_t)4 * 64 * 16 * sizeof(float) : 0);   // dT rows (+ the matrix form's partial tiles)
     if (nc <= SKB_VCH || !split_on) {
         hipLaunchKernelGGL((skin_bwd_kernel<CONTACT, false>), dim3(nrows), dim3(256), lds, st, sm, nc, X, Voff, A, M, scale, row0, dVw, dVoff, dA,
                            dbeta_v, dtransl_v, dMv, dsv, cg, (float*)nullptr);
@@ -57,6 +57,7 @@ struct SkinSet {          // skinning constants for a vertex set (all V, or the 
     DevBuf<float> vt, ww, posedirs, csc_w;      // posedirs [496, ldp] = [posedirs ; shapedirs^T], zero padding
     DevBuf<int> wj, csc_start, csc_v, csc_chunk;
     int nch = 0, ja_hi = NJ;
+    DevBuf<int> wf_tab; DevBuf<uint2> wf_step; DevBuf<float4> wf_frag;              // SkinModel::wf_*
     DevBuf<float4> vpack;                       // SkinModel::vpack / csc_v16 (K <= 4 and nv <= 65535 only)
     DevBuf<unsigned short> csc_v16;
     // the blend matrix in MFMA fragment order (fdc_panel.h), built for vertex sets whose K = 3 nv image fits the LDS slabs:
@@ -73,10 +74,11 @@ struct SkinSet {          // skinning constants for a vertex set (all V, or the 
         m.csc_start = csc_start.p; m.csc_v = csc_v.p; m.csc_w = csc_w.p;
         m.vpack = (const float*)vpack.p; m.csc_v16 = csc_v16.p;
         m.csc_chunk = csc_chunk.p; m.nch = nch; m.ja_hi = ja_hi;
+        m.wf_tab = wf_tab.p; m.wf_step = (const unsigned*)wf_step.p; m.wf_frag = (const float*)wf_frag.p;
         return m;
     }
     void release() { vt.release(); ww.release(); posedirs.release(); wj.release(); csc_w.release(); csc_start.release(); csc_v.release();
-                     vpack.release(); csc_v16.release(); csc_chunk.release();
+                     vpack.release(); csc_v16.release(); csc_chunk.release(); wf_tab.release(); wf_step.release(); wf_frag.release();
                      pn_fwd_f.release(); pn_bwd_f.release(); pn_fwd = PanelB(); pn_bwd = PanelB();
                      pn_fwd3_f.release(); pn_bwd3_f.release(); pn_fwd3_s.release(); pn_bwd3_s.release(); pn_fwdS_f.release(); pn_fwdS_s.release(); pn_fwdS = PanelB3(); pn_fwd3 = PanelB3(); pn_bwd3 = PanelB3(); }
 };
@@ -304,6 +306,49 @@ int build_skin_set(fdcap_ctx* c, const std::vector<int64_t>& ids, SkinSet* out) 
         out->ja_hi = 1;
         for (int j = 0; j < NJ; ++j) if (csc_start[j + 1] > csc_start[j]) out->ja_hi = j + 1;
         HIP_TRY(out->csc_chunk.upload(cc.data(), cc.size()));
+    }
+    out->wf_tab.release(); out->wf_step.release(); out->wf_frag.release();
+    {   // the weights as MFMA fragments for skin_bwd_kernel's dA (SkinModel::wf_*): vertex sets beyond the contact-set kernels' reach;
+        // FDCAP_SKIN_DA_MFMA=0: the ordered list form
+        const char* e = getenv("FDCAP_SKIN_DA_MFMA");
+        if (!(e && e[0] == '0') && nv > 512) {
+            const int nchm = (nv + SKB_VCH - 1) / SKB_VCH;
+            std::vector<int> tab((size_t)nchm * 16 + 1, 0);
+            std::vector<uint2> steps;
+            std::vector<float4> frag;
+            for (int ch = 0; ch < nchm; ++ch)
+                for (int q = 0; q < 4; ++q)
+                    for (int jt = 0; jt < 4; ++jt) {
+                        tab[((size_t)ch * 4 + q) * 4 + jt] = (int)steps.size();
+                        std::vector<int> st;                               // the steps of this quarter that touch the tile
+                        std::vector<float> fr;                             // their fragments [step][64]
+                        for (int s = 64 * q; s < 64 * q + 64; ++s) {
+                            const int v0 = ch * SKB_VCH + 4 * s;
+                            if (v0 >= nv) break;
+                            float f[64];
+                            bool any = false;
+                            for (int l = 0; l < 64; ++l) f[l] = 0.f;
+                            for (int kk = 0; kk < 4 && v0 + kk < nv; ++kk)
+                                for (int k = 0; k < K; ++k) {
+                                    const int j = wj[(size_t)(v0 + kk) * K + k];
+                                    const float w = ww[(size_t)(v0 + kk) * K + k];
+                                    if (w != 0.f && (j >> 4) == jt) { f[16 * kk + (j & 15)] += w; any = true; }
+                                }
+                            if (any) { st.push_back(s); fr.insert(fr.end(), f, f + 64); }
+                        }
+                        while (st.size() & 3) { st.push_back(st.empty() ? 0 : st.back()); fr.insert(fr.end(), 64, 0.f); }   // zero weights: no contribution
+                        for (size_t g = 0; g < st.size(); g += 4) {
+                            steps.push_back(make_uint2((unsigned)st[g] | ((unsigned)st[g + 1] << 16), (unsigned)st[g + 2] | ((unsigned)st[g + 3] << 16)));
+                            for (int l = 0; l < 64; ++l)
+                                frag.push_back(make_float4(fr[(g + 0) * 64 + l], fr[(g + 1) * 64 + l], fr[(g + 2) * 64 + l], fr[(g + 3) * 64 + l]));
+                        }
+                    }
+            tab.back() = (int)steps.size();
+            if (steps.empty()) { steps.push_back(make_uint2(0u, 0u)); frag.resize(64, make_float4(0.f, 0.f, 0.f, 0.f)); }
+            HIP_TRY(out->wf_tab.upload(tab.data(), tab.size()));
+            HIP_TRY(out->wf_step.upload(steps.data(), steps.size()));
+            HIP_TRY(out->wf_frag.upload(frag.data(), frag.size()));
+        }
     }
     HIP_TRY(out->csc_start.upload(csc_start.data(), csc_start.size()));
     HIP_TRY(out->csc_v.upload(csc_v.data(), csc_v.size()));
