@@ -196,7 +196,10 @@ static_assert(NJ * 12 + SKB_NACC + 1 <= SKP_STRIDE, "partial record");
 // [frame][chunk][SKP_STRIDE]; skin_bwd_reduce_kernel adds the chunks in ascending order.  One workgroup per frame walking all
 // 10 475 vertices (41 per thread, eleven dA reductions in a row) put two workgroups on a CU for half a millisecond: 541 us per
 // launch at 512 frames, 17 % of a config-5 iteration (profiles/r5_c5_kernel_trace_stats.txt).
-constexpr int SKB_WFQ = 8;                   // quads (of four steps) per block of the matrix-form dA: 32 fragments in flight per wave
+#ifndef FDC_SKB_WFQ
+#define FDC_SKB_WFQ 4
+#endif
+constexpr int SKB_WFQ = FDC_SKB_WFQ;                   // quads (of four steps) per block of the matrix-form dA (measured at config 5: 4 -> 231 us, 8 -> 239, 16 -> 261)
 template <bool CONTACT, bool SPLIT = false>
 __global__ __launch_bounds__(256) void skin_bwd_kernel(SkinModel sm, int nc, const float* __restrict__ X,
                                                        const float* __restrict__ Voff, const float* __restrict__ A,
@@ -310,7 +313,7 @@ __global__ __launch_bounds__(256) void skin_bwd_kernel(SkinModel sm, int nc, con
                     }
 #pragma unroll
                     for (int u = 0; u < SKB_WFQ; ++u) {
-                        const bool on = g0 + u < g_hi && e < 12;
+                        const bool on = g0 + u < g_hi && e < 12;              // (padded quads multiply zeros: a uniform branch here measured slower)
                         const int v0 = 4 * (int)(st[u].x & 0xFFFFu) + kk, v1 = 4 * (int)(st[u].x >> 16) + kk;
                         const int v2 = 4 * (int)(st[u].y & 0xFFFFu) + kk, v3 = 4 * (int)(st[u].y >> 16) + kk;
                         dacc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[u].x, (on && c0 + v0 < c1) ? sdT[v0 * 12 + e] : 0.f, dacc, 0, 0, 0);
