@@ -675,7 +675,16 @@ __global__ __launch_bounds__(64 * WPB, NQ == 1 ? FDC_ST4_OCC : FDC_ST4_OCC2) voi
             // every wave rebuilt its list in every launch, 14 us of a 26 us lifetime: tools/phase_switch_timeline.py)
             const float speed = dmax / age;
             slk = __builtin_amdgcn_readfirstlane(__float_as_int(fminf(fmaxf(FDC_AS_MULT * speed, cache.slack), FDC_AS_MAX * cache.slack)));
-            inflate = 3.f * speed <= __int_as_float(slk);
+            // ... measured against the SMALLEST slack a query of the group gets (far queries' is scaled down, slack_of below): a list
+            // is only as durable as its most constrained anchor (late r5: with every vertex a contact and the bodies moving centimetres
+            // per launch, config 5's groups built inflated lists that the far queries voided one launch later)
+            float smin = __int_as_float(slk);
+#pragma unroll
+            for (int n = 0; n < NQ; ++n)
+                if (qidx[n] < nq && rq[n] > FDC_AS_NEAR) smin = fminf(smin, fmaxf(cache.slack, __int_as_float(slk) * (FDC_AS_NEAR / rq[n])));
+            smin = -max_rows01(-smin);
+            smin = fminf(smin, __shfl_xor(smin, 32, 64));
+            inflate = 3.f * speed <= smin;
 #else
             inflate = dmax * 6.f <= cache.slack * age;
 #endif
