@@ -55,10 +55,10 @@ int fdcap_opt_backward_local2(fdcap_ctx* c, const float* contact_weight, int32_t
     hipLaunchKernelGGL(param_loss_kernel, dim3(nl), dim3(128), 0, st, o->X.p, o->X0.p, o->mask.p, o->Jw.p, 2, cf.frame0, N,
                        w_rec, w_sm, 0.f, 0, o->dX.p, o->dJw.p, o->losses.p);
     const float w_vs = (N >= 3) ? 1.f / ((float)(N - 2) * (float)nv3) : 0.f;
-    hipLaunchKernelGGL(vert_smooth_kernel, dim3((nv3 + 255) / 256, nl), dim3(256), 0, st, o->VwF.p, nv3, 2, cf.frame0, N, w_vs,
+    hipLaunchKernelGGL(vert_smooth_kernel, dim3(VS_NB, nl), dim3(256), 0, st, o->VwF.p, nv3, 2, cf.frame0, N, w_vs,
                        o->dVF.p, o->losses.p + 5);
     if (N >= 2)
-        hipLaunchKernelGGL(foot_skate_kernel, dim3((nc * 3 + 255) / 256, nl), dim3(256), 0, st, o->VwF.p, nv3, c->contact_vid.p,
+        hipLaunchKernelGGL(foot_skate_kernel, dim3(1, nl), dim3(256), 0, st, o->VwF.p, nv3, c->contact_vid.p,
                            nc, n_left, contact_weight, 2, cf.frame0, N, o->dVF.p, o->losses.p + 6);
     { int es = skin_bwd_any<false>(c->ws_skin, st, nl, c->full.model(), V, o->X.p, o->VoffF.p, o->A.p, o->M.p, o->scale.p, 2, o->dVF.p, o->dVF.p,
                                    o->dA.p, (float*)nullptr, o->dtransl_v.p, o->dMv.p, o->dsv.p, ContactGradIn()); if (es) return es; }

@@ -6,19 +6,22 @@ namespace {
 
 // mode 'local', cal_loss2 (:404-405): d/dV of mean |second difference over frames| of ALL world vertices.
 // V is [rows, nv3] (nv3 = 3 * vertices); owned rows start at row0, global frame = frame0 + blockIdx.y.
+// Grid (VS_NB, frames): a workgroup walks its frame's elements blockIdx.x * 256 + tid, + VS_NB * 256, ...  (r5, late: with one
+// workgroup per 256 elements the launch was 63 000 double-precision atomics on ONE address -- 762 us for 128 MB of traffic, 60 % of a
+// mode-'local' second-loop iteration at 512 frames; tools/trace_outliers.py on tools/modes_trace.py)
+constexpr int VS_NB = 8;
 __global__ void vert_smooth_kernel(const float* __restrict__ V, size_t nv3, int row0, int frame0, int n_total,
                                    float w_over_cnt, float* __restrict__ dV, double* __restrict__ loss_sum) {
     __shared__ float sred[4];
-    const size_t e = (size_t)blockIdx.x * 256 + threadIdx.x;
     const int r = row0 + blockIdx.y, g = frame0 + blockIdx.y;
     float ab = 0.f;
-    if (e < nv3) {
+    for (size_t e = (size_t)blockIdx.x * 256 + threadIdx.x; e < nv3; e += (size_t)gridDim.x * 256) {
         const float* v = V + (size_t)r * nv3 + e;
         const float x0 = v[0];
         const float xm2 = g >= 2 ? v[-2 * (ptrdiff_t)nv3] : 0.f, xm1 = g >= 1 ? v[-(ptrdiff_t)nv3] : 0.f;
         const float xp1 = g + 1 < n_total ? v[nv3] : 0.f, xp2 = g + 2 < n_total ? v[2 * nv3] : 0.f;
         float s0 = 0.f, s1 = 0.f, s2 = 0.f;
-        if (g <= n_total - 3) { float d = second_diff(x0, xp1, xp2); s0 = sgn(d); ab = fabsf(d); }
+        if (g <= n_total - 3) { float d = second_diff(x0, xp1, xp2); s0 = sgn(d); ab += fabsf(d); }
         if (g >= 1 && g <= n_total - 2) s1 = sgn(second_diff(xm1, x0, xp1));
         if (g >= 2) s2 = sgn(second_diff(xm2, xm1, x0));
         dV[(size_t)r * nv3 + e] = (s0 - 2.f * s1 + s2) * w_over_cnt;
@@ -35,11 +38,11 @@ __global__ void vert_smooth_kernel(const float* __restrict__ V, size_t nv3, int 
 __global__ void foot_skate_kernel(const float* __restrict__ V, size_t nv3, const int* __restrict__ vid, int nc,
                                   int n_left, const float* __restrict__ wgt, int row0, int frame0, int n_total,
                                   float* __restrict__ dV, double* __restrict__ loss_sum) {
+    // (grid (1, frames) since late r5: one atomic per frame instead of one per 256 elements)
     __shared__ float sred[4];
-    const int t = blockIdx.x * 256 + threadIdx.x;
     const int r = row0 + blockIdx.y, g = frame0 + blockIdx.y;
     float ab = 0.f;
-    if (t < nc * 3) {
+    for (int t = blockIdx.x * 256 + threadIdx.x; t < nc * 3; t += gridDim.x * 256) {
         const int c = t / 3, k = t % 3;
         const bool is_left = c < n_left;
         const int npart = is_left ? n_left : nc - n_left;
@@ -53,7 +56,7 @@ __global__ void foot_skate_kernel(const float* __restrict__ V, size_t nv3, const
             w = is_left ? 1.f - w : w;
             w = w < 0.5f ? 0.f : w;
             float d = (v[0] - v[nv3]) * w;
-            ab = fabsf(d);
+            ab += fabsf(d) * inv;                            // (the two parts have different denominators)
             grad += sgn(d) * w;
         }
         if (g >= 1) {
@@ -63,7 +66,6 @@ __global__ void foot_skate_kernel(const float* __restrict__ V, size_t nv3, const
             grad -= sgn((v[-(ptrdiff_t)nv3] - v[0]) * w) * w;
         }
         dV[(size_t)r * nv3 + e] += grad * inv;
-        ab *= inv;                                          // the two parts have different denominators
     }
     ab = wave_sum(ab);
     if ((threadIdx.x & 63) == 0) sred[threadIdx.x >> 6] = ab;
