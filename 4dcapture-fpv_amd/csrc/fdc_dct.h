@@ -66,20 +66,24 @@ __global__ __launch_bounds__(64) void dct_fit_kernel(const float* __restrict__ J
     const int traj = blockIdx.x, wl = traj / 69, ij = traj % 69, lane = threadIdx.x;
     const bool act = lane < T;
     const float t = act ? Jw[(size_t)(jw_row0 + wl * T + lane) * 69 + ij] : 0.f;
-    float Dl[DCT_MAXC], cc[DCT_MAXC], mm[DCT_MAXC], vv[DCT_MAXC];
+    // Lane c OWNS coefficient c: its value and Adam moments live in that lane only, and one adam_update per iteration serves all C
+    // coefficients at once (r5, late: every lane used to carry all C and repeat all C updates -- ~45 instructions each with their
+    // exact division and square root -- 1800 instructions per iteration of this one-wave chain, 4.8 us; the coefficient values the
+    // prediction needs are read from their lanes).  Same operations on the same operands: bit-identical results.
+    static_assert(DCT_MAXC <= 64, "a lane per coefficient");
+    float Dl[DCT_MAXC];
     const size_t off = ((size_t)(w0 + wl) * 69 + ij) * C;
 #pragma unroll
-    for (int c = 0; c < DCT_MAXC; ++c) {
-        const bool on = c < C;
-        Dl[c] = (on && act) ? D[lane * C + c] : 0.f;
-        cc[c] = on ? coef[off + c] : 0.f;
-        mm[c] = on ? m[off + c] : 0.f;
-        vv[c] = on ? v[off + c] : 0.f;
-    }
+    for (int c = 0; c < DCT_MAXC; ++c) Dl[c] = (c < C && act) ? D[lane * C + c] : 0.f;
+    const bool own = lane < C;
+    float cc = own ? coef[off + lane] : 0.f, mm = own ? m[off + lane] : 0.f, vv = own ? v[off + lane] : 0.f;
+    AdamScalars a_next = tab[0];
     for (int it = 0; it < iters; ++it) {
+        const AdamScalars a = a_next;
+        a_next = tab[min(it + 1, iters - 1)];
         float p = 0.f;
 #pragma unroll
-        for (int c = 0; c < DCT_MAXC; ++c) p += Dl[c] * cc[c];
+        for (int c = 0; c < DCT_MAXC; ++c) p += Dl[c] * __int_as_float(__builtin_amdgcn_readlane(__float_as_int(cc), c));
         float obj;
         float gp = dct_residual(t, p, &obj) * w_over_cnt;
         if (!act) { gp = 0.f; obj = 0.f; }
@@ -87,20 +91,17 @@ __global__ __launch_bounds__(64) void dct_fit_kernel(const float* __restrict__ J
             float s = dct_wave_sum(obj);
             if (lane == 0) obj_hist[(size_t)(it / log_stride) * gridDim.x + traj] = s;
         }
-        const AdamScalars a = tab[it];
+        float g = 0.f;
 #pragma unroll
         for (int c = 0; c < DCT_MAXC; ++c) {
             if (c < C) {
-                float g = dct_wave_sum(Dl[c] * gp);
-                adam_update(cc[c], mm[c], vv[c], g, a);
+                const float gc = dct_wave_sum(Dl[c] * gp);
+                if (lane == c) g = gc;
             }
         }
+        if (own) adam_update(cc, mm, vv, g, a);
     }
-    if (lane == 0) {
-#pragma unroll
-        for (int c = 0; c < DCT_MAXC; ++c)
-            if (c < C) { coef[off + c] = cc[c]; m[off + c] = mm[c]; v[off + c] = vv[c]; }
-    }
+    if (own) { coef[off + lane] = cc; m[off + lane] = mm; v[off + lane] = vv; }
 }
 
 // d (w * loss_dct) / d Jw for the owned rows (written, not accumulated; rows outside every window get 0)
