@@ -9,7 +9,10 @@ namespace {
 // Grid (VS_NB, frames): a workgroup walks its frame's elements blockIdx.x * 256 + tid, + VS_NB * 256, ...  (r5, late: with one
 // workgroup per 256 elements the launch was 63 000 double-precision atomics on ONE address -- 762 us for 128 MB of traffic, 60 % of a
 // mode-'local' second-loop iteration at 512 frames; tools/trace_outliers.py on tools/modes_trace.py)
-constexpr int VS_NB = 8;
+#ifndef FDC_VS_NB
+#define FDC_VS_NB 4
+#endif
+constexpr int VS_NB = FDC_VS_NB;                    // (measured at 512 frames: 1 -> 96 us, 2 -> 63, 4 -> 54, 8 -> 63, 16 -> 107, 32 -> 202: the atomics again)
 __global__ void vert_smooth_kernel(const float* __restrict__ V, size_t nv3, int row0, int frame0, int n_total,
                                    float w_over_cnt, float* __restrict__ dV, double* __restrict__ loss_sum) {
     __shared__ float sred[4];
