@@ -222,135 +222,49 @@ int fdcap_set_scene(fdcap_ctx* c, const float* xyz, int64_t ns) {
     // a live optimiser holds buffers sized for, and pruning state (seeds, kept work lists) valid for, the registered scene
     if (c->opt) return FDCAP_E_STATE;
     c->sop.nq = 0;                                          // (the scene operator's seeds / kept lists were for the old scene)
-    std::vector<float4> orig((size_t)ns), sorted((size_t)ns);
-    for (int64_t i = 0; i < ns; ++i) {
-        orig[i] = make_float4(xyz[3 * i], xyz[3 * i + 1], xyz[3 * i + 2], 0.f);
-        int ii = (int)i;
-        memcpy(&orig[i].w, &ii, 4);
-    }
-    // Spatial order by recursive median splits (k-d cells): every MF_CH-point chunk is one cell and every
-    // 32-point MFMA tile inside it a sub-cell, so the chunk boxes the NN scan culls with are compact and
-    // disjoint (runs of a Morton curve jump across quadrant borders and give long, overlapping boxes).
-    // A node of n points is cut at a multiple of the unit below it (chunks above MF_CH, tiles below), along
-    // its longest axis; ties by index, so the order is deterministic.  Results never depend on this order.
-    std::vector<int> order((size_t)ns), inv((size_t)ns);
-    for (int64_t i = 0; i < ns; ++i) order[i] = (int)i;
+    static_assert(SC_SUPER == ST4_SUPER, "fdc_scene.h builds the super-cell boxes the search reads");
+    // Spatial order by recursive median splits (k-d cells): every MF_CH-point chunk is one cell and every 32-point MFMA tile inside it
+    // a sub-cell, so the boxes the NN scan culls with are compact and disjoint (runs of a Morton curve jump across quadrant borders
+    // and give long, overlapping boxes).  r6: sorted, boxed and packed ON THE DEVICE (fdc_scene.h); FDCAP_SCENE_BUILD=host takes the
+    // order from the host recursion of r1-r5 instead (the same order by specification: tests compare the tables of the two).
+    // Results never depend on this order.
+    const int64_t nchunk = (ns + MF_CH - 1) / MF_CH, nsuper = (nchunk + ST4_SUPER - 1) / ST4_SUPER;
+    HIP_TRY(c->scene.ensure((size_t)ns)); HIP_TRY(c->scene_sorted.ensure((size_t)ns)); HIP_TRY(c->scene_inv.ensure((size_t)ns));
+    HIP_TRY(c->scene_bounds.ensure((size_t)nchunk * 2)); HIP_TRY(c->scene_qbounds.ensure((size_t)nchunk * 8));
+    HIP_TRY(c->scene_frags.ensure((size_t)nchunk * (MF_CH / 32) * 64)); HIP_TRY(c->scene_centers.ensure((size_t)nchunk));
     {
-        std::vector<std::pair<int64_t, int64_t>> stack;
-        if (ns > 0) stack.push_back({0, ns});
-        while (!stack.empty()) {
-            const int64_t a = stack.back().first, b = stack.back().second;
-            stack.pop_back();
-            const int64_t n = b - a;
-            if (n <= 32) continue;
-            const int64_t unit = n > MF_CH ? MF_CH : 32;
-            const int64_t units = (n + unit - 1) / unit;
-            const int64_t nleft = std::min(n - 1, (units / 2) * unit);
-            if (nleft <= 0) continue;
-            float blo[3] = {1e30f, 1e30f, 1e30f}, bhi[3] = {-1e30f, -1e30f, -1e30f};
-            for (int64_t p = a; p < b; ++p)
-                for (int k = 0; k < 3; ++k) { float v = xyz[3 * (int64_t)order[p] + k]; blo[k] = std::min(blo[k], v); bhi[k] = std::max(bhi[k], v); }
-            int ax = 0;
-            for (int k = 1; k < 3; ++k) if (bhi[k] - blo[k] > bhi[ax] - blo[ax]) ax = k;
-            std::nth_element(order.begin() + a, order.begin() + a + nleft, order.begin() + b, [&](int i, int j) {
-                const float vi = xyz[3 * (int64_t)i + ax], vj = xyz[3 * (int64_t)j + ax];
-                return vi < vj || (vi == vj && i < j);
-            });
-            stack.push_back({a, a + nleft});
-            stack.push_back({a + nleft, b});
-        }
-    }
-    for (int64_t p = 0; p < ns; ++p) { sorted[p] = orig[order[p]]; inv[order[p]] = (int)p; }
-    const int64_t nchunk = (ns + MF_CH - 1) / MF_CH;
-    std::vector<float4> bounds((size_t)nchunk * 2);           // axis-aligned box per chunk, slightly inflated
-    for (int64_t ch = 0; ch < nchunk; ++ch) {
-        int64_t a = ch * MF_CH, b = std::min<int64_t>(ns, a + MF_CH);
-        float blo[3] = {1e30f, 1e30f, 1e30f}, bhi[3] = {-1e30f, -1e30f, -1e30f};
-        for (int64_t p = a; p < b; ++p) {
-            const float v[3] = {sorted[p].x, sorted[p].y, sorted[p].z};
-            for (int k = 0; k < 3; ++k) { blo[k] = std::min(blo[k], v[k]); bhi[k] = std::max(bhi[k], v[k]); }
-        }
-        for (int k = 0; k < 3; ++k) {
-            float pad = 1e-6f + 1e-6f * std::max(fabsf(blo[k]), fabsf(bhi[k]));
-            blo[k] -= pad; bhi[k] += pad;
-        }
-        bounds[2 * ch] = make_float4(blo[0], blo[1], blo[2], 0.f);
-        bounds[2 * ch + 1] = make_float4(bhi[0], bhi[1], bhi[2], 0.f);
-    }
-    // boxes of the quarter chunks (the k-d recursion goes on below the chunk, so 128 consecutive points are one node);
-    // a quarter past the end of the scene gets the empty box (+inf, +inf): at infinite distance from every query (box_d2)
-    std::vector<float4> qbounds((size_t)nchunk * 8);
-    for (int64_t qc = 0; qc < nchunk * 4; ++qc) {
-        int64_t a = qc * (MF_CH / 4), b = std::min<int64_t>(ns, a + MF_CH / 4);
-        float blo[3] = {INFINITY, INFINITY, INFINITY}, bhi[3] = {-INFINITY, -INFINITY, -INFINITY};
-        for (int64_t p = a; p < b; ++p) {
-            const float v[3] = {sorted[p].x, sorted[p].y, sorted[p].z};
-            for (int k = 0; k < 3; ++k) { blo[k] = std::min(blo[k], v[k]); bhi[k] = std::max(bhi[k], v[k]); }
-        }
-        if (a < b)
-            for (int k = 0; k < 3; ++k) {
-                float pad = 1e-6f + 1e-6f * std::max(fabsf(blo[k]), fabsf(bhi[k]));
-                blo[k] -= pad; bhi[k] += pad;
-            }
-        else
-            for (int k = 0; k < 3; ++k) bhi[k] = INFINITY;
-        qbounds[2 * qc] = make_float4(blo[0], blo[1], blo[2], 0.f);
-        qbounds[2 * qc + 1] = make_float4(bhi[0], bhi[1], bhi[2], 0.f);
-    }
-    // chunk-centred bf16 hi/lo fragments in MFMA A layout (see nn_stream4_kernel)
-    auto bf = [](float f) -> uint32_t { uint32_t u; memcpy(&u, &f, 4); u += 0x7FFFu + ((u >> 16) & 1u); return u >> 16; };   // RNE
-    auto bff = [](uint32_t h) -> float { uint32_t u = h << 16; float f; memcpy(&f, &u, 4); return f; };
-    std::vector<uint4> frags((size_t)nchunk * (MF_CH / 32) * 64);
-    std::vector<float4> centers((size_t)nchunk);
-    for (int64_t ch = 0; ch < nchunk; ++ch) {
-        const float4 lo = bounds[2 * ch], hi = bounds[2 * ch + 1];
-        const float cx = 0.5f * (lo.x + hi.x), cy = 0.5f * (lo.y + hi.y), cz = 0.5f * (lo.z + hi.z);
-        float r2 = 0.f;
-        for (int j = 0; j < MF_CH; ++j) {
-            const int64_t p = ch * MF_CH + j;
-            float yx = 0.f, yy = 0.f, yz = 0.f, n2 = 1e30f;      // padding rows: score 1e30
-            if (p < ns) {
-                yx = sorted[p].x - cx; yy = sorted[p].y - cy; yz = sorted[p].z - cz;
-                n2 = yz * yz + (yy * yy + yx * yx);
-                r2 = std::max(r2, n2);
-            }
-            uint32_t hx = bf(yx), hy = bf(yy), hz = bf(yz);
-            uint32_t lx = bf(yx - bff(hx)), ly = bf(yy - bff(hy)), lz = bf(yz - bff(hz));
-            // the score's factor -2 (|y|^2 - 2 x.y) rides on the static side: exact in bf16, and the per-chunk query
-            // fragment is the plain hi | lo split
-            hx = bf(-2.f * bff(hx)); hy = bf(-2.f * bff(hy)); hz = bf(-2.f * bff(hz));
-            lx = bf(-2.f * bff(lx)); ly = bf(-2.f * bff(ly)); lz = bf(-2.f * bff(lz));
-            const uint32_t nh = bf(n2);
-            const float r1 = n2 - bff(nh);
-            const uint32_t nm = bf(r1), nl = bf(r1 - bff(nm));
-            const int tile = j >> 5, pt = j & 31;
-            uint4* t = frags.data() + ((size_t)ch * (MF_CH / 32) + tile) * 64;
-            t[pt] = make_uint4(hx | (hx << 16), lx | (lx << 16), hy | (hy << 16), ly | (ly << 16));
-            t[32 + pt] = make_uint4(hz | (hz << 16), lz | (lz << 16), nh | (nm << 16), nl);
-        }
-        centers[ch] = make_float4(cx, cy, cz, sqrtf(r2) * 1.00001f + 1e-6f);
-    }
-    HIP_TRY(c->scene_frags.upload(frags.data(), frags.size()));
-    HIP_TRY(c->scene_centers.upload(centers.data(), centers.size()));
-    HIP_TRY(c->scene.upload(orig.data(), orig.size()));
-    HIP_TRY(c->scene_sorted.upload(sorted.data(), sorted.size()));
-    HIP_TRY(c->scene_bounds.upload(bounds.data(), bounds.size()));
-    {
-        const int64_t nsuper = (nchunk + ST4_SUPER - 1) / ST4_SUPER;
         std::vector<float4> sb((size_t)std::max<int64_t>(nsuper, 1) * 2, make_float4(0.f, 0.f, 0.f, 0.f));
-        for (int64_t su = 0; su < nsuper; ++su) {
-            float4 lo = make_float4(1e30f, 1e30f, 1e30f, 0.f), hi = make_float4(-1e30f, -1e30f, -1e30f, 0.f);
-            for (int64_t ch = su * ST4_SUPER; ch < std::min(nchunk, (su + 1) * ST4_SUPER); ++ch) {
-                lo.x = std::min(lo.x, bounds[2 * ch].x); lo.y = std::min(lo.y, bounds[2 * ch].y); lo.z = std::min(lo.z, bounds[2 * ch].z);
-                hi.x = std::max(hi.x, bounds[2 * ch + 1].x); hi.y = std::max(hi.y, bounds[2 * ch + 1].y); hi.z = std::max(hi.z, bounds[2 * ch + 1].z);
-            }
-            sb[2 * su] = lo; sb[2 * su + 1] = hi;
-        }
         HIP_TRY(c->scene_sbounds.upload(sb.data(), sb.size()));
-        HIP_TRY(c->scene_qbounds.upload(qbounds.data(), qbounds.size()));
     }
-    HIP_TRY(c->scene_inv.upload(inv.data(), inv.size()));
+    const char* how = getenv("FDCAP_SCENE_BUILD");
+    std::vector<int> order;
+    const bool host_order = how && !strcmp(how, "host");
+    if (host_order) scene_order_host(xyz, ns, order);
+    const SceneTables T{c->scene.p, c->scene_sorted.p, c->scene_inv.p, c->scene_bounds.p, c->scene_qbounds.p, c->scene_sbounds.p,
+                        c->scene_frags.p, c->scene_centers.p};
+    HIP_TRY(scene_build_device(xyz, ns, T, host_order ? order.data() : nullptr));
     c->ns = ns;
+    return FDCAP_OK;
+}
+
+// test / diagnosis: FNV-1a hashes of the registered scene's eight device tables (input-order points, sorted points, inverse
+// permutation, cell boxes, quarter boxes, super-cell boxes, fragments, centres), so two builds of the same scene can be compared
+int fdcap_debug_scene_hash(fdcap_ctx* c, uint64_t* out8) {
+    if (!c || !out8) return FDCAP_E_ARG;
+    HIP_TRY(hipDeviceSynchronize());
+    const int64_t ns = c->ns, nchunk = (ns + MF_CH - 1) / MF_CH, nsuper = std::max<int64_t>((nchunk + ST4_SUPER - 1) / ST4_SUPER, 1);
+    struct { const void* p; size_t bytes; } t[8] = {
+        {c->scene.p, (size_t)ns * 16}, {c->scene_sorted.p, (size_t)ns * 16}, {c->scene_inv.p, (size_t)ns * 4},
+        {c->scene_bounds.p, (size_t)nchunk * 32}, {c->scene_qbounds.p, (size_t)nchunk * 128}, {c->scene_sbounds.p, (size_t)nsuper * 32},
+        {c->scene_frags.p, (size_t)nchunk * (MF_CH / 32) * 64 * 16}, {c->scene_centers.p, (size_t)nchunk * 16}};
+    std::vector<unsigned char> h;
+    for (int i = 0; i < 8; ++i) {
+        h.resize(t[i].bytes);
+        if (t[i].bytes) HIP_TRY(hipMemcpy(h.data(), t[i].p, t[i].bytes, hipMemcpyDeviceToHost));
+        uint64_t v = 1469598103934665603ull;
+        for (size_t k = 0; k < t[i].bytes; ++k) { v ^= h[k]; v *= 1099511628211ull; }
+        out8[i] = v;
+    }
     return FDCAP_OK;
 }
 

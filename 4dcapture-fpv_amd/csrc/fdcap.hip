@@ -38,6 +38,7 @@ __device__ unsigned long long g_fr_times[3][2048 * 8];
 #include "fdc_loss.h"
 #include "fdc_math.h"
 #include "fdc_panel.h"
+#include "fdc_scene.h"
 #include "fdc_skin.h"
 #include "fdc_trace.h"
 

@@ -93,10 +93,16 @@ const char* fdcap_version(void);
 const char* fdcap_build_info(void);
 
 /* Scene vertices, stored ONCE (the reference repeats them per frame, :175-176).  `scene_xyz`
- * is a HOST pointer [ns,3]; registered (copied + packed for the NN kernel); ns <= FDCAP_MAX_SCENE_POINTS.
+ * is a HOST pointer [ns,3]; registered (copied, sorted into k-d cells and packed for the NN kernel -- on the device, one
+ * synchronous call); ns <= FDCAP_MAX_SCENE_POINTS.
  * Both setters return FDCAP_E_STATE while an optimiser exists on the context (fdcap_opt_create .. fdcap_opt_destroy): its
  * buffers are sized for the registered sets and its pruning state (seeds, kept work lists) is only valid for them. */
 int fdcap_set_scene(fdcap_ctx* ctx, const float* scene_xyz, int64_t ns);
+/* Diagnosis: out8[0..7] = FNV-1a hashes of the registered scene's device tables (input-order points, cell-ordered points, inverse
+ * permutation, cell / quarter-cell / super-cell boxes, MFMA fragments, cell centres).  The tables are built on the device since r6
+ * (csrc/fdc_scene.h); with FDCAP_SCENE_BUILD=host in the environment fdcap_set_scene takes the cell order from the host recursion of
+ * r1-r5 instead -- the same order by specification, which tests check by comparing these hashes.  Synchronises the device. */
+int fdcap_debug_scene_hash(fdcap_ctx* ctx, uint64_t* out8);
 /* Contact vertex ids = get_contact_id(...) (global_optimization.py:79-94, :288); HOST pointer. */
 int fdcap_set_contact_ids(fdcap_ctx* ctx, const int64_t* vid, int32_t nc);
 

@@ -1,0 +1,101 @@
+"""fdcap_set_scene builds the search's scene tables on the device (csrc/fdc_scene.h: three radix-sorted index lists, one stable
+partition per k-d level, boxes / fragments per cell).  The order is a specification (longest axis, (coordinate, index) rank,
+512 / 32-point units, input order inside a tile) that the host recursion of r1-r5 also follows, so every table must come out
+the same bit for bit from both -- ragged sizes, duplicate points, coordinate ties that straddle a cut, signed zeros, and the
+BASELINE scenes.  What the search RETURNS never depends on the order at all (tests/test_gpu_parity.py, test_gpu_fullsize.py);
+this file pins the order itself, and that an arbitrary scene's neighbours match the oracle's scan after the device build."""
+import ctypes
+import os
+
+import numpy as np
+import pytest
+import torch
+
+import fdcap_amd  # noqa: F401
+from fdcap_amd import capi, synth
+from oracle.chamfer import nn_direct
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    c = capi.Context(synth.make_body_model(400, seed=0), synth.make_vposer(seed=1))
+    yield c
+    c.close()
+
+
+def _hashes(ctx, scene, how):
+    old = os.environ.get("FDCAP_SCENE_BUILD")
+    try:
+        if how == "host":
+            os.environ["FDCAP_SCENE_BUILD"] = "host"
+        else:
+            os.environ.pop("FDCAP_SCENE_BUILD", None)
+        ctx.set_scene(scene)
+    finally:
+        if old is None:
+            os.environ.pop("FDCAP_SCENE_BUILD", None)
+        else:
+            os.environ["FDCAP_SCENE_BUILD"] = old
+    out = (ctypes.c_uint64 * 8)()
+    capi.check(ctx.lib.fdcap_debug_scene_hash(ctx.handle, out), "fdcap_debug_scene_hash")
+    return list(out)
+
+
+def _scenes():
+    rng = np.random.default_rng(11)
+    for n in (1, 31, 32, 33, 64, 65, 511, 512, 513, 1000, 1025, 4097, 16385, 70001):
+        yield f"uniform{n}", rng.uniform(-3, 3, (n, 3)).astype(np.float32)
+    # ties: coordinates on a coarse grid (hundreds of equal coordinates across every cut), duplicates of whole points
+    g = (rng.integers(0, 12, (20000, 3)) * 0.25 - 1.5).astype(np.float32)
+    yield "grid_ties", g
+    yield "duplicates", np.repeat(rng.uniform(-1, 1, (700, 3)).astype(np.float32), 9, axis=0)
+    z = rng.uniform(-1, 1, (5000, 3)).astype(np.float32)
+    z[::3, 0] = 0.0
+    z[1::3, 0] = -0.0                                       # -0 == +0 for the order; the point keeps its bits
+    z[:, 2] = 0.5                                           # a flat axis (extent 0: never the longest)
+    yield "signed_zeros_flat", z
+    yield "floor_like", synth.make_scene(30000, seed=5)
+
+
+@pytest.mark.parametrize("name,scene", list(_scenes()), ids=[n for n, _ in _scenes()])
+def test_device_build_gives_the_host_recursions_tables(ctx, name, scene):
+    dev = _hashes(ctx, scene, "device")
+    host = _hashes(ctx, scene, "host")
+    names = ["scene", "sorted", "inv", "bounds", "qbounds", "sbounds", "frags", "centers"]
+    assert dev == host, [n for n, a, b in zip(names, dev, host) if a != b]
+    assert _hashes(ctx, scene, "device") == dev             # and run to run
+
+
+@pytest.mark.parametrize("ns", [100_000, 500_000, 2_000_000])
+def test_baseline_scenes_build_identically_and_fast(ctx, ns):
+    import time
+    scene = synth.make_scene(ns, seed=2)
+    dev = _hashes(ctx, scene, "device")
+    assert dev == _hashes(ctx, scene, "host")
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    ctx.set_scene(scene)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    print(f"fdcap_set_scene({ns}) {dt * 1e3:.1f} ms")
+    assert dt < (0.08 if ns >= 2_000_000 else 0.02) * 3, dt   # <= 20 ms at 500 k, <= 80 ms at 2 M (x3: shared hosts)
+
+
+def test_search_on_a_device_built_scene_matches_the_oracles_scan(ctx):
+    rng = np.random.default_rng(3)
+    scene = np.concatenate([synth.make_scene(40000, seed=9), rng.uniform(-2, 2, (3000, 3)).astype(np.float32)])
+    scene = scene[rng.permutation(len(scene))]
+    ctx.set_scene(scene)
+    q = torch.tensor(rng.uniform(-1.5, 1.5, (4, 300, 3)).astype(np.float32)).cuda()
+    d = torch.empty(4, 300, device="cuda")
+    i = torch.empty(4, 300, device="cuda", dtype=torch.int32)
+    for forget in (1, 0):                                   # seeded by nn_seed_kernel, then by its own neighbours
+        capi.check(ctx.lib.fdcap_chamfer_fwd_scene(ctx.handle, capi.dptr(q), 4, 300, capi.dptr(d), capi.dptr(i), forget,
+                                                   capi.current_stream()), "fdcap_chamfer_fwd_scene")
+        torch.cuda.synchronize()
+        od, oi = nn_direct(q.cpu().reshape(-1, 3), torch.tensor(scene))
+        np.testing.assert_allclose(d.cpu().numpy().ravel(), od.numpy(), rtol=2e-6, atol=1e-12)
+        same = i.cpu().numpy().ravel() == oi.numpy()
+        assert same.mean() > 0.999                          # (indices: equal up to rounding ties between the two distance forms)
