@@ -103,16 +103,24 @@ int fdcap_ctx_create(const fdcap_model_desc* md, fdcap_ctx** out) {
         return FDCAP_E_ARG;
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) return FDCAP_E_NODEVICE;
+    SetupTrace tr("fdcap_ctx_create");
     fdcap_ctx* c = new fdcap_ctx();
     const int V = c->V = md->num_verts;
     c->h_vt.assign(md->v_template, md->v_template + (size_t)V * 3);
     c->h_S10.resize((size_t)V * 30);
     for (size_t i = 0; i < (size_t)V * 3; ++i)
         for (int l = 0; l < NBETA; ++l) c->h_S10[i * NBETA + l] = md->shapedirs[i * md->num_shape + l];
-    c->h_posedirs.assign(md->posedirs, md->posedirs + (size_t)NPF * 3 * V);
     c->h_lbs.assign(md->lbs_weights, md->lbs_weights + (size_t)V * NJ);
+    tr.mark("host copies of the model");
+    {   // posedirs (61 MB for SMPL-X) goes straight to the device: vertex sets gather their blend matrix there (build_skin_set)
+        hipError_t e_ = c->d_posedirs.upload(md->posedirs, (size_t)NPF * 3 * V);
+        if (e_ == hipSuccess) e_ = c->d_S10.upload(c->h_S10.data(), c->h_S10.size());
+        if (e_ != hipSuccess) { fdcap_ctx_destroy(c); return (int)e_; }
+    }
+    tr.mark("posedirs upload");
     HostPoseSetup hs;
     if (!host_pose_setup(V, c->h_vt.data(), c->h_S10.data(), md->J_regressor, md->parents, &hs)) { delete c; return FDCAP_E_ARG; }
+    tr.mark("host_pose_setup");
     std::vector<float>&Jt = hs.Jt, &Jd = hs.Jd;
     std::vector<int>&parents = hs.parents, &order = hs.order, &level_start = hs.level_start,
                     &child_start = hs.child_start, &child_list = hs.child_list;
@@ -149,6 +157,7 @@ int fdcap_ctx_create(const fdcap_model_desc* md, fdcap_ctx** out) {
     UP(c->W2, md->vp_fc2_w, 512 * 512) UP(c->b2, md->vp_fc2_b, 512)
     UP(c->W3, md->vp_out_w, ODIM * 512) UP(c->b3, md->vp_out_b, ODIM)
 #undef UP
+    tr.mark("small uploads");
     if (!err) {
         // decoder weights in MFMA fragment order.  torch Linear weights are [out, in]: forward y = x W^T -> B(k, n) = W[n][k];
         // data gradient dx = dy W -> B(k, n) = W[k][n]
@@ -156,24 +165,18 @@ int fdcap_ctx_create(const fdcap_model_desc* md, fdcap_ctx** out) {
             {md->vp_fc1_w, 1, VP_Z, VP_Z, VP_H, &c->vp.w1}, {md->vp_fc2_w, 1, VP_H, VP_H, VP_H, &c->vp.w2},
             {md->vp_out_w, 1, VP_H, VP_H, ODIM, &c->vp.w3}, {md->vp_out_w, VP_H, 1, ODIM, VP_H, &c->vp.w3t},
             {md->vp_fc2_w, VP_H, 1, VP_H, VP_H, &c->vp.w2t}, {md->vp_fc1_w, VP_Z, 1, VP_H, VP_Z, &c->vp.w1t}};
-        std::vector<float> pf;
+        const float* dw[6] = {c->W1.p, c->W2.p, c->W3.p, c->W3.p, c->W2.p, c->W1.p};        // the same weights on the device (uploaded above)
+        const size_t dwn[6] = {(size_t)512 * 32, (size_t)512 * 512, (size_t)ODIM * 512, (size_t)ODIM * 512, (size_t)512 * 512, (size_t)512 * 32};
         for (int i = 0; i < 6 && !err; ++i) {
             int nt = 0, ns = 0;
-            panel_pack(pk[i].w, pk[i].sk, pk[i].sn, pk[i].K, pk[i].N, pf, &nt, &ns);
-            hipError_t e_ = c->vp_pn[i].upload(pf.data(), pf.size());
-            if (e_ != hipSuccess) err = (int)e_;
+            err = panel_pack_dev(dw[i], dwn[i], pk[i].sk, pk[i].sn, pk[i].K, pk[i].N, c->vp_pn[i], &nt, &ns);
             pk[i].dst->f = (const float4*)c->vp_pn[i].p; pk[i].dst->ntile = nt; pk[i].dst->nss = ns;
         }
         c->vp.b1 = c->b1.p; c->vp.b2 = c->b2.p; c->vp.b3 = c->b3.p;
         PanelB3* dst3[6] = {&c->vp3.w1, &c->vp3.w2, &c->vp3.w3, &c->vp3.w3t, &c->vp3.w2t, &c->vp3.w1t};
-        std::vector<unsigned> p3;
-        std::vector<float> sc3;
         float c1n[6];                                                      // largest column 1-norm of each operand (VPoserPanels3::c1 ...)
         for (int i = 0; i < 6 && !err; ++i) {
-            VpF::pack(pk[i].w, pk[i].sk, pk[i].sn, pk[i].K, pk[i].N, p3, sc3, &dst3[i]->ntile, &dst3[i]->nst);
-            hipError_t e_ = c->vp_pn3[i].upload(p3.data(), p3.size());
-            if (e_ == hipSuccess) e_ = c->vp_pn3s[i].upload(sc3.data(), sc3.size());
-            if (e_ != hipSuccess) err = (int)e_;
+            err = pnf_pack_dev(dw[i], dwn[i], pk[i].sk, pk[i].sn, pk[i].K, pk[i].N, c->vp_pn3[i], c->vp_pn3s[i], &dst3[i]->ntile, &dst3[i]->nst);
             dst3[i]->f = (const uint4*)c->vp_pn3[i].p; dst3[i]->isc = c->vp_pn3s[i].p;
             double mx = 0.0;
             for (int n = 0; n < pk[i].N; ++n) {
@@ -188,6 +191,7 @@ int fdcap_ctx_create(const fdcap_model_desc* md, fdcap_ctx** out) {
         c->vp3.b1max = amax(md->vp_fc1_b, 512); c->vp3.b2max = amax(md->vp_fc2_b, 512);
         c->vp3.b1 = c->b1.p; c->vp3.b2 = c->b2.p; c->vp3.b3 = c->b3.p;
     }
+    tr.mark("decoder panels");
     if (err) { fdcap_ctx_destroy(c); return err; }
     *out = c;
     return FDCAP_OK;
@@ -199,7 +203,7 @@ void fdcap_ctx_destroy(fdcap_ctx* c) {
     (void)fdcap_comm_destroy(c);
     c->xch_send.release(); c->xch_all.release();
     c->ws_adam.release();
-    c->Jt.release(); c->Jd.release(); c->hand_comp.release(); c->hand_mean.release();
+    c->Jt.release(); c->Jd.release(); c->hand_comp.release(); c->hand_mean.release(); c->d_posedirs.release(); c->d_S10.release();
     c->parents.release(); c->order.release(); c->level_start.release(); c->child_start.release(); c->child_list.release(); c->depth.release();
     c->pose_tab.release();
     c->W1.release(); c->b1.release(); c->W2.release(); c->b2.release(); c->W3.release(); c->b3.release();
@@ -271,6 +275,7 @@ int fdcap_debug_scene_hash(fdcap_ctx* c, uint64_t* out8) {
 int fdcap_set_contact_ids(fdcap_ctx* c, const int64_t* vid, int32_t nc) {
     if (!c || nc < 0 || (nc > 0 && !vid)) return FDCAP_E_ARG;
     if (c->opt) return FDCAP_E_STATE;                  // (see fdcap_set_scene)
+    SetupTrace tr("fdcap_set_contact_ids");
     for (int i = 0; i < nc; ++i) if (vid[i] < 0 || vid[i] >= c->V) return FDCAP_E_ARG;
     // Internal slot order = Morton order of the template positions: the 256 consecutive queries of an NN
     // workgroup are then spatially compact, so far fewer scene chunks survive its bound test (with all
@@ -299,8 +304,10 @@ int fdcap_set_contact_ids(fdcap_ctx* c, const int64_t* vid, int32_t nc) {
     std::vector<int> perm((size_t)std::max(nc, 1), 0), v32((size_t)std::max(nc, 1), 0);
     for (int sl = 0; sl < nc; ++sl) { ids[sl] = vid[key[sl].second]; perm[sl] = key[sl].second; }
     for (int i = 0; i < nc; ++i) v32[i] = (int)vid[i];
+    tr.mark("slot order");
     int e = build_skin_set(c, ids, &c->contact);
     if (e) return e;
+    tr.mark("build_skin_set");
     HIP_TRY(c->contact_vid.upload(v32.data(), v32.size()));
     HIP_TRY(c->contact_perm.upload(perm.data(), perm.size()));
     c->nc = nc;

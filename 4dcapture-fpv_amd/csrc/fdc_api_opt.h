@@ -28,6 +28,7 @@ int fdcap_opt_create(fdcap_ctx* c, const fdcap_opt_config* cfg, float* rows_x, f
     if (!c || !cfg || !rows_x || !rows_cam || !scale_d || !dscale_d || !losses_d || cfg->n_local <= 0 || cfg->n_total < cfg->n_local || cfg->frame0 < 0 ||
         cfg->frame0 + cfg->n_local > cfg->n_total)
         return FDCAP_E_ARG;
+    SetupTrace tr("fdcap_opt_create");
     // a second clip of the same shape reuses the scratch allocations (every buffer is re-zeroed below)
     OptState* o = c->opt ? c->opt : new OptState();
     c->opt = o;
@@ -71,6 +72,7 @@ int fdcap_opt_create(fdcap_ctx* c, const fdcap_opt_config* cfg, float* rows_x, f
         AL(o->pd, (size_t)std::max(o->nsplit, o->nsplit_bf) * nq) AL(o->pi, (size_t)std::max(o->nsplit, o->nsplit_bf) * nq)
     }
 #undef AL
+    tr.mark("buffers");
     if (!err && o->contact_on) {
         hipError_t e_ = hipMemset(o->idx.p, 0xFF, nq * sizeof(int));      // -1: no seed yet
         if (e_ != hipSuccess) err = (int)e_;
@@ -99,6 +101,7 @@ int fdcap_opt_create(fdcap_ctx* c, const fdcap_opt_config* cfg, float* rows_x, f
         hipError_t e_ = hipMemcpy(o->scale.p, &s, sizeof(float), hipMemcpyHostToDevice);
         if (e_ != hipSuccess) err = (int)e_;
     }
+    tr.mark("search state");
     if (err) { fdcap_opt_destroy(c); return err; }
     return FDCAP_OK;
 }

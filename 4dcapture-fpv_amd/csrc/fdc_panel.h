@@ -58,6 +58,23 @@ static inline void panel_pack(const float* src, long sk, long sn, int K, int N, 
     *nss = ns;
 }
 
+// device form of panel_pack (r6: a vertex set's panels are built where they are used -- the host loops cost 0.3 s per full-mesh set);
+// one thread per fragment lane: out[(tile * nss + s) * 64 + lane]
+__global__ __launch_bounds__(256) void panel_pack_kernel(const float* __restrict__ src, long sk, long sn, int K, int N, int nt, int ns,
+                                                         float4* __restrict__ out) {
+    const size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= (size_t)nt * ns * 64) return;
+    const int l = (int)(idx & 63), s = (int)((idx >> 6) % ns), t = (int)((idx >> 6) / ns);
+    const int n = 16 * t + (l & 15);
+    float v[4] = {0.f, 0.f, 0.f, 0.f};
+    if (n < N)
+        for (int m = 0; m < 4; ++m) {
+            const int k = 16 * s + 4 * (l >> 4) + m;
+            if (k < K) v[m] = src[(long)k * sk + (long)n * sn];
+        }
+    out[idx] = make_float4(v[0], v[1], v[2], v[3]);
+}
+
 // LDS image of a 16-row A block, k-blocked: element (row i, column k) -- a super-step's fragment is lane-linear
 __host__ __device__ __forceinline__ int pn_lds_index(int i, int k) { return (((k >> 2) << 4) + i) * 4 + (k & 3); }
 
@@ -675,6 +692,59 @@ struct PnH2 {
         *nst = ns;
     }
 };
+// device form of PnH2::pack (r6), same arithmetic: the column scales (largest |B(., n)| -> [2^13, 2^14), all-zero / non-finite
+// columns keep 1) by one of two kernels -- B row-major (sn == 1): a thread per column; B column-major (sk == 1): a workgroup per
+// column -- then one thread per fragment lane writes its 16 bytes of each plane.  scl / isc: [16 ntile], padding columns 1.
+__device__ __forceinline__ void pnh2_col_scale(float mx, float* scl, float* isc) {
+    int ex = 0;
+    if (mx > 0.f && mx < INFINITY) { (void)frexpf(mx, &ex); ex = min(max(14 - ex, -100), 100); }
+    *scl = ldexpf(1.f, ex);
+    *isc = ldexpf(1.f, -ex);
+}
+__global__ __launch_bounds__(256) void pnh2_colscale_rowmajor_kernel(const float* __restrict__ src, long sk, int K, int N, int npad,
+                                                                     float* __restrict__ scl, float* __restrict__ isc) {
+    const int n = blockIdx.x * 256 + threadIdx.x;
+    if (n >= npad) return;
+    float mx = 0.f;
+    if (n < N) for (int k = 0; k < K; ++k) mx = fmaxf(mx, fabsf(src[(long)k * sk + n]));
+    pnh2_col_scale(mx, scl + n, isc + n);
+}
+__global__ __launch_bounds__(256) void pnh2_colscale_colmajor_kernel(const float* __restrict__ src, long sn, int K, int N, int npad,
+                                                                     float* __restrict__ scl, float* __restrict__ isc) {
+    __shared__ float part[4];
+    const int n = blockIdx.x;
+    float mx = 0.f;
+    if (n < N) for (int k = threadIdx.x; k < K; k += 256) mx = fmaxf(mx, fabsf(src[(long)n * sn + k]));
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o));
+    if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = mx;
+    __syncthreads();
+    if (threadIdx.x == 0) pnh2_col_scale(fmaxf(fmaxf(part[0], part[1]), fmaxf(part[2], part[3])), scl + n, isc + n);
+}
+__global__ __launch_bounds__(256) void pnh2_pack_kernel(const float* __restrict__ src, long sk, long sn, int K, int N, int nt, int ns,
+                                                        const float* __restrict__ scl, uint4* __restrict__ out) {
+    const size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= (size_t)nt * ns * 64) return;
+    const int l = (int)(idx & 63), s = (int)((idx >> 6) % ns), t = (int)((idx >> 6) / ns);
+    const int n = 16 * t + (l & 15);
+    unsigned h[4] = {0u, 0u, 0u, 0u}, lo[4] = {0u, 0u, 0u, 0u};
+    if (n < N) {
+        const float sc = scl[n];
+        for (int e = 0; e < 8; ++e) {
+            const int k = 32 * s + 8 * (l >> 4) + e;
+            if (k >= K) continue;
+            const float x = src[(long)k * sk + (long)n * sn] * sc;
+            const _Float16 hh = (_Float16)x;
+            const _Float16 ll = (_Float16)((x - (float)hh) * 2048.f);
+            h[e >> 1] |= (unsigned)__builtin_bit_cast(unsigned short, hh) << (16 * (e & 1));
+            lo[e >> 1] |= (unsigned)__builtin_bit_cast(unsigned short, ll) << (16 * (e & 1));
+        }
+    }
+    uint4* const o = out + (((size_t)t * ns + s) * 2) * 64 + l;
+    o[0] = make_uint4(h[0], h[1], h[2], h[3]);
+    o[64] = make_uint4(lo[0], lo[1], lo[2], lo[3]);
+}
+
 #if FDC_PN_H2
 typedef PnH2 PnF;                                               // the format of the panel_gemm3_* family
 #else

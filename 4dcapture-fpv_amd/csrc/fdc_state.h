@@ -7,6 +7,27 @@ namespace {
 // ------------------------------------------------------------------------------------------
 // host side
 // ------------------------------------------------------------------------------------------
+// FDCAP_SETUP_TRACE=1: the set-up entry points (fdcap_ctx_create, fdcap_set_contact_ids, fdcap_opt_create) print the host time
+// of their stages to stderr (tools/setup_timing.py reads the totals from outside; this says where they go)
+struct SetupTrace {
+    bool on;
+    const char* who;
+    std::chrono::steady_clock::time_point t0, last;
+    explicit SetupTrace(const char* w) : who(w) {
+        const char* e = getenv("FDCAP_SETUP_TRACE");
+        on = e && e[0] == '1';
+        if (on) t0 = last = std::chrono::steady_clock::now();
+    }
+    void mark(const char* what) {
+        if (!on) return;
+        (void)hipDeviceSynchronize();
+        const auto now = std::chrono::steady_clock::now();
+        fprintf(stderr, "[fdcap setup] %s: %-28s %8.3f ms (at %8.3f)\n", who, what, std::chrono::duration<double, std::milli>(now - last).count(),
+                std::chrono::duration<double, std::milli>(now - t0).count());
+        last = now;
+    }
+};
+
 template <class T>
 struct DevBuf {
     T* p = nullptr;
@@ -157,7 +178,8 @@ struct fdcap_lbfgs {          // batched L-BFGS (csrc/fdc_lbfgs.h): n independen
 struct fdcap_ctx {
     int V = 0;
     // host copies needed to build vertex subsets
-    std::vector<float> h_vt, h_S10, h_posedirs, h_lbs;
+    std::vector<float> h_vt, h_S10, h_lbs;
+    DevBuf<float> d_posedirs, d_S10;    // posedirs [486, 3V] and shapedirs' first ten [3V, 10]: what a vertex set's blend matrix is gathered from (r6: on the device)
     // device constants
     DevBuf<float> Jt, Jd, hand_comp, hand_mean;
     DevBuf<int> parents, order, level_start, child_start, child_list, depth;
@@ -228,7 +250,73 @@ namespace {
 // largest K = 3 nv for which the blend products run on the fragment-ordered panels (both copies: 2 x 496 x K floats)
 constexpr int PANEL_MAX_K = 6144;
 
+// [posedirs ; shapedirs^T] of a vertex set, rows of ldp floats: pd[r, 3 i + k] = component k of vertex ids[i], zero padding
+__global__ __launch_bounds__(256) void blend_rows_gather_kernel(const float* __restrict__ posedirs, const float* __restrict__ S10, int V,
+                                                                const int* __restrict__ ids, int nv, int ldp, float* __restrict__ pd) {
+    const int col = blockIdx.x * 256 + threadIdx.x, r = blockIdx.y;
+    if (col >= ldp) return;
+    float v = 0.f;
+    if (col < 3 * nv) {
+        const int src = 3 * ids[col / 3] + col % 3;
+        v = r < NPF ? posedirs[(size_t)r * 3 * V + src] : S10[(size_t)src * NBETA + (r - NPF)];
+    }
+    pd[(size_t)r * ldp + col] = v;
+}
+// its columns permuted for blend_skin_fwd_kernel: block b = vertices 64 b .. + 63, tile 3 g + c = component c of vertices 64 b + 16 g .. + 15
+__global__ __launch_bounds__(256) void blend_rows_permute_kernel(const float* __restrict__ pd, int ldp, int nv, int ncs, float* __restrict__ ps) {
+    const int dst = blockIdx.x * 256 + threadIdx.x, k = blockIdx.y;
+    if (dst >= ncs) return;
+    const int b = dst / 192, t = (dst % 192) / 16, jj = dst % 16;
+    const int v = 64 * b + 16 * (t / 3) + jj;
+    ps[(size_t)k * ncs + dst] = v < nv ? pd[(size_t)k * ldp + 3 * v + (t % 3)] : 0.f;
+}
+
+// FDCAP_PANEL_PACK=host: the static operands are packed by the host loops of fdc_panel.h (r1-r5) instead of the device kernels --
+// the same arithmetic, kept as the specification (tests compare whole fits of the two, bit for bit).  Read at every call.
+inline bool panel_pack_on_host() { const char* e = getenv("FDCAP_PANEL_PACK"); return e && !strcmp(e, "host"); }
+
+// B(k, n) = src[k * sk + n * sn] (DEVICE pointer; sk == 1 or sn == 1) -> fp32 fragment order
+int panel_pack_dev(const float* src, size_t src_floats, long sk, long sn, int K, int N, DevBuf<float>& out, int* ntile, int* nss) {
+    const int nt = (N + 15) / 16, ns = (K + 15) / 16;
+    *ntile = nt; *nss = ns;
+    if (panel_pack_on_host()) {
+        std::vector<float> h(src_floats), pf;
+        HIP_TRY(hipMemcpy(h.data(), src, src_floats * sizeof(float), hipMemcpyDeviceToHost));
+        panel_pack(h.data(), sk, sn, K, N, pf, ntile, nss);
+        return (int)out.upload(pf.data(), pf.size());
+    }
+    const size_t lanes = (size_t)nt * ns * 64;
+    HIP_TRY(out.ensure(lanes * 4));
+    hipLaunchKernelGGL(panel_pack_kernel, dim3((unsigned)((lanes + 255) / 256)), dim3(256), 0, 0, src, sk, sn, K, N, nt, ns, (float4*)out.p);
+    return (int)hipGetLastError();
+}
+// ... -> the split format PnF (planes + the column tiles' inverse scales)
+int pnf_pack_dev(const float* src, size_t src_floats, long sk, long sn, int K, int N, DevBuf<unsigned>& out, DevBuf<float>& isc, int* ntile,
+                 int* nst) {
+    const int nt = (N + 15) / 16, ns = (K + 31) / 32;
+    if (PnF::NP != 2 || panel_pack_on_host() || (sk != 1 && sn != 1)) {
+        std::vector<float> h(src_floats), sc;
+        std::vector<unsigned> p3;
+        HIP_TRY(hipMemcpy(h.data(), src, src_floats * sizeof(float), hipMemcpyDeviceToHost));
+        PnF::pack(h.data(), sk, sn, K, N, p3, sc, ntile, nst);
+        HIP_TRY(out.upload(p3.data(), p3.size()));
+        return (int)isc.upload(sc.data(), sc.size());
+    }
+    *ntile = nt; *nst = ns;
+    const size_t lanes = (size_t)nt * ns * 64;
+    DevBuf<float> scl;
+    HIP_TRY(out.ensure(lanes * 2 * 4)); HIP_TRY(isc.ensure((size_t)nt * 16)); HIP_TRY(scl.ensure((size_t)nt * 16));
+    if (sn == 1) hipLaunchKernelGGL(pnh2_colscale_rowmajor_kernel, dim3((nt * 16 + 255) / 256), dim3(256), 0, 0, src, sk, K, N, nt * 16, scl.p, isc.p);
+    else hipLaunchKernelGGL(pnh2_colscale_colmajor_kernel, dim3(nt * 16), dim3(256), 0, 0, src, sn, K, N, nt * 16, scl.p, isc.p);
+    hipLaunchKernelGGL(pnh2_pack_kernel, dim3((unsigned)((lanes + 255) / 256)), dim3(256), 0, 0, src, sk, sn, K, N, nt, ns, scl.p, (uint4*)out.p);
+    hipError_t e = hipGetLastError();
+    if (e == hipSuccess) e = hipDeviceSynchronize();              // (scl is freed on return)
+    scl.release();
+    return (int)e;
+}
+
 int build_skin_set(fdcap_ctx* c, const std::vector<int64_t>& ids, SkinSet* out) {
+    SetupTrace tr("build_skin_set");
     const int V = c->V;
     const int nv = (int)ids.size();
     int K = 1;
@@ -238,7 +326,7 @@ int build_skin_set(fdcap_ctx* c, const std::vector<int64_t>& ids, SkinSet* out) 
         K = std::max(K, k);
     }
     const int ldp = (3 * nv + 3) & ~3;
-    std::vector<float> vt((size_t)nv * 3), ww((size_t)nv * K, 0.f), pd((size_t)NPFX * ldp, 0.f);
+    std::vector<float> vt((size_t)nv * 3), ww((size_t)nv * K, 0.f);
     std::vector<int> wj((size_t)nv * K, 0);
     for (int i = 0; i < nv; ++i) {
         int64_t v = ids[i];
@@ -249,15 +337,23 @@ int build_skin_set(fdcap_ctx* c, const std::vector<int64_t>& ids, SkinSet* out) 
             if (w != 0.f) { wj[(size_t)i * K + k] = j; ww[(size_t)i * K + k] = w; ++k; }
         }
     }
-    for (int r = 0; r < NPF; ++r)
-        for (int i = 0; i < nv; ++i)
-            for (int k = 0; k < 3; ++k)
-                pd[(size_t)r * ldp + 3 * i + k] = c->h_posedirs[(size_t)r * 3 * V + 3 * ids[i] + k];
-    // rows 486..495: shapedirs^T (betas part), so [pose feature | betas] x this matrix = pose offsets + shape offsets
-    for (int l = 0; l < NBETA; ++l)
-        for (int i = 0; i < nv; ++i)
-            for (int k = 0; k < 3; ++k)
-                pd[(size_t)(NPF + l) * ldp + 3 * i + k] = c->h_S10[((size_t)3 * ids[i] + k) * 10 + l];
+    // the set's blend matrix [posedirs ; shapedirs^T] (rows 486..495: the betas part, so [pose feature | betas] x this matrix =
+    // pose offsets + shape offsets), gathered on the device from the context's copies
+    const size_t pd_floats = (size_t)NPFX * ldp;
+    HIP_TRY(out->posedirs.ensure(pd_floats));
+    {
+        std::vector<int> id32((size_t)std::max(nv, 1), 0);
+        for (int i = 0; i < nv; ++i) id32[i] = (int)ids[i];
+        DevBuf<int> d_ids;
+        HIP_TRY(d_ids.upload(id32.data(), id32.size()));
+        if (ldp > 0) hipLaunchKernelGGL(blend_rows_gather_kernel, dim3((ldp + 255) / 256, NPFX), dim3(256), 0, 0, c->d_posedirs.p, c->d_S10.p, V, d_ids.p, nv, ldp, out->posedirs.p);
+        hipError_t e_ = hipGetLastError();
+        if (e_ == hipSuccess) e_ = hipDeviceSynchronize();
+        d_ids.release();
+        HIP_TRY(e_);
+    }
+    const float* pd = out->posedirs.p;
+    tr.mark("gather vt / weights / posedirs");
     std::vector<int> csc_start(NJ + 1, 0), csc_v;
     std::vector<float> csc_w;
     for (int j = 0; j < NJ; ++j) {
@@ -307,6 +403,7 @@ int build_skin_set(fdcap_ctx* c, const std::vector<int64_t>& ids, SkinSet* out) 
         for (int j = 0; j < NJ; ++j) if (csc_start[j + 1] > csc_start[j]) out->ja_hi = j + 1;
         HIP_TRY(out->csc_chunk.upload(cc.data(), cc.size()));
     }
+    tr.mark("lists, vpack, chunk table");
     out->wf_tab.release(); out->wf_step.release(); out->wf_frag.release();
     {   // the weights as MFMA fragments for skin_bwd_kernel's dA (SkinModel::wf_*): vertex sets beyond the contact-set kernels' reach;
         // FDCAP_SKIN_DA_MFMA=0: the ordered list form
@@ -350,64 +447,56 @@ int build_skin_set(fdcap_ctx* c, const std::vector<int64_t>& ids, SkinSet* out) 
             HIP_TRY(out->wf_frag.upload(frag.data(), frag.size()));
         }
     }
+    tr.mark("weight fragments");
     HIP_TRY(out->csc_start.upload(csc_start.data(), csc_start.size()));
     HIP_TRY(out->csc_v.upload(csc_v.data(), csc_v.size()));
     HIP_TRY(out->csc_w.upload(csc_w.data(), csc_w.size()));
     HIP_TRY(out->vt.upload(vt.data(), vt.size()));
     HIP_TRY(out->ww.upload(ww.data(), ww.size()));
     HIP_TRY(out->wj.upload(wj.data(), wj.size()));
-    HIP_TRY(out->posedirs.upload(pd.data(), pd.size()));
+    tr.mark("uploads");
     out->pn_fwd = PanelB(); out->pn_bwd = PanelB();
     if (nv > 0) {                                  // forward panel for every set (the full mesh takes the wide form of the kernel)
-        std::vector<float> pf;
         int nt = 0, ns = 0;
-        panel_pack(pd.data(), ldp, 1, NPFX, 3 * nv, pf, &nt, &ns);
-        HIP_TRY(out->pn_fwd_f.upload(pf.data(), pf.size()));
+        int e = panel_pack_dev(pd, pd_floats, ldp, 1, NPFX, 3 * nv, out->pn_fwd_f, &nt, &ns);
+        if (e) return e;
         out->pn_fwd.f = (const float4*)out->pn_fwd_f.p; out->pn_fwd.ntile = nt; out->pn_fwd.nss = ns;
     }
     if (nv > 0 && 3 * nv <= PANEL_MAX_K) {         // data-gradient panel while a 16-row block of K = 3 nv columns fits the LDS slabs
-        std::vector<float> pf;
         int nt = 0, ns = 0;
-        panel_pack(pd.data(), 1, ldp, 3 * nv, NPFX, pf, &nt, &ns);
-        HIP_TRY(out->pn_bwd_f.upload(pf.data(), pf.size()));
+        int e = panel_pack_dev(pd, pd_floats, 1, ldp, 3 * nv, NPFX, out->pn_bwd_f, &nt, &ns);
+        if (e) return e;
         out->pn_bwd.f = (const float4*)out->pn_bwd_f.p; out->pn_bwd.ntile = nt; out->pn_bwd.nss = ns;
     }
+    tr.mark("fp32 panels");
     out->pn_fwd3 = PanelB3(); out->pn_bwd3 = PanelB3();
     if (nv > 0) {                                 // the forward operand of every set also as split planes (format PnF)
-        std::vector<unsigned> p3;
-        std::vector<float> sc;
-        PnF::pack(pd.data(), ldp, 1, NPFX, 3 * nv, p3, sc, &out->pn_fwd3.ntile, &out->pn_fwd3.nst);
-        HIP_TRY(out->pn_fwd3_f.upload(p3.data(), p3.size()));
-        HIP_TRY(out->pn_fwd3_s.upload(sc.data(), sc.size()));
+        int e = pnf_pack_dev(pd, pd_floats, ldp, 1, NPFX, 3 * nv, out->pn_fwd3_f, out->pn_fwd3_s, &out->pn_fwd3.ntile, &out->pn_fwd3.nst);
+        if (e) return e;
         out->pn_fwd3.f = (const uint4*)out->pn_fwd3_f.p; out->pn_fwd3.isc = out->pn_fwd3_s.p;
     }
+    tr.mark("split forward panel");
     out->pn_fwdS = PanelB3();
-    if (nv > 0 && nv <= 512 && K <= 4) {          // ... and with permuted columns: block b = vertices 64 b .. + 63, tile 3 g + c = component c of vertices 64 b + 16 g .. + 15
+    if (nv > 0 && nv <= 512 && K <= 4) {          // ... and with permuted columns (blend_rows_permute_kernel)
         const int nb = (nv + 63) / 64, ncs = nb * 192;
-        std::vector<float> ps((size_t)NPFX * ncs, 0.f);
-        for (int b = 0; b < nb; ++b)
-            for (int t = 0; t < 12; ++t)
-                for (int jj = 0; jj < 16; ++jj) {
-                    const int v = 64 * b + 16 * (t / 3) + jj;
-                    if (v >= nv) continue;
-                    const int src = 3 * v + (t % 3), dst = b * 192 + t * 16 + jj;
-                    for (int k = 0; k < NPFX; ++k) ps[(size_t)k * ncs + dst] = pd[(size_t)k * ldp + src];
-                }
-        std::vector<unsigned> p3;
-        std::vector<float> sc;
-        PnF::pack(ps.data(), ncs, 1, NPFX, ncs, p3, sc, &out->pn_fwdS.ntile, &out->pn_fwdS.nst);
-        HIP_TRY(out->pn_fwdS_f.upload(p3.data(), p3.size()));
-        HIP_TRY(out->pn_fwdS_s.upload(sc.data(), sc.size()));
+        DevBuf<float> ps;
+        HIP_TRY(ps.ensure((size_t)NPFX * ncs));
+        hipLaunchKernelGGL(blend_rows_permute_kernel, dim3((ncs + 255) / 256, NPFX), dim3(256), 0, 0, pd, ldp, nv, ncs, ps.p);
+        int e = (int)hipGetLastError();
+        if (!e) e = pnf_pack_dev(ps.p, (size_t)NPFX * ncs, ncs, 1, NPFX, ncs, out->pn_fwdS_f, out->pn_fwdS_s, &out->pn_fwdS.ntile, &out->pn_fwdS.nst);
+        if (!e) e = (int)hipDeviceSynchronize();
+        ps.release();
+        if (e) return e;
         out->pn_fwdS.f = (const uint4*)out->pn_fwdS_f.p; out->pn_fwdS.isc = out->pn_fwdS_s.p;
     }
+    tr.mark("permuted forward panel");
     if (nv > 0) {                                 // ... and the data-gradient operand (one LDS image up to K = 1696: panel_gemm3 / _rb2k; beyond: panel_gemm3_kloop)
-        std::vector<unsigned> p3;
-        std::vector<float> sc;
-        PnF::pack(pd.data(), 1, ldp, 3 * nv, NPFX, p3, sc, &out->pn_bwd3.ntile, &out->pn_bwd3.nst);
-        HIP_TRY(out->pn_bwd3_f.upload(p3.data(), p3.size()));
-        HIP_TRY(out->pn_bwd3_s.upload(sc.data(), sc.size()));
+        int e = pnf_pack_dev(pd, pd_floats, 1, ldp, 3 * nv, NPFX, out->pn_bwd3_f, out->pn_bwd3_s, &out->pn_bwd3.ntile, &out->pn_bwd3.nst);
+        if (e) return e;
         out->pn_bwd3.f = (const uint4*)out->pn_bwd3_f.p; out->pn_bwd3.isc = out->pn_bwd3_s.p;
     }
+    HIP_TRY(hipDeviceSynchronize());
+    tr.mark("split gradient panel");
     return 0;
 }
 

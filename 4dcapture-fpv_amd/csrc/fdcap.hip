@@ -6,6 +6,8 @@
 #include <string.h>
 
 #include <algorithm>
+#include <chrono>
+#include <string>
 #include <vector>
 
 // Build requirement (the finding: NOTES.md section 6): this file is compiled WITHOUT packed fp32 instructions

@@ -1,9 +1,16 @@
-"""fdcap_set_scene builds the search's scene tables on the device (csrc/fdc_scene.h: three radix-sorted index lists, one stable
+"""The set-up entry points run on the device since r6 (their host loops cost more than the fits they served).
+
+fdcap_set_scene builds the search's scene tables on the device (csrc/fdc_scene.h: three radix-sorted index lists, one stable
 partition per k-d level, boxes / fragments per cell).  The order is a specification (longest axis, (coordinate, index) rank,
 512 / 32-point units, input order inside a tile) that the host recursion of r1-r5 also follows, so every table must come out
 the same bit for bit from both -- ragged sizes, duplicate points, coordinate ties that straddle a cut, signed zeros, and the
 BASELINE scenes.  What the search RETURNS never depends on the order at all (tests/test_gpu_parity.py, test_gpu_fullsize.py);
-this file pins the order itself, and that an arbitrary scene's neighbours match the oracle's scan after the device build."""
+this file pins the order itself, and that an arbitrary scene's neighbours match the oracle's scan after the device build.
+
+fdcap_ctx_create / fdcap_set_contact_ids pack the static operands of the dense products (fp32 fragment order, two scaled fp16
+planes + column scales) with device kernels; FDCAP_PANEL_PACK=host keeps the host loops of csrc/fdc_panel.h as the specification:
+whole fits on the two must agree bit for bit -- contact sets that take the fused contact forward, the generic path, and the
+full mesh (K-loop data gradient, wide forward)."""
 import ctypes
 import os
 
@@ -99,3 +106,43 @@ def test_search_on_a_device_built_scene_matches_the_oracles_scan(ctx):
         np.testing.assert_allclose(d.cpu().numpy().ravel(), od.numpy(), rtol=2e-6, atol=1e-12)
         same = i.cpu().numpy().ravel() == oi.numpy()
         assert same.mean() > 0.999                          # (indices: equal up to rounding ties between the two distance forms)
+
+
+def _fit(pack, n, V, per_part, all_contacts, ns=20000, iters=8):
+    from fdcap_amd.fitting import FittingOP
+    from fdcap_amd.io import read_camerapose
+    old = os.environ.get("FDCAP_PANEL_PACK")
+    try:
+        if pack == "host":
+            os.environ["FDCAP_PANEL_PACK"] = "host"
+        else:
+            os.environ.pop("FDCAP_PANEL_PACK", None)
+        bm = synth.make_body_model(V, seed=0)
+        vp = synth.make_vposer(seed=1)
+        clip = synth.make_clip(n, seed=3)
+        scene = synth.make_scene(ns, seed=2)
+        left, right = synth.make_contact_ids(bm.v_template, per_part=per_part, seed=4)
+        vid = np.arange(V) if all_contacts else np.concatenate([left, right])
+        fop = FittingOP({"num_iter": iters}, {}, n, body_model=bm, vposer=vp, scene_verts=scene, contact_ids=vid,
+                        camera_ext=read_camerapose(clip.camerapose_lines))
+        body, scale, cam = fop.fitting(torch.tensor(clip.body_params).cuda(), "global", log_every=1)
+        out = body.cpu().numpy().copy(), float(scale), cam.cpu().numpy().copy(), np.array(fop.log.total)
+        fop.close()
+        return out
+    finally:
+        if old is None:
+            os.environ.pop("FDCAP_PANEL_PACK", None)
+        else:
+            os.environ["FDCAP_PANEL_PACK"] = old
+
+
+@pytest.mark.parametrize("n,V,per_part,all_contacts", [(40, 700, 30, False), (400, 10475, 250, False), (12, 10475, 0, True), (20, 1500, 0, True)],
+                         ids=["small", "config3_like_fused_forward", "full_mesh_contacts", "mid_mesh_contacts"])
+def test_device_packed_operands_give_the_host_packed_fit_bit_for_bit(n, V, per_part, all_contacts):
+    a = _fit("device", n, V, per_part, all_contacts)
+    b = _fit("host", n, V, per_part, all_contacts)
+    assert np.isfinite(a[0]).all()
+    np.testing.assert_array_equal(a[0], b[0])
+    assert a[1] == b[1]
+    np.testing.assert_array_equal(a[2], b[2])
+    np.testing.assert_array_equal(a[3], b[3])
