@@ -134,6 +134,8 @@ SYMBOLS = {
     "fdcap_time_blend_gemm": (c_int32, [c_void_p, c_int32, c_int32, POINTER(c_float), c_void_p]),
     "fdcap_opt_nn_timing": (c_int32, [c_void_p, c_int32]),
     "fdcap_opt_nn_timing_read": (c_int32, [c_void_p, POINTER(c_float), POINTER(c_int32)]),
+    "fdcap_opt_launch_timing": (c_int32, [c_void_p, c_int32]),
+    "fdcap_opt_launch_timing_read": (c_int32, [c_void_p, c_void_p, c_void_p]),
     "fdcap_opt_time_chamfer": (c_int32, [c_void_p, c_int32, c_int32, POINTER(c_float), c_void_p]),
 }
 
@@ -258,6 +260,7 @@ class Context:
         self.num_scene = s.shape[0]
         self._scene_host = s                   # (ops.chamferDist recognises a target tensor that holds exactly these points)
         self._scene_dev = None
+        self._scene_gen = getattr(self, "_scene_gen", 0) + 1     # ... and forgets what it concluded about an earlier scene
 
     def set_contact_ids(self, vid):
         v = np.ascontiguousarray(vid, dtype=np.int64)

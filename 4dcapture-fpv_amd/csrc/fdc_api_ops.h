@@ -403,7 +403,7 @@ int fdcap_chamfer_fwd_scene(fdcap_ctx* c, const float* xyz1, int32_t B, int32_t 
     const int nsplit = nn_pick_nsplit(nq, (int)c->ns, true);
     HIP_TRY(c->ws_f[0].ensure((size_t)nsplit * nq));
     HIP_TRY(c->ws_i[0].ensure((size_t)nsplit * nq));
-    static float slack = -1.f;
+    static std::atomic<float> slack{-1.f};
     if (slack < 0.f) { const char* e = getenv("FDCAP_NN_CACHE_SLACK"); slack = e ? (float)atof(e) : 0.03f; }
     const NNCache cache{slack > 0.f ? so.ids.p : nullptr, slack > 0.f ? so.hdr.p : nullptr, so.anchor.p, slack};
     bool pt_written = false;

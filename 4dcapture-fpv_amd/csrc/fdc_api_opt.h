@@ -19,6 +19,8 @@ void fdcap_opt_destroy(fdcap_ctx* c) {
     o->nnc_ids.release(); o->nnc_hdr.release(); o->nnc_anchor.release();
     for (hipEvent_t e : o->nn_ev) (void)hipEventDestroy(e);
     o->nn_ev.clear();
+    for (hipEvent_t e : o->lt.ev) (void)hipEventDestroy(e);
+    o->lt.ev.clear(); o->lt.what.clear(); o->lt.on = false; o->lt.used = 0;
     delete o;
     c->opt = nullptr;
 }
@@ -130,10 +132,10 @@ static int opt_contact_forward(fdcap_ctx* c, hipStream_t st, bool blend_done = f
     const bool fused = !blend_done && o->fuse_skin && gemm_split3_enabled() && c->contact.pn_fwdS.f && smf.vpack && smf.K <= 4 && nl >= 384 &&
                        blend_skin_lds_bytes(smf.ja_hi) <= (size_t)150 * 1024;
     if (fused) {
-        static bool attr = false;
-        if (!attr) {
+        static std::atomic<uint64_t> attr{0};                  // per DEVICE: the attribute belongs to one device's code object
+        if (fdc_attr_needed(attr)) {
             HIP_TRY(hipFuncSetAttribute((const void*)blend_skin_fwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
-            attr = true;
+            fdc_attr_done(attr);
         }
         hipLaunchKernelGGL(blend_skin_fwd_kernel, dim3(8 * ((nl + 31) / 32)), dim3(768), blend_skin_lds_bytes(smf.ja_hi), st, o->PF.p, nl,
                            c->contact.pn_fwdS, smf, nc, smf.ja_hi, o->X.p, XDIM, X_TRANSL, o->A.p, o->M.p, o->scale.p, 2, o->Voff.p, o->Vw.p);
@@ -142,6 +144,7 @@ static int opt_contact_forward(fdcap_ctx* c, hipStream_t st, bool blend_done = f
         hipLaunchKernelGGL(skin_fwd_kernel, dim3((nc + 255) / 256, nl), dim3(256), 0, st, smf, nc, o->X.p, XDIM,
                            X_BETAS, X_TRANSL, o->Voff.p, o->A.p, o->M.p, o->scale.p, 2, 1, o->Vw.p);
     }
+    lt_mark(o, FDCAP_LT_CONTACT_FWD, st);
     const int nq = nl * nc;
     // the first contact forward of a fit has no neighbours from a previous iteration yet (idx = -1)
     const NNCache cache = o->nn_cache(0);
@@ -154,6 +157,7 @@ static int opt_contact_forward(fdcap_ctx* c, hipStream_t st, bool blend_done = f
                           &cache, &o->nn_order));
     }
     if (timed) { HIP_TRY(hipEventRecord(o->nn_ev[o->nn_ev_used + 1], st)); o->nn_ev_used += 2; }
+    lt_mark(o, FDCAP_LT_CHAMFER_NN, st);
     o->seeded = true;
     return 0;
 }
@@ -187,6 +191,7 @@ static int opt_backward_impl(fdcap_ctx* c, const LossWeights& lw, int32_t log_te
     const bool ahead = o->ahead, blend_done = o->ahead && o->ahead_blend;
     const bool contact_grad = o->contact_on && lw.contact != 0.f;
     const bool contact_fwd = o->contact_on && (contact_grad || log_terms);
+    o->lt.phase = contact_grad ? 0 : 1;
     int e = ahead ? opt_pose_forward_rest(c, row_lo, row_hi, st) : opt_pose_forward(c, row_lo, row_hi, st, contact_fwd || (dct_on || o->dctW > 0));
     o->ahead = false;
     if (e) return e;
@@ -246,7 +251,9 @@ static int opt_backward_impl(fdcap_ctx* c, const LossWeights& lw, int32_t log_te
         { int es = skin_bwd_any<true>(c->ws_skin, st, nl, c->contact.model(), nc, o->X.p, o->Voff.p, o->A.p, o->M.p, o->scale.p, 2,
                                       (const float*)nullptr, o->dVoff.p, o->dA.p, (float*)nullptr, o->dtransl_v.p, o->dMv.p, o->dsv.p, cg);
           if (es) return es; }
+        lt_mark(o, FDCAP_LT_SKIN_BWD, st);
         HIP_TRY(blend_backward(c->contact, o->dVoff.p + (size_t)2 * nc * 3, nl, o->dPF.p + 2 * NPFX, (size_t)o->R * NPFX, c->ws_kpart, st, &dpf_split));
+        lt_mark(o, FDCAP_LT_BLEND_BWD, st);
     } else if (contact_fwd && losses) {
         if (fuse_pl && rows_log) { pli.cdist = o->dist.p; pli.cnc = nc; }        // (rides in pose_bwd_kernel's prologue: one launch less)
         else hipLaunchKernelGGL(contact_loss_rows_kernel, dim3(nl), dim3(256), 0, st, o->dist.p, nc, 2, o->loss_rows.p);
@@ -258,6 +265,7 @@ static int opt_backward_impl(fdcap_ctx* c, const LossWeights& lw, int32_t log_te
                        contact_grad ? o->dPF.p + NPF : nullptr, NPFX, contact_grad ? o->dtransl_v.p : nullptr, o->dX.p, o->dO.p,
                        o->dCAM.p, o->dscale_row.p, pli, (contact_grad && dpf_split) ? (const float*)(o->dPF.p + (size_t)o->R * NPFX) : (const float*)nullptr,
                        dA_rows);
+    lt_mark(o, FDCAP_LT_POSE_BWD, st);
     const unsigned log_mask = (rows_log ? 0x17u : 0u) | (contact_fwd ? 0x8u : 0u);     // 0 rec, 1 z^2, 2 smoothing, 4 world | 3 contact
     bool log_in_tail = false;
     {

@@ -370,6 +370,38 @@ int fdcap_opt_nn_timing_read(fdcap_ctx* c, float* mean_ms, int32_t* launches) {
     return FDCAP_OK;
 }
 
+int fdcap_opt_launch_timing(fdcap_ctx* c, int32_t max_events) {
+    if (!c || !c->opt || max_events < 0) return FDCAP_E_ARG;
+    OptState::LaunchTimes& t = c->opt->lt;
+    t.on = max_events > 0;
+    t.used = 0;
+    while ((int)t.ev.size() < max_events) {
+        hipEvent_t e;
+        HIP_TRY(hipEventCreate(&e));
+        t.ev.push_back(e);
+    }
+    t.what.resize(t.ev.size(), (signed char)-1);
+    return FDCAP_OK;
+}
+int fdcap_opt_launch_timing_read(fdcap_ctx* c, float* mean_us, int32_t* counts) {
+    if (!c || !c->opt || !mean_us || !counts) return FDCAP_E_ARG;
+    OptState::LaunchTimes& t = c->opt->lt;
+    double sum[2 * FDCAP_LT_NUM] = {0.0};
+    for (int i = 0; i < 2 * FDCAP_LT_NUM; ++i) counts[i] = 0;
+    if (t.used > 0) HIP_TRY(hipEventSynchronize(t.ev[t.used - 1]));
+    for (int k = 1; k < t.used; ++k) {
+        const int w = t.what[k];
+        if (w < 0) continue;                                 // (from the previous iteration's last launch to this one's first event: host time)
+        const int slot = (w & 15) + FDCAP_LT_NUM * (w >> 4);
+        float ms = 0.f;
+        HIP_TRY(hipEventElapsedTime(&ms, t.ev[k - 1], t.ev[k]));
+        sum[slot] += ms * 1e3;
+        counts[slot] += 1;
+    }
+    for (int i = 0; i < 2 * FDCAP_LT_NUM; ++i) mean_us[i] = counts[i] ? (float)(sum[i] / counts[i]) : 0.f;
+    return FDCAP_OK;
+}
+
 int fdcap_time_blend_gemm(fdcap_ctx* c, int32_t rows, int32_t iters, float* ms, void* stream) {
     if (!c || rows <= 0 || iters <= 0 || !ms) return FDCAP_E_ARG;
     hipStream_t st = (hipStream_t)stream;

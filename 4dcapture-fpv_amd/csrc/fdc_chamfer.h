@@ -17,6 +17,8 @@
 #include <hip/hip_runtime.h>
 #include <stdlib.h>
 
+#include <atomic>
+
 #include "fdc_math.h"
 
 namespace fdc {
@@ -1311,8 +1313,8 @@ __global__ void nn_grad_kernel(const float* __restrict__ q, const float4* __rest
 
 // kernel choice: 0 = by size (MFMA-filtered for non-trivial sizes), 1 = plain VALU scan,
 // 2 = MFMA-filtered.  Env FDCAP_NN_KERNEL=direct|mfma or fdcap_set_nn_kernel() override (A/B).
-inline int& nn_mode_ref() {
-    static int mode = -1;
+inline std::atomic<int>& nn_mode_ref() {
+    static std::atomic<int> mode{-1};
     if (mode < 0) {
         const char* e = getenv("FDCAP_NN_KERNEL");
         mode = (e && e[0] == 'd') ? 1 : (e && e[0] == 'm') ? 2 : 0;
@@ -1391,14 +1393,14 @@ static inline hipError_t nn_search(const float* q, int nq, const NNTarget& T, fl
     // staged chunk: 9.7 ms vs 10.9 at NQ = 2); a seeded + chunk-culled scan wants NQ = 2 (the union of
     // the chunks 256 queries need is smaller than what 512 need, twice the workgroups: 0.92 ms vs
     // 1.10 ms at NQ = 4, 1.09 ms at NQ = 1).  FDCAP_NN_NQ overrides.
-    static int forced_nq = -1;
+    static std::atomic<int> forced_nq{-1};
     if (forced_nq < 0) { const char* e = getenv("FDCAP_NN_NQ"); forced_nq = e ? atoi(e) : 0; }
     const bool culled = seed != nullptr && T.bounds != nullptr;
     // FDCAP_NN_STREAM (A/B): 0 staged kernel, WQ = nn_stream4_kernel with W waves per group of 32 Q queries
     // (41, 42, 21, 22, 11, 12); default: 32-query groups, waves per group by launch size --
     // measured (1024 / 512 / 256 / 128 frames x 500 queries): 11: 0.139 / 0.095 / 0.054 / 0.072 ms, 21: 0.140 / 0.087 /
     // 0.049 / 0.047, 41: 0.153 / 0.086 / 0.047 / 0.036
-    static int use_stream = -1;
+    static std::atomic<int> use_stream{-1};
     if (use_stream < 0) { const char* e = getenv("FDCAP_NN_STREAM"); use_stream = e ? atoi(e) : -2; }
     // (the streaming kernel's work list holds 16-bit ids 4 k + quarter: scenes up to 16384 chunks = 8.4 M points; beyond, the staged kernel)
     if (culled && T.frags != nullptr && use_stream && nn_use_mfma(nq, T.n) && seedpt != nullptr && seed == idx &&
@@ -1417,7 +1419,7 @@ static inline hipError_t nn_search(const float* q, int nq, const NNTarget& T, fl
                 nqv = (use_stream % 10 == 2) ? 2 : 1;
                 wpg = (use_stream / 10 == 4) ? 4 : (use_stream / 10 == 2) ? 2 : 1;
             }
-            static int wpb1 = -1;                             // FDCAP_NN_WPB=4 (A/B): four-wave workgroups for one-wave groups too
+            static std::atomic<int> wpb1{-1};                             // FDCAP_NN_WPB=4 (A/B): four-wave workgroups for one-wave groups too
             if (wpb1 < 0) { const char* e = getenv("FDCAP_NN_WPB"); wpb1 = (e && atoi(e) == 4) ? 0 : 1; }
             const int groups = (nq + 32 * nqv - 1) / (32 * nqv);
             const int wpb = (wpg == 1 && nqv == 1 && wpb1) ? 1 : 4;
@@ -1443,7 +1445,8 @@ static inline hipError_t nn_search(const float* q, int nq, const NNTarget& T, fl
         }
         return hipGetLastError();
     }
-    const int NQsel = forced_nq ? forced_nq : (culled ? 2 : 4);
+    const int fq_ = forced_nq;
+    const int NQsel = fq_ ? fq_ : (culled ? 2 : 4);
     if (nn_use_mfma(nq, T.n) && NQsel == 1)
         hipLaunchKernelGGL((nn_mfma_kernel<1>), dim3(nn_grid_blocks((nq + 127) / 128, nsplit)), dim3(256), 0, st, q, nq, T, nsplit, seed, pd, pi);
     else if (nn_use_mfma(nq, T.n) && NQsel == 2)

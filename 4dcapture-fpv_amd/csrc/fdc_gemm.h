@@ -13,6 +13,8 @@
 #include <stdint.h>
 #include <stdlib.h>
 
+#include <atomic>
+
 namespace fdc {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -669,16 +671,16 @@ static inline hipError_t gemm_dispatch_tile(const float* A, int lda, const float
         // 16x16 tiles read twice the operand bytes per MAC: they pay off while the grid is small (latency-bound) and
         // K is short; the K = 1500 pose-blend data-gradient at 1024 frames (528 32x32 tiles) is L2-bandwidth-bound
         // with them (35.9 us vs 31.3).  FDCAP_GEMM_T16 overrides the tile-count threshold (A/B).
-        static int t16 = -1;
+        static std::atomic<int> t16{-1};
         if (t16 < 0) { const char* e = getenv("FDCAP_GEMM_T16"); t16 = e ? atoi(e) : 1024; }
         const long long tiles32 = (long long)((N + 31) / 32) * ((M + 31) / 32);
-        static int v4 = -1;                                  // FDCAP_GEMM_V4=0: scalar staging only (A/B)
+        static std::atomic<int> v4{-1};                                  // FDCAP_GEMM_V4=0: scalar staging only (A/B)
         if (v4 < 0) { const char* e = getenv("FDCAP_GEMM_V4"); v4 = (e && e[0] == '0') ? 0 : 1; }
         const bool aligned = (lda % 4 == 0) && (ldb % 4 == 0) && (K % 4 == 0) && (NK || N % 4 == 0) &&
                              ((reinterpret_cast<uintptr_t>(A) | reinterpret_cast<uintptr_t>(B)) & 15) == 0;
         if (tiles32 < t16 / 4 || (tiles32 < t16 && K <= 768)) {
             dim3 grid((N + 15) / 16, (M + 15) / 16);
-            static int bk256 = -1;                           // FDCAP_GEMM_BK256=0: 128-deep slabs only (A/B)
+            static std::atomic<int> bk256{-1};                           // FDCAP_GEMM_BK256=0: 128-deep slabs only (A/B)
             if (bk256 < 0) { const char* e = getenv("FDCAP_GEMM_BK256"); bk256 = (e && e[0] == '0') ? 0 : 1; }
             // deep products on small grids: half the slab rounds (barriers + exposed load latencies); with >= 1024 workgroups
             // in flight the shorter slabs overlap better (measured: N = 512 layers 14.1 vs 15.0 us, N = 126 / 32 layers 6.8 / 7.1 vs 5.8 / 6.7)
@@ -706,7 +708,7 @@ static inline hipError_t gemm_dispatch_tile(const float* A, int lda, const float
     if (!NK && (EPI == EPI_STORE || EPI == EPI_ACCUM) && (long long)M * N >= 128LL * 128 * 512 && N >= 8 * 128) {
         const int MT = (M + 127) / 128, NT = (N + 127) / 128;
         const int blocks = (NT + 7) / 8 * 8 * MT;
-        static int wv4 = -1;                                 // FDCAP_GEMM_V4=0: scalar staging only (A/B)
+        static std::atomic<int> wv4{-1};                                 // FDCAP_GEMM_V4=0: scalar staging only (A/B)
         if (wv4 < 0) { const char* e = getenv("FDCAP_GEMM_V4"); wv4 = (e && e[0] == '0') ? 0 : 1; }
         if (wv4 && lda % 4 == 0 && ldb % 4 == 0 && K % 4 == 0 &&
             ((reinterpret_cast<uintptr_t>(A) | reinterpret_cast<uintptr_t>(B)) & 15) == 0)

@@ -22,14 +22,21 @@
 #pragma once
 #include <hip/hip_runtime.h>
 
+#include <stdint.h>
 #include <string.h>
 
+#include <atomic>
 #include <vector>
 
 #include "fdc_frame.h"
 #include "fdc_loss.h"
 
 namespace fdc {
+
+// hipFuncSetAttribute(MaxDynamicSharedMemorySize) is a property of ONE device's code object: one bit per device ordinal, set after
+// the attribute took (two threads racing set it twice: harmless)
+inline bool fdc_attr_needed(const std::atomic<uint64_t>& mask) { int d = 0; (void)hipGetDevice(&d); return !(mask.load() & (1ull << (d & 63))); }
+inline void fdc_attr_done(std::atomic<uint64_t>& mask) { int d = 0; (void)hipGetDevice(&d); mask.fetch_or(1ull << (d & 63)); }
 
 typedef float f32x4_t __attribute__((ext_vector_type(4)));
 
@@ -936,7 +943,7 @@ __global__ __launch_bounds__(512) void panel_gemm3_rb2k_kernel(const float* __re
 }
 // may the product take that form?  (the caller then provides the second partial buffer and adds the two)
 static inline bool panel_gemm3_rb2k_ok(int M, int K, const PanelB3& B) {
-    static int rb2 = -1;
+    static std::atomic<int> rb2{-1};
     if (rb2 < 0) { const char* e = getenv("FDCAP_PN_RB2"); rb2 = e ? atoi(e) : 1; }     // 0 off, 1 both forms, 2 forward only, 3 K-split only
     const int nst_all = (K + 31) >> 5;
     return (rb2 == 1 || rb2 == 3) && M >= 384 && B.ntile <= 32 && nst_all >= 2 && 32 * ((nst_all + 1) / 2) <= 768;
@@ -1008,14 +1015,14 @@ static inline hipError_t panel_gemm3(const float* A, int lda, int M, int K, cons
     if ((size_t)B.ntile * B.nst * PNF * 1024 > (size_t)(16u << 20) && M >= 32 && kpad <= 768) {
         // one workgroup per CU (the 98 KB image leaves room for one): as many column parts as it takes to reach 256 workgroups
         const int nrb = (M + 31) / 32, ncb = (B.ntile + 7) / 8, cpg = (ncb + 7) / 8;
-        static int cs_env = -1;                          // FDCAP_PN_WIDE_CS=1 (A/B): the r2-r4 form, one part
+        static std::atomic<int> cs_env{-1};                          // FDCAP_PN_WIDE_CS=1 (A/B): the r2-r4 form, one part
         if (cs_env < 0) { const char* e = getenv("FDCAP_PN_WIDE_CS"); cs_env = e ? atoi(e) : 0; }
         // (r5: two column tiles per wave, as in the K-loop product, measured no faster here: 0.186 vs 0.179 ms at 1024 rows, equal at 512)
-        const int cs = cs_env > 0 ? cs_env : std::max(1, std::min(cpg, (256 + 8 * nrb - 1) / (8 * nrb)));
+        const int cs = cs_env > 0 ? (int)cs_env : std::max(1, std::min(cpg, (256 + 8 * nrb - 1) / (8 * nrb)));
         hipLaunchKernelGGL(panel_gemm3_wide_kernel<2>, dim3(8 * nrb * cs), dim3(512), pnf_lds_bytes(kpad, 2), st, A, lda, M, K, B, C, ldc, N, cs);
         return hipGetLastError();
     }
-    static int rb2 = -1;                                  // FDCAP_PN_RB2=0 (A/B): one row block per fragment stream everywhere
+    static std::atomic<int> rb2{-1};                                  // FDCAP_PN_RB2=0 (A/B): one row block per fragment stream everywhere
     if (rb2 < 0) { const char* e = getenv("FDCAP_PN_RB2"); rb2 = e ? atoi(e) : 1; }
     if ((rb2 == 1 || rb2 == 2) && M >= 384 && kpad <= 768 && B.ntile >= 48) {   // (measured: 256 rows 50.2 vs 49.8 ms per step, 384 rows 56.7 vs 57.8)
         // (r5: six waves x two tiles over the same 32 x 192 block -- half the LDS bytes per MFMA, the lever that took the K-loop
@@ -1024,7 +1031,7 @@ static inline hipError_t panel_gemm3(const float* A, int lda, int M, int K, cons
         return hipGetLastError();
     }
     // waves per workgroup: eight while that gives >= 192 workgroups, else four, else two (FDCAP_PN_NW pins it: A/B)
-    static int nw_env = -1;
+    static std::atomic<int> nw_env{-1};
     if (nw_env < 0) { const char* e = getenv("FDCAP_PN_NW"); nw_env = e ? atoi(e) : 0; }
     const int nrb = (M + 15) / 16;
     int nw = 8;                                            // (measured at 128 rows: forward 7.8 -> 6.6 us with four waves; two waves stage too slowly)
@@ -1337,7 +1344,7 @@ __global__ __launch_bounds__(512) void panel_gemm3_ksw_kernel(const float* __res
 }
 // when the form pays: a long K in one LDS image, few row blocks (FDCAP_PN_KSW=0: never)
 static inline bool panel_gemm3_ksw_ok(int M, int K, const PanelB3& B) {
-    static int on = -1;
+    static std::atomic<int> on{-1};
     if (on < 0) { const char* e = getenv("FDCAP_PN_KSW"); on = (e && e[0] == '0') ? 0 : 1; }
     const int kpad = (K + 31) & ~31;
     return on && kpad <= PN3_MAX_K && kpad >= 768 && ((M + 15) / 16) * ((B.ntile + 7) / 8) < 128;
@@ -1345,15 +1352,15 @@ static inline bool panel_gemm3_ksw_ok(int M, int K, const PanelB3& B) {
 static inline hipError_t panel_gemm3_ksw(const float* A, int lda, int M, int K, const PanelB3& B, float* C, int ldc, int N, hipStream_t st) {
     if (M <= 0 || N <= 0) return hipSuccess;
     const int kpad = (K + 31) & ~31;
-    static bool attr = false;
-    if (!attr) {
+    static std::atomic<uint64_t> attr{0};                      // per DEVICE: the attribute belongs to one device's code object
+    if (fdc_attr_needed(attr)) {
         hipError_t e = hipFuncSetAttribute((const void*)panel_gemm3_ksw_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)pnf_lds_bytes(PN3_MAX_K, 1));
         if (e == hipSuccess) e = hipFuncSetAttribute((const void*)panel_gemm3_ksw_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)pnf_lds_bytes(PN3_MAX_K, 1));
         if (e != hipSuccess) return e;
-        attr = true;
+        fdc_attr_done(attr);
     }
     // column tiles per workgroup: two while that still gives >= 192 workgroups, else one (FDCAP_PN_KSW_T pins it: A/B)
-    static int t_env = -1;
+    static std::atomic<int> t_env{-1};
     if (t_env < 0) { const char* e = getenv("FDCAP_PN_KSW_T"); t_env = e ? atoi(e) : 0; }
     const int nrb = (M + 15) / 16;
     int T = nrb * ((B.ntile + 1) / 2) >= 192 ? 2 : 1;
@@ -1446,24 +1453,24 @@ __global__ void panel_part_sum_kernel(const float* __restrict__ part, int ks, si
 }
 constexpr int PN3_KLOOP_SLAB = 24;                               // steps (32 columns each) per slab: two 16-row images of 768 columns = 144 KB
 // parts of K for M rows and B's tiles: enough workgroups for 256 CUs, ks x column blocks a multiple of 8 (XCD <-> slice of B), <= 32
-inline int& panel_gemm3_kloop_slab() {                          // FDCAP_KLOOP_SLAB (A/B): steps per slab, 4..24
-    static int v = -1;
+inline std::atomic<int>& panel_gemm3_kloop_slab() {                          // FDCAP_KLOOP_SLAB (A/B): steps per slab, 4..24
+    static std::atomic<int> v{-1};
     if (v < 0) { const char* e = getenv("FDCAP_KLOOP_SLAB"); v = e ? std::min(24, std::max(4, atoi(e))) : PN3_KLOOP_SLAB; }
     return v;
 }
-inline int& panel_gemm3_kloop_rb() {                             // FDCAP_KLOOP_RB (A/B): 16-row blocks per fragment stream, 2 or 4
-    static int v = -1;
+inline std::atomic<int>& panel_gemm3_kloop_rb() {                             // FDCAP_KLOOP_RB (A/B): 16-row blocks per fragment stream, 2 or 4
+    static std::atomic<int> v{-1};
     if (v < 0) { const char* e = getenv("FDCAP_KLOOP_RB"); v = (e && atoi(e) == 4) ? 4 : 2; }
     return v;
 }
-inline int& panel_gemm3_kloop_t() {                              // FDCAP_KLOOP_T (A/B): column tiles per wave, 1 or 2
-    static int v = -1;
+inline std::atomic<int>& panel_gemm3_kloop_t() {                              // FDCAP_KLOOP_T (A/B): column tiles per wave, 1 or 2
+    static std::atomic<int> v{-1};
     if (v < 0) { const char* e = getenv("FDCAP_KLOOP_T"); v = (e && atoi(e) == 1) ? 1 : 2; }
     return v;
 }
 static inline int panel_gemm3_kloop_parts(int M, const PanelB3& B) {
     const int rb = panel_gemm3_kloop_rb(), T = panel_gemm3_kloop_t(), ncb = (B.ntile + 8 * T - 1) / (8 * T), nrp = (M + 16 * rb - 1) / (16 * rb);
-    static int wgs = -1;                                         // FDCAP_KLOOP_WGS (A/B): workgroups to aim for
+    static std::atomic<int> wgs{-1};                                         // FDCAP_KLOOP_WGS (A/B): workgroups to aim for
     if (wgs < 0) { const char* e = getenv("FDCAP_KLOOP_WGS"); wgs = e ? atoi(e) : 256; }
     int ks = std::max(1, (wgs + ncb * nrp - 1) / (ncb * nrp));
     while ((ks * ncb) % 8 != 0 && ks < 64) ++ks;
@@ -1476,17 +1483,17 @@ static inline hipError_t panel_gemm3_kloop(const float* A, int lda, int M, int K
     const int rb = panel_gemm3_kloop_rb(), T = panel_gemm3_kloop_t(), ks = panel_gemm3_kloop_parts(M, B), ncb = (B.ntile + 8 * T - 1) / (8 * T), nrp = (M + 16 * rb - 1) / (16 * rb);
     const size_t stride = (size_t)M * ldc;
     // steps per slab: RB images of 32 x slab columns, 6 bytes each, in <= 147 KB
-    const int slab = std::min(panel_gemm3_kloop_slab(), rb == 4 ? 12 : 24);   // (measured at 512 / 128 rows: RB 4 T 1 192 / 55 us, RB 2 T 2 139 / 44, RB 4 T 2 166 / 57 with 55 spilled registers)
+    const int slab = std::min((int)panel_gemm3_kloop_slab(), rb == 4 ? 12 : 24);   // (measured at 512 / 128 rows: RB 4 T 1 192 / 55 us, RB 2 T 2 139 / 44, RB 4 T 2 166 / 57 with 55 spilled registers)
     const size_t lds = pnf_lds_bytes(32 * slab, rb);
-    static bool attr = false;
-    if (!attr) {
+    static std::atomic<uint64_t> attr{0};                      // per DEVICE: the attribute belongs to one device's code object
+    if (fdc_attr_needed(attr)) {
         hipError_t e = hipSuccess;
         const void* fs[] = {(const void*)panel_gemm3_kloop_kernel<2, 1>, (const void*)panel_gemm3_kloop_kernel<4, 1>,
                             (const void*)panel_gemm3_kloop_kernel<2, 2>, (const void*)panel_gemm3_kloop_kernel<4, 2>};
         for (const void* f : fs)
             if (e == hipSuccess) e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
         if (e != hipSuccess) return e;
-        attr = true;
+        fdc_attr_done(attr);
     }
     const dim3 grid(ks * ncb * nrp);
 #define FDC_KLOOP(RBV, TV) hipLaunchKernelGGL((panel_gemm3_kloop_kernel<RBV, TV>), grid, dim3(512), lds, st, A, lda, M, K, B, part, stride, ldc, N, ks, slab)

@@ -54,7 +54,7 @@ template <bool CONTACT>
 static int skin_bwd_any(DevBuf<float>& part, hipStream_t st, int nrows, SkinModel sm, int nc, const float* X, const float* Voff, const float* A,
                         const float* M, const float* scale, int row0, const float* dVw, float* dVoff, float* dA, float* dbeta_v,
                         float* dtransl_v, float* dMv, float* dsv, ContactGradIn cg) {
-    static int split_on = -1;                              // FDCAP_SKIN_SPLIT=0: the one-workgroup-per-frame form at every size (A/B)
+    static std::atomic<int> split_on{-1};                              // FDCAP_SKIN_SPLIT=0: the one-workgroup-per-frame form at every size (A/B)
     if (split_on < 0) { const char* e = getenv("FDCAP_SKIN_SPLIT"); split_on = (e && e[0] == '0') ? 0 : 1; }
     const size_t lds = (size_t)std::min(nc, SKB_VCH) * 12 * sizeof(float) + (sm.wf_tab ? (size_t)4 * 64 * 16 * sizeof(float) : 0);   // dT rows (+ the matrix form's partial tiles)
     if (nc <= SKB_VCH || !split_on) {
@@ -140,6 +140,14 @@ struct OptState {
     DevBuf<float4> nnc_anchor;
     NNOrder nn_order;                      // launch order of the in-loop NN launch (fdc_chamfer.h NNOrder; its tables sit behind nnc_hdr); FDCAP_NN_ORDER=0 turns it off, =k re-sorts every k launches
     float nnc_slack = 0.03f;  // metres; FDCAP_NN_CACHE_SLACK overrides, 0 disables the cache
+    // fdcap_opt_launch_timing (r6): a HIP event on the launch stream at every boundary between two launches of an iteration; the time
+    // from one event to the next is booked on the launch in between (its ~1 us dependent-launch gap included), per phase of the fit
+    struct LaunchTimes {
+        bool on = false;
+        int used = 0, phase = 0;
+        std::vector<hipEvent_t> ev;
+        std::vector<signed char> what;         // what[k]: the stage that ended at event k (FDCAP_LT_*; -1: an iteration's first event), + 16 in phase 2
+    } lt;
     // fdcap_opt_nn_timing: HIP events around every in-loop NN launch of a fit (the bench's roofline figure)
     bool nn_timing = false;
     std::vector<hipEvent_t> nn_ev;
@@ -162,6 +170,14 @@ struct OptState {
     bool use_seed = true;     // last iteration's neighbours seed the NN bound (pruning only)
     bool use_cull = true;     // skip k-d cells whose box is out of every query's reach
 };
+
+// (fdcap_opt_launch_timing) the stage `what` ended here; -1: an iteration begins
+inline void lt_mark(OptState* o, int what, hipStream_t st) {
+    OptState::LaunchTimes& t = o->lt;
+    if (!t.on || t.used >= (int)t.ev.size()) return;
+    if (hipEventRecord(t.ev[t.used], st) != hipSuccess) return;
+    t.what[t.used++] = (signed char)(what < 0 ? -1 : what + 16 * t.phase);
+}
 
 }  // namespace
 
@@ -502,7 +518,7 @@ int build_skin_set(fdcap_ctx* c, const std::vector<int64_t>& ids, SkinSet* out) 
 
 // dense products on the split formats of fdc_panel.h (FDCAP_GEMM_SPLIT3=0: exact-fp32 MFMA chains instead)
 inline bool gemm_split3_enabled() {
-    static int v = -1;
+    static std::atomic<int> v{-1};
     if (v < 0) { const char* e = getenv("FDCAP_GEMM_SPLIT3"); v = (e && e[0] == '0') ? 0 : 1; }
     return v == 1;
 }
@@ -625,8 +641,10 @@ int opt_pose_forward(fdcap_ctx* c, int lo, int hi, hipStream_t st, bool contact_
             if (e) return e;
         }
     }
+    lt_mark(o, -1, st);
     int e = vposer_forward(c, o->X.p, XDIM, X_LATENT, lo, hi, o->H1.p, o->H2.p, o->Opart.p, ps, nullptr, st, 0, 0, ds);
     if (e) return e;
+    lt_mark(o, FDCAP_LT_VPOSER_FWD, st);
     hipLaunchKernelGGL(pose_fwd_kernel<true>, dim3(hi - lo), dim3(64 * POSE_NW), 0, st, c->pose_model(), o->X.p, o->O.p, o->CAM.p, o->scale.p, lo,
 #ifdef FDC_DEBUG_BUFFERS
                        o->Rm.p,                                // (the per-joint rotations: nobody reads them back but fdcap_debug_rows)
@@ -635,6 +653,7 @@ int opt_pose_forward(fdcap_ctx* c, int lo, int hi, hipStream_t st, bool contact_
 #endif
                        contact_state ? o->PF.p : (float*)nullptr, o->Jrest.p, o->G.p, contact_state ? o->A.p : (float*)nullptr, o->M.p, o->Jw.p,
                        (const float*)nullptr, (const float*)o->Opart.p, ps, 0, 0, ds);
+    lt_mark(o, FDCAP_LT_POSE_FWD, st);
     if (ds.on) {                                            // the step has been issued: the launches that follow see its results
         o->pend.on = false;
         o->dz_pending = false;
@@ -675,6 +694,7 @@ int opt_vposer_backward(fdcap_ctx* c, bool fold, hipStream_t st, ScaleTail tail 
     else
         hipLaunchKernelGGL(vposer_bwd_fused_kernel, dim3(nb + (tail.block >= 0 ? 1 : 0)), dim3(512), 0, st, c->vp, o->dO.p, 2, 2 + nl, o->H1.p, o->H2.p,
                            o->dZpart.p, ps, tail);
+    lt_mark(o, FDCAP_LT_VPOSER_BWD, st);
     if (fold) {
         hipLaunchKernelGGL(vposer_fold_dz_kernel, dim3((nl * VP_Z + 255) / 256), dim3(256), 0, st, o->dZpart.p, ps, 2, nl, o->dX.p);
         o->dz_pending = false;

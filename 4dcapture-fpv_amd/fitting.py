@@ -309,7 +309,9 @@ class FittingOP:
             iterations and keeps c_dct with its Adam moments (with log_every: k must be a multiple of it);
           resume=path: continue such a run from where the file left off -- bit-identical to the uninterrupted run;
           check_finite_every=k: every k iterations count the non-finite parameters on the device and raise if any
-            (the opt-in counterpart of the reference's set_detect_anomaly(True), :561);
+            (the opt-in counterpart of the reference's set_detect_anomaly(True), :561); all three modes -- mode 'dct' checks the
+            DCT coefficients and their Adam moments through its first phase (every lcm(k, log_every) iterations there), the body
+            parameters from then on;
           snapshot_at=(k, ...) (mode 'global'): after the k-th optimiser step keep device copies of (body_rotation_rec [N_local,78],
             scale, camera_ext [N_local,16]) in self.snapshots[k] -- no host sync; for trajectory comparisons (tests/test_gpu_parity500.py).
         Sharded runs: every argument of this call and `num_iter` must be the same on all ranks (they decide which collectives
@@ -525,16 +527,22 @@ class FittingOP:
         """the iteration budget a checkpoint belongs to (mode 'dct' runs its own, :596)"""
         return int(self.dct_num_iter if getattr(self, "_mode", "global") == "dct" else self.num_iter)
 
-    def _save_checkpoint(self, path, next_iter, **extra):
+    def _save_checkpoint(self, path, next_iter, extra_fn=None, **extra):
+        """`extra_fn`: callable returning more arrays for the file (mode 'dct': c_dct and its moments, read from the device).
+        EVERYTHING that can fail on one rank alone -- the allocation, the library's state export, the extras' read-back, the
+        write -- runs inside the try whose outcome the ranks then agree on (a HIP error or an out-of-memory in the
+        export used to raise before the agreement and leave the peers waiting in it)."""
         import os
         import torch
         lib, h, nl = self.ctx.lib, self.ctx.handle, self.shard.n_local
-        state = torch.empty(int(lib.fdcap_opt_state_len(h)), device=self.device)
-        capi.check(lib.fdcap_opt_export_state(h, capi.dptr(state), capi.current_stream()), "fdcap_opt_export_state")   # (applies a deferred step first)
         fn = self._ckpt_file(path)
         tmp = fn + ".tmp.npz"
         err = None
         try:
+            state = torch.empty(int(lib.fdcap_opt_state_len(h)), device=self.device)
+            capi.check(lib.fdcap_opt_export_state(h, capi.dptr(state), capi.current_stream()), "fdcap_opt_export_state")   # (applies a deferred step first)
+            if extra_fn is not None:
+                extra = dict(extra, **extra_fn())
             np.savez(tmp, next_iter=np.int64(next_iter), num_iter=np.int64(self._budget()), n_total=np.int64(self.num_body),
                      frame0=np.int64(self.shard.frame0), n_local=np.int64(nl), rows_x=self._rows_x[2:2 + nl].cpu().numpy(),
                      rows_cam=self._rows_cam[2:2 + nl].cpu().numpy(), scale=self._scale.cpu().numpy(), state=state.cpu().numpy(),
@@ -648,23 +656,45 @@ class FittingOP:
         ntraj = 69 * (w1.value - w0.value)
 
         def save(next_iter):                                   # parameters + Adam moments + c_dct with ITS moments
-            cd_ = torch.empty(W, 69 * C, device=dev)
-            dm_, dv_ = torch.empty_like(cd_), torch.empty_like(cd_)
-            capi.check(lib.fdcap_opt_get_dct(h, capi.dptr(cd_), capi.current_stream()), "fdcap_opt_get_dct")
-            capi.check(lib.fdcap_opt_get_dct_state(h, capi.dptr(dm_), capi.dptr(dv_), capi.current_stream()), "fdcap_opt_get_dct_state")
-            self._save_checkpoint(ck_path, next_iter, c_dct=cd_, dct_m=dm_, dct_v=dv_)
+            def dct_state():                                   # (runs inside _save_checkpoint's agreed-on try)
+                cd_ = torch.empty(W, 69 * C, device=dev)
+                dm_, dv_ = torch.empty_like(cd_), torch.empty_like(cd_)
+                capi.check(lib.fdcap_opt_get_dct(h, capi.dptr(cd_), capi.current_stream()), "fdcap_opt_get_dct")
+                capi.check(lib.fdcap_opt_get_dct_state(h, capi.dptr(dm_), capi.dptr(dv_), capi.current_stream()), "fdcap_opt_get_dct_state")
+                return {"c_dct": cd_, "dct_m": dm_, "dct_v": dv_}
+            self._save_checkpoint(ck_path, next_iter, extra_fn=dct_state)
 
         # first phase [ii0, P): ONE launch -- or one per stretch between two checkpoint iterations (the launch keeps coefficients
         # and moments in registers and writes them back at its end; Adam's step counter runs on through step0: same bits)
         hist = None
         if log_every and ntraj and P > ii0:
             hist = torch.zeros((P - ii0 + log_every - 1) // log_every, ntraj, device=dev)
+        def check_dct_finite(done):                            # phase 1 moves only c_dct: count ITS non-finite entries (and its moments')
+            cd_ = torch.empty(W, 69 * C, device=dev)
+            dm_, dv_ = torch.empty_like(cd_), torch.empty_like(cd_)
+            capi.check(lib.fdcap_opt_get_dct(h, capi.dptr(cd_), capi.current_stream()), "fdcap_opt_get_dct")
+            capi.check(lib.fdcap_opt_get_dct_state(h, capi.dptr(dm_), capi.dptr(dv_), capi.current_stream()), "fdcap_opt_get_dct_state")
+            own = slice(w0.value, w1.value)                    # (sharded: the windows this rank fits)
+            bad = sum((~torch.isfinite(t[own])).sum() for t in (cd_, dm_, dv_)).to(torch.float32).reshape(1)
+            if multi:
+                allreduce_scalars(sh, bad)
+            if int(bad.cpu()):
+                raise capi.FdcapError(f"{int(bad.cpu())} non-finite DCT coefficients / Adam moments after iteration {done - 1}")
+
+        # (a stretch's logged rows are counted from its first iteration: a cut must fall on a logging iteration -- checkpoints
+        #  already require it; the finite check of this phase therefore runs every lcm(check_finite_every, log_every) iterations)
+        finite_cut = (finite_every * log_every // math.gcd(finite_every, log_every)) if (finite_every and log_every) else finite_every
         ii = ii0
         while ii < P:
-            end = min(P, (ii // ck_every + 1) * ck_every) if ck_every else P
+            end = P                                            # cut at the next checkpoint / finite-check iteration, if any
+            for every in (ck_every, finite_cut):
+                if every:
+                    end = min(end, (ii // every + 1) * every)
             row = capi.dptr(hist[(ii - ii0) // log_every]) if hist is not None else None
             capi.check(lib.fdcap_opt_dct_fit(h, end - ii, ii, DCT_PHASE1_WEIGHT, row, max(int(log_every), 1), st), "fdcap_opt_dct_fit")
             ii = end
+            if finite_cut and (ii % finite_cut == 0 or ii == P):
+                check_dct_finite(ii)
             if ck_every and ii % ck_every == 0 and ii < num_iter:
                 save(ii)                                       # (sharded: every rank's own windows; merged after the phase, below)
         self.log_dct = []

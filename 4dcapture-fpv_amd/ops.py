@@ -26,18 +26,24 @@ def _ctx_of(obj):
     return obj.ctx
 
 
-def _is_registered_scene(fctx, x2, memo):
-    """Does the [m,3] device tensor x2 hold exactly the points registered with fctx.set_scene?  Compared ON THE DEVICE once per
-    (storage, version) of the tensor -- the caller's loop passes the same tensor every iteration (:176, :293) -- and remembered in
-    `memo`; any in-place write to the tensor bumps its version and is looked at again."""
+def _is_registered_scene(fctx, x2, memo, memoise=True):
+    """Does the [m,3] device tensor x2 hold exactly the points registered with fctx.set_scene?  Compared ON THE DEVICE and
+    remembered in `memo` -- the caller's loop passes the same tensor every iteration (:176, :293).  The remembered verdict is
+    tied to everything it depends on: the context's scene GENERATION (Context.set_scene bumps it: a re-registered scene of the
+    same size is looked at again), the tensor's storage address + offset + version (any in-place write bumps the version), and
+    the memo holds a strong reference to the compared tensor, so its storage cannot be freed and handed to another point set at
+    the same address while the verdict is alive.  `memoise=False` (a temporary the caller made, e.g. by .contiguous()): compared
+    on every call, never remembered."""
     host = getattr(fctx, "_scene_host", None)
     if host is None or tuple(x2.shape) != tuple(host.shape):
         return False
-    key = (x2.data_ptr(), x2._version, x2.device)
+    if getattr(fctx, "_scene_dev", None) is None or fctx._scene_dev.device != x2.device:
+        fctx._scene_dev = torch.from_numpy(host).to(x2.device)
+    if not memoise:
+        return bool(torch.equal(x2, fctx._scene_dev))
+    key = (getattr(fctx, "_scene_gen", 0), x2.untyped_storage().data_ptr(), x2.storage_offset(), x2._version, x2.device)
     if memo.get("key") != key:
-        if getattr(fctx, "_scene_dev", None) is None or fctx._scene_dev.device != x2.device:
-            fctx._scene_dev = torch.from_numpy(host).to(x2.device)
-        memo["key"], memo["same"] = key, bool(torch.equal(x2, fctx._scene_dev))
+        memo["key"], memo["same"], memo["tensor"] = key, bool(torch.equal(x2, fctx._scene_dev)), x2
     return memo["same"]
 
 
@@ -48,7 +54,8 @@ class _ChamferFn(torch.autograd.Function):
         m = xyz2.shape[1]
         shared = xyz2.stride(0) == 0 or xyz2.shape[0] == 1
         x1 = xyz1.contiguous()
-        x2 = (xyz2[0] if shared else xyz2).contiguous()
+        x2v = xyz2[0] if shared else xyz2
+        x2 = x2v.contiguous()                                # (a view of the caller's storage when x2v is contiguous, else a temporary)
         stride2 = 0 if shared else m * 3
         dev = x1.device
         d1 = torch.empty(B, n, device=dev)
@@ -56,7 +63,7 @@ class _ChamferFn(torch.autograd.Function):
         d2 = torch.zeros(B, m, device=dev) if both else None
         i2 = torch.zeros(B, m, device=dev, dtype=torch.int32) if both else None
         # the shared target IS the registered scene: body -> scene through the optimiser loop's culled, seeded search (same bits)
-        scene = memo is not None and shared and _is_registered_scene(fctx, x2, memo)
+        scene = memo is not None and shared and _is_registered_scene(fctx, x2, memo, memoise=x2v.is_contiguous())
         if scene:
             capi.check(fctx.lib.fdcap_chamfer_fwd_scene(fctx.handle, capi.dptr(x1), B, n, capi.dptr(d1), capi.dptr(i1), 0,
                                                         capi.current_stream()), "fdcap_chamfer_fwd_scene")

@@ -461,6 +461,42 @@ def time_nn_launches(fop, one_step, iters):
     return ms_inloop.value, n_inloop.value, ms_loop.value
 
 
+LT_STAGES = ("vposer_fwd", "pose_fwd", "contact_fwd", "nn_in_loop_all", "skin_bwd", "blend_bwd", "pose_bwd", "vposer_bwd")   # include/fdcap.h FDCAP_LT_*
+
+
+def time_all_launches(fop, one_step, iters, steady_fit_s=None):
+    """One more (untimed) fit with a HIP event at every boundary between two launches of an iteration (fdcap_opt_launch_timing):
+    mean microseconds per launch and phase, measured on THIS box in THIS run (the table's microseconds used to be
+    copies from the committed trace)."""
+    import ctypes
+    from fdcap_amd import capi
+    lib, h = fop.ctx.lib, fop.ctx.handle
+    n = len(LT_STAGES)
+    capi.check(lib.fdcap_opt_launch_timing(h, 10 * iters + 16), "fdcap_opt_launch_timing")
+    one_step()
+    us = (ctypes.c_float * (2 * n))()
+    cnt = (ctypes.c_int32 * (2 * n))()
+    capi.check(lib.fdcap_opt_launch_timing_read(h, us, cnt), "fdcap_opt_launch_timing_read")
+    capi.check(lib.fdcap_opt_launch_timing(h, 0), "fdcap_opt_launch_timing")
+    out = {}
+    for ph in (0, 1):
+        d = {LT_STAGES[i]: {"us": float(us[ph * n + i]), "launches": int(cnt[ph * n + i])} for i in range(n) if cnt[ph * n + i]}
+        out["phase1" if ph == 0 else "phase2"] = d
+    if steady_fit_s:
+        # the events are not free: kernels run back to back (the host is ahead), so the sum of all event-to-event intervals of the
+        # fit minus a plain fit's wall time, per interval, is what one event adds to the interval it closes
+        tot = sum(v["us"] * v["launches"] for d in out.values() for v in d.values())
+        nint = sum(v["launches"] for d in out.values() for v in d.values())
+        ov = max(0.0, (tot - steady_fit_s * 1e6) / max(nint, 1))
+        out["event_overhead_us_per_launch"] = ov
+        out["event_overhead_note"] = ("(sum of all event-to-event intervals of the instrumented fit - wall time of a plain fit) / intervals: what "
+                                      "recording an event adds to the interval it closes; us_live_corrected = us - this")
+        for d in (out["phase1"], out["phase2"]):
+            for v in d.values():
+                v["us_corrected"] = v["us"] - ov
+    return out
+
+
 def nn_roofline(pk, src, sec_loop, ms_steady, n_timed, alg_bytes):
     """The in-loop launch is an exact PRUNED search (seeds, k-d cells, kept work lists; bit-identical to the full scan): it touches
     ~1 % of the pairs the algorithmic byte count pays for, so bytes-over-time says nothing about a hardware limit.  What bounds it
@@ -506,7 +542,7 @@ def nn_roofline(pk, src, sec_loop, ms_steady, n_timed, alg_bytes):
     return roofline, nn
 
 
-def per_kernel_table(pk, F, nc, K, src):
+def per_kernel_table(pk, F, nc, K, src, live=None):
     """Every launch of a phase-1 iteration next to the peak that binds it.  Microseconds: kernel-trace averages of the committed
     profile (the same command's rocprofv3 --kernel-trace --stats).  Dense products: EXECUTED 16-bit MFMA flops (SQ_INSTS_MFMA of
     the PMC mix pass x 16 384 flop per v_mfma_f32_16x16x32_f16 wave instruction; the fp32-equivalent useful flops beside them)
@@ -529,14 +565,25 @@ def per_kernel_table(pk, F, nc, K, src):
         ("pose_bwd", "chain / rotation / joint-regression backward + parameter-space losses (A14)", "hbm", 4.0 * F * 3224),
         ("vposer_bwd", "VPoser data gradient 126-512-512-32", "mfma", fl((126, 512), (512, 512), (512, 32))),
     ]
-    out, total = [], 0.0
+    out, total, total_live = [], 0.0, 0.0
+    lv1 = (live or {}).get("phase1", {})
+    # the contact forward is one launch at clip size (blend_skin_fwd) and two below: the live event pair spans both either way
+    live_key = {"blend_skin_fwd": "contact_fwd", "blend_fwd": "contact_fwd", "skin_fwd": None}
     for key, what, bound, work in rows:
         k = pk.get(key)
         if not k or not k.get("duration_us_trace"):
             continue
-        us = k["duration_us_trace"]
-        total += us
-        e = {"kernel": k.get("name"), "computes": what, "us": us, "bound": bound, "traffic": k.get("hbm_bytes")}
+        us_trace = k["duration_us_trace"]
+        total += us_trace
+        lk = live_key.get(key, key)
+        us_live = lv1.get(lk, {}).get("us_corrected", lv1.get(lk, {}).get("us")) if lk else None
+        if us_live:
+            total_live += us_live
+        us = us_live or us_trace                                  # fractions below: on the LIVE time when this run measured one
+        e = {"kernel": k.get("name"), "computes": what, "us": us, "us_live": us_live, "us_trace": us_trace, "bound": bound,
+             "traffic": k.get("hbm_bytes")}
+        if key == "blend_fwd" and us_live:
+            e["us_live_note"] = "live figure spans this launch AND skin_fwd (one event pair around the contact forward)"
         c = counter_fracs(k) or {}
         if c.get("mfma_busy_frac") is not None:
             e["mfma_busy_frac"] = c["mfma_busy_frac"]
@@ -555,7 +602,13 @@ def per_kernel_table(pk, F, nc, K, src):
         else:
             e.update({"frac": None, "note": "priced on VALU issue in the top-level roofline block (live launch time)"})
         out.append(e)
-    return {"source": src, "phase1_iteration_us": total, "kernels": out,
+    return {"source": src, "phase1_iteration_us": total_live or total, "phase1_iteration_us_trace": total,
+            "phase1_iteration_us_live": total_live or None, "phase2_live": (live or {}).get("phase2"),
+            "event_overhead_us_per_launch": (live or {}).get("event_overhead_us_per_launch"), "kernels": out,
+            "timing": "us_live: HIP events on the launch stream between consecutive launches of every iteration of one whole (extra, untimed) fit of "
+                      "THIS run, mean over the fit's phase-1 iterations, ~1 us of dependent-launch gap included, the events' own cost (event_overhead_us_per_launch, "
+                      "estimated from the instrumented fit's total against a plain fit) subtracted; us_trace: rocprofv3 kernel-trace "
+                      "average of the committed profile (another box, another day); counters (flops, traffic) always from the committed PMC passes",
             "note": "floor_us = the kernel's work at the binding peak; every launch also pays ~1.2 us fixed + ~0.2 us per MB it leaves dirty in "
                     "L2 (profiles/r4_launch_overhead_probe.txt).  Phase 2 of a fit issues four of them (VPoser and pose, both ways)"}
 
@@ -594,9 +647,12 @@ def other_config(name, args):
            "mfma_busy_frac": rl.get("mfma_busy_frac"), "mean_waves_per_simd": rl.get("mean_waves_per_simd"),
            "traffic": rl.get("traffic"), "contract_frac_on_algorithmic_bytes": rl["contract"]["frac_on_algorithmic_bytes"],
            "counters_from": rl.get("counters_from"), "setup": setup_block(fop, first, dt, f)}
-    pkt = per_kernel_table(pk, f, nc, 4, src) if name == "c2" else None
+    live = time_all_launches(fop, one_step, args.iters, dt)
+    out["launches_live_us"] = live
+    pkt = per_kernel_table(pk, f, nc, 4, src, live) if name == "c2" else None
     if pkt:
-        out["phase1_iteration_us_by_trace"] = pkt["phase1_iteration_us"]
+        out["phase1_iteration_us_by_trace"] = pkt["phase1_iteration_us_trace"]
+        out["phase1_iteration_us_live"] = pkt["phase1_iteration_us_live"]
     fop.close()
     del fop
     torch.cuda.empty_cache()
@@ -709,8 +765,17 @@ def main():
         "traffic": None if not bf else bf.get("hbm_bytes_per_launch"),
         "hbm": {"achieved": alg_bytes / sec_bf / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": alg_bytes / sec_bf / 1e9 / HBM_PEAK_GBS,
                 "on": "algorithmic bytes"}}
-    roofline["per_kernel"] = per_kernel_table(pk, nl, nc, args.lbs_nnz, pmc_src)
+    live = time_all_launches(fop, one_step, args.iters, dt / max(args.steps, 1))
+    roofline["per_kernel"] = per_kernel_table(pk, nl, nc, args.lbs_nnz, pmc_src, live)
+    if roofline["per_kernel"] is None:                      # no committed counters for these sizes: the live times alone
+        roofline["per_kernel"] = {"source": None, "launches_live_us": live}
+    # the two other readings of the dominant kernel, up where the fraction is: what the counters say it moves
+    # against HBM, and SURVEY 8d's contract figure (algorithmic bytes of the every-frame scene copy / launch time: > 1 = pruning)
+    roofline["contract_frac"] = roofline["contract"]["frac_on_algorithmic_bytes"]
+    roofline.setdefault("hbm_frac_on_counter_bytes", None)
     out["roofline"] = roofline
+    out["dtype_note"] = ("values and accumulation fp32; dense products: 2 x fp16 planes of power-of-two-scaled fp32 operands, three MFMA products per "
+                         "term, error <= 1e-6 * sum|a||b| vs fp64 (tests/test_gpu_panel.py); strict fp32 products = exact_fp32 below")
 
     # north-star item: the full-mesh pose + shape blendshape GEMM (body-model operator / output meshes; the loop itself only
     # needs the contact-vertex columns, whose two products are listed under roofline.per_kernel)

@@ -461,6 +461,25 @@ int fdcap_panel_gemm(const float* A_d, int32_t lda, int32_t M, int32_t K, const 
 int fdcap_opt_nn_timing(fdcap_ctx* ctx, int32_t max_launches);
 int fdcap_opt_nn_timing_read(fdcap_ctx* ctx, float* mean_ms, int32_t* launches);
 
+/* In-loop timing of EVERY launch of an iteration (r6; bench.py's roofline.per_kernel[].us_live): while enabled (max_events > 0) the
+ * optimiser records a HIP event on its launch stream at every boundary between two launches of an iteration (up to max_events
+ * events in all; 0 disables and resets) -- one fit of 500 iterations records ~4100.  fdcap_opt_launch_timing_read waits for them and
+ * returns, per stage and per phase of the fit, the mean microseconds from the event before the stage's launch(es) to the event
+ * after them (so ~1 us of dependent-launch gap is inside every figure) and the number of samples:
+ *   mean_us[FDCAP_LT_NUM * phase + stage], counts[...]   phase 0: iterations whose loss has the contact term (ii < P), 1: the others.
+ * The events themselves cost a few microseconds per iteration: a fit timed this way is for the per-kernel table, never `value`. */
+#define FDCAP_LT_VPOSER_FWD 0    /* VPoser decode (+ the deferred Adam step of the rows) */
+#define FDCAP_LT_POSE_FWD 1      /* rotations, joint regression, kinematic chain, world joints */
+#define FDCAP_LT_CONTACT_FWD 2   /* contact set: blend product + skinning + world transform (one launch at clip size, else two) */
+#define FDCAP_LT_CHAMFER_NN 3    /* Chamfer nearest-neighbour search (+ its seeding launch in a fit's first iteration) */
+#define FDCAP_LT_SKIN_BWD 4      /* contact robustifier + skinning backward */
+#define FDCAP_LT_BLEND_BWD 5     /* data gradient of the blend product */
+#define FDCAP_LT_POSE_BWD 6      /* chain / rotation backward + parameter-space losses */
+#define FDCAP_LT_VPOSER_BWD 7    /* VPoser data gradient (+ the `scale` step) */
+#define FDCAP_LT_NUM 8
+int fdcap_opt_launch_timing(fdcap_ctx* ctx, int32_t max_events);
+int fdcap_opt_launch_timing_read(fdcap_ctx* ctx, float* mean_us /* [2 * FDCAP_LT_NUM] */, int32_t* counts /* [2 * FDCAP_LT_NUM] */);
+
 /* Kernel-level timing of the Chamfer NN launch for the roofline line: runs `iters` launches of
  * the optimiser's Chamfer forward on `stream` between two HIP events and returns the mean
  * milliseconds per launch in *ms.  brute_force = 1: every (query, scene point) pair is visited

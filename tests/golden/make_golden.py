@@ -19,6 +19,9 @@ Recipe:
 Usage:  python tests/golden/make_golden.py            (writes tests/golden/*.npz)
         python tests/golden/make_golden.py --chamfer  (ref_chamfer_python.npz: /root/reference/chamfer_python.py)
         python tests/golden/make_golden.py --smoother | --dct | --g500 | --g500b (ref_global_500it[_b].npz: the fixed budget, :672)
+        python tests/golden/make_golden.py --g5full | --g5allverts   (r6: the reference's loop at BASELINE BODY SIZE, V = 10 475: five
+                                                                      iterations across the phase switch with 500 contact vertices vs a
+                                                                      100 k-point scene / with ALL vertices as contacts vs 20 k points)
         python tests/golden/make_golden.py --yardstick500 f64 | f32t1   (oracle_global_500it_*.npz: the ORACLE on the same inputs in
                                                                          fp64 / in fp32 on one thread -- yardsticks, not goldens)
 """
@@ -112,13 +115,15 @@ LOG2_RE = re.compile(r"iter=(\d+), l_rec=([-\d.e]+), loss_local_smoothing=([-\d.
 
 
 def run_global(g, num_iter, num_verts, ns, model_seed, vposer_seed, clip_seed, scene_seed,
-               contact_seed, per_part, tmp, mode="global", snapshot_at=(), state_at=()):
+               contact_seed, per_part, tmp, mode="global", snapshot_at=(), state_at=(), all_contacts=False):
     n = 300  # the reference hard-codes 300 (:465, :472, :41-42)
     bm = synth.make_body_model(num_verts, seed=model_seed)
     vp = synth.make_vposer(seed=vposer_seed)
     clip = synth.make_clip(n, seed=clip_seed, num_outliers=3)
     scene = synth.make_scene(ns, seed=scene_seed)
     left, right = synth.make_contact_ids(bm.v_template, per_part=per_part, seed=contact_seed)
+    if all_contacts:                      # BASELINE config 5's contact set: every mesh vertex (the two "parts" = the two halves of the id range)
+        left, right = np.arange(0, num_verts // 2), np.arange(num_verts // 2, num_verts)
 
     seg = os.path.join(tmp, "body_segments")
     os.makedirs(seg, exist_ok=True)
@@ -412,6 +417,25 @@ def main():
                              snapshot_at=SNAP500, state_at=STATE500)
             np.savez_compressed(os.path.join(HERE, "ref_global_500it_b.npz"), **res)
             print("wrote ref_global_500it_b", "idx1", res["idx1"], "scale", res["scale"], "last log", res["log"][-1])
+        return
+    if "--g5full" in sys.argv or "--g5allverts" in sys.argv:
+        # r6 (missing 2): the reference's own loop at the body size the bench times -- V = 10 475, 300 frames, five
+        # iterations across the phase switch (num_iter = 5: ii = 0..3 phase 1, ii = 4 phase 2) -- so that "reference loop -> oracle ->
+        # HIP" closes on the kernel forms BASELINE configs 2 / 3 / 5 select: 500 contact vertices (Nc = 500 panels, the fused contact
+        # forward, skin_bwd_vec) against a 100 k-point scene; and every vertex a contact (chunked skin_bwd_kernel, K = 31 425
+        # products) against 20 k points.  Minutes of CPU each (the Chamfer stub visits every pair, both directions, as the ext does).
+        torch.set_num_threads(8)
+        allv = "--g5allverts" in sys.argv
+        name = "ref_global_5it_allverts" if allv else "ref_global_5it_full"
+        with tempfile.TemporaryDirectory() as tmp:
+            res = run_global(g, tmp=tmp, num_iter=5, num_verts=10475, ns=20000 if allv else 100000, model_seed=0, vposer_seed=1,
+                             clip_seed=73 if allv else 71, scene_seed=74 if allv else 72, contact_seed=4, per_part=250,
+                             snapshot_at=(1, 2, 3, 4, 5), all_contacts=allv)
+            if allv:
+                del res["scene"]          # regenerated from scene_seed by the test (synth.make_scene is deterministic; checked by sha)
+            res["sha_scene"] = sha(synth.make_scene(res["ns"], seed=res["scene_seed"]))
+            np.savez_compressed(os.path.join(HERE, name + ".npz"), **res)
+            print("wrote", name, "idx1", res["idx1"], "scale", res["scale"], "last log", res["log"][-1])
         return
     if "--dct" in sys.argv:            # ~20 min of CPU: the reference's own 10000-iteration 'dct' run
         torch.set_num_threads(2)

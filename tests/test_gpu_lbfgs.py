@@ -258,11 +258,9 @@ def _px_err(orc, rows, kp):
     return float(np.sqrt(((uv - kp[..., :2]) ** 2).sum(-1))[w].mean())
 
 
-def test_inner_fit_with_lbfgs_ends_where_torchs_lbfgs_ends_on_the_oracles_objective():
-    """fdcap_opt_fit2d_lbfgs (every frame its own L-BFGS problem) against oracle/innerfit.py fitting_lbfgs = torch.optim.LBFGS
-    per frame on the oracle's autograd objective, SMPLify-X's settings (30 x 30, ftol 2e-9), in the first stage: its strong priors
-    make the minimum unique enough that two arithmetics reach the same one (the oracle in fp32 and in fp64: objective within
-    1.5e-4, parameters within 4.5e-3 of each other)."""
+def _stage1_lbfgs_case():
+    """stage-1 inner fit of 8 frames with the library's L-BFGS and with torch.optim.LBFGS on the oracle's objective (float32 and
+    float64) -> (library rows, oracle rows fp32, oracle rows fp64, library's per-frame objective, InnerFitOP, fp64 oracle, kp, stage)"""
     from fdcap_amd.innerfit import DEFAULT_STAGES, InnerFitOP
     from oracle.innerfit import InnerFitOracle
     from oracle.smplx import SMPLXOracle
@@ -275,20 +273,87 @@ def test_inner_fit_with_lbfgs_ends_where_torchs_lbfgs_ends_on_the_oracles_object
     out = op.fitting(init, kp, log_every=1).cpu().numpy()
     orc = InnerFitOracle(SMPLXOracle(bm), VPoserDecoder.from_data(vp))
     ref = orc.fitting_lbfgs(init, kp, stages).numpy()
-    err = np.abs(out - ref)
+    o64 = InnerFitOracle(SMPLXOracle(bm, dtype=torch.float64), VPoserDecoder.from_data(vp, dtype=torch.float64), dtype=torch.float64)
+    ref64 = o64.fitting_lbfgs(init, kp, stages).numpy()
+    return out, ref, ref64, op, orc, o64, kp, stages[0]
+
+
+def _objective64(o64, rows75, kp, stage):
+    """per-frame objective and largest gradient entry of the float64 oracle at the given [N,75] rows (format-independent yardstick)"""
+    from oracle import rotrepr
+    x = rotrepr.convert_to_6D_rot(torch.tensor(rows75, dtype=torch.float64)).detach().requires_grad_(True)
+    k = torch.tensor(kp, dtype=torch.float64)
+    f, g = [], []
+    for i in range(x.shape[0]):
+        xi = x[i:i + 1].detach().clone().requires_grad_(True)
+        li = sum(o64.loss(xi, k[i:i + 1], stage))
+        gi, = torch.autograd.grad(li, xi)
+        f.append(float(li.detach())); g.append(float(gi.abs().max()))
+    return np.array(f), np.array(g)
+
+
+def test_inner_fit_with_lbfgs_ends_where_torchs_lbfgs_ends_on_the_oracles_objective():
+    """fdcap_opt_fit2d_lbfgs (every frame its own L-BFGS problem) against oracle/innerfit.py fitting_lbfgs = torch.optim.LBFGS
+    per frame on the oracle's autograd objective, SMPLify-X's settings (30 x 30, ftol 2e-9), in the first stage: its strong priors
+    make the minimum unique enough that two arithmetics reach the same one.
+
+    ADVICE r5: the bars of the default product format (two fp16 planes) must not be derived from that format's own deviation.
+    They are now FORMAT-INDEPENDENT: the float64 objective at the library's end point, the stationarity of that point, and its
+    distance to torch's float64 run measured with torch's float32 run as the yardstick (two arithmetics of the SAME optimiser).
+    The old parameter bars (3e-2 / 2e-3, loss 1e-3) stay on the exact-fp32 form: the next test, in a child process."""
+    out, ref, ref64, op, orc, o64, kp, stage = _stage1_lbfgs_case()
     fl, ofl = op.frame_loss[0], np.array(orc.final_loss[0])
-    print("L-BFGS inner fit, stage 1, vs torch.optim.LBFGS on the oracle: parameters max", err.max(), "q90", np.quantile(err, 0.9),
-          "| objective per frame, worst relative difference", np.abs(fl / ofl - 1).max(), "| evaluation rounds", op.rounds,
-          "oracle closure calls (max over frames)", max(orc.evals[0]), "| directions per frame", op.frame_iterations[0])
-    # Where a 60-120-direction L-BFGS run ends along the flattest direction depends on rounding-level differences in the gradient: the
-    # three forms of the SAME library (exact fp32 MFMA chains / three bf16 planes / two fp16 planes -- all three within 2e-5 of a
-    # float64 decoder, tools/vposer_error_probe.py) end 3.2e-3 / 8.0e-3 / 3.7e-2 from torch's run in their worst parameter, with
-    # the objective 4.9e-4 / 3.2e-4 / 9.0e-4 apart and q90 7.2e-4 / 7.5e-4 / 1.2e-3 (one box, r5).  Bars: twice the worst of those.
-    np.testing.assert_allclose(fl, ofl, rtol=2e-3)
-    np.testing.assert_allclose(op.log[0][0] + op.log[0][1], ofl.sum(), rtol=2e-3)      # re-evaluated at the returned rows
-    assert np.quantile(err, 0.9) < 2.5e-3 and err.max() < 7.5e-2
+    f_out, g_out = _objective64(o64, out, kp, stage)
+    f_ref, g_ref = _objective64(o64, ref, kp, stage)
+    f_r64, g_r64 = _objective64(o64, ref64, kp, stage)
+    err64, yard = np.abs(out - ref64), np.abs(ref - ref64)
+    print("L-BFGS inner fit, stage 1: float64 objective at the end points, worst frame relative to torch-fp64's: library",
+          (f_out / f_r64 - 1).max(), "torch fp32", (f_ref / f_r64 - 1).max(), "| largest gradient entry: library", g_out.max(), "torch fp32",
+          g_ref.max(), "torch fp64", g_r64.max(), "| parameters vs torch fp64: library max", err64.max(), "q90", np.quantile(err64, 0.9),
+          "; torch fp32 max", yard.max(), "q90", np.quantile(yard, 0.9), "| rounds", op.rounds, "directions", op.frame_iterations[0])
+    # (1) the end point is as good a minimiser as torch's, frame by frame, in float64 -- fixed bar, whatever the product format
+    assert np.all(f_out <= f_r64 * (1 + 2e-3)), (f_out / f_r64 - 1)   # (measured: library +7.1e-4, torch's own float32 run +3.4e-4)
+    # (2) the objective the library reports is the objective there (its own arithmetic against float64)
+    np.testing.assert_allclose(fl, f_out, rtol=5e-4)
+    np.testing.assert_allclose(op.log[0][0] + op.log[0][1], f_out.sum(), rtol=5e-4)    # re-evaluated at the returned rows
+    # (3) ... and a stationary point to the degree torch's own float32 run is one (objective ~5e3 per frame, parameters O(1))
+    assert g_out.max() <= max(10.0 * g_ref.max(), 1.0), (g_out.max(), g_ref.max())
+    # (4) the bulk of the parameters sits where torch's float64 run ends (fixed); the flattest direction may differ by what
+    #     separates torch's own float32 and float64 runs, times a margin that is NOT read off the library
+    assert np.quantile(err64, 0.9) < 2e-3
+    assert err64.max() <= max(25.0 * yard.max(), 0.1), (err64.max(), yard.max())
     assert op.rounds[0] < 30 * 38                                                       # stopped by the rules, not by the cap
     op.close()
+
+
+_EXACT_CHILD = r"""
+import json, sys
+sys.path.insert(0, %r)
+import numpy as np
+from tests.test_gpu_lbfgs import _stage1_lbfgs_case
+out, ref, ref64, op, orc, o64, kp, stage = _stage1_lbfgs_case()
+err = np.abs(out - ref)
+fl, ofl = op.frame_loss[0], np.array(orc.final_loss[0])
+print("RESULT " + json.dumps({"max": float(err.max()), "q90": float(np.quantile(err, 0.9)), "loss_rel": float(np.abs(fl / ofl - 1).max())}))
+"""
+
+
+def test_exact_fp32_inner_fit_keeps_the_round_4_parameter_bars():
+    """The bars this comparison carried before the two-plane fp16 products became the default (r4: err.max 3e-2, q90 2e-3,
+    objective rtol 1e-3) are kept on the exact-fp32 product form (FDCAP_GEMM_SPLIT3=0; the switch is read once per process:
+    child process), so a regression of the optimiser itself cannot hide behind a product format's rounding."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    p = subprocess.run([sys.executable, "-c", _EXACT_CHILD % root], env=dict(os.environ, FDCAP_GEMM_SPLIT3="0"), capture_output=True,
+                       text=True, timeout=900, cwd=root)
+    line = [l for l in p.stdout.splitlines() if l.startswith("RESULT ")]
+    assert p.returncode == 0 and line, p.stderr[-2000:]
+    r = json.loads(line[-1][7:])
+    print("exact fp32 products vs torch.optim.LBFGS (fp32):", r)
+    assert r["max"] < 3e-2 and r["q90"] < 2e-3 and r["loss_rel"] < 1e-3, r
 
 
 def test_five_stage_lbfgs_fit_reduces_the_reprojection_error_like_the_oracles():

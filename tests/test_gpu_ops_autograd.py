@@ -249,3 +249,45 @@ def test_chamfer_operator_takes_the_culled_search_for_the_registered_scene(B, n,
     assert rc == -2
     ctx2.close()
     ctx.close()
+
+
+def test_registered_scene_verdict_does_not_outlive_the_scene_or_the_tensor():
+    """the memo that remembers "this target tensor IS the registered scene" must not survive (1) a re-registration of
+    another scene of the same size, (2) the freeing of the compared tensor and a new point set allocated at the same address,
+    (3) temporaries made by .contiguous() on a non-contiguous target.  Each case is checked against the generic scan."""
+    bm = synth.make_body_model(300, seed=0)
+    ctx = capi.Context(bm, synth.make_vposer(seed=1))
+    ns = 6000
+    scene_a, scene_b = synth.make_scene(ns, seed=9), synth.make_scene(ns, seed=10)
+    fast, slow = ops.chamferDist(ctx, both=False), ops.chamferDist(ctx, both=False, use_registered_scene=False)
+    x = torch.tensor(scene_a[:90].reshape(3, 30, 3) + 0.05, device="cuda")
+
+    def same(target):
+        t = target.unsqueeze(0).expand(3, -1, -1)
+        d_f, _ = fast(x, t)
+        d_s, _ = slow(x, t)
+        return torch.equal(d_f, d_s) and torch.equal(fast.last_idx1, slow.last_idx1)
+
+    ctx.set_scene(scene_a)
+    a_dev = torch.tensor(scene_a, device="cuda")
+    assert same(a_dev) and fast._memo["same"] is True
+    # (1) another scene of the same point count is registered: the old tensor is no longer "the scene"
+    ctx.set_scene(scene_b)
+    assert same(a_dev) and fast._memo["same"] is False
+    b_dev = torch.tensor(scene_b, device="cuda")
+    assert same(b_dev) and fast._memo["same"] is True
+    # (2) free the recognised tensor, allocate other points of the same shape (the caching allocator hands the block back):
+    # the memo's reference keeps the old storage alive, so the new tensor cannot alias the remembered address
+    ptr = b_dev.untyped_storage().data_ptr()
+    del b_dev
+    c_dev = torch.tensor(scene_a, device="cuda")
+    assert c_dev.untyped_storage().data_ptr() != ptr
+    assert same(c_dev) and fast._memo["same"] is False
+    # (3) a non-contiguous target (every second row of a wider buffer): compared on every call, nothing remembered about the copy
+    wide = torch.zeros(ns, 6, device="cuda")
+    wide[:, :3] = torch.tensor(scene_b, device="cuda")
+    key = fast._memo["key"]
+    assert same(wide[:, :3]) and fast._memo["key"] == key
+    wide[:, :3] = torch.tensor(scene_a, device="cuda")
+    assert same(wide[:, :3]) and fast._memo["key"] == key
+    ctx.close()
