@@ -90,6 +90,7 @@ SYMBOLS = {
     "fdcap_comm_last_error": (c_char_p, [c_void_p]),
     "fdcap_opt_halo_exchange": (c_int32, [c_void_p, c_void_p]),
     "fdcap_opt_exchange": (c_int32, [c_void_p, c_int32, c_int32, c_void_p]),
+    "fdcap_opt_time_exchange": (c_int32, [c_void_p, c_int32, POINTER(c_float), POINTER(c_float), c_void_p]),
     "fdcap_comm_allreduce_f64": (c_int32, [c_void_p, c_void_p, c_int32, c_void_p]),
     "fdcap_opt_state_len": (c_int32, [c_void_p]),
     "fdcap_opt_export_state": (c_int32, [c_void_p, c_void_p, c_void_p]),

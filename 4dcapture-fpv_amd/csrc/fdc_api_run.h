@@ -226,6 +226,39 @@ int fdcap_opt_exchange(fdcap_ctx* c, int32_t ii, int32_t P, void* stream) {
     return fdcap_opt_unpack_and_step_scale(c, ii, P, c->xch_all.p, c->comm.rank, c->comm.world, stream);
 }
 
+// What the exchange costs on THIS group, measured (DESIGN 6 assumed 8 / 10 / 12 us for 2 / 4 / 8 ranks until a multi-GPU box shows up):
+// `iters` whole tails (fdcap_opt_exchange: Adam on the rows + message, all-gather, unpack + `scale` step) and `iters` bare all-gathers of
+// the message, each train between two HIP events on `stream`; mean microseconds of each.  EVERY rank of the communicator must make the
+// same call.  The optimiser's parameters and moments are stepped `iters` times with whatever gradients are there: call it after the fit.
+int fdcap_opt_time_exchange(fdcap_ctx* c, int32_t iters, float* us_exchange, float* us_allgather, void* stream) {
+    if (!c || !c->opt || iters <= 0 || !us_exchange || !us_allgather) return FDCAP_E_ARG;
+    if (!c->comm.comm) return FDCAP_E_STATE;
+    hipStream_t st = (hipStream_t)stream;
+    int e = comm_buffers(c);
+    if (e) return e;
+    hipEvent_t ev[4];
+    for (auto& x : ev) HIP_TRY(hipEventCreate(&x));
+    const int big = 1 << 30;                                  // (P: every iteration is a phase-1 iteration -- `scale` steps, camera_ext rests)
+    for (int k = 0; k < 8 && !e; ++k) e = fdcap_opt_exchange(c, k, big, stream);              // warm-up
+    if (!e) e = (int)hipEventRecord(ev[0], st);
+    for (int k = 0; k < iters && !e; ++k) e = fdcap_opt_exchange(c, 8 + k, big, stream);
+    if (!e) e = (int)hipEventRecord(ev[1], st);
+    if (!e) e = (int)hipEventRecord(ev[2], st);
+    for (int k = 0; k < iters && !e; ++k) {
+        const ncclResult_t r = rccl().AllGather(c->xch_send.p, c->xch_all.p, XCH_LEN, ncclFloat, c->comm.comm, st);
+        if (r != ncclSuccess) e = comm_fail(c, r, "ncclAllGather");
+    }
+    if (!e) e = (int)hipEventRecord(ev[3], st);
+    if (!e) e = (int)hipEventSynchronize(ev[3]);
+    float a = 0.f, b = 0.f;
+    if (!e) e = (int)hipEventElapsedTime(&a, ev[0], ev[1]);
+    if (!e) e = (int)hipEventElapsedTime(&b, ev[2], ev[3]);
+    for (auto& x : ev) (void)hipEventDestroy(x);
+    *us_exchange = a * 1e3f / iters;
+    *us_allgather = b * 1e3f / iters;
+    return e;
+}
+
 // The loop :560-593 itself, iterations [ii0, ii1) of a fit of num_iter, in ONE call (r4): what FittingOP.fitting's Python `for` issues --
 // every iteration but the fit's last as fdcap_opt_backward_and_step, the last as fdcap_opt_backward + fdcap_opt_step; a sharded
 // context (which must hold a communicator) as fdcap_opt_backward + fdcap_opt_exchange.  Logging iterations (log_every > 0:

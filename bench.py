@@ -715,6 +715,14 @@ def main():
         if not weak:      # which iteration schedule rank 0's last fit kept after timing both (same results either way)
             out["config"]["exchange_schedule"] = "next forward's head under the all-gather" if getattr(fop, "exchange_overlap", False) else "plain"
             out["config"]["exchange_inside_library"] = bool(getattr(fop, "_c_comm", False))
+    if (rk.world > 1 or os.environ.get("FDCAP_FORCE_EXCHANGE") == "1") and not weak and getattr(fop, "_c_comm", False):
+        # what one iteration's exchange costs on THIS group (every rank makes the call; rank 0's figures go into the line).  Measured
+        # after the timed steps: the call steps the optimiser state, the next fit re-initialises it.
+        xus, gus = ctypes.c_float(0), ctypes.c_float(0)
+        capi.check(fop.ctx.lib.fdcap_opt_time_exchange(fop.ctx.handle, 300, ctypes.byref(xus), ctypes.byref(gus), capi.current_stream()),
+                   "fdcap_opt_time_exchange")
+        out["config"]["exchange_us_measured"] = {"whole_tail": float(xus.value), "allgather_alone": float(gus.value), "ranks": rk.world,
+                                                 "note": "mean of 300 back-to-back calls between two HIP events on the compute stream"}
     out["setup"] = setup_block(fop, first_fit_s, dt / max(args.steps, 1), N if weak or rk.world == 1 else nl)
     if args.value_only:
         if args.profile_logging:

@@ -418,6 +418,10 @@ int fdcap_comm_destroy(fdcap_ctx* ctx);
 const char* fdcap_comm_last_error(fdcap_ctx* ctx);
 int fdcap_opt_halo_exchange(fdcap_ctx* ctx, void* stream);
 int fdcap_opt_exchange(fdcap_ctx* ctx, int32_t ii, int32_t first_phase2_iter, void* stream);
+/* The exchange measured on the communicator at hand: mean microseconds of `iters` whole tails (fdcap_opt_exchange) and of `iters` bare
+ * ncclAllGather calls of the iteration's message, each train between two HIP events on `stream`.  Every rank must make the same
+ * call; the optimiser's state is stepped `iters` times with the gradients it holds (call it after the fit).  Synchronises. */
+int fdcap_opt_time_exchange(fdcap_ctx* ctx, int32_t iters, float* us_exchange, float* us_allgather, void* stream);
 int fdcap_comm_allreduce_f64(fdcap_ctx* ctx, double* buf_d, int32_t n, void* stream);
 /* Overlap of the exchange with the next forward.  Issued between the two calls above, i.e. while the all-gather is in
  * flight: the part of iteration ii's forward (ii = the NEXT iteration; log_terms as its fdcap_opt_backward will get) that needs

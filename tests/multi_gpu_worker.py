@@ -2,6 +2,7 @@
 RCCL).  Fits the shared test clip sharded over the ranks THROUGH THE LIBRARY'S OWN COMMUNICATOR (fdcap_comm_create /
 fdcap_opt_exchange -- asserted, not assumed) and writes this rank's rows to <outdir>/rank<r>.npz.
 usage: multi_gpu_worker.py <outdir> <mode> <frames> <iters>"""
+import ctypes
 import os
 import sys
 
@@ -28,8 +29,17 @@ def main(outdir, mode, frames, iters):
         c_comm = bool(fop._c_comm)
         body, scale, cam = fop.fitting(torch.tensor(clip.body_params).cuda(), mode, log_every=1)
         tot = np.array(fop.log.total) if mode == "global" else np.array(fop.log2)[:, 5]
+        # what the per-iteration exchange costs on THIS group (DESIGN 6 assumes 8 / 10 / 12 us for 2 / 4 / 8 ranks): measured after
+        # the results are taken (the call steps the optimiser state with stale gradients)
+        xus, gus = ctypes.c_float(0), ctypes.c_float(0)
+        if c_comm:
+            from fdcap_amd import capi
+            body, cam = body.clone(), cam.clone()
+            capi.check(fop.ctx.lib.fdcap_opt_time_exchange(fop.ctx.handle, 300, ctypes.byref(xus), ctypes.byref(gus), capi.current_stream()),
+                       "fdcap_opt_time_exchange")
         np.savez(os.path.join(outdir, f"rank{rank}.npz"), frame0=fop.shard.frame0, body=body.cpu().numpy(), scale=float(scale),
-                 cam=cam.cpu().numpy(), total=tot, c_comm=c_comm, world=dist.get_world_size(), device=torch.cuda.current_device())
+                 cam=cam.cpu().numpy(), total=tot, c_comm=c_comm, world=dist.get_world_size(), device=torch.cuda.current_device(),
+                 exchange_us=float(xus.value), allgather_us=float(gus.value))
         fop.close()
     finally:
         dist.barrier()

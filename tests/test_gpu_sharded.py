@@ -314,3 +314,62 @@ def test_exchange_message_layout_matches_the_host_mirror():
     np.testing.assert_array_equal(fop._rows_cam.cpu().numpy(), rc)
     assert float(fop._dscale.cpu()) == s
     fop.close()
+
+
+def test_world_8_exchange_tail_with_adversarial_messages():
+    """VERDICT r5 (next 8): the RCCL path has only ever run with one rank, so the consumer of an 8-rank all-gather is rehearsed on
+    one GPU.  ONE gathered buffer of world 8 (what ncclAllGather leaves, identically, on every rank), built by the host mirror
+    of the packing kernel and then made hostile -- NaN and Inf in boundary rows, partials spread over 12 decades with signs
+    that cancel, a rank that sends -0.0 -- is consumed by eight optimisers that play ranks 0..7 of BASELINE config 3's partition
+    (128 frames each).  Every rank must (1) take exactly its two neighbours' boundary rows, NaNs included, and leave the clip's
+    ends alone; (2) form the SAME scale gradient, bit for bit -- the sum in rank order, which the host mirror restates -- and
+    step `scale` to the same bits; (3) not let a NaN halo row leak into the scale gradient.  A permutation of the ranks' partials
+    changes the rounded sum (that is why the order is fixed) but still agrees on every rank."""
+    from fdcap_amd import capi
+    from fdcap_amd.fitting import FittingOP
+    from tests.host_pipeline import XCH_LEN, XCH_ROW, xch_unpack
+    world, n_total = 8, 1024
+    nl = n_total // world
+    bm, vp, clip, scene, vid = _inputs(nl)
+    rng = np.random.default_rng(8)
+    gathered = rng.standard_normal((world, XCH_LEN)).astype(np.float32)
+    parts = np.array([1e8, 1.0, -1e8, 1.0, 0.5, -0.0, 2.5e-3, 7.7e-7], np.float32)     # cancellation across 15 decades: 1e8 + 1 rounds the 1 away
+    gathered[:, 4 * XCH_ROW] = parts
+    gathered[:, 4 * XCH_ROW + 1:] = 0.0
+    gathered[2, 0:XCH_ROW] = np.nan                          # rank 2's FIRST owned row (rank 1's right halo) is NaN
+    gathered[5, 3 * XCH_ROW + 4] = np.inf                    # one entry of rank 5's LAST owned row (rank 6's left halo)
+    want_sum = None
+    out = {}
+    for perm_name, g in (("rank order", gathered), ("partials permuted", None)):
+        if g is None:
+            g = gathered.copy()
+            g[:, 4 * XCH_ROW] = parts[[0, 2, 1, 3, 4, 5, 6, 7]]   # 1e8 - 1e8 first: both 1.0 survive
+        dev = torch.tensor(g).cuda()
+        scales, sums = [], []
+        for rank in range(world):
+            fop = FittingOP({"num_iter": 500}, {}, nl, body_model=bm, vposer=vp, scene_verts=scene, contact_ids=vid,
+                            camera_ext=read_camerapose(clip.camerapose_lines))
+            lib, h = fop.ctx.lib, fop.ctx.handle
+            x78 = torch.empty(nl, capi.XDIM, device="cuda")
+            capi.check(lib.fdcap_params_75_to_78(capi.dptr(torch.tensor(clip.body_params).cuda()), nl, capi.dptr(x78), capi.current_stream()), "75->78")
+            fop._mode = "global"
+            fop.init(x78)
+            rx, rc = fop._rows_x.cpu().numpy().copy(), fop._rows_cam.cpu().numpy().copy()
+            s = xch_unpack(g, rank, world, nl, rx, rc)
+            capi.check(lib.fdcap_opt_unpack_and_step_scale(h, 7, 400, capi.dptr(dev), rank, world, capi.current_stream()), "unpack")
+            torch.cuda.synchronize()
+            np.testing.assert_array_equal(fop._rows_x.cpu().numpy(), rx)           # (NaN == NaN position-wise: assert_array_equal)
+            np.testing.assert_array_equal(fop._rows_cam.cpu().numpy(), rc)
+            got = fop._dscale.cpu().numpy().copy()
+            assert np.isfinite(got).all() and got.view(np.uint32)[0] == np.float32(s).view(np.uint32), (rank, got, s)
+            scales.append(fop._scale.cpu().numpy().copy().view(np.uint32)[0])
+            sums.append(got.view(np.uint32)[0])
+            if rank == 1:
+                assert np.isnan(fop._rows_x[nl + 2].cpu().numpy()).all() and not np.isnan(fop._rows_x[2:nl + 2].cpu().numpy()).any()
+            if rank == 0:                                     # the clip's first rank has no left neighbour: its left halo rows keep what init put there
+                np.testing.assert_array_equal(fop._rows_x[0:2].cpu().numpy(), rx[0:2])
+            fop.close()
+        assert len(set(sums)) == 1 and len(set(scales)) == 1, (perm_name, sums, scales)
+        out[perm_name] = sums[0]
+    # the two orders round differently on these partials: the sum is only reproducible because the order is fixed
+    assert out["rank order"] != out["partials permuted"]
