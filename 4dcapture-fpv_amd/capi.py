@@ -60,6 +60,7 @@ SYMBOLS = {
     "fdcap_ctx_destroy": (None, [c_void_p]),
     "fdcap_set_scene": (c_int32, [c_void_p, c_void_p, c_int64]),
     "fdcap_debug_scene_hash": (c_int32, [c_void_p, c_void_p]),
+    "fdcap_debug_kernel_forms": (c_int32, [c_void_p, c_int32, c_int32]),
     "fdcap_set_contact_ids": (c_int32, [c_void_p, c_void_p, c_int32]),
     "fdcap_chamfer_fwd": (c_int32, [c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_int32, c_int64, c_void_p,
                                      c_void_p, c_void_p, c_void_p, c_void_p]),

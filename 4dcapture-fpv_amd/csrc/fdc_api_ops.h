@@ -88,6 +88,17 @@ int fdcap_debug_panel_times(unsigned long long* out, int n) {
 }
 #endif
 
+// test / diagnosis: the kernel forms launched since the last call with reset != 0 (fdc_math.h FormLog), "a;b;c" into buf
+int fdcap_debug_kernel_forms(char* buf, int32_t len, int32_t reset) {
+    if (!buf || len <= 0) return FDCAP_E_ARG;
+    FormLog& f = form_log();
+    std::string s;
+    for (int i = 0; i < f.n; ++i) { if (i) s += ";"; s += f.name[i]; }
+    snprintf(buf, (size_t)len, "%s", s.c_str());
+    if (reset) f.n = 0;
+    return FDCAP_OK;
+}
+
 int fdcap_set_nn_kernel(int32_t mode) {
     if (mode < 0 || mode > 2) return FDCAP_E_ARG;
     nn_mode_ref() = mode;

@@ -129,7 +129,7 @@ static int opt_contact_forward(fdcap_ctx* c, hipStream_t st, bool blend_done = f
     const size_t off = (size_t)2 * nc * 3;
     // clip-sized shares: the blend product and the skinning in one launch (blend_skin_fwd_kernel; FDCAP_FUSE_SKIN=0: two launches)
     const SkinModel smf = c->contact.model();
-    const bool fused = !blend_done && o->fuse_skin && gemm_split3_enabled() && c->contact.pn_fwdS.f && smf.vpack && smf.K <= 4 && nl >= 384 &&
+    const bool fused = !blend_done && o->fuse_skin && gemm_split3_enabled() && c->contact.pn_fwdS.f && smf.vpack && smf.K <= 4 && nl >= clip_forms_min_rows() &&
                        blend_skin_lds_bytes(smf.ja_hi) <= (size_t)150 * 1024;
     if (fused) {
         static std::atomic<uint64_t> attr{0};                  // per DEVICE: the attribute belongs to one device's code object
@@ -137,10 +137,12 @@ static int opt_contact_forward(fdcap_ctx* c, hipStream_t st, bool blend_done = f
             HIP_TRY(hipFuncSetAttribute((const void*)blend_skin_fwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
             fdc_attr_done(attr);
         }
+        note_form("blend_skin_fwd_kernel");
         hipLaunchKernelGGL(blend_skin_fwd_kernel, dim3(8 * ((nl + 31) / 32)), dim3(768), blend_skin_lds_bytes(smf.ja_hi), st, o->PF.p, nl,
                            c->contact.pn_fwdS, smf, nc, smf.ja_hi, o->X.p, XDIM, X_TRANSL, o->A.p, o->M.p, o->scale.p, 2, o->Voff.p, o->Vw.p);
     } else {
         if (!blend_done) HIP_TRY(blend_forward(c->contact, o->PF.p + 2 * NPFX, nl, o->Voff.p + off, st));
+        note_form("skin_fwd_kernel");
         hipLaunchKernelGGL(skin_fwd_kernel, dim3((nc + 255) / 256, nl), dim3(256), 0, st, smf, nc, o->X.p, XDIM,
                            X_BETAS, X_TRANSL, o->Voff.p, o->A.p, o->M.p, o->scale.p, 2, 1, o->Vw.p);
     }
@@ -233,9 +235,10 @@ static int opt_backward_impl(fdcap_ctx* c, const LossWeights& lw, int32_t log_te
                 (((size_t)o->Vw.p | (size_t)o->Voff.p | (size_t)o->dVoff.p | (size_t)o->A.p) & 15) == 0) {
 #define FDC_SKV(GG) hipLaunchKernelGGL(skin_bwd_vec_kernel<GG>, dim3(nl), dim3(256), ldsv, st, smc, nc, nnz, o->X.p, o->Voff.p, o->A.p, \
                                    o->M.p, o->scale.p, 2, o->dVoff.p, o->dA.p, o->dtransl_v.p, o->dMv.p, o->dsv.p, cg)
+                note_form("skin_bwd_vec_kernel");
                 if (G == 1) FDC_SKV(1); else if (G == 2) FDC_SKV(2); else FDC_SKV(3);
 #undef FDC_SKV
-            } else if (nc <= 512 && nnz <= 2048)
+            } else if (note_form("skin_bwd_small_kernel"), nc <= 512 && nnz <= 2048)
                 hipLaunchKernelGGL((skin_bwd_small_kernel<2, 8>), dim3(nl), dim3(256), lds, st, c->contact.model(), nc, nnz, o->X.p, o->Voff.p, o->A.p,
                                    o->M.p, o->scale.p, 2, o->dVoff.p, o->dA.p, o->dtransl_v.p, o->dMv.p, o->dsv.p, cg);
             else if (nc <= 512)                                       // (K > 4 at the loop's contact-set size: up to 6144 list entries)

@@ -1429,6 +1429,8 @@ static inline hipError_t nn_search(const float* q, int nq, const NNTarget& T, fl
             const bool ordered = ord != nullptr && ord->on && nc.hdr != nullptr && ord->every > 0 && nqv == 1 && wpg == 1 && wpb == 1;
             nc.order_mode = !ordered ? 0 : (ord->sorted_groups == groups ? 2 + ord->cur : 1);
 #define FDC_ST4(NQV, WPGV) hipLaunchKernelGGL((nn_stream4_kernel<NQV, WPGV>), grid, dim3(256), 0, st, q, nq, T, seed, seedpt, dist, idx, nc)
+            note_form(wpg == 4 ? "nn_stream4_kernel(4 waves per group)" : wpg == 2 ? "nn_stream4_kernel(2 waves per group)" :
+                      wpb == 4 ? "nn_stream4_kernel(1 wave per group, 4-wave workgroups)" : "nn_stream4_kernel<1,1,1>");
             if (nqv == 2 && wpg == 4) FDC_ST4(2, 4); else if (nqv == 2 && wpg == 2) FDC_ST4(2, 2); else if (nqv == 2) FDC_ST4(2, 1);
             else if (wpg == 4) FDC_ST4(1, 4); else if (wpg == 2) FDC_ST4(1, 2); else if (wpb == 4) FDC_ST4(1, 1);
             else hipLaunchKernelGGL((nn_stream4_kernel<1, 1, 1>), grid, dim3(64), 0, st, q, nq, T, seed, seedpt, dist, idx, nc);
@@ -1447,6 +1449,7 @@ static inline hipError_t nn_search(const float* q, int nq, const NNTarget& T, fl
     }
     const int fq_ = forced_nq;
     const int NQsel = fq_ ? fq_ : (culled ? 2 : 4);
+    note_form(nn_use_mfma(nq, T.n) ? "nn_mfma_kernel" : "nn_direct_kernel");
     if (nn_use_mfma(nq, T.n) && NQsel == 1)
         hipLaunchKernelGGL((nn_mfma_kernel<1>), dim3(nn_grid_blocks((nq + 127) / 128, nsplit)), dim3(256), 0, st, q, nq, T, nsplit, seed, pd, pi);
     else if (nn_use_mfma(nq, T.n) && NQsel == 2)

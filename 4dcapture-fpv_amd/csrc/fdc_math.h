@@ -19,6 +19,16 @@
 
 namespace fdc {
 
+// Diagnosis (fdcap_debug_kernel_forms): the name of every kernel FORM the host side has launched since the last reset -- several
+// stages pick among forms by row count / set size, and tests that mean to cover one form must be able to see that it ran.
+struct FormLog { const char* name[48]; int n; };
+inline FormLog& form_log() { static FormLog f{}; return f; }
+inline void note_form(const char* name) {                  // (string literals: compared by address first, by content across headers)
+    FormLog& f = form_log();
+    for (int i = 0; i < f.n; ++i) if (f.name[i] == name || !__builtin_strcmp(f.name[i], name)) return;
+    if (f.n < 48) f.name[f.n++] = name;
+}
+
 #if defined(__HIPCC__)
 // Sum over the 64 lanes of a wavefront, the same bits in every lane, fixed order.  Four DPP steps (quad_perm x2,
 // row_half_mirror, row_mirror: no LDS traffic) leave every 16-lane row with its row sum, then ((r0 + r1) + r2) + r3 down the rows.  The obvious __shfl_xor butterfly compiles to six ds_bpermute_b32 (LDS crossbar round trips) per sum.

@@ -25,6 +25,7 @@
 #include <stdint.h>
 #include <string.h>
 
+#include <algorithm>
 #include <atomic>
 #include <vector>
 
@@ -39,6 +40,15 @@ inline bool fdc_attr_needed(const std::atomic<uint64_t>& mask) { int d = 0; (voi
 inline void fdc_attr_done(std::atomic<uint64_t>& mask) { int d = 0; (void)hipGetDevice(&d); mask.fetch_or(1ull << (d & 63)); }
 
 typedef float f32x4_t __attribute__((ext_vector_type(4)));
+
+// Row count from which the clip-sized kernel forms are selected (two row blocks per fragment stream in the blend products, the
+// fused contact forward): measured break-even 384.  FDCAP_CLIP_FORMS_MIN_ROWS overrides it -- tests run the reference's own
+// 300-frame fixtures (the reference hard-codes 300, :41-42) through the forms BASELINE configs 2 / 3 / 5 select.
+inline int clip_forms_min_rows() {
+    static std::atomic<int> v{-1};
+    if (v < 0) { const char* e = getenv("FDCAP_CLIP_FORMS_MIN_ROWS"); v = e ? std::max(32, atoi(e)) : 384; }
+    return v;
+}
 
 // B operand in fragment order: f[(tile * nss + s) * 64 + lane] = { B(16 s + 4 (lane >> 4) + m, 16 tile + (lane & 15)) }, m = 0..3
 struct PanelB {
@@ -946,12 +956,12 @@ static inline bool panel_gemm3_rb2k_ok(int M, int K, const PanelB3& B) {
     static std::atomic<int> rb2{-1};
     if (rb2 < 0) { const char* e = getenv("FDCAP_PN_RB2"); rb2 = e ? atoi(e) : 1; }     // 0 off, 1 both forms, 2 forward only, 3 K-split only
     const int nst_all = (K + 31) >> 5;
-    return (rb2 == 1 || rb2 == 3) && M >= 384 && B.ntile <= 32 && nst_all >= 2 && 32 * ((nst_all + 1) / 2) <= 768;
+    return (rb2 == 1 || rb2 == 3) && M >= clip_forms_min_rows() && B.ntile <= 32 && nst_all >= 2 && 32 * ((nst_all + 1) / 2) <= 768;
 }
 static inline hipError_t panel_gemm3_rb2k(const float* A, int lda, int M, int K, const PanelB3& B, float* Cpart, size_t part_stride,
                                           int ldc, int N, hipStream_t st) {
     const int kh = 32 * ((((K + 31) >> 5) + 1) / 2);
-    hipLaunchKernelGGL(panel_gemm3_rb2k_kernel, dim3(8 * ((M + 31) / 32)), dim3(512), pnf_lds_bytes(kh, 2), st, A, lda, M, K, B, Cpart,
+    note_form("panel_gemm3_rb2k_kernel"); hipLaunchKernelGGL(panel_gemm3_rb2k_kernel, dim3(8 * ((M + 31) / 32)), dim3(512), pnf_lds_bytes(kh, 2), st, A, lda, M, K, B, Cpart,
                        part_stride, ldc, N);
     return hipGetLastError();
 }
@@ -1019,15 +1029,15 @@ static inline hipError_t panel_gemm3(const float* A, int lda, int M, int K, cons
         if (cs_env < 0) { const char* e = getenv("FDCAP_PN_WIDE_CS"); cs_env = e ? atoi(e) : 0; }
         // (r5: two column tiles per wave, as in the K-loop product, measured no faster here: 0.186 vs 0.179 ms at 1024 rows, equal at 512)
         const int cs = cs_env > 0 ? (int)cs_env : std::max(1, std::min(cpg, (256 + 8 * nrb - 1) / (8 * nrb)));
-        hipLaunchKernelGGL(panel_gemm3_wide_kernel<2>, dim3(8 * nrb * cs), dim3(512), pnf_lds_bytes(kpad, 2), st, A, lda, M, K, B, C, ldc, N, cs);
+        note_form("panel_gemm3_wide_kernel"); hipLaunchKernelGGL(panel_gemm3_wide_kernel<2>, dim3(8 * nrb * cs), dim3(512), pnf_lds_bytes(kpad, 2), st, A, lda, M, K, B, C, ldc, N, cs);
         return hipGetLastError();
     }
     static std::atomic<int> rb2{-1};                                  // FDCAP_PN_RB2=0 (A/B): one row block per fragment stream everywhere
     if (rb2 < 0) { const char* e = getenv("FDCAP_PN_RB2"); rb2 = e ? atoi(e) : 1; }
-    if ((rb2 == 1 || rb2 == 2) && M >= 384 && kpad <= 768 && B.ntile >= 48) {   // (measured: 256 rows 50.2 vs 49.8 ms per step, 384 rows 56.7 vs 57.8)
+    if ((rb2 == 1 || rb2 == 2) && M >= clip_forms_min_rows() && kpad <= 768 && B.ntile >= 48) {   // (measured: 256 rows 50.2 vs 49.8 ms per step, 384 rows 56.7 vs 57.8)
         // (r5: six waves x two tiles over the same 32 x 192 block -- half the LDS bytes per MFMA, the lever that took the K-loop
         //  product from 192 to 139 us -- is SLOWER here: 14.4 vs 12.8 us; with K = 512 the twelve waves' latency hiding is worth more)
-        hipLaunchKernelGGL(panel_gemm3_rb2_kernel, dim3(8 * ((M + 31) / 32)), dim3(768), pnf_lds_bytes(kpad, 2), st, A, lda, M, K, B, C, ldc, N);
+        note_form("panel_gemm3_rb2_kernel"); hipLaunchKernelGGL(panel_gemm3_rb2_kernel, dim3(8 * ((M + 31) / 32)), dim3(768), pnf_lds_bytes(kpad, 2), st, A, lda, M, K, B, C, ldc, N);
         return hipGetLastError();
     }
     // waves per workgroup: eight while that gives >= 192 workgroups, else four, else two (FDCAP_PN_NW pins it: A/B)
@@ -1040,6 +1050,7 @@ static inline hipError_t panel_gemm3(const float* A, int lda, int M, int K, cons
     const PnMap mp = panel_map(nrb, (B.ntile + nw - 1) / nw, (size_t)M * K * 4, (size_t)B.ntile * B.nst * PNF * 1024);
     const dim3 grid(8 * mp.rpg * mp.cpg);
     const size_t lds = pnf_lds_bytes(kpad, 1);
+    note_form("panel_gemm3_kernel");
     if (nw == 8) hipLaunchKernelGGL(panel_gemm3_kernel<8>, grid, dim3(512), lds, st, A, lda, M, K, B, C, ldc, N, mp);
     else if (nw == 4) hipLaunchKernelGGL(panel_gemm3_kernel<4>, grid, dim3(256), lds, st, A, lda, M, K, B, C, ldc, N, mp);
     else hipLaunchKernelGGL(panel_gemm3_kernel<2>, grid, dim3(128), lds, st, A, lda, M, K, B, C, ldc, N, mp);
@@ -1366,6 +1377,7 @@ static inline hipError_t panel_gemm3_ksw(const float* A, int lda, int M, int K, 
     int T = nrb * ((B.ntile + 1) / 2) >= 192 ? 2 : 1;
     if (t_env == 1 || t_env == 2) T = t_env;
     const PnMap mp = panel_map(nrb, (B.ntile + T - 1) / T, (size_t)M * K * 4, (size_t)B.ntile * B.nst * PNF * 1024);
+    note_form("panel_gemm3_ksw_kernel");
     if (T == 2)
         hipLaunchKernelGGL(panel_gemm3_ksw_kernel<2>, dim3(8 * mp.rpg * mp.cpg), dim3(512), pnf_lds_bytes(kpad, 1), st, A, lda, M, K, B, C, ldc, N, mp);
     else
@@ -1499,6 +1511,7 @@ static inline hipError_t panel_gemm3_kloop(const float* A, int lda, int M, int K
 #define FDC_KLOOP(RBV, TV) hipLaunchKernelGGL((panel_gemm3_kloop_kernel<RBV, TV>), grid, dim3(512), lds, st, A, lda, M, K, B, part, stride, ldc, N, ks, slab)
     if (rb == 4 && T == 2) FDC_KLOOP(4, 2); else if (rb == 4) FDC_KLOOP(4, 1); else if (T == 2) FDC_KLOOP(2, 2); else FDC_KLOOP(2, 1);
 #undef FDC_KLOOP
+    note_form("panel_gemm3_kloop_kernel");
     hipLaunchKernelGGL(panel_part_sum_kernel, dim3((unsigned)((stride + 255) / 256)), dim3(256), 0, st, part, ks, stride, stride, C);
     return hipGetLastError();
 }

@@ -58,6 +58,7 @@ static int skin_bwd_any(DevBuf<float>& part, hipStream_t st, int nrows, SkinMode
     if (split_on < 0) { const char* e = getenv("FDCAP_SKIN_SPLIT"); split_on = (e && e[0] == '0') ? 0 : 1; }
     const size_t lds = (size_t)std::min(nc, SKB_VCH) * 12 * sizeof(float) + (sm.wf_tab ? (size_t)4 * 64 * 16 * sizeof(float) : 0);   // dT rows (+ the matrix form's partial tiles)
     if (nc <= SKB_VCH || !split_on) {
+        note_form("skin_bwd_kernel(one workgroup per frame)");
         hipLaunchKernelGGL((skin_bwd_kernel<CONTACT, false>), dim3(nrows), dim3(256), lds, st, sm, nc, X, Voff, A, M, scale, row0, dVw, dVoff, dA,
                            dbeta_v, dtransl_v, dMv, dsv, cg, (float*)nullptr);
         return (int)hipGetLastError();
@@ -65,6 +66,7 @@ static int skin_bwd_any(DevBuf<float>& part, hipStream_t st, int nrows, SkinMode
     const int nch = (nc + SKB_VCH - 1) / SKB_VCH;
     hipError_t e = part.ensure((size_t)nrows * nch * SKP_STRIDE);
     if (e != hipSuccess) return (int)e;
+    note_form(sm.wf_tab ? "skin_bwd_kernel(chunks, MFMA dA)" : "skin_bwd_kernel(chunks, list dA)");
     hipLaunchKernelGGL((skin_bwd_kernel<CONTACT, true>), dim3(nrows, nch), dim3(256), lds, st, sm, nc, X, Voff, A, M, scale, row0, dVw, dVoff, dA,
                        dbeta_v, dtransl_v, dMv, dsv, cg, part.p);
     hipLaunchKernelGGL(skin_bwd_reduce_kernel, dim3(nrows), dim3(256), 0, st, part.p, nch, row0, dA, dbeta_v, dtransl_v, dMv, dsv,
