@@ -232,6 +232,9 @@ __global__ __launch_bounds__(256) void skin_bwd_kernel(SkinModel sm, int nc, con
     const int c_lo = SPLIT ? (int)blockIdx.y * VCH : 0, c_hi = SPLIT ? min(nc, c_lo + VCH) : nc;
     for (int c0 = c_lo; c0 < c_hi; c0 += VCH) {
         const int c1 = min(c_hi, c0 + VCH);
+#ifdef FDC_SKB_VUNROLL
+#pragma unroll FDC_SKB_VUNROLL
+#endif
         for (int c = c0 + tid; c < c1; c += 256) {
             size_t qi = (size_t)r * nc + c;
             // every global load of this vertex goes out before the first use (the kernel is a chain of latencies: four
@@ -267,8 +270,14 @@ __global__ __launch_bounds__(256) void skin_bwd_kernel(SkinModel sm, int nc, con
 #pragma unroll
             for (int e = 0; e < 12; ++e) acc[NBETA + 3 + e] += b.dM[e];
             acc[NBETA + 15] += b.ds;
+            if (sm.wf_tab) {                                 // (kernel-uniform) matrix-form dA: dT_v = gv (x) [vp ; 1] stays factored -- 32 B per vertex
+                float* const t = sdT + (c - c0) * 8;            // instead of 48: four workgroups per CU instead of two (r6)
+                t[0] = b.gv.x; t[1] = b.gv.y; t[2] = b.gv.z; t[3] = 0.f;
+                t[4] = f.vp.x; t[5] = f.vp.y; t[6] = f.vp.z; t[7] = 1.f;
+            } else {
 #pragma unroll
-            for (int e = 0; e < 12; ++e) sdT[(c - c0) * 12 + e] = b.dT[e];
+                for (int e = 0; e < 12; ++e) sdT[(c - c0) * 12 + e] = b.dT[e];
+            }
         }
         // lane j: where joint j's list enters / leaves this chunk (loaded while the vertex phase's stores drain)
         int clo = 0, chi = 0;
@@ -292,16 +301,22 @@ __global__ __launch_bounds__(256) void skin_bwd_kernel(SkinModel sm, int nc, con
             // waves' partial tiles added in wave order.  The list form spends 34 k of a chunk workgroup's 55 k cycles here (55 joints x
             // twelve wave sums per chunk, lists fetched joint by joint); a first matrix form with one 4-byte load per step took as
             // long -- 1000 vector-memory instructions per workgroup: their NUMBER binds, not their bytes.  Same terms, another order.
-            float* const sPart = sdT + (size_t)min(nc, VCH) * 12;             // [4 waves][64 joints][16]
+            // r6: the LDS rows hold the FACTORS of dT_v = gv (x) [vp ; 1] (32 B per vertex; a lane forms its entry gv[e >> 2] * [vp ; 1][e & 3]
+            // -- the product skin_backward_vertex forms, same bits -- when it reads it), and the waves' partial tiles go where the rows
+            // were once every wave is done with them: 38 KB of LDS per workgroup instead of 70, four workgroups per CU instead of two
+            // (the phase is a chain of latencies: fragment loads from L2, dependent LDS reads, one accumulator per tile).
+            float* const sPart = sdT;                                          // [4 waves][64 joints][16], after the barrier below
             const int e = lane & 15, kk = lane >> 4;
+            const int eg = min(e >> 2, 2), ep = 4 + (e & 3);
             const int tb = ((c0 / VCH) * 4 + wave) * 4;
             typedef unsigned wf_u2 __attribute__((ext_vector_type(2)));
             typedef const wf_u2 __attribute__((address_space(4)))* wf_sp_t;    // (wave-uniform: s_load)
             const wf_sp_t steps_c = (wf_sp_t)(const void*)sm.wf_step;
+            f32x4_t dacc[4];
 #pragma unroll
             for (int jt = 0; jt < 4; ++jt) {
                 const int g_lo = sm.wf_tab[tb + jt], g_hi = sm.wf_tab[tb + jt + 1];     // (wave-uniform) quads
-                f32x4_t dacc = {0.f, 0.f, 0.f, 0.f};
+                dacc[jt] = f32x4_t{0.f, 0.f, 0.f, 0.f};
                 for (int g0 = g_lo; g0 < g_hi; g0 += SKB_WFQ) {                  // blocks of SKB_WFQ quads: all their loads first
                     float4 a[SKB_WFQ];
                     wf_u2 st[SKB_WFQ];
@@ -316,15 +331,20 @@ __global__ __launch_bounds__(256) void skin_bwd_kernel(SkinModel sm, int nc, con
                         const bool on = g0 + u < g_hi && e < 12;              // (padded quads multiply zeros: a uniform branch here measured slower)
                         const int v0 = 4 * (int)(st[u].x & 0xFFFFu) + kk, v1 = 4 * (int)(st[u].x >> 16) + kk;
                         const int v2 = 4 * (int)(st[u].y & 0xFFFFu) + kk, v3 = 4 * (int)(st[u].y >> 16) + kk;
-                        dacc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[u].x, (on && c0 + v0 < c1) ? sdT[v0 * 12 + e] : 0.f, dacc, 0, 0, 0);
-                        dacc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[u].y, (on && c0 + v1 < c1) ? sdT[v1 * 12 + e] : 0.f, dacc, 0, 0, 0);
-                        dacc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[u].z, (on && c0 + v2 < c1) ? sdT[v2 * 12 + e] : 0.f, dacc, 0, 0, 0);
-                        dacc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[u].w, (on && c0 + v3 < c1) ? sdT[v3 * 12 + e] : 0.f, dacc, 0, 0, 0);
+#define FDC_DT(v) ((on && c0 + (v) < c1) ? sdT[(v) * 8 + eg] * sdT[(v) * 8 + ep] : 0.f)
+                        dacc[jt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[u].x, FDC_DT(v0), dacc[jt], 0, 0, 0);
+                        dacc[jt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[u].y, FDC_DT(v1), dacc[jt], 0, 0, 0);
+                        dacc[jt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[u].z, FDC_DT(v2), dacc[jt], 0, 0, 0);
+                        dacc[jt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[u].w, FDC_DT(v3), dacc[jt], 0, 0, 0);
+#undef FDC_DT
                     }
                 }
-#pragma unroll
-                for (int i = 0; i < 4; ++i) sPart[(size_t)((wave * 64 + jt * 16 + 4 * kk + i) * 16) + e] = dacc[i];
             }
+            __syncthreads();                                                   // every wave is done reading the rows: their space takes the tiles
+#pragma unroll
+            for (int jt = 0; jt < 4; ++jt)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) sPart[(size_t)((wave * 64 + jt * 16 + 4 * kk + i) * 16) + e] = dacc[jt][i];
             __syncthreads();
             for (int i = tid; i < NJ * 12; i += 256) {
                 const int j = i / 12, o = j * 16 + (i - 12 * j);

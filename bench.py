@@ -67,7 +67,12 @@ CONFIG_NAMES = {"c3": "BASELINE config 3", "c5": "BASELINE config 5 (Chamfer str
 
 
 def pmc_summary_path(cfg):
-    return os.path.join(ROOT, "profiles", f"r5_{cfg}_pmc_summary.json")
+    """the newest committed PMC summary of the configuration (tools/run_prof_r6.sh; r5's where r6 has none)"""
+    for rnd in ("r6", "r5"):
+        p = os.path.join(ROOT, "profiles", f"{rnd}_{cfg}_pmc_summary.json")
+        if os.path.exists(p):
+            return p
+    return os.path.join(ROOT, "profiles", f"r6_{cfg}_pmc_summary.json")
 # VALU issue cost per wave64 instruction on one gfx950 SIMD, MEASURED (tools/valu_issue_probe.hip, 8 waves per SIMD, per physical
 # SIMD; profiles/r4_valu_issue_probe.txt): v_fma / v_add / v_mul / v_sub_f32, v_and_b32, v_add_u32 issue every ~2.2 cycles (the
 # guide's "2 cycles"); v_min3 / v_min / v_med3 / v_cmp_f32, v_alignbit_b32, 64-bit shifts and the packed fp32 forms every ~4.16.
@@ -758,7 +763,7 @@ def main():
     # (the brute-force launch and the wide GEMM are not in the r5 per-configuration command: their counters come from the passes of
     #  the full bench command, profiles/r5_c3_ops_pmc_summary.json -- r4's summary before that file existed)
     ops_pk = {}
-    for name in ("r5_c3_ops_pmc_summary.json", "r4_pmc_summary.json"):
+    for name in ("r6_c3_ops_pmc_summary.json", "r5_c3_ops_pmc_summary.json", "r4_pmc_summary.json"):
         fn = os.path.join(ROOT, "profiles", name)
         if quoted and os.path.exists(fn):
             ops_pk = json.load(open(fn)).get("kernels", {})

@@ -258,7 +258,7 @@ def _px_err(orc, rows, kp):
     return float(np.sqrt(((uv - kp[..., :2]) ** 2).sum(-1))[w].mean())
 
 
-def _stage1_lbfgs_case():
+def _stage1_lbfgs_case(with64=True):
     """stage-1 inner fit of 8 frames with the library's L-BFGS and with torch.optim.LBFGS on the oracle's objective (float32 and
     float64) -> (library rows, oracle rows fp32, oracle rows fp64, library's per-frame objective, InnerFitOP, fp64 oracle, kp, stage)"""
     from fdcap_amd.innerfit import DEFAULT_STAGES, InnerFitOP
@@ -274,7 +274,7 @@ def _stage1_lbfgs_case():
     orc = InnerFitOracle(SMPLXOracle(bm), VPoserDecoder.from_data(vp))
     ref = orc.fitting_lbfgs(init, kp, stages).numpy()
     o64 = InnerFitOracle(SMPLXOracle(bm, dtype=torch.float64), VPoserDecoder.from_data(vp, dtype=torch.float64), dtype=torch.float64)
-    ref64 = o64.fitting_lbfgs(init, kp, stages).numpy()
+    ref64 = o64.fitting_lbfgs(init, kp, stages).numpy() if with64 else None
     return out, ref, ref64, op, orc, o64, kp, stages[0]
 
 
@@ -331,7 +331,7 @@ import json, sys
 sys.path.insert(0, %r)
 import numpy as np
 from tests.test_gpu_lbfgs import _stage1_lbfgs_case
-out, ref, ref64, op, orc, o64, kp, stage = _stage1_lbfgs_case()
+out, ref, ref64, op, orc, o64, kp, stage = _stage1_lbfgs_case(with64=False)
 err = np.abs(out - ref)
 fl, ofl = op.frame_loss[0], np.array(orc.final_loss[0])
 print("RESULT " + json.dumps({"max": float(err.max()), "q90": float(np.quantile(err, 0.9)), "loss_rel": float(np.abs(fl / ofl - 1).max())}))

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Are two builds of the library bit-identical in what they compute?  Runs the same fits (a small one with every loss term logged,
-mode 'local', and 60 iterations of the bench workload) once per library in a child process each and compares parameters, scale,
+mode 'local', 60 iterations of the bench workload, and a short fit with all 10 475 vertices as contacts) once per library in a child process each and compares parameters, scale,
 camera_ext and the loss log bit for bit.   tools/compare_builds.py <libA.so> <libB.so>"""
 import os, subprocess, sys, tempfile
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -14,7 +14,8 @@ from fdcap_amd.io import read_camerapose
 out = {}
 def fit(tag, n, V, ns, per_part, iters, mode, log_every):
     bm = synth.make_body_model(V, seed=7); vp = synth.make_vposer(seed=8); clip = synth.make_clip(n, seed=9)
-    scene = synth.make_scene(ns, seed=10); l, r = synth.make_contact_ids(bm.v_template, per_part=per_part, seed=11)
+    scene = synth.make_scene(ns, seed=10); l, r = synth.make_contact_ids(bm.v_template, per_part=max(per_part, 1), seed=11)
+    if per_part == 0: l, r = np.arange(0, V // 2), np.arange(V // 2, V)        # every vertex a contact (BASELINE config 5's forms)
     fop = FittingOP({"num_iter": iters}, {}, n, body_model=bm, vposer=vp, scene_verts=scene, contact_ids=np.concatenate([l, r]),
                     camera_ext=read_camerapose(clip.camerapose_lines), n_left=len(l))
     b, s, c = fop.fitting(torch.tensor(clip.body_params).cuda(), mode, log_every=log_every)
@@ -25,6 +26,7 @@ def fit(tag, n, V, ns, per_part, iters, mode, log_every):
 fit("small", 37, 300, 6000, 20, 40, "global", 1)
 fit("local", 21, 300, 6000, 20, 30, "local", 1)
 fit("bench", 1024, 10475, 500000, 250, 60, "global", 0)
+fit("allverts", 24, 10475, 50000, 0, 12, "global", 1)
 np.savez(sys.argv[1], **out)
 '''
 res = []

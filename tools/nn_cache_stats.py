@@ -9,9 +9,11 @@ import fdcap_amd  # noqa
 from fdcap_amd import capi, synth
 from fdcap_amd.fitting import FittingOP, first_phase2_iter
 from fdcap_amd.io import read_camerapose
-N, ns = int(os.environ.get("FRAMES", "1024")), 500000
+C5 = os.environ.get("CONFIG") == "c5"                       # r6: BASELINE config 5 (512 frames, 2 M points, every vertex a contact)
+N, ns = int(os.environ.get("FRAMES", "512" if C5 else "1024")), (2000000 if C5 else 500000)
 bm = synth.make_body_model(10475, seed=0); vp = synth.make_vposer(seed=1); clip = synth.make_clip(N, seed=3)
 scene = synth.make_scene(ns, seed=2); l, r = synth.make_contact_ids(bm.v_template, per_part=250, seed=4)
+if C5: l, r = np.arange(0, 5237), np.arange(5237, 10475)
 fop = FittingOP({"num_iter": 500}, {}, N, body_model=bm, vposer=vp, scene_verts=scene, contact_ids=np.concatenate([l, r]),
                 camera_ext=read_camerapose(clip.camerapose_lines))
 lib, h = fop.ctx.lib, fop.ctx.handle
