@@ -1028,6 +1028,21 @@ static inline hipError_t panel_gemm3(const float* A, int lda, int M, int K, cons
         static std::atomic<int> cs_env{-1};                          // FDCAP_PN_WIDE_CS=1 (A/B): the r2-r4 form, one part
         if (cs_env < 0) { const char* e = getenv("FDCAP_PN_WIDE_CS"); cs_env = e ? atoi(e) : 0; }
         // (r5: two column tiles per wave, as in the K-loop product, measured no faster here: 0.186 vs 0.179 ms at 1024 rows, equal at 512)
+        static std::atomic<int> rb_env{-1};                          // FDCAP_PN_WIDE_RB=4 (A/B, r6): 64 rows per workgroup -- half the fragment bytes per MFMA
+        if (rb_env < 0) { const char* e = getenv("FDCAP_PN_WIDE_RB"); rb_env = e ? atoi(e) : 2; }
+        if (rb_env == 4 && M >= 64) {
+            const int nrb4 = (M + 63) / 64;
+            const int cs4 = cs_env > 0 ? (int)cs_env : std::max(1, std::min(cpg, (256 + 8 * nrb4 - 1) / (8 * nrb4)));
+            static std::atomic<uint64_t> attr4{0};
+            if (fdc_attr_needed(attr4)) {
+                hipError_t e = hipFuncSetAttribute((const void*)panel_gemm3_wide_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)pnf_lds_bytes(kpad, 4));
+                if (e != hipSuccess) return e;
+                fdc_attr_done(attr4);
+            }
+            note_form("panel_gemm3_wide_kernel<4>");
+            hipLaunchKernelGGL(panel_gemm3_wide_kernel<4>, dim3(8 * nrb4 * cs4), dim3(512), pnf_lds_bytes(kpad, 4), st, A, lda, M, K, B, C, ldc, N, cs4);
+            return hipGetLastError();
+        }
         const int cs = cs_env > 0 ? (int)cs_env : std::max(1, std::min(cpg, (256 + 8 * nrb - 1) / (8 * nrb)));
         note_form("panel_gemm3_wide_kernel"); hipLaunchKernelGGL(panel_gemm3_wide_kernel<2>, dim3(8 * nrb * cs), dim3(512), pnf_lds_bytes(kpad, 2), st, A, lda, M, K, B, C, ldc, N, cs);
         return hipGetLastError();

@@ -1,7 +1,9 @@
 #!/usr/bin/env python3
 """Are two builds of the library bit-identical in what they compute?  Runs the same fits (a small one with every loss term logged,
 mode 'local', 60 iterations of the bench workload, and a short fit with all 10 475 vertices as contacts) once per library in a child process each and compares parameters, scale,
-camera_ext and the loss log bit for bit.   tools/compare_builds.py <libA.so> <libB.so>"""
+camera_ext and the loss log bit for bit.   tools/compare_builds.py <libA.so> <libB.so>
+r6: an argument of the form NAME=value (instead of a path) runs the tree's library with that environment setting, so two
+settings of an A/B switch can be compared the same way:   tools/compare_builds.py FDCAP_PN_WIDE_RB=2 FDCAP_PN_WIDE_RB=4"""
 import os, subprocess, sys, tempfile
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 CHILD = r'''
@@ -32,7 +34,12 @@ np.savez(sys.argv[1], **out)
 res = []
 for lib in sys.argv[1:3]:
     f = tempfile.mktemp(suffix=".npz")
-    subprocess.run([sys.executable, "-c", CHILD % ROOT, f], env=dict(os.environ, FDCAP_LIB=os.path.abspath(lib)), check=True)
+    if "=" in lib and not os.path.exists(lib):
+        k, v = lib.split("=", 1)
+        env = dict(os.environ, **{k: v})
+    else:
+        env = dict(os.environ, FDCAP_LIB=os.path.abspath(lib))
+    subprocess.run([sys.executable, "-c", CHILD % ROOT, f], env=env, check=True)
     import numpy as np
     res.append(dict(np.load(f)))
 bad = 0
