@@ -147,7 +147,13 @@ __global__ __launch_bounds__(256) void nn_direct_kernel(const float* __restrict_
 //            point of a skipped chunk can beat or tie any query's bound.  (Boxes, not spheres: scanned
 //            surfaces give flat chunks, and a query 1 m above a floor patch must not pull in every
 //            patch within 1 m.)  Without seeds the bound is infinite and the scan is plain brute force.
-constexpr float MF_K1 = 1e-4f, MF_K2 = 8e-6f;
+#ifndef FDC_MF_K1
+#define FDC_MF_K1 1e-4f
+#endif
+#ifndef FDC_MF_K2
+#define FDC_MF_K2 8e-6f
+#endif
+constexpr float MF_K1 = FDC_MF_K1, MF_K2 = FDC_MF_K2;
 constexpr int MF_MAXCHUNK = 2048;      // chunks per split the survivor list can hold (host keeps splits below it)
 
 #ifdef FDC_NN_TIMELINE

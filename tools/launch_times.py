@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Live per-launch times of an iteration at given clip sizes (fdcap_opt_launch_timing through bench.time_all_launches):
-usage: python tools/launch_times.py [--config c3|c5|c2] frames [frames ...]     (one rank's share of a sharded clip = a smaller clip)"""
+usage: python tools/launch_times.py [--log] [--config c3|c5|c2] frames [frames ...]     (one rank's share of a sharded clip = a smaller clip)"""
 import json
 import os
 import sys
@@ -15,7 +15,9 @@ import bench  # noqa: E402
 
 def main():
     argv = sys.argv[1:]
-    cfg = "c3"
+    cfg, log_every = "c3", 0
+    if argv and argv[0] == "--log":                      # the every-iteration-logging fit (bench.py's with_reference_logging)
+        log_every, argv = 1, argv[1:]
     if argv and argv[0] == "--config":
         cfg, argv = argv[1], argv[2:]
     _, ns, allc = bench.CONFIGS[cfg]
@@ -23,7 +25,7 @@ def main():
         fop, body_gpu, *_ = bench.build_problem(frames, ns, allc, 10475, 4, 250, 500, None)
 
         def one_step():
-            b, sc, cam = fop.fitting(body_gpu, "global")
+            b, sc, cam = fop.fitting(body_gpu, "global", log_every=log_every)
             return b.cpu(), sc, cam.cpu()
         one_step()
         torch.cuda.synchronize()
