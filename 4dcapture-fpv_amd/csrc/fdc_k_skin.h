@@ -27,7 +27,7 @@ __global__ __launch_bounds__(256) void skin_fwd_kernel(SkinModel sm, int nv, con
     }
     const float sc_v = world ? *scale : 1.f;
     float* o = Vout + ((size_t)r * nv + c) * 3;
-    if (sm.vpack && !sm.S) {
+    if (sm.vpack && !FDC_SKIN_HAS_S(sm)) {
         // packed per-vertex constants (two 16-byte loads instead of eleven 4-byte ones); same terms, same order
         const float4* const vp4 = (const float4*)sm.vpack;
         const int G = (sm.K + 3) >> 2;                                       // (wave-uniform)
@@ -200,8 +200,12 @@ static_assert(NJ * 12 + SKB_NACC + 1 <= SKP_STRIDE, "partial record");
 #define FDC_SKB_WFQ 4
 #endif
 constexpr int SKB_WFQ = FDC_SKB_WFQ;                   // quads (of four steps) per block of the matrix-form dA (measured at config 5: 4 -> 231 us, 8 -> 239, 16 -> 261)
+#ifndef FDC_SKB_OCC
+#define FDC_SKB_OCC 5
+#endif
+constexpr int SKB_ROW = 6;                             // floats per vertex of the factored dT rows (matrix-form dA): gv[3] | vp[3]
 template <bool CONTACT, bool SPLIT = false>
-__global__ __launch_bounds__(256) void skin_bwd_kernel(SkinModel sm, int nc, const float* __restrict__ X,
+__global__ __launch_bounds__(256, FDC_SKB_OCC) void skin_bwd_kernel(SkinModel sm, int nc, const float* __restrict__ X,
                                                        const float* __restrict__ Voff, const float* __restrict__ A,
                                                        const float* __restrict__ M, const float* __restrict__ scale,
                                                        int row0, const float* dVw, float* dVoff,
@@ -262,7 +266,7 @@ __global__ __launch_bounds__(256) void skin_bwd_kernel(SkinModel sm, int nc, con
             }
             SkinBwd b = skin_backward_vertex(f, M + (size_t)r * 12, s, g);
             dVoff[3 * qi] = b.dvp.x; dVoff[3 * qi + 1] = b.dvp.y; dVoff[3 * qi + 2] = b.dvp.z;
-            if (sm.S)                                       // else: d betas = dVoff x shapedirs, columns 486.. of the blend data-gradient GEMM
+            if (FDC_SKIN_HAS_S(sm))                         // else: d betas = dVoff x shapedirs, columns 486.. of the blend data-gradient GEMM
                 for (int l = 0; l < NBETA; ++l)
                     acc[l] += sm.S[(3 * c) * 10 + l] * b.dvp.x + sm.S[(3 * c + 1) * 10 + l] * b.dvp.y +
                               sm.S[(3 * c + 2) * 10 + l] * b.dvp.z;
@@ -271,9 +275,9 @@ __global__ __launch_bounds__(256) void skin_bwd_kernel(SkinModel sm, int nc, con
             for (int e = 0; e < 12; ++e) acc[NBETA + 3 + e] += b.dM[e];
             acc[NBETA + 15] += b.ds;
             if (sm.wf_tab) {                                 // (kernel-uniform) matrix-form dA: dT_v = gv (x) [vp ; 1] stays factored -- 32 B per vertex
-                float* const t = sdT + (c - c0) * 8;            // instead of 48: four workgroups per CU instead of two (r6)
-                t[0] = b.gv.x; t[1] = b.gv.y; t[2] = b.gv.z; t[3] = 0.f;
-                t[4] = f.vp.x; t[5] = f.vp.y; t[6] = f.vp.z; t[7] = 1.f;
+                float* const t = sdT + (c - c0) * SKB_ROW;      // instead of 48: five workgroups per CU instead of two (r6)
+                t[0] = b.gv.x; t[1] = b.gv.y; t[2] = b.gv.z;
+                t[3] = f.vp.x; t[4] = f.vp.y; t[5] = f.vp.z;
             } else {
 #pragma unroll
                 for (int e = 0; e < 12; ++e) sdT[(c - c0) * 12 + e] = b.dT[e];
@@ -301,13 +305,15 @@ __global__ __launch_bounds__(256) void skin_bwd_kernel(SkinModel sm, int nc, con
             // waves' partial tiles added in wave order.  The list form spends 34 k of a chunk workgroup's 55 k cycles here (55 joints x
             // twelve wave sums per chunk, lists fetched joint by joint); a first matrix form with one 4-byte load per step took as
             // long -- 1000 vector-memory instructions per workgroup: their NUMBER binds, not their bytes.  Same terms, another order.
-            // r6: the LDS rows hold the FACTORS of dT_v = gv (x) [vp ; 1] (32 B per vertex; a lane forms its entry gv[e >> 2] * [vp ; 1][e & 3]
+            // r6: the LDS rows hold the FACTORS of dT_v = gv (x) [vp ; 1] (24 B per vertex; a lane forms its entry gv[e >> 2] * [vp ; 1][e & 3]
             // -- the product skin_backward_vertex forms, same bits -- when it reads it), and the waves' partial tiles go where the rows
-            // were once every wave is done with them: 38 KB of LDS per workgroup instead of 70, four workgroups per CU instead of two
-            // (the phase is a chain of latencies: fragment loads from L2, dependent LDS reads, one accumulator per tile).
+            // were once every wave is done with them: 30 KB of LDS per workgroup instead of 70, and with the register budget of five waves
+            // per SIMD (86 registers, no spills: the ten dead d-beta accumulators went with SkinModel::S) FIVE workgroups per CU instead
+            // of two (the phase is a chain of latencies: fragment loads from L2, dependent LDS reads, one accumulator per tile).
             float* const sPart = sdT;                                          // [4 waves][64 joints][16], after the barrier below
             const int e = lane & 15, kk = lane >> 4;
-            const int eg = min(e >> 2, 2), ep = 4 + (e & 3);
+            const int eg = min(e >> 2, 2), ep = 3 + min(e & 3, 2);
+            const bool one = (e & 3) == 3;                                     // dT[4 r + 3] = gv[r] * 1
             const int tb = ((c0 / VCH) * 4 + wave) * 4;
             typedef unsigned wf_u2 __attribute__((ext_vector_type(2)));
             typedef const wf_u2 __attribute__((address_space(4)))* wf_sp_t;    // (wave-uniform: s_load)
@@ -331,7 +337,7 @@ __global__ __launch_bounds__(256) void skin_bwd_kernel(SkinModel sm, int nc, con
                         const bool on = g0 + u < g_hi && e < 12;              // (padded quads multiply zeros: a uniform branch here measured slower)
                         const int v0 = 4 * (int)(st[u].x & 0xFFFFu) + kk, v1 = 4 * (int)(st[u].x >> 16) + kk;
                         const int v2 = 4 * (int)(st[u].y & 0xFFFFu) + kk, v3 = 4 * (int)(st[u].y >> 16) + kk;
-#define FDC_DT(v) ((on && c0 + (v) < c1) ? sdT[(v) * 8 + eg] * sdT[(v) * 8 + ep] : 0.f)
+#define FDC_DT(v) ((on && c0 + (v) < c1) ? sdT[(v) * SKB_ROW + eg] * (one ? 1.f : sdT[(v) * SKB_ROW + ep]) : 0.f)
                         dacc[jt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[u].x, FDC_DT(v0), dacc[jt], 0, 0, 0);
                         dacc[jt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[u].y, FDC_DT(v1), dacc[jt], 0, 0, 0);
                         dacc[jt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[u].z, FDC_DT(v2), dacc[jt], 0, 0, 0);

@@ -46,6 +46,15 @@ struct SkinModel {
     const float* wf_frag = nullptr;         // [quads][64][4]
 };
 
+// The per-vertex shapedirs rows (SkinModel::S) are only ever set by the HOST harness (tests/cpu_harness): every device-side vertex set
+// folds the shape blend into the blend product (build_skin_set leaves S null).  Device code therefore drops the branch at compile
+// time -- ten accumulator registers and their arithmetic in the skinning backward.
+#ifdef __HIP_DEVICE_COMPILE__
+#define FDC_SKIN_HAS_S(sm) false
+#else
+#define FDC_SKIN_HAS_S(sm) ((sm).S != nullptr)
+#endif
+
 FDC_HD int skin_vpack_planes(int K) { const int G = (K + 3) / 4; return G <= 1 ? 2 : G + 2; }
 
 struct SkinFwd { V3 vp, vb, vw; float T[12]; };
@@ -57,7 +66,7 @@ FDC_HD SkinFwd skin_forward_vertex(const SkinModel& sm, int v, const float* beta
     float p[3];
     for (int c = 0; c < 3; ++c) {
         float acc = sm.vt[3 * v + c];
-        if (sm.S) {
+        if (FDC_SKIN_HAS_S(sm)) {
             const float* s = sm.S + (3 * v + c) * 10;
             for (int l = 0; l < 10; ++l) acc += s[l] * beta[l];
         }

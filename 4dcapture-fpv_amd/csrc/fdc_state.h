@@ -56,9 +56,9 @@ static int skin_bwd_any(DevBuf<float>& part, hipStream_t st, int nrows, SkinMode
                         float* dtransl_v, float* dMv, float* dsv, ContactGradIn cg) {
     static std::atomic<int> split_on{-1};                              // FDCAP_SKIN_SPLIT=0: the one-workgroup-per-frame form at every size (A/B)
     if (split_on < 0) { const char* e = getenv("FDCAP_SKIN_SPLIT"); split_on = (e && e[0] == '0') ? 0 : 1; }
-    // dT rows: 12 floats per vertex for the list form; the matrix form keeps them factored (8 floats) and reuses the space for its
+    // dT rows: 12 floats per vertex for the list form; the matrix form keeps them factored (SKB_ROW = 6 floats) and reuses the space for its
     // four waves' partial tiles (16 KB: more than 512 vertices of rows, which is when the matrix form is built)
-    const size_t lds = sm.wf_tab ? std::max((size_t)std::min(nc, SKB_VCH) * 8, (size_t)4 * 64 * 16) * sizeof(float)
+    const size_t lds = sm.wf_tab ? std::max((size_t)std::min(nc, SKB_VCH) * SKB_ROW, (size_t)4 * 64 * 16) * sizeof(float)
                                  : (size_t)std::min(nc, SKB_VCH) * 12 * sizeof(float);
     if (nc <= SKB_VCH || !split_on) {
         note_form("skin_bwd_kernel(one workgroup per frame)");
