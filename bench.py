@@ -534,6 +534,10 @@ def nn_roofline(pk, src, sec_loop, ms_steady, n_timed, alg_bytes):
                                  "sustained in the PMC pass.  frac is the mean over the whole launch: the port is saturated while all 8 wave "
                                  "slots per SIMD are filled and idles through the drain (mean_waves_per_simd); HBM and the matrix pipe are far "
                                  "from their limits"})
+        if roofline["frac"] > 0.97:
+            roofline["frac_note"] = ("saturated: the instruction prices are measured means (+-3 %) and the counters come from another run of the same "
+                                     "configuration, so a VALU-bound launch can read a few per cent above 1; long launches of this configuration also run "
+                                     "below the 2.4 GHz maximum (clock_ghz_under_pmc: the chip's power limit), which `peak` reflects")
     else:
         roofline.update({"bound": "hbm", "achieved": None, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": None, "traffic": None,
                          "note": "no committed PMC summary for these sizes (profiles/r5_<config>_pmc_summary.json exist for BASELINE configs 3, 5 "
