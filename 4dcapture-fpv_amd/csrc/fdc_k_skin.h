@@ -200,8 +200,41 @@ static_assert(NJ * 12 + SKB_NACC + 1 <= SKP_STRIDE, "partial record");
 #define FDC_SKB_WFQ 4
 #endif
 constexpr int SKB_WFQ = FDC_SKB_WFQ;                   // quads (of four steps) per block of the matrix-form dA (measured at config 5: 4 -> 231 us, 8 -> 239, 16 -> 261)
+// skin_forward_vertex for a vertex whose constants come packed (SkinModel::vpack planes 0 and 1: K <= 4), the skinning transforms
+// read as 16-byte LDS rows: the same terms in the same order (padding weights are zeros on joint 0, as in the unpacked lists)
+__device__ __forceinline__ SkinFwd skin_forward_vertex_packed(const float4 p0, const float4 p1, int K, const float* __restrict__ voff,
+                                                              const float* sA /* LDS, 16-byte aligned */, V3 transl, const float* M, float scale) {
+    SkinFwd r;
+    const float px = p0.x + voff[0], py = p0.y + voff[1], pz = p0.z + voff[2];
+    r.vp = v3(px, py, pz);
+    const unsigned jb = __float_as_uint(p0.w);
+    const float w4[4] = {p1.x, p1.y, p1.z, p1.w};
+#pragma unroll
+    for (int e = 0; e < 12; ++e) r.T[e] = 0.f;
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+        if (k < K) {
+            const float4* a = (const float4*)(sA + 12 * ((jb >> (8 * k)) & 255u));
+            const float4 a0 = a[0], a1 = a[1], a2 = a[2];
+            const float w = w4[k];
+            r.T[0] += w * a0.x; r.T[1] += w * a0.y; r.T[2] += w * a0.z; r.T[3] += w * a0.w;
+            r.T[4] += w * a1.x; r.T[5] += w * a1.y; r.T[6] += w * a1.z; r.T[7] += w * a1.w;
+            r.T[8] += w * a2.x; r.T[9] += w * a2.y; r.T[10] += w * a2.z; r.T[11] += w * a2.w;
+        }
+    const V3 vl = v3(r.T[0] * px + r.T[1] * py + r.T[2] * pz + r.T[3], r.T[4] * px + r.T[5] * py + r.T[6] * pz + r.T[7],
+                     r.T[8] * px + r.T[9] * py + r.T[10] * pz + r.T[11]);
+    r.vb = vl + transl;
+    const V3 sv = scale * r.vb;
+    r.vw = v3(M[0] * sv.x + M[1] * sv.y + M[2] * sv.z + M[3], M[4] * sv.x + M[5] * sv.y + M[6] * sv.z + M[7],
+              M[8] * sv.x + M[9] * sv.y + M[10] * sv.z + M[11]);
+    return r;
+}
+
 #ifndef FDC_SKB_OCC
 #define FDC_SKB_OCC 5
+#endif
+#ifndef FDC_SKB_PACKED
+#define FDC_SKB_PACKED 1
 #endif
 constexpr int SKB_ROW = 6;                             // floats per vertex of the factored dT rows (matrix-form dA): gv[3] | vp[3]
 template <bool CONTACT, bool SPLIT = false>
@@ -226,8 +259,12 @@ __global__ __launch_bounds__(256, FDC_SKB_OCC) void skin_bwd_kernel(SkinModel sm
     float cterm = 0.f;
     // lane j of every wave: joint j's range in the transposed weight list (loaded once, while the vertex phase runs)
     const int jlo = lane < NJ ? sm.csc_start[lane] : 0, jhi = lane < NJ ? sm.csc_start[lane + 1] : 0;
-    __shared__ float sAf[NJ * 12];                  // this frame's skinning transforms (see skin_fwd_kernel)
+    __shared__ __attribute__((aligned(16))) float sAf[NJ * 12];   // this frame's skinning transforms (see skin_fwd_kernel)
+    __shared__ float sM[12];                        // ... and its world matrix (r6: every vertex read it from global memory twice)
     for (int i = tid; i < NJ * 12; i += 256) sAf[i] = A[(size_t)r * NJ * 12 + i];
+    if (tid < 12) sM[tid] = M[(size_t)r * 12 + tid];
+    const bool packed = FDC_SKB_PACKED && sm.vpack && sm.K <= 4;             // (kernel-uniform)
+    const float4* const vp4 = (const float4*)sm.vpack;
 #pragma unroll
     for (int i = 0; i < SKB_NACC; ++i) acc[i] = 0.f;
     for (int i = tid; i < NJ * 12; i += 256) sdA[i] = 0.f;
@@ -252,7 +289,9 @@ __global__ __launch_bounds__(256, FDC_SKB_OCC) void skin_bwd_kernel(SkinModel sm
                 if (cg.nnpt) pq = cg.nnpt[qi];                                   // kernel-uniform
                 vwx = cg.Vw[3 * qi]; vwy = cg.Vw[3 * qi + 1]; vwz = cg.Vw[3 * qi + 2];
             }
-            SkinFwd f = skin_forward_vertex(sm, c, x + X_BETAS, Voff + 3 * qi, sAf, transl, M + (size_t)r * 12, s);
+            SkinFwd f;
+            if (packed) f = skin_forward_vertex_packed(vp4[c], vp4[nc + c], sm.K, Voff + 3 * qi, sAf, transl, sM, s);
+            else f = skin_forward_vertex(sm, c, x + X_BETAS, Voff + 3 * qi, sAf, transl, sM, s);
             V3 g;
             if (CONTACT) {
                 float dterm;
@@ -264,7 +303,7 @@ __global__ __launch_bounds__(256, FDC_SKB_OCC) void skin_bwd_kernel(SkinModel sm
             } else {
                 g = v3(dVw[3 * qi], dVw[3 * qi + 1], dVw[3 * qi + 2]);
             }
-            SkinBwd b = skin_backward_vertex(f, M + (size_t)r * 12, s, g);
+            SkinBwd b = skin_backward_vertex(f, sM, s, g);
             dVoff[3 * qi] = b.dvp.x; dVoff[3 * qi + 1] = b.dvp.y; dVoff[3 * qi + 2] = b.dvp.z;
             if (FDC_SKIN_HAS_S(sm))                         // else: d betas = dVoff x shapedirs, columns 486.. of the blend data-gradient GEMM
                 for (int l = 0; l < NBETA; ++l)
