@@ -146,3 +146,34 @@ def test_device_packed_operands_give_the_host_packed_fit_bit_for_bit(n, V, per_p
     assert a[1] == b[1]
     np.testing.assert_array_equal(a[2], b[2])
     np.testing.assert_array_equal(a[3], b[3])
+
+
+def test_launch_timing_books_every_launch_of_every_iteration():
+    """fdcap_opt_launch_timing (bench.py's roofline.per_kernel[].us_live): one interval per launch and iteration, booked on the right
+    stage and phase -- a 20-iteration fit with the phase switch at 16 has 16 samples of all eight stages in phase 1 and 4 samples of the
+    four pose / VPoser stages in phase 2 -- and leaves the fit's results untouched."""
+    from fdcap_amd.fitting import FittingOP
+    from fdcap_amd.io import read_camerapose
+    n, iters = 48, 20
+    bm = synth.make_body_model(600, seed=0)
+    vp = synth.make_vposer(seed=1)
+    clip = synth.make_clip(n, seed=3)
+    scene = synth.make_scene(8000, seed=2)
+    left, right = synth.make_contact_ids(bm.v_template, per_part=20, seed=4)
+    fop = FittingOP({"num_iter": iters}, {}, n, body_model=bm, vposer=vp, scene_verts=scene, contact_ids=np.concatenate([left, right]),
+                    camera_ext=read_camerapose(clip.camerapose_lines))
+    body = torch.tensor(clip.body_params).cuda()
+    ref = fop.fitting(body, "global")[0].cpu().numpy().copy()
+    lib, h = fop.ctx.lib, fop.ctx.handle
+    capi.check(lib.fdcap_opt_launch_timing(h, 10 * iters + 16), "fdcap_opt_launch_timing")
+    out = fop.fitting(body, "global")[0].cpu().numpy()
+    us = (ctypes.c_float * 16)()
+    cnt = (ctypes.c_int32 * 16)()
+    capi.check(lib.fdcap_opt_launch_timing_read(h, us, cnt), "fdcap_opt_launch_timing_read")
+    capi.check(lib.fdcap_opt_launch_timing(h, 0), "fdcap_opt_launch_timing")
+    np.testing.assert_array_equal(out, ref)
+    assert list(cnt[:8]) == [16] * 8, list(cnt)
+    assert list(cnt[8:]) == [4, 4, 0, 0, 0, 0, 4, 4], list(cnt)
+    live = [us[i] for i in range(16) if cnt[i]]
+    assert all(0.5 < v < 2000.0 for v in live), live
+    fop.close()
