@@ -50,6 +50,16 @@ inline int clip_forms_min_rows() {
     return v;
 }
 
+// ... and for the K-split data gradient (panel_gemm3_rb2k): from 257 rows.  r6 (tools/launch_times.py): the one-tile-stream form
+// (panel_gemm3_ksw) keeps one workgroup per CU, so from 17 row blocks x 16 column groups = 272 workgroups on it runs in two rounds --
+// 16.6 us at 272-352 rows against 9.7 at 256 -- while the two-row-block K-split form takes 10.7-11.0 us there: a 300-frame clip
+// (the reference's real clip length) 42.4 -> 40.0 ms per fit.  At 256 rows and below the one-round form wins (9.7 vs 11.2 us).
+inline int clip_kgrad_min_rows() {
+    static std::atomic<int> v{-1};
+    if (v < 0) { const char* e = getenv("FDCAP_CLIP_FORMS_MIN_ROWS"); v = e ? std::max(32, atoi(e)) : 257; }
+    return v;
+}
+
 // B operand in fragment order: f[(tile * nss + s) * 64 + lane] = { B(16 s + 4 (lane >> 4) + m, 16 tile + (lane & 15)) }, m = 0..3
 struct PanelB {
     const float4* f = nullptr;
@@ -956,7 +966,7 @@ static inline bool panel_gemm3_rb2k_ok(int M, int K, const PanelB3& B) {
     static std::atomic<int> rb2{-1};
     if (rb2 < 0) { const char* e = getenv("FDCAP_PN_RB2"); rb2 = e ? atoi(e) : 1; }     // 0 off, 1 both forms, 2 forward only, 3 K-split only
     const int nst_all = (K + 31) >> 5;
-    return (rb2 == 1 || rb2 == 3) && M >= clip_forms_min_rows() && B.ntile <= 32 && nst_all >= 2 && 32 * ((nst_all + 1) / 2) <= 768;
+    return (rb2 == 1 || rb2 == 3) && M >= clip_kgrad_min_rows() && B.ntile <= 32 && nst_all >= 2 && 32 * ((nst_all + 1) / 2) <= 768;
 }
 static inline hipError_t panel_gemm3_rb2k(const float* A, int lda, int M, int K, const PanelB3& B, float* Cpart, size_t part_stride,
                                           int ldc, int N, hipStream_t st) {
