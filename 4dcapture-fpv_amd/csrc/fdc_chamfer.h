@@ -1420,7 +1420,9 @@ static inline hipError_t nn_search(const float* q, int nq, const NNTarget& T, fl
             int nqv = 1, wpg;
             if (use_stream < 0) {                             // enough waves to fill 1024 SIMDs x 4 twice over, no more (the
                 const int g32 = (nq + 31) / 32;               // per-group setup is repeated by every wave of the group)
-                wpg = g32 >= 3072 ? 1 : 4;                    // re-measured with quarter work items: 128 / 256 / 512 / 768 frames: 11: 0.036 / 0.033 / 0.057 / 0.068 ms, 21: 0.028 / 0.034 / 0.059 / 0.074, 41: 0.024 / 0.036 / 0.063 / 0.084
+                // r6 sweep (tools/launch_times.py at 64 .. 224 frames x 500 queries, us per launch; waves per group 1 / 2 / 4):
+                //   2000 groups 25.8 / 23.7 / 22.7, 2500: 25.1 / 24.2 / 25.5, 3000: 25.8 / 26.8 / 28.7, 3500: 24.1 / 26.9 / 30.1
+                wpg = g32 >= 2816 ? 1 : g32 >= 2304 ? 2 : 4;  // (3072 / 4 until r6) re-measured with quarter work items: 128 / 256 / 512 / 768 frames: 11: 0.036 / 0.033 / 0.057 / 0.068 ms, 21: 0.028 / 0.034 / 0.059 / 0.074, 41: 0.024 / 0.036 / 0.063 / 0.084
             } else {
                 nqv = (use_stream % 10 == 2) ? 2 : 1;
                 wpg = (use_stream / 10 == 4) ? 4 : (use_stream / 10 == 2) ? 2 : 1;

@@ -1395,11 +1395,13 @@ static inline hipError_t panel_gemm3_ksw(const float* A, int lda, int M, int K, 
         if (e != hipSuccess) return e;
         fdc_attr_done(attr);
     }
-    // column tiles per workgroup: two while that still gives >= 192 workgroups, else one (FDCAP_PN_KSW_T pins it: A/B)
+    // column tiles per workgroup: two while that still gives >= 192 workgroups, else one (FDCAP_PN_KSW_T pins it: A/B) -- r6: and two
+    // whenever one tile per workgroup would mean more workgroups than CUs (one workgroup fits a CU: 129-176 rows ran in two rounds,
+    // 14.7 us at 160 rows against 8.8 at 128 and 9.5 at 192: tools/launch_times.py sweep)
     static std::atomic<int> t_env{-1};
     if (t_env < 0) { const char* e = getenv("FDCAP_PN_KSW_T"); t_env = e ? atoi(e) : 0; }
     const int nrb = (M + 15) / 16;
-    int T = nrb * ((B.ntile + 1) / 2) >= 192 ? 2 : 1;
+    int T = (nrb * ((B.ntile + 1) / 2) >= 192 || nrb * B.ntile > 256) ? 2 : 1;
     if (t_env == 1 || t_env == 2) T = t_env;
     const PnMap mp = panel_map(nrb, (B.ntile + T - 1) / T, (size_t)M * K * 4, (size_t)B.ntile * B.nst * PNF * 1024);
     note_form("panel_gemm3_ksw_kernel");
