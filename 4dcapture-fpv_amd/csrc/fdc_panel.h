@@ -1511,8 +1511,12 @@ static inline int panel_gemm3_kloop_parts(int M, const PanelB3& B) {
     const int rb = panel_gemm3_kloop_rb(), T = panel_gemm3_kloop_t(), ncb = (B.ntile + 8 * T - 1) / (8 * T), nrp = (M + 16 * rb - 1) / (16 * rb);
     static std::atomic<int> wgs{-1};                                         // FDCAP_KLOOP_WGS (A/B): workgroups to aim for
     if (wgs < 0) { const char* e = getenv("FDCAP_KLOOP_WGS"); wgs = e ? atoi(e) : 256; }
-    int ks = std::max(1, (wgs + ncb * nrp - 1) / (ncb * nrp));
-    while ((ks * ncb) % 8 != 0 && ks < 64) ++ks;
+    // r6: the LARGEST admissible part count that still fits one round of workgroups (a workgroup fills a CU's LDS: one per CU).  The
+    // count used to be rounded UP to the next admissible one -- 288-336 workgroups at 96 / 192 / 320 / 384 / 448 rows, two rounds:
+    // 141.8 us at 384 rows against 113.9 at 512 (tools/launch_times.py --config c5 sweep).
+    int ks = std::min(64, std::max(1, wgs / (ncb * nrp)));
+    while (ks > 1 && (ks * ncb) % 8 != 0) --ks;
+    if ((ks * ncb) % 8 != 0) { ks = 1; while ((ks * ncb) % 8 != 0 && ks < 64) ++ks; }       // (nothing admissible below: the smallest above)
     return std::min(ks, 64);
 }
 // C [M rows of ldc] = sum of the parts; `part` must hold ks x M x ldc floats (panel_gemm3_kloop_parts)

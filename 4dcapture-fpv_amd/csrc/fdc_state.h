@@ -547,8 +547,14 @@ hipError_t blend_backward(const SkinSet& ss, const float* dV, int M, float* dPF,
             *split = true;
             return panel_gemm3_rb2k(dV, K, M, K, ss.pn_bwd3, dPF, part2_stride, NPFX, NPFX, st);
         }
-        if (panel_gemm3_ksw_ok(M, K, ss.pn_bwd3)) return panel_gemm3_ksw(dV, K, M, K, ss.pn_bwd3, dPF, NPFX, NPFX, st);
-        if (panel_gemm3_fits(K)) return panel_gemm3(dV, K, M, K, ss.pn_bwd3, dPF, NPFX, NPFX, st);
+        // r6: the K-loop form also where one LDS image would still fit, from K = 1664 at clip sizes and K = 1904 from 192 rows -- contact
+        // sets of 560-840 vertices ran the one-image forms at 17-35 us where the K-loop form takes 14-21 (tools/launch_times.py
+        // --per-leg 280 / 320 / 375 / 420 at 1024 / 512 / 256 / 128 rows; at 128 rows the one-image forms stay ahead).  FDCAP_KLOOP_MIN_K: A/B.
+        static std::atomic<int> kmin{-1};
+        if (kmin < 0) { const char* e = getenv("FDCAP_KLOOP_MIN_K"); kmin = e ? atoi(e) : 1664; }
+        const bool big_k = (M >= 384 && K >= kmin) || (M >= 192 && K >= kmin + 240);
+        if (!big_k && panel_gemm3_ksw_ok(M, K, ss.pn_bwd3)) return panel_gemm3_ksw(dV, K, M, K, ss.pn_bwd3, dPF, NPFX, NPFX, st);
+        if (!big_k && panel_gemm3_fits(K)) return panel_gemm3(dV, K, M, K, ss.pn_bwd3, dPF, NPFX, NPFX, st);
         hipError_t e = ws.ensure((size_t)panel_gemm3_kloop_parts(M, ss.pn_bwd3) * M * NPFX);
         if (e != hipSuccess) return e;
         return panel_gemm3_kloop(dV, K, M, K, ss.pn_bwd3, ws.p, dPF, NPFX, NPFX, st);
