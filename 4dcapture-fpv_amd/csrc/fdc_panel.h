@@ -42,11 +42,12 @@ inline void fdc_attr_done(std::atomic<uint64_t>& mask) { int d = 0; (void)hipGet
 typedef float f32x4_t __attribute__((ext_vector_type(4)));
 
 // Row count from which the clip-sized kernel forms are selected (two row blocks per fragment stream in the blend products, the
-// fused contact forward): measured break-even 384.  FDCAP_CLIP_FORMS_MIN_ROWS overrides it -- tests run the reference's own
+// fused contact forward): measured break-even 336 (r6 sweep: contact forward as two launches / fused 11.7 / 12.6 us at 320 rows,
+// 13.7 / 12.8 at 352; 384 until then).  FDCAP_CLIP_FORMS_MIN_ROWS overrides it -- tests run the reference's own
 // 300-frame fixtures (the reference hard-codes 300, :41-42) through the forms BASELINE configs 2 / 3 / 5 select.
 inline int clip_forms_min_rows() {
     static std::atomic<int> v{-1};
-    if (v < 0) { const char* e = getenv("FDCAP_CLIP_FORMS_MIN_ROWS"); v = e ? std::max(32, atoi(e)) : 384; }
+    if (v < 0) { const char* e = getenv("FDCAP_CLIP_FORMS_MIN_ROWS"); v = e ? std::max(32, atoi(e)) : 336; }
     return v;
 }
 

@@ -106,7 +106,7 @@ int fdcap_debug_scene_hash(fdcap_ctx* ctx, uint64_t* out8);
 /* Diagnosis: names of the kernel FORMS launched by this process since the last reset, "a;b;c" (several stages pick among forms by
  * row count and set size: blend products, contact forward, skinning backward, the Chamfer search).  Tests that mean to cover a form
  * check that it ran.  FDCAP_CLIP_FORMS_MIN_ROWS (environment, read once per process) lowers the row count from which the
- * clip-sized forms are selected (default 384): the reference's 300-frame fixtures then run through them. */
+ * clip-sized forms are selected (default 336): the reference's 300-frame fixtures then run through them. */
 int fdcap_debug_kernel_forms(char* buf, int32_t len, int32_t reset);
 /* Contact vertex ids = get_contact_id(...) (global_optimization.py:79-94, :288); HOST pointer. */
 int fdcap_set_contact_ids(fdcap_ctx* ctx, const int64_t* vid, int32_t nc);
