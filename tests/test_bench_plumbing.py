@@ -114,7 +114,7 @@ def _bench_module():
 
 def test_config_presets_and_the_blocks_built_from_the_committed_profiles():
     """r5: `--config` presets, and the two blocks of the line that are arithmetic on COMMITTED files (no GPU needed to check them):
-    `roofline.per_kernel` from profiles/r5_c3_pmc_summary.json -- every launch of a phase-1 iteration (eight since the blend forward and
+    `roofline.per_kernel` from profiles/r6_c3_pmc_summary.json (r5's until r6) -- every launch of a phase-1 iteration (eight since the blend forward and
     the skinning forward are one launch), each with its time, its
     work and a fraction of its binding peak in (0, 1) -- and the counter fractions of configs 5 and 2 (`other_configs`)."""
     b = _bench_module()
@@ -125,10 +125,17 @@ def test_config_presets_and_the_blocks_built_from_the_committed_profiles():
     assert b.which_config(1024, 500_000, 500, 10475, 4) == "c3" and b.which_config(512, 2_000_000, 10475, 10475, 4) == "c5"
     assert b.which_config(1024, 500_000, 500, 10475, 8) is None and b.which_config(1000, 500_000, 500, 10475, 4) is None
     pmc, src = b.load_pmc("c3")
-    assert src == os.path.join("profiles", "r5_c3_pmc_summary.json")
+    assert src == os.path.join("profiles", "r6_c3_pmc_summary.json")          # (the newest committed round)
     t = b.per_kernel_table(pmc["kernels"], 1024, 500, 4, src)
     ks = t["kernels"]
     assert len(ks) == 8 and abs(sum(k["us"] for k in ks) - t["phase1_iteration_us"]) < 1e-6
+    assert all(k["us_live"] is None and k["us"] == k["us_trace"] for k in ks)       # no live times without a GPU: the trace's
+    # r6: with live times (fdcap_opt_launch_timing) the table's microseconds and fractions are the LIVE ones, the trace's stay beside them
+    live = {"phase1": {n: {"us": 10.0 + i, "us_corrected": 8.0 + i, "launches": 400} for i, n in enumerate(b.LT_STAGES)}, "phase2": {},
+            "event_overhead_us_per_launch": 2.0}
+    tl = b.per_kernel_table(pmc["kernels"], 1024, 500, 4, src, live)
+    assert [k["us_live"] for k in tl["kernels"]] == [8.0 + i for i in range(8)] and all(k["us"] == k["us_live"] for k in tl["kernels"])
+    assert abs(tl["phase1_iteration_us_live"] - sum(8.0 + i for i in range(8))) < 1e-9 and tl["phase1_iteration_us_trace"] == t["phase1_iteration_us"]
     assert 120.0 < t["phase1_iteration_us"] < 170.0
     assert [k["bound"] for k in ks] == ["mfma", "hbm", "mfma", "valu_issue", "hbm", "mfma", "hbm", "mfma"]
     for k in ks:
@@ -136,7 +143,7 @@ def test_config_presets_and_the_blocks_built_from_the_committed_profiles():
             assert 0.0 < k["frac"] < 1.0 and 0.0 < k["floor_us"] < k["us"], k
     rl, _ = b.nn_roofline(pmc["kernels"], src, 60e-6, 0.052, 400, 1024 * (12.0 * 500_000 + 20.0 * 500))
     assert rl["bound"] == "valu_issue" and 0.3 < rl["frac"] < 1.0 and rl["contract"]["frac_on_algorithmic_bytes"] > 1.0
-    for cfg, t_launch in (("c5", 1.15e-3), ("c2", 18e-6)):
+    for cfg, t_launch in (("c5", 0.9e-3), ("c2", 18e-6)):
         pk, s2 = b.load_pmc(cfg)
         rl, nn = b.nn_roofline(pk["kernels"], s2, t_launch, t_launch * 1e3, 400, 1.0)
         assert rl["bound"] == "valu_issue" and 0.1 < rl["frac"] < 1.0 and 0.0 < rl["hbm_frac_on_counter_bytes"] < 1.0, (cfg, rl)
