@@ -325,13 +325,16 @@ int pnf_pack_dev(const float* src, size_t src_floats, long sk, long sn, int K, i
     }
     *ntile = nt; *nst = ns;
     const size_t lanes = (size_t)nt * ns * 64;
-    DevBuf<float> scl;
-    HIP_TRY(out.ensure(lanes * 2 * 4)); HIP_TRY(isc.ensure((size_t)nt * 16)); HIP_TRY(scl.ensure((size_t)nt * 16));
-    if (sn == 1) hipLaunchKernelGGL(pnh2_colscale_rowmajor_kernel, dim3((nt * 16 + 255) / 256), dim3(256), 0, 0, src, sk, K, N, nt * 16, scl.p, isc.p);
-    else hipLaunchKernelGGL(pnh2_colscale_colmajor_kernel, dim3(nt * 16), dim3(256), 0, 0, src, sn, K, N, nt * 16, scl.p, isc.p);
-    hipLaunchKernelGGL(pnh2_pack_kernel, dim3((unsigned)((lanes + 255) / 256)), dim3(256), 0, 0, src, sk, sn, K, N, nt, ns, scl.p, (uint4*)out.p);
-    hipError_t e = hipGetLastError();
-    if (e == hipSuccess) e = hipDeviceSynchronize();              // (scl is freed on return)
+    HIP_TRY(out.ensure(lanes * 2 * 4)); HIP_TRY(isc.ensure((size_t)nt * 16));
+    DevBuf<float> scl;                                            // the columns' scales: only the packing launch needs them
+    hipError_t e = scl.ensure((size_t)nt * 16);
+    if (e == hipSuccess) {
+        if (sn == 1) hipLaunchKernelGGL(pnh2_colscale_rowmajor_kernel, dim3((nt * 16 + 255) / 256), dim3(256), 0, 0, src, sk, K, N, nt * 16, scl.p, isc.p);
+        else hipLaunchKernelGGL(pnh2_colscale_colmajor_kernel, dim3(nt * 16), dim3(256), 0, 0, src, sn, K, N, nt * 16, scl.p, isc.p);
+        hipLaunchKernelGGL(pnh2_pack_kernel, dim3((unsigned)((lanes + 255) / 256)), dim3(256), 0, 0, src, sk, sn, K, N, nt, ns, scl.p, (uint4*)out.p);
+        e = hipGetLastError();
+        if (e == hipSuccess) e = hipDeviceSynchronize();          // (scl is freed below: the launch must be done with it)
+    }
     scl.release();
     return (int)e;
 }
@@ -366,7 +369,7 @@ int build_skin_set(fdcap_ctx* c, const std::vector<int64_t>& ids, SkinSet* out) 
         std::vector<int> id32((size_t)std::max(nv, 1), 0);
         for (int i = 0; i < nv; ++i) id32[i] = (int)ids[i];
         DevBuf<int> d_ids;
-        HIP_TRY(d_ids.upload(id32.data(), id32.size()));
+        { hipError_t eu = d_ids.upload(id32.data(), id32.size()); if (eu != hipSuccess) { d_ids.release(); return (int)eu; } }
         if (ldp > 0) hipLaunchKernelGGL(blend_rows_gather_kernel, dim3((ldp + 255) / 256, NPFX), dim3(256), 0, 0, c->d_posedirs.p, c->d_S10.p, V, d_ids.p, nv, ldp, out->posedirs.p);
         hipError_t e_ = hipGetLastError();
         if (e_ == hipSuccess) e_ = hipDeviceSynchronize();
@@ -501,7 +504,7 @@ int build_skin_set(fdcap_ctx* c, const std::vector<int64_t>& ids, SkinSet* out) 
     if (nv > 0 && nv <= 512 && K <= 4) {          // ... and with permuted columns (blend_rows_permute_kernel)
         const int nb = (nv + 63) / 64, ncs = nb * 192;
         DevBuf<float> ps;
-        HIP_TRY(ps.ensure((size_t)NPFX * ncs));
+        { hipError_t ep = ps.ensure((size_t)NPFX * ncs); if (ep != hipSuccess) return (int)ep; }
         hipLaunchKernelGGL(blend_rows_permute_kernel, dim3((ncs + 255) / 256, NPFX), dim3(256), 0, 0, pd, ldp, nv, ncs, ps.p);
         int e = (int)hipGetLastError();
         if (!e) e = pnf_pack_dev(ps.p, (size_t)NPFX * ncs, ncs, 1, NPFX, ncs, out->pn_fwdS_f, out->pn_fwdS_s, &out->pn_fwdS.ntile, &out->pn_fwdS.nst);

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Live per-launch times of an iteration at given clip sizes (fdcap_opt_launch_timing through bench.time_all_launches):
-usage: python tools/launch_times.py [--log] [--config c3|c5|c2] [--scene NS] [--per-leg N] frames [frames ...]     (one rank's share of a sharded clip = a smaller clip)"""
+usage: python tools/launch_times.py [--log] [--config c3|c5|c2] [--scene NS] [--lbs-nnz K] [--per-leg N] frames [frames ...]     (one rank's share of a sharded clip = a smaller clip)"""
 import json
 import os
 import sys
@@ -23,13 +23,16 @@ def main():
     ns_over = None
     if argv and argv[0] == "--scene":                    # scene points (overrides the configuration's)
         ns_over, argv = int(argv[1]), argv[2:]
+    lbs = 4
+    if argv and argv[0] == "--lbs-nnz":                  # skinning weights per vertex of the synthetic body model
+        lbs, argv = int(argv[1]), argv[2:]
     per_leg = 250
     if argv and argv[0] == "--per-leg":                  # contact vertices per leg (BASELINE: 250 -> 500 contact vertices)
         per_leg, argv = int(argv[1]), argv[2:]
     _, ns, allc = bench.CONFIGS[cfg]
     ns = ns_over or ns
     for frames in [int(a) for a in argv]:
-        fop, body_gpu, *_ = bench.build_problem(frames, ns, allc, 10475, 4, per_leg, 500, None)
+        fop, body_gpu, *_ = bench.build_problem(frames, ns, allc, 10475, lbs, per_leg, 500, None)
 
         def one_step():
             b, sc, cam = fop.fitting(body_gpu, "global", log_every=log_every)
