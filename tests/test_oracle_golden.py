@@ -38,7 +38,7 @@ def test_units_against_reference_functions(golden_dir):
     np.testing.assert_array_equal(body_params_parse(d), u["parse_out"])
 
 
-_SLOW = pytest.mark.skipif(os.environ.get("FDCAP_SLOW_TESTS") != "1", reason="~10 min of CPU each (V = 10 475): FDCAP_SLOW_TESTS=1; "
+_SLOW = pytest.mark.skipif(os.environ.get("FDCAP_SLOW_TESTS") != "1", reason="10 / 63 min of CPU (V = 10 475): FDCAP_SLOW_TESTS=1; "
                            "run once in the build container when the fixture was made (DESIGN section 7)")
 
 
