@@ -358,33 +358,42 @@ __global__ __launch_bounds__(256, FDC_SKB_OCC) void skin_bwd_kernel(SkinModel sm
             typedef const wf_u2 __attribute__((address_space(4)))* wf_sp_t;    // (wave-uniform: s_load)
             const wf_sp_t steps_c = (wf_sp_t)(const void*)sm.wf_step;
             f32x4_t dacc[4];
-#pragma unroll
-            for (int jt = 0; jt < 4; ++jt) {
-                const int g_lo = sm.wf_tab[tb + jt], g_hi = sm.wf_tab[tb + jt + 1];     // (wave-uniform) quads
-                dacc[jt] = f32x4_t{0.f, 0.f, 0.f, 0.f};
-                for (int g0 = g_lo; g0 < g_hi; g0 += SKB_WFQ) {                  // blocks of SKB_WFQ quads: all their loads first
-                    float4 a[SKB_WFQ];
-                    wf_u2 st[SKB_WFQ];
-#pragma unroll
-                    for (int u = 0; u < SKB_WFQ; ++u) {
-                        const int gc = min(g0 + u, g_hi - 1);
-                        a[u] = ((const float4*)sm.wf_frag)[(size_t)gc * 64 + lane];
-                        st[u] = steps_c[gc];
-                    }
-#pragma unroll
-                    for (int u = 0; u < SKB_WFQ; ++u) {
-                        const bool on = g0 + u < g_hi && e < 12;              // (padded quads multiply zeros: a uniform branch here measured slower)
-                        const int v0 = 4 * (int)(st[u].x & 0xFFFFu) + kk, v1 = 4 * (int)(st[u].x >> 16) + kk;
-                        const int v2 = 4 * (int)(st[u].y & 0xFFFFu) + kk, v3 = 4 * (int)(st[u].y >> 16) + kk;
-#define FDC_DT(v) ((on && c0 + (v) < c1) ? sdT[(v) * SKB_ROW + eg] * (one ? 1.f : sdT[(v) * SKB_ROW + ep]) : 0.f)
-                        dacc[jt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[u].x, FDC_DT(v0), dacc[jt], 0, 0, 0);
-                        dacc[jt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[u].y, FDC_DT(v1), dacc[jt], 0, 0, 0);
-                        dacc[jt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[u].z, FDC_DT(v2), dacc[jt], 0, 0, 0);
-                        dacc[jt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[u].w, FDC_DT(v3), dacc[jt], 0, 0, 0);
-#undef FDC_DT
-                    }
-                }
+            // (r6) what a lane adds to a step's row address is constant: its vertex of the step (kk) and its entry's two factors.  Result
+            // columns 12-15 of a tile are never read (dT has 12 entries), so lanes e >= 12 need no masking; a FULL chunk (all but a
+            // frame's last) needs no bounds test either; a padded quad (wave-uniform) contributes through a zeroed weight fragment.
+            const int og = kk * SKB_ROW + eg, op = kk * SKB_ROW + ep;
+            const bool full = c1 - c0 == VCH;                                  // (workgroup-uniform)
+#define FDC_SKB_MMA(MASKED)                                                                                                          \
+            _Pragma("unroll")                                                                                                        \
+            for (int jt = 0; jt < 4; ++jt) {                                                                                         \
+                const int g_lo = sm.wf_tab[tb + jt], g_hi = sm.wf_tab[tb + jt + 1];     /* (wave-uniform) quads */                   \
+                dacc[jt] = f32x4_t{0.f, 0.f, 0.f, 0.f};                                                                              \
+                for (int g0 = g_lo; g0 < g_hi; g0 += SKB_WFQ) {                  /* blocks of SKB_WFQ quads: all their loads first */ \
+                    float4 a[SKB_WFQ];                                                                                               \
+                    wf_u2 st[SKB_WFQ];                                                                                               \
+                    _Pragma("unroll")                                                                                                \
+                    for (int u = 0; u < SKB_WFQ; ++u) {                                                                              \
+                        const int gc = min(g0 + u, g_hi - 1);                                                                        \
+                        a[u] = ((const float4*)sm.wf_frag)[(size_t)gc * 64 + lane];                                                  \
+                        st[u] = steps_c[gc];                                                                                         \
+                    }                                                                                                                \
+                    _Pragma("unroll")                                                                                                \
+                    for (int u = 0; u < SKB_WFQ; ++u) {                                                                              \
+                        const bool on = g0 + u < g_hi;                          /* (wave-uniform) */                                 \
+                        const float4 w = on ? a[u] : make_float4(0.f, 0.f, 0.f, 0.f);                                                \
+                        const int s0 = (int)(st[u].x & 0xFFFFu), s1 = (int)(st[u].x >> 16), s2 = (int)(st[u].y & 0xFFFFu), s3 = (int)(st[u].y >> 16); \
+                        dacc[jt] = __builtin_amdgcn_mfma_f32_16x16x4f32(w.x, FDC_DT(s0, MASKED), dacc[jt], 0, 0, 0);                 \
+                        dacc[jt] = __builtin_amdgcn_mfma_f32_16x16x4f32(w.y, FDC_DT(s1, MASKED), dacc[jt], 0, 0, 0);                 \
+                        dacc[jt] = __builtin_amdgcn_mfma_f32_16x16x4f32(w.z, FDC_DT(s2, MASKED), dacc[jt], 0, 0, 0);                 \
+                        dacc[jt] = __builtin_amdgcn_mfma_f32_16x16x4f32(w.w, FDC_DT(s3, MASKED), dacc[jt], 0, 0, 0);                 \
+                    }                                                                                                                \
+                }                                                                                                                    \
             }
+            // a step's entry: rows of the step's four vertices start at 4 s SKB_ROW; MASKED: vertices beyond the chunk's end read as zero
+#define FDC_DT(s, MASKED) ((!(MASKED) || c0 + 4 * (s) + kk < c1) ? sdT[4 * SKB_ROW * (s) + og] * (one ? 1.f : sdT[4 * SKB_ROW * (s) + op]) : 0.f)
+            if (full) { FDC_SKB_MMA(false) } else { FDC_SKB_MMA(true) }
+#undef FDC_DT
+#undef FDC_SKB_MMA
             __syncthreads();                                                   // every wave is done reading the rows: their space takes the tiles
 #pragma unroll
             for (int jt = 0; jt < 4; ++jt)
