@@ -4,7 +4,7 @@
 
 extern "C" {
 
-const char* fdcap_version(void) { return "fdcap-hip 0.3 (gfx950)"; }
+const char* fdcap_version(void) { return "fdcap-hip 0.4 (gfx950)"; }
 const char* fdcap_build_info(void) {
 #ifdef FDC_BUILD_NO_PK_F32
     return "packed_fp32=off";
