@@ -534,6 +534,15 @@ def nn_roofline(pk, src, sec_loop, ms_steady, n_timed, alg_bytes):
                                  "sustained in the PMC pass.  frac is the mean over the whole launch: the port is saturated while all 8 wave "
                                  "slots per SIMD are filled and idles through the drain (mean_waves_per_simd); HBM and the matrix pipe are far "
                                  "from their limits"})
+        wts = nn.get("wave_time_split") or {}
+        roofline["reading"] = (
+            f"VALU issue {roofline['frac']:.2f} of the SIMDs' cycles over the live launch time; {nn.get('mean_waves_per_simd', 0):.1f} of {WAVES_PER_SIMD} wave slots filled "
+            f"on average; a wave's life: {wts.get('issuing', 0):.0%} issuing, {wts.get('waiting_to_issue', 0):.0%} waiting to issue, "
+            f"{wts.get('waiting_on_waitcnt', 0):.0%} at s_waitcnt; matrix pipe busy {nn.get('mfma_busy_frac') or 0:.2f}; HBM {nn.get('hbm_frac_on_counter_bytes') or 0:.2f} on counter bytes; "
+            f"clock under the counters {nn['clock_ghz_under_pmc']:.2f} GHz.  " +
+            ("VALU-saturated (and, for long launches, at the chip's power limit): only fewer executed instructions help."
+             if roofline["frac"] > 0.85 else
+             "Latency- and issue-mix-bound: the port is saturated while all wave slots are filled and idles through the launch's drain."))
         if roofline["frac"] > 0.97:
             roofline["frac_note"] = ("saturated: the instruction prices are measured means (+-3 %) and the counters come from another run of the same "
                                      "configuration, so a VALU-bound launch can read a few per cent above 1; long launches of this configuration also run "
@@ -655,7 +664,7 @@ def other_config(name, args):
            "bound": rl.get("bound"), "frac": rl.get("frac"), "hbm_frac_on_counter_bytes": rl.get("hbm_frac_on_counter_bytes"),
            "mfma_busy_frac": rl.get("mfma_busy_frac"), "mean_waves_per_simd": rl.get("mean_waves_per_simd"),
            "traffic": rl.get("traffic"), "contract_frac_on_algorithmic_bytes": rl["contract"]["frac_on_algorithmic_bytes"],
-           "counters_from": rl.get("counters_from"), "setup": setup_block(fop, first, dt, f)}
+           "counters_from": rl.get("counters_from"), "reading": rl.get("reading"), "setup": setup_block(fop, first, dt, f)}
     live = time_all_launches(fop, one_step, args.iters, dt)
     out["launches_live_us"] = live
     pkt = per_kernel_table(pk, f, nc, 4, src, live) if name == "c2" else None
